@@ -1,0 +1,663 @@
+/* oracle/ptm_oracle.c -- TEST INFRASTRUCTURE ONLY (see ptm_oracle.h for the contract).
+ *
+ * Plain-C restatement of ptmcmc's chain::step() hot path.  Scalar, one chain at a time,
+ * written for legibility; the only concession to speed is an optional OpenMP loop over
+ * chains in the MH sweep (used by bench.py's cpu_baseline leg, kind "port").
+ *
+ * Arithmetic contract shared with the HIP kernels (DESIGN.md "Numerics"): every floating
+ * point result below is produced by IEEE-754 binary64 +, -, *, /, sqrt and explicitly
+ * written fma() in the order written here; the file is compiled with -ffp-contract=off.
+ * log / exp / sin / cos are the deterministic implementations in this file (classic
+ * fdlibm-style argument reduction + polynomial, see each function), never libm, except
+ * where a value is a per-problem CONSTANT that the reference also computes with libm on
+ * the host (prior normalisations, the ladder).
+ */
+#define _GNU_SOURCE
+#include "ptm_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ============================================================================================
+ * Philox4x32-10  (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3")
+ * ============================================================================================ */
+#define PHILOX_M0 0xD2511F53u
+#define PHILOX_M1 0xCD9E8D57u
+#define PHILOX_W0 0x9E3779B9u
+#define PHILOX_W1 0xBB67AE85u
+
+void ptmo_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+  uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3];
+  uint32_t k0 = key[0], k1 = key[1];
+  for (int r = 0; r < 10; r++) {
+    uint64_t p0 = (uint64_t)PHILOX_M0 * c0;
+    uint64_t p1 = (uint64_t)PHILOX_M1 * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    uint32_t n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += PHILOX_W0; k1 += PHILOX_W1;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+/* newran1.cxx:432  MotherOfAll::Next(): ((double)seed + 0.5) / 4294967296.0 */
+double ptmo_u01(uint32_t k) { return ((double)k + 0.5) * (1.0 / 4294967296.0); }
+
+void ptmo_draw_block(uint64_t seed, int tag, uint32_t stream, uint64_t step, uint32_t block, uint32_t out[4]) {
+  uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+  uint32_t ctr[4] = {block, stream, (uint32_t)step, ((uint32_t)(step >> 32) & 0x00FFFFFFu) | ((uint32_t)tag << 24)};
+  ptmo_philox4x32_10(ctr, key, out);
+}
+
+/* ============================================================================================
+ * deterministic elementary functions
+ * ============================================================================================ */
+static inline uint64_t d2u(double x) { uint64_t u; memcpy(&u, &x, 8); return u; }
+static inline double u2d(uint64_t u) { double x; memcpy(&x, &u, 8); return x; }
+
+/* log(x): x = 2^e * m, m in (sqrt(1/2), sqrt(2)];  f = m-1, s = f/(2+f);
+ * log(1+f) = 2s + (2/3)s^3 + ... via the degree-14 even polynomial of the classic
+ * FreeBSD/fdlibm e_log.c algorithm (coefficients Lg1..Lg7 published there).  < 1 ulp. */
+double ptmo_log(double x) {
+  static const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
+  static const double L1 = 6.666666666666735130e-01, L2 = 3.999999999940941908e-01, L3 = 2.857142874366239149e-01,
+                      L4 = 2.222219843214978396e-01, L5 = 1.818357216161805012e-01, L6 = 1.531383769920937332e-01,
+                      L7 = 1.479819860511658591e-01;
+  int e = 0;
+  if (x != x) return x;
+  if (x < 0.0) return NAN;
+  if (x == 0.0) return -INFINITY;
+  if (x == INFINITY) return x;
+  if (x < 2.2250738585072014e-308) { x *= 18014398509481984.0; e = -54; } /* subnormal: scale by 2^54 */
+  uint64_t b = d2u(x);
+  e += (int)(b >> 52) - 1023;
+  double m = u2d((b & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull); /* [1,2) */
+  if (m > 1.4142135623730951) { m *= 0.5; e += 1; }
+  double f = m - 1.0;
+  double s = f / (2.0 + f);
+  double z = s * s;
+  double r = L7;
+  r = fma(r, z, L6); r = fma(r, z, L5); r = fma(r, z, L4); r = fma(r, z, L3); r = fma(r, z, L2); r = fma(r, z, L1);
+  double R = r * z;
+  double hfsq = 0.5 * f * f;
+  double dk = (double)e;
+  return dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
+}
+
+/* exp(x): k = round(x/ln2), r = x - k ln2 (hi/lo split), exp(r) = 1 + 2r/(2-c)... with the degree-10
+ * even polynomial of the classic fdlibm e_exp.c algorithm (coefficients P1..P5 published there);
+ * result scaled by 2^k with gradual underflow.  < 1 ulp in the normal range. */
+double ptmo_exp(double x) {
+  static const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
+                      invln2 = 1.44269504088896338700e+00;
+  static const double P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03, P3 = 6.61375632143793436117e-05,
+                      P4 = -1.65339022054652515390e-06, P5 = 4.13813679705723846039e-08;
+  if (x != x) return x;
+  if (x > 709.782712893384) return INFINITY;
+  if (x < -745.1332191019412) return 0.0;
+  int k = (int)(x * invln2 + (x < 0.0 ? -0.5 : 0.5));
+  double dk = (double)k;
+  double hi = x - dk * ln2_hi;
+  double lo = dk * ln2_lo;
+  double r = hi - lo;
+  double t = r * r;
+  double p = P5;
+  p = fma(p, t, P4); p = fma(p, t, P3); p = fma(p, t, P2); p = fma(p, t, P1);
+  double c = r - t * p;
+  double y = 1.0 - ((lo - (r * c) / (2.0 - c)) - hi);
+  if (k >= -1021 && k <= 1023) return y * u2d((uint64_t)(k + 1023) << 52);
+  if (k > 1023) return y * 2.0 * u2d((uint64_t)(k - 1 + 1023) << 52);
+  return (y * u2d((uint64_t)(k + 1000 + 1023) << 52)) * u2d((uint64_t)(-1000 + 1023) << 52);
+}
+
+/* sin / cos on [0, pi/4]: Taylor series in Horner/fma form (truncation < 1e-17) */
+static inline double sin_k(double p) {
+  double z = p * p;
+  double r = -1.0 / 1307674368000.0;
+  r = fma(r, z, 1.0 / 6227020800.0);
+  r = fma(r, z, -1.0 / 39916800.0);
+  r = fma(r, z, 1.0 / 362880.0);
+  r = fma(r, z, -1.0 / 5040.0);
+  r = fma(r, z, 1.0 / 120.0);
+  r = fma(r, z, -1.0 / 6.0);
+  return fma(p * z, r, p);
+}
+static inline double cos_k(double p) {
+  double z = p * p;
+  double r = 1.0 / 20922789888000.0;
+  r = fma(r, z, -1.0 / 87178291200.0);
+  r = fma(r, z, 1.0 / 479001600.0);
+  r = fma(r, z, -1.0 / 3628800.0);
+  r = fma(r, z, 1.0 / 40320.0);
+  r = fma(r, z, -1.0 / 720.0);
+  r = fma(r, z, 1.0 / 24.0);
+  return fma(z * z, r, fma(-0.5, z, 1.0));
+}
+#define PI_HI 3.141592653589793116e+00 /* 0x1.921fb54442d18p+1 */
+#define PI_LO 1.224646799147353207e-16 /* pi - PI_HI */
+#define HPI_HI 1.570796326794896558e+00
+#define HPI_LO 6.123233995736766036e-17
+#define QPI 7.853981633974482790e-01
+
+/* sin on [0,pi] (UniformPolarDist::pdf argument range, ProbabilityDist.h:197-201) */
+double ptmo_sin_0_pi(double x) {
+  if (x > HPI_HI) x = (PI_HI - x) + PI_LO;   /* sin(pi - x) */
+  if (x <= QPI) return sin_k(x);
+  return cos_k((HPI_HI - x) + HPI_LO);
+}
+/* cos on [-pi/2,pi/2] (UniformCoPolarDist::pdf, ProbabilityDist.h:243-247) */
+double ptmo_cos_hpi(double x) {
+  x = fabs(x);
+  if (x <= QPI) return cos_k(x);
+  return sin_k((HPI_HI - x) + HPI_LO);
+}
+
+/* Box-Muller on two 32-bit draws.  u1 = (k1+.5)/2^32, theta = 2 pi (k2+.5)/2^32 reduced exactly
+ * (integer arithmetic) to an octant and an angle in (0, pi/4). */
+void ptmo_boxmuller(uint32_t k1, uint32_t k2, double* z0, double* z1) {
+  double u1 = ((double)k1 + 0.5) * (1.0 / 4294967296.0);
+  double r = sqrt(-2.0 * ptmo_log(u1));
+  uint32_t q = k2 >> 29, m = k2 & 0x1FFFFFFFu;
+  if (q & 1u) m ^= 0x1FFFFFFFu;
+  double phi = ((double)m + 0.5) * 1.4629180792671596e-09; /* (pi/4) * 2^-29 = 0x1.921fb54442d18p-30 */
+  double sn = sin_k(phi), cs = cos_k(phi);
+  if (((q + 1u) >> 1) & 1u) { double t = sn; sn = cs; cs = t; }
+  if (((q + 2u) >> 2) & 1u) cs = -cs;
+  if (q >> 2) sn = -sn;
+  *z0 = r * cs;
+  *z1 = r * sn;
+}
+
+/* ============================================================================================
+ * state algebra: boundary::enforce (states.cc:11-58), stateSpace::enforce (states.cc:86-102)
+ * ============================================================================================ */
+/* fmod restated with exact semantics for the magnitudes that occur (|q| < 2^52):
+ * r = x - w*trunc(x/w) evaluated with one fma, then corrected into (-w, w) with x's sign. */
+static double fmod_det(double x, double w) {
+  double q = trunc(x / w);
+  double r = fma(-q, w, x);
+  if (x >= 0.0) { if (r < 0.0) r += w; else if (r >= w) r -= w; }
+  else          { if (r > 0.0) r -= w; else if (r <= -w) r += w; }
+  return r;
+}
+
+int ptmo_boundary_enforce(int lo, int hi, double xmin, double xmax, double* px) {
+  double x = *px;
+  if ((lo == PTMO_WRAP) != (hi == PTMO_WRAP)) return 0;         /* states.cc:14-16 inconsistent wrap */
+  if (lo == PTMO_WRAP) {                                         /* states.cc:17-29 */
+    double width = xmax - xmin;
+    if (width <= 0) return 0;
+    double xt = fmod_det(x - xmin, width);
+    if (xt < 0) xt += width;
+    *px = xmin + xt;
+    return 1;
+  }
+  if (lo == PTMO_REFLECT && hi == PTMO_REFLECT) {                /* states.cc:31-45 */
+    double halfwidth = xmax - xmin;
+    if (halfwidth <= 0) return 0;
+    double width = 2 * halfwidth;
+    double xt = fmod_det(x - xmin, width);
+    if (xt < 0) xt += width;
+    if (xt >= halfwidth) xt = halfwidth - xt;                    /* sic: the reference folds to a NEGATIVE offset */
+    *px = xmin + xt;
+    return 1;
+  }
+  if (lo == PTMO_REFLECT && x < xmin) x = xmin + (xmin - x);     /* states.cc:46-47 */
+  else if (hi == PTMO_REFLECT && x > xmax) x = xmax - (x - xmax);
+  *px = x;
+  if (lo == PTMO_LIMIT && x < xmin) return 0;                    /* states.cc:48-55 */
+  if (hi == PTMO_LIMIT && x > xmax) return 0;
+  return 1;
+}
+
+int ptmo_enforce(const ptmo_problem* pb, double* x) {
+  for (int i = 0; i < pb->D; i++)
+    if (!ptmo_boundary_enforce(pb->blo[i], pb->bhi[i], pb->bmin[i], pb->bmax[i], &x[i])) return 0; /* stops at first failure */
+  return 1;
+}
+
+/* ============================================================================================
+ * prior: sampleable_probability_function::evaluate_log = log(evaluate) (probability_function.hh:59)
+ * with mixed_dist_product::evaluate = prod_i pdf_i(x_i)  (probability_function.cc:281-304) and the
+ * pdfs of ProbabilityDist.h:88-93 (uniform), :126-130 (log), :153-156 (gaussian), :197-201 (polar),
+ * :243-247 (copolar).  Invalid state => 0 => log(0) = -inf.
+ * ============================================================================================ */
+static double pdf1(const ptmo_problem* pb, int i, double x) {
+  double lo = pb->plo[i], hi = pb->phi[i];
+  switch (pb->ptype[i]) {
+    case PTMO_FLAT: return 1;
+    case PTMO_UNIFORM:
+      if (x < lo) return 0;
+      if (x > hi) return 0;
+      return pb->pcoef[i];                               /* 1/(xmax-xmin) */
+    case PTMO_GAUSSIAN: {
+      double xn = (x - lo) / hi;                         /* lo = x0, hi = sigma */
+      return ptmo_exp(-xn * xn / 2) / 2.5066282746310002 / hi;  /* exp(-xnorm*xnorm/2)/sqrt(2*M_PI)/sigma */
+    }
+    case PTMO_POLAR:
+      if (x < lo) return 0;
+      if (x > hi) return 0;
+      return ptmo_sin_0_pi(x) / pb->pcoef[i];
+    case PTMO_COPOLAR:
+      if (x < lo) return 0;
+      if (x > hi) return 0;
+      return ptmo_cos_hpi(x) / pb->pcoef[i];
+    case PTMO_LOG:
+      if (x < lo) return 0;
+      if (x > hi) return 0;
+      return 1 / pb->pcoef[i] / x;                       /* 1/(log_xmax-log_xmin)/x */
+  }
+  return NAN;
+}
+
+double ptmo_lprior(const ptmo_problem* pb, const double* x, int valid) {
+  if (!valid) return -INFINITY;                          /* evaluate() returns 0 for an invalid state */
+  if (pb->all_uniform) {
+    for (int i = 0; i < pb->D; i++) {
+      if (x[i] < pb->plo[i]) return -INFINITY;
+      if (x[i] > pb->phi[i]) return -INFINITY;
+    }
+    return pb->lprior_const;
+  }
+  double result = 1;
+  for (int i = 0; i < pb->D; i++) result *= pdf1(pb, i, x[i]);
+  return ptmo_log(result);
+}
+
+/* Gaussian target of cython/exampleGaussian.py:103-109: like0 - 0.5 x^T invcov x, evaluated in the
+ * symmetric-packed order  q = sum_i y_i (P_ii y_i + sum_{j<i} 2 P_ij y_j)  shared with the kernel */
+double ptmo_llike(const ptmo_problem* pb, const double* x) {
+  if (pb->user_fn) return pb->user_fn(pb->user, x, pb->D);
+  int D = pb->D;
+  double q = 0;
+  for (int i = 0; i < D; i++) {
+    double s = 0;
+    for (int j = 0; j < i; j++) {
+      double yj = pb->mean ? x[j] - pb->mean[j] : x[j];
+      s = fma(pb->P2[i * D + j], yj, s);
+    }
+    double yi = pb->mean ? x[i] - pb->mean[i] : x[i];
+    s = fma(pb->P2[i * D + i], yi, s);
+    q = fma(yi, s, q);
+  }
+  return pb->like0 - 0.5 * q;
+}
+
+/* chain.cc:928 / :982 / :1090: lprior + invtemp*llike, product rounded before the sum */
+double ptmo_lpost(double lprior, double beta, double llike) {
+  double t = beta * llike;
+  return lprior + t;
+}
+
+/* chain.cc:1181-1183 (tratio=exp(log(Tmax)/(Ntemps-1)); temps[i]=temps[i-1]*tratio) and :1340 (invtemp=1/temps[i]).
+ * Per-problem constants: libm here exactly as in the reference. */
+void ptmo_ladder(int Nt, double Tmax, double* beta) {
+  double tratio = exp(log(Tmax) / (Nt - 1));
+  double t = 1;
+  beta[0] = 1 / t;
+  for (int i = 1; i < Nt; i++) { t = t * tratio; beta[i] = 1 / t; }
+}
+
+/* ============================================================================================
+ * problem set-up
+ * ============================================================================================ */
+ptmo_problem* ptmo_problem_create(int D) {
+  ptmo_problem* p = (ptmo_problem*)calloc(1, sizeof *p);
+  p->D = D;
+  p->blo = (int*)calloc(D, sizeof(int)); p->bhi = (int*)calloc(D, sizeof(int));
+  p->bmin = (double*)calloc(D, sizeof(double)); p->bmax = (double*)calloc(D, sizeof(double));
+  p->ptype = (int*)calloc(D, sizeof(int));
+  p->plo = (double*)calloc(D, sizeof(double)); p->phi = (double*)calloc(D, sizeof(double));
+  p->pcoef = (double*)calloc(D, sizeof(double));
+  for (int i = 0; i < D; i++) { p->bmin[i] = -INFINITY; p->bmax[i] = INFINITY; p->plo[i] = -INFINITY; p->phi[i] = INFINITY; p->pcoef[i] = 1; }
+  p->origin_valid = 1; p->all_uniform = 1; p->lprior_const = 0; p->minPrior = -30;
+  p->P2 = (double*)calloc((size_t)D * D, sizeof(double));
+  return p;
+}
+void ptmo_problem_free(ptmo_problem* p) {
+  if (!p) return;
+  free(p->blo); free(p->bhi); free(p->bmin); free(p->bmax); free(p->ptype); free(p->plo); free(p->phi); free(p->pcoef);
+  free(p->mean); free(p->P2); free(p);
+}
+void ptmo_problem_set_bounds(ptmo_problem* p, const int* lo, const int* hi, const double* xmin, const double* xmax) {
+  for (int i = 0; i < p->D; i++) { p->blo[i] = lo[i]; p->bhi[i] = hi[i]; p->bmin[i] = xmin[i]; p->bmax[i] = xmax[i]; }
+  /* Q9: state(space,n) is a zero vector passed through enforce() (states.cc:183-192) */
+  double* z = (double*)calloc(p->D, sizeof(double));
+  p->origin_valid = ptmo_enforce(p, z);
+  free(z);
+}
+void ptmo_problem_set_prior(ptmo_problem* p, const int* types, const double* c, const double* h) {
+  /* mixed_dist_product ctor, probability_function.cc:232-254; Uniform{Polar,CoPolar}Dist ctors clamp the
+   * PARAMETER copies of xmin/xmax for the normalisation but keep the unclamped members for the support
+   * test (ProbabilityDist.h:181-186, 227-232: the ctor arguments shadow the members). */
+  p->all_uniform = 1;
+  double prod = 1;
+  for (int i = 0; i < p->D; i++) {
+    p->ptype[i] = types[i];
+    switch (types[i]) {
+      case PTMO_UNIFORM: p->plo[i] = c[i] - h[i]; p->phi[i] = c[i] + h[i]; p->pcoef[i] = 1 / (p->phi[i] - p->plo[i]); break;
+      case PTMO_GAUSSIAN: p->plo[i] = c[i]; p->phi[i] = h[i]; p->pcoef[i] = 0; p->all_uniform = 0; break;
+      case PTMO_POLAR: {
+        double a = c[i] - h[i], b = c[i] + h[i];
+        p->plo[i] = a; p->phi[i] = b;
+        if (a < 0) a = 0;
+        if (b > M_PI) b = M_PI;
+        p->pcoef[i] = -cos(b) + cos(a); p->all_uniform = 0; break;
+      }
+      case PTMO_COPOLAR: {
+        double a = c[i] - h[i], b = c[i] + h[i];
+        p->plo[i] = a; p->phi[i] = b;
+        if (a < -M_PI / 2) a = -M_PI / 2;
+        if (b > M_PI / 2) b = M_PI / 2;
+        p->pcoef[i] = sin(b) - sin(a); p->all_uniform = 0; break;
+      }
+      case PTMO_FLAT: p->pcoef[i] = 1; break;
+      case PTMO_LOG: p->plo[i] = c[i] / h[i]; p->phi[i] = c[i] * h[i]; p->pcoef[i] = log(p->phi[i]) - log(p->plo[i]); p->all_uniform = 0; break;
+    }
+    if (types[i] == PTMO_UNIFORM || types[i] == PTMO_FLAT) prod *= p->pcoef[i];
+  }
+  p->lprior_const = log(prod);   /* the reference takes libm log of the running product every call */
+}
+void ptmo_problem_set_gauss(ptmo_problem* p, const double* mean, const double* P, double like0) {
+  int D = p->D;
+  p->have_gauss = 1; p->like0 = like0; p->user_fn = 0;
+  free(p->mean); p->mean = 0;
+  if (mean) { p->mean = (double*)malloc(D * sizeof(double)); memcpy(p->mean, mean, D * sizeof(double)); }
+  for (int i = 0; i < D; i++)
+    for (int j = 0; j < D; j++)
+      p->P2[i * D + j] = (j < i) ? (P[i * D + j] + P[j * D + i]) : (j == i ? P[i * D + i] : 0.0);
+}
+void ptmo_problem_set_user(ptmo_problem* p, ptmo_loglike_fn fn, void* user) { p->user_fn = fn; p->user = user; }
+
+/* ============================================================================================
+ * ladder state
+ * ============================================================================================ */
+ptmo_pt* ptmo_pt_create(int D, int Nt, int W, const double* beta, double swap_rate, int add_every_N) {
+  ptmo_pt* s = (ptmo_pt*)calloc(1, sizeof *s);
+  size_t N = (size_t)Nt * W;
+  s->D = D; s->Nt = Nt; s->W = W; s->swap_rate = swap_rate; s->add_every_N = add_every_N;
+  s->maxswaps = (int)(1 + 2 * swap_rate * Nt);                  /* chain.cc:1192 (int = double truncation) */
+  s->beta = (double*)malloc(Nt * sizeof(double)); memcpy(s->beta, beta, Nt * sizeof(double));
+  s->x = (double*)calloc(N * D, sizeof(double));
+  s->llike = (double*)calloc(N, sizeof(double)); s->lprior = (double*)calloc(N, sizeof(double));
+  s->ntries = (int32_t*)malloc(N * 4); s->naccept = (int32_t*)malloc(N * 4); s->last_type = (int32_t*)malloc(N * 4);
+  s->nhist = (int64_t*)calloc(N, 8); s->nsize = (int64_t*)calloc(N, 8);
+  for (size_t c = 0; c < N; c++) { s->ntries[c] = 1; s->naccept[c] = 1; s->last_type[c] = -1; } /* chain.cc:649 */
+  size_t np = (size_t)W * (Nt > 1 ? Nt - 1 : 1);
+  s->swap_count = (int64_t*)calloc(np, 8); s->swap_accept_count = (int64_t*)calloc(np, 8);
+  s->last_pairs = (int*)calloc((size_t)W * s->maxswaps, sizeof(int));
+  s->last_accept = (int*)calloc((size_t)W * s->maxswaps, sizeof(int));
+  s->touched = (uint8_t*)calloc(N, 1);
+  return s;
+}
+void ptmo_pt_free(ptmo_pt* s) {
+  if (!s) return;
+  free(s->beta); free(s->x); free(s->llike); free(s->lprior); free(s->ntries); free(s->naccept); free(s->last_type);
+  free(s->nhist); free(s->nsize); free(s->swap_count); free(s->swap_accept_count); free(s->last_pairs); free(s->last_accept);
+  free(s->touched); free(s);
+}
+
+/* MH_chain::add_state bookkeeping (chain.cc:935-947) */
+static inline void add_state_count(ptmo_pt* s, size_t c) {
+  if (s->nhist[c] % s->add_every_N == 0) s->nsize[c]++;
+  s->nhist[c]++;
+}
+
+void ptmo_pt_set_states(ptmo_pt* s, const ptmo_problem* pb, const double* x, const double* llike) {
+  size_t N = (size_t)s->Nt * s->W;
+  memcpy(s->x, x, N * s->D * sizeof(double));
+  for (size_t c = 0; c < N; c++) {
+    double* xc = s->x + c * s->D;
+    int valid = ptmo_enforce(pb, xc);                     /* state ctor enforces (states.cc:194-199) */
+    s->lprior[c] = ptmo_lprior(pb, xc, valid);
+    s->llike[c] = llike ? llike[c] : ptmo_llike(pb, xc);
+    s->nhist[c] = 0; s->nsize[c] = 1;                     /* MH_chain::initialize(1): one row, Nhist reset (chain.cc:871-875) */
+  }
+}
+
+/* ============================================================================================
+ * MH_chain::step  (chain.cc:966-1022) with gaussian_prop::draw (proposal_distribution.hh:194-218)
+ * ============================================================================================ */
+int ptmo_mh_step(ptmo_pt* s, const ptmo_problem* pb, const ptmo_proposal* prop, const ptmo_rng* rng, int w, int r) {
+  int D = s->D;
+  size_t c = (size_t)w * s->Nt + r;
+  double beta = s->beta[r];
+  double* x = s->x + c * D;
+  double cur_llike = s->llike[c], cur_lprior = s->lprior[c];
+  double cur_lpost = ptmo_lpost(cur_lprior, beta, cur_llike);
+  double oldlprior = cur_lpost - beta * cur_llike;                       /* :973 */
+  double xn[64], off[64];
+  int type = rng->draw_offset(rng->ctx, w, r, s->step, prop, D, off);   /* :975 prop.draw */
+  for (int i = 0; i < D; i++) xn[i] = x[i] + off[i];                     /* state::add, states.cc:205-214 */
+  int valid = pb->origin_valid;                                          /* Q9 */
+  if (valid) valid = ptmo_enforce(pb, xn);                               /* :976 newstate.enforce() */
+  double newlprior = ptmo_lprior(pb, xn, valid);                         /* :977 */
+  double newlike, newlpost;
+  /* :980  (!current_lpost>-1e200 parses as (!current_lpost)>-1e200 == true: SURVEY Q1) */
+  if (valid && (newlprior > -1e200 || newlprior - oldlprior > pb->minPrior)) {
+    newlike = ptmo_llike(pb, xn);                                        /* :981 */
+    newlpost = newlike * beta + newlprior;                               /* :982 */
+  } else {
+    newlike = newlpost = -INFINITY;                                      /* :986 */
+  }
+  double logH = 0.0;                                                     /* gaussian_prop: log_hastings = 0 */
+  int accept = 1;
+  logH += newlpost - cur_lpost;                                          /* :994 */
+  if (!valid) accept = 0;                                                /* :996 */
+  if (accept && logH < 0) {                                              /* :998 (NaN => stays accepted) */
+    double u = rng->chain_uniform(rng->ctx, w, r, s->step, 0);
+    accept = (ptmo_log(u) < logH);
+  }
+  s->ntries[c]++;                                                        /* :1005 */
+  if (accept) {
+    s->naccept[c]++;
+    s->last_type[c] = type;
+    memcpy(x, xn, D * sizeof(double));
+    s->llike[c] = newlike; s->lprior[c] = newlprior;
+  }
+  add_state_count(s, c);
+  return accept;
+}
+
+void ptmo_sweep(ptmo_pt* s, const ptmo_problem* pb, const ptmo_proposal* props, const ptmo_rng* rng, int nthreads) {
+  long N = (long)s->Nt * s->W;
+  (void)nthreads;
+#pragma omp parallel for schedule(static) num_threads(nthreads) if (nthreads > 1)
+  for (long c = 0; c < N; c++) {
+    int w = (int)(c / s->Nt), r = (int)(c % s->Nt);
+    ptmo_mh_step(s, pb, &props[r], rng, w, r);
+  }
+  s->step++;
+}
+
+/* ============================================================================================
+ * parallel_tempering_chains::step  (chain.cc:1393-1571), fixed ladder (evolve_temps off)
+ * ============================================================================================ */
+static void swap_phase(ptmo_pt* s, const ptmo_rng* rng, int w) {
+  int Nt = s->Nt, D = s->D, ms = s->maxswaps;
+  int* iswaps = s->last_pairs + (size_t)w * ms;
+  int* acc = s->last_accept + (size_t)w * ms;
+  size_t base = (size_t)w * Nt;
+  /* :1410-1420 candidate selection */
+  for (int i = 0; i < ms; i++) {
+    iswaps[i] = -2; acc[i] = 0;
+    double x = rng->pt_uniform(rng->ctx, w, s->step, i, 0);
+    if (Nt > 1 && x < (Nt - 1) * s->swap_rate / ms) {
+      x = rng->pt_uniform(rng->ctx, w, s->step, i, 1);
+      iswaps[i] = (int)(x * (Nt - 1));
+      for (int j = 0; j < i; j++)
+        if (iswaps[j] == iswaps[i] || iswaps[j] + 1 == iswaps[i]) iswaps[i] = -2;
+    }
+  }
+  /* :1436-1537 trials, in pick order, on the in-place updated view */
+  double tmp[64];
+  for (int j = 0; j < ms; j++) {
+    int i = iswaps[j];
+    if (i < 0) continue;
+    size_t a = base + i, b = base + i + 1;
+    double lla = s->llike[a]; if (!(lla > -1e200)) lla = -1e200;        /* :1459 */
+    double llb = s->llike[b]; if (!(llb > -1e200)) llb = -1e200;        /* :1461 */
+    double logH = -(s->beta[i + 1] - s->beta[i]) * (llb - lla);         /* :1463 */
+    int accept = 1;
+    if (logH < 0) {
+      double u = rng->pt_uniform(rng->ctx, w, s->step, j, 2);
+      accept = (ptmo_log(u) < logH);                                     /* :1464-1467 */
+    }
+    if (accept) {                                                        /* :1487-1492 exchange states, temps stay */
+      memcpy(tmp, s->x + a * D, D * sizeof(double));
+      memcpy(s->x + a * D, s->x + b * D, D * sizeof(double));
+      memcpy(s->x + b * D, tmp, D * sizeof(double));
+      double t = s->llike[a]; s->llike[a] = s->llike[b]; s->llike[b] = t;
+      t = s->lprior[a]; s->lprior[a] = s->lprior[b]; s->lprior[b] = t;   /* lprior is a pure function of the state */
+      s->swap_accept_count[(size_t)w * (Nt - 1) + i]++;                   /* :1498 */
+    }
+    acc[j] = accept;
+    add_state_count(s, a); add_state_count(s, b);                        /* add_state on both rungs either way (:1487-1490,:1531-1534) */
+    s->touched[a]++; s->touched[b]++;
+    s->swap_count[(size_t)w * (Nt - 1) + i]++;                            /* :1536 */
+  }
+}
+
+void ptmo_pt_step(ptmo_pt* s, const ptmo_problem* pb, const ptmo_proposal* props, const ptmo_rng* rng, int nthreads) {
+  long N = (long)s->Nt * s->W;
+  memset(s->touched, 0, (size_t)N);
+  (void)nthreads;
+#pragma omp parallel for schedule(static) num_threads(nthreads) if (nthreads > 1)
+  for (int w = 0; w < s->W; w++) swap_phase(s, rng, w);
+  /* :1544-1559 MH move for every rung not involved in a swap attempt this step */
+#pragma omp parallel for schedule(static) num_threads(nthreads) if (nthreads > 1)
+  for (long c = 0; c < N; c++) {
+    if (s->touched[c]) continue;
+    int w = (int)(c / s->Nt), r = (int)(c % s->Nt);
+    ptmo_mh_step(s, pb, &props[r], rng, w, r);
+  }
+  s->step++;
+}
+
+/* ============================================================================================
+ * RNG providers
+ * ============================================================================================ */
+typedef struct { uint64_t seed; int Nt; } philox_ctx;
+
+static double ph_chain_uniform(void* vctx, int w, int r, uint64_t step, int slot) {
+  philox_ctx* c = (philox_ctx*)vctx;
+  uint32_t o[4];
+  ptmo_draw_block(c->seed, PTMO_TAG_MH, (uint32_t)((uint64_t)w * c->Nt + r), step, 0, o);
+  return ptmo_u01(o[slot]);
+}
+static int ph_draw_offset(void* vctx, int w, int r, uint64_t step, const ptmo_proposal* p, int D, double* off) {
+  philox_ctx* c = (philox_ctx*)vctx;
+  uint32_t stream = (uint32_t)((uint64_t)w * c->Nt + r);
+  double z[64 + 4];
+  for (int b = 0; 4 * b < D; b++) {                       /* gaussian_dist_product::drawSample: D normals (probability_function.cc:37-47) */
+    uint32_t o[4];
+    ptmo_draw_block(c->seed, PTMO_TAG_MH, stream, step, (uint32_t)(b + 1), o);
+    ptmo_boxmuller(o[0], o[1], &z[4 * b], &z[4 * b + 1]);
+    ptmo_boxmuller(o[2], o[3], &z[4 * b + 2], &z[4 * b + 3]);
+  }
+  int type = 0;
+  if (p->oneDfrac > 0) {                                  /* proposal_distribution.hh:196-206 */
+    uint32_t o[4];
+    ptmo_draw_block(c->seed, PTMO_TAG_MH, stream, step, 0, o);
+    double x = ptmo_u01(o[1]);
+    if (x < p->oneDfrac) {
+      int ax = (int)(D * ptmo_u01(o[2]));
+      for (int j = 0; j < D; j++) if (j != ax) z[j] = 0.0;
+      type = 1;
+    }
+  }
+  if (p->kind == PTMO_PROP_DIAG) {
+    for (int i = 0; i < D; i++) off[i] = p->M[i] * z[i];
+  } else {
+    for (int i = 0; i < D; i++) {
+      double a = 0.0;
+      for (int j = 0; j < D; j++) a = fma(p->M[i * D + j], z[j], a);
+      off[i] = a;
+    }
+  }
+  return type;
+}
+static double ph_pt_uniform(void* vctx, int w, uint64_t step, int k, int slot) {
+  philox_ctx* c = (philox_ctx*)vctx;
+  uint32_t o[4];
+  ptmo_draw_block(c->seed, PTMO_TAG_PT, (uint32_t)w, step, (uint32_t)k, o);
+  return ptmo_u01(o[slot]);
+}
+ptmo_rng* ptmo_rng_philox(uint64_t seed, int Nt) {
+  ptmo_rng* r = (ptmo_rng*)calloc(1, sizeof *r);
+  philox_ctx* c = (philox_ctx*)calloc(1, sizeof *c);
+  c->seed = seed; c->Nt = Nt;
+  r->ctx = c; r->chain_uniform = ph_chain_uniform; r->draw_offset = ph_draw_offset; r->pt_uniform = ph_pt_uniform;
+  return r;
+}
+
+typedef struct {
+  int W, Nt, D, len_c, len_p, nsteps;
+  const double *chain_tapes, *pt_tapes, *deltas;
+  int *cpos, *ppos, *dpos;
+} tape_ctx;
+static double tp_chain_uniform(void* v, int w, int r, uint64_t step, int slot) {
+  tape_ctx* t = (tape_ctx*)v; (void)step; (void)slot;
+  size_t c = (size_t)w * t->Nt + r;
+  return t->chain_tapes[c * t->len_c + t->cpos[c]++];
+}
+static int tp_draw_offset(void* v, int w, int r, uint64_t step, const ptmo_proposal* p, int D, double* off) {
+  tape_ctx* t = (tape_ctx*)v; (void)step; (void)p;
+  size_t c = (size_t)w * t->Nt + r;
+  const double* d = t->deltas + (c * t->nsteps + t->dpos[c]++) * D;
+  for (int i = 0; i < D; i++) off[i] = d[i];
+  return 0;
+}
+static double tp_pt_uniform(void* v, int w, uint64_t step, int k, int slot) {
+  tape_ctx* t = (tape_ctx*)v; (void)step; (void)k; (void)slot;
+  return t->pt_tapes[(size_t)w * t->len_p + t->ppos[w]++];
+}
+ptmo_rng* ptmo_rng_tape(int W, int Nt, int D, const double* chain_tapes, int len_c, const double* pt_tapes, int len_p,
+                        const double* deltas, int nsteps) {
+  ptmo_rng* r = (ptmo_rng*)calloc(1, sizeof *r);
+  tape_ctx* t = (tape_ctx*)calloc(1, sizeof *t);
+  t->W = W; t->Nt = Nt; t->D = D; t->len_c = len_c; t->len_p = len_p; t->nsteps = nsteps;
+  t->chain_tapes = chain_tapes; t->pt_tapes = pt_tapes; t->deltas = deltas;
+  t->cpos = (int*)calloc((size_t)W * Nt, sizeof(int)); t->ppos = (int*)calloc(W, sizeof(int)); t->dpos = (int*)calloc((size_t)W * Nt, sizeof(int));
+  r->ctx = t; r->chain_uniform = tp_chain_uniform; r->draw_offset = tp_draw_offset; r->pt_uniform = tp_pt_uniform;
+  return r;
+}
+void ptmo_rng_free(ptmo_rng* r) {
+  if (!r) return;
+  if (r->chain_uniform == tp_chain_uniform) { tape_ctx* t = (tape_ctx*)r->ctx; free(t->cpos); free(t->ppos); free(t->dpos); }
+  free(r->ctx); free(r);
+}
+
+/* MH_chain::initialize(1) (chain.cc:846-876): draw from the prior until valid with llike >= -1e100.
+ * Dimension d of attempt a uses block d of stream (chain), step = a, tag INIT:
+ * uniform dims x = u*(hi-lo)+lo (ProbabilityDist.h:94-97), gaussian dims x = z*sigma+x0 (ProbabilityDist.cxx:79). */
+void ptmo_init_from_prior(ptmo_pt* s, const ptmo_problem* pb, uint64_t seed) {
+  int D = s->D;
+  size_t N = (size_t)s->Nt * s->W;
+  for (size_t c = 0; c < N; c++) {
+    double* x = s->x + c * D;
+    for (uint64_t a = 0;; a++) {
+      for (int d = 0; d < D; d++) {
+        uint32_t o[4];
+        ptmo_draw_block(seed, PTMO_TAG_INIT, (uint32_t)c, a, (uint32_t)d, o);
+        if (pb->ptype[d] == PTMO_UNIFORM) x[d] = ptmo_u01(o[0]) * (pb->phi[d] - pb->plo[d]) + pb->plo[d];
+        else if (pb->ptype[d] == PTMO_GAUSSIAN) { double z0, z1; ptmo_boxmuller(o[0], o[1], &z0, &z1); x[d] = z0 * pb->phi[d] + pb->plo[d]; }
+        else x[d] = NAN;
+      }
+      int valid = ptmo_enforce(pb, x);
+      if (!valid) continue;
+      double ll = ptmo_llike(pb, x);
+      if (ll < -1e100) continue;
+      s->llike[c] = ll;
+      s->lprior[c] = ptmo_lprior(pb, x, 1);
+      break;
+    }
+    s->nhist[c] = 0; s->nsize[c] = 1;
+  }
+}

@@ -1,0 +1,155 @@
+/* oracle/ptm_oracle.h -- TEST INFRASTRUCTURE ONLY.
+ *
+ * Plain-C CPU restatement of the one hot path this repository accelerates:
+ * ptmcmc's chain::step()  (MH_chain::step + parallel_tempering_chains::step).
+ * It exists to CHECK the HIP engine; nothing in the product (ptmcmc_amd/, include/,
+ * bench.py's GPU leg) may link, import or call it.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg use it.
+ *
+ * Parity status: PINNED.  The restatement is checked (tests/test_oracle_*.py) against
+ *   - golden vectors produced by the real reference compiled from /root/reference
+ *     (oracle/Makefile target `ref`, generator tests/golden/make_golden.py):
+ *     boundary::enforce tables, mixed_dist_product::evaluate_log tables, the ladder,
+ *     and three full parallel_tempering_chains traces replayed from recorded RNG tapes;
+ *   - the reference's own golden file test/exampleLISA/exampleLISA_test_0_t0.dat
+ *     (31 prior-draw rows: lpost, llike, parameters);
+ *   - the Random123 known-answer vectors for Philox4x32-10.
+ *
+ * Every function cites the reference file:line (relative to /root/reference) it follows.
+ */
+#ifndef PTM_ORACLE_H
+#define PTM_ORACLE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* boundary types: states.hh:34-37 */
+enum { PTMO_OPEN = 0, PTMO_LIMIT = 1, PTMO_REFLECT = 2, PTMO_WRAP = 3 };
+/* prior types: the values of mixed_dist_product::{uniform,gaussian,polar,copolar,log} (probability_function.hh:151-155);
+   0 = flat (the base probability_function: evaluate_log == 0, probability_function.hh:40) */
+enum { PTMO_FLAT = 0, PTMO_UNIFORM = 1, PTMO_GAUSSIAN = 2, PTMO_POLAR = 3, PTMO_COPOLAR = 4, PTMO_LOG = 5 };
+/* proposal kinds */
+enum { PTMO_PROP_DENSE = 0, PTMO_PROP_DIAG = 1 };
+/* RNG domains (counter word 3, top byte) */
+enum { PTMO_TAG_MH = 0, PTMO_TAG_PT = 1, PTMO_TAG_INIT = 2 };
+
+typedef double (*ptmo_loglike_fn)(void* user, const double* x, int dim);
+
+typedef struct {
+  int D;
+  /* per-dimension boundary descriptors (states.hh:29-48) */
+  int *blo, *bhi;
+  double *bmin, *bmax;
+  int origin_valid;   /* quirk Q9: state::add() builds its result from an enforced zero vector
+                         (states.cc:183-192,205-214); if 0 is outside a `limit` bound every
+                         proposed state is invalid */
+  /* per-dimension prior descriptors (probability_function.cc:219-262) */
+  int *ptype;
+  double *plo, *phi;  /* support [lo,hi] (uniform/polar/copolar/log) or {x0,sigma} (gaussian) */
+  double *pcoef;      /* uniform: 1/(hi-lo); gaussian: unused; polar/copolar: norm; log: log(hi)-log(lo) */
+  int all_uniform;
+  double lprior_const; /* log(prod 1/(hi-lo)) when all_uniform */
+  /* target */
+  int have_gauss;
+  double *mean;       /* may be NULL */
+  double *P2;         /* D*D row-major: strictly-lower part holds 2*P_ij, diagonal holds P_ii */
+  double like0;
+  ptmo_loglike_fn user_fn;
+  void* user;
+  double minPrior;    /* MH_chain ctor arg (chain.cc:647), sampler default -30 */
+} ptmo_problem;
+
+typedef struct {
+  int kind;        /* PTMO_PROP_DENSE / PTMO_PROP_DIAG */
+  double* M;       /* DENSE: D*D row-major factor (offset = M z);  DIAG: D sigmas */
+  double oneDfrac; /* gaussian_prop oneDfrac (proposal_distribution.hh:194-206) */
+} ptmo_proposal;
+
+/* RNG provider: Philox in production parity tests, tapes for the reference-trace fixtures */
+typedef struct ptmo_rng {
+  void* ctx;
+  /* uniform for chain (walker w, global rung r) at PT step `step`; slot 0 = MH accept */
+  double (*chain_uniform)(void* ctx, int w, int r, uint64_t step, int slot);
+  /* proposal offset for the chain; returns proposal type (0 full, 1 one-dimensional) */
+  int (*draw_offset)(void* ctx, int w, int r, uint64_t step, const ptmo_proposal* p, int D, double* offset);
+  /* uniform of the ladder-level generator of walker w; k = candidate slot, slot 0 try,1 pick,2 accept */
+  double (*pt_uniform)(void* ctx, int w, uint64_t step, int k, int slot);
+} ptmo_rng;
+
+typedef struct {
+  int D, Nt, W;        /* Nt = GLOBAL number of rungs; chain (w,r) lives at index w*Nt + r */
+  double* beta;        /* [Nt] */
+  double swap_rate;
+  int maxswaps;        /* 1 + 2*swap_rate*Nt (chain.cc:1192) */
+  int add_every_N;
+  uint64_t step;       /* PT steps taken */
+  double* x;           /* [W*Nt][D] */
+  double *llike, *lprior; /* lpost is always fl(lprior + fl(beta*llike)) */
+  int32_t *ntries, *naccept, *last_type; /* init 1,1,-1 (chain.cc:649) */
+  int64_t *nhist, *nsize;               /* add_state counters (chain.cc:916-949) */
+  /* swap diagnostics per walker: [W][Nt-1] */
+  int64_t *swap_count, *swap_accept_count;
+  /* per-step log of the last step's swap attempts (walker-major): pair index or -2, and accept flag */
+  int* last_pairs;     /* [W][maxswaps] */
+  int* last_accept;    /* [W][maxswaps] */
+  uint8_t* touched;    /* [W*Nt] scratch: add_state calls received in the swap phase of the last step */
+} ptmo_pt;
+
+/* ---- RNG: Philox4x32-10 (Salmon et al., SC'11; Random123) -------------------------------- */
+void ptmo_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+/* open-interval map (k+0.5)/2^32 of newran1.cxx:432 */
+double ptmo_u01(uint32_t k);
+/* engine counter layout: c0 = block, c1 = stream, c2 = step low, c3 = step high(24) | tag<<24 */
+void ptmo_draw_block(uint64_t seed, int tag, uint32_t stream, uint64_t step, uint32_t block, uint32_t out[4]);
+void ptmo_boxmuller(uint32_t k1, uint32_t k2, double* z0, double* z1);
+
+/* ---- deterministic elementary functions (same IEEE op sequence as the HIP kernels) ------- */
+double ptmo_log(double x);
+double ptmo_exp(double x);
+double ptmo_sin_0_pi(double x);      /* x in [0, pi]        */
+double ptmo_cos_hpi(double x);       /* x in [-pi/2, pi/2]  */
+
+/* ---- reference restatements -------------------------------------------------------------- */
+int ptmo_boundary_enforce(int lo, int hi, double xmin, double xmax, double* x); /* states.cc:11-58 */
+int ptmo_enforce(const ptmo_problem* pb, double* x);                              /* states.cc:86-102 */
+double ptmo_lprior(const ptmo_problem* pb, const double* x, int valid);          /* probability_function.hh:59, .cc:281-304 */
+double ptmo_llike(const ptmo_problem* pb, const double* x);
+double ptmo_lpost(double lprior, double beta, double llike);
+void ptmo_ladder(int Nt, double Tmax, double* beta);                              /* chain.cc:1181-1183,1340 */
+
+ptmo_problem* ptmo_problem_create(int D);
+void ptmo_problem_free(ptmo_problem*);
+void ptmo_problem_set_bounds(ptmo_problem*, const int* lo, const int* hi, const double* xmin, const double* xmax);
+/* (types, centers, halfwidths) exactly as mixed_dist_product's constructor takes them */
+void ptmo_problem_set_prior(ptmo_problem*, const int* types, const double* centers, const double* halfwidths);
+void ptmo_problem_set_gauss(ptmo_problem*, const double* mean, const double* P, double like0);
+void ptmo_problem_set_user(ptmo_problem*, ptmo_loglike_fn fn, void* user);
+
+ptmo_pt* ptmo_pt_create(int D, int Nt, int W, const double* beta, double swap_rate, int add_every_N);
+void ptmo_pt_free(ptmo_pt*);
+/* set states and (re)evaluate lprior/llike; llike may be NULL => evaluate the target */
+void ptmo_pt_set_states(ptmo_pt*, const ptmo_problem*, const double* x, const double* llike);
+
+/* one MH_chain::step for chain index c (chain.cc:966-1022); returns 1 if accepted */
+int ptmo_mh_step(ptmo_pt*, const ptmo_problem*, const ptmo_proposal* prop, const ptmo_rng*, int w, int r);
+/* one parallel_tempering_chains::step for every walker (chain.cc:1393-1571); props[Nt] per rung */
+void ptmo_pt_step(ptmo_pt*, const ptmo_problem*, const ptmo_proposal* props, const ptmo_rng*, int nthreads);
+/* MH sweep only (no swap phase) */
+void ptmo_sweep(ptmo_pt*, const ptmo_problem*, const ptmo_proposal* props, const ptmo_rng*, int nthreads);
+
+/* Philox provider */
+ptmo_rng* ptmo_rng_philox(uint64_t seed, int Nt);
+/* tape provider: chain tapes [W*Nt][len_c], pt tapes [W][len_p], deltas [W*Nt][nsteps][D] */
+ptmo_rng* ptmo_rng_tape(int W, int Nt, int D, const double* chain_tapes, int len_c, const double* pt_tapes, int len_p,
+                        const double* deltas, int nsteps);
+void ptmo_rng_free(ptmo_rng*);
+
+/* prior draw used by init (uniform / gaussian dims only; others return NaN) */
+void ptmo_init_from_prior(ptmo_pt*, const ptmo_problem*, uint64_t seed);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,484 @@
+// oracle/ref_driver.cc -- TEST INFRASTRUCTURE ONLY.
+//
+// Our own harness around the REAL reference (JohnGBaker/ptmcmc) classes.  It is
+// compiled only by oracle/Makefile target `ref` against the reference sources
+// where they lie under /root/reference; the resulting binary lives in
+// oracle/_ref/ (git-ignored, travels to the GPU box).  No reference source text
+// is contained in this file -- it only #includes the reference headers at build
+// time and calls the reference's public API.
+//
+// Sub-commands
+//   golden-basic            JSON on stdout: boundary::enforce cases, prior
+//                           evaluate_log tables, ladder values, swap log-Hastings.
+//   golden-trace <id>       JSON on stdout: a full parallel_tempering_chains run
+//                           with *scripted* proposals and *recorded* RNG tapes, so
+//                           that a CPU restatement fed the same tapes must land on
+//                           the same states after every PT step.
+//   bench <spec-file>       time parallel_tempering_chains::step() on the
+//                           correlated-Gaussian problem described in spec-file;
+//                           prints one JSON line (cpu_baseline, kind "reference").
+//
+// Reference interfaces exercised (file:line under /root/reference):
+//   boundary::enforce                     states.cc:11-58
+//   mixed_dist_product / evaluate_log     probability_function.cc:219-304, .hh:59
+//   bayes_likelihood::basic_setup / register_evaluate_log   bayesian.hh:360-381,536-581
+//   MH_chain::step / add_state            chain.cc:966-1022, 916-949
+//   parallel_tempering_chains ctor/initialize/set_proposal/step
+//                                         chain.cc:1163-1211,1281-1386,1393-1571
+//   gaussian_prop(cov)                    proposal_distribution.hh:165-218
+
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "bayesian.hh"
+#include "chain.hh"
+#include "probability_function.hh"
+#include "proposal_distribution.hh"
+
+shared_ptr<Random> globalRNG;  // the reference declares this extern (probability_function.hh:22)
+
+// ----------------------------------------------------------------------------------------------
+// tiny JSON helpers (numbers are printed with 17 significant digits => exact round trip)
+// ----------------------------------------------------------------------------------------------
+static std::string jnum(double v) {
+  char b[64];
+  if (std::isnan(v)) return "\"nan\"";
+  if (std::isinf(v)) return v > 0 ? "\"inf\"" : "\"-inf\"";
+  snprintf(b, sizeof b, "%.17g", v);
+  return b;
+}
+template <class V>
+static std::string jarr(const V& v) {
+  std::ostringstream s;
+  s << "[";
+  for (size_t i = 0; i < v.size(); i++) s << (i ? "," : "") << jnum(v[i]);
+  s << "]";
+  return s.str();
+}
+static std::string jarr_i(const std::vector<int>& v) {
+  std::ostringstream s;
+  s << "[";
+  for (size_t i = 0; i < v.size(); i++) s << (i ? "," : "") << v[i];
+  s << "]";
+  return s.str();
+}
+
+// deterministic helper stream for *inputs* (not part of any algorithm under test)
+struct splitmix {
+  unsigned long long s;
+  explicit splitmix(unsigned long long seed) : s(seed) {}
+  unsigned long long next() {
+    unsigned long long z = (s += 0x9E3779B97F4A7C15ULL);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+  }
+  double uni() { return (double)(next() >> 11) * (1.0 / 9007199254740992.0); }  // [0,1)
+  double sym() { return 2 * uni() - 1; }
+};
+
+// silence the reference's chatter on cout while we produce JSON there
+struct cout_mute {
+  std::streambuf* old;
+  std::ostringstream sink;
+  cout_mute() { old = std::cout.rdbuf(sink.rdbuf()); }
+  ~cout_mute() { std::cout.rdbuf(old); }
+};
+
+// ----------------------------------------------------------------------------------------------
+// golden-basic
+// ----------------------------------------------------------------------------------------------
+static void golden_boundary(std::ostream& os) {
+  struct cfg { int lo, hi; double xmin, xmax; };
+  const int O = boundary::open, L = boundary::limit, R = boundary::reflect, W = boundary::wrap;
+  std::vector<cfg> cfgs = {
+      {O, O, -1, 1},   {L, L, 0, 30},   {L, O, 0, 1},   {O, L, -2, 0.5}, {R, O, 0, 1},
+      {O, R, 0, 1},    {R, L, -1, 2},   {L, R, -1, 2},  {W, W, 0, 6.283185307179586},
+      {W, W, -1.5, 2.25}, {R, R, 0, 1}, {R, R, -2, 3.5}, {W, W, 2, 2}, {R, R, 1, 1}, {W, O, 0, 1}};
+  std::vector<double> xs = {-7.3, -2.0, -1.0, -0.25, 0.0, 0.3, 0.5, 1.0, 1.7, 2.0, 2.25, 3.1, 6.283185307179586,
+                            6.5, 12.9, 29.999, 30.0, 30.5, -1e-9, 1e9 + 0.5, -1e9 - 0.25};
+  os << "\"boundary\":[";
+  bool first = true;
+  for (auto& c : cfgs) {
+    boundary b(c.lo, c.hi, c.xmin, c.xmax);
+    for (double x0 : xs) {
+      double x = x0;
+      bool ok;
+      {
+        cout_mute m;
+        ok = b.enforce(x);
+      }
+      os << (first ? "" : ",") << "\n {\"lo\":" << c.lo << ",\"hi\":" << c.hi << ",\"xmin\":" << jnum(c.xmin)
+         << ",\"xmax\":" << jnum(c.xmax) << ",\"x\":" << jnum(x0) << ",\"ok\":" << (ok ? 1 : 0)
+         << ",\"y\":" << jnum(x) << "}";
+      first = false;
+    }
+  }
+  os << "]";
+}
+
+static void golden_priors(std::ostream& os) {
+  // several mixed_dist_product configurations, each evaluated on a batch of states
+  const int uni = mixed_dist_product::uniform, gau = mixed_dist_product::gaussian, pol = mixed_dist_product::polar,
+            cpol = mixed_dist_product::copolar, lg = mixed_dist_product::log;
+  struct pcfg {
+    std::string name;
+    std::vector<int> types;
+    std::vector<double> centers, halfwidths;
+    std::vector<int> blo, bhi;
+    std::vector<double> bmin, bmax;
+  };
+  const double PI = M_PI;
+  const int O = boundary::open, L = boundary::limit, W = boundary::wrap, R = boundary::reflect;
+  std::vector<pcfg> cfgs;
+  cfgs.push_back({"lisa6", {uni, uni, pol, uni, cpol, uni}, {1.667, PI, PI / 2, PI, 0, PI / 2},
+                  {1.333, PI, PI / 2, PI, PI / 2, PI / 2}, {L, W, L, W, L, W}, {L, W, L, W, L, W},
+                  {0, 0, 0, 0, -PI / 2, 0}, {30, 2 * PI, PI, 2 * PI, PI / 2, PI}});
+  cfgs.push_back({"mixed5", {gau, lg, uni, pol, cpol}, {0.5, 3.0, -1.0, 1.0, 0.2}, {2.0, 4.0, 2.5, 0.6, 0.7},
+                  {O, L, R, O, O}, {O, O, O, O, L}, {-1e300, 0.75, -3.5, 0, 0}, {1e300, 1e300, 1e300, 0, 0.9}});
+  cfgs.push_back({"gauss3", {gau, gau, gau}, {0, 1, -2}, {1, 0.5, 3}, {O, O, O}, {O, O, O}, {0, 0, 0}, {0, 0, 0}});
+  {
+    pcfg c;
+    c.name = "unibox8";
+    for (int i = 0; i < 8; i++) {
+      c.types.push_back(uni);
+      c.centers.push_back(0.1 * i);
+      c.halfwidths.push_back(10 + 3 * i);
+      c.blo.push_back(O); c.bhi.push_back(O); c.bmin.push_back(0); c.bmax.push_back(0);
+    }
+    cfgs.push_back(c);
+  }
+  {
+    pcfg c;  // wide gaussian prior in 32-D: exercises the log(prod pdf) underflow
+    c.name = "gauss32";
+    for (int i = 0; i < 32; i++) {
+      c.types.push_back(gau);
+      c.centers.push_back(0);
+      c.halfwidths.push_back(1.0);
+      c.blo.push_back(O); c.bhi.push_back(O); c.bmin.push_back(0); c.bmax.push_back(0);
+    }
+    cfgs.push_back(c);
+  }
+  os << "\"priors\":[";
+  splitmix g(0xA11CE);
+  for (size_t ic = 0; ic < cfgs.size(); ic++) {
+    pcfg& c = cfgs[ic];
+    int D = c.types.size();
+    stateSpace sp(D);
+    for (int i = 0; i < D; i++) sp.set_bound(i, boundary(c.blo[i], c.bhi[i], c.bmin[i], c.bmax[i]));
+    std::valarray<int> tv(D);
+    std::valarray<double> cv(D), hv(D);
+    for (int i = 0; i < D; i++) { tv[i] = c.types[i]; cv[i] = c.centers[i]; hv[i] = c.halfwidths[i]; }
+    mixed_dist_product prior(&sp, tv, cv, hv);
+    os << (ic ? "," : "") << "\n {\"name\":\"" << c.name << "\",\"types\":" << jarr_i(c.types)
+       << ",\"centers\":" << jarr(c.centers) << ",\"halfwidths\":" << jarr(c.halfwidths)
+       << ",\"blo\":" << jarr_i(c.blo) << ",\"bhi\":" << jarr_i(c.bhi) << ",\"bmin\":" << jarr(c.bmin)
+       << ",\"bmax\":" << jarr(c.bmax) << ",\"cases\":[";
+    int ncase = (c.name == "gauss32") ? 24 : 40;
+    for (int k = 0; k < ncase; k++) {
+      std::vector<double> x(D);
+      // mostly inside the support, sometimes a bit outside (=> pdf 0 / boundary action)
+      double spread = (k % 5 == 4) ? 1.6 : 0.98;
+      if (c.name == "gauss32") spread = 0.3 + 0.16 * k;  // walks out to |z|~11 per dim => underflow to -inf
+      for (int i = 0; i < D; i++) {
+        double hw = c.halfwidths[i];
+        if (c.types[i] == lg) x[i] = c.centers[i] * std::exp(g.sym() * spread * std::log(hw));
+        else x[i] = c.centers[i] + g.sym() * spread * hw * (c.types[i] == gau ? 3 : 1);
+      }
+      state s(&sp, x);  // the constructor enforces the boundaries (states.cc:194-199)
+      double lp;
+      {
+        cout_mute m;
+        lp = prior.evaluate_log(s);
+      }
+      os << (k ? "," : "") << "\n  {\"x\":" << jarr(x) << ",\"valid\":" << (s.invalid() ? 0 : 1)
+         << ",\"xe\":" << jarr(s.get_params_vector()) << ",\"lprior\":" << jnum(lp) << "}";
+    }
+    os << "]}";
+  }
+  os << "]";
+}
+
+static void golden_ladder(std::ostream& os) {
+  // ladder as built by the parallel_tempering_chains constructor + initialize (chain.cc:1181-1183,1340)
+  struct lc { int nt; double tmax; };
+  std::vector<lc> ls = {{8, 1e2}, {20, 1e9}, {64, 1e4}, {256, 1e6}, {1024, 1e9}, {2, 50.0}};
+  os << "\"ladders\":[";
+  for (size_t k = 0; k < ls.size(); k++) {
+    std::vector<double> beta;
+    {
+      cout_mute m;
+      stateSpace sp(1);
+      std::valarray<double> c(0.0, 1), h(1.0, 1);
+      std::valarray<int> t(mixed_dist_product::uniform, 1);
+      mixed_dist_product prior(&sp, t, c, h);
+      parallel_tempering_chains ptc(ls[k].nt, ls[k].tmax, 0.1, 1);
+      ptc.initialize(&prior, &prior, 1);  // likelihood := prior (flat inside the box) is enough here
+      for (int i = 0; i < ls[k].nt; i++) beta.push_back(ptc.subchain(i)->invTemp());
+    }
+    os << (k ? "," : "") << "\n {\"ntemps\":" << ls[k].nt << ",\"tmax\":" << jnum(ls[k].tmax)
+       << ",\"invtemps\":" << jarr(beta) << "}";
+  }
+  os << "]";
+}
+
+// ----------------------------------------------------------------------------------------------
+// Gaussian target registered through the bayes_likelihood function-pointer surface
+// ----------------------------------------------------------------------------------------------
+struct gauss_target {
+  int D;
+  std::vector<double> P;  // precision, row-major
+  double like0;
+  long ncalls;
+};
+static double gauss_eval(void* obj, const state& s) {
+  gauss_target* g = (gauss_target*)obj;
+  g->ncalls++;
+  std::valarray<double> x = s.get_params();
+  double q = 0;
+  for (int i = 0; i < g->D; i++) {
+    double r = 0;
+    for (int j = 0; j < g->D; j++) r += g->P[i * g->D + j] * x[j];
+    q += x[i] * r;
+  }
+  return g->like0 - 0.5 * q;
+}
+
+// scripted proposal: x' = x + delta[rung][ncalls], added exactly the way gaussian_prop adds its
+// offset (state::add of a space-less offset state, proposal_distribution.hh:217)
+struct tape_prop : public proposal_distribution {
+  const std::vector<std::vector<std::vector<double>>>* deltas;  // [rung][call][D]
+  int rung;
+  mutable int* nextrung;
+  size_t ncall;
+  tape_prop(const std::vector<std::vector<std::vector<double>>>* d, int* nextrung_)
+      : deltas(d), rung(-1), nextrung(nextrung_), ncall(0) {}
+  state draw(state& s, chain* caller) override {
+    const std::vector<double>& d = (*deltas)[rung][ncall++];
+    last_type = 0;
+    log_hastings = 0;
+    return s.add(state(nullptr, d));
+  }
+  tape_prop* clone() const override {
+    tape_prop* c = new tape_prop(*this);
+    c->rung = (*nextrung)++;  // parallel_tempering_chains::set_proposal clones in rung order (chain.cc:1368-1372)
+    c->ncall = 0;
+    return c;
+  }
+  string show() override { return "TapeProp()"; }
+};
+
+static std::vector<double> peek_tape(chain* c, int n) {
+  // copy of the chain's private generator => the values the chain WILL draw, without disturbing it
+  MotherOfAll* m = dynamic_cast<MotherOfAll*>(c->getPRNG().get());
+  if (!m) { fprintf(stderr, "peek_tape: chain RNG is not MotherOfAll\n"); exit(2); }
+  MotherOfAll copy(*m);
+  std::vector<double> t(n);
+  for (int i = 0; i < n; i++) t[i] = copy.Next();
+  return t;
+}
+
+static int golden_trace(int id) {
+  // --- problem definitions -------------------------------------------------------------------
+  int D, Nt, nsteps, Ninit = 1;
+  double Tmax, swap_rate, step_scale, minPrior = -30;
+  std::vector<std::string> types;
+  std::vector<double> centers, scales;
+  std::vector<int> blo, bhi;
+  std::vector<double> bmin, bmax;
+  const int O = boundary::open, L = boundary::limit, W = boundary::wrap, R = boundary::reflect;
+  if (id == 1) {  // BASELINE configs[0]: 2-D correlated Gaussian, 8-rung ladder
+    D = 2; Nt = 8; nsteps = 160; Tmax = 1e2; swap_rate = 0.1; step_scale = 1.2;
+    types = {"uni", "uni"}; centers = {0, 0}; scales = {60, 45};
+    blo = {O, O}; bhi = {O, O}; bmin = {0, 0}; bmax = {0, 0};
+  } else if (id == 2) {  // many swap attempts per step (Q6 overlap cases), narrow box (out-of-prior proposals)
+    D = 3; Nt = 7; nsteps = 160; Tmax = 30; swap_rate = 0.45; step_scale = 2.5;
+    types = {"uni", "uni", "uni"}; centers = {0.5, 0, -0.5}; scales = {4, 3, 5};
+    blo = {O, O, O}; bhi = {O, O, O}; bmin = {0, 0, 0}; bmax = {0, 0, 0};
+  } else if (id == 3) {  // mixed prior + wrap / limit / reflect boundaries
+    D = 5; Nt = 6; nsteps = 160; Tmax = 1e3; swap_rate = 0.3; step_scale = 1.5;
+    types = {"gauss", "log", "uni", "pol", "cpol"};
+    centers = {0.5, 3.0, 1.0, M_PI / 2, 0.0}; scales = {2.0, 4.0, 2.5, M_PI / 2, M_PI / 2};
+    blo = {O, L, W, L, R}; bhi = {O, O, W, L, R};
+    bmin = {0, 0.75, -1.5, 0, -M_PI / 2}; bmax = {0, 0, 3.5, M_PI, M_PI / 2};
+  } else {
+    fprintf(stderr, "unknown trace id %d\n", id);
+    return 2;
+  }
+  // target: zero-mean correlated Gaussian, precision P = inv(A^T A / D + 0.1 I) built directly as
+  // P = B^T B + 0.5 I with small-integer-ish B so the fixture is self-contained
+  splitmix g(0xC0FFEE + id);
+  gauss_target tgt;
+  tgt.D = D; tgt.ncalls = 0; tgt.P.assign(D * D, 0.0);
+  {
+    std::vector<double> B(D * D);
+    for (auto& b : B) b = g.sym();
+    for (int i = 0; i < D; i++)
+      for (int j = 0; j < D; j++) {
+        double a = 0;
+        for (int k = 0; k < D; k++) a += B[k * D + i] * B[k * D + j];
+        tgt.P[i * D + j] = a + (i == j ? 0.5 : 0.0);
+      }
+    tgt.like0 = -1.25 * D;
+  }
+  std::ostringstream js;
+  {
+    cout_mute mute;
+    ProbabilityDist::setSeed(0.012556 + 0.001 * id);
+    globalRNG.reset(ProbabilityDist::getPRNG());
+    stateSpace space(D);
+    std::vector<std::string> names;
+    for (int i = 0; i < D; i++) names.push_back("x" + std::to_string(i));
+    space.set_names(names);
+    for (int i = 0; i < D; i++) space.set_bound(i, boundary(blo[i], bhi[i], bmin[i], bmax[i]));
+    bayes_likelihood like;
+    like.register_reference_object(&tgt);
+    like.register_evaluate_log(gauss_eval);
+    like.basic_setup(&space, types, centers, scales);
+    const sampleable_probability_function* prior = like.getObjectPrior().get();
+
+    parallel_tempering_chains ptc(Nt, Tmax, swap_rate, 1, false, false, minPrior);
+    ptc.initialize(&like, prior, Ninit);
+
+    // scripted proposal offsets
+    std::vector<std::vector<std::vector<double>>> deltas(Nt);
+    for (int r = 0; r < Nt; r++) {
+      double beta = ptc.subchain(r)->invTemp();
+      double sc = step_scale / std::sqrt(std::max(beta, 0.02));
+      deltas[r].resize(nsteps);
+      for (int k = 0; k < nsteps; k++) {
+        deltas[r][k].resize(D);
+        for (int d = 0; d < D; d++) deltas[r][k][d] = g.sym() * sc;
+      }
+    }
+    int nextrung = 0;
+    tape_prop prop(&deltas, &nextrung);
+    ptc.set_proposal(prop);
+
+    int maxswaps = 1 + 2 * swap_rate * Nt;  // chain.cc:1192
+    std::vector<double> pt_tape = peek_tape(&ptc, 3 * maxswaps * nsteps + 8);
+    std::vector<std::vector<double>> ch_tape(Nt);
+    for (int r = 0; r < Nt; r++) ch_tape[r] = peek_tape(ptc.subchain(r), nsteps + 8);
+
+    js << "{\"id\":" << id << ",\"D\":" << D << ",\"Nt\":" << Nt << ",\"nsteps\":" << nsteps << ",\"Tmax\":" << jnum(Tmax)
+       << ",\"swap_rate\":" << jnum(swap_rate) << ",\"maxswaps\":" << maxswaps << ",\"minPrior\":" << jnum(minPrior)
+       << ",\"add_every_N\":1,\n\"types\":[";
+    for (int i = 0; i < D; i++) js << (i ? "," : "") << "\"" << types[i] << "\"";
+    js << "],\"centers\":" << jarr(centers) << ",\"scales\":" << jarr(scales) << ",\"blo\":" << jarr_i(blo)
+       << ",\"bhi\":" << jarr_i(bhi) << ",\"bmin\":" << jarr(bmin) << ",\"bmax\":" << jarr(bmax)
+       << ",\n\"P\":" << jarr(tgt.P) << ",\"like0\":" << jnum(tgt.like0) << ",\n\"invtemps\":[";
+    for (int r = 0; r < Nt; r++) js << (r ? "," : "") << jnum(ptc.subchain(r)->invTemp());
+    js << "],\n\"init\":[";
+    for (int r = 0; r < Nt; r++) {
+      chain* c = ptc.subchain(r);
+      js << (r ? "," : "") << "\n {\"x\":" << jarr(c->getState().get_params_vector()) << ",\"llike\":" << jnum(c->getLogLike())
+         << ",\"lpost\":" << jnum(c->getLogPost()) << ",\"size\":" << c->size() << "}";
+    }
+    js << "],\n\"pt_tape\":" << jarr(pt_tape) << ",\n\"chain_tapes\":[";
+    for (int r = 0; r < Nt; r++) js << (r ? "," : "") << "\n " << jarr(ch_tape[r]);
+    js << "],\n\"deltas\":[";
+    for (int r = 0; r < Nt; r++) {
+      js << (r ? "," : "") << "\n [";
+      for (int k = 0; k < nsteps; k++) js << (k ? "," : "") << jarr(deltas[r][k]);
+      js << "]";
+    }
+    js << "],\n\"steps\":[";
+    for (int k = 0; k < nsteps; k++) {
+      ptc.step();
+      js << (k ? "," : "") << "\n [";
+      for (int r = 0; r < Nt; r++) {
+        chain* c = ptc.subchain(r);
+        js << (r ? "," : "") << "{\"x\":" << jarr(c->getState().get_params_vector()) << ",\"llike\":" << jnum(c->getLogLike())
+           << ",\"lpost\":" << jnum(c->getLogPost()) << ",\"size\":" << c->size() << "}";
+      }
+      js << "]";
+    }
+    js << "],\n\"likelihood_calls\":" << tgt.ncalls << "}\n";
+    globalRNG.reset();  // do not let the shared_ptr delete the master generator twice
+  }
+  std::cout << js.str();
+  return 0;
+}
+
+// ----------------------------------------------------------------------------------------------
+// bench: the reference's own classes on the correlated-Gaussian ladder, timed
+// ----------------------------------------------------------------------------------------------
+static int bench(const char* specfile) {
+  // spec file (text): D Nt nsteps Tmax swap_rate seed  / then D*D covariance (row-major) / then D prior half-widths
+  std::ifstream in(specfile);
+  if (!in) { fprintf(stderr, "cannot open %s\n", specfile); return 2; }
+  int D, Nt, nsteps;
+  double Tmax, swap_rate, seed;
+  in >> D >> Nt >> nsteps >> Tmax >> swap_rate >> seed;
+  Eigen::MatrixXd cov(D, D);
+  for (int i = 0; i < D; i++) for (int j = 0; j < D; j++) in >> cov(i, j);
+  std::vector<double> hw(D);
+  for (int i = 0; i < D; i++) in >> hw[i];
+  if (!in) { fprintf(stderr, "short spec file\n"); return 2; }
+  Eigen::MatrixXd P = cov.inverse();
+  gauss_target tgt;
+  tgt.D = D; tgt.ncalls = 0; tgt.P.resize(D * D);
+  for (int i = 0; i < D; i++) for (int j = 0; j < D; j++) tgt.P[i * D + j] = P(i, j);
+  tgt.like0 = -0.5 * (D * std::log(2 * M_PI) + std::log(cov.determinant()));
+  double secs, acc0 = 0;
+  long nmh = 0;
+  {
+    cout_mute mute;
+    ProbabilityDist::setSeed(seed);
+    globalRNG.reset(ProbabilityDist::getPRNG());
+    stateSpace space(D);
+    std::vector<std::string> names, types(D, "uni");
+    std::vector<double> centers(D, 0.0);
+    for (int i = 0; i < D; i++) names.push_back("x" + std::to_string(i));
+    space.set_names(names);
+    bayes_likelihood like;
+    like.register_reference_object(&tgt);
+    like.register_evaluate_log(gauss_eval);
+    like.basic_setup(&space, types, centers, hw);
+    const sampleable_probability_function* prior = like.getObjectPrior().get();
+    Eigen::MatrixXd pcov = cov * (2.38 * 2.38 / D);
+    gaussian_prop prop(pcov);
+    parallel_tempering_chains ptc(Nt, Tmax, swap_rate, 100, false, false, -30);
+    ptc.initialize(&like, prior, 1);
+    ptc.set_proposal(prop);
+    int warm = nsteps / 10 + 1;
+    for (int k = 0; k < warm; k++) ptc.step();
+    auto t0 = std::chrono::steady_clock::now();
+    for (int k = 0; k < nsteps; k++) ptc.step();
+    auto t1 = std::chrono::steady_clock::now();
+    secs = std::chrono::duration<double>(t1 - t0).count();
+    nmh = (long)nsteps * Nt;
+    globalRNG.reset();
+  }
+  printf("{\"kind\":\"reference\",\"D\":%d,\"ntemps\":%d,\"nsteps\":%d,\"seconds\":%.6f,\"steps_per_s\":%.6g,"
+         "\"threads\":1,\"likelihood_calls\":%ld}\n",
+         D, Nt, nsteps, secs, nmh / secs, tgt.ncalls);
+  (void)acc0;
+  return 0;
+}
+
+int main(int argc, char** argv) {
+  if (argc >= 2 && !strcmp(argv[1], "golden-basic")) {
+    ProbabilityDist::setSeed(0.224);  // chain() constructors draw their seed from the master generator (chain.hh:58-62)
+    std::ostringstream os;
+    os << "{";
+    golden_boundary(os);
+    os << ",\n";
+    golden_priors(os);
+    os << ",\n";
+    golden_ladder(os);
+    os << "}\n";
+    std::cout << os.str();
+    return 0;
+  }
+  if (argc >= 3 && !strcmp(argv[1], "golden-trace")) return golden_trace(atoi(argv[2]));
+  if (argc >= 3 && !strcmp(argv[1], "bench")) return bench(argv[2]);
+  fprintf(stderr, "usage: %s golden-basic | golden-trace <1|2|3> | bench <specfile>\n", argv[0]);
+  return 2;
+}

@@ -1,0 +1,168 @@
+"""The oracle (oracle/ptm_oracle.c) against fixtures produced by the REAL reference
+(tests/golden/make_golden.py) and against the reference's own golden file.  CPU only."""
+import math
+
+import numpy as np
+import pytest
+
+import golden_io
+import lisa_toy
+import oracle_lib as O
+
+TOL = 1e-10   # |delta log-posterior| bar of BASELINE.json north_star
+
+
+def close(a, b, tol=TOL):
+    if math.isinf(a) or math.isinf(b) or math.isnan(a) or math.isnan(b):
+        return (a == b) or (math.isnan(a) and math.isnan(b))
+    return abs(a - b) <= tol * max(1.0, abs(b))
+
+
+def test_philox_known_answers():
+    # Random123 kat_vectors, philox4x32 10 rounds
+    assert O.philox([0, 0, 0, 0], [0, 0]) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert O.philox([0xffffffff] * 4, [0xffffffff] * 2) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert O.philox([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]) == \
+        [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+
+
+def test_uniform_map_matches_newran():
+    # newran1.cxx:432: ((double)seed + 0.5) / 4294967296.0 -- open interval, log() always finite
+    L = O.lib()
+    assert L.ptmo_u01(0) == 0.5 / 4294967296.0
+    assert L.ptmo_u01(0xffffffff) == (4294967295.0 + 0.5) / 4294967296.0 < 1.0
+
+
+def test_elementary_functions_vs_libm():
+    L = O.lib()
+    rng = np.random.default_rng(7)
+    for x in np.concatenate([rng.uniform(1e-300, 1, 3000), 10 ** rng.uniform(-320, 300, 3000), rng.uniform(.5, 2, 3000)]):
+        assert abs(L.ptmo_log(float(x)) - math.log(x)) <= 4e-16 * max(1, abs(math.log(x)))
+    for x in rng.uniform(-740, 700, 5000):
+        assert abs(L.ptmo_exp(float(x)) - math.exp(x)) <= 4e-16 * math.exp(x) + 1e-320
+    for x in rng.uniform(0, math.pi, 5000):
+        assert abs(L.ptmo_sin_0_pi(float(x)) - math.sin(x)) <= 4e-16
+    for x in rng.uniform(-math.pi / 2, math.pi / 2, 5000):
+        assert abs(L.ptmo_cos_hpi(float(x)) - math.cos(x)) <= 4e-16
+    assert L.ptmo_log(0.0) == -math.inf and math.isnan(L.ptmo_log(-1.0)) and L.ptmo_exp(-800.0) == 0.0
+
+
+def test_boxmuller_matches_formula_and_moments():
+    rng = np.random.default_rng(11)
+    ks = rng.integers(0, 2 ** 32, size=(40000, 2), dtype=np.uint64)
+    z = np.array([O.boxmuller(int(a), int(b)) for a, b in ks])
+    u1 = (ks[:, 0].astype(float) + .5) / 2 ** 32
+    th = 2 * np.pi * (ks[:, 1].astype(float) + .5) / 2 ** 32
+    ref = np.stack([np.sqrt(-2 * np.log(u1)) * np.cos(th), np.sqrt(-2 * np.log(u1)) * np.sin(th)], 1)
+    assert np.abs(z - ref).max() < 1e-13
+    assert abs(z.mean()) < 0.02 and abs(z.var() - 1) < 0.02
+    # extreme draws stay finite
+    for k1, k2 in [(0, 0), (0xffffffff, 0xffffffff), (0, 0x80000000), (1, 0x1fffffff), (5, 0x20000000)]:
+        a, b = O.boxmuller(k1, k2)
+        assert math.isfinite(a) and math.isfinite(b)
+
+
+def test_boundary_enforce_table():
+    g = golden_io.load("basic.json.gz")["boundary"]
+    assert len(g) > 300
+    for c in g:
+        ok, y = O.boundary_enforce(c["lo"], c["hi"], c["xmin"], c["xmax"], c["x"])
+        assert ok == c["ok"], c
+        if ok:
+            assert close(y, c["y"], 1e-12), (c, y)
+
+
+def _problem_from(cfg):
+    D = len(cfg["types"])
+    pb = O.Problem(D)
+    pb.set_bounds(cfg["blo"], cfg["bhi"], cfg["bmin"], cfg["bmax"])
+    pb.set_prior(cfg["types"], cfg["centers"], cfg["halfwidths"])
+    return pb
+
+
+def test_prior_tables():
+    n = 0
+    for cfg in golden_io.load("basic.json.gz")["priors"]:
+        pb = _problem_from(cfg)
+        for case in cfg["cases"]:
+            ok, xe = pb.enforce(case["x"])
+            assert ok == case["valid"], (cfg["name"], case)
+            if ok:
+                assert np.allclose(xe, case["xe"], rtol=0, atol=1e-12)
+            lp = pb.lprior(xe, ok)
+            exp = case["lprior"]
+            # Q2: log(prod pdf) loses precision once the product is subnormal (< ~1e-308, lprior < -709)
+            tol = TOL if not (math.isfinite(exp) and exp < -700) else 1e-6
+            assert close(lp, exp, tol), (cfg["name"], case, lp)
+            n += 1
+    assert n > 150
+
+
+def test_ladder():
+    for l in golden_io.load("basic.json.gz")["ladders"]:
+        b = O.ladder(l["ntemps"], l["tmax"])
+        assert np.allclose(b, l["invtemps"], rtol=1e-14, atol=0)
+        assert b[0] == 1.0
+
+
+def test_gaussian_target_values():
+    for g in golden_io.load("gauss_target.json"):
+        D = g["D"]
+        pb = O.Problem(D)
+        pb.set_gauss(np.array(g["invcov"]).reshape(D, D), g["like0"])
+        for x, ll in zip(g["x"], g["llike"]):
+            assert close(pb.llike(x), ll), (D, ll)
+
+
+def test_reference_exampleLISA_golden_rows():
+    """The 31 prior-draw rows of test/exampleLISA/exampleLISA_test_0_t0.dat: (lpost, llike, params) printed with
+    13 significant digits.  Pins the mixed prior (uniform/polar/copolar) and the plug-in likelihood."""
+    rows = golden_io.load("lisa_init_rows.json")
+    assert len(rows) == 31
+    pb = O.Problem(6)
+    pb.set_bounds(lisa_toy.BLO, lisa_toy.BHI, lisa_toy.BMIN, lisa_toy.BMAX)
+    pb.set_prior(lisa_toy.TYPES, lisa_toy.CENTERS, lisa_toy.SCALES)
+    pb.set_user(lisa_toy.loglike)
+    for r in rows:
+        ok, xe = pb.enforce(r["x"])
+        assert ok
+        ll = pb.llike(xe)
+        lp = pb.lprior(xe, 1)
+        # parameters carry 13 digits; llike ~ 1e4..5e5 with gradient ~1e5 => absolute agreement ~1e-6 relative
+        assert abs(ll - r["llike"]) <= 2e-9 * abs(r["llike"]) + 1e-6, (r, ll)
+        assert abs((lp + ll) - r["lpost"]) <= 2e-9 * abs(r["lpost"]) + 1e-6, (r, lp)
+        assert abs(lp - (r["lpost"] - r["llike"])) < 5e-7
+
+
+@pytest.mark.parametrize("tid", [1, 2, 3])
+def test_reference_pt_trace(tid):
+    """Replay a real parallel_tempering_chains run: same initial states, same uniforms (recorded tapes of the
+    reference's MotherOfAll generators), same scripted proposal offsets => the restatement must hold the same
+    state on every rung after every PT step (chain.cc:1393-1571 + 966-1022 semantics incl. quirks Q1,Q5,Q6,Q7)."""
+    g = golden_io.load("trace%d.json.gz" % tid)
+    D, Nt, ns = g["D"], g["Nt"], g["nsteps"]
+    pb = O.Problem(D, min_prior=g["minPrior"])
+    pb.set_bounds(g["blo"], g["bhi"], g["bmin"], g["bmax"])
+    pb.set_prior(g["types"], g["centers"], g["scales"])
+    pb.set_gauss(np.array(g["P"]).reshape(D, D), g["like0"])
+    beta = O.ladder(Nt, g["Tmax"])
+    assert np.allclose(beta, g["invtemps"], rtol=1e-14)
+    lad = O.Ladder(pb, g["invtemps"], W=1, swap_rate=g["swap_rate"], add_every_N=g["add_every_N"])
+    assert lad.s.contents.maxswaps == g["maxswaps"]
+    lad.set_proposals([(O.PROP_DIAG, np.ones(D), 0.0)] * Nt)   # unused: offsets come from the tape
+    lad.use_tape(np.array(g["chain_tapes"]), np.array(g["pt_tape"])[None, :], np.array(g["deltas"]))
+    lad.set_states(np.array([c["x"] for c in g["init"]]))
+    for r, c in enumerate(g["init"]):
+        assert close(lad.llike[r], c["llike"]) and close(lad.lpost[r], c["lpost"])
+    nswapped = 0
+    for k in range(ns):
+        lad.pt_step()
+        x, ll, lp, nsz = lad.x, lad.llike, lad.lpost, lad.nsize
+        nswapped += int(lad.last_accept.sum())
+        for r, c in enumerate(g["steps"][k]):
+            assert np.array_equal(x[r], np.array(c["x"])), (tid, k, r, x[r], c["x"])
+            assert close(ll[r], c["llike"]), (tid, k, r)
+            assert close(lp[r], c["lpost"]), (tid, k, r)
+            assert nsz[r] == c["size"], (tid, k, r, nsz[r], c["size"])
+    assert nswapped > 5          # the trace really exercised accepted exchanges
+    assert lad.naccept.sum() > Nt + 20 and (lad.ntries > 20).all()
