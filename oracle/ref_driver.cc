@@ -307,6 +307,13 @@ static int golden_trace(int id) {
     centers = {0.5, 3.0, 1.0, M_PI / 2, 0.0}; scales = {2.0, 4.0, 2.5, M_PI / 2, M_PI / 2};
     blo = {O, L, W, L, R}; bhi = {O, O, W, L, R};
     bmin = {0, 0.75, -1.5, 0, -M_PI / 2}; bmax = {0, 0, 3.5, M_PI, M_PI / 2};
+  } else if (id == 4) {  // as 3, but the origin lies inside every `limit` bound (see quirk Q9: in trace 3 it does not,
+                         // so there state::add() yields an invalid state and the reference never accepts a move)
+    D = 5; Nt = 6; nsteps = 160; Tmax = 1e3; swap_rate = 0.3; step_scale = 0.9;
+    types = {"gauss", "log", "uni", "pol", "cpol"};
+    centers = {0.5, 3.0, 1.0, M_PI / 2, 0.0}; scales = {2.0, 4.0, 2.5, M_PI / 2, M_PI / 2};
+    blo = {O, L, W, L, R}; bhi = {O, O, W, L, R};
+    bmin = {0, -0.5, -1.5, 0, -M_PI / 2}; bmax = {0, 0, 3.5, M_PI, M_PI / 2};
   } else {
     fprintf(stderr, "unknown trace id %d\n", id);
     return 2;
@@ -479,6 +486,6 @@ int main(int argc, char** argv) {
   }
   if (argc >= 3 && !strcmp(argv[1], "golden-trace")) return golden_trace(atoi(argv[2]));
   if (argc >= 3 && !strcmp(argv[1], "bench")) return bench(argv[2]);
-  fprintf(stderr, "usage: %s golden-basic | golden-trace <1|2|3> | bench <specfile>\n", argv[0]);
+  fprintf(stderr, "usage: %s golden-basic | golden-trace <1|2|3|4> | bench <specfile>\n", argv[0]);
   return 2;
 }
