@@ -1,0 +1,172 @@
+/* include/ptm_engine.h -- C ABI of the MI355X parallel-tempering step engine.
+ *
+ * This is the drop-in boundary for ONE hot path of JohnGBaker/ptmcmc: chain::step()
+ *   MH_chain::step                       chain.cc:966-1022
+ *   MH_chain::add_state                  chain.cc:916-949
+ *   parallel_tempering_chains::step      chain.cc:1393-1571
+ * behind the reference's plug-in surface (bayes_likelihood / probability_function /
+ * proposal_distribution, ptmcmc_sampler).  Plain C: pointers and sizes only, no C++ or
+ * torch types.  All HOST pointers unless a parameter says "device".
+ *
+ * Conventions
+ *   - every function returns PTM_OK (0) or a negative ptm_status; ptm_last_error() gives text.
+ *   - a "chain" is one (rung, walker) pair.  Walkers are W independent ladders batched together
+ *     (the reference's nearest notion is Nchain independent repeats, testMH.cpp:17,206).
+ *   - an engine holds the contiguous rung block [rung_begin, rung_begin+rung_count) of a global ladder
+ *     of n_rungs rungs, for all W walkers.  Local chain index  c = (rung - rung_begin) * W + walker.
+ *     Host-visible arrays are chain-major in that order; states are [chain][dim] row-major.
+ *   - random streams are keyed by GLOBAL identities (seed, global rung, walker, step), so results do
+ *     not depend on how the ladder is sharded or how kernels are launched.
+ */
+#ifndef PTM_ENGINE_H
+#define PTM_ENGINE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PTM_ABI_VERSION 1
+
+typedef struct ptm_engine ptm_engine;
+
+typedef enum {
+  PTM_OK = 0,
+  PTM_ERR_INVALID = -1,      /* bad argument / call order */
+  PTM_ERR_UNSUPPORTED = -2,  /* feature not available on the device path (caller must use the host path) */
+  PTM_ERR_HIP = -3,          /* HIP runtime error (text in ptm_last_error) */
+  PTM_ERR_NO_DEVICE = -4,    /* no gfx950 device / code object cannot load */
+  PTM_ERR_FAR_MOVE = -5,     /* neighbour-exchange mode saw a state cross more than one shard boundary in one step */
+  PTM_ERR_CALLBACK = -6
+} ptm_status;
+
+/* boundary types -- values of boundary::{open,limit,reflect,wrap}, states.hh:34-37 */
+enum { PTM_BOUND_OPEN = 0, PTM_BOUND_LIMIT = 1, PTM_BOUND_REFLECT = 2, PTM_BOUND_WRAP = 3 };
+/* per-dimension prior types -- values of mixed_dist_product::{uniform,gaussian,polar,copolar,log},
+ * probability_function.hh:151-155; 0 = flat (base probability_function, probability_function.hh:40) */
+enum { PTM_PRIOR_FLAT = 0, PTM_PRIOR_UNIFORM = 1, PTM_PRIOR_GAUSSIAN = 2, PTM_PRIOR_POLAR = 3, PTM_PRIOR_COPOLAR = 4,
+       PTM_PRIOR_LOG = 5 };
+/* Gaussian step proposal storage (gaussian_prop, proposal_distribution.hh:145-227) */
+enum {
+  PTM_PROP_DENSE = 0, /* offset = M z, M dense D x D (e.g. eigenvectors * sqrt(eigenvalues), hh:173-176,207-213) */
+  PTM_PROP_DIAG = 1,  /* offset_i = sigma_i z_i  (identity_trans, hh:155-163) */
+  PTM_PROP_LOWER = 2  /* offset = L z, L lower triangular (Cholesky factor); same numbers as DENSE with zeros */
+};
+
+typedef struct ptm_config {
+  uint32_t struct_size;   /* sizeof(ptm_config), for ABI evolution */
+  int32_t dim;            /* D, 1..64 */
+  int32_t n_rungs;        /* global ladder length (Ntemps) */
+  int32_t rung_begin;     /* first global rung held by this engine */
+  int32_t rung_count;     /* rungs held by this engine (== n_rungs on one GPU) */
+  int32_t n_walkers;      /* W independent ladders */
+  uint64_t seed;          /* Philox key */
+  double swap_rate;       /* parallel_tempering_chains ctor arg (chain.cc:1163); maxswapsperstep = 1+2*swap_rate*n_rungs */
+  int32_t add_every_n;    /* history stride (save_every), >= 1 */
+  double min_prior;       /* dpriormin / minPrior, MH_chain ctor (chain.cc:647); sampler default -30 */
+  int32_t device;         /* HIP device ordinal, -1 = current device */
+  void* stream;           /* hipStream_t to launch on; NULL = the engine creates its own */
+  int32_t time_kernels;   /* !=0: bracket every sweep-kernel launch with HIP events (ptm_get_kernel_times) */
+  int32_t swap_log_steps; /* >0: keep the per-candidate swap log of the last N steps on the device */
+} ptm_config;
+
+/* user plug-in likelihood, batched: the C shape of bayes_likelihood::register_evaluate_log
+ * (bayesian.hh:536-552: double(*)(void* object, const state& s)).  X is [n][dim] row-major. */
+typedef void (*ptm_loglike_batch_fn)(void* user, const double* X, int n, int dim, double* out_llike);
+
+const char* ptm_last_error(void);
+int ptm_abi_version(void);
+/* number of usable gfx950 devices (0 if none); never fails */
+int ptm_device_count(void);
+
+int ptm_engine_create(const ptm_config* cfg, ptm_engine** out);
+int ptm_engine_destroy(ptm_engine* e);
+
+/* ---- problem description (what bayes_likelihood::basic_setup + stateSpace describe) ---------------- */
+/* stateSpace::set_bound per dimension (states.hh:70-76) */
+int ptm_set_bounds(ptm_engine* e, const int32_t* lower_type, const int32_t* upper_type, const double* xmin,
+                   const double* xmax);
+/* mixed_dist_product(space, types, centers, halfwidths) (probability_function.cc:219-262) */
+int ptm_set_prior(ptm_engine* e, const int32_t* types, const double* centers, const double* halfwidths);
+/* llike(x) = like0 - 1/2 (x-mean)^T P (x-mean);  P row-major D x D symmetric; mean may be NULL
+ * (cython/exampleGaussian.py:53-54,61,103-109) */
+int ptm_set_target_gaussian(ptm_engine* e, const double* mean, const double* precision, double like0);
+/* user likelihood evaluated on the host between a propose and an accept kernel */
+int ptm_set_target_callback(ptm_engine* e, ptm_loglike_batch_fn fn, void* user);
+/* inverse temperatures of the GLOBAL ladder, beta[n_rungs] (chain.cc:1181-1183,1340) */
+int ptm_set_ladder(ptm_engine* e, const double* beta);
+/* proposals of the LOCAL rungs: factors[rung_count][D*D] row-major (DENSE/LOWER) or [rung_count][D] (DIAG);
+ * one_d_frac[rung_count] (gaussian_prop oneDfrac) may be NULL (= 0).  One clone per rung as
+ * parallel_tempering_chains::set_proposal does (chain.cc:1367-1386). */
+int ptm_set_proposals(ptm_engine* e, int kind, const double* factors, const double* one_d_frac);
+
+/* ---- state ------------------------------------------------------------------------------------------ */
+/* X[n_local_chains][D]; llike may be NULL (the device target evaluates it).  Resets counters the way
+ * MH_chain::initialize(1) leaves them (chain.cc:649,846-876). */
+int ptm_set_states(ptm_engine* e, const double* X, const double* llike);
+/* MH_chain::initialize(1): draw each chain's start from the prior until valid (uniform/gaussian dims only) */
+int ptm_init_from_prior(ptm_engine* e);
+
+/* ---- the hot path ------------------------------------------------------------------------------------- */
+/* n x { MH_chain::step for every chain } -- no exchange phase */
+int ptm_sweep(ptm_engine* e, int n);
+/* n x parallel_tempering_chains::step (single-shard engines: rung_count == n_rungs) */
+int ptm_step(ptm_engine* e, int n);
+/* wait for all queued work */
+int ptm_sync(ptm_engine* e);
+
+/* ---- multi-GPU building blocks (one engine per GPU; the caller moves bytes with RCCL) ---------------- */
+/* device pointer to the local llike array of the CURRENT step, [rung_count*W] doubles, chain-major */
+int ptm_llike_device_ptr(ptm_engine* e, void** dev_ptr);
+/* exchange phase, part 1: decide all exchanges of the next step from the GLOBAL llike array
+ * (device pointer, [n_rungs*W] doubles = concatenation of the shards' local arrays) and pack the rows that
+ * leave this shard into send_up / send_down (device buffers of W*(D+2) doubles each, may be NULL at the ends). */
+int ptm_exchange_decide(ptm_engine* e, const void* llike_global_dev, void* send_up_dev, void* send_down_dev);
+/* exchange phase, part 2 + MH sweep: rows arriving from the neighbours (device buffers, W*(D+2) doubles) */
+int ptm_exchange_finish_and_sweep(ptm_engine* e, const void* recv_from_below_dev, const void* recv_from_above_dev);
+
+/* ---- read-back ------------------------------------------------------------------------------------------ */
+enum {
+  PTM_ARR_LLIKE = 0,  /* double */
+  PTM_ARR_LPRIOR = 1, /* double */
+  PTM_ARR_LPOST = 2,  /* double: lprior + beta*llike (chain.cc:928) */
+  PTM_ARR_NTRIES = 3, /* int32: MH_chain::Ntries (starts at 1, chain.cc:649) */
+  PTM_ARR_NACCEPT = 4,/* int32 */
+  PTM_ARR_LAST_TYPE = 5, /* int32 */
+  PTM_ARR_NHIST = 6,  /* int64: add_state calls */
+  PTM_ARR_NSIZE = 7   /* int64: history rows (chain.cc:935-946) */
+};
+int ptm_get_states(ptm_engine* e, double* X);
+int ptm_get_array(ptm_engine* e, int which, void* out);
+/* per walker, per adjacent pair: attempts and accepts (swap_count / swap_accept_count, chain.hh:244-245);
+ * each [W][n_rungs-1] int64 */
+int ptm_get_swap_counts(ptm_engine* e, int64_t* tries, int64_t* accepts);
+/* candidates of the most recent step: pairs[W][maxswaps] (lower rung or -2), accepted[W][maxswaps] */
+int ptm_get_last_swaps(ptm_engine* e, int32_t* pairs, int32_t* accepted);
+int ptm_max_swaps_per_step(ptm_engine* e);
+uint64_t ptm_step_count(ptm_engine* e);
+
+/* ---- measurement ---------------------------------------------------------------------------------------- */
+/* HIP events on the engine's stream */
+int ptm_timer_start(ptm_engine* e);
+int ptm_timer_stop(ptm_engine* e, float* elapsed_ms); /* synchronises on the stop event */
+/* per-launch durations of the fused sweep kernel recorded since the last call (cfg.time_kernels) */
+int ptm_get_kernel_times(ptm_engine* e, float* ms, int capacity, int* count);
+/* name of the sweep kernel variant in use (for matching rocprofv3 traces) */
+const char* ptm_sweep_kernel_name(ptm_engine* e);
+
+/* ---- verification hooks (used by tests/ only; evaluate device functions on arrays) ---------------------- */
+enum { PTM_FN_LOG = 0, PTM_FN_EXP = 1, PTM_FN_SIN_0_PI = 2, PTM_FN_COS_HPI = 3, PTM_FN_SQRT = 4, PTM_FN_DIV = 5 };
+int ptm_debug_eval(int device, int fn, const double* a, const double* b, double* out, int n);
+int ptm_debug_philox(int device, uint64_t seed, int tag, uint32_t stream, uint64_t step, uint32_t block, uint32_t out[4]);
+int ptm_debug_boxmuller(int device, const uint32_t* k1, const uint32_t* k2, double* z0, double* z1, int n);
+/* evaluate lprior / llike of arbitrary states with the engine's problem description: X[n][D] */
+int ptm_debug_evaluate(ptm_engine* e, const double* X, int n, int32_t* valid, double* X_enforced, double* lprior,
+                       double* llike);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTM_ENGINE_H */

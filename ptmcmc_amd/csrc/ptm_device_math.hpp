@@ -1,0 +1,190 @@
+// ptm_device_math.hpp -- gfx950 device functions: Philox4x32-10, the open-interval uniform map,
+// Box-Muller, and the deterministic log / exp / sin / cos used on the hot path.
+//
+// Numerics contract (DESIGN.md "Numerics"): every result is produced by IEEE-754 binary64
+// +, -, *, /, sqrt and explicitly written fma in the order written here; the translation unit is
+// compiled with -ffp-contract=off so hipcc adds no contractions of its own.  The CPU checker
+// (oracle/ptm_oracle.c) states the same sequences independently; tests compare bit for bit.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ptm {
+
+// ------------------------------------------------------------------------------------------------
+// Philox4x32-10 (Salmon, Moraes, Dror, Shaw, SC'11).  Replaces newran's MotherOfAll
+// (ProbabilityDist/newran1.cxx:383-432) -- counter based, so a chain's stream depends only on
+// (seed, chain identity, step), never on launch geometry.
+// ------------------------------------------------------------------------------------------------
+struct u32x4 { uint32_t v0, v1, v2, v3; };
+
+__device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                                uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  return {c0, c1, c2, c3};
+}
+
+// counter layout of the engine: c0 = block, c1 = stream, c2 = step[31:0], c3 = step[55:32] | tag << 24
+enum { TAG_MH = 0, TAG_PT = 1, TAG_INIT = 2 };
+__device__ __forceinline__ u32x4 draw_block(uint64_t seed, int tag, uint32_t stream, uint64_t step, uint32_t block) {
+  return philox4x32_10(block, stream, (uint32_t)step, ((uint32_t)(step >> 32) & 0x00FFFFFFu) | ((uint32_t)tag << 24),
+                       (uint32_t)seed, (uint32_t)(seed >> 32));
+}
+
+// (k + 0.5) / 2^32: the open-interval map of MotherOfAll::Next (newran1.cxx:432), so log(u) is finite
+__device__ __forceinline__ double u01(uint32_t k) { return ((double)k + 0.5) * (1.0 / 4294967296.0); }
+
+// ------------------------------------------------------------------------------------------------
+// log / exp: classic argument reduction + polynomial (coefficients of the FreeBSD/fdlibm e_log.c /
+// e_exp.c algorithms), written with explicit fma Horner steps.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double dlog(double x) {
+  const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
+  const double L1 = 6.666666666666735130e-01, L2 = 3.999999999940941908e-01, L3 = 2.857142874366239149e-01,
+               L4 = 2.222219843214978396e-01, L5 = 1.818357216161805012e-01, L6 = 1.531383769920937332e-01,
+               L7 = 1.479819860511658591e-01;
+  int e = 0;
+  if (x != x) return x;
+  if (x < 0.0) return __builtin_nan("");
+  if (x == 0.0) return -__builtin_inf();
+  if (x == __builtin_inf()) return x;
+  if (x < 2.2250738585072014e-308) { x *= 18014398509481984.0; e = -54; }
+  const uint64_t b = (uint64_t)__double_as_longlong(x);
+  e += (int)(b >> 52) - 1023;
+  double m = __longlong_as_double((long long)((b & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull));
+  if (m > 1.4142135623730951) { m *= 0.5; e += 1; }
+  const double f = m - 1.0;
+  const double s = f / (2.0 + f);
+  const double z = s * s;
+  double r = L7;
+  r = __builtin_fma(r, z, L6); r = __builtin_fma(r, z, L5); r = __builtin_fma(r, z, L4);
+  r = __builtin_fma(r, z, L3); r = __builtin_fma(r, z, L2); r = __builtin_fma(r, z, L1);
+  const double R = r * z;
+  const double hfsq = 0.5 * f * f;
+  const double dk = (double)e;
+  return dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
+}
+
+// log of an open-interval uniform (k+0.5)/2^32: same sequence as dlog() minus the special cases that
+// cannot occur (the argument is a normal number in (2^-33, 1))
+__device__ __forceinline__ double dlog_u01(uint32_t k) { return dlog(u01(k)); }
+
+__device__ __forceinline__ double dexp(double x) {
+  const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
+               invln2 = 1.44269504088896338700e+00;
+  const double P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03, P3 = 6.61375632143793436117e-05,
+               P4 = -1.65339022054652515390e-06, P5 = 4.13813679705723846039e-08;
+  if (x != x) return x;
+  if (x > 709.782712893384) return __builtin_inf();
+  if (x < -745.1332191019412) return 0.0;
+  const int k = (int)(x * invln2 + (x < 0.0 ? -0.5 : 0.5));
+  const double dk = (double)k;
+  const double hi = x - dk * ln2_hi;
+  const double lo = dk * ln2_lo;
+  const double r = hi - lo;
+  const double t = r * r;
+  double p = P5;
+  p = __builtin_fma(p, t, P4); p = __builtin_fma(p, t, P3); p = __builtin_fma(p, t, P2); p = __builtin_fma(p, t, P1);
+  const double c = r - t * p;
+  const double y = 1.0 - ((lo - (r * c) / (2.0 - c)) - hi);
+  if (k >= -1021 && k <= 1023) return y * __longlong_as_double((long long)((uint64_t)(k + 1023) << 52));
+  if (k > 1023) return y * 2.0 * __longlong_as_double((long long)((uint64_t)(k - 1 + 1023) << 52));
+  return (y * __longlong_as_double((long long)((uint64_t)(k + 1000 + 1023) << 52))) *
+         __longlong_as_double((long long)((uint64_t)(-1000 + 1023) << 52));
+}
+
+// sin / cos on [0, pi/4]: Taylor polynomials, Horner with fma
+__device__ __forceinline__ double sin_k(double p) {
+  const double z = p * p;
+  double r = -1.0 / 1307674368000.0;
+  r = __builtin_fma(r, z, 1.0 / 6227020800.0);
+  r = __builtin_fma(r, z, -1.0 / 39916800.0);
+  r = __builtin_fma(r, z, 1.0 / 362880.0);
+  r = __builtin_fma(r, z, -1.0 / 5040.0);
+  r = __builtin_fma(r, z, 1.0 / 120.0);
+  r = __builtin_fma(r, z, -1.0 / 6.0);
+  return __builtin_fma(p * z, r, p);
+}
+__device__ __forceinline__ double cos_k(double p) {
+  const double z = p * p;
+  double r = 1.0 / 20922789888000.0;
+  r = __builtin_fma(r, z, -1.0 / 87178291200.0);
+  r = __builtin_fma(r, z, 1.0 / 479001600.0);
+  r = __builtin_fma(r, z, -1.0 / 3628800.0);
+  r = __builtin_fma(r, z, 1.0 / 40320.0);
+  r = __builtin_fma(r, z, -1.0 / 720.0);
+  r = __builtin_fma(r, z, 1.0 / 24.0);
+  return __builtin_fma(z * z, r, __builtin_fma(-0.5, z, 1.0));
+}
+
+constexpr double PI_HI = 3.141592653589793116e+00, PI_LO = 1.224646799147353207e-16;
+constexpr double HPI_HI = 1.570796326794896558e+00, HPI_LO = 6.123233995736766036e-17;
+constexpr double QPI = 7.853981633974482790e-01;
+
+// sin on [0, pi]: UniformPolarDist::pdf (ProbabilityDist.h:197-201)
+__device__ __forceinline__ double dsin_0_pi(double x) {
+  if (x > HPI_HI) x = (PI_HI - x) + PI_LO;
+  if (x <= QPI) return sin_k(x);
+  return cos_k((HPI_HI - x) + HPI_LO);
+}
+// cos on [-pi/2, pi/2]: UniformCoPolarDist::pdf (ProbabilityDist.h:243-247)
+__device__ __forceinline__ double dcos_hpi(double x) {
+  x = __builtin_fabs(x);
+  if (x <= QPI) return cos_k(x);
+  return sin_k((HPI_HI - x) + HPI_LO);
+}
+
+// correctly rounded square root: the compiler's f64 sqrt expansion followed by one exact-residual
+// correction step, so that the result is the IEEE value the CPU checker's sqrt() returns
+__device__ __forceinline__ double dsqrt(double a) {
+  double g = __builtin_sqrt(a);  // faithful (<= 1 ulp)
+  if (a > 0.0 && a < __builtin_inf()) {
+    // r = a - g*g (sign exact).  If r != 0 the root lies between g and its neighbour gn on that side; g is the
+    // correctly rounded value iff the root is on g's side of the midpoint, i.e. a vs ((g+gn)/2)^2 = g*gn + d^2/4.
+    // In units of ulp^2 the quantity a - g*gn is an integer N and d^2/4 < 1, so the test is N > 0 (r > 0) / N <= 0 (r < 0).
+    const double r = __builtin_fma(-g, g, a);
+    if (r != 0.0) {
+      const double gn = __longlong_as_double(__double_as_longlong(g) + (r > 0.0 ? 1 : -1));
+      const double t = __builtin_fma(-g, gn, a);
+      if (r > 0.0 ? (t > 0.0) : (t <= 0.0)) g = gn;
+    }
+  }
+  return g;
+}
+
+// Box-Muller on two 32-bit draws; replaces newran's table-rejection Normal (newran2.cxx:164-217)
+// behind gaussian_dist_product::drawSample (probability_function.cc:37-47).
+__device__ __forceinline__ void boxmuller(uint32_t k1, uint32_t k2, double& z0, double& z1) {
+  const double r = dsqrt(-2.0 * dlog(u01(k1)));
+  const uint32_t q = k2 >> 29;
+  uint32_t m = k2 & 0x1FFFFFFFu;
+  if (q & 1u) m ^= 0x1FFFFFFFu;
+  const double phi = ((double)m + 0.5) * 1.4629180792671596e-09;  // (pi/4) * 2^-29
+  double sn = sin_k(phi), cs = cos_k(phi);
+  if (((q + 1u) >> 1) & 1u) { const double t = sn; sn = cs; cs = t; }
+  if (((q + 2u) >> 2) & 1u) cs = -cs;
+  if (q >> 2) sn = -sn;
+  z0 = r * cs;
+  z1 = r * sn;
+}
+
+// fmod restated for the boundary wrap (states.cc:24,39): exact for |x/w| < 2^52
+__device__ __forceinline__ double fmod_det(double x, double w) {
+  const double q = __builtin_trunc(x / w);
+  double r = __builtin_fma(-q, w, x);
+  if (x >= 0.0) { if (r < 0.0) r += w; else if (r >= w) r -= w; }
+  else          { if (r > 0.0) r -= w; else if (r <= -w) r += w; }
+  return r;
+}
+
+}  // namespace ptm

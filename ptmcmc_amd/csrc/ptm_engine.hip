@@ -1,0 +1,748 @@
+// ptm_engine.hip -- host side of the C ABI declared in include/ptm_engine.h.
+//
+// Thin by design: it owns device memory, packs the problem description the way the kernels want it,
+// and enqueues kernels on one HIP stream.  No algorithmic work happens on the host; there is no CPU
+// fallback -- without a gfx950 device every entry point that computes returns PTM_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/ptm_engine.h"
+#include "ptm_kernels.hpp"
+
+using namespace ptm;
+
+static thread_local std::string g_err;
+static int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+#define HIPCHK(x)                                                                                         \
+  do {                                                                                                    \
+    hipError_t _e = (x);                                                                                  \
+    if (_e != hipSuccess) return fail(PTM_ERR_HIP, "%s failed: %s (%s:%d)", #x, hipGetErrorString(_e), __FILE__, __LINE__); \
+  } while (0)
+
+struct ptm_engine {
+  ptm_config cfg;
+  int D = 0, DP = 0, Nt = 0, r0 = 0, nloc = 0, W = 0, Nc = 0, ms = 0;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  uint64_t step = 0;
+  int cur = 0;
+  // device state
+  double *x[2] = {nullptr, nullptr}, *ll[2] = {nullptr, nullptr}, *lp[2] = {nullptr, nullptr};
+  int *ntries = nullptr, *naccept = nullptr, *last_type = nullptr, *src = nullptr, *err = nullptr;
+  long long *nhist = nullptr, *nsize = nullptr, *swap_try = nullptr, *swap_acc = nullptr;
+  unsigned char* touch = nullptr;
+  int *last_pairs = nullptr, *last_acc = nullptr;
+  // device problem description
+  int *blo = nullptr, *bhi = nullptr, *ptype = nullptr;
+  double *bmin = nullptr, *bmax = nullptr, *plo = nullptr, *phi = nullptr, *pcoef = nullptr;
+  double *P2 = nullptr, *mean = nullptr, *beta = nullptr, *prop = nullptr, *onedfrac = nullptr;
+  // host copies / flags
+  int has_bounds = 0, origin_valid = 1, all_uniform = 1, has_mean = 0, have_target = 0, have_ladder = 0,
+      have_prop = 0, have_state = 0, prop_kind = KIND_DIAG, prop_stride = 0, any_oned = 0;
+  double lprior_const = 0, like0 = 0, thresh = 0;
+  std::vector<double> h_beta;
+  std::vector<int> h_ptype;
+  std::vector<double> h_plo, h_phi;
+  ptm_loglike_batch_fn cb = nullptr;
+  void* cb_user = nullptr;
+  // timing
+  hipEvent_t t0 = nullptr, t1 = nullptr;
+  std::vector<hipEvent_t> kev;  // pairs
+  size_t kev_used = 0;
+  std::string kname;
+};
+
+static int round_dp(int D) {
+  if (D <= 4) return 4;
+  if (D <= 8) return 8;
+  if (D <= 16) return 16;
+  if (D <= 32) return 32;
+  return 64;
+}
+
+template <class T>
+static int dalloc(T** p, size_t n) {
+  HIPCHK(hipMalloc((void**)p, (n ? n : 1) * sizeof(T)));
+  return PTM_OK;
+}
+template <class T>
+static int upload(T* d, const T* h, size_t n, hipStream_t s) {
+  HIPCHK(hipMemcpyAsync(d, h, n * sizeof(T), hipMemcpyHostToDevice, s));
+  HIPCHK(hipStreamSynchronize(s));
+  return PTM_OK;
+}
+
+extern "C" const char* ptm_last_error(void) { return g_err.c_str(); }
+extern "C" int ptm_abi_version(void) { return PTM_ABI_VERSION; }
+
+extern "C" int ptm_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  int ok = 0;
+  for (int i = 0; i < n; ++i) {
+    hipDeviceProp_t pr;
+    if (hipGetDeviceProperties(&pr, i) == hipSuccess && strncmp(pr.gcnArchName, "gfx950", 6) == 0) ok++;
+  }
+  return ok;
+}
+
+static int need_device() {
+  if (ptm_device_count() <= 0)
+    return fail(PTM_ERR_NO_DEVICE, "no gfx950 (MI355X) device visible: the engine has no CPU fallback");
+  return PTM_OK;
+}
+
+extern "C" int ptm_engine_create(const ptm_config* cfg, ptm_engine** out) {
+  if (!cfg || !out) return fail(PTM_ERR_INVALID, "null argument");
+  if (cfg->struct_size != sizeof(ptm_config)) return fail(PTM_ERR_INVALID, "ptm_config size mismatch (ABI)");
+  if (cfg->dim < 1 || cfg->dim > 64) return fail(PTM_ERR_INVALID, "dim must be in 1..64");
+  if (cfg->n_rungs < 1 || cfg->n_rungs > 65535) return fail(PTM_ERR_INVALID, "n_rungs must be in 1..65535");
+  if (cfg->rung_begin < 0 || cfg->rung_count < 1 || cfg->rung_begin + cfg->rung_count > cfg->n_rungs)
+    return fail(PTM_ERR_INVALID, "rung block out of range");
+  if (cfg->n_walkers < 1) return fail(PTM_ERR_INVALID, "n_walkers must be >= 1");
+  if (cfg->add_every_n < 1) return fail(PTM_ERR_INVALID, "add_every_n must be >= 1");
+  if ((double)cfg->rung_count * cfg->n_walkers > 2.0e9) return fail(PTM_ERR_INVALID, "too many chains for one engine");
+  if ((double)cfg->n_rungs * cfg->n_walkers > 4.0e9) return fail(PTM_ERR_INVALID, "too many chains for 32-bit stream ids");
+  int rc = need_device();
+  if (rc) return rc;
+  ptm_engine* e = new ptm_engine();
+  e->cfg = *cfg;
+  e->D = cfg->dim; e->DP = round_dp(cfg->dim); e->Nt = cfg->n_rungs; e->r0 = cfg->rung_begin; e->nloc = cfg->rung_count;
+  e->W = cfg->n_walkers; e->Nc = e->nloc * e->W;
+  e->ms = (int)(1 + 2 * cfg->swap_rate * cfg->n_rungs);                      // chain.cc:1192
+  e->thresh = (e->Nt - 1) * cfg->swap_rate / e->ms;                          // chain.cc:1413
+  if (cfg->device >= 0) { HIPCHK(hipSetDevice(cfg->device)); e->device = cfg->device; } else HIPCHK(hipGetDevice(&e->device));
+  if (cfg->stream) e->stream = (hipStream_t)cfg->stream;
+  else { HIPCHK(hipStreamCreate(&e->stream)); e->own_stream = true; }
+  const size_t Nc = e->Nc, D = e->D;
+  for (int b = 0; b < 2; ++b) {
+    if ((rc = dalloc(&e->x[b], Nc * D))) return rc;
+    if ((rc = dalloc(&e->ll[b], Nc))) return rc;
+    if ((rc = dalloc(&e->lp[b], Nc))) return rc;
+  }
+  if ((rc = dalloc(&e->ntries, Nc)) || (rc = dalloc(&e->naccept, Nc)) || (rc = dalloc(&e->last_type, Nc)) ||
+      (rc = dalloc(&e->src, Nc)) || (rc = dalloc(&e->touch, Nc)) || (rc = dalloc(&e->nhist, Nc)) ||
+      (rc = dalloc(&e->nsize, Nc)) || (rc = dalloc(&e->err, 4)))
+    return rc;
+  const size_t np = (size_t)e->W * (e->Nt > 1 ? e->Nt - 1 : 1);
+  if ((rc = dalloc(&e->swap_try, np)) || (rc = dalloc(&e->swap_acc, np)) || (rc = dalloc(&e->last_pairs, (size_t)e->W * e->ms)) ||
+      (rc = dalloc(&e->last_acc, (size_t)e->W * e->ms)))
+    return rc;
+  HIPCHK(hipMemsetAsync(e->swap_try, 0, np * 8, e->stream));
+  HIPCHK(hipMemsetAsync(e->swap_acc, 0, np * 8, e->stream));
+  HIPCHK(hipMemsetAsync(e->last_pairs, 0xFF, (size_t)e->W * e->ms * 4, e->stream));
+  HIPCHK(hipMemsetAsync(e->last_acc, 0, (size_t)e->W * e->ms * 4, e->stream));
+  HIPCHK(hipMemsetAsync(e->err, 0, 16, e->stream));
+  if ((rc = dalloc(&e->blo, D)) || (rc = dalloc(&e->bhi, D)) || (rc = dalloc(&e->ptype, D)) || (rc = dalloc(&e->bmin, D)) ||
+      (rc = dalloc(&e->bmax, D)) || (rc = dalloc(&e->plo, D)) || (rc = dalloc(&e->phi, D)) || (rc = dalloc(&e->pcoef, D)) ||
+      (rc = dalloc(&e->P2, D * (D + 1) / 2)) || (rc = dalloc(&e->mean, D)) || (rc = dalloc(&e->beta, (size_t)e->Nt)) ||
+      (rc = dalloc(&e->onedfrac, (size_t)e->nloc)))
+    return rc;
+  // defaults: open bounds, flat prior
+  std::vector<int> zi(D, 0);
+  std::vector<double> zd(D, 0.0), one(D, 1.0);
+  if ((rc = upload(e->blo, zi.data(), D, e->stream)) || (rc = upload(e->bhi, zi.data(), D, e->stream)) ||
+      (rc = upload(e->ptype, zi.data(), D, e->stream)) || (rc = upload(e->bmin, zd.data(), D, e->stream)) ||
+      (rc = upload(e->bmax, zd.data(), D, e->stream)) || (rc = upload(e->plo, zd.data(), D, e->stream)) ||
+      (rc = upload(e->phi, zd.data(), D, e->stream)) || (rc = upload(e->pcoef, one.data(), D, e->stream)))
+    return rc;
+  e->h_ptype.assign(D, 0); e->h_plo.assign(D, 0.0); e->h_phi.assign(D, 0.0);
+  e->all_uniform = 0;  // flat prior goes through the general product (pdf == 1)
+  HIPCHK(hipEventCreate(&e->t0));
+  HIPCHK(hipEventCreate(&e->t1));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  *out = e;
+  return PTM_OK;
+}
+
+extern "C" int ptm_engine_destroy(ptm_engine* e) {
+  if (!e) return PTM_OK;
+  (void)hipStreamSynchronize(e->stream);
+  void* ptrs[] = {e->x[0], e->x[1], e->ll[0], e->ll[1], e->lp[0], e->lp[1], e->ntries, e->naccept, e->last_type, e->src,
+                  e->err, e->nhist, e->nsize, e->swap_try, e->swap_acc, e->touch, e->last_pairs, e->last_acc, e->blo,
+                  e->bhi, e->ptype, e->bmin, e->bmax, e->plo, e->phi, e->pcoef, e->P2, e->mean, e->beta, e->prop, e->onedfrac};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  for (hipEvent_t ev : e->kev) (void)hipEventDestroy(ev);
+  if (e->t0) (void)hipEventDestroy(e->t0);
+  if (e->t1) (void)hipEventDestroy(e->t1);
+  if (e->own_stream) (void)hipStreamDestroy(e->stream);
+  delete e;
+  return PTM_OK;
+}
+
+// ---- problem description ----------------------------------------------------------------------------------
+extern "C" int ptm_set_bounds(ptm_engine* e, const int32_t* lo, const int32_t* hi, const double* xmin, const double* xmax) {
+  if (!e || !lo || !hi || !xmin || !xmax) return fail(PTM_ERR_INVALID, "null argument");
+  int rc;
+  const int D = e->D;
+  e->has_bounds = 0;
+  for (int d = 0; d < D; ++d) {
+    if (lo[d] < 0 || lo[d] > 3 || hi[d] < 0 || hi[d] > 3) return fail(PTM_ERR_INVALID, "bad boundary type in dimension %d", d);
+    if (lo[d] != PTM_BOUND_OPEN || hi[d] != PTM_BOUND_OPEN) e->has_bounds = 1;
+  }
+  // Q9: state::add() builds on state(space,n) = enforced zero vector (states.cc:183-192,205-214).  Plain host
+  // arithmetic on D constants; zero is only ever *rejected* by a `limit` bound, any other bound type maps it.
+  e->origin_valid = 1;
+  for (int d = 0; d < D; ++d) {
+    const bool lw = lo[d] == PTM_BOUND_WRAP, hw = hi[d] == PTM_BOUND_WRAP;
+    if (lw != hw) { e->origin_valid = 0; break; }
+    if (lw) { if (xmax[d] - xmin[d] <= 0) { e->origin_valid = 0; break; } continue; }
+    if (lo[d] == PTM_BOUND_REFLECT && hi[d] == PTM_BOUND_REFLECT) { if (xmax[d] - xmin[d] <= 0) { e->origin_valid = 0; break; } continue; }
+    double z = 0.0;
+    if (lo[d] == PTM_BOUND_REFLECT && z < xmin[d]) z = xmin[d] + (xmin[d] - z);
+    else if (hi[d] == PTM_BOUND_REFLECT && z > xmax[d]) z = xmax[d] - (z - xmax[d]);
+    if (lo[d] == PTM_BOUND_LIMIT && z < xmin[d]) { e->origin_valid = 0; break; }
+    if (hi[d] == PTM_BOUND_LIMIT && z > xmax[d]) { e->origin_valid = 0; break; }
+  }
+  if ((rc = upload(e->blo, lo, D, e->stream)) || (rc = upload(e->bhi, hi, D, e->stream)) ||
+      (rc = upload(e->bmin, xmin, D, e->stream)) || (rc = upload(e->bmax, xmax, D, e->stream)))
+    return rc;
+  return PTM_OK;
+}
+
+extern "C" int ptm_set_prior(ptm_engine* e, const int32_t* types, const double* c, const double* h) {
+  if (!e || !types || !c || !h) return fail(PTM_ERR_INVALID, "null argument");
+  const int D = e->D;
+  std::vector<double> lo(D), hi(D), coef(D);
+  std::vector<int> ty(D);
+  e->all_uniform = 1;
+  double prod = 1;
+  for (int d = 0; d < D; ++d) {
+    ty[d] = types[d];
+    switch (types[d]) {  // mixed_dist_product ctor (probability_function.cc:232-254) and the 1-D ctors it calls
+      case PTM_PRIOR_FLAT: lo[d] = hi[d] = 0; coef[d] = 1; e->all_uniform = 0; break;
+      case PTM_PRIOR_UNIFORM: lo[d] = c[d] - h[d]; hi[d] = c[d] + h[d]; coef[d] = 1 / (hi[d] - lo[d]); prod *= coef[d]; break;
+      case PTM_PRIOR_GAUSSIAN: lo[d] = c[d]; hi[d] = h[d]; coef[d] = 0; e->all_uniform = 0; break;
+      case PTM_PRIOR_POLAR: {  // UniformPolarDist ctor: clamps only the normalisation (ProbabilityDist.h:181-186)
+        double a = c[d] - h[d], b = c[d] + h[d];
+        lo[d] = a; hi[d] = b;
+        if (a < 0) a = 0;
+        if (b > M_PI) b = M_PI;
+        coef[d] = -std::cos(b) + std::cos(a);
+        e->all_uniform = 0;
+        break;
+      }
+      case PTM_PRIOR_COPOLAR: {  // ProbabilityDist.h:227-232
+        double a = c[d] - h[d], b = c[d] + h[d];
+        lo[d] = a; hi[d] = b;
+        if (a < -M_PI / 2) a = -M_PI / 2;
+        if (b > M_PI / 2) b = M_PI / 2;
+        coef[d] = std::sin(b) - std::sin(a);
+        e->all_uniform = 0;
+        break;
+      }
+      case PTM_PRIOR_LOG:  // probability_function.cc:245-250, ProbabilityDist.h:109-117
+        if (c[d] <= 0 || h[d] <= 1) return fail(PTM_ERR_INVALID, "log prior needs center>0 and halfwidth>1 (dimension %d)", d);
+        lo[d] = c[d] / h[d]; hi[d] = c[d] * h[d]; coef[d] = std::log(hi[d]) - std::log(lo[d]);
+        e->all_uniform = 0;
+        break;
+      default: return fail(PTM_ERR_INVALID, "unknown prior type %d in dimension %d", types[d], d);
+    }
+  }
+  e->lprior_const = std::log(prod);  // the reference takes libm log of the product of these constants on every call
+  e->h_ptype = ty; e->h_plo = lo; e->h_phi = hi;
+  int rc;
+  if ((rc = upload(e->ptype, ty.data(), D, e->stream)) || (rc = upload(e->plo, lo.data(), D, e->stream)) ||
+      (rc = upload(e->phi, hi.data(), D, e->stream)) || (rc = upload(e->pcoef, coef.data(), D, e->stream)))
+    return rc;
+  return PTM_OK;
+}
+
+extern "C" int ptm_set_target_gaussian(ptm_engine* e, const double* mean, const double* P, double like0) {
+  if (!e || !P) return fail(PTM_ERR_INVALID, "null argument");
+  const int D = e->D;
+  std::vector<double> packed((size_t)D * (D + 1) / 2);
+  size_t o = 0;
+  for (int i = 0; i < D; ++i) {
+    for (int j = 0; j < i; ++j) packed[o++] = P[i * D + j] + P[j * D + i];
+    packed[o++] = P[i * D + i];
+  }
+  int rc;
+  if ((rc = upload(e->P2, packed.data(), packed.size(), e->stream))) return rc;
+  e->has_mean = mean ? 1 : 0;
+  if (mean && (rc = upload(e->mean, mean, D, e->stream))) return rc;
+  e->like0 = like0;
+  e->have_target = 1;
+  e->cb = nullptr;
+  return PTM_OK;
+}
+
+extern "C" int ptm_set_target_callback(ptm_engine* e, ptm_loglike_batch_fn fn, void* user) {
+  if (!e || !fn) return fail(PTM_ERR_INVALID, "null argument");
+  e->cb = fn; e->cb_user = user;
+  return fail(PTM_ERR_UNSUPPORTED, "host-callback likelihood path is not built yet (DESIGN.md: config C5)");
+}
+
+extern "C" int ptm_set_ladder(ptm_engine* e, const double* beta) {
+  if (!e || !beta) return fail(PTM_ERR_INVALID, "null argument");
+  e->h_beta.assign(beta, beta + e->Nt);
+  int rc = upload(e->beta, beta, (size_t)e->Nt, e->stream);
+  if (rc) return rc;
+  e->have_ladder = 1;
+  return PTM_OK;
+}
+
+extern "C" int ptm_set_proposals(ptm_engine* e, int kind, const double* factors, const double* one_d_frac) {
+  if (!e || !factors) return fail(PTM_ERR_INVALID, "null argument");
+  const int D = e->D, DP = e->DP, nloc = e->nloc;
+  int stride;
+  std::vector<double> packed;
+  if (kind == PTM_PROP_DIAG) {
+    stride = DP;
+    packed.assign((size_t)nloc * stride, 0.0);
+    for (int r = 0; r < nloc; ++r)
+      for (int d = 0; d < D; ++d) packed[(size_t)r * stride + d] = factors[(size_t)r * D + d];
+  } else if (kind == PTM_PROP_DENSE) {
+    stride = DP * DP;  // column-major, padded: element (i,j) at j*DP + i
+    packed.assign((size_t)nloc * stride, 0.0);
+    for (int r = 0; r < nloc; ++r)
+      for (int i = 0; i < D; ++i)
+        for (int j = 0; j < D; ++j) packed[(size_t)r * stride + (size_t)j * DP + i] = factors[(size_t)r * D * D + (size_t)i * D + j];
+  } else if (kind == PTM_PROP_LOWER) {
+    stride = DP * (DP + 1) / 2;  // packed columns: column j holds rows j..DP-1 at offset j*DP - j(j-1)/2
+    packed.assign((size_t)nloc * stride, 0.0);
+    for (int r = 0; r < nloc; ++r)
+      for (int j = 0; j < D; ++j)
+        for (int i = j; i < D; ++i)
+          packed[(size_t)r * stride + (size_t)(j * DP - (j * (j - 1)) / 2) + (i - j)] = factors[(size_t)r * D * D + (size_t)i * D + j];
+    for (int r = 0; r < nloc; ++r)
+      for (int i = 0; i < D; ++i)
+        for (int j = i + 1; j < D; ++j)
+          if (factors[(size_t)r * D * D + (size_t)i * D + j] != 0.0)
+            return fail(PTM_ERR_INVALID, "PTM_PROP_LOWER factor of local rung %d has a non-zero above the diagonal", r);
+  } else {
+    return fail(PTM_ERR_INVALID, "unknown proposal kind %d", kind);
+  }
+  if (e->prop) { HIPCHK(hipStreamSynchronize(e->stream)); HIPCHK(hipFree(e->prop)); e->prop = nullptr; }
+  int rc;
+  if ((rc = dalloc(&e->prop, packed.size())) || (rc = upload(e->prop, packed.data(), packed.size(), e->stream))) return rc;
+  std::vector<double> f(nloc, 0.0);
+  e->any_oned = 0;
+  if (one_d_frac)
+    for (int r = 0; r < nloc; ++r) {
+      if (one_d_frac[r] < 0 || one_d_frac[r] > 1) return fail(PTM_ERR_INVALID, "oneDfrac must be in [0,1]");  // hh:159-162
+      f[r] = one_d_frac[r];
+      if (f[r] > 0) e->any_oned = 1;
+    }
+  if ((rc = upload(e->onedfrac, f.data(), (size_t)nloc, e->stream))) return rc;
+  e->prop_kind = kind; e->prop_stride = stride; e->have_prop = 1;
+  return PTM_OK;
+}
+
+// ---- kernel argument block ----------------------------------------------------------------------------------
+static Dev make_dev(ptm_engine* e) {
+  Dev p;
+  memset(&p, 0, sizeof p);
+  p.D = e->D; p.Nt = e->Nt; p.r0 = e->r0; p.nloc = e->nloc; p.W = e->W; p.Nc = e->Nc;
+  p.seed = e->cfg.seed; p.step = e->step; p.add_every_n = e->cfg.add_every_n; p.min_prior = e->cfg.min_prior;
+  p.has_bounds = e->has_bounds; p.origin_valid = e->origin_valid;
+  p.blo = e->blo; p.bhi = e->bhi; p.bmin = e->bmin; p.bmax = e->bmax;
+  p.all_uniform = e->all_uniform; p.lprior_const = e->lprior_const;
+  p.ptype = e->ptype; p.plo = e->plo; p.phi = e->phi; p.pcoef = e->pcoef;
+  p.P2 = e->P2; p.mean = e->mean; p.has_mean = e->has_mean; p.like0 = e->like0;
+  p.beta = e->beta; p.prop = e->prop; p.onedfrac = e->onedfrac; p.prop_stride = e->prop_stride; p.any_oned = e->any_oned;
+  const int in = e->cur, out = 1 - e->cur;
+  p.x_in = e->x[in]; p.x_out = e->x[out]; p.ll_in = e->ll[in]; p.ll_out = e->ll[out]; p.lp_in = e->lp[in]; p.lp_out = e->lp[out];
+  p.ntries = e->ntries; p.naccept = e->naccept; p.last_type = e->last_type; p.nhist = e->nhist; p.nsize = e->nsize;
+  p.src = e->src; p.touch = e->touch; p.err = e->err;
+  return p;
+}
+
+template <int DP>
+static void launch_sweep_dp(ptm_engine* e, const Dev& p, bool uni) {
+  const dim3 grid((e->Nc + 255) / 256), block(256);
+  switch (e->prop_kind) {
+    case PTM_PROP_DIAG:
+      if (uni) hipLaunchKernelGGL((sweep_kernel<DP, KIND_DIAG, true>), grid, block, 0, e->stream, p);
+      else hipLaunchKernelGGL((sweep_kernel<DP, KIND_DIAG, false>), grid, block, 0, e->stream, p);
+      break;
+    case PTM_PROP_LOWER:
+      if (uni) hipLaunchKernelGGL((sweep_kernel<DP, KIND_LOWER, true>), grid, block, 0, e->stream, p);
+      else hipLaunchKernelGGL((sweep_kernel<DP, KIND_LOWER, false>), grid, block, 0, e->stream, p);
+      break;
+    default:
+      if (uni) hipLaunchKernelGGL((sweep_kernel<DP, KIND_DENSE, true>), grid, block, 0, e->stream, p);
+      else hipLaunchKernelGGL((sweep_kernel<DP, KIND_DENSE, false>), grid, block, 0, e->stream, p);
+  }
+}
+
+static int launch_sweep(ptm_engine* e, const double* recv_below, const double* recv_above) {
+  Dev p = make_dev(e);
+  p.recv_below = recv_below; p.recv_above = recv_above;
+  const bool uni = (e->W % 64) == 0;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  if (e->cfg.time_kernels) {
+    if (e->kev_used + 2 > e->kev.size()) {
+      for (int k = 0; k < 2; ++k) { hipEvent_t ev; HIPCHK(hipEventCreate(&ev)); e->kev.push_back(ev); }
+    }
+    ev0 = e->kev[e->kev_used]; ev1 = e->kev[e->kev_used + 1];
+    e->kev_used += 2;
+    HIPCHK(hipEventRecord(ev0, e->stream));
+  }
+  switch (e->DP) {
+    case 4: launch_sweep_dp<4>(e, p, uni); break;
+    case 8: launch_sweep_dp<8>(e, p, uni); break;
+    case 16: launch_sweep_dp<16>(e, p, uni); break;
+    case 32: launch_sweep_dp<32>(e, p, uni); break;
+    default: return fail(PTM_ERR_UNSUPPORTED, "dim > 32 is not built in this round");
+  }
+  HIPCHK(hipGetLastError());
+  if (ev1) HIPCHK(hipEventRecord(ev1, e->stream));
+  e->cur = 1 - e->cur;
+  e->step += 1;
+  return PTM_OK;
+}
+
+static size_t decide_lds_bytes(int Nt, int ms) {
+  const size_t msp = (size_t)((ms + 1) & ~1);
+  return (size_t)Nt * 8 + msp * 4 * 3 + (size_t)((Nt + 3) & ~3) * 2 + (size_t)((Nt + 7) & ~7) + (size_t)((Nt + 1 + 7) & ~7) + 16;
+}
+
+static int launch_decide(ptm_engine* e, const double* llg, double* send_up, double* send_down) {
+  Decide p;
+  memset(&p, 0, sizeof p);
+  p.D = e->D; p.Nt = e->Nt; p.r0 = e->r0; p.nloc = e->nloc; p.W = e->W; p.Nc = e->Nc; p.ms = e->ms;
+  p.seed = e->cfg.seed; p.step = e->step; p.thresh = e->thresh;
+  p.beta = e->beta; p.llg = llg; p.x_in = e->x[e->cur]; p.ll_in = e->ll[e->cur]; p.lp_in = e->lp[e->cur];
+  p.src = e->src; p.touch = e->touch; p.swap_try = e->swap_try; p.swap_acc = e->swap_acc;
+  p.last_pairs = e->last_pairs; p.last_acc = e->last_acc; p.send_up = send_up; p.send_down = send_down; p.err = e->err;
+  const size_t lds = decide_lds_bytes(e->Nt, e->ms);
+  if (lds > 160 * 1024) return fail(PTM_ERR_UNSUPPORTED, "ladder too long for the LDS-resident exchange kernel (%zu B)", lds);
+  if (lds > 64 * 1024)
+    HIPCHK(hipFuncSetAttribute((const void*)decide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(decide_kernel, dim3(e->W), dim3(64), lds, e->stream, p);
+  HIPCHK(hipGetLastError());
+  return PTM_OK;
+}
+
+static int ready(ptm_engine* e) {
+  if (!e) return fail(PTM_ERR_INVALID, "null engine");
+  if (!e->have_target) return fail(PTM_ERR_INVALID, "no target set (ptm_set_target_gaussian)");
+  if (!e->have_ladder) return fail(PTM_ERR_INVALID, "no ladder set (ptm_set_ladder)");
+  if (!e->have_prop) return fail(PTM_ERR_INVALID, "no proposals set (ptm_set_proposals)");
+  if (!e->have_state) return fail(PTM_ERR_INVALID, "no states set (ptm_set_states / ptm_init_from_prior)");
+  return PTM_OK;
+}
+
+// ---- state ------------------------------------------------------------------------------------------------------
+static int reset_counters(ptm_engine* e) {
+  const size_t Nc = e->Nc;
+  std::vector<int> one(Nc, 1), m1(Nc, -1), ident(Nc);
+  std::vector<long long> z(Nc, 0), o(Nc, 1);
+  for (size_t c = 0; c < Nc; ++c) ident[c] = (int)c;
+  int rc;
+  if ((rc = upload(e->ntries, one.data(), Nc, e->stream)) || (rc = upload(e->naccept, one.data(), Nc, e->stream)) ||  // chain.cc:649
+      (rc = upload(e->last_type, m1.data(), Nc, e->stream)) || (rc = upload(e->src, ident.data(), Nc, e->stream)) ||
+      (rc = upload(e->nhist, z.data(), Nc, e->stream)) || (rc = upload(e->nsize, o.data(), Nc, e->stream)))        // chain.cc:871-875
+    return rc;
+  HIPCHK(hipMemsetAsync(e->touch, 0, Nc, e->stream));
+  e->step = 0;
+  return PTM_OK;
+}
+
+template <int DP>
+static void launch_eval(ptm_engine* e, const Dev& p, int n, double* x, int* valid, double* lp, double* ll, int eval_like) {
+  hipLaunchKernelGGL((evaluate_kernel<DP>), dim3((n + 255) / 256), dim3(256), 0, e->stream, p, n, x, valid, lp, ll, eval_like);
+}
+static int run_eval(ptm_engine* e, int n, double* x, int* valid, double* lp, double* ll, int eval_like) {
+  Dev p = make_dev(e);
+  switch (e->DP) {
+    case 4: launch_eval<4>(e, p, n, x, valid, lp, ll, eval_like); break;
+    case 8: launch_eval<8>(e, p, n, x, valid, lp, ll, eval_like); break;
+    case 16: launch_eval<16>(e, p, n, x, valid, lp, ll, eval_like); break;
+    case 32: launch_eval<32>(e, p, n, x, valid, lp, ll, eval_like); break;
+    default: return fail(PTM_ERR_UNSUPPORTED, "dim > 32 is not built in this round");
+  }
+  HIPCHK(hipGetLastError());
+  return PTM_OK;
+}
+
+extern "C" int ptm_set_states(ptm_engine* e, const double* X, const double* llike) {
+  if (!e || !X) return fail(PTM_ERR_INVALID, "null argument");
+  if (!e->have_target && !llike) return fail(PTM_ERR_INVALID, "set the target first (or pass llike)");
+  const size_t Nc = e->Nc, D = e->D;
+  std::vector<double> soa(Nc * D);
+  for (size_t c = 0; c < Nc; ++c)
+    for (size_t d = 0; d < D; ++d) soa[d * Nc + c] = X[c * D + d];
+  int rc;
+  e->cur = 0;
+  if ((rc = upload(e->x[0], soa.data(), Nc * D, e->stream))) return rc;
+  if (llike && (rc = upload(e->ll[0], llike, Nc, e->stream))) return rc;
+  if ((rc = run_eval(e, (int)Nc, e->x[0], nullptr, e->lp[0], e->ll[0], llike ? 0 : 1))) return rc;
+  if ((rc = reset_counters(e))) return rc;
+  HIPCHK(hipStreamSynchronize(e->stream));
+  e->have_state = 1;
+  return PTM_OK;
+}
+
+template <int DP>
+static void launch_init(ptm_engine* e, const Dev& p, int* failflag) {
+  hipLaunchKernelGGL((init_prior_kernel<DP>), dim3((e->Nc + 255) / 256), dim3(256), 0, e->stream, p, e->x[0], e->ll[0], e->lp[0], failflag);
+}
+extern "C" int ptm_init_from_prior(ptm_engine* e) {
+  if (!e) return fail(PTM_ERR_INVALID, "null engine");
+  if (!e->have_target) return fail(PTM_ERR_INVALID, "set the target first");
+  for (int d = 0; d < e->D; ++d)
+    if (e->h_ptype[d] != PTM_PRIOR_UNIFORM && e->h_ptype[d] != PTM_PRIOR_GAUSSIAN)
+      return fail(PTM_ERR_UNSUPPORTED, "device prior draws exist for uniform/gaussian dimensions only (dimension %d)", d);
+  e->cur = 0;
+  Dev p = make_dev(e);
+  HIPCHK(hipMemsetAsync(e->err + 1, 0, 4, e->stream));
+  switch (e->DP) {
+    case 4: launch_init<4>(e, p, e->err + 1); break;
+    case 8: launch_init<8>(e, p, e->err + 1); break;
+    case 16: launch_init<16>(e, p, e->err + 1); break;
+    case 32: launch_init<32>(e, p, e->err + 1); break;
+    default: return fail(PTM_ERR_UNSUPPORTED, "dim > 32 is not built in this round");
+  }
+  HIPCHK(hipGetLastError());
+  int rc = reset_counters(e);
+  if (rc) return rc;
+  int flag = 0;
+  HIPCHK(hipMemcpy(&flag, e->err + 1, 4, hipMemcpyDeviceToHost));
+  if (flag) return fail(PTM_ERR_INVALID, "could not draw a valid start state from the prior for some chain");
+  e->have_state = 1;
+  return PTM_OK;
+}
+
+// ---- hot path ----------------------------------------------------------------------------------------------------
+extern "C" int ptm_sweep(ptm_engine* e, int n) {
+  int rc = ready(e);
+  if (rc) return rc;
+  for (int k = 0; k < n; ++k)
+    if ((rc = launch_sweep(e, nullptr, nullptr))) return rc;
+  return PTM_OK;
+}
+
+extern "C" int ptm_step(ptm_engine* e, int n) {
+  int rc = ready(e);
+  if (rc) return rc;
+  if (e->nloc != e->Nt) return fail(PTM_ERR_INVALID, "ptm_step needs the whole ladder on this engine; sharded engines use ptm_exchange_*");
+  for (int k = 0; k < n; ++k) {
+    if (e->Nt > 1 && (rc = launch_decide(e, e->ll[e->cur], nullptr, nullptr))) return rc;
+    if ((rc = launch_sweep(e, nullptr, nullptr))) return rc;
+  }
+  return PTM_OK;
+}
+
+extern "C" int ptm_sync(ptm_engine* e) {
+  if (!e) return fail(PTM_ERR_INVALID, "null engine");
+  HIPCHK(hipStreamSynchronize(e->stream));
+  int flag = 0;
+  HIPCHK(hipMemcpy(&flag, e->err, 4, hipMemcpyDeviceToHost));
+  if (flag) return fail(PTM_ERR_FAR_MOVE, "a state crossed more than one shard boundary in one step (neighbour exchange mode)");
+  return PTM_OK;
+}
+
+extern "C" int ptm_llike_device_ptr(ptm_engine* e, void** p) {
+  if (!e || !p) return fail(PTM_ERR_INVALID, "null argument");
+  *p = e->ll[e->cur];
+  return PTM_OK;
+}
+
+extern "C" int ptm_exchange_decide(ptm_engine* e, const void* llg, void* send_up, void* send_down) {
+  int rc = ready(e);
+  if (rc) return rc;
+  if (!llg) return fail(PTM_ERR_INVALID, "null llike_global");
+  if (e->Nt > 1) return launch_decide(e, (const double*)llg, (double*)send_up, (double*)send_down);
+  return PTM_OK;
+}
+
+extern "C" int ptm_exchange_finish_and_sweep(ptm_engine* e, const void* recv_below, const void* recv_above) {
+  int rc = ready(e);
+  if (rc) return rc;
+  return launch_sweep(e, (const double*)recv_below, (const double*)recv_above);
+}
+
+// ---- read-back ------------------------------------------------------------------------------------------------------
+extern "C" int ptm_get_states(ptm_engine* e, double* X) {
+  if (!e || !X) return fail(PTM_ERR_INVALID, "null argument");
+  const size_t Nc = e->Nc, D = e->D;
+  std::vector<double> soa(Nc * D);
+  HIPCHK(hipStreamSynchronize(e->stream));
+  HIPCHK(hipMemcpy(soa.data(), e->x[e->cur], Nc * D * 8, hipMemcpyDeviceToHost));
+  for (size_t c = 0; c < Nc; ++c)
+    for (size_t d = 0; d < D; ++d) X[c * D + d] = soa[d * Nc + c];
+  return PTM_OK;
+}
+
+extern "C" int ptm_get_array(ptm_engine* e, int which, void* out) {
+  if (!e || !out) return fail(PTM_ERR_INVALID, "null argument");
+  const size_t Nc = e->Nc;
+  HIPCHK(hipStreamSynchronize(e->stream));
+  switch (which) {
+    case PTM_ARR_LLIKE: HIPCHK(hipMemcpy(out, e->ll[e->cur], Nc * 8, hipMemcpyDeviceToHost)); break;
+    case PTM_ARR_LPRIOR: HIPCHK(hipMemcpy(out, e->lp[e->cur], Nc * 8, hipMemcpyDeviceToHost)); break;
+    case PTM_ARR_LPOST: {
+      if (!e->have_ladder) return fail(PTM_ERR_INVALID, "no ladder set");
+      std::vector<double> ll(Nc), lp(Nc);
+      HIPCHK(hipMemcpy(ll.data(), e->ll[e->cur], Nc * 8, hipMemcpyDeviceToHost));
+      HIPCHK(hipMemcpy(lp.data(), e->lp[e->cur], Nc * 8, hipMemcpyDeviceToHost));
+      double* o = (double*)out;
+      for (size_t c = 0; c < Nc; ++c) {
+        volatile double t = e->h_beta[e->r0 + c / e->W] * ll[c];  // product rounded before the sum (chain.cc:928)
+        o[c] = lp[c] + t;
+      }
+      break;
+    }
+    case PTM_ARR_NTRIES: HIPCHK(hipMemcpy(out, e->ntries, Nc * 4, hipMemcpyDeviceToHost)); break;
+    case PTM_ARR_NACCEPT: HIPCHK(hipMemcpy(out, e->naccept, Nc * 4, hipMemcpyDeviceToHost)); break;
+    case PTM_ARR_LAST_TYPE: HIPCHK(hipMemcpy(out, e->last_type, Nc * 4, hipMemcpyDeviceToHost)); break;
+    case PTM_ARR_NHIST: HIPCHK(hipMemcpy(out, e->nhist, Nc * 8, hipMemcpyDeviceToHost)); break;
+    case PTM_ARR_NSIZE: HIPCHK(hipMemcpy(out, e->nsize, Nc * 8, hipMemcpyDeviceToHost)); break;
+    default: return fail(PTM_ERR_INVALID, "unknown array id %d", which);
+  }
+  return PTM_OK;
+}
+
+extern "C" int ptm_get_swap_counts(ptm_engine* e, int64_t* tries, int64_t* accepts) {
+  if (!e) return fail(PTM_ERR_INVALID, "null engine");
+  const size_t np = (size_t)e->W * (e->Nt > 1 ? e->Nt - 1 : 1);
+  HIPCHK(hipStreamSynchronize(e->stream));
+  if (tries) HIPCHK(hipMemcpy(tries, e->swap_try, np * 8, hipMemcpyDeviceToHost));
+  if (accepts) HIPCHK(hipMemcpy(accepts, e->swap_acc, np * 8, hipMemcpyDeviceToHost));
+  return PTM_OK;
+}
+
+extern "C" int ptm_get_last_swaps(ptm_engine* e, int32_t* pairs, int32_t* accepted) {
+  if (!e) return fail(PTM_ERR_INVALID, "null engine");
+  const size_t n = (size_t)e->W * e->ms;
+  HIPCHK(hipStreamSynchronize(e->stream));
+  if (pairs) HIPCHK(hipMemcpy(pairs, e->last_pairs, n * 4, hipMemcpyDeviceToHost));
+  if (accepted) HIPCHK(hipMemcpy(accepted, e->last_acc, n * 4, hipMemcpyDeviceToHost));
+  return PTM_OK;
+}
+
+extern "C" int ptm_max_swaps_per_step(ptm_engine* e) { return e ? e->ms : 0; }
+extern "C" uint64_t ptm_step_count(ptm_engine* e) { return e ? e->step : 0; }
+
+// ---- measurement ------------------------------------------------------------------------------------------------------
+extern "C" int ptm_timer_start(ptm_engine* e) {
+  if (!e) return fail(PTM_ERR_INVALID, "null engine");
+  HIPCHK(hipEventRecord(e->t0, e->stream));
+  return PTM_OK;
+}
+extern "C" int ptm_timer_stop(ptm_engine* e, float* ms) {
+  if (!e || !ms) return fail(PTM_ERR_INVALID, "null argument");
+  HIPCHK(hipEventRecord(e->t1, e->stream));
+  HIPCHK(hipEventSynchronize(e->t1));
+  HIPCHK(hipEventElapsedTime(ms, e->t0, e->t1));
+  return PTM_OK;
+}
+extern "C" int ptm_get_kernel_times(ptm_engine* e, float* ms, int capacity, int* count) {
+  if (!e || !count) return fail(PTM_ERR_INVALID, "null argument");
+  HIPCHK(hipStreamSynchronize(e->stream));
+  int n = 0;
+  for (size_t k = 0; k + 1 < e->kev_used + 1 && k + 1 < e->kev.size() + 1 && k < e->kev_used; k += 2) {
+    float t = 0;
+    HIPCHK(hipEventElapsedTime(&t, e->kev[k], e->kev[k + 1]));
+    if (ms && n < capacity) ms[n] = t;
+    n++;
+  }
+  *count = n;
+  e->kev_used = 0;
+  return PTM_OK;
+}
+
+extern "C" const char* ptm_sweep_kernel_name(ptm_engine* e) {
+  if (!e) return "";
+  char b[96];
+  const char* k = e->prop_kind == PTM_PROP_DIAG ? "1" : (e->prop_kind == PTM_PROP_LOWER ? "2" : "0");
+  snprintf(b, sizeof b, "sweep_kernel<%d, %s, %s>", e->DP, k, (e->W % 64) == 0 ? "true" : "false");
+  e->kname = b;
+  return e->kname.c_str();
+}
+
+// ---- verification hooks ------------------------------------------------------------------------------------------------
+extern "C" int ptm_debug_eval(int device, int fn, const double* a, const double* b, double* out, int n) {
+  int rc = need_device();
+  if (rc) return rc;
+  if (device >= 0) HIPCHK(hipSetDevice(device));
+  double *da = nullptr, *db = nullptr, *dout = nullptr;
+  HIPCHK(hipMalloc((void**)&da, (size_t)n * 8));
+  HIPCHK(hipMalloc((void**)&db, (size_t)n * 8));
+  HIPCHK(hipMalloc((void**)&dout, (size_t)n * 8));
+  HIPCHK(hipMemcpy(da, a, (size_t)n * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(db, b ? b : a, (size_t)n * 8, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(debug_eval_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, fn, da, db, dout, n);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpy(out, dout, (size_t)n * 8, hipMemcpyDeviceToHost));
+  (void)hipFree(da); (void)hipFree(db); (void)hipFree(dout);
+  return PTM_OK;
+}
+
+extern "C" int ptm_debug_philox(int device, uint64_t seed, int tag, uint32_t stream, uint64_t step, uint32_t block, uint32_t out[4]) {
+  int rc = need_device();
+  if (rc) return rc;
+  if (device >= 0) HIPCHK(hipSetDevice(device));
+  uint32_t* d = nullptr;
+  HIPCHK(hipMalloc((void**)&d, 16));
+  hipLaunchKernelGGL(debug_philox_kernel, dim3(1), dim3(1), 0, 0, seed, tag, stream, step, block, d);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpy(out, d, 16, hipMemcpyDeviceToHost));
+  (void)hipFree(d);
+  return PTM_OK;
+}
+
+extern "C" int ptm_debug_boxmuller(int device, const uint32_t* k1, const uint32_t* k2, double* z0, double* z1, int n) {
+  int rc = need_device();
+  if (rc) return rc;
+  if (device >= 0) HIPCHK(hipSetDevice(device));
+  uint32_t *d1 = nullptr, *d2 = nullptr;
+  double *o0 = nullptr, *o1 = nullptr;
+  HIPCHK(hipMalloc((void**)&d1, (size_t)n * 4));
+  HIPCHK(hipMalloc((void**)&d2, (size_t)n * 4));
+  HIPCHK(hipMalloc((void**)&o0, (size_t)n * 8));
+  HIPCHK(hipMalloc((void**)&o1, (size_t)n * 8));
+  HIPCHK(hipMemcpy(d1, k1, (size_t)n * 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(d2, k2, (size_t)n * 4, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(debug_boxmuller_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, d1, d2, o0, o1, n);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpy(z0, o0, (size_t)n * 8, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(z1, o1, (size_t)n * 8, hipMemcpyDeviceToHost));
+  (void)hipFree(d1); (void)hipFree(d2); (void)hipFree(o0); (void)hipFree(o1);
+  return PTM_OK;
+}
+
+extern "C" int ptm_debug_evaluate(ptm_engine* e, const double* X, int n, int32_t* valid, double* Xe, double* lprior, double* llike) {
+  if (!e || !X || n < 1) return fail(PTM_ERR_INVALID, "bad argument");
+  const size_t D = e->D;
+  std::vector<double> soa((size_t)n * D);
+  for (size_t c = 0; c < (size_t)n; ++c)
+    for (size_t d = 0; d < D; ++d) soa[d * n + c] = X[c * D + d];
+  double *dx = nullptr, *dlp = nullptr, *dll = nullptr;
+  int* dv = nullptr;
+  HIPCHK(hipMalloc((void**)&dx, (size_t)n * D * 8));
+  HIPCHK(hipMalloc((void**)&dlp, (size_t)n * 8));
+  HIPCHK(hipMalloc((void**)&dll, (size_t)n * 8));
+  HIPCHK(hipMalloc((void**)&dv, (size_t)n * 4));
+  HIPCHK(hipMemcpy(dx, soa.data(), (size_t)n * D * 8, hipMemcpyHostToDevice));
+  int rc = run_eval(e, n, dx, dv, dlp, dll, e->have_target ? 1 : 0);
+  if (rc) return rc;
+  HIPCHK(hipStreamSynchronize(e->stream));
+  HIPCHK(hipMemcpy(soa.data(), dx, (size_t)n * D * 8, hipMemcpyDeviceToHost));
+  if (Xe)
+    for (size_t c = 0; c < (size_t)n; ++c)
+      for (size_t d = 0; d < D; ++d) Xe[c * D + d] = soa[d * n + c];
+  if (valid) HIPCHK(hipMemcpy(valid, dv, (size_t)n * 4, hipMemcpyDeviceToHost));
+  if (lprior) HIPCHK(hipMemcpy(lprior, dlp, (size_t)n * 8, hipMemcpyDeviceToHost));
+  if (llike && e->have_target) HIPCHK(hipMemcpy(llike, dll, (size_t)n * 8, hipMemcpyDeviceToHost));
+  (void)hipFree(dx); (void)hipFree(dlp); (void)hipFree(dll); (void)hipFree(dv);
+  return PTM_OK;
+}

@@ -1,0 +1,299 @@
+"""ctypes binding of libptm_engine.so (C ABI: include/ptm_engine.h).
+
+Thin by design: numpy arrays in, numpy arrays out; every call goes straight through the C ABI
+into the HIP engine.  There is no CPU fallback -- without the built library or without an
+MI355X the constructor raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libptm_engine.so")
+
+# enums of include/ptm_engine.h
+BOUND_OPEN, BOUND_LIMIT, BOUND_REFLECT, BOUND_WRAP = 0, 1, 2, 3
+PRIOR_FLAT, PRIOR_UNIFORM, PRIOR_GAUSSIAN, PRIOR_POLAR, PRIOR_COPOLAR, PRIOR_LOG = 0, 1, 2, 3, 4, 5
+PROP_DENSE, PROP_DIAG, PROP_LOWER = 0, 1, 2
+ARR_LLIKE, ARR_LPRIOR, ARR_LPOST, ARR_NTRIES, ARR_NACCEPT, ARR_LAST_TYPE, ARR_NHIST, ARR_NSIZE = range(8)
+FN_LOG, FN_EXP, FN_SIN_0_PI, FN_COS_HPI, FN_SQRT, FN_DIV = range(6)
+PRIOR_NAMES = {"uni": 1, "uniform": 1, "gauss": 2, "gaussian": 2, "pol": 3, "polar": 3, "cpol": 4, "copol": 4, "log": 5}
+
+EXPORTS = [
+    "ptm_last_error", "ptm_abi_version", "ptm_device_count", "ptm_engine_create", "ptm_engine_destroy",
+    "ptm_set_bounds", "ptm_set_prior", "ptm_set_target_gaussian", "ptm_set_target_callback", "ptm_set_ladder",
+    "ptm_set_proposals", "ptm_set_states", "ptm_init_from_prior", "ptm_sweep", "ptm_step", "ptm_sync",
+    "ptm_llike_device_ptr", "ptm_exchange_decide", "ptm_exchange_finish_and_sweep", "ptm_get_states",
+    "ptm_get_array", "ptm_get_swap_counts", "ptm_get_last_swaps", "ptm_max_swaps_per_step", "ptm_step_count",
+    "ptm_timer_start", "ptm_timer_stop", "ptm_get_kernel_times", "ptm_sweep_kernel_name", "ptm_debug_eval",
+    "ptm_debug_philox", "ptm_debug_boxmuller", "ptm_debug_evaluate",
+]
+
+
+class PtmConfig(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("dim", C.c_int32), ("n_rungs", C.c_int32), ("rung_begin", C.c_int32),
+                ("rung_count", C.c_int32), ("n_walkers", C.c_int32), ("seed", C.c_uint64), ("swap_rate", C.c_double),
+                ("add_every_n", C.c_int32), ("min_prior", C.c_double), ("device", C.c_int32), ("stream", C.c_void_p),
+                ("time_kernels", C.c_int32), ("swap_log_steps", C.c_int32)]
+
+
+class PtmError(RuntimeError):
+    pass
+
+
+_lib = None
+_dp = C.POINTER(C.c_double)
+_i32p = C.POINTER(C.c_int32)
+_i64p = C.POINTER(C.c_int64)
+_u32p = C.POINTER(C.c_uint32)
+
+LOGLIKE_BATCH_FN = C.CFUNCTYPE(None, C.c_void_p, _dp, C.c_int, C.c_int, _dp)
+
+
+def load():
+    """dlopen the engine; raises if it has not been built (python __graft_entry__.py build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PtmError("HIP engine not built: %s is missing (run `python -c 'import __graft_entry__ as g; g.build()'`)" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    L.ptm_last_error.restype = C.c_char_p
+    L.ptm_sweep_kernel_name.restype = C.c_char_p
+    L.ptm_sweep_kernel_name.argtypes = [C.c_void_p]
+    L.ptm_step_count.restype = C.c_uint64
+    L.ptm_step_count.argtypes = [C.c_void_p]
+    L.ptm_engine_create.argtypes = [C.POINTER(PtmConfig), C.POINTER(C.c_void_p)]
+    L.ptm_engine_destroy.argtypes = [C.c_void_p]
+    L.ptm_set_bounds.argtypes = [C.c_void_p, _i32p, _i32p, _dp, _dp]
+    L.ptm_set_prior.argtypes = [C.c_void_p, _i32p, _dp, _dp]
+    L.ptm_set_target_gaussian.argtypes = [C.c_void_p, _dp, _dp, C.c_double]
+    L.ptm_set_target_callback.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.ptm_set_ladder.argtypes = [C.c_void_p, _dp]
+    L.ptm_set_proposals.argtypes = [C.c_void_p, C.c_int, _dp, _dp]
+    L.ptm_set_states.argtypes = [C.c_void_p, _dp, _dp]
+    L.ptm_init_from_prior.argtypes = [C.c_void_p]
+    L.ptm_sweep.argtypes = [C.c_void_p, C.c_int]
+    L.ptm_step.argtypes = [C.c_void_p, C.c_int]
+    L.ptm_sync.argtypes = [C.c_void_p]
+    L.ptm_llike_device_ptr.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+    L.ptm_exchange_decide.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.ptm_exchange_finish_and_sweep.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.ptm_get_states.argtypes = [C.c_void_p, _dp]
+    L.ptm_get_array.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    L.ptm_get_swap_counts.argtypes = [C.c_void_p, _i64p, _i64p]
+    L.ptm_get_last_swaps.argtypes = [C.c_void_p, _i32p, _i32p]
+    L.ptm_max_swaps_per_step.argtypes = [C.c_void_p]
+    L.ptm_timer_start.argtypes = [C.c_void_p]
+    L.ptm_timer_stop.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+    L.ptm_get_kernel_times.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_int)]
+    L.ptm_debug_eval.argtypes = [C.c_int, C.c_int, _dp, _dp, _dp, C.c_int]
+    L.ptm_debug_philox.argtypes = [C.c_int, C.c_uint64, C.c_int, C.c_uint32, C.c_uint64, C.c_uint32, _u32p]
+    L.ptm_debug_boxmuller.argtypes = [C.c_int, _u32p, _u32p, _dp, _dp, C.c_int]
+    L.ptm_debug_evaluate.argtypes = [C.c_void_p, _dp, C.c_int, _i32p, _dp, _dp, _dp]
+    _lib = L
+    return L
+
+
+def _chk(rc):
+    if rc != 0:
+        raise PtmError("ptm error %d: %s" % (rc, load().ptm_last_error().decode()))
+
+
+def _d(a):
+    return a.ctypes.data_as(_dp)
+
+
+def device_count():
+    return load().ptm_device_count()
+
+
+def debug_eval(fn, a, b=None, device=-1):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    bb = a if b is None else np.ascontiguousarray(b, dtype=np.float64)
+    out = np.empty_like(a)
+    _chk(load().ptm_debug_eval(device, fn, _d(a), _d(bb), _d(out), a.size))
+    return out
+
+
+def debug_philox(seed, tag, stream, step, block, device=-1):
+    o = (C.c_uint32 * 4)()
+    _chk(load().ptm_debug_philox(device, seed, tag, stream, step, block, o))
+    return [int(v) for v in o]
+
+
+def debug_boxmuller(k1, k2, device=-1):
+    k1 = np.ascontiguousarray(k1, dtype=np.uint32)
+    k2 = np.ascontiguousarray(k2, dtype=np.uint32)
+    z0, z1 = np.empty(k1.size), np.empty(k1.size)
+    _chk(load().ptm_debug_boxmuller(device, k1.ctypes.data_as(_u32p), k2.ctypes.data_as(_u32p), _d(z0), _d(z1), k1.size))
+    return z0, z1
+
+
+def geometric_ladder(n_rungs, tmax):
+    """beta of parallel_tempering_chains' constructor + initialize (chain.cc:1181-1183,1340): host constants."""
+    import math
+    tratio = math.exp(math.log(tmax) / (n_rungs - 1)) if n_rungs > 1 else 1.0
+    t, beta = 1.0, [1.0]
+    for _ in range(1, n_rungs):
+        t = t * tratio
+        beta.append(1 / t)
+    return np.array(beta)
+
+
+class Engine:
+    """One GPU shard of a parallel-tempering ladder: rungs [rung_begin, rung_begin+rung_count) x W walkers."""
+
+    def __init__(self, dim, n_rungs, n_walkers=1, seed=0x5EED0001, swap_rate=0.1, add_every_n=1, min_prior=-30.0,
+                 rung_begin=0, rung_count=None, device=-1, stream=None, time_kernels=False):
+        L = load()
+        cfg = PtmConfig()
+        cfg.struct_size = C.sizeof(PtmConfig)
+        cfg.dim, cfg.n_rungs, cfg.rung_begin = dim, n_rungs, rung_begin
+        cfg.rung_count = n_rungs if rung_count is None else rung_count
+        cfg.n_walkers, cfg.seed, cfg.swap_rate = n_walkers, seed, swap_rate
+        cfg.add_every_n, cfg.min_prior, cfg.device = add_every_n, min_prior, device
+        cfg.stream = stream
+        cfg.time_kernels = 1 if time_kernels else 0
+        cfg.swap_log_steps = 0
+        h = C.c_void_p()
+        _chk(L.ptm_engine_create(C.byref(cfg), C.byref(h)))
+        self.h, self.L = h, L
+        self.D, self.Nt, self.W = dim, n_rungs, n_walkers
+        self.r0, self.nloc = rung_begin, cfg.rung_count
+        self.Nc = self.nloc * n_walkers
+        self._keep = []
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.ptm_engine_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    # -- problem description
+    def set_bounds(self, lo, hi, xmin, xmax):
+        lo = np.ascontiguousarray(lo, dtype=np.int32); hi = np.ascontiguousarray(hi, dtype=np.int32)
+        xmin = np.ascontiguousarray(xmin, dtype=np.float64); xmax = np.ascontiguousarray(xmax, dtype=np.float64)
+        _chk(self.L.ptm_set_bounds(self.h, lo.ctypes.data_as(_i32p), hi.ctypes.data_as(_i32p), _d(xmin), _d(xmax)))
+
+    def set_prior(self, types, centers, halfwidths):
+        t = np.ascontiguousarray([PRIOR_NAMES[v] if isinstance(v, str) else int(v) for v in types], dtype=np.int32)
+        c = np.ascontiguousarray(centers, dtype=np.float64); h = np.ascontiguousarray(halfwidths, dtype=np.float64)
+        _chk(self.L.ptm_set_prior(self.h, t.ctypes.data_as(_i32p), _d(c), _d(h)))
+
+    def set_target_gaussian(self, precision, like0, mean=None):
+        P = np.ascontiguousarray(precision, dtype=np.float64).reshape(self.D, self.D)
+        m = None if mean is None else np.ascontiguousarray(mean, dtype=np.float64)
+        _chk(self.L.ptm_set_target_gaussian(self.h, None if m is None else _d(m), _d(P), like0))
+
+    def set_ladder(self, beta):
+        b = np.ascontiguousarray(beta, dtype=np.float64)
+        assert b.size == self.Nt
+        _chk(self.L.ptm_set_ladder(self.h, _d(b)))
+
+    def set_proposals(self, kind, factors, one_d_frac=None):
+        f = np.ascontiguousarray(factors, dtype=np.float64)
+        per = self.D if kind == PROP_DIAG else self.D * self.D
+        assert f.size == self.nloc * per, (f.size, self.nloc, per)
+        o = None if one_d_frac is None else np.ascontiguousarray(one_d_frac, dtype=np.float64)
+        _chk(self.L.ptm_set_proposals(self.h, kind, _d(f), None if o is None else _d(o)))
+
+    # -- state
+    def set_states(self, X, llike=None):
+        X = np.ascontiguousarray(X, dtype=np.float64).reshape(self.Nc, self.D)
+        ll = None if llike is None else np.ascontiguousarray(llike, dtype=np.float64)
+        _chk(self.L.ptm_set_states(self.h, _d(X), None if ll is None else _d(ll)))
+
+    def init_from_prior(self):
+        _chk(self.L.ptm_init_from_prior(self.h))
+
+    # -- hot path
+    def sweep(self, n=1):
+        _chk(self.L.ptm_sweep(self.h, n))
+
+    def step(self, n=1):
+        _chk(self.L.ptm_step(self.h, n))
+
+    def sync(self):
+        _chk(self.L.ptm_sync(self.h))
+
+    def llike_device_ptr(self):
+        p = C.c_void_p()
+        _chk(self.L.ptm_llike_device_ptr(self.h, C.byref(p)))
+        return p.value
+
+    def exchange_decide(self, llike_global_dev, send_up_dev, send_down_dev):
+        _chk(self.L.ptm_exchange_decide(self.h, llike_global_dev, send_up_dev, send_down_dev))
+
+    def exchange_finish_and_sweep(self, recv_below_dev, recv_above_dev):
+        _chk(self.L.ptm_exchange_finish_and_sweep(self.h, recv_below_dev, recv_above_dev))
+
+    # -- read-back
+    def states(self):
+        X = np.empty((self.Nc, self.D))
+        _chk(self.L.ptm_get_states(self.h, _d(X)))
+        return X
+
+    def array(self, which):
+        dt = {ARR_LLIKE: np.float64, ARR_LPRIOR: np.float64, ARR_LPOST: np.float64, ARR_NTRIES: np.int32,
+              ARR_NACCEPT: np.int32, ARR_LAST_TYPE: np.int32, ARR_NHIST: np.int64, ARR_NSIZE: np.int64}[which]
+        out = np.empty(self.Nc, dtype=dt)
+        _chk(self.L.ptm_get_array(self.h, which, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    llike = property(lambda s: s.array(ARR_LLIKE))
+    lprior = property(lambda s: s.array(ARR_LPRIOR))
+    lpost = property(lambda s: s.array(ARR_LPOST))
+    ntries = property(lambda s: s.array(ARR_NTRIES))
+    naccept = property(lambda s: s.array(ARR_NACCEPT))
+    last_type = property(lambda s: s.array(ARR_LAST_TYPE))
+    nhist = property(lambda s: s.array(ARR_NHIST))
+    nsize = property(lambda s: s.array(ARR_NSIZE))
+
+    def swap_counts(self):
+        n = self.W * max(self.Nt - 1, 1)
+        t, a = np.empty(n, dtype=np.int64), np.empty(n, dtype=np.int64)
+        _chk(self.L.ptm_get_swap_counts(self.h, t.ctypes.data_as(_i64p), a.ctypes.data_as(_i64p)))
+        return t.reshape(self.W, -1), a.reshape(self.W, -1)
+
+    def last_swaps(self):
+        ms = self.max_swaps
+        p, a = np.empty(self.W * ms, dtype=np.int32), np.empty(self.W * ms, dtype=np.int32)
+        _chk(self.L.ptm_get_last_swaps(self.h, p.ctypes.data_as(_i32p), a.ctypes.data_as(_i32p)))
+        return p.reshape(self.W, ms), a.reshape(self.W, ms)
+
+    @property
+    def max_swaps(self):
+        return self.L.ptm_max_swaps_per_step(self.h)
+
+    @property
+    def step_count(self):
+        return int(self.L.ptm_step_count(self.h))
+
+    def debug_evaluate(self, X):
+        X = np.ascontiguousarray(X, dtype=np.float64).reshape(-1, self.D)
+        n = X.shape[0]
+        valid = np.empty(n, dtype=np.int32); Xe = np.empty_like(X); lp = np.empty(n); ll = np.full(n, np.nan)
+        _chk(self.L.ptm_debug_evaluate(self.h, _d(X), n, valid.ctypes.data_as(_i32p), _d(Xe), _d(lp), _d(ll)))
+        return valid, Xe, lp, ll
+
+    # -- measurement
+    def timer_start(self):
+        _chk(self.L.ptm_timer_start(self.h))
+
+    def timer_stop(self):
+        ms = C.c_float()
+        _chk(self.L.ptm_timer_stop(self.h, C.byref(ms)))
+        return ms.value
+
+    def kernel_times(self, capacity=1 << 16):
+        buf = (C.c_float * capacity)()
+        n = C.c_int()
+        _chk(self.L.ptm_get_kernel_times(self.h, buf, capacity, C.byref(n)))
+        return np.array(buf[:min(n.value, capacity)], dtype=np.float64)
+
+    @property
+    def sweep_kernel_name(self):
+        return self.L.ptm_sweep_kernel_name(self.h).decode()

@@ -1,0 +1,231 @@
+"""Parity tests proper: the HIP engine (through the C ABI) against the CPU oracle on the same seeded inputs.
+Bar: bit-exact for the accept/reject index stream and everything integer; floating-point state bit-exact too
+(same IEEE op sequence on both sides); |delta log-posterior| < 1e-10 against the reference-derived fixtures."""
+import math
+
+import numpy as np
+import pytest
+
+import golden_io
+import oracle_lib as O
+import parity_util as PU
+from ptmcmc_amd import engine as E
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+
+
+def test_device_present_and_abi():
+    assert E.device_count() >= 1
+    assert E.load().ptm_abi_version() == 1
+
+
+def test_philox_on_device_matches_known_answers_and_oracle():
+    # the engine's counter layout on (seed=0,tag=0,stream=0,step=0,block=0) is the all-zero Random123 vector
+    assert E.debug_philox(0, 0, 0, 0, 0) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    rng = np.random.default_rng(3)
+    for _ in range(20):
+        seed = int(rng.integers(0, 2 ** 63)); tag = int(rng.integers(0, 3)); stream = int(rng.integers(0, 2 ** 32))
+        step = int(rng.integers(0, 2 ** 40)); block = int(rng.integers(0, 300))
+        assert E.debug_philox(seed, tag, stream, step, block) == O.draw_block(seed, tag, stream, step, block)
+
+
+def test_elementary_functions_bit_exact():
+    L = O.lib()
+    rng = np.random.default_rng(5)
+    n = 200000
+    cases = {
+        E.FN_LOG: (np.concatenate([rng.uniform(1e-300, 1, n), 10 ** rng.uniform(-320, 300, n), rng.uniform(.5, 2, n),
+                                   (rng.integers(0, 2 ** 32, n) + .5) / 2 ** 32]), L.ptmo_log),
+        E.FN_EXP: (np.concatenate([rng.uniform(-750, 710, n), rng.uniform(-2, 2, n)]), L.ptmo_exp),
+        E.FN_SIN_0_PI: (rng.uniform(0, math.pi, n), L.ptmo_sin_0_pi),
+        E.FN_COS_HPI: (rng.uniform(-math.pi / 2, math.pi / 2, n), L.ptmo_cos_hpi),
+    }
+    for fn, (xs, ofn) in cases.items():
+        got = E.debug_eval(fn, xs)
+        sub = rng.choice(xs.size, 20000, replace=False)
+        exp = np.array([ofn(float(xs[i])) for i in sub])
+        assert np.array_equal(got[sub], exp, equal_nan=True), fn
+    # sqrt and division must be the IEEE correctly rounded results (what the CPU checker computes)
+    xs = np.concatenate([rng.uniform(0, 50, n), 10 ** rng.uniform(-300, 300, n), -2 * np.log((rng.integers(0, 2 ** 32, n) + .5) / 2 ** 32)])
+    assert np.array_equal(E.debug_eval(E.FN_SQRT, xs), np.sqrt(xs))
+    a, b = rng.normal(size=n) * 10 ** rng.uniform(-50, 50, n), rng.normal(size=n) * 10 ** rng.uniform(-50, 50, n)
+    assert np.array_equal(E.debug_eval(E.FN_DIV, a, b), a / b)
+
+
+def test_boxmuller_bit_exact():
+    rng = np.random.default_rng(9)
+    k1 = rng.integers(0, 2 ** 32, 100000, dtype=np.uint64).astype(np.uint32)
+    k2 = rng.integers(0, 2 ** 32, 100000, dtype=np.uint64).astype(np.uint32)
+    k1[:6] = [0, 0xffffffff, 0, 1, 5, 0x80000000]; k2[:6] = [0, 0xffffffff, 0x80000000, 0x1fffffff, 0x20000000, 0x7fffffff]
+    z0, z1 = E.debug_boxmuller(k1, k2)
+    for i in list(range(6)) + list(rng.choice(100000, 5000, replace=False)):
+        a, b = O.boxmuller(int(k1[i]), int(k2[i]))
+        assert z0[i] == a and z1[i] == b, i
+    assert abs(z0.mean()) < 0.02 and abs(z0.var() - 1) < 0.02 and abs(z1.var() - 1) < 0.02
+
+
+def test_prior_and_boundary_tables_from_reference():
+    """mixed_dist_product::evaluate_log and stateSpace::enforce on the device vs the real reference's values."""
+    for cfg in golden_io.load("basic.json.gz")["priors"]:
+        D = len(cfg["types"])
+        eng = E.Engine(D, 2, 1)
+        eng.set_bounds(cfg["blo"], cfg["bhi"], cfg["bmin"], cfg["bmax"])
+        eng.set_prior(cfg["types"], cfg["centers"], cfg["halfwidths"])
+        X = np.array([c["x"] for c in cfg["cases"]])
+        valid, Xe, lp, _ = eng.debug_evaluate(X)
+        pb = O.Problem(D)
+        pb.set_bounds(cfg["blo"], cfg["bhi"], cfg["bmin"], cfg["bmax"])
+        pb.set_prior(cfg["types"], cfg["centers"], cfg["halfwidths"])
+        for k, c in enumerate(cfg["cases"]):
+            assert valid[k] == c["valid"], (cfg["name"], k)
+            ok, xo = pb.enforce(c["x"])
+            if ok:
+                assert np.array_equal(Xe[k], xo), (cfg["name"], k)          # bit-exact vs oracle
+                assert np.allclose(Xe[k], c["xe"], rtol=0, atol=1e-12)       # and the reference's value
+            lo = pb.lprior(xo, ok)
+            assert (lp[k] == lo) or (math.isnan(lp[k]) and math.isnan(lo)), (cfg["name"], k, lp[k], lo)
+            exp = c["lprior"]
+            if math.isinf(exp):
+                assert lp[k] == exp
+            elif exp > -700:   # Q2: beyond that the reference's product is subnormal
+                assert abs(lp[k] - exp) <= TOL * max(1, abs(exp)), (cfg["name"], k, lp[k], exp)
+        eng.close()
+
+
+def test_gaussian_target_values_from_reference_formula():
+    for g in golden_io.load("gauss_target.json"):
+        D = g["D"]
+        eng = E.Engine(D, 2, 1)
+        eng.set_target_gaussian(np.array(g["invcov"]).reshape(D, D), g["like0"])
+        _, _, _, ll = eng.debug_evaluate(np.array(g["x"]))
+        for a, b in zip(ll, g["llike"]):
+            assert abs(a - b) <= TOL * max(1, abs(b)), (D, a, b)
+        pb = O.Problem(D)
+        pb.set_gauss(np.array(g["invcov"]).reshape(D, D), g["like0"])
+        assert np.array_equal(ll, np.array([pb.llike(x) for x in g["x"]]))
+        eng.close()
+
+
+def test_init_from_prior_matches_oracle():
+    pr, eng, lad = PU.make_pair(5, 6, 3, 1e3)
+    lad2 = O.Ladder(lad.pb, pr.beta, W=3)
+    lad2.init_from_prior(0x5EED0001)
+    # same draws: oracle INIT stream is keyed by the oracle chain index w*Nt+r, as is the engine's
+    assert np.array_equal(PU.to_engine_order(lad2.x, 6, 3), eng.states())
+    assert np.array_equal(PU.to_engine_order(lad2.llike, 6, 3), eng.llike)
+    eng.close()
+
+
+SWEEP_CASES = [
+    # (D, Nt, W, Tmax, kind, oneDfrac)      BASELINE configs first
+    (2, 8, 1, 1e2, E.PROP_LOWER, None),      # C1
+    (16, 64, 1, 1e4, E.PROP_LOWER, None),    # C2
+    (32, 256, 4, 1e6, E.PROP_LOWER, None),   # C3
+    (32, 16, 64, 1e6, E.PROP_LOWER, None),   # wave-uniform rung path
+    (32, 8, 128, 1e3, E.PROP_DENSE, None),
+    (16, 12, 64, 1e3, E.PROP_DIAG, 0.5),     # the sampler's default Gaussian flavour: diagonal + 1-D moves
+    (5, 7, 3, 1e2, E.PROP_DENSE, 0.3),       # padded dimension (5 -> 8), ragged sizes
+    (3, 5, 70, 1e2, E.PROP_DIAG, None),      # W not a multiple of 64
+    (1, 4, 2, 1e1, E.PROP_DIAG, 1.0),
+    (9, 3, 64, 1e2, E.PROP_LOWER, 0.25),
+]
+
+
+@pytest.mark.parametrize("D,Nt,W,tmax,kind,odf", SWEEP_CASES)
+def test_mh_sweeps_bit_exact(D, Nt, W, tmax, kind, odf):
+    pr, eng, lad = PU.make_pair(D, Nt, W, tmax, kind=kind, one_d_frac=odf)
+    PU.assert_same_state(eng, lad, "start")
+    for k in range(3):
+        eng.sweep(7); eng.sync()
+        lad.sweep(7)
+        PU.assert_same_state(eng, lad, "after %d sweeps" % (7 * (k + 1)))
+    acc = eng.naccept.sum() - eng.Nc
+    assert 0 < acc < 21 * eng.Nc
+    eng.close()
+
+
+@pytest.mark.parametrize("D,Nt,W,tmax,kind,odf", SWEEP_CASES)
+def test_pt_steps_bit_exact(D, Nt, W, tmax, kind, odf):
+    """parallel_tempering_chains::step: exchange phase + MH sweep, incl. the candidate log and per-pair counters."""
+    sr = 0.1 if Nt >= 16 else 0.35
+    pr, eng, lad = PU.make_pair(D, Nt, W, tmax, kind=kind, one_d_frac=odf, swap_rate=sr)
+    assert eng.max_swaps == lad.s.contents.maxswaps
+    nacc = 0
+    for k in range(12):
+        eng.step(1); eng.sync()
+        lad.pt_step(1)
+        PU.assert_same_state(eng, lad, "after PT step %d" % (k + 1))
+        pairs, acc = eng.last_swaps()
+        assert np.array_equal(pairs, lad.last_pairs) and np.array_equal(acc, lad.last_accept), k
+        nacc += int(acc.sum())
+    eng.step(20); eng.sync(); lad.pt_step(20)
+    PU.assert_same_state(eng, lad, "after 32 PT steps")
+    t, a = eng.swap_counts()
+    assert np.array_equal(t, lad.swap_count) and np.array_equal(a, lad.swap_accept_count)
+    assert nacc > 0
+    eng.close()
+
+
+def test_add_every_n_history_counters():
+    pr, eng, lad = PU.make_pair(4, 9, 64, 1e2, swap_rate=0.4, add_every_n=3)
+    eng.step(40); eng.sync(); lad.pt_step(40)
+    PU.assert_same_state(eng, lad)
+    assert (eng.nhist >= 40).all() and (eng.nhist > 40).any()   # Q6: a rung in two attempts gets two rows
+    eng.close()
+
+
+def test_bounds_and_mixed_prior_path_bit_exact():
+    """wrap / limit / reflect boundaries and a gaussian+log+uniform+polar+copolar prior on the device path."""
+    D, Nt, W = 5, 6, 64
+    pi = math.pi
+    bounds = ([0, 1, 3, 1, 2], [0, 0, 3, 1, 2], [0, -0.5, -1.5, 0, -pi / 2], [0, 0, 3.5, pi, pi / 2])
+    prior = ([2, 5, 1, 3, 4], [0.5, 3.0, 1.0, pi / 2, 0.0], [2.0, 4.0, 2.5, pi / 2, pi / 2])
+    rng = np.random.default_rng(1)
+    x0 = np.stack([rng.normal(0.5, 1, Nt * W), rng.uniform(0.8, 11, Nt * W), rng.uniform(-1.4, 3.4, Nt * W),
+                   rng.uniform(0.1, 3.0, Nt * W), rng.uniform(-1.5, 1.5, Nt * W)], 1)
+    pr, eng, lad = PU.make_pair(D, Nt, W, 1e3, kind=E.PROP_DENSE, bounds=bounds, prior=prior, swap_rate=0.3, x0=x0,
+                                mean=np.array([0.5, 3.0, 1.0, 1.5, 0.0]))
+    PU.assert_same_state(eng, lad, "start")
+    eng.step(30); eng.sync(); lad.pt_step(30)
+    PU.assert_same_state(eng, lad, "after 30 steps")
+    acc = eng.naccept.sum() - eng.Nc
+    assert acc > 100
+    assert np.isfinite(eng.lprior).all()
+    eng.close()
+
+
+def test_origin_outside_limit_bound_rejects_everything():
+    """quirk Q9 (states.cc:183-192,205-214), pinned against the reference by golden trace 3."""
+    D, Nt, W = 2, 4, 64
+    bounds = ([1, 0], [0, 0], [0.75, 0], [0, 0])
+    prior = ([1, 1], [3.0, 0.0], [2.0, 50.0])
+    rng = np.random.default_rng(2)
+    x0 = np.stack([rng.uniform(1.1, 4.9, Nt * W), rng.normal(size=Nt * W)], 1)
+    pr, eng, lad = PU.make_pair(D, Nt, W, 10.0, kind=E.PROP_DIAG, bounds=bounds, prior=prior, x0=x0)
+    eng.sweep(10); eng.sync(); lad.sweep(10)
+    PU.assert_same_state(eng, lad)
+    assert (eng.naccept == 1).all() and (eng.ntries == 11).all()
+    eng.close()
+
+
+def test_streams_do_not_depend_on_batch_composition():
+    """Size-independent property: a walker's chain depends only on (seed, walker, rung, step) -- batching it with
+    64 or 192 walkers, or launching with the per-lane or the wave-uniform kernel, gives the same chain."""
+    D, Nt = 8, 16
+    pr, e1, lad = PU.make_pair(D, Nt, 64, 1e3)
+    x0 = e1.states().reshape(Nt, 64, D)
+    e2 = E.Engine(D, Nt, 192)
+    pr.configure(e2, E.PROP_LOWER)
+    x2 = np.concatenate([x0, x0[:, ::-1], x0], axis=1)          # walkers 0..63 identical, the rest arbitrary
+    e2.set_states(x2.reshape(-1, D))
+    e3 = E.Engine(D, Nt, 3)                                      # non-uniform kernel variant
+    pr.configure(e3, E.PROP_LOWER)
+    e3.set_states(x0[:, :3].reshape(-1, D))
+    for e in (e1, e2, e3):
+        e.step(25); e.sync()
+    a = e1.states().reshape(Nt, 64, D)
+    assert np.array_equal(a, e2.states().reshape(Nt, 192, D)[:, :64])
+    assert np.array_equal(a[:, :3], e3.states().reshape(Nt, 3, D))
+    for e in (e1, e2, e3):
+        e.close()
