@@ -1,0 +1,164 @@
+#!/usr/bin/env python3
+"""bench.py -- ladder-wide MH steps/s of the fused parallel-tempering step on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
+
+Workload (BASELINE.json): D=32 correlated Gaussian, 1024-rung geometric ladder (Tmax=1e9), swap_rate 0.1,
+per-rung Cholesky proposal factors, uniform box prior; `walkers` independent ladders are batched per GPU so the
+chip is full (1024 chains alone are 16 wavefronts on a 256-CU part; that latency-bound case is reported beside the
+headline as "w1").  A step = one parallel_tempering_chains::step for every ladder: exchange phase + MH sweep.
+With N GPUs the ladder is sharded in contiguous rung blocks (1024/N rungs per GPU) and the walker count grows
+with N so that per-GPU work is fixed (weak scaling); accepted exchanges across a shard boundary travel as
+point-to-point messages between neighbouring ranks.
+
+Prints ONE JSON line (rank 0).  roofline.achieved = algorithmic bytes per launch (16*D+44 B per MH step x chains,
+SURVEY.md section 8(d)) / mean sweep-kernel duration from HIP events recorded around each launch on the engine's
+stream inside the timed region.  cpu_baseline = the real reference's own parallel_tempering_chains::step
+(oracle/_ref/ptm_ref_driver, built from /root/reference) on this host, 1 thread, bounded sample.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+D, NT, TMAX, SWAP_RATE, SEED = 32, 1024, 1e9, 0.1, 0x5EED0001
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+
+
+def algorithmic_bytes(dim):
+    return 16 * dim + 44   # r+w state, beta, r+w lpost & llike, accept/type flag
+
+
+def cpu_baseline(problem, budget_s=15.0):
+    """Reference CPU path on this box's host cores.  Bounded: ~10-30 s of CPU work."""
+    drv = os.path.join(ROOT, "oracle", "_ref", "ptm_ref_driver")
+    nsteps = 300   # 1024 rungs x 300 steps ~ 3e5 reference MH steps ~ 10 s at the ~3e4 steps/s measured in BASELINE.md
+    if os.path.exists(drv):
+        with tempfile.NamedTemporaryFile("w", suffix=".spec", delete=False) as f:
+            f.write("%d %d %d %.17g %.17g %.17g\n" % (D, NT, nsteps, TMAX, SWAP_RATE, 0.012556))
+            for row in problem.cov:
+                f.write(" ".join("%.17g" % v for v in row) + "\n")
+            f.write(" ".join("%.17g" % v for v in problem.halfwidths) + "\n")
+            spec = f.name
+        try:
+            out = subprocess.check_output([drv, "bench", spec], timeout=600).decode().strip().splitlines()[-1]
+            r = json.loads(out)
+            return {"value": r["steps_per_s"], "unit": "MH steps/s", "cores": 1, "kind": "reference",
+                    "sample": "parallel_tempering_chains::step, D=%d, %d rungs x 1 ladder, %d steps after %d warm-up, "
+                              "gaussian_prop(cov), OpenMP inert as written (1 thread)" % (D, NT, nsteps, nsteps // 10 + 1)}
+        except Exception as ex:  # fall through to the port
+            sys.stderr.write("[bench] reference driver failed (%s); timing the C port instead\n" % ex)
+        finally:
+            os.unlink(spec)
+    # fallback: the C restatement, all host cores
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    ncore = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    ncore = max(1, min(ncore, 64))
+    W = 4
+    pb = O.Problem(D)
+    pb.set_bounds([0] * D, [0] * D, [0.0] * D, [0.0] * D)
+    pb.set_prior(problem.types, problem.centers, problem.halfwidths)
+    pb.set_gauss(problem.P, problem.like0)
+    lad = O.Ladder(pb, problem.beta, W=W, swap_rate=SWAP_RATE)
+    fac = problem.proposal_factors()
+    lad.set_proposals([(O.PROP_DENSE, fac[r], 0.0) for r in range(NT)])
+    lad.use_philox(SEED)
+    lad.init_from_prior(SEED)
+    lad.pt_step(3, ncore)
+    t0 = time.perf_counter()
+    n = 0
+    while time.perf_counter() - t0 < budget_s:
+        lad.pt_step(5, ncore)
+        n += 5
+    dt = time.perf_counter() - t0
+    return {"value": n * NT * W / dt, "unit": "MH steps/s", "cores": ncore, "kind": "port",
+            "sample": "oracle/ptm_oracle.c pt_step, D=%d, %d rungs x %d ladders, %d steps, OpenMP over chains" % (D, NT, W, n)}
+
+
+def run_single(args):
+    from ptmcmc_amd import engine as E
+    from ptmcmc_amd.problems import GaussianProblem
+    if E.device_count() < 1:
+        raise SystemExit("bench.py needs an MI355X (no gfx950 device visible); there is no CPU fallback")
+    pr = GaussianProblem(D, NT, TMAX)
+    W = args.walkers
+    eng = E.Engine(D, NT, W, seed=SEED, swap_rate=SWAP_RATE, add_every_n=100, time_kernels=True)
+    pr.configure(eng, E.PROP_LOWER)
+    eng.init_from_prior()
+    eng.step(args.warmup)
+    eng.sync()
+    eng.kernel_times()   # drop warm-up records
+    eng.timer_start()
+    t0 = time.perf_counter()
+    eng.step(args.steps)
+    ms_dev = eng.timer_stop()
+    eng.sync()
+    wall = time.perf_counter() - t0
+    kt = eng.kernel_times()
+    nchains = NT * W
+    value = nchains * args.steps / wall
+    kavg_ms = float(kt.mean())
+    achieved = algorithmic_bytes(D) * nchains / (kavg_ms * 1e-3) / 1e9
+    acc = float((eng.naccept.sum() - eng.Nc)) / max(1, float((eng.ntries.sum() - eng.Nc)))
+    t, a = eng.swap_counts()
+    # latency-bound companion: the bare 1024-chain ladder (W=1)
+    w1 = None
+    if not args.no_w1:
+        e1 = E.Engine(D, NT, 1, seed=SEED, swap_rate=SWAP_RATE, add_every_n=100)
+        pr.configure(e1, E.PROP_LOWER)
+        e1.init_from_prior()
+        e1.step(50); e1.sync()
+        n1 = 500
+        t1 = time.perf_counter()
+        e1.step(n1); e1.sync()
+        d1 = time.perf_counter() - t1
+        w1 = {"chains": NT, "value": NT * n1 / d1, "ms_per_step": d1 / n1 * 1e3}
+        e1.close()
+    out = {
+        "metric": "ladder-wide MH steps/sec (D=32 Gaussian, 1024 temps)",
+        "value": value, "unit": "MH steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "D=32 correlated Gaussian, 1024-rung ladder (Tmax=1e9, swap_rate=0.1) x %d walkers; "
+                               "per-rung Cholesky proposal factors; uniform box prior" % W,
+                   "dim": D, "rungs": NT, "walkers": W, "chains": nchains, "sharding": "1 GPU holds the whole ladder"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": eng.sweep_kernel_name,
+                     "kernel_avg_ms": kavg_ms, "launches": int(kt.size), "bytes_per_mh_step": algorithmic_bytes(D)},
+        "device_ms_per_step": ms_dev / args.steps,
+        "mh_accept_rate": acc, "swap_accept_rate": float(a.sum()) / max(1, float(t.sum())),
+        "w1": w1,
+    }
+    if not args.no_cpu:
+        out["cpu_baseline"] = cpu_baseline(pr)
+    eng.close()
+    print(json.dumps(out), flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--walkers", type=int, default=4096, help="independent ladders batched per GPU")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-w1", action="store_true", help="skip the 1024-chain latency companion")
+    args = ap.parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 or world > 1:
+        from ptmcmc_amd import parallel
+        return parallel.bench_main(args)
+    run_single(args)
+
+
+if __name__ == "__main__":
+    main()
