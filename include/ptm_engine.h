@@ -122,10 +122,13 @@ int ptm_sync(ptm_engine* e);
 int ptm_llike_device_ptr(ptm_engine* e, void** dev_ptr);
 /* exchange phase, part 1: decide all exchanges of the next step from the GLOBAL llike array
  * (device pointer, [n_rungs*W] doubles = concatenation of the shards' local arrays) and pack the rows that
- * leave this shard into send_up / send_down (device buffers of W*(D+2) doubles each, may be NULL at the ends). */
+ * leave this shard into send_up / send_down (device buffers of ptm_exchange_buffer_doubles() doubles each; may be
+ * NULL at the ends of the ladder). */
 int ptm_exchange_decide(ptm_engine* e, const void* llike_global_dev, void* send_up_dev, void* send_down_dev);
-/* exchange phase, part 2 + MH sweep: rows arriving from the neighbours (device buffers, W*(D+2) doubles) */
+/* exchange phase, part 2 + MH sweep: rows arriving from the neighbours (device buffers of the same size) */
 int ptm_exchange_finish_and_sweep(ptm_engine* e, const void* recv_from_below_dev, const void* recv_from_above_dev);
+/* size of one boundary buffer in doubles: W * (padded dim + 2) -- one state row + llike + lprior per walker, SoA */
+int ptm_exchange_buffer_doubles(ptm_engine* e);
 
 /* ---- read-back ------------------------------------------------------------------------------------------ */
 enum {
@@ -158,10 +161,14 @@ int ptm_get_kernel_times(ptm_engine* e, float* ms, int capacity, int* count);
 const char* ptm_sweep_kernel_name(ptm_engine* e);
 
 /* ---- verification hooks (used by tests/ only; evaluate device functions on arrays) ---------------------- */
-enum { PTM_FN_LOG = 0, PTM_FN_EXP = 1, PTM_FN_SIN_0_PI = 2, PTM_FN_COS_HPI = 3, PTM_FN_SQRT = 4, PTM_FN_DIV = 5 };
+enum { PTM_FN_LOG = 0, PTM_FN_EXP = 1, PTM_FN_SIN_0_PI = 2, PTM_FN_COS_HPI = 3, PTM_FN_SQRT = 4, PTM_FN_DIV = 5,
+       PTM_FN_SQRT_RAW = 6 };
 int ptm_debug_eval(int device, int fn, const double* a, const double* b, double* out, int n);
 int ptm_debug_philox(int device, uint64_t seed, int tag, uint32_t stream, uint64_t step, uint32_t block, uint32_t out[4]);
 int ptm_debug_boxmuller(int device, const uint32_t* k1, const uint32_t* k2, double* z0, double* z1, int n);
+/* exhaustive scan of all 2^32 Box-Muller radius arguments: how many are NOT already correctly rounded by the
+ * compiler's sqrt expansion (i.e. need the engine's fix-up step) */
+int ptm_debug_sqrt_scan(int device, uint64_t* mismatches);
 /* evaluate lprior / llike of arbitrary states with the engine's problem description: X[n][D] */
 int ptm_debug_evaluate(ptm_engine* e, const double* X, int n, int32_t* valid, double* X_enforced, double* lprior,
                        double* llike);

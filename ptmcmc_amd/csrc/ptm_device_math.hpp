@@ -75,9 +75,31 @@ __device__ __forceinline__ double dlog(double x) {
   return dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
 }
 
-// log of an open-interval uniform (k+0.5)/2^32: same sequence as dlog() minus the special cases that
-// cannot occur (the argument is a normal number in (2^-33, 1))
-__device__ __forceinline__ double dlog_u01(uint32_t k) { return dlog(u01(k)); }
+// log of an open-interval uniform u = (k+0.5)/2^32: u is a positive normal number in [2^-33, 1), so none of
+// dlog()'s special cases can fire; this is the same operation sequence without them (bit-identical results).
+__device__ __forceinline__ double dlog_u01(uint32_t k) {
+  const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
+  const double L1 = 6.666666666666735130e-01, L2 = 3.999999999940941908e-01, L3 = 2.857142874366239149e-01,
+               L4 = 2.222219843214978396e-01, L5 = 1.818357216161805012e-01, L6 = 1.531383769920937332e-01,
+               L7 = 1.479819860511658591e-01;
+  const double x = u01(k);
+  const uint64_t b = (uint64_t)__double_as_longlong(x);
+  int e = (int)(b >> 52) - 1023;
+  double m = __longlong_as_double((long long)((b & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull));
+  const bool big = m > 1.4142135623730951;
+  m = big ? m * 0.5 : m;
+  e += big ? 1 : 0;
+  const double f = m - 1.0;
+  const double s = f / (2.0 + f);
+  const double z = s * s;
+  double r = L7;
+  r = __builtin_fma(r, z, L6); r = __builtin_fma(r, z, L5); r = __builtin_fma(r, z, L4);
+  r = __builtin_fma(r, z, L3); r = __builtin_fma(r, z, L2); r = __builtin_fma(r, z, L1);
+  const double R = r * z;
+  const double hfsq = 0.5 * f * f;
+  const double dk = (double)e;
+  return dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
+}
 
 __device__ __forceinline__ double dexp(double x) {
   const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
@@ -144,28 +166,26 @@ __device__ __forceinline__ double dcos_hpi(double x) {
   return sin_k((HPI_HI - x) + HPI_LO);
 }
 
-// correctly rounded square root: the compiler's f64 sqrt expansion followed by one exact-residual
-// correction step, so that the result is the IEEE value the CPU checker's sqrt() returns
+// correctly rounded square root: the compiler's f64 sqrt expansion (faithful, <= 1 ulp) followed by one
+// exact-residual decision, so that the result is the IEEE value the CPU checker's sqrt() returns.
+//   r = a - g*g (sign exact via fma).  If r != 0 the root lies between g and its neighbour gn on that side; g is
+//   correctly rounded iff the root is on g's side of the midpoint, i.e. a vs ((g+gn)/2)^2 = g*gn + d^2/4.  In units
+//   of ulp^2 the quantity a - g*gn is an integer N and d^2/4 < 1, so the test is N > 0 (r > 0) / N <= 0 (r < 0).
+// Branch-free; valid for finite a > 0 (the only arguments the hot path produces); other inputs pass through.
 __device__ __forceinline__ double dsqrt(double a) {
-  double g = __builtin_sqrt(a);  // faithful (<= 1 ulp)
-  if (a > 0.0 && a < __builtin_inf()) {
-    // r = a - g*g (sign exact).  If r != 0 the root lies between g and its neighbour gn on that side; g is the
-    // correctly rounded value iff the root is on g's side of the midpoint, i.e. a vs ((g+gn)/2)^2 = g*gn + d^2/4.
-    // In units of ulp^2 the quantity a - g*gn is an integer N and d^2/4 < 1, so the test is N > 0 (r > 0) / N <= 0 (r < 0).
-    const double r = __builtin_fma(-g, g, a);
-    if (r != 0.0) {
-      const double gn = __longlong_as_double(__double_as_longlong(g) + (r > 0.0 ? 1 : -1));
-      const double t = __builtin_fma(-g, gn, a);
-      if (r > 0.0 ? (t > 0.0) : (t <= 0.0)) g = gn;
-    }
-  }
-  return g;
+  const double g = __builtin_sqrt(a);
+  const double r = __builtin_fma(-g, g, a);
+  const double gn = __longlong_as_double(__double_as_longlong(g) + (r > 0.0 ? 1 : -1));
+  const double t = __builtin_fma(-g, gn, a);
+  const bool move = (r > 0.0) ? (t > 0.0) : ((r < 0.0) ? (t <= 0.0) : false);
+  const bool ok = (a > 0.0) && (a < __builtin_inf());
+  return (ok && move) ? gn : g;
 }
 
 // Box-Muller on two 32-bit draws; replaces newran's table-rejection Normal (newran2.cxx:164-217)
 // behind gaussian_dist_product::drawSample (probability_function.cc:37-47).
 __device__ __forceinline__ void boxmuller(uint32_t k1, uint32_t k2, double& z0, double& z1) {
-  const double r = dsqrt(-2.0 * dlog(u01(k1)));
+  const double r = dsqrt(-2.0 * dlog_u01(k1));
   const uint32_t q = k2 >> 29;
   uint32_t m = k2 & 0x1FFFFFFFu;
   if (q & 1u) m ^= 0x1FFFFFFFu;

@@ -13,7 +13,8 @@
 #include <vector>
 
 #include "../../include/ptm_engine.h"
-#include "ptm_kernels.hpp"
+#include "ptm_aux_kernels.hpp"
+#include "ptm_launch.hpp"
 
 using namespace ptm;
 
@@ -44,7 +45,8 @@ struct ptm_engine {
   // device state
   double *x[2] = {nullptr, nullptr}, *ll[2] = {nullptr, nullptr}, *lp[2] = {nullptr, nullptr};
   int *ntries = nullptr, *naccept = nullptr, *last_type = nullptr, *src = nullptr, *err = nullptr;
-  long long *nhist = nullptr, *nsize = nullptr, *swap_try = nullptr, *swap_acc = nullptr;
+  unsigned int* nhist = nullptr;
+  long long *swap_try = nullptr, *swap_acc = nullptr;
   unsigned char* touch = nullptr;
   int *last_pairs = nullptr, *last_acc = nullptr;
   // device problem description
@@ -129,15 +131,16 @@ extern "C" int ptm_engine_create(const ptm_config* cfg, ptm_engine** out) {
   if (cfg->device >= 0) { HIPCHK(hipSetDevice(cfg->device)); e->device = cfg->device; } else HIPCHK(hipGetDevice(&e->device));
   if (cfg->stream) e->stream = (hipStream_t)cfg->stream;
   else { HIPCHK(hipStreamCreate(&e->stream)); e->own_stream = true; }
-  const size_t Nc = e->Nc, D = e->D;
+  const size_t Nc = e->Nc, D = e->DP;  // every per-dimension table is padded to DP
   for (int b = 0; b < 2; ++b) {
     if ((rc = dalloc(&e->x[b], Nc * D))) return rc;
+    HIPCHK(hipMemsetAsync(e->x[b], 0, Nc * D * 8, e->stream));
     if ((rc = dalloc(&e->ll[b], Nc))) return rc;
     if ((rc = dalloc(&e->lp[b], Nc))) return rc;
   }
   if ((rc = dalloc(&e->ntries, Nc)) || (rc = dalloc(&e->naccept, Nc)) || (rc = dalloc(&e->last_type, Nc)) ||
       (rc = dalloc(&e->src, Nc)) || (rc = dalloc(&e->touch, Nc)) || (rc = dalloc(&e->nhist, Nc)) ||
-      (rc = dalloc(&e->nsize, Nc)) || (rc = dalloc(&e->err, 4)))
+      (rc = dalloc(&e->err, 4)))
     return rc;
   const size_t np = (size_t)e->W * (e->Nt > 1 ? e->Nt - 1 : 1);
   if ((rc = dalloc(&e->swap_try, np)) || (rc = dalloc(&e->swap_acc, np)) || (rc = dalloc(&e->last_pairs, (size_t)e->W * e->ms)) ||
@@ -153,15 +156,16 @@ extern "C" int ptm_engine_create(const ptm_config* cfg, ptm_engine** out) {
       (rc = dalloc(&e->P2, D * (D + 1) / 2)) || (rc = dalloc(&e->mean, D)) || (rc = dalloc(&e->beta, (size_t)e->Nt)) ||
       (rc = dalloc(&e->onedfrac, (size_t)e->nloc)))
     return rc;
-  // defaults: open bounds, flat prior
+  // defaults (and the permanent content of the pad dimensions): open bounds, flat prior with unbounded support
   std::vector<int> zi(D, 0);
-  std::vector<double> zd(D, 0.0), one(D, 1.0);
+  std::vector<double> zd(D, 0.0), one(D, 1.0), ninf(D, -INFINITY), pinf(D, INFINITY);
   if ((rc = upload(e->blo, zi.data(), D, e->stream)) || (rc = upload(e->bhi, zi.data(), D, e->stream)) ||
       (rc = upload(e->ptype, zi.data(), D, e->stream)) || (rc = upload(e->bmin, zd.data(), D, e->stream)) ||
-      (rc = upload(e->bmax, zd.data(), D, e->stream)) || (rc = upload(e->plo, zd.data(), D, e->stream)) ||
-      (rc = upload(e->phi, zd.data(), D, e->stream)) || (rc = upload(e->pcoef, one.data(), D, e->stream)))
+      (rc = upload(e->bmax, zd.data(), D, e->stream)) || (rc = upload(e->plo, ninf.data(), D, e->stream)) ||
+      (rc = upload(e->phi, pinf.data(), D, e->stream)) || (rc = upload(e->pcoef, one.data(), D, e->stream)) ||
+      (rc = upload(e->mean, zd.data(), D, e->stream)))
     return rc;
-  e->h_ptype.assign(D, 0); e->h_plo.assign(D, 0.0); e->h_phi.assign(D, 0.0);
+  e->h_ptype.assign(D, 0); e->h_plo.assign(D, -INFINITY); e->h_phi.assign(D, INFINITY);
   e->all_uniform = 0;  // flat prior goes through the general product (pdf == 1)
   HIPCHK(hipEventCreate(&e->t0));
   HIPCHK(hipEventCreate(&e->t1));
@@ -174,7 +178,7 @@ extern "C" int ptm_engine_destroy(ptm_engine* e) {
   if (!e) return PTM_OK;
   (void)hipStreamSynchronize(e->stream);
   void* ptrs[] = {e->x[0], e->x[1], e->ll[0], e->ll[1], e->lp[0], e->lp[1], e->ntries, e->naccept, e->last_type, e->src,
-                  e->err, e->nhist, e->nsize, e->swap_try, e->swap_acc, e->touch, e->last_pairs, e->last_acc, e->blo,
+                  e->err, e->nhist, e->swap_try, e->swap_acc, e->touch, e->last_pairs, e->last_acc, e->blo,
                   e->bhi, e->ptype, e->bmin, e->bmax, e->plo, e->phi, e->pcoef, e->P2, e->mean, e->beta, e->prop, e->onedfrac};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -210,7 +214,7 @@ extern "C" int ptm_set_bounds(ptm_engine* e, const int32_t* lo, const int32_t* h
     if (lo[d] == PTM_BOUND_LIMIT && z < xmin[d]) { e->origin_valid = 0; break; }
     if (hi[d] == PTM_BOUND_LIMIT && z > xmax[d]) { e->origin_valid = 0; break; }
   }
-  if ((rc = upload(e->blo, lo, D, e->stream)) || (rc = upload(e->bhi, hi, D, e->stream)) ||
+  if ((rc = upload(e->blo, lo, D, e->stream)) || (rc = upload(e->bhi, hi, D, e->stream)) ||      // pad dimensions stay open
       (rc = upload(e->bmin, xmin, D, e->stream)) || (rc = upload(e->bmax, xmax, D, e->stream)))
     return rc;
   return PTM_OK;
@@ -226,7 +230,7 @@ extern "C" int ptm_set_prior(ptm_engine* e, const int32_t* types, const double* 
   for (int d = 0; d < D; ++d) {
     ty[d] = types[d];
     switch (types[d]) {  // mixed_dist_product ctor (probability_function.cc:232-254) and the 1-D ctors it calls
-      case PTM_PRIOR_FLAT: lo[d] = hi[d] = 0; coef[d] = 1; e->all_uniform = 0; break;
+      case PTM_PRIOR_FLAT: lo[d] = -INFINITY; hi[d] = INFINITY; coef[d] = 1; e->all_uniform = 0; break;
       case PTM_PRIOR_UNIFORM: lo[d] = c[d] - h[d]; hi[d] = c[d] + h[d]; coef[d] = 1 / (hi[d] - lo[d]); prod *= coef[d]; break;
       case PTM_PRIOR_GAUSSIAN: lo[d] = c[d]; hi[d] = h[d]; coef[d] = 0; e->all_uniform = 0; break;
       case PTM_PRIOR_POLAR: {  // UniformPolarDist ctor: clamps only the normalisation (ProbabilityDist.h:181-186)
@@ -256,7 +260,7 @@ extern "C" int ptm_set_prior(ptm_engine* e, const int32_t* types, const double* 
     }
   }
   e->lprior_const = std::log(prod);  // the reference takes libm log of the product of these constants on every call
-  e->h_ptype = ty; e->h_plo = lo; e->h_phi = hi;
+  for (int d = 0; d < D; ++d) { e->h_ptype[d] = ty[d]; e->h_plo[d] = lo[d]; e->h_phi[d] = hi[d]; }
   int rc;
   if ((rc = upload(e->ptype, ty.data(), D, e->stream)) || (rc = upload(e->plo, lo.data(), D, e->stream)) ||
       (rc = upload(e->phi, hi.data(), D, e->stream)) || (rc = upload(e->pcoef, coef.data(), D, e->stream)))
@@ -266,12 +270,12 @@ extern "C" int ptm_set_prior(ptm_engine* e, const int32_t* types, const double* 
 
 extern "C" int ptm_set_target_gaussian(ptm_engine* e, const double* mean, const double* P, double like0) {
   if (!e || !P) return fail(PTM_ERR_INVALID, "null argument");
-  const int D = e->D;
-  std::vector<double> packed((size_t)D * (D + 1) / 2);
-  size_t o = 0;
+  const int D = e->D, DP = e->DP;
+  std::vector<double> packed((size_t)DP * (DP + 1) / 2, 0.0);
   for (int i = 0; i < D; ++i) {
-    for (int j = 0; j < i; ++j) packed[o++] = P[i * D + j] + P[j * D + i];
-    packed[o++] = P[i * D + i];
+    const size_t o = (size_t)i * (i + 1) / 2;
+    for (int j = 0; j < i; ++j) packed[o + j] = P[i * D + j] + P[j * D + i];
+    packed[o + i] = P[i * D + i];
   }
   int rc;
   if ((rc = upload(e->P2, packed.data(), packed.size(), e->stream))) return rc;
@@ -349,7 +353,7 @@ extern "C" int ptm_set_proposals(ptm_engine* e, int kind, const double* factors,
 static Dev make_dev(ptm_engine* e) {
   Dev p;
   memset(&p, 0, sizeof p);
-  p.D = e->D; p.Nt = e->Nt; p.r0 = e->r0; p.nloc = e->nloc; p.W = e->W; p.Nc = e->Nc;
+  p.D = e->D; p.DP = e->DP; p.Nt = e->Nt; p.r0 = e->r0; p.nloc = e->nloc; p.W = e->W; p.Nc = e->Nc;
   p.seed = e->cfg.seed; p.step = e->step; p.add_every_n = e->cfg.add_every_n; p.min_prior = e->cfg.min_prior;
   p.has_bounds = e->has_bounds; p.origin_valid = e->origin_valid;
   p.blo = e->blo; p.bhi = e->bhi; p.bmin = e->bmin; p.bmax = e->bmax;
@@ -359,33 +363,22 @@ static Dev make_dev(ptm_engine* e) {
   p.beta = e->beta; p.prop = e->prop; p.onedfrac = e->onedfrac; p.prop_stride = e->prop_stride; p.any_oned = e->any_oned;
   const int in = e->cur, out = 1 - e->cur;
   p.x_in = e->x[in]; p.x_out = e->x[out]; p.ll_in = e->ll[in]; p.ll_out = e->ll[out]; p.lp_in = e->lp[in]; p.lp_out = e->lp[out];
-  p.ntries = e->ntries; p.naccept = e->naccept; p.last_type = e->last_type; p.nhist = e->nhist; p.nsize = e->nsize;
+  p.ntries = e->ntries; p.naccept = e->naccept; p.last_type = e->last_type; p.nhist = e->nhist;
   p.src = e->src; p.touch = e->touch; p.err = e->err;
   return p;
 }
 
-template <int DP>
-static void launch_sweep_dp(ptm_engine* e, const Dev& p, bool uni) {
-  const dim3 grid((e->Nc + 255) / 256), block(256);
-  switch (e->prop_kind) {
-    case PTM_PROP_DIAG:
-      if (uni) hipLaunchKernelGGL((sweep_kernel<DP, KIND_DIAG, true>), grid, block, 0, e->stream, p);
-      else hipLaunchKernelGGL((sweep_kernel<DP, KIND_DIAG, false>), grid, block, 0, e->stream, p);
-      break;
-    case PTM_PROP_LOWER:
-      if (uni) hipLaunchKernelGGL((sweep_kernel<DP, KIND_LOWER, true>), grid, block, 0, e->stream, p);
-      else hipLaunchKernelGGL((sweep_kernel<DP, KIND_LOWER, false>), grid, block, 0, e->stream, p);
-      break;
-    default:
-      if (uni) hipLaunchKernelGGL((sweep_kernel<DP, KIND_DENSE, true>), grid, block, 0, e->stream, p);
-      else hipLaunchKernelGGL((sweep_kernel<DP, KIND_DENSE, false>), grid, block, 0, e->stream, p);
-  }
+static SweepSel sweep_sel(const ptm_engine* e) {
+  SweepSel s;
+  s.kind = e->prop_kind == PTM_PROP_DIAG ? KIND_DIAG : (e->prop_kind == PTM_PROP_LOWER ? KIND_LOWER : KIND_DENSE);
+  s.uni = (e->W % 64) == 0;
+  s.simple = s.uni && !e->has_bounds && e->all_uniform && !e->has_mean && !e->any_oned;
+  return s;
 }
 
 static int launch_sweep(ptm_engine* e, const double* recv_below, const double* recv_above) {
   Dev p = make_dev(e);
   p.recv_below = recv_below; p.recv_above = recv_above;
-  const bool uni = (e->W % 64) == 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   if (e->cfg.time_kernels) {
     if (e->kev_used + 2 > e->kev.size()) {
@@ -395,14 +388,14 @@ static int launch_sweep(ptm_engine* e, const double* recv_below, const double* r
     e->kev_used += 2;
     HIPCHK(hipEventRecord(ev0, e->stream));
   }
+  const SweepSel sel = sweep_sel(e);
   switch (e->DP) {
-    case 4: launch_sweep_dp<4>(e, p, uni); break;
-    case 8: launch_sweep_dp<8>(e, p, uni); break;
-    case 16: launch_sweep_dp<16>(e, p, uni); break;
-    case 32: launch_sweep_dp<32>(e, p, uni); break;
+    case 4: HIPCHK(launch_sweep_4(p, sel, e->stream)); break;
+    case 8: HIPCHK(launch_sweep_8(p, sel, e->stream)); break;
+    case 16: HIPCHK(launch_sweep_16(p, sel, e->stream)); break;
+    case 32: HIPCHK(launch_sweep_32(p, sel, e->stream)); break;
     default: return fail(PTM_ERR_UNSUPPORTED, "dim > 32 is not built in this round");
   }
-  HIPCHK(hipGetLastError());
   if (ev1) HIPCHK(hipEventRecord(ev1, e->stream));
   e->cur = 1 - e->cur;
   e->step += 1;
@@ -417,7 +410,7 @@ static size_t decide_lds_bytes(int Nt, int ms) {
 static int launch_decide(ptm_engine* e, const double* llg, double* send_up, double* send_down) {
   Decide p;
   memset(&p, 0, sizeof p);
-  p.D = e->D; p.Nt = e->Nt; p.r0 = e->r0; p.nloc = e->nloc; p.W = e->W; p.Nc = e->Nc; p.ms = e->ms;
+  p.DP = e->DP; p.Nt = e->Nt; p.r0 = e->r0; p.nloc = e->nloc; p.W = e->W; p.Nc = e->Nc; p.ms = e->ms;
   p.seed = e->cfg.seed; p.step = e->step; p.thresh = e->thresh;
   p.beta = e->beta; p.llg = llg; p.x_in = e->x[e->cur]; p.ll_in = e->ll[e->cur]; p.lp_in = e->lp[e->cur];
   p.src = e->src; p.touch = e->touch; p.swap_try = e->swap_try; p.swap_acc = e->swap_acc;
@@ -444,45 +437,40 @@ static int ready(ptm_engine* e) {
 static int reset_counters(ptm_engine* e) {
   const size_t Nc = e->Nc;
   std::vector<int> one(Nc, 1), m1(Nc, -1), ident(Nc);
-  std::vector<long long> z(Nc, 0), o(Nc, 1);
+  std::vector<unsigned int> z(Nc, 0u);
   for (size_t c = 0; c < Nc; ++c) ident[c] = (int)c;
   int rc;
   if ((rc = upload(e->ntries, one.data(), Nc, e->stream)) || (rc = upload(e->naccept, one.data(), Nc, e->stream)) ||  // chain.cc:649
       (rc = upload(e->last_type, m1.data(), Nc, e->stream)) || (rc = upload(e->src, ident.data(), Nc, e->stream)) ||
-      (rc = upload(e->nhist, z.data(), Nc, e->stream)) || (rc = upload(e->nsize, o.data(), Nc, e->stream)))        // chain.cc:871-875
+      (rc = upload(e->nhist, z.data(), Nc, e->stream)))                                                        // chain.cc:871-875
     return rc;
   HIPCHK(hipMemsetAsync(e->touch, 0, Nc, e->stream));
   e->step = 0;
   return PTM_OK;
 }
 
-template <int DP>
-static void launch_eval(ptm_engine* e, const Dev& p, int n, double* x, int* valid, double* lp, double* ll, int eval_like) {
-  hipLaunchKernelGGL((evaluate_kernel<DP>), dim3((n + 255) / 256), dim3(256), 0, e->stream, p, n, x, valid, lp, ll, eval_like);
-}
 static int run_eval(ptm_engine* e, int n, double* x, int* valid, double* lp, double* ll, int eval_like) {
   Dev p = make_dev(e);
   switch (e->DP) {
-    case 4: launch_eval<4>(e, p, n, x, valid, lp, ll, eval_like); break;
-    case 8: launch_eval<8>(e, p, n, x, valid, lp, ll, eval_like); break;
-    case 16: launch_eval<16>(e, p, n, x, valid, lp, ll, eval_like); break;
-    case 32: launch_eval<32>(e, p, n, x, valid, lp, ll, eval_like); break;
+    case 4: HIPCHK(launch_eval_4(p, n, x, valid, lp, ll, eval_like, e->stream)); break;
+    case 8: HIPCHK(launch_eval_8(p, n, x, valid, lp, ll, eval_like, e->stream)); break;
+    case 16: HIPCHK(launch_eval_16(p, n, x, valid, lp, ll, eval_like, e->stream)); break;
+    case 32: HIPCHK(launch_eval_32(p, n, x, valid, lp, ll, eval_like, e->stream)); break;
     default: return fail(PTM_ERR_UNSUPPORTED, "dim > 32 is not built in this round");
   }
-  HIPCHK(hipGetLastError());
   return PTM_OK;
 }
 
 extern "C" int ptm_set_states(ptm_engine* e, const double* X, const double* llike) {
   if (!e || !X) return fail(PTM_ERR_INVALID, "null argument");
   if (!e->have_target && !llike) return fail(PTM_ERR_INVALID, "set the target first (or pass llike)");
-  const size_t Nc = e->Nc, D = e->D;
-  std::vector<double> soa(Nc * D);
+  const size_t Nc = e->Nc, D = e->D, DP = e->DP;
+  std::vector<double> soa(Nc * DP, 0.0);
   for (size_t c = 0; c < Nc; ++c)
     for (size_t d = 0; d < D; ++d) soa[d * Nc + c] = X[c * D + d];
   int rc;
   e->cur = 0;
-  if ((rc = upload(e->x[0], soa.data(), Nc * D, e->stream))) return rc;
+  if ((rc = upload(e->x[0], soa.data(), Nc * DP, e->stream))) return rc;
   if (llike && (rc = upload(e->ll[0], llike, Nc, e->stream))) return rc;
   if ((rc = run_eval(e, (int)Nc, e->x[0], nullptr, e->lp[0], e->ll[0], llike ? 0 : 1))) return rc;
   if ((rc = reset_counters(e))) return rc;
@@ -491,10 +479,6 @@ extern "C" int ptm_set_states(ptm_engine* e, const double* X, const double* llik
   return PTM_OK;
 }
 
-template <int DP>
-static void launch_init(ptm_engine* e, const Dev& p, int* failflag) {
-  hipLaunchKernelGGL((init_prior_kernel<DP>), dim3((e->Nc + 255) / 256), dim3(256), 0, e->stream, p, e->x[0], e->ll[0], e->lp[0], failflag);
-}
 extern "C" int ptm_init_from_prior(ptm_engine* e) {
   if (!e) return fail(PTM_ERR_INVALID, "null engine");
   if (!e->have_target) return fail(PTM_ERR_INVALID, "set the target first");
@@ -505,13 +489,12 @@ extern "C" int ptm_init_from_prior(ptm_engine* e) {
   Dev p = make_dev(e);
   HIPCHK(hipMemsetAsync(e->err + 1, 0, 4, e->stream));
   switch (e->DP) {
-    case 4: launch_init<4>(e, p, e->err + 1); break;
-    case 8: launch_init<8>(e, p, e->err + 1); break;
-    case 16: launch_init<16>(e, p, e->err + 1); break;
-    case 32: launch_init<32>(e, p, e->err + 1); break;
+    case 4: HIPCHK(launch_init_4(p, e->x[0], e->ll[0], e->lp[0], e->err + 1, e->stream)); break;
+    case 8: HIPCHK(launch_init_8(p, e->x[0], e->ll[0], e->lp[0], e->err + 1, e->stream)); break;
+    case 16: HIPCHK(launch_init_16(p, e->x[0], e->ll[0], e->lp[0], e->err + 1, e->stream)); break;
+    case 32: HIPCHK(launch_init_32(p, e->x[0], e->ll[0], e->lp[0], e->err + 1, e->stream)); break;
     default: return fail(PTM_ERR_UNSUPPORTED, "dim > 32 is not built in this round");
   }
-  HIPCHK(hipGetLastError());
   int rc = reset_counters(e);
   if (rc) return rc;
   int flag = 0;
@@ -564,6 +547,8 @@ extern "C" int ptm_exchange_decide(ptm_engine* e, const void* llg, void* send_up
   return PTM_OK;
 }
 
+extern "C" int ptm_exchange_buffer_doubles(ptm_engine* e) { return e ? e->W * (e->DP + 2) : 0; }
+
 extern "C" int ptm_exchange_finish_and_sweep(ptm_engine* e, const void* recv_below, const void* recv_above) {
   int rc = ready(e);
   if (rc) return rc;
@@ -576,7 +561,7 @@ extern "C" int ptm_get_states(ptm_engine* e, double* X) {
   const size_t Nc = e->Nc, D = e->D;
   std::vector<double> soa(Nc * D);
   HIPCHK(hipStreamSynchronize(e->stream));
-  HIPCHK(hipMemcpy(soa.data(), e->x[e->cur], Nc * D * 8, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(soa.data(), e->x[e->cur], Nc * D * 8, hipMemcpyDeviceToHost));  // the first D of the DP planes
   for (size_t c = 0; c < Nc; ++c)
     for (size_t d = 0; d < D; ++d) X[c * D + d] = soa[d * Nc + c];
   return PTM_OK;
@@ -604,8 +589,16 @@ extern "C" int ptm_get_array(ptm_engine* e, int which, void* out) {
     case PTM_ARR_NTRIES: HIPCHK(hipMemcpy(out, e->ntries, Nc * 4, hipMemcpyDeviceToHost)); break;
     case PTM_ARR_NACCEPT: HIPCHK(hipMemcpy(out, e->naccept, Nc * 4, hipMemcpyDeviceToHost)); break;
     case PTM_ARR_LAST_TYPE: HIPCHK(hipMemcpy(out, e->last_type, Nc * 4, hipMemcpyDeviceToHost)); break;
-    case PTM_ARR_NHIST: HIPCHK(hipMemcpy(out, e->nhist, Nc * 8, hipMemcpyDeviceToHost)); break;
-    case PTM_ARR_NSIZE: HIPCHK(hipMemcpy(out, e->nsize, Nc * 8, hipMemcpyDeviceToHost)); break;
+    case PTM_ARR_NHIST:
+    case PTM_ARR_NSIZE: {
+      std::vector<unsigned int> h(Nc);
+      HIPCHK(hipMemcpy(h.data(), e->nhist, Nc * 4, hipMemcpyDeviceToHost));
+      int64_t* o = (int64_t*)out;
+      const int64_t N = e->cfg.add_every_n;
+      // add k (k = 0,1,..) appends a row iff k % N == 0 (chain.cc:935-946); one row exists after initialize(1)
+      for (size_t c = 0; c < Nc; ++c) o[c] = which == PTM_ARR_NHIST ? (int64_t)h[c] : 1 + ((int64_t)h[c] + N - 1) / N;
+      break;
+    }
     default: return fail(PTM_ERR_INVALID, "unknown array id %d", which);
   }
   return PTM_OK;
@@ -663,8 +656,8 @@ extern "C" int ptm_get_kernel_times(ptm_engine* e, float* ms, int capacity, int*
 extern "C" const char* ptm_sweep_kernel_name(ptm_engine* e) {
   if (!e) return "";
   char b[96];
-  const char* k = e->prop_kind == PTM_PROP_DIAG ? "1" : (e->prop_kind == PTM_PROP_LOWER ? "2" : "0");
-  snprintf(b, sizeof b, "sweep_kernel<%d, %s, %s>", e->DP, k, (e->W % 64) == 0 ? "true" : "false");
+  const SweepSel s = sweep_sel(e);
+  snprintf(b, sizeof b, "sweep_kernel<%d, %d, %s, %s>", e->DP, s.kind, s.uni ? "true" : "false", s.simple ? "true" : "false");
   e->kname = b;
   return e->kname.c_str();
 }
@@ -720,23 +713,40 @@ extern "C" int ptm_debug_boxmuller(int device, const uint32_t* k1, const uint32_
   return PTM_OK;
 }
 
+extern "C" int ptm_debug_sqrt_scan(int device, uint64_t* mismatches) {
+  int rc = need_device();
+  if (rc) return rc;
+  if (!mismatches) return fail(PTM_ERR_INVALID, "null argument");
+  if (device >= 0) HIPCHK(hipSetDevice(device));
+  unsigned long long* d = nullptr;
+  HIPCHK(hipMalloc((void**)&d, 8));
+  HIPCHK(hipMemset(d, 0, 8));
+  hipLaunchKernelGGL(debug_sqrt_scan_kernel, dim3(256 * 16), dim3(256), 0, 0, d);
+  HIPCHK(hipGetLastError());
+  unsigned long long v = 0;
+  HIPCHK(hipMemcpy(&v, d, 8, hipMemcpyDeviceToHost));
+  (void)hipFree(d);
+  *mismatches = v;
+  return PTM_OK;
+}
+
 extern "C" int ptm_debug_evaluate(ptm_engine* e, const double* X, int n, int32_t* valid, double* Xe, double* lprior, double* llike) {
   if (!e || !X || n < 1) return fail(PTM_ERR_INVALID, "bad argument");
-  const size_t D = e->D;
-  std::vector<double> soa((size_t)n * D);
+  const size_t D = e->D, DP = e->DP;
+  std::vector<double> soa((size_t)n * DP, 0.0);
   for (size_t c = 0; c < (size_t)n; ++c)
     for (size_t d = 0; d < D; ++d) soa[d * n + c] = X[c * D + d];
   double *dx = nullptr, *dlp = nullptr, *dll = nullptr;
   int* dv = nullptr;
-  HIPCHK(hipMalloc((void**)&dx, (size_t)n * D * 8));
+  HIPCHK(hipMalloc((void**)&dx, (size_t)n * DP * 8));
   HIPCHK(hipMalloc((void**)&dlp, (size_t)n * 8));
   HIPCHK(hipMalloc((void**)&dll, (size_t)n * 8));
   HIPCHK(hipMalloc((void**)&dv, (size_t)n * 4));
-  HIPCHK(hipMemcpy(dx, soa.data(), (size_t)n * D * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dx, soa.data(), (size_t)n * DP * 8, hipMemcpyHostToDevice));
   int rc = run_eval(e, n, dx, dv, dlp, dll, e->have_target ? 1 : 0);
   if (rc) return rc;
   HIPCHK(hipStreamSynchronize(e->stream));
-  HIPCHK(hipMemcpy(soa.data(), dx, (size_t)n * D * 8, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(soa.data(), dx, (size_t)n * DP * 8, hipMemcpyDeviceToHost));
   if (Xe)
     for (size_t c = 0; c < (size_t)n; ++c)
       for (size_t d = 0; d < D; ++d) Xe[c * D + d] = soa[d * n + c];

@@ -1,0 +1,25 @@
+// ptm_launch.hpp -- host-side launch entry points of the per-dimension translation units.
+// The fused sweep kernel is instantiated for DP in {4,8,16,32}; each DP lives in its own .hip file so the
+// (large, fully unrolled) kernels compile in parallel.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "ptm_kernels.hpp"
+
+namespace ptm {
+struct SweepSel {
+  int kind;     // KIND_DENSE / KIND_DIAG / KIND_LOWER
+  bool uni;     // W % 64 == 0: wave-uniform rung
+  bool simple;  // open bounds, all-uniform prior, zero mean, no 1-D moves
+};
+#define PTM_DECL_DP(N)                                                                                              \
+  hipError_t launch_sweep_##N(const Dev& p, SweepSel s, hipStream_t st);                                            \
+  hipError_t launch_eval_##N(const Dev& p, int n, double* x, int* valid, double* lp, double* ll, int eval_like,     \
+                             hipStream_t st);                                                                       \
+  hipError_t launch_init_##N(const Dev& p, double* x, double* ll, double* lp, int* fail, hipStream_t st);
+PTM_DECL_DP(4)
+PTM_DECL_DP(8)
+PTM_DECL_DP(16)
+PTM_DECL_DP(32)
+#undef PTM_DECL_DP
+}  // namespace ptm

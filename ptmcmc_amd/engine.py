@@ -17,17 +17,17 @@ BOUND_OPEN, BOUND_LIMIT, BOUND_REFLECT, BOUND_WRAP = 0, 1, 2, 3
 PRIOR_FLAT, PRIOR_UNIFORM, PRIOR_GAUSSIAN, PRIOR_POLAR, PRIOR_COPOLAR, PRIOR_LOG = 0, 1, 2, 3, 4, 5
 PROP_DENSE, PROP_DIAG, PROP_LOWER = 0, 1, 2
 ARR_LLIKE, ARR_LPRIOR, ARR_LPOST, ARR_NTRIES, ARR_NACCEPT, ARR_LAST_TYPE, ARR_NHIST, ARR_NSIZE = range(8)
-FN_LOG, FN_EXP, FN_SIN_0_PI, FN_COS_HPI, FN_SQRT, FN_DIV = range(6)
+FN_LOG, FN_EXP, FN_SIN_0_PI, FN_COS_HPI, FN_SQRT, FN_DIV, FN_SQRT_RAW = range(7)
 PRIOR_NAMES = {"uni": 1, "uniform": 1, "gauss": 2, "gaussian": 2, "pol": 3, "polar": 3, "cpol": 4, "copol": 4, "log": 5}
 
 EXPORTS = [
     "ptm_last_error", "ptm_abi_version", "ptm_device_count", "ptm_engine_create", "ptm_engine_destroy",
     "ptm_set_bounds", "ptm_set_prior", "ptm_set_target_gaussian", "ptm_set_target_callback", "ptm_set_ladder",
     "ptm_set_proposals", "ptm_set_states", "ptm_init_from_prior", "ptm_sweep", "ptm_step", "ptm_sync",
-    "ptm_llike_device_ptr", "ptm_exchange_decide", "ptm_exchange_finish_and_sweep", "ptm_get_states",
+    "ptm_llike_device_ptr", "ptm_exchange_decide", "ptm_exchange_finish_and_sweep", "ptm_exchange_buffer_doubles", "ptm_get_states",
     "ptm_get_array", "ptm_get_swap_counts", "ptm_get_last_swaps", "ptm_max_swaps_per_step", "ptm_step_count",
     "ptm_timer_start", "ptm_timer_stop", "ptm_get_kernel_times", "ptm_sweep_kernel_name", "ptm_debug_eval",
-    "ptm_debug_philox", "ptm_debug_boxmuller", "ptm_debug_evaluate",
+    "ptm_debug_philox", "ptm_debug_boxmuller", "ptm_debug_sqrt_scan", "ptm_debug_evaluate",
 ]
 
 
@@ -91,6 +91,8 @@ def load():
     L.ptm_debug_eval.argtypes = [C.c_int, C.c_int, _dp, _dp, _dp, C.c_int]
     L.ptm_debug_philox.argtypes = [C.c_int, C.c_uint64, C.c_int, C.c_uint32, C.c_uint64, C.c_uint32, _u32p]
     L.ptm_debug_boxmuller.argtypes = [C.c_int, _u32p, _u32p, _dp, _dp, C.c_int]
+    L.ptm_exchange_buffer_doubles.argtypes = [C.c_void_p]
+    L.ptm_debug_sqrt_scan.argtypes = [C.c_int, C.POINTER(C.c_uint64)]
     L.ptm_debug_evaluate.argtypes = [C.c_void_p, _dp, C.c_int, _i32p, _dp, _dp, _dp]
     _lib = L
     return L
@@ -129,6 +131,12 @@ def debug_boxmuller(k1, k2, device=-1):
     z0, z1 = np.empty(k1.size), np.empty(k1.size)
     _chk(load().ptm_debug_boxmuller(device, k1.ctypes.data_as(_u32p), k2.ctypes.data_as(_u32p), _d(z0), _d(z1), k1.size))
     return z0, z1
+
+
+def debug_sqrt_scan(device=-1):
+    n = C.c_uint64()
+    _chk(load().ptm_debug_sqrt_scan(device, C.byref(n)))
+    return n.value
 
 
 def geometric_ladder(n_rungs, tmax):
@@ -226,6 +234,10 @@ class Engine:
 
     def exchange_decide(self, llike_global_dev, send_up_dev, send_down_dev):
         _chk(self.L.ptm_exchange_decide(self.h, llike_global_dev, send_up_dev, send_down_dev))
+
+    @property
+    def exchange_buffer_doubles(self):
+        return self.L.ptm_exchange_buffer_doubles(self.h)
 
     def exchange_finish_and_sweep(self, recv_below_dev, recv_above_dev):
         _chk(self.L.ptm_exchange_finish_and_sweep(self.h, recv_below_dev, recv_above_dev))
