@@ -8,8 +8,8 @@ namespace ptm {
 // exchange phase of parallel_tempering_chains::step (chain.cc:1410-1537), one wave per walker-ladder.
 // Candidate draws are parallel over lanes; the in-order filter and trials (quirk Q6: later picks see the
 // in-place updated view) run on lane 0 over LDS copies of the picked rungs' llikes.
-// The kernel moves no state: it names, for every local rung that took part, the row its state comes from
-// (src[]) and the number of add_state calls it received (touch[]); the sweep kernel does the move.
+// The kernel moves no state: it names, for every local row that took part, the slot it moves to (dst[]) and the
+// number of add_state calls its rung received (touch[]); the sweep kernel does the move.
 // ------------------------------------------------------------------------------------------------
 struct Decide {
   int DP, Nt, r0, nloc, W, Nc, ms;
@@ -20,8 +20,9 @@ struct Decide {
   const double* x_in;         // local state planes (for packing departures)
   const double* ll_in;
   const double* lp_in;
-  int* src;
+  int* dst;
   unsigned char* touch;
+  int *arr_below, *arr_above;      // [W]
   long long *swap_try, *swap_acc;  // [W][Nt-1]
   int *last_pairs, *last_acc;      // [W][ms]
   double *send_up, *send_down;     // [(DP+2)][W] or null
@@ -34,9 +35,10 @@ __global__ __launch_bounds__(64) void decide_kernel(const Decide p) {
   const int lane = threadIdx.x;
   const int Nt = p.Nt, ms = p.ms;
   // LDS carve (all offsets multiples of 8)
-  double* llc = reinterpret_cast<double*>(smem);                              // [Nt]
-  unsigned int* ukey = reinterpret_cast<unsigned int*>(llc + Nt);             // [ms]
-  int* cand = reinterpret_cast<int*>(ukey + ((ms + 1) & ~1));                 // [ms]
+  double* llc = reinterpret_cast<double*>(smem);                              // [Nt]   llike view of the picked rungs
+  double* lu = llc + Nt;                                                      // [ms]   log(u_accept) per candidate
+  double* db = lu + ms;                                                       // [ms]   beta[i+1]-beta[i] per candidate
+  int* cand = reinterpret_cast<int*>(db + ms);                                // [ms]
   int* accf = cand + ((ms + 1) & ~1);                                         // [ms]
   unsigned short* perm = reinterpret_cast<unsigned short*>(accf + ((ms + 1) & ~1));  // [Nt]
   unsigned char* tch = reinterpret_cast<unsigned char*>(perm + ((Nt + 3) & ~3));     // [Nt]
@@ -52,7 +54,7 @@ __global__ __launch_bounds__(64) void decide_kernel(const Decide p) {
     int n = -2;
     if (Nt > 1 && u01(o.v0) < p.thresh) n = (int)(u01(o.v1) * (Nt - 1));
     cand[k] = n;
-    ukey[k] = o.v2;
+    lu[k] = dlog_u01(o.v2);  // the accept uniform's slot is reserved whether or not it is needed (cf. Q5)
     accf[k] = 0;
   }
   __syncthreads();
@@ -72,6 +74,7 @@ __global__ __launch_bounds__(64) void decide_kernel(const Decide p) {
     if (n < 0) continue;
     llc[n] = p.llg[(size_t)n * p.W + w];
     llc[n + 1] = p.llg[(size_t)(n + 1) * p.W + w];
+    db[k] = p.beta[n + 1] - p.beta[n];
     perm[n] = (unsigned short)n;
     perm[n + 1] = (unsigned short)(n + 1);
     tch[n] = 0;
@@ -80,8 +83,6 @@ __global__ __launch_bounds__(64) void decide_kernel(const Decide p) {
   __syncthreads();
   // -- trials in pick order (chain.cc:1436-1537)
   if (lane == 0) {
-    long long* st = p.swap_try + (size_t)w * (Nt - 1);
-    long long* sa = p.swap_acc + (size_t)w * (Nt - 1);
     for (int k = 0; k < ms; ++k) {
       const int i = cand[k];
       if (i < 0) continue;
@@ -89,19 +90,17 @@ __global__ __launch_bounds__(64) void decide_kernel(const Decide p) {
       if (!(lla > -1e200)) lla = -1e200;
       double llb = llc[i + 1];
       if (!(llb > -1e200)) llb = -1e200;
-      const double logH = -(p.beta[i + 1] - p.beta[i]) * (llb - lla);
+      const double logH = -db[k] * (llb - lla);
       bool acc = true;
-      if (logH < 0) acc = dlog(u01(ukey[k])) < logH;
+      if (logH < 0) acc = lu[k] < logH;
       if (acc) {
         if (i + 1 == p.r0) *down_src_p = perm[i + 1];  // the row that leaves this shard downwards
         const double t = llc[i]; llc[i] = llc[i + 1]; llc[i + 1] = t;
         const unsigned short s = perm[i]; perm[i] = perm[i + 1]; perm[i + 1] = s;
-        sa[i] += 1;
         accf[k] = 1;
       }
       tch[i] += 1;
       tch[i + 1] += 1;
-      st[i] += 1;
     }
   }
   __syncthreads();
@@ -113,12 +112,18 @@ __global__ __launch_bounds__(64) void decide_kernel(const Decide p) {
     p.last_pairs[(size_t)w * ms + k] = i;
     p.last_acc[(size_t)w * ms + k] = accf[k];
     if (i < 0) continue;
+    // swap_count / swap_accept_count (chain.cc:1498,1536): a pair is tried at most once per step, so no two lanes
+    // of this wave (the only writer of walker w's counters) touch the same entry
+    p.swap_try[(size_t)w * (Nt - 1) + i] += 1;
+    if (accf[k]) p.swap_acc[(size_t)w * (Nt - 1) + i] += 1;
     for (int r = i; r <= i + 1; ++r) {
-      if (r < p.r0 || r >= r1) continue;
-      const int c = (r - p.r0) * p.W + w;
+      // rung r ends the phase holding the row that started the step at rung s = perm[r]: publish the move from the
+      // row's point of view (dst of the source slot) -- or, for a row coming from another shard, its landing slot
       const int s = perm[r];
-      p.touch[c] = tch[r];
-      p.src[c] = (s >= p.r0 && s < r1) ? (s - p.r0) * p.W + w : (s >= r1 ? SRC_ABOVE : SRC_BELOW);
+      const bool r_local = r >= p.r0 && r < r1, s_local = s >= p.r0 && s < r1;
+      if (r_local) p.touch[(r - p.r0) * p.W + w] = tch[r];
+      if (s_local) p.dst[(s - p.r0) * p.W + w] = r_local ? (r - p.r0) * p.W + w : DST_GONE;
+      else if (r_local) (s >= r1 ? p.arr_above : p.arr_below)[w] = (r - p.r0) * p.W + w;
     }
     if (accf[k] && i + 1 == r1 && r1 < Nt && p.send_up) {
       // exchange across the upper shard boundary: our top rung's row (always its start-of-step content) goes up

@@ -44,7 +44,8 @@ struct ptm_engine {
   int cur = 0;
   // device state
   double *x[2] = {nullptr, nullptr}, *ll[2] = {nullptr, nullptr}, *lp[2] = {nullptr, nullptr};
-  int *ntries = nullptr, *naccept = nullptr, *last_type = nullptr, *src = nullptr, *err = nullptr;
+  int *ntries = nullptr, *naccept = nullptr, *last_type = nullptr, *dst = nullptr, *err = nullptr;
+  int *arr_below = nullptr, *arr_above = nullptr;
   unsigned int* nhist = nullptr;
   long long *swap_try = nullptr, *swap_acc = nullptr;
   unsigned char* touch = nullptr;
@@ -52,7 +53,7 @@ struct ptm_engine {
   // device problem description
   int *blo = nullptr, *bhi = nullptr, *ptype = nullptr;
   double *bmin = nullptr, *bmax = nullptr, *plo = nullptr, *phi = nullptr, *pcoef = nullptr;
-  double *P2 = nullptr, *mean = nullptr, *beta = nullptr, *prop = nullptr, *onedfrac = nullptr;
+  double *P2 = nullptr, *mean = nullptr, *beta = nullptr, *prop = nullptr, *prop_dense = nullptr, *onedfrac = nullptr;
   // host copies / flags
   int has_bounds = 0, origin_valid = 1, all_uniform = 1, has_mean = 0, have_target = 0, have_ladder = 0,
       have_prop = 0, have_state = 0, prop_kind = KIND_DIAG, prop_stride = 0, any_oned = 0;
@@ -139,7 +140,8 @@ extern "C" int ptm_engine_create(const ptm_config* cfg, ptm_engine** out) {
     if ((rc = dalloc(&e->lp[b], Nc))) return rc;
   }
   if ((rc = dalloc(&e->ntries, Nc)) || (rc = dalloc(&e->naccept, Nc)) || (rc = dalloc(&e->last_type, Nc)) ||
-      (rc = dalloc(&e->src, Nc)) || (rc = dalloc(&e->touch, Nc)) || (rc = dalloc(&e->nhist, Nc)) ||
+      (rc = dalloc(&e->dst, Nc)) || (rc = dalloc(&e->arr_below, (size_t)cfg->n_walkers)) ||
+      (rc = dalloc(&e->arr_above, (size_t)cfg->n_walkers)) || (rc = dalloc(&e->touch, Nc)) || (rc = dalloc(&e->nhist, Nc)) ||
       (rc = dalloc(&e->err, 4)))
     return rc;
   const size_t np = (size_t)e->W * (e->Nt > 1 ? e->Nt - 1 : 1);
@@ -177,9 +179,9 @@ extern "C" int ptm_engine_create(const ptm_config* cfg, ptm_engine** out) {
 extern "C" int ptm_engine_destroy(ptm_engine* e) {
   if (!e) return PTM_OK;
   (void)hipStreamSynchronize(e->stream);
-  void* ptrs[] = {e->x[0], e->x[1], e->ll[0], e->ll[1], e->lp[0], e->lp[1], e->ntries, e->naccept, e->last_type, e->src,
+  void* ptrs[] = {e->x[0], e->x[1], e->ll[0], e->ll[1], e->lp[0], e->lp[1], e->ntries, e->naccept, e->last_type, e->dst, e->arr_below, e->arr_above,
                   e->err, e->nhist, e->swap_try, e->swap_acc, e->touch, e->last_pairs, e->last_acc, e->blo,
-                  e->bhi, e->ptype, e->bmin, e->bmax, e->plo, e->phi, e->pcoef, e->P2, e->mean, e->beta, e->prop, e->onedfrac};
+                  e->bhi, e->ptype, e->bmin, e->bmax, e->plo, e->phi, e->pcoef, e->P2, e->mean, e->beta, e->prop, e->prop_dense, e->onedfrac};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (hipEvent_t ev : e->kev) (void)hipEventDestroy(ev);
@@ -319,12 +321,19 @@ extern "C" int ptm_set_proposals(ptm_engine* e, int kind, const double* factors,
       for (int i = 0; i < D; ++i)
         for (int j = 0; j < D; ++j) packed[(size_t)r * stride + (size_t)j * DP + i] = factors[(size_t)r * D * D + (size_t)i * D + j];
   } else if (kind == PTM_PROP_LOWER) {
-    stride = DP * (DP + 1) / 2;  // packed columns: column j holds rows j..DP-1 at offset j*DP - j(j-1)/2
+    // column panels of PC columns (ptm_kernels.hpp, Panels<DP>): panel P = columns [PC*P, PC*P+PC) x rows [PC*P, DP),
+    // column-major inside the panel
+    const int PC = DP >= 8 ? 8 : 4, NP = DP / PC;
+    std::vector<int> poff(NP + 1, 0);
+    for (int P = 0; P < NP; ++P) poff[P + 1] = poff[P] + PC * (DP - PC * P);
+    stride = poff[NP];
     packed.assign((size_t)nloc * stride, 0.0);
     for (int r = 0; r < nloc; ++r)
-      for (int j = 0; j < D; ++j)
+      for (int j = 0; j < D; ++j) {
+        const int P = j / PC, R0 = PC * P, NR = DP - R0;
         for (int i = j; i < D; ++i)
-          packed[(size_t)r * stride + (size_t)(j * DP - (j * (j - 1)) / 2) + (i - j)] = factors[(size_t)r * D * D + (size_t)i * D + j];
+          packed[(size_t)r * stride + poff[P] + (size_t)(j - R0) * NR + (i - R0)] = factors[(size_t)r * D * D + (size_t)i * D + j];
+      }
     for (int r = 0; r < nloc; ++r)
       for (int i = 0; i < D; ++i)
         for (int j = i + 1; j < D; ++j)
@@ -334,8 +343,17 @@ extern "C" int ptm_set_proposals(ptm_engine* e, int kind, const double* factors,
     return fail(PTM_ERR_INVALID, "unknown proposal kind %d", kind);
   }
   if (e->prop) { HIPCHK(hipStreamSynchronize(e->stream)); HIPCHK(hipFree(e->prop)); e->prop = nullptr; }
+  if (e->prop_dense) { HIPCHK(hipFree(e->prop_dense)); e->prop_dense = nullptr; }
   int rc;
   if ((rc = dalloc(&e->prop, packed.size())) || (rc = upload(e->prop, packed.data(), packed.size(), e->stream))) return rc;
+  if (kind != PTM_PROP_DIAG) {
+    // dense column-major image (element (i,j) at j*DP + i), used by the wave-uniform DPP product
+    std::vector<double> dense((size_t)nloc * DP * DP, 0.0);
+    for (int r = 0; r < nloc; ++r)
+      for (int i = 0; i < D; ++i)
+        for (int j = 0; j < D; ++j) dense[(size_t)r * DP * DP + (size_t)j * DP + i] = factors[(size_t)r * D * D + (size_t)i * D + j];
+    if ((rc = dalloc(&e->prop_dense, dense.size())) || (rc = upload(e->prop_dense, dense.data(), dense.size(), e->stream))) return rc;
+  }
   std::vector<double> f(nloc, 0.0);
   e->any_oned = 0;
   if (one_d_frac)
@@ -360,11 +378,11 @@ static Dev make_dev(ptm_engine* e) {
   p.all_uniform = e->all_uniform; p.lprior_const = e->lprior_const;
   p.ptype = e->ptype; p.plo = e->plo; p.phi = e->phi; p.pcoef = e->pcoef;
   p.P2 = e->P2; p.mean = e->mean; p.has_mean = e->has_mean; p.like0 = e->like0;
-  p.beta = e->beta; p.prop = e->prop; p.onedfrac = e->onedfrac; p.prop_stride = e->prop_stride; p.any_oned = e->any_oned;
+  p.beta = e->beta; p.prop = e->prop; p.prop_dense = e->prop_dense; p.onedfrac = e->onedfrac; p.prop_stride = e->prop_stride; p.any_oned = e->any_oned;
   const int in = e->cur, out = 1 - e->cur;
   p.x_in = e->x[in]; p.x_out = e->x[out]; p.ll_in = e->ll[in]; p.ll_out = e->ll[out]; p.lp_in = e->lp[in]; p.lp_out = e->lp[out];
   p.ntries = e->ntries; p.naccept = e->naccept; p.last_type = e->last_type; p.nhist = e->nhist;
-  p.src = e->src; p.touch = e->touch; p.err = e->err;
+  p.dst = e->dst; p.touch = e->touch; p.arr_below = e->arr_below; p.arr_above = e->arr_above; p.err = e->err;
   return p;
 }
 
@@ -404,7 +422,7 @@ static int launch_sweep(ptm_engine* e, const double* recv_below, const double* r
 
 static size_t decide_lds_bytes(int Nt, int ms) {
   const size_t msp = (size_t)((ms + 1) & ~1);
-  return (size_t)Nt * 8 + msp * 4 * 3 + (size_t)((Nt + 3) & ~3) * 2 + (size_t)((Nt + 7) & ~7) + (size_t)((Nt + 1 + 7) & ~7) + 16;
+  return (size_t)Nt * 8 + (size_t)ms * 16 + msp * 4 * 2 + (size_t)((Nt + 3) & ~3) * 2 + (size_t)((Nt + 7) & ~7) + (size_t)((Nt + 1 + 7) & ~7) + 16;
 }
 
 static int launch_decide(ptm_engine* e, const double* llg, double* send_up, double* send_down) {
@@ -413,7 +431,7 @@ static int launch_decide(ptm_engine* e, const double* llg, double* send_up, doub
   p.DP = e->DP; p.Nt = e->Nt; p.r0 = e->r0; p.nloc = e->nloc; p.W = e->W; p.Nc = e->Nc; p.ms = e->ms;
   p.seed = e->cfg.seed; p.step = e->step; p.thresh = e->thresh;
   p.beta = e->beta; p.llg = llg; p.x_in = e->x[e->cur]; p.ll_in = e->ll[e->cur]; p.lp_in = e->lp[e->cur];
-  p.src = e->src; p.touch = e->touch; p.swap_try = e->swap_try; p.swap_acc = e->swap_acc;
+  p.dst = e->dst; p.touch = e->touch; p.arr_below = e->arr_below; p.arr_above = e->arr_above; p.swap_try = e->swap_try; p.swap_acc = e->swap_acc;
   p.last_pairs = e->last_pairs; p.last_acc = e->last_acc; p.send_up = send_up; p.send_down = send_down; p.err = e->err;
   const size_t lds = decide_lds_bytes(e->Nt, e->ms);
   if (lds > 160 * 1024) return fail(PTM_ERR_UNSUPPORTED, "ladder too long for the LDS-resident exchange kernel (%zu B)", lds);
@@ -441,10 +459,12 @@ static int reset_counters(ptm_engine* e) {
   for (size_t c = 0; c < Nc; ++c) ident[c] = (int)c;
   int rc;
   if ((rc = upload(e->ntries, one.data(), Nc, e->stream)) || (rc = upload(e->naccept, one.data(), Nc, e->stream)) ||  // chain.cc:649
-      (rc = upload(e->last_type, m1.data(), Nc, e->stream)) || (rc = upload(e->src, ident.data(), Nc, e->stream)) ||
+      (rc = upload(e->last_type, m1.data(), Nc, e->stream)) || (rc = upload(e->dst, ident.data(), Nc, e->stream)) ||
       (rc = upload(e->nhist, z.data(), Nc, e->stream)))                                                        // chain.cc:871-875
     return rc;
   HIPCHK(hipMemsetAsync(e->touch, 0, Nc, e->stream));
+  HIPCHK(hipMemsetAsync(e->arr_below, 0xFF, (size_t)e->W * 4, e->stream));
+  HIPCHK(hipMemsetAsync(e->arr_above, 0xFF, (size_t)e->W * 4, e->stream));
   e->step = 0;
   return PTM_OK;
 }

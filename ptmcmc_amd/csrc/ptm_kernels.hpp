@@ -6,8 +6,13 @@
 //   llike  [2][Nc], lprior [2][Nc]  double         (lpost is always fl(lprior + fl(beta*llike)), chain.cc:928)
 //   ntries, naccept, last_type [Nc] int32; nhist [Nc] uint32          (MH_chain counters, chain.hh:150-170;
 //                              Nsize is a function of Nhist: 1 + ceil(nhist / add_every_N), chain.cc:935-947)
-//   src [Nc] int32, touch [Nc] uint8   exchange phase -> sweep hand-off: where the chain's state comes from
-//                                      this step and how many add_state calls it already received
+//   dst [Nc] int32, touch [Nc] uint8   exchange phase -> sweep hand-off: where the chain's CURRENT row goes this
+//                                      step (its own slot unless an exchange moved it; -1 = it left the shard) and
+//                                      how many add_state calls the rung received; arr_above/arr_below [W] name the
+//                                      slot where a row arriving from the adjacent shard lands.
+//                                      Rows are PUSHED: every lane reads its own row (coalesced) and the few moved
+//                                      ones store to another rung's slot -- scattered 8-byte writes that L2 merges,
+//                                      instead of scattered reads on the critical path.
 // Walker is the fastest index, so the 64 lanes of a wave hold 64 walkers of ONE rung whenever W % 64 == 0:
 // beta, the proposal factor and the precision matrix are then wave-uniform and are fetched through the scalar
 // cache straight into SGPR operands of v_fma_f64 (constant-address-space loads), while every state plane is read
@@ -20,6 +25,10 @@
 
 // keeps the scheduler from hoisting every scalar table load of the unrolled mat-vecs to the top of the kernel
 // (which spills SGPRs by the thousand); one fence per factor column / precision row
+// minimum waves per SIMD the fused sweep kernel is compiled for (register budget 512 / waves)
+#ifndef PTM_SWEEP_WAVES
+#define PTM_SWEEP_WAVES 3
+#endif
 #ifndef PTM_SCHED_FENCE
 #define PTM_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #endif
@@ -27,12 +36,17 @@
 namespace ptm {
 
 enum { KIND_DENSE = 0, KIND_DIAG = 1, KIND_LOWER = 2 };
-enum { SRC_ABOVE = -2, SRC_BELOW = -3 };
+enum { DST_GONE = -1 };
 enum { B_OPEN = 0, B_LIMIT = 1, B_REFLECT = 2, B_WRAP = 3 };
 enum { P_FLAT = 0, P_UNIFORM = 1, P_GAUSSIAN = 2, P_POLAR = 3, P_COPOLAR = 4, P_LOG = 5 };
 
 // read-only tables written by the host before any launch: reading them through the constant address space lets
 // the backend use scalar loads whenever the address is wave-uniform, with no alias analysis in the way.
+// register-resident per-lane vectors: constant-index element access on an ext_vector is pure SSA (no alloca), so the
+// accumulators survive the non-unrolled draw loops in VGPRs
+template <int N>
+using vecd = double __attribute__((ext_vector_type(N)));
+
 typedef const double __attribute__((address_space(4))) * cdp;
 typedef const int __attribute__((address_space(4))) * cip;
 __device__ __forceinline__ cdp as_c(const double* p) { return (cdp)(uintptr_t)p; }
@@ -61,6 +75,7 @@ struct Dev {
   // ladder + proposals
   const double* beta;      // [Nt] global
   const double* prop;      // [nloc][prop_stride]  column-packed factor or sigmas
+  const double* prop_dense;  // [nloc][DP*DP] dense column-major image (zeros above the diagonal) for the DPP product
   const double* onedfrac;  // [nloc]
   int prop_stride, any_oned;
   // state
@@ -69,8 +84,9 @@ struct Dev {
   const double* lp_in; double* lp_out;
   int *ntries, *naccept, *last_type;
   unsigned int* nhist;
-  int* src;
+  int* dst;
   unsigned char* touch;
+  int *arr_below, *arr_above;             // [W] landing slot of the row arriving across the lower / upper boundary, or -1
   const double *recv_below, *recv_above;  // [(DP+2)][W] rows that crossed the shard boundary this step
   int* err;
 };
@@ -161,8 +177,8 @@ __device__ __noinline__ double enforce_and_lprior(const Dev& p, double (&x)[DP],
 }
 
 // like0 - 1/2 y^T P y in the symmetric-packed order q = sum_i y_i (P_ii y_i + sum_{j<i} 2P_ij y_j)
-template <int DP, bool MEAN>
-__device__ __forceinline__ double gauss_llike(const Dev& p, const double (&x)[DP]) {
+template <int DP, bool MEAN, class XV>
+__device__ __forceinline__ double gauss_llike(const Dev& p, const XV& x) {
   double q = 0;
   cdp row = as_c(p.P2);
   cdp mean = as_c(p.mean);
@@ -178,9 +194,134 @@ __device__ __forceinline__ double gauss_llike(const Dev& p, const double (&x)[DP
     s = __builtin_fma(row[i], yi, s);
     q = __builtin_fma(yi, s, q);
     row += i + 1;
-    PTM_SCHED_FENCE();
   }
   return p.like0 - 0.5 * q;
+}
+
+// ------------------------------------------------------------------------------------------------
+// gaussian_prop::draw (proposal_distribution.hh:194-218): offset = factor * z, z ~ N(0,1)^D drawn four at a time
+// (one Philox block = two Box-Muller pairs).  Written as REAL loops over Philox blocks and factor columns -- only
+// the row index is unrolled, so the accumulators stay in registers, the code stays small, and the staged-table
+// reads of one column sit next to their FMAs (a fully unrolled version lets the scheduler hoist every table read
+// to the top and spill).  Lower-triangular factors are stored in column panels of 8 (4 for DP=4): panel P holds
+// columns [PC*P, PC*P+PC) x rows [PC*P, DP); the (few) structural zeros inside a panel contribute fma(0,z,acc)=acc.
+// ------------------------------------------------------------------------------------------------
+struct DrawCtx {
+  uint64_t seed, step;
+  uint32_t stream;
+  int axis;  // >= 0: one-dimensional move along that axis (proposal_distribution.hh:197-205), -1: full move
+};
+__device__ __forceinline__ void draw4(const DrawCtx& dc, int b, double (&z)[4]) {
+  const u32x4 o = draw_block(dc.seed, TAG_MH, dc.stream, dc.step, (uint32_t)(b + 1));
+#if defined(PTM_ABLATE) && (PTM_ABLATE & 1)
+  z[0] = 0.1 * (dc.stream & 7); z[1] = 0.2; z[2] = -0.1; z[3] = 0.05 * b;
+#elif defined(PTM_ABLATE) && (PTM_ABLATE & 8)
+  z[0] = u01(o.v0); z[1] = u01(o.v1); z[2] = u01(o.v2); z[3] = u01(o.v3);
+#else
+  boxmuller(o.v0, o.v1, z[0], z[1]);
+  boxmuller(o.v2, o.v3, z[2], z[3]);
+#endif
+  if (dc.axis >= 0) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      if (4 * b + t != dc.axis) z[t] = 0.0;
+  }
+}
+
+template <int DP>
+struct Panels {
+  static constexpr int PC = DP >= 8 ? 8 : 4;   // columns per panel
+  static constexpr int NP = DP / PC;           // panels
+  static constexpr int rows(int P) { return DP - PC * P; }
+  static constexpr int offset(int P) { return P == 0 ? 0 : offset(P - 1) + PC * rows(P - 1); }
+  static constexpr int lower_doubles = offset(NP);   // 640 for DP=32
+};
+
+// one column panel: acc[R0 + i] += T[R0 + i][j] * z_j  for the panel's columns j, rows R0..DP-1
+template <int DP, int R0, int NROW, int NCOLBLK, class TP>
+__device__ __forceinline__ void panel_product(const DrawCtx& dc, int first_block, TP tab, double (&acc)[DP]) {
+#pragma unroll 1
+  for (int bb = 0; bb < NCOLBLK; ++bb) {
+    double z[4];
+    draw4(dc, first_block + bb, z);
+#pragma unroll 1
+    for (int t = 0; t < 4; ++t) {
+      const double zj = z[0];
+      z[0] = z[1]; z[1] = z[2]; z[2] = z[3]; z[3] = zj;  // rotate: keeps the register index static
+      TP col = tab + (bb * 4 + t) * NROW;
+#if !(defined(PTM_ABLATE) && (PTM_ABLATE & 2))
+#pragma unroll
+      for (int i = 0; i < NROW; ++i) acc[R0 + i] = __builtin_fma(col[i], zj, acc[R0 + i]);
+#else
+      acc[R0] += zj;
+#endif
+    }
+  }
+}
+
+// ---- wave-uniform rung: broadcast-by-DPP factor product ------------------------------------------------------
+// The rung's factor (dense column-major in LDS, zeros above the diagonal for a Cholesky factor) is the same for all
+// 64 lanes.  Feeding it to v_fma_f64 as a broadcast LDS read costs a full 512-B register write-back per operand
+// (4 LDS clocks each: a quarter of the FMA rate), and as SGPR operands it misses the scalar cache (one factor per
+// rung).  Instead each column is read ONCE per 16 rows with every lane fetching "its" row element
+// (lane l <- T[l & 15 (+16)][j], 512 B per instruction, conflict-free), and the FMA takes its table operand from
+// lane i of each 16-lane row through the DPP row_newbcast control -- one VALU instruction per multiply-add, no
+// operand traffic.  All 64 lanes must be active (DPP reads lanes, not memory): callers run this with full EXEC.
+#define PTM_DPP_FMA(I) "v_fmac_f64_dpp %" #I ", %16, %17 row_newbcast:" #I " row_mask:0xf bank_mask:0xf\n\t"
+template <int NROW16>  // how many of the 16 rows of this half are live (16, or 8 for the half-height panels)
+__device__ __forceinline__ void dpp_fma16(double* a, double col, double z) {
+  // rows [16 - NROW16, 16) of the half: the leading rows of a lower-triangular panel are structural zeros
+  if constexpr (NROW16 == 16) {
+    asm("s_nop 1\n\t" PTM_DPP_FMA(0) PTM_DPP_FMA(1) PTM_DPP_FMA(2) PTM_DPP_FMA(3) PTM_DPP_FMA(4) PTM_DPP_FMA(5) PTM_DPP_FMA(6)
+        PTM_DPP_FMA(7) PTM_DPP_FMA(8) PTM_DPP_FMA(9) PTM_DPP_FMA(10) PTM_DPP_FMA(11) PTM_DPP_FMA(12) PTM_DPP_FMA(13)
+        PTM_DPP_FMA(14) PTM_DPP_FMA(15)
+        : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]),
+          "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15])
+        : "v"(col), "v"(z));
+  } else {
+    asm("s_nop 1\n\t" PTM_DPP_FMA(8) PTM_DPP_FMA(9) PTM_DPP_FMA(10) PTM_DPP_FMA(11) PTM_DPP_FMA(12) PTM_DPP_FMA(13)
+        PTM_DPP_FMA(14) PTM_DPP_FMA(15)
+        : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]),
+          "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15])
+        : "v"(col), "v"(z));
+  }
+}
+
+// columns [8*P8, 8*P8+8) of a 32-dimensional factor staged dense column-major at `tab` (LDS); LOWER skips the
+// row blocks that are structurally zero for this panel
+template <int KIND, int P8>
+__device__ __forceinline__ void dpp_panel32(const DrawCtx& dc, const double* tab, int lane16, double (&acc)[32]) {
+#pragma unroll 1
+  for (int bb = 0; bb < 2; ++bb) {
+    double z[4];
+    draw4(dc, 2 * P8 + bb, z);
+#pragma unroll 1
+    for (int t = 0; t < 4; ++t) {
+      const double zj = z[0];
+      z[0] = z[1]; z[1] = z[2]; z[2] = z[3]; z[3] = zj;
+      const double* col = tab + (8 * P8 + 4 * bb + t) * 32 + lane16;
+      if (KIND == KIND_DENSE || P8 < 2) {
+        const double ca = col[0];
+        if (KIND == KIND_DENSE || P8 == 0) dpp_fma16<16>(&acc[0], ca, zj); else dpp_fma16<8>(&acc[0], ca, zj);
+      }
+      const double cb = col[16];
+      if (KIND == KIND_DENSE || P8 < 3) dpp_fma16<16>(&acc[16], cb, zj); else dpp_fma16<8>(&acc[16], cb, zj);
+    }
+  }
+}
+
+template <int DP, int KIND, class TP>
+__device__ __forceinline__ void factor_product(const DrawCtx& dc, TP tab, double (&acc)[DP]) {
+  using PN = Panels<DP>;
+  if (KIND == KIND_DENSE) {
+    panel_product<DP, 0, DP, DP / 4, TP>(dc, 0, tab, acc);   // column-major dense: one panel of all columns
+  } else {
+    constexpr int BPP = PN::PC / 4;  // Philox blocks per panel
+    panel_product<DP, 0, PN::rows(0), BPP, TP>(dc, 0, tab + PN::offset(0), acc);
+    if constexpr (PN::NP > 1) panel_product<DP, PN::PC * 1, PN::rows(1), BPP, TP>(dc, BPP * 1, tab + PN::offset(1), acc);
+    if constexpr (PN::NP > 2) panel_product<DP, PN::PC * 2, PN::rows(2), BPP, TP>(dc, BPP * 2, tab + PN::offset(2), acc);
+    if constexpr (PN::NP > 3) panel_product<DP, PN::PC * 3, PN::rows(3), BPP, TP>(dc, BPP * 3, tab + PN::offset(3), acc);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -193,88 +334,109 @@ __device__ __forceinline__ double gauss_llike(const Dev& p, const double (&x)[DP
 //          the general state-space / prior code is not even compiled in.
 // ------------------------------------------------------------------------------------------------
 template <int DP, int KIND, bool UNI, bool SIMPLE>
-__global__ __launch_bounds__(256) void sweep_kernel(const Dev p) {
+__global__ __launch_bounds__(256, PTM_SWEEP_WAVES) void sweep_kernel(const Dev p) {
+  // Per-wave LDS staging of the rung's proposal factor (UNI only): every rung has its own D x D factor, so unlike
+  // the shared precision matrix it misses the scalar cache; one coalesced 512-B-per-instruction copy into LDS per
+  // wave, then wave-uniform (broadcast) LDS reads feed the mat-vec.  Same-wave LDS traffic only: no barrier.
+  extern __shared__ __attribute__((aligned(16))) double lds_fac[];
   const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= p.Nc) return;
-  int rl = c / p.W;
-  const int w = c - rl * p.W;
+  int rl = (c < p.Nc ? c : p.Nc - 1) / p.W;
   if (UNI) rl = __builtin_amdgcn_readfirstlane(rl);
+  // (DP == 32: the DPP product wants the dense column-major image, which the host keeps beside the packed one)
+  const int fstride = (UNI && DP == 32) ? DP * DP : p.prop_stride;
+  double* myfac = lds_fac + (threadIdx.x >> 6) * fstride;
+  if (UNI && KIND != KIND_DIAG) {
+    const double* g = ((UNI && DP == 32) ? p.prop_dense : p.prop) + (size_t)rl * fstride;
+    for (int k = threadIdx.x & 63; k < fstride; k += 64) myfac[k] = g[k];
+  }
+  if (c >= p.Nc) return;
+  const int w = c - rl * p.W;
   const int rg = p.r0 + rl;
   const int Nc = p.Nc;
 
-  const int sc = p.src[c];
-  const int tc = p.touch[c];
-
-  // ---- gather the chain's current state (its own row, a neighbour rung's row after an exchange, or an arrival)
-  double x[DP];
-  double ll, lp;
-  if (sc >= 0) {
-#pragma unroll
-    for (int d = 0; d < DP; ++d) x[d] = p.x_in[(size_t)d * Nc + sc];
-    ll = p.ll_in[sc];
-    lp = p.lp_in[sc];
-  } else {
-    const double* rb = (sc == SRC_ABOVE) ? p.recv_above : p.recv_below;
-#pragma unroll
-    for (int d = 0; d < DP; ++d) x[d] = rb[(size_t)d * p.W + w];
-    ll = rb[(size_t)DP * p.W + w];
-    lp = rb[(size_t)(DP + 1) * p.W + w];
-  }
-  unsigned int nhist = p.nhist[c];  // add_state calls since initialisation (chain.cc:947)
-
+  const int tc = p.touch[c];  // > 0: the rung took part in that many exchange attempts => no MH move this step
+  int out = c;                // slot this lane's row is written to
   if (tc) {
-    // rung took part in 1 or 2 exchange attempts: no MH move this step, one add_state per attempt
-    // (chain.cc:1487-1490,1531-1534,1554-1557)
-    nhist += (unsigned int)tc;
+    out = p.dst[c];
+    p.nhist[c] += (unsigned int)tc;  // one add_state per attempt (chain.cc:1487-1490,1531-1534,1554-1557)
     p.touch[c] = 0;
-    p.src[c] = c;
+    p.dst[c] = c;
+  }
+  // rows arriving from the adjacent shards are installed by the boundary rungs' lanes (one row per walker at most)
+  if (p.recv_above && rl == p.nloc - 1) {
+    const int a = p.arr_above[w];
+    if (a >= 0) {
+#pragma unroll
+      for (int d = 0; d < DP + 2; ++d) {
+        const double v = p.recv_above[(size_t)d * p.W + w];
+        if (d < DP) p.x_out[(size_t)d * Nc + a] = v; else if (d == DP) p.ll_out[a] = v; else p.lp_out[a] = v;
+      }
+      p.arr_above[w] = -1;
+    }
+  }
+  if (p.recv_below && rl == 0) {
+    const int a = p.arr_below[w];
+    if (a >= 0) {
+#pragma unroll
+      for (int d = 0; d < DP + 2; ++d) {
+        const double v = p.recv_below[(size_t)d * p.W + w];
+        if (d < DP) p.x_out[(size_t)d * Nc + a] = v; else if (d == DP) p.ll_out[a] = v; else p.lp_out[a] = v;
+      }
+      p.arr_below[w] = -1;
+    }
+  }
+
+  // ---- MH_chain::step for the untouched rungs; touched lanes idle through the draw loops
+  const uint32_t stream = (uint32_t)w * (uint32_t)p.Nt + (uint32_t)rg;
+  const u32x4 o0 = draw_block(p.seed, TAG_MH, stream, p.step, 0);
+
+  // -- gaussian_prop::draw: D normals, optional one-dimensional move, offset = factor * z
+  int type = 0, axis = -1;
+  if (!SIMPLE && p.any_oned) {
+    const double f = as_c(p.onedfrac)[rl];
+    if (!tc && f > 0 && u01(o0.v1) < f) { axis = (int)(p.D * u01(o0.v2)); type = 1; }
+  }
+  double xn[DP];  // accumulates the offset, then becomes the proposed state
+#pragma unroll
+  for (int i = 0; i < DP; ++i) xn[i] = 0.0;
+  const DrawCtx dc{p.seed, p.step, stream, (!SIMPLE) ? axis : -1};
+  // (touched lanes run the draw too: the DPP product needs every lane of the wave active, and they would idle anyway)
+  if (KIND == KIND_DIAG) {
+    cdp fac = as_c(p.prop) + (size_t)rl * p.prop_stride;
+#pragma unroll
+    for (int b = 0; b < DP / 4; ++b) {
+      double z[4];
+      draw4(dc, b, z);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) xn[4 * b + t] = fac[4 * b + t] * z[t];
+    }
+  } else if (UNI && DP == 32) {
+    if constexpr (DP == 32) {
+      const int lane16 = threadIdx.x & 15;
+      dpp_panel32<KIND, 0>(dc, myfac, lane16, xn);
+      dpp_panel32<KIND, 1>(dc, myfac, lane16, xn);
+      dpp_panel32<KIND, 2>(dc, myfac, lane16, xn);
+      dpp_panel32<KIND, 3>(dc, myfac, lane16, xn);
+    }
+  } else if (UNI) {
+    factor_product<DP, KIND>(dc, (const double*)myfac, xn);
   } else {
+    factor_product<DP, KIND>(dc, as_c(p.prop) + (size_t)rl * p.prop_stride, xn);
+  }
+
+  // -- current state: read only now (its registers are not live across the draw loops) and folded straight into the
+  //    proposal; every lane reads its own row, one fully coalesced access per plane for the whole wave.  The old
+  //    state is NOT kept: a rejected (or merely moved) row is re-read at the end -- an L2 / Infinity-Cache hit, the
+  //    row was fetched a few microseconds earlier -- which halves the live register set of the quadratic form.
+  double ll = p.ll_in[c], lp = p.lp_in[c];
+  bool accept = false;
+  if (!tc) {
+#pragma unroll
+    for (int d = 0; d < DP; ++d) xn[d] = p.x_in[(size_t)d * Nc + c] + xn[d];  // state::add (states.cc:205-214)
     const double beta = as_c(p.beta)[rg];
     const double bl = beta * ll;
     const double cur_lpost = lp + bl;
     const double oldlprior = cur_lpost - bl;  // chain.cc:973
-    const uint32_t stream = (uint32_t)w * (uint32_t)p.Nt + (uint32_t)rg;
-    const u32x4 o0 = draw_block(p.seed, TAG_MH, stream, p.step, 0);
-
-    // -- gaussian_prop::draw: D normals, optional one-dimensional move, offset = factor * z
-    int type = 0, axis = -1;
-    if (!SIMPLE && p.any_oned) {
-      const double f = as_c(p.onedfrac)[rl];
-      if (f > 0 && u01(o0.v1) < f) { axis = (int)(p.D * u01(o0.v2)); type = 1; }
-    }
-    cdp fac = as_c(p.prop) + (size_t)rl * p.prop_stride;
-    double acc[DP];
-#pragma unroll
-    for (int i = 0; i < DP; ++i) acc[i] = 0.0;
-#pragma unroll
-    for (int b = 0; b < DP / 4; ++b) {
-      const u32x4 o = draw_block(p.seed, TAG_MH, stream, p.step, (uint32_t)(b + 1));
-      double z[4];
-      boxmuller(o.v0, o.v1, z[0], z[1]);
-      boxmuller(o.v2, o.v3, z[2], z[3]);
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int j = 4 * b + t;
-        double zj = z[t];
-        if (!SIMPLE && axis >= 0 && j != axis) zj = 0.0;
-        if (KIND == KIND_DIAG) {
-          acc[j] = fac[j] * zj;
-        } else if (KIND == KIND_LOWER) {
-          // column j of the packed lower factor: rows j..DP-1 at offset j*DP - j(j-1)/2
-          cdp col = fac + (j * DP - (j * (j - 1)) / 2);
-#pragma unroll
-          for (int i = j; i < DP; ++i) acc[i] = __builtin_fma(col[i - j], zj, acc[i]);
-        } else {
-          cdp col = fac + j * DP;
-#pragma unroll
-          for (int i = 0; i < DP; ++i) acc[i] = __builtin_fma(col[i], zj, acc[i]);
-        }
-        PTM_SCHED_FENCE();
-      }
-    }
-    double xn[DP];
-#pragma unroll
-    for (int d = 0; d < DP; ++d) xn[d] = x[d] + acc[d];  // state::add (states.cc:205-214)
 
     bool valid;
     double newlprior;
@@ -287,35 +449,47 @@ __global__ __launch_bounds__(256) void sweep_kernel(const Dev p) {
       newlprior = in ? p.lprior_const : -__builtin_inf();
     } else {
       valid = p.origin_valid != 0;  // Q9: the sum is built on an enforced zero state
-      newlprior = enforce_and_lprior<DP>(p, xn, valid);
+      double xa[DP];                // general state-space / prior code works on an addressable copy
+#pragma unroll
+      for (int d = 0; d < DP; ++d) xa[d] = xn[d];
+      newlprior = enforce_and_lprior<DP>(p, xa, valid);
+#pragma unroll
+      for (int d = 0; d < DP; ++d) xn[d] = xa[d];
     }
     double newlike, newlpost;
     if (valid && (newlprior > -1e200 || newlprior - oldlprior > p.min_prior)) {  // chain.cc:980 (Q1)
+#if defined(PTM_ABLATE) && (PTM_ABLATE & 4)
+      newlike = xn[0] + xn[DP - 1];  // ablation: no quadratic form
+#else
       newlike = (!SIMPLE && p.has_mean) ? gauss_llike<DP, true>(p, xn) : gauss_llike<DP, false>(p, xn);
+#endif
       newlpost = newlike * beta + newlprior;
     } else {
       newlike = newlpost = -__builtin_inf();
     }
     const double logH = newlpost - cur_lpost;  // gaussian_prop: log_hastings_ratio() == 0
-    bool accept = valid;
+    accept = valid;
     if (accept && logH < 0) accept = dlog_u01(o0.v0) < logH;  // chain.cc:998-1001 (NaN stays accepted)
 
     p.ntries[c] += 1;
     if (accept) {
       p.naccept[c] += 1;
       p.last_type[c] = type;
-#pragma unroll
-      for (int d = 0; d < DP; ++d) x[d] = xn[d];
       ll = newlike;
       lp = newlprior;
     }
-    nhist += 1u;
+    p.nhist[c] += 1u;
   }
+  if (out >= 0) {  // (a row that left the shard was packed into the send buffer by the exchange kernel)
 #pragma unroll
-  for (int d = 0; d < DP; ++d) p.x_out[(size_t)d * Nc + c] = x[d];
-  p.ll_out[c] = ll;
-  p.lp_out[c] = lp;
-  p.nhist[c] = nhist;
+    for (int d = 0; d < DP; ++d) {
+      double v = xn[d];
+      if (!accept) v = p.x_in[(size_t)d * Nc + c];
+      p.x_out[(size_t)d * Nc + out] = v;
+    }
+    p.ll_out[out] = ll;
+    p.lp_out[out] = lp;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------

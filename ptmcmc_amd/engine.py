@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libptm_engine.so")
+LIB_PATH = os.environ.get("PTM_ENGINE_LIB") or os.path.join(_HERE, "libptm_engine.so")   # override: A/B builds
 
 # enums of include/ptm_engine.h
 BOUND_OPEN, BOUND_LIMIT, BOUND_REFLECT, BOUND_WRAP = 0, 1, 2, 3

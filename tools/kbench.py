@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Kernel A/B harness: time the fused sweep kernel (and the exchange kernel) of a given engine build.
+usage: PTM_ENGINE_LIB=path/to/lib.so python tools/kbench.py [--walkers W] [--dim D] [--rungs N] [--kind lower|dense|diag]"""
+import argparse
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from ptmcmc_amd import engine as E
+from ptmcmc_amd.problems import GaussianProblem
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--walkers", type=int, default=4096)
+ap.add_argument("--dim", type=int, default=32)
+ap.add_argument("--rungs", type=int, default=1024)
+ap.add_argument("--tmax", type=float, default=1e9)
+ap.add_argument("--kind", default="lower")
+ap.add_argument("--reps", type=int, default=20)
+ap.add_argument("--tag", default="")
+a = ap.parse_args()
+kind = {"lower": E.PROP_LOWER, "dense": E.PROP_DENSE, "diag": E.PROP_DIAG}[a.kind]
+pr = GaussianProblem(a.dim, a.rungs, a.tmax)
+eng = E.Engine(a.dim, a.rungs, a.walkers, add_every_n=100, time_kernels=True)
+pr.configure(eng, kind)
+eng.init_from_prior()
+eng.sweep(3); eng.sync(); eng.kernel_times()
+eng.timer_start(); eng.sweep(a.reps); ms_sweep = eng.timer_stop() / a.reps
+kt = eng.kernel_times()
+eng.timer_start(); eng.step(a.reps); ms_step = eng.timer_stop() / a.reps
+kt2 = eng.kernel_times()
+nch = a.rungs * a.walkers
+bytes_alg = (16 * a.dim + 44) * nch
+print("%-28s %-34s sweep %.4f ms (min %.4f)  step %.4f ms [sweep-in-step %.4f, exchange %.4f]  -> %.3e MH steps/s (sweep only), %.0f GB/s algorithmic = %.1f%% of 8 TB/s"
+      % (a.tag or os.path.basename(E.LIB_PATH), eng.sweep_kernel_name, ms_sweep, kt.min(), ms_step, kt2.mean(), ms_step - kt2.mean(), nch / (ms_sweep * 1e-3),
+         bytes_alg / (ms_sweep * 1e-3) / 1e9, bytes_alg / (ms_sweep * 1e-3) / 8e12 * 100), flush=True)
