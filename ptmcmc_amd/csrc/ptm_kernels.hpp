@@ -29,6 +29,10 @@
 #ifndef PTM_SWEEP_WAVES
 #define PTM_SWEEP_WAVES 3
 #endif
+// 1: keep the current state in registers through the likelihood (no re-read of rejected rows, 2*DP more VGPRs)
+#ifndef PTM_KEEP_X
+#define PTM_KEEP_X 0
+#endif
 #ifndef PTM_SCHED_FENCE
 #define PTM_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #endif
@@ -300,6 +304,10 @@ __device__ __forceinline__ void dpp_panel32(const DrawCtx& dc, const double* tab
       const double zj = z[0];
       z[0] = z[1]; z[1] = z[2]; z[2] = z[3]; z[3] = zj;
       const double* col = tab + (8 * P8 + 4 * bb + t) * 32 + lane16;
+#if defined(PTM_ABLATE) && (PTM_ABLATE & 2)
+      acc[8 * P8] += zj;
+      continue;
+#endif
       if (KIND == KIND_DENSE || P8 < 2) {
         const double ca = col[0];
         if (KIND == KIND_DENSE || P8 == 0) dpp_fma16<16>(&acc[0], ca, zj); else dpp_fma16<8>(&acc[0], ca, zj);
@@ -430,9 +438,20 @@ __global__ __launch_bounds__(256, PTM_SWEEP_WAVES) void sweep_kernel(const Dev p
   //    row was fetched a few microseconds earlier -- which halves the live register set of the quadratic form.
   double ll = p.ll_in[c], lp = p.lp_in[c];
   bool accept = false;
+#if PTM_KEEP_X
+  double xk[DP];
+#pragma unroll
+  for (int d = 0; d < DP; ++d) xk[d] = p.x_in[(size_t)d * Nc + c];
+#endif
   if (!tc) {
 #pragma unroll
-    for (int d = 0; d < DP; ++d) xn[d] = p.x_in[(size_t)d * Nc + c] + xn[d];  // state::add (states.cc:205-214)
+    for (int d = 0; d < DP; ++d) {
+#if PTM_KEEP_X
+      xn[d] = xk[d] + xn[d];  // state::add (states.cc:205-214)
+#else
+      xn[d] = p.x_in[(size_t)d * Nc + c] + xn[d];  // state::add (states.cc:205-214)
+#endif
+    }
     const double beta = as_c(p.beta)[rg];
     const double bl = beta * ll;
     const double cur_lpost = lp + bl;
@@ -483,9 +502,13 @@ __global__ __launch_bounds__(256, PTM_SWEEP_WAVES) void sweep_kernel(const Dev p
   if (out >= 0) {  // (a row that left the shard was packed into the send buffer by the exchange kernel)
 #pragma unroll
     for (int d = 0; d < DP; ++d) {
+#if PTM_KEEP_X
+      p.x_out[(size_t)d * Nc + out] = accept ? xn[d] : xk[d];
+#else
       double v = xn[d];
       if (!accept) v = p.x_in[(size_t)d * Nc + c];
       p.x_out[(size_t)d * Nc + out] = v;
+#endif
     }
     p.ll_out[out] = ll;
     p.lp_out[out] = lp;
