@@ -37,6 +37,23 @@ def algorithmic_bytes(dim):
     return 16 * dim + 44   # r+w state, beta, r+w lpost & llike, accept/type flag
 
 
+def measured_traffic(kernel_name):
+    """HBM bytes per launch of the sweep kernel from the newest committed rocprofv3 --pmc summary (profiles/*_pmc_summary.json,
+    written by tools/summarize_profile.py from separate FETCH_SIZE / WRITE_SIZE passes with the gfx950 corrections of
+    MI355X_MICROARCH.md).  Counters cannot be read from inside this process; None if no matching profile is committed."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json"))):
+        try:
+            ks = json.load(open(f))["kernels"]
+        except Exception:
+            continue
+        for k, v in ks.items():
+            if kernel_name.replace(" ", "") in k.replace(" ", ""):
+                best = {"bytes": v["hbm_bytes"], "read": v["hbm_read_bytes"], "write": v["hbm_write_bytes"], "source": os.path.basename(f)}
+    return best
+
+
 def cpu_baseline(problem, budget_s=15.0):
     """Reference CPU path on this box's host cores.  Bounded: ~10-30 s of CPU work."""
     drv = os.path.join(ROOT, "oracle", "_ref", "ptm_ref_driver")
@@ -108,6 +125,7 @@ def run_single(args):
     value = nchains * args.steps / wall
     kavg_ms = float(kt.mean())
     achieved = algorithmic_bytes(D) * nchains / (kavg_ms * 1e-3) / 1e9
+    tr = measured_traffic(eng.sweep_kernel_name) if W == 4096 else None
     acc = float((eng.naccept.sum() - eng.Nc)) / max(1, float((eng.ntries.sum() - eng.Nc)))
     t, a = eng.swap_counts()
     # latency-bound companion: the bare 1024-chain ladder (W=1)
@@ -132,7 +150,8 @@ def run_single(args):
                                "per-rung Cholesky proposal factors; uniform box prior" % W,
                    "dim": D, "rungs": NT, "walkers": W, "chains": nchains, "sharding": "1 GPU holds the whole ladder"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": eng.sweep_kernel_name,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": (tr["bytes"] if tr else None),
+                     "traffic_detail": tr, "algorithmic_bytes": algorithmic_bytes(D) * nchains, "kernel": eng.sweep_kernel_name,
                      "kernel_avg_ms": kavg_ms, "launches": int(kt.size), "bytes_per_mh_step": algorithmic_bytes(D)},
         "device_ms_per_step": ms_dev / args.steps,
         "mh_accept_rate": acc, "swap_accept_rate": float(a.sum()) / max(1, float(t.sum())),
