@@ -169,6 +169,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--walkers", type=int, default=4096, help="independent ladders batched per GPU")
+    ap.add_argument("--halo", type=int, default=4, help="llike halo depth (rungs) between shards")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-w1", action="store_true", help="skip the 1024-chain latency companion")
     args = ap.parse_args()

@@ -118,13 +118,20 @@ int ptm_step(ptm_engine* e, int n);
 int ptm_sync(ptm_engine* e);
 
 /* ---- multi-GPU building blocks (one engine per GPU; the caller moves bytes with RCCL) ---------------- */
+/* Exchanges only ever propagate DOWN the ladder within one step (a candidate one above an earlier pick is dropped,
+ * chain.cc:1417-1418), so a shard can replay every decision that concerns its rungs from: its own llikes, the llike
+ * of the top rung of the shard below (W doubles) and the llikes of the bottom `halo_rungs` rungs of the shard above
+ * ([halo_rungs][W]).  A chain of accepted exchanges longer than the halo sets PTM_ERR_FAR_MOVE (reported by ptm_sync). */
+/* copy n_rungs rungs of the local llike array (current step), starting at local rung first_local_rung, to a device
+ * buffer ([n_rungs][W] doubles) -- the halo a neighbour needs; asynchronous on the engine's stream */
+int ptm_copy_llike(ptm_engine* e, int first_local_rung, int n_rungs, void* dst_dev);
 /* device pointer to the local llike array of the CURRENT step, [rung_count*W] doubles, chain-major */
 int ptm_llike_device_ptr(ptm_engine* e, void** dev_ptr);
-/* exchange phase, part 1: decide all exchanges of the next step from the GLOBAL llike array
- * (device pointer, [n_rungs*W] doubles = concatenation of the shards' local arrays) and pack the rows that
- * leave this shard into send_up / send_down (device buffers of ptm_exchange_buffer_doubles() doubles each; may be
- * NULL at the ends of the ladder). */
-int ptm_exchange_decide(ptm_engine* e, const void* llike_global_dev, void* send_up_dev, void* send_down_dev);
+/* exchange phase, part 1: decide all exchanges that concern this shard and pack the rows that leave it into
+ * send_up / send_down (device buffers of ptm_exchange_buffer_doubles() doubles each; ignored at the ladder's ends).
+ * ll_below_dev: [W] (ignored on the first shard); ll_above_dev: [halo_rungs][W] (ignored on the last shard). */
+int ptm_exchange_decide(ptm_engine* e, const void* ll_below_dev, const void* ll_above_dev, int halo_rungs, void* send_up_dev,
+                        void* send_down_dev);
 /* exchange phase, part 2 + MH sweep: rows arriving from the neighbours (device buffers of the same size) */
 int ptm_exchange_finish_and_sweep(ptm_engine* e, const void* recv_from_below_dev, const void* recv_from_above_dev);
 /* size of one boundary buffer in doubles: W * (padded dim + 2) -- one state row + llike + lprior per walker, SoA */
@@ -170,6 +177,10 @@ int ptm_debug_boxmuller(int device, const uint32_t* k1, const uint32_t* k2, doub
  * compiler's sqrt expansion (i.e. need the engine's fix-up step) */
 int ptm_debug_sqrt_scan(int device, uint64_t* mismatches);
 /* evaluate lprior / llike of arbitrary states with the engine's problem description: X[n][D] */
+/* device-memory helpers for callers without a GPU array library (tests, tools) */
+int ptm_dev_alloc(size_t bytes, void** out);
+int ptm_dev_free(void* p);
+int ptm_dev_copy(void* dst, const void* src, size_t bytes); /* any direction, synchronous */
 int ptm_debug_evaluate(ptm_engine* e, const double* X, int n, int32_t* valid, double* X_enforced, double* lprior,
                        double* llike);
 

@@ -16,7 +16,9 @@ struct Decide {
   uint64_t seed, step;
   double thresh;              // (Ntemps-1)*swap_rate/maxswapsperstep (chain.cc:1413)
   const double* beta;         // [Nt]
-  const double* llg;          // GLOBAL llike [Nt][W]
+  const double* ll_below;     // [W]      llike of rung r0-1 (top rung of the shard below), null on the first shard
+  const double* ll_above;     // [H][W]   llike of rungs r1 .. r1+H-1 (bottom rungs of the shard above), null on the last
+  int H;                      // halo depth actually available above (0 on the last shard)
   const double* x_in;         // local state planes (for packing departures)
   const double* ll_in;
   const double* lp_in;
@@ -28,6 +30,14 @@ struct Decide {
   double *send_up, *send_down;     // [(DP+2)][W] or null
   int* err;
 };
+
+// llike of global rung r for walker w, r inside the shard's window
+__device__ __forceinline__ double win_llike(const Decide& p, int r, int w) {
+  const int r1 = p.r0 + p.nloc;
+  if (r < p.r0) return p.ll_below[w];
+  if (r >= r1) return p.ll_above[(size_t)(r - r1) * p.W + w];
+  return p.ll_in[(size_t)(r - p.r0) * p.W + w];
+}
 
 __global__ __launch_bounds__(64) void decide_kernel(const Decide p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -46,6 +56,8 @@ __global__ __launch_bounds__(64) void decide_kernel(const Decide p) {
   int* down_src_p = reinterpret_cast<int*>(mark + ((Nt + 1 + 7) & ~7));              // [1]
   // (no static __shared__: it would precede the dynamic region and break its 16-byte base alignment)
 
+  // window of rungs whose llike this shard knows: its own, one below, H above
+  const int wlo = p.r0 - (p.ll_below ? 1 : 0), whi = p.r0 + p.nloc - 1 + p.H;
   for (int i = lane; i < Nt + 1; i += 64) mark[i] = 0;
   if (lane == 0) *down_src_p = -1;
   // -- candidate draws (chain.cc:1410-1416): block k of the ladder stream gives {u_try, u_pick, u_accept}
@@ -72,8 +84,10 @@ __global__ __launch_bounds__(64) void decide_kernel(const Decide p) {
   for (int k = lane; k < ms; k += 64) {
     const int n = cand[k];
     if (n < 0) continue;
-    llc[n] = p.llg[(size_t)n * p.W + w];
-    llc[n + 1] = p.llg[(size_t)(n + 1) * p.W + w];
+    // only pairs inside the window [r0-1, r1+H) can concern this shard (exchanges propagate downwards only)
+    if (n < wlo || n + 1 > whi) continue;
+    llc[n] = win_llike(p, n, w);
+    llc[n + 1] = win_llike(p, n + 1, w);
     db[k] = p.beta[n + 1] - p.beta[n];
     perm[n] = (unsigned short)n;
     perm[n + 1] = (unsigned short)(n + 1);
@@ -83,9 +97,24 @@ __global__ __launch_bounds__(64) void decide_kernel(const Decide p) {
   __syncthreads();
   // -- trials in pick order (chain.cc:1436-1537)
   if (lane == 0) {
+    // `taint`: lowest rung (>= r1) whose content is unknown because an exchange above the window may have changed it;
+    // it moves down with every later pick right below it.  Reaching the shard boundary means the halo was too shallow.
+    int taint = Nt + 1;
+    const int r1s = p.r0 + p.nloc;
     for (int k = 0; k < ms; ++k) {
       const int i = cand[k];
       if (i < 0) continue;
+      if (i + 1 > whi || i < wlo) {                       // pair outside the window
+        if (i == whi && i + 1 < Nt) taint = i;            // ... but it may have replaced the window's top rung
+        cand[k] = -3;                                     // (not logged as a local decision; -3 = "not ours")
+        continue;
+      }
+      if (i + 1 >= taint) {                               // upper rung's content unknown
+        if (i + 1 <= r1s) atomicOr(p.err, 2);             // would decide a local / straddling exchange blindly
+        if (i < taint) taint = i;
+        cand[k] = -3;
+        continue;
+      }
       double lla = llc[i];
       if (!(lla > -1e200)) lla = -1e200;
       double llb = llc[i + 1];
@@ -109,13 +138,16 @@ __global__ __launch_bounds__(64) void decide_kernel(const Decide p) {
   const int DP = p.DP;
   for (int k = lane; k < ms; k += 64) {
     const int i = cand[k];
-    p.last_pairs[(size_t)w * ms + k] = i;
+    p.last_pairs[(size_t)w * ms + k] = i;                 // -2: no candidate / dropped, -3: outside this shard's window
     p.last_acc[(size_t)w * ms + k] = accf[k];
     if (i < 0) continue;
     // swap_count / swap_accept_count (chain.cc:1498,1536): a pair is tried at most once per step, so no two lanes
     // of this wave (the only writer of walker w's counters) touch the same entry
-    p.swap_try[(size_t)w * (Nt - 1) + i] += 1;
-    if (accf[k]) p.swap_acc[(size_t)w * (Nt - 1) + i] += 1;
+    // (a pair is counted by the shard that owns its lower rung, so per-shard counters add up to the ladder's)
+    if (i >= p.r0 && i < r1) {
+      p.swap_try[(size_t)w * (Nt - 1) + i] += 1;
+      if (accf[k]) p.swap_acc[(size_t)w * (Nt - 1) + i] += 1;
+    }
     for (int r = i; r <= i + 1; ++r) {
       // rung r ends the phase holding the row that started the step at rung s = perm[r]: publish the move from the
       // row's point of view (dst of the source slot) -- or, for a row coming from another shard, its landing slot

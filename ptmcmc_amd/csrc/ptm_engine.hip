@@ -425,12 +425,12 @@ static size_t decide_lds_bytes(int Nt, int ms) {
   return (size_t)Nt * 8 + (size_t)ms * 16 + msp * 4 * 2 + (size_t)((Nt + 3) & ~3) * 2 + (size_t)((Nt + 7) & ~7) + (size_t)((Nt + 1 + 7) & ~7) + 16;
 }
 
-static int launch_decide(ptm_engine* e, const double* llg, double* send_up, double* send_down) {
+static int launch_decide(ptm_engine* e, const double* ll_below, const double* ll_above, int H, double* send_up, double* send_down) {
   Decide p;
   memset(&p, 0, sizeof p);
   p.DP = e->DP; p.Nt = e->Nt; p.r0 = e->r0; p.nloc = e->nloc; p.W = e->W; p.Nc = e->Nc; p.ms = e->ms;
   p.seed = e->cfg.seed; p.step = e->step; p.thresh = e->thresh;
-  p.beta = e->beta; p.llg = llg; p.x_in = e->x[e->cur]; p.ll_in = e->ll[e->cur]; p.lp_in = e->lp[e->cur];
+  p.beta = e->beta; p.ll_below = ll_below; p.ll_above = ll_above; p.H = ll_above ? H : 0; p.x_in = e->x[e->cur]; p.ll_in = e->ll[e->cur]; p.lp_in = e->lp[e->cur];
   p.dst = e->dst; p.touch = e->touch; p.arr_below = e->arr_below; p.arr_above = e->arr_above; p.swap_try = e->swap_try; p.swap_acc = e->swap_acc;
   p.last_pairs = e->last_pairs; p.last_acc = e->last_acc; p.send_up = send_up; p.send_down = send_down; p.err = e->err;
   const size_t lds = decide_lds_bytes(e->Nt, e->ms);
@@ -538,7 +538,7 @@ extern "C" int ptm_step(ptm_engine* e, int n) {
   if (rc) return rc;
   if (e->nloc != e->Nt) return fail(PTM_ERR_INVALID, "ptm_step needs the whole ladder on this engine; sharded engines use ptm_exchange_*");
   for (int k = 0; k < n; ++k) {
-    if (e->Nt > 1 && (rc = launch_decide(e, e->ll[e->cur], nullptr, nullptr))) return rc;
+    if (e->Nt > 1 && (rc = launch_decide(e, nullptr, nullptr, 0, nullptr, nullptr))) return rc;
     if ((rc = launch_sweep(e, nullptr, nullptr))) return rc;
   }
   return PTM_OK;
@@ -549,7 +549,8 @@ extern "C" int ptm_sync(ptm_engine* e) {
   HIPCHK(hipStreamSynchronize(e->stream));
   int flag = 0;
   HIPCHK(hipMemcpy(&flag, e->err, 4, hipMemcpyDeviceToHost));
-  if (flag) return fail(PTM_ERR_FAR_MOVE, "a state crossed more than one shard boundary in one step (neighbour exchange mode)");
+  if (flag & 1) return fail(PTM_ERR_FAR_MOVE, "a state crossed more than one shard boundary in one step (neighbour exchange mode)");
+  if (flag & 2) return fail(PTM_ERR_FAR_MOVE, "an exchange chain reached past the llike halo: rerun with a deeper halo");
   return PTM_OK;
 }
 
@@ -559,11 +560,41 @@ extern "C" int ptm_llike_device_ptr(ptm_engine* e, void** p) {
   return PTM_OK;
 }
 
-extern "C" int ptm_exchange_decide(ptm_engine* e, const void* llg, void* send_up, void* send_down) {
+extern "C" int ptm_exchange_decide(ptm_engine* e, const void* ll_below, const void* ll_above, int halo_rungs, void* send_up,
+                                   void* send_down) {
   int rc = ready(e);
   if (rc) return rc;
-  if (!llg) return fail(PTM_ERR_INVALID, "null llike_global");
-  if (e->Nt > 1) return launch_decide(e, (const double*)llg, (double*)send_up, (double*)send_down);
+  const bool first = e->r0 == 0, last = e->r0 + e->nloc == e->Nt;
+  if ((!first && !ll_below) || (!last && (!ll_above || halo_rungs < 1)))
+    return fail(PTM_ERR_INVALID, "missing llike halo: a shard needs the top rung below it and >= 1 rung above it");
+  if (!last && halo_rungs > e->Nt - (e->r0 + e->nloc)) return fail(PTM_ERR_INVALID, "halo deeper than the ladder above this shard");
+  if (e->Nt > 1)
+    return launch_decide(e, first ? nullptr : (const double*)ll_below, last ? nullptr : (const double*)ll_above, halo_rungs,
+                         last ? nullptr : (double*)send_up, first ? nullptr : (double*)send_down);
+  return PTM_OK;
+}
+
+extern "C" int ptm_copy_llike(ptm_engine* e, int first_local_rung, int n_rungs, void* dst_dev) {
+  if (!e || !dst_dev) return fail(PTM_ERR_INVALID, "null argument");
+  if (first_local_rung < 0 || n_rungs < 1 || first_local_rung + n_rungs > e->nloc) return fail(PTM_ERR_INVALID, "rung range out of the shard");
+  HIPCHK(hipMemcpyAsync(dst_dev, e->ll[e->cur] + (size_t)first_local_rung * e->W, (size_t)n_rungs * e->W * 8, hipMemcpyDeviceToDevice, e->stream));
+  return PTM_OK;
+}
+
+// small device-memory helpers for callers without a GPU array library (tests, tools)
+extern "C" int ptm_dev_alloc(size_t bytes, void** out) {
+  int rc = need_device();
+  if (rc) return rc;
+  HIPCHK(hipMalloc(out, bytes ? bytes : 1));
+  return PTM_OK;
+}
+extern "C" int ptm_dev_free(void* p) {
+  if (p) HIPCHK(hipFree(p));
+  return PTM_OK;
+}
+extern "C" int ptm_dev_copy(void* dst, const void* src, size_t bytes) {
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyDefault));
   return PTM_OK;
 }
 

@@ -24,10 +24,11 @@ EXPORTS = [
     "ptm_last_error", "ptm_abi_version", "ptm_device_count", "ptm_engine_create", "ptm_engine_destroy",
     "ptm_set_bounds", "ptm_set_prior", "ptm_set_target_gaussian", "ptm_set_target_callback", "ptm_set_ladder",
     "ptm_set_proposals", "ptm_set_states", "ptm_init_from_prior", "ptm_sweep", "ptm_step", "ptm_sync",
-    "ptm_llike_device_ptr", "ptm_exchange_decide", "ptm_exchange_finish_and_sweep", "ptm_exchange_buffer_doubles", "ptm_get_states",
+    "ptm_copy_llike", "ptm_llike_device_ptr", "ptm_exchange_decide", "ptm_exchange_finish_and_sweep", "ptm_exchange_buffer_doubles", "ptm_get_states",
     "ptm_get_array", "ptm_get_swap_counts", "ptm_get_last_swaps", "ptm_max_swaps_per_step", "ptm_step_count",
     "ptm_timer_start", "ptm_timer_stop", "ptm_get_kernel_times", "ptm_sweep_kernel_name", "ptm_debug_eval",
     "ptm_debug_philox", "ptm_debug_boxmuller", "ptm_debug_sqrt_scan", "ptm_debug_evaluate",
+    "ptm_dev_alloc", "ptm_dev_free", "ptm_dev_copy",
 ]
 
 
@@ -78,7 +79,11 @@ def load():
     L.ptm_step.argtypes = [C.c_void_p, C.c_int]
     L.ptm_sync.argtypes = [C.c_void_p]
     L.ptm_llike_device_ptr.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
-    L.ptm_exchange_decide.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.ptm_exchange_decide.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    L.ptm_copy_llike.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    L.ptm_dev_alloc.argtypes = [C.c_size_t, C.POINTER(C.c_void_p)]
+    L.ptm_dev_free.argtypes = [C.c_void_p]
+    L.ptm_dev_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     L.ptm_exchange_finish_and_sweep.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.ptm_get_states.argtypes = [C.c_void_p, _dp]
     L.ptm_get_array.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
@@ -137,6 +142,33 @@ def debug_sqrt_scan(device=-1):
     n = C.c_uint64()
     _chk(load().ptm_debug_sqrt_scan(device, C.byref(n)))
     return n.value
+
+
+class DeviceBuffer:
+    """A raw device allocation (for tests and tools that have no GPU array library at hand)."""
+
+    def __init__(self, nbytes):
+        p = C.c_void_p()
+        _chk(load().ptm_dev_alloc(nbytes, C.byref(p)))
+        self.ptr, self.nbytes = p.value, nbytes
+
+    def data_ptr(self):
+        return self.ptr
+
+    def copy_from(self, src_ptr, nbytes=None):
+        _chk(load().ptm_dev_copy(self.ptr, src_ptr, self.nbytes if nbytes is None else nbytes))
+
+    def to_numpy(self, dtype=np.float64):
+        out = np.empty(self.nbytes // np.dtype(dtype).itemsize, dtype=dtype)
+        _chk(load().ptm_dev_copy(out.ctypes.data_as(C.c_void_p), self.ptr, self.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr:
+            load().ptm_dev_free(self.ptr)
+            self.ptr = None
+
+    __del__ = free
 
 
 def geometric_ladder(n_rungs, tmax):
@@ -232,8 +264,11 @@ class Engine:
         _chk(self.L.ptm_llike_device_ptr(self.h, C.byref(p)))
         return p.value
 
-    def exchange_decide(self, llike_global_dev, send_up_dev, send_down_dev):
-        _chk(self.L.ptm_exchange_decide(self.h, llike_global_dev, send_up_dev, send_down_dev))
+    def copy_llike(self, first_local_rung, n_rungs, dst_dev):
+        _chk(self.L.ptm_copy_llike(self.h, first_local_rung, n_rungs, dst_dev))
+
+    def exchange_decide(self, ll_below_dev, ll_above_dev, halo_rungs, send_up_dev, send_down_dev):
+        _chk(self.L.ptm_exchange_decide(self.h, ll_below_dev, ll_above_dev, halo_rungs, send_up_dev, send_down_dev))
 
     @property
     def exchange_buffer_doubles(self):

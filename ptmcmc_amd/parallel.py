@@ -1,0 +1,190 @@
+"""Ladder sharding across the GPUs of one node: one process per GPU, torch.distributed (backend "nccl" = RCCL over
+xGMI on ROCm; "gloo" on CPU for the protocol tests).
+
+The reference distributes rungs cyclically over MPI ranks and all-gathers every state, llike and invtemp each step
+(chain.cc:1298-1309,1433-1435,1905-1967).  Here the ladder is cut into CONTIGUOUS rung blocks, so only the G-1 rung
+pairs that straddle two GPUs ever move data, and -- because exchanges propagate only downwards within one step
+(chain.cc:1417-1418) -- every shard can replay the decisions that concern it from a small llike halo:
+
+  per step and per shard boundary
+    1. llike halos, point-to-point:   top rung's llike      -> upper neighbour   (W doubles)
+                                      bottom H rungs' llike -> lower neighbour   (H*W doubles)
+    2. exchange kernel (ptm_exchange_decide): replays the candidate draws of every ladder (replicated counter RNG),
+       decides, names the row moves inside the shard and packs the rows that leave it
+    3. boundary rows, point-to-point: one (state, llike, lprior) row per walker and direction, only neighbours talk
+    4. fused MH sweep (ptm_exchange_finish_and_sweep) installs arrivals and advances every untouched rung
+
+There is no collective on the data path; swap bookkeeping stays where the reference keeps it (host side, from the
+per-pair counters each shard owns).  Chains are bit-identical for any number of shards: all random streams are keyed by
+global (seed, walker, rung, step).
+"""
+import os
+import time
+
+import numpy as np
+
+
+def shard_bounds(n_rungs, world, rank):
+    """contiguous block of rungs of `rank`: sizes differ by at most one, lower ranks take the remainder"""
+    base, rem = divmod(n_rungs, world)
+    lo = rank * base + min(rank, rem)
+    return lo, base + (1 if rank < rem else 0)
+
+
+class EngineShard:
+    """Backend of ShardedLadder on a GPU: a ptmcmc_amd Engine + torch tensors for the message buffers."""
+
+    def __init__(self, engine, torch, device):
+        self.e, self.torch, self.device = engine, torch, device
+        self.W, self.nloc, self.r0, self.Nt = engine.W, engine.nloc, engine.r0, engine.Nt
+        self.row_doubles = engine.exchange_buffer_doubles
+
+    def alloc(self, n):
+        return self.torch.empty(n, dtype=self.torch.float64, device=self.device)
+
+    def copy_llike(self, first_rung, n_rungs, dst):
+        self.e.copy_llike(first_rung, n_rungs, dst.data_ptr())
+
+    def exchange_decide(self, ll_below, ll_above, halo, send_up, send_down):
+        p = lambda t: None if t is None else t.data_ptr()
+        self.e.exchange_decide(p(ll_below), p(ll_above), halo, p(send_up), p(send_down))
+
+    def finish_and_sweep(self, recv_below, recv_above):
+        p = lambda t: None if t is None else t.data_ptr()
+        self.e.exchange_finish_and_sweep(p(recv_below), p(recv_above))
+
+    def sync(self):
+        self.e.sync()
+
+
+class ShardedLadder:
+    """Drives one shard of a ladder that is spread over `world` ranks.  `backend` supplies the local compute
+    (EngineShard on a GPU; the tests plug a CPU stand-in with the same five methods)."""
+
+    def __init__(self, backend, dist, rank, world, halo=4, sizes=None):
+        self.b, self.dist, self.rank, self.world = backend, dist, rank, world
+        W = backend.W
+        sizes = sizes or [shard_bounds(backend.Nt, world, r)[1] for r in range(world)]
+        self.up = rank + 1 if rank + 1 < world else None
+        self.down = rank - 1 if rank > 0 else None
+        # halo depth: what I receive from above is limited by the upper neighbour's size, what I send down by mine
+        self.h_recv = min(halo, sizes[rank + 1]) if self.up is not None else 0
+        self.h_send = min(halo, sizes[rank]) if self.down is not None else 0
+        a = backend.alloc
+        self.ll_top = a(W) if self.up is not None else None            # my top rung's llike  -> up
+        self.ll_bottom = a(self.h_send * W) if self.down is not None else None  # my bottom rungs -> down
+        self.ll_below = a(W) if self.down is not None else None        # <- from below
+        self.ll_above = a(self.h_recv * W) if self.up is not None else None     # <- from above
+        n = backend.row_doubles
+        self.send_up = a(n) if self.up is not None else None
+        self.recv_above = a(n) if self.up is not None else None
+        self.send_down = a(n) if self.down is not None else None
+        self.recv_below = a(n) if self.down is not None else None
+
+    # -- the step, in phases (the in-process shard simulator of the tests drives the same phases in lockstep)
+    def stage_halos(self):
+        b = self.b
+        if self.up is not None:
+            b.copy_llike(b.nloc - 1, 1, self.ll_top)
+        if self.down is not None:
+            b.copy_llike(0, self.h_send, self.ll_bottom)
+
+    def halo_messages(self):
+        """(send buffer, receive buffer, peer rank): my top rung's llike goes up, my bottom rungs' llikes go down"""
+        return [(self.ll_top, self.ll_above, self.up), (self.ll_bottom, self.ll_below, self.down)]
+
+    def decide(self):
+        self.b.exchange_decide(self.ll_below, self.ll_above, self.h_recv, self.send_up, self.send_down)
+
+    def row_messages(self):
+        return [(self.send_up, self.recv_above, self.up), (self.send_down, self.recv_below, self.down)]
+
+    def finish(self):
+        self.b.finish_and_sweep(self.recv_below, self.recv_above)
+
+    def _exchange(self, msgs):
+        ops = []
+        for send, recv, peer in msgs:
+            if peer is None:
+                continue
+            ops.append(self.dist.P2POp(self.dist.isend, send, peer))
+            ops.append(self.dist.P2POp(self.dist.irecv, recv, peer))
+        if ops:
+            for r in self.dist.batch_isend_irecv(ops):
+                r.wait()
+
+    def step(self, n=1):
+        for _ in range(n):
+            self.stage_halos()
+            self._exchange(self.halo_messages())
+            self.decide()
+            self._exchange(self.row_messages())
+            self.finish()
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# bench.py --gpus N  (launched by torch.distributed.run, one rank per GPU)
+# ----------------------------------------------------------------------------------------------------------------------
+def bench_main(args):
+    import json
+    import torch
+    import torch.distributed as dist
+    from . import engine as E
+    from .problems import GaussianProblem
+    import bench as B
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", str(args.gpus)))
+    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist.init_process_group("nccl", device_id=dev)
+    D, NT = B.D, B.NT
+    W = args.walkers * world            # weak scaling: chains per GPU stay 1024 * walkers
+    r0, nloc = shard_bounds(NT, world, rank)
+    pr = GaussianProblem(D, NT, B.TMAX)
+    stream = torch.cuda.current_stream().cuda_stream
+    eng = E.Engine(D, NT, W, seed=B.SEED, swap_rate=B.SWAP_RATE, add_every_n=100, rung_begin=r0, rung_count=nloc,
+                   device=local, stream=stream, time_kernels=True)
+    pr.configure(eng, E.PROP_LOWER)
+    eng.init_from_prior()
+    lad = ShardedLadder(EngineShard(eng, torch, dev), dist, rank, world, halo=args.halo)
+    lad.step(args.warmup)
+    eng.sync()
+    eng.kernel_times()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    lad.step(args.steps)
+    eng.sync()
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    wall = float(dt.item())
+    kt = eng.kernel_times()
+    kavg = torch.tensor([float(kt.mean())], dtype=torch.float64, device=dev)
+    dist.all_reduce(kavg, op=dist.ReduceOp.MAX)
+    nchains = NT * W
+    if rank == 0:
+        kavg_ms = float(kavg.item())
+        per_gpu_bytes = B.algorithmic_bytes(D) * nloc * W
+        achieved = per_gpu_bytes / (kavg_ms * 1e-3) / 1e9
+        out = {
+            "metric": "ladder-wide MH steps/sec (D=32 Gaussian, 1024 temps)",
+            "value": nchains * args.steps / wall, "unit": "MH steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "D=32 correlated Gaussian, 1024-rung ladder (Tmax=1e9, swap_rate=0.1) x %d walkers; "
+                                   "per-rung Cholesky proposal factors; uniform box prior" % W,
+                       "dim": D, "rungs": NT, "walkers": W, "chains": nchains,
+                       "sharding": "%d contiguous rung blocks of %d rungs; llike halo %d rungs; neighbour p2p over RCCL"
+                                   % (world, nloc, args.halo)},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": B.HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / B.HBM_PEAK_GBS, "traffic": None, "kernel": eng.sweep_kernel_name,
+                         "kernel_avg_ms": kavg_ms, "per_gpu": True, "bytes_per_mh_step": B.algorithmic_bytes(D)},
+        }
+        print(json.dumps(out), flush=True)
+    eng.close()
+    dist.destroy_process_group()

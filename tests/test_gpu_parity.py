@@ -229,3 +229,76 @@ def test_streams_do_not_depend_on_batch_composition():
     assert np.array_equal(a[:, :3], e3.states().reshape(Nt, 3, D))
     for e in (e1, e2, e3):
         e.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# ladder sharding: G engines (one per "GPU") must reproduce the single-engine chains bit for bit
+# ---------------------------------------------------------------------------------------------------------------
+class _DevShard:
+    """EngineShard with raw device buffers instead of torch tensors (same five methods)."""
+
+    def __init__(self, eng):
+        self.e = eng
+        self.W, self.nloc, self.r0, self.Nt = eng.W, eng.nloc, eng.r0, eng.Nt
+        self.row_doubles = eng.exchange_buffer_doubles
+
+    def alloc(self, n):
+        return E.DeviceBuffer(n * 8)
+
+    def copy_llike(self, first, n, dst):
+        self.e.copy_llike(first, n, dst.ptr)
+
+    def exchange_decide(self, lb, la, halo, su, sd):
+        p = lambda b: None if b is None else b.ptr
+        self.e.exchange_decide(p(lb), p(la), halo, p(su), p(sd))
+
+    def finish_and_sweep(self, rb, ra):
+        p = lambda b: None if b is None else b.ptr
+        self.e.exchange_finish_and_sweep(p(rb), p(ra))
+
+    def sync(self):
+        self.e.sync()
+
+
+@pytest.mark.parametrize("D,Nt,W,G,halo,sr", [(32, 16, 64, 2, 4, 0.3), (8, 12, 64, 3, 4, 0.45), (5, 9, 3, 4, 3, 0.45),
+                                              (32, 64, 64, 8, 4, 0.1), (4, 6, 64, 6, 2, 0.5)])
+def test_sharded_engines_match_single_engine(D, Nt, W, G, halo, sr):
+    import shard_sim
+    from ptmcmc_amd.parallel import shard_bounds
+    from ptmcmc_amd.problems import GaussianProblem
+    pr = GaussianProblem(D, Nt, 1e3)
+    ref = E.Engine(D, Nt, W, swap_rate=sr)
+    pr.configure(ref, E.PROP_LOWER)
+    ref.init_from_prior()
+    x0 = ref.states()
+    shards = []
+    for g in range(G):
+        r0, n = shard_bounds(Nt, G, g)
+        e = E.Engine(D, Nt, W, swap_rate=sr, rung_begin=r0, rung_count=n)
+        pr.configure(e, E.PROP_LOWER)
+        e.set_states(x0[r0 * W:(r0 + n) * W])
+        shards.append(e)
+    lads = shard_sim.build([_DevShard(e) for e in shards], halo=halo)
+    copy = lambda dst, src: dst.copy_from(src.ptr)
+    nsteps, far = 40, False
+    for k in range(nsteps):
+        ref.step(1)
+        try:
+            shard_sim.step(lads, copy, 1)
+        except E.PtmError as ex:         # a chain longer than the halo / a row through a whole shard: must be LOUD
+            assert "halo" in str(ex) or "crossed" in str(ex)
+            far = True
+            break
+        xs = np.concatenate([e.states() for e in shards])
+        assert np.array_equal(xs, ref.states()), "states differ after step %d" % (k + 1)
+    if not far:
+        for name in ("llike", "lprior", "ntries", "naccept", "nhist", "nsize", "last_type"):
+            assert np.array_equal(np.concatenate([getattr(e, name) for e in shards]), getattr(ref, name)), name
+        t = sum(e.swap_counts()[0] for e in shards); a = sum(e.swap_counts()[1] for e in shards)
+        rt, ra = ref.swap_counts()
+        assert np.array_equal(t, rt) and np.array_equal(a, ra)
+        assert a.sum() > 0
+    else:
+        assert min(e.nloc for e in shards) <= 2   # only tiny shards may trip the halo / far-move guard in 40 steps
+    for e in shards + [ref]:
+        e.close()
