@@ -1,0 +1,169 @@
+"""CPU stand-in for ptmcmc_amd.parallel.EngineShard, built on the oracle -- TEST INFRASTRUCTURE.
+
+Implements the five backend methods of ShardedLadder with numpy/torch-CPU buffers so that the multi-rank protocol
+(halo messages, windowed decision replay, boundary rows) can be exercised over gloo without a GPU.  The exchange
+decisions restate parallel_tempering_chains::step's swap phase (chain.cc:1410-1537) on the shard's llike window."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+import oracle_lib as O
+
+
+class OracleShard:
+    def __init__(self, lad, r0, nloc, seed):
+        """lad: an oracle Ladder over the GLOBAL ladder (only rungs [r0, r0+nloc) of it are kept valid)"""
+        self.lad, self.r0, self.nloc, self.seed = lad, r0, nloc, seed
+        self.W, self.Nt, self.D = lad.W, lad.Nt, lad.D
+        self.row_doubles = self.W * (self.D + 2)
+        s = lad.s.contents
+        N = self.Nt * self.W
+        self.x = np.ctypeslib.as_array(s.x, shape=(N, self.D))
+        self.ll = np.ctypeslib.as_array(s.llike, shape=(N,))
+        self.lp = np.ctypeslib.as_array(s.lprior, shape=(N,))
+        self.nhist = np.ctypeslib.as_array(s.nhist, shape=(N,))
+        self.nsize = np.ctypeslib.as_array(s.nsize, shape=(N,))
+        self.touched = np.ctypeslib.as_array(s.touched, shape=(N,))
+        self.swap_try = np.zeros((self.W, self.Nt - 1), dtype=np.int64)
+        self.swap_acc = np.zeros((self.W, self.Nt - 1), dtype=np.int64)
+        self.ms = s.maxswaps
+        self.thresh = (self.Nt - 1) * s.swap_rate / self.ms
+        self.moves = []
+        self.far = False
+
+    def alloc(self, n):
+        return torch.zeros(n, dtype=torch.float64)
+
+    def idx(self, w, r):
+        return w * self.Nt + r            # oracle chain order
+
+    def copy_llike(self, first, n, dst):
+        out = dst.numpy().reshape(n, self.W)
+        for k in range(n):
+            for w in range(self.W):
+                out[k, w] = self.ll[self.idx(w, self.r0 + first + k)]
+
+    def _add_state(self, c):
+        every = self.lad.s.contents.add_every_N
+        if self.nhist[c] % every == 0:
+            self.nsize[c] += 1
+        self.nhist[c] += 1
+
+    def exchange_decide(self, ll_below, ll_above, H, send_up, send_down):
+        r0, r1, Nt, W, D = self.r0, self.r0 + self.nloc, self.Nt, self.W, self.D
+        step = self.lad.step
+        wlo = r0 - (1 if ll_below is not None else 0)
+        whi = r1 - 1 + (H if ll_above is not None else 0)
+        lb = None if ll_below is None else ll_below.numpy()
+        la = None if ll_above is None else ll_above.numpy().reshape(H, W)
+        su = None if send_up is None else send_up.numpy().reshape(D + 2, W)
+        sd = None if send_down is None else send_down.numpy().reshape(D + 2, W)
+        self.touched[:] = 0
+        self.moves = []        # (dst chain, row) applied in finish
+        self.arrive = []       # (dst chain, "above"/"below", w)
+        beta = self.lad.beta
+        for w in range(W):
+            cand, lu = [], []
+            for k in range(self.ms):
+                o = O.draw_block(self.seed, 1, w, step, k)
+                n = -2
+                if Nt > 1 and O.lib().ptmo_u01(o[0]) < self.thresh:
+                    n = int(O.lib().ptmo_u01(o[1]) * (Nt - 1))
+                    for j in cand:
+                        if j == n or j + 1 == n:
+                            n = -2
+                            break
+                cand.append(n)
+                lu.append(O.lib().ptmo_log(O.lib().ptmo_u01(o[2])))
+
+            def llike0(r):
+                if r < r0:
+                    return lb[w]
+                if r >= r1:
+                    return la[r - r1, w]
+                return self.ll[self.idx(w, r)]
+            cur = {}      # rung -> (llike, source rung) view of the window
+            def get(r):
+                if r not in cur:
+                    cur[r] = (llike0(r), r)
+                return cur[r]
+            taint = Nt + 1
+            tch = {}
+            for k, i in enumerate(cand):
+                if i < 0:
+                    continue
+                if i + 1 > whi or i < wlo:
+                    if i == whi and i + 1 < Nt:
+                        taint = i
+                    continue
+                if i + 1 >= taint:
+                    if i + 1 <= r1:
+                        self.far = True
+                    taint = min(taint, i)
+                    continue
+                (lla, sa), (llb, sb) = get(i), get(i + 1)
+                a_, b_ = (lla if lla > -1e200 else -1e200), (llb if llb > -1e200 else -1e200)
+                logH = -(beta[i + 1] - beta[i]) * (b_ - a_)
+                acc = True
+                if logH < 0:
+                    acc = lu[k] < logH
+                if acc:
+                    if i + 1 == r0 and sd is not None:         # the row leaving downwards
+                        s = sb
+                        if not (r0 <= s < r1):
+                            self.far = True
+                        else:
+                            c = self.idx(w, s)
+                            sd[:D, w] = self.x[c]; sd[D, w] = self.ll[c]; sd[D + 1, w] = self.lp[c]
+                    if i + 1 == r1 and r1 < Nt and su is not None:
+                        c = self.idx(w, i)
+                        su[:D, w] = self.x[c]; su[D, w] = self.ll[c]; su[D + 1, w] = self.lp[c]
+                    cur[i], cur[i + 1] = (llb, sb), (lla, sa)
+                    if r0 <= i < r1:
+                        self.swap_acc[w, i] += 1
+                tch[i] = tch.get(i, 0) + 1
+                tch[i + 1] = tch.get(i + 1, 0) + 1
+                if r0 <= i < r1:
+                    self.swap_try[w, i] += 1
+            for r, n in tch.items():
+                if r0 <= r < r1:
+                    c = self.idx(w, r)
+                    self.touched[c] = n
+                    _, s = cur[r]
+                    if r0 <= s < r1:
+                        if s != r:
+                            cs = self.idx(w, s)
+                            self.moves.append((c, self.x[cs].copy(), self.ll[cs], self.lp[cs]))
+                    else:
+                        self.arrive.append((c, "above" if s >= r1 else "below", w))
+
+    def finish_and_sweep(self, recv_below, recv_above):
+        D, W = self.D, self.W
+        rb = None if recv_below is None else recv_below.numpy().reshape(D + 2, W)
+        ra = None if recv_above is None else recv_above.numpy().reshape(D + 2, W)
+        for c, x, ll, lp in self.moves:
+            self.x[c] = x; self.ll[c] = ll; self.lp[c] = lp
+        for c, where, w in self.arrive:
+            buf = ra if where == "above" else rb
+            self.x[c] = buf[:D, w]; self.ll[c] = buf[D, w]; self.lp[c] = buf[D + 1, w]
+        L = O.lib()
+        lad = self.lad
+        for w in range(W):
+            for r in range(self.r0, self.r0 + self.nloc):
+                c = self.idx(w, r)
+                if self.touched[c]:
+                    for _ in range(int(self.touched[c])):
+                        self._add_state(c)
+                    continue
+                L.ptmo_mh_step(lad.s, lad.pb.p, C.byref(lad._props[r]), lad.rng, w, r)
+        lad.s.contents.step += 1
+
+    def sync(self):
+        if self.far:
+            raise RuntimeError("halo exceeded / far move")
+
+    # local results in engine order (rung-major over the local rungs)
+    def local(self, arr):
+        a = np.asarray(arr)
+        return np.stack([a[self.idx(w, r)] for r in range(self.r0, self.r0 + self.nloc) for w in range(self.W)])

@@ -1,0 +1,63 @@
+"""N>1 path on CPU: the sharding protocol of ptmcmc_amd.parallel.ShardedLadder over torch.distributed/gloo
+(world_size 2 and 3), with the oracle as each rank's local compute, against the single-process oracle."""
+import os
+import socket
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+import parity_util as PU
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("world,D,Nt,W,halo,sr", [(2, 4, 10, 3, 4, 0.4), (3, 3, 12, 2, 3, 0.45)])
+def test_sharded_ladder_over_gloo_matches_single_process(world, D, Nt, W, halo, sr):
+    sys.path.insert(0, HERE)
+    import dist_worker
+    nsteps = 25
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "rank%d.npz")
+        port = free_port()
+        procs = []
+        for r in range(world):
+            env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                       OMP_NUM_THREADS="1")
+            procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "dist_worker.py"), str(D), str(Nt), str(W),
+                                           str(nsteps), str(halo), str(sr), out], env=env))
+        for p in procs:
+            assert p.wait(timeout=300) == 0
+        parts = [np.load(out % r) for r in range(world)]
+    ref = dist_worker.make_ladder(D, Nt, W, sr, 0x5EED0001)
+    ref.pt_step(nsteps)
+    x = np.concatenate([p["x"] for p in parts])
+    assert np.array_equal(x, PU.to_engine_order(ref.x, Nt, W))
+    assert np.array_equal(np.concatenate([p["ll"] for p in parts]), PU.to_engine_order(ref.llike, Nt, W))
+    assert np.array_equal(np.concatenate([p["nhist"] for p in parts]), PU.to_engine_order(ref.nhist, Nt, W))
+    assert np.array_equal(np.concatenate([p["nacc"] for p in parts]), PU.to_engine_order(ref.naccept, Nt, W))
+    assert np.array_equal(sum(p["st"] for p in parts), ref.swap_count)
+    assert np.array_equal(sum(p["sa"] for p in parts), ref.swap_accept_count)
+    assert ref.swap_accept_count.sum() > 0
+
+
+def test_shard_bounds_cover_the_ladder():
+    from ptmcmc_amd.parallel import shard_bounds
+    for nt in (1024, 10, 7):
+        for g in (1, 2, 3, 4, 8):
+            if g > nt:
+                continue
+            blocks = [shard_bounds(nt, g, r) for r in range(g)]
+            assert blocks[0][0] == 0 and sum(n for _, n in blocks) == nt
+            for (a, n), (b, _) in zip(blocks, blocks[1:]):
+                assert a + n == b
