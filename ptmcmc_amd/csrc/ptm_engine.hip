@@ -63,6 +63,10 @@ struct ptm_engine {
   std::vector<double> h_plo, h_phi;
   ptm_loglike_batch_fn cb = nullptr;
   void* cb_user = nullptr;
+  double *xprop = nullptr, *lprior_new = nullptr, *llike_new = nullptr;  // device buffers of the callback path
+  unsigned char* gate = nullptr;
+  std::vector<double> h_xprop, h_batch, h_llbatch, h_llnew;
+  std::vector<unsigned char> h_gate;
   // timing
   hipEvent_t t0 = nullptr, t1 = nullptr;
   std::vector<hipEvent_t> kev;  // pairs
@@ -181,7 +185,7 @@ extern "C" int ptm_engine_destroy(ptm_engine* e) {
   (void)hipStreamSynchronize(e->stream);
   void* ptrs[] = {e->x[0], e->x[1], e->ll[0], e->ll[1], e->lp[0], e->lp[1], e->ntries, e->naccept, e->last_type, e->dst, e->arr_below, e->arr_above,
                   e->err, e->nhist, e->swap_try, e->swap_acc, e->touch, e->last_pairs, e->last_acc, e->blo,
-                  e->bhi, e->ptype, e->bmin, e->bmax, e->plo, e->phi, e->pcoef, e->P2, e->mean, e->beta, e->prop, e->prop_dense, e->onedfrac};
+                  e->bhi, e->ptype, e->bmin, e->bmax, e->plo, e->phi, e->pcoef, e->P2, e->mean, e->beta, e->prop, e->prop_dense, e->onedfrac, e->xprop, e->lprior_new, e->llike_new, e->gate};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (hipEvent_t ev : e->kev) (void)hipEventDestroy(ev);
@@ -285,14 +289,33 @@ extern "C" int ptm_set_target_gaussian(ptm_engine* e, const double* mean, const 
   if (mean && (rc = upload(e->mean, mean, D, e->stream))) return rc;
   e->like0 = like0;
   e->have_target = 1;
-  e->cb = nullptr;
+  e->cb = nullptr;  // a device target replaces a host callback
   return PTM_OK;
 }
 
 extern "C" int ptm_set_target_callback(ptm_engine* e, ptm_loglike_batch_fn fn, void* user) {
   if (!e || !fn) return fail(PTM_ERR_INVALID, "null argument");
+  const size_t Nc = e->Nc, DP = e->DP;
+  int rc;
+  if (!e->xprop && ((rc = dalloc(&e->xprop, Nc * DP)) || (rc = dalloc(&e->lprior_new, Nc)) || (rc = dalloc(&e->llike_new, Nc)) ||
+                    (rc = dalloc(&e->gate, Nc))))
+    return rc;
+  e->h_xprop.resize(Nc * DP); e->h_gate.resize(Nc); e->h_llnew.assign(Nc, 0.0);
   e->cb = fn; e->cb_user = user;
-  return fail(PTM_ERR_UNSUPPORTED, "host-callback likelihood path is not built yet (DESIGN.md: config C5)");
+  e->have_target = 1;
+  return PTM_OK;
+}
+
+// the user's batched log-likelihood on `n` chains picked by `pick` (indices into the SoA image `soa` with row length Nc)
+static int call_user(ptm_engine* e, const std::vector<double>& soa, const std::vector<size_t>& pick, std::vector<double>& out) {
+  const size_t Nc = e->Nc, D = e->D, n = pick.size();
+  out.assign(n, 0.0);
+  if (!n) return PTM_OK;
+  e->h_batch.resize(n * D);
+  for (size_t k = 0; k < n; ++k)
+    for (size_t d = 0; d < D; ++d) e->h_batch[k * D + d] = soa[d * Nc + pick[k]];
+  e->cb(e->cb_user, e->h_batch.data(), (int)n, (int)D, out.data());
+  return PTM_OK;
 }
 
 extern "C" int ptm_set_ladder(ptm_engine* e, const double* beta) {
@@ -390,7 +413,7 @@ static SweepSel sweep_sel(const ptm_engine* e) {
   SweepSel s;
   s.kind = e->prop_kind == PTM_PROP_DIAG ? KIND_DIAG : (e->prop_kind == PTM_PROP_LOWER ? KIND_LOWER : KIND_DENSE);
   s.uni = (e->W % 64) == 0;
-  s.simple = s.uni && !e->has_bounds && e->all_uniform && !e->has_mean && !e->any_oned;
+  s.simple = s.uni && !e->has_bounds && e->all_uniform && !e->has_mean && !e->any_oned && !e->cb;
   return s;
 }
 
@@ -407,12 +430,37 @@ static int launch_sweep(ptm_engine* e, const double* recv_below, const double* r
     HIPCHK(hipEventRecord(ev0, e->stream));
   }
   const SweepSel sel = sweep_sel(e);
-  switch (e->DP) {
-    case 4: HIPCHK(launch_sweep_4(p, sel, e->stream)); break;
-    case 8: HIPCHK(launch_sweep_8(p, sel, e->stream)); break;
-    case 16: HIPCHK(launch_sweep_16(p, sel, e->stream)); break;
-    case 32: HIPCHK(launch_sweep_32(p, sel, e->stream)); break;
-    default: return fail(PTM_ERR_UNSUPPORTED, "dim > 32 is not built in this round");
+  auto launch = [&](const Dev& q) -> hipError_t {
+    switch (e->DP) {
+      case 4: return launch_sweep_4(q, sel, e->stream);
+      case 8: return launch_sweep_8(q, sel, e->stream);
+      case 16: return launch_sweep_16(q, sel, e->stream);
+      case 32: return launch_sweep_32(q, sel, e->stream);
+    }
+    return hipErrorInvalidValue;
+  };
+  if (e->DP > 32) return fail(PTM_ERR_UNSUPPORTED, "dim > 32 is not built in this round");
+  if (!e->cb) {
+    HIPCHK(launch(p));
+  } else {
+    // host-callback likelihood: propose kernel -> user function on the gated proposals -> accept kernel
+    const size_t Nc = e->Nc, DP = e->DP;
+    p.xprop = e->xprop; p.lprior_new = e->lprior_new; p.gate = e->gate; p.llike_new = e->llike_new;
+    p.mode = 1;
+    HIPCHK(hipMemsetAsync(e->gate, 0, Nc, e->stream));
+    HIPCHK(launch(p));
+    HIPCHK(hipMemcpyAsync(e->h_gate.data(), e->gate, Nc, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(e->h_xprop.data(), e->xprop, Nc * DP * 8, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    std::vector<size_t> pick;
+    for (size_t c = 0; c < Nc; ++c)
+      if (e->h_gate[c] & 2) pick.push_back(c);
+    int rc = call_user(e, e->h_xprop, pick, e->h_llbatch);
+    if (rc) return rc;
+    for (size_t k = 0; k < pick.size(); ++k) e->h_llnew[pick[k]] = e->h_llbatch[k];
+    HIPCHK(hipMemcpyAsync(e->llike_new, e->h_llnew.data(), Nc * 8, hipMemcpyHostToDevice, e->stream));
+    p.mode = 2;
+    HIPCHK(launch(p));
   }
   if (ev1) HIPCHK(hipEventRecord(ev1, e->stream));
   e->cur = 1 - e->cur;
@@ -492,7 +540,16 @@ extern "C" int ptm_set_states(ptm_engine* e, const double* X, const double* llik
   e->cur = 0;
   if ((rc = upload(e->x[0], soa.data(), Nc * DP, e->stream))) return rc;
   if (llike && (rc = upload(e->ll[0], llike, Nc, e->stream))) return rc;
-  if ((rc = run_eval(e, (int)Nc, e->x[0], nullptr, e->lp[0], e->ll[0], llike ? 0 : 1))) return rc;
+  if ((rc = run_eval(e, (int)Nc, e->x[0], nullptr, e->lp[0], e->ll[0], (llike || e->cb) ? 0 : 1))) return rc;
+  if (e->cb && !llike) {
+    // MH_chain::add_state(s) with the 999 sentinel: the likelihood plug-in evaluates the (enforced) start states (chain.cc:925)
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipMemcpy(e->h_xprop.data(), e->x[0], Nc * DP * 8, hipMemcpyDeviceToHost));
+    std::vector<size_t> all(Nc);
+    for (size_t c = 0; c < Nc; ++c) all[c] = c;
+    if ((rc = call_user(e, e->h_xprop, all, e->h_llbatch))) return rc;
+    if ((rc = upload(e->ll[0], e->h_llbatch.data(), Nc, e->stream))) return rc;
+  }
   if ((rc = reset_counters(e))) return rc;
   HIPCHK(hipStreamSynchronize(e->stream));
   e->have_state = 1;
@@ -502,6 +559,7 @@ extern "C" int ptm_set_states(ptm_engine* e, const double* X, const double* llik
 extern "C" int ptm_init_from_prior(ptm_engine* e) {
   if (!e) return fail(PTM_ERR_INVALID, "null engine");
   if (!e->have_target) return fail(PTM_ERR_INVALID, "set the target first");
+  if (e->cb) return fail(PTM_ERR_UNSUPPORTED, "prior draws with a host-callback likelihood are done by the caller (ptm_set_states)");
   for (int d = 0; d < e->D; ++d)
     if (e->h_ptype[d] != PTM_PRIOR_UNIFORM && e->h_ptype[d] != PTM_PRIOR_GAUSSIAN)
       return fail(PTM_ERR_UNSUPPORTED, "device prior draws exist for uniform/gaussian dimensions only (dimension %d)", d);

@@ -93,6 +93,13 @@ struct Dev {
   int *arr_below, *arr_above;             // [W] landing slot of the row arriving across the lower / upper boundary, or -1
   const double *recv_below, *recv_above;  // [(DP+2)][W] rows that crossed the shard boundary this step
   int* err;
+  // host-callback likelihood (bayes_likelihood::register_evaluate_log surface): the sweep is split around the host
+  //   mode 0: fused (device target)   mode 1: propose only -> xprop/lprior_new/gate   mode 2: accept with llike_new
+  int mode;
+  double* xprop;            // [DP][Nc] proposed (enforced) states
+  double* lprior_new;       // [Nc]
+  unsigned char* gate;      // [Nc] bit0: state valid, bit1: likelihood wanted (chain.cc:980)
+  const double* llike_new;  // [Nc] filled by the host for gated chains
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -364,14 +371,15 @@ __global__ __launch_bounds__(256, PTM_SWEEP_WAVES) void sweep_kernel(const Dev p
 
   const int tc = p.touch[c];  // > 0: the rung took part in that many exchange attempts => no MH move this step
   int out = c;                // slot this lane's row is written to
-  if (tc) {
+  const bool propose_only = !SIMPLE && p.mode == 1;
+  if (tc && !propose_only) {
     out = p.dst[c];
     p.nhist[c] += (unsigned int)tc;  // one add_state per attempt (chain.cc:1487-1490,1531-1534,1554-1557)
     p.touch[c] = 0;
     p.dst[c] = c;
   }
   // rows arriving from the adjacent shards are installed by the boundary rungs' lanes (one row per walker at most)
-  if (p.recv_above && rl == p.nloc - 1) {
+  if (!propose_only && p.recv_above && rl == p.nloc - 1) {
     const int a = p.arr_above[w];
     if (a >= 0) {
 #pragma unroll
@@ -382,7 +390,7 @@ __global__ __launch_bounds__(256, PTM_SWEEP_WAVES) void sweep_kernel(const Dev p
       p.arr_above[w] = -1;
     }
   }
-  if (p.recv_below && rl == 0) {
+  if (!propose_only && p.recv_below && rl == 0) {
     const int a = p.arr_below[w];
     if (a >= 0) {
 #pragma unroll
@@ -408,8 +416,11 @@ __global__ __launch_bounds__(256, PTM_SWEEP_WAVES) void sweep_kernel(const Dev p
 #pragma unroll
   for (int i = 0; i < DP; ++i) xn[i] = 0.0;
   const DrawCtx dc{p.seed, p.step, stream, (!SIMPLE) ? axis : -1};
+  const int mode = SIMPLE ? 0 : p.mode;
   // (touched lanes run the draw too: the DPP product needs every lane of the wave active, and they would idle anyway)
-  if (KIND == KIND_DIAG) {
+  if (mode == 2) {
+    // accept pass of the host-callback path: the proposal was drawn and stored by the propose pass
+  } else if (KIND == KIND_DIAG) {
     cdp fac = as_c(p.prop) + (size_t)rl * p.prop_stride;
 #pragma unroll
     for (int b = 0; b < DP / 4; ++b) {
@@ -444,13 +455,15 @@ __global__ __launch_bounds__(256, PTM_SWEEP_WAVES) void sweep_kernel(const Dev p
   for (int d = 0; d < DP; ++d) xk[d] = p.x_in[(size_t)d * Nc + c];
 #endif
   if (!tc) {
+    if (mode != 2) {
 #pragma unroll
-    for (int d = 0; d < DP; ++d) {
+      for (int d = 0; d < DP; ++d) {
 #if PTM_KEEP_X
-      xn[d] = xk[d] + xn[d];  // state::add (states.cc:205-214)
+        xn[d] = xk[d] + xn[d];  // state::add (states.cc:205-214)
 #else
-      xn[d] = p.x_in[(size_t)d * Nc + c] + xn[d];  // state::add (states.cc:205-214)
+        xn[d] = p.x_in[(size_t)d * Nc + c] + xn[d];  // state::add (states.cc:205-214)
 #endif
+      }
     }
     const double beta = as_c(p.beta)[rg];
     const double bl = beta * ll;
@@ -466,6 +479,11 @@ __global__ __launch_bounds__(256, PTM_SWEEP_WAVES) void sweep_kernel(const Dev p
 #pragma unroll
       for (int d = 0; d < DP; ++d) in = in && !(xn[d] < plo[d]) && !(xn[d] > phi[d]);
       newlprior = in ? p.lprior_const : -__builtin_inf();
+    } else if (mode == 2) {
+      valid = (p.gate[c] & 1) != 0;
+      newlprior = p.lprior_new[c];
+#pragma unroll
+      for (int d = 0; d < DP; ++d) xn[d] = p.xprop[(size_t)d * Nc + c];
     } else {
       valid = p.origin_valid != 0;  // Q9: the sum is built on an enforced zero state
       double xa[DP];                // general state-space / prior code works on an addressable copy
@@ -475,8 +493,20 @@ __global__ __launch_bounds__(256, PTM_SWEEP_WAVES) void sweep_kernel(const Dev p
 #pragma unroll
       for (int d = 0; d < DP; ++d) xn[d] = xa[d];
     }
+    const bool want_like = valid && (newlprior > -1e200 || newlprior - oldlprior > p.min_prior);  // chain.cc:980 (Q1)
+    if (mode == 1) {
+      // propose pass: hand the proposal to the host, change nothing else
+#pragma unroll
+      for (int d = 0; d < DP; ++d) p.xprop[(size_t)d * Nc + c] = xn[d];
+      p.lprior_new[c] = newlprior;
+      p.gate[c] = (unsigned char)((valid ? 1 : 0) | (want_like ? 2 : 0));
+      return;
+    }
     double newlike, newlpost;
-    if (valid && (newlprior > -1e200 || newlprior - oldlprior > p.min_prior)) {  // chain.cc:980 (Q1)
+    if (mode == 2) {
+      newlike = want_like ? p.llike_new[c] : -__builtin_inf();
+      newlpost = want_like ? newlike * beta + newlprior : -__builtin_inf();
+    } else if (want_like) {
 #if defined(PTM_ABLATE) && (PTM_ABLATE & 4)
       newlike = xn[0] + xn[DP - 1];  // ablation: no quadratic form
 #else
@@ -499,6 +529,7 @@ __global__ __launch_bounds__(256, PTM_SWEEP_WAVES) void sweep_kernel(const Dev p
     }
     p.nhist[c] += 1u;
   }
+  if (propose_only) return;  // (touched lanes: nothing to propose)
   if (out >= 0) {  // (a row that left the shard was packed into the send buffer by the exchange kernel)
 #pragma unroll
     for (int d = 0; d < DP; ++d) {

@@ -228,6 +228,21 @@ class Engine:
         m = None if mean is None else np.ascontiguousarray(mean, dtype=np.float64)
         _chk(self.L.ptm_set_target_gaussian(self.h, None if m is None else _d(m), _d(P), like0))
 
+    def set_target_callback(self, fn, batched=False):
+        """user plug-in likelihood (the C shape of bayes_likelihood::register_evaluate_log, bayesian.hh:536-552).
+        fn(x[D]) -> float, or with batched=True fn(X[n][D]) -> array of n."""
+        def tramp(user, Xp, n, dim, outp):
+            X = np.ctypeslib.as_array(Xp, shape=(n, dim))
+            out = np.ctypeslib.as_array(outp, shape=(n,))
+            if batched:
+                out[:] = fn(X)
+            else:
+                for k in range(n):
+                    out[k] = fn(X[k])
+        cb = LOGLIKE_BATCH_FN(tramp)
+        self._keep.append(cb)
+        _chk(self.L.ptm_set_target_callback(self.h, C.cast(cb, C.c_void_p), None))
+
     def set_ladder(self, beta):
         b = np.ascontiguousarray(beta, dtype=np.float64)
         assert b.size == self.Nt

@@ -302,3 +302,40 @@ def test_sharded_engines_match_single_engine(D, Nt, W, G, halo, sr):
         assert min(e.nloc for e in shards) <= 2   # only tiny shards may trip the halo / far-move guard in 40 steps
     for e in shards + [ref]:
         e.close()
+
+
+def test_host_callback_likelihood_C5_exampleLISA():
+    """BASELINE configs[4]: a user plug-in likelihood (the reference's toy LISA likelihood, exampleLISA.cc:59-72,130-142)
+    through the C-ABI callback, mixed uniform/polar/copolar prior with wrap + limit boundaries (exampleLISA.cc:528-593).
+    The propose kernel, the host call and the accept kernel must reproduce the oracle's chain bit for bit."""
+    import lisa_toy
+    D, Nt, W = 6, 16, 4
+    beta = E.geometric_ladder(Nt, 1e9)
+    rng = np.random.default_rng(4)
+    lo = np.array(lisa_toy.CENTERS) - np.array(lisa_toy.SCALES)
+    hi = np.array(lisa_toy.CENTERS) + np.array(lisa_toy.SCALES)
+    x0 = rng.uniform(lo + 0.05, hi - 0.05, size=(Nt * W, D))
+    sig = np.array(lisa_toy.SCALES) / 20.0
+    eng = E.Engine(D, Nt, W, swap_rate=0.3)
+    eng.set_bounds(lisa_toy.BLO, lisa_toy.BHI, lisa_toy.BMIN, lisa_toy.BMAX)
+    eng.set_prior(lisa_toy.TYPES, lisa_toy.CENTERS, lisa_toy.SCALES)
+    eng.set_target_callback(lisa_toy.loglike)
+    eng.set_ladder(beta)
+    eng.set_proposals(E.PROP_DIAG, np.tile(sig, (Nt, 1)) / np.sqrt(beta)[:, None].clip(1e-3), np.full(Nt, 0.5))
+    eng.set_states(x0)
+    pb = O.Problem(D)
+    pb.set_bounds(lisa_toy.BLO, lisa_toy.BHI, lisa_toy.BMIN, lisa_toy.BMAX)
+    pb.set_prior(lisa_toy.TYPES, lisa_toy.CENTERS, lisa_toy.SCALES)
+    pb.set_user(lisa_toy.loglike)
+    lad = O.Ladder(pb, beta, W=W, swap_rate=0.3)
+    fac = np.tile(sig, (Nt, 1)) / np.sqrt(beta)[:, None].clip(1e-3)
+    lad.set_proposals([(O.PROP_DIAG, fac[r], 0.5) for r in range(Nt)])
+    lad.use_philox(0x5EED0001)
+    lad.set_states(PU.to_oracle_order(x0, Nt, W))
+    PU.assert_same_state(eng, lad, "start")
+    for k in range(6):
+        eng.step(5); eng.sync(); lad.pt_step(5)
+        PU.assert_same_state(eng, lad, "after %d steps" % (5 * (k + 1)))
+    assert eng.naccept.sum() - eng.Nc > 50
+    assert (eng.last_type >= 0).any()
+    eng.close()
