@@ -1,0 +1,590 @@
+// ptmcmc_gpu.hh -- host-side C++ mirror of ptmcmc's plug-in surface for the chain::step() path, on top of the C ABI
+// (include/ptm_engine.h).  Header only, C++11, no HIP types: link against libptm_engine.so.
+//
+// Same class names, constructor arguments and call sequence as the reference, so that user code written against
+//   states.hh / probability_function.hh / proposal_distribution.hh / bayesian.hh / chain.hh / ptmcmc.hh
+// reads the same here (namespace ptmgpu; `using namespace ptmgpu;` gives the reference's global names):
+//
+//   stateSpace space(D); space.set_bound(i, boundary(boundary::wrap, boundary::wrap, 0, 2*M_PI));      states.hh:29-145
+//   bayes_likelihood like;  like.basic_setup(&space, types, centers, scales);                        bayesian.hh:360-381
+//   like.register_reference_object(obj);  like.register_evaluate_log(fn);                            bayesian.hh:536-552
+//   gaussian_prop prop(cov_or_sigmas, oneDfrac);                                       proposal_distribution.hh:145-227
+//   parallel_tempering_chains ptc(Ntemps, Tmax, swap_rate, add_every_N);                                chain.cc:1163
+//   ptc.initialize(&like, like.getObjectPrior().get(), 1);  ptc.set_proposal(prop);                  chain.cc:1281,1367
+//   for (...) ptc.step();                                                                               chain.cc:1393
+//   ptc.subchain(i)->getState() / getLogPost() / getLogLike() / invTemp()                             chain.hh:89-141
+//
+// What runs where: these classes only DESCRIBE the problem (bounds, per-dimension prior, target, ladder, per-rung
+// proposal factor) to the engine; every step() is kernels on the MI355X.  A likelihood registered as a function pointer is
+// called on the host between the propose and the accept kernel (batched); `gaussian_likelihood` is evaluated on the
+// device.  Errors follow the reference: print and exit(1) (chain.cc:967-971, states.cc:87-90).
+#ifndef PTMCMC_GPU_HH
+#define PTMCMC_GPU_HH
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iostream>
+#include <map>
+#include <memory>
+#include <sstream>
+#include <string>
+#include <valarray>
+#include <vector>
+
+#include "ptm_engine.h"
+
+namespace ptmgpu {
+
+inline void ptm_check(int rc, const char* what) {
+  if (rc != PTM_OK) {
+    std::cout << what << ": " << ptm_last_error() << std::endl;
+    exit(1);
+  }
+}
+
+// ---- states.hh --------------------------------------------------------------------------------------------------
+class boundary {  // states.hh:29-48
+  int lowertype, uppertype;
+  double xmin, xmax;
+
+ public:
+  static const int open = 0, limit = 1, reflect = 2, wrap = 3;
+  boundary(int lowertype = open, int uppertype = open, double min = -INFINITY, double max = INFINITY)
+      : lowertype(lowertype), uppertype(uppertype), xmin(min), xmax(max) {}
+  void getDomainLimits(double& xmin_, double& xmax_) const { xmin_ = xmin; xmax_ = xmax; }
+  bool isWrapped() const { return lowertype == wrap && uppertype == wrap; }
+  int lower() const { return lowertype; }
+  int upper() const { return uppertype; }
+  std::string show() const {
+    std::ostringstream s;
+    if (lowertype == wrap) s << "w[" << xmin << "," << xmax << ")w";
+    else s << (lowertype == reflect ? "R[" : lowertype == limit ? "[" : "(") << xmin << "," << xmax
+           << (uppertype == reflect ? "]R" : uppertype == limit ? "]" : ")");
+    return s.str();
+  }
+};
+
+class stateSpace {  // states.hh:60-145 (names, bounds; symmetries are out of scope)
+  int dim;
+  std::vector<boundary> bounds;
+  std::vector<std::string> names;
+  std::map<std::string, int> index;
+  bool have_names;
+
+ public:
+  stateSpace(int dim = 0) : dim(dim), bounds(dim), have_names(false) {}
+  int size() const { return dim; }
+  void set_bound(int i, const boundary& b) {
+    if (i < dim) bounds[i] = b;
+    else { std::cout << "stateSpace::set_bound: Index out of range, " << i << ">=" << dim << "." << std::endl; exit(1); }
+  }
+  boundary get_bound(int i) const {
+    if (i < 0 || i >= dim) { std::cout << "stateSpace::set_bound: Index out of range, " << i << ">=" << dim << "." << std::endl; exit(1); }
+    return bounds[i];
+  }
+  void set_names(const std::vector<std::string>& n) {
+    if ((int)n.size() < dim) { std::cout << "stateSpace::set_names: Vector of param names is too short. Quitting." << std::endl; exit(-1); }
+    names.assign(n.begin(), n.begin() + dim);
+    for (int i = 0; i < dim; i++) index[names[i]] = i;
+    have_names = true;
+  }
+  void set_names(const std::string n[]) { set_names(std::vector<std::string>(n, n + dim)); }
+  std::string get_name(int i) const { return have_names && i < dim ? names[i] : "[unnamed]"; }
+  int get_index(const std::string& name) const { return have_names && index.count(name) ? index.at(name) : -1; }
+  int requireIndex(const std::string& name) const {
+    int i = get_index(name);
+    if (i < 0) { std::cout << "stateSpace::checkNames(): Name '" << name << "' not found in state space." << std::endl; exit(1); }
+    return i;
+  }
+  std::string show() const {
+    std::ostringstream s;
+    s << "StateSpace:(dim=" << dim << ")\n";
+    for (int i = 0; i < dim; i++) s << "  " << get_name(i) << " in " << bounds[i].show() << "\n";
+    return s.str();
+  }
+};
+
+class state {  // states.hh:147-234: a host value (parameters + space); validity is decided on the device
+  const stateSpace* space;
+  std::valarray<double> params;
+  bool valid;
+
+ public:
+  state(const stateSpace* space = nullptr, int n = 0) : space(space), params(0.0, n), valid(space != nullptr) {}
+  state(const stateSpace* sp, const std::valarray<double>& a) : space(sp), params(a), valid(sp != nullptr) {}
+  state(const stateSpace* sp, const std::vector<double>& a) : space(sp), params(a.data(), a.size()), valid(sp != nullptr) {}
+  int size() const { return params.size(); }
+  double get_param(int i) const { return params[i]; }
+  double get_param(const std::string& name) const { return params[space->requireIndex(name)]; }
+  void set_param(int i, double v) { params[i] = v; }
+  std::valarray<double> get_params() const { return params; }
+  std::vector<double> get_params_vector() const { return std::vector<double>(std::begin(params), std::end(params)); }
+  const stateSpace* getSpace() const { return space; }
+  bool invalid() const { return !valid; }
+  std::string get_string(int prec = -1) const {
+    std::ostringstream s;
+    if (prec > 0) s.precision(prec);
+    for (int i = 0; i < size(); i++) s << (i ? ", " : "") << params[i];
+    return s.str();
+  }
+};
+
+// ---- probability_function.hh --------------------------------------------------------------------------------------
+class probability_function {  // probability_function.hh:31-44
+ protected:
+  const stateSpace* space;
+
+ public:
+  virtual ~probability_function() {}
+  probability_function(const stateSpace* space) : space(space) {}
+  virtual double evaluate_log(state& s) { return 0; }
+  const stateSpace* get_space() const { return space; }
+};
+
+class sampleable_probability_function : public probability_function {  // probability_function.hh:48-83
+ protected:
+  unsigned int dim;
+
+ public:
+  sampleable_probability_function(const stateSpace* space) : probability_function(space), dim(0) {}
+  virtual int getDim() const { return dim; }
+  virtual void getScales(std::valarray<double>& out) const {}
+  // engine description: per-dimension (type, center, halfwidth), types as mixed_dist_product::{uniform,...}
+  virtual void describe(std::vector<int>& types, std::vector<double>& centers, std::vector<double>& halfwidths) const = 0;
+};
+
+class mixed_dist_product : public sampleable_probability_function {  // probability_function.hh:141-170, .cc:219-262
+ protected:
+  std::valarray<int> types;
+  std::valarray<double> centers, halfwidths;
+
+ public:
+  static const int uniform = 1, gaussian = 2, polar = 3, copolar = 4, log = 5;
+  mixed_dist_product(const stateSpace* space, const std::valarray<int>& types, const std::valarray<double>& centers,
+                     const std::valarray<double>& halfwidths)
+      : sampleable_probability_function(space), types(types), centers(centers), halfwidths(halfwidths) {
+    dim = centers.size();
+    if (dim != halfwidths.size() || dim != types.size() || (space && (unsigned)space->size() > dim)) {
+      std::cout << "mixed_dist_product(constructor): Array sizes mismatch.\n";
+      exit(1);
+    }
+    for (unsigned i = 0; i < dim; i++)
+      if (types[i] == log && (centers[i] <= 0 || halfwidths[i] <= 1)) {
+        std::cout << "mixed_dist_product(constructor): Need centers>0 and halfwidths>1 for log-type dimension [" << i << "]." << std::endl;
+        exit(1);
+      }
+  }
+  void getScales(std::valarray<double>& out) const override { out = halfwidths; }
+  void describe(std::vector<int>& t, std::vector<double>& c, std::vector<double>& h) const override {
+    t.assign(std::begin(types), std::end(types));
+    c.assign(std::begin(centers), std::end(centers));
+    h.assign(std::begin(halfwidths), std::end(halfwidths));
+  }
+};
+
+class uniform_dist_product : public mixed_dist_product {  // probability_function.hh:113-125
+  static std::valarray<double> mid(const std::valarray<double>& a, const std::valarray<double>& b) { return (a + b) / 2.0; }
+  static std::valarray<double> half(const std::valarray<double>& a, const std::valarray<double>& b) { return (b - a) / 2.0; }
+
+ public:
+  uniform_dist_product(const stateSpace* space, const std::valarray<double>& min_corner, const std::valarray<double>& max_corner)
+      : mixed_dist_product(space, std::valarray<int>(uniform, min_corner.size()), mid(min_corner, max_corner), half(min_corner, max_corner)) {}
+};
+
+class gaussian_dist_product : public mixed_dist_product {  // probability_function.hh:92-108
+ public:
+  gaussian_dist_product(const stateSpace* space, const std::valarray<double>& x0s, const std::valarray<double>& sigmas)
+      : mixed_dist_product(space, std::valarray<int>(gaussian, x0s.size()), x0s, sigmas) {}
+};
+
+// ---- bayesian.hh: the likelihood plug-in -----------------------------------------------------------------------------
+class bayes_likelihood : public probability_function {  // bayesian.hh:307-581 (minimal interface)
+ protected:
+  stateSpace nativeSpace;
+  std::shared_ptr<const sampleable_probability_function> nativePrior;
+  double (*user_evaluate_log)(void* object, const state& s);
+  void* user_object;
+  bool evaluate_log_registered;
+  double best_post;
+
+ public:
+  bool check_posterior;
+  bayes_likelihood() : probability_function(nullptr), user_evaluate_log(nullptr), user_object(nullptr),
+                       evaluate_log_registered(false), best_post(-INFINITY), check_posterior(true) {}
+  void basic_setup(const stateSpace* sp, sampleable_probability_function* prior) {  // bayesian.hh:345-358
+    nativeSpace = *sp;
+    nativePrior.reset(prior);
+    space = &nativeSpace;
+  }
+  void basic_setup(const stateSpace* sp, const std::vector<std::string>& types, const std::vector<double>& centers,
+                   const std::vector<double>& priorScales) {  // bayesian.hh:360-381
+    std::valarray<int> t(types.size());
+    for (size_t i = 0; i < types.size(); i++) {
+      const std::string& s = types[i];
+      if (s == "uni" || s == "uniform") t[i] = mixed_dist_product::uniform;
+      else if (s == "gauss" || s == "gaussian") t[i] = mixed_dist_product::gaussian;
+      else if (s == "pol" || s == "polar") t[i] = mixed_dist_product::polar;
+      else if (s == "cpol" || s == "copol") t[i] = mixed_dist_product::copolar;
+      else if (s == "log") t[i] = mixed_dist_product::log;
+      else { std::cout << "bayes_likelihood::basic_setup: unknown prior type '" << s << "'" << std::endl; exit(1); }
+    }
+    nativeSpace = *sp;
+    basic_setup(sp, new mixed_dist_product(&nativeSpace, t, std::valarray<double>(centers.data(), centers.size()),
+                                           std::valarray<double>(priorScales.data(), priorScales.size())));
+  }
+  void register_reference_object(void* object) { user_object = object; }
+  void register_evaluate_log(double (*function)(void* object, const state& s)) {
+    user_evaluate_log = function;
+    evaluate_log_registered = true;
+  }
+  std::shared_ptr<const sampleable_probability_function> getObjectPrior() const {
+    if (!nativePrior) { std::cout << "bayes_component::getObjectPrior: No prior is defined for this object!" << std::endl; exit(1); }
+    return nativePrior;
+  }
+  const stateSpace* getObjectStateSpace() const { return &nativeSpace; }
+  // host evaluation of the plug-in (bayesian.hh:553-581; the prior part of the posterior check happens on the device)
+  double evaluate_log(state& s) override {
+    if (!evaluate_log_registered) { std::cout << "bayes_component::panic!\nNo evaluate_log function is registered" << std::endl; exit(1); }
+    double result = (*user_evaluate_log)(user_object, s);
+    if (check_posterior && !std::isfinite(result) && !(result < 0)) result = -INFINITY;  // NaN/+inf -> -inf (bayesian.hh:569-575)
+    return result;
+  }
+  // device-resident targets override this and return true after describing themselves to the engine
+  virtual bool describe_device_target(ptm_engine* e) { return false; }
+  // C-ABI trampoline: the engine hands over the gated proposals of one sweep
+  static void batch_trampoline(void* self, const double* X, int n, int dim, double* out) {
+    bayes_likelihood* l = (bayes_likelihood*)self;
+    for (int k = 0; k < n; k++) {
+      state s(l->getObjectStateSpace(), std::valarray<double>(X + (size_t)k * dim, dim));
+      out[k] = l->evaluate_log(s);
+    }
+  }
+};
+
+// correlated Gaussian target evaluated ON the device: like0 - 1/2 (x-mean)^T P (x-mean) (cython/exampleGaussian.py:46-109)
+class gaussian_likelihood : public bayes_likelihood {
+  std::vector<double> mean, precision;
+  double like0;
+
+ public:
+  gaussian_likelihood(const std::vector<double>& precision_row_major, double like0, const std::vector<double>& mean = std::vector<double>())
+      : mean(mean), precision(precision_row_major), like0(like0) {}
+  bool describe_device_target(ptm_engine* e) override {
+    ptm_check(ptm_set_target_gaussian(e, mean.empty() ? nullptr : mean.data(), precision.data(), like0), "gaussian_likelihood");
+    return true;
+  }
+  double evaluate_log(state& s) override {
+    const int D = s.size();
+    double q = 0;
+    for (int i = 0; i < D; i++)
+      for (int j = 0; j < D; j++)
+        q += (s.get_param(i) - (mean.empty() ? 0 : mean[i])) * precision[i * D + j] * (s.get_param(j) - (mean.empty() ? 0 : mean[j]));
+    return like0 - 0.5 * q;
+  }
+};
+
+// ---- proposal_distribution.hh ---------------------------------------------------------------------------------------
+class proposal_distribution {  // proposal_distribution.hh:38-88 (what the device path needs of it)
+ public:
+  virtual ~proposal_distribution() {}
+  virtual proposal_distribution* clone() const = 0;
+  virtual std::string show() { return "UnspecifiedProposal()"; }
+  virtual bool device_describe(int dim, int& kind, std::vector<double>& factor, double& oneDfrac) const { return false; }
+};
+
+class gaussian_prop : public proposal_distribution {  // proposal_distribution.hh:145-227
+  bool identity_trans;
+  std::vector<double> factor;  // DIAG: sigmas; else dense D x D row-major V*diag(sqrt(lambda))
+  int ndim;
+  double oneDfrac;
+
+  // symmetric eigen-decomposition by cyclic Jacobi (the reference uses Eigen::SelfAdjointEigenSolver, hh:173-176);
+  // eigenvalues ascending, factor = V * diag(sqrt(lambda)) so that offset = factor * z as in hh:207-213
+  static void eigen_factor(std::vector<double> A, int n, std::vector<double>& F) {
+    std::vector<double> V(n * n, 0.0);
+    for (int i = 0; i < n; i++) V[i * n + i] = 1;
+    for (int sweep = 0; sweep < 100; sweep++) {
+      double off = 0;
+      for (int p = 0; p < n; p++) for (int q = p + 1; q < n; q++) off += A[p * n + q] * A[p * n + q];
+      if (off < 1e-300) break;
+      for (int p = 0; p < n; p++)
+        for (int q = p + 1; q < n; q++) {
+          if (std::fabs(A[p * n + q]) < 1e-300) continue;
+          double theta = (A[q * n + q] - A[p * n + p]) / (2 * A[p * n + q]);
+          double t = (theta >= 0 ? 1 : -1) / (std::fabs(theta) + std::sqrt(theta * theta + 1));
+          double c = 1 / std::sqrt(t * t + 1), s = t * c;
+          for (int k = 0; k < n; k++) { double a = A[k * n + p], b = A[k * n + q]; A[k * n + p] = c * a - s * b; A[k * n + q] = s * a + c * b; }
+          for (int k = 0; k < n; k++) { double a = A[p * n + k], b = A[q * n + k]; A[p * n + k] = c * a - s * b; A[q * n + k] = s * a + c * b; }
+          for (int k = 0; k < n; k++) { double a = V[k * n + p], b = V[k * n + q]; V[k * n + p] = c * a - s * b; V[k * n + q] = s * a + c * b; }
+        }
+    }
+    std::vector<int> order(n);
+    for (int i = 0; i < n; i++) order[i] = i;
+    for (int i = 0; i < n; i++) for (int j = i + 1; j < n; j++) if (A[order[j] * n + order[j]] < A[order[i] * n + order[i]]) std::swap(order[i], order[j]);
+    F.assign(n * n, 0.0);
+    for (int j = 0; j < n; j++) {
+      double lam = A[order[j] * n + order[j]];
+      double sg = std::sqrt(lam > 0 ? lam : 0.0);
+      for (int i = 0; i < n; i++) F[i * n + j] = V[i * n + order[j]] * sg;
+    }
+  }
+
+ public:
+  gaussian_prop(const std::valarray<double>& sigmas, double oneDfrac = 0.0, bool scaleWithTemp = false)
+      : identity_trans(true), factor(std::begin(sigmas), std::end(sigmas)), ndim(sigmas.size()), oneDfrac(oneDfrac) { check(); }
+  gaussian_prop(const std::vector<double>& sigmas, double oneDfrac = 0.0, bool scaleWithTemp = false)
+      : identity_trans(true), factor(sigmas), ndim(sigmas.size()), oneDfrac(oneDfrac) { check(); }
+  // covariance, row-major ndim x ndim (the reference takes an Eigen::MatrixXd, hh:165)
+  gaussian_prop(const std::vector<double>& covar, int ndim, double oneDfrac = 0.0, bool scaleWithTemp = false)
+      : identity_trans(false), ndim(ndim), oneDfrac(oneDfrac) {
+    if ((int)covar.size() != ndim * ndim) { std::cout << "gaussian_prop(constructor II): covar must be a square matrix!" << std::endl; exit(-1); }
+    eigen_factor(covar, ndim, factor);
+    check();
+  }
+  void check() const {
+    if (oneDfrac < 0 || oneDfrac > 1) { std::cout << "gaussian_prop(constructor): We require 0<=oneDfrac<=1. " << std::endl; exit(1); }
+  }
+  gaussian_prop* clone() const override { return new gaussian_prop(*this); }
+  std::string show() override {
+    std::ostringstream ss;
+    ss << "StepBy" << (identity_trans ? "" : "Covar") << "[dim=" << ndim << "](1Dfrac=" << oneDfrac << ")";
+    return ss.str();
+  }
+  bool device_describe(int dim, int& kind, std::vector<double>& f, double& odf) const override {
+    if (dim != ndim) { std::cout << "gaussian_prop: dimension mismatch with the chain (" << ndim << " vs " << dim << ")" << std::endl; exit(1); }
+    kind = identity_trans ? PTM_PROP_DIAG : PTM_PROP_DENSE;
+    f = factor;
+    odf = oneDfrac;
+    return true;
+  }
+};
+
+// ---- chain.hh ----------------------------------------------------------------------------------------------------------
+class chain {  // chain.hh:34-141 (the part of the interface the driver uses)
+ public:
+  virtual ~chain() {}
+  virtual void step() = 0;
+  virtual state getState(int elem = -1, bool raw_indexing = false) = 0;
+  virtual double getLogPost(int elem = -1, bool raw_indexing = false) = 0;
+  virtual double getLogLike(int elem = -1, bool raw_indexing = false) = 0;
+  virtual double invTemp() { return 1.0; }
+  virtual int multiplicity() { return 1; }
+  virtual chain* subchain(int index) { return this; }
+  virtual int getStep() = 0;
+  virtual std::string status() { return ""; }
+};
+
+class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:1163-1571
+  const int Ntemps, add_every_N;
+  const double Tmax, swap_rate, dpriormin;
+  ptm_engine* eng;
+  const stateSpace* sp;
+  int dim, nstep;
+  std::vector<double> temps, X, llike, lpost;
+  bool fresh;
+  std::vector<proposal_distribution*> props;
+
+  class rung_view : public chain {
+    parallel_tempering_chains* p;
+    int i;
+
+   public:
+    rung_view(parallel_tempering_chains* p, int i) : p(p), i(i) {}
+    void step() override { std::cout << "rung_view::step: step the ladder, not a rung" << std::endl; exit(1); }
+    state getState(int = -1, bool = false) override { p->refresh(); return state(p->sp, std::vector<double>(p->X.begin() + (size_t)i * p->dim, p->X.begin() + (size_t)(i + 1) * p->dim)); }
+    double getLogPost(int = -1, bool = false) override { p->refresh(); return p->lpost[i]; }
+    double getLogLike(int = -1, bool = false) override { p->refresh(); return p->llike[i]; }
+    double invTemp() override { return 1 / p->temps[i]; }
+    int getStep() override { return p->nstep; }
+  };
+  std::vector<rung_view> views;
+
+  void refresh() {
+    if (fresh) return;
+    ptm_check(ptm_get_states(eng, X.data()), "parallel_tempering_chains");
+    ptm_check(ptm_get_array(eng, PTM_ARR_LLIKE, llike.data()), "parallel_tempering_chains");
+    ptm_check(ptm_get_array(eng, PTM_ARR_LPOST, lpost.data()), "parallel_tempering_chains");
+    fresh = true;
+  }
+
+ public:
+  parallel_tempering_chains(int Ntemps, double Tmax, double swap_rate = 0.01, int add_every_N = 1, bool do_evid = false,
+                            bool verbose_evid = true, double dpriormin = -30)
+      : Ntemps(Ntemps), add_every_N(add_every_N), Tmax(Tmax), swap_rate(swap_rate), dpriormin(dpriormin), eng(nullptr),
+        sp(nullptr), dim(0), nstep(0), temps(Ntemps, 1.0), fresh(false) {
+    // geometric ladder, chain.cc:1181-1183
+    double tratio = Ntemps > 1 ? std::exp(std::log(Tmax) / (Ntemps - 1)) : 1.0;
+    for (int i = 1; i < Ntemps; i++) temps[i] = temps[i - 1] * tratio;
+  }
+  ~parallel_tempering_chains() {
+    if (eng) ptm_engine_destroy(eng);
+    for (auto p : props) delete p;
+  }
+  // chain.cc:1281-1365: n prior draws per rung; the device draws them (uniform / gaussian dimensions)
+  void initialize(bayes_likelihood* log_likelihood, const sampleable_probability_function* log_prior, int n = 1, uint64_t seed = 0x5EED0001ull,
+                  const std::vector<double>* start_states = nullptr) {
+    sp = log_prior->get_space();
+    dim = log_prior->getDim();
+    ptm_config cfg;
+    cfg.struct_size = sizeof cfg;
+    cfg.dim = dim; cfg.n_rungs = Ntemps; cfg.rung_begin = 0; cfg.rung_count = Ntemps; cfg.n_walkers = 1; cfg.seed = seed;
+    cfg.swap_rate = swap_rate; cfg.add_every_n = add_every_N; cfg.min_prior = dpriormin; cfg.device = -1; cfg.stream = nullptr;
+    cfg.time_kernels = 0; cfg.swap_log_steps = 0;
+    ptm_check(ptm_engine_create(&cfg, &eng), "parallel_tempering_chains::initialize");
+    std::vector<int> lo(dim), hi(dim), types;
+    std::vector<double> xmin(dim), xmax(dim), centers, halfwidths;
+    for (int i = 0; i < dim; i++) {
+      boundary b = sp ? sp->get_bound(i) : boundary();
+      lo[i] = b.lower(); hi[i] = b.upper();
+      b.getDomainLimits(xmin[i], xmax[i]);
+      if (lo[i] == boundary::open && hi[i] == boundary::open) xmin[i] = xmax[i] = 0;
+    }
+    ptm_check(ptm_set_bounds(eng, lo.data(), hi.data(), xmin.data(), xmax.data()), "set_bounds");
+    log_prior->describe(types, centers, halfwidths);
+    ptm_check(ptm_set_prior(eng, types.data(), centers.data(), halfwidths.data()), "set_prior");
+    if (!log_likelihood->describe_device_target(eng))
+      ptm_check(ptm_set_target_callback(eng, &bayes_likelihood::batch_trampoline, log_likelihood), "set_target_callback");
+    std::vector<double> beta(Ntemps);
+    for (int i = 0; i < Ntemps; i++) beta[i] = 1 / temps[i];  // chain.cc:1340
+    ptm_check(ptm_set_ladder(eng, beta.data()), "set_ladder");
+    X.assign((size_t)Ntemps * dim, 0.0); llike.assign(Ntemps, 0.0); lpost.assign(Ntemps, 0.0);
+    if (start_states) {
+      ptm_check(ptm_set_states(eng, start_states->data(), nullptr), "set_states");
+    } else {
+      int rc = ptm_init_from_prior(eng);
+      if (rc == PTM_ERR_UNSUPPORTED) {
+        std::cout << "parallel_tempering_chains::initialize: " << ptm_last_error() << "; pass start states" << std::endl;
+        exit(1);
+      }
+      ptm_check(rc, "init_from_prior");
+    }
+    views.clear();
+    for (int i = 0; i < Ntemps; i++) views.push_back(rung_view(this, i));
+    fresh = false;
+  }
+  // chain.cc:1367-1386: one clone per rung
+  void set_proposal(proposal_distribution& proposal) {
+    int kind = 0;
+    double odf = 0;
+    std::vector<double> f, all, odfs(Ntemps);
+    for (int i = 0; i < Ntemps; i++) {
+      props.push_back(proposal.clone());
+      if (!props.back()->device_describe(dim, kind, f, odf)) {
+        std::cout << "parallel_tempering_chains::set_proposal: " << proposal.show() << " has no device form (only gaussian_prop in this build)" << std::endl;
+        exit(1);
+      }
+      all.insert(all.end(), f.begin(), f.end());
+      odfs[i] = odf;
+    }
+    ptm_check(ptm_set_proposals(eng, kind, all.data(), odfs.data()), "set_proposals");
+  }
+  // per-rung factors for proposals that differ by rung (what user_gaussian_prop's check_update achieves in the reference)
+  void set_proposal_factors(int kind, const std::vector<double>& factors, const std::vector<double>& oneDfracs = std::vector<double>()) {
+    ptm_check(ptm_set_proposals(eng, kind, factors.data(), oneDfracs.empty() ? nullptr : oneDfracs.data()), "set_proposals");
+  }
+  void step() override {
+    ptm_check(ptm_step(eng, 1), "parallel_tempering_chains::step");
+    nstep++;
+    fresh = false;
+  }
+  void step(int n) {
+    ptm_check(ptm_step(eng, n), "parallel_tempering_chains::step");
+    nstep += n;
+    fresh = false;
+  }
+  state getState(int = -1, bool = false) override { return views[0].getState(); }
+  double getLogPost(int = -1, bool = false) override { return views[0].getLogPost(); }
+  double getLogLike(int = -1, bool = false) override { return views[0].getLogLike(); }
+  int getStep() override { return nstep; }
+  int multiplicity() override { return Ntemps; }
+  chain* subchain(int index) override {
+    if (index >= 0 && index < Ntemps) return &views[index];
+    std::cout << "parallel_tempering_chains::subchain:index out of range. (" << index << " of " << Ntemps << ")" << std::endl;
+    exit(1);
+  }
+  ptm_engine* engine() { return eng; }
+  // swap_count / swap_accept_count (chain.hh:244-245)
+  void swap_counts(std::vector<int64_t>& tries, std::vector<int64_t>& accepts) {
+    tries.assign(Ntemps > 1 ? Ntemps - 1 : 1, 0); accepts = tries;
+    ptm_check(ptm_get_swap_counts(eng, tries.data(), accepts.data()), "swap_counts");
+  }
+  std::string status() override {  // chain.cc:2053-2094 flavour
+    refresh();
+    std::vector<int32_t> nt(Ntemps), na(Ntemps);
+    ptm_get_array(eng, PTM_ARR_NTRIES, nt.data());
+    ptm_get_array(eng, PTM_ARR_NACCEPT, na.data());
+    std::ostringstream s;
+    for (int i = 0; i < Ntemps; i++)
+      s << "T=" << temps[i] << ": lpost=" << lpost[i] << " llike=" << llike[i] << " acc=" << (double)na[i] / nt[i] << "\n";
+    return s.str();
+  }
+  // MH_chain::dumpChain row format of the current state (chain.cc:1112-1135): i lpost llike acc type: params invtemp
+  void dumpCurrent(int ichain, std::ostream& os) {
+    refresh();
+    std::vector<int32_t> nt(Ntemps), na(Ntemps), ty(Ntemps);
+    ptm_get_array(eng, PTM_ARR_NTRIES, nt.data());
+    ptm_get_array(eng, PTM_ARR_NACCEPT, na.data());
+    ptm_get_array(eng, PTM_ARR_LAST_TYPE, ty.data());
+    os << nstep << " " << lpost[ichain] << " " << llike[ichain] << " " << (double)na[ichain] / nt[ichain] << " " << ty[ichain] << ": ";
+    for (int j = 0; j < dim; j++) os << X[(size_t)ichain * dim + j] << " ";
+    os << 1 / temps[ichain] << std::endl;
+  }
+};
+
+// ---- ptmcmc.hh: the driver, reduced to the run loop around cc->step() (ptmcmc.cc:530-679) ---------------------------------
+class ptmcmc_sampler {
+  std::map<std::string, std::string> opt;
+  bayes_likelihood* chain_llike;
+  const sampleable_probability_function* chain_prior;
+  proposal_distribution* cprop;
+  std::unique_ptr<parallel_tempering_chains> cc;
+
+ public:
+  ptmcmc_sampler() : chain_llike(nullptr), chain_prior(nullptr), cprop(nullptr) {
+    // flag names and defaults of ptmcmc.cc:375-427 that shape this path
+    opt["nsteps"] = "5000"; opt["save_every"] = "10"; opt["nevery"] = "1000"; opt["pt"] = "20"; opt["pt_swap_rate"] = "0.10";
+    opt["pt_Tmax"] = "1e9"; opt["chain_dprior_min"] = "-30"; opt["seed"] = "-1"; opt["outname"] = "mcmc_output";
+  }
+  void set(const std::string& name, const std::string& value) { opt[name] = value; }
+  bool parse(int argc, char* argv[]) {  // --name=value / --name (options.hh semantics)
+    for (int i = 1; i < argc; i++) {
+      std::string a = argv[i];
+      if (a.compare(0, 2, "--")) return false;
+      size_t eq = a.find('=');
+      opt[a.substr(2, eq == std::string::npos ? std::string::npos : eq - 2)] = eq == std::string::npos ? "true" : a.substr(eq + 1);
+    }
+    return true;
+  }
+  double num(const std::string& n) const { return atof(opt.at(n).c_str()); }
+  void setup(bayes_likelihood& llike) { chain_llike = &llike; chain_prior = llike.getObjectPrior().get(); }
+  void select_proposal(proposal_distribution& p) { cprop = &p; }
+  int initialize() {
+    if (!chain_llike || !cprop) { std::cout << "ptmcmc_sampler::initialize.  Must call setup() and set proposal before initialization!" << std::endl; exit(1); }
+    cc.reset(new parallel_tempering_chains((int)num("pt"), num("pt_Tmax"), num("pt_swap_rate"), (int)num("save_every"), false, false, num("chain_dprior_min")));
+    uint64_t seed = num("seed") >= 0 ? (uint64_t)(num("seed") * 4294967296.0) : 0x5EED0001ull;
+    cc->initialize(chain_llike, chain_prior, 1, seed);
+    cc->set_proposal(*cprop);
+    return 0;
+  }
+  int run(const std::string& base, int ic = 0) {
+    const int Nstep = (int)num("nsteps"), Nevery = (int)num("nevery");
+    std::ostringstream ss;
+    ss << base << "_t" << ic << ".dat";  // ptmcmc.cc:547-554
+    std::ofstream out(ss.str().c_str());
+    out.precision(13);
+    out << "#eval: log(posterior) log(likelihood) acceptance_ratio prop_type: ";
+    for (int i = 0; i < chain_prior->getDim(); i++) out << chain_llike->getObjectStateSpace()->get_name(i) << " ";
+    out << std::endl;
+    for (int istep = 0; istep < Nstep; istep += Nevery) {
+      cc->step(std::min(Nevery, Nstep - istep));
+      cc->dumpCurrent(0, out);
+    }
+    return 0;
+  }
+  parallel_tempering_chains* chains() { return cc.get(); }
+};
+
+}  // namespace ptmgpu
+#endif
