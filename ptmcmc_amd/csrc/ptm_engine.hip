@@ -556,24 +556,58 @@ extern "C" int ptm_set_states(ptm_engine* e, const double* X, const double* llik
   return PTM_OK;
 }
 
+static int launch_init(ptm_engine* e, const Dev& p, long long attempt, unsigned char* pending) {
+  switch (e->DP) {
+    case 4: HIPCHK(launch_init_4(p, e->x[0], e->ll[0], e->lp[0], e->err + 1, attempt, pending, e->stream)); break;
+    case 8: HIPCHK(launch_init_8(p, e->x[0], e->ll[0], e->lp[0], e->err + 1, attempt, pending, e->stream)); break;
+    case 16: HIPCHK(launch_init_16(p, e->x[0], e->ll[0], e->lp[0], e->err + 1, attempt, pending, e->stream)); break;
+    case 32: HIPCHK(launch_init_32(p, e->x[0], e->ll[0], e->lp[0], e->err + 1, attempt, pending, e->stream)); break;
+    default: return fail(PTM_ERR_UNSUPPORTED, "dim > 32 is not built in this round");
+  }
+  return PTM_OK;
+}
+
 extern "C" int ptm_init_from_prior(ptm_engine* e) {
   if (!e) return fail(PTM_ERR_INVALID, "null engine");
   if (!e->have_target) return fail(PTM_ERR_INVALID, "set the target first");
-  if (e->cb) return fail(PTM_ERR_UNSUPPORTED, "prior draws with a host-callback likelihood are done by the caller (ptm_set_states)");
   for (int d = 0; d < e->D; ++d)
     if (e->h_ptype[d] != PTM_PRIOR_UNIFORM && e->h_ptype[d] != PTM_PRIOR_GAUSSIAN)
       return fail(PTM_ERR_UNSUPPORTED, "device prior draws exist for uniform/gaussian dimensions only (dimension %d)", d);
   e->cur = 0;
   Dev p = make_dev(e);
   HIPCHK(hipMemsetAsync(e->err + 1, 0, 4, e->stream));
-  switch (e->DP) {
-    case 4: HIPCHK(launch_init_4(p, e->x[0], e->ll[0], e->lp[0], e->err + 1, e->stream)); break;
-    case 8: HIPCHK(launch_init_8(p, e->x[0], e->ll[0], e->lp[0], e->err + 1, e->stream)); break;
-    case 16: HIPCHK(launch_init_16(p, e->x[0], e->ll[0], e->lp[0], e->err + 1, e->stream)); break;
-    case 32: HIPCHK(launch_init_32(p, e->x[0], e->ll[0], e->lp[0], e->err + 1, e->stream)); break;
-    default: return fail(PTM_ERR_UNSUPPORTED, "dim > 32 is not built in this round");
+  int rc;
+  if (!e->cb) {
+    if ((rc = launch_init(e, p, -1, nullptr))) return rc;
+  } else {
+    // MH_chain::initialize's redraw loop (chain.cc:856-869) with the plug-in likelihood on the host: one attempt per
+    // launch for the chains still pending; `gate` doubles as the pending flag array
+    const size_t Nc = e->Nc, DP = e->DP;
+    HIPCHK(hipMemsetAsync(e->gate, 0, Nc, e->stream));
+    std::vector<double> llh(Nc, 0.0);
+    size_t left = Nc;
+    for (long long a = 0; left && a < 100000; ++a) {
+      if ((rc = launch_init(e, p, a, e->gate))) return rc;
+      HIPCHK(hipMemcpyAsync(e->h_gate.data(), e->gate, Nc, hipMemcpyDeviceToHost, e->stream));
+      HIPCHK(hipMemcpyAsync(e->h_xprop.data(), e->x[0], Nc * DP * 8, hipMemcpyDeviceToHost, e->stream));
+      HIPCHK(hipStreamSynchronize(e->stream));
+      std::vector<size_t> pick;
+      for (size_t c = 0; c < Nc; ++c)
+        if (e->h_gate[c] == 1) pick.push_back(c);
+      if ((rc = call_user(e, e->h_xprop, pick, e->h_llbatch))) return rc;
+      for (size_t k = 0; k < pick.size(); ++k) {
+        const double v = e->h_llbatch[k];
+        if (v < -1e100) { e->h_gate[pick[k]] = 0; continue; }   // chain.cc:858: (slike=evaluate_log(s)) < -1e100 => redraw
+        llh[pick[k]] = v;
+        e->h_gate[pick[k]] = 2;
+        left--;
+      }
+      HIPCHK(hipMemcpyAsync(e->gate, e->h_gate.data(), Nc, hipMemcpyHostToDevice, e->stream));
+    }
+    if (left) return fail(PTM_ERR_INVALID, "could not draw a valid start state from the prior for some chain");
+    if ((rc = upload(e->ll[0], llh.data(), Nc, e->stream))) return rc;
   }
-  int rc = reset_counters(e);
+  rc = reset_counters(e);
   if (rc) return rc;
   int flag = 0;
   HIPCHK(hipMemcpy(&flag, e->err + 1, 4, hipMemcpyDeviceToHost));

@@ -568,11 +568,15 @@ __global__ __launch_bounds__(256) void evaluate_kernel(const Dev p, int n, doubl
 
 // MH_chain::initialize(1) (chain.cc:846-876): redraw from the prior until valid and llike >= -1e100.
 // Dimension d of attempt a uses block d of the chain's INIT stream with step = a.
+// With a host-callback likelihood (cb_attempt >= 0) one launch makes ONE attempt for the chains not yet done and
+// reports validity in `pending` (1 = drawn a valid state that awaits its likelihood, 2 = done earlier); the host
+// evaluates the plug-in and relaunches for the rest.
 template <int DP>
 __global__ __launch_bounds__(256) void init_prior_kernel(const Dev p, double* x_out, double* ll_out, double* lp_out,
-                                                          int* fail) {
+                                                          int* fail, long long cb_attempt, unsigned char* pending) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= p.Nc) return;
+  if (cb_attempt >= 0 && pending[c] == 2) return;
   const int rl = c / p.W, w = c - rl * p.W;
   const uint32_t stream = (uint32_t)w * (uint32_t)p.Nt + (uint32_t)(p.r0 + rl);
   cip pt = as_c(p.ptype);
@@ -580,7 +584,8 @@ __global__ __launch_bounds__(256) void init_prior_kernel(const Dev p, double* x_
   double x[DP];
   double ll = 0, lp = 0;
   bool done = false;
-  for (uint64_t a = 0; a < 100000 && !done; ++a) {
+  const uint64_t a_begin = cb_attempt >= 0 ? (uint64_t)cb_attempt : 0, a_end = cb_attempt >= 0 ? a_begin + 1 : 100000;
+  for (uint64_t a = a_begin; a < a_end && !done; ++a) {
 #pragma unroll
     for (int d = 0; d < DP; ++d) {
       x[d] = 0.0;
@@ -594,11 +599,15 @@ __global__ __launch_bounds__(256) void init_prior_kernel(const Dev p, double* x_
     bool valid = true;
     lp = enforce_and_lprior<DP>(p, x, valid);
     if (!valid) continue;
+    if (cb_attempt >= 0) { done = true; break; }   // the host evaluates the likelihood of this draw
     ll = p.has_mean ? gauss_llike<DP, true>(p, x) : gauss_llike<DP, false>(p, x);
     if (ll < -1e100) continue;
     done = true;
   }
-  if (!done) atomicOr(fail, 1);
+  if (cb_attempt >= 0) {
+    pending[c] = done ? 1 : 0;
+    if (!done) return;
+  } else if (!done) atomicOr(fail, 1);
 #pragma unroll
   for (int d = 0; d < DP; ++d) x_out[(size_t)d * p.Nc + c] = x[d];
   ll_out[c] = ll;

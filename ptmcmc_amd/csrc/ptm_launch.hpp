@@ -16,7 +16,8 @@ struct SweepSel {
   hipError_t launch_sweep_##N(const Dev& p, SweepSel s, hipStream_t st);                                            \
   hipError_t launch_eval_##N(const Dev& p, int n, double* x, int* valid, double* lp, double* ll, int eval_like,     \
                              hipStream_t st);                                                                       \
-  hipError_t launch_init_##N(const Dev& p, double* x, double* ll, double* lp, int* fail, hipStream_t st);
+  hipError_t launch_init_##N(const Dev& p, double* x, double* ll, double* lp, int* fail, long long cb_attempt,          \
+                             unsigned char* pending, hipStream_t st);
 PTM_DECL_DP(4)
 PTM_DECL_DP(8)
 PTM_DECL_DP(16)
