@@ -134,7 +134,7 @@ int ptm_exchange_decide(ptm_engine* e, const void* ll_below_dev, const void* ll_
                         void* send_down_dev);
 /* exchange phase, part 2 + MH sweep: rows arriving from the neighbours (device buffers of the same size) */
 int ptm_exchange_finish_and_sweep(ptm_engine* e, const void* recv_from_below_dev, const void* recv_from_above_dev);
-/* size of one boundary buffer in doubles: W * (padded dim + 2) -- one state row + llike + lprior per walker, SoA */
+/* size of one boundary buffer in doubles: W * (padded dim + 2) -- per walker one row {state, llike, lprior} */
 int ptm_exchange_buffer_doubles(ptm_engine* e);
 
 /* ---- read-back ------------------------------------------------------------------------------------------ */

@@ -8,8 +8,8 @@ namespace ptm {
 // exchange phase of parallel_tempering_chains::step (chain.cc:1410-1537), one wave per walker-ladder.
 // Candidate draws are parallel over lanes; the in-order filter and trials (quirk Q6: later picks see the
 // in-place updated view) run on lane 0 over LDS copies of the picked rungs' llikes.
-// The kernel moves no state: it names, for every local row that took part, the slot it moves to (dst[]) and the
-// number of add_state calls its rung received (touch[]); the sweep kernel does the move.
+// After the decisions the kernel exchanges the rows themselves, in place (whole contiguous rows), packs the rows that
+// leave the shard and names the landing slot of arrivals; touch[] tells the sweep kernel which rungs skip their MH move.
 // ------------------------------------------------------------------------------------------------
 struct Decide {
   int DP, Nt, r0, nloc, W, Nc, ms;
@@ -19,15 +19,14 @@ struct Decide {
   const double* ll_below;     // [W]      llike of rung r0-1 (top rung of the shard below), null on the first shard
   const double* ll_above;     // [H][W]   llike of rungs r1 .. r1+H-1 (bottom rungs of the shard above), null on the last
   int H;                      // halo depth actually available above (0 on the last shard)
-  const double* x_in;         // local state planes (for packing departures)
-  const double* ll_in;
-  const double* lp_in;
-  int* dst;
+  double* x;                  // [Nc][DP] rows, moved in place
+  double* ll;
+  double* lp;
   unsigned char* touch;
   int *arr_below, *arr_above;      // [W]
   long long *swap_try, *swap_acc;  // [W][Nt-1]
   int *last_pairs, *last_acc;      // [W][ms]
-  double *send_up, *send_down;     // [(DP+2)][W] or null
+  double *send_up, *send_down;     // [W][DP+2] rows {x, llike, lprior} or null
   int* err;
 };
 
@@ -36,7 +35,7 @@ __device__ __forceinline__ double win_llike(const Decide& p, int r, int w) {
   const int r1 = p.r0 + p.nloc;
   if (r < p.r0) return p.ll_below[w];
   if (r >= r1) return p.ll_above[(size_t)(r - r1) * p.W + w];
-  return p.ll_in[(size_t)(r - p.r0) * p.W + w];
+  return p.ll[(size_t)(r - p.r0) * p.W + w];
 }
 
 __global__ __launch_bounds__(64) void decide_kernel(const Decide p) {
@@ -53,13 +52,13 @@ __global__ __launch_bounds__(64) void decide_kernel(const Decide p) {
   unsigned short* perm = reinterpret_cast<unsigned short*>(accf + ((ms + 1) & ~1));  // [Nt]
   unsigned char* tch = reinterpret_cast<unsigned char*>(perm + ((Nt + 3) & ~3));     // [Nt]
   unsigned char* mark = tch + ((Nt + 7) & ~7);                                       // [Nt+1]
-  int* down_src_p = reinterpret_cast<int*>(mark + ((Nt + 1 + 7) & ~7));              // [1]
+  unsigned short* owner = reinterpret_cast<unsigned short*>(mark + ((Nt + 1 + 7) & ~7));  // [Nt] pick that handles the rung
+  unsigned short* inv = owner + ((Nt + 3) & ~3);                                         // [Nt] inverse of perm
   // (no static __shared__: it would precede the dynamic region and break its 16-byte base alignment)
 
   // window of rungs whose llike this shard knows: its own, one below, H above
   const int wlo = p.r0 - (p.ll_below ? 1 : 0), whi = p.r0 + p.nloc - 1 + p.H;
   for (int i = lane; i < Nt + 1; i += 64) mark[i] = 0;
-  if (lane == 0) *down_src_p = -1;
   // -- candidate draws (chain.cc:1410-1416): block k of the ladder stream gives {u_try, u_pick, u_accept}
   for (int k = lane; k < ms; k += 64) {
     const u32x4 o = draw_block(p.seed, TAG_PT, (uint32_t)w, p.step, (uint32_t)k);
@@ -91,6 +90,8 @@ __global__ __launch_bounds__(64) void decide_kernel(const Decide p) {
     db[k] = p.beta[n + 1] - p.beta[n];
     perm[n] = (unsigned short)n;
     perm[n + 1] = (unsigned short)(n + 1);
+    inv[n] = (unsigned short)n;
+    inv[n + 1] = (unsigned short)(n + 1);
     tch[n] = 0;
     tch[n + 1] = 0;
   }
@@ -123,7 +124,8 @@ __global__ __launch_bounds__(64) void decide_kernel(const Decide p) {
       bool acc = true;
       if (logH < 0) acc = lu[k] < logH;
       if (acc) {
-        if (i + 1 == p.r0) *down_src_p = perm[i + 1];  // the row that leaves this shard downwards
+        // the row that leaves this shard downwards must be one of ours (else it crossed two boundaries in one step)
+        if (i + 1 == p.r0 && (perm[i + 1] < p.r0 || perm[i + 1] >= p.r0 + p.nloc)) atomicOr(p.err, 1);
         const double t = llc[i]; llc[i] = llc[i + 1]; llc[i + 1] = t;
         const unsigned short s = perm[i]; perm[i] = perm[i + 1]; perm[i + 1] = s;
         accf[k] = 1;
@@ -133,7 +135,7 @@ __global__ __launch_bounds__(64) void decide_kernel(const Decide p) {
     }
   }
   __syncthreads();
-  // -- publish: hand-off arrays for local rungs, the step's log, departures
+  // -- publish the step's log, counters and the touch counts of the local rungs; name one OWNER pick per touched rung
   const int r1 = p.r0 + p.nloc;
   const int DP = p.DP;
   for (int k = lane; k < ms; k += 64) {
@@ -142,37 +144,72 @@ __global__ __launch_bounds__(64) void decide_kernel(const Decide p) {
     p.last_acc[(size_t)w * ms + k] = accf[k];
     if (i < 0) continue;
     // swap_count / swap_accept_count (chain.cc:1498,1536): a pair is tried at most once per step, so no two lanes
-    // of this wave (the only writer of walker w's counters) touch the same entry
-    // (a pair is counted by the shard that owns its lower rung, so per-shard counters add up to the ladder's)
+    // of this wave (the only writer of walker w's counters) touch the same entry; a pair is counted by the shard that
+    // owns its lower rung, so per-shard counters add up to the ladder's
     if (i >= p.r0 && i < r1) {
       p.swap_try[(size_t)w * (Nt - 1) + i] += 1;
       if (accf[k]) p.swap_acc[(size_t)w * (Nt - 1) + i] += 1;
     }
     for (int r = i; r <= i + 1; ++r) {
-      // rung r ends the phase holding the row that started the step at rung s = perm[r]: publish the move from the
-      // row's point of view (dst of the source slot) -- or, for a row coming from another shard, its landing slot
+      if (r >= p.r0 && r < r1) p.touch[(r - p.r0) * p.W + w] = tch[r];
+      owner[r] = (unsigned short)k;                       // any single winner will do
       const int s = perm[r];
-      const bool r_local = r >= p.r0 && r < r1, s_local = s >= p.r0 && s < r1;
-      if (r_local) p.touch[(r - p.r0) * p.W + w] = tch[r];
-      if (s_local) p.dst[(s - p.r0) * p.W + w] = r_local ? (r - p.r0) * p.W + w : DST_GONE;
-      else if (r_local) (s >= r1 ? p.arr_above : p.arr_below)[w] = (r - p.r0) * p.W + w;
+      if (s != r) inv[s] = (unsigned short)r;             // the row that started at s ends at r
     }
-    if (accf[k] && i + 1 == r1 && r1 < Nt && p.send_up) {
-      // exchange across the upper shard boundary: our top rung's row (always its start-of-step content) goes up
-      const int cs = (i - p.r0) * p.W + w;
-      for (int d = 0; d < DP; ++d) p.send_up[(size_t)d * p.W + w] = p.x_in[(size_t)d * p.Nc + cs];
-      p.send_up[(size_t)DP * p.W + w] = p.ll_in[cs];
-      p.send_up[(size_t)(DP + 1) * p.W + w] = p.lp_in[cs];
-    }
-    if (accf[k] && i + 1 == p.r0 && p.send_down) {
-      const int s = *down_src_p;
-      if (s < p.r0 || s >= r1) {
-        atomicOr(p.err, 1);  // the departing row is not ours: it crossed two boundaries in one step
-      } else {
-        const int cs = (s - p.r0) * p.W + w;
-        for (int d = 0; d < DP; ++d) p.send_down[(size_t)d * p.W + w] = p.x_in[(size_t)d * p.Nc + cs];
-        p.send_down[(size_t)DP * p.W + w] = p.ll_in[cs];
-        p.send_down[(size_t)(DP + 1) * p.W + w] = p.lp_in[cs];
+  }
+  __syncthreads();
+  // -- move the rows IN PLACE.  The phase's net effect on the touched rungs is a permutation that decomposes into
+  //    disjoint closed cycles inside the shard and at most two open paths through its boundaries (one row leaves, the
+  //    others shift by one rung, an arrival fills the hole later).  One lane per cycle / path: nobody else touches
+  //    those rows, so plain loads and stores in path order are safe.
+  for (int k = lane; k < ms; k += 64) {
+    const int i = cand[k];
+    if (i < 0) continue;
+    for (int r = i; r <= i + 1; ++r) {
+      if (owner[r] != k || r < p.r0 || r >= r1 || perm[r] == r) continue;
+      const int to = inv[r];                              // where rung r's old row goes
+      const bool departs = to < p.r0 || to >= r1;
+      bool head = departs;
+      if (!departs) {                                     // closed cycle? then the lowest member leads
+        head = true;
+        int cc = perm[r], guard = 0;
+        while (cc != r) {
+          if (cc < p.r0 || cc >= r1 || cc < r || ++guard > Nt) { head = false; break; }  // open path or not the minimum
+          cc = perm[cc];
+        }
+      }
+      if (!head) continue;
+      const size_t rowlen = DP;
+      double* X = p.x;
+      const int c0 = (r - p.r0) * p.W + w;
+      double tmp[34];                                      // the head's old row {x[0..DP), llike, lprior}, DP <= 32
+      for (int d = 0; d < DP; ++d) tmp[d] = X[(size_t)c0 * rowlen + d];
+      tmp[DP] = p.ll[c0];
+      tmp[DP + 1] = p.lp[c0];
+      if (departs) {
+        double* sb = (to >= r1) ? p.send_up : p.send_down;
+        if (!sb) { atomicOr(p.err, 1); continue; }
+        for (int d = 0; d < DP + 2; ++d) sb[(size_t)w * (DP + 2) + d] = tmp[d];
+      }
+      int cur = r;
+      for (int guard = 0; guard <= Nt; ++guard) {
+        const int src = perm[cur];
+        const int cc = (cur - p.r0) * p.W + w;
+        if (src == r) {                                    // closed the cycle: the saved row lands here
+          for (int d = 0; d < DP; ++d) X[(size_t)cc * rowlen + d] = tmp[d];
+          p.ll[cc] = tmp[DP];
+          p.lp[cc] = tmp[DP + 1];
+          break;
+        }
+        if (src < p.r0 || src >= r1) {                     // the hole: an arrival from the adjacent shard lands here
+          (src >= r1 ? p.arr_above : p.arr_below)[w] = cc;
+          break;
+        }
+        const int cs = (src - p.r0) * p.W + w;
+        for (int d = 0; d < DP; ++d) X[(size_t)cc * rowlen + d] = X[(size_t)cs * rowlen + d];
+        p.ll[cc] = p.ll[cs];
+        p.lp[cc] = p.lp[cs];
+        cur = src;
       }
     }
   }

@@ -41,10 +41,9 @@ struct ptm_engine {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   uint64_t step = 0;
-  int cur = 0;
   // device state
-  double *x[2] = {nullptr, nullptr}, *ll[2] = {nullptr, nullptr}, *lp[2] = {nullptr, nullptr};
-  int *ntries = nullptr, *naccept = nullptr, *last_type = nullptr, *dst = nullptr, *err = nullptr;
+  double *x = nullptr, *ll = nullptr, *lp = nullptr;   // rows [Nc][DP] and per-chain scalars, updated in place
+  int *ntries = nullptr, *naccept = nullptr, *last_type = nullptr, *err = nullptr;
   int *arr_below = nullptr, *arr_above = nullptr;
   unsigned int* nhist = nullptr;
   long long *swap_try = nullptr, *swap_acc = nullptr;
@@ -137,14 +136,10 @@ extern "C" int ptm_engine_create(const ptm_config* cfg, ptm_engine** out) {
   if (cfg->stream) e->stream = (hipStream_t)cfg->stream;
   else { HIPCHK(hipStreamCreate(&e->stream)); e->own_stream = true; }
   const size_t Nc = e->Nc, D = e->DP;  // every per-dimension table is padded to DP
-  for (int b = 0; b < 2; ++b) {
-    if ((rc = dalloc(&e->x[b], Nc * D))) return rc;
-    HIPCHK(hipMemsetAsync(e->x[b], 0, Nc * D * 8, e->stream));
-    if ((rc = dalloc(&e->ll[b], Nc))) return rc;
-    if ((rc = dalloc(&e->lp[b], Nc))) return rc;
-  }
+  if ((rc = dalloc(&e->x, Nc * D)) || (rc = dalloc(&e->ll, Nc)) || (rc = dalloc(&e->lp, Nc))) return rc;
+  HIPCHK(hipMemsetAsync(e->x, 0, Nc * D * 8, e->stream));
   if ((rc = dalloc(&e->ntries, Nc)) || (rc = dalloc(&e->naccept, Nc)) || (rc = dalloc(&e->last_type, Nc)) ||
-      (rc = dalloc(&e->dst, Nc)) || (rc = dalloc(&e->arr_below, (size_t)cfg->n_walkers)) ||
+      (rc = dalloc(&e->arr_below, (size_t)cfg->n_walkers)) ||
       (rc = dalloc(&e->arr_above, (size_t)cfg->n_walkers)) || (rc = dalloc(&e->touch, Nc)) || (rc = dalloc(&e->nhist, Nc)) ||
       (rc = dalloc(&e->err, 4)))
     return rc;
@@ -183,7 +178,7 @@ extern "C" int ptm_engine_create(const ptm_config* cfg, ptm_engine** out) {
 extern "C" int ptm_engine_destroy(ptm_engine* e) {
   if (!e) return PTM_OK;
   (void)hipStreamSynchronize(e->stream);
-  void* ptrs[] = {e->x[0], e->x[1], e->ll[0], e->ll[1], e->lp[0], e->lp[1], e->ntries, e->naccept, e->last_type, e->dst, e->arr_below, e->arr_above,
+  void* ptrs[] = {e->x, e->ll, e->lp, e->ntries, e->naccept, e->last_type, e->arr_below, e->arr_above,
                   e->err, e->nhist, e->swap_try, e->swap_acc, e->touch, e->last_pairs, e->last_acc, e->blo,
                   e->bhi, e->ptype, e->bmin, e->bmax, e->plo, e->phi, e->pcoef, e->P2, e->mean, e->beta, e->prop, e->prop_dense, e->onedfrac, e->xprop, e->lprior_new, e->llike_new, e->gate};
   for (void* p : ptrs)
@@ -306,14 +301,14 @@ extern "C" int ptm_set_target_callback(ptm_engine* e, ptm_loglike_batch_fn fn, v
   return PTM_OK;
 }
 
-// the user's batched log-likelihood on `n` chains picked by `pick` (indices into the SoA image `soa` with row length Nc)
-static int call_user(ptm_engine* e, const std::vector<double>& soa, const std::vector<size_t>& pick, std::vector<double>& out) {
-  const size_t Nc = e->Nc, D = e->D, n = pick.size();
+// the user's batched log-likelihood on the chains picked by `pick` (row indices into the padded row image `rows`)
+static int call_user(ptm_engine* e, const std::vector<double>& rows, const std::vector<size_t>& pick, std::vector<double>& out) {
+  const size_t D = e->D, DP = e->DP, n = pick.size();
   out.assign(n, 0.0);
   if (!n) return PTM_OK;
   e->h_batch.resize(n * D);
   for (size_t k = 0; k < n; ++k)
-    for (size_t d = 0; d < D; ++d) e->h_batch[k * D + d] = soa[d * Nc + pick[k]];
+    for (size_t d = 0; d < D; ++d) e->h_batch[k * D + d] = rows[pick[k] * DP + d];
   e->cb(e->cb_user, e->h_batch.data(), (int)n, (int)D, out.data());
   return PTM_OK;
 }
@@ -402,10 +397,9 @@ static Dev make_dev(ptm_engine* e) {
   p.ptype = e->ptype; p.plo = e->plo; p.phi = e->phi; p.pcoef = e->pcoef;
   p.P2 = e->P2; p.mean = e->mean; p.has_mean = e->has_mean; p.like0 = e->like0;
   p.beta = e->beta; p.prop = e->prop; p.prop_dense = e->prop_dense; p.onedfrac = e->onedfrac; p.prop_stride = e->prop_stride; p.any_oned = e->any_oned;
-  const int in = e->cur, out = 1 - e->cur;
-  p.x_in = e->x[in]; p.x_out = e->x[out]; p.ll_in = e->ll[in]; p.ll_out = e->ll[out]; p.lp_in = e->lp[in]; p.lp_out = e->lp[out];
+  p.x = e->x; p.ll = e->ll; p.lp = e->lp;
   p.ntries = e->ntries; p.naccept = e->naccept; p.last_type = e->last_type; p.nhist = e->nhist;
-  p.dst = e->dst; p.touch = e->touch; p.arr_below = e->arr_below; p.arr_above = e->arr_above; p.err = e->err;
+  p.touch = e->touch; p.arr_below = e->arr_below; p.arr_above = e->arr_above; p.err = e->err;
   return p;
 }
 
@@ -463,14 +457,13 @@ static int launch_sweep(ptm_engine* e, const double* recv_below, const double* r
     HIPCHK(launch(p));
   }
   if (ev1) HIPCHK(hipEventRecord(ev1, e->stream));
-  e->cur = 1 - e->cur;
   e->step += 1;
   return PTM_OK;
 }
 
 static size_t decide_lds_bytes(int Nt, int ms) {
   const size_t msp = (size_t)((ms + 1) & ~1);
-  return (size_t)Nt * 8 + (size_t)ms * 16 + msp * 4 * 2 + (size_t)((Nt + 3) & ~3) * 2 + (size_t)((Nt + 7) & ~7) + (size_t)((Nt + 1 + 7) & ~7) + 16;
+  return (size_t)Nt * 8 + (size_t)ms * 16 + msp * 4 * 2 + (size_t)((Nt + 3) & ~3) * 2 * 3 + (size_t)((Nt + 7) & ~7) + (size_t)((Nt + 1 + 7) & ~7) + 16;
 }
 
 static int launch_decide(ptm_engine* e, const double* ll_below, const double* ll_above, int H, double* send_up, double* send_down) {
@@ -478,8 +471,8 @@ static int launch_decide(ptm_engine* e, const double* ll_below, const double* ll
   memset(&p, 0, sizeof p);
   p.DP = e->DP; p.Nt = e->Nt; p.r0 = e->r0; p.nloc = e->nloc; p.W = e->W; p.Nc = e->Nc; p.ms = e->ms;
   p.seed = e->cfg.seed; p.step = e->step; p.thresh = e->thresh;
-  p.beta = e->beta; p.ll_below = ll_below; p.ll_above = ll_above; p.H = ll_above ? H : 0; p.x_in = e->x[e->cur]; p.ll_in = e->ll[e->cur]; p.lp_in = e->lp[e->cur];
-  p.dst = e->dst; p.touch = e->touch; p.arr_below = e->arr_below; p.arr_above = e->arr_above; p.swap_try = e->swap_try; p.swap_acc = e->swap_acc;
+  p.beta = e->beta; p.ll_below = ll_below; p.ll_above = ll_above; p.H = ll_above ? H : 0; p.x = e->x; p.ll = e->ll; p.lp = e->lp;
+  p.touch = e->touch; p.arr_below = e->arr_below; p.arr_above = e->arr_above; p.swap_try = e->swap_try; p.swap_acc = e->swap_acc;
   p.last_pairs = e->last_pairs; p.last_acc = e->last_acc; p.send_up = send_up; p.send_down = send_down; p.err = e->err;
   const size_t lds = decide_lds_bytes(e->Nt, e->ms);
   if (lds > 160 * 1024) return fail(PTM_ERR_UNSUPPORTED, "ladder too long for the LDS-resident exchange kernel (%zu B)", lds);
@@ -502,12 +495,11 @@ static int ready(ptm_engine* e) {
 // ---- state ------------------------------------------------------------------------------------------------------
 static int reset_counters(ptm_engine* e) {
   const size_t Nc = e->Nc;
-  std::vector<int> one(Nc, 1), m1(Nc, -1), ident(Nc);
+  std::vector<int> one(Nc, 1), m1(Nc, -1);
   std::vector<unsigned int> z(Nc, 0u);
-  for (size_t c = 0; c < Nc; ++c) ident[c] = (int)c;
   int rc;
   if ((rc = upload(e->ntries, one.data(), Nc, e->stream)) || (rc = upload(e->naccept, one.data(), Nc, e->stream)) ||  // chain.cc:649
-      (rc = upload(e->last_type, m1.data(), Nc, e->stream)) || (rc = upload(e->dst, ident.data(), Nc, e->stream)) ||
+      (rc = upload(e->last_type, m1.data(), Nc, e->stream)) ||
       (rc = upload(e->nhist, z.data(), Nc, e->stream)))                                                        // chain.cc:871-875
     return rc;
   HIPCHK(hipMemsetAsync(e->touch, 0, Nc, e->stream));
@@ -529,26 +521,35 @@ static int run_eval(ptm_engine* e, int n, double* x, int* valid, double* lp, dou
   return PTM_OK;
 }
 
+// host rows [n][D] -> padded rows [n][DP]
+static std::vector<double> pad_rows(const double* X, size_t n, size_t D, size_t DP) {
+  std::vector<double> r(n * DP, 0.0);
+  for (size_t c = 0; c < n; ++c)
+    for (size_t d = 0; d < D; ++d) r[c * DP + d] = X[c * D + d];
+  return r;
+}
+static void unpad_rows(const std::vector<double>& r, size_t n, size_t D, size_t DP, double* X) {
+  for (size_t c = 0; c < n; ++c)
+    for (size_t d = 0; d < D; ++d) X[c * D + d] = r[c * DP + d];
+}
+
 extern "C" int ptm_set_states(ptm_engine* e, const double* X, const double* llike) {
   if (!e || !X) return fail(PTM_ERR_INVALID, "null argument");
   if (!e->have_target && !llike) return fail(PTM_ERR_INVALID, "set the target first (or pass llike)");
   const size_t Nc = e->Nc, D = e->D, DP = e->DP;
-  std::vector<double> soa(Nc * DP, 0.0);
-  for (size_t c = 0; c < Nc; ++c)
-    for (size_t d = 0; d < D; ++d) soa[d * Nc + c] = X[c * D + d];
+  const std::vector<double> rows = pad_rows(X, Nc, D, DP);
   int rc;
-  e->cur = 0;
-  if ((rc = upload(e->x[0], soa.data(), Nc * DP, e->stream))) return rc;
-  if (llike && (rc = upload(e->ll[0], llike, Nc, e->stream))) return rc;
-  if ((rc = run_eval(e, (int)Nc, e->x[0], nullptr, e->lp[0], e->ll[0], (llike || e->cb) ? 0 : 1))) return rc;
+  if ((rc = upload(e->x, rows.data(), Nc * DP, e->stream))) return rc;
+  if (llike && (rc = upload(e->ll, llike, Nc, e->stream))) return rc;
+  if ((rc = run_eval(e, (int)Nc, e->x, nullptr, e->lp, e->ll, (llike || e->cb) ? 0 : 1))) return rc;
   if (e->cb && !llike) {
     // MH_chain::add_state(s) with the 999 sentinel: the likelihood plug-in evaluates the (enforced) start states (chain.cc:925)
     HIPCHK(hipStreamSynchronize(e->stream));
-    HIPCHK(hipMemcpy(e->h_xprop.data(), e->x[0], Nc * DP * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(e->h_xprop.data(), e->x, Nc * DP * 8, hipMemcpyDeviceToHost));
     std::vector<size_t> all(Nc);
     for (size_t c = 0; c < Nc; ++c) all[c] = c;
     if ((rc = call_user(e, e->h_xprop, all, e->h_llbatch))) return rc;
-    if ((rc = upload(e->ll[0], e->h_llbatch.data(), Nc, e->stream))) return rc;
+    if ((rc = upload(e->ll, e->h_llbatch.data(), Nc, e->stream))) return rc;
   }
   if ((rc = reset_counters(e))) return rc;
   HIPCHK(hipStreamSynchronize(e->stream));
@@ -558,10 +559,10 @@ extern "C" int ptm_set_states(ptm_engine* e, const double* X, const double* llik
 
 static int launch_init(ptm_engine* e, const Dev& p, long long attempt, unsigned char* pending) {
   switch (e->DP) {
-    case 4: HIPCHK(launch_init_4(p, e->x[0], e->ll[0], e->lp[0], e->err + 1, attempt, pending, e->stream)); break;
-    case 8: HIPCHK(launch_init_8(p, e->x[0], e->ll[0], e->lp[0], e->err + 1, attempt, pending, e->stream)); break;
-    case 16: HIPCHK(launch_init_16(p, e->x[0], e->ll[0], e->lp[0], e->err + 1, attempt, pending, e->stream)); break;
-    case 32: HIPCHK(launch_init_32(p, e->x[0], e->ll[0], e->lp[0], e->err + 1, attempt, pending, e->stream)); break;
+    case 4: HIPCHK(launch_init_4(p, e->x, e->ll, e->lp, e->err + 1, attempt, pending, e->stream)); break;
+    case 8: HIPCHK(launch_init_8(p, e->x, e->ll, e->lp, e->err + 1, attempt, pending, e->stream)); break;
+    case 16: HIPCHK(launch_init_16(p, e->x, e->ll, e->lp, e->err + 1, attempt, pending, e->stream)); break;
+    case 32: HIPCHK(launch_init_32(p, e->x, e->ll, e->lp, e->err + 1, attempt, pending, e->stream)); break;
     default: return fail(PTM_ERR_UNSUPPORTED, "dim > 32 is not built in this round");
   }
   return PTM_OK;
@@ -573,7 +574,6 @@ extern "C" int ptm_init_from_prior(ptm_engine* e) {
   for (int d = 0; d < e->D; ++d)
     if (e->h_ptype[d] != PTM_PRIOR_UNIFORM && e->h_ptype[d] != PTM_PRIOR_GAUSSIAN)
       return fail(PTM_ERR_UNSUPPORTED, "device prior draws exist for uniform/gaussian dimensions only (dimension %d)", d);
-  e->cur = 0;
   Dev p = make_dev(e);
   HIPCHK(hipMemsetAsync(e->err + 1, 0, 4, e->stream));
   int rc;
@@ -589,7 +589,7 @@ extern "C" int ptm_init_from_prior(ptm_engine* e) {
     for (long long a = 0; left && a < 100000; ++a) {
       if ((rc = launch_init(e, p, a, e->gate))) return rc;
       HIPCHK(hipMemcpyAsync(e->h_gate.data(), e->gate, Nc, hipMemcpyDeviceToHost, e->stream));
-      HIPCHK(hipMemcpyAsync(e->h_xprop.data(), e->x[0], Nc * DP * 8, hipMemcpyDeviceToHost, e->stream));
+      HIPCHK(hipMemcpyAsync(e->h_xprop.data(), e->x, Nc * DP * 8, hipMemcpyDeviceToHost, e->stream));
       HIPCHK(hipStreamSynchronize(e->stream));
       std::vector<size_t> pick;
       for (size_t c = 0; c < Nc; ++c)
@@ -605,7 +605,7 @@ extern "C" int ptm_init_from_prior(ptm_engine* e) {
       HIPCHK(hipMemcpyAsync(e->gate, e->h_gate.data(), Nc, hipMemcpyHostToDevice, e->stream));
     }
     if (left) return fail(PTM_ERR_INVALID, "could not draw a valid start state from the prior for some chain");
-    if ((rc = upload(e->ll[0], llh.data(), Nc, e->stream))) return rc;
+    if ((rc = upload(e->ll, llh.data(), Nc, e->stream))) return rc;
   }
   rc = reset_counters(e);
   if (rc) return rc;
@@ -648,7 +648,7 @@ extern "C" int ptm_sync(ptm_engine* e) {
 
 extern "C" int ptm_llike_device_ptr(ptm_engine* e, void** p) {
   if (!e || !p) return fail(PTM_ERR_INVALID, "null argument");
-  *p = e->ll[e->cur];
+  *p = e->ll;
   return PTM_OK;
 }
 
@@ -669,7 +669,7 @@ extern "C" int ptm_exchange_decide(ptm_engine* e, const void* ll_below, const vo
 extern "C" int ptm_copy_llike(ptm_engine* e, int first_local_rung, int n_rungs, void* dst_dev) {
   if (!e || !dst_dev) return fail(PTM_ERR_INVALID, "null argument");
   if (first_local_rung < 0 || n_rungs < 1 || first_local_rung + n_rungs > e->nloc) return fail(PTM_ERR_INVALID, "rung range out of the shard");
-  HIPCHK(hipMemcpyAsync(dst_dev, e->ll[e->cur] + (size_t)first_local_rung * e->W, (size_t)n_rungs * e->W * 8, hipMemcpyDeviceToDevice, e->stream));
+  HIPCHK(hipMemcpyAsync(dst_dev, e->ll + (size_t)first_local_rung * e->W, (size_t)n_rungs * e->W * 8, hipMemcpyDeviceToDevice, e->stream));
   return PTM_OK;
 }
 
@@ -701,12 +701,11 @@ extern "C" int ptm_exchange_finish_and_sweep(ptm_engine* e, const void* recv_bel
 // ---- read-back ------------------------------------------------------------------------------------------------------
 extern "C" int ptm_get_states(ptm_engine* e, double* X) {
   if (!e || !X) return fail(PTM_ERR_INVALID, "null argument");
-  const size_t Nc = e->Nc, D = e->D;
-  std::vector<double> soa(Nc * D);
+  const size_t Nc = e->Nc, D = e->D, DP = e->DP;
+  std::vector<double> rows(Nc * DP);
   HIPCHK(hipStreamSynchronize(e->stream));
-  HIPCHK(hipMemcpy(soa.data(), e->x[e->cur], Nc * D * 8, hipMemcpyDeviceToHost));  // the first D of the DP planes
-  for (size_t c = 0; c < Nc; ++c)
-    for (size_t d = 0; d < D; ++d) X[c * D + d] = soa[d * Nc + c];
+  HIPCHK(hipMemcpy(rows.data(), e->x, Nc * DP * 8, hipMemcpyDeviceToHost));
+  unpad_rows(rows, Nc, D, DP, X);
   return PTM_OK;
 }
 
@@ -715,13 +714,13 @@ extern "C" int ptm_get_array(ptm_engine* e, int which, void* out) {
   const size_t Nc = e->Nc;
   HIPCHK(hipStreamSynchronize(e->stream));
   switch (which) {
-    case PTM_ARR_LLIKE: HIPCHK(hipMemcpy(out, e->ll[e->cur], Nc * 8, hipMemcpyDeviceToHost)); break;
-    case PTM_ARR_LPRIOR: HIPCHK(hipMemcpy(out, e->lp[e->cur], Nc * 8, hipMemcpyDeviceToHost)); break;
+    case PTM_ARR_LLIKE: HIPCHK(hipMemcpy(out, e->ll, Nc * 8, hipMemcpyDeviceToHost)); break;
+    case PTM_ARR_LPRIOR: HIPCHK(hipMemcpy(out, e->lp, Nc * 8, hipMemcpyDeviceToHost)); break;
     case PTM_ARR_LPOST: {
       if (!e->have_ladder) return fail(PTM_ERR_INVALID, "no ladder set");
       std::vector<double> ll(Nc), lp(Nc);
-      HIPCHK(hipMemcpy(ll.data(), e->ll[e->cur], Nc * 8, hipMemcpyDeviceToHost));
-      HIPCHK(hipMemcpy(lp.data(), e->lp[e->cur], Nc * 8, hipMemcpyDeviceToHost));
+      HIPCHK(hipMemcpy(ll.data(), e->ll, Nc * 8, hipMemcpyDeviceToHost));
+      HIPCHK(hipMemcpy(lp.data(), e->lp, Nc * 8, hipMemcpyDeviceToHost));
       double* o = (double*)out;
       for (size_t c = 0; c < Nc; ++c) {
         volatile double t = e->h_beta[e->r0 + c / e->W] * ll[c];  // product rounded before the sum (chain.cc:928)
@@ -876,26 +875,22 @@ extern "C" int ptm_debug_sqrt_scan(int device, uint64_t* mismatches) {
 extern "C" int ptm_debug_evaluate(ptm_engine* e, const double* X, int n, int32_t* valid, double* Xe, double* lprior, double* llike) {
   if (!e || !X || n < 1) return fail(PTM_ERR_INVALID, "bad argument");
   const size_t D = e->D, DP = e->DP;
-  std::vector<double> soa((size_t)n * DP, 0.0);
-  for (size_t c = 0; c < (size_t)n; ++c)
-    for (size_t d = 0; d < D; ++d) soa[d * n + c] = X[c * D + d];
+  std::vector<double> rows = pad_rows(X, (size_t)n, D, DP);
   double *dx = nullptr, *dlp = nullptr, *dll = nullptr;
   int* dv = nullptr;
   HIPCHK(hipMalloc((void**)&dx, (size_t)n * DP * 8));
   HIPCHK(hipMalloc((void**)&dlp, (size_t)n * 8));
   HIPCHK(hipMalloc((void**)&dll, (size_t)n * 8));
   HIPCHK(hipMalloc((void**)&dv, (size_t)n * 4));
-  HIPCHK(hipMemcpy(dx, soa.data(), (size_t)n * DP * 8, hipMemcpyHostToDevice));
-  int rc = run_eval(e, n, dx, dv, dlp, dll, e->have_target ? 1 : 0);
+  HIPCHK(hipMemcpy(dx, rows.data(), (size_t)n * DP * 8, hipMemcpyHostToDevice));
+  int rc = run_eval(e, n, dx, dv, dlp, dll, (e->have_target && !e->cb) ? 1 : 0);
   if (rc) return rc;
   HIPCHK(hipStreamSynchronize(e->stream));
-  HIPCHK(hipMemcpy(soa.data(), dx, (size_t)n * DP * 8, hipMemcpyDeviceToHost));
-  if (Xe)
-    for (size_t c = 0; c < (size_t)n; ++c)
-      for (size_t d = 0; d < D; ++d) Xe[c * D + d] = soa[d * n + c];
+  HIPCHK(hipMemcpy(rows.data(), dx, (size_t)n * DP * 8, hipMemcpyDeviceToHost));
+  if (Xe) unpad_rows(rows, (size_t)n, D, DP, Xe);
   if (valid) HIPCHK(hipMemcpy(valid, dv, (size_t)n * 4, hipMemcpyDeviceToHost));
   if (lprior) HIPCHK(hipMemcpy(lprior, dlp, (size_t)n * 8, hipMemcpyDeviceToHost));
-  if (llike && e->have_target) HIPCHK(hipMemcpy(llike, dll, (size_t)n * 8, hipMemcpyDeviceToHost));
+  if (llike && e->have_target && !e->cb) HIPCHK(hipMemcpy(llike, dll, (size_t)n * 8, hipMemcpyDeviceToHost));
   (void)hipFree(dx); (void)hipFree(dlp); (void)hipFree(dll); (void)hipFree(dv);
   return PTM_OK;
 }

@@ -1,22 +1,20 @@
 // ptm_kernels.hpp -- gfx950 kernels of the parallel-tempering step engine.
 //
 // Data layout in HBM (per engine = per GPU shard), Nc = rung_count * W chains, chain c = rung_local * W + walker:
-//   x      [2][DP][Nc] double  SoA state planes, ping-pong (a step reads buffer `cur`, writes the other);
-//                              DP = dimension padded to 4/8/16/32 (pad planes stay 0, pad factor rows are 0)
-//   llike  [2][Nc], lprior [2][Nc]  double         (lpost is always fl(lprior + fl(beta*llike)), chain.cc:928)
+//   x      [Nc][DP]  double   one contiguous ROW per chain (DP = dimension padded to 4/8/16/32; pad entries stay 0,
+//                             pad factor rows / precision rows are 0), updated IN PLACE
+//   llike, lprior [Nc] double (lpost is always fl(lprior + fl(beta*llike)), chain.cc:928)
 //   ntries, naccept, last_type [Nc] int32; nhist [Nc] uint32          (MH_chain counters, chain.hh:150-170;
-//                              Nsize is a function of Nhist: 1 + ceil(nhist / add_every_N), chain.cc:935-947)
-//   dst [Nc] int32, touch [Nc] uint8   exchange phase -> sweep hand-off: where the chain's CURRENT row goes this
-//                                      step (its own slot unless an exchange moved it; -1 = it left the shard) and
-//                                      how many add_state calls the rung received; arr_above/arr_below [W] name the
-//                                      slot where a row arriving from the adjacent shard lands.
-//                                      Rows are PUSHED: every lane reads its own row (coalesced) and the few moved
-//                                      ones store to another rung's slot -- scattered 8-byte writes that L2 merges,
-//                                      instead of scattered reads on the critical path.
-// Walker is the fastest index, so the 64 lanes of a wave hold 64 walkers of ONE rung whenever W % 64 == 0:
-// beta, the proposal factor and the precision matrix are then wave-uniform and are fetched through the scalar
-// cache straight into SGPR operands of v_fma_f64 (constant-address-space loads), while every state plane is read
-// and written with fully coalesced 512-B wave accesses.
+//                             Nsize is a function of Nhist: 1 + ceil(nhist / add_every_N), chain.cc:935-947)
+//   touch [Nc] uint8          exchange phase -> sweep hand-off: add_state calls the rung received (=> no MH move);
+//   arr_above / arr_below [W] slot where a row arriving from the adjacent shard lands.
+// Why rows: a Metropolis step rejects ~3/4 of its proposals and the exchange phase moves ~1/5 of the rows.  With rows
+// contiguous (256 B at D=32 = 4 full cache lines) a lane reads its row with 16-byte loads (lanes 256 B apart: measured
+// 5.1 TB/s vs 5.8 TB/s for the plane-wise layout), writes it back ONLY when the move is accepted, and the exchange
+// kernel swaps whole rows in place -- no copy-through of unchanged rows, no second buffer.  The plane-wise (SoA)
+// ping-pong layout of the first version moved 3.7 GB per sweep against 2.3 GB algorithmic (profiles/r01_*).
+// Walker is the fastest index, so the 64 lanes of a wave hold 64 walkers of ONE rung whenever W % 64 == 0: beta, the
+// proposal factor and the precision matrix are then wave-uniform (LDS-staged / scalar-cache operands).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -40,7 +38,6 @@
 namespace ptm {
 
 enum { KIND_DENSE = 0, KIND_DIAG = 1, KIND_LOWER = 2 };
-enum { DST_GONE = -1 };
 enum { B_OPEN = 0, B_LIMIT = 1, B_REFLECT = 2, B_WRAP = 3 };
 enum { P_FLAT = 0, P_UNIFORM = 1, P_GAUSSIAN = 2, P_POLAR = 3, P_COPOLAR = 4, P_LOG = 5 };
 
@@ -82,21 +79,19 @@ struct Dev {
   const double* prop_dense;  // [nloc][DP*DP] dense column-major image (zeros above the diagonal) for the DPP product
   const double* onedfrac;  // [nloc]
   int prop_stride, any_oned;
-  // state
-  const double* x_in;  double* x_out;
-  const double* ll_in; double* ll_out;
-  const double* lp_in; double* lp_out;
+  // state (in place)
+  double* x;                              // [Nc][DP] rows
+  double *ll, *lp;                        // [Nc]
   int *ntries, *naccept, *last_type;
   unsigned int* nhist;
-  int* dst;
   unsigned char* touch;
   int *arr_below, *arr_above;             // [W] landing slot of the row arriving across the lower / upper boundary, or -1
-  const double *recv_below, *recv_above;  // [(DP+2)][W] rows that crossed the shard boundary this step
+  const double *recv_below, *recv_above;  // [W][DP+2] rows {x, llike, lprior} that crossed the shard boundary this step
   int* err;
   // host-callback likelihood (bayes_likelihood::register_evaluate_log surface): the sweep is split around the host
   //   mode 0: fused (device target)   mode 1: propose only -> xprop/lprior_new/gate   mode 2: accept with llike_new
   int mode;
-  double* xprop;            // [DP][Nc] proposed (enforced) states
+  double* xprop;            // [Nc][DP] proposed (enforced) states
   double* lprior_new;       // [Nc]
   unsigned char* gate;      // [Nc] bit0: state valid, bit1: likelihood wanted (chain.cc:980)
   const double* llike_new;  // [Nc] filled by the host for gated chains
@@ -370,34 +365,32 @@ __global__ __launch_bounds__(256, PTM_SWEEP_WAVES) void sweep_kernel(const Dev p
   const int Nc = p.Nc;
 
   const int tc = p.touch[c];  // > 0: the rung took part in that many exchange attempts => no MH move this step
-  int out = c;                // slot this lane's row is written to
   const bool propose_only = !SIMPLE && p.mode == 1;
   if (tc && !propose_only) {
-    out = p.dst[c];
     p.nhist[c] += (unsigned int)tc;  // one add_state per attempt (chain.cc:1487-1490,1531-1534,1554-1557)
-    p.touch[c] = 0;
-    p.dst[c] = c;
+    p.touch[c] = 0;                  // (the exchange kernel already moved the rows)
   }
-  // rows arriving from the adjacent shards are installed by the boundary rungs' lanes (one row per walker at most)
+  // rows arriving from the adjacent shards are installed by the boundary rungs' lanes (one row per walker at most);
+  // the landing slot's own lane is a touched lane and neither reads nor writes its row this step
   if (!propose_only && p.recv_above && rl == p.nloc - 1) {
     const int a = p.arr_above[w];
     if (a >= 0) {
+      const double* r = p.recv_above + (size_t)w * (DP + 2);
 #pragma unroll
-      for (int d = 0; d < DP + 2; ++d) {
-        const double v = p.recv_above[(size_t)d * p.W + w];
-        if (d < DP) p.x_out[(size_t)d * Nc + a] = v; else if (d == DP) p.ll_out[a] = v; else p.lp_out[a] = v;
-      }
+      for (int d = 0; d < DP; ++d) p.x[(size_t)a * DP + d] = r[d];
+      p.ll[a] = r[DP];
+      p.lp[a] = r[DP + 1];
       p.arr_above[w] = -1;
     }
   }
   if (!propose_only && p.recv_below && rl == 0) {
     const int a = p.arr_below[w];
     if (a >= 0) {
+      const double* r = p.recv_below + (size_t)w * (DP + 2);
 #pragma unroll
-      for (int d = 0; d < DP + 2; ++d) {
-        const double v = p.recv_below[(size_t)d * p.W + w];
-        if (d < DP) p.x_out[(size_t)d * Nc + a] = v; else if (d == DP) p.ll_out[a] = v; else p.lp_out[a] = v;
-      }
+      for (int d = 0; d < DP; ++d) p.x[(size_t)a * DP + d] = r[d];
+      p.ll[a] = r[DP];
+      p.lp[a] = r[DP + 1];
       p.arr_below[w] = -1;
     }
   }
@@ -443,106 +436,75 @@ __global__ __launch_bounds__(256, PTM_SWEEP_WAVES) void sweep_kernel(const Dev p
     factor_product<DP, KIND>(dc, as_c(p.prop) + (size_t)rl * p.prop_stride, xn);
   }
 
+  if (tc) return;  // touched rung: no MH move (its add_state calls were counted above)
+
   // -- current state: read only now (its registers are not live across the draw loops) and folded straight into the
-  //    proposal; every lane reads its own row, one fully coalesced access per plane for the whole wave.  The old
-  //    state is NOT kept: a rejected (or merely moved) row is re-read at the end -- an L2 / Infinity-Cache hit, the
-  //    row was fetched a few microseconds earlier -- which halves the live register set of the quadratic form.
-  double ll = p.ll_in[c], lp = p.lp_in[c];
-  bool accept = false;
-#if PTM_KEEP_X
-  double xk[DP];
+  //    proposal.  The row is written back only if the move is accepted.
+  const double ll = p.ll[c], lp = p.lp[c];
+  double* __restrict__ row = p.x + (size_t)c * DP;
+  if (mode != 2) {
 #pragma unroll
-  for (int d = 0; d < DP; ++d) xk[d] = p.x_in[(size_t)d * Nc + c];
-#endif
-  if (!tc) {
-    if (mode != 2) {
-#pragma unroll
-      for (int d = 0; d < DP; ++d) {
-#if PTM_KEEP_X
-        xn[d] = xk[d] + xn[d];  // state::add (states.cc:205-214)
-#else
-        xn[d] = p.x_in[(size_t)d * Nc + c] + xn[d];  // state::add (states.cc:205-214)
-#endif
-      }
-    }
-    const double beta = as_c(p.beta)[rg];
-    const double bl = beta * ll;
-    const double cur_lpost = lp + bl;
-    const double oldlprior = cur_lpost - bl;  // chain.cc:973
-
-    bool valid;
-    double newlprior;
-    if (SIMPLE) {
-      valid = true;
-      bool in = true;
-      cdp plo = as_c(p.plo), phi = as_c(p.phi);
-#pragma unroll
-      for (int d = 0; d < DP; ++d) in = in && !(xn[d] < plo[d]) && !(xn[d] > phi[d]);
-      newlprior = in ? p.lprior_const : -__builtin_inf();
-    } else if (mode == 2) {
-      valid = (p.gate[c] & 1) != 0;
-      newlprior = p.lprior_new[c];
-#pragma unroll
-      for (int d = 0; d < DP; ++d) xn[d] = p.xprop[(size_t)d * Nc + c];
-    } else {
-      valid = p.origin_valid != 0;  // Q9: the sum is built on an enforced zero state
-      double xa[DP];                // general state-space / prior code works on an addressable copy
-#pragma unroll
-      for (int d = 0; d < DP; ++d) xa[d] = xn[d];
-      newlprior = enforce_and_lprior<DP>(p, xa, valid);
-#pragma unroll
-      for (int d = 0; d < DP; ++d) xn[d] = xa[d];
-    }
-    const bool want_like = valid && (newlprior > -1e200 || newlprior - oldlprior > p.min_prior);  // chain.cc:980 (Q1)
-    if (mode == 1) {
-      // propose pass: hand the proposal to the host, change nothing else
-#pragma unroll
-      for (int d = 0; d < DP; ++d) p.xprop[(size_t)d * Nc + c] = xn[d];
-      p.lprior_new[c] = newlprior;
-      p.gate[c] = (unsigned char)((valid ? 1 : 0) | (want_like ? 2 : 0));
-      return;
-    }
-    double newlike, newlpost;
-    if (mode == 2) {
-      newlike = want_like ? p.llike_new[c] : -__builtin_inf();
-      newlpost = want_like ? newlike * beta + newlprior : -__builtin_inf();
-    } else if (want_like) {
-#if defined(PTM_ABLATE) && (PTM_ABLATE & 4)
-      newlike = xn[0] + xn[DP - 1];  // ablation: no quadratic form
-#else
-      newlike = (!SIMPLE && p.has_mean) ? gauss_llike<DP, true>(p, xn) : gauss_llike<DP, false>(p, xn);
-#endif
-      newlpost = newlike * beta + newlprior;
-    } else {
-      newlike = newlpost = -__builtin_inf();
-    }
-    const double logH = newlpost - cur_lpost;  // gaussian_prop: log_hastings_ratio() == 0
-    accept = valid;
-    if (accept && logH < 0) accept = dlog_u01(o0.v0) < logH;  // chain.cc:998-1001 (NaN stays accepted)
-
-    p.ntries[c] += 1;
-    if (accept) {
-      p.naccept[c] += 1;
-      p.last_type[c] = type;
-      ll = newlike;
-      lp = newlprior;
-    }
-    p.nhist[c] += 1u;
+    for (int d = 0; d < DP; ++d) xn[d] = row[d] + xn[d];  // state::add (states.cc:205-214)
   }
-  if (propose_only) return;  // (touched lanes: nothing to propose)
-  if (out >= 0) {  // (a row that left the shard was packed into the send buffer by the exchange kernel)
+  const double beta = as_c(p.beta)[rg];
+  const double bl = beta * ll;
+  const double cur_lpost = lp + bl;
+  const double oldlprior = cur_lpost - bl;  // chain.cc:973
+
+  bool valid;
+  double newlprior;
+  if (SIMPLE) {
+    valid = true;
+    bool in = true;
+    cdp plo = as_c(p.plo), phi = as_c(p.phi);
 #pragma unroll
-    for (int d = 0; d < DP; ++d) {
-#if PTM_KEEP_X
-      p.x_out[(size_t)d * Nc + out] = accept ? xn[d] : xk[d];
+    for (int d = 0; d < DP; ++d) in = in && !(xn[d] < plo[d]) && !(xn[d] > phi[d]);
+    newlprior = in ? p.lprior_const : -__builtin_inf();
+  } else if (mode == 2) {
+    valid = (p.gate[c] & 1) != 0;
+    newlprior = p.lprior_new[c];
+#pragma unroll
+    for (int d = 0; d < DP; ++d) xn[d] = p.xprop[(size_t)c * DP + d];
+  } else {
+    valid = p.origin_valid != 0;  // Q9: the sum is built on an enforced zero state
+    newlprior = enforce_and_lprior<DP>(p, xn, valid);
+  }
+  const bool want_like = valid && (newlprior > -1e200 || newlprior - oldlprior > p.min_prior);  // chain.cc:980 (Q1)
+  if (mode == 1) {
+    // propose pass: hand the proposal to the host, change nothing else
+#pragma unroll
+    for (int d = 0; d < DP; ++d) p.xprop[(size_t)c * DP + d] = xn[d];
+    p.lprior_new[c] = newlprior;
+    p.gate[c] = (unsigned char)((valid ? 1 : 0) | (want_like ? 2 : 0));
+    return;
+  }
+  double newlike, newlpost;
+  if (mode == 2) {
+    newlike = want_like ? p.llike_new[c] : -__builtin_inf();
+    newlpost = want_like ? newlike * beta + newlprior : -__builtin_inf();
+  } else if (want_like) {
+#if defined(PTM_ABLATE) && (PTM_ABLATE & 4)
+    newlike = xn[0] + xn[DP - 1];  // ablation: no quadratic form
 #else
-      double v = xn[d];
-      if (!accept) v = p.x_in[(size_t)d * Nc + c];
-      p.x_out[(size_t)d * Nc + out] = v;
+    newlike = (!SIMPLE && p.has_mean) ? gauss_llike<DP, true>(p, xn) : gauss_llike<DP, false>(p, xn);
 #endif
-    }
-    p.ll_out[out] = ll;
-    p.lp_out[out] = lp;
+    newlpost = newlike * beta + newlprior;
+  } else {
+    newlike = newlpost = -__builtin_inf();
+  }
+  const double logH = newlpost - cur_lpost;  // gaussian_prop: log_hastings_ratio() == 0
+  bool accept = valid;
+  if (accept && logH < 0) accept = dlog_u01(o0.v0) < logH;  // chain.cc:998-1001 (NaN stays accepted)
+
+  p.ntries[c] += 1;
+  p.nhist[c] += 1u;
+  if (accept) {
+    p.naccept[c] += 1;
+    p.last_type[c] = type;
+#pragma unroll
+    for (int d = 0; d < DP; ++d) row[d] = xn[d];
+    p.ll[c] = newlike;
+    p.lp[c] = newlprior;
   }
 }
 
@@ -550,17 +512,17 @@ __global__ __launch_bounds__(256, PTM_SWEEP_WAVES) void sweep_kernel(const Dev p
 // evaluation of given states (set_states / debug_evaluate): enforce, lprior, llike
 // ------------------------------------------------------------------------------------------------
 template <int DP>
-__global__ __launch_bounds__(256) void evaluate_kernel(const Dev p, int n, double* x_io /*[DP][n]*/, int* valid_out,
+__global__ __launch_bounds__(256) void evaluate_kernel(const Dev p, int n, double* x_io /*[n][DP]*/, int* valid_out,
                                                         double* lprior_out, double* llike_out, int eval_like) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= n) return;
   double x[DP];
 #pragma unroll
-  for (int d = 0; d < DP; ++d) x[d] = x_io[(size_t)d * n + c];
+  for (int d = 0; d < DP; ++d) x[d] = x_io[(size_t)c * DP + d];
   bool valid = true;  // state(space, values) constructor: valid unless enforce fails (states.cc:194-199)
   const double lp = enforce_and_lprior<DP>(p, x, valid);
 #pragma unroll
-  for (int d = 0; d < DP; ++d) x_io[(size_t)d * n + c] = x[d];
+  for (int d = 0; d < DP; ++d) x_io[(size_t)c * DP + d] = x[d];
   if (valid_out) valid_out[c] = valid ? 1 : 0;
   lprior_out[c] = lp;
   if (eval_like) llike_out[c] = p.has_mean ? gauss_llike<DP, true>(p, x) : gauss_llike<DP, false>(p, x);
@@ -609,7 +571,7 @@ __global__ __launch_bounds__(256) void init_prior_kernel(const Dev p, double* x_
     if (!done) return;
   } else if (!done) atomicOr(fail, 1);
 #pragma unroll
-  for (int d = 0; d < DP; ++d) x_out[(size_t)d * p.Nc + c] = x[d];
+  for (int d = 0; d < DP; ++d) x_out[(size_t)c * DP + d] = x[d];
   ll_out[c] = ll;
   lp_out[c] = lp;
 }
