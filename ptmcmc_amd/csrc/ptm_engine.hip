@@ -45,6 +45,7 @@ struct ptm_engine {
   double *x = nullptr, *ll = nullptr, *lp = nullptr;   // rows [Nc][DP] and per-chain scalars, updated in place
   int *ntries = nullptr, *naccept = nullptr, *last_type = nullptr, *err = nullptr;
   int *arr_below = nullptr, *arr_above = nullptr;
+  int *mv_src = nullptr, *mv_dst = nullptr, *mv_n = nullptr;   // per-ladder move lists (exchange kernel -> move kernel)
   unsigned int* nhist = nullptr;
   long long *swap_try = nullptr, *swap_acc = nullptr;
   unsigned char* touch = nullptr;
@@ -139,7 +140,8 @@ extern "C" int ptm_engine_create(const ptm_config* cfg, ptm_engine** out) {
   if ((rc = dalloc(&e->x, Nc * D)) || (rc = dalloc(&e->ll, Nc)) || (rc = dalloc(&e->lp, Nc))) return rc;
   HIPCHK(hipMemsetAsync(e->x, 0, Nc * D * 8, e->stream));
   if ((rc = dalloc(&e->ntries, Nc)) || (rc = dalloc(&e->naccept, Nc)) || (rc = dalloc(&e->last_type, Nc)) ||
-      (rc = dalloc(&e->arr_below, (size_t)cfg->n_walkers)) ||
+      (rc = dalloc(&e->arr_below, (size_t)cfg->n_walkers)) || (rc = dalloc(&e->mv_src, (size_t)cfg->n_walkers * MVCAP)) ||
+      (rc = dalloc(&e->mv_dst, (size_t)cfg->n_walkers * MVCAP)) || (rc = dalloc(&e->mv_n, (size_t)cfg->n_walkers)) ||
       (rc = dalloc(&e->arr_above, (size_t)cfg->n_walkers)) || (rc = dalloc(&e->touch, Nc)) || (rc = dalloc(&e->nhist, Nc)) ||
       (rc = dalloc(&e->err, 4)))
     return rc;
@@ -152,6 +154,7 @@ extern "C" int ptm_engine_create(const ptm_config* cfg, ptm_engine** out) {
   HIPCHK(hipMemsetAsync(e->last_pairs, 0xFF, (size_t)e->W * e->ms * 4, e->stream));
   HIPCHK(hipMemsetAsync(e->last_acc, 0, (size_t)e->W * e->ms * 4, e->stream));
   HIPCHK(hipMemsetAsync(e->err, 0, 16, e->stream));
+  HIPCHK(hipMemsetAsync(e->mv_n, 0, (size_t)e->W * 4, e->stream));
   if ((rc = dalloc(&e->blo, D)) || (rc = dalloc(&e->bhi, D)) || (rc = dalloc(&e->ptype, D)) || (rc = dalloc(&e->bmin, D)) ||
       (rc = dalloc(&e->bmax, D)) || (rc = dalloc(&e->plo, D)) || (rc = dalloc(&e->phi, D)) || (rc = dalloc(&e->pcoef, D)) ||
       (rc = dalloc(&e->P2, D * (D + 1) / 2)) || (rc = dalloc(&e->mean, D)) || (rc = dalloc(&e->beta, (size_t)e->Nt)) ||
@@ -178,7 +181,7 @@ extern "C" int ptm_engine_create(const ptm_config* cfg, ptm_engine** out) {
 extern "C" int ptm_engine_destroy(ptm_engine* e) {
   if (!e) return PTM_OK;
   (void)hipStreamSynchronize(e->stream);
-  void* ptrs[] = {e->x, e->ll, e->lp, e->ntries, e->naccept, e->last_type, e->arr_below, e->arr_above,
+  void* ptrs[] = {e->x, e->ll, e->lp, e->ntries, e->naccept, e->last_type, e->arr_below, e->arr_above, e->mv_src, e->mv_dst, e->mv_n,
                   e->err, e->nhist, e->swap_try, e->swap_acc, e->touch, e->last_pairs, e->last_acc, e->blo,
                   e->bhi, e->ptype, e->bmin, e->bmax, e->plo, e->phi, e->pcoef, e->P2, e->mean, e->beta, e->prop, e->prop_dense, e->onedfrac, e->xprop, e->lprior_new, e->llike_new, e->gate};
   for (void* p : ptrs)
@@ -462,8 +465,9 @@ static int launch_sweep(ptm_engine* e, const double* recv_below, const double* r
 }
 
 static size_t decide_lds_bytes(int Nt, int ms) {
-  const size_t msp = (size_t)((ms + 1) & ~1);
-  return (size_t)Nt * 8 + (size_t)ms * 16 + msp * 4 * 2 + (size_t)((Nt + 3) & ~3) * 2 * 3 + (size_t)((Nt + 7) & ~7) + (size_t)((Nt + 1 + 7) & ~7) + 16;
+  // mirrors the carve at the top of decide_kernel
+  return (size_t)Nt * 8 + (size_t)ms * 8 + (size_t)((Nt + 1) & ~1) * 4 + (size_t)((ms + 1) & ~1) * 4 + (size_t)MVCAP * 8 + 8 +
+         (size_t)((Nt + 3) & ~3) * 2 * 2 + (size_t)((ms + 7) & ~7) * 2 + 32;
 }
 
 static int launch_decide(ptm_engine* e, const double* ll_below, const double* ll_above, int H, double* send_up, double* send_down) {
@@ -474,11 +478,17 @@ static int launch_decide(ptm_engine* e, const double* ll_below, const double* ll
   p.beta = e->beta; p.ll_below = ll_below; p.ll_above = ll_above; p.H = ll_above ? H : 0; p.x = e->x; p.ll = e->ll; p.lp = e->lp;
   p.touch = e->touch; p.arr_below = e->arr_below; p.arr_above = e->arr_above; p.swap_try = e->swap_try; p.swap_acc = e->swap_acc;
   p.last_pairs = e->last_pairs; p.last_acc = e->last_acc; p.send_up = send_up; p.send_down = send_down; p.err = e->err;
+  p.mv_src = e->mv_src; p.mv_dst = e->mv_dst; p.mv_n = e->mv_n;
   const size_t lds = decide_lds_bytes(e->Nt, e->ms);
   if (lds > 160 * 1024) return fail(PTM_ERR_UNSUPPORTED, "ladder too long for the LDS-resident exchange kernel (%zu B)", lds);
   if (lds > 64 * 1024)
     HIPCHK(hipFuncSetAttribute((const void*)decide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(decide_kernel, dim3(e->W), dim3(64), lds, e->stream, p);
+  HIPCHK(hipGetLastError());
+  Move m;
+  m.DP = e->DP; m.W = e->W; m.x = e->x; m.ll = e->ll; m.lp = e->lp; m.send_up = send_up; m.send_down = send_down;
+  m.mv_src = e->mv_src; m.mv_dst = e->mv_dst; m.mv_n = e->mv_n;
+  hipLaunchKernelGGL(move_kernel, dim3(e->W), dim3(64), 0, e->stream, m);
   HIPCHK(hipGetLastError());
   return PTM_OK;
 }
@@ -643,6 +653,7 @@ extern "C" int ptm_sync(ptm_engine* e) {
   HIPCHK(hipMemcpy(&flag, e->err, 4, hipMemcpyDeviceToHost));
   if (flag & 1) return fail(PTM_ERR_FAR_MOVE, "a state crossed more than one shard boundary in one step (neighbour exchange mode)");
   if (flag & 2) return fail(PTM_ERR_FAR_MOVE, "an exchange chain reached past the llike halo: rerun with a deeper halo");
+  if (flag & 4) return fail(PTM_ERR_UNSUPPORTED, "more than 256 rows of one ladder moved in one step (swap_rate too high for this build)");
   return PTM_OK;
 }
 

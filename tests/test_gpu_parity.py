@@ -339,3 +339,16 @@ def test_host_callback_likelihood_C5_exampleLISA():
     assert eng.naccept.sum() - eng.Nc > 50
     assert (eng.last_type >= 0).any()
     eng.close()
+
+
+def test_exchange_overflow_path_many_moved_rows():
+    """More than 256 rows of one ladder move in one step (high swap rate on a long ladder): the exchange kernel's
+    in-kernel cycle walk must give the same chain as the register gather/scatter kernel does for smaller counts."""
+    pr, eng, lad = PU.make_pair(4, 400, 64, 1e3, kind=E.PROP_DIAG, swap_rate=0.45)
+    moved_max = 0
+    for k in range(6):
+        eng.step(1); eng.sync(); lad.pt_step(1)
+        PU.assert_same_state(eng, lad, "after step %d" % (k + 1))
+        moved_max = max(moved_max, int(2 * eng.last_swaps()[1].sum(axis=1).max()))
+    assert moved_max > 256, moved_max
+    eng.close()
