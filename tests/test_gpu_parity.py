@@ -344,7 +344,7 @@ def test_host_callback_likelihood_C5_exampleLISA():
 def test_exchange_overflow_path_many_moved_rows():
     """More than 256 rows of one ladder move in one step (high swap rate on a long ladder): the exchange kernel's
     in-kernel cycle walk must give the same chain as the register gather/scatter kernel does for smaller counts."""
-    pr, eng, lad = PU.make_pair(4, 400, 64, 1e3, kind=E.PROP_DIAG, swap_rate=0.45)
+    pr, eng, lad = PU.make_pair(4, 900, 64, 1e3, kind=E.PROP_DIAG, swap_rate=0.45)
     moved_max = 0
     for k in range(6):
         eng.step(1); eng.sync(); lad.pt_step(1)
