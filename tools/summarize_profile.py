@@ -14,7 +14,8 @@ src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
 
-stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
+newest = lambda pat: max(glob.glob(pat), key=os.path.getmtime)
+stats = newest(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
 shutil.copy(stats, os.path.join(dst, "%s_kernel_stats.csv" % tag))
 for leg in ("trace", "fetch", "write"):
     p = os.path.join(src, "bench_%s.json" % leg)
@@ -23,7 +24,7 @@ for leg in ("trace", "fetch", "write"):
 
 pmc = {}
 for leg, name in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
-    f = glob.glob(os.path.join(src, "pmc_" + leg, "*", "*_counter_collection.csv"))[0]
+    f = newest(os.path.join(src, "pmc_" + leg, "*", "*_counter_collection.csv"))
     per = {}
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] != name:
