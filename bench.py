@@ -172,9 +172,10 @@ def main():
     ap.add_argument("--halo", type=int, default=4, help="llike halo depth (rungs) between shards")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-w1", action="store_true", help="skip the 1024-chain latency companion")
+    ap.add_argument("--force-dist", action="store_true", help="take the torch.distributed path even with one rank (smoke test)")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 or world > 1:
+    if args.gpus > 1 or world > 1 or args.force_dist:
         from ptmcmc_amd import parallel
         return parallel.bench_main(args)
     run_single(args)
