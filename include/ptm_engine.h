@@ -70,6 +70,9 @@ typedef struct ptm_config {
   void* stream;           /* hipStream_t to launch on; NULL = the engine creates its own */
   int32_t time_kernels;   /* !=0: bracket every sweep-kernel launch with HIP events (ptm_get_kernel_times) */
   int32_t swap_log_steps; /* >0: keep the per-candidate swap log of the last N steps on the device */
+  int32_t exchange_row_capacity; /* row slots per boundary message (multi-GPU); 0 = automatic:
+                                  * min(n_walkers, n_walkers*swap_rate + 8 sigma + 64).  More rows crossing one boundary in
+                                  * one step than this is reported as PTM_ERR_FAR_MOVE by ptm_sync, never silently dropped */
 } ptm_config;
 
 /* user plug-in likelihood, batched: the C shape of bayes_likelihood::register_evaluate_log
@@ -127,15 +130,20 @@ int ptm_sync(ptm_engine* e);
 int ptm_copy_llike(ptm_engine* e, int first_local_rung, int n_rungs, void* dst_dev);
 /* device pointer to the local llike array of the CURRENT step, [rung_count*W] doubles, chain-major */
 int ptm_llike_device_ptr(ptm_engine* e, void** dev_ptr);
-/* exchange phase, part 1: decide all exchanges that concern this shard and pack the rows that leave it into
- * send_up / send_down (device buffers of ptm_exchange_buffer_doubles() doubles each; ignored at the ladder's ends).
+/* exchange phase, part 1: decide all exchanges that concern this shard, move the rows that stay inside it and pack the
+ * rows that leave it into the boundary messages send_up / send_down (device buffers of ptm_exchange_buffer_doubles()
+ * doubles each; ignored at the ladder's ends).  A message is opaque to the caller: it is delivered whole to the
+ * neighbour's ptm_exchange_finish_and_sweep.  (Layout: int32 row count, then ptm_exchange_row_capacity() slots of
+ * {state[padded dim], llike, lprior, walker, 0}.)
  * ll_below_dev: [W] (ignored on the first shard); ll_above_dev: [halo_rungs][W] (ignored on the last shard). */
 int ptm_exchange_decide(ptm_engine* e, const void* ll_below_dev, const void* ll_above_dev, int halo_rungs, void* send_up_dev,
                         void* send_down_dev);
-/* exchange phase, part 2 + MH sweep: rows arriving from the neighbours (device buffers of the same size) */
+/* exchange phase, part 2 + MH sweep: lands the rows of the neighbours' messages (device buffers of the same size; the
+ * message from below is required unless this is the first shard, the one from above unless it is the last) */
 int ptm_exchange_finish_and_sweep(ptm_engine* e, const void* recv_from_below_dev, const void* recv_from_above_dev);
-/* size of one boundary buffer in doubles: W * (padded dim + 2) -- per walker one row {state, llike, lprior} */
+/* size of one boundary message in doubles: 2 + row capacity * (padded dim + 4) */
 int ptm_exchange_buffer_doubles(ptm_engine* e);
+int ptm_exchange_row_capacity(ptm_engine* e);
 
 /* ---- read-back ------------------------------------------------------------------------------------------ */
 enum {

@@ -6,11 +6,24 @@ namespace ptm {
 
 // ------------------------------------------------------------------------------------------------
 // exchange phase of parallel_tempering_chains::step (chain.cc:1410-1537), one wave per walker-ladder.
-// Candidate draws are parallel over lanes; the in-order filter and trials (quirk Q6: later picks see the
-// in-place updated view) run on lane 0 over LDS copies of the picked rungs' llikes.
-// After the decisions the kernel exchanges the rows themselves, in place (whole contiguous rows), packs the rows that
-// leave the shard and names the landing slot of arrivals; touch[] tells the sweep kernel which rungs skip their MH move.
+// decide_kernel replays the step's candidate draws, decides every exchange that concerns the shard and lists the row
+// moves; move_kernel applies them in place (whole contiguous rows) and packs the rows that leave the shard;
+// install_kernel lands the rows that arrive from the adjacent shards.  touch[] tells the sweep kernel which rungs skip
+// their MH move.
+//
+// Boundary message (one per direction and step): an int32 row count in the first 8 bytes (+8 bytes padding), then
+// `row_cap` slots of RD = DP+4 doubles {x[DP], llike, lprior, walker, 0}.  Rows are appended in no particular order.
 // ------------------------------------------------------------------------------------------------
+constexpr int MSG_HDR = 2;    // doubles before the first row slot
+constexpr int ROW_EXTRA = 4;  // {llike, lprior, walker, pad}: keeps row slots 32-byte multiples
+
+// claims the next slot of a boundary message; null (and error bit 4) when the message is full
+__device__ __forceinline__ double* claim_row(double* buf, int cap, int RD, int* err) {
+  const int slot = atomicAdd(reinterpret_cast<int*>(buf), 1);
+  if (slot >= cap) { atomicOr(err, 4); return nullptr; }
+  return buf + MSG_HDR + (size_t)slot * RD;
+}
+
 struct Decide {
   int DP, Nt, r0, nloc, W, Nc, ms;
   uint64_t seed, step;
@@ -19,14 +32,15 @@ struct Decide {
   const double* ll_below;     // [W]      llike of rung r0-1 (top rung of the shard below), null on the first shard
   const double* ll_above;     // [H][W]   llike of rungs r1 .. r1+H-1 (bottom rungs of the shard above), null on the last
   int H;                      // halo depth actually available above (0 on the last shard)
-  double* x;                  // [Nc][DP] rows, moved in place
+  double* x;                  // [Nc][DP] rows (only the overflow path moves rows here)
   double* ll;
   double* lp;
   unsigned char* touch;
-  int *arr_below, *arr_above;      // [W]
+  int *arr_below, *arr_above;      // [W]  landing slot of the row arriving across the lower / upper boundary, or -1
   long long *swap_try, *swap_acc;  // [W][Nt-1]
-  int *last_pairs, *last_acc;      // [W][ms]
-  double *send_up, *send_down;     // [W][DP+2] rows {x, llike, lprior} or null
+  int* swap_log;                   // [W][ms]  per candidate: -2 none/dropped, -3 not this shard's, else rung | accepted<<30
+  double *send_up, *send_down;     // boundary messages or null
+  int row_cap;
   int *mv_src, *mv_dst, *mv_n;     // [W][MVCAP], [W][MVCAP], [W]: the ladder's row moves for move_kernel
   int* err;
 };
@@ -49,34 +63,38 @@ constexpr int MVCAP = 256;  // rows one ladder can move per step on the register
 //   (2) trials: two surviving picks on adjacent rungs (n, n+1) exist only if n+1 was picked first, and only then does
 //       pick n see an updated upper rung -- so each run of consecutive surviving rungs is decided top-down, and runs
 //       are independent of each other.
-// One lane walks each run; everything else (draws, logs, counters, move list) is parallel over picks.
+// One lane walks each run; everything else (draws, counters, move list) is parallel over picks.  The draws and the
+// filter cover the whole ladder (they are replicated on every shard); everything after them runs over the compacted
+// list of the surviving picks inside the shard's window, on LDS arrays indexed by window rung.
 __global__ __launch_bounds__(64) void decide_kernel(const Decide p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int w = blockIdx.x;
   const int lane = threadIdx.x;
   const int Nt = p.Nt, ms = p.ms;
   const int NONE = 0x7fffffff;
-  // LDS carve (all offsets multiples of 8)
-  double* llc = reinterpret_cast<double*>(smem);                              // [Nt]   llike view of the touched rungs
-  double* lu = llc + Nt;                                                      // [ms]   log(u_accept) per candidate
-  int* first = reinterpret_cast<int*>(lu + ms);                               // [Nt]   first pick of each rung value
-  int* cand = first + ((Nt + 1) & ~1);                                        // [ms]   rung of the pick / -2 none or dropped
-  int* mvsrc = cand + ((ms + 1) & ~1);                                        // [MVCAP]
-  int* mvdst = mvsrc + MVCAP;                                                 // [MVCAP]
-  int* mvcnt = mvdst + MVCAP;                                                 // [2]
-  unsigned short* perm = reinterpret_cast<unsigned short*>(mvcnt + 2);        // [Nt]   source rung of the row now at a rung
-  unsigned short* inv = perm + ((Nt + 3) & ~3);                               // [Nt]   inverse of perm
-  unsigned char* alive = reinterpret_cast<unsigned char*>(inv + ((Nt + 3) & ~3));  // [ms] 0 dropped, 1 survives and is ours,
-                                                                                   //      2 survives, not ours to decide
-  unsigned char* accf = alive + ((ms + 7) & ~7);                              // [ms]
-
   const int r1 = p.r0 + p.nloc;
   // window of rungs whose llike this shard knows: its own, one below, H above
   const int wlo = p.r0 - (p.ll_below ? 1 : 0), whi = r1 - 1 + p.H;
+  const int WN = whi - wlo + 1;
+  // LDS carve (mirrored by decide_lds_bytes on the host; all offsets multiples of 8)
+  double* llc_ = reinterpret_cast<double*>(smem);                             // [WN]  llike view of the touched rungs
+  int* first = reinterpret_cast<int*>(llc_ + WN);                             // [Nt]  first pick of each rung value
+  int* cand = first + ((Nt + 1) & ~1);                                        // [ms]  rung of the pick / -2 none or dropped
+  uint32_t* ua = reinterpret_cast<uint32_t*>(cand + ((ms + 1) & ~1));         // [ms]  accept uniform of the pick (raw)
+  int* cnt = reinterpret_cast<int*>(ua + ((ms + 1) & ~1));                    // [2]   list length, move count
+  unsigned short* perm_ = reinterpret_cast<unsigned short*>(cnt + 2);         // [WN]  source rung of the row now at a rung
+  unsigned short* inv_ = perm_ + ((WN + 3) & ~3);                             // [WN]  inverse of perm
+  unsigned short* list = inv_ + ((WN + 3) & ~3);                              // [ms]  surviving picks that are ours
+  unsigned char* alive = reinterpret_cast<unsigned char*>(list + ((ms + 3) & ~3));  // [ms] 0 dropped, 1 survives and is
+                                                                                    //      ours, 2 survives, not ours
+  unsigned char* accf = alive + ((ms + 7) & ~7);                              // [ms]
+  double* llc = llc_ - wlo;                // indexed by global rung
+  unsigned short* perm = perm_ - wlo;
+  unsigned short* inv = inv_ - wlo;
   cdp beta = as_c(p.beta);
 
   for (int i = lane; i < Nt; i += 64) first[i] = NONE;
-  if (lane == 0) *mvcnt = 0;
+  if (lane == 0) { cnt[0] = 0; cnt[1] = 0; p.arr_below[w] = -1; p.arr_above[w] = -1; }
   __syncthreads();
   // -- candidate draws (chain.cc:1410-1416): block k of the ladder stream gives {u_try, u_pick, u_accept}
   for (int k = lane; k < ms; k += 64) {
@@ -84,7 +102,7 @@ __global__ __launch_bounds__(64) void decide_kernel(const Decide p) {
     int n = -2;
     if (Nt > 1 && u01(o.v0) < p.thresh) n = (int)(u01(o.v1) * (Nt - 1));
     cand[k] = n;
-    lu[k] = dlog_u01(o.v2);  // the accept uniform's slot is reserved whether or not it is needed (cf. Q5)
+    ua[k] = o.v2;  // the accept uniform's slot is reserved whether or not it is needed (cf. Q5)
     alive[k] = 0;
     accf[k] = 0;
     if (n >= 0) atomicMin(&first[n], k);
@@ -104,68 +122,81 @@ __global__ __launch_bounds__(64) void decide_kernel(const Decide p) {
   }
   __syncthreads();
 #define PTM_ALIVE_RUNG(r) ((r) >= 0 && (r) <= Nt - 2 && first[(r)] != NONE && alive[first[(r)]])
-  // -- working copy of the touched rungs inside the window (gather_llikes, chain.cc:1434); each touched rung is set up
-  //    by exactly one lane: the pick whose lower rung it is, or -- for the top of a run -- the pick just below it
+  // -- compaction: the surviving picks whose pair lies inside the window
   for (int k = lane; k < ms; k += 64) {
     const int n = cand[k];
     if (n < 0) continue;
     if (!alive[k]) { cand[k] = -2; continue; }
     if (n < wlo || n + 1 > whi) { alive[k] = 2; continue; }     // survives, but is not this shard's to decide
-    llc[n] = win_llike(p, n, w);
+    list[atomicAdd(&cnt[0], 1)] = (unsigned short)k;
+  }
+  __syncthreads();
+  const int nl = cnt[0];
+  // -- working copy of the touched rungs (gather_llikes, chain.cc:1434); each touched rung is set up by exactly one
+  //    lane: the pick whose lower rung it is, or -- for the top of a run -- the pick just below it
+  for (int j = lane; j < nl; j += 64) {
+    const int n = cand[list[j]];
+    const bool top = !PTM_ALIVE_RUNG(n + 1) || n + 2 > whi;    // (an alive pick above that lies outside the window sets up nothing)
+    const double a = win_llike(p, n, w);
+    const double b = top ? win_llike(p, n + 1, w) : 0.0;
+    llc[n] = a;
     perm[n] = (unsigned short)n;
     inv[n] = (unsigned short)n;
-    if (!PTM_ALIVE_RUNG(n + 1) || n + 2 > whi) {               // (an alive pick above that lies outside the window sets up nothing)
-      llc[n + 1] = win_llike(p, n + 1, w);
+    if (top) {
+      llc[n + 1] = b;
       perm[n + 1] = (unsigned short)(n + 1);
       inv[n + 1] = (unsigned short)(n + 1);
     }
   }
   __syncthreads();
   // -- trials (2): the top pick of each run of surviving rungs walks the run downwards (chain.cc:1436-1537)
-  for (int k = lane; k < ms; k += 64) {
-    const int n = cand[k];
-    if (n < 0 || PTM_ALIVE_RUNG(n + 1)) continue;               // not the top of a run
-    bool taint = false;  // the upper rung's content is unknown: an exchange above the window may have replaced it
-    for (int i = n; i >= 0; --i) {
-      const int kk = first[i];
-      if (i < wlo) break;                                        // below the window: nothing further down concerns us
-      if (i + 1 > whi) {                                         // pair above the window: not decided here ...
-        taint = (i == whi);                                      // ... but the one right above it may replace its top rung
-      } else if (taint) {
+  for (int j = lane; j < nl; j += 64) {
+    const int n = cand[list[j]];
+    const bool up = PTM_ALIVE_RUNG(n + 1);
+    if (up && n + 1 < whi) continue;                             // not the top of a run (the pick above is in the list)
+    if (up) {
+      // the pick above decides the pair (whi, whi+1), outside the window, and may replace rung whi: the content of
+      // every rung of this run is then unknown here.  Harmless as long as the run ends above the shard's own rungs.
+      for (int i = n; i >= wlo; --i) {
         if (i + 1 <= r1) atomicOr(p.err, 2);                     // would decide a local / straddling exchange blindly
-        alive[kk] = 2;
-      } else {
-        double lla = llc[i];
-        if (!(lla > -1e200)) lla = -1e200;
-        double llb = llc[i + 1];
-        if (!(llb > -1e200)) llb = -1e200;
-        const double logH = -(beta[i + 1] - beta[i]) * (llb - lla);
-        bool acc = true;
-        if (logH < 0) acc = lu[kk] < logH;
-        if (acc) {
-          // the row that leaves this shard downwards must be one of ours (else it crossed two boundaries in one step)
-          if (i + 1 == p.r0 && (perm[i + 1] < p.r0 || perm[i + 1] >= r1)) atomicOr(p.err, 1);
-          const double t = llc[i]; llc[i] = llc[i + 1]; llc[i + 1] = t;
-          const unsigned short s = perm[i]; perm[i] = perm[i + 1]; perm[i + 1] = s;
-          accf[kk] = 1;
-        }
+        alive[first[i]] = 2;
+        if (!PTM_ALIVE_RUNG(i - 1)) break;
+      }
+      continue;
+    }
+    for (int i = n; i >= wlo; --i) {                             // below the window nothing concerns us
+      const int kk = first[i];
+      double lla = llc[i];
+      if (!(lla > -1e200)) lla = -1e200;
+      double llb = llc[i + 1];
+      if (!(llb > -1e200)) llb = -1e200;
+      const double logH = -(beta[i + 1] - beta[i]) * (llb - lla);
+      bool acc = true;
+      if (logH < 0) acc = dlog_u01(ua[kk]) < logH;
+      if (acc) {
+        // the row that leaves this shard downwards must be one of ours (else it crossed two boundaries in one step)
+        if (i + 1 == p.r0 && (perm[i + 1] < p.r0 || perm[i + 1] >= r1)) atomicOr(p.err, 1);
+        const double t = llc[i]; llc[i] = llc[i + 1]; llc[i + 1] = t;
+        const unsigned short s = perm[i]; perm[i] = perm[i + 1]; perm[i + 1] = s;
+        accf[kk] = 1;
       }
       if (!PTM_ALIVE_RUNG(i - 1)) break;
     }
   }
   __syncthreads();
-  // -- publish the step's log, counters, the touch counts of the local rungs and the inverse permutation
-  const int DP = p.DP;
-  for (int k = lane; k < ms; k += 64) {
-    const int i = alive[k] == 1 ? cand[k] : (alive[k] == 2 ? -3 : -2);
-    p.last_pairs[(size_t)w * ms + k] = i;                 // -2: no candidate / dropped, -3: not this shard's to decide
-    p.last_acc[(size_t)w * ms + k] = accf[k];
-    if (i < 0) continue;
+  // -- the step's log
+  for (int k = lane; k < ms; k += 64)
+    p.swap_log[(size_t)w * ms + k] = alive[k] == 1 ? (cand[k] | (accf[k] ? 0x40000000 : 0)) : (alive[k] == 2 ? -3 : -2);
+  // -- counters, the touch counts of the local rungs and the inverse permutation
+  for (int j = lane; j < nl; j += 64) {
+    const int k = list[j];
+    if (alive[k] != 1) continue;
+    const int i = cand[k];
     // swap_count / swap_accept_count (chain.cc:1498,1536); a pair is counted by the shard that owns its lower rung, so
     // per-shard counters add up to the ladder's
     if (i >= p.r0 && i < r1) {
-      p.swap_try[(size_t)w * (Nt - 1) + i] += 1;
-      if (accf[k]) p.swap_acc[(size_t)w * (Nt - 1) + i] += 1;
+      atomicAdd(reinterpret_cast<unsigned long long*>(p.swap_try) + (size_t)w * (Nt - 1) + i, 1ull);
+      if (accf[k]) atomicAdd(reinterpret_cast<unsigned long long*>(p.swap_acc) + (size_t)w * (Nt - 1) + i, 1ull);
     }
     const int rtop = (PTM_ALIVE_RUNG(i + 1) && alive[first[i + 1]] == 1) ? i : i + 1;  // rung i+1 belongs to the pick above, if ours
     for (int r = i; r <= rtop; ++r) {
@@ -180,9 +211,12 @@ __global__ __launch_bounds__(64) void decide_kernel(const Decide p) {
   }
   __syncthreads();
   // -- the row moves.  The phase's net effect on the touched rungs is a permutation of rows: new row[r] =
-  //    old row[perm[r]].  List every move (source slot -> destination slot, or -> send buffer for a row that leaves
-  //    the shard) for move_kernel; the hole an arrival will fill is named in arr_above / arr_below.
-  for (int k = lane; k < ms; k += 64) {
+  //    old row[perm[r]].  List every move (source slot -> destination slot, or -> boundary message for a row that
+  //    leaves the shard) for move_kernel; the hole an arrival will fill is named in arr_above / arr_below.
+  int* gs = p.mv_src + (size_t)w * MVCAP;
+  int* gd = p.mv_dst + (size_t)w * MVCAP;
+  for (int j = lane; j < nl; j += 64) {
+    const int k = list[j];
     if (alive[k] != 1) continue;
     const int i = cand[k];
     const int rtop = (PTM_ALIVE_RUNG(i + 1) && alive[first[i + 1]] == 1) ? i : i + 1;
@@ -191,140 +225,194 @@ __global__ __launch_bounds__(64) void decide_kernel(const Decide p) {
       const int s = perm[r], to = inv[r];
       const int cr = (r - p.r0) * p.W + w;
       if (s >= p.r0 && s < r1) {                            // local -> local
-        const int j = atomicAdd(mvcnt, 1);
-        if (j < MVCAP) { mvsrc[j] = (s - p.r0) * p.W + w; mvdst[j] = cr; }
+        const int m = atomicAdd(&cnt[1], 1);
+        if (m < MVCAP) { gs[m] = (s - p.r0) * p.W + w; gd[m] = cr; }
       } else {
         (s >= r1 ? p.arr_above : p.arr_below)[w] = cr;       // the hole: an arrival from the adjacent shard lands here
       }
       if (to < p.r0 || to >= r1) {                           // rung r's old row leaves the shard
-        const int j = atomicAdd(mvcnt, 1);
-        if (j < MVCAP) { mvsrc[j] = cr; mvdst[j] = (to >= r1) ? -1 : -2; }
+        const int m = atomicAdd(&cnt[1], 1);
+        if (m < MVCAP) { gs[m] = cr; gd[m] = (to >= r1) ? -1 : -2; }
         if (!((to >= r1) ? p.send_up : p.send_down)) atomicOr(p.err, 1);
       }
     }
   }
   __syncthreads();
-  const int nmv = *mvcnt;
-  if (nmv > MVCAP) {
-    // rare overflow of the register path (more than MVCAP moved rows in one ladder and step): the permutation
-    // decomposes into disjoint closed cycles inside the shard and at most two open paths through its boundaries;
-    // one lane walks each in path order, so plain loads and stores are safe.  Slow, correct.
-    for (int k = lane; k < ms; k += 64) {
-      if (alive[k] != 1) continue;
-      const int i = cand[k];
-      const int rtop = (PTM_ALIVE_RUNG(i + 1) && alive[first[i + 1]] == 1) ? i : i + 1;
-      for (int r = i; r <= rtop; ++r) {
-        if (r < p.r0 || r >= r1 || perm[r] == r) continue;
-        const int to = inv[r];
-        const bool departs = to < p.r0 || to >= r1;
-        bool head = departs;
-        if (!departs) {                                     // closed cycle? then the lowest member leads
-          head = true;
-          int cc = perm[r], guard = 0;
-          while (cc != r) {
-            if (cc < p.r0 || cc >= r1 || cc < r || ++guard > Nt) { head = false; break; }
-            cc = perm[cc];
-          }
-        }
-        if (!head) continue;
-        double* X = p.x;
-        const int c0 = (r - p.r0) * p.W + w;
-        double tmp[34];                                      // the head's old row {x[0..DP), llike, lprior}, DP <= 32
-        for (int d = 0; d < DP; ++d) tmp[d] = X[(size_t)c0 * DP + d];
-        tmp[DP] = p.ll[c0];
-        tmp[DP + 1] = p.lp[c0];
-        if (departs) {
-          double* sb = (to >= r1) ? p.send_up : p.send_down;
-          if (!sb) continue;
-          for (int d = 0; d < DP + 2; ++d) sb[(size_t)w * (DP + 2) + d] = tmp[d];
-        }
-        int cur = r;
-        for (int guard = 0; guard <= Nt; ++guard) {
-          const int src = perm[cur];
-          const int cc = (cur - p.r0) * p.W + w;
-          if (src == r) {
-            for (int d = 0; d < DP; ++d) X[(size_t)cc * DP + d] = tmp[d];
-            p.ll[cc] = tmp[DP];
-            p.lp[cc] = tmp[DP + 1];
-            break;
-          }
-          if (src < p.r0 || src >= r1) break;                // the hole (named above)
-          const int cs = (src - p.r0) * p.W + w;
-          for (int d = 0; d < DP; ++d) X[(size_t)cc * DP + d] = X[(size_t)cs * DP + d];
-          p.ll[cc] = p.ll[cs];
-          p.lp[cc] = p.lp[cs];
-          cur = src;
-        }
-      }
-    }
-    if (lane == 0) p.mv_n[w] = 0;
+  const int nmv = cnt[1];
+  if (nmv <= MVCAP) {
+    if (lane == 0) p.mv_n[w] = nmv;   // move_kernel takes it from here
     return;
   }
-  // hand the list to move_kernel (a register-heavy gather/scatter that would cost this kernel its occupancy)
-  int* gs = p.mv_src + (size_t)w * MVCAP;
-  int* gd = p.mv_dst + (size_t)w * MVCAP;
-  for (int j = lane; j < nmv; j += 64) { gs[j] = mvsrc[j]; gd[j] = mvdst[j]; }
-  if (lane == 0) p.mv_n[w] = nmv;
+  // rare overflow of the register path (more than MVCAP moved rows in one ladder and step): the permutation
+  // decomposes into disjoint closed cycles inside the shard and at most two open paths through its boundaries;
+  // one lane walks each in path order, so plain loads and stores are safe.  Slow, correct.
+  const int DP = p.DP;
+  for (int j = lane; j < nl; j += 64) {
+    const int k = list[j];
+    if (alive[k] != 1) continue;
+    const int i = cand[k];
+    const int rtop = (PTM_ALIVE_RUNG(i + 1) && alive[first[i + 1]] == 1) ? i : i + 1;
+    for (int r = i; r <= rtop; ++r) {
+      if (r < p.r0 || r >= r1 || perm[r] == r) continue;
+      const int to = inv[r];
+      const bool departs = to < p.r0 || to >= r1;
+      bool head = departs;
+      if (!departs) {                                     // closed cycle? then the lowest member leads
+        head = true;
+        int cc = perm[r], guard = 0;
+        while (cc != r) {
+          if (cc < p.r0 || cc >= r1 || cc < r || ++guard > Nt) { head = false; break; }
+          cc = perm[cc];
+        }
+      }
+      if (!head) continue;
+      double* X = p.x;
+      const int c0 = (r - p.r0) * p.W + w;
+      double tmp[34];                                      // the head's old row {x[0..DP), llike, lprior}, DP <= 32
+      for (int d = 0; d < DP; ++d) tmp[d] = X[(size_t)c0 * DP + d];
+      tmp[DP] = p.ll[c0];
+      tmp[DP + 1] = p.lp[c0];
+      if (departs) {
+        double* sb = (to >= r1) ? p.send_up : p.send_down;
+        if (!sb) continue;
+        double* row = claim_row(sb, p.row_cap, DP + ROW_EXTRA, p.err);
+        if (row) {
+          for (int d = 0; d < DP + 2; ++d) row[d] = tmp[d];
+          row[DP + 2] = (double)w;
+          row[DP + 3] = 0.0;
+        }
+      }
+      int cur = r;
+      for (int guard = 0; guard <= Nt; ++guard) {
+        const int src = perm[cur];
+        const int cc = (cur - p.r0) * p.W + w;
+        if (src == r) {
+          for (int d = 0; d < DP; ++d) X[(size_t)cc * DP + d] = tmp[d];
+          p.ll[cc] = tmp[DP];
+          p.lp[cc] = tmp[DP + 1];
+          break;
+        }
+        if (src < p.r0 || src >= r1) break;                // the hole (named above)
+        const int cs = (src - p.r0) * p.W + w;
+        for (int d = 0; d < DP; ++d) X[(size_t)cc * DP + d] = X[(size_t)cs * DP + d];
+        p.ll[cc] = p.ll[cs];
+        p.lp[cc] = p.lp[cs];
+        cur = src;
+      }
+    }
+  }
+  if (lane == 0) p.mv_n[w] = 0;
 #undef PTM_ALIVE_RUNG
 }
 
 // ------------------------------------------------------------------------------------------------
 // applies one ladder's row moves IN PLACE, one wave per ladder: GATHER every moved row into registers (16 lanes x 16 B =
-// one 256-B row per quarter wave, four rows per load instruction, up to MVCAP rows), wait for all loads, then SCATTER.
+// one 256-B row per quarter wave, four rows per load instruction, up to MV rows), wait for all loads, then SCATTER.
 // With every read finished before the first write no ordering between the moves is needed (the moves of one ladder
 // form cycles over its own rows; other ladders' rows are never touched).
+// Two instances: MV = 64 (four ladders per 256-thread block, few registers: short lists, i.e. shards of a few hundred
+// rungs) and MV = MVCAP (one ladder per block).  Each handles the ladders whose list fits it and clears mv_n.
 // ------------------------------------------------------------------------------------------------
 struct Move {
-  int DP, W;
+  int DP, W, row_cap;
   double *x, *ll, *lp;
   double *send_up, *send_down;
   const int *mv_src, *mv_dst;
   int* mv_n;
+  int* err;
 };
 typedef double d2_t __attribute__((ext_vector_type(2)));  // (HIP's double2 struct does not stay in registers as an array)
 
-__global__ __launch_bounds__(64, 1) void move_kernel(const Move p) {
-  __shared__ int s_src[MVCAP], s_dst[MVCAP];
-  const int w = blockIdx.x, lane = threadIdx.x;
+template <int MV, int WPB>
+__global__ __launch_bounds__(64 * WPB, MV > 64 ? 1 : 4) void move_kernel(const Move p) {
+  __shared__ int s_all[WPB][2][MV];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int w = blockIdx.x * WPB + wv;
+  if (w >= p.W) return;
   const int nmv = p.mv_n[w];
-  if (nmv <= 0) return;
-  const int DP = p.DP;
-  // the list goes through LDS so that the row gathers below are not chained behind index loads from memory
-  for (int j = lane; j < MVCAP; j += 64) {
+  if (nmv <= 0 || nmv > MV) return;
+  int* s_src = s_all[wv][0];
+  int* s_dst = s_all[wv][1];   // >= 0 row slot, -3 nothing, <= -4: slot (-d-4)>>1 of the up (bit 0 clear) / down message
+  const int DP = p.DP, RD = DP + ROW_EXTRA;
+  // the list goes through LDS (this wave's private part: no block barrier) so that the row gathers below are not
+  // chained behind index loads from memory
+  for (int j = lane; j < MV; j += 64) {
     const bool in = j < nmv;
-    s_src[j] = in ? p.mv_src[(size_t)w * MVCAP + j] : 0;
-    s_dst[j] = in ? p.mv_dst[(size_t)w * MVCAP + j] : -3;
+    const int sv = in ? p.mv_src[(size_t)w * MVCAP + j] : 0;
+    int dv = in ? p.mv_dst[(size_t)w * MVCAP + j] : -3;
+    if (dv == -1 || dv == -2) {   // a row that leaves the shard: claim its slot in the boundary message
+      const int dir = dv == -1 ? 0 : 1;
+      const int slot = atomicAdd(reinterpret_cast<int*>(dir ? p.send_down : p.send_up), 1);
+      if (slot >= p.row_cap) { atomicOr(p.err, 4); dv = -3; }
+      else dv = -4 - (2 * slot + dir);
+    }
+    s_src[j] = sv;
+    s_dst[j] = dv;
   }
-  __syncthreads();
+  __builtin_amdgcn_wave_barrier();
   const int g = lane >> 4, sub = lane & 15;
   const bool act = 2 * sub < DP;          // DP/2 lanes of 16 carry a row (16 B each)
   const int col = act ? 2 * sub : 0;      // idle lanes re-read column 0 (harmless) so that no load is predicated
-  d2_t v[MVCAP / 4];
-  double sl[MVCAP / 64], sp[MVCAP / 64];
+  d2_t v[MV / 4];
+  double sl[MV / 64], sp[MV / 64];
 #pragma unroll
-  for (int q = 0; q < MVCAP / 4; ++q)     // unconditional loads: entries past the list read row 0 and are never stored
+  for (int q = 0; q < MV / 4; ++q)        // unconditional loads: entries past the list read row 0 and are never stored
     v[q] = *reinterpret_cast<const d2_t*>(p.x + (size_t)s_src[4 * q + g] * DP + col);
 #pragma unroll
-  for (int q = 0; q < MVCAP / 64; ++q) {
+  for (int q = 0; q < MV / 64; ++q) {
     sl[q] = p.ll[s_src[64 * q + lane]];
     sp[q] = p.lp[s_src[64 * q + lane]];
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every gather has landed before the first scatter
 #pragma unroll
-  for (int q = 0; q < MVCAP / 4; ++q) {
+  for (int q = 0; q < MV / 4; ++q) {
     const int d = s_dst[4 * q + g];
     if (d != -3 && act) {
-      double* dstp = d >= 0 ? p.x + (size_t)d * DP : (d == -1 ? p.send_up : p.send_down) + (size_t)w * (DP + 2);
+      double* dstp;
+      if (d >= 0) dstp = p.x + (size_t)d * DP;
+      else { const int e = -d - 4; dstp = ((e & 1) ? p.send_down : p.send_up) + MSG_HDR + (size_t)(e >> 1) * RD; }
       *reinterpret_cast<d2_t*>(dstp + col) = v[q];
     }
   }
 #pragma unroll
-  for (int q = 0; q < MVCAP / 64; ++q) {
+  for (int q = 0; q < MV / 64; ++q) {
     const int d = s_dst[64 * q + lane];
     if (d >= 0) { p.ll[d] = sl[q]; p.lp[d] = sp[q]; }
-    else if (d != -3) { double* sb = (d == -1 ? p.send_up : p.send_down) + (size_t)w * (DP + 2); sb[DP] = sl[q]; sb[DP + 1] = sp[q]; }
+    else if (d != -3) {
+      const int e = -d - 4;
+      double* row = ((e & 1) ? p.send_down : p.send_up) + MSG_HDR + (size_t)(e >> 1) * RD;
+      row[DP] = sl[q]; row[DP + 1] = sp[q]; row[DP + 2] = (double)w; row[DP + 3] = 0.0;
+    }
   }
   if (lane == 0) p.mv_n[w] = 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// lands the rows of the two boundary messages in the holes decide_kernel named (arr_below / arr_above); 16 lanes per
+// row.  blockIdx.y = 0: message from below, 1: from above.
+// ------------------------------------------------------------------------------------------------
+struct Install {
+  int DP, W, row_cap;
+  double *x, *ll, *lp;
+  const double *recv_below, *recv_above;
+  int *arr_below, *arr_above;
+  int* err;
+};
+__global__ __launch_bounds__(256) void install_kernel(const Install p) {
+  const double* msg = blockIdx.y ? p.recv_above : p.recv_below;
+  if (!msg) return;
+  int* arr = blockIdx.y ? p.arr_above : p.arr_below;
+  int n = *reinterpret_cast<const int*>(msg);
+  if (n > p.row_cap) n = p.row_cap;         // (the sender has flagged the overflow)
+  const int j = blockIdx.x * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
+  if (j >= n) return;
+  const int DP = p.DP, RD = DP + ROW_EXTRA;
+  const double* row = msg + MSG_HDR + (size_t)j * RD;
+  const int w = (int)row[DP + 2];
+  const int a = (w >= 0 && w < p.W) ? arr[w] : -1;
+  if (a < 0) { atomicOr(p.err, 8); return; }  // a row nobody expects: the two shards disagree about the step
+  if (2 * sub < DP) *reinterpret_cast<d2_t*>(p.x + (size_t)a * DP + 2 * sub) = *reinterpret_cast<const d2_t*>(row + 2 * sub);
+  if (sub == 0) { p.ll[a] = row[DP]; p.lp[a] = row[DP + 1]; }
 }
 
 // verification hooks

@@ -49,7 +49,8 @@ struct ptm_engine {
   unsigned int* nhist = nullptr;
   long long *swap_try = nullptr, *swap_acc = nullptr;
   unsigned char* touch = nullptr;
-  int *last_pairs = nullptr, *last_acc = nullptr;
+  int* swap_log = nullptr;   // [W][ms] candidate log of the last step
+  int row_cap = 0;           // row slots per boundary message
   // device problem description
   int *blo = nullptr, *bhi = nullptr, *ptype = nullptr;
   double *bmin = nullptr, *bmax = nullptr, *plo = nullptr, *phi = nullptr, *pcoef = nullptr;
@@ -132,6 +133,15 @@ extern "C" int ptm_engine_create(const ptm_config* cfg, ptm_engine** out) {
   e->D = cfg->dim; e->DP = round_dp(cfg->dim); e->Nt = cfg->n_rungs; e->r0 = cfg->rung_begin; e->nloc = cfg->rung_count;
   e->W = cfg->n_walkers; e->Nc = e->nloc * e->W;
   e->ms = (int)(1 + 2 * cfg->swap_rate * cfg->n_rungs);                      // chain.cc:1192
+  {
+    // Rows that cross one shard boundary in one direction per step: at most one per walker, and a walker's boundary pair
+    // is a candidate with probability <= swap_rate (maxswapsperstep * thresh / (Ntemps-1), chain.cc:1413-1416).
+    // Default capacity: that binomial's mean + 8 sigma + 64, or every walker if that is less.
+    const double pr = cfg->swap_rate < 1 ? (cfg->swap_rate > 0 ? cfg->swap_rate : 0) : 1;
+    const double want = e->W * pr + 8 * std::sqrt(e->W * pr) + 64;
+    e->row_cap = cfg->exchange_row_capacity > 0 ? cfg->exchange_row_capacity : (want < e->W ? (int)want : e->W);
+    if (e->row_cap > e->W) e->row_cap = e->W;
+  }
   e->thresh = (e->Nt - 1) * cfg->swap_rate / e->ms;                          // chain.cc:1413
   if (cfg->device >= 0) { HIPCHK(hipSetDevice(cfg->device)); e->device = cfg->device; } else HIPCHK(hipGetDevice(&e->device));
   if (cfg->stream) e->stream = (hipStream_t)cfg->stream;
@@ -146,13 +156,11 @@ extern "C" int ptm_engine_create(const ptm_config* cfg, ptm_engine** out) {
       (rc = dalloc(&e->err, 4)))
     return rc;
   const size_t np = (size_t)e->W * (e->Nt > 1 ? e->Nt - 1 : 1);
-  if ((rc = dalloc(&e->swap_try, np)) || (rc = dalloc(&e->swap_acc, np)) || (rc = dalloc(&e->last_pairs, (size_t)e->W * e->ms)) ||
-      (rc = dalloc(&e->last_acc, (size_t)e->W * e->ms)))
+  if ((rc = dalloc(&e->swap_try, np)) || (rc = dalloc(&e->swap_acc, np)) || (rc = dalloc(&e->swap_log, (size_t)e->W * e->ms)))
     return rc;
   HIPCHK(hipMemsetAsync(e->swap_try, 0, np * 8, e->stream));
   HIPCHK(hipMemsetAsync(e->swap_acc, 0, np * 8, e->stream));
-  HIPCHK(hipMemsetAsync(e->last_pairs, 0xFF, (size_t)e->W * e->ms * 4, e->stream));
-  HIPCHK(hipMemsetAsync(e->last_acc, 0, (size_t)e->W * e->ms * 4, e->stream));
+  HIPCHK(hipMemsetAsync(e->swap_log, 0xFE, (size_t)e->W * e->ms * 4, e->stream));  // 0xFEFEFEFE < 0: "none"
   HIPCHK(hipMemsetAsync(e->err, 0, 16, e->stream));
   HIPCHK(hipMemsetAsync(e->mv_n, 0, (size_t)e->W * 4, e->stream));
   if ((rc = dalloc(&e->blo, D)) || (rc = dalloc(&e->bhi, D)) || (rc = dalloc(&e->ptype, D)) || (rc = dalloc(&e->bmin, D)) ||
@@ -182,7 +190,7 @@ extern "C" int ptm_engine_destroy(ptm_engine* e) {
   if (!e) return PTM_OK;
   (void)hipStreamSynchronize(e->stream);
   void* ptrs[] = {e->x, e->ll, e->lp, e->ntries, e->naccept, e->last_type, e->arr_below, e->arr_above, e->mv_src, e->mv_dst, e->mv_n,
-                  e->err, e->nhist, e->swap_try, e->swap_acc, e->touch, e->last_pairs, e->last_acc, e->blo,
+                  e->err, e->nhist, e->swap_try, e->swap_acc, e->touch, e->swap_log, e->blo,
                   e->bhi, e->ptype, e->bmin, e->bmax, e->plo, e->phi, e->pcoef, e->P2, e->mean, e->beta, e->prop, e->prop_dense, e->onedfrac, e->xprop, e->lprior_new, e->llike_new, e->gate};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -402,7 +410,7 @@ static Dev make_dev(ptm_engine* e) {
   p.beta = e->beta; p.prop = e->prop; p.prop_dense = e->prop_dense; p.onedfrac = e->onedfrac; p.prop_stride = e->prop_stride; p.any_oned = e->any_oned;
   p.x = e->x; p.ll = e->ll; p.lp = e->lp;
   p.ntries = e->ntries; p.naccept = e->naccept; p.last_type = e->last_type; p.nhist = e->nhist;
-  p.touch = e->touch; p.arr_below = e->arr_below; p.arr_above = e->arr_above; p.err = e->err;
+  p.touch = e->touch; p.err = e->err;
   return p;
 }
 
@@ -414,9 +422,8 @@ static SweepSel sweep_sel(const ptm_engine* e) {
   return s;
 }
 
-static int launch_sweep(ptm_engine* e, const double* recv_below, const double* recv_above) {
+static int launch_sweep(ptm_engine* e) {
   Dev p = make_dev(e);
-  p.recv_below = recv_below; p.recv_above = recv_above;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   if (e->cfg.time_kernels) {
     if (e->kev_used + 2 > e->kev.size()) {
@@ -464,10 +471,10 @@ static int launch_sweep(ptm_engine* e, const double* recv_below, const double* r
   return PTM_OK;
 }
 
-static size_t decide_lds_bytes(int Nt, int ms) {
+static size_t decide_lds_bytes(int Nt, int ms, int WN) {
   // mirrors the carve at the top of decide_kernel
-  return (size_t)Nt * 8 + (size_t)ms * 8 + (size_t)((Nt + 1) & ~1) * 4 + (size_t)((ms + 1) & ~1) * 4 + (size_t)MVCAP * 8 + 8 +
-         (size_t)((Nt + 3) & ~3) * 2 * 2 + (size_t)((ms + 7) & ~7) * 2 + 32;
+  return (size_t)WN * 8 + (size_t)((Nt + 1) & ~1) * 4 + (size_t)((ms + 1) & ~1) * 4 * 2 + 8 + (size_t)((WN + 3) & ~3) * 2 * 2 +
+         (size_t)((ms + 3) & ~3) * 2 + (size_t)((ms + 7) & ~7) * 2 + 32;
 }
 
 static int launch_decide(ptm_engine* e, const double* ll_below, const double* ll_above, int H, double* send_up, double* send_down) {
@@ -477,18 +484,38 @@ static int launch_decide(ptm_engine* e, const double* ll_below, const double* ll
   p.seed = e->cfg.seed; p.step = e->step; p.thresh = e->thresh;
   p.beta = e->beta; p.ll_below = ll_below; p.ll_above = ll_above; p.H = ll_above ? H : 0; p.x = e->x; p.ll = e->ll; p.lp = e->lp;
   p.touch = e->touch; p.arr_below = e->arr_below; p.arr_above = e->arr_above; p.swap_try = e->swap_try; p.swap_acc = e->swap_acc;
-  p.last_pairs = e->last_pairs; p.last_acc = e->last_acc; p.send_up = send_up; p.send_down = send_down; p.err = e->err;
+  p.swap_log = e->swap_log; p.send_up = send_up; p.send_down = send_down; p.row_cap = e->row_cap; p.err = e->err;
   p.mv_src = e->mv_src; p.mv_dst = e->mv_dst; p.mv_n = e->mv_n;
-  const size_t lds = decide_lds_bytes(e->Nt, e->ms);
+  const int WN = e->nloc + (ll_below ? 1 : 0) + p.H;
+  const size_t lds = decide_lds_bytes(e->Nt, e->ms, WN);
   if (lds > 160 * 1024) return fail(PTM_ERR_UNSUPPORTED, "ladder too long for the LDS-resident exchange kernel (%zu B)", lds);
   if (lds > 64 * 1024)
     HIPCHK(hipFuncSetAttribute((const void*)decide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  // the boundary messages start empty (the row count lives in their first word)
+  if (send_up) HIPCHK(hipMemsetAsync(send_up, 0, 16, e->stream));
+  if (send_down) HIPCHK(hipMemsetAsync(send_down, 0, 16, e->stream));
   hipLaunchKernelGGL(decide_kernel, dim3(e->W), dim3(64), lds, e->stream, p);
   HIPCHK(hipGetLastError());
   Move m;
-  m.DP = e->DP; m.W = e->W; m.x = e->x; m.ll = e->ll; m.lp = e->lp; m.send_up = send_up; m.send_down = send_down;
-  m.mv_src = e->mv_src; m.mv_dst = e->mv_dst; m.mv_n = e->mv_n;
-  hipLaunchKernelGGL(move_kernel, dim3(e->W), dim3(64), 0, e->stream, m);
+  m.DP = e->DP; m.W = e->W; m.row_cap = e->row_cap; m.x = e->x; m.ll = e->ll; m.lp = e->lp; m.send_up = send_up; m.send_down = send_down;
+  m.mv_src = e->mv_src; m.mv_dst = e->mv_dst; m.mv_n = e->mv_n; m.err = e->err;
+  // a ladder moves about 0.17 rows per local rung and step at the default swap rate: short shards take the light kernel
+  // first; whatever does not fit it is left for the MVCAP-row kernel
+  if (e->nloc <= 256) {
+    hipLaunchKernelGGL((move_kernel<64, 4>), dim3((e->W + 3) / 4), dim3(256), 0, e->stream, m);
+    HIPCHK(hipGetLastError());
+  }
+  hipLaunchKernelGGL((move_kernel<MVCAP, 1>), dim3(e->W), dim3(64), 0, e->stream, m);
+  HIPCHK(hipGetLastError());
+  return PTM_OK;
+}
+
+static int launch_install(ptm_engine* e, const double* recv_below, const double* recv_above) {
+  if (!recv_below && !recv_above) return PTM_OK;
+  Install q;
+  q.DP = e->DP; q.W = e->W; q.row_cap = e->row_cap; q.x = e->x; q.ll = e->ll; q.lp = e->lp;
+  q.recv_below = recv_below; q.recv_above = recv_above; q.arr_below = e->arr_below; q.arr_above = e->arr_above; q.err = e->err;
+  hipLaunchKernelGGL(install_kernel, dim3((e->row_cap + 15) / 16, 2), dim3(256), 0, e->stream, q);
   HIPCHK(hipGetLastError());
   return PTM_OK;
 }
@@ -631,7 +658,7 @@ extern "C" int ptm_sweep(ptm_engine* e, int n) {
   int rc = ready(e);
   if (rc) return rc;
   for (int k = 0; k < n; ++k)
-    if ((rc = launch_sweep(e, nullptr, nullptr))) return rc;
+    if ((rc = launch_sweep(e))) return rc;
   return PTM_OK;
 }
 
@@ -641,7 +668,7 @@ extern "C" int ptm_step(ptm_engine* e, int n) {
   if (e->nloc != e->Nt) return fail(PTM_ERR_INVALID, "ptm_step needs the whole ladder on this engine; sharded engines use ptm_exchange_*");
   for (int k = 0; k < n; ++k) {
     if (e->Nt > 1 && (rc = launch_decide(e, nullptr, nullptr, 0, nullptr, nullptr))) return rc;
-    if ((rc = launch_sweep(e, nullptr, nullptr))) return rc;
+    if ((rc = launch_sweep(e))) return rc;
   }
   return PTM_OK;
 }
@@ -653,7 +680,9 @@ extern "C" int ptm_sync(ptm_engine* e) {
   HIPCHK(hipMemcpy(&flag, e->err, 4, hipMemcpyDeviceToHost));
   if (flag & 1) return fail(PTM_ERR_FAR_MOVE, "a state crossed more than one shard boundary in one step (neighbour exchange mode)");
   if (flag & 2) return fail(PTM_ERR_FAR_MOVE, "an exchange chain reached past the llike halo: rerun with a deeper halo");
-  if (flag & 4) return fail(PTM_ERR_UNSUPPORTED, "more than 256 rows of one ladder moved in one step (swap_rate too high for this build)");
+  if (flag & 4) return fail(PTM_ERR_FAR_MOVE, "a boundary message overflowed: more rows crossed a shard boundary in one step than "
+                            "ptm_config.exchange_row_capacity slots (%d)", e->row_cap);
+  if (flag & 8) return fail(PTM_ERR_FAR_MOVE, "a boundary message carried a row this shard did not expect (neighbour shards out of step?)");
   return PTM_OK;
 }
 
@@ -701,12 +730,16 @@ extern "C" int ptm_dev_copy(void* dst, const void* src, size_t bytes) {
   return PTM_OK;
 }
 
-extern "C" int ptm_exchange_buffer_doubles(ptm_engine* e) { return e ? e->W * (e->DP + 2) : 0; }
+extern "C" int ptm_exchange_buffer_doubles(ptm_engine* e) { return e ? MSG_HDR + e->row_cap * (e->DP + ROW_EXTRA) : 0; }
+extern "C" int ptm_exchange_row_capacity(ptm_engine* e) { return e ? e->row_cap : 0; }
 
 extern "C" int ptm_exchange_finish_and_sweep(ptm_engine* e, const void* recv_below, const void* recv_above) {
   int rc = ready(e);
   if (rc) return rc;
-  return launch_sweep(e, (const double*)recv_below, (const double*)recv_above);
+  const bool first = e->r0 == 0, last = e->r0 + e->nloc == e->Nt;
+  if ((!first && !recv_below) || (!last && !recv_above)) return fail(PTM_ERR_INVALID, "missing boundary message from a neighbour shard");
+  if ((rc = launch_install(e, first ? nullptr : (const double*)recv_below, last ? nullptr : (const double*)recv_above))) return rc;
+  return launch_sweep(e);
 }
 
 // ---- read-back ------------------------------------------------------------------------------------------------------
@@ -770,8 +803,13 @@ extern "C" int ptm_get_last_swaps(ptm_engine* e, int32_t* pairs, int32_t* accept
   if (!e) return fail(PTM_ERR_INVALID, "null engine");
   const size_t n = (size_t)e->W * e->ms;
   HIPCHK(hipStreamSynchronize(e->stream));
-  if (pairs) HIPCHK(hipMemcpy(pairs, e->last_pairs, n * 4, hipMemcpyDeviceToHost));
-  if (accepted) HIPCHK(hipMemcpy(accepted, e->last_acc, n * 4, hipMemcpyDeviceToHost));
+  std::vector<int32_t> log(n);
+  HIPCHK(hipMemcpy(log.data(), e->swap_log, n * 4, hipMemcpyDeviceToHost));
+  for (size_t i = 0; i < n; ++i) {
+    const int32_t v = log[i];
+    if (pairs) pairs[i] = v < 0 ? (v == -3 ? -3 : -2) : (v & 0x3fffffff);
+    if (accepted) accepted[i] = (v >= 0 && (v & 0x40000000)) ? 1 : 0;
+  }
   return PTM_OK;
 }
 

@@ -85,8 +85,6 @@ struct Dev {
   int *ntries, *naccept, *last_type;
   unsigned int* nhist;
   unsigned char* touch;
-  int *arr_below, *arr_above;             // [W] landing slot of the row arriving across the lower / upper boundary, or -1
-  const double *recv_below, *recv_above;  // [W][DP+2] rows {x, llike, lprior} that crossed the shard boundary this step
   int* err;
   // host-callback likelihood (bayes_likelihood::register_evaluate_log surface): the sweep is split around the host
   //   mode 0: fused (device target)   mode 1: propose only -> xprop/lprior_new/gate   mode 2: accept with llike_new
@@ -370,31 +368,6 @@ __global__ __launch_bounds__(256, PTM_SWEEP_WAVES) void sweep_kernel(const Dev p
     p.nhist[c] += (unsigned int)tc;  // one add_state per attempt (chain.cc:1487-1490,1531-1534,1554-1557)
     p.touch[c] = 0;                  // (the exchange kernel already moved the rows)
   }
-  // rows arriving from the adjacent shards are installed by the boundary rungs' lanes (one row per walker at most);
-  // the landing slot's own lane is a touched lane and neither reads nor writes its row this step
-  if (!propose_only && p.recv_above && rl == p.nloc - 1) {
-    const int a = p.arr_above[w];
-    if (a >= 0) {
-      const double* r = p.recv_above + (size_t)w * (DP + 2);
-#pragma unroll
-      for (int d = 0; d < DP; ++d) p.x[(size_t)a * DP + d] = r[d];
-      p.ll[a] = r[DP];
-      p.lp[a] = r[DP + 1];
-      p.arr_above[w] = -1;
-    }
-  }
-  if (!propose_only && p.recv_below && rl == 0) {
-    const int a = p.arr_below[w];
-    if (a >= 0) {
-      const double* r = p.recv_below + (size_t)w * (DP + 2);
-#pragma unroll
-      for (int d = 0; d < DP; ++d) p.x[(size_t)a * DP + d] = r[d];
-      p.ll[a] = r[DP];
-      p.lp[a] = r[DP + 1];
-      p.arr_below[w] = -1;
-    }
-  }
-
   // ---- MH_chain::step for the untouched rungs; touched lanes idle through the draw loops
   const uint32_t stream = (uint32_t)w * (uint32_t)p.Nt + (uint32_t)rg;
   const u32x4 o0 = draw_block(p.seed, TAG_MH, stream, p.step, 0);

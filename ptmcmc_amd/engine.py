@@ -24,7 +24,7 @@ EXPORTS = [
     "ptm_last_error", "ptm_abi_version", "ptm_device_count", "ptm_engine_create", "ptm_engine_destroy",
     "ptm_set_bounds", "ptm_set_prior", "ptm_set_target_gaussian", "ptm_set_target_callback", "ptm_set_ladder",
     "ptm_set_proposals", "ptm_set_states", "ptm_init_from_prior", "ptm_sweep", "ptm_step", "ptm_sync",
-    "ptm_copy_llike", "ptm_llike_device_ptr", "ptm_exchange_decide", "ptm_exchange_finish_and_sweep", "ptm_exchange_buffer_doubles", "ptm_get_states",
+    "ptm_copy_llike", "ptm_llike_device_ptr", "ptm_exchange_decide", "ptm_exchange_finish_and_sweep", "ptm_exchange_buffer_doubles", "ptm_exchange_row_capacity", "ptm_get_states",
     "ptm_get_array", "ptm_get_swap_counts", "ptm_get_last_swaps", "ptm_max_swaps_per_step", "ptm_step_count",
     "ptm_timer_start", "ptm_timer_stop", "ptm_get_kernel_times", "ptm_sweep_kernel_name", "ptm_debug_eval",
     "ptm_debug_philox", "ptm_debug_boxmuller", "ptm_debug_sqrt_scan", "ptm_debug_evaluate",
@@ -36,7 +36,7 @@ class PtmConfig(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("dim", C.c_int32), ("n_rungs", C.c_int32), ("rung_begin", C.c_int32),
                 ("rung_count", C.c_int32), ("n_walkers", C.c_int32), ("seed", C.c_uint64), ("swap_rate", C.c_double),
                 ("add_every_n", C.c_int32), ("min_prior", C.c_double), ("device", C.c_int32), ("stream", C.c_void_p),
-                ("time_kernels", C.c_int32), ("swap_log_steps", C.c_int32)]
+                ("time_kernels", C.c_int32), ("swap_log_steps", C.c_int32), ("exchange_row_capacity", C.c_int32)]
 
 
 class PtmError(RuntimeError):
@@ -97,6 +97,7 @@ def load():
     L.ptm_debug_philox.argtypes = [C.c_int, C.c_uint64, C.c_int, C.c_uint32, C.c_uint64, C.c_uint32, _u32p]
     L.ptm_debug_boxmuller.argtypes = [C.c_int, _u32p, _u32p, _dp, _dp, C.c_int]
     L.ptm_exchange_buffer_doubles.argtypes = [C.c_void_p]
+    L.ptm_exchange_row_capacity.argtypes = [C.c_void_p]
     L.ptm_debug_sqrt_scan.argtypes = [C.c_int, C.POINTER(C.c_uint64)]
     L.ptm_debug_evaluate.argtypes = [C.c_void_p, _dp, C.c_int, _i32p, _dp, _dp, _dp]
     _lib = L
@@ -186,7 +187,7 @@ class Engine:
     """One GPU shard of a parallel-tempering ladder: rungs [rung_begin, rung_begin+rung_count) x W walkers."""
 
     def __init__(self, dim, n_rungs, n_walkers=1, seed=0x5EED0001, swap_rate=0.1, add_every_n=1, min_prior=-30.0,
-                 rung_begin=0, rung_count=None, device=-1, stream=None, time_kernels=False):
+                 rung_begin=0, rung_count=None, device=-1, stream=None, time_kernels=False, exchange_row_capacity=0):
         L = load()
         cfg = PtmConfig()
         cfg.struct_size = C.sizeof(PtmConfig)
@@ -197,6 +198,7 @@ class Engine:
         cfg.stream = stream
         cfg.time_kernels = 1 if time_kernels else 0
         cfg.swap_log_steps = 0
+        cfg.exchange_row_capacity = exchange_row_capacity
         h = C.c_void_p()
         _chk(L.ptm_engine_create(C.byref(cfg), C.byref(h)))
         self.h, self.L = h, L
@@ -288,6 +290,10 @@ class Engine:
     @property
     def exchange_buffer_doubles(self):
         return self.L.ptm_exchange_buffer_doubles(self.h)
+
+    @property
+    def exchange_row_capacity(self):
+        return self.L.ptm_exchange_row_capacity(self.h)
 
     def exchange_finish_and_sweep(self, recv_below_dev, recv_above_dev):
         _chk(self.L.ptm_exchange_finish_and_sweep(self.h, recv_below_dev, recv_above_dev))

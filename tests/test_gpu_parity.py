@@ -286,7 +286,7 @@ def test_sharded_engines_match_single_engine(D, Nt, W, G, halo, sr):
         try:
             shard_sim.step(lads, copy, 1)
         except E.PtmError as ex:         # a chain longer than the halo / a row through a whole shard: must be LOUD
-            assert "halo" in str(ex) or "crossed" in str(ex)
+            assert "halo" in str(ex) or "crossed" in str(ex)   # (never "overflowed": capacity = W at these sizes)
             far = True
             break
         xs = np.concatenate([e.states() for e in shards])
@@ -302,6 +302,42 @@ def test_sharded_engines_match_single_engine(D, Nt, W, G, halo, sr):
         assert min(e.nloc for e in shards) <= 2   # only tiny shards may trip the halo / far-move guard in 40 steps
     for e in shards + [ref]:
         e.close()
+
+
+def test_boundary_message_overflow_is_loud():
+    """A boundary message with fewer row slots than rows crossing must raise at the next sync, never drop rows silently;
+    with the automatic capacity the same run is clean."""
+    import shard_sim
+    from ptmcmc_amd.parallel import shard_bounds
+    from ptmcmc_amd.problems import GaussianProblem
+    D, Nt, W, G, sr = 8, 8, 256, 2, 0.5
+    pr = GaussianProblem(D, Nt, 1e3)
+    for cap, loud in ((1, True), (0, False)):
+        shards = []
+        for g in range(G):
+            r0, n = shard_bounds(Nt, G, g)
+            e = E.Engine(D, Nt, W, swap_rate=sr, rung_begin=r0, rung_count=n, exchange_row_capacity=cap)
+            pr.configure(e, E.PROP_LOWER)
+            e.init_from_prior()
+            shards.append(e)
+        assert shards[0].exchange_row_capacity == (1 if cap else W)    # W*0.5 + 8 sigma + 64 > W here
+        assert shards[0].exchange_buffer_doubles == 2 + shards[0].exchange_row_capacity * (D + 4)
+        lads = shard_sim.build([_DevShard(e) for e in shards], halo=4)
+        copy = lambda dst, src: dst.copy_from(src.ptr)
+        if loud:
+            with pytest.raises(E.PtmError, match="overflowed"):
+                shard_sim.step(lads, copy, 5)
+        else:
+            shard_sim.step(lads, copy, 5)
+        for e in shards:
+            e.close()
+
+
+def test_default_row_capacity_tracks_swap_rate():
+    e = E.Engine(4, 8, 100000, swap_rate=0.1, rung_begin=0, rung_count=4)
+    want = int(100000 * 0.1 + 8 * np.sqrt(100000 * 0.1) + 64)
+    assert e.exchange_row_capacity == want
+    e.close()
 
 
 def test_host_callback_likelihood_C5_exampleLISA():
