@@ -181,8 +181,8 @@ enum { PTM_FN_LOG = 0, PTM_FN_EXP = 1, PTM_FN_SIN_0_PI = 2, PTM_FN_COS_HPI = 3, 
 int ptm_debug_eval(int device, int fn, const double* a, const double* b, double* out, int n);
 int ptm_debug_philox(int device, uint64_t seed, int tag, uint32_t stream, uint64_t step, uint32_t block, uint32_t out[4]);
 int ptm_debug_boxmuller(int device, const uint32_t* k1, const uint32_t* k2, double* z0, double* z1, int n);
-/* exhaustive scan of all 2^32 Box-Muller radius arguments: how many are NOT already correctly rounded by the
- * compiler's sqrt expansion (i.e. need the engine's fix-up step) */
+/* exhaustive scan of all 2^32 Box-Muller radius arguments a = -2 ln((k+.5)/2^32): for how many is the hot path's
+ * unscaled Newton square root NOT the correctly rounded one (or a outside its domain).  Must be 0. */
 int ptm_debug_sqrt_scan(int device, uint64_t* mismatches);
 /* evaluate lprior / llike of arbitrary states with the engine's problem description: X[n][D] */
 /* device-memory helpers for callers without a GPU array library (tests, tools) */

@@ -158,11 +158,39 @@ double ptmo_cos_hpi(double x) {
   return sin_k((HPI_HI - x) + HPI_LO);
 }
 
-/* Box-Muller on two 32-bit draws.  u1 = (k1+.5)/2^32, theta = 2 pi (k2+.5)/2^32 reduced exactly
+/* -2 ln(u) for u = (k+0.5)/2^32, the Box-Muller radius argument: table of {fl(1/c_i), A_i} over the top 8 mantissa
+ * bits (oracle/ptm_tables.inc, generated DATA, re-derived by tests/test_tables.py) + degree-6 log1p polynomial:
+ *   x = k+0.5 = 2^E m;  t = fma(m, 1/c_i, -1);  q = 1 - (2/3)t + (1/2)t^2 - (2/5)t^3 + (1/3)t^4;
+ *   -2 ln u = [(E-32+adj)(-2 ln2_hi) + A_i] + [(E-32+adj)(-2 ln2_lo) + (t^2 q - 2t)],  adj = [i >= SPLIT]. */
+#include "ptm_tables.inc"
+static const double bm_table[512] = {PTM_BMTAB_VALUES};
+double ptmo_bm_neg2log(uint32_t k) {
+  const double M2LN2_HI = -2.0 * 6.93147180369123816490e-01, M2LN2_LO = -2.0 * 1.90821492927058770002e-10;
+  double x = (double)k + 0.5;
+  uint64_t b;
+  memcpy(&b, &x, 8);
+  uint32_t hi = (uint32_t)(b >> 32);
+  uint32_t idx = (hi >> 12) & 255u;
+  int e = (int)(hi >> 20) - (1023 + 32) + (idx >= PTM_BMTAB_SPLIT ? 1 : 0);
+  uint64_t mb = (b & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull;
+  double m;
+  memcpy(&m, &mb, 8);
+  double rc = bm_table[2 * idx], A = bm_table[2 * idx + 1];
+  double t = fma(m, rc, -1.0);
+  double q = 1.0 / 3.0;
+  q = fma(q, t, -0.4);
+  q = fma(q, t, 0.5);
+  q = fma(q, t, -2.0 / 3.0);
+  q = fma(q, t, 1.0);
+  double l = fma(t * t, q, -2.0 * t);
+  double dk = (double)e;
+  return fma(dk, M2LN2_HI, A) + fma(dk, M2LN2_LO, l);
+}
+
+/* Box-Muller on two 32-bit draws.  r = sqrt(-2 ln u1) (IEEE sqrt), theta = 2 pi (k2+.5)/2^32 reduced exactly
  * (integer arithmetic) to an octant and an angle in (0, pi/4). */
 void ptmo_boxmuller(uint32_t k1, uint32_t k2, double* z0, double* z1) {
-  double u1 = ((double)k1 + 0.5) * (1.0 / 4294967296.0);
-  double r = sqrt(-2.0 * ptmo_log(u1));
+  double r = sqrt(ptmo_bm_neg2log(k1));
   uint32_t q = k2 >> 29, m = k2 & 0x1FFFFFFFu;
   if (q & 1u) m ^= 0x1FFFFFFFu;
   double phi = ((double)m + 0.5) * 1.4629180792671596e-09; /* (pi/4) * 2^-29 = 0x1.921fb54442d18p-30 */

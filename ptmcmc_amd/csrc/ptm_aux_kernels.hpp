@@ -438,19 +438,22 @@ __global__ void debug_philox_kernel(uint64_t seed, int tag, uint32_t stream, uin
 __global__ void debug_boxmuller_kernel(const uint32_t* k1, const uint32_t* k2, double* z0, double* z1, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  boxmuller(k1[i], k2[i], z0[i], z1[i]);
+  boxmuller(k1[i], k2[i], (const double*)BM_TABLE, z0[i], z1[i]);
 }
-// exhaustive scan over all 2^32 first arguments of Box-Muller: counts the k for which the raw sqrt expansion
-// differs from the corrected one (i.e. is not already correctly rounded) on r = sqrt(-2 log((k+.5)/2^32))
+// exhaustive scan over all 2^32 first arguments of Box-Muller: counts the k for which the unscaled Newton sqrt of
+// the hot path (bm_sqrt) differs from the correctly rounded dsqrt() on a = -2 ln((k+.5)/2^32), and the k with a
+// outside (0, 64) (bm_sqrt's domain)
 __global__ void debug_sqrt_scan_kernel(unsigned long long* mismatches) {
   const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t stride = gridDim.x * blockDim.x;
-  unsigned long long bad = 0;
+  unsigned long long bad = 0, out = 0;
   for (uint64_t k = tid; k < (1ull << 32); k += stride) {
-    const double a = -2.0 * dlog_u01((uint32_t)k);
-    if (__builtin_sqrt(a) != dsqrt(a)) bad++;
+    const double a = bm_neg2log((uint32_t)k, (const double*)BM_TABLE);
+    if (bm_sqrt(a) != dsqrt(a)) bad++;
+    if (!(a > 0.0 && a < 64.0)) out++;
   }
   if (bad) atomicAdd(mismatches, bad);
+  if (out) atomicAdd(mismatches + 1, out);
 }
 
 }  // namespace ptm

@@ -182,10 +182,63 @@ __device__ __forceinline__ double dsqrt(double a) {
   return (ok && move) ? gn : g;
 }
 
+// ------------------------------------------------------------------------------------------------
 // Box-Muller on two 32-bit draws; replaces newran's table-rejection Normal (newran2.cxx:164-217)
 // behind gaussian_dist_product::drawSample (probability_function.cc:37-47).
-__device__ __forceinline__ void boxmuller(uint32_t k1, uint32_t k2, double& z0, double& z1) {
-  const double r = dsqrt(-2.0 * dlog_u01(k1));
+//
+// The radius is the hot half: 32 normals per chain and step.  -2 ln(u) for u = (k+0.5)/2^32 comes from a 256-entry
+// table of {fl(1/c_i), A_i} (tools/gen_tables.py) and a degree-6 log1p polynomial -- no division:
+//     x = k + 0.5 = 2^E m,  i = top 8 mantissa bits,  t = fma(m, 1/c_i, -1)  (|t| <= 2^-9, exact for i = 255),
+//     -2 ln(u) = [(E-32+adj_i)(-2 ln2_hi) + A_i] + [(E-32+adj_i)(-2 ln2_lo) + (t^2 q(t) - 2t)],
+//     q(t) = 1 - (2/3)t + (1/2)t^2 - (2/5)t^3 + (1/3)t^4         (truncation < 2^-56 relative).
+// Its square root needs none of the generic sqrt's range scaling (the argument lies in [2^-32, 46]) and is the
+// v_rsq_f64 seed + one coupled Newton step + two residual corrections; tests/test_gpu_parity.py scans all 2^32
+// arguments on the GPU to prove it equal to the correctly rounded dsqrt() -- the CPU checker calls sqrt().
+// ------------------------------------------------------------------------------------------------
+#include "ptm_tables.inc"
+__device__ __attribute__((aligned(16))) const double BM_TABLE[512] = {PTM_BMTAB_VALUES};   // per translation unit; the sweep kernel stages it in LDS
+
+typedef double bm_d2 __attribute__((ext_vector_type(2)));
+
+template <class Tab>   // Tab: pointer to 256 {rc, A} pairs, 16-byte aligned (LDS or global)
+__device__ __forceinline__ double bm_neg2log(uint32_t k, Tab tab) {
+  const double M2LN2_HI = -2.0 * 6.93147180369123816490e-01, M2LN2_LO = -2.0 * 1.90821492927058770002e-10;
+  const double x = (double)k + 0.5;
+  const uint64_t b = (uint64_t)__double_as_longlong(x);
+  const uint32_t hi = (uint32_t)(b >> 32);
+  const uint32_t idx = (hi >> 12) & 255u;
+  const int e = (int)(hi >> 20) - (1023 + 32) + (idx >= (uint32_t)PTM_BMTAB_SPLIT ? 1 : 0);
+  const double m = __longlong_as_double((long long)((b & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull));
+  const bm_d2 ra = *reinterpret_cast<const bm_d2*>(tab + 2 * idx);
+  const double t = __builtin_fma(m, ra.x, -1.0);
+  double q = 1.0 / 3.0;
+  q = __builtin_fma(q, t, -0.4);
+  q = __builtin_fma(q, t, 0.5);
+  q = __builtin_fma(q, t, -2.0 / 3.0);
+  q = __builtin_fma(q, t, 1.0);
+  const double l = __builtin_fma(t * t, q, -2.0 * t);
+  const double dk = (double)e;
+  return __builtin_fma(dk, M2LN2_HI, ra.y) + __builtin_fma(dk, M2LN2_LO, l);
+}
+
+// sqrt for a in [2^-32, 64): no scaling, no special cases
+__device__ __forceinline__ double bm_sqrt(double a) {
+  const double y = __builtin_amdgcn_rsq(a);
+  double g = a * y;
+  double h = 0.5 * y;
+  const double r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g);
+  h = __builtin_fma(h, r, h);
+  double d = __builtin_fma(-g, g, a);
+  g = __builtin_fma(d, h, g);
+  d = __builtin_fma(-g, g, a);
+  g = __builtin_fma(d, h, g);
+  return g;
+}
+
+template <class Tab>
+__device__ __forceinline__ void boxmuller(uint32_t k1, uint32_t k2, Tab tab, double& z0, double& z1) {
+  const double r = bm_sqrt(bm_neg2log(k1, tab));
   const uint32_t q = k2 >> 29;
   uint32_t m = k2 & 0x1FFFFFFFu;
   if (q & 1u) m ^= 0x1FFFFFFFu;

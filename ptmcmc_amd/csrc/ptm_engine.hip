@@ -910,14 +910,14 @@ extern "C" int ptm_debug_sqrt_scan(int device, uint64_t* mismatches) {
   if (!mismatches) return fail(PTM_ERR_INVALID, "null argument");
   if (device >= 0) HIPCHK(hipSetDevice(device));
   unsigned long long* d = nullptr;
-  HIPCHK(hipMalloc((void**)&d, 8));
-  HIPCHK(hipMemset(d, 0, 8));
+  HIPCHK(hipMalloc((void**)&d, 16));
+  HIPCHK(hipMemset(d, 0, 16));
   hipLaunchKernelGGL(debug_sqrt_scan_kernel, dim3(256 * 16), dim3(256), 0, 0, d);
   HIPCHK(hipGetLastError());
-  unsigned long long v = 0;
-  HIPCHK(hipMemcpy(&v, d, 8, hipMemcpyDeviceToHost));
+  unsigned long long v[2] = {0, 0};
+  HIPCHK(hipMemcpy(v, d, 16, hipMemcpyDeviceToHost));
   (void)hipFree(d);
-  *mismatches = v;
+  *mismatches = v[0] + v[1];   // arguments where bm_sqrt is not the correctly rounded root + arguments outside its domain
   return PTM_OK;
 }
 

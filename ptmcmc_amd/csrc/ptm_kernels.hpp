@@ -214,6 +214,7 @@ struct DrawCtx {
   uint64_t seed, step;
   uint32_t stream;
   int axis;  // >= 0: one-dimensional move along that axis (proposal_distribution.hh:197-205), -1: full move
+  const double* bmtab;  // Box-Muller radius table (the block's LDS copy)
 };
 __device__ __forceinline__ void draw4(const DrawCtx& dc, int b, double (&z)[4]) {
   const u32x4 o = draw_block(dc.seed, TAG_MH, dc.stream, dc.step, (uint32_t)(b + 1));
@@ -222,8 +223,8 @@ __device__ __forceinline__ void draw4(const DrawCtx& dc, int b, double (&z)[4]) 
 #elif defined(PTM_ABLATE) && (PTM_ABLATE & 8)
   z[0] = u01(o.v0); z[1] = u01(o.v1); z[2] = u01(o.v2); z[3] = u01(o.v3);
 #else
-  boxmuller(o.v0, o.v1, z[0], z[1]);
-  boxmuller(o.v2, o.v3, z[2], z[3]);
+  boxmuller(o.v0, o.v1, dc.bmtab, z[0], z[1]);
+  boxmuller(o.v2, o.v3, dc.bmtab, z[2], z[3]);
 #endif
   if (dc.axis >= 0) {
 #pragma unroll
@@ -346,7 +347,10 @@ __global__ __launch_bounds__(256, PTM_SWEEP_WAVES) void sweep_kernel(const Dev p
   // Per-wave LDS staging of the rung's proposal factor (UNI only): every rung has its own D x D factor, so unlike
   // the shared precision matrix it misses the scalar cache; one coalesced 512-B-per-instruction copy into LDS per
   // wave, then wave-uniform (broadcast) LDS reads feed the mat-vec.  Same-wave LDS traffic only: no barrier.
-  extern __shared__ __attribute__((aligned(16))) double lds_fac[];
+  // The first 4 KB of the block's LDS hold the Box-Muller radius table (per-lane gathers, one 16-byte entry per draw).
+  extern __shared__ __attribute__((aligned(16))) double lds_all[];
+  double* lds_fac = lds_all + 512;
+  reinterpret_cast<bm_d2*>(lds_all)[threadIdx.x] = reinterpret_cast<const bm_d2*>(BM_TABLE)[threadIdx.x];
   const int c = blockIdx.x * 256 + threadIdx.x;
   int rl = (c < p.Nc ? c : p.Nc - 1) / p.W;
   if (UNI) rl = __builtin_amdgcn_readfirstlane(rl);
@@ -357,6 +361,9 @@ __global__ __launch_bounds__(256, PTM_SWEEP_WAVES) void sweep_kernel(const Dev p
     const double* g = ((UNI && DP == 32) ? p.prop_dense : p.prop) + (size_t)rl * fstride;
     for (int k = threadIdx.x & 63; k < fstride; k += 64) myfac[k] = g[k];
   }
+  // the table is shared by the block's four waves: wait for this wave's LDS writes only (a full __syncthreads would
+  // also drain the factor loads just issued) and meet the others
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   if (c >= p.Nc) return;
   const int w = c - rl * p.W;
   const int rg = p.r0 + rl;
@@ -381,8 +388,10 @@ __global__ __launch_bounds__(256, PTM_SWEEP_WAVES) void sweep_kernel(const Dev p
   double xn[DP];  // accumulates the offset, then becomes the proposed state
 #pragma unroll
   for (int i = 0; i < DP; ++i) xn[i] = 0.0;
-  const DrawCtx dc{p.seed, p.step, stream, (!SIMPLE) ? axis : -1};
+  const DrawCtx dc{p.seed, p.step, stream, (!SIMPLE) ? axis : -1, lds_all};
   const int mode = SIMPLE ? 0 : p.mode;
+  constexpr bool EARLY_ROW = UNI && DP == 32 && KIND == KIND_LOWER && SIMPLE;
+  uint64_t box_mask = ~0ull;  // lanes whose proposal is inside the prior's box so far
   // (touched lanes run the draw too: the DPP product needs every lane of the wave active, and they would idle anyway)
   if (mode == 2) {
     // accept pass of the host-callback path: the proposal was drawn and stored by the propose pass
@@ -398,10 +407,30 @@ __global__ __launch_bounds__(256, PTM_SWEEP_WAVES) void sweep_kernel(const Dev p
   } else if (UNI && DP == 32) {
     if constexpr (DP == 32) {
       const int lane16 = threadIdx.x & 15;
-      dpp_panel32<KIND, 0>(dc, myfac, lane16, xn);
-      dpp_panel32<KIND, 1>(dc, myfac, lane16, xn);
-      dpp_panel32<KIND, 2>(dc, myfac, lane16, xn);
-      dpp_panel32<KIND, 3>(dc, myfac, lane16, xn);
+      // A Cholesky factor's panel P completes offset rows [8P, 8P+8): the matching eight entries of the current state
+      // are loaded before the panel and folded in right after it (state::add, states.cc:205-214), so the row's HBM
+      // latency hides behind the panel's arithmetic at a cost of 16 live registers.
+      // (the box test of the all-uniform prior rides along, eight dimensions at a time: 16 scalar bounds live, not 64)
+      const double* __restrict__ rowc = p.x + (size_t)c * DP;
+      double rr[8];
+#define PTM_PANEL(P)                                                       \
+  if (EARLY_ROW) {                                                         \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i) rr[i] = rowc[8 * P + i]; \
+  }                                                                        \
+  dpp_panel32<KIND, P>(dc, myfac, lane16, xn);                             \
+  if (EARLY_ROW) {                                                         \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i) xn[8 * P + i] = rr[i] + xn[8 * P + i]; \
+    bool ok8 = true;                                                       \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i)                          \
+      ok8 = ok8 & !(xn[8 * P + i] < as_c(p.plo)[8 * P + i]) & !(xn[8 * P + i] > as_c(p.phi)[8 * P + i]); \
+    box_mask &= __builtin_amdgcn_ballot_w64(ok8);                          \
+    asm volatile("" : "+s"(box_mask)); /* one live lane mask, not 64 compare results */ \
+  }
+      PTM_PANEL(0)
+      PTM_PANEL(1)
+      PTM_PANEL(2)
+      PTM_PANEL(3)
+#undef PTM_PANEL
     }
   } else if (UNI) {
     factor_product<DP, KIND>(dc, (const double*)myfac, xn);
@@ -415,7 +444,7 @@ __global__ __launch_bounds__(256, PTM_SWEEP_WAVES) void sweep_kernel(const Dev p
   //    proposal.  The row is written back only if the move is accepted.
   const double ll = p.ll[c], lp = p.lp[c];
   double* __restrict__ row = p.x + (size_t)c * DP;
-  if (mode != 2) {
+  if (mode != 2 && !EARLY_ROW) {
 #pragma unroll
     for (int d = 0; d < DP; ++d) xn[d] = row[d] + xn[d];  // state::add (states.cc:205-214)
   }
@@ -428,10 +457,12 @@ __global__ __launch_bounds__(256, PTM_SWEEP_WAVES) void sweep_kernel(const Dev p
   double newlprior;
   if (SIMPLE) {
     valid = true;
-    bool in = true;
-    cdp plo = as_c(p.plo), phi = as_c(p.phi);
+    bool in = ((box_mask >> (threadIdx.x & 63)) & 1ull) != 0;
+    if (!EARLY_ROW) {
+      cdp plo = as_c(p.plo), phi = as_c(p.phi);
 #pragma unroll
-    for (int d = 0; d < DP; ++d) in = in && !(xn[d] < plo[d]) && !(xn[d] > phi[d]);
+      for (int d = 0; d < DP; ++d) in = in & !(xn[d] < plo[d]) & !(xn[d] > phi[d]);   // (no short circuit: branch-free)
+    }
     newlprior = in ? p.lprior_const : -__builtin_inf();
   } else if (mode == 2) {
     valid = (p.gate[c] & 1) != 0;
@@ -527,7 +558,7 @@ __global__ __launch_bounds__(256) void init_prior_kernel(const Dev p, double* x_
       if (d < p.D) {
         const u32x4 o = draw_block(p.seed, TAG_INIT, stream, a, (uint32_t)d);
         if (pt[d] == P_UNIFORM) x[d] = u01(o.v0) * (phi[d] - plo[d]) + plo[d];
-        else if (pt[d] == P_GAUSSIAN) { double z0, z1; boxmuller(o.v0, o.v1, z0, z1); x[d] = z0 * phi[d] + plo[d]; }
+        else if (pt[d] == P_GAUSSIAN) { double z0, z1; boxmuller(o.v0, o.v1, (const double*)BM_TABLE, z0, z1); x[d] = z0 * phi[d] + plo[d]; }
         else x[d] = __builtin_nan("");
       }
     }

@@ -26,7 +26,7 @@ _u32p = C.POINTER(C.c_uint32)
 
 
 def build(force=False):
-    src = [os.path.join(ORACLE_DIR, f) for f in ("ptm_oracle.c", "ptm_oracle.h")]
+    src = [os.path.join(ORACLE_DIR, f) for f in ("ptm_oracle.c", "ptm_oracle.h", "ptm_tables.inc")]
     stale = force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in src)
     if stale:
         subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "oracle"])
@@ -64,6 +64,8 @@ def lib():
     L.ptmo_philox4x32_10.argtypes = [_u32p, _u32p, _u32p]
     L.ptmo_u01.restype = C.c_double
     L.ptmo_u01.argtypes = [C.c_uint32]
+    L.ptmo_bm_neg2log.restype = C.c_double
+    L.ptmo_bm_neg2log.argtypes = [C.c_uint32]
     L.ptmo_draw_block.argtypes = [C.c_uint64, C.c_int, C.c_uint32, C.c_uint64, C.c_uint32, _u32p]
     L.ptmo_boxmuller.argtypes = [C.c_uint32, C.c_uint32, _dp, _dp]
     for f in ("ptmo_log", "ptmo_exp", "ptmo_sin_0_pi", "ptmo_cos_hpi"):
@@ -125,6 +127,10 @@ def draw_block(seed, tag, stream, step, block):
     o = (C.c_uint32 * 4)()
     lib().ptmo_draw_block(seed, tag, stream, step, block, o)
     return [int(v) for v in o]
+
+
+def bm_neg2log(k):
+    return lib().ptmo_bm_neg2log(k)
 
 
 def boxmuller(k1, k2):

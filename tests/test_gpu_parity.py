@@ -65,6 +65,12 @@ def test_boxmuller_bit_exact():
     assert abs(z0.mean()) < 0.02 and abs(z0.var() - 1) < 0.02 and abs(z1.var() - 1) < 0.02
 
 
+def test_boxmuller_radius_sqrt_is_correctly_rounded_for_all_arguments():
+    """The hot path takes sqrt(-2 ln u) with an unscaled v_rsq_f64 + Newton sequence; the CPU checker calls sqrt().
+    All 2^32 possible arguments are scanned on the GPU against the exact-residual corrected root."""
+    assert E.debug_sqrt_scan() == 0
+
+
 def test_prior_and_boundary_tables_from_reference():
     """mixed_dist_product::evaluate_log and stateSpace::enforce on the device vs the real reference's values."""
     for cfg in golden_io.load("basic.json.gz")["priors"]:
