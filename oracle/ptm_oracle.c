@@ -298,12 +298,14 @@ double ptmo_lprior(const ptmo_problem* pb, const double* x, int valid) {
   return ptmo_log(result);
 }
 
-/* Gaussian target of cython/exampleGaussian.py:103-109: like0 - 0.5 x^T invcov x, evaluated in the
- * symmetric-packed order  q = sum_i y_i (P_ii y_i + sum_{j<i} 2 P_ij y_j)  shared with the kernel */
+/* Gaussian target of cython/exampleGaussian.py:103-109: like0 - 0.5 x^T invcov x, evaluated in the order shared with
+ * the kernels:  s_i = P_ii y_i + sum_{j<i} 2 P_ij y_j  (one fma chain per row, j ascending -- on the GPU a column of
+ * 16x16x4 f64 MFMA tiles, whose accumulation is exactly this chain), then the dot product y.s in four interleaved
+ * partial sums p_q = sum_{i = q mod 4} y_i s_i (i ascending) combined as ((p0 + p1) + p2) + p3. */
 double ptmo_llike(const ptmo_problem* pb, const double* x) {
   if (pb->user_fn) return pb->user_fn(pb->user, x, pb->D);
   int D = pb->D;
-  double q = 0;
+  double pq[4] = {0.0, 0.0, 0.0, 0.0};
   for (int i = 0; i < D; i++) {
     double s = 0;
     for (int j = 0; j < i; j++) {
@@ -312,9 +314,29 @@ double ptmo_llike(const ptmo_problem* pb, const double* x) {
     }
     double yi = pb->mean ? x[i] - pb->mean[i] : x[i];
     s = fma(pb->P2[i * D + i], yi, s);
-    q = fma(yi, s, q);
+    pq[i & 3] = fma(yi, s, pq[i & 3]);
   }
+  double q = ((pq[0] + pq[1]) + pq[2]) + pq[3];
   return pb->like0 - 0.5 * q;
+}
+
+/* order in which the columns of a proposal factor are accumulated (the kernels' tile order): natural for padded
+ * dimension <= 8; otherwise in halves of 16 columns, inside a half s + 4k with s = 0..3 outer, k = 0..3 inner.
+ * Padded dimension = D rounded up to 4, 8, 16, 32, 64. */
+int ptmo_column_order(int D, int* ord) {
+  int DP = D <= 4 ? 4 : (D <= 8 ? 8 : (D <= 16 ? 16 : (D <= 32 ? 32 : 64)));
+  int n = 0;
+  if (DP <= 8) {
+    for (int j = 0; j < D; j++) ord[n++] = j;
+    return n;
+  }
+  for (int h = 0; 16 * h < DP; h++)
+    for (int sct = 0; sct < 4; sct++)
+      for (int k = 0; k < 4; k++) {
+        int col = 16 * h + 4 * k + sct;
+        if (col < D) ord[n++] = col;
+      }
+  return n;
 }
 
 /* chain.cc:928 / :982 / :1090: lprior + invtemp*llike, product rounded before the sum */
@@ -603,9 +625,11 @@ static int ph_draw_offset(void* vctx, int w, int r, uint64_t step, const ptmo_pr
   if (p->kind == PTMO_PROP_DIAG) {
     for (int i = 0; i < D; i++) off[i] = p->M[i] * z[i];
   } else {
+    int ord[64];
+    int n = ptmo_column_order(D, ord);
     for (int i = 0; i < D; i++) {
       double a = 0.0;
-      for (int j = 0; j < D; j++) a = fma(p->M[i * D + j], z[j], a);
+      for (int t = 0; t < n; t++) a = fma(p->M[i * D + ord[t]], z[ord[t]], a);
       off[i] = a;
     }
   }

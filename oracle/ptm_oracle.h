@@ -101,6 +101,7 @@ typedef struct {
 void ptmo_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 /* open-interval map (k+0.5)/2^32 of newran1.cxx:432 */
 double ptmo_u01(uint32_t k);
+int ptmo_column_order(int D, int* ord); /* accumulation order of a proposal factor's columns; returns D */
 double ptmo_bm_neg2log(uint32_t k); /* -2 ln((k+.5)/2^32), the Box-Muller radius argument */
 /* engine counter layout: c0 = block, c1 = stream, c2 = step low, c3 = step high(24) | tag<<24 */
 void ptmo_draw_block(uint64_t seed, int tag, uint32_t stream, uint64_t step, uint32_t block, uint32_t out[4]);

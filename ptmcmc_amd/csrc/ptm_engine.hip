@@ -343,31 +343,18 @@ extern "C" int ptm_set_proposals(ptm_engine* e, int kind, const double* factors,
     packed.assign((size_t)nloc * stride, 0.0);
     for (int r = 0; r < nloc; ++r)
       for (int d = 0; d < D; ++d) packed[(size_t)r * stride + d] = factors[(size_t)r * D + d];
-  } else if (kind == PTM_PROP_DENSE) {
-    stride = DP * DP;  // column-major, padded: element (i,j) at j*DP + i
+  } else if (kind == PTM_PROP_DENSE || kind == PTM_PROP_LOWER) {
+    stride = DP * DP;  // column-major, padded: element (i,j) at j*DP + i; a Cholesky factor keeps its zeros
     packed.assign((size_t)nloc * stride, 0.0);
     for (int r = 0; r < nloc; ++r)
       for (int i = 0; i < D; ++i)
         for (int j = 0; j < D; ++j) packed[(size_t)r * stride + (size_t)j * DP + i] = factors[(size_t)r * D * D + (size_t)i * D + j];
-  } else if (kind == PTM_PROP_LOWER) {
-    // column panels of PC columns (ptm_kernels.hpp, Panels<DP>): panel P = columns [PC*P, PC*P+PC) x rows [PC*P, DP),
-    // column-major inside the panel
-    const int PC = DP >= 8 ? 8 : 4, NP = DP / PC;
-    std::vector<int> poff(NP + 1, 0);
-    for (int P = 0; P < NP; ++P) poff[P + 1] = poff[P] + PC * (DP - PC * P);
-    stride = poff[NP];
-    packed.assign((size_t)nloc * stride, 0.0);
-    for (int r = 0; r < nloc; ++r)
-      for (int j = 0; j < D; ++j) {
-        const int P = j / PC, R0 = PC * P, NR = DP - R0;
-        for (int i = j; i < D; ++i)
-          packed[(size_t)r * stride + poff[P] + (size_t)(j - R0) * NR + (i - R0)] = factors[(size_t)r * D * D + (size_t)i * D + j];
-      }
-    for (int r = 0; r < nloc; ++r)
-      for (int i = 0; i < D; ++i)
-        for (int j = i + 1; j < D; ++j)
-          if (factors[(size_t)r * D * D + (size_t)i * D + j] != 0.0)
-            return fail(PTM_ERR_INVALID, "PTM_PROP_LOWER factor of local rung %d has a non-zero above the diagonal", r);
+    if (kind == PTM_PROP_LOWER)
+      for (int r = 0; r < nloc; ++r)
+        for (int i = 0; i < D; ++i)
+          for (int j = i + 1; j < D; ++j)
+            if (factors[(size_t)r * D * D + (size_t)i * D + j] != 0.0)
+              return fail(PTM_ERR_INVALID, "PTM_PROP_LOWER factor of local rung %d has a non-zero above the diagonal", r);
   } else {
     return fail(PTM_ERR_INVALID, "unknown proposal kind %d", kind);
   }
@@ -375,14 +362,6 @@ extern "C" int ptm_set_proposals(ptm_engine* e, int kind, const double* factors,
   if (e->prop_dense) { HIPCHK(hipFree(e->prop_dense)); e->prop_dense = nullptr; }
   int rc;
   if ((rc = dalloc(&e->prop, packed.size())) || (rc = upload(e->prop, packed.data(), packed.size(), e->stream))) return rc;
-  if (kind != PTM_PROP_DIAG) {
-    // dense column-major image (element (i,j) at j*DP + i), used by the wave-uniform DPP product
-    std::vector<double> dense((size_t)nloc * DP * DP, 0.0);
-    for (int r = 0; r < nloc; ++r)
-      for (int i = 0; i < D; ++i)
-        for (int j = 0; j < D; ++j) dense[(size_t)r * DP * DP + (size_t)j * DP + i] = factors[(size_t)r * D * D + (size_t)i * D + j];
-    if ((rc = dalloc(&e->prop_dense, dense.size())) || (rc = upload(e->prop_dense, dense.data(), dense.size(), e->stream))) return rc;
-  }
   std::vector<double> f(nloc, 0.0);
   e->any_oned = 0;
   if (one_d_frac)

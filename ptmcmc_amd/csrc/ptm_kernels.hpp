@@ -75,7 +75,7 @@ struct Dev {
   double like0;
   // ladder + proposals
   const double* beta;      // [Nt] global
-  const double* prop;      // [nloc][prop_stride]  column-packed factor or sigmas
+  const double* prop;      // [nloc][prop_stride]  factor, dense column-major [col][row] (DP*DP), or sigmas (DP)
   const double* prop_dense;  // [nloc][DP*DP] dense column-major image (zeros above the diagonal) for the DPP product
   const double* onedfrac;  // [nloc]
   int prop_stride, any_oned;
@@ -180,10 +180,12 @@ __device__ __noinline__ double enforce_and_lprior(const Dev& p, double (&x)[DP],
   return dlog(result);
 }
 
-// like0 - 1/2 y^T P y in the symmetric-packed order q = sum_i y_i (P_ii y_i + sum_{j<i} 2P_ij y_j)
+// like0 - 1/2 y^T P y in the order shared by every path (and the CPU checker): s_i = P_ii y_i + sum_{j<i} 2P_ij y_j as
+// one fma chain per row (j ascending: exactly what a column of f64 MFMA tiles accumulates), then the dot product y.s
+// in four interleaved partial sums p_q = sum_{i = q mod 4} y_i s_i combined as ((p0 + p1) + p2) + p3.
 template <int DP, bool MEAN, class XV>
 __device__ __forceinline__ double gauss_llike(const Dev& p, const XV& x) {
-  double q = 0;
+  double pq[4] = {0.0, 0.0, 0.0, 0.0};
   cdp row = as_c(p.P2);
   cdp mean = as_c(p.mean);
 #pragma unroll
@@ -196,9 +198,10 @@ __device__ __forceinline__ double gauss_llike(const Dev& p, const XV& x) {
     }
     const double yi = MEAN ? x[i] - mean[i] : x[i];
     s = __builtin_fma(row[i], yi, s);
-    q = __builtin_fma(yi, s, q);
+    pq[i & 3] = __builtin_fma(yi, s, pq[i & 3]);
     row += i + 1;
   }
+  const double q = ((pq[0] + pq[1]) + pq[2]) + pq[3];
   return p.like0 - 0.5 * q;
 }
 
@@ -233,33 +236,47 @@ __device__ __forceinline__ void draw4(const DrawCtx& dc, int b, double (&z)[4]) 
   }
 }
 
-template <int DP>
-struct Panels {
-  static constexpr int PC = DP >= 8 ? 8 : 4;   // columns per panel
-  static constexpr int NP = DP / PC;           // panels
-  static constexpr int rows(int P) { return DP - PC * P; }
-  static constexpr int offset(int P) { return P == 0 ? 0 : offset(P - 1) + PC * rows(P - 1); }
-  static constexpr int lower_doubles = offset(NP);   // 640 for DP=32
-};
-
-// one column panel: acc[R0 + i] += T[R0 + i][j] * z_j  for the panel's columns j, rows R0..DP-1
-template <int DP, int R0, int NROW, int NCOLBLK, class TP>
-__device__ __forceinline__ void panel_product(const DrawCtx& dc, int first_block, TP tab, double (&acc)[DP]) {
+// Column order of the product (shared with the CPU checker and the MFMA kernel, whose tile steps fix it): natural for
+// DP <= 8; for DP >= 16 in halves of 16 columns, inside a half s + 4k with s = 0..3 outer and k = 0..3 inner -- i.e.
+// slot s of the half's four Philox blocks k = 0..3.  Factors are stored dense column-major [col][row] (DP*DP per rung,
+// zeros above the diagonal of a Cholesky factor); LOWER skips the leading rows of a column block, whose entries are
+// structural zeros (fma(0, z, acc) == acc: same bits either way).
+template <int DP, int KIND, class TP>
+__device__ __forceinline__ void factor_product(const DrawCtx& dc, TP tab, double (&acc)[DP]) {
+  if constexpr (DP <= 8) {
 #pragma unroll 1
-  for (int bb = 0; bb < NCOLBLK; ++bb) {
-    double z[4];
-    draw4(dc, first_block + bb, z);
+    for (int bb = 0; bb < DP / 4; ++bb) {
+      double z[4];
+      draw4(dc, bb, z);
 #pragma unroll 1
-    for (int t = 0; t < 4; ++t) {
-      const double zj = z[0];
-      z[0] = z[1]; z[1] = z[2]; z[2] = z[3]; z[3] = zj;  // rotate: keeps the register index static
-      TP col = tab + (bb * 4 + t) * NROW;
-#if !(defined(PTM_ABLATE) && (PTM_ABLATE & 2))
+      for (int t = 0; t < 4; ++t) {
+        const double zj = z[0];
+        z[0] = z[1]; z[1] = z[2]; z[2] = z[3]; z[3] = zj;  // rotate: keeps the register index static
+        TP col = tab + (bb * 4 + t) * DP;
 #pragma unroll
-      for (int i = 0; i < NROW; ++i) acc[R0 + i] = __builtin_fma(col[i], zj, acc[R0 + i]);
-#else
-      acc[R0] += zj;
-#endif
+        for (int i = 0; i < DP; ++i) acc[i] = __builtin_fma(col[i], zj, acc[i]);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int h = 0; h < DP / 16; ++h) {
+      double zz[4][4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) draw4(dc, 4 * h + k, zz[k]);
+#pragma unroll 1
+      for (int sl = 0; sl < 4; ++sl) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const double zj = zz[k][0];
+          zz[k][0] = zz[k][1]; zz[k][1] = zz[k][2]; zz[k][2] = zz[k][3]; zz[k][3] = zj;
+          TP col = tab + (16 * h + 4 * k + sl) * DP;
+          constexpr int dummy = 0; (void)dummy;
+          const int R0 = (KIND == KIND_LOWER) ? 16 * h + 4 * k : 0;   // compile-time after unrolling h and k
+#pragma unroll
+          for (int i = 0; i < DP; ++i)
+            if (i >= R0) acc[i] = __builtin_fma(col[i], zj, acc[i]);
+        }
+      }
     }
   }
 }
@@ -292,44 +309,27 @@ __device__ __forceinline__ void dpp_fma16(double* a, double col, double z) {
   }
 }
 
-// columns [8*P8, 8*P8+8) of a 32-dimensional factor staged dense column-major at `tab` (LDS); LOWER skips the
-// row blocks that are structurally zero for this panel
-template <int KIND, int P8>
-__device__ __forceinline__ void dpp_panel32(const DrawCtx& dc, const double* tab, int lane16, double (&acc)[32]) {
+// half h (columns [16h, 16h+16)) of a 32-dimensional factor staged dense column-major at `tab` (LDS), in the shared
+// column order; LOWER skips the row blocks that are structurally zero
+template <int KIND, int H>
+__device__ __forceinline__ void dpp_half32(const DrawCtx& dc, const double* tab, int lane16, double (&acc)[32]) {
+  double zz[4][4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) draw4(dc, 4 * H + k, zz[k]);
 #pragma unroll 1
-  for (int bb = 0; bb < 2; ++bb) {
-    double z[4];
-    draw4(dc, 2 * P8 + bb, z);
-#pragma unroll 1
-    for (int t = 0; t < 4; ++t) {
-      const double zj = z[0];
-      z[0] = z[1]; z[1] = z[2]; z[2] = z[3]; z[3] = zj;
-      const double* col = tab + (8 * P8 + 4 * bb + t) * 32 + lane16;
-#if defined(PTM_ABLATE) && (PTM_ABLATE & 2)
-      acc[8 * P8] += zj;
-      continue;
-#endif
-      if (KIND == KIND_DENSE || P8 < 2) {
+  for (int sl = 0; sl < 4; ++sl) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const double zj = zz[k][0];
+      zz[k][0] = zz[k][1]; zz[k][1] = zz[k][2]; zz[k][2] = zz[k][3]; zz[k][3] = zj;
+      const double* col = tab + (16 * H + 4 * k + sl) * 32 + lane16;
+      if (KIND == KIND_DENSE || H == 0) {          // rows 0..15: only columns < 16 reach them in a Cholesky factor
         const double ca = col[0];
-        if (KIND == KIND_DENSE || P8 == 0) dpp_fma16<16>(&acc[0], ca, zj); else dpp_fma16<8>(&acc[0], ca, zj);
+        if (KIND == KIND_DENSE || k < 2) dpp_fma16<16>(&acc[0], ca, zj); else dpp_fma16<8>(&acc[0], ca, zj);
       }
-      const double cb = col[16];
-      if (KIND == KIND_DENSE || P8 < 3) dpp_fma16<16>(&acc[16], cb, zj); else dpp_fma16<8>(&acc[16], cb, zj);
+      const double cb = col[16];                   // rows 16..31
+      if (KIND == KIND_DENSE || H == 0 || k < 2) dpp_fma16<16>(&acc[16], cb, zj); else dpp_fma16<8>(&acc[16], cb, zj);
     }
-  }
-}
-
-template <int DP, int KIND, class TP>
-__device__ __forceinline__ void factor_product(const DrawCtx& dc, TP tab, double (&acc)[DP]) {
-  using PN = Panels<DP>;
-  if (KIND == KIND_DENSE) {
-    panel_product<DP, 0, DP, DP / 4, TP>(dc, 0, tab, acc);   // column-major dense: one panel of all columns
-  } else {
-    constexpr int BPP = PN::PC / 4;  // Philox blocks per panel
-    panel_product<DP, 0, PN::rows(0), BPP, TP>(dc, 0, tab + PN::offset(0), acc);
-    if constexpr (PN::NP > 1) panel_product<DP, PN::PC * 1, PN::rows(1), BPP, TP>(dc, BPP * 1, tab + PN::offset(1), acc);
-    if constexpr (PN::NP > 2) panel_product<DP, PN::PC * 2, PN::rows(2), BPP, TP>(dc, BPP * 2, tab + PN::offset(2), acc);
-    if constexpr (PN::NP > 3) panel_product<DP, PN::PC * 3, PN::rows(3), BPP, TP>(dc, BPP * 3, tab + PN::offset(3), acc);
   }
 }
 
@@ -355,10 +355,10 @@ __global__ __launch_bounds__(256, PTM_SWEEP_WAVES) void sweep_kernel(const Dev p
   int rl = (c < p.Nc ? c : p.Nc - 1) / p.W;
   if (UNI) rl = __builtin_amdgcn_readfirstlane(rl);
   // (DP == 32: the DPP product wants the dense column-major image, which the host keeps beside the packed one)
-  const int fstride = (UNI && DP == 32) ? DP * DP : p.prop_stride;
+  const int fstride = p.prop_stride;
   double* myfac = lds_fac + (threadIdx.x >> 6) * fstride;
   if (UNI && KIND != KIND_DIAG) {
-    const double* g = ((UNI && DP == 32) ? p.prop_dense : p.prop) + (size_t)rl * fstride;
+    const double* g = p.prop + (size_t)rl * fstride;
     for (int k = threadIdx.x & 63; k < fstride; k += 64) myfac[k] = g[k];
   }
   // the table is shared by the block's four waves: wait for this wave's LDS writes only (a full __syncthreads would
@@ -390,8 +390,7 @@ __global__ __launch_bounds__(256, PTM_SWEEP_WAVES) void sweep_kernel(const Dev p
   for (int i = 0; i < DP; ++i) xn[i] = 0.0;
   const DrawCtx dc{p.seed, p.step, stream, (!SIMPLE) ? axis : -1, lds_all};
   const int mode = SIMPLE ? 0 : p.mode;
-  constexpr bool EARLY_ROW = UNI && DP == 32 && KIND == KIND_LOWER && SIMPLE;
-  uint64_t box_mask = ~0ull;  // lanes whose proposal is inside the prior's box so far
+
   // (touched lanes run the draw too: the DPP product needs every lane of the wave active, and they would idle anyway)
   if (mode == 2) {
     // accept pass of the host-callback path: the proposal was drawn and stored by the propose pass
@@ -407,30 +406,8 @@ __global__ __launch_bounds__(256, PTM_SWEEP_WAVES) void sweep_kernel(const Dev p
   } else if (UNI && DP == 32) {
     if constexpr (DP == 32) {
       const int lane16 = threadIdx.x & 15;
-      // A Cholesky factor's panel P completes offset rows [8P, 8P+8): the matching eight entries of the current state
-      // are loaded before the panel and folded in right after it (state::add, states.cc:205-214), so the row's HBM
-      // latency hides behind the panel's arithmetic at a cost of 16 live registers.
-      // (the box test of the all-uniform prior rides along, eight dimensions at a time: 16 scalar bounds live, not 64)
-      const double* __restrict__ rowc = p.x + (size_t)c * DP;
-      double rr[8];
-#define PTM_PANEL(P)                                                       \
-  if (EARLY_ROW) {                                                         \
-    _Pragma("unroll") for (int i = 0; i < 8; ++i) rr[i] = rowc[8 * P + i]; \
-  }                                                                        \
-  dpp_panel32<KIND, P>(dc, myfac, lane16, xn);                             \
-  if (EARLY_ROW) {                                                         \
-    _Pragma("unroll") for (int i = 0; i < 8; ++i) xn[8 * P + i] = rr[i] + xn[8 * P + i]; \
-    bool ok8 = true;                                                       \
-    _Pragma("unroll") for (int i = 0; i < 8; ++i)                          \
-      ok8 = ok8 & !(xn[8 * P + i] < as_c(p.plo)[8 * P + i]) & !(xn[8 * P + i] > as_c(p.phi)[8 * P + i]); \
-    box_mask &= __builtin_amdgcn_ballot_w64(ok8);                          \
-    asm volatile("" : "+s"(box_mask)); /* one live lane mask, not 64 compare results */ \
-  }
-      PTM_PANEL(0)
-      PTM_PANEL(1)
-      PTM_PANEL(2)
-      PTM_PANEL(3)
-#undef PTM_PANEL
+      dpp_half32<KIND, 0>(dc, myfac, lane16, xn);
+      dpp_half32<KIND, 1>(dc, myfac, lane16, xn);
     }
   } else if (UNI) {
     factor_product<DP, KIND>(dc, (const double*)myfac, xn);
@@ -444,7 +421,7 @@ __global__ __launch_bounds__(256, PTM_SWEEP_WAVES) void sweep_kernel(const Dev p
   //    proposal.  The row is written back only if the move is accepted.
   const double ll = p.ll[c], lp = p.lp[c];
   double* __restrict__ row = p.x + (size_t)c * DP;
-  if (mode != 2 && !EARLY_ROW) {
+  if (mode != 2) {
 #pragma unroll
     for (int d = 0; d < DP; ++d) xn[d] = row[d] + xn[d];  // state::add (states.cc:205-214)
   }
@@ -457,12 +434,18 @@ __global__ __launch_bounds__(256, PTM_SWEEP_WAVES) void sweep_kernel(const Dev p
   double newlprior;
   if (SIMPLE) {
     valid = true;
-    bool in = ((box_mask >> (threadIdx.x & 63)) & 1ull) != 0;
-    if (!EARLY_ROW) {
-      cdp plo = as_c(p.plo), phi = as_c(p.phi);
+    // the box of the all-uniform prior, eight dimensions at a time: one live lane mask, not 2*DP compare results
+    uint64_t box_mask = ~0ull;
+    cdp plo = as_c(p.plo), phi = as_c(p.phi);
 #pragma unroll
-      for (int d = 0; d < DP; ++d) in = in & !(xn[d] < plo[d]) & !(xn[d] > phi[d]);   // (no short circuit: branch-free)
+    for (int d0 = 0; d0 < DP; d0 += (DP < 8 ? DP : 8)) {
+      bool ok8 = true;
+#pragma unroll
+      for (int d = d0; d < d0 + (DP < 8 ? DP : 8); ++d) ok8 = ok8 & !(xn[d] < plo[d]) & !(xn[d] > phi[d]);
+      box_mask &= __builtin_amdgcn_ballot_w64(ok8);
+      asm volatile("" : "+s"(box_mask));
     }
+    const bool in = ((box_mask >> (threadIdx.x & 63)) & 1ull) != 0;
     newlprior = in ? p.lprior_const : -__builtin_inf();
   } else if (mode == 2) {
     valid = (p.gate[c] & 1) != 0;
