@@ -54,7 +54,7 @@ struct ptm_engine {
   // device problem description
   int *blo = nullptr, *bhi = nullptr, *ptype = nullptr;
   double *bmin = nullptr, *bmax = nullptr, *plo = nullptr, *phi = nullptr, *pcoef = nullptr;
-  double *P2 = nullptr, *mean = nullptr, *beta = nullptr, *prop = nullptr, *prop_dense = nullptr, *onedfrac = nullptr;
+  double *P2 = nullptr, *mean = nullptr, *beta = nullptr, *prop = nullptr, *prop_tiles = nullptr, *P2_tiles = nullptr, *box_row = nullptr, *onedfrac = nullptr;
   // host copies / flags
   int has_bounds = 0, origin_valid = 1, all_uniform = 1, has_mean = 0, have_target = 0, have_ladder = 0,
       have_prop = 0, have_state = 0, prop_kind = KIND_DIAG, prop_stride = 0, any_oned = 0;
@@ -166,8 +166,14 @@ extern "C" int ptm_engine_create(const ptm_config* cfg, ptm_engine** out) {
   if ((rc = dalloc(&e->blo, D)) || (rc = dalloc(&e->bhi, D)) || (rc = dalloc(&e->ptype, D)) || (rc = dalloc(&e->bmin, D)) ||
       (rc = dalloc(&e->bmax, D)) || (rc = dalloc(&e->plo, D)) || (rc = dalloc(&e->phi, D)) || (rc = dalloc(&e->pcoef, D)) ||
       (rc = dalloc(&e->P2, D * (D + 1) / 2)) || (rc = dalloc(&e->mean, D)) || (rc = dalloc(&e->beta, (size_t)e->Nt)) ||
-      (rc = dalloc(&e->onedfrac, (size_t)e->nloc)))
+      (rc = dalloc(&e->onedfrac, (size_t)e->nloc)) || (rc = dalloc(&e->P2_tiles, 16 * 64)) || (rc = dalloc(&e->box_row, 64)))
     return rc;
+  {
+    std::vector<double> box(64);
+    for (int d = 0; d < 32; ++d) { box[d] = -INFINITY; box[32 + d] = INFINITY; }
+    if ((rc = upload(e->box_row, box.data(), 64, e->stream))) return rc;
+    HIPCHK(hipMemsetAsync(e->P2_tiles, 0, 16 * 64 * 8, e->stream));
+  }
   // defaults (and the permanent content of the pad dimensions): open bounds, flat prior with unbounded support
   std::vector<int> zi(D, 0);
   std::vector<double> zd(D, 0.0), one(D, 1.0), ninf(D, -INFINITY), pinf(D, INFINITY);
@@ -191,7 +197,7 @@ extern "C" int ptm_engine_destroy(ptm_engine* e) {
   (void)hipStreamSynchronize(e->stream);
   void* ptrs[] = {e->x, e->ll, e->lp, e->ntries, e->naccept, e->last_type, e->arr_below, e->arr_above, e->mv_src, e->mv_dst, e->mv_n,
                   e->err, e->nhist, e->swap_try, e->swap_acc, e->touch, e->swap_log, e->blo,
-                  e->bhi, e->ptype, e->bmin, e->bmax, e->plo, e->phi, e->pcoef, e->P2, e->mean, e->beta, e->prop, e->prop_dense, e->onedfrac, e->xprop, e->lprior_new, e->llike_new, e->gate};
+                  e->bhi, e->ptype, e->bmin, e->bmax, e->plo, e->phi, e->pcoef, e->P2, e->mean, e->beta, e->prop, e->prop_tiles, e->P2_tiles, e->box_row, e->onedfrac, e->xprop, e->lprior_new, e->llike_new, e->gate};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (hipEvent_t ev : e->kev) (void)hipEventDestroy(ev);
@@ -232,6 +238,7 @@ extern "C" int ptm_set_bounds(ptm_engine* e, const int32_t* lo, const int32_t* h
   return PTM_OK;
 }
 
+static inline size_t host_row_pos(size_t DP, size_t d);
 extern "C" int ptm_set_prior(ptm_engine* e, const int32_t* types, const double* c, const double* h) {
   if (!e || !types || !c || !h) return fail(PTM_ERR_INVALID, "null argument");
   const int D = e->D;
@@ -277,6 +284,14 @@ extern "C" int ptm_set_prior(ptm_engine* e, const int32_t* types, const double* 
   if ((rc = upload(e->ptype, ty.data(), D, e->stream)) || (rc = upload(e->plo, lo.data(), D, e->stream)) ||
       (rc = upload(e->phi, hi.data(), D, e->stream)) || (rc = upload(e->pcoef, coef.data(), D, e->stream)))
     return rc;
+  if (e->DP == 32) {   // the box in row layout, for the MFMA kernel (pad dimensions stay unbounded)
+    std::vector<double> box(64);
+    for (int d = 0; d < 32; ++d) {
+      box[host_row_pos(32, d)] = d < D ? lo[d] : -INFINITY;
+      box[32 + host_row_pos(32, d)] = d < D ? hi[d] : INFINITY;
+    }
+    if ((rc = upload(e->box_row, box.data(), 64, e->stream))) return rc;
+  }
   return PTM_OK;
 }
 
@@ -291,6 +306,19 @@ extern "C" int ptm_set_target_gaussian(ptm_engine* e, const double* mean, const 
   }
   int rc;
   if ((rc = upload(e->P2, packed.data(), packed.size(), e->stream))) return rc;
+  if (DP == 32) {
+    // A-operand tiles of the MFMA kernel: tile t = step*2 + rowtile, lane 16k + i holds P2[16 rowtile + i][4 step + k]
+    std::vector<double> tiles(16 * 64, 0.0);
+    for (int t = 0; t < 16; ++t) {
+      const int rt = t & 1, m = t >> 1;
+      for (int k = 0; k < 4; ++k)
+        for (int i = 0; i < 16; ++i) {
+          const int row = 16 * rt + i, col = 4 * m + k;
+          if (row < D && col <= row) tiles[(size_t)t * 64 + 16 * k + i] = packed[(size_t)row * (row + 1) / 2 + col];
+        }
+    }
+    if ((rc = upload(e->P2_tiles, tiles.data(), tiles.size(), e->stream))) return rc;
+  }
   e->has_mean = mean ? 1 : 0;
   if (mean && (rc = upload(e->mean, mean, D, e->stream))) return rc;
   e->like0 = like0;
@@ -319,7 +347,7 @@ static int call_user(ptm_engine* e, const std::vector<double>& rows, const std::
   if (!n) return PTM_OK;
   e->h_batch.resize(n * D);
   for (size_t k = 0; k < n; ++k)
-    for (size_t d = 0; d < D; ++d) e->h_batch[k * D + d] = rows[pick[k] * DP + d];
+    for (size_t d = 0; d < D; ++d) e->h_batch[k * D + d] = rows[pick[k] * DP + host_row_pos(DP, d)];
   e->cb(e->cb_user, e->h_batch.data(), (int)n, (int)D, out.data());
   return PTM_OK;
 }
@@ -359,9 +387,24 @@ extern "C" int ptm_set_proposals(ptm_engine* e, int kind, const double* factors,
     return fail(PTM_ERR_INVALID, "unknown proposal kind %d", kind);
   }
   if (e->prop) { HIPCHK(hipStreamSynchronize(e->stream)); HIPCHK(hipFree(e->prop)); e->prop = nullptr; }
-  if (e->prop_dense) { HIPCHK(hipFree(e->prop_dense)); e->prop_dense = nullptr; }
+  if (e->prop_tiles) { HIPCHK(hipFree(e->prop_tiles)); e->prop_tiles = nullptr; }
   int rc;
   if ((rc = dalloc(&e->prop, packed.size())) || (rc = upload(e->prop, packed.data(), packed.size(), e->stream))) return rc;
+  if (kind != PTM_PROP_DIAG && DP == 32) {
+    // A-operand tiles of the MFMA kernel: tile t = (half*4 + slot)*2 + rowtile, lane 16k + i holds
+    // T[16 rowtile + i][16 half + 4k + slot]
+    std::vector<double> tiles((size_t)nloc * 16 * 64, 0.0);
+    for (int r = 0; r < nloc; ++r)
+      for (int t = 0; t < 16; ++t) {
+        const int rt = t & 1, sl = (t >> 1) & 3, hb = t >> 3;
+        for (int k = 0; k < 4; ++k)
+          for (int i = 0; i < 16; ++i) {
+            const int row = 16 * rt + i, col = 16 * hb + 4 * k + sl;
+            if (row < D && col < D) tiles[((size_t)r * 16 + t) * 64 + 16 * k + i] = factors[(size_t)r * D * D + (size_t)row * D + col];
+          }
+      }
+    if ((rc = dalloc(&e->prop_tiles, tiles.size())) || (rc = upload(e->prop_tiles, tiles.data(), tiles.size(), e->stream))) return rc;
+  }
   std::vector<double> f(nloc, 0.0);
   e->any_oned = 0;
   if (one_d_frac)
@@ -386,7 +429,7 @@ static Dev make_dev(ptm_engine* e) {
   p.all_uniform = e->all_uniform; p.lprior_const = e->lprior_const;
   p.ptype = e->ptype; p.plo = e->plo; p.phi = e->phi; p.pcoef = e->pcoef;
   p.P2 = e->P2; p.mean = e->mean; p.has_mean = e->has_mean; p.like0 = e->like0;
-  p.beta = e->beta; p.prop = e->prop; p.prop_dense = e->prop_dense; p.onedfrac = e->onedfrac; p.prop_stride = e->prop_stride; p.any_oned = e->any_oned;
+  p.beta = e->beta; p.prop = e->prop; p.prop_tiles = e->prop_tiles; p.P2_tiles = e->P2_tiles; p.box_row = e->box_row; p.onedfrac = e->onedfrac; p.prop_stride = e->prop_stride; p.any_oned = e->any_oned;
   p.x = e->x; p.ll = e->ll; p.lp = e->lp;
   p.ntries = e->ntries; p.naccept = e->naccept; p.last_type = e->last_type; p.nhist = e->nhist;
   p.touch = e->touch; p.err = e->err;
@@ -537,16 +580,18 @@ static int run_eval(ptm_engine* e, int n, double* x, int* valid, double* lp, dou
   return PTM_OK;
 }
 
-// host rows [n][D] -> padded rows [n][DP]
+// host rows [n][D] -> device row image [n][DP]: padded, and for DP == 32 with dimension d at position row_pos(d)
+// (ptm_kernels.hpp: the MFMA accumulator layout)
+static inline size_t host_row_pos(size_t DP, size_t d) { return DP == 32 ? 8 * ((d >> 2) >> 1) + 2 * (d & 3) + ((d >> 2) & 1) : d; }
 static std::vector<double> pad_rows(const double* X, size_t n, size_t D, size_t DP) {
   std::vector<double> r(n * DP, 0.0);
   for (size_t c = 0; c < n; ++c)
-    for (size_t d = 0; d < D; ++d) r[c * DP + d] = X[c * D + d];
+    for (size_t d = 0; d < D; ++d) r[c * DP + host_row_pos(DP, d)] = X[c * D + d];
   return r;
 }
 static void unpad_rows(const std::vector<double>& r, size_t n, size_t D, size_t DP, double* X) {
   for (size_t c = 0; c < n; ++c)
-    for (size_t d = 0; d < D; ++d) X[c * D + d] = r[c * DP + d];
+    for (size_t d = 0; d < D; ++d) X[c * D + d] = r[c * DP + host_row_pos(DP, d)];
 }
 
 extern "C" int ptm_set_states(ptm_engine* e, const double* X, const double* llike) {
@@ -827,7 +872,8 @@ extern "C" const char* ptm_sweep_kernel_name(ptm_engine* e) {
   if (!e) return "";
   char b[96];
   const SweepSel s = sweep_sel(e);
-  snprintf(b, sizeof b, "sweep_kernel<%d, %d, %s, %s>", e->DP, s.kind, s.uni ? "true" : "false", s.simple ? "true" : "false");
+  if (e->DP == 32 && s.uni && s.simple && s.kind != KIND_DIAG) snprintf(b, sizeof b, "sweep_mfma32_kernel<%d>", s.kind);
+  else snprintf(b, sizeof b, "sweep_kernel<%d, %d, %s, %s>", e->DP, s.kind, s.uni ? "true" : "false", s.simple ? "true" : "false");
   e->kname = b;
   return e->kname.c_str();
 }

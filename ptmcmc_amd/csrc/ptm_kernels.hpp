@@ -76,7 +76,10 @@ struct Dev {
   // ladder + proposals
   const double* beta;      // [Nt] global
   const double* prop;      // [nloc][prop_stride]  factor, dense column-major [col][row] (DP*DP), or sigmas (DP)
-  const double* prop_dense;  // [nloc][DP*DP] dense column-major image (zeros above the diagonal) for the DPP product
+  // operand images of the MFMA kernel (DP == 32 only, ptm_mfma_kernel.hpp): 64-lane A tiles, and the box in row layout
+  const double* prop_tiles;  // [nloc][16][64]  tile (half*4 + slot)*2 + rowtile, lane 16k+i: T[16 rowtile + i][16 half + 4k + slot]
+  const double* P2_tiles;    // [16][64]        tile step*2 + rowtile, lane 16k+i: P2[16 rowtile + i][4 step + k] (lower, doubled)
+  const double* box_row;     // [2][32]         prior box lo | hi at row_pos
   const double* onedfrac;  // [nloc]
   int prop_stride, any_oned;
   // state (in place)
@@ -234,6 +237,17 @@ __device__ __forceinline__ void draw4(const DrawCtx& dc, int b, double (&z)[4]) 
     for (int t = 0; t < 4; ++t)
       if (4 * b + t != dc.axis) z[t] = 0.0;
   }
+}
+
+// Position of dimension d inside a stored row.  For DP == 32 rows are kept in the accumulator layout of the f64 MFMA
+// kernel: lane group q of a wave owns the eight dimensions d = q + 4m of a chain and moves them as four 16-byte
+// pieces {m = 2t, 2t+1}; piece t of lane group q sits at 16-byte slot 4t + q, so that ONE load instruction of the
+// chain's four lanes covers 64 contiguous bytes (a quarter of the row) instead of four scattered 16-byte pieces.
+// Every [n][DP] row image (states, proposals handed to a host callback, boundary messages) uses this layout; the
+// host converts on set / get.
+template <int DP>
+__device__ __forceinline__ constexpr int row_pos(int d) {
+  return DP == 32 ? 8 * ((d >> 2) >> 1) + 2 * (d & 3) + ((d >> 2) & 1) : d;
 }
 
 // Column order of the product (shared with the CPU checker and the MFMA kernel, whose tile steps fix it): natural for
@@ -423,7 +437,7 @@ __global__ __launch_bounds__(256, PTM_SWEEP_WAVES) void sweep_kernel(const Dev p
   double* __restrict__ row = p.x + (size_t)c * DP;
   if (mode != 2) {
 #pragma unroll
-    for (int d = 0; d < DP; ++d) xn[d] = row[d] + xn[d];  // state::add (states.cc:205-214)
+    for (int d = 0; d < DP; ++d) xn[d] = row[row_pos<DP>(d)] + xn[d];  // state::add (states.cc:205-214)
   }
   const double beta = as_c(p.beta)[rg];
   const double bl = beta * ll;
@@ -451,7 +465,7 @@ __global__ __launch_bounds__(256, PTM_SWEEP_WAVES) void sweep_kernel(const Dev p
     valid = (p.gate[c] & 1) != 0;
     newlprior = p.lprior_new[c];
 #pragma unroll
-    for (int d = 0; d < DP; ++d) xn[d] = p.xprop[(size_t)c * DP + d];
+    for (int d = 0; d < DP; ++d) xn[d] = p.xprop[(size_t)c * DP + row_pos<DP>(d)];
   } else {
     valid = p.origin_valid != 0;  // Q9: the sum is built on an enforced zero state
     newlprior = enforce_and_lprior<DP>(p, xn, valid);
@@ -460,7 +474,7 @@ __global__ __launch_bounds__(256, PTM_SWEEP_WAVES) void sweep_kernel(const Dev p
   if (mode == 1) {
     // propose pass: hand the proposal to the host, change nothing else
 #pragma unroll
-    for (int d = 0; d < DP; ++d) p.xprop[(size_t)c * DP + d] = xn[d];
+    for (int d = 0; d < DP; ++d) p.xprop[(size_t)c * DP + row_pos<DP>(d)] = xn[d];
     p.lprior_new[c] = newlprior;
     p.gate[c] = (unsigned char)((valid ? 1 : 0) | (want_like ? 2 : 0));
     return;
@@ -489,7 +503,7 @@ __global__ __launch_bounds__(256, PTM_SWEEP_WAVES) void sweep_kernel(const Dev p
     p.naccept[c] += 1;
     p.last_type[c] = type;
 #pragma unroll
-    for (int d = 0; d < DP; ++d) row[d] = xn[d];
+    for (int d = 0; d < DP; ++d) row[row_pos<DP>(d)] = xn[d];
     p.ll[c] = newlike;
     p.lp[c] = newlprior;
   }
@@ -505,11 +519,11 @@ __global__ __launch_bounds__(256) void evaluate_kernel(const Dev p, int n, doubl
   if (c >= n) return;
   double x[DP];
 #pragma unroll
-  for (int d = 0; d < DP; ++d) x[d] = x_io[(size_t)c * DP + d];
+  for (int d = 0; d < DP; ++d) x[d] = x_io[(size_t)c * DP + row_pos<DP>(d)];
   bool valid = true;  // state(space, values) constructor: valid unless enforce fails (states.cc:194-199)
   const double lp = enforce_and_lprior<DP>(p, x, valid);
 #pragma unroll
-  for (int d = 0; d < DP; ++d) x_io[(size_t)c * DP + d] = x[d];
+  for (int d = 0; d < DP; ++d) x_io[(size_t)c * DP + row_pos<DP>(d)] = x[d];
   if (valid_out) valid_out[c] = valid ? 1 : 0;
   lprior_out[c] = lp;
   if (eval_like) llike_out[c] = p.has_mean ? gauss_llike<DP, true>(p, x) : gauss_llike<DP, false>(p, x);
@@ -558,7 +572,7 @@ __global__ __launch_bounds__(256) void init_prior_kernel(const Dev p, double* x_
     if (!done) return;
   } else if (!done) atomicOr(fail, 1);
 #pragma unroll
-  for (int d = 0; d < DP; ++d) x_out[(size_t)c * DP + d] = x[d];
+  for (int d = 0; d < DP; ++d) x_out[(size_t)c * DP + row_pos<DP>(d)] = x[d];
   ll_out[c] = ll;
   lp_out[c] = lp;
 }

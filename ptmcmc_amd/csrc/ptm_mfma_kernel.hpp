@@ -1,0 +1,220 @@
+// ptm_mfma_kernel.hpp -- the hot kernel of the BASELINE workload: one fused MH_chain::step (chain.cc:966-1022) for a
+// 32-dimensional Gaussian target with a dense or Cholesky proposal factor per rung, uniform box prior, open bounds.
+// One wave = 64 chains of ONE rung (W % 64 == 0).  Both matrix products run on the f64 matrix cores
+// (v_mfma_f64_16x16x4_f64), the VALU is left with the random numbers:
+//
+//   offset (32 x 64) = T (32 x 32, the rung's factor)  x  Z (32 x 64 normals)          gaussian_prop::draw
+//   S      (32 x 64) = P2 (32 x 32, lower triangle of the precision, off-diagonal doubled) x X' (32 x 64 proposals)
+//   x'.S, reduced per chain                                                              the Gaussian log-likelihood
+//
+// Lane roles.  Lane l = 16q + j.  Per-chain scalars (llike, counters, the Metropolis test) belong to chain l of the
+// wave.  Matrix data follow the MFMA operand maps (A[i][k]: lane 16k+i; B[k][n]: lane 16k+n; D[q+4r][n]: lane 16q+n,
+// register r): for the four 16-chain groups g = 0..3 lane (q, j) works on chain 16g + j and on the eight dimensions
+// d = q (mod 4) -- its normals are Philox blocks q and 4+q of that chain's stream (dimensions 4q..4q+3 and
+// 16+4q..16+4q+3), and it holds x'[q + 4m], m = 0..7, which is why stored rows are laid out by (m/2, q, m%2)
+// (row_pos).  An accumulator tile is the next product's B operand as it stands: step m of S = P2 X' needs dimension
+// 4m + k on lane group k, and that is register m of the accumulators.  No lane ever moves data to another lane except
+// the final 4-way reduction of x'.S (through 2 KB of LDS per wave) and two ballots.
+//
+// The accumulation order of every sum is the one the CPU checker states (oracle/ptm_oracle.c: ptmo_column_order,
+// ptmo_llike): an f64 MFMA accumulates its four products as one fma chain in k order on top of C (measured:
+// tools/probes/mfma_f64_probe.hip), so results are bit-identical to the VALU kernels and to the checker.
+#pragma once
+#include "ptm_kernels.hpp"
+
+namespace ptm {
+
+typedef double mf_d4 __attribute__((ext_vector_type(4)));
+typedef double mf_d2 __attribute__((ext_vector_type(2)));
+
+// scheduling fence: nothing moves across it.  The kernel is written as stages ("issue loads" / "arithmetic that does
+// not need them yet"); left alone, the machine scheduler sinks every load next to its first use to save registers and
+// the wave then pays each HBM latency in full.
+#define PTM_STAGE() __builtin_amdgcn_sched_barrier(0)
+
+template <int KIND>
+__global__ __launch_bounds__(256, 3) void sweep_mfma32_kernel(const Dev p) {
+  constexpr int DP = 32;
+  constexpr bool LOW = KIND == KIND_LOWER;
+  // LDS: [512] Box-Muller table | [12][64] precision tiles (shared by the block's waves) | 128 doubles per wave
+  extern __shared__ __attribute__((aligned(16))) double lds_all[];
+  reinterpret_cast<bm_d2*>(lds_all)[threadIdx.x] = reinterpret_cast<const bm_d2*>(BM_TABLE)[threadIdx.x];
+  double* ptile = lds_all + 512;   // tile (row tile 1, step m) at m*64, m = 0..7; (row tile 0, step m) at (8+m)*64, m = 0..3
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    const int e = threadIdx.x + 256 * t, tile = e >> 6;
+    const int src = tile < 8 ? (tile * 2 + 1) : ((tile - 8) * 2 + 0);
+    ptile[e] = p.P2_tiles[src * 64 + (e & 63)];
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
+  const int c0 = (blockIdx.x * 4 + wave) * 64;   // first chain of the wave; Nc is a multiple of 64
+  if (c0 >= p.Nc) return;
+  double* red = lds_all + 512 + 12 * 64 + wave * 128;
+  const int rl = __builtin_amdgcn_readfirstlane(c0 / p.W);
+  const int w0 = c0 - rl * p.W;
+  const int rg = p.r0 + rl;
+  const int q = l >> 4, j = l & 15;
+  const int c = c0 + l;   // "my" chain for the per-chain work
+  const double* timg = p.prop_tiles + (size_t)rl * (16 * 64) + l;   // tile t = (half*4 + slot)*2 + row tile
+  const double* pimg = ptile + l;
+  const mf_d2* box = reinterpret_cast<const mf_d2*>(p.box_row) + q;   // lo piece t at 4t, hi piece t at 16 + 4t (row layout)
+
+  // per-chain scalars, asked for now and used at the very end
+  const int tc = p.touch[c];  // > 0: the rung took part in that many exchange attempts => no MH move this step
+  const double ll = p.ll[c], lp = p.lp[c];
+  const double beta = as_c(p.beta)[rg];
+
+  // The wave's 64 chains are worked in two passes of two 16-chain groups (g = 2 gp + gg): every live set is halved.
+#pragma unroll
+  for (int gp = 0; gp < 2; ++gp) {
+    // ---- stage 1: ask for the two groups' rows and the first half's factor tiles
+    mf_d2 rowv[2][4];
+    mf_d2* rowp[2];
+#pragma unroll
+    for (int gg = 0; gg < 2; ++gg) {
+      rowp[gg] = reinterpret_cast<mf_d2*>(p.x + (size_t)(c0 + 16 * (2 * gp + gg) + j) * DP) + q;   // piece t at [4t]
+#pragma unroll
+      for (int t = 0; t < 4; ++t) rowv[gg][t] = rowp[gg][4 * t];
+    }
+    double ta[4][2];
+#pragma unroll
+    for (int sl = 0; sl < 4; ++sl) {
+      ta[sl][0] = timg[((0 * 4 + sl) * 2 + 0) * 64];
+      ta[sl][1] = timg[((0 * 4 + sl) * 2 + 1) * 64];
+    }
+    PTM_STAGE();
+    // ---- stage 2: T x Z, one 16-column half at a time (the half's normals: one Philox block per chain)
+    mf_d4 acc[2][2];
+#pragma unroll
+    for (int gg = 0; gg < 2; ++gg) {
+      acc[gg][0] = mf_d4{0.0, 0.0, 0.0, 0.0};
+      acc[gg][1] = mf_d4{0.0, 0.0, 0.0, 0.0};
+    }
+    double tb[4][2];
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb) {
+      double z[2][4];
+#pragma unroll
+      for (int gg = 0; gg < 2; ++gg) {
+        const uint32_t stream = (uint32_t)(w0 + 16 * (2 * gp + gg) + j) * (uint32_t)p.Nt + (uint32_t)rg;
+        const u32x4 o = draw_block(p.seed, TAG_MH, stream, p.step, (uint32_t)(1 + 4 * hb + q));
+        boxmuller(o.v0, o.v1, (const double*)lds_all, z[gg][0], z[gg][1]);
+        boxmuller(o.v2, o.v3, (const double*)lds_all, z[gg][2], z[gg][3]);
+        PTM_STAGE();   // one chain's draw at a time: the temporaries of two interleaved draws cost 40 registers
+      }
+#pragma unroll
+      for (int sl = 0; sl < 4; ++sl) {
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+          if (LOW && hb == 1 && rt == 0) continue;   // columns >= 16 never reach rows < 16
+          const double a = hb == 0 ? ta[sl][rt] : tb[sl][rt];
+#pragma unroll
+          for (int gg = 0; gg < 2; ++gg) acc[gg][rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, z[gg][sl], acc[gg][rt], 0, 0, 0);
+        }
+      }
+      if (hb == 0) {   // ask for the second half's tiles while the second half's normals are drawn
+#pragma unroll
+        for (int sl = 0; sl < 4; ++sl) {
+          tb[sl][0] = LOW ? 0.0 : timg[((1 * 4 + sl) * 2 + 0) * 64];
+          tb[sl][1] = timg[((1 * 4 + sl) * 2 + 1) * 64];
+        }
+      }
+      PTM_STAGE();
+    }
+    // ---- stage 3: x' = x + offset (state::add, states.cc:205-214); the prior's box
+    double xp[2][8];
+    uint64_t inbox = 0;   // bit 16 gg + j: chain (2 gp + gg, j) is inside the box
+#pragma unroll
+    for (int gg = 0; gg < 2; ++gg) {
+      bool ok = true;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const mf_d2 v = rowv[gg][t], lo = box[4 * t], hi = box[16 + 4 * t];
+        const int m = 2 * t;   // registers m, m+1 <-> dimensions q + 4m, q + 4m + 4
+        xp[gg][m] = v.x + acc[gg][m >> 2][m & 3];
+        xp[gg][m + 1] = v.y + acc[gg][(m + 1) >> 2][(m + 1) & 3];
+        ok = ok & !(xp[gg][m] < lo.x) & !(xp[gg][m] > hi.x) & !(xp[gg][m + 1] < lo.y) & !(xp[gg][m + 1] > hi.y);
+      }
+      uint64_t b = __builtin_amdgcn_ballot_w64(ok);
+      b &= b >> 32;
+      b &= b >> 16;                                  // bit jj: all four lanes (q, jj) of chain (g, jj) are inside
+      inbox |= (b & 0xFFFFull) << (16 * gg);
+    }
+    // ---- stage 4: S = P2 x X' and the four partial dot products of each chain
+    mf_d4 sacc[2][2];
+#pragma unroll
+    for (int gg = 0; gg < 2; ++gg) {
+      sacc[gg][0] = mf_d4{0.0, 0.0, 0.0, 0.0};
+      sacc[gg][1] = mf_d4{0.0, 0.0, 0.0, 0.0};
+    }
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+        if (rt == 0 && m >= 4) continue;
+        const double a = pimg[(rt ? m : 8 + m) * 64];
+#pragma unroll
+        for (int gg = 0; gg < 2; ++gg) sacc[gg][rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, xp[gg][m], sacc[gg][rt], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int gg = 0; gg < 2; ++gg) {
+      double pq = 0.0;
+#pragma unroll
+      for (int m = 0; m < 8; ++m) pq = __builtin_fma(xp[gg][m], sacc[gg][m >> 2][m & 3], pq);
+      // chain (g, j)'s four partial sums sit on lanes (0..3, j): hand them to lane 16 g + j through this wave's LDS
+      red[(gg * 4 + q) * 16 + j] = pq;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- stage 5, lanes 32 gp .. 32 gp + 31 (chain = lane): Metropolis test and add_state counters
+    //      (chain.cc:973-1019, 916-949)
+    bool accept = false;
+    if ((q >> 1) == gp) {
+      const double* mine = red + ((q & 1) * 4) * 16 + j;
+      const double quad = ((mine[0] + mine[16]) + mine[32]) + mine[48];
+      if (tc) {
+        p.nhist[c] += (unsigned int)tc;
+        p.touch[c] = 0;
+      } else {
+        const double bl = beta * ll;
+        const double cur_lpost = lp + bl;
+        const double oldlprior = cur_lpost - bl;  // chain.cc:973
+        const bool in = ((inbox >> (l & 31)) & 1ull) != 0;
+        const double newlprior = in ? p.lprior_const : -__builtin_inf();
+        const bool want_like = newlprior > -1e200 || newlprior - oldlprior > p.min_prior;  // chain.cc:980 (Q1)
+        double newlike = p.like0 - 0.5 * quad;
+        double newlpost = newlike * beta + newlprior;
+        if (!want_like) newlike = newlpost = -__builtin_inf();
+        const double logH = newlpost - cur_lpost;
+        accept = true;
+        if (logH < 0) {
+          const uint32_t stream = (uint32_t)(w0 + l) * (uint32_t)p.Nt + (uint32_t)rg;
+          const u32x4 o0 = draw_block(p.seed, TAG_MH, stream, p.step, 0);
+          accept = dlog_u01(o0.v0) < logH;  // chain.cc:998-1001 (NaN stays accepted)
+        }
+        p.ntries[c] += 1;
+        p.nhist[c] += 1u;
+        if (accept) {
+          p.naccept[c] += 1;
+          p.last_type[c] = 0;
+          p.ll[c] = newlike;
+          p.lp[c] = newlprior;
+        }
+      }
+    }
+    // ---- accepted proposals replace their rows; each of a chain's four lanes writes its 64 bytes
+    const uint64_t acc_bits = __builtin_amdgcn_ballot_w64(accept) >> (32 * gp);
+#pragma unroll
+    for (int gg = 0; gg < 2; ++gg) {
+      if ((acc_bits >> (16 * gg + j)) & 1ull) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) rowp[gg][4 * t] = mf_d2{xp[gg][2 * t], xp[gg][2 * t + 1]};
+      }
+    }
+    __builtin_amdgcn_wave_barrier();   // the next pass reuses the LDS slots
+  }
+}
+#undef PTM_STAGE
+
+}  // namespace ptm
