@@ -36,7 +36,8 @@ template <int KIND>
 __global__ __launch_bounds__(256, 3) void sweep_mfma32_kernel(const Dev p) {
   constexpr int DP = 32;
   constexpr bool LOW = KIND == KIND_LOWER;
-  // LDS: [512] Box-Muller table | [12][64] precision tiles (shared by the block's waves) | 128 doubles per wave
+  // LDS: [512] Box-Muller table | [12][64] precision tiles | [64] prior box (all shared by the block's waves) |
+  //      128 doubles per wave
   extern __shared__ __attribute__((aligned(16))) double lds_all[];
   reinterpret_cast<bm_d2*>(lds_all)[threadIdx.x] = reinterpret_cast<const bm_d2*>(BM_TABLE)[threadIdx.x];
   double* ptile = lds_all + 512;   // tile (row tile 1, step m) at m*64, m = 0..7; (row tile 0, step m) at (8+m)*64, m = 0..3
@@ -46,11 +47,13 @@ __global__ __launch_bounds__(256, 3) void sweep_mfma32_kernel(const Dev p) {
     const int src = tile < 8 ? (tile * 2 + 1) : ((tile - 8) * 2 + 0);
     ptile[e] = p.P2_tiles[src * 64 + (e & 63)];
   }
+  double* lbox = ptile + 12 * 64;
+  if (threadIdx.x < 64) lbox[threadIdx.x] = p.box_row[threadIdx.x];
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
   const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
   const int c0 = (blockIdx.x * 4 + wave) * 64;   // first chain of the wave; Nc is a multiple of 64
   if (c0 >= p.Nc) return;
-  double* red = lds_all + 512 + 12 * 64 + wave * 128;
+  double* red = lbox + 64 + wave * 128;
   const int rl = __builtin_amdgcn_readfirstlane(c0 / p.W);
   const int w0 = c0 - rl * p.W;
   const int rg = p.r0 + rl;
@@ -58,12 +61,19 @@ __global__ __launch_bounds__(256, 3) void sweep_mfma32_kernel(const Dev p) {
   const int c = c0 + l;   // "my" chain for the per-chain work
   const double* timg = p.prop_tiles + (size_t)rl * (16 * 64) + l;   // tile t = (half*4 + slot)*2 + row tile
   const double* pimg = ptile + l;
-  const mf_d2* box = reinterpret_cast<const mf_d2*>(p.box_row) + q;   // lo piece t at 4t, hi piece t at 16 + 4t (row layout)
+  const mf_d2* box = reinterpret_cast<const mf_d2*>(lbox) + q;   // lo piece t at 4t, hi piece t at 16 + 4t (row layout)
 
-  // per-chain scalars, asked for now and used at the very end
-  const int tc = p.touch[c];  // > 0: the rung took part in that many exchange attempts => no MH move this step
-  const double ll = p.ll[c], lp = p.lp[c];
+  // per-chain scalars: asked for right after the first rows, used at the very end
+  int tc = 0, ntries0 = 0, naccept0 = 0;   // tc > 0: the rung took part in that many exchange attempts => no MH move
+  unsigned int nhist0 = 0;
+  double ll = 0, lp = 0;
   const double beta = as_c(p.beta)[rg];
+  auto load_scalars = [&]() {
+    tc = p.touch[c];
+    ll = p.ll[c]; lp = p.lp[c];
+    ntries0 = p.ntries[c]; naccept0 = p.naccept[c];
+    nhist0 = p.nhist[c];
+  };
 
   // The wave's 64 chains are worked in two passes of two 16-chain groups (g = 2 gp + gg): every live set is halved.
 #pragma unroll
@@ -83,6 +93,8 @@ __global__ __launch_bounds__(256, 3) void sweep_mfma32_kernel(const Dev p) {
       ta[sl][0] = timg[((0 * 4 + sl) * 2 + 0) * 64];
       ta[sl][1] = timg[((0 * 4 + sl) * 2 + 1) * 64];
     }
+    PTM_STAGE();
+    if (gp == 0) load_scalars();
     PTM_STAGE();
     // ---- stage 2: T x Z, one 16-column half at a time (the half's normals: one Philox block per chain)
     mf_d4 acc[2][2];
@@ -174,7 +186,7 @@ __global__ __launch_bounds__(256, 3) void sweep_mfma32_kernel(const Dev p) {
       const double* mine = red + ((q & 1) * 4) * 16 + j;
       const double quad = ((mine[0] + mine[16]) + mine[32]) + mine[48];
       if (tc) {
-        p.nhist[c] += (unsigned int)tc;
+        p.nhist[c] = nhist0 + (unsigned int)tc;
         p.touch[c] = 0;
       } else {
         const double bl = beta * ll;
@@ -193,10 +205,10 @@ __global__ __launch_bounds__(256, 3) void sweep_mfma32_kernel(const Dev p) {
           const u32x4 o0 = draw_block(p.seed, TAG_MH, stream, p.step, 0);
           accept = dlog_u01(o0.v0) < logH;  // chain.cc:998-1001 (NaN stays accepted)
         }
-        p.ntries[c] += 1;
-        p.nhist[c] += 1u;
+        p.ntries[c] = ntries0 + 1;
+        p.nhist[c] = nhist0 + 1u;
         if (accept) {
-          p.naccept[c] += 1;
+          p.naccept[c] = naccept0 + 1;
           p.last_type[c] = 0;
           p.ll[c] = newlike;
           p.lp[c] = newlprior;
