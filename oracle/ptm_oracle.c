@@ -187,17 +187,23 @@ double ptmo_bm_neg2log(uint32_t k) {
   return fma(dk, M2LN2_HI, A) + fma(dk, M2LN2_LO, l);
 }
 
-/* Box-Muller on two 32-bit draws.  r = sqrt(-2 ln u1) (IEEE sqrt), theta = 2 pi (k2+.5)/2^32 reduced exactly
- * (integer arithmetic) to an octant and an angle in (0, pi/4). */
+/* Box-Muller on two 32-bit draws.  r = sqrt(-2 ln u1) (IEEE sqrt).  theta = 2 pi (k2+.5)/2^32: bit 31 of k2 is the
+ * half turn (sign of r), bits 30..21 select {sin a_i, cos a_i}, a_i = (i+.5) pi/1024, from the generated table, the low
+ * 21 bits give delta = theta - a_i (|delta| <= pi/2048), added with
+ *   sin(a+d) = S + (S (cos d - 1) + C sin d),  cos(a+d) = C + (C (cos d - 1) - S sin d),
+ *   sin d = d + d^3 (-1/6 + d^2/120),  cos d - 1 = d^2 (-1/2 + d^2/24). */
+static const double trig_table[2048] = {PTM_TRIGTAB_VALUES};
 void ptmo_boxmuller(uint32_t k1, uint32_t k2, double* z0, double* z1) {
   double r = sqrt(ptmo_bm_neg2log(k1));
-  uint32_t q = k2 >> 29, m = k2 & 0x1FFFFFFFu;
-  if (q & 1u) m ^= 0x1FFFFFFFu;
-  double phi = ((double)m + 0.5) * 1.4629180792671596e-09; /* (pi/4) * 2^-29 = 0x1.921fb54442d18p-30 */
-  double sn = sin_k(phi), cs = cos_k(phi);
-  if (((q + 1u) >> 1) & 1u) { double t = sn; sn = cs; cs = t; }
-  if (((q + 2u) >> 2) & 1u) cs = -cs;
-  if (q >> 2) sn = -sn;
+  uint32_t idx = (k2 >> 21) & 1023u;
+  double S = trig_table[2 * idx], C = trig_table[2 * idx + 1];
+  double d = ((double)((int)(k2 & 0x1FFFFFu) - (1 << 20)) + 0.5) * 1.4629180792671596e-09; /* 2 pi / 2^32 = 0x1.921fb54442d18p-30 */
+  double d2 = d * d;
+  double sd = fma(d * d2, fma(d2, 1.0 / 120.0, -1.0 / 6.0), d);
+  double cm1 = d2 * fma(d2, 1.0 / 24.0, -0.5);
+  double sn = fma(C, sd, S * cm1) + S;
+  double cs = fma(-S, sd, C * cm1) + C;
+  if (k2 >> 31) r = -r;
   *z0 = r * cs;
   *z1 = r * sn;
 }

@@ -196,7 +196,10 @@ __device__ __forceinline__ double dsqrt(double a) {
 // arguments on the GPU to prove it equal to the correctly rounded dsqrt() -- the CPU checker calls sqrt().
 // ------------------------------------------------------------------------------------------------
 #include "ptm_tables.inc"
-__device__ __attribute__((aligned(16))) const double BM_TABLE[512] = {PTM_BMTAB_VALUES};   // per translation unit; the sweep kernel stages it in LDS
+// One table image, staged whole into LDS by the sweep kernels: [0, 512) the radius table, [512, 2560) the angle table
+// {sin a_i, cos a_i}, a_i = (i + 0.5) pi / 1024.
+constexpr int BM_TABLE_DOUBLES = 512 + 2048;
+__device__ __attribute__((aligned(16))) const double BM_TABLE[BM_TABLE_DOUBLES] = {PTM_BMTAB_VALUES, PTM_TRIGTAB_VALUES};
 
 typedef double bm_d2 __attribute__((ext_vector_type(2)));
 
@@ -236,17 +239,22 @@ __device__ __forceinline__ double bm_sqrt(double a) {
   return g;
 }
 
-template <class Tab>
+// The angle theta = 2 pi (k2 + 0.5) / 2^32: bit 31 of k2 is the half turn (a sign flip of the radius), bits 30..21
+// pick the table interval, and the low 21 bits give delta = theta - a_i, |delta| <= pi/2048, added with
+//   sin(a+d) = S + (S (cos d - 1) + C sin d),   cos(a+d) = C + (C (cos d - 1) - S sin d),
+//   sin d = d + d^3 (-1/6 + d^2/120),  cos d - 1 = d^2 (-1/2 + d^2/24)        (truncation < 2^-65).
+template <class Tab>   // Tab: pointer to the BM_TABLE image (LDS or global)
 __device__ __forceinline__ void boxmuller(uint32_t k1, uint32_t k2, Tab tab, double& z0, double& z1) {
-  const double r = bm_sqrt(bm_neg2log(k1, tab));
-  const uint32_t q = k2 >> 29;
-  uint32_t m = k2 & 0x1FFFFFFFu;
-  if (q & 1u) m ^= 0x1FFFFFFFu;
-  const double phi = ((double)m + 0.5) * 1.4629180792671596e-09;  // (pi/4) * 2^-29
-  double sn = sin_k(phi), cs = cos_k(phi);
-  if (((q + 1u) >> 1) & 1u) { const double t = sn; sn = cs; cs = t; }
-  if (((q + 2u) >> 2) & 1u) cs = -cs;
-  if (q >> 2) sn = -sn;
+  double r = bm_sqrt(bm_neg2log(k1, tab));
+  const uint32_t idx = (k2 >> 21) & 1023u;
+  const bm_d2 sc = *reinterpret_cast<const bm_d2*>(tab + 512 + 2 * idx);
+  const double d = ((double)((int)(k2 & 0x1FFFFFu) - (1 << 20)) + 0.5) * 1.4629180792671596e-09;  // 2 pi / 2^32
+  const double d2 = d * d;
+  const double sd = __builtin_fma(d * d2, __builtin_fma(d2, 1.0 / 120.0, -1.0 / 6.0), d);
+  const double cm1 = d2 * __builtin_fma(d2, 1.0 / 24.0, -0.5);
+  const double sn = __builtin_fma(sc.y, sd, sc.x * cm1) + sc.x;
+  const double cs = __builtin_fma(-sc.x, sd, sc.y * cm1) + sc.y;
+  r = __longlong_as_double(__double_as_longlong(r) ^ ((long long)(k2 >> 31) << 63));
   z0 = r * cs;
   z1 = r * sn;
 }

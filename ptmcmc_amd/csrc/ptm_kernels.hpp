@@ -361,10 +361,12 @@ __global__ __launch_bounds__(256, PTM_SWEEP_WAVES) void sweep_kernel(const Dev p
   // Per-wave LDS staging of the rung's proposal factor (UNI only): every rung has its own D x D factor, so unlike
   // the shared precision matrix it misses the scalar cache; one coalesced 512-B-per-instruction copy into LDS per
   // wave, then wave-uniform (broadcast) LDS reads feed the mat-vec.  Same-wave LDS traffic only: no barrier.
-  // The first 4 KB of the block's LDS hold the Box-Muller radius table (per-lane gathers, one 16-byte entry per draw).
+  // The first 20 KB of the block's LDS hold the Box-Muller tables (per-lane gathers, one 16-byte entry per draw each).
   extern __shared__ __attribute__((aligned(16))) double lds_all[];
-  double* lds_fac = lds_all + 512;
-  reinterpret_cast<bm_d2*>(lds_all)[threadIdx.x] = reinterpret_cast<const bm_d2*>(BM_TABLE)[threadIdx.x];
+  double* lds_fac = lds_all + BM_TABLE_DOUBLES;
+#pragma unroll
+  for (int t = 0; t < BM_TABLE_DOUBLES / 512; ++t)
+    reinterpret_cast<bm_d2*>(lds_all)[threadIdx.x + 256 * t] = reinterpret_cast<const bm_d2*>(BM_TABLE)[threadIdx.x + 256 * t];
   const int c = blockIdx.x * 256 + threadIdx.x;
   int rl = (c < p.Nc ? c : p.Nc - 1) / p.W;
   if (UNI) rl = __builtin_amdgcn_readfirstlane(rl);

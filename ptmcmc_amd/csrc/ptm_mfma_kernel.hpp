@@ -32,69 +32,82 @@ typedef double mf_d2 __attribute__((ext_vector_type(2)));
 // the wave then pays each HBM latency in full.
 #define PTM_STAGE() __builtin_amdgcn_sched_barrier(0)
 
+#ifndef PTM_MFMA_WAVES
+#define PTM_MFMA_WAVES 3   // waves per SIMD the register budget is cut for
+#endif
 template <int KIND>
-__global__ __launch_bounds__(256, 3) void sweep_mfma32_kernel(const Dev p) {
+__global__ __launch_bounds__(256, PTM_MFMA_WAVES) void sweep_mfma32_kernel(const Dev p) {
   constexpr int DP = 32;
   constexpr bool LOW = KIND == KIND_LOWER;
-  // LDS: [512] Box-Muller table | [12][64] precision tiles | [64] prior box (all shared by the block's waves) |
+  // LDS: [2560] Box-Muller tables | [12][64] precision tiles | [64] prior box (all shared by the block's waves) |
   //      128 doubles per wave
   extern __shared__ __attribute__((aligned(16))) double lds_all[];
-  reinterpret_cast<bm_d2*>(lds_all)[threadIdx.x] = reinterpret_cast<const bm_d2*>(BM_TABLE)[threadIdx.x];
-  double* ptile = lds_all + 512;   // tile (row tile 1, step m) at m*64, m = 0..7; (row tile 0, step m) at (8+m)*64, m = 0..3
-#pragma unroll
-  for (int t = 0; t < 3; ++t) {
-    const int e = threadIdx.x + 256 * t, tile = e >> 6;
-    const int src = tile < 8 ? (tile * 2 + 1) : ((tile - 8) * 2 + 0);
-    ptile[e] = p.P2_tiles[src * 64 + (e & 63)];
-  }
+  double* ptile = lds_all + BM_TABLE_DOUBLES;   // tile (row tile 1, step m) at m*64, m = 0..7; (row tile 0, step m) at (8+m)*64, m = 0..3
   double* lbox = ptile + 12 * 64;
-  if (threadIdx.x < 64) lbox[threadIdx.x] = p.box_row[threadIdx.x];
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
   const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
   const int c0 = (blockIdx.x * 4 + wave) * 64;   // first chain of the wave; Nc is a multiple of 64
-  if (c0 >= p.Nc) return;
+  const bool live = c0 < p.Nc;                    // (a wave past the end still helps to stage the tables)
+  const int c0s = live ? c0 : 0;
   double* red = lbox + 64 + wave * 128;
-  const int rl = __builtin_amdgcn_readfirstlane(c0 / p.W);
-  const int w0 = c0 - rl * p.W;
+  const int rl = __builtin_amdgcn_readfirstlane(c0s / p.W);
+  const int w0 = c0s - rl * p.W;
   const int rg = p.r0 + rl;
   const int q = l >> 4, j = l & 15;
-  const int c = c0 + l;   // "my" chain for the per-chain work
+  const int c = c0s + l;   // "my" chain for the per-chain work
   const double* timg = p.prop_tiles + (size_t)rl * (16 * 64) + l;   // tile t = (half*4 + slot)*2 + row tile
   const double* pimg = ptile + l;
   const mf_d2* box = reinterpret_cast<const mf_d2*>(lbox) + q;   // lo piece t at 4t, hi piece t at 16 + 4t (row layout)
 
-  // per-chain scalars: asked for right after the first rows, used at the very end
-  int tc = 0, ntries0 = 0, naccept0 = 0;   // tc > 0: the rung took part in that many exchange attempts => no MH move
-  unsigned int nhist0 = 0;
-  double ll = 0, lp = 0;
-  const double beta = as_c(p.beta)[rg];
-  auto load_scalars = [&]() {
-    tc = p.touch[c];
-    ll = p.ll[c]; lp = p.lp[c];
-    ntries0 = p.ntries[c]; naccept0 = p.naccept[c];
-    nhist0 = p.nhist[c];
-  };
-
-  // The wave's 64 chains are worked in two passes of two 16-chain groups (g = 2 gp + gg): every live set is halved.
+  // The block's tables are read first, the wave's first rows / tiles / scalars right behind them -- all in flight
+  // together; the tables then go to LDS and the block meets once.
+  bm_d2 st_bm[BM_TABLE_DOUBLES / 512];
 #pragma unroll
-  for (int gp = 0; gp < 2; ++gp) {
-    // ---- stage 1: ask for the two groups' rows and the first half's factor tiles
-    mf_d2 rowv[2][4];
-    mf_d2* rowp[2];
+  for (int t = 0; t < BM_TABLE_DOUBLES / 512; ++t) st_bm[t] = reinterpret_cast<const bm_d2*>(BM_TABLE)[threadIdx.x + 256 * t];
+  double st_p[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    const int e = threadIdx.x + 256 * t, tile = e >> 6;
+    const int src = tile < 8 ? (tile * 2 + 1) : ((tile - 8) * 2 + 0);
+    st_p[t] = p.P2_tiles[src * 64 + (e & 63)];
+  }
+  const double st_box = p.box_row[threadIdx.x & 63];
+
+  // A tile's 64 chains are worked in two passes of two 16-chain groups (g = 2 gp + gg): every live set is halved.
+  mf_d2 rowv[2][4];   // the pass's rows, asked for one pass ahead
+  mf_d2* rowp[2];
+  auto ask_rows = [&](int gpp, mf_d2 (&rv)[2][4], mf_d2* (&rp)[2]) {
 #pragma unroll
     for (int gg = 0; gg < 2; ++gg) {
-      rowp[gg] = reinterpret_cast<mf_d2*>(p.x + (size_t)(c0 + 16 * (2 * gp + gg) + j) * DP) + q;   // piece t at [4t]
+      rp[gg] = reinterpret_cast<mf_d2*>(p.x + (size_t)(c0s + 16 * (2 * gpp + gg) + j) * DP) + q;   // piece t at [4t]
 #pragma unroll
-      for (int t = 0; t < 4; ++t) rowv[gg][t] = rowp[gg][4 * t];
+      for (int t = 0; t < 4; ++t) rv[gg][t] = rp[gg][4 * t];
     }
+  };
+  ask_rows(0, rowv, rowp);
+  // per-chain scalars: used at the very end
+  const int tc = p.touch[c];  // > 0: the rung took part in that many exchange attempts => no MH move this step
+  const double ll = p.ll[c], lp = p.lp[c];
+  const int ntries0 = p.ntries[c], naccept0 = p.naccept[c];
+  const unsigned int nhist0 = p.nhist[c];
+  const double beta = as_c(p.beta)[rg];
+
+#pragma unroll
+  for (int t = 0; t < BM_TABLE_DOUBLES / 512; ++t) reinterpret_cast<bm_d2*>(lds_all)[threadIdx.x + 256 * t] = st_bm[t];
+#pragma unroll
+  for (int t = 0; t < 3; ++t) ptile[threadIdx.x + 256 * t] = st_p[t];
+  if (threadIdx.x < 64) lbox[threadIdx.x] = st_box;
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  if (!live) return;
+
+#pragma unroll
+  for (int gp = 0; gp < 2; ++gp) {
+    // ---- stage 1: ask for the first half's factor tiles (L2-resident; behind them the first draw)
     double ta[4][2];
 #pragma unroll
     for (int sl = 0; sl < 4; ++sl) {
       ta[sl][0] = timg[((0 * 4 + sl) * 2 + 0) * 64];
       ta[sl][1] = timg[((0 * 4 + sl) * 2 + 1) * 64];
     }
-    PTM_STAGE();
-    if (gp == 0) load_scalars();
     PTM_STAGE();
     // ---- stage 2: T x Z, one 16-column half at a time (the half's normals: one Philox block per chain)
     mf_d4 acc[2][2];
@@ -111,8 +124,14 @@ __global__ __launch_bounds__(256, 3) void sweep_mfma32_kernel(const Dev p) {
       for (int gg = 0; gg < 2; ++gg) {
         const uint32_t stream = (uint32_t)(w0 + 16 * (2 * gp + gg) + j) * (uint32_t)p.Nt + (uint32_t)rg;
         const u32x4 o = draw_block(p.seed, TAG_MH, stream, p.step, (uint32_t)(1 + 4 * hb + q));
+#if defined(PTM_ABLATE) && (PTM_ABLATE & 1)   // timing experiment: no Box-Muller
+        z[gg][0] = u01(o.v0); z[gg][1] = u01(o.v1); z[gg][2] = u01(o.v2); z[gg][3] = u01(o.v3);
+#elif defined(PTM_ABLATE) && (PTM_ABLATE & 8)  // timing experiment: no random numbers at all
+        z[gg][0] = 0.1 * q; z[gg][1] = 0.2; z[gg][2] = 0.3 * j; z[gg][3] = 0.4 + (double)stream * 0;
+#else
         boxmuller(o.v0, o.v1, (const double*)lds_all, z[gg][0], z[gg][1]);
         boxmuller(o.v2, o.v3, (const double*)lds_all, z[gg][2], z[gg][3]);
+#endif
         PTM_STAGE();   // one chain's draw at a time: the temporaries of two interleaved draws cost 40 registers
       }
 #pragma unroll
@@ -122,7 +141,13 @@ __global__ __launch_bounds__(256, 3) void sweep_mfma32_kernel(const Dev p) {
           if (LOW && hb == 1 && rt == 0) continue;   // columns >= 16 never reach rows < 16
           const double a = hb == 0 ? ta[sl][rt] : tb[sl][rt];
 #pragma unroll
-          for (int gg = 0; gg < 2; ++gg) acc[gg][rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, z[gg][sl], acc[gg][rt], 0, 0, 0);
+          for (int gg = 0; gg < 2; ++gg) {
+#if defined(PTM_ABLATE) && (PTM_ABLATE & 2)   // timing experiment: no T x Z
+            acc[gg][rt][sl] += a * z[gg][sl];
+#else
+            acc[gg][rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, z[gg][sl], acc[gg][rt], 0, 0, 0);
+#endif
+          }
         }
       }
       if (hb == 0) {   // ask for the second half's tiles while the second half's normals are drawn
@@ -153,6 +178,12 @@ __global__ __launch_bounds__(256, 3) void sweep_mfma32_kernel(const Dev p) {
       b &= b >> 16;                                  // bit jj: all four lanes (q, jj) of chain (g, jj) are inside
       inbox |= (b & 0xFFFFull) << (16 * gg);
     }
+    PTM_STAGE();
+    // the second pass's rows are asked for here: the registers of the first pass's rows have just been freed
+    mf_d2 rown[2][4];
+    mf_d2* rowpn[2] = {rowp[0], rowp[1]};
+    if (gp == 0) ask_rows(1, rown, rowpn);
+    PTM_STAGE();
     // ---- stage 4: S = P2 x X' and the four partial dot products of each chain
     mf_d4 sacc[2][2];
 #pragma unroll
@@ -167,7 +198,13 @@ __global__ __launch_bounds__(256, 3) void sweep_mfma32_kernel(const Dev p) {
         if (rt == 0 && m >= 4) continue;
         const double a = pimg[(rt ? m : 8 + m) * 64];
 #pragma unroll
-        for (int gg = 0; gg < 2; ++gg) sacc[gg][rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, xp[gg][m], sacc[gg][rt], 0, 0, 0);
+        for (int gg = 0; gg < 2; ++gg) {
+#if defined(PTM_ABLATE) && (PTM_ABLATE & 4)   // timing experiment: no P2 x X'
+          sacc[gg][rt][m & 3] += a * xp[gg][m];
+#else
+          sacc[gg][rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, xp[gg][m], sacc[gg][rt], 0, 0, 0);
+#endif
+        }
       }
     }
 #pragma unroll
@@ -225,6 +262,14 @@ __global__ __launch_bounds__(256, 3) void sweep_mfma32_kernel(const Dev p) {
       }
     }
     __builtin_amdgcn_wave_barrier();   // the next pass reuses the LDS slots
+    if (gp == 0) {
+#pragma unroll
+      for (int gg = 0; gg < 2; ++gg) {
+        rowp[gg] = rowpn[gg];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) rowv[gg][t] = rown[gg][t];
+      }
+    }
   }
 }
 #undef PTM_STAGE
