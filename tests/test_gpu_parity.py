@@ -129,7 +129,9 @@ SWEEP_CASES = [
     (16, 64, 1, 1e4, E.PROP_LOWER, None),    # C2
     (32, 256, 4, 1e6, E.PROP_LOWER, None),   # C3
     (32, 16, 64, 1e6, E.PROP_LOWER, None),   # wave-uniform rung path
-    (32, 8, 128, 1e3, E.PROP_DENSE, None),
+    (32, 8, 128, 1e3, E.PROP_DENSE, None),   # MFMA kernel, dense factor tiles
+    (21, 6, 64, 1e3, E.PROP_LOWER, None),    # MFMA kernel with 11 pad dimensions (21 -> 32)
+    (27, 5, 192, 1e2, E.PROP_DENSE, None),
     (16, 12, 64, 1e3, E.PROP_DIAG, 0.5),     # the sampler's default Gaussian flavour: diagonal + 1-D moves
     (5, 7, 3, 1e2, E.PROP_DENSE, 0.3),       # padded dimension (5 -> 8), ragged sizes
     (3, 5, 70, 1e2, E.PROP_DIAG, None),      # W not a multiple of 64
@@ -170,6 +172,24 @@ def test_pt_steps_bit_exact(D, Nt, W, tmax, kind, odf):
     t, a = eng.swap_counts()
     assert np.array_equal(t, lad.swap_count) and np.array_equal(a, lad.swap_accept_count)
     assert nacc > 0
+    eng.close()
+
+
+def test_mfma_kernel_with_a_tight_prior_box():
+    """The MFMA kernel's box test (ballots over the four lanes of a chain): a uniform prior so narrow that a large share
+    of the proposals leaves it on some dimension; accept stream, states and counters must still match the oracle."""
+    D, Nt, W = 32, 6, 128
+    rng = np.random.default_rng(12)
+    prior = ([1] * D, list(rng.uniform(-0.2, 0.2, D)), list(rng.uniform(0.8, 1.6, D)))   # uniform: centers, halfwidths
+    pr, eng, lad = PU.make_pair(D, Nt, W, 1e4, kind=E.PROP_LOWER, prior=prior, swap_rate=0.3)
+    assert "mfma" in eng.sweep_kernel_name
+    for k in range(10):
+        eng.step(2); eng.sync()
+        lad.pt_step(2)
+        PU.assert_same_state(eng, lad, "after PT step %d" % (2 * (k + 1)))
+    tries = eng.ntries.sum() - eng.Nc
+    acc = eng.naccept.sum() - eng.Nc
+    assert 0 < acc < 0.8 * tries          # the box (and the target) reject a good share
     eng.close()
 
 
