@@ -5,7 +5,7 @@
 namespace ptm {
 
 // ------------------------------------------------------------------------------------------------
-// exchange phase of parallel_tempering_chains::step (chain.cc:1410-1537), one wave per walker-ladder.
+// exchange phase of parallel_tempering_chains::step (chain.cc:1410-1537), one block per walker-ladder.
 // decide_kernel replays the step's candidate draws, decides every exchange that concerns the shard and lists the row
 // moves; move_kernel applies them in place (whole contiguous rows) and packs the rows that leave the shard;
 // install_kernel lands the rows that arrive from the adjacent shards.  touch[] tells the sweep kernel which rungs skip
@@ -66,7 +66,10 @@ constexpr int MVCAP = 256;  // rows one ladder can move per step on the register
 // One lane walks each run; everything else (draws, counters, move list) is parallel over picks.  The draws and the
 // filter cover the whole ladder (they are replicated on every shard); everything after them runs over the compacted
 // list of the surviving picks inside the shard's window, on LDS arrays indexed by window rung.
-__global__ __launch_bounds__(64) void decide_kernel(const Decide p) {
+// DECIDE_THREADS = 256 when the shard sees most of the ladder (~200 candidates and ~100 survivors in ONE pass per phase),
+// 64 for a short shard of many ladders, where the per-block fixed costs are what counts.
+template <int DECIDE_THREADS>
+__global__ __launch_bounds__(DECIDE_THREADS) void decide_kernel(const Decide p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int w = blockIdx.x;
   const int lane = threadIdx.x;
@@ -93,11 +96,11 @@ __global__ __launch_bounds__(64) void decide_kernel(const Decide p) {
   unsigned short* inv = inv_ - wlo;
   cdp beta = as_c(p.beta);
 
-  for (int i = lane; i < Nt; i += 64) first[i] = NONE;
+  for (int i = lane; i < Nt; i += DECIDE_THREADS) first[i] = NONE;
   if (lane == 0) { cnt[0] = 0; cnt[1] = 0; p.arr_below[w] = -1; p.arr_above[w] = -1; }
   __syncthreads();
   // -- candidate draws (chain.cc:1410-1416): block k of the ladder stream gives {u_try, u_pick, u_accept}
-  for (int k = lane; k < ms; k += 64) {
+  for (int k = lane; k < ms; k += DECIDE_THREADS) {
     const u32x4 o = draw_block(p.seed, TAG_PT, (uint32_t)w, p.step, (uint32_t)k);
     int n = -2;
     if (Nt > 1 && u01(o.v0) < p.thresh) n = (int)(u01(o.v1) * (Nt - 1));
@@ -109,7 +112,7 @@ __global__ __launch_bounds__(64) void decide_kernel(const Decide p) {
   }
   __syncthreads();
   // -- filter (1): run heads walk their run upwards
-  for (int k = lane; k < ms; k += 64) {
+  for (int k = lane; k < ms; k += DECIDE_THREADS) {
     const int n = cand[k];
     if (n < 0 || first[n] != k) continue;                      // repeated rung value: dropped
     if (n > 0 && first[n - 1] != NONE) continue;               // not a run head
@@ -123,7 +126,7 @@ __global__ __launch_bounds__(64) void decide_kernel(const Decide p) {
   __syncthreads();
 #define PTM_ALIVE_RUNG(r) ((r) >= 0 && (r) <= Nt - 2 && first[(r)] != NONE && alive[first[(r)]])
   // -- compaction: the surviving picks whose pair lies inside the window
-  for (int k = lane; k < ms; k += 64) {
+  for (int k = lane; k < ms; k += DECIDE_THREADS) {
     const int n = cand[k];
     if (n < 0) continue;
     if (!alive[k]) { cand[k] = -2; continue; }
@@ -134,7 +137,7 @@ __global__ __launch_bounds__(64) void decide_kernel(const Decide p) {
   const int nl = cnt[0];
   // -- working copy of the touched rungs (gather_llikes, chain.cc:1434); each touched rung is set up by exactly one
   //    lane: the pick whose lower rung it is, or -- for the top of a run -- the pick just below it
-  for (int j = lane; j < nl; j += 64) {
+  for (int j = lane; j < nl; j += DECIDE_THREADS) {
     const int n = cand[list[j]];
     const bool top = !PTM_ALIVE_RUNG(n + 1) || n + 2 > whi;    // (an alive pick above that lies outside the window sets up nothing)
     const double a = win_llike(p, n, w);
@@ -150,7 +153,7 @@ __global__ __launch_bounds__(64) void decide_kernel(const Decide p) {
   }
   __syncthreads();
   // -- trials (2): the top pick of each run of surviving rungs walks the run downwards (chain.cc:1436-1537)
-  for (int j = lane; j < nl; j += 64) {
+  for (int j = lane; j < nl; j += DECIDE_THREADS) {
     const int n = cand[list[j]];
     const bool up = PTM_ALIVE_RUNG(n + 1);
     if (up && n + 1 < whi) continue;                             // not the top of a run (the pick above is in the list)
@@ -185,10 +188,10 @@ __global__ __launch_bounds__(64) void decide_kernel(const Decide p) {
   }
   __syncthreads();
   // -- the step's log
-  for (int k = lane; k < ms; k += 64)
+  for (int k = lane; k < ms; k += DECIDE_THREADS)
     p.swap_log[(size_t)w * ms + k] = alive[k] == 1 ? (cand[k] | (accf[k] ? 0x40000000 : 0)) : (alive[k] == 2 ? -3 : -2);
   // -- counters, the touch counts of the local rungs and the inverse permutation
-  for (int j = lane; j < nl; j += 64) {
+  for (int j = lane; j < nl; j += DECIDE_THREADS) {
     const int k = list[j];
     if (alive[k] != 1) continue;
     const int i = cand[k];
@@ -215,7 +218,7 @@ __global__ __launch_bounds__(64) void decide_kernel(const Decide p) {
   //    leaves the shard) for move_kernel; the hole an arrival will fill is named in arr_above / arr_below.
   int* gs = p.mv_src + (size_t)w * MVCAP;
   int* gd = p.mv_dst + (size_t)w * MVCAP;
-  for (int j = lane; j < nl; j += 64) {
+  for (int j = lane; j < nl; j += DECIDE_THREADS) {
     const int k = list[j];
     if (alive[k] != 1) continue;
     const int i = cand[k];
@@ -247,7 +250,7 @@ __global__ __launch_bounds__(64) void decide_kernel(const Decide p) {
   // decomposes into disjoint closed cycles inside the shard and at most two open paths through its boundaries;
   // one lane walks each in path order, so plain loads and stores are safe.  Slow, correct.
   const int DP = p.DP;
-  for (int j = lane; j < nl; j += 64) {
+  for (int j = lane; j < nl; j += DECIDE_THREADS) {
     const int k = list[j];
     if (alive[k] != 1) continue;
     const int i = cand[k];

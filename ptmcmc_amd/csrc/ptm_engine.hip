@@ -511,12 +511,16 @@ static int launch_decide(ptm_engine* e, const double* ll_below, const double* ll
   const int WN = e->nloc + (ll_below ? 1 : 0) + p.H;
   const size_t lds = decide_lds_bytes(e->Nt, e->ms, WN);
   if (lds > 160 * 1024) return fail(PTM_ERR_UNSUPPORTED, "ladder too long for the LDS-resident exchange kernel (%zu B)", lds);
-  if (lds > 64 * 1024)
-    HIPCHK(hipFuncSetAttribute((const void*)decide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const bool wide = (double)e->ms * WN / e->Nt > 96.0;   // expected candidates inside the window
+  if (lds > 64 * 1024) {
+    HIPCHK(hipFuncSetAttribute((const void*)decide_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIPCHK(hipFuncSetAttribute((const void*)decide_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  }
   // the boundary messages start empty (the row count lives in their first word)
   if (send_up) HIPCHK(hipMemsetAsync(send_up, 0, 16, e->stream));
   if (send_down) HIPCHK(hipMemsetAsync(send_down, 0, 16, e->stream));
-  hipLaunchKernelGGL(decide_kernel, dim3(e->W), dim3(64), lds, e->stream, p);
+  if (wide) hipLaunchKernelGGL(decide_kernel<256>, dim3(e->W), dim3(256), lds, e->stream, p);
+  else hipLaunchKernelGGL(decide_kernel<64>, dim3(e->W), dim3(64), lds, e->stream, p);
   HIPCHK(hipGetLastError());
   Move m;
   m.DP = e->DP; m.W = e->W; m.row_cap = e->row_cap; m.x = e->x; m.ll = e->ll; m.lp = e->lp; m.send_up = send_up; m.send_down = send_down;
