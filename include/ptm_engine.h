@@ -73,6 +73,9 @@ typedef struct ptm_config {
   int32_t exchange_row_capacity; /* row slots per boundary message (multi-GPU); 0 = automatic:
                                   * min(n_walkers, n_walkers*swap_rate + 8 sigma + 64).  More rows crossing one boundary in
                                   * one step than this is reported as PTM_ERR_FAR_MOVE by ptm_sync, never silently dropped */
+  int32_t history_rungs;    /* >0: keep the history MH_chain::add_state pushes (chain.cc:935-946) for the first
+                             * history_rungs rungs held by this engine; 0 = off */
+  int32_t history_capacity; /* rows per chain kept on the device (a ring: saved row s sits in slot s % capacity) */
 } ptm_config;
 
 /* user plug-in likelihood, batched: the C shape of bayes_likelihood::register_evaluate_log
@@ -164,6 +167,12 @@ int ptm_get_swap_counts(ptm_engine* e, int64_t* tries, int64_t* accepts);
 /* candidates of the most recent step: pairs[W][maxswaps] (lower rung or -2), accepted[W][maxswaps] */
 int ptm_get_last_swaps(ptm_engine* e, int32_t* pairs, int32_t* accepted);
 int ptm_max_swaps_per_step(ptm_engine* e);
+/* History of the recorded rungs (ptm_config.history_rungs): for chain (local rung r, walker w) at index r*W + w and ring
+ * slot k: X[(k*HC + index)*dim ..], llike / lprior [k*HC + index], meta [4*(k*HC + index)] = {Naccept, Ntries,
+ * last_type, saved row number} as MH_chain::add_state saw them (acceptance_ratio = Naccept/Ntries, lpost = lprior +
+ * beta*llike); HC = history_rungs * n_walkers.  Saved row s is in slot s % history_capacity; row 0 is the initial state
+ * and a chain has saved Nsize rows (PTM_ARR_NSIZE).  Any output pointer may be NULL. */
+int ptm_get_history(ptm_engine* e, double* X, double* llike, double* lprior, int32_t* meta);
 uint64_t ptm_step_count(ptm_engine* e);
 
 /* ---- measurement ---------------------------------------------------------------------------------------- */

@@ -456,12 +456,29 @@ void ptmo_pt_free(ptmo_pt* s) {
   if (!s) return;
   free(s->beta); free(s->x); free(s->llike); free(s->lprior); free(s->ntries); free(s->naccept); free(s->last_type);
   free(s->nhist); free(s->nsize); free(s->swap_count); free(s->swap_accept_count); free(s->last_pairs); free(s->last_accept);
-  free(s->touched); free(s);
+  free(s->touched);
+  free(s->hist_x); free(s->hist_ll); free(s->hist_lp); free(s->hist_nacc); free(s->hist_ntry); free(s->hist_type);
+  free(s);
+}
+void ptmo_pt_enable_history(ptmo_pt* s, int cap) {
+  size_t N = (size_t)s->Nt * s->W;
+  s->hist_cap = cap;
+  s->hist_x = (double*)calloc(N * cap * s->D, sizeof(double));
+  s->hist_ll = (double*)calloc(N * cap, sizeof(double)); s->hist_lp = (double*)calloc(N * cap, sizeof(double));
+  s->hist_nacc = (int32_t*)calloc(N * cap, 4); s->hist_ntry = (int32_t*)calloc(N * cap, 4); s->hist_type = (int32_t*)calloc(N * cap, 4);
+}
+/* the push_back block of MH_chain::add_state (chain.cc:935-946); row index = Nsize before the push */
+static void hist_push(ptmo_pt* s, size_t c, int64_t row) {
+  if (!s->hist_cap || row >= s->hist_cap) return;
+  size_t o = c * s->hist_cap + (size_t)row;
+  memcpy(s->hist_x + o * s->D, s->x + c * s->D, s->D * sizeof(double));
+  s->hist_ll[o] = s->llike[c]; s->hist_lp[o] = s->lprior[c];
+  s->hist_nacc[o] = s->naccept[c]; s->hist_ntry[o] = s->ntries[c]; s->hist_type[o] = s->last_type[c];
 }
 
 /* MH_chain::add_state bookkeeping (chain.cc:935-947) */
 static inline void add_state_count(ptmo_pt* s, size_t c) {
-  if (s->nhist[c] % s->add_every_N == 0) s->nsize[c]++;
+  if (s->nhist[c] % s->add_every_N == 0) { hist_push(s, c, s->nsize[c]); s->nsize[c]++; }
   s->nhist[c]++;
 }
 
@@ -474,6 +491,7 @@ void ptmo_pt_set_states(ptmo_pt* s, const ptmo_problem* pb, const double* x, con
     s->lprior[c] = ptmo_lprior(pb, xc, valid);
     s->llike[c] = llike ? llike[c] : ptmo_llike(pb, xc);
     s->nhist[c] = 0; s->nsize[c] = 1;                     /* MH_chain::initialize(1): one row, Nhist reset (chain.cc:871-875) */
+    hist_push(s, c, 0);
   }
 }
 
@@ -717,5 +735,6 @@ void ptmo_init_from_prior(ptmo_pt* s, const ptmo_problem* pb, uint64_t seed) {
       break;
     }
     s->nhist[c] = 0; s->nsize[c] = 1;
+    hist_push(s, c, 0);
   }
 }

@@ -95,6 +95,12 @@ typedef struct {
   int* last_pairs;     /* [W][maxswaps] */
   int* last_accept;    /* [W][maxswaps] */
   uint8_t* touched;    /* [W*Nt] scratch: add_state calls received in the swap phase of the last step */
+  /* optional history (MH_chain::states / llikes / acceptance_ratio / types, chain.cc:935-946): row s of chain c is
+   * what add_state pushed when Nsize was s; row 0 is the initial state.  hist_cap rows per chain (no ring here). */
+  int hist_cap;
+  double* hist_x;      /* [W*Nt][hist_cap][D] */
+  double *hist_ll, *hist_lp;             /* [W*Nt][hist_cap] */
+  int32_t *hist_nacc, *hist_ntry, *hist_type; /* [W*Nt][hist_cap] */
 } ptmo_pt;
 
 /* ---- RNG: Philox4x32-10 (Salmon et al., SC'11; Random123) -------------------------------- */
@@ -131,6 +137,7 @@ void ptmo_problem_set_user(ptmo_problem*, ptmo_loglike_fn fn, void* user);
 
 ptmo_pt* ptmo_pt_create(int D, int Nt, int W, const double* beta, double swap_rate, int add_every_N);
 void ptmo_pt_free(ptmo_pt*);
+void ptmo_pt_enable_history(ptmo_pt*, int rows_per_chain); /* call before ptmo_pt_set_states / ptmo_init_from_prior */
 /* set states and (re)evaluate lprior/llike; llike may be NULL => evaluate the target */
 void ptmo_pt_set_states(ptmo_pt*, const ptmo_problem*, const double* x, const double* llike);
 

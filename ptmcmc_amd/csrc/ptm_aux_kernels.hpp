@@ -43,7 +43,14 @@ struct Decide {
   int row_cap;
   int *mv_src, *mv_dst, *mv_n;     // [W][MVCAP], [W][MVCAP], [W]: the ladder's row moves for move_kernel
   int* err;
+  // history (Hist, ptm_kernels.hpp): a rung touched twice in one step makes two add_state calls; the first one sees the
+  // row the rung held BETWEEN its two exchanges.  If that call is one that saves, the row is copied by move_kernel.
+  Hist hist;
+  int add_every_n;
+  const unsigned int* nhist;
+  const int *naccept, *ntries, *last_type;
 };
+constexpr int HIST_DST = -(1 << 30);   // move-list destination code: HIST_DST - c = "into chain c's history"
 
 // llike of global rung r for walker w, r inside the shard's window
 __device__ __forceinline__ double win_llike(const Decide& p, int r, int w) {
@@ -88,12 +95,14 @@ __global__ __launch_bounds__(DECIDE_THREADS) void decide_kernel(const Decide p) 
   unsigned short* perm_ = reinterpret_cast<unsigned short*>(cnt + 2);         // [WN]  source rung of the row now at a rung
   unsigned short* inv_ = perm_ + ((WN + 3) & ~3);                             // [WN]  inverse of perm
   unsigned short* list = inv_ + ((WN + 3) & ~3);                              // [ms]  surviving picks that are ours
-  unsigned char* alive = reinterpret_cast<unsigned char*>(list + ((ms + 3) & ~3));  // [ms] 0 dropped, 1 survives and is
+  unsigned short* mid_ = list + ((ms + 3) & ~3);                              // [WN]  row a twice-touched rung held in between
+  unsigned char* alive = reinterpret_cast<unsigned char*>(mid_ + ((WN + 3) & ~3));  // [ms] 0 dropped, 1 survives and is
                                                                                     //      ours, 2 survives, not ours
   unsigned char* accf = alive + ((ms + 7) & ~7);                              // [ms]
   double* llc = llc_ - wlo;                // indexed by global rung
   unsigned short* perm = perm_ - wlo;
   unsigned short* inv = inv_ - wlo;
+  unsigned short* mid = mid_ - wlo;
   cdp beta = as_c(p.beta);
 
   for (int i = lane; i < Nt; i += DECIDE_THREADS) first[i] = NONE;
@@ -184,6 +193,7 @@ __global__ __launch_bounds__(DECIDE_THREADS) void decide_kernel(const Decide p) 
         accf[kk] = 1;
       }
       if (!PTM_ALIVE_RUNG(i - 1)) break;
+      mid[i] = perm[i];   // the pick below exchanges rung i again: this is what it held in between
     }
   }
   __syncthreads();
@@ -218,11 +228,28 @@ __global__ __launch_bounds__(DECIDE_THREADS) void decide_kernel(const Decide p) 
   //    leaves the shard) for move_kernel; the hole an arrival will fill is named in arr_above / arr_below.
   int* gs = p.mv_src + (size_t)w * MVCAP;
   int* gd = p.mv_dst + (size_t)w * MVCAP;
+  // source slot of the in-between row of rung r if its FIRST add_state of this step is one that saves, else -1
+  auto hist_mid_src = [&](int r) -> int {
+    if (r - p.r0 >= p.hist.rungs || r < p.r0 || r >= r1) return -1;
+    if (!(r > 0 && PTM_ALIVE_RUNG(r - 1) && alive[first[r - 1]] == 1)) return -1;   // touched once only
+    const int c = (r - p.r0) * p.W + w;
+    if (p.nhist[c] % (unsigned int)p.add_every_n != 0u) return -1;
+    const int s1 = mid[r];
+    if (s1 < p.r0 || s1 >= r1) { atomicOr(p.err, 16); return -1; }   // (the host keeps recorded rungs away from shard tops)
+    return (s1 - p.r0) * p.W + w;
+  };
   for (int j = lane; j < nl; j += DECIDE_THREADS) {
     const int k = list[j];
     if (alive[k] != 1) continue;
     const int i = cand[k];
     const int rtop = (PTM_ALIVE_RUNG(i + 1) && alive[first[i + 1]] == 1) ? i : i + 1;
+    if (p.hist.rungs) {
+      const int hs = hist_mid_src(i);
+      if (hs >= 0) {
+        const int m = atomicAdd(&cnt[1], 1);
+        if (m < MVCAP) { gs[m] = hs; gd[m] = HIST_DST - ((i - p.r0) * p.W + w); }
+      }
+    }
     for (int r = i; r <= rtop; ++r) {
       if (r < p.r0 || r >= r1 || perm[r] == r) continue;
       const int s = perm[r], to = inv[r];
@@ -250,6 +277,21 @@ __global__ __launch_bounds__(DECIDE_THREADS) void decide_kernel(const Decide p) 
   // decomposes into disjoint closed cycles inside the shard and at most two open paths through its boundaries;
   // one lane walks each in path order, so plain loads and stores are safe.  Slow, correct.
   const int DP = p.DP;
+  if (p.hist.rungs) {   // in-between rows first: they are read from rows nobody has moved yet
+    for (int j = lane; j < nl; j += DECIDE_THREADS) {
+      const int k = list[j];
+      if (alive[k] != 1) continue;
+      const int i = cand[k];
+      const int hs = hist_mid_src(i);
+      if (hs < 0) continue;
+      const int c = (i - p.r0) * p.W + w;
+      const long long hrow = 1 + (long long)(p.nhist[c] / (unsigned int)p.add_every_n);
+      const size_t o = hist_slot(p.hist, hrow, c);
+      for (int d = 0; d < DP; ++d) p.hist.x[o * DP + d] = p.x[(size_t)hs * DP + d];
+      hist_scalars(p.hist, o, hrow, p.ll[hs], p.lp[hs], p.naccept[c], p.ntries[c], p.last_type[c]);
+    }
+    __syncthreads();
+  }
   for (int j = lane; j < nl; j += DECIDE_THREADS) {
     const int k = list[j];
     if (alive[k] != 1) continue;
@@ -323,6 +365,10 @@ struct Move {
   const int *mv_src, *mv_dst;
   int* mv_n;
   int* err;
+  Hist hist;                        // destination codes <= HIST_DST: the row goes to that chain's history
+  int add_every_n;
+  const unsigned int* nhist;
+  const int *naccept, *ntries, *last_type;
 };
 typedef double d2_t __attribute__((ext_vector_type(2)));  // (HIP's double2 struct does not stay in registers as an array)
 
@@ -373,7 +419,10 @@ __global__ __launch_bounds__(64 * WPB, MV > 64 ? 1 : 4) void move_kernel(const M
     if (d != -3 && act) {
       double* dstp;
       if (d >= 0) dstp = p.x + (size_t)d * DP;
-      else { const int e = -d - 4; dstp = ((e & 1) ? p.send_down : p.send_up) + MSG_HDR + (size_t)(e >> 1) * RD; }
+      else if (d <= HIST_DST) {
+        const int c = HIST_DST - d;
+        dstp = p.hist.x + hist_slot(p.hist, 1 + (long long)(p.nhist[c] / (unsigned int)p.add_every_n), c) * DP;
+      } else { const int e = -d - 4; dstp = ((e & 1) ? p.send_down : p.send_up) + MSG_HDR + (size_t)(e >> 1) * RD; }
       *reinterpret_cast<d2_t*>(dstp + col) = v[q];
     }
   }
@@ -381,7 +430,11 @@ __global__ __launch_bounds__(64 * WPB, MV > 64 ? 1 : 4) void move_kernel(const M
   for (int q = 0; q < MV / 64; ++q) {
     const int d = s_dst[64 * q + lane];
     if (d >= 0) { p.ll[d] = sl[q]; p.lp[d] = sp[q]; }
-    else if (d != -3) {
+    else if (d <= HIST_DST) {
+      const int c = HIST_DST - d;
+      const long long hrow = 1 + (long long)(p.nhist[c] / (unsigned int)p.add_every_n);
+      hist_scalars(p.hist, hist_slot(p.hist, hrow, c), hrow, sl[q], sp[q], p.naccept[c], p.ntries[c], p.last_type[c]);
+    } else if (d != -3) {
       const int e = -d - 4;
       double* row = ((e & 1) ? p.send_down : p.send_up) + MSG_HDR + (size_t)(e >> 1) * RD;
       row[DP] = sl[q]; row[DP + 1] = sp[q]; row[DP + 2] = (double)w; row[DP + 3] = 0.0;
@@ -416,6 +469,16 @@ __global__ __launch_bounds__(256) void install_kernel(const Install p) {
   if (a < 0) { atomicOr(p.err, 8); return; }  // a row nobody expects: the two shards disagree about the step
   if (2 * sub < DP) *reinterpret_cast<d2_t*>(p.x + (size_t)a * DP + 2 * sub) = *reinterpret_cast<const d2_t*>(row + 2 * sub);
   if (sub == 0) { p.ll[a] = row[DP]; p.lp[a] = row[DP + 1]; }
+}
+
+// history row 0: the initial state (MH_chain::initialize -> add_state, chain.cc:871-875)
+__global__ void hist_init_kernel(Hist h, int DP, const double* x, const double* ll, const double* lp, const int* naccept,
+                                 const int* ntries, const int* last_type) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= h.HC) return;
+  const size_t o = hist_slot(h, 0, c);
+  for (int d = 0; d < DP; ++d) h.x[o * DP + d] = x[(size_t)c * DP + d];
+  hist_scalars(h, o, 0, ll[c], lp[c], naccept[c], ntries[c], last_type[c]);
 }
 
 // verification hooks

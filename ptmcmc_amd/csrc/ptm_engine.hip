@@ -49,6 +49,7 @@ struct ptm_engine {
   unsigned int* nhist = nullptr;
   long long *swap_try = nullptr, *swap_acc = nullptr;
   unsigned char* touch = nullptr;
+  Hist hist = {0, 0, 0, nullptr, nullptr, nullptr, nullptr};   // optional history ring (ptm_config.history_rungs)
   int* swap_log = nullptr;   // [W][ms] candidate log of the last step
   int row_cap = 0;           // row slots per boundary message
   // device problem description
@@ -143,6 +144,18 @@ extern "C" int ptm_engine_create(const ptm_config* cfg, ptm_engine** out) {
     if (e->row_cap > e->W) e->row_cap = e->W;
   }
   e->thresh = (e->Nt - 1) * cfg->swap_rate / e->ms;                          // chain.cc:1413
+  if (cfg->history_rungs < 0 || cfg->history_rungs > cfg->rung_count) { delete e; return fail(PTM_ERR_INVALID, "history_rungs out of range"); }
+  if (cfg->history_rungs > 0) {
+    if (cfg->history_capacity < 2) { delete e; return fail(PTM_ERR_INVALID, "history_capacity must be >= 2"); }
+    // a rung touched twice in a step saves the row it held in between, which may be the row of the rung above: on a
+    // shard that is not the ladder's last, the shard's top rung therefore cannot be recorded
+    if (cfg->history_rungs == cfg->rung_count && cfg->rung_begin + cfg->rung_count < cfg->n_rungs) {
+      delete e;
+      return fail(PTM_ERR_UNSUPPORTED, "the top rung of a shard below the ladder's top cannot be recorded: history_rungs < rung_count");
+    }
+    if ((double)cfg->history_rungs * cfg->n_walkers >= (double)(1 << 30)) { delete e; return fail(PTM_ERR_INVALID, "too many recorded chains"); }
+    e->hist.rungs = cfg->history_rungs; e->hist.cap = cfg->history_capacity; e->hist.HC = cfg->history_rungs * cfg->n_walkers;
+  }
   if (cfg->device >= 0) { HIPCHK(hipSetDevice(cfg->device)); e->device = cfg->device; } else HIPCHK(hipGetDevice(&e->device));
   if (cfg->stream) e->stream = (hipStream_t)cfg->stream;
   else { HIPCHK(hipStreamCreate(&e->stream)); e->own_stream = true; }
@@ -155,6 +168,12 @@ extern "C" int ptm_engine_create(const ptm_config* cfg, ptm_engine** out) {
       (rc = dalloc(&e->arr_above, (size_t)cfg->n_walkers)) || (rc = dalloc(&e->touch, Nc)) || (rc = dalloc(&e->nhist, Nc)) ||
       (rc = dalloc(&e->err, 4)))
     return rc;
+  if (e->hist.rungs) {
+    const size_t n = (size_t)e->hist.cap * e->hist.HC;
+    if ((rc = dalloc(&e->hist.x, n * D)) || (rc = dalloc(&e->hist.ll, n)) || (rc = dalloc(&e->hist.lp, n)) || (rc = dalloc(&e->hist.meta, n)))
+      return rc;
+    HIPCHK(hipMemsetAsync(e->hist.meta, 0xFF, n * sizeof(int4), e->stream));   // saved row number -1: empty slot
+  }
   const size_t np = (size_t)e->W * (e->Nt > 1 ? e->Nt - 1 : 1);
   if ((rc = dalloc(&e->swap_try, np)) || (rc = dalloc(&e->swap_acc, np)) || (rc = dalloc(&e->swap_log, (size_t)e->W * e->ms)))
     return rc;
@@ -196,7 +215,7 @@ extern "C" int ptm_engine_destroy(ptm_engine* e) {
   if (!e) return PTM_OK;
   (void)hipStreamSynchronize(e->stream);
   void* ptrs[] = {e->x, e->ll, e->lp, e->ntries, e->naccept, e->last_type, e->arr_below, e->arr_above, e->mv_src, e->mv_dst, e->mv_n,
-                  e->err, e->nhist, e->swap_try, e->swap_acc, e->touch, e->swap_log, e->blo,
+                  e->err, e->nhist, e->swap_try, e->swap_acc, e->touch, e->swap_log, e->hist.x, e->hist.ll, e->hist.lp, e->hist.meta, e->blo,
                   e->bhi, e->ptype, e->bmin, e->bmax, e->plo, e->phi, e->pcoef, e->P2, e->mean, e->beta, e->prop, e->prop_tiles, e->P2_tiles, e->box_row, e->onedfrac, e->xprop, e->lprior_new, e->llike_new, e->gate};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -433,6 +452,7 @@ static Dev make_dev(ptm_engine* e) {
   p.x = e->x; p.ll = e->ll; p.lp = e->lp;
   p.ntries = e->ntries; p.naccept = e->naccept; p.last_type = e->last_type; p.nhist = e->nhist;
   p.touch = e->touch; p.err = e->err;
+  p.hist = e->hist;
   return p;
 }
 
@@ -495,7 +515,7 @@ static int launch_sweep(ptm_engine* e) {
 
 static size_t decide_lds_bytes(int Nt, int ms, int WN) {
   // mirrors the carve at the top of decide_kernel
-  return (size_t)WN * 8 + (size_t)((Nt + 1) & ~1) * 4 + (size_t)((ms + 1) & ~1) * 4 * 2 + 8 + (size_t)((WN + 3) & ~3) * 2 * 2 +
+  return (size_t)WN * 8 + (size_t)((Nt + 1) & ~1) * 4 + (size_t)((ms + 1) & ~1) * 4 * 2 + 8 + (size_t)((WN + 3) & ~3) * 2 * 3 +
          (size_t)((ms + 3) & ~3) * 2 + (size_t)((ms + 7) & ~7) * 2 + 32;
 }
 
@@ -508,6 +528,8 @@ static int launch_decide(ptm_engine* e, const double* ll_below, const double* ll
   p.touch = e->touch; p.arr_below = e->arr_below; p.arr_above = e->arr_above; p.swap_try = e->swap_try; p.swap_acc = e->swap_acc;
   p.swap_log = e->swap_log; p.send_up = send_up; p.send_down = send_down; p.row_cap = e->row_cap; p.err = e->err;
   p.mv_src = e->mv_src; p.mv_dst = e->mv_dst; p.mv_n = e->mv_n;
+  p.hist = e->hist; p.add_every_n = e->cfg.add_every_n; p.nhist = e->nhist;
+  p.naccept = e->naccept; p.ntries = e->ntries; p.last_type = e->last_type;
   const int WN = e->nloc + (ll_below ? 1 : 0) + p.H;
   const size_t lds = decide_lds_bytes(e->Nt, e->ms, WN);
   if (lds > 160 * 1024) return fail(PTM_ERR_UNSUPPORTED, "ladder too long for the LDS-resident exchange kernel (%zu B)", lds);
@@ -525,6 +547,8 @@ static int launch_decide(ptm_engine* e, const double* ll_below, const double* ll
   Move m;
   m.DP = e->DP; m.W = e->W; m.row_cap = e->row_cap; m.x = e->x; m.ll = e->ll; m.lp = e->lp; m.send_up = send_up; m.send_down = send_down;
   m.mv_src = e->mv_src; m.mv_dst = e->mv_dst; m.mv_n = e->mv_n; m.err = e->err;
+  m.hist = e->hist; m.add_every_n = e->cfg.add_every_n; m.nhist = e->nhist;
+  m.naccept = e->naccept; m.ntries = e->ntries; m.last_type = e->last_type;
   // a ladder moves about 0.17 rows per local rung and step at the default swap rate: short shards take the light kernel
   // first; whatever does not fit it is left for the MVCAP-row kernel
   if (e->nloc <= 256) {
@@ -569,6 +593,12 @@ static int reset_counters(ptm_engine* e) {
   HIPCHK(hipMemsetAsync(e->arr_below, 0xFF, (size_t)e->W * 4, e->stream));
   HIPCHK(hipMemsetAsync(e->arr_above, 0xFF, (size_t)e->W * 4, e->stream));
   e->step = 0;
+  if (e->hist.rungs) {   // history row 0 = the initial state (chain.cc:871-875)
+    HIPCHK(hipMemsetAsync(e->hist.meta, 0xFF, (size_t)e->hist.cap * e->hist.HC * sizeof(int4), e->stream));
+    hipLaunchKernelGGL(hist_init_kernel, dim3((e->hist.HC + 255) / 256), dim3(256), 0, e->stream, e->hist, e->DP, e->x, e->ll, e->lp,
+                       e->naccept, e->ntries, e->last_type);
+    HIPCHK(hipGetLastError());
+  }
   return PTM_OK;
 }
 
@@ -711,6 +741,7 @@ extern "C" int ptm_sync(ptm_engine* e) {
   if (flag & 4) return fail(PTM_ERR_FAR_MOVE, "a boundary message overflowed: more rows crossed a shard boundary in one step than "
                             "ptm_config.exchange_row_capacity slots (%d)", e->row_cap);
   if (flag & 8) return fail(PTM_ERR_FAR_MOVE, "a boundary message carried a row this shard did not expect (neighbour shards out of step?)");
+  if (flag & 16) return fail(PTM_ERR_UNSUPPORTED, "a recorded rung's in-between history row belongs to the neighbour shard");
   return PTM_OK;
 }
 
@@ -842,6 +873,22 @@ extern "C" int ptm_get_last_swaps(ptm_engine* e, int32_t* pairs, int32_t* accept
 }
 
 extern "C" int ptm_max_swaps_per_step(ptm_engine* e) { return e ? e->ms : 0; }
+
+extern "C" int ptm_get_history(ptm_engine* e, double* X, double* llike, double* lprior, int32_t* meta) {
+  if (!e) return fail(PTM_ERR_INVALID, "null engine");
+  if (!e->hist.rungs) return fail(PTM_ERR_INVALID, "history is off (ptm_config.history_rungs)");
+  const size_t n = (size_t)e->hist.cap * e->hist.HC, D = e->D, DP = e->DP;
+  HIPCHK(hipStreamSynchronize(e->stream));
+  if (X) {
+    std::vector<double> rows(n * DP);
+    HIPCHK(hipMemcpy(rows.data(), e->hist.x, n * DP * 8, hipMemcpyDeviceToHost));
+    unpad_rows(rows, n, D, DP, X);
+  }
+  if (llike) HIPCHK(hipMemcpy(llike, e->hist.ll, n * 8, hipMemcpyDeviceToHost));
+  if (lprior) HIPCHK(hipMemcpy(lprior, e->hist.lp, n * 8, hipMemcpyDeviceToHost));
+  if (meta) HIPCHK(hipMemcpy(meta, e->hist.meta, n * 16, hipMemcpyDeviceToHost));
+  return PTM_OK;
+}
 extern "C" uint64_t ptm_step_count(ptm_engine* e) { return e ? e->step : 0; }
 
 // ---- measurement ------------------------------------------------------------------------------------------------------
@@ -876,7 +923,7 @@ extern "C" const char* ptm_sweep_kernel_name(ptm_engine* e) {
   if (!e) return "";
   char b[96];
   const SweepSel s = sweep_sel(e);
-  if (e->DP == 32 && s.uni && s.simple && s.kind != KIND_DIAG) snprintf(b, sizeof b, "sweep_mfma32_kernel<%d>", s.kind);
+  if (e->DP == 32 && s.uni && s.simple && s.kind != KIND_DIAG) snprintf(b, sizeof b, "sweep_mfma32_kernel<%d, %s>", s.kind, e->hist.rungs ? "true" : "false");
   else snprintf(b, sizeof b, "sweep_kernel<%d, %d, %s, %s>", e->DP, s.kind, s.uni ? "true" : "false", s.simple ? "true" : "false");
   e->kname = b;
   return e->kname.c_str();

@@ -54,8 +54,24 @@ __device__ __forceinline__ cdp as_c(const double* p) { return (cdp)(uintptr_t)p;
 __device__ __forceinline__ cip as_c(const int* p) { return (cip)(uintptr_t)p; }
 
 // problem description + state pointers; passed BY VALUE to every kernel (kernarg segment => scalar loads)
+// Optional history of the first `rungs` local rungs -- what MH_chain::add_state pushes every add_every_N-th call
+// (chain.cc:935-946: state, llike, lpost, acceptance ratio, type).  A ring of `cap` rows per chain: saved row s of chain
+// c sits in slot s % cap -- x at [slot][c][DP] (row layout), llike / lprior at [slot][c], meta = {Naccept, Ntries,
+// last_type, s} at [slot][c].  Row 0 is the initial state; the add number a (a % add_every_N == 0) saves row 1 + a/N.
+struct Hist {
+  int rungs, cap, HC;   // rungs == 0: off; HC = rungs * W chains
+  double *x, *ll, *lp;
+  int4* meta;
+};
+__device__ __forceinline__ size_t hist_slot(const Hist& h, long long row, int c) { return (size_t)(row % h.cap) * h.HC + c; }
+__device__ __forceinline__ void hist_scalars(const Hist& h, size_t o, long long row, double ll, double lp, int nacc, int ntry, int type) {
+  h.ll[o] = ll; h.lp[o] = lp;
+  h.meta[o] = make_int4(nacc, ntry, type, (int)row);
+}
+
 struct Dev {
   int D, DP, Nt, r0, nloc, W, Nc;
+  Hist hist;
   uint64_t seed, step;
   int add_every_n;
   double min_prior;
@@ -388,8 +404,18 @@ __global__ __launch_bounds__(256, PTM_SWEEP_WAVES) void sweep_kernel(const Dev p
   const int tc = p.touch[c];  // > 0: the rung took part in that many exchange attempts => no MH move this step
   const bool propose_only = !SIMPLE && p.mode == 1;
   if (tc && !propose_only) {
-    p.nhist[c] += (unsigned int)tc;  // one add_state per attempt (chain.cc:1487-1490,1531-1534,1554-1557)
-    p.touch[c] = 0;                  // (the exchange kernel already moved the rows)
+    const unsigned int nh0 = p.nhist[c];
+    p.nhist[c] = nh0 + (unsigned int)tc;  // one add_state per attempt (chain.cc:1487-1490,1531-1534,1554-1557)
+    p.touch[c] = 0;                       // (the exchange kernel already moved the rows)
+    // history: the LAST of these adds saw the row as it is now (an earlier one of two saw the intermediate row: the
+    // exchange kernels save that one, ptm_aux_kernels.hpp)
+    const unsigned int a = nh0 + (unsigned int)tc - 1u;
+    if (rl < p.hist.rungs && a % (unsigned int)p.add_every_n == 0u) {
+      const long long row = 1 + (long long)(a / (unsigned int)p.add_every_n);
+      const size_t o = hist_slot(p.hist, row, c);
+      for (int d = 0; d < DP; ++d) p.hist.x[o * DP + d] = p.x[(size_t)c * DP + d];
+      hist_scalars(p.hist, o, row, p.ll[c], p.lp[c], p.naccept[c], p.ntries[c], p.last_type[c]);
+    }
   }
   // ---- MH_chain::step for the untouched rungs; touched lanes idle through the draw loops
   const uint32_t stream = (uint32_t)w * (uint32_t)p.Nt + (uint32_t)rg;
@@ -499,8 +525,22 @@ __global__ __launch_bounds__(256, PTM_SWEEP_WAVES) void sweep_kernel(const Dev p
   bool accept = valid;
   if (accept && logH < 0) accept = dlog_u01(o0.v0) < logH;  // chain.cc:998-1001 (NaN stays accepted)
 
-  p.ntries[c] += 1;
-  p.nhist[c] += 1u;
+  const int ntries1 = p.ntries[c] + 1;
+  p.ntries[c] = ntries1;
+  const unsigned int nh0 = p.nhist[c];
+  p.nhist[c] = nh0 + 1u;
+  if (rl < p.hist.rungs && nh0 % (unsigned int)p.add_every_n == 0u) {   // add_state saves this one (chain.cc:935-946)
+    const long long hrow = 1 + (long long)(nh0 / (unsigned int)p.add_every_n);
+    const size_t o = hist_slot(p.hist, hrow, c);
+    if (accept) {
+#pragma unroll
+      for (int d = 0; d < DP; ++d) p.hist.x[o * DP + row_pos<DP>(d)] = xn[d];
+      hist_scalars(p.hist, o, hrow, newlike, newlprior, p.naccept[c] + 1, ntries1, type);
+    } else {
+      for (int d = 0; d < DP; ++d) p.hist.x[o * DP + d] = row[d];
+      hist_scalars(p.hist, o, hrow, ll, lp, p.naccept[c], ntries1, p.last_type[c]);
+    }
+  }
   if (accept) {
     p.naccept[c] += 1;
     p.last_type[c] = type;

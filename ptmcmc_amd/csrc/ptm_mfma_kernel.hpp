@@ -35,7 +35,7 @@ typedef double mf_d2 __attribute__((ext_vector_type(2)));
 #ifndef PTM_MFMA_WAVES
 #define PTM_MFMA_WAVES 3   // waves per SIMD the register budget is cut for
 #endif
-template <int KIND>
+template <int KIND, bool HIST>   // HIST: the engine keeps a history (compiled apart: the hot build carries none of it)
 __global__ __launch_bounds__(256, PTM_MFMA_WAVES) void sweep_mfma32_kernel(const Dev p) {
   constexpr int DP = 32;
   constexpr bool LOW = KIND == KIND_LOWER;
@@ -219,12 +219,20 @@ __global__ __launch_bounds__(256, PTM_MFMA_WAVES) void sweep_mfma32_kernel(const
     // ---- stage 5, lanes 32 gp .. 32 gp + 31 (chain = lane): Metropolis test and add_state counters
     //      (chain.cc:973-1019, 916-949)
     bool accept = false;
+    int hrow = -1;   // >= 0: this add_state call saves a history row (chain.cc:935-946), the ring row index
+    const bool hist_on = HIST && rl < p.hist.rungs;
     if ((q >> 1) == gp) {
       const double* mine = red + ((q & 1) * 4) * 16 + j;
       const double quad = ((mine[0] + mine[16]) + mine[32]) + mine[48];
       if (tc) {
         p.nhist[c] = nhist0 + (unsigned int)tc;
         p.touch[c] = 0;
+        // history: the last of these adds saw the row as it is now (the exchange kernels save an earlier one of two)
+        const unsigned int a = nhist0 + (unsigned int)tc - 1u;
+        if (hist_on && a % (unsigned int)p.add_every_n == 0u) {
+          hrow = 1 + (int)(a / (unsigned int)p.add_every_n);
+          hist_scalars(p.hist, hist_slot(p.hist, hrow, c), hrow, ll, lp, naccept0, ntries0, p.last_type[c]);
+        }
       } else {
         const double bl = beta * ll;
         const double cur_lpost = lp + bl;
@@ -244,6 +252,12 @@ __global__ __launch_bounds__(256, PTM_MFMA_WAVES) void sweep_mfma32_kernel(const
         }
         p.ntries[c] = ntries0 + 1;
         p.nhist[c] = nhist0 + 1u;
+        if (hist_on && nhist0 % (unsigned int)p.add_every_n == 0u) {
+          hrow = 1 + (int)(nhist0 / (unsigned int)p.add_every_n);
+          const size_t o = hist_slot(p.hist, hrow, c);
+          if (accept) hist_scalars(p.hist, o, hrow, newlike, newlprior, naccept0 + 1, ntries0 + 1, 0);
+          else hist_scalars(p.hist, o, hrow, ll, lp, naccept0, ntries0 + 1, p.last_type[c]);
+        }
         if (accept) {
           p.naccept[c] = naccept0 + 1;
           p.last_type[c] = 0;
@@ -259,6 +273,25 @@ __global__ __launch_bounds__(256, PTM_MFMA_WAVES) void sweep_mfma32_kernel(const
       if ((acc_bits >> (16 * gg + j)) & 1ull) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) rowp[gg][4 * t] = mf_d2{xp[gg][2 * t], xp[gg][2 * t + 1]};
+      }
+    }
+    // ---- history rows (rare: every add_every_N-th add of the recorded rungs): the chain's four lanes copy the state
+    //      the add saw -- the proposal if it was accepted, else the row as it stands in memory
+    if (hist_on) {
+      const uint64_t rec_bits = __builtin_amdgcn_ballot_w64(hrow >= 0) >> (32 * gp);
+      if (rec_bits & 0xFFFFFFFFull) {
+#pragma unroll
+        for (int gg = 0; gg < 2; ++gg) {
+          const int src_lane = 32 * gp + 16 * gg + j;
+          const int hr = __builtin_amdgcn_ds_bpermute(4 * src_lane, hrow);
+          if ((rec_bits >> (16 * gg + j)) & 1ull) {
+            const int cg = c0 + src_lane;
+            mf_d2* dst = reinterpret_cast<mf_d2*>(p.hist.x + hist_slot(p.hist, hr, cg) * DP) + q;
+            const bool took = (acc_bits >> (16 * gg + j)) & 1ull;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) dst[4 * t] = took ? mf_d2{xp[gg][2 * t], xp[gg][2 * t + 1]} : rowp[gg][4 * t];
+          }
+        }
       }
     }
     __builtin_amdgcn_wave_barrier();   // the next pass reuses the LDS slots

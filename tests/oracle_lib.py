@@ -50,7 +50,9 @@ class _PT(C.Structure):
                 ("lprior", _dp), ("ntries", C.POINTER(C.c_int32)), ("naccept", C.POINTER(C.c_int32)),
                 ("last_type", C.POINTER(C.c_int32)), ("nhist", C.POINTER(C.c_int64)), ("nsize", C.POINTER(C.c_int64)),
                 ("swap_count", C.POINTER(C.c_int64)), ("swap_accept_count", C.POINTER(C.c_int64)),
-                ("last_pairs", _ip), ("last_accept", _ip), ("touched", C.POINTER(C.c_uint8))]
+                ("last_pairs", _ip), ("last_accept", _ip), ("touched", C.POINTER(C.c_uint8)),
+                ("hist_cap", C.c_int), ("hist_x", _dp), ("hist_ll", _dp), ("hist_lp", _dp),
+                ("hist_nacc", C.POINTER(C.c_int32)), ("hist_ntry", C.POINTER(C.c_int32)), ("hist_type", C.POINTER(C.c_int32))]
 
 
 _lib = None
@@ -90,6 +92,7 @@ def lib():
     L.ptmo_pt_create.restype = C.POINTER(_PT)
     L.ptmo_pt_create.argtypes = [C.c_int, C.c_int, C.c_int, _dp, C.c_double, C.c_int]
     L.ptmo_pt_free.argtypes = [C.POINTER(_PT)]
+    L.ptmo_pt_enable_history.argtypes = [C.POINTER(_PT), C.c_int]
     L.ptmo_pt_set_states.argtypes = [C.POINTER(_PT), C.POINTER(_Problem), _dp, _dp]
     L.ptmo_mh_step.argtypes = [C.POINTER(_PT), C.POINTER(_Problem), C.POINTER(_Proposal), C.c_void_p, C.c_int, C.c_int]
     L.ptmo_pt_step.argtypes = [C.POINTER(_PT), C.POINTER(_Problem), C.POINTER(_Proposal), C.c_void_p, C.c_int]
@@ -290,6 +293,16 @@ class Ladder:
     @property
     def last_type(self):
         return self._arr(self.s.contents.last_type, (self.N,), np.int64)
+
+    def enable_history(self, rows_per_chain):
+        lib().ptmo_pt_enable_history(self.s, rows_per_chain)
+
+    def history(self):
+        """dict of arrays [N][cap](,D): x, llike, lprior, naccept, ntries, last_type (oracle chain order w*Nt + r)"""
+        c, cap = self.s.contents, self.s.contents.hist_cap
+        return dict(x=self._arr(c.hist_x, (self.N, cap, self.D), np.float64), llike=self._arr(c.hist_ll, (self.N, cap), np.float64),
+                    lprior=self._arr(c.hist_lp, (self.N, cap), np.float64), naccept=self._arr(c.hist_nacc, (self.N, cap), np.int64),
+                    ntries=self._arr(c.hist_ntry, (self.N, cap), np.int64), last_type=self._arr(c.hist_type, (self.N, cap), np.int64))
 
     @property
     def nhist(self):

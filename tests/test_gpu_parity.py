@@ -201,6 +201,89 @@ def test_add_every_n_history_counters():
     eng.close()
 
 
+@pytest.mark.parametrize("D,Nt,W,kind,N,sr", [(32, 8, 64, E.PROP_LOWER, 1, 0.45),    # MFMA kernel, every add saved
+                                              (32, 6, 128, E.PROP_DENSE, 3, 0.45),
+                                              (5, 7, 3, E.PROP_DENSE, 2, 0.45),     # general kernel, ragged sizes
+                                              (16, 12, 64, E.PROP_DIAG, 4, 0.3),
+                                              (4, 900, 64, E.PROP_DIAG, 2, 0.45)])  # > 256 moved rows: the slow exchange path
+def test_history_rows_match_the_oracle(D, Nt, W, kind, N, sr):
+    """What MH_chain::add_state pushes every add_every_N-th call (chain.cc:935-946): state, llike, lprior, Naccept,
+    Ntries, last_type -- including the rows a rung holds BETWEEN two exchanges of one step (quirk Q6)."""
+    from ptmcmc_amd.problems import GaussianProblem
+    steps, cap = (10 if Nt > 100 else 24), 64
+    pr = GaussianProblem(D, Nt, 1e3)
+    eng = E.Engine(D, Nt, W, swap_rate=sr, add_every_n=N, history_rungs=Nt, history_capacity=cap)
+    fac = pr.configure(eng, kind)
+    eng.init_from_prior()
+    x0 = eng.states()
+    pb = PU.oracle_problem(pr)
+    lad = O.Ladder(pb, pr.beta, W=W, swap_rate=sr, add_every_N=N)
+    lad.set_proposals([(PU.KIND_TO_ORACLE[kind], fac[r], 0.0) for r in range(Nt)])
+    lad.use_philox(0x5EED0001)
+    lad.enable_history(cap)
+    lad.set_states(PU.to_oracle_order(x0, Nt, W))
+    eng.step(steps); eng.sync()
+    lad.pt_step(steps)
+    PU.assert_same_state(eng, lad, "after %d steps" % steps)
+    he, ho = eng.history(), lad.history()
+    nsize = eng.nsize
+    assert nsize.max() <= cap and nsize.min() >= 2
+    double_adds = int((eng.nhist > steps).sum())
+    assert double_adds > 0                                  # some rungs made two add_state calls in one step
+    for name in ("x", "llike", "lprior", "naccept", "ntries", "last_type"):
+        a = he[name]                                        # [cap][Nt*W] engine order
+        b = ho[name]                                        # [N][cap] oracle order
+        for s_ in range(int(nsize.max())):
+            have = nsize > s_
+            got = a[s_ % cap][have]
+            want = PU.to_engine_order(b[:, s_], Nt, W)[have]
+            assert np.array_equal(got, want), (name, s_, np.argwhere(got != want)[:3].tolist())
+    assert np.array_equal(he["row"][0], np.zeros(Nt * W))
+    eng.close()
+
+
+def test_history_ring_wraps_and_sharded_cold_chain():
+    """(1) a ring shorter than the run keeps the newest rows; (2) the cold rung recorded on the first of two shards equals
+    the single-engine history (the shard's top rung cannot be recorded: loud)."""
+    import shard_sim
+    from ptmcmc_amd.parallel import shard_bounds
+    from ptmcmc_amd.problems import GaussianProblem
+    D, Nt, W, sr, steps = 8, 8, 64, 0.45, 30
+    pr = GaussianProblem(D, Nt, 1e3)
+    ref = E.Engine(D, Nt, W, swap_rate=sr, history_rungs=Nt, history_capacity=64)
+    small = E.Engine(D, Nt, W, swap_rate=sr, history_rungs=2, history_capacity=5)
+    for e in (ref, small):
+        pr.configure(e, E.PROP_LOWER)
+    ref.init_from_prior()
+    x0 = ref.states()
+    small.set_states(x0)
+    shards = []
+    for g in range(2):
+        r0, n = shard_bounds(Nt, 2, g)
+        e = E.Engine(D, Nt, W, swap_rate=sr, rung_begin=r0, rung_count=n, history_rungs=(1 if g == 0 else 0), history_capacity=64)
+        pr.configure(e, E.PROP_LOWER)
+        e.set_states(x0[r0 * W:(r0 + n) * W])
+        shards.append(e)
+    with pytest.raises(E.PtmError, match="top rung"):
+        E.Engine(D, Nt, W, rung_begin=0, rung_count=4, history_rungs=4, history_capacity=8)
+    lads = shard_sim.build([_DevShard(e) for e in shards], halo=4)
+    copy = lambda dst, src: dst.copy_from(src.ptr)
+    ref.step(steps); small.step(steps); shard_sim.step(lads, copy, steps)
+    ref.sync(); small.sync()
+    hr, hs, h0 = ref.history(), small.history(), shards[0].history()
+    ns = ref.nsize
+    for name in ("x", "llike", "lprior", "naccept", "ntries", "last_type", "row"):
+        # the ring of 5 holds saved rows nsize-5 .. nsize-1 of the two recorded rungs
+        for c in range(2 * W):
+            for s_ in range(int(ns[c]) - 5, int(ns[c])):
+                assert np.array_equal(hs[name][s_ % 5][c], hr[name][s_][c]), (name, c, s_)
+        for c in range(W):                       # cold rung on shard 0
+            n = int(ns[c])
+            assert np.array_equal(h0[name][:n, c], hr[name][:n, c]), (name, c)
+    for e in shards + [ref, small]:
+        e.close()
+
+
 def test_bounds_and_mixed_prior_path_bit_exact():
     """wrap / limit / reflect boundaries and a gaussian+log+uniform+polar+copolar prior on the device path."""
     D, Nt, W = 5, 6, 64
