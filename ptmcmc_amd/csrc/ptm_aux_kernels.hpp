@@ -372,7 +372,7 @@ struct Move {
 };
 typedef double d2_t __attribute__((ext_vector_type(2)));  // (HIP's double2 struct does not stay in registers as an array)
 
-template <int MV, int WPB>
+template <int MV, int WPB, bool HIST>   // HIST: history destinations exist (compiled apart: the hot build carries none of it)
 __global__ __launch_bounds__(64 * WPB, MV > 64 ? 1 : 4) void move_kernel(const Move p) {
   __shared__ int s_all[WPB][2][MV];
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -419,7 +419,7 @@ __global__ __launch_bounds__(64 * WPB, MV > 64 ? 1 : 4) void move_kernel(const M
     if (d != -3 && act) {
       double* dstp;
       if (d >= 0) dstp = p.x + (size_t)d * DP;
-      else if (d <= HIST_DST) {
+      else if (HIST && d <= HIST_DST) {
         const int c = HIST_DST - d;
         dstp = p.hist.x + hist_slot(p.hist, 1 + (long long)(p.nhist[c] / (unsigned int)p.add_every_n), c) * DP;
       } else { const int e = -d - 4; dstp = ((e & 1) ? p.send_down : p.send_up) + MSG_HDR + (size_t)(e >> 1) * RD; }
@@ -430,7 +430,7 @@ __global__ __launch_bounds__(64 * WPB, MV > 64 ? 1 : 4) void move_kernel(const M
   for (int q = 0; q < MV / 64; ++q) {
     const int d = s_dst[64 * q + lane];
     if (d >= 0) { p.ll[d] = sl[q]; p.lp[d] = sp[q]; }
-    else if (d <= HIST_DST) {
+    else if (HIST && d <= HIST_DST) {
       const int c = HIST_DST - d;
       const long long hrow = 1 + (long long)(p.nhist[c] / (unsigned int)p.add_every_n);
       hist_scalars(p.hist, hist_slot(p.hist, hrow, c), hrow, sl[q], sp[q], p.naccept[c], p.ntries[c], p.last_type[c]);

@@ -552,10 +552,12 @@ static int launch_decide(ptm_engine* e, const double* ll_below, const double* ll
   // a ladder moves about 0.17 rows per local rung and step at the default swap rate: short shards take the light kernel
   // first; whatever does not fit it is left for the MVCAP-row kernel
   if (e->nloc <= 256) {
-    hipLaunchKernelGGL((move_kernel<64, 4>), dim3((e->W + 3) / 4), dim3(256), 0, e->stream, m);
+    if (e->hist.rungs) hipLaunchKernelGGL((move_kernel<64, 4, true>), dim3((e->W + 3) / 4), dim3(256), 0, e->stream, m);
+    else hipLaunchKernelGGL((move_kernel<64, 4, false>), dim3((e->W + 3) / 4), dim3(256), 0, e->stream, m);
     HIPCHK(hipGetLastError());
   }
-  hipLaunchKernelGGL((move_kernel<MVCAP, 1>), dim3(e->W), dim3(64), 0, e->stream, m);
+  if (e->hist.rungs) hipLaunchKernelGGL((move_kernel<MVCAP, 1, true>), dim3(e->W), dim3(64), 0, e->stream, m);
+  else hipLaunchKernelGGL((move_kernel<MVCAP, 1, false>), dim3(e->W), dim3(64), 0, e->stream, m);
   HIPCHK(hipGetLastError());
   return PTM_OK;
 }
