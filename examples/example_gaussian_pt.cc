@@ -1,10 +1,11 @@
 // example_gaussian_pt.cc -- the reference's PT-on-a-correlated-Gaussian set-up (cython/exampleGaussian.py main(),
 // BASELINE.md scratch driver) written against ptmcmc_gpu.hh: same classes, same call sequence, every step on the MI355X.
 //   build: g++ -std=c++11 -O2 -Iinclude -Iptmcmc_amd/host examples/example_gaussian_pt.cc -Lptmcmc_amd -lptm_engine -Wl,-rpath,$PWD/ptmcmc_amd
-//   usage: example_gaussian_pt [mode] [D] [Ntemps] [nsteps]      mode = device | callback
+//   usage: example_gaussian_pt [mode] [D] [Ntemps] [nsteps] [chainfile]      mode = device | callback
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <fstream>
 #include <vector>
 
 #include "ptmcmc_gpu.hh"
@@ -45,6 +46,7 @@ int main(int argc, char** argv) {
   gaussian_prop prop(sig, 0.0);
 
   parallel_tempering_chains ptc(Nt, 100.0, 0.2, 10);
+  ptc.keep_history(1 + (nsteps + nsteps / 4) / 5);   // every 10th state, up to two adds per step
   ptc.initialize(&like, like.getObjectPrior().get(), 1);
   ptc.set_proposal(prop);
 
@@ -64,5 +66,11 @@ int main(int argc, char** argv) {
          callback ? "callback" : "device", D, Nt, ptc.getStep(), m2[0] / nsteps, D - 1, m2[D - 1] / nsteps, ptc.getLogPost(),
          ptc.subchain(Nt - 1)->invTemp(), sa, st, t.calls);
   printf("%s", ptc.status().c_str());
+  if (argc > 5) {   // the cold chain's file, as MH_chain::dumpChain writes it (chain.cc:1112-1135)
+    std::ofstream os(argv[5]);
+    os.precision(13);
+    ptc.dumpChain(0, os, nsteps / 4, 10);
+    printf("wrote %s\n", argv[5]);
+  }
   return 0;
 }

@@ -381,7 +381,7 @@ class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:
   const double Tmax, swap_rate, dpriormin;
   ptm_engine* eng;
   const stateSpace* sp;
-  int dim, nstep;
+  int dim, nstep, hist_rows;
   std::vector<double> temps, X, llike, lpost;
   bool fresh;
   std::vector<proposal_distribution*> props;
@@ -413,7 +413,7 @@ class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:
   parallel_tempering_chains(int Ntemps, double Tmax, double swap_rate = 0.01, int add_every_N = 1, bool do_evid = false,
                             bool verbose_evid = true, double dpriormin = -30)
       : Ntemps(Ntemps), add_every_N(add_every_N), Tmax(Tmax), swap_rate(swap_rate), dpriormin(dpriormin), eng(nullptr),
-        sp(nullptr), dim(0), nstep(0), temps(Ntemps, 1.0), fresh(false) {
+        sp(nullptr), dim(0), nstep(0), hist_rows(0), temps(Ntemps, 1.0), fresh(false) {
     // geometric ladder, chain.cc:1181-1183
     double tratio = Ntemps > 1 ? std::exp(std::log(Tmax) / (Ntemps - 1)) : 1.0;
     for (int i = 1; i < Ntemps; i++) temps[i] = temps[i - 1] * tratio;
@@ -422,6 +422,10 @@ class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:
     if (eng) ptm_engine_destroy(eng);
     for (auto p : props) delete p;
   }
+  // Keep what MH_chain::add_state saves (every add_every_N-th state of every rung, chain.cc:935-946) on the device, in a
+  // ring of `rows_per_chain` rows per rung; call before initialize().  The reference keeps the whole history in host
+  // vectors; dumpChain() below writes the same file from the ring.
+  void keep_history(int rows_per_chain) { hist_rows = rows_per_chain; }
   // chain.cc:1281-1365: n prior draws per rung; the device draws them (uniform / gaussian dimensions)
   void initialize(bayes_likelihood* log_likelihood, const sampleable_probability_function* log_prior, int n = 1, uint64_t seed = 0x5EED0001ull,
                   const std::vector<double>* start_states = nullptr) {
@@ -431,7 +435,7 @@ class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:
     cfg.struct_size = sizeof cfg;
     cfg.dim = dim; cfg.n_rungs = Ntemps; cfg.rung_begin = 0; cfg.rung_count = Ntemps; cfg.n_walkers = 1; cfg.seed = seed;
     cfg.swap_rate = swap_rate; cfg.add_every_n = add_every_N; cfg.min_prior = dpriormin; cfg.device = -1; cfg.stream = nullptr;
-    cfg.time_kernels = 0; cfg.swap_log_steps = 0; cfg.exchange_row_capacity = 0; cfg.history_rungs = 0; cfg.history_capacity = 0;
+    cfg.time_kernels = 0; cfg.swap_log_steps = 0; cfg.exchange_row_capacity = 0; cfg.history_rungs = hist_rows > 0 ? Ntemps : 0; cfg.history_capacity = hist_rows;
     ptm_check(ptm_engine_create(&cfg, &eng), "parallel_tempering_chains::initialize");
     std::vector<int> lo(dim), hi(dim), types;
     std::vector<double> xmin(dim), xmax(dim), centers, halfwidths;
@@ -505,6 +509,37 @@ class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:
     exit(1);
   }
   ptm_engine* engine() { return eng; }
+  // MH_chain::dumpChain (chain.cc:1112-1135) for rung `ichain`: one line per saved step i = Nburn, Nburn+ievery, ... :
+  //   i lpost llike acceptance_ratio prop_type: p0 ... pD-1 invtemp
+  // Rows that have already left the ring are skipped (the ring holds the newest rows_per_chain saved states).
+  void dumpChain(int ichain, std::ostream& os, int Nburn = 0, int ievery = 1) {
+    if (hist_rows <= 0) { std::cout << "parallel_tempering_chains::dumpChain: call keep_history(rows) before initialize()" << std::endl; exit(1); }
+    const size_t HC = Ntemps, cap = hist_rows;
+    std::vector<double> hx(cap * HC * dim), hl(cap * HC), hp(cap * HC);
+    std::vector<int32_t> meta(cap * HC * 4);
+    std::vector<int64_t> nhist(Ntemps);
+    ptm_check(ptm_get_history(eng, hx.data(), hl.data(), hp.data(), meta.data()), "dumpChain");
+    ptm_check(ptm_get_array(eng, PTM_ARR_NHIST, nhist.data()), "dumpChain");
+    const int Ninit = 1, Nhist = (int)nhist[ichain];
+    os << "#Ninit=" << Ninit << ", Nburn=" << Nburn << "\n";
+    os << "#eval: log(posterior) log(likelihood) acceptance_ratio prop_type: ";
+    for (int i = 0; i < dim; i++) os << (sp ? sp->get_name(i) : std::string("[unnamed]")) << " ";
+    os << std::endl;
+    if (Nburn + Ninit < 0) Nburn = -Ninit;
+    const double invtemp = 1 / temps[ichain];
+    for (int i = Nburn; i < Nhist; i += ievery) {
+      int idx = Ninit + i;                                          // chain.cc:1124-1125
+      if (i >= 0) idx = Ninit + i / add_every_N;                    // get_state_idx, chain.cc:1041-1050 (Nzero = 0)
+      const size_t o = (size_t)(idx % (int)cap) * HC + ichain;
+      if (idx < 0 || meta[4 * o + 3] != idx) continue;              // not saved yet / overwritten in the ring
+      const double lpo = hp[o] + invtemp * hl[o];                   // chain.cc:928
+      os << i << " " << lpo << " " << hl[o] << " " << meta[4 * o] / (double)meta[4 * o + 1] << " " << meta[4 * o + 2] << ": ";
+      for (int j = 0; j < dim - 1; j++) os << hx[o * dim + j] << " ";
+      os << hx[o * dim + dim - 1];
+      os << " " << invtemp;
+      os << std::endl;
+    }
+  }
   // swap_count / swap_accept_count (chain.hh:244-245)
   void swap_counts(std::vector<int64_t>& tries, std::vector<int64_t>& accepts) {
     tries.assign(Ntemps > 1 ? Ntemps - 1 : 1, 0); accepts = tries;

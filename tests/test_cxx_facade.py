@@ -49,3 +49,31 @@ def test_facade_runs_pt_on_device_and_with_user_callback():
             abs(f(outs["device"], "var(x0)") - f(outs["callback"], "var(x0)")) < 1e-6
         assert int(outs["callback"].split("likelihood_calls=")[1]) > 1000
         assert int(outs["device"].split("likelihood_calls=")[1]) == 0
+
+
+@pytest.mark.gpu
+def test_facade_writes_the_cold_chain_file_from_the_device_history():
+    """MH_chain::dumpChain's format (chain.cc:1112-1135) from the history ring: header, then
+    'i lpost llike acceptance_ratio type: p0 .. pD-1 invtemp' for every saved step after burn-in."""
+    with tempfile.TemporaryDirectory() as d:
+        exe, out = os.path.join(d, "ex"), os.path.join(d, "chain.dat")
+        build(exe)
+        r = subprocess.run([exe, "device", "4", "8", "4000", out], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        lines = open(out).read().splitlines()
+        assert lines[0] == "#Ninit=1, Nburn=1000"
+        assert lines[1].startswith("#eval: log(posterior) log(likelihood) acceptance_ratio prop_type: x0 x1 x2 x3")
+        rows = [l for l in lines[2:] if l]
+        idx = np.array([int(l.split()[0]) for l in rows])
+        assert idx[0] == 1000 and np.all(np.diff(idx) == 10) and len(rows) >= 395   # >= 4000 adds after burn-in, every 10th
+        head, pars = zip(*(l.split(": ") for l in rows))
+        H = np.array([[float(v) for v in h.split()] for h in head])
+        X = np.array([[float(v) for v in p.split()] for p in pars])
+        assert X.shape[1] == 5 and np.all(X[:, 4] == 1.0)                  # D parameters + invtemp of the cold rung
+        assert np.all((H[:, 3] > 0) & (H[:, 3] <= 1)) and set(H[:, 4]) <= {-1.0, 0.0}
+        P = np.eye(4) + np.diag([-0.4] * 3, 1) + np.diag([-0.4] * 3, -1)
+        # flat box prior => lpost - llike is the prior constant; llike = -x'Px/2
+        assert np.allclose(H[:, 2], -0.5 * np.einsum("ni,ij,nj->n", X[:, :4], P, X[:, :4]), atol=1e-9)
+        assert np.allclose(H[:, 1] - H[:, 2], (H[:, 1] - H[:, 2])[0], atol=1e-9)
+        v0 = np.linalg.inv(P)[0, 0]
+        assert abs(X[:, 0].var() - v0) < 0.35 * v0
