@@ -166,6 +166,15 @@ int ptm_get_array(ptm_engine* e, int which, void* out);
 int ptm_get_swap_counts(ptm_engine* e, int64_t* tries, int64_t* accepts);
 /* candidates of the most recent step: pairs[W][maxswaps] (lower rung or -2), accepted[W][maxswaps] */
 int ptm_get_last_swaps(ptm_engine* e, int32_t* pairs, int32_t* accepted);
+/* Checkpoint / resume.  Everything a run's future depends on is: the states and their llikes (ptm_get_states,
+ * PTM_ARR_LLIKE), the MH_chain counters (PTM_ARR_NTRIES / NACCEPT / LAST_TYPE / NHIST), the step count (the random
+ * streams are counters of it) and, for the bookkeeping, the swap counters.  ptm_restore puts them back into an engine
+ * configured like the one they came from (same seed, ladder, proposals, target); the run then continues bit for bit.
+ * swap_tries / swap_accepts may be NULL (counters restart at 0).  Not built yet: restoring into an engine that keeps a
+ * history ring (PTM_ERR_UNSUPPORTED). */
+int ptm_restore(ptm_engine* e, const double* X, const double* llike, const int32_t* ntries, const int32_t* naccept,
+                const int32_t* last_type, const int64_t* nhist, uint64_t step_count, const int64_t* swap_tries,
+                const int64_t* swap_accepts);
 int ptm_max_swaps_per_step(ptm_engine* e);
 /* History of the recorded rungs (ptm_config.history_rungs): for chain (local rung r, walker w) at index r*W + w and ring
  * slot k: X[(k*HC + index)*dim ..], llike / lprior [k*HC + index], meta [4*(k*HC + index)] = {Naccept, Ntries,

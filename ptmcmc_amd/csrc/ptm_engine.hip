@@ -874,6 +874,33 @@ extern "C" int ptm_get_last_swaps(ptm_engine* e, int32_t* pairs, int32_t* accept
   return PTM_OK;
 }
 
+extern "C" int ptm_restore(ptm_engine* e, const double* X, const double* llike, const int32_t* ntries, const int32_t* naccept,
+                           const int32_t* last_type, const int64_t* nhist, uint64_t step_count, const int64_t* swap_tries,
+                           const int64_t* swap_accepts) {
+  if (!e || !X || !llike || !ntries || !naccept || !last_type || !nhist) return fail(PTM_ERR_INVALID, "null argument");
+  if (e->hist.rungs)
+    return fail(PTM_ERR_UNSUPPORTED, "restoring into an engine that keeps a history ring is not built yet (read the ring out with the checkpoint)");
+  int rc = ptm_set_states(e, X, llike);   // enforces (a no-op on saved states), recomputes lprior, resets counters
+  if (rc) return rc;
+  const size_t Nc = e->Nc;
+  std::vector<unsigned int> nh(Nc);
+  for (size_t c = 0; c < Nc; ++c) {
+    if (nhist[c] < 0 || nhist[c] > 0xFFFFFFFFll) return fail(PTM_ERR_INVALID, "nhist out of range");
+    nh[c] = (unsigned int)nhist[c];
+  }
+  if ((rc = upload(e->ntries, ntries, Nc, e->stream)) || (rc = upload(e->naccept, naccept, Nc, e->stream)) ||
+      (rc = upload(e->last_type, last_type, Nc, e->stream)) || (rc = upload(e->nhist, nh.data(), Nc, e->stream)))
+    return rc;
+  const size_t np = (size_t)e->W * (e->Nt > 1 ? e->Nt - 1 : 1);
+  if (swap_tries && (rc = upload(e->swap_try, (const long long*)swap_tries, np, e->stream))) return rc;
+  if (swap_accepts && (rc = upload(e->swap_acc, (const long long*)swap_accepts, np, e->stream))) return rc;
+  if (!swap_tries) HIPCHK(hipMemsetAsync(e->swap_try, 0, np * 8, e->stream));
+  if (!swap_accepts) HIPCHK(hipMemsetAsync(e->swap_acc, 0, np * 8, e->stream));
+  e->step = step_count;
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return PTM_OK;
+}
+
 extern "C" int ptm_max_swaps_per_step(ptm_engine* e) { return e ? e->ms : 0; }
 
 extern "C" int ptm_get_history(ptm_engine* e, double* X, double* llike, double* lprior, int32_t* meta) {

@@ -25,7 +25,7 @@ EXPORTS = [
     "ptm_set_bounds", "ptm_set_prior", "ptm_set_target_gaussian", "ptm_set_target_callback", "ptm_set_ladder",
     "ptm_set_proposals", "ptm_set_states", "ptm_init_from_prior", "ptm_sweep", "ptm_step", "ptm_sync",
     "ptm_copy_llike", "ptm_llike_device_ptr", "ptm_exchange_decide", "ptm_exchange_finish_and_sweep", "ptm_exchange_buffer_doubles", "ptm_exchange_row_capacity", "ptm_get_states",
-    "ptm_get_array", "ptm_get_swap_counts", "ptm_get_last_swaps", "ptm_max_swaps_per_step", "ptm_get_history", "ptm_step_count",
+    "ptm_get_array", "ptm_get_swap_counts", "ptm_get_last_swaps", "ptm_max_swaps_per_step", "ptm_get_history", "ptm_restore", "ptm_step_count",
     "ptm_timer_start", "ptm_timer_stop", "ptm_get_kernel_times", "ptm_sweep_kernel_name", "ptm_debug_eval",
     "ptm_debug_philox", "ptm_debug_boxmuller", "ptm_debug_sqrt_scan", "ptm_debug_evaluate",
     "ptm_dev_alloc", "ptm_dev_free", "ptm_dev_copy",
@@ -100,6 +100,8 @@ def load():
     L.ptm_exchange_buffer_doubles.argtypes = [C.c_void_p]
     L.ptm_exchange_row_capacity.argtypes = [C.c_void_p]
     L.ptm_get_history.argtypes = [C.c_void_p, _dp, _dp, _dp, _i32p]
+    L.ptm_restore.argtypes = [C.c_void_p, _dp, _dp, _i32p, _i32p, _i32p, C.POINTER(C.c_int64), C.c_uint64, C.POINTER(C.c_int64),
+                              C.POINTER(C.c_int64)]
     L.ptm_debug_sqrt_scan.argtypes = [C.c_int, C.POINTER(C.c_uint64)]
     L.ptm_debug_evaluate.argtypes = [C.c_void_p, _dp, C.c_int, _i32p, _dp, _dp, _dp]
     _lib = L
@@ -295,6 +297,20 @@ class Engine:
     @property
     def exchange_buffer_doubles(self):
         return self.L.ptm_exchange_buffer_doubles(self.h)
+
+    def checkpoint(self):
+        """everything the run's future depends on (ptm_restore)"""
+        t, a = self.swap_counts()
+        return dict(x=self.states(), llike=self.llike, ntries=self.ntries.astype(np.int32), naccept=self.naccept.astype(np.int32),
+                    last_type=self.last_type.astype(np.int32), nhist=self.nhist.astype(np.int64), step=self.step_count,
+                    swap_tries=np.ascontiguousarray(t, dtype=np.int64), swap_accepts=np.ascontiguousarray(a, dtype=np.int64))
+
+    def restore(self, ck):
+        i64 = lambda v: np.ascontiguousarray(v, dtype=np.int64).ctypes.data_as(C.POINTER(C.c_int64))
+        i32 = lambda v: np.ascontiguousarray(v, dtype=np.int32).ctypes.data_as(_i32p)
+        f64 = lambda v: np.ascontiguousarray(v, dtype=np.float64).ctypes.data_as(_dp)
+        _chk(self.L.ptm_restore(self.h, f64(ck["x"]), f64(ck["llike"]), i32(ck["ntries"]), i32(ck["naccept"]), i32(ck["last_type"]),
+                                i64(ck["nhist"]), int(ck["step"]), i64(ck["swap_tries"]), i64(ck["swap_accepts"])))
 
     def history(self):
         """dict of arrays [cap][history_rungs*W](,D): x, llike, lprior, naccept, ntries, last_type, row (saved row number,

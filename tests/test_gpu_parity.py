@@ -284,6 +284,30 @@ def test_history_ring_wraps_and_sharded_cold_chain():
         e.close()
 
 
+@pytest.mark.parametrize("D,Nt,W,kind", [(32, 16, 64, E.PROP_LOWER), (6, 9, 5, E.PROP_DENSE)])
+def test_checkpoint_and_resume_continue_bit_for_bit(D, Nt, W, kind):
+    """ptm_restore: states, llikes, counters, step count and swap counters put into a fresh engine => the same future."""
+    from ptmcmc_amd.problems import GaussianProblem
+    pr = GaussianProblem(D, Nt, 1e3)
+    a = E.Engine(D, Nt, W, swap_rate=0.3, add_every_n=3)
+    pr.configure(a, kind)
+    a.init_from_prior()
+    a.step(17); a.sync()
+    ck = a.checkpoint()
+    a.step(23); a.sync()
+    b = E.Engine(D, Nt, W, swap_rate=0.3, add_every_n=3)
+    pr.configure(b, kind)
+    b.restore(ck)
+    assert b.step_count == 17
+    b.step(23); b.sync()
+    assert np.array_equal(a.states(), b.states())
+    for name in ("llike", "lprior", "ntries", "naccept", "nhist", "nsize", "last_type"):
+        assert np.array_equal(getattr(a, name), getattr(b, name)), name
+    ta, aa = a.swap_counts(); tb, ab = b.swap_counts()
+    assert np.array_equal(ta, tb) and np.array_equal(aa, ab)
+    a.close(); b.close()
+
+
 def test_bounds_and_mixed_prior_path_bit_exact():
     """wrap / limit / reflect boundaries and a gaussian+log+uniform+polar+copolar prior on the device path."""
     D, Nt, W = 5, 6, 64
