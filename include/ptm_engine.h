@@ -144,6 +144,12 @@ int ptm_exchange_decide(ptm_engine* e, const void* ll_below_dev, const void* ll_
 /* exchange phase, part 2 + MH sweep: lands the rows of the neighbours' messages (device buffers of the same size; the
  * message from below is required unless this is the first shard, the one from above unless it is the last) */
 int ptm_exchange_finish_and_sweep(ptm_engine* e, const void* recv_from_below_dev, const void* recv_from_above_dev);
+/* The same in pieces, for callers that overlap the messages with arithmetic: the Metropolis moves of a step do not
+ * depend on the rows in flight (their landing slots are exchanged rungs, which make no move), only the llike halo of
+ * the NEXT step does.  ptm_sweep_rungs sweeps local rungs [first_local_rung, first_local_rung + n_rungs); every local
+ * rung must be swept exactly once per step and the last call passes closes_step != 0. */
+int ptm_exchange_install(ptm_engine* e, const void* recv_from_below_dev, const void* recv_from_above_dev);
+int ptm_sweep_rungs(ptm_engine* e, int first_local_rung, int n_rungs, int closes_step);
 /* size of one boundary message in doubles: 2 + row capacity * (padded dim + 4) */
 int ptm_exchange_buffer_doubles(ptm_engine* e);
 int ptm_exchange_row_capacity(ptm_engine* e);

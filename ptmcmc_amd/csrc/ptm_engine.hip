@@ -453,6 +453,7 @@ static Dev make_dev(ptm_engine* e) {
   p.ntries = e->ntries; p.naccept = e->naccept; p.last_type = e->last_type; p.nhist = e->nhist;
   p.touch = e->touch; p.err = e->err;
   p.hist = e->hist;
+  p.c_begin = 0; p.c_end = e->Nc;
   return p;
 }
 
@@ -464,8 +465,14 @@ static SweepSel sweep_sel(const ptm_engine* e) {
   return s;
 }
 
-static int launch_sweep(ptm_engine* e) {
+// one fused MH sweep over local rungs [rung0, rung0 + nr); `last` closes the step (the step count is the RNG position)
+static int launch_sweep(ptm_engine* e, int rung0 = 0, int nr = -1, bool last = true) {
   Dev p = make_dev(e);
+  if (nr < 0) nr = e->nloc - rung0;
+  if (rung0 < 0 || nr < 0 || rung0 + nr > e->nloc) return fail(PTM_ERR_INVALID, "rung range out of the shard");
+  p.c_begin = rung0 * e->W; p.c_end = (rung0 + nr) * e->W;
+  if (e->cb && (rung0 != 0 || nr != e->nloc)) return fail(PTM_ERR_UNSUPPORTED, "partial sweeps with a host-callback likelihood are not built");
+  if (nr == 0) { if (last) e->step += 1; return PTM_OK; }
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   if (e->cfg.time_kernels) {
     if (e->kev_used + 2 > e->kev.size()) {
@@ -509,7 +516,7 @@ static int launch_sweep(ptm_engine* e) {
     HIPCHK(launch(p));
   }
   if (ev1) HIPCHK(hipEventRecord(ev1, e->stream));
-  e->step += 1;
+  if (last) e->step += 1;
   return PTM_OK;
 }
 
@@ -789,6 +796,19 @@ extern "C" int ptm_dev_copy(void* dst, const void* src, size_t bytes) {
   HIPCHK(hipDeviceSynchronize());
   HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyDefault));
   return PTM_OK;
+}
+
+extern "C" int ptm_exchange_install(ptm_engine* e, const void* recv_below, const void* recv_above) {
+  int rc = ready(e);
+  if (rc) return rc;
+  const bool first = e->r0 == 0, last = e->r0 + e->nloc == e->Nt;
+  if ((!first && !recv_below) || (!last && !recv_above)) return fail(PTM_ERR_INVALID, "missing boundary message from a neighbour shard");
+  return launch_install(e, first ? nullptr : (const double*)recv_below, last ? nullptr : (const double*)recv_above);
+}
+extern "C" int ptm_sweep_rungs(ptm_engine* e, int first_local_rung, int n_rungs, int closes_step) {
+  int rc = ready(e);
+  if (rc) return rc;
+  return launch_sweep(e, first_local_rung, n_rungs, closes_step != 0);
 }
 
 extern "C" int ptm_exchange_buffer_doubles(ptm_engine* e) { return e ? MSG_HDR + e->row_cap * (e->DP + ROW_EXTRA) : 0; }

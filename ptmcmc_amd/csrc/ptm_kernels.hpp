@@ -71,6 +71,7 @@ __device__ __forceinline__ void hist_scalars(const Hist& h, size_t o, long long 
 
 struct Dev {
   int D, DP, Nt, r0, nloc, W, Nc;
+  int c_begin, c_end;   // chains [c_begin, c_end) are swept by this launch (whole rungs; the full range is [0, Nc))
   Hist hist;
   uint64_t seed, step;
   int add_every_n;
@@ -383,8 +384,8 @@ __global__ __launch_bounds__(256, PTM_SWEEP_WAVES) void sweep_kernel(const Dev p
 #pragma unroll
   for (int t = 0; t < BM_TABLE_DOUBLES / 512; ++t)
     reinterpret_cast<bm_d2*>(lds_all)[threadIdx.x + 256 * t] = reinterpret_cast<const bm_d2*>(BM_TABLE)[threadIdx.x + 256 * t];
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  int rl = (c < p.Nc ? c : p.Nc - 1) / p.W;
+  const int c = p.c_begin + blockIdx.x * 256 + threadIdx.x;
+  int rl = (c < p.c_end ? c : p.c_end - 1) / p.W;
   if (UNI) rl = __builtin_amdgcn_readfirstlane(rl);
   // (DP == 32: the DPP product wants the dense column-major image, which the host keeps beside the packed one)
   const int fstride = p.prop_stride;
@@ -396,10 +397,9 @@ __global__ __launch_bounds__(256, PTM_SWEEP_WAVES) void sweep_kernel(const Dev p
   // the table is shared by the block's four waves: wait for this wave's LDS writes only (a full __syncthreads would
   // also drain the factor loads just issued) and meet the others
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-  if (c >= p.Nc) return;
+  if (c >= p.c_end) return;
   const int w = c - rl * p.W;
   const int rg = p.r0 + rl;
-  const int Nc = p.Nc;
 
   const int tc = p.touch[c];  // > 0: the rung took part in that many exchange attempts => no MH move this step
   const bool propose_only = !SIMPLE && p.mode == 1;

@@ -45,8 +45,8 @@ __global__ __launch_bounds__(256, PTM_MFMA_WAVES) void sweep_mfma32_kernel(const
   double* ptile = lds_all + BM_TABLE_DOUBLES;   // tile (row tile 1, step m) at m*64, m = 0..7; (row tile 0, step m) at (8+m)*64, m = 0..3
   double* lbox = ptile + 12 * 64;
   const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
-  const int c0 = (blockIdx.x * 4 + wave) * 64;   // first chain of the wave; Nc is a multiple of 64
-  const bool live = c0 < p.Nc;                    // (a wave past the end still helps to stage the tables)
+  const int c0 = p.c_begin + (blockIdx.x * 4 + wave) * 64;   // first chain of the wave; ranges are multiples of 64
+  const bool live = c0 < p.c_end;                              // (a wave past the end still helps to stage the tables)
   const int c0s = live ? c0 : 0;
   double* red = lbox + 64 + wave * 128;
   const int rl = __builtin_amdgcn_readfirstlane(c0s / p.W);

@@ -24,7 +24,7 @@ EXPORTS = [
     "ptm_last_error", "ptm_abi_version", "ptm_device_count", "ptm_engine_create", "ptm_engine_destroy",
     "ptm_set_bounds", "ptm_set_prior", "ptm_set_target_gaussian", "ptm_set_target_callback", "ptm_set_ladder",
     "ptm_set_proposals", "ptm_set_states", "ptm_init_from_prior", "ptm_sweep", "ptm_step", "ptm_sync",
-    "ptm_copy_llike", "ptm_llike_device_ptr", "ptm_exchange_decide", "ptm_exchange_finish_and_sweep", "ptm_exchange_buffer_doubles", "ptm_exchange_row_capacity", "ptm_get_states",
+    "ptm_copy_llike", "ptm_llike_device_ptr", "ptm_exchange_decide", "ptm_exchange_finish_and_sweep", "ptm_exchange_install", "ptm_sweep_rungs", "ptm_exchange_buffer_doubles", "ptm_exchange_row_capacity", "ptm_get_states",
     "ptm_get_array", "ptm_get_swap_counts", "ptm_get_last_swaps", "ptm_max_swaps_per_step", "ptm_get_history", "ptm_restore", "ptm_step_count",
     "ptm_timer_start", "ptm_timer_stop", "ptm_get_kernel_times", "ptm_sweep_kernel_name", "ptm_debug_eval",
     "ptm_debug_philox", "ptm_debug_boxmuller", "ptm_debug_sqrt_scan", "ptm_debug_evaluate",
@@ -86,6 +86,8 @@ def load():
     L.ptm_dev_free.argtypes = [C.c_void_p]
     L.ptm_dev_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     L.ptm_exchange_finish_and_sweep.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.ptm_exchange_install.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.ptm_sweep_rungs.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
     L.ptm_get_states.argtypes = [C.c_void_p, _dp]
     L.ptm_get_array.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     L.ptm_get_swap_counts.argtypes = [C.c_void_p, _i64p, _i64p]
@@ -293,6 +295,12 @@ class Engine:
 
     def exchange_decide(self, ll_below_dev, ll_above_dev, halo_rungs, send_up_dev, send_down_dev):
         _chk(self.L.ptm_exchange_decide(self.h, ll_below_dev, ll_above_dev, halo_rungs, send_up_dev, send_down_dev))
+
+    def exchange_install(self, recv_below_dev, recv_above_dev):
+        _chk(self.L.ptm_exchange_install(self.h, recv_below_dev, recv_above_dev))
+
+    def sweep_rungs(self, first_local_rung, n_rungs, closes_step):
+        _chk(self.L.ptm_sweep_rungs(self.h, first_local_rung, n_rungs, 1 if closes_step else 0))
 
     @property
     def exchange_buffer_doubles(self):

@@ -38,6 +38,7 @@ if __name__ == "__main__":
     sh = OracleShard(lad, r0, nloc, seed)
     sl = ShardedLadder(sh, dist, rank, world, halo=halo)
     sl.step(nsteps)
+    sl.drain()
     sh.sync()
     np.savez(out % rank, x=sh.local(sh.x), ll=sh.local(sh.ll), nhist=sh.local(sh.nhist), nacc=sh.local(lad.naccept),
              st=sh.swap_try, sa=sh.swap_acc, r0=r0, nloc=nloc)

@@ -137,27 +137,41 @@ class OracleShard:
                             self.moves.append((c, self.x[cs].copy(), self.ll[cs], self.lp[cs]))
                     else:
                         self.arrive.append((c, "above" if s >= r1 else "below", w))
+        # rows that stay inside the shard move now (the engine's move kernel); arrivals wait for install()
+        for c, x, ll, lp in self.moves:
+            self.x[c] = x; self.ll[c] = ll; self.lp[c] = lp
+        self.moves = []
 
-    def finish_and_sweep(self, recv_below, recv_above):
+    can_overlap = True
+
+    def install(self, recv_below, recv_above):
+        """rows that arrived from the neighbours land in the holes the decisions named"""
         D, W = self.D, self.W
         rb = None if recv_below is None else recv_below.numpy().reshape(D + 2, W)
         ra = None if recv_above is None else recv_above.numpy().reshape(D + 2, W)
-        for c, x, ll, lp in self.moves:
-            self.x[c] = x; self.ll[c] = ll; self.lp[c] = lp
         for c, where, w in self.arrive:
             buf = ra if where == "above" else rb
             self.x[c] = buf[:D, w]; self.ll[c] = buf[D, w]; self.lp[c] = buf[D + 1, w]
+        self.arrive = []
+
+    def sweep_rungs(self, first, n, closes_step):
         L = O.lib()
         lad = self.lad
-        for w in range(W):
-            for r in range(self.r0, self.r0 + self.nloc):
+        for w in range(self.W):
+            for r in range(self.r0 + first, self.r0 + first + n):
                 c = self.idx(w, r)
                 if self.touched[c]:
                     for _ in range(int(self.touched[c])):
                         self._add_state(c)
+                    self.touched[c] = 0
                     continue
                 L.ptmo_mh_step(lad.s, lad.pb.p, C.byref(lad._props[r]), lad.rng, w, r)
-        lad.s.contents.step += 1
+        if closes_step:
+            lad.s.contents.step += 1
+
+    def finish_and_sweep(self, recv_below, recv_above):
+        self.install(recv_below, recv_above)
+        self.sweep_rungs(0, self.nloc, True)
 
     def sync(self):
         if self.far:

@@ -40,3 +40,39 @@ def step(ladders, copy, n=1):
             lad.finish()
         for lad in ladders:
             lad.b.sync()
+
+
+def step_overlapped(ladders, copy, n=1):
+    """the order ShardedLadder.step uses to hide both message rounds (interior A | install | boundary | halos | interior B),
+    driven in lockstep with the messages delivered by plain copies"""
+    for lad in ladders:
+        if lad._halo_reqs is None:
+            lad.stage_halos()
+            lad._halo_reqs = []
+    for lad in ladders:
+        lad.b.sync()
+    if not getattr(ladders[0], "_sim_halos_delivered", False):
+        _deliver(ladders, "halo", copy)
+        for lad in ladders:
+            lad._sim_halos_delivered = True
+    for _ in range(n):
+        plans = [lad.sweep_plan() for lad in ladders]
+        for lad in ladders:
+            lad.decide()
+        for lad, (bottom, int_a, int_b, top) in zip(ladders, plans):
+            lad.b.sweep_rungs(int_a[0], int_a[1], False)
+        for lad in ladders:
+            lad.b.sync()
+        _deliver(ladders, "rows", copy)
+        for lad, (bottom, int_a, int_b, top) in zip(ladders, plans):
+            lad.b.install(lad.recv_below, lad.recv_above)
+            lad.b.sweep_rungs(bottom[0], bottom[1], False)
+            lad.b.sweep_rungs(top[0], top[1], False)
+            lad.stage_halos()
+        for lad in ladders:
+            lad.b.sync()
+        _deliver(ladders, "halo", copy)
+        for lad, (bottom, int_a, int_b, top) in zip(ladders, plans):
+            lad.b.sweep_rungs(int_b[0], int_b[1], True)
+        for lad in ladders:
+            lad.b.sync()

@@ -389,13 +389,23 @@ class _DevShard:
         p = lambda b: None if b is None else b.ptr
         self.e.exchange_finish_and_sweep(p(rb), p(ra))
 
+    def install(self, rb, ra):
+        p = lambda b: None if b is None else b.ptr
+        self.e.exchange_install(p(rb), p(ra))
+
+    def sweep_rungs(self, first, n, closes_step):
+        self.e.sweep_rungs(first, n, closes_step)
+
+    can_overlap = True
+
     def sync(self):
         self.e.sync()
 
 
+@pytest.mark.parametrize("overlap", [False, True])
 @pytest.mark.parametrize("D,Nt,W,G,halo,sr", [(32, 16, 64, 2, 4, 0.3), (8, 12, 64, 3, 4, 0.45), (5, 9, 3, 4, 3, 0.45),
                                               (32, 64, 64, 8, 4, 0.1), (4, 6, 64, 6, 2, 0.5)])
-def test_sharded_engines_match_single_engine(D, Nt, W, G, halo, sr):
+def test_sharded_engines_match_single_engine(D, Nt, W, G, halo, sr, overlap):
     import shard_sim
     from ptmcmc_amd.parallel import shard_bounds
     from ptmcmc_amd.problems import GaussianProblem
@@ -417,7 +427,7 @@ def test_sharded_engines_match_single_engine(D, Nt, W, G, halo, sr):
     for k in range(nsteps):
         ref.step(1)
         try:
-            shard_sim.step(lads, copy, 1)
+            (shard_sim.step_overlapped if overlap else shard_sim.step)(lads, copy, 1)
         except E.PtmError as ex:         # a chain longer than the halo / a row through a whole shard: must be LOUD
             assert "halo" in str(ex) or "crossed" in str(ex)   # (never "overflowed": capacity = W at these sizes)
             far = True
