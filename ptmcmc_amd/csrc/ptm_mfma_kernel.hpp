@@ -90,6 +90,10 @@ __global__ __launch_bounds__(256, PTM_MFMA_WAVES) void sweep_mfma32_kernel(const
   const int ntries0 = p.ntries[c], naccept0 = p.naccept[c];
   const unsigned int nhist0 = p.nhist[c];
   const double beta = as_c(p.beta)[rg];
+  // log of the chain's accept uniform (block 0 of its stream): drawn here once for all 64 chains -- the Metropolis test
+  // itself runs per pass on half the lanes, and this is its expensive part.  (The reference draws the uniform only when
+  // logH < 0, chain.cc:998; a counter-based stream makes the draw free of side effects, so drawing it always is the same.)
+  const double log_u = dlog_u01(draw_block(p.seed, TAG_MH, (uint32_t)(w0 + l) * (uint32_t)p.Nt + (uint32_t)rg, p.step, 0).v0);
 
 #pragma unroll
   for (int t = 0; t < BM_TABLE_DOUBLES / 512; ++t) reinterpret_cast<bm_d2*>(lds_all)[threadIdx.x + 256 * t] = st_bm[t];
@@ -245,11 +249,7 @@ __global__ __launch_bounds__(256, PTM_MFMA_WAVES) void sweep_mfma32_kernel(const
         if (!want_like) newlike = newlpost = -__builtin_inf();
         const double logH = newlpost - cur_lpost;
         accept = true;
-        if (logH < 0) {
-          const uint32_t stream = (uint32_t)(w0 + l) * (uint32_t)p.Nt + (uint32_t)rg;
-          const u32x4 o0 = draw_block(p.seed, TAG_MH, stream, p.step, 0);
-          accept = dlog_u01(o0.v0) < logH;  // chain.cc:998-1001 (NaN stays accepted)
-        }
+        if (logH < 0) accept = log_u < logH;  // chain.cc:998-1001 (NaN stays accepted)
         p.ntries[c] = ntries0 + 1;
         p.nhist[c] = nhist0 + 1u;
         if (hist_on && nhist0 % (unsigned int)p.add_every_n == 0u) {
