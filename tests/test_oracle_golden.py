@@ -62,6 +62,35 @@ def test_boxmuller_matches_formula_and_moments():
         assert math.isfinite(a) and math.isfinite(b)
 
 
+def test_boxmuller_normals_are_normal():
+    """distribution checks of the table-driven Box-Muller on 4e5 draws of a Philox stream: moments up to the 6th,
+    a Kolmogorov-Smirnov distance, tail frequencies, independence of the pair, and symmetry."""
+    from scipy import stats
+    n = 200000
+    z = np.empty((n, 2))
+    for i in range(0, n, 2):
+        o = O.draw_block(12345, 0, 7, i // 2, 1)
+        z[i] = O.boxmuller(o[0], o[1])
+        z[i + 1] = O.boxmuller(o[2], o[3])
+    a = z.ravel()
+    m = a.size
+    assert abs(a.mean()) < 4 / np.sqrt(m)
+    assert abs(a.var() - 1) < 4 * np.sqrt(2 / m)
+    assert abs(stats.skew(a)) < 4 * np.sqrt(6 / m)
+    assert abs(stats.kurtosis(a)) < 4 * np.sqrt(24 / m)                    # excess kurtosis
+    assert abs((a ** 6).mean() - 15) < 4 * np.sqrt((10395 - 225) / m)      # E z^6 = 15, Var z^6 = 10395 - 15^2
+    assert stats.kstest(a, "norm").statistic < 1.63 / np.sqrt(m)            # 1 % critical value
+    for t in (1.0, 2.0, 3.0, 4.0):
+        p = 2 * stats.norm.sf(t)
+        assert abs((np.abs(a) > t).mean() - p) < 4.5 * np.sqrt(p / m), t
+    assert abs(np.corrcoef(z[:, 0], z[:, 1])[0, 1]) < 4 / np.sqrt(n)
+    assert abs(np.corrcoef(z[:, 0] ** 2, z[:, 1] ** 2)[0, 1]) < 4 / np.sqrt(n)
+    # exact symmetry: flipping the half-turn bit of the angle draw flips both normals
+    for k1, k2 in [(5, 77), (0xdeadbeef, 0x12345678), (0xffffffff, 0x7fffffff)]:
+        p0, p1 = O.boxmuller(k1, k2), O.boxmuller(k1, k2 ^ 0x80000000)
+        assert p0[0] == -p1[0] and p0[1] == -p1[1]
+
+
 def test_boundary_enforce_table():
     g = golden_io.load("basic.json.gz")["boundary"]
     assert len(g) > 300
