@@ -69,7 +69,7 @@ typedef struct ptm_config {
   int32_t device;         /* HIP device ordinal, -1 = current device */
   void* stream;           /* hipStream_t to launch on; NULL = the engine creates its own */
   int32_t time_kernels;   /* !=0: bracket every sweep-kernel launch with HIP events (ptm_get_kernel_times) */
-  int32_t swap_log_steps; /* >0: keep the per-candidate swap log of the last N steps on the device */
+  int32_t swap_log_steps; /* reserved, must be 0 (the per-candidate swap log of the LAST step is always kept: ptm_get_last_swaps) */
   int32_t exchange_row_capacity; /* row slots per boundary message (multi-GPU); 0 = automatic:
                                   * min(n_walkers, n_walkers*swap_rate + 8 sigma + 64).  More rows crossing one boundary in
                                   * one step than this is reported as PTM_ERR_FAR_MOVE by ptm_sync, never silently dropped */

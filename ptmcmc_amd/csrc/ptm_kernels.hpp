@@ -1,8 +1,12 @@
-// ptm_kernels.hpp -- gfx950 kernels of the parallel-tempering step engine.
+// ptm_kernels.hpp -- gfx950 kernels of the parallel-tempering step engine: the data layout, the shared device
+// functions (state space, prior, Gaussian target, proposal product) and the GENERAL fused sweep kernel (one lane = one
+// chain).  The 32-dimensional workload has its own kernel on the f64 matrix cores (ptm_mfma_kernel.hpp); the exchange
+// phase is in ptm_aux_kernels.hpp.
 //
 // Data layout in HBM (per engine = per GPU shard), Nc = rung_count * W chains, chain c = rung_local * W + walker:
 //   x      [Nc][DP]  double   one contiguous ROW per chain (DP = dimension padded to 4/8/16/32; pad entries stay 0,
-//                             pad factor rows / precision rows are 0), updated IN PLACE
+//                             pad factor rows / precision rows are 0), updated IN PLACE; position of dimension d
+//                             inside the row: row_pos (identity except for DP = 32)
 //   llike, lprior [Nc] double (lpost is always fl(lprior + fl(beta*llike)), chain.cc:928)
 //   ntries, naccept, last_type [Nc] int32; nhist [Nc] uint32          (MH_chain counters, chain.hh:150-170;
 //                             Nsize is a function of Nhist: 1 + ceil(nhist / add_every_N), chain.cc:935-947)
@@ -21,18 +25,9 @@
 
 #include "ptm_device_math.hpp"
 
-// keeps the scheduler from hoisting every scalar table load of the unrolled mat-vecs to the top of the kernel
-// (which spills SGPRs by the thousand); one fence per factor column / precision row
-// minimum waves per SIMD the fused sweep kernel is compiled for (register budget 512 / waves)
+// minimum waves per SIMD the general sweep kernel is compiled for (register budget 512 / waves)
 #ifndef PTM_SWEEP_WAVES
 #define PTM_SWEEP_WAVES 3
-#endif
-// 1: keep the current state in registers through the likelihood (no re-read of rejected rows, 2*DP more VGPRs)
-#ifndef PTM_KEEP_X
-#define PTM_KEEP_X 0
-#endif
-#ifndef PTM_SCHED_FENCE
-#define PTM_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #endif
 
 namespace ptm {
@@ -43,11 +38,6 @@ enum { P_FLAT = 0, P_UNIFORM = 1, P_GAUSSIAN = 2, P_POLAR = 3, P_COPOLAR = 4, P_
 
 // read-only tables written by the host before any launch: reading them through the constant address space lets
 // the backend use scalar loads whenever the address is wave-uniform, with no alias analysis in the way.
-// register-resident per-lane vectors: constant-index element access on an ext_vector is pure SSA (no alloca), so the
-// accumulators survive the non-unrolled draw loops in VGPRs
-template <int N>
-using vecd = double __attribute__((ext_vector_type(N)));
-
 typedef const double __attribute__((address_space(4))) * cdp;
 typedef const int __attribute__((address_space(4))) * cip;
 __device__ __forceinline__ cdp as_c(const double* p) { return (cdp)(uintptr_t)p; }
@@ -365,10 +355,10 @@ __device__ __forceinline__ void dpp_half32(const DrawCtx& dc, const double* tab,
 }
 
 // ------------------------------------------------------------------------------------------------
-// THE hot kernel: one fused MH_chain::step (chain.cc:966-1022) per chain, all rungs x walkers per launch:
+// The general fused sweep kernel: one MH_chain::step (chain.cc:966-1022) per lane, all rungs x walkers per launch:
 //   gaussian_prop::draw (proposal_distribution.hh:194-218) -> state::add / enforce (states.cc:205-214,161-166)
-//   -> prior -> Gaussian likelihood -> Metropolis test -> add_state counters (chain.cc:916-949),
-// fused with the state hand-off of the exchange phase (rows named by src[]).
+//   -> prior -> Gaussian likelihood -> Metropolis test -> add_state counters and history (chain.cc:916-949).
+// Rungs that took part in an exchange attempt this step (touch[] > 0) make no move (chain.cc:1553-1557).
 //   UNI    the wave's 64 chains share one rung (W % 64 == 0): factor / beta addresses are wave-uniform (SGPR operands)
 //   SIMPLE open boundaries, all-uniform prior, zero mean, no one-dimensional moves (the BASELINE workload):
 //          the general state-space / prior code is not even compiled in.
