@@ -61,6 +61,7 @@ __device__ __forceinline__ double win_llike(const Decide& p, int r, int w) {
 }
 
 constexpr int MVCAP = 256;  // rows one ladder can move per step on the register path (move_kernel)
+typedef double d2_t __attribute__((ext_vector_type(2)));  // (HIP's double2 struct does not stay in registers as an array)
 
 // The reference decides the candidates strictly in pick order (chain.cc:1410-1537).  Two facts make that order
 // parallel over the ladder without changing any outcome:
@@ -99,6 +100,10 @@ __global__ __launch_bounds__(DECIDE_THREADS) void decide_kernel(const Decide p) 
   unsigned char* alive = reinterpret_cast<unsigned char*>(mid_ + ((WN + 3) & ~3));  // [ms] 0 dropped, 1 survives and is
                                                                                     //      ours, 2 survives, not ours
   unsigned char* accf = alive + ((ms + 7) & ~7);                              // [ms]
+  // The 256-thread form applies the moves itself (below), from a list kept in LDS; the 64-thread form hands the list to
+  // move_kernel through global memory.
+  constexpr bool FUSED = DECIDE_THREADS == 256;
+  int* lmv = reinterpret_cast<int*>(accf + ((ms + 7) & ~7));                  // [2][MVCAP], FUSED only
   double* llc = llc_ - wlo;                // indexed by global rung
   unsigned short* perm = perm_ - wlo;
   unsigned short* inv = inv_ - wlo;
@@ -226,8 +231,8 @@ __global__ __launch_bounds__(DECIDE_THREADS) void decide_kernel(const Decide p) 
   // -- the row moves.  The phase's net effect on the touched rungs is a permutation of rows: new row[r] =
   //    old row[perm[r]].  List every move (source slot -> destination slot, or -> boundary message for a row that
   //    leaves the shard) for move_kernel; the hole an arrival will fill is named in arr_above / arr_below.
-  int* gs = p.mv_src + (size_t)w * MVCAP;
-  int* gd = p.mv_dst + (size_t)w * MVCAP;
+  int* gs = FUSED ? lmv : p.mv_src + (size_t)w * MVCAP;
+  int* gd = FUSED ? lmv + MVCAP : p.mv_dst + (size_t)w * MVCAP;
   // source slot of the in-between row of rung r if its FIRST add_state of this step is one that saves, else -1
   auto hist_mid_src = [&](int r) -> int {
     if (r - p.r0 >= p.hist.rungs || r < p.r0 || r >= r1) return -1;
@@ -269,8 +274,66 @@ __global__ __launch_bounds__(DECIDE_THREADS) void decide_kernel(const Decide p) 
   }
   __syncthreads();
   const int nmv = cnt[1];
-  if (nmv <= MVCAP) {
+  if (nmv <= MVCAP && !FUSED) {
     if (lane == 0) p.mv_n[w] = nmv;   // move_kernel takes it from here
+    return;
+  }
+  if (nmv <= MVCAP) {
+    // ---- the moves, in place, by this block: GATHER every moved row into registers (16 lanes x 16 B = one 256-B row,
+    //      16 rows per round, up to 16 rounds), wait for all loads of all threads, then SCATTER.  With every read
+    //      finished before the first write no ordering between the moves is needed (they form cycles over this ladder's
+    //      own rows; other ladders' rows are never touched).
+    const int DPm = p.DP, RD = DPm + ROW_EXTRA;
+    for (int j = lane; j < nmv; j += DECIDE_THREADS) {
+      const int dv = gd[j];
+      if (dv == -1 || dv == -2) {   // a row that leaves the shard: claim its slot in the boundary message
+        const int dir = dv == -1 ? 0 : 1;
+        const int slot = atomicAdd(reinterpret_cast<int*>(dir ? p.send_down : p.send_up), 1);
+        if (slot >= p.row_cap) { atomicOr(p.err, 4); gd[j] = -3; }
+        else gd[j] = -4 - (2 * slot + dir);
+      }
+    }
+    __syncthreads();
+    const int g = lane >> 4, sub = lane & 15;
+    const bool act = 2 * sub < DPm;         // DP/2 lanes of 16 carry a row (16 B each)
+    const int col = act ? 2 * sub : 0;      // idle lanes re-read column 0 (harmless) so that no load is predicated
+    d2_t v[MVCAP / 16];
+#pragma unroll
+    for (int q = 0; q < MVCAP / 16; ++q) {
+      const int j = 16 * q + g;
+      v[q] = *reinterpret_cast<const d2_t*>(p.x + (size_t)(j < nmv ? gs[j] : 0) * DPm + col);   // past the list: row 0, never stored
+    }
+    const int msrc = lane < nmv ? gs[lane] : 0;
+    const double sl = p.ll[msrc], sp = p.lp[msrc];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();   // every gather of every thread has landed before the first scatter
+#pragma unroll
+    for (int q = 0; q < MVCAP / 16; ++q) {
+      const int j = 16 * q + g;
+      const int d = j < nmv ? gd[j] : -3;
+      if (d != -3 && act) {
+        double* dstp;
+        if (d >= 0) dstp = p.x + (size_t)d * DPm;
+        else if (d <= HIST_DST) {
+          const int c = HIST_DST - d;
+          dstp = p.hist.x + hist_slot(p.hist, 1 + (long long)(p.nhist[c] / (unsigned int)p.add_every_n), c) * DPm;
+        } else { const int e = -d - 4; dstp = ((e & 1) ? p.send_down : p.send_up) + MSG_HDR + (size_t)(e >> 1) * RD; }
+        *reinterpret_cast<d2_t*>(dstp + col) = v[q];
+      }
+    }
+    if (lane < nmv) {
+      const int d = gd[lane];
+      if (d >= 0) { p.ll[d] = sl; p.lp[d] = sp; }
+      else if (d <= HIST_DST) {
+        const int c = HIST_DST - d;
+        const long long hrow = 1 + (long long)(p.nhist[c] / (unsigned int)p.add_every_n);
+        hist_scalars(p.hist, hist_slot(p.hist, hrow, c), hrow, sl, sp, p.naccept[c], p.ntries[c], p.last_type[c]);
+      } else if (d != -3) {
+        const int e = -d - 4;
+        double* row = ((e & 1) ? p.send_down : p.send_up) + MSG_HDR + (size_t)(e >> 1) * RD;
+        row[DPm] = sl; row[DPm + 1] = sp; row[DPm + 2] = (double)w; row[DPm + 3] = 0.0;
+      }
+    }
     return;
   }
   // rare overflow of the register path (more than MVCAP moved rows in one ladder and step): the permutation
@@ -370,8 +433,6 @@ struct Move {
   const unsigned int* nhist;
   const int *naccept, *ntries, *last_type;
 };
-typedef double d2_t __attribute__((ext_vector_type(2)));  // (HIP's double2 struct does not stay in registers as an array)
-
 template <int MV, int WPB, bool HIST>   // HIST: history destinations exist (compiled apart: the hot build carries none of it)
 __global__ __launch_bounds__(64 * WPB, MV > 64 ? 1 : 4) void move_kernel(const Move p) {
   __shared__ int s_all[WPB][2][MV];

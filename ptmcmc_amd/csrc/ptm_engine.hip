@@ -523,7 +523,7 @@ static int launch_sweep(ptm_engine* e, int rung0 = 0, int nr = -1, bool last = t
 static size_t decide_lds_bytes(int Nt, int ms, int WN) {
   // mirrors the carve at the top of decide_kernel
   return (size_t)WN * 8 + (size_t)((Nt + 1) & ~1) * 4 + (size_t)((ms + 1) & ~1) * 4 * 2 + 8 + (size_t)((WN + 3) & ~3) * 2 * 3 +
-         (size_t)((ms + 3) & ~3) * 2 + (size_t)((ms + 7) & ~7) * 2 + 32;
+         (size_t)((ms + 3) & ~3) * 2 + (size_t)((ms + 7) & ~7) * 2 + (size_t)2 * MVCAP * 4 + 32;
 }
 
 static int launch_decide(ptm_engine* e, const double* ll_below, const double* ll_above, int H, double* send_up, double* send_down) {
@@ -551,6 +551,7 @@ static int launch_decide(ptm_engine* e, const double* ll_below, const double* ll
   if (wide) hipLaunchKernelGGL(decide_kernel<256>, dim3(e->W), dim3(256), lds, e->stream, p);
   else hipLaunchKernelGGL(decide_kernel<64>, dim3(e->W), dim3(64), lds, e->stream, p);
   HIPCHK(hipGetLastError());
+  if (wide) return PTM_OK;   // the 256-thread decide kernel has applied the moves itself
   Move m;
   m.DP = e->DP; m.W = e->W; m.row_cap = e->row_cap; m.x = e->x; m.ll = e->ll; m.lp = e->lp; m.send_up = send_up; m.send_down = send_down;
   m.mv_src = e->mv_src; m.mv_dst = e->mv_dst; m.mv_n = e->mv_n; m.err = e->err;
