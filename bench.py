@@ -101,6 +101,16 @@ def cpu_baseline(problem, budget_s=15.0):
             "sample": "oracle/ptm_oracle.c pt_step, D=%d, %d rungs x %d ladders, %d steps, OpenMP over chains" % (D, NT, W, n)}
 
 
+def settle(eng, seconds=0.25):
+    """set-up, before the W warm-up steps: run the ladder for a quarter of a second so that the GPU's clocks have ramped
+    and the chains have left their prior draws (the acceptance pattern, and with it the row traffic, is then the
+    stationary one).  Not timed, not counted."""
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        eng.step(20)
+        eng.sync()
+
+
 def run_single(args):
     from ptmcmc_amd import engine as E
     from ptmcmc_amd.problems import GaussianProblem
@@ -111,6 +121,7 @@ def run_single(args):
     eng = E.Engine(D, NT, W, seed=SEED, swap_rate=SWAP_RATE, add_every_n=100, time_kernels=True)
     pr.configure(eng, E.PROP_LOWER)
     eng.init_from_prior()
+    settle(eng)
     eng.step(args.warmup)
     eng.sync()
     eng.kernel_times()   # drop warm-up records
@@ -166,8 +177,8 @@ def run_single(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--walkers", type=int, default=4096, help="independent ladders batched per GPU")
     ap.add_argument("--halo", type=int, default=4, help="llike halo depth (rungs) between shards")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")

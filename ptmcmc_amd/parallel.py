@@ -218,6 +218,7 @@ def bench_main(args):
     pr.configure(eng, E.PROP_LOWER)
     eng.init_from_prior()
     lad = ShardedLadder(EngineShard(eng, torch, dev), dist, rank, world, halo=args.halo)
+    lad.step(300)             # set-up (untimed, uncounted): clocks ramped, chains off their prior draws, RCCL channels open
     lad.step(args.warmup)
     lad.drain()
     eng.sync()
