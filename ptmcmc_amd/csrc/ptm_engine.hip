@@ -116,6 +116,9 @@ static int need_device() {
   return PTM_OK;
 }
 
+extern "C" int ptm_engine_destroy(ptm_engine* e);
+static int build_engine(ptm_engine* e, const ptm_config* cfg);
+
 extern "C" int ptm_engine_create(const ptm_config* cfg, ptm_engine** out) {
   if (!cfg || !out) return fail(PTM_ERR_INVALID, "null argument");
   if (cfg->struct_size != sizeof(ptm_config)) return fail(PTM_ERR_INVALID, "ptm_config size mismatch (ABI)");
@@ -130,6 +133,14 @@ extern "C" int ptm_engine_create(const ptm_config* cfg, ptm_engine** out) {
   int rc = need_device();
   if (rc) return rc;
   ptm_engine* e = new ptm_engine();
+  rc = build_engine(e, cfg);
+  if (rc) { (void)ptm_engine_destroy(e); return rc; }   // nothing of a half-built engine survives
+  *out = e;
+  return PTM_OK;
+}
+
+static int build_engine(ptm_engine* e, const ptm_config* cfg) {
+  int rc;
   e->cfg = *cfg;
   e->D = cfg->dim; e->DP = round_dp(cfg->dim); e->Nt = cfg->n_rungs; e->r0 = cfg->rung_begin; e->nloc = cfg->rung_count;
   e->W = cfg->n_walkers; e->Nc = e->nloc * e->W;
@@ -144,16 +155,15 @@ extern "C" int ptm_engine_create(const ptm_config* cfg, ptm_engine** out) {
     if (e->row_cap > e->W) e->row_cap = e->W;
   }
   e->thresh = (e->Nt - 1) * cfg->swap_rate / e->ms;                          // chain.cc:1413
-  if (cfg->history_rungs < 0 || cfg->history_rungs > cfg->rung_count) { delete e; return fail(PTM_ERR_INVALID, "history_rungs out of range"); }
+  if (cfg->history_rungs < 0 || cfg->history_rungs > cfg->rung_count) { return fail(PTM_ERR_INVALID, "history_rungs out of range"); }
   if (cfg->history_rungs > 0) {
-    if (cfg->history_capacity < 2) { delete e; return fail(PTM_ERR_INVALID, "history_capacity must be >= 2"); }
+    if (cfg->history_capacity < 2) { return fail(PTM_ERR_INVALID, "history_capacity must be >= 2"); }
     // a rung touched twice in a step saves the row it held in between, which may be the row of the rung above: on a
     // shard that is not the ladder's last, the shard's top rung therefore cannot be recorded
     if (cfg->history_rungs == cfg->rung_count && cfg->rung_begin + cfg->rung_count < cfg->n_rungs) {
-      delete e;
       return fail(PTM_ERR_UNSUPPORTED, "the top rung of a shard below the ladder's top cannot be recorded: history_rungs < rung_count");
     }
-    if ((double)cfg->history_rungs * cfg->n_walkers >= (double)(1 << 30)) { delete e; return fail(PTM_ERR_INVALID, "too many recorded chains"); }
+    if ((double)cfg->history_rungs * cfg->n_walkers >= (double)(1 << 30)) { return fail(PTM_ERR_INVALID, "too many recorded chains"); }
     e->hist.rungs = cfg->history_rungs; e->hist.cap = cfg->history_capacity; e->hist.HC = cfg->history_rungs * cfg->n_walkers;
   }
   if (cfg->device >= 0) { HIPCHK(hipSetDevice(cfg->device)); e->device = cfg->device; } else HIPCHK(hipGetDevice(&e->device));
@@ -207,7 +217,6 @@ extern "C" int ptm_engine_create(const ptm_config* cfg, ptm_engine** out) {
   HIPCHK(hipEventCreate(&e->t0));
   HIPCHK(hipEventCreate(&e->t1));
   HIPCHK(hipStreamSynchronize(e->stream));
-  *out = e;
   return PTM_OK;
 }
 
