@@ -364,6 +364,48 @@ def test_streams_do_not_depend_on_batch_composition():
         e.close()
 
 
+def test_full_size_baseline_config_through_size_independent_properties():
+    """BASELINE configs[1] at FULL size (D=32, 1024 rungs x 4096 walkers = 4.19 M chains, the benchmark workload), checked
+    through properties that do not need a 4-million-chain oracle run:
+      (1) a walker's chain does not depend on the batch: walkers 0..63 of the full run == a 64-walker run, bit for bit;
+      (2) that 64-walker run (65 536 chains) == the CPU oracle, bit for bit;
+      (3) conservation: every chain made exactly one add_state-or-MH per step and exchange (Ntries + exchanged adds ==
+          steps + 1 + adds), accepts <= tries, every swap attempt touched two rungs, all values finite."""
+    from ptmcmc_amd.problems import GaussianProblem
+    D, Nt, Wfull, Wsmall, steps, sr = 32, 1024, 4096, 64, 6, 0.1
+    pr = GaussianProblem(D, Nt, 1e9)
+    big = E.Engine(D, Nt, Wfull, swap_rate=sr)
+    fac = pr.configure(big, E.PROP_LOWER)
+    assert "mfma" in big.sweep_kernel_name
+    big.init_from_prior()
+    x0 = big.states().reshape(Nt, Wfull, D)[:, :Wsmall].reshape(-1, D).copy()
+    small = E.Engine(D, Nt, Wsmall, swap_rate=sr)
+    pr.configure(small, E.PROP_LOWER)
+    small.set_states(x0)
+    big.step(steps); small.step(steps)
+    big.sync(); small.sync()
+    xb = big.states().reshape(Nt, Wfull, D)
+    assert np.array_equal(xb[:, :Wsmall].reshape(-1, D), small.states())                       # (1)
+    for name in ("llike", "ntries", "naccept", "nhist"):
+        assert np.array_equal(getattr(big, name).reshape(Nt, Wfull)[:, :Wsmall].ravel(), getattr(small, name)), name
+    pb = PU.oracle_problem(pr)                                                                  # (2)
+    lad = O.Ladder(pb, pr.beta, W=Wsmall, swap_rate=sr)
+    lad.set_proposals([(O.PROP_DENSE, fac[r], 0.0) for r in range(Nt)])
+    lad.use_philox(0x5EED0001)
+    lad.set_states(PU.to_oracle_order(x0, Nt, Wsmall))
+    lad.pt_step(steps, nthreads=8)
+    PU.assert_same_state(small, lad, "full-length ladder, 64 walkers, %d steps" % steps)
+    nt, na, nh = big.ntries, big.naccept, big.nhist                                             # (3)
+    t, a = big.swap_counts()
+    assert np.all(np.isfinite(xb)) and np.all(np.isfinite(big.llike))
+    assert np.all(na <= nt) and np.all(nt >= 1)
+    assert int((nt - 1).sum()) + 2 * int(t.sum()) == int(nh.sum())      # MH adds + two adds per exchange attempt
+    assert np.all(nh >= steps) and np.all(nh <= 2 * steps)
+    assert 0 < a.sum() <= t.sum()
+    for e in (big, small):
+        e.close()
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # ladder sharding: G engines (one per "GPU") must reproduce the single-engine chains bit for bit
 # ---------------------------------------------------------------------------------------------------------------
