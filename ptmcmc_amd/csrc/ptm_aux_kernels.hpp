@@ -100,10 +100,10 @@ __global__ __launch_bounds__(DECIDE_THREADS) void decide_kernel(const Decide p) 
   unsigned char* alive = reinterpret_cast<unsigned char*>(mid_ + ((WN + 3) & ~3));  // [ms] 0 dropped, 1 survives and is
                                                                                     //      ours, 2 survives, not ours
   unsigned char* accf = alive + ((ms + 7) & ~7);                              // [ms]
-  // The 256-thread form applies the moves itself (below), from a list kept in LDS; the 64-thread form hands the list to
-  // move_kernel through global memory.
-  constexpr bool FUSED = DECIDE_THREADS == 256;
-  int* lmv = reinterpret_cast<int*>(accf + ((ms + 7) & ~7));                  // [2][MVCAP], FUSED only
+  // The block applies the ladder's row moves itself (below) from a list kept in LDS, up to FCAP rows (16 rounds of one
+  // row per 16-lane group); a longer list (64-thread form only) goes to move_kernel through global memory.
+  constexpr int FCAP = DECIDE_THREADS;
+  int* lmv = reinterpret_cast<int*>(accf + ((ms + 7) & ~7));                  // [2][MVCAP]
   double* llc = llc_ - wlo;                // indexed by global rung
   unsigned short* perm = perm_ - wlo;
   unsigned short* inv = inv_ - wlo;
@@ -231,8 +231,8 @@ __global__ __launch_bounds__(DECIDE_THREADS) void decide_kernel(const Decide p) 
   // -- the row moves.  The phase's net effect on the touched rungs is a permutation of rows: new row[r] =
   //    old row[perm[r]].  List every move (source slot -> destination slot, or -> boundary message for a row that
   //    leaves the shard) for move_kernel; the hole an arrival will fill is named in arr_above / arr_below.
-  int* gs = FUSED ? lmv : p.mv_src + (size_t)w * MVCAP;
-  int* gd = FUSED ? lmv + MVCAP : p.mv_dst + (size_t)w * MVCAP;
+  int* gs = lmv;
+  int* gd = lmv + MVCAP;
   // source slot of the in-between row of rung r if its FIRST add_state of this step is one that saves, else -1
   auto hist_mid_src = [&](int r) -> int {
     if (r - p.r0 >= p.hist.rungs || r < p.r0 || r >= r1) return -1;
@@ -274,13 +274,17 @@ __global__ __launch_bounds__(DECIDE_THREADS) void decide_kernel(const Decide p) 
   }
   __syncthreads();
   const int nmv = cnt[1];
-  if (nmv <= MVCAP && !FUSED) {
-    if (lane == 0) p.mv_n[w] = nmv;   // move_kernel takes it from here
+  if (nmv > FCAP && nmv <= MVCAP) {   // too long for this block's registers: move_kernel takes it from here
+    for (int j = lane; j < nmv; j += DECIDE_THREADS) {
+      p.mv_src[(size_t)w * MVCAP + j] = gs[j];
+      p.mv_dst[(size_t)w * MVCAP + j] = gd[j];
+    }
+    if (lane == 0) p.mv_n[w] = nmv;
     return;
   }
-  if (nmv <= MVCAP) {
+  if (nmv <= FCAP) {
     // ---- the moves, in place, by this block: GATHER every moved row into registers (16 lanes x 16 B = one 256-B row,
-    //      16 rows per round, up to 16 rounds), wait for all loads of all threads, then SCATTER.  With every read
+    //      one row per 16-lane group and round, up to 16 rounds), wait for all loads of all threads, then SCATTER.  With every read
     //      finished before the first write no ordering between the moves is needed (they form cycles over this ladder's
     //      own rows; other ladders' rows are never touched).
     const int DPm = p.DP, RD = DPm + ROW_EXTRA;
@@ -297,10 +301,11 @@ __global__ __launch_bounds__(DECIDE_THREADS) void decide_kernel(const Decide p) 
     const int g = lane >> 4, sub = lane & 15;
     const bool act = 2 * sub < DPm;         // DP/2 lanes of 16 carry a row (16 B each)
     const int col = act ? 2 * sub : 0;      // idle lanes re-read column 0 (harmless) so that no load is predicated
-    d2_t v[MVCAP / 16];
+    constexpr int GR = DECIDE_THREADS / 16;   // rows per round
+    d2_t v[16];
 #pragma unroll
-    for (int q = 0; q < MVCAP / 16; ++q) {
-      const int j = 16 * q + g;
+    for (int q = 0; q < 16; ++q) {
+      const int j = GR * q + g;
       v[q] = *reinterpret_cast<const d2_t*>(p.x + (size_t)(j < nmv ? gs[j] : 0) * DPm + col);   // past the list: row 0, never stored
     }
     const int msrc = lane < nmv ? gs[lane] : 0;
@@ -308,8 +313,8 @@ __global__ __launch_bounds__(DECIDE_THREADS) void decide_kernel(const Decide p) 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();   // every gather of every thread has landed before the first scatter
 #pragma unroll
-    for (int q = 0; q < MVCAP / 16; ++q) {
-      const int j = 16 * q + g;
+    for (int q = 0; q < 16; ++q) {
+      const int j = GR * q + g;
       const int d = j < nmv ? gd[j] : -3;
       if (d != -3 && act) {
         double* dstp;

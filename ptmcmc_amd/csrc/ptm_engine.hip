@@ -566,13 +566,8 @@ static int launch_decide(ptm_engine* e, const double* ll_below, const double* ll
   m.mv_src = e->mv_src; m.mv_dst = e->mv_dst; m.mv_n = e->mv_n; m.err = e->err;
   m.hist = e->hist; m.add_every_n = e->cfg.add_every_n; m.nhist = e->nhist;
   m.naccept = e->naccept; m.ntries = e->ntries; m.last_type = e->last_type;
-  // a ladder moves about 0.17 rows per local rung and step at the default swap rate: short shards take the light kernel
-  // first; whatever does not fit it is left for the MVCAP-row kernel
-  if (e->nloc <= 256) {
-    if (e->hist.rungs) hipLaunchKernelGGL((move_kernel<64, 4, true>), dim3((e->W + 3) / 4), dim3(256), 0, e->stream, m);
-    else hipLaunchKernelGGL((move_kernel<64, 4, false>), dim3((e->W + 3) / 4), dim3(256), 0, e->stream, m);
-    HIPCHK(hipGetLastError());
-  }
+  // (64-thread form only) ladders whose list did not fit the decide block's registers: rare, the kernel exits at once
+  // for everybody else
   if (e->hist.rungs) hipLaunchKernelGGL((move_kernel<MVCAP, 1, true>), dim3(e->W), dim3(64), 0, e->stream, m);
   else hipLaunchKernelGGL((move_kernel<MVCAP, 1, false>), dim3(e->W), dim3(64), 0, e->stream, m);
   HIPCHK(hipGetLastError());

@@ -137,6 +137,8 @@ SWEEP_CASES = [
     (3, 5, 70, 1e2, E.PROP_DIAG, None),      # W not a multiple of 64
     (1, 4, 2, 1e1, E.PROP_DIAG, 1.0),
     (9, 3, 64, 1e2, E.PROP_LOWER, 0.25),
+    (4, 400, 64, 1e3, E.PROP_DIAG, None),    # ~64 moved rows per ladder and step: both sides of the 64-thread exchange
+                                             # block's register capacity (in-block moves / list handed to move_kernel)
 ]
 
 
