@@ -299,8 +299,12 @@ double ptmo_lprior(const ptmo_problem* pb, const double* x, int valid) {
     }
     return pb->lprior_const;
   }
-  double result = 1;
-  for (int i = 0; i < pb->D; i++) result *= pdf1(pb, i, x[i]);
+  /* mixed_dist_product::evaluate (probability_function.cc:281-304) multiplies the factors in dimension order; here (and
+   * in the kernels, whose MFMA layout spreads a chain's dimensions over four lanes) they are multiplied in four
+   * interleaved partial products p_q = prod_{i = q mod 4} pdf_i (i ascending), combined as ((p0 p1) p2) p3 */
+  double pq[4] = {1, 1, 1, 1};
+  for (int i = 0; i < pb->D; i++) pq[i & 3] *= pdf1(pb, i, x[i]);
+  double result = ((pq[0] * pq[1]) * pq[2]) * pq[3];
   return ptmo_log(result);
 }
 

@@ -471,6 +471,7 @@ static SweepSel sweep_sel(const ptm_engine* e) {
   s.kind = e->prop_kind == PTM_PROP_DIAG ? KIND_DIAG : (e->prop_kind == PTM_PROP_LOWER ? KIND_LOWER : KIND_DENSE);
   s.uni = (e->W % 64) == 0;
   s.simple = s.uni && !e->has_bounds && e->all_uniform && !e->has_mean && !e->any_oned && !e->cb;
+  s.callback = e->cb != nullptr;
   return s;
 }
 
@@ -977,7 +978,8 @@ extern "C" const char* ptm_sweep_kernel_name(ptm_engine* e) {
   if (!e) return "";
   char b[96];
   const SweepSel s = sweep_sel(e);
-  if (e->DP == 32 && s.uni && s.simple && s.kind != KIND_DIAG) snprintf(b, sizeof b, "sweep_mfma32_kernel<%d, %s>", s.kind, e->hist.rungs ? "true" : "false");
+  if (e->DP == 32 && s.uni && !s.callback && s.kind != KIND_DIAG)
+    snprintf(b, sizeof b, "sweep_mfma32_kernel<%d, %s, %s>", s.kind, e->hist.rungs ? "true" : "false", s.simple ? "false" : "true");
   else snprintf(b, sizeof b, "sweep_kernel<%d, %d, %s, %s>", e->DP, s.kind, s.uni ? "true" : "false", s.simple ? "true" : "false");
   e->kname = b;
   return e->kname.c_str();

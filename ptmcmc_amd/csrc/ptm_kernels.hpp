@@ -183,10 +183,12 @@ __device__ __noinline__ double enforce_and_lprior(const Dev& p, double (&x)[DP],
       if (d < p.D) in = in && !(x[d] < plo[d]) && !(x[d] > phi[d]);
     return in ? p.lprior_const : -__builtin_inf();
   }
-  double result = 1;
+  // four interleaved partial products, combined as ((p0 p1) p2) p3: the order every path and the CPU checker share
+  double pq[4] = {1.0, 1.0, 1.0, 1.0};
 #pragma unroll
   for (int d = 0; d < DP; ++d)
-    if (d < p.D) result *= prior_pdf(pt[d], plo[d], phi[d], pco[d], x[d]);
+    if (d < p.D) pq[d & 3] *= prior_pdf(pt[d], plo[d], phi[d], pco[d], x[d]);
+  const double result = ((pq[0] * pq[1]) * pq[2]) * pq[3];
   return dlog(result);
 }
 

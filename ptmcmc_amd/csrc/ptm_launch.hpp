@@ -11,6 +11,7 @@ struct SweepSel {
   int kind;     // KIND_DENSE / KIND_DIAG / KIND_LOWER
   bool uni;     // W % 64 == 0: wave-uniform rung
   bool simple;  // open bounds, all-uniform prior, zero mean, no 1-D moves
+  bool callback;  // host-callback likelihood (propose / accept passes): general VALU kernel only
 };
 #define PTM_DECL_DP(N)                                                                                              \
   hipError_t launch_sweep_##N(const Dev& p, SweepSel s, hipStream_t st);                                            \

@@ -35,7 +35,12 @@ typedef double mf_d2 __attribute__((ext_vector_type(2)));
 #ifndef PTM_MFMA_WAVES
 #define PTM_MFMA_WAVES 3   // waves per SIMD the register budget is cut for
 #endif
-template <int KIND, bool HIST>   // HIST: the engine keeps a history (compiled apart: the hot build carries none of it)
+// HIST: the engine keeps a history.  GEN: the general state space / prior / target -- boundaries of any kind
+// (boundary::enforce, states.cc:11-58), mixed priors (probability_function.cc:281-304), a mean, one-dimensional moves
+// (proposal_distribution.hh:196-206).  Both are compiled apart: the hot build (false, false) carries none of it.
+// All of the general work is per dimension, so it runs in the accumulator layout as it stands: a lane enforces and
+// prices its own eight dimensions of each chain, and the chain's four lanes meet in two more LDS reductions / ballots.
+template <int KIND, bool HIST, bool GEN>
 __global__ __launch_bounds__(256, PTM_MFMA_WAVES) void sweep_mfma32_kernel(const Dev p) {
   constexpr int DP = 32;
   constexpr bool LOW = KIND == KIND_LOWER;
@@ -49,6 +54,10 @@ __global__ __launch_bounds__(256, PTM_MFMA_WAVES) void sweep_mfma32_kernel(const
   const bool live = c0 < p.c_end;                              // (a wave past the end still helps to stage the tables)
   const int c0s = live ? c0 : 0;
   double* red = lbox + 64 + wave * 128;
+  // GEN: per-dimension tables of the state space and the prior, natural index (after the waves' reduction slots)
+  double* gtab = lbox + 64 + 4 * 128;                   // bmin | bmax | plo | phi | pcoef | mean, 32 each
+  int* gint = reinterpret_cast<int*>(gtab + 6 * 32);    // blo | bhi | ptype, 32 each
+  double* red2 = reinterpret_cast<double*>(gint + 3 * 32) + wave * 128;   // the prior's partial products
   const int rl = __builtin_amdgcn_readfirstlane(c0s / p.W);
   const int w0 = c0s - rl * p.W;
   const int rg = p.r0 + rl;
@@ -71,6 +80,14 @@ __global__ __launch_bounds__(256, PTM_MFMA_WAVES) void sweep_mfma32_kernel(const
     st_p[t] = p.P2_tiles[src * 64 + (e & 63)];
   }
   const double st_box = p.box_row[threadIdx.x & 63];
+  double st_g[6] = {0, 0, 0, 0, 0, 0};
+  int st_i[3] = {0, 0, 0};
+  if (GEN && threadIdx.x < 32) {
+    const int d = threadIdx.x;
+    st_g[0] = p.bmin[d]; st_g[1] = p.bmax[d]; st_g[2] = p.plo[d]; st_g[3] = p.phi[d]; st_g[4] = p.pcoef[d];
+    st_g[5] = p.has_mean ? p.mean[d] : 0.0;
+    st_i[0] = p.blo[d]; st_i[1] = p.bhi[d]; st_i[2] = p.ptype[d];
+  }
 
   // A tile's 64 chains are worked in two passes of two 16-chain groups (g = 2 gp + gg): every live set is halved.
   mf_d2 rowv[2][4];   // the pass's rows, asked for one pass ahead
@@ -93,13 +110,26 @@ __global__ __launch_bounds__(256, PTM_MFMA_WAVES) void sweep_mfma32_kernel(const
   // log of the chain's accept uniform (block 0 of its stream): drawn here once for all 64 chains -- the Metropolis test
   // itself runs per pass on half the lanes, and this is its expensive part.  (The reference draws the uniform only when
   // logH < 0, chain.cc:998; a counter-based stream makes the draw free of side effects, so drawing it always is the same.)
-  const double log_u = dlog_u01(draw_block(p.seed, TAG_MH, (uint32_t)(w0 + l) * (uint32_t)p.Nt + (uint32_t)rg, p.step, 0).v0);
+  const u32x4 o0 = draw_block(p.seed, TAG_MH, (uint32_t)(w0 + l) * (uint32_t)p.Nt + (uint32_t)rg, p.step, 0);
+  const double log_u = dlog_u01(o0.v0);
+  // one-dimensional move of "my" chain (proposal_distribution.hh:196-206): its axis, or -1
+  int my_axis = -1;
+  if (GEN && p.any_oned) {
+    const double f = as_c(p.onedfrac)[rl];
+    if (f > 0 && u01(o0.v1) < f) my_axis = (int)(p.D * u01(o0.v2));
+  }
 
 #pragma unroll
   for (int t = 0; t < BM_TABLE_DOUBLES / 512; ++t) reinterpret_cast<bm_d2*>(lds_all)[threadIdx.x + 256 * t] = st_bm[t];
 #pragma unroll
   for (int t = 0; t < 3; ++t) ptile[threadIdx.x + 256 * t] = st_p[t];
   if (threadIdx.x < 64) lbox[threadIdx.x] = st_box;
+  if (GEN && threadIdx.x < 32) {
+#pragma unroll
+    for (int t = 0; t < 6; ++t) gtab[32 * t + threadIdx.x] = st_g[t];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) gint[32 * t + threadIdx.x] = st_i[t];
+  }
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   if (!live) return;
 
@@ -121,6 +151,11 @@ __global__ __launch_bounds__(256, PTM_MFMA_WAVES) void sweep_mfma32_kernel(const
       acc[gg][1] = mf_d4{0.0, 0.0, 0.0, 0.0};
     }
     double tb[4][2];
+    int axis[2] = {-1, -1};   // GEN: the one-dimensional move's axis of chain (2 gp + gg, j), from its own lane
+    if (GEN && p.any_oned) {
+#pragma unroll
+      for (int gg = 0; gg < 2; ++gg) axis[gg] = __builtin_amdgcn_ds_bpermute(4 * (32 * gp + 16 * gg + j), my_axis);
+    }
 #pragma unroll
     for (int hb = 0; hb < 2; ++hb) {
       double z[2][4];
@@ -136,6 +171,11 @@ __global__ __launch_bounds__(256, PTM_MFMA_WAVES) void sweep_mfma32_kernel(const
         boxmuller(o.v0, o.v1, (const double*)lds_all, z[gg][0], z[gg][1]);
         boxmuller(o.v2, o.v3, (const double*)lds_all, z[gg][2], z[gg][3]);
 #endif
+        if (GEN && axis[gg] >= 0) {
+#pragma unroll
+          for (int sl = 0; sl < 4; ++sl)
+            if (16 * hb + 4 * q + sl != axis[gg]) z[gg][sl] = 0.0;
+        }
         PTM_STAGE();   // one chain's draw at a time: the temporaries of two interleaved draws cost 40 registers
       }
 #pragma unroll
@@ -163,24 +203,42 @@ __global__ __launch_bounds__(256, PTM_MFMA_WAVES) void sweep_mfma32_kernel(const
       }
       PTM_STAGE();
     }
-    // ---- stage 3: x' = x + offset (state::add, states.cc:205-214); the prior's box
+    // ---- stage 3: x' = x + offset (state::add, states.cc:205-214); boundaries; the prior
     double xp[2][8];
-    uint64_t inbox = 0;   // bit 16 gg + j: chain (2 gp + gg, j) is inside the box
+    uint64_t inbox = 0;     // bit 16 gg + j: chain (2 gp + gg, j) is inside the box of an all-uniform prior
+    uint64_t validb = ~0ull; // GEN: bit 16 gg + j: the chain's state is valid (stateSpace::enforce, states.cc:86-102)
+    const bool boxed = !GEN || p.all_uniform;
 #pragma unroll
     for (int gg = 0; gg < 2; ++gg) {
-      bool ok = true;
+      bool ok = true, vok = true;
+      double pp = 1.0;      // GEN: this lane's partial product of the prior's factors (its dimensions, ascending)
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const mf_d2 v = rowv[gg][t], lo = box[4 * t], hi = box[16 + 4 * t];
         const int m = 2 * t;   // registers m, m+1 <-> dimensions q + 4m, q + 4m + 4
         xp[gg][m] = v.x + acc[gg][m >> 2][m & 3];
         xp[gg][m + 1] = v.y + acc[gg][(m + 1) >> 2][(m + 1) & 3];
+        if (GEN) {
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const int d = q + 4 * (m + u);
+            if (p.has_bounds) vok = vok & boundary_enforce(gint[d], gint[32 + d], gtab[d], gtab[32 + d], xp[gg][m + u]);
+            if (!boxed) pp *= prior_pdf(gint[64 + d], gtab[64 + d], gtab[96 + d], gtab[128 + d], xp[gg][m + u]);
+          }
+        }
         ok = ok & !(xp[gg][m] < lo.x) & !(xp[gg][m] > hi.x) & !(xp[gg][m + 1] < lo.y) & !(xp[gg][m + 1] > hi.y);
       }
       uint64_t b = __builtin_amdgcn_ballot_w64(ok);
       b &= b >> 32;
       b &= b >> 16;                                  // bit jj: all four lanes (q, jj) of chain (g, jj) are inside
       inbox |= (b & 0xFFFFull) << (16 * gg);
+      if (GEN) {
+        uint64_t vb = __builtin_amdgcn_ballot_w64(vok);
+        vb &= vb >> 32;
+        vb &= vb >> 16;
+        validb = (validb & ~(0xFFFFull << (16 * gg))) | ((vb & 0xFFFFull) << (16 * gg));
+        red2[(gg * 4 + q) * 16 + j] = pp;
+      }
     }
     PTM_STAGE();
     // the second pass's rows are asked for here: the registers of the first pass's rows have just been freed
@@ -188,7 +246,8 @@ __global__ __launch_bounds__(256, PTM_MFMA_WAVES) void sweep_mfma32_kernel(const
     mf_d2* rowpn[2] = {rowp[0], rowp[1]};
     if (gp == 0) ask_rows(1, rown, rowpn);
     PTM_STAGE();
-    // ---- stage 4: S = P2 x X' and the four partial dot products of each chain
+    // ---- stage 4: S = P2 x Y, Y = X' (- mean), and the four partial dot products of each chain
+    auto yv = [&](int gg, int m) -> double { return (GEN && p.has_mean) ? xp[gg][m] - gtab[160 + q + 4 * m] : xp[gg][m]; };
     mf_d4 sacc[2][2];
 #pragma unroll
     for (int gg = 0; gg < 2; ++gg) {
@@ -206,7 +265,7 @@ __global__ __launch_bounds__(256, PTM_MFMA_WAVES) void sweep_mfma32_kernel(const
 #if defined(PTM_ABLATE) && (PTM_ABLATE & 4)   // timing experiment: no P2 x X'
           sacc[gg][rt][m & 3] += a * xp[gg][m];
 #else
-          sacc[gg][rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, xp[gg][m], sacc[gg][rt], 0, 0, 0);
+          sacc[gg][rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, yv(gg, m), sacc[gg][rt], 0, 0, 0);
 #endif
         }
       }
@@ -215,7 +274,7 @@ __global__ __launch_bounds__(256, PTM_MFMA_WAVES) void sweep_mfma32_kernel(const
     for (int gg = 0; gg < 2; ++gg) {
       double pq = 0.0;
 #pragma unroll
-      for (int m = 0; m < 8; ++m) pq = __builtin_fma(xp[gg][m], sacc[gg][m >> 2][m & 3], pq);
+      for (int m = 0; m < 8; ++m) pq = __builtin_fma(yv(gg, m), sacc[gg][m >> 2][m & 3], pq);
       // chain (g, j)'s four partial sums sit on lanes (0..3, j): hand them to lane 16 g + j through this wave's LDS
       red[(gg * 4 + q) * 16 + j] = pq;
     }
@@ -242,25 +301,33 @@ __global__ __launch_bounds__(256, PTM_MFMA_WAVES) void sweep_mfma32_kernel(const
         const double cur_lpost = lp + bl;
         const double oldlprior = cur_lpost - bl;  // chain.cc:973
         const bool in = ((inbox >> (l & 31)) & 1ull) != 0;
-        const double newlprior = in ? p.lprior_const : -__builtin_inf();
-        const bool want_like = newlprior > -1e200 || newlprior - oldlprior > p.min_prior;  // chain.cc:980 (Q1)
+        // Q9: state::add builds on an enforced zero state -- an origin outside a `limit` bound invalidates every proposal
+        const bool valid = !GEN || (p.origin_valid != 0 && ((validb >> (l & 31)) & 1ull) != 0);
+        double newlprior = in ? p.lprior_const : -__builtin_inf();
+        if (GEN && !p.all_uniform) {   // log of the product of the factors, ((p0 p1) p2) p3 (probability_function.hh:59)
+          const double* pm = red2 + ((q & 1) * 4) * 16 + j;
+          newlprior = dlog(((pm[0] * pm[16]) * pm[32]) * pm[48]);
+        }
+        if (!valid) newlprior = -__builtin_inf();
+        const bool want_like = valid && (newlprior > -1e200 || newlprior - oldlprior > p.min_prior);  // chain.cc:980 (Q1)
         double newlike = p.like0 - 0.5 * quad;
         double newlpost = newlike * beta + newlprior;
         if (!want_like) newlike = newlpost = -__builtin_inf();
         const double logH = newlpost - cur_lpost;
-        accept = true;
-        if (logH < 0) accept = log_u < logH;  // chain.cc:998-1001 (NaN stays accepted)
+        accept = valid;
+        if (accept && logH < 0) accept = log_u < logH;  // chain.cc:998-1001 (NaN stays accepted)
+        const int type = (GEN && my_axis >= 0) ? 1 : 0;
         p.ntries[c] = ntries0 + 1;
         p.nhist[c] = nhist0 + 1u;
         if (hist_on && nhist0 % (unsigned int)p.add_every_n == 0u) {
           hrow = 1 + (int)(nhist0 / (unsigned int)p.add_every_n);
           const size_t o = hist_slot(p.hist, hrow, c);
-          if (accept) hist_scalars(p.hist, o, hrow, newlike, newlprior, naccept0 + 1, ntries0 + 1, 0);
+          if (accept) hist_scalars(p.hist, o, hrow, newlike, newlprior, naccept0 + 1, ntries0 + 1, type);
           else hist_scalars(p.hist, o, hrow, ll, lp, naccept0, ntries0 + 1, p.last_type[c]);
         }
         if (accept) {
           p.naccept[c] = naccept0 + 1;
-          p.last_type[c] = 0;
+          p.last_type[c] = type;
           p.ll[c] = newlike;
           p.lp[c] = newlprior;
         }

@@ -330,6 +330,55 @@ def test_bounds_and_mixed_prior_path_bit_exact():
     eng.close()
 
 
+@pytest.mark.parametrize("kind,odf,with_mean,all_uniform", [(E.PROP_DENSE, 0.0, True, False), (E.PROP_LOWER, 0.3, False, False),
+                                                            (E.PROP_LOWER, 0.0, False, True), (E.PROP_DENSE, 1.0, True, True)])
+def test_mfma_kernel_general_state_space_and_priors(kind, odf, with_mean, all_uniform):
+    """The MFMA kernel's general build (27 dimensions -> 32, 64 walkers): wrap / limit / reflect boundaries, a
+    gaussian + log + uniform + polar + copolar + flat prior (or an all-uniform box with limit bounds), a mean, and
+    one-dimensional moves -- states, llike, lprior and counters bit-identical to the oracle; also with a history."""
+    D, Nt, W = 27, 5, 64
+    pi = math.pi
+    rng = np.random.default_rng(21)
+    blo, bhi, bmin, bmax = [0] * D, [0] * D, [0.0] * D, [0.0] * D
+    types, cen, hw = [1] * D, [0.0] * D, [30.0] * D
+    lo_x, hi_x = np.full(D, -2.0), np.full(D, 2.0)
+    def setb(d, lo, hi, mn, mx):
+        blo[d], bhi[d], bmin[d], bmax[d] = lo, hi, mn, mx
+    setb(1, 1, 0, -6.0, 0.0)           # limit below only
+    setb(2, 3, 3, -3.0, 3.0)           # wrap
+    setb(7, 2, 2, -2.5, 2.5)           # reflect both
+    setb(12, 1, 1, -4.0, 4.0)          # limit both
+    setb(20, 0, 2, 0.0, 3.5)           # reflect above only
+    setb(26, 3, 3, 0.0, 2 * pi)        # wrap on the last (padded-tile) dimension
+    lo_x[26], hi_x[26] = 0.5, 5.5
+    if not all_uniform:
+        types[0], cen[0], hw[0] = 2, 0.3, 1.5                  # gaussian
+        types[3], cen[3], hw[3] = 5, 3.0, 4.0                  # log on (0.75, 12)
+        lo_x[3], hi_x[3] = 1.0, 9.0
+        types[5], cen[5], hw[5] = 3, pi / 2, pi / 2            # polar on (0, pi)
+        lo_x[5], hi_x[5] = 0.3, 2.8
+        types[9], cen[9], hw[9] = 4, 0.0, pi / 2               # copolar
+        lo_x[9], hi_x[9] = -1.3, 1.3
+        types[13] = 0                                          # flat
+    else:
+        hw = [5.0 + 0.1 * d for d in range(D)]
+        cen[26], hw[26] = pi, pi
+    x0 = rng.uniform(lo_x, hi_x, size=(Nt * W, D))
+    mean = rng.normal(size=D) * 0.2 if with_mean else None
+    pr, eng, lad = PU.make_pair(D, Nt, W, 50.0, kind=kind, bounds=(blo, bhi, bmin, bmax), prior=(types, cen, hw), swap_rate=0.3,
+                                x0=x0, mean=mean, one_d_frac=(odf if odf > 0 else None))
+    assert "mfma32_kernel" in eng.sweep_kernel_name and eng.sweep_kernel_name.endswith("true>")
+    PU.assert_same_state(eng, lad, "start")
+    for k in range(6):
+        eng.step(5); eng.sync(); lad.pt_step(5)
+        PU.assert_same_state(eng, lad, "after %d steps" % (5 * (k + 1)))
+    acc = eng.naccept.sum() - eng.Nc
+    assert acc > 100 and np.isfinite(eng.lprior).all()
+    if odf > 0:
+        assert (eng.last_type == 1).any()
+    eng.close()
+
+
 def test_origin_outside_limit_bound_rejects_everything():
     """quirk Q9 (states.cc:183-192,205-214), pinned against the reference by golden trace 3."""
     D, Nt, W = 2, 4, 64
