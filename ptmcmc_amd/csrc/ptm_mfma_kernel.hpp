@@ -1,5 +1,6 @@
 // ptm_mfma_kernel.hpp -- the hot kernel of the BASELINE workload: one fused MH_chain::step (chain.cc:966-1022) for a
-// 32-dimensional Gaussian target with a dense or Cholesky proposal factor per rung, uniform box prior, open bounds.
+// Gaussian target of 17..32 dimensions with a dense or Cholesky proposal factor per rung.  The lean build assumes a
+// uniform box prior and open bounds (the benchmark); the general build adds every boundary / prior / mean / 1-D move.
 // One wave = 64 chains of ONE rung (W % 64 == 0).  Both matrix products run on the f64 matrix cores
 // (v_mfma_f64_16x16x4_f64), the VALU is left with the random numbers:
 //
