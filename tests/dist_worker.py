@@ -37,7 +37,9 @@ if __name__ == "__main__":
     r0, nloc = shard_bounds(Nt, world, rank)
     sh = OracleShard(lad, r0, nloc, seed)
     sl = ShardedLadder(sh, dist, rank, world, halo=halo)
-    sl.step(nsteps)
+    sl.step(10)            # as bench.py drives it: several calls, halos left in flight between them, drained at the end
+    sl.drain()
+    sl.step(nsteps - 10)
     sl.drain()
     sh.sync()
     np.savez(out % rank, x=sh.local(sh.x), ll=sh.local(sh.ll), nhist=sh.local(sh.nhist), nacc=sh.local(lad.naccept),
