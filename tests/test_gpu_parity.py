@@ -137,6 +137,8 @@ SWEEP_CASES = [
     (3, 5, 70, 1e2, E.PROP_DIAG, None),      # W not a multiple of 64
     (1, 4, 2, 1e1, E.PROP_DIAG, 1.0),
     (9, 3, 64, 1e2, E.PROP_LOWER, 0.25),
+    (3, 1, 64, 1.0, E.PROP_DENSE, None),     # a single rung: no exchange phase at all
+    (3, 2, 5, 4.0, E.PROP_LOWER, 0.5),       # two rungs: one pair
     (4, 400, 64, 1e3, E.PROP_DIAG, None),    # ~64 moved rows per ladder and step: both sides of the 64-thread exchange
                                              # block's register capacity (in-block moves / list handed to move_kernel)
 ]
@@ -173,7 +175,7 @@ def test_pt_steps_bit_exact(D, Nt, W, tmax, kind, odf):
     PU.assert_same_state(eng, lad, "after 32 PT steps")
     t, a = eng.swap_counts()
     assert np.array_equal(t, lad.swap_count) and np.array_equal(a, lad.swap_accept_count)
-    assert nacc > 0
+    assert nacc > 0 or Nt == 1
     eng.close()
 
 
