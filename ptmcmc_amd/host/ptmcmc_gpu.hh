@@ -581,6 +581,7 @@ class ptmcmc_sampler {
     // flag names and defaults of ptmcmc.cc:375-427 that shape this path
     opt["nsteps"] = "5000"; opt["save_every"] = "10"; opt["nevery"] = "1000"; opt["pt"] = "20"; opt["pt_swap_rate"] = "0.10";
     opt["pt_Tmax"] = "1e9"; opt["chain_dprior_min"] = "-30"; opt["seed"] = "-1"; opt["outname"] = "mcmc_output";
+    opt["nskip"] = "10"; opt["pt_dump_n"] = "1";
   }
   void set(const std::string& name, const std::string& value) { opt[name] = value; }
   bool parse(int argc, char* argv[]) {  // --name=value / --name (options.hh semantics)
@@ -598,24 +599,34 @@ class ptmcmc_sampler {
   int initialize() {
     if (!chain_llike || !cprop) { std::cout << "ptmcmc_sampler::initialize.  Must call setup() and set proposal before initialization!" << std::endl; exit(1); }
     cc.reset(new parallel_tempering_chains((int)num("pt"), num("pt_Tmax"), num("pt_swap_rate"), (int)num("save_every"), false, false, num("chain_dprior_min")));
+    // the chain files are written from the device's history ring, every "nevery" steps: it must hold what one such
+    // interval saves (up to two add_state calls per step, every save_every-th saved)
+    cc->keep_history(2 + 2 * (int)num("nevery") / std::max(1, (int)num("save_every")));
     uint64_t seed = num("seed") >= 0 ? (uint64_t)(num("seed") * 4294967296.0) : 0x5EED0001ull;
     cc->initialize(chain_llike, chain_prior, 1, seed);
     cc->set_proposal(*cprop);
     return 0;
   }
+  // ptmcmc_sampler::run (ptmcmc.cc:530-679): step; every "nevery" steps append what the coldest pt_dump_n chains saved
+  // since the last report to <base>_t<k>.dat (k = 0 the coldest), as dumpChain writes it
   int run(const std::string& base, int ic = 0) {
-    const int Nstep = (int)num("nsteps"), Nevery = (int)num("nevery");
-    std::ostringstream ss;
-    ss << base << "_t" << ic << ".dat";  // ptmcmc.cc:547-554
-    std::ofstream out(ss.str().c_str());
-    out.precision(13);
-    out << "#eval: log(posterior) log(likelihood) acceptance_ratio prop_type: ";
-    for (int i = 0; i < chain_prior->getDim(); i++) out << chain_llike->getObjectStateSpace()->get_name(i) << " ";
-    out << std::endl;
-    for (int istep = 0; istep < Nstep; istep += Nevery) {
-      cc->step(std::min(Nevery, Nstep - istep));
-      cc->dumpCurrent(0, out);
+    (void)ic;
+    const int Nstep = (int)num("nsteps"), Nevery = std::max(1, (int)num("nevery")), Nskip = std::max(1, (int)num("nskip"));
+    int dump_n = (int)num("pt_dump_n");
+    if (dump_n > cc->multiplicity() || dump_n <= 0) dump_n = cc->multiplicity();   // ptmcmc.cc:458
+    std::vector<std::unique_ptr<std::ofstream> > out;
+    for (int ich = 0; ich < dump_n; ich++) {   // ptmcmc.cc:547-554
+      std::ostringstream ss;
+      ss << base << "_t" << ich << ".dat";
+      out.emplace_back(new std::ofstream(ss.str().c_str()));
+      out.back()->precision(13);
     }
+    for (int istep = 0; istep <= Nstep; istep++) {   // ptmcmc.cc:565,599-607
+      cc->step();
+      if (0 == istep % Nevery)
+        for (int ich = 0; ich < dump_n; ich++) cc->dumpChain(ich, *out[ich], istep - Nevery + 1, Nskip);
+    }
+    for (int ich = 0; ich < dump_n; ich++) *out[ich] << "\n" << std::endl;   // ptmcmc.cc:665
     return 0;
   }
   parallel_tempering_chains* chains() { return cc.get(); }

@@ -10,15 +10,16 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def build(out):
+def build(out, src="example_gaussian_pt.cc"):
     cmd = ["g++", "-std=c++11", "-O2", "-Wall", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "ptmcmc_amd", "host"),
-           os.path.join(ROOT, "examples", "example_gaussian_pt.cc"), "-L", os.path.join(ROOT, "ptmcmc_amd"), "-lptm_engine",
+           os.path.join(ROOT, "examples", src), "-L", os.path.join(ROOT, "ptmcmc_amd"), "-lptm_engine",
            "-Wl,-rpath," + os.path.join(ROOT, "ptmcmc_amd"), "-o", out]
     subprocess.check_call(cmd)
 
 
 def test_facade_compiles_as_cxx11_against_the_c_abi():
     with tempfile.TemporaryDirectory() as d:
+        build(os.path.join(d, "ex2"), "example_sampler.cc")
         build(os.path.join(d, "ex"))
         # without a GPU the program must fail loudly, not compute on the host
         if not os.path.exists("/dev/kfd"):
@@ -77,3 +78,28 @@ def test_facade_writes_the_cold_chain_file_from_the_device_history():
         assert np.allclose(H[:, 1] - H[:, 2], (H[:, 1] - H[:, 2])[0], atol=1e-9)
         v0 = np.linalg.inv(P)[0, 0]
         assert abs(X[:, 0].var() - v0) < 0.35 * v0
+
+
+@pytest.mark.gpu
+def test_sampler_driver_writes_the_reference_chain_files():
+    """ptmcmc_sampler::run (ptmcmc.cc:563-607): every nevery steps dumpChain(ich, out, istep-nevery+1, nskip) for the
+    pt_dump_n coldest chains into <base>_t<ich>.dat -- here from the device's history ring."""
+    with tempfile.TemporaryDirectory() as d:
+        exe, base = os.path.join(d, "ex2"), os.path.join(d, "run")
+        build(exe, "example_sampler.cc")
+        r = subprocess.run([exe, base], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        for ich, beta_expect in ((0, 1.0), (1, 50.0 ** (-1 / 5))):
+            lines = open("%s_t%d.dat" % (base, ich)).read().splitlines()
+            assert sum(l.startswith("#Ninit=1, Nburn=") for l in lines) == 5     # istep = 0, 500, ..., 2000
+            rows = [l for l in lines if l and not l.startswith("#")]
+            idx = np.array([int(l.split()[0]) for l in rows])
+            assert idx[0] == -1 and idx[1] == 1 and np.mean(np.diff(idx) == 4) > 0.9   # the reference's loop: i = Nburn, Nburn + nskip, ...; -1 = the
+                                                                   # initial state (chain.cc:1122-1125); a report restarts at istep-nevery+1 whatever the last one reached
+            assert len(rows) > 400                                                # ~ >= 2000 adds / nskip 4
+            X = np.array([[float(v) for v in l.split(": ")[1].split()] for l in rows])
+            assert X.shape[1] == 4 and np.allclose(X[:, 3], beta_expect, rtol=1e-10)
+            H = np.array([[float(v) for v in l.split(": ")[0].split()] for l in rows])
+            P = np.array([[2.0, 0.6, 0.0], [0.6, 1.0, -0.3], [0.0, -0.3, 1.5]])
+            assert np.allclose(H[:, 2], -0.5 * np.einsum("ni,ij,nj->n", X[:, :3], P, X[:, :3]), atol=1e-9)
+            assert set(H[:, 4]) <= {-1.0, 0.0, 1.0}
