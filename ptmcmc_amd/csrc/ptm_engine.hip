@@ -58,7 +58,7 @@ struct ptm_engine {
   double *P2 = nullptr, *mean = nullptr, *beta = nullptr, *prop = nullptr, *prop_tiles = nullptr, *P2_tiles = nullptr, *box_row = nullptr, *onedfrac = nullptr;
   // host copies / flags
   int has_bounds = 0, origin_valid = 1, all_uniform = 1, has_mean = 0, have_target = 0, have_ladder = 0,
-      have_prop = 0, have_state = 0, prop_kind = KIND_DIAG, prop_stride = 0, any_oned = 0;
+      have_prop = 0, have_state = 0, prop_kind = KIND_DIAG, prop_stride = 0, any_oned = 0, bounds_box = 1;
   double lprior_const = 0, like0 = 0, thresh = 0;
   std::vector<double> h_beta;
   std::vector<int> h_ptype;
@@ -242,9 +242,11 @@ extern "C" int ptm_set_bounds(ptm_engine* e, const int32_t* lo, const int32_t* h
   int rc;
   const int D = e->D;
   e->has_bounds = 0;
+  e->bounds_box = 1;
   for (int d = 0; d < D; ++d) {
     if (lo[d] < 0 || lo[d] > 3 || hi[d] < 0 || hi[d] > 3) return fail(PTM_ERR_INVALID, "bad boundary type in dimension %d", d);
     if (lo[d] != PTM_BOUND_OPEN || hi[d] != PTM_BOUND_OPEN) e->has_bounds = 1;
+    if ((lo[d] != PTM_BOUND_OPEN && lo[d] != PTM_BOUND_LIMIT) || (hi[d] != PTM_BOUND_OPEN && hi[d] != PTM_BOUND_LIMIT)) e->bounds_box = 0;
   }
   // Q9: state::add() builds on state(space,n) = enforced zero vector (states.cc:183-192,205-214).  Plain host
   // arithmetic on D constants; zero is only ever *rejected* by a `limit` bound, any other bound type maps it.
@@ -452,7 +454,7 @@ static Dev make_dev(ptm_engine* e) {
   memset(&p, 0, sizeof p);
   p.D = e->D; p.DP = e->DP; p.Nt = e->Nt; p.r0 = e->r0; p.nloc = e->nloc; p.W = e->W; p.Nc = e->Nc;
   p.seed = e->cfg.seed; p.step = e->step; p.add_every_n = e->cfg.add_every_n; p.min_prior = e->cfg.min_prior;
-  p.has_bounds = e->has_bounds; p.origin_valid = e->origin_valid;
+  p.has_bounds = e->has_bounds; p.origin_valid = e->origin_valid; p.bounds_box = e->bounds_box;
   p.blo = e->blo; p.bhi = e->bhi; p.bmin = e->bmin; p.bmax = e->bmax;
   p.all_uniform = e->all_uniform; p.lprior_const = e->lprior_const;
   p.ptype = e->ptype; p.plo = e->plo; p.phi = e->phi; p.pcoef = e->pcoef;
@@ -979,7 +981,8 @@ extern "C" const char* ptm_sweep_kernel_name(ptm_engine* e) {
   char b[96];
   const SweepSel s = sweep_sel(e);
   if (e->DP == 32 && s.uni && !s.callback && s.kind != KIND_DIAG)
-    snprintf(b, sizeof b, "sweep_mfma32_kernel<%d, %s, %s>", s.kind, e->hist.rungs ? "true" : "false", s.simple ? "false" : "true");
+    snprintf(b, sizeof b, "sweep_mfma32_kernel<%d, %s, %d>", s.kind, e->hist.rungs ? "true" : "false",
+             s.simple ? 0 : ((e->all_uniform && (!e->has_bounds || e->bounds_box)) ? 1 : 2));
   else snprintf(b, sizeof b, "sweep_kernel<%d, %d, %s, %s>", e->DP, s.kind, s.uni ? "true" : "false", s.simple ? "true" : "false");
   e->kname = b;
   return e->kname.c_str();

@@ -68,6 +68,7 @@ struct Dev {
   double min_prior;
   // state space (states.hh:29-48)
   int has_bounds, origin_valid;
+  int bounds_box;   // every boundary side is open or `limit`: enforcing is a box test
   const int *blo, *bhi;
   const double *bmin, *bmax;
   // prior (probability_function.cc:219-262)

@@ -21,6 +21,8 @@
 // ptmo_llike): an f64 MFMA accumulates its four products as one fma chain in k order on top of C (measured:
 // tools/probes/mfma_f64_probe.hip), so results are bit-identical to the VALU kernels and to the checker.
 #pragma once
+#include <type_traits>
+
 #include "ptm_kernels.hpp"
 
 namespace ptm {
@@ -36,12 +38,12 @@ typedef double mf_d2 __attribute__((ext_vector_type(2)));
 #ifndef PTM_MFMA_WAVES
 #define PTM_MFMA_WAVES 3   // waves per SIMD the register budget is cut for
 #endif
-// HIST: the engine keeps a history.  GEN: the general state space / prior / target -- boundaries of any kind
+// HIST: the engine keeps a history.  GEN > 0: the general state space / prior / target -- boundaries of any kind
 // (boundary::enforce, states.cc:11-58), mixed priors (probability_function.cc:281-304), a mean, one-dimensional moves
 // (proposal_distribution.hh:196-206).  Both are compiled apart: the hot build (false, false) carries none of it.
 // All of the general work is per dimension, so it runs in the accumulator layout as it stands: a lane enforces and
 // prices its own eight dimensions of each chain, and the chain's four lanes meet in two more LDS reductions / ballots.
-template <int KIND, bool HIST, bool GEN>
+template <int KIND, bool HIST, int GEN>   // GEN: 0 lean, 1 box boundaries + uniform prior (+ mean, 1-D moves), 2 everything
 __global__ __launch_bounds__(256, PTM_MFMA_WAVES) void sweep_mfma32_kernel(const Dev p) {
   constexpr int DP = 32;
   constexpr bool LOW = KIND == KIND_LOWER;
@@ -59,6 +61,8 @@ __global__ __launch_bounds__(256, PTM_MFMA_WAVES) void sweep_mfma32_kernel(const
   double* gtab = lbox + 64 + 4 * 128;                   // bmin | bmax | plo | phi | pcoef | mean, 32 each
   int* gint = reinterpret_cast<int*>(gtab + 6 * 32);    // blo | bhi | ptype, 32 each
   double* red2 = reinterpret_cast<double*>(gint + 3 * 32) + wave * 128;   // the prior's partial products
+  // all boundaries open or `limit` (the usual case): enforcing is a box test -- lower | upper limits in row layout
+  double* ebox = reinterpret_cast<double*>(gint + 3 * 32) + 4 * 128;
   const int rl = __builtin_amdgcn_readfirstlane(c0s / p.W);
   const int w0 = c0s - rl * p.W;
   const int rg = p.r0 + rl;
@@ -67,6 +71,7 @@ __global__ __launch_bounds__(256, PTM_MFMA_WAVES) void sweep_mfma32_kernel(const
   const double* timg = p.prop_tiles + (size_t)rl * (16 * 64) + l;   // tile t = (half*4 + slot)*2 + row tile
   const double* pimg = ptile + l;
   const mf_d2* box = reinterpret_cast<const mf_d2*>(lbox) + q;   // lo piece t at 4t, hi piece t at 16 + 4t (row layout)
+  const mf_d2* ebx = reinterpret_cast<const mf_d2*>(ebox) + q;
 
   // The block's tables are read first, the wave's first rows / tiles / scalars right behind them -- all in flight
   // together; the tables then go to LDS and the block meets once.
@@ -130,12 +135,17 @@ __global__ __launch_bounds__(256, PTM_MFMA_WAVES) void sweep_mfma32_kernel(const
     for (int t = 0; t < 6; ++t) gtab[32 * t + threadIdx.x] = st_g[t];
 #pragma unroll
     for (int t = 0; t < 3; ++t) gint[32 * t + threadIdx.x] = st_i[t];
+    const int pos = row_pos<32>(threadIdx.x);
+    ebox[pos] = st_i[0] == B_LIMIT ? st_g[0] : -__builtin_inf();
+    ebox[32 + pos] = st_i[1] == B_LIMIT ? st_g[1] : __builtin_inf();
   }
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   if (!live) return;
 
-#pragma unroll
-  for (int gp = 0; gp < 2; ++gp) {
+  // (a generic lambda called with compile-time pass numbers: `#pragma unroll` gives up on a body of this size in the
+  //  general build, and a pass number known only at run time costs dynamic register indexing)
+  auto pass = [&](auto gpc) {
+    constexpr int gp = decltype(gpc)::value;
     // ---- stage 1: ask for the first half's factor tiles (L2-resident; behind them the first draw)
     double ta[4][2];
 #pragma unroll
@@ -208,7 +218,7 @@ __global__ __launch_bounds__(256, PTM_MFMA_WAVES) void sweep_mfma32_kernel(const
     double xp[2][8];
     uint64_t inbox = 0;     // bit 16 gg + j: chain (2 gp + gg, j) is inside the box of an all-uniform prior
     uint64_t validb = ~0ull; // GEN: bit 16 gg + j: the chain's state is valid (stateSpace::enforce, states.cc:86-102)
-    const bool boxed = !GEN || p.all_uniform;
+    const bool boxed = GEN < 2 || p.all_uniform;
 #pragma unroll
     for (int gg = 0; gg < 2; ++gg) {
       bool ok = true, vok = true;
@@ -219,11 +229,16 @@ __global__ __launch_bounds__(256, PTM_MFMA_WAVES) void sweep_mfma32_kernel(const
         const int m = 2 * t;   // registers m, m+1 <-> dimensions q + 4m, q + 4m + 4
         xp[gg][m] = v.x + acc[gg][m >> 2][m & 3];
         xp[gg][m + 1] = v.y + acc[gg][(m + 1) >> 2][(m + 1) & 3];
-        if (GEN) {
+        if (GEN && p.has_bounds && p.bounds_box) {   // boundary::enforce for open / limit sides (states.cc:53-55)
+          const mf_d2 el = ebx[4 * t], eh = ebx[16 + 4 * t];
+          vok = vok & !(xp[gg][m] < el.x) & !(xp[gg][m] > eh.x) & !(xp[gg][m + 1] < el.y) & !(xp[gg][m + 1] > eh.y);
+        }
+        if (GEN == 2) {
 #pragma unroll
           for (int u = 0; u < 2; ++u) {
             const int d = q + 4 * (m + u);
-            if (p.has_bounds) vok = vok & boundary_enforce(gint[d], gint[32 + d], gtab[d], gtab[32 + d], xp[gg][m + u]);
+            if (p.has_bounds && !p.bounds_box)
+              vok = vok & boundary_enforce(gint[d], gint[32 + d], gtab[d], gtab[32 + d], xp[gg][m + u]);
             if (!boxed) pp *= prior_pdf(gint[64 + d], gtab[64 + d], gtab[96 + d], gtab[128 + d], xp[gg][m + u]);
           }
         }
@@ -238,7 +253,7 @@ __global__ __launch_bounds__(256, PTM_MFMA_WAVES) void sweep_mfma32_kernel(const
         vb &= vb >> 32;
         vb &= vb >> 16;
         validb = (validb & ~(0xFFFFull << (16 * gg))) | ((vb & 0xFFFFull) << (16 * gg));
-        red2[(gg * 4 + q) * 16 + j] = pp;
+        if (GEN == 2) red2[(gg * 4 + q) * 16 + j] = pp;
       }
     }
     PTM_STAGE();
@@ -305,7 +320,7 @@ __global__ __launch_bounds__(256, PTM_MFMA_WAVES) void sweep_mfma32_kernel(const
         // Q9: state::add builds on an enforced zero state -- an origin outside a `limit` bound invalidates every proposal
         const bool valid = !GEN || (p.origin_valid != 0 && ((validb >> (l & 31)) & 1ull) != 0);
         double newlprior = in ? p.lprior_const : -__builtin_inf();
-        if (GEN && !p.all_uniform) {   // log of the product of the factors, ((p0 p1) p2) p3 (probability_function.hh:59)
+        if (GEN == 2 && !p.all_uniform) {   // log of the product of the factors, ((p0 p1) p2) p3 (probability_function.hh:59)
           const double* pm = red2 + ((q & 1) * 4) * 16 + j;
           newlprior = dlog(((pm[0] * pm[16]) * pm[32]) * pm[48]);
         }
@@ -371,7 +386,9 @@ __global__ __launch_bounds__(256, PTM_MFMA_WAVES) void sweep_mfma32_kernel(const
         for (int t = 0; t < 4; ++t) rowv[gg][t] = rown[gg][t];
       }
     }
-  }
+  };
+  pass(std::integral_constant<int, 0>{});
+  pass(std::integral_constant<int, 1>{});
 }
 #undef PTM_STAGE
 

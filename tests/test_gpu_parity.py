@@ -369,7 +369,7 @@ def test_mfma_kernel_general_state_space_and_priors(kind, odf, with_mean, all_un
     mean = rng.normal(size=D) * 0.2 if with_mean else None
     pr, eng, lad = PU.make_pair(D, Nt, W, 50.0, kind=kind, bounds=(blo, bhi, bmin, bmax), prior=(types, cen, hw), swap_rate=0.3,
                                 x0=x0, mean=mean, one_d_frac=(odf if odf > 0 else None))
-    assert "mfma32_kernel" in eng.sweep_kernel_name and eng.sweep_kernel_name.endswith("true>")
+    assert "mfma32_kernel" in eng.sweep_kernel_name and eng.sweep_kernel_name.endswith(", 2>")
     PU.assert_same_state(eng, lad, "start")
     for k in range(6):
         eng.step(5); eng.sync(); lad.pt_step(5)
@@ -378,6 +378,29 @@ def test_mfma_kernel_general_state_space_and_priors(kind, odf, with_mean, all_un
     assert acc > 100 and np.isfinite(eng.lprior).all()
     if odf > 0:
         assert (eng.last_type == 1).any()
+    eng.close()
+
+
+@pytest.mark.parametrize("kind,odf,with_mean", [(E.PROP_LOWER, 0.0, False), (E.PROP_DENSE, 0.4, True)])
+def test_mfma_kernel_limit_bounds_with_uniform_prior(kind, odf, with_mean):
+    """The usual real-world state space -- uniform priors, `limit` / open boundaries -- has its own build of the MFMA
+    kernel (enforcing is a box test); narrow limits so that a good share of the proposals is invalid."""
+    D, Nt, W = 30, 6, 128
+    rng = np.random.default_rng(33)
+    blo = [1 if d % 3 else 0 for d in range(D)]
+    bhi = [1 if d % 2 else 0 for d in range(D)]
+    bmin = list(rng.uniform(-2.5, -1.5, D)); bmax = list(rng.uniform(1.5, 2.5, D))
+    prior = ([1] * D, [0.0] * D, list(rng.uniform(3.0, 6.0, D)))
+    x0 = rng.uniform(-1.4, 1.4, size=(Nt * W, D))
+    mean = rng.normal(size=D) * 0.1 if with_mean else None
+    pr, eng, lad = PU.make_pair(D, Nt, W, 1e3, kind=kind, bounds=(blo, bhi, bmin, bmax), prior=prior, swap_rate=0.3, x0=x0, mean=mean,
+                                one_d_frac=(odf if odf > 0 else None))
+    assert eng.sweep_kernel_name.endswith(", 1>")
+    for k in range(5):
+        eng.step(4); eng.sync(); lad.pt_step(4)
+        PU.assert_same_state(eng, lad, "after %d steps" % (4 * (k + 1)))
+    tries, acc = eng.ntries.sum() - eng.Nc, eng.naccept.sum() - eng.Nc
+    assert 0 < acc < 0.8 * tries
     eng.close()
 
 

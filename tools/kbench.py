@@ -19,12 +19,15 @@ ap.add_argument("--tmax", type=float, default=1e9)
 ap.add_argument("--kind", default="lower")
 ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--tag", default="")
+ap.add_argument("--bounds", action="store_true", help="limit bounds on every dimension, uniform prior: the general build's cheap case")
 ap.add_argument("--general", action="store_true", help="limit bounds on every dimension + one gaussian prior factor: the general build")
 a = ap.parse_args()
 kind = {"lower": E.PROP_LOWER, "dense": E.PROP_DENSE, "diag": E.PROP_DIAG}[a.kind]
 pr = GaussianProblem(a.dim, a.rungs, a.tmax)
 eng = E.Engine(a.dim, a.rungs, a.walkers, add_every_n=100, time_kernels=True)
 pr.configure(eng, kind)
+if a.bounds:
+    eng.set_bounds([1] * a.dim, [1] * a.dim, [-1e3] * a.dim, [1e3] * a.dim)
 if a.general:
     D = a.dim
     eng.set_bounds([1] * D, [1] * D, [-1e3] * D, [1e3] * D)
