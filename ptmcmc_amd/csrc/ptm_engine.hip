@@ -420,9 +420,10 @@ extern "C" int ptm_set_proposals(ptm_engine* e, int kind, const double* factors,
   if (e->prop_tiles) { HIPCHK(hipFree(e->prop_tiles)); e->prop_tiles = nullptr; }
   int rc;
   if ((rc = dalloc(&e->prop, packed.size())) || (rc = upload(e->prop, packed.data(), packed.size(), e->stream))) return rc;
-  if (kind != PTM_PROP_DIAG && DP == 32) {
+  if (DP == 32) {
     // A-operand tiles of the MFMA kernel: tile t = (half*4 + slot)*2 + rowtile, lane 16k + i holds
-    // T[16 rowtile + i][16 half + 4k + slot]
+    // T[16 rowtile + i][16 half + 4k + slot].  A diagonal proposal (sigmas) goes through the same kernel as the diagonal
+    // matrix it is: fma(sigma_i, z_i, +0) is the product sigma_i z_i, and the zero terms around it change nothing.
     std::vector<double> tiles((size_t)nloc * 16 * 64, 0.0);
     for (int r = 0; r < nloc; ++r)
       for (int t = 0; t < 16; ++t) {
@@ -430,7 +431,9 @@ extern "C" int ptm_set_proposals(ptm_engine* e, int kind, const double* factors,
         for (int k = 0; k < 4; ++k)
           for (int i = 0; i < 16; ++i) {
             const int row = 16 * rt + i, col = 16 * hb + 4 * k + sl;
-            if (row < D && col < D) tiles[((size_t)r * 16 + t) * 64 + 16 * k + i] = factors[(size_t)r * D * D + (size_t)row * D + col];
+            if (row < D && col < D)
+              tiles[((size_t)r * 16 + t) * 64 + 16 * k + i] =
+                  kind == PTM_PROP_DIAG ? (row == col ? factors[(size_t)r * D + row] : 0.0) : factors[(size_t)r * D * D + (size_t)row * D + col];
           }
       }
     if ((rc = dalloc(&e->prop_tiles, tiles.size())) || (rc = upload(e->prop_tiles, tiles.data(), tiles.size(), e->stream))) return rc;
@@ -980,8 +983,8 @@ extern "C" const char* ptm_sweep_kernel_name(ptm_engine* e) {
   if (!e) return "";
   char b[96];
   const SweepSel s = sweep_sel(e);
-  if (e->DP == 32 && s.uni && !s.callback && s.kind != KIND_DIAG)
-    snprintf(b, sizeof b, "sweep_mfma32_kernel<%d, %s, %d>", s.kind, e->hist.rungs ? "true" : "false",
+  if (e->DP == 32 && s.uni && !s.callback)
+    snprintf(b, sizeof b, "sweep_mfma32_kernel<%d, %s, %d>", s.kind == KIND_DIAG ? KIND_LOWER : s.kind, e->hist.rungs ? "true" : "false",
              s.simple ? 0 : ((e->all_uniform && (!e->has_bounds || e->bounds_box)) ? 1 : 2));
   else snprintf(b, sizeof b, "sweep_kernel<%d, %d, %s, %s>", e->DP, s.kind, s.uni ? "true" : "false", s.simple ? "true" : "false");
   e->kname = b;

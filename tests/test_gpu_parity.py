@@ -131,6 +131,8 @@ SWEEP_CASES = [
     (32, 16, 64, 1e6, E.PROP_LOWER, None),   # wave-uniform rung path
     (32, 8, 128, 1e3, E.PROP_DENSE, None),   # MFMA kernel, dense factor tiles
     (21, 6, 64, 1e3, E.PROP_LOWER, None),    # MFMA kernel with 11 pad dimensions (21 -> 32)
+    (32, 7, 64, 1e3, E.PROP_DIAG, None),     # diagonal sigmas through the MFMA kernel (as the diagonal matrix they are)
+    (19, 5, 128, 1e2, E.PROP_DIAG, 0.5),     # ... with one-dimensional moves: the sampler's default Gaussian flavour
     (27, 5, 192, 1e2, E.PROP_DENSE, None),
     (16, 12, 64, 1e3, E.PROP_DIAG, 0.5),     # the sampler's default Gaussian flavour: diagonal + 1-D moves
     (5, 7, 3, 1e2, E.PROP_DENSE, 0.3),       # padded dimension (5 -> 8), ragged sizes
