@@ -382,20 +382,26 @@ class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:
   ptm_engine* eng;
   const stateSpace* sp;
   int dim, nstep, hist_rows;
+  int W;   // independent replicas of the ladder run side by side (the reference runs its Nchain repeats one after the
+           // other, ptmcmc.cc main loop): chain (rung i, replica w) sits at index i*W + w of every engine array
   std::vector<double> temps, X, llike, lpost;
-  bool fresh;
+  bool fresh, hist_fresh = false;
+  std::vector<double> hx, hl, hp;       // host copy of the history ring (dumpChain)
+  std::vector<int32_t> hmeta;
+  std::vector<int64_t> hnhist;
   std::vector<proposal_distribution*> props;
 
   class rung_view : public chain {
     parallel_tempering_chains* p;
-    int i;
+    int i, w;
 
    public:
-    rung_view(parallel_tempering_chains* p, int i) : p(p), i(i) {}
+    rung_view(parallel_tempering_chains* p, int i, int w = 0) : p(p), i(i), w(w) {}
     void step() override { std::cout << "rung_view::step: step the ladder, not a rung" << std::endl; exit(1); }
-    state getState(int = -1, bool = false) override { p->refresh(); return state(p->sp, std::vector<double>(p->X.begin() + (size_t)i * p->dim, p->X.begin() + (size_t)(i + 1) * p->dim)); }
-    double getLogPost(int = -1, bool = false) override { p->refresh(); return p->lpost[i]; }
-    double getLogLike(int = -1, bool = false) override { p->refresh(); return p->llike[i]; }
+    size_t at() const { return (size_t)i * p->W + w; }
+    state getState(int = -1, bool = false) override { p->refresh(); return state(p->sp, std::vector<double>(p->X.begin() + at() * p->dim, p->X.begin() + (at() + 1) * p->dim)); }
+    double getLogPost(int = -1, bool = false) override { p->refresh(); return p->lpost[at()]; }
+    double getLogLike(int = -1, bool = false) override { p->refresh(); return p->llike[at()]; }
     double invTemp() override { return 1 / p->temps[i]; }
     int getStep() override { return p->nstep; }
   };
@@ -413,7 +419,7 @@ class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:
   parallel_tempering_chains(int Ntemps, double Tmax, double swap_rate = 0.01, int add_every_N = 1, bool do_evid = false,
                             bool verbose_evid = true, double dpriormin = -30)
       : Ntemps(Ntemps), add_every_N(add_every_N), Tmax(Tmax), swap_rate(swap_rate), dpriormin(dpriormin), eng(nullptr),
-        sp(nullptr), dim(0), nstep(0), hist_rows(0), temps(Ntemps, 1.0), fresh(false) {
+        sp(nullptr), dim(0), nstep(0), hist_rows(0), W(1), temps(Ntemps, 1.0), fresh(false) {
     // geometric ladder, chain.cc:1181-1183
     double tratio = Ntemps > 1 ? std::exp(std::log(Tmax) / (Ntemps - 1)) : 1.0;
     for (int i = 1; i < Ntemps; i++) temps[i] = temps[i - 1] * tratio;
@@ -426,6 +432,11 @@ class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:
   // ring of `rows_per_chain` rows per rung; call before initialize().  The reference keeps the whole history in host
   // vectors; dumpChain() below writes the same file from the ring.
   void keep_history(int rows_per_chain) { hist_rows = rows_per_chain; }
+  // Run `n` independent replicas of the ladder in one engine (call before initialize()).  Replica w uses the random
+  // streams of walker w; every accessor below takes the replica as an optional last argument (default 0).  Multiples
+  // of 64 fill whole wavefronts and take the fast kernels.
+  void set_replicas(int n) { W = n < 1 ? 1 : n; }
+  int replicas() const { return W; }
   // chain.cc:1281-1365: n prior draws per rung; the device draws them (uniform / gaussian dimensions)
   void initialize(bayes_likelihood* log_likelihood, const sampleable_probability_function* log_prior, int n = 1, uint64_t seed = 0x5EED0001ull,
                   const std::vector<double>* start_states = nullptr) {
@@ -433,7 +444,7 @@ class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:
     dim = log_prior->getDim();
     ptm_config cfg;
     cfg.struct_size = sizeof cfg;
-    cfg.dim = dim; cfg.n_rungs = Ntemps; cfg.rung_begin = 0; cfg.rung_count = Ntemps; cfg.n_walkers = 1; cfg.seed = seed;
+    cfg.dim = dim; cfg.n_rungs = Ntemps; cfg.rung_begin = 0; cfg.rung_count = Ntemps; cfg.n_walkers = W; cfg.seed = seed;
     cfg.swap_rate = swap_rate; cfg.add_every_n = add_every_N; cfg.min_prior = dpriormin; cfg.device = -1; cfg.stream = nullptr;
     cfg.time_kernels = 0; cfg.swap_log_steps = 0; cfg.exchange_row_capacity = 0; cfg.history_rungs = hist_rows > 0 ? Ntemps : 0; cfg.history_capacity = hist_rows;
     ptm_check(ptm_engine_create(&cfg, &eng), "parallel_tempering_chains::initialize");
@@ -453,7 +464,7 @@ class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:
     std::vector<double> beta(Ntemps);
     for (int i = 0; i < Ntemps; i++) beta[i] = 1 / temps[i];  // chain.cc:1340
     ptm_check(ptm_set_ladder(eng, beta.data()), "set_ladder");
-    X.assign((size_t)Ntemps * dim, 0.0); llike.assign(Ntemps, 0.0); lpost.assign(Ntemps, 0.0);
+    X.assign((size_t)Ntemps * W * dim, 0.0); llike.assign((size_t)Ntemps * W, 0.0); lpost.assign((size_t)Ntemps * W, 0.0);
     if (start_states) {
       ptm_check(ptm_set_states(eng, start_states->data(), nullptr), "set_states");
     } else {
@@ -465,7 +476,8 @@ class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:
       ptm_check(rc, "init_from_prior");
     }
     views.clear();
-    for (int i = 0; i < Ntemps; i++) views.push_back(rung_view(this, i));
+    for (int w = 0; w < W; w++)
+      for (int i = 0; i < Ntemps; i++) views.push_back(rung_view(this, i, w));   // views[w*Ntemps + i]
     fresh = false;
   }
   // chain.cc:1367-1386: one clone per rung
@@ -491,20 +503,21 @@ class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:
   void step() override {
     ptm_check(ptm_step(eng, 1), "parallel_tempering_chains::step");
     nstep++;
-    fresh = false;
+    fresh = hist_fresh = false;
   }
   void step(int n) {
     ptm_check(ptm_step(eng, n), "parallel_tempering_chains::step");
     nstep += n;
-    fresh = false;
+    fresh = hist_fresh = false;
   }
   state getState(int = -1, bool = false) override { return views[0].getState(); }
   double getLogPost(int = -1, bool = false) override { return views[0].getLogPost(); }
   double getLogLike(int = -1, bool = false) override { return views[0].getLogLike(); }
   int getStep() override { return nstep; }
   int multiplicity() override { return Ntemps; }
-  chain* subchain(int index) override {
-    if (index >= 0 && index < Ntemps) return &views[index];
+  chain* subchain(int index) override { return subchain(index, 0); }
+  chain* subchain(int index, int replica) {
+    if (index >= 0 && index < Ntemps && replica >= 0 && replica < W) return &views[(size_t)replica * Ntemps + index];
     std::cout << "parallel_tempering_chains::subchain:index out of range. (" << index << " of " << Ntemps << ")" << std::endl;
     exit(1);
   }
@@ -512,15 +525,17 @@ class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:
   // MH_chain::dumpChain (chain.cc:1112-1135) for rung `ichain`: one line per saved step i = Nburn, Nburn+ievery, ... :
   //   i lpost llike acceptance_ratio prop_type: p0 ... pD-1 invtemp
   // Rows that have already left the ring are skipped (the ring holds the newest rows_per_chain saved states).
-  void dumpChain(int ichain, std::ostream& os, int Nburn = 0, int ievery = 1) {
+  void dumpChain(int ichain, std::ostream& os, int Nburn = 0, int ievery = 1, int replica = 0) {
     if (hist_rows <= 0) { std::cout << "parallel_tempering_chains::dumpChain: call keep_history(rows) before initialize()" << std::endl; exit(1); }
-    const size_t HC = Ntemps, cap = hist_rows;
-    std::vector<double> hx(cap * HC * dim), hl(cap * HC), hp(cap * HC);
-    std::vector<int32_t> meta(cap * HC * 4);
-    std::vector<int64_t> nhist(Ntemps);
-    ptm_check(ptm_get_history(eng, hx.data(), hl.data(), hp.data(), meta.data()), "dumpChain");
-    ptm_check(ptm_get_array(eng, PTM_ARR_NHIST, nhist.data()), "dumpChain");
-    const int Ninit = 1, Nhist = (int)nhist[ichain];
+    const size_t HC = (size_t)Ntemps * W, cap = hist_rows, at = (size_t)ichain * W + replica;
+    if (!hist_fresh) {   // one read-back serves every rung / replica dumped at this step
+      hx.resize(cap * HC * dim); hl.resize(cap * HC); hp.resize(cap * HC); hmeta.resize(cap * HC * 4); hnhist.resize(HC);
+      ptm_check(ptm_get_history(eng, hx.data(), hl.data(), hp.data(), hmeta.data()), "dumpChain");
+      ptm_check(ptm_get_array(eng, PTM_ARR_NHIST, hnhist.data()), "dumpChain");
+      hist_fresh = true;
+    }
+    const std::vector<int32_t>& meta = hmeta;
+    const int Ninit = 1, Nhist = (int)hnhist[at];
     os << "#Ninit=" << Ninit << ", Nburn=" << Nburn << "\n";
     os << "#eval: log(posterior) log(likelihood) acceptance_ratio prop_type: ";
     for (int i = 0; i < dim; i++) os << (sp ? sp->get_name(i) : std::string("[unnamed]")) << " ";
@@ -530,7 +545,7 @@ class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:
     for (int i = Nburn; i < Nhist; i += ievery) {
       int idx = Ninit + i;                                          // chain.cc:1124-1125
       if (i >= 0) idx = Ninit + i / add_every_N;                    // get_state_idx, chain.cc:1041-1050 (Nzero = 0)
-      const size_t o = (size_t)(idx % (int)cap) * HC + ichain;
+      const size_t o = (size_t)(idx % (int)cap) * HC + at;
       if (idx < 0 || meta[4 * o + 3] != idx) continue;              // not saved yet / overwritten in the ring
       const double lpo = hp[o] + invtemp * hl[o];                   // chain.cc:928
       os << i << " " << lpo << " " << hl[o] << " " << meta[4 * o] / (double)meta[4 * o + 1] << " " << meta[4 * o + 2] << ": ";
@@ -542,28 +557,33 @@ class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:
   }
   // swap_count / swap_accept_count (chain.hh:244-245)
   void swap_counts(std::vector<int64_t>& tries, std::vector<int64_t>& accepts) {
-    tries.assign(Ntemps > 1 ? Ntemps - 1 : 1, 0); accepts = tries;
-    ptm_check(ptm_get_swap_counts(eng, tries.data(), accepts.data()), "swap_counts");
+    std::vector<int64_t> t((size_t)W * (Ntemps > 1 ? Ntemps - 1 : 1)), a(t.size());
+    ptm_check(ptm_get_swap_counts(eng, t.data(), a.data()), "swap_counts");
+    tries.assign(t.begin(), t.begin() + (Ntemps > 1 ? Ntemps - 1 : 1));       // replica 0
+    accepts.assign(a.begin(), a.begin() + (Ntemps > 1 ? Ntemps - 1 : 1));
   }
   std::string status() override {  // chain.cc:2053-2094 flavour
     refresh();
-    std::vector<int32_t> nt(Ntemps), na(Ntemps);
+    std::vector<int32_t> nt((size_t)Ntemps * W), na((size_t)Ntemps * W);
     ptm_get_array(eng, PTM_ARR_NTRIES, nt.data());
     ptm_get_array(eng, PTM_ARR_NACCEPT, na.data());
     std::ostringstream s;
-    for (int i = 0; i < Ntemps; i++)
-      s << "T=" << temps[i] << ": lpost=" << lpost[i] << " llike=" << llike[i] << " acc=" << (double)na[i] / nt[i] << "\n";
+    for (int i = 0; i < Ntemps; i++) {   // replica 0
+      const size_t c = (size_t)i * W;
+      s << "T=" << temps[i] << ": lpost=" << lpost[c] << " llike=" << llike[c] << " acc=" << (double)na[c] / nt[c] << "\n";
+    }
     return s.str();
   }
   // MH_chain::dumpChain row format of the current state (chain.cc:1112-1135): i lpost llike acc type: params invtemp
-  void dumpCurrent(int ichain, std::ostream& os) {
+  void dumpCurrent(int ichain, std::ostream& os, int replica = 0) {
     refresh();
-    std::vector<int32_t> nt(Ntemps), na(Ntemps), ty(Ntemps);
+    std::vector<int32_t> nt((size_t)Ntemps * W), na((size_t)Ntemps * W), ty((size_t)Ntemps * W);
     ptm_get_array(eng, PTM_ARR_NTRIES, nt.data());
     ptm_get_array(eng, PTM_ARR_NACCEPT, na.data());
     ptm_get_array(eng, PTM_ARR_LAST_TYPE, ty.data());
-    os << nstep << " " << lpost[ichain] << " " << llike[ichain] << " " << (double)na[ichain] / nt[ichain] << " " << ty[ichain] << ": ";
-    for (int j = 0; j < dim; j++) os << X[(size_t)ichain * dim + j] << " ";
+    const size_t c = (size_t)ichain * W + replica;
+    os << nstep << " " << lpost[c] << " " << llike[c] << " " << (double)na[c] / nt[c] << " " << ty[c] << ": ";
+    for (int j = 0; j < dim; j++) os << X[c * dim + j] << " ";
     os << 1 / temps[ichain] << std::endl;
   }
 };
@@ -581,7 +601,7 @@ class ptmcmc_sampler {
     // flag names and defaults of ptmcmc.cc:375-427 that shape this path
     opt["nsteps"] = "5000"; opt["save_every"] = "10"; opt["nevery"] = "1000"; opt["pt"] = "20"; opt["pt_swap_rate"] = "0.10";
     opt["pt_Tmax"] = "1e9"; opt["chain_dprior_min"] = "-30"; opt["seed"] = "-1"; opt["outname"] = "mcmc_output";
-    opt["nskip"] = "10"; opt["pt_dump_n"] = "1";
+    opt["nskip"] = "10"; opt["pt_dump_n"] = "1"; opt["nchains"] = "1";
   }
   void set(const std::string& name, const std::string& value) { opt[name] = value; }
   bool parse(int argc, char* argv[]) {  // --name=value / --name (options.hh semantics)
@@ -602,6 +622,7 @@ class ptmcmc_sampler {
     // the chain files are written from the device's history ring, every "nevery" steps: it must hold what one such
     // interval saves (up to two add_state calls per step, every save_every-th saved)
     cc->keep_history(2 + 2 * (int)num("nevery") / std::max(1, (int)num("save_every")));
+    cc->set_replicas((int)num("nchains"));   // the reference's Nchain repeats, all at once
     uint64_t seed = num("seed") >= 0 ? (uint64_t)(num("seed") * 4294967296.0) : 0x5EED0001ull;
     cc->initialize(chain_llike, chain_prior, 1, seed);
     cc->set_proposal(*cprop);
@@ -614,19 +635,24 @@ class ptmcmc_sampler {
     const int Nstep = (int)num("nsteps"), Nevery = std::max(1, (int)num("nevery")), Nskip = std::max(1, (int)num("nskip"));
     int dump_n = (int)num("pt_dump_n");
     if (dump_n > cc->multiplicity() || dump_n <= 0) dump_n = cc->multiplicity();   // ptmcmc.cc:458
+    const int nrep = cc->replicas();
     std::vector<std::unique_ptr<std::ofstream> > out;
-    for (int ich = 0; ich < dump_n; ich++) {   // ptmcmc.cc:547-554
-      std::ostringstream ss;
-      ss << base << "_t" << ich << ".dat";
-      out.emplace_back(new std::ofstream(ss.str().c_str()));
-      out.back()->precision(13);
-    }
+    for (int w = 0; w < nrep; w++)
+      for (int ich = 0; ich < dump_n; ich++) {   // ptmcmc.cc:547-554; replica w > 0: <base>_c<w>_t<ich>.dat
+        std::ostringstream ss;
+        ss << base;
+        if (w > 0) ss << "_c" << w;
+        ss << "_t" << ich << ".dat";
+        out.emplace_back(new std::ofstream(ss.str().c_str()));
+        out.back()->precision(13);
+      }
     for (int istep = 0; istep <= Nstep; istep++) {   // ptmcmc.cc:565,599-607
       cc->step();
       if (0 == istep % Nevery)
-        for (int ich = 0; ich < dump_n; ich++) cc->dumpChain(ich, *out[ich], istep - Nevery + 1, Nskip);
+        for (int w = 0; w < nrep; w++)
+          for (int ich = 0; ich < dump_n; ich++) cc->dumpChain(ich, *out[(size_t)w * dump_n + ich], istep - Nevery + 1, Nskip, w);
     }
-    for (int ich = 0; ich < dump_n; ich++) *out[ich] << "\n" << std::endl;   // ptmcmc.cc:665
+    for (size_t k = 0; k < out.size(); k++) *out[k] << "\n" << std::endl;   // ptmcmc.cc:665
     return 0;
   }
   parallel_tempering_chains* chains() { return cc.get(); }

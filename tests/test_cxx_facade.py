@@ -103,3 +103,22 @@ def test_sampler_driver_writes_the_reference_chain_files():
             P = np.array([[2.0, 0.6, 0.0], [0.6, 1.0, -0.3], [0.0, -0.3, 1.5]])
             assert np.allclose(H[:, 2], -0.5 * np.einsum("ni,ij,nj->n", X[:, :3], P, X[:, :3]), atol=1e-9)
             assert set(H[:, 4]) <= {-1.0, 0.0, 1.0}
+
+
+@pytest.mark.gpu
+def test_sampler_replicas_run_side_by_side_and_do_not_change_each_other():
+    """--nchains=N runs the reference's Nchain repeats as N replicas in one engine: replica 0's chain files are, byte
+    for byte, those of a run with a single replica; the other replicas are different, valid chains."""
+    with tempfile.TemporaryDirectory() as d:
+        exe = os.path.join(d, "ex2")
+        build(exe, "example_sampler.cc")
+        one, many = os.path.join(d, "one"), os.path.join(d, "many")
+        for base, n in ((one, 1), (many, 64)):
+            r = subprocess.run([exe, base, "--nchains=%d" % n, "--nsteps=600", "--nevery=200"], capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stdout + r.stderr
+        for ich in (0, 1):
+            assert open("%s_t%d.dat" % (one, ich)).read() == open("%s_t%d.dat" % (many, ich)).read()
+        a = open(many + "_t0.dat").read()
+        for w in (1, 17, 63):
+            b = open("%s_c%d_t0.dat" % (many, w)).read()
+            assert b != a and len(b.splitlines()) > 100
