@@ -1,5 +1,5 @@
 #!/bin/bash
-# matrix-pipe / memory-pipe counters of the sweep kernel.  usage: bash tools/pmc_mfma.sh <tag>
+# matrix-pipe / L2 counters of the sweep kernel.  (TA_* / TCP_* counters hang rocprofv3 on this pool: left out.)  usage: bash tools/pmc_mfma.sh <tag>
 TAG=${1:-r01}
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
@@ -9,7 +9,6 @@ ARGS="$R/bench.py --steps 5 --warmup 2 --no-cpu --no-w1"
 i=0
 for G in "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_VALU" \
          "SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_LEVEL_WAVES SQ_WAVE_CYCLES SQ_INSTS_VMEM_RD" \
-         "TA_TA_BUSY TA_ADDR_STALLED_BY_TC_CYCLES TA_DATA_STALLED_BY_TC_CYCLES TCP_PENDING_STALL_CYCLES GRBM_GUI_ACTIVE" \
          "TCC_BUSY TCC_REQ TCC_HIT TCC_MISS TCC_EA0_RDREQ" \
          "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU SQ_INST_CYCLES_VMEM_RD"; do
   i=$((i+1))
