@@ -101,6 +101,11 @@ def cpu_baseline(problem, budget_s=15.0):
             "sample": "oracle/ptm_oracle.c pt_step, D=%d, %d rungs x %d ladders, %d steps, OpenMP over chains" % (D, NT, W, n)}
 
 
+# Independent ladders batched per GPU.  Throughput still grows a little with the batch (launch tails amortise: 6.7e9 steps/s
+# at 4096, 7.0e9 at 8192, 7.1e9 at 16384 on chains fresh from the prior); 16384 x 1024 rungs = 16.8 M chains = 4.8 GB of state.
+DEFAULT_WALKERS = 16384
+
+
 def settle(eng, seconds=0.25):
     """set-up, before the W warm-up steps: run the ladder for a quarter of a second so that the GPU's clocks have ramped
     and the chains have left their prior draws (the acceptance pattern, and with it the row traffic, is then the
@@ -136,7 +141,7 @@ def run_single(args):
     value = nchains * args.steps / wall
     kavg_ms = float(kt.mean())
     achieved = algorithmic_bytes(D) * nchains / (kavg_ms * 1e-3) / 1e9
-    tr = measured_traffic(eng.sweep_kernel_name) if W == 4096 else None
+    tr = measured_traffic(eng.sweep_kernel_name) if W == DEFAULT_WALKERS else None
     acc = float((eng.naccept.sum() - eng.Nc)) / max(1, float((eng.ntries.sum() - eng.Nc)))
     t, a = eng.swap_counts()
     # latency-bound companion: the bare 1024-chain ladder (W=1)
@@ -179,7 +184,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--walkers", type=int, default=4096, help="independent ladders batched per GPU")
+    ap.add_argument("--walkers", type=int, default=DEFAULT_WALKERS, help="independent ladders batched per GPU")
     ap.add_argument("--halo", type=int, default=4, help="llike halo depth (rungs) between shards")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-w1", action="store_true", help="skip the 1024-chain latency companion")
