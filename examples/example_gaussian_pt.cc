@@ -47,6 +47,7 @@ int main(int argc, char** argv) {
 
   parallel_tempering_chains ptc(Nt, 100.0, 0.2, 10);
   ptc.keep_history(1 + (nsteps + nsteps / 4) / 5);   // every 10th state, up to two adds per step
+  ptc.track_exchanges(true);                          // instances / directions / ups / downs (chain.cc:1448-1451,1495-1498)
   ptc.initialize(&like, like.getObjectPrior().get(), 1);
   ptc.set_proposal(prop);
 
@@ -66,6 +67,15 @@ int main(int argc, char** argv) {
          callback ? "callback" : "device", D, Nt, ptc.getStep(), m2[0] / nsteps, D - 1, m2[D - 1] / nsteps, ptc.getLogPost(),
          ptc.subchain(Nt - 1)->invTemp(), sa, st, t.calls);
   printf("%s", ptc.status().c_str());
+  {   // every instance is still on exactly one rung, and hot states did travel down
+    std::vector<int> seen(Nt, 0);
+    int moved = 0;
+    for (int i = 0; i < Nt; i++) { seen[ptc.getInstances()[i]]++; moved += ptc.getInstances()[i] != i; }
+    bool perm = true;
+    for (int i = 0; i < Nt; i++) perm = perm && seen[i] == 1;
+    printf("instances %s a permutation of the rungs, %d displaced\n", perm ? "are" : "ARE NOT", moved);
+    if (argc > 5) { std::ofstream ts(std::string(argv[5]) + ".tempstats"); ptc.dumpTempStats(ts); }
+  }
   if (argc > 5) {   // the cold chain's file, as MH_chain::dumpChain writes it (chain.cc:1112-1135)
     std::ofstream os(argv[5]);
     os.precision(13);

@@ -386,6 +386,31 @@ class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:
            // other, ptmcmc.cc main loop): chain (rung i, replica w) sits at index i*W + w of every engine array
   std::vector<double> temps, X, llike, lpost;
   bool fresh, hist_fresh = false;
+  // replica-exchange diagnostics of chain.cc:1346-1356,1448-1451,1495-1498 (directions / instances / ups / downs), kept
+  // on the host by replaying each step's candidate log (replica 0); on after track_exchanges(true)
+  bool tracking = false;
+  std::vector<int> directions, instances;
+  std::vector<long> ups, downs;
+  std::vector<int32_t> log_pairs, log_acc;
+  void replay_step() {   // the loop of chain.cc:1436-1537, bookkeeping part, in pick order
+    const int ms = ptm_max_swaps_per_step(eng);
+    log_pairs.resize((size_t)W * ms); log_acc.resize((size_t)W * ms);
+    ptm_check(ptm_get_last_swaps(eng, log_pairs.data(), log_acc.data()), "replay_step");
+    for (int j = 0; j < ms; j++) {
+      const int i = log_pairs[j];
+      if (i < 0) continue;
+      if (i > 0) {                                   // chain.cc:1448-1451
+        if (directions[i] > 0) ups[i]++;
+        if (directions[i] < 0) downs[i]++;
+      }
+      if (log_acc[j]) {                              // chain.cc:1495-1498
+        std::swap(directions[i], directions[i + 1]);
+        std::swap(instances[i], instances[i + 1]);
+        if (i == 0) directions[i] = 1;
+        if (i + 1 == Ntemps - 1) directions[i + 1] = -1;
+      }
+    }
+  }
   std::vector<double> hx, hl, hp;       // host copy of the history ring (dumpChain)
   std::vector<int32_t> hmeta;
   std::vector<int64_t> hnhist;
@@ -436,6 +461,33 @@ class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:
   // streams of walker w; every accessor below takes the replica as an optional last argument (default 0).  Multiples
   // of 64 fill whole wavefronts and take the fast kernels.
   void set_replicas(int n) { W = n < 1 ? 1 : n; }
+  // Keep the reference's exchange diagnostics (which instance sits on which rung, round-trip directions, ups / downs)
+  // for replica 0: costs one read-back of the step's candidate log per step, so it is off by default.
+  void track_exchanges(bool on) {
+    tracking = on;
+    directions.assign(Ntemps, 0); instances.resize(Ntemps); ups.assign(Ntemps, 0); downs.assign(Ntemps, 0);
+    for (int i = 0; i < Ntemps; i++) instances[i] = i;                       // chain.cc:1346-1356
+    if (Ntemps > 0) { directions[0] = -1; directions[Ntemps - 1] = 1; }
+    if (Ntemps == 1) directions[0] = -1;
+  }
+  const std::vector<int>& getInstances() const { return instances; }
+  const std::vector<int>& getDirections() const { return directions; }
+  // parallel_tempering_chains::dumpTempStats (chain.cc:2025-2040): T, up fraction, swap acceptance of the pair above
+  void dumpTempStats(std::ostream& os) {
+    std::vector<int64_t> tries, acc;
+    swap_counts(tries, acc);
+    os << "#T0 up_frac0 up-swap_ratio0-1" << std::endl;
+    for (int i = 0; i < Ntemps; i++) {
+      double up_frac;
+      if (i == 0) up_frac = 1;
+      else if (i == Ntemps - 1) up_frac = 0;
+      else up_frac = tracking ? ups[i] / (double)(ups[i] + downs[i]) : 0.0 / 0.0;
+      os << temps[i] << " " << up_frac << " ";
+      if (i < Ntemps - 1) os << acc[i] / (double)tries[i] << ": ";
+      os << std::endl;
+    }
+    os << "\n" << std::endl;
+  }
   int replicas() const { return W; }
   // chain.cc:1281-1365: n prior draws per rung; the device draws them (uniform / gaussian dimensions)
   void initialize(bayes_likelihood* log_likelihood, const sampleable_probability_function* log_prior, int n = 1, uint64_t seed = 0x5EED0001ull,
@@ -504,8 +556,10 @@ class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:
     ptm_check(ptm_step(eng, 1), "parallel_tempering_chains::step");
     nstep++;
     fresh = hist_fresh = false;
+    if (tracking) replay_step();
   }
   void step(int n) {
+    if (tracking) { for (int k = 0; k < n; k++) step(); return; }
     ptm_check(ptm_step(eng, n), "parallel_tempering_chains::step");
     nstep += n;
     fresh = hist_fresh = false;

@@ -61,6 +61,10 @@ def test_facade_writes_the_cold_chain_file_from_the_device_history():
         build(exe)
         r = subprocess.run([exe, "device", "4", "8", "4000", out], capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stdout + r.stderr
+        assert "instances are a permutation of the rungs" in r.stdout and " 0 displaced" not in r.stdout
+        ts = [l.split() for l in open(out + ".tempstats").read().splitlines() if l and not l.startswith("#")]
+        assert len(ts) == 8 and float(ts[0][1]) == 1.0 and float(ts[7][1]) == 0.0
+        assert all(0.0 <= float(t[1]) <= 1.0 for t in ts) and all(0.0 < float(t[2].rstrip(":")) <= 1.0 for t in ts[:7])
         lines = open(out).read().splitlines()
         assert lines[0] == "#Ninit=1, Nburn=1000"
         assert lines[1].startswith("#eval: log(posterior) log(likelihood) acceptance_ratio prop_type: x0 x1 x2 x3")
