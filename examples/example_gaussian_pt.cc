@@ -1,6 +1,6 @@
 // example_gaussian_pt.cc -- the reference's PT-on-a-correlated-Gaussian set-up (cython/exampleGaussian.py main(),
 // BASELINE.md scratch driver) written against ptmcmc_gpu.hh: same classes, same call sequence, every step on the MI355X.
-//   build: g++ -std=c++11 -O2 -Iinclude -Iptmcmc_amd/host examples/example_gaussian_pt.cc -Lptmcmc_amd -lptm_engine -Wl,-rpath,$PWD/ptmcmc_amd
+//   build: g++ -std=c++11 -O2 -Iinclude -Iptmcmc_amd/host examples/example_gaussian_pt.cc -Lptmcmc_amd -lptm_engine -Wl,-rpath,$PWD/ptmcmc_amd -pthread
 //   usage: example_gaussian_pt [mode] [D] [Ntemps] [nsteps] [chainfile]      mode = device | callback
 #include <cstdio>
 #include <cstdlib>
@@ -15,7 +15,7 @@ struct target { int D; std::vector<double> P; double like0; long calls; };
 // a user likelihood in the reference's function-pointer form (bayesian.hh:547)
 static double my_loglike(void* object, const state& s) {
   target* t = (target*)object;
-  t->calls++;
+  __sync_fetch_and_add(&t->calls, 1);   // (evaluated from several host threads)
   double q = 0;
   for (int i = 0; i < t->D; i++)
     for (int j = 0; j < t->D; j++) q += s.get_param(i) * t->P[i * t->D + j] * s.get_param(j);

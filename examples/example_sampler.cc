@@ -1,6 +1,6 @@
 // example_sampler.cc -- the reference's driver loop (ptmcmc_sampler: setup, select_proposal, initialize, run;
 // ptmcmc.cc:489-679) written against ptmcmc_gpu.hh: chain files <base>_t<k>.dat come out of the device's history ring.
-//   build: g++ -std=c++11 -O2 -Iinclude -Iptmcmc_amd/host examples/example_sampler.cc -Lptmcmc_amd -lptm_engine -Wl,-rpath,$PWD/ptmcmc_amd
+//   build: g++ -std=c++11 -O2 -Iinclude -Iptmcmc_amd/host examples/example_sampler.cc -Lptmcmc_amd -lptm_engine -Wl,-rpath,$PWD/ptmcmc_amd -pthread
 //   usage: example_sampler <outbase> [--nsteps=N] [--pt=Ntemps] [--save_every=S] [--nevery=E] [--nskip=K] [--pt_dump_n=M]
 #include <cmath>
 #include <cstdio>

@@ -30,6 +30,7 @@
 #include <memory>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <valarray>
 #include <vector>
 
@@ -254,13 +255,30 @@ class bayes_likelihood : public probability_function {  // bayesian.hh:307-581 (
   // device-resident targets override this and return true after describing themselves to the engine
   virtual bool describe_device_target(ptm_engine* e) { return false; }
   // C-ABI trampoline: the engine hands over the gated proposals of one sweep
+  // The batch is spread over host threads -- the reference evaluates the rungs of one step under `omp parallel for`
+  // (chain.cc:1544-1557) and so requires a thread-safe evaluate_log already; set_eval_threads(1) serialises.
+  void set_eval_threads(int n) { eval_threads = n; }
   static void batch_trampoline(void* self, const double* X, int n, int dim, double* out) {
     bayes_likelihood* l = (bayes_likelihood*)self;
-    for (int k = 0; k < n; k++) {
-      state s(l->getObjectStateSpace(), std::valarray<double>(X + (size_t)k * dim, dim));
-      out[k] = l->evaluate_log(s);
-    }
+    auto work = [l, X, dim, out](int k0, int k1) {
+      for (int k = k0; k < k1; k++) {
+        state s(l->getObjectStateSpace(), std::valarray<double>(X + (size_t)k * dim, dim));
+        out[k] = l->evaluate_log(s);
+      }
+    };
+    int nt = l->eval_threads > 0 ? l->eval_threads : (int)std::thread::hardware_concurrency();
+    if (nt > n / 8) nt = n / 8;      // at least 8 states per thread
+    if (nt <= 1) { work(0, n); return; }
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nt; t++) pool.emplace_back(work, (int)((long)n * t / nt), (int)((long)n * (t + 1) / nt));
+    work(0, n / nt);
+    for (auto& th : pool) th.join();
   }
+
+ private:
+  int eval_threads = 0;   // 0: all hardware threads
+
+ public:
 };
 
 // correlated Gaussian target evaluated ON the device: like0 - 1/2 (x-mean)^T P (x-mean) (cython/exampleGaussian.py:46-109)

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def build(out, src="example_gaussian_pt.cc"):
     cmd = ["g++", "-std=c++11", "-O2", "-Wall", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "ptmcmc_amd", "host"),
            os.path.join(ROOT, "examples", src), "-L", os.path.join(ROOT, "ptmcmc_amd"), "-lptm_engine",
-           "-Wl,-rpath," + os.path.join(ROOT, "ptmcmc_amd"), "-o", out]
+           "-Wl,-rpath," + os.path.join(ROOT, "ptmcmc_amd"), "-pthread", "-o", out]
     subprocess.check_call(cmd)
 
 
