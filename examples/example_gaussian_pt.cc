@@ -67,6 +67,7 @@ int main(int argc, char** argv) {
          callback ? "callback" : "device", D, Nt, ptc.getStep(), m2[0] / nsteps, D - 1, m2[D - 1] / nsteps, ptc.getLogPost(),
          ptc.subchain(Nt - 1)->invTemp(), sa, st, t.calls);
   printf("%s", ptc.status().c_str());
+  printf("MAP lpost=%.6f at x0=%.4f (lpost now %.6f)\n", ptc.getMAPlpost(), ptc.getMAPstate().get_param(0), ptc.getLogPost());
   {   // every instance is still on exactly one rung, and hot states did travel down
     std::vector<int> seen(Nt, 0);
     int moved = 0;

@@ -76,6 +76,8 @@ typedef struct ptm_config {
   int32_t history_rungs;    /* >0: keep the history MH_chain::add_state pushes (chain.cc:935-946) for the first
                              * history_rungs rungs held by this engine; 0 = off */
   int32_t history_capacity; /* rows per chain kept on the device (a ring: saved row s sits in slot s % capacity) */
+  int32_t map_rungs;        /* >0: track the MAP state MH_chain::add_state keeps (chain.cc:931-934) for the first map_rungs
+                             * rungs held by this engine (the ladder's MAP is rung 0's, chain.cc:1570-1571); 0 = off */
 } ptm_config;
 
 /* user plug-in likelihood, batched: the C shape of bayes_likelihood::register_evaluate_log
@@ -188,6 +190,10 @@ int ptm_max_swaps_per_step(ptm_engine* e);
  * beta*llike); HC = history_rungs * n_walkers.  Saved row s is in slot s % history_capacity; row 0 is the initial state
  * and a chain has saved Nsize rows (PTM_ARR_NSIZE).  Any output pointer may be NULL. */
 int ptm_get_history(ptm_engine* e, double* X, double* llike, double* lprior, int32_t* meta);
+/* MAP of the tracked rungs (ptm_config.map_rungs): chain (local rung r, walker w) at index r*W + w: X[index*dim ..], its
+ * log-posterior at the rung's temperature (MH_chain::getMAPlpost / getMAPstate, chain.hh:116-117), llike, lprior.
+ * lpost is -1e200 while no valid state was seen.  Any output pointer may be NULL. */
+int ptm_get_map(ptm_engine* e, double* X, double* lpost, double* llike, double* lprior);
 uint64_t ptm_step_count(ptm_engine* e);
 
 /* ---- measurement ---------------------------------------------------------------------------------------- */

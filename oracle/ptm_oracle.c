@@ -454,13 +454,16 @@ ptmo_pt* ptmo_pt_create(int D, int Nt, int W, const double* beta, double swap_ra
   s->last_pairs = (int*)calloc((size_t)W * s->maxswaps, sizeof(int));
   s->last_accept = (int*)calloc((size_t)W * s->maxswaps, sizeof(int));
   s->touched = (uint8_t*)calloc(N, 1);
+  s->map_lpost = (double*)malloc(N * sizeof(double));
+  s->map_x = (double*)calloc(N * D, sizeof(double));
+  for (size_t c = 0; c < N; c++) s->map_lpost[c] = -1e200;        /* chain.hh:69 */
   return s;
 }
 void ptmo_pt_free(ptmo_pt* s) {
   if (!s) return;
   free(s->beta); free(s->x); free(s->llike); free(s->lprior); free(s->ntries); free(s->naccept); free(s->last_type);
   free(s->nhist); free(s->nsize); free(s->swap_count); free(s->swap_accept_count); free(s->last_pairs); free(s->last_accept);
-  free(s->touched);
+  free(s->touched); free(s->map_lpost); free(s->map_x);
   free(s->hist_x); free(s->hist_ll); free(s->hist_lp); free(s->hist_nacc); free(s->hist_ntry); free(s->hist_type);
   free(s);
 }
@@ -481,7 +484,16 @@ static void hist_push(ptmo_pt* s, size_t c, int64_t row) {
 }
 
 /* MH_chain::add_state bookkeeping (chain.cc:935-947) */
+/* the MAP update of add_state (chain.cc:931-934) for the state chain c holds now, at its own temperature */
+static void map_update(ptmo_pt* s, size_t c) {
+  double lpost = ptmo_lpost(s->lprior[c], s->beta[c % s->Nt], s->llike[c]);
+  if (lpost > s->map_lpost[c]) {
+    s->map_lpost[c] = lpost;
+    memcpy(s->map_x + c * s->D, s->x + c * s->D, s->D * sizeof(double));
+  }
+}
 static inline void add_state_count(ptmo_pt* s, size_t c) {
+  map_update(s, c);
   if (s->nhist[c] % s->add_every_N == 0) { hist_push(s, c, s->nsize[c]); s->nsize[c]++; }
   s->nhist[c]++;
 }
@@ -495,6 +507,8 @@ void ptmo_pt_set_states(ptmo_pt* s, const ptmo_problem* pb, const double* x, con
     s->lprior[c] = ptmo_lprior(pb, xc, valid);
     s->llike[c] = llike ? llike[c] : ptmo_llike(pb, xc);
     s->nhist[c] = 0; s->nsize[c] = 1;                     /* MH_chain::initialize(1): one row, Nhist reset (chain.cc:871-875) */
+    s->map_lpost[c] = -1e200;
+    map_update(s, c);
     hist_push(s, c, 0);
   }
 }
@@ -739,6 +753,8 @@ void ptmo_init_from_prior(ptmo_pt* s, const ptmo_problem* pb, uint64_t seed) {
       break;
     }
     s->nhist[c] = 0; s->nsize[c] = 1;
+    s->map_lpost[c] = -1e200;
+    map_update(s, c);
     hist_push(s, c, 0);
   }
 }

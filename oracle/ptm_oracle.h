@@ -101,6 +101,9 @@ typedef struct {
   double* hist_x;      /* [W*Nt][hist_cap][D] */
   double *hist_ll, *hist_lp;             /* [W*Nt][hist_cap] */
   int32_t *hist_nacc, *hist_ntry, *hist_type; /* [W*Nt][hist_cap] */
+  /* MAP tracking of MH_chain::add_state (chain.cc:931-934; MAPlpost starts at -1e200, chain.hh:69) */
+  double* map_lpost;   /* [W*Nt] */
+  double* map_x;       /* [W*Nt][D] */
 } ptmo_pt;
 
 /* ---- RNG: Philox4x32-10 (Salmon et al., SC'11; Random123) -------------------------------- */

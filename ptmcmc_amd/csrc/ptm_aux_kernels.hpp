@@ -49,8 +49,10 @@ struct Decide {
   int add_every_n;
   const unsigned int* nhist;
   const int *naccept, *ntries, *last_type;
+  MapT map;   // MAP tracking: the in-between row is a candidate too (its log-posterior at this rung's temperature)
 };
 constexpr int HIST_DST = -(1 << 30);   // move-list destination code: HIST_DST - c = "into chain c's history"
+constexpr int MAP_DST = -(1 << 29);    //                             MAP_DST - c  = "chain c's new MAP" (c < 2^29)
 
 // llike of global rung r for walker w, r inside the shard's window
 __device__ __forceinline__ double win_llike(const Decide& p, int r, int w) {
@@ -243,6 +245,17 @@ __global__ __launch_bounds__(DECIDE_THREADS) void decide_kernel(const Decide p) 
     if (s1 < p.r0 || s1 >= r1) { atomicOr(p.err, 16); return -1; }   // (the host keeps recorded rungs away from shard tops)
     return (s1 - p.r0) * p.W + w;
   };
+  // the same for MAP tracking: source slot of rung r's in-between row if its log-posterior at rung r's temperature
+  // beats the rung's MAP (the first of the two add_state calls sees it, chain.cc:931-934), else -1
+  auto map_mid_src = [&](int r) -> int {
+    if (r - p.r0 >= p.map.rungs || r < p.r0 || r >= r1) return -1;
+    if (!(r > 0 && PTM_ALIVE_RUNG(r - 1) && alive[first[r - 1]] == 1)) return -1;   // touched once only
+    const int s1 = mid[r];
+    if (s1 < p.r0 || s1 >= r1) { atomicOr(p.err, 16); return -1; }
+    const int cs = (s1 - p.r0) * p.W + w;
+    const double t = beta[r] * p.ll[cs];
+    return (p.lp[cs] + t > p.map.lpost[(r - p.r0) * p.W + w]) ? cs : -1;
+  };
   for (int j = lane; j < nl; j += DECIDE_THREADS) {
     const int k = list[j];
     if (alive[k] != 1) continue;
@@ -253,6 +266,13 @@ __global__ __launch_bounds__(DECIDE_THREADS) void decide_kernel(const Decide p) 
       if (hs >= 0) {
         const int m = atomicAdd(&cnt[1], 1);
         if (m < MVCAP) { gs[m] = hs; gd[m] = HIST_DST - ((i - p.r0) * p.W + w); }
+      }
+    }
+    if (p.map.rungs) {
+      const int ms_ = map_mid_src(i);
+      if (ms_ >= 0) {
+        const int m = atomicAdd(&cnt[1], 1);
+        if (m < MVCAP) { gs[m] = ms_; gd[m] = MAP_DST - ((i - p.r0) * p.W + w); }
       }
     }
     for (int r = i; r <= rtop; ++r) {
@@ -322,6 +342,8 @@ __global__ __launch_bounds__(DECIDE_THREADS) void decide_kernel(const Decide p) 
         else if (d <= HIST_DST) {
           const int c = HIST_DST - d;
           dstp = p.hist.x + hist_slot(p.hist, 1 + (long long)(p.nhist[c] / (unsigned int)p.add_every_n), c) * DPm;
+        } else if (d <= MAP_DST) {
+          dstp = p.map.x + (size_t)(MAP_DST - d) * DPm;
         } else { const int e = -d - 4; dstp = ((e & 1) ? p.send_down : p.send_up) + MSG_HDR + (size_t)(e >> 1) * RD; }
         *reinterpret_cast<d2_t*>(dstp + col) = v[q];
       }
@@ -333,6 +355,10 @@ __global__ __launch_bounds__(DECIDE_THREADS) void decide_kernel(const Decide p) 
         const int c = HIST_DST - d;
         const long long hrow = 1 + (long long)(p.nhist[c] / (unsigned int)p.add_every_n);
         hist_scalars(p.hist, hist_slot(p.hist, hrow, c), hrow, sl, sp, p.naccept[c], p.ntries[c], p.last_type[c]);
+      } else if (d <= MAP_DST) {
+        const int c = MAP_DST - d;
+        const double t = beta[p.r0 + c / p.W] * sl;
+        p.map.lpost[c] = sp + t; p.map.ll[c] = sl; p.map.lp[c] = sp;
       } else if (d != -3) {
         const int e = -d - 4;
         double* row = ((e & 1) ? p.send_down : p.send_up) + MSG_HDR + (size_t)(e >> 1) * RD;
@@ -357,6 +383,20 @@ __global__ __launch_bounds__(DECIDE_THREADS) void decide_kernel(const Decide p) 
       const size_t o = hist_slot(p.hist, hrow, c);
       for (int d = 0; d < DP; ++d) p.hist.x[o * DP + d] = p.x[(size_t)hs * DP + d];
       hist_scalars(p.hist, o, hrow, p.ll[hs], p.lp[hs], p.naccept[c], p.ntries[c], p.last_type[c]);
+    }
+    __syncthreads();
+  }
+  if (p.map.rungs) {
+    for (int j = lane; j < nl; j += DECIDE_THREADS) {
+      const int k = list[j];
+      if (alive[k] != 1) continue;
+      const int i = cand[k];
+      const int cs = map_mid_src(i);
+      if (cs < 0) continue;
+      const int c = (i - p.r0) * p.W + w;
+      const double t = beta[i] * p.ll[cs];
+      p.map.lpost[c] = p.lp[cs] + t; p.map.ll[c] = p.ll[cs]; p.map.lp[c] = p.lp[cs];
+      for (int d = 0; d < DP; ++d) p.map.x[(size_t)c * DP + d] = p.x[(size_t)cs * DP + d];
     }
     __syncthreads();
   }
@@ -437,6 +477,9 @@ struct Move {
   int add_every_n;
   const unsigned int* nhist;
   const int *naccept, *ntries, *last_type;
+  MapT map;                         // destination codes in (HIST_DST, MAP_DST]: the row is that chain's new MAP
+  const double* beta;
+  int r0;
 };
 template <int MV, int WPB, bool HIST>   // HIST: history destinations exist (compiled apart: the hot build carries none of it)
 __global__ __launch_bounds__(64 * WPB, MV > 64 ? 1 : 4) void move_kernel(const Move p) {
@@ -485,6 +528,7 @@ __global__ __launch_bounds__(64 * WPB, MV > 64 ? 1 : 4) void move_kernel(const M
     if (d != -3 && act) {
       double* dstp;
       if (d >= 0) dstp = p.x + (size_t)d * DP;
+      else if (HIST && d <= MAP_DST && d > HIST_DST) dstp = p.map.x + (size_t)(MAP_DST - d) * DP;
       else if (HIST && d <= HIST_DST) {
         const int c = HIST_DST - d;
         dstp = p.hist.x + hist_slot(p.hist, 1 + (long long)(p.nhist[c] / (unsigned int)p.add_every_n), c) * DP;
@@ -496,7 +540,11 @@ __global__ __launch_bounds__(64 * WPB, MV > 64 ? 1 : 4) void move_kernel(const M
   for (int q = 0; q < MV / 64; ++q) {
     const int d = s_dst[64 * q + lane];
     if (d >= 0) { p.ll[d] = sl[q]; p.lp[d] = sp[q]; }
-    else if (HIST && d <= HIST_DST) {
+    else if (HIST && d <= MAP_DST && d > HIST_DST) {
+      const int c = MAP_DST - d;
+      const double t = p.beta[p.r0 + c / p.W] * sl[q];
+      p.map.lpost[c] = sp[q] + t; p.map.ll[c] = sl[q]; p.map.lp[c] = sp[q];
+    } else if (HIST && d <= HIST_DST) {
       const int c = HIST_DST - d;
       const long long hrow = 1 + (long long)(p.nhist[c] / (unsigned int)p.add_every_n);
       hist_scalars(p.hist, hist_slot(p.hist, hrow, c), hrow, sl[q], sp[q], p.naccept[c], p.ntries[c], p.last_type[c]);
@@ -545,6 +593,16 @@ __global__ void hist_init_kernel(Hist h, int DP, const double* x, const double* 
   const size_t o = hist_slot(h, 0, c);
   for (int d = 0; d < DP; ++d) h.x[o * DP + d] = x[(size_t)c * DP + d];
   hist_scalars(h, o, 0, ll[c], lp[c], naccept[c], ntries[c], last_type[c]);
+}
+
+// MAP after initialize: the initial state, if its log-posterior beats -1e200 (chain.hh:69, chain.cc:931-934)
+__global__ void map_init_kernel(MapT m, int DP, int W, int r0, const double* beta, const double* x, const double* ll, const double* lp) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= m.MC) return;
+  m.lpost[c] = -1e200;
+  const double t = beta[r0 + c / W] * ll[c];
+  if (map_try(m, c, lp[c] + t, ll[c], lp[c]))
+    for (int d = 0; d < DP; ++d) m.x[(size_t)c * DP + d] = x[(size_t)c * DP + d];
 }
 
 // verification hooks

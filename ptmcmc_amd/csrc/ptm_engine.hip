@@ -50,6 +50,7 @@ struct ptm_engine {
   long long *swap_try = nullptr, *swap_acc = nullptr;
   unsigned char* touch = nullptr;
   Hist hist = {0, 0, 0, nullptr, nullptr, nullptr, nullptr};   // optional history ring (ptm_config.history_rungs)
+  MapT map = {0, 0, nullptr, nullptr, nullptr, nullptr};       // optional MAP tracking (ptm_config.map_rungs)
   int* swap_log = nullptr;   // [W][ms] candidate log of the last step
   int row_cap = 0;           // row slots per boundary message
   // device problem description
@@ -178,6 +179,16 @@ static int build_engine(ptm_engine* e, const ptm_config* cfg) {
       (rc = dalloc(&e->arr_above, (size_t)cfg->n_walkers)) || (rc = dalloc(&e->touch, Nc)) || (rc = dalloc(&e->nhist, Nc)) ||
       (rc = dalloc(&e->err, 4)))
     return rc;
+  if (cfg->map_rungs < 0 || cfg->map_rungs > cfg->rung_count) return fail(PTM_ERR_INVALID, "map_rungs out of range");
+  if (cfg->map_rungs > 0) {
+    if (cfg->map_rungs == cfg->rung_count && cfg->rung_begin + cfg->rung_count < cfg->n_rungs)
+      return fail(PTM_ERR_UNSUPPORTED, "the top rung of a shard below the ladder's top cannot be tracked: map_rungs < rung_count");
+    if ((double)cfg->map_rungs * cfg->n_walkers >= (double)(1 << 29)) return fail(PTM_ERR_INVALID, "too many MAP-tracked chains");
+    e->map.rungs = cfg->map_rungs; e->map.MC = cfg->map_rungs * cfg->n_walkers;
+    const size_t n = (size_t)e->map.MC;
+    if ((rc = dalloc(&e->map.lpost, n)) || (rc = dalloc(&e->map.ll, n)) || (rc = dalloc(&e->map.lp, n)) || (rc = dalloc(&e->map.x, n * D)))
+      return rc;
+  }
   if (e->hist.rungs) {
     const size_t n = (size_t)e->hist.cap * e->hist.HC;
     if ((rc = dalloc(&e->hist.x, n * D)) || (rc = dalloc(&e->hist.ll, n)) || (rc = dalloc(&e->hist.lp, n)) || (rc = dalloc(&e->hist.meta, n)))
@@ -224,7 +235,7 @@ extern "C" int ptm_engine_destroy(ptm_engine* e) {
   if (!e) return PTM_OK;
   (void)hipStreamSynchronize(e->stream);
   void* ptrs[] = {e->x, e->ll, e->lp, e->ntries, e->naccept, e->last_type, e->arr_below, e->arr_above, e->mv_src, e->mv_dst, e->mv_n,
-                  e->err, e->nhist, e->swap_try, e->swap_acc, e->touch, e->swap_log, e->hist.x, e->hist.ll, e->hist.lp, e->hist.meta, e->blo,
+                  e->err, e->nhist, e->swap_try, e->swap_acc, e->touch, e->swap_log, e->hist.x, e->hist.ll, e->hist.lp, e->hist.meta, e->map.lpost, e->map.ll, e->map.lp, e->map.x, e->blo,
                   e->bhi, e->ptype, e->bmin, e->bmax, e->plo, e->phi, e->pcoef, e->P2, e->mean, e->beta, e->prop, e->prop_tiles, e->P2_tiles, e->box_row, e->onedfrac, e->xprop, e->lprior_new, e->llike_new, e->gate};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -467,6 +478,7 @@ static Dev make_dev(ptm_engine* e) {
   p.ntries = e->ntries; p.naccept = e->naccept; p.last_type = e->last_type; p.nhist = e->nhist;
   p.touch = e->touch; p.err = e->err;
   p.hist = e->hist;
+  p.map = e->map;
   p.c_begin = 0; p.c_end = e->Nc;
   return p;
 }
@@ -552,6 +564,7 @@ static int launch_decide(ptm_engine* e, const double* ll_below, const double* ll
   p.mv_src = e->mv_src; p.mv_dst = e->mv_dst; p.mv_n = e->mv_n;
   p.hist = e->hist; p.add_every_n = e->cfg.add_every_n; p.nhist = e->nhist;
   p.naccept = e->naccept; p.ntries = e->ntries; p.last_type = e->last_type;
+  p.map = e->map;
   const int WN = e->nloc + (ll_below ? 1 : 0) + p.H;
   const size_t lds = decide_lds_bytes(e->Nt, e->ms, WN);
   if (lds > 160 * 1024) return fail(PTM_ERR_UNSUPPORTED, "ladder too long for the LDS-resident exchange kernel (%zu B)", lds);
@@ -572,9 +585,10 @@ static int launch_decide(ptm_engine* e, const double* ll_below, const double* ll
   m.mv_src = e->mv_src; m.mv_dst = e->mv_dst; m.mv_n = e->mv_n; m.err = e->err;
   m.hist = e->hist; m.add_every_n = e->cfg.add_every_n; m.nhist = e->nhist;
   m.naccept = e->naccept; m.ntries = e->ntries; m.last_type = e->last_type;
+  m.map = e->map; m.beta = e->beta; m.r0 = e->r0;
   // (64-thread form only) ladders whose list did not fit the decide block's registers: rare, the kernel exits at once
   // for everybody else
-  if (e->hist.rungs) hipLaunchKernelGGL((move_kernel<MVCAP, 1, true>), dim3(e->W), dim3(64), 0, e->stream, m);
+  if (e->hist.rungs || e->map.rungs) hipLaunchKernelGGL((move_kernel<MVCAP, 1, true>), dim3(e->W), dim3(64), 0, e->stream, m);
   else hipLaunchKernelGGL((move_kernel<MVCAP, 1, false>), dim3(e->W), dim3(64), 0, e->stream, m);
   HIPCHK(hipGetLastError());
   return PTM_OK;
@@ -613,6 +627,12 @@ static int reset_counters(ptm_engine* e) {
   HIPCHK(hipMemsetAsync(e->arr_below, 0xFF, (size_t)e->W * 4, e->stream));
   HIPCHK(hipMemsetAsync(e->arr_above, 0xFF, (size_t)e->W * 4, e->stream));
   e->step = 0;
+  if (e->map.rungs) {    // MAP = the initial state (MH_chain::initialize -> add_state)
+    if (!e->have_ladder) return fail(PTM_ERR_INVALID, "set the ladder before the states when tracking the MAP (ptm_set_ladder)");
+    hipLaunchKernelGGL(map_init_kernel, dim3((e->map.MC + 255) / 256), dim3(256), 0, e->stream, e->map, e->DP, e->W, e->r0, e->beta, e->x, e->ll,
+                       e->lp);
+    HIPCHK(hipGetLastError());
+  }
   if (e->hist.rungs) {   // history row 0 = the initial state (chain.cc:871-875)
     HIPCHK(hipMemsetAsync(e->hist.meta, 0xFF, (size_t)e->hist.cap * e->hist.HC * sizeof(int4), e->stream));
     hipLaunchKernelGGL(hist_init_kernel, dim3((e->hist.HC + 255) / 256), dim3(256), 0, e->stream, e->hist, e->DP, e->x, e->ll, e->lp,
@@ -905,12 +925,28 @@ extern "C" int ptm_get_last_swaps(ptm_engine* e, int32_t* pairs, int32_t* accept
   return PTM_OK;
 }
 
+extern "C" int ptm_get_map(ptm_engine* e, double* X, double* lpost, double* llike, double* lprior) {
+  if (!e) return fail(PTM_ERR_INVALID, "null engine");
+  if (!e->map.rungs) return fail(PTM_ERR_INVALID, "MAP tracking is off (ptm_config.map_rungs)");
+  const size_t n = (size_t)e->map.MC, D = e->D, DP = e->DP;
+  HIPCHK(hipStreamSynchronize(e->stream));
+  if (X) {
+    std::vector<double> rows(n * DP);
+    HIPCHK(hipMemcpy(rows.data(), e->map.x, n * DP * 8, hipMemcpyDeviceToHost));
+    unpad_rows(rows, n, D, DP, X);
+  }
+  if (lpost) HIPCHK(hipMemcpy(lpost, e->map.lpost, n * 8, hipMemcpyDeviceToHost));
+  if (llike) HIPCHK(hipMemcpy(llike, e->map.ll, n * 8, hipMemcpyDeviceToHost));
+  if (lprior) HIPCHK(hipMemcpy(lprior, e->map.lp, n * 8, hipMemcpyDeviceToHost));
+  return PTM_OK;
+}
+
 extern "C" int ptm_restore(ptm_engine* e, const double* X, const double* llike, const int32_t* ntries, const int32_t* naccept,
                            const int32_t* last_type, const int64_t* nhist, uint64_t step_count, const int64_t* swap_tries,
                            const int64_t* swap_accepts) {
   if (!e || !X || !llike || !ntries || !naccept || !last_type || !nhist) return fail(PTM_ERR_INVALID, "null argument");
-  if (e->hist.rungs)
-    return fail(PTM_ERR_UNSUPPORTED, "restoring into an engine that keeps a history ring is not built yet (read the ring out with the checkpoint)");
+  if (e->hist.rungs || e->map.rungs)
+    return fail(PTM_ERR_UNSUPPORTED, "restoring into an engine that keeps a history ring or a MAP is not built yet (read them out with the checkpoint)");
   int rc = ptm_set_states(e, X, llike);   // enforces (a no-op on saved states), recomputes lprior, resets counters
   if (rc) return rc;
   const size_t Nc = e->Nc;
@@ -984,7 +1020,7 @@ extern "C" const char* ptm_sweep_kernel_name(ptm_engine* e) {
   char b[96];
   const SweepSel s = sweep_sel(e);
   if (e->DP == 32 && s.uni && !s.callback)
-    snprintf(b, sizeof b, "sweep_mfma32_kernel<%d, %s, %d>", s.kind == KIND_DIAG ? KIND_LOWER : s.kind, e->hist.rungs ? "true" : "false",
+    snprintf(b, sizeof b, "sweep_mfma32_kernel<%d, %s, %d>", s.kind == KIND_DIAG ? KIND_LOWER : s.kind, (e->hist.rungs || e->map.rungs) ? "true" : "false",
              s.simple ? 0 : ((e->all_uniform && (!e->has_bounds || e->bounds_box)) ? 1 : 2));
   else snprintf(b, sizeof b, "sweep_kernel<%d, %d, %s, %s>", e->DP, s.kind, s.uni ? "true" : "false", s.simple ? "true" : "false");
   e->kname = b;

@@ -59,10 +59,25 @@ __device__ __forceinline__ void hist_scalars(const Hist& h, size_t o, long long 
   h.meta[o] = make_int4(nacc, ntry, type, (int)row);
 }
 
+// Optional MAP tracking of the first `rungs` local rungs: MH_chain::add_state keeps the state of the largest log-posterior
+// it was ever called with (chain.cc:931-934; MAPlpost starts at -1e200, chain.hh:69; the ladder's MAP is the cold
+// rung's, chain.cc:1570-1571).  lpost [MC], llike / lprior [MC], x [MC][DP] (row layout), MC = rungs * W.
+struct MapT {
+  int rungs, MC;
+  double *lpost, *ll, *lp, *x;
+};
+// records the candidate's scalars if it beats the stored MAP; the caller then copies the row
+__device__ __forceinline__ bool map_try(const MapT& m, int c, double lpost, double ll, double lp) {
+  if (!(lpost > m.lpost[c])) return false;
+  m.lpost[c] = lpost; m.ll[c] = ll; m.lp[c] = lp;
+  return true;
+}
+
 struct Dev {
   int D, DP, Nt, r0, nloc, W, Nc;
   int c_begin, c_end;   // chains [c_begin, c_end) are swept by this launch (whole rungs; the full range is [0, Nc))
   Hist hist;
+  MapT map;
   uint64_t seed, step;
   int add_every_n;
   double min_prior;
@@ -409,6 +424,12 @@ __global__ __launch_bounds__(256, PTM_SWEEP_WAVES) void sweep_kernel(const Dev p
       for (int d = 0; d < DP; ++d) p.hist.x[o * DP + d] = p.x[(size_t)c * DP + d];
       hist_scalars(p.hist, o, row, p.ll[c], p.lp[c], p.naccept[c], p.ntries[c], p.last_type[c]);
     }
+    if (rl < p.map.rungs) {   // MAP: the row the last add saw, at this rung's temperature
+      const double tl = p.ll[c], tp = p.lp[c];
+      const double tb = as_c(p.beta)[rg] * tl;
+      if (map_try(p.map, c, tp + tb, tl, tp))
+        for (int d = 0; d < DP; ++d) p.map.x[(size_t)c * DP + d] = p.x[(size_t)c * DP + d];
+    }
   }
   // ---- MH_chain::step for the untouched rungs; touched lanes idle through the draw loops
   const uint32_t stream = (uint32_t)w * (uint32_t)p.Nt + (uint32_t)rg;
@@ -533,6 +554,10 @@ __global__ __launch_bounds__(256, PTM_SWEEP_WAVES) void sweep_kernel(const Dev p
       for (int d = 0; d < DP; ++d) p.hist.x[o * DP + d] = row[d];
       hist_scalars(p.hist, o, hrow, ll, lp, p.naccept[c], ntries1, p.last_type[c]);
     }
+  }
+  if (accept && rl < p.map.rungs && map_try(p.map, c, newlpost, newlike, newlprior)) {   // MAP (chain.cc:931-934)
+#pragma unroll
+    for (int d = 0; d < DP; ++d) p.map.x[(size_t)c * DP + row_pos<DP>(d)] = xn[d];
   }
   if (accept) {
     p.naccept[c] += 1;

@@ -299,7 +299,9 @@ __global__ __launch_bounds__(256, PTM_MFMA_WAVES) void sweep_mfma32_kernel(const
     //      (chain.cc:973-1019, 916-949)
     bool accept = false;
     int hrow = -1;   // >= 0: this add_state call saves a history row (chain.cc:935-946), the ring row index
+    bool mapw = false;   // this add_state call sets a new MAP (chain.cc:931-934): the row is copied below
     const bool hist_on = HIST && rl < p.hist.rungs;
+    const bool map_on = HIST && rl < p.map.rungs;
     if ((q >> 1) == gp) {
       const double* mine = red + ((q & 1) * 4) * 16 + j;
       const double quad = ((mine[0] + mine[16]) + mine[32]) + mine[48];
@@ -312,6 +314,7 @@ __global__ __launch_bounds__(256, PTM_MFMA_WAVES) void sweep_mfma32_kernel(const
           hrow = 1 + (int)(a / (unsigned int)p.add_every_n);
           hist_scalars(p.hist, hist_slot(p.hist, hrow, c), hrow, ll, lp, naccept0, ntries0, p.last_type[c]);
         }
+        if (map_on) { const double tb = beta * ll; mapw = map_try(p.map, c, lp + tb, ll, lp); }
       } else {
         const double bl = beta * ll;
         const double cur_lpost = lp + bl;
@@ -341,6 +344,7 @@ __global__ __launch_bounds__(256, PTM_MFMA_WAVES) void sweep_mfma32_kernel(const
           if (accept) hist_scalars(p.hist, o, hrow, newlike, newlprior, naccept0 + 1, ntries0 + 1, type);
           else hist_scalars(p.hist, o, hrow, ll, lp, naccept0, ntries0 + 1, p.last_type[c]);
         }
+        if (map_on && accept) mapw = map_try(p.map, c, newlpost, newlike, newlprior);
         if (accept) {
           p.naccept[c] = naccept0 + 1;
           p.last_type[c] = type;
@@ -370,6 +374,21 @@ __global__ __launch_bounds__(256, PTM_MFMA_WAVES) void sweep_mfma32_kernel(const
           if ((rec_bits >> (16 * gg + j)) & 1ull) {
             const int cg = c0 + src_lane;
             mf_d2* dst = reinterpret_cast<mf_d2*>(p.hist.x + hist_slot(p.hist, hr, cg) * DP) + q;
+            const bool took = (acc_bits >> (16 * gg + j)) & 1ull;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) dst[4 * t] = took ? mf_d2{xp[gg][2 * t], xp[gg][2 * t + 1]} : rowp[gg][4 * t];
+          }
+        }
+      }
+    }
+    if (map_on) {   // the new MAP's row: the proposal if it was accepted, else (an exchanged rung) the row in memory
+      const uint64_t mb = __builtin_amdgcn_ballot_w64(mapw) >> (32 * gp);
+      if (mb & 0xFFFFFFFFull) {
+#pragma unroll
+        for (int gg = 0; gg < 2; ++gg) {
+          if ((mb >> (16 * gg + j)) & 1ull) {
+            const int cg = c0 + 32 * gp + 16 * gg + j;
+            mf_d2* dst = reinterpret_cast<mf_d2*>(p.map.x + (size_t)cg * DP) + q;
             const bool took = (acc_bits >> (16 * gg + j)) & 1ull;
 #pragma unroll
             for (int t = 0; t < 4; ++t) dst[4 * t] = took ? mf_d2{xp[gg][2 * t], xp[gg][2 * t + 1]} : rowp[gg][4 * t];

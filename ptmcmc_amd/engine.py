@@ -25,7 +25,7 @@ EXPORTS = [
     "ptm_set_bounds", "ptm_set_prior", "ptm_set_target_gaussian", "ptm_set_target_callback", "ptm_set_ladder",
     "ptm_set_proposals", "ptm_set_states", "ptm_init_from_prior", "ptm_sweep", "ptm_step", "ptm_sync",
     "ptm_copy_llike", "ptm_llike_device_ptr", "ptm_exchange_decide", "ptm_exchange_finish_and_sweep", "ptm_exchange_install", "ptm_sweep_rungs", "ptm_exchange_buffer_doubles", "ptm_exchange_row_capacity", "ptm_get_states",
-    "ptm_get_array", "ptm_get_swap_counts", "ptm_get_last_swaps", "ptm_max_swaps_per_step", "ptm_get_history", "ptm_restore", "ptm_step_count",
+    "ptm_get_array", "ptm_get_swap_counts", "ptm_get_last_swaps", "ptm_max_swaps_per_step", "ptm_get_history", "ptm_get_map", "ptm_restore", "ptm_step_count",
     "ptm_timer_start", "ptm_timer_stop", "ptm_get_kernel_times", "ptm_sweep_kernel_name", "ptm_debug_eval",
     "ptm_debug_philox", "ptm_debug_boxmuller", "ptm_debug_sqrt_scan", "ptm_debug_evaluate",
     "ptm_dev_alloc", "ptm_dev_free", "ptm_dev_copy",
@@ -37,7 +37,7 @@ class PtmConfig(C.Structure):
                 ("rung_count", C.c_int32), ("n_walkers", C.c_int32), ("seed", C.c_uint64), ("swap_rate", C.c_double),
                 ("add_every_n", C.c_int32), ("min_prior", C.c_double), ("device", C.c_int32), ("stream", C.c_void_p),
                 ("time_kernels", C.c_int32), ("swap_log_steps", C.c_int32), ("exchange_row_capacity", C.c_int32), ("history_rungs", C.c_int32),
-                ("history_capacity", C.c_int32)]
+                ("history_capacity", C.c_int32), ("map_rungs", C.c_int32)]
 
 
 class PtmError(RuntimeError):
@@ -102,6 +102,7 @@ def load():
     L.ptm_exchange_buffer_doubles.argtypes = [C.c_void_p]
     L.ptm_exchange_row_capacity.argtypes = [C.c_void_p]
     L.ptm_get_history.argtypes = [C.c_void_p, _dp, _dp, _dp, _i32p]
+    L.ptm_get_map.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp]
     L.ptm_restore.argtypes = [C.c_void_p, _dp, _dp, _i32p, _i32p, _i32p, C.POINTER(C.c_int64), C.c_uint64, C.POINTER(C.c_int64),
                               C.POINTER(C.c_int64)]
     L.ptm_debug_sqrt_scan.argtypes = [C.c_int, C.POINTER(C.c_uint64)]
@@ -194,7 +195,7 @@ class Engine:
 
     def __init__(self, dim, n_rungs, n_walkers=1, seed=0x5EED0001, swap_rate=0.1, add_every_n=1, min_prior=-30.0,
                  rung_begin=0, rung_count=None, device=-1, stream=None, time_kernels=False, exchange_row_capacity=0, history_rungs=0,
-                 history_capacity=0):
+                 history_capacity=0, map_rungs=0):
         L = load()
         cfg = PtmConfig()
         cfg.struct_size = C.sizeof(PtmConfig)
@@ -208,6 +209,8 @@ class Engine:
         cfg.exchange_row_capacity = exchange_row_capacity
         cfg.history_rungs, cfg.history_capacity = history_rungs, history_capacity
         self.hist_rungs, self.hist_cap = history_rungs, history_capacity
+        cfg.map_rungs = map_rungs
+        self.map_rungs = map_rungs
         h = C.c_void_p()
         _chk(L.ptm_engine_create(C.byref(cfg), C.byref(h)))
         self.h, self.L = h, L
@@ -305,6 +308,13 @@ class Engine:
     @property
     def exchange_buffer_doubles(self):
         return self.L.ptm_exchange_buffer_doubles(self.h)
+
+    def map(self):
+        """MAP of the tracked rungs: dict x [map_rungs*W][D], lpost, llike, lprior [map_rungs*W]"""
+        n = self.map_rungs * self.W
+        X = np.empty((n, self.D)); lpo = np.empty(n); ll = np.empty(n); lp = np.empty(n)
+        _chk(self.L.ptm_get_map(self.h, X.ctypes.data_as(_dp), lpo.ctypes.data_as(_dp), ll.ctypes.data_as(_dp), lp.ctypes.data_as(_dp)))
+        return dict(x=X, lpost=lpo, llike=ll, lprior=lp)
 
     def checkpoint(self):
         """everything the run's future depends on (ptm_restore)"""

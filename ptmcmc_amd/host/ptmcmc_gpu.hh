@@ -391,6 +391,8 @@ class chain {  // chain.hh:34-141 (the part of the interface the driver uses)
   virtual int multiplicity() { return 1; }
   virtual chain* subchain(int index) { return this; }
   virtual int getStep() = 0;
+  virtual double getMAPlpost() { return -1e200; }                    // chain.hh:116-117
+  virtual state getMAPstate() { return getState(); }
   virtual std::string status() { return ""; }
 };
 
@@ -447,9 +449,19 @@ class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:
     double getLogLike(int = -1, bool = false) override { p->refresh(); return p->llike[at()]; }
     double invTemp() override { return 1 / p->temps[i]; }
     int getStep() override { return p->nstep; }
+    double getMAPlpost() override { p->refresh_map(); return p->mlpost[at()]; }
+    state getMAPstate() override { p->refresh_map(); return state(p->sp, std::vector<double>(p->mX.begin() + at() * p->dim, p->mX.begin() + (at() + 1) * p->dim)); }
   };
   std::vector<rung_view> views;
 
+  std::vector<double> mX, mlpost;   // host copy of the MAP states (chain.cc:931-934), all rungs / replicas
+  bool map_fresh = false;
+  void refresh_map() {
+    if (map_fresh) return;
+    mX.resize((size_t)Ntemps * W * dim); mlpost.resize((size_t)Ntemps * W);
+    ptm_check(ptm_get_map(eng, mX.data(), mlpost.data(), nullptr, nullptr), "parallel_tempering_chains");
+    map_fresh = true;
+  }
   void refresh() {
     if (fresh) return;
     ptm_check(ptm_get_states(eng, X.data()), "parallel_tempering_chains");
@@ -516,7 +528,7 @@ class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:
     cfg.struct_size = sizeof cfg;
     cfg.dim = dim; cfg.n_rungs = Ntemps; cfg.rung_begin = 0; cfg.rung_count = Ntemps; cfg.n_walkers = W; cfg.seed = seed;
     cfg.swap_rate = swap_rate; cfg.add_every_n = add_every_N; cfg.min_prior = dpriormin; cfg.device = -1; cfg.stream = nullptr;
-    cfg.time_kernels = 0; cfg.swap_log_steps = 0; cfg.exchange_row_capacity = 0; cfg.history_rungs = hist_rows > 0 ? Ntemps : 0; cfg.history_capacity = hist_rows;
+    cfg.time_kernels = 0; cfg.swap_log_steps = 0; cfg.exchange_row_capacity = 0; cfg.history_rungs = hist_rows > 0 ? Ntemps : 0; cfg.history_capacity = hist_rows; cfg.map_rungs = Ntemps;
     ptm_check(ptm_engine_create(&cfg, &eng), "parallel_tempering_chains::initialize");
     std::vector<int> lo(dim), hi(dim), types;
     std::vector<double> xmin(dim), xmax(dim), centers, halfwidths;
@@ -573,15 +585,17 @@ class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:
   void step() override {
     ptm_check(ptm_step(eng, 1), "parallel_tempering_chains::step");
     nstep++;
-    fresh = hist_fresh = false;
+    fresh = hist_fresh = map_fresh = false;
     if (tracking) replay_step();
   }
   void step(int n) {
     if (tracking) { for (int k = 0; k < n; k++) step(); return; }
     ptm_check(ptm_step(eng, n), "parallel_tempering_chains::step");
     nstep += n;
-    fresh = hist_fresh = false;
+    fresh = hist_fresh = map_fresh = false;
   }
+  double getMAPlpost() override { return views[0].getMAPlpost(); }   // the cold rung's (chain.cc:1570-1571)
+  state getMAPstate() override { return views[0].getMAPstate(); }
   state getState(int = -1, bool = false) override { return views[0].getState(); }
   double getLogPost(int = -1, bool = false) override { return views[0].getLogPost(); }
   double getLogLike(int = -1, bool = false) override { return views[0].getLogLike(); }

@@ -67,7 +67,7 @@ class EngineShard:
 
     @property
     def can_overlap(self):
-        return self.e.hist_rungs == 0     # (a recorded exchanged rung reads its final row: needs the arrivals first)
+        return self.e.hist_rungs == 0 and self.e.map_rungs == 0   # (a recorded exchanged rung reads its final row: needs the arrivals first)
 
     def sync(self):
         self.e.sync()

@@ -52,7 +52,8 @@ class _PT(C.Structure):
                 ("swap_count", C.POINTER(C.c_int64)), ("swap_accept_count", C.POINTER(C.c_int64)),
                 ("last_pairs", _ip), ("last_accept", _ip), ("touched", C.POINTER(C.c_uint8)),
                 ("hist_cap", C.c_int), ("hist_x", _dp), ("hist_ll", _dp), ("hist_lp", _dp),
-                ("hist_nacc", C.POINTER(C.c_int32)), ("hist_ntry", C.POINTER(C.c_int32)), ("hist_type", C.POINTER(C.c_int32))]
+                ("hist_nacc", C.POINTER(C.c_int32)), ("hist_ntry", C.POINTER(C.c_int32)), ("hist_type", C.POINTER(C.c_int32)),
+                ("map_lpost", _dp), ("map_x", _dp)]
 
 
 _lib = None
@@ -293,6 +294,14 @@ class Ladder:
     @property
     def last_type(self):
         return self._arr(self.s.contents.last_type, (self.N,), np.int64)
+
+    @property
+    def map_lpost(self):
+        return self._arr(self.s.contents.map_lpost, (self.N,), np.float64)
+
+    @property
+    def map_x(self):
+        return self._arr(self.s.contents.map_x, (self.N, self.D), np.float64)
 
     def enable_history(self, rows_per_chain):
         lib().ptmo_pt_enable_history(self.s, rows_per_chain)

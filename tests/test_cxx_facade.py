@@ -62,6 +62,8 @@ def test_facade_writes_the_cold_chain_file_from_the_device_history():
         r = subprocess.run([exe, "device", "4", "8", "4000", out], capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stdout + r.stderr
         assert "instances are a permutation of the rungs" in r.stdout and " 0 displaced" not in r.stdout
+        mp = [l for l in r.stdout.splitlines() if l.startswith("MAP lpost=")][0]
+        assert float(mp.split("MAP lpost=")[1].split()[0]) >= float(mp.split("lpost now ")[1].rstrip(")"))
         ts = [l.split() for l in open(out + ".tempstats").read().splitlines() if l and not l.startswith("#")]
         assert len(ts) == 8 and float(ts[0][1]) == 1.0 and float(ts[7][1]) == 0.0
         assert all(0.0 <= float(t[1]) <= 1.0 for t in ts) and all(0.0 < float(t[2].rstrip(":")) <= 1.0 for t in ts[:7])

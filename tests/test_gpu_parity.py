@@ -218,7 +218,7 @@ def test_history_rows_match_the_oracle(D, Nt, W, kind, N, sr):
     from ptmcmc_amd.problems import GaussianProblem
     steps, cap = (10 if Nt > 100 else 24), 64
     pr = GaussianProblem(D, Nt, 1e3)
-    eng = E.Engine(D, Nt, W, swap_rate=sr, add_every_n=N, history_rungs=Nt, history_capacity=cap)
+    eng = E.Engine(D, Nt, W, swap_rate=sr, add_every_n=N, history_rungs=Nt, history_capacity=cap, map_rungs=Nt)
     fac = pr.configure(eng, kind)
     eng.init_from_prior()
     x0 = eng.states()
@@ -245,6 +245,11 @@ def test_history_rows_match_the_oracle(D, Nt, W, kind, N, sr):
             want = PU.to_engine_order(b[:, s_], Nt, W)[have]
             assert np.array_equal(got, want), (name, s_, np.argwhere(got != want)[:3].tolist())
     assert np.array_equal(he["row"][0], np.zeros(Nt * W))
+    # MAP tracking (chain.cc:931-934), every rung: the in-between rows of twice-exchanged rungs are candidates too
+    m = eng.map()
+    assert np.array_equal(m["lpost"], PU.to_engine_order(lad.map_lpost, Nt, W))
+    assert np.array_equal(m["x"], PU.to_engine_order(lad.map_x, Nt, W))
+    assert np.all(m["lpost"] >= eng.lpost)
     eng.close()
 
 
