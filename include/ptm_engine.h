@@ -109,6 +109,10 @@ int ptm_set_ladder(ptm_engine* e, const double* beta);
  * one_d_frac[rung_count] (gaussian_prop oneDfrac) may be NULL (= 0).  One clone per rung as
  * parallel_tempering_chains::set_proposal does (chain.cc:1367-1386). */
 int ptm_set_proposals(ptm_engine* e, int kind, const double* factors, const double* one_d_frac);
+/* Replace ONE rung's factor between steps (same kind and layout as given to ptm_set_proposals; one_d_frac < 0 keeps the
+ * rung's value): the engine side of user_gaussian_prop::check_update / reset_dist (proposal_distribution.cc:406-441,
+ * 340-403), whose user callback hands a chain a new covariance during the run. */
+int ptm_set_proposal_rung(ptm_engine* e, int local_rung, const double* factor, double one_d_frac);
 
 /* ---- state ------------------------------------------------------------------------------------------ */
 /* X[n_local_chains][D]; llike may be NULL (the device target evaluates it).  Resets counters the way

@@ -462,6 +462,48 @@ extern "C" int ptm_set_proposals(ptm_engine* e, int kind, const double* factors,
   return PTM_OK;
 }
 
+// One rung's factor replaced between steps -- what user_gaussian_prop::check_update achieves in the reference when its
+// callback returns a new covariance for a chain (proposal_distribution.cc:406-441, reset_dist :340-403).  Same kind and
+// storage as the factors set by ptm_set_proposals; one_d_frac < 0 keeps the rung's current value.
+extern "C" int ptm_set_proposal_rung(ptm_engine* e, int local_rung, const double* factor, double one_d_frac) {
+  if (!e || !factor) return fail(PTM_ERR_INVALID, "null argument");
+  if (!e->have_prop) return fail(PTM_ERR_INVALID, "set all proposals first (ptm_set_proposals)");
+  if (local_rung < 0 || local_rung >= e->nloc) return fail(PTM_ERR_INVALID, "rung out of the shard");
+  const int D = e->D, DP = e->DP, kind = e->prop_kind == KIND_DIAG ? PTM_PROP_DIAG : (e->prop_kind == KIND_LOWER ? PTM_PROP_LOWER : PTM_PROP_DENSE);
+  std::vector<double> packed((size_t)e->prop_stride, 0.0);
+  if (kind == PTM_PROP_DIAG) {
+    for (int d = 0; d < D; ++d) packed[d] = factor[d];
+  } else {
+    for (int i = 0; i < D; ++i)
+      for (int j = 0; j < D; ++j) {
+        if (kind == PTM_PROP_LOWER && j > i && factor[(size_t)i * D + j] != 0.0)
+          return fail(PTM_ERR_INVALID, "PTM_PROP_LOWER factor has a non-zero above the diagonal");
+        packed[(size_t)j * DP + i] = factor[(size_t)i * D + j];
+      }
+  }
+  int rc;
+  if ((rc = upload(e->prop + (size_t)local_rung * e->prop_stride, packed.data(), packed.size(), e->stream))) return rc;
+  if (DP == 32) {
+    std::vector<double> tiles(16 * 64, 0.0);
+    for (int t = 0; t < 16; ++t) {
+      const int rt = t & 1, sl = (t >> 1) & 3, hb = t >> 3;
+      for (int k = 0; k < 4; ++k)
+        for (int i = 0; i < 16; ++i) {
+          const int row = 16 * rt + i, col = 16 * hb + 4 * k + sl;
+          if (row < D && col < D)
+            tiles[(size_t)t * 64 + 16 * k + i] = kind == PTM_PROP_DIAG ? (row == col ? factor[row] : 0.0) : factor[(size_t)row * D + col];
+        }
+    }
+    if ((rc = upload(e->prop_tiles + (size_t)local_rung * 16 * 64, tiles.data(), tiles.size(), e->stream))) return rc;
+  }
+  if (one_d_frac >= 0) {
+    if (one_d_frac > 1) return fail(PTM_ERR_INVALID, "oneDfrac must be in [0,1]");
+    if ((rc = upload(e->onedfrac + local_rung, &one_d_frac, 1, e->stream))) return rc;
+    if (one_d_frac > 0) e->any_oned = 1;
+  }
+  return PTM_OK;
+}
+
 // ---- kernel argument block ----------------------------------------------------------------------------------
 static Dev make_dev(ptm_engine* e) {
   Dev p;

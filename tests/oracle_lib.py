@@ -230,6 +230,7 @@ class Ladder:
     def set_proposals(self, props):
         arr = (_Proposal * self.Nt)()
         self._keep = []
+        self._prop_specs = [tuple(p) for p in props]
         for r, (kind, M, f) in enumerate(props):
             M = np.ascontiguousarray(M, dtype=np.float64)
             self._keep.append(M)

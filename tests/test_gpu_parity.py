@@ -319,6 +319,30 @@ def test_checkpoint_and_resume_continue_bit_for_bit(D, Nt, W, kind):
     a.close(); b.close()
 
 
+@pytest.mark.parametrize("D,W,kind", [(32, 64, E.PROP_LOWER), (6, 5, E.PROP_DENSE), (16, 64, E.PROP_DIAG)])
+def test_one_rung_gets_a_new_proposal_factor_mid_run(D, W, kind):
+    """ptm_set_proposal_rung: what user_gaussian_prop::check_update does for one chain (proposal_distribution.cc:406-441);
+    the run continues bit-identical to an oracle whose rung got the same new factor."""
+    Nt = 7
+    pr, eng, lad = PU.make_pair(D, Nt, W, 1e3, kind=kind, swap_rate=0.3)
+    fac = pr.proposal_factors() if kind != E.PROP_DIAG else None
+    eng.step(6); eng.sync(); lad.pt_step(6)
+    rng = np.random.default_rng(3)
+    if kind == E.PROP_DIAG:
+        new = rng.uniform(0.05, 0.3, D)
+    elif kind == E.PROP_LOWER:
+        new = np.tril(rng.normal(size=(D, D)) * 0.05) + np.eye(D) * 0.2
+    else:
+        new = rng.normal(size=(D, D)) * 0.05 + np.eye(D) * 0.2
+    eng.set_proposal_rung(3, new)
+    props = lad._prop_specs
+    props[3] = (PU.KIND_TO_ORACLE[kind], new, props[3][2])
+    lad.set_proposals(props)
+    eng.step(9); eng.sync(); lad.pt_step(9)
+    PU.assert_same_state(eng, lad, "after the factor change")
+    eng.close()
+
+
 def test_bounds_and_mixed_prior_path_bit_exact():
     """wrap / limit / reflect boundaries and a gaussian+log+uniform+polar+copolar prior on the device path."""
     D, Nt, W = 5, 6, 64
