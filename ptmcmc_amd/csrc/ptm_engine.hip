@@ -123,7 +123,8 @@ static int build_engine(ptm_engine* e, const ptm_config* cfg);
 extern "C" int ptm_engine_create(const ptm_config* cfg, ptm_engine** out) {
   if (!cfg || !out) return fail(PTM_ERR_INVALID, "null argument");
   if (cfg->struct_size != sizeof(ptm_config)) return fail(PTM_ERR_INVALID, "ptm_config size mismatch (ABI)");
-  if (cfg->dim < 1 || cfg->dim > 64) return fail(PTM_ERR_INVALID, "dim must be in 1..64");
+  if (cfg->dim < 1) return fail(PTM_ERR_INVALID, "dim must be >= 1");
+  if (cfg->dim > 32) return fail(PTM_ERR_UNSUPPORTED, "dim > 32 is not built (kernels exist for padded dimensions 4, 8, 16, 32)");
   if (cfg->n_rungs < 1 || cfg->n_rungs > 65535) return fail(PTM_ERR_INVALID, "n_rungs must be in 1..65535");
   if (cfg->rung_begin < 0 || cfg->rung_count < 1 || cfg->rung_begin + cfg->rung_count > cfg->n_rungs)
     return fail(PTM_ERR_INVALID, "rung block out of range");
