@@ -19,8 +19,21 @@ int main(int argc, char** argv) {
   std::vector<std::string> types(D, "uni");
   std::vector<double> centers(D, 0.0), scales(D, 20.0);
   like.basic_setup(&space, types, centers, scales);
-  std::vector<double> sig(D, 1.0);
-  gaussian_prop prop(sig, 0.2);
+  // the sampler's default Gaussian recipe (ptmcmc.cc:117-139): six diagonal Gaussians a factor 4 apart in scale with
+  // doubling shares, each with 20 % one-dimensional moves; here without the differential-evolution part
+  std::vector<proposal_distribution*> gset;
+  std::vector<double> gshares;
+  double fac = std::pow(2.0 / 4.0, 4.0), share = 1;
+  for (int i = 0; i < 6; i++) {
+    fac *= 4.0;
+    std::vector<double> sig(D);
+    for (int d = 0; d < D; d++) sig[d] = scales[d] / 100.0 / fac * 400.0;
+    gset.push_back(new gaussian_prop(sig, 0.2));
+    share *= 2;
+    gshares.push_back(share);
+  }
+  proposal_distribution_set prop(gset, gshares);
+  for (auto g : gset) delete g;
   ptmcmc_sampler mcmc;
   mcmc.set("nsteps", "2000"); mcmc.set("pt", "6"); mcmc.set("pt_Tmax", "50"); mcmc.set("save_every", "2");
   mcmc.set("nevery", "500"); mcmc.set("nskip", "4"); mcmc.set("pt_dump_n", "2"); mcmc.set("pt_swap_rate", "0.3");

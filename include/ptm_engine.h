@@ -113,6 +113,12 @@ int ptm_set_proposals(ptm_engine* e, int kind, const double* factors, const doub
  * rung's value): the engine side of user_gaussian_prop::check_update / reset_dist (proposal_distribution.cc:406-441,
  * 340-403), whose user callback hands a chain a new covariance during the run. */
 int ptm_set_proposal_rung(ptm_engine* e, int local_rung, const double* factor, double one_d_frac);
+/* Scale mixture on top of the rungs' factors: a proposal_distribution_set (proposal_distribution.cc:99-129) of K Gaussian
+ * members that are scalar multiples of the rung's factor -- the sampler's default Gaussian recipe (ptmcmc.cc:117-139).
+ * Arrays [rung_count][K]: cumulative shares (the set's bin_max: one uniform x picks the first member with x < share),
+ * scales, oneDfracs.  offset = scale_k * (factor z); last_type = k + 10 * (1 if the move was one-dimensional).
+ * K = 0 removes the mixture. */
+int ptm_set_proposal_mixture(ptm_engine* e, int K, const double* cum_shares, const double* scales, const double* one_d_fracs);
 
 /* ---- state ------------------------------------------------------------------------------------------ */
 /* X[n_local_chains][D]; llike may be NULL (the device target evaluates it).  Resets counters the way

@@ -653,12 +653,26 @@ static int ph_draw_offset(void* vctx, int w, int r, uint64_t step, const ptmo_pr
     ptmo_boxmuller(o[0], o[1], &z[4 * b], &z[4 * b + 1]);
     ptmo_boxmuller(o[2], o[3], &z[4 * b + 2], &z[4 * b + 3]);
   }
-  int type = 0;
-  if (p->oneDfrac > 0) {                                  /* proposal_distribution.hh:196-206 */
+  int type = 0, kmix = 0;
+  double odf = p->oneDfrac, scale = 1.0;
+  if (p->K > 0) {                                         /* proposal_distribution_set::draw (proposal_distribution.cc:99-129) */
+    double xs = 0.0;
+    if (p->K > 1) {                                       /* a set of one draws nothing (:105-110) */
+      uint32_t o[4];
+      ptmo_draw_block(c->seed, PTMO_TAG_MH, stream, step, 0, o);
+      xs = ptmo_u01(o[3]);
+    }
+    kmix = p->K - 1;
+    for (int k = 0; k < p->K; k++)
+      if (xs < p->mix[3 * k]) { kmix = k; break; }
+    scale = p->mix[3 * kmix + 1];
+    odf = p->mix[3 * kmix + 2];
+  }
+  if (odf > 0) {                                          /* proposal_distribution.hh:196-206 */
     uint32_t o[4];
     ptmo_draw_block(c->seed, PTMO_TAG_MH, stream, step, 0, o);
     double x = ptmo_u01(o[1]);
-    if (x < p->oneDfrac) {
+    if (x < odf) {
       int ax = (int)(D * ptmo_u01(o[2]));
       for (int j = 0; j < D; j++) if (j != ax) z[j] = 0.0;
       type = 1;
@@ -674,6 +688,10 @@ static int ph_draw_offset(void* vctx, int w, int r, uint64_t step, const ptmo_pr
       for (int t = 0; t < n; t++) a = fma(p->M[i * D + ord[t]], z[ord[t]], a);
       off[i] = a;
     }
+  }
+  if (p->K > 0) {
+    for (int i = 0; i < D; i++) off[i] = scale * off[i];  /* the member is scale_k times the base factor */
+    type = kmix + 10 * type;                              /* proposal_distribution.cc:117 */
   }
   return type;
 }

@@ -65,6 +65,12 @@ typedef struct {
   int kind;        /* PTMO_PROP_DENSE / PTMO_PROP_DIAG */
   double* M;       /* DENSE: D*D row-major factor (offset = M z);  DIAG: D sigmas */
   double oneDfrac; /* gaussian_prop oneDfrac (proposal_distribution.hh:194-206) */
+  /* optional scale mixture -- a proposal_distribution_set (proposal_distribution.cc:99-129) of K Gaussian members that
+   * are scalar multiples of M (the sampler's default Gaussian recipe, ptmcmc.cc:117-139): mix[k] = {cumulative share,
+   * scale, oneDfrac}; one uniform picks the first k with x < cumulative share; offset = scale_k * (M z);
+   * type = k + 10 * (member's type).  K = 0: no mixture (M and oneDfrac alone). */
+  int K;
+  const double* mix;
 } ptmo_proposal;
 
 /* RNG provider: Philox in production parity tests, tapes for the reference-trace fixtures */

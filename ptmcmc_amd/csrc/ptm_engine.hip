@@ -56,7 +56,8 @@ struct ptm_engine {
   // device problem description
   int *blo = nullptr, *bhi = nullptr, *ptype = nullptr;
   double *bmin = nullptr, *bmax = nullptr, *plo = nullptr, *phi = nullptr, *pcoef = nullptr;
-  double *P2 = nullptr, *mean = nullptr, *beta = nullptr, *prop = nullptr, *prop_tiles = nullptr, *P2_tiles = nullptr, *box_row = nullptr, *onedfrac = nullptr;
+  double *P2 = nullptr, *mean = nullptr, *beta = nullptr, *prop = nullptr, *prop_tiles = nullptr, *P2_tiles = nullptr, *box_row = nullptr, *onedfrac = nullptr, *mix = nullptr;
+  int mix_K = 0;
   // host copies / flags
   int has_bounds = 0, origin_valid = 1, all_uniform = 1, has_mean = 0, have_target = 0, have_ladder = 0,
       have_prop = 0, have_state = 0, prop_kind = KIND_DIAG, prop_stride = 0, any_oned = 0, bounds_box = 1;
@@ -237,7 +238,7 @@ extern "C" int ptm_engine_destroy(ptm_engine* e) {
   (void)hipStreamSynchronize(e->stream);
   void* ptrs[] = {e->x, e->ll, e->lp, e->ntries, e->naccept, e->last_type, e->arr_below, e->arr_above, e->mv_src, e->mv_dst, e->mv_n,
                   e->err, e->nhist, e->swap_try, e->swap_acc, e->touch, e->swap_log, e->hist.x, e->hist.ll, e->hist.lp, e->hist.meta, e->map.lpost, e->map.ll, e->map.lp, e->map.x, e->blo,
-                  e->bhi, e->ptype, e->bmin, e->bmax, e->plo, e->phi, e->pcoef, e->P2, e->mean, e->beta, e->prop, e->prop_tiles, e->P2_tiles, e->box_row, e->onedfrac, e->xprop, e->lprior_new, e->llike_new, e->gate};
+                  e->bhi, e->ptype, e->bmin, e->bmax, e->plo, e->phi, e->pcoef, e->P2, e->mean, e->beta, e->prop, e->prop_tiles, e->P2_tiles, e->box_row, e->onedfrac, e->mix, e->xprop, e->lprior_new, e->llike_new, e->gate};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (hipEvent_t ev : e->kev) (void)hipEventDestroy(ev);
@@ -463,6 +464,36 @@ extern "C" int ptm_set_proposals(ptm_engine* e, int kind, const double* factors,
   return PTM_OK;
 }
 
+// A proposal_distribution_set of Gaussian members (proposal_distribution.cc:99-129) whose members are scalar multiples of
+// the rung's factor -- the sampler's default Gaussian recipe (six diagonal Gaussians a factor gauss_step_fac apart with
+// doubling shares, ptmcmc.cc:117-139).  Per local rung K members: cumulative shares (proposal_distribution_set's
+// bin_max), scales, oneDfracs.  K = 0 removes the mixture.  last_type becomes member + 10 * (member's type).
+extern "C" int ptm_set_proposal_mixture(ptm_engine* e, int K, const double* cum_shares, const double* scales, const double* one_d_fracs) {
+  if (!e) return fail(PTM_ERR_INVALID, "null engine");
+  if (!e->have_prop) return fail(PTM_ERR_INVALID, "set the base proposals first (ptm_set_proposals)");
+  if (K < 0 || K > 64) return fail(PTM_ERR_INVALID, "mixture size must be in 0..64");
+  if (e->mix) { HIPCHK(hipStreamSynchronize(e->stream)); HIPCHK(hipFree(e->mix)); e->mix = nullptr; }
+  e->mix_K = 0;
+  if (K == 0) return PTM_OK;
+  if (!cum_shares || !scales || !one_d_fracs) return fail(PTM_ERR_INVALID, "null argument");
+  const int nloc = e->nloc;
+  std::vector<double> t((size_t)nloc * K * 3);
+  int oned = 0;
+  for (int r = 0; r < nloc; ++r)
+    for (int k = 0; k < K; ++k) {
+      const size_t i = (size_t)r * K + k;
+      if (k > 0 && cum_shares[i] < cum_shares[i - 1]) return fail(PTM_ERR_INVALID, "cumulative shares must not decrease (rung %d)", r);
+      if (one_d_fracs[i] < 0 || one_d_fracs[i] > 1) return fail(PTM_ERR_INVALID, "oneDfrac must be in [0,1]");
+      t[3 * i] = cum_shares[i]; t[3 * i + 1] = scales[i]; t[3 * i + 2] = one_d_fracs[i];
+      if (one_d_fracs[i] > 0) oned = 1;
+    }
+  int rc;
+  if ((rc = dalloc(&e->mix, t.size())) || (rc = upload(e->mix, t.data(), t.size(), e->stream))) return rc;
+  e->mix_K = K;
+  if (oned) e->any_oned = 1;
+  return PTM_OK;
+}
+
 // One rung's factor replaced between steps -- what user_gaussian_prop::check_update achieves in the reference when its
 // callback returns a new covariance for a chain (proposal_distribution.cc:406-441, reset_dist :340-403).  Same kind and
 // storage as the factors set by ptm_set_proposals; one_d_frac < 0 keeps the rung's current value.
@@ -517,6 +548,7 @@ static Dev make_dev(ptm_engine* e) {
   p.ptype = e->ptype; p.plo = e->plo; p.phi = e->phi; p.pcoef = e->pcoef;
   p.P2 = e->P2; p.mean = e->mean; p.has_mean = e->has_mean; p.like0 = e->like0;
   p.beta = e->beta; p.prop = e->prop; p.prop_tiles = e->prop_tiles; p.P2_tiles = e->P2_tiles; p.box_row = e->box_row; p.onedfrac = e->onedfrac; p.prop_stride = e->prop_stride; p.any_oned = e->any_oned;
+  p.mix_K = e->mix_K; p.mix = e->mix;
   p.x = e->x; p.ll = e->ll; p.lp = e->lp;
   p.ntries = e->ntries; p.naccept = e->naccept; p.last_type = e->last_type; p.nhist = e->nhist;
   p.touch = e->touch; p.err = e->err;
@@ -530,7 +562,7 @@ static SweepSel sweep_sel(const ptm_engine* e) {
   SweepSel s;
   s.kind = e->prop_kind == PTM_PROP_DIAG ? KIND_DIAG : (e->prop_kind == PTM_PROP_LOWER ? KIND_LOWER : KIND_DENSE);
   s.uni = (e->W % 64) == 0;
-  s.simple = s.uni && !e->has_bounds && e->all_uniform && !e->has_mean && !e->any_oned && !e->cb;
+  s.simple = s.uni && !e->has_bounds && e->all_uniform && !e->has_mean && !e->any_oned && !e->cb && e->mix_K == 0;
   s.callback = e->cb != nullptr;
   return s;
 }

@@ -104,6 +104,11 @@ struct Dev {
   const double* P2_tiles;    // [16][64]        tile step*2 + rowtile, lane 16k+i: P2[16 rowtile + i][4 step + k] (lower, doubled)
   const double* box_row;     // [2][32]         prior box lo | hi at row_pos
   const double* onedfrac;  // [nloc]
+  // optional scale mixture (a proposal_distribution_set of Gaussian members that are scalar multiples of the rung's
+  // factor, proposal_distribution.cc:99-129, the sampler's default Gaussian recipe ptmcmc.cc:117-139):
+  // mix [nloc][mix_K][3] = {cumulative share, scale, oneDfrac}; mix_K == 0: none
+  int mix_K;
+  const double* mix;
   int prop_stride, any_oned;
   // state (in place)
   double* x;                              // [Nc][DP] rows
@@ -436,10 +441,20 @@ __global__ __launch_bounds__(256, PTM_SWEEP_WAVES) void sweep_kernel(const Dev p
   const u32x4 o0 = draw_block(p.seed, TAG_MH, stream, p.step, 0);
 
   // -- gaussian_prop::draw: D normals, optional one-dimensional move, offset = factor * z
-  int type = 0, axis = -1;
-  if (!SIMPLE && p.any_oned) {
-    const double f = as_c(p.onedfrac)[rl];
-    if (!tc && f > 0 && u01(o0.v1) < f) { axis = (int)(p.D * u01(o0.v2)); type = 1; }
+  int type = 0, axis = -1, kmix = 0;
+  double mix_scale = 1.0;
+  if (!SIMPLE) {
+    double f = as_c(p.onedfrac)[rl];
+    if (p.mix_K > 0) {   // proposal_distribution_set::draw: one uniform picks the member (a set of one draws nothing)
+      cdp mx = as_c(p.mix) + (size_t)rl * p.mix_K * 3;
+      const double xs = p.mix_K > 1 ? u01(o0.v3) : 0.0;
+      kmix = p.mix_K - 1;
+      for (int k = p.mix_K - 2; k >= 0; --k)
+        if (xs < mx[3 * k]) kmix = k;
+      mix_scale = mx[3 * kmix + 1];
+      f = mx[3 * kmix + 2];
+    }
+    if (p.any_oned && !tc && f > 0 && u01(o0.v1) < f) { axis = (int)(p.D * u01(o0.v2)); type = 1; }
   }
   double xn[DP];  // accumulates the offset, then becomes the proposed state
 #pragma unroll
@@ -477,6 +492,13 @@ __global__ __launch_bounds__(256, PTM_SWEEP_WAVES) void sweep_kernel(const Dev p
   //    proposal.  The row is written back only if the move is accepted.
   const double ll = p.ll[c], lp = p.lp[c];
   double* __restrict__ row = p.x + (size_t)c * DP;
+  if (!SIMPLE && p.mix_K > 0) {
+    type = kmix + 10 * type;   // proposal_distribution.cc:117
+    if (mode != 2) {
+#pragma unroll
+      for (int d = 0; d < DP; ++d) xn[d] = mix_scale * xn[d];   // the member is scale_k times the rung's factor
+    }
+  }
   if (mode != 2) {
 #pragma unroll
     for (int d = 0; d < DP; ++d) xn[d] = row[row_pos<DP>(d)] + xn[d];  // state::add (states.cc:205-214)

@@ -119,10 +119,20 @@ __global__ __launch_bounds__(256, PTM_MFMA_WAVES) void sweep_mfma32_kernel(const
   const u32x4 o0 = draw_block(p.seed, TAG_MH, (uint32_t)(w0 + l) * (uint32_t)p.Nt + (uint32_t)rg, p.step, 0);
   const double log_u = dlog_u01(o0.v0);
   // one-dimensional move of "my" chain (proposal_distribution.hh:196-206): its axis, or -1
-  int my_axis = -1;
-  if (GEN && p.any_oned) {
-    const double f = as_c(p.onedfrac)[rl];
-    if (f > 0 && u01(o0.v1) < f) my_axis = (int)(p.D * u01(o0.v2));
+  int my_axis = -1, my_kmix = 0;
+  double my_scale = 1.0;   // scale mixture: "my" chain's member (proposal_distribution_set::draw, proposal_distribution.cc:99-129)
+  if (GEN) {
+    double f = as_c(p.onedfrac)[rl];
+    if (p.mix_K > 0) {
+      cdp mx = as_c(p.mix) + (size_t)rl * p.mix_K * 3;
+      const double xs = p.mix_K > 1 ? u01(o0.v3) : 0.0;
+      my_kmix = p.mix_K - 1;
+      for (int k = p.mix_K - 2; k >= 0; --k)
+        if (xs < mx[3 * k]) my_kmix = k;
+      my_scale = mx[3 * my_kmix + 1];
+      f = mx[3 * my_kmix + 2];
+    }
+    if (p.any_oned && f > 0 && u01(o0.v1) < f) my_axis = (int)(p.D * u01(o0.v2));
   }
 
 #pragma unroll
@@ -163,9 +173,20 @@ __global__ __launch_bounds__(256, PTM_MFMA_WAVES) void sweep_mfma32_kernel(const
     }
     double tb[4][2];
     int axis[2] = {-1, -1};   // GEN: the one-dimensional move's axis of chain (2 gp + gg, j), from its own lane
+    double mscale[2] = {1.0, 1.0};   // GEN: the chain's mixture scale
     if (GEN && p.any_oned) {
 #pragma unroll
       for (int gg = 0; gg < 2; ++gg) axis[gg] = __builtin_amdgcn_ds_bpermute(4 * (32 * gp + 16 * gg + j), my_axis);
+    }
+    if (GEN && p.mix_K > 0) {
+#pragma unroll
+      for (int gg = 0; gg < 2; ++gg) {
+        const long long b = __double_as_longlong(my_scale);
+        const int src = 4 * (32 * gp + 16 * gg + j);
+        const unsigned int lo = (unsigned int)__builtin_amdgcn_ds_bpermute(src, (int)(unsigned int)b);
+        const unsigned int hi = (unsigned int)__builtin_amdgcn_ds_bpermute(src, (int)(unsigned int)(b >> 32));
+        mscale[gg] = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+      }
     }
 #pragma unroll
     for (int hb = 0; hb < 2; ++hb) {
@@ -227,8 +248,13 @@ __global__ __launch_bounds__(256, PTM_MFMA_WAVES) void sweep_mfma32_kernel(const
       for (int t = 0; t < 4; ++t) {
         const mf_d2 v = rowv[gg][t], lo = box[4 * t], hi = box[16 + 4 * t];
         const int m = 2 * t;   // registers m, m+1 <-> dimensions q + 4m, q + 4m + 4
-        xp[gg][m] = v.x + acc[gg][m >> 2][m & 3];
-        xp[gg][m + 1] = v.y + acc[gg][(m + 1) >> 2][(m + 1) & 3];
+        if (GEN && p.mix_K > 0) {   // the member is scale_k times the rung's factor
+          xp[gg][m] = v.x + mscale[gg] * acc[gg][m >> 2][m & 3];
+          xp[gg][m + 1] = v.y + mscale[gg] * acc[gg][(m + 1) >> 2][(m + 1) & 3];
+        } else {
+          xp[gg][m] = v.x + acc[gg][m >> 2][m & 3];
+          xp[gg][m + 1] = v.y + acc[gg][(m + 1) >> 2][(m + 1) & 3];
+        }
         if (GEN && p.has_bounds && p.bounds_box) {   // boundary::enforce for open / limit sides (states.cc:53-55)
           const mf_d2 el = ebx[4 * t], eh = ebx[16 + 4 * t];
           vok = vok & !(xp[gg][m] < el.x) & !(xp[gg][m] > eh.x) & !(xp[gg][m + 1] < el.y) & !(xp[gg][m + 1] > eh.y);
@@ -335,7 +361,8 @@ __global__ __launch_bounds__(256, PTM_MFMA_WAVES) void sweep_mfma32_kernel(const
         const double logH = newlpost - cur_lpost;
         accept = valid;
         if (accept && logH < 0) accept = log_u < logH;  // chain.cc:998-1001 (NaN stays accepted)
-        const int type = (GEN && my_axis >= 0) ? 1 : 0;
+        int type = (GEN && my_axis >= 0) ? 1 : 0;
+        if (GEN && p.mix_K > 0) type = my_kmix + 10 * type;   // proposal_distribution.cc:117
         p.ntries[c] = ntries0 + 1;
         p.nhist[c] = nhist0 + 1u;
         if (hist_on && nhist0 % (unsigned int)p.add_every_n == 0u) {

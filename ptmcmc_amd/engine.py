@@ -23,7 +23,7 @@ PRIOR_NAMES = {"uni": 1, "uniform": 1, "gauss": 2, "gaussian": 2, "pol": 3, "pol
 EXPORTS = [
     "ptm_last_error", "ptm_abi_version", "ptm_device_count", "ptm_engine_create", "ptm_engine_destroy",
     "ptm_set_bounds", "ptm_set_prior", "ptm_set_target_gaussian", "ptm_set_target_callback", "ptm_set_ladder",
-    "ptm_set_proposals", "ptm_set_proposal_rung", "ptm_set_states", "ptm_init_from_prior", "ptm_sweep", "ptm_step", "ptm_sync",
+    "ptm_set_proposals", "ptm_set_proposal_rung", "ptm_set_proposal_mixture", "ptm_set_states", "ptm_init_from_prior", "ptm_sweep", "ptm_step", "ptm_sync",
     "ptm_copy_llike", "ptm_llike_device_ptr", "ptm_exchange_decide", "ptm_exchange_finish_and_sweep", "ptm_exchange_install", "ptm_sweep_rungs", "ptm_exchange_buffer_doubles", "ptm_exchange_row_capacity", "ptm_get_states",
     "ptm_get_array", "ptm_get_swap_counts", "ptm_get_last_swaps", "ptm_max_swaps_per_step", "ptm_get_history", "ptm_get_map", "ptm_restore", "ptm_step_count",
     "ptm_timer_start", "ptm_timer_stop", "ptm_get_kernel_times", "ptm_sweep_kernel_name", "ptm_debug_eval",
@@ -104,6 +104,7 @@ def load():
     L.ptm_get_history.argtypes = [C.c_void_p, _dp, _dp, _dp, _i32p]
     L.ptm_get_map.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp]
     L.ptm_set_proposal_rung.argtypes = [C.c_void_p, C.c_int, _dp, C.c_double]
+    L.ptm_set_proposal_mixture.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp]
     L.ptm_restore.argtypes = [C.c_void_p, _dp, _dp, _i32p, _i32p, _i32p, C.POINTER(C.c_int64), C.c_uint64, C.POINTER(C.c_int64),
                               C.POINTER(C.c_int64)]
     L.ptm_debug_sqrt_scan.argtypes = [C.c_int, C.POINTER(C.c_uint64)]
@@ -309,6 +310,12 @@ class Engine:
     @property
     def exchange_buffer_doubles(self):
         return self.L.ptm_exchange_buffer_doubles(self.h)
+
+    def set_proposal_mixture(self, cum_shares, scales, one_d_fracs):
+        """arrays [rung_count][K]; K = 0 (empty arrays) removes the mixture"""
+        cs, sc, od = (np.ascontiguousarray(a, dtype=np.float64) for a in (cum_shares, scales, one_d_fracs))
+        K = 0 if cs.size == 0 else cs.shape[1]
+        _chk(self.L.ptm_set_proposal_mixture(self.h, K, cs.ctypes.data_as(_dp), sc.ctypes.data_as(_dp), od.ctypes.data_as(_dp)))
 
     def set_proposal_rung(self, local_rung, factor, one_d_frac=-1.0):
         f = np.ascontiguousarray(factor, dtype=np.float64)

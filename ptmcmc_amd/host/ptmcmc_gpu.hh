@@ -310,6 +310,8 @@ class proposal_distribution {  // proposal_distribution.hh:38-88 (what the devic
   virtual proposal_distribution* clone() const = 0;
   virtual std::string show() { return "UnspecifiedProposal()"; }
   virtual bool device_describe(int dim, int& kind, std::vector<double>& factor, double& oneDfrac) const { return false; }
+  // a set of Gaussian members that are scalar multiples of one factor: cumulative shares, scales, oneDfracs (else false)
+  virtual bool device_describe_mixture(int dim, std::vector<double>& cum, std::vector<double>& scales, std::vector<double>& odfs) const { return false; }
 };
 
 class gaussian_prop : public proposal_distribution {  // proposal_distribution.hh:145-227
@@ -375,6 +377,54 @@ class gaussian_prop : public proposal_distribution {  // proposal_distribution.h
     kind = identity_trans ? PTM_PROP_DIAG : PTM_PROP_DENSE;
     f = factor;
     odf = oneDfrac;
+    return true;
+  }
+};
+
+// proposal_distribution_set (proposal_distribution.hh:90-143, .cc:99-129): draws a member with probability share_i.
+// On the device: members must be gaussian_props that are scalar multiples of the first one (the sampler's default
+// Gaussian recipe, ptmcmc.cc:117-139, is exactly that) -- the rung keeps ONE factor and a table of scales.
+class proposal_distribution_set : public proposal_distribution {
+  std::vector<proposal_distribution*> proposals;   // owned
+  std::vector<double> shares;
+
+ public:
+  proposal_distribution_set(const std::vector<proposal_distribution*>& props, const std::vector<double>& shares_) : shares(shares_) {
+    if (props.size() != shares.size() || props.empty()) { std::cout << "proposal_distribution_set: need one share per proposal" << std::endl; exit(1); }
+    for (auto p : props) proposals.push_back(p->clone());
+  }
+  ~proposal_distribution_set() { for (auto p : proposals) delete p; }
+  proposal_distribution* clone() const override { return new proposal_distribution_set(proposals, shares); }
+  std::string show() override {
+    std::ostringstream ss;
+    ss << "ProposalSet(";
+    for (size_t i = 0; i < proposals.size(); i++) ss << shares[i] << " : " << proposals[i]->show() << (i + 1 < proposals.size() ? ", " : ")");
+    return ss.str();
+  }
+  bool device_describe(int dim, int& kind, std::vector<double>& f, double& odf) const override {
+    if (!proposals[0]->device_describe(dim, kind, f, odf)) return false;
+    odf = 0;   // the members' oneDfracs live in the mixture table
+    return true;
+  }
+  bool device_describe_mixture(int dim, std::vector<double>& cum, std::vector<double>& scales, std::vector<double>& odfs) const override {
+    int kind0; double odf0; std::vector<double> f0;
+    if (!proposals[0]->device_describe(dim, kind0, f0, odf0)) return false;
+    double sum = 0;
+    for (double sh : shares) sum += sh;
+    double run = 0;
+    cum.clear(); scales.clear(); odfs.clear();
+    for (size_t i = 0; i < proposals.size(); i++) {
+      int kind; double odf; std::vector<double> f;
+      if (!proposals[i]->device_describe(dim, kind, f, odf) || kind != kind0 || f.size() != f0.size()) return false;
+      double sc = 0;
+      for (size_t k = 0; k < f.size(); k++) if (f0[k] != 0) { sc = f[k] / f0[k]; break; }
+      for (size_t k = 0; k < f.size(); k++)
+        if (std::fabs(f[k] - sc * f0[k]) > 1e-12 * (std::fabs(f[k]) + std::fabs(sc * f0[k])) + 1e-300) return false;   // not a multiple
+      run += shares[i] / sum;                                  // bin_max (proposal_distribution.cc reset_bins)
+      cum.push_back(i + 1 == proposals.size() ? 1.0 : run);
+      scales.push_back(sc);
+      odfs.push_back(odf);
+    }
     return true;
   }
 };
@@ -577,6 +627,16 @@ class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:
       odfs[i] = odf;
     }
     ptm_check(ptm_set_proposals(eng, kind, all.data(), odfs.data()), "set_proposals");
+    std::vector<double> cum, sc, od;
+    if (proposal.device_describe_mixture(dim, cum, sc, od)) {   // a proposal_distribution_set of scaled Gaussians
+      const int K = (int)cum.size();
+      std::vector<double> C((size_t)Ntemps * K), S(C.size()), O(C.size());
+      for (int i = 0; i < Ntemps; i++)
+        for (int k = 0; k < K; k++) { C[(size_t)i * K + k] = cum[k]; S[(size_t)i * K + k] = sc[k]; O[(size_t)i * K + k] = od[k]; }
+      ptm_check(ptm_set_proposal_mixture(eng, K, C.data(), S.data(), O.data()), "set_proposal_mixture");
+    } else {
+      ptm_check(ptm_set_proposal_mixture(eng, 0, nullptr, nullptr, nullptr), "set_proposal_mixture");
+    }
   }
   // per-rung factors for proposals that differ by rung (what user_gaussian_prop's check_update achieves in the reference)
   void set_proposal_factors(int kind, const std::vector<double>& factors, const std::vector<double>& oneDfracs = std::vector<double>()) {

@@ -40,8 +40,8 @@ class _Problem(C.Structure):
                 ("like0", C.c_double), ("user_fn", C.c_void_p), ("user", C.c_void_p), ("minPrior", C.c_double)]
 
 
-class _Proposal(C.Structure):
-    _fields_ = [("kind", C.c_int), ("M", _dp), ("oneDfrac", C.c_double)]
+class _Proposal(C.Structure):  # (fields below; K, mix appended for scale mixtures)
+    _fields_ = [("kind", C.c_int), ("M", _dp), ("oneDfrac", C.c_double), ("K", C.c_int), ("mix", _dp)]
 
 
 class _PT(C.Structure):
@@ -235,7 +235,18 @@ class Ladder:
             M = np.ascontiguousarray(M, dtype=np.float64)
             self._keep.append(M)
             arr[r].kind, arr[r].M, arr[r].oneDfrac = kind, _d(M), f
+            arr[r].K = 0
         self._props = arr
+
+    def set_mixture(self, cum_shares, scales, one_d_fracs):
+        """scale mixture on top of set_proposals: arrays [Nt][K] (cumulative shares, scales, oneDfracs)"""
+        cs, sc, od = (np.asarray(a, dtype=np.float64) for a in (cum_shares, scales, one_d_fracs))
+        K = cs.shape[1]
+        for r in range(self.Nt):
+            m = np.ascontiguousarray(np.stack([cs[r], sc[r], od[r]], axis=1).ravel())
+            self._keep.append(m)
+            self._props[r].K = K
+            self._props[r].mix = _d(m)
 
     def use_philox(self, seed):
         self.rng = lib().ptmo_rng_philox(seed, self.Nt)

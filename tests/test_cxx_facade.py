@@ -108,7 +108,8 @@ def test_sampler_driver_writes_the_reference_chain_files():
             H = np.array([[float(v) for v in l.split(": ")[0].split()] for l in rows])
             P = np.array([[2.0, 0.6, 0.0], [0.6, 1.0, -0.3], [0.0, -0.3, 1.5]])
             assert np.allclose(H[:, 2], -0.5 * np.einsum("ni,ij,nj->n", X[:, :3], P, X[:, :3]), atol=1e-9)
-            assert set(H[:, 4]) <= {-1.0, 0.0, 1.0}
+            types = set(H[:, 4])                                  # member + 10 * (one-dimensional move), proposal_distribution.cc:117
+            assert types <= {-1.0} | {float(k) for k in range(6)} | {float(10 + k) for k in range(6)} and len(types) >= 4
 
 
 @pytest.mark.gpu

@@ -343,6 +343,36 @@ def test_one_rung_gets_a_new_proposal_factor_mid_run(D, W, kind):
     eng.close()
 
 
+@pytest.mark.parametrize("D,Nt,W,kind,K", [(32, 6, 64, E.PROP_DIAG, 6), (24, 5, 128, E.PROP_LOWER, 3), (5, 7, 3, E.PROP_DENSE, 4),
+                                          (16, 6, 64, E.PROP_DIAG, 1)])
+def test_scale_mixture_proposals(D, Nt, W, kind, K):
+    """A proposal_distribution_set of Gaussian members that are scalar multiples of the rung's factor (the sampler's
+    default Gaussian recipe, ptmcmc.cc:117-139): member choice, scales, per-member one-dimensional moves and the
+    reference's type code (member + 10 * type, proposal_distribution.cc:117) -- bit-identical to the oracle."""
+    pr, eng, lad = PU.make_pair(D, Nt, W, 1e3, kind=kind, swap_rate=0.3)
+    rng = np.random.default_rng(8)
+    shares = 2.0 ** np.arange(1, K + 1)                     # doubling shares (ptmcmc.cc:121-136)
+    cum = np.tile(np.cumsum(shares) / shares.sum(), (Nt, 1))
+    cum[:, -1] = 1.0
+    scales = np.tile(4.0 ** -np.arange(K)[::-1] * 1.5, (Nt, 1)) * rng.uniform(0.8, 1.2, (Nt, 1))
+    odf = np.tile(np.where(np.arange(K) % 2 == 0, 0.5, 0.0), (Nt, 1))
+    eng.set_proposal_mixture(cum, scales, odf)
+    lad.set_mixture(cum, scales, odf)
+    for k in range(5):
+        eng.step(5); eng.sync(); lad.pt_step(5)
+        PU.assert_same_state(eng, lad, "after %d steps" % (5 * (k + 1)))
+    lt = eng.last_type
+    seen = set(int(v) for v in np.unique(lt))
+    assert seen <= set(range(K)) | set(10 + k for k in range(K)) | {-1}
+    if K > 1:
+        assert len(seen - {-1}) >= 3 and any(v >= 10 for v in seen)
+    eng.set_proposal_mixture(np.zeros((Nt, 0)), np.zeros((Nt, 0)), np.zeros((Nt, 0)))   # back to the plain proposal
+    lad.set_proposals(lad._prop_specs)
+    eng.step(5); eng.sync(); lad.pt_step(5)
+    PU.assert_same_state(eng, lad, "mixture removed")
+    eng.close()
+
+
 def test_bounds_and_mixed_prior_path_bit_exact():
     """wrap / limit / reflect boundaries and a gaussian+log+uniform+polar+copolar prior on the device path."""
     D, Nt, W = 5, 6, 64
