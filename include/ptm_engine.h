@@ -105,6 +105,18 @@ int ptm_set_target_gaussian(ptm_engine* e, const double* mean, const double* pre
 int ptm_set_target_callback(ptm_engine* e, ptm_loglike_batch_fn fn, void* user);
 /* inverse temperatures of the GLOBAL ladder, beta[n_rungs] (chain.cc:1181-1183,1340) */
 int ptm_set_ladder(ptm_engine* e, const double* beta);
+/* parallel_tempering_chains::evolve_temps(rate, lpost_cut) (chain.hh:302-307; default-on in the sampler with rate 0.01,
+ * lpost_cut -1: ptmcmc.cc:389-390,512).  After every accepted exchange of rungs (i, i+1) the reference widens that gap of
+ * inverse temperatures by (1 + rate), renormalises all gaps and resets every rung's temperature (pry_temps,
+ * chain.cc:1501-1518,1809-1846).  Each of the n_walkers ladders then owns its temperatures.  The engine keeps a ladder's
+ * gaps lazily normalised inside a step (same values up to rounding, pinned against the reference by tests/golden traces
+ * 5 and 6) and rebuilds the temperatures once per step.  Call after ptm_set_ladder.  Not built: lpost_cut >= 0, sharded
+ * ladders, history / MAP tracking together with evolution (PTM_ERR_UNSUPPORTED). */
+int ptm_set_evolve_temps(ptm_engine* e, double rate, double lpost_cut);
+/* every ladder's inverse temperatures, beta[n_walkers][n_rungs] (the common ladder repeated while nothing evolves);
+ * ptm_set_invtemps puts them back (checkpoint / resume of an evolving run; needs ptm_set_evolve_temps first) */
+int ptm_get_invtemps(ptm_engine* e, double* beta);
+int ptm_set_invtemps(ptm_engine* e, const double* beta);
 /* proposals of the LOCAL rungs: factors[rung_count][D*D] row-major (DENSE/LOWER) or [rung_count][D] (DIAG);
  * one_d_frac[rung_count] (gaussian_prop oneDfrac) may be NULL (= 0).  One clone per rung as
  * parallel_tempering_chains::set_proposal does (chain.cc:1367-1386). */

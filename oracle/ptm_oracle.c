@@ -463,9 +463,34 @@ void ptmo_pt_free(ptmo_pt* s) {
   if (!s) return;
   free(s->beta); free(s->x); free(s->llike); free(s->lprior); free(s->ntries); free(s->naccept); free(s->last_type);
   free(s->nhist); free(s->nsize); free(s->swap_count); free(s->swap_accept_count); free(s->last_pairs); free(s->last_accept);
-  free(s->touched); free(s->map_lpost); free(s->map_x);
+  free(s->touched); free(s->map_lpost); free(s->map_x); free(s->betaw);
   free(s->hist_x); free(s->hist_ll); free(s->hist_lp); free(s->hist_nacc); free(s->hist_ntry); free(s->hist_type);
   free(s);
+}
+void ptmo_pt_evolve_temps(ptmo_pt* s, double rate) {
+  s->evolve_rate = rate;
+  free(s->betaw);
+  s->betaw = NULL;
+  if (!(rate > 0)) return;
+  s->betaw = (double*)malloc((size_t)s->W * s->Nt * sizeof(double));
+  for (int w = 0; w < s->W; w++) memcpy(s->betaw + (size_t)w * s->Nt, s->beta, s->Nt * sizeof(double));
+}
+/* inverse temperature of chain (w, r) */
+static inline double chain_beta(const ptmo_pt* s, int w, int r) { return s->betaw ? s->betaw[(size_t)w * s->Nt + r] : s->beta[r]; }
+
+double ptmo_chunk_prefix(const double* v, int n, double* P) {
+  double off = 0.0;
+  for (int q = 0; 32 * q < n; q++) {
+    double loc = 0.0;
+    for (int k = 32 * q; k < n && k < 32 * q + 32; k++) {
+      if (P) P[k] = loc;            /* local part first ... */
+      loc = loc + v[k];
+    }
+    if (P)
+      for (int k = 32 * q; k < n && k < 32 * q + 32; k++) P[k] = off + P[k];   /* ... then the chunk's offset */
+    off = off + loc;
+  }
+  return off;
 }
 void ptmo_pt_enable_history(ptmo_pt* s, int cap) {
   size_t N = (size_t)s->Nt * s->W;
@@ -486,7 +511,7 @@ static void hist_push(ptmo_pt* s, size_t c, int64_t row) {
 /* MH_chain::add_state bookkeeping (chain.cc:935-947) */
 /* the MAP update of add_state (chain.cc:931-934) for the state chain c holds now, at its own temperature */
 static void map_update(ptmo_pt* s, size_t c) {
-  double lpost = ptmo_lpost(s->lprior[c], s->beta[c % s->Nt], s->llike[c]);
+  double lpost = ptmo_lpost(s->lprior[c], chain_beta(s, (int)(c / s->Nt), (int)(c % s->Nt)), s->llike[c]);
   if (lpost > s->map_lpost[c]) {
     s->map_lpost[c] = lpost;
     memcpy(s->map_x + c * s->D, s->x + c * s->D, s->D * sizeof(double));
@@ -519,7 +544,7 @@ void ptmo_pt_set_states(ptmo_pt* s, const ptmo_problem* pb, const double* x, con
 int ptmo_mh_step(ptmo_pt* s, const ptmo_problem* pb, const ptmo_proposal* prop, const ptmo_rng* rng, int w, int r) {
   int D = s->D;
   size_t c = (size_t)w * s->Nt + r;
-  double beta = s->beta[r];
+  double beta = chain_beta(s, w, r);
   double* x = s->x + c * D;
   double cur_llike = s->llike[c], cur_lprior = s->lprior[c];
   double cur_lpost = ptmo_lpost(cur_lprior, beta, cur_llike);
@@ -569,7 +594,15 @@ void ptmo_sweep(ptmo_pt* s, const ptmo_problem* pb, const ptmo_proposal* props, 
 }
 
 /* ============================================================================================
- * parallel_tempering_chains::step  (chain.cc:1393-1571), fixed ladder (evolve_temps off)
+ * parallel_tempering_chains::step  (chain.cc:1393-1571)
+ *
+ * Evolving ladder (do_evolve_temps, chain.cc:1501-1518): after EVERY accepted exchange the reference widens that gap,
+ * renormalises all the gaps so that they add up to 1 - beta_last again and resets every temperature (pry_temps,
+ * chain.cc:1809-1846, lpost_cut < 0).  The same ladder is kept here in lazily normalised form: gaps sp[] and their sum S;
+ * a pry is sp[i] *= 1 + rate, S += the increase; the gap a later trial of the step sees is sp[i] / (S / (1 - beta_last)) --
+ * the reference's value up to rounding (O(1) per exchange instead of O(Nt); exact same bits until the step's first
+ * accepted exchange).  At the end of the step the temperatures are rebuilt from the gaps' prefix sums
+ * (ptmo_chunk_prefix), beta_k = 1 - P_k / (total / (1 - beta_last)) as the reference does (invtemp starts at 1).
  * ============================================================================================ */
 static void swap_phase(ptmo_pt* s, const ptmo_rng* rng, int w) {
   int Nt = s->Nt, D = s->D, ms = s->maxswaps;
@@ -589,13 +622,24 @@ static void swap_phase(ptmo_pt* s, const ptmo_rng* rng, int w) {
   }
   /* :1436-1537 trials, in pick order, on the in-place updated view */
   double tmp[64];
+  double *bw = NULL, *sp = NULL, S = 0.0, c1 = 0.0, nrm = 1.0;
+  const double grow = 1.0 + s->evolve_rate;
+  int npry = 0;
+  if (s->betaw && Nt > 1) {
+    bw = s->betaw + base;
+    sp = (double*)malloc((size_t)Nt * sizeof(double));
+    for (int k = 0; k < Nt - 1; k++) sp[k] = bw[k] - bw[k + 1];        /* :1816 splits */
+    S = ptmo_chunk_prefix(sp, Nt - 1, NULL);
+    c1 = 1 - bw[Nt - 1];                                                /* :1833 */
+  }
   for (int j = 0; j < ms; j++) {
     int i = iswaps[j];
     if (i < 0) continue;
     size_t a = base + i, b = base + i + 1;
     double lla = s->llike[a]; if (!(lla > -1e200)) lla = -1e200;        /* :1459 */
     double llb = s->llike[b]; if (!(llb > -1e200)) llb = -1e200;        /* :1461 */
-    double logH = -(s->beta[i + 1] - s->beta[i]) * (llb - lla);         /* :1463 */
+    double db = sp ? -(sp[i] / nrm) : s->beta[i + 1] - s->beta[i];
+    double logH = -db * (llb - lla);                                    /* :1463 */
     int accept = 1;
     if (logH < 0) {
       double u = rng->pt_uniform(rng->ctx, w, s->step, j, 2);
@@ -608,12 +652,27 @@ static void swap_phase(ptmo_pt* s, const ptmo_rng* rng, int w) {
       double t = s->llike[a]; s->llike[a] = s->llike[b]; s->llike[b] = t;
       t = s->lprior[a]; s->lprior[a] = s->lprior[b]; s->lprior[b] = t;   /* lprior is a pure function of the state */
       s->swap_accept_count[(size_t)w * (Nt - 1) + i]++;                   /* :1498 */
+      if (sp) {                                                          /* :1501-1518 pry_temps({i}) */
+        double sn = sp[i] * grow;                                        /* :1829 */
+        S = S + (sn - sp[i]);
+        sp[i] = sn;
+        nrm = S / c1;                                                    /* :1833 */
+        npry++;
+      }
     }
     acc[j] = accept;
     add_state_count(s, a); add_state_count(s, b);                        /* add_state on both rungs either way (:1487-1490,:1531-1534) */
     s->touched[a]++; s->touched[b]++;
     s->swap_count[(size_t)w * (Nt - 1) + i]++;                            /* :1536 */
   }
+  if (npry) {                                                            /* :1834-1844 the new temperatures */
+    double* P = (double*)malloc((size_t)Nt * sizeof(double));
+    double total = ptmo_chunk_prefix(sp, Nt - 1, P);
+    double nn = total / c1;
+    for (int k = 1; k < Nt - 1; k++) bw[k] = 1 - P[k] / nn;
+    free(P);
+  }
+  free(sp);
 }
 
 void ptmo_pt_step(ptmo_pt* s, const ptmo_problem* pb, const ptmo_proposal* props, const ptmo_rng* rng, int nthreads) {

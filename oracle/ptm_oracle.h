@@ -110,6 +110,11 @@ typedef struct {
   /* MAP tracking of MH_chain::add_state (chain.cc:931-934; MAPlpost starts at -1e200, chain.hh:69) */
   double* map_lpost;   /* [W*Nt] */
   double* map_x;       /* [W*Nt][D] */
+  /* temperature evolution (parallel_tempering_chains::evolve_temps, chain.hh:302-307; pry_temps chain.cc:1809-1846):
+   * every ladder re-tunes its own temperatures, so the inverse temperatures become per walker.  evolve_rate == 0: off
+   * (betaw NULL, beta[] rules). */
+  double evolve_rate;
+  double* betaw;       /* [W][Nt] */
 } ptmo_pt;
 
 /* ---- RNG: Philox4x32-10 (Salmon et al., SC'11; Random123) -------------------------------- */
@@ -146,6 +151,13 @@ void ptmo_problem_set_user(ptmo_problem*, ptmo_loglike_fn fn, void* user);
 
 ptmo_pt* ptmo_pt_create(int D, int Nt, int W, const double* beta, double swap_rate, int add_every_N);
 void ptmo_pt_free(ptmo_pt*);
+/* evolve_temps(rate) with lpost_cut < 0 (the sampler's defaults, ptmcmc.cc:389-390,512).  History rows and MAP values taken
+ * DURING a swap phase would need the rung's temperature between two pries of one step; that is not modelled (the engine
+ * refuses history / MAP tracking together with evolving ladders). */
+void ptmo_pt_evolve_temps(ptmo_pt*, double rate);
+/* exclusive prefix sums of v[0..n) in the order the engine uses: chunks of 32 summed left to right from 0, then the chunk
+ * totals summed left to right; P (may be NULL) gets P[k] = offset[k/32] + local sum before k.  Returns the total. */
+double ptmo_chunk_prefix(const double* v, int n, double* P);
 void ptmo_pt_enable_history(ptmo_pt*, int rows_per_chain); /* call before ptmo_pt_set_states / ptmo_init_from_prior */
 /* set states and (re)evaluate lprior/llike; llike may be NULL => evaluate the target */
 void ptmo_pt_set_states(ptmo_pt*, const ptmo_problem*, const double* x, const double* llike);

@@ -288,7 +288,7 @@ static std::vector<double> peek_tape(chain* c, int n) {
 static int golden_trace(int id) {
   // --- problem definitions -------------------------------------------------------------------
   int D, Nt, nsteps, Ninit = 1;
-  double Tmax, swap_rate, step_scale, minPrior = -30;
+  double Tmax, swap_rate, step_scale, minPrior = -30, evolve = 0;
   std::vector<std::string> types;
   std::vector<double> centers, scales;
   std::vector<int> blo, bhi;
@@ -315,6 +315,14 @@ static int golden_trace(int id) {
     centers = {0.5, 3.0, 1.0, M_PI / 2, 0.0}; scales = {2.0, 4.0, 2.5, M_PI / 2, M_PI / 2};
     blo = {O, L, W, L, R}; bhi = {O, O, W, L, R};
     bmin = {0, -0.5, -1.5, 0, -M_PI / 2}; bmax = {0, 0, 3.5, M_PI, M_PI / 2};
+  } else if (id == 5) {  // trace 1 with the ladder evolving (evolve_temps, chain.hh:302; pry_temps chain.cc:1809-1846)
+    D = 2; Nt = 8; nsteps = 160; Tmax = 1e2; swap_rate = 0.1; step_scale = 1.2; evolve = 0.05;
+    types = {"uni", "uni"}; centers = {0, 0}; scales = {60, 45};
+    blo = {O, O}; bhi = {O, O}; bmin = {0, 0}; bmax = {0, 0};
+  } else if (id == 6) {  // trace 2 (several accepted exchanges per step) with the ladder evolving at the sampler's default rate
+    D = 3; Nt = 7; nsteps = 160; Tmax = 30; swap_rate = 0.45; step_scale = 2.5; evolve = 0.01;
+    types = {"uni", "uni", "uni"}; centers = {0.5, 0, -0.5}; scales = {4, 3, 5};
+    blo = {O, O, O}; bhi = {O, O, O}; bmin = {0, 0, 0}; bmax = {0, 0, 0};
   } else {
     fprintf(stderr, "unknown trace id %d\n", id);
     return 2;
@@ -353,6 +361,7 @@ static int golden_trace(int id) {
 
     parallel_tempering_chains ptc(Nt, Tmax, swap_rate, 1, false, false, minPrior);
     ptc.initialize(&like, prior, Ninit);
+    if (evolve > 0) ptc.evolve_temps(evolve);
 
     // scripted proposal offsets
     std::vector<std::vector<std::vector<double>>> deltas(Nt);
@@ -376,7 +385,7 @@ static int golden_trace(int id) {
 
     js << "{\"id\":" << id << ",\"D\":" << D << ",\"Nt\":" << Nt << ",\"nsteps\":" << nsteps << ",\"Tmax\":" << jnum(Tmax)
        << ",\"swap_rate\":" << jnum(swap_rate) << ",\"maxswaps\":" << maxswaps << ",\"minPrior\":" << jnum(minPrior)
-       << ",\"add_every_N\":1,\n\"types\":[";
+       << ",\"add_every_N\":1,\"evolve_rate\":" << jnum(evolve) << ",\n\"types\":[";
     for (int i = 0; i < D; i++) js << (i ? "," : "") << "\"" << types[i] << "\"";
     js << "],\"centers\":" << jarr(centers) << ",\"scales\":" << jarr(scales) << ",\"blo\":" << jarr_i(blo)
        << ",\"bhi\":" << jarr_i(bhi) << ",\"bmin\":" << jarr(bmin) << ",\"bmax\":" << jarr(bmax)
@@ -403,7 +412,7 @@ static int golden_trace(int id) {
       for (int r = 0; r < Nt; r++) {
         chain* c = ptc.subchain(r);
         js << (r ? "," : "") << "{\"x\":" << jarr(c->getState().get_params_vector()) << ",\"llike\":" << jnum(c->getLogLike())
-           << ",\"lpost\":" << jnum(c->getLogPost()) << ",\"size\":" << c->size() << "}";
+           << ",\"lpost\":" << jnum(c->getLogPost()) << ",\"size\":" << c->size() << ",\"invtemp\":" << jnum(c->invTemp()) << "}";
       }
       js << "]";
     }
@@ -491,6 +500,6 @@ int main(int argc, char** argv) {
   }
   if (argc >= 3 && !strcmp(argv[1], "golden-trace")) return golden_trace(atoi(argv[2]));
   if (argc >= 3 && !strcmp(argv[1], "bench")) return bench(argv[2]);
-  fprintf(stderr, "usage: %s golden-basic | golden-trace <1|2|3|4> | bench <specfile>\n", argv[0]);
+  fprintf(stderr, "usage: %s golden-basic | golden-trace <1..6> | bench <specfile>\n", argv[0]);
   return 2;
 }

@@ -50,6 +50,10 @@ struct Decide {
   const unsigned int* nhist;
   const int *naccept, *ntries, *last_type;
   MapT map;   // MAP tracking: the in-between row is a candidate too (its log-posterior at this rung's temperature)
+  // evolving ladders (parallel_tempering_chains::evolve_temps, chain.hh:302-307): every accepted exchange pries its gap
+  // apart (pry_temps, chain.cc:1501-1518,1809-1846), so each ladder owns its temperatures.  Whole-ladder shards only.
+  double evolve_rate;   // 0: fixed ladder (beta[] rules)
+  double* beta_w;       // [W][Nt] the ladders' inverse temperatures, rewritten after a step that pried
 };
 constexpr int HIST_DST = -(1 << 30);   // move-list destination code: HIST_DST - c = "into chain c's history"
 constexpr int MAP_DST = -(1 << 29);    //                             MAP_DST - c  = "chain c's new MAP" (c < 2^29)
@@ -60,6 +64,12 @@ __device__ __forceinline__ double win_llike(const Decide& p, int r, int w) {
   if (r < p.r0) return p.ll_below[w];
   if (r >= r1) return p.ll_above[(size_t)(r - r1) * p.W + w];
   return p.ll[(size_t)(r - p.r0) * p.W + w];
+}
+
+// bijection block -> walker that gives XCD k (blocks k, k+8, ...) the k-th contiguous eighth of the walkers
+__device__ __forceinline__ int xcd_walker(int b, int W) {
+  const int q = W >> 3, rem = W & 7, xcd = b & 7;
+  return xcd * q + (xcd < rem ? xcd : rem) + (b >> 3);
 }
 
 constexpr int MVCAP = 256;  // rows one ladder can move per step on the register path (move_kernel)
@@ -81,7 +91,10 @@ typedef double d2_t __attribute__((ext_vector_type(2)));  // (HIP's double2 stru
 template <int DECIDE_THREADS>
 __global__ __launch_bounds__(DECIDE_THREADS) void decide_kernel(const Decide p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int w = blockIdx.x;
+  // walker of this block.  Consecutive workgroups go round the 8 XCDs, each with its own L2, while ll / lp / touch are
+  // [rung][walker]: a 128-byte line holds 16 (128 for touch) neighbouring walkers.  Handing each XCD a contiguous range of
+  // walkers keeps the ladders that share those lines on one L2.
+  const int w = xcd_walker(blockIdx.x, p.W);
   const int lane = threadIdx.x;
   const int Nt = p.Nt, ms = p.ms;
   const int NONE = 0x7fffffff;
@@ -106,6 +119,11 @@ __global__ __launch_bounds__(DECIDE_THREADS) void decide_kernel(const Decide p) 
   // row per 16-lane group); a longer list (64-thread form only) goes to move_kernel through global memory.
   constexpr int FCAP = DECIDE_THREADS;
   int* lmv = reinterpret_cast<int*>(accf + ((ms + 7) & ~7));                  // [2][MVCAP]
+  // evolving ladders only: gaps (in the end their local prefix sums), chunk totals / offsets, {normaliser, pries}
+  double* sp = reinterpret_cast<double*>(lmv + 2 * MVCAP);                    // [Nt]
+  double* ct = sp + Nt;                                                       // [2][(Nt + 31) / 32]
+  double* ev = ct + 2 * ((Nt + 31) / 32);                                     // [2]
+  double* lu = ev + 2;                                                        // [ms]  log of the picks' accept uniforms
   double* llc = llc_ - wlo;                // indexed by global rung
   unsigned short* perm = perm_ - wlo;
   unsigned short* inv = inv_ - wlo;
@@ -125,6 +143,13 @@ __global__ __launch_bounds__(DECIDE_THREADS) void decide_kernel(const Decide p) 
     alive[k] = 0;
     accf[k] = 0;
     if (n >= 0) atomicMin(&first[n], k);
+  }
+  const bool evolve = p.evolve_rate > 0 && Nt > 1;
+  if (evolve) {
+    if (lane < 8 && ms + lane < ((ms + 7) & ~7)) alive[ms + lane] = 0;   // the trial walk reads alive[] eight at a time
+    const double* bw = p.beta_w + (size_t)w * Nt;
+    for (int k = lane; k < Nt - 1; k += DECIDE_THREADS) sp[k] = bw[k] - bw[k + 1];   // chain.cc:1816
+    for (int k = lane; k < ms; k += DECIDE_THREADS) lu[k] = dlog_u01(ua[k]);         // (own slot: written by this thread above)
   }
   __syncthreads();
   // -- filter (1): run heads walk their run upwards
@@ -168,8 +193,75 @@ __global__ __launch_bounds__(DECIDE_THREADS) void decide_kernel(const Decide p) 
     }
   }
   __syncthreads();
+  // -- evolving ladder: every accepted exchange changes the normalisation of ALL the gaps (pry_temps renormalises the
+  //    ladder, chain.cc:1829-1844), so the trials are one chain in pick order.  The gaps stay lazily normalised: a pry is
+  //    sp[i] *= 1 + rate and S += the increase; the gap a later trial sees is sp[i] / (S / (1 - beta_last)) -- O(1) per
+  //    exchange, and the very bits of the stored temperatures until the step's first accepted exchange.
+  if (evolve) {
+    const int nch = (Nt - 1 + 31) / 32;
+    for (int q = lane; q < nch; q += DECIDE_THREADS) {   // S: chunks of 32 left to right, then the chunk totals
+      double loc = 0.0;
+      for (int k = 32 * q; k < Nt - 1 && k < 32 * q + 32; ++k) loc = loc + sp[k];
+      ct[q] = loc;
+    }
+    __syncthreads();
+    if (lane == 0) {
+      double S = 0.0;
+      for (int q = 0; q < nch; ++q) S = S + ct[q];
+      const double c1 = 1 - p.beta_w[(size_t)w * Nt + Nt - 1];   // chain.cc:1833
+      const double grow = 1.0 + p.evolve_rate;
+      double nrm = 1.0;
+      int npry = 0;
+      for (int k8 = 0; k8 < ms; k8 += 8) {
+        unsigned long long av = *reinterpret_cast<const unsigned long long*>(alive + k8);
+        while (av) {
+          const int b = __builtin_ctzll(av) >> 3;
+          av &= ~(0xffull << (8 * b));
+          const int kk = k8 + b;
+          const int i = cand[kk];
+          double lla = llc[i];
+          if (!(lla > -1e200)) lla = -1e200;
+          double llb = llc[i + 1];
+          if (!(llb > -1e200)) llb = -1e200;
+          const double db = -(sp[i] / nrm);
+          const double logH = -db * (llb - lla);
+          bool acc = true;
+          if (logH < 0) acc = lu[kk] < logH;
+          if (acc) {
+            const double t = llc[i]; llc[i] = llc[i + 1]; llc[i + 1] = t;
+            const unsigned short s_ = perm[i]; perm[i] = perm[i + 1]; perm[i + 1] = s_;
+            accf[kk] = 1;
+            const double sn = sp[i] * grow;   // chain.cc:1829
+            S = S + (sn - sp[i]);
+            sp[i] = sn;
+            nrm = S / c1;
+            ++npry;
+          }
+          if (PTM_ALIVE_RUNG(i - 1)) mid[i] = perm[i];   // the pick below (a later one) exchanges rung i again
+        }
+      }
+      ev[1] = (double)npry;
+    }
+    __syncthreads();
+    if (ev[1] > 0) {   // the new temperatures (chain.cc:1834-1844): beta_k = 1 - P_k / (total / (1 - beta_last))
+      for (int q = lane; q < nch; q += DECIDE_THREADS) {
+        double loc = 0.0;
+        for (int k = 32 * q; k < Nt - 1 && k < 32 * q + 32; ++k) { const double g = sp[k]; sp[k] = loc; loc = loc + g; }
+        ct[q] = loc;
+      }
+      __syncthreads();
+      if (lane == 0) {
+        double off = 0.0;
+        for (int q = 0; q < nch; ++q) { ct[nch + q] = off; off = off + ct[q]; }
+        ev[0] = off / (1 - p.beta_w[(size_t)w * Nt + Nt - 1]);
+      }
+      __syncthreads();
+      const double nn = ev[0];
+      for (int k = 1 + lane; k < Nt - 1; k += DECIDE_THREADS) p.beta_w[(size_t)w * Nt + k] = 1 - (ct[nch + (k >> 5)] + sp[k]) / nn;
+    }
+  }
   // -- trials (2): the top pick of each run of surviving rungs walks the run downwards (chain.cc:1436-1537)
-  for (int j = lane; j < nl; j += DECIDE_THREADS) {
+  for (int j = lane; j < (evolve ? 0 : nl); j += DECIDE_THREADS) {
     const int n = cand[list[j]];
     const bool up = PTM_ALIVE_RUNG(n + 1);
     if (up && n + 1 < whi) continue;                             // not the top of a run (the pick above is in the list)
@@ -205,8 +297,10 @@ __global__ __launch_bounds__(DECIDE_THREADS) void decide_kernel(const Decide p) 
   }
   __syncthreads();
   // -- the step's log
+#if !(defined(PTM_DECIDE_ABLATE) && (PTM_DECIDE_ABLATE & 4))
   for (int k = lane; k < ms; k += DECIDE_THREADS)
     p.swap_log[(size_t)w * ms + k] = alive[k] == 1 ? (cand[k] | (accf[k] ? 0x40000000 : 0)) : (alive[k] == 2 ? -3 : -2);
+#endif
   // -- counters, the touch counts of the local rungs and the inverse permutation
   for (int j = lane; j < nl; j += DECIDE_THREADS) {
     const int k = list[j];
@@ -214,7 +308,11 @@ __global__ __launch_bounds__(DECIDE_THREADS) void decide_kernel(const Decide p) 
     const int i = cand[k];
     // swap_count / swap_accept_count (chain.cc:1498,1536); a pair is counted by the shard that owns its lower rung, so
     // per-shard counters add up to the ladder's
+#if defined(PTM_DECIDE_ABLATE) && (PTM_DECIDE_ABLATE & 1)
+    if (false) {
+#else
     if (i >= p.r0 && i < r1) {
+#endif
       atomicAdd(reinterpret_cast<unsigned long long*>(p.swap_try) + (size_t)w * (Nt - 1) + i, 1ull);
       if (accf[k]) atomicAdd(reinterpret_cast<unsigned long long*>(p.swap_acc) + (size_t)w * (Nt - 1) + i, 1ull);
     }
@@ -223,7 +321,9 @@ __global__ __launch_bounds__(DECIDE_THREADS) void decide_kernel(const Decide p) 
       if (r >= p.r0 && r < r1) {
         const int below_alive = (r > 0 && PTM_ALIVE_RUNG(r - 1) && alive[first[r - 1]] == 1) ? 1 : 0;
         const int self_alive = (r == i) ? 1 : 0;
+#if !(defined(PTM_DECIDE_ABLATE) && (PTM_DECIDE_ABLATE & 2))
         p.touch[(r - p.r0) * p.W + w] = (unsigned char)(below_alive + self_alive);
+#endif
       }
       const int s = perm[r];
       if (s != r) inv[s] = (unsigned short)r;             // the row that started at s ends at r
@@ -293,7 +393,11 @@ __global__ __launch_bounds__(DECIDE_THREADS) void decide_kernel(const Decide p) 
     }
   }
   __syncthreads();
+#if defined(PTM_DECIDE_ABLATE) && (PTM_DECIDE_ABLATE & 8)
+  const int nmv = 0;
+#else
   const int nmv = cnt[1];
+#endif
   if (nmv > FCAP && nmv <= MVCAP) {   // too long for this block's registers: move_kernel takes it from here
     for (int j = lane; j < nmv; j += DECIDE_THREADS) {
       p.mv_src[(size_t)w * MVCAP + j] = gs[j];
@@ -456,6 +560,25 @@ __global__ __launch_bounds__(DECIDE_THREADS) void decide_kernel(const Decide p) 
   }
   if (lane == 0) p.mv_n[w] = 0;
 #undef PTM_ALIVE_RUNG
+}
+
+// [W][Nt] -> [Nt][W]: the exchange kernel keeps each evolving ladder's temperatures together, the sweep kernels read a
+// chain's inverse temperature at its chain index (rung-major).  32 x 32 tiles through LDS, 256 threads.
+__global__ __launch_bounds__(256) void beta_transpose_kernel(const double* __restrict__ in, double* __restrict__ out, int W, int Nt) {
+  __shared__ double t[32][33];
+  const int r_0 = blockIdx.x * 32, w_0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int w = w_0 + ty + 8 * j, r = r_0 + tx;
+    if (w < W && r < Nt) t[ty + 8 * j][tx] = in[(size_t)w * Nt + r];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int r = r_0 + ty + 8 * j, w = w_0 + tx;
+    if (w < W && r < Nt) out[(size_t)r * W + w] = t[tx][ty + 8 * j];
+  }
 }
 
 // ------------------------------------------------------------------------------------------------

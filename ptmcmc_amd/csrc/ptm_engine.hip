@@ -58,6 +58,9 @@ struct ptm_engine {
   double *bmin = nullptr, *bmax = nullptr, *plo = nullptr, *phi = nullptr, *pcoef = nullptr;
   double *P2 = nullptr, *mean = nullptr, *beta = nullptr, *prop = nullptr, *prop_tiles = nullptr, *P2_tiles = nullptr, *box_row = nullptr, *onedfrac = nullptr, *mix = nullptr;
   int mix_K = 0;
+  // evolving ladders (ptm_set_evolve_temps): per-ladder inverse temperatures [W][Nt] and their chain-indexed image [Nc]
+  double evolve_rate = 0;
+  double *beta_w = nullptr, *betaC = nullptr;
   // host copies / flags
   int has_bounds = 0, origin_valid = 1, all_uniform = 1, has_mean = 0, have_target = 0, have_ladder = 0,
       have_prop = 0, have_state = 0, prop_kind = KIND_DIAG, prop_stride = 0, any_oned = 0, bounds_box = 1;
@@ -120,6 +123,8 @@ static int need_device() {
 
 extern "C" int ptm_engine_destroy(ptm_engine* e);
 static int build_engine(ptm_engine* e, const ptm_config* cfg);
+static int launch_beta_transpose(ptm_engine* e);
+static int fill_evolving_ladders(ptm_engine* e);
 
 extern "C" int ptm_engine_create(const ptm_config* cfg, ptm_engine** out) {
   if (!cfg || !out) return fail(PTM_ERR_INVALID, "null argument");
@@ -238,7 +243,7 @@ extern "C" int ptm_engine_destroy(ptm_engine* e) {
   (void)hipStreamSynchronize(e->stream);
   void* ptrs[] = {e->x, e->ll, e->lp, e->ntries, e->naccept, e->last_type, e->arr_below, e->arr_above, e->mv_src, e->mv_dst, e->mv_n,
                   e->err, e->nhist, e->swap_try, e->swap_acc, e->touch, e->swap_log, e->hist.x, e->hist.ll, e->hist.lp, e->hist.meta, e->map.lpost, e->map.ll, e->map.lp, e->map.x, e->blo,
-                  e->bhi, e->ptype, e->bmin, e->bmax, e->plo, e->phi, e->pcoef, e->P2, e->mean, e->beta, e->prop, e->prop_tiles, e->P2_tiles, e->box_row, e->onedfrac, e->mix, e->xprop, e->lprior_new, e->llike_new, e->gate};
+                  e->bhi, e->ptype, e->bmin, e->bmax, e->plo, e->phi, e->pcoef, e->P2, e->mean, e->beta, e->prop, e->prop_tiles, e->P2_tiles, e->box_row, e->onedfrac, e->mix, e->beta_w, e->betaC, e->xprop, e->lprior_new, e->llike_new, e->gate};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (hipEvent_t ev : e->kev) (void)hipEventDestroy(ev);
@@ -401,7 +406,59 @@ extern "C" int ptm_set_ladder(ptm_engine* e, const double* beta) {
   int rc = upload(e->beta, beta, (size_t)e->Nt, e->stream);
   if (rc) return rc;
   e->have_ladder = 1;
+  if (e->beta_w) return fill_evolving_ladders(e);   // evolving ladders restart from the new common ladder
   return PTM_OK;
+}
+
+// every ladder starts from the common ladder
+static int fill_evolving_ladders(ptm_engine* e) {
+  std::vector<double> bw((size_t)e->W * e->Nt);
+  for (int w = 0; w < e->W; ++w) std::copy(e->h_beta.begin(), e->h_beta.end(), bw.begin() + (size_t)w * e->Nt);
+  int rc = upload(e->beta_w, bw.data(), bw.size(), e->stream);
+  if (rc) return rc;
+  HIPCHK(hipStreamSynchronize(e->stream));   // bw leaves scope
+  return launch_beta_transpose(e);
+}
+
+extern "C" int ptm_set_evolve_temps(ptm_engine* e, double rate, double lpost_cut) {
+  if (!e) return fail(PTM_ERR_INVALID, "null engine");
+  if (!(rate > 0)) {
+    if (e->evolve_rate > 0) return fail(PTM_ERR_UNSUPPORTED, "an evolving ladder cannot be frozen again (the reference has no such call either)");
+    return PTM_OK;   // evolve_temps is never called with rate <= 0 (ptmcmc.cc:512)
+  }
+  if (lpost_cut >= 0) return fail(PTM_ERR_UNSUPPORTED, "evolve_temps with a posterior-ordering cut (lpost_cut >= 0) is not built");
+  if (e->nloc != e->Nt) return fail(PTM_ERR_UNSUPPORTED, "evolving ladders need the whole ladder on one engine (every pry renormalises all rungs)");
+  if (e->hist.rungs || e->map.rungs)
+    return fail(PTM_ERR_UNSUPPORTED, "history / MAP tracking together with evolving ladders is not built (rows taken during the "
+                "exchange phase would need the rung's temperature between two pries of one step)");
+  if (!e->have_ladder) return fail(PTM_ERR_INVALID, "set the ladder first (ptm_set_ladder)");
+  int rc;
+  if (!e->beta_w) {
+    if ((rc = dalloc(&e->beta_w, (size_t)e->W * e->Nt)) || (rc = dalloc(&e->betaC, (size_t)e->Nc))) return rc;
+    if ((rc = fill_evolving_ladders(e))) return rc;
+  }
+  e->evolve_rate = rate;
+  return PTM_OK;
+}
+
+extern "C" int ptm_get_invtemps(ptm_engine* e, double* beta) {
+  if (!e || !beta) return fail(PTM_ERR_INVALID, "null argument");
+  if (!e->have_ladder) return fail(PTM_ERR_INVALID, "no ladder set");
+  if (e->beta_w) {
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipMemcpy(beta, e->beta_w, (size_t)e->W * e->Nt * 8, hipMemcpyDeviceToHost));
+  } else {
+    for (int w = 0; w < e->W; ++w) std::copy(e->h_beta.begin(), e->h_beta.end(), beta + (size_t)w * e->Nt);
+  }
+  return PTM_OK;
+}
+
+extern "C" int ptm_set_invtemps(ptm_engine* e, const double* beta) {
+  if (!e || !beta) return fail(PTM_ERR_INVALID, "null argument");
+  if (!e->beta_w) return fail(PTM_ERR_INVALID, "per-ladder temperatures exist only once the ladders evolve (ptm_set_evolve_temps)");
+  HIPCHK(hipStreamSynchronize(e->stream));
+  HIPCHK(hipMemcpy(e->beta_w, beta, (size_t)e->W * e->Nt * 8, hipMemcpyHostToDevice));
+  return launch_beta_transpose(e);
 }
 
 extern "C" int ptm_set_proposals(ptm_engine* e, int kind, const double* factors, const double* one_d_frac) {
@@ -549,6 +606,7 @@ static Dev make_dev(ptm_engine* e) {
   p.P2 = e->P2; p.mean = e->mean; p.has_mean = e->has_mean; p.like0 = e->like0;
   p.beta = e->beta; p.prop = e->prop; p.prop_tiles = e->prop_tiles; p.P2_tiles = e->P2_tiles; p.box_row = e->box_row; p.onedfrac = e->onedfrac; p.prop_stride = e->prop_stride; p.any_oned = e->any_oned;
   p.mix_K = e->mix_K; p.mix = e->mix;
+  p.betaC = e->betaC;
   p.x = e->x; p.ll = e->ll; p.lp = e->lp;
   p.ntries = e->ntries; p.naccept = e->naccept; p.last_type = e->last_type; p.nhist = e->nhist;
   p.touch = e->touch; p.err = e->err;
@@ -562,7 +620,7 @@ static SweepSel sweep_sel(const ptm_engine* e) {
   SweepSel s;
   s.kind = e->prop_kind == PTM_PROP_DIAG ? KIND_DIAG : (e->prop_kind == PTM_PROP_LOWER ? KIND_LOWER : KIND_DENSE);
   s.uni = (e->W % 64) == 0;
-  s.simple = s.uni && !e->has_bounds && e->all_uniform && !e->has_mean && !e->any_oned && !e->cb && e->mix_K == 0;
+  s.simple = s.uni && !e->has_bounds && e->all_uniform && !e->has_mean && !e->any_oned && !e->cb && e->mix_K == 0 && !e->betaC;
   s.callback = e->cb != nullptr;
   return s;
 }
@@ -622,10 +680,18 @@ static int launch_sweep(ptm_engine* e, int rung0 = 0, int nr = -1, bool last = t
   return PTM_OK;
 }
 
-static size_t decide_lds_bytes(int Nt, int ms, int WN) {
+static size_t decide_lds_bytes(int Nt, int ms, int WN, bool evolve) {
   // mirrors the carve at the top of decide_kernel
   return (size_t)WN * 8 + (size_t)((Nt + 1) & ~1) * 4 + (size_t)((ms + 1) & ~1) * 4 * 2 + 8 + (size_t)((WN + 3) & ~3) * 2 * 3 +
-         (size_t)((ms + 3) & ~3) * 2 + (size_t)((ms + 7) & ~7) * 2 + (size_t)2 * MVCAP * 4 + 32;
+         (size_t)((ms + 3) & ~3) * 2 + (size_t)((ms + 7) & ~7) * 2 + (size_t)2 * MVCAP * 4 + 32 +
+         (evolve ? ((size_t)Nt + 2 * ((Nt + 31) / 32) + 2 + ms) * 8 : 0);
+}
+
+// chain-indexed image of the evolving ladders' temperatures, for the sweep kernels
+static int launch_beta_transpose(ptm_engine* e) {
+  hipLaunchKernelGGL(beta_transpose_kernel, dim3((e->Nt + 31) / 32, (e->W + 31) / 32), dim3(256), 0, e->stream, e->beta_w, e->betaC, e->W, e->Nt);
+  HIPCHK(hipGetLastError());
+  return PTM_OK;
 }
 
 static int launch_decide(ptm_engine* e, const double* ll_below, const double* ll_above, int H, double* send_up, double* send_down) {
@@ -640,8 +706,9 @@ static int launch_decide(ptm_engine* e, const double* ll_below, const double* ll
   p.hist = e->hist; p.add_every_n = e->cfg.add_every_n; p.nhist = e->nhist;
   p.naccept = e->naccept; p.ntries = e->ntries; p.last_type = e->last_type;
   p.map = e->map;
+  p.evolve_rate = e->evolve_rate; p.beta_w = e->beta_w;
   const int WN = e->nloc + (ll_below ? 1 : 0) + p.H;
-  const size_t lds = decide_lds_bytes(e->Nt, e->ms, WN);
+  const size_t lds = decide_lds_bytes(e->Nt, e->ms, WN, e->evolve_rate > 0);
   if (lds > 160 * 1024) return fail(PTM_ERR_UNSUPPORTED, "ladder too long for the LDS-resident exchange kernel (%zu B)", lds);
   const bool wide = (double)e->ms * WN / e->Nt > 96.0;   // expected candidates inside the window
   if (lds > 64 * 1024) {
@@ -654,6 +721,7 @@ static int launch_decide(ptm_engine* e, const double* ll_below, const double* ll
   if (wide) hipLaunchKernelGGL(decide_kernel<256>, dim3(e->W), dim3(256), lds, e->stream, p);
   else hipLaunchKernelGGL(decide_kernel<64>, dim3(e->W), dim3(64), lds, e->stream, p);
   HIPCHK(hipGetLastError());
+  if (e->evolve_rate > 0) { int rc = launch_beta_transpose(e); if (rc) return rc; }
   if (wide) return PTM_OK;   // the 256-thread decide kernel has applied the moves itself
   Move m;
   m.DP = e->DP; m.W = e->W; m.row_cap = e->row_cap; m.x = e->x; m.ll = e->ll; m.lp = e->lp; m.send_up = send_up; m.send_down = send_down;
@@ -953,8 +1021,10 @@ extern "C" int ptm_get_array(ptm_engine* e, int which, void* out) {
       HIPCHK(hipMemcpy(ll.data(), e->ll, Nc * 8, hipMemcpyDeviceToHost));
       HIPCHK(hipMemcpy(lp.data(), e->lp, Nc * 8, hipMemcpyDeviceToHost));
       double* o = (double*)out;
+      std::vector<double> bc;
+      if (e->betaC) { bc.resize(Nc); HIPCHK(hipMemcpy(bc.data(), e->betaC, Nc * 8, hipMemcpyDeviceToHost)); }
       for (size_t c = 0; c < Nc; ++c) {
-        volatile double t = e->h_beta[e->r0 + c / e->W] * ll[c];  // product rounded before the sum (chain.cc:928)
+        volatile double t = (e->betaC ? bc[c] : e->h_beta[e->r0 + c / e->W]) * ll[c];  // product rounded before the sum (chain.cc:928)
         o[c] = lp[c] + t;
       }
       break;
@@ -1096,7 +1166,7 @@ extern "C" const char* ptm_sweep_kernel_name(ptm_engine* e) {
   const SweepSel s = sweep_sel(e);
   if (e->DP == 32 && s.uni && !s.callback)
     snprintf(b, sizeof b, "sweep_mfma32_kernel<%d, %s, %d>", s.kind == KIND_DIAG ? KIND_LOWER : s.kind, (e->hist.rungs || e->map.rungs) ? "true" : "false",
-             s.simple ? 0 : ((e->all_uniform && (!e->has_bounds || e->bounds_box)) ? 1 : 2));
+             s.simple ? 0 : ((e->all_uniform && (!e->has_bounds || e->bounds_box) && !e->betaC) ? 1 : 2));
   else snprintf(b, sizeof b, "sweep_kernel<%d, %d, %s, %s>", e->DP, s.kind, s.uni ? "true" : "false", s.simple ? "true" : "false");
   e->kname = b;
   return e->kname.c_str();

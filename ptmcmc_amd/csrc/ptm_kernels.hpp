@@ -98,6 +98,8 @@ struct Dev {
   double like0;
   // ladder + proposals
   const double* beta;      // [Nt] global
+  const double* betaC;     // [Nc] per-chain inverse temperatures once the ladders evolve (evolve_temps), else null; the
+                           // SIMPLE / GEN 0 / GEN 1 builds never see it
   const double* prop;      // [nloc][prop_stride]  factor, dense column-major [col][row] (DP*DP), or sigmas (DP)
   // operand images of the MFMA kernel (DP == 32 only, ptm_mfma_kernel.hpp): 64-lane A tiles, and the box in row layout
   const double* prop_tiles;  // [nloc][16][64]  tile (half*4 + slot)*2 + rowtile, lane 16k+i: T[16 rowtile + i][16 half + 4k + slot]
@@ -431,7 +433,7 @@ __global__ __launch_bounds__(256, PTM_SWEEP_WAVES) void sweep_kernel(const Dev p
     }
     if (rl < p.map.rungs) {   // MAP: the row the last add saw, at this rung's temperature
       const double tl = p.ll[c], tp = p.lp[c];
-      const double tb = as_c(p.beta)[rg] * tl;
+      const double tb = as_c(p.beta)[rg] * tl;   // (MAP tracking and evolving ladders exclude each other)
       if (map_try(p.map, c, tp + tb, tl, tp))
         for (int d = 0; d < DP; ++d) p.map.x[(size_t)c * DP + d] = p.x[(size_t)c * DP + d];
     }
@@ -503,7 +505,7 @@ __global__ __launch_bounds__(256, PTM_SWEEP_WAVES) void sweep_kernel(const Dev p
 #pragma unroll
     for (int d = 0; d < DP; ++d) xn[d] = row[row_pos<DP>(d)] + xn[d];  // state::add (states.cc:205-214)
   }
-  const double beta = as_c(p.beta)[rg];
+  const double beta = (!SIMPLE && p.betaC) ? p.betaC[c] : as_c(p.beta)[rg];
   const double bl = beta * ll;
   const double cur_lpost = lp + bl;
   const double oldlprior = cur_lpost - bl;  // chain.cc:973

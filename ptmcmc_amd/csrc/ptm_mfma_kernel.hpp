@@ -112,7 +112,8 @@ __global__ __launch_bounds__(256, PTM_MFMA_WAVES) void sweep_mfma32_kernel(const
   const double ll = p.ll[c], lp = p.lp[c];
   const int ntries0 = p.ntries[c], naccept0 = p.naccept[c];
   const unsigned int nhist0 = p.nhist[c];
-  const double beta = as_c(p.beta)[rg];
+    // (evolving ladders run the GEN 2 build: a per-chain beta in the GEN 1 build costs its fixed-ladder users 4 %)
+  const double beta = (GEN == 2 && p.betaC) ? p.betaC[c] : as_c(p.beta)[rg];
   // log of the chain's accept uniform (block 0 of its stream): drawn here once for all 64 chains -- the Metropolis test
   // itself runs per pass on half the lanes, and this is its expensive part.  (The reference draws the uniform only when
   // logH < 0, chain.cc:998; a counter-based stream makes the draw free of side effects, so drawing it always is the same.)

@@ -22,7 +22,7 @@ PRIOR_NAMES = {"uni": 1, "uniform": 1, "gauss": 2, "gaussian": 2, "pol": 3, "pol
 
 EXPORTS = [
     "ptm_last_error", "ptm_abi_version", "ptm_device_count", "ptm_engine_create", "ptm_engine_destroy",
-    "ptm_set_bounds", "ptm_set_prior", "ptm_set_target_gaussian", "ptm_set_target_callback", "ptm_set_ladder",
+    "ptm_set_bounds", "ptm_set_prior", "ptm_set_target_gaussian", "ptm_set_target_callback", "ptm_set_ladder", "ptm_set_evolve_temps", "ptm_get_invtemps", "ptm_set_invtemps",
     "ptm_set_proposals", "ptm_set_proposal_rung", "ptm_set_proposal_mixture", "ptm_set_states", "ptm_init_from_prior", "ptm_sweep", "ptm_step", "ptm_sync",
     "ptm_copy_llike", "ptm_llike_device_ptr", "ptm_exchange_decide", "ptm_exchange_finish_and_sweep", "ptm_exchange_install", "ptm_sweep_rungs", "ptm_exchange_buffer_doubles", "ptm_exchange_row_capacity", "ptm_get_states",
     "ptm_get_array", "ptm_get_swap_counts", "ptm_get_last_swaps", "ptm_max_swaps_per_step", "ptm_get_history", "ptm_get_map", "ptm_restore", "ptm_step_count",
@@ -73,6 +73,9 @@ def load():
     L.ptm_set_target_gaussian.argtypes = [C.c_void_p, _dp, _dp, C.c_double]
     L.ptm_set_target_callback.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.ptm_set_ladder.argtypes = [C.c_void_p, _dp]
+    L.ptm_set_evolve_temps.argtypes = [C.c_void_p, C.c_double, C.c_double]
+    L.ptm_get_invtemps.argtypes = [C.c_void_p, _dp]
+    L.ptm_set_invtemps.argtypes = [C.c_void_p, _dp]
     L.ptm_set_proposals.argtypes = [C.c_void_p, C.c_int, _dp, _dp]
     L.ptm_set_states.argtypes = [C.c_void_p, _dp, _dp]
     L.ptm_init_from_prior.argtypes = [C.c_void_p]
@@ -219,6 +222,7 @@ class Engine:
         self.D, self.Nt, self.W = dim, n_rungs, n_walkers
         self.r0, self.nloc = rung_begin, cfg.rung_count
         self.Nc = self.nloc * n_walkers
+        self._evolving = False
         self._keep = []
 
     def close(self):
@@ -263,6 +267,22 @@ class Engine:
         b = np.ascontiguousarray(beta, dtype=np.float64)
         assert b.size == self.Nt
         _chk(self.L.ptm_set_ladder(self.h, _d(b)))
+
+    def set_evolve_temps(self, rate, lpost_cut=-1.0):
+        """parallel_tempering_chains::evolve_temps (chain.hh:302-307): every accepted exchange pries its gap apart"""
+        _chk(self.L.ptm_set_evolve_temps(self.h, float(rate), float(lpost_cut)))
+        self._evolving = self._evolving or rate > 0
+
+    def invtemps(self):
+        """[W][Nt] inverse temperatures of every ladder"""
+        b = np.empty((self.W, self.Nt))
+        _chk(self.L.ptm_get_invtemps(self.h, b.ctypes.data_as(_dp)))
+        return b
+
+    def set_invtemps(self, beta):
+        b = np.ascontiguousarray(beta, dtype=np.float64)
+        assert b.size == self.W * self.Nt
+        _chk(self.L.ptm_set_invtemps(self.h, b.ctypes.data_as(_dp)))
 
     def set_proposals(self, kind, factors, one_d_frac=None):
         f = np.ascontiguousarray(factors, dtype=np.float64)
@@ -331,7 +351,7 @@ class Engine:
     def checkpoint(self):
         """everything the run's future depends on (ptm_restore)"""
         t, a = self.swap_counts()
-        return dict(x=self.states(), llike=self.llike, ntries=self.ntries.astype(np.int32), naccept=self.naccept.astype(np.int32),
+        return dict(invtemps=self.invtemps() if self._evolving else None, x=self.states(), llike=self.llike, ntries=self.ntries.astype(np.int32), naccept=self.naccept.astype(np.int32),
                     last_type=self.last_type.astype(np.int32), nhist=self.nhist.astype(np.int64), step=self.step_count,
                     swap_tries=np.ascontiguousarray(t, dtype=np.int64), swap_accepts=np.ascontiguousarray(a, dtype=np.int64))
 
@@ -341,6 +361,8 @@ class Engine:
         f64 = lambda v: np.ascontiguousarray(v, dtype=np.float64).ctypes.data_as(_dp)
         _chk(self.L.ptm_restore(self.h, f64(ck["x"]), f64(ck["llike"]), i32(ck["ntries"]), i32(ck["naccept"]), i32(ck["last_type"]),
                                 i64(ck["nhist"]), int(ck["step"]), i64(ck["swap_tries"]), i64(ck["swap_accepts"])))
+        if ck.get("invtemps") is not None:   # an evolving run: set_evolve_temps first, then the ladders as they were
+            self.set_invtemps(ck["invtemps"])
 
     def history(self):
         """dict of arrays [cap][history_rungs*W](,D): x, llike, lprior, naccept, ntries, last_type, row (saved row number,

@@ -8,7 +8,7 @@ Runs only in the build container, where /root/reference is mounted:
 
 Outputs (data only -- inputs and expected outputs; no reference source text):
     basic.json.gz        boundary::enforce table, mixed_dist_product::evaluate_log tables, ladders
-    trace{1..4}.json.gz parallel_tempering_chains traces (recorded RNG tapes, scripted proposals,
+    trace{1..6}.json.gz parallel_tempering_chains traces (5, 6: ladder evolving, evolve_temps) (recorded RNG tapes, scripted proposals,
                          expected per-step per-rung state / llike / lpost / history size)
     lisa_init_rows.json  the 31 prior-draw rows of the reference's own golden file
                          test/exampleLISA/exampleLISA_test_0_t0.dat (i, lpost, llike, params)
@@ -78,7 +78,7 @@ def main():
     if not os.path.exists(DRIVER):
         sys.exit("build the reference first: make -C oracle ref")
     dump_gz("basic.json.gz", run("golden-basic"))
-    for i in (1, 2, 3, 4):
+    for i in (1, 2, 3, 4, 5, 6):
         dump_gz("trace%d.json.gz" % i, run("golden-trace", str(i)))
     with open(os.path.join(HERE, "lisa_init_rows.json"), "w") as f:
         json.dump(lisa_rows(), f, indent=0)

@@ -53,7 +53,7 @@ class _PT(C.Structure):
                 ("last_pairs", _ip), ("last_accept", _ip), ("touched", C.POINTER(C.c_uint8)),
                 ("hist_cap", C.c_int), ("hist_x", _dp), ("hist_ll", _dp), ("hist_lp", _dp),
                 ("hist_nacc", C.POINTER(C.c_int32)), ("hist_ntry", C.POINTER(C.c_int32)), ("hist_type", C.POINTER(C.c_int32)),
-                ("map_lpost", _dp), ("map_x", _dp)]
+                ("map_lpost", _dp), ("map_x", _dp), ("evolve_rate", C.c_double), ("betaw", _dp)]
 
 
 _lib = None
@@ -94,6 +94,9 @@ def lib():
     L.ptmo_pt_create.argtypes = [C.c_int, C.c_int, C.c_int, _dp, C.c_double, C.c_int]
     L.ptmo_pt_free.argtypes = [C.POINTER(_PT)]
     L.ptmo_pt_enable_history.argtypes = [C.POINTER(_PT), C.c_int]
+    L.ptmo_pt_evolve_temps.argtypes = [C.POINTER(_PT), C.c_double]
+    L.ptmo_chunk_prefix.restype = C.c_double
+    L.ptmo_chunk_prefix.argtypes = [_dp, C.c_int, _dp]
     L.ptmo_pt_set_states.argtypes = [C.POINTER(_PT), C.POINTER(_Problem), _dp, _dp]
     L.ptmo_mh_step.argtypes = [C.POINTER(_PT), C.POINTER(_Problem), C.POINTER(_Proposal), C.c_void_p, C.c_int, C.c_int]
     L.ptmo_pt_step.argtypes = [C.POINTER(_PT), C.POINTER(_Problem), C.POINTER(_Proposal), C.c_void_p, C.c_int]
@@ -289,9 +292,19 @@ class Ladder:
     def lprior(self):
         return self._arr(self.s.contents.lprior, (self.N,), np.float64)
 
+    def evolve_temps(self, rate):
+        lib().ptmo_pt_evolve_temps(self.s, float(rate))
+
+    @property
+    def betaw(self):
+        """[W][Nt] inverse temperatures (per walker once the ladders evolve)"""
+        if not self.s.contents.betaw:
+            return np.tile(self.beta, (self.W, 1))
+        return self._arr(self.s.contents.betaw, (self.W, self.Nt), np.float64)
+
     @property
     def lpost(self):
-        b = np.tile(self.beta, self.W)
+        b = self.betaw.ravel()
         ll, lp = self.llike, self.lprior
         return np.array([lib().ptmo_lpost(lp[c], b[c], ll[c]) for c in range(self.N)])
 

@@ -373,6 +373,81 @@ def test_scale_mixture_proposals(D, Nt, W, kind, K):
     eng.close()
 
 
+@pytest.mark.parametrize("D,Nt,W,kind,sr,rate", [(4, 8, 3, E.PROP_DENSE, 0.3, 0.05), (32, 40, 64, E.PROP_LOWER, 0.45, 0.01),
+                                                 (16, 70, 64, E.PROP_DIAG, 0.2, 0.02), (32, 1024, 64, E.PROP_LOWER, 0.1, 0.01),
+                                                 (5, 2, 64, E.PROP_DENSE, 0.4, 0.05), (3, 3, 7, E.PROP_DIAG, 0.5, 0.1)])
+def test_evolving_ladders_match_the_oracle(D, Nt, W, kind, sr, rate):
+    """parallel_tempering_chains::evolve_temps (chain.hh:302-307): every accepted exchange pries its temperature gap apart
+    and renormalises the ladder (pry_temps, chain.cc:1501-1518,1809-1846), so each walker's ladder owns its temperatures.
+    States, llikes, counters, exchange decisions AND the temperatures are bit-identical to the oracle (which
+    tests/test_oracle_golden.py pins against the real reference with evolve_temps on, traces 5 and 6)."""
+    pr, eng, lad = PU.make_pair(D, Nt, W, 1e3, kind=kind, swap_rate=sr)
+    b0 = eng.invtemps()
+    assert b0.shape == (W, Nt) and np.array_equal(b0, np.tile(pr.beta, (W, 1)))
+    eng.set_evolve_temps(rate)
+    lad.evolve_temps(rate)
+    nsteps = 4 if Nt >= 1024 else 8
+    for k in range(3):
+        eng.step(nsteps); eng.sync(); lad.pt_step(nsteps)
+        PU.assert_same_state(eng, lad, "after %d steps" % (nsteps * (k + 1)))
+        be, bo = eng.invtemps(), lad.betaw
+        assert np.array_equal(be, bo), (np.abs(be - bo).max(), np.argwhere(be != bo)[:4].tolist())
+        assert np.array_equal(eng.lpost, PU.to_engine_order(lad.lpost, Nt, W))
+    t, a = eng.swap_counts()
+    assert np.array_equal(a, np.asarray(lad._arr(lad.s.contents.swap_accept_count, (W, max(Nt - 1, 1)), np.int64)))
+    be = eng.invtemps()
+    assert (be[:, 0] == pr.beta[0]).all() and (be[:, -1] == pr.beta[-1]).all()      # the ends stay (chain.cc:1836-1843)
+    if Nt > 2:
+        assert a.sum() > 0 and (np.abs(be - pr.beta)[:, 1:-1].max(axis=1) > 0).mean() > 0.5   # the ladders moved ...
+        assert (np.diff(be, axis=1) < 0).all()                                                 # ... and stay ordered
+        if W > 1:
+            assert not np.array_equal(be[0], be[1])                                            # each on its own
+    eng.close()
+
+
+def test_evolving_ladders_checkpoint_resume_and_refusals():
+    """checkpoint / resume of an evolving run carries the ladders (ptm_get_invtemps / ptm_set_invtemps); the combinations
+    that are not built are refused loudly."""
+    from ptmcmc_amd.problems import GaussianProblem
+    D, Nt, W = 6, 9, 5
+    pr = GaussianProblem(D, Nt, 1e3)
+    a = E.Engine(D, Nt, W, swap_rate=0.4)
+    pr.configure(a, E.PROP_DENSE)
+    a.set_evolve_temps(0.03)
+    a.init_from_prior()
+    a.step(15); a.sync()
+    ck = a.checkpoint()
+    assert ck["invtemps"] is not None and not np.array_equal(ck["invtemps"], np.tile(pr.beta, (W, 1)))
+    a.step(20); a.sync()
+    b = E.Engine(D, Nt, W, swap_rate=0.4)
+    pr.configure(b, E.PROP_DENSE)
+    b.set_evolve_temps(0.03)
+    b.restore(ck)
+    b.step(20); b.sync()
+    assert np.array_equal(a.states(), b.states()) and np.array_equal(a.invtemps(), b.invtemps())
+    assert np.array_equal(a.lpost, b.lpost)
+    with pytest.raises(E.PtmError):
+        a.set_evolve_temps(0.0)          # no way back (nor in the reference)
+    a.close(); b.close()
+    c = E.Engine(D, Nt, W, swap_rate=0.4, history_rungs=1, history_capacity=8)
+    pr.configure(c, E.PROP_DENSE)
+    with pytest.raises(E.PtmError):
+        c.set_evolve_temps(0.01)         # history + evolution: not built
+    c.close()
+    d = E.Engine(D, Nt, W, swap_rate=0.4)
+    pr.configure(d, E.PROP_DENSE)
+    with pytest.raises(E.PtmError):
+        d.set_evolve_temps(0.01, lpost_cut=0.5)
+    with pytest.raises(E.PtmError):
+        d.set_invtemps(np.tile(pr.beta, (W, 1)))   # only once the ladders evolve
+    d.close()
+    s = E.Engine(D, Nt, W, swap_rate=0.4, rung_begin=0, rung_count=4)
+    s.set_ladder(pr.beta)
+    with pytest.raises(E.PtmError):
+        s.set_evolve_temps(0.01)         # a shard of the ladder
+    s.close()
+
+
 def test_bounds_and_mixed_prior_path_bit_exact():
     """wrap / limit / reflect boundaries and a gaussian+log+uniform+polar+copolar prior on the device path."""
     D, Nt, W = 5, 6, 64

@@ -163,7 +163,7 @@ def test_reference_exampleLISA_golden_rows():
         assert abs(lp - (r["lpost"] - r["llike"])) < 5e-7
 
 
-@pytest.mark.parametrize("tid", [1, 2, 3, 4])
+@pytest.mark.parametrize("tid", [1, 2, 3, 4, 5, 6])
 def test_reference_pt_trace(tid):
     """Replay a real parallel_tempering_chains run: same initial states, same uniforms (recorded tapes of the
     reference's MotherOfAll generators), same scripted proposal offsets => the restatement must hold the same
@@ -181,6 +181,11 @@ def test_reference_pt_trace(tid):
     lad.set_proposals([(O.PROP_DIAG, np.ones(D), 0.0)] * Nt)   # unused: offsets come from the tape
     lad.use_tape(np.array(g["chain_tapes"]), np.array(g["pt_tape"])[None, :], np.array(g["deltas"]))
     lad.set_states(np.array([c["x"] for c in g["init"]]))
+    evolve = g.get("evolve_rate", 0.0) > 0
+    if evolve:
+        # traces 5, 6: evolve_temps(rate) -- pry_temps after every accepted exchange (chain.cc:1501-1518,1809-1846).  The
+        # restatement keeps the gaps lazily normalised, so temperatures agree to rounding, not to the bit.
+        lad.evolve_temps(g["evolve_rate"])
     for r, c in enumerate(g["init"]):
         assert close(lad.llike[r], c["llike"]) and close(lad.lpost[r], c["lpost"])
     nswapped = 0
@@ -193,7 +198,13 @@ def test_reference_pt_trace(tid):
             assert close(ll[r], c["llike"]), (tid, k, r)
             assert close(lp[r], c["lpost"]), (tid, k, r)
             assert nsz[r] == c["size"], (tid, k, r, nsz[r], c["size"])
+        if evolve:
+            want = np.array([c["invtemp"] for c in g["steps"][k]])
+            assert np.allclose(lad.betaw[0], want, rtol=1e-12, atol=0), (tid, k, lad.betaw[0] - want)
     assert nswapped > 5          # the trace really exercised accepted exchanges
+    if evolve:
+        moved = np.abs(lad.betaw[0] - np.array(g["invtemps"]))[1:-1]
+        assert (moved > 1e-4).all() and lad.betaw[0][0] == 1.0 and lad.betaw[0][-1] == g["invtemps"][-1]
     assert (lad.ntries > 20).all()
     if tid == 3:
         # quirk Q9 (states.cc:183-192,205-214): the origin violates a `limit` bound, so every state::add() result is

@@ -21,6 +21,7 @@ ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--tag", default="")
 ap.add_argument("--bounds", action="store_true", help="limit bounds on every dimension, uniform prior: the general build's cheap case")
 ap.add_argument("--general", action="store_true", help="limit bounds on every dimension + one gaussian prior factor: the general build")
+ap.add_argument("--evolve", type=float, default=0.0, help="evolve_temps rate (per-ladder temperatures, sequential exchange decisions)")
 a = ap.parse_args()
 kind = {"lower": E.PROP_LOWER, "dense": E.PROP_DENSE, "diag": E.PROP_DIAG}[a.kind]
 pr = GaussianProblem(a.dim, a.rungs, a.tmax)
@@ -32,6 +33,8 @@ if a.general:
     D = a.dim
     eng.set_bounds([1] * D, [1] * D, [-1e3] * D, [1e3] * D)
     eng.set_prior([2] + [1] * (D - 1), list(pr.centers), [30.0] + list(pr.halfwidths[1:]))
+if a.evolve > 0:
+    eng.set_evolve_temps(a.evolve)
 eng.init_from_prior()
 eng.sweep(3); eng.sync(); eng.kernel_times()
 eng.timer_start(); eng.sweep(a.reps); ms_sweep = eng.timer_stop() / a.reps
