@@ -110,8 +110,9 @@ int ptm_set_ladder(ptm_engine* e, const double* beta);
  * inverse temperatures by (1 + rate), renormalises all gaps and resets every rung's temperature (pry_temps,
  * chain.cc:1501-1518,1809-1846).  Each of the n_walkers ladders then owns its temperatures.  The engine keeps a ladder's
  * gaps lazily normalised inside a step (same values up to rounding, pinned against the reference by tests/golden traces
- * 5 and 6) and rebuilds the temperatures once per step.  Call after ptm_set_ladder.  Not built: lpost_cut >= 0, sharded
- * ladders, history / MAP tracking together with evolution (PTM_ERR_UNSUPPORTED). */
+ * 5 and 6) and rebuilds the temperatures once per step.  Call after ptm_set_ladder.  History rows and MAP values taken
+ * during an exchange phase carry the temperature their rung had at that add_state, between two pries of the step, as in
+ * the reference (chain.cc:1487-1490,1531-1534).  Not built: lpost_cut >= 0, sharded ladders (PTM_ERR_UNSUPPORTED). */
 int ptm_set_evolve_temps(ptm_engine* e, double rate, double lpost_cut);
 /* every ladder's inverse temperatures, beta[n_walkers][n_rungs] (the common ladder repeated while nothing evolves);
  * ptm_set_invtemps puts them back (checkpoint / resume of an evolving run; needs ptm_set_evolve_temps first) */
@@ -212,6 +213,9 @@ int ptm_max_swaps_per_step(ptm_engine* e);
  * beta*llike); HC = history_rungs * n_walkers.  Saved row s is in slot s % history_capacity; row 0 is the initial state
  * and a chain has saved Nsize rows (PTM_ARR_NSIZE).  Any output pointer may be NULL. */
 int ptm_get_history(ptm_engine* e, double* X, double* llike, double* lprior, int32_t* meta);
+/* the inverse temperature each saved row was saved at (MH_chain::invtemps, chain.cc:943), beta[k*HC + index]: the
+ * ladder's value while the ladder is fixed, the chain's own once the ladders evolve */
+int ptm_get_history_invtemps(ptm_engine* e, double* beta);
 /* MAP of the tracked rungs (ptm_config.map_rungs): chain (local rung r, walker w) at index r*W + w: X[index*dim ..], its
  * log-posterior at the rung's temperature (MH_chain::getMAPlpost / getMAPstate, chain.hh:116-117), llike, lprior.
  * lpost is -1e200 while no valid state was seen.  Any output pointer may be NULL. */

@@ -464,7 +464,7 @@ void ptmo_pt_free(ptmo_pt* s) {
   free(s->beta); free(s->x); free(s->llike); free(s->lprior); free(s->ntries); free(s->naccept); free(s->last_type);
   free(s->nhist); free(s->nsize); free(s->swap_count); free(s->swap_accept_count); free(s->last_pairs); free(s->last_accept);
   free(s->touched); free(s->map_lpost); free(s->map_x); free(s->betaw);
-  free(s->hist_x); free(s->hist_ll); free(s->hist_lp); free(s->hist_nacc); free(s->hist_ntry); free(s->hist_type);
+  free(s->hist_x); free(s->hist_ll); free(s->hist_lp); free(s->hist_beta); free(s->hist_nacc); free(s->hist_ntry); free(s->hist_type);
   free(s);
 }
 void ptmo_pt_evolve_temps(ptmo_pt* s, double rate) {
@@ -497,12 +497,14 @@ void ptmo_pt_enable_history(ptmo_pt* s, int cap) {
   s->hist_cap = cap;
   s->hist_x = (double*)calloc(N * cap * s->D, sizeof(double));
   s->hist_ll = (double*)calloc(N * cap, sizeof(double)); s->hist_lp = (double*)calloc(N * cap, sizeof(double));
+  s->hist_beta = (double*)calloc(N * cap, sizeof(double));
   s->hist_nacc = (int32_t*)calloc(N * cap, 4); s->hist_ntry = (int32_t*)calloc(N * cap, 4); s->hist_type = (int32_t*)calloc(N * cap, 4);
 }
 /* the push_back block of MH_chain::add_state (chain.cc:935-946); row index = Nsize before the push */
-static void hist_push(ptmo_pt* s, size_t c, int64_t row) {
+static void hist_push(ptmo_pt* s, size_t c, int64_t row, double beta) {
   if (!s->hist_cap || row >= s->hist_cap) return;
   size_t o = c * s->hist_cap + (size_t)row;
+  s->hist_beta[o] = beta;
   memcpy(s->hist_x + o * s->D, s->x + c * s->D, s->D * sizeof(double));
   s->hist_ll[o] = s->llike[c]; s->hist_lp[o] = s->lprior[c];
   s->hist_nacc[o] = s->naccept[c]; s->hist_ntry[o] = s->ntries[c]; s->hist_type[o] = s->last_type[c];
@@ -510,16 +512,17 @@ static void hist_push(ptmo_pt* s, size_t c, int64_t row) {
 
 /* MH_chain::add_state bookkeeping (chain.cc:935-947) */
 /* the MAP update of add_state (chain.cc:931-934) for the state chain c holds now, at its own temperature */
-static void map_update(ptmo_pt* s, size_t c) {
-  double lpost = ptmo_lpost(s->lprior[c], chain_beta(s, (int)(c / s->Nt), (int)(c % s->Nt)), s->llike[c]);
+static void map_update(ptmo_pt* s, size_t c, double beta) {
+  double lpost = ptmo_lpost(s->lprior[c], beta, s->llike[c]);
   if (lpost > s->map_lpost[c]) {
     s->map_lpost[c] = lpost;
     memcpy(s->map_x + c * s->D, s->x + c * s->D, s->D * sizeof(double));
   }
 }
-static inline void add_state_count(ptmo_pt* s, size_t c) {
-  map_update(s, c);
-  if (s->nhist[c] % s->add_every_N == 0) { hist_push(s, c, s->nsize[c]); s->nsize[c]++; }
+/* beta: the chain's inverse temperature at this call */
+static inline void add_state_count(ptmo_pt* s, size_t c, double beta) {
+  map_update(s, c, beta);
+  if (s->nhist[c] % s->add_every_N == 0) { hist_push(s, c, s->nsize[c], beta); s->nsize[c]++; }
   s->nhist[c]++;
 }
 
@@ -533,8 +536,8 @@ void ptmo_pt_set_states(ptmo_pt* s, const ptmo_problem* pb, const double* x, con
     s->llike[c] = llike ? llike[c] : ptmo_llike(pb, xc);
     s->nhist[c] = 0; s->nsize[c] = 1;                     /* MH_chain::initialize(1): one row, Nhist reset (chain.cc:871-875) */
     s->map_lpost[c] = -1e200;
-    map_update(s, c);
-    hist_push(s, c, 0);
+    map_update(s, c, chain_beta(s, (int)(c / s->Nt), (int)(c % s->Nt)));
+    hist_push(s, c, 0, chain_beta(s, (int)(c / s->Nt), (int)(c % s->Nt)));
   }
 }
 
@@ -578,7 +581,7 @@ int ptmo_mh_step(ptmo_pt* s, const ptmo_problem* pb, const ptmo_proposal* prop, 
     memcpy(x, xn, D * sizeof(double));
     s->llike[c] = newlike; s->lprior[c] = newlprior;
   }
-  add_state_count(s, c);
+  add_state_count(s, c, beta);
   return accept;
 }
 
@@ -622,14 +625,18 @@ static void swap_phase(ptmo_pt* s, const ptmo_rng* rng, int w) {
   }
   /* :1436-1537 trials, in pick order, on the in-place updated view */
   double tmp[64];
-  double *bw = NULL, *sp = NULL, S = 0.0, c1 = 0.0, nrm = 1.0;
+  double *bw = NULL, *sp = NULL, *P0 = NULL, *inc = NULL, S = 0.0, c1 = 0.0, nrm = 1.0;
+  int* ipry = NULL;
   const double grow = 1.0 + s->evolve_rate;
   int npry = 0;
   if (s->betaw && Nt > 1) {
     bw = s->betaw + base;
     sp = (double*)malloc((size_t)Nt * sizeof(double));
+    P0 = (double*)malloc((size_t)Nt * sizeof(double));
+    inc = (double*)malloc((size_t)ms * sizeof(double));
+    ipry = (int*)malloc((size_t)ms * sizeof(int));
     for (int k = 0; k < Nt - 1; k++) sp[k] = bw[k] - bw[k + 1];        /* :1816 splits */
-    S = ptmo_chunk_prefix(sp, Nt - 1, NULL);
+    S = ptmo_chunk_prefix(sp, Nt - 1, P0);
     c1 = 1 - bw[Nt - 1];                                                /* :1833 */
   }
   for (int j = 0; j < ms; j++) {
@@ -638,6 +645,22 @@ static void swap_phase(ptmo_pt* s, const ptmo_rng* rng, int w) {
     size_t a = base + i, b = base + i + 1;
     double lla = s->llike[a]; if (!(lla > -1e200)) lla = -1e200;        /* :1459 */
     double llb = s->llike[b]; if (!(llb > -1e200)) llb = -1e200;        /* :1461 */
+    /* the two rungs' temperatures as this pick's add_state calls see them (before the pick's own pry): the stored ones
+     * until something was pried this step, then 1 - (P0 + D) / normaliser with P0 the prefix sum of the step's first gaps
+     * and D what the earlier pries added to the gaps below the rung, in pick order; the ladder's ends never move */
+    double ba = s->beta[i], bb = s->beta[i + 1];
+    if (sp) {
+      ba = bw[i]; bb = bw[i + 1];
+      if (npry) {
+        double Da = 0.0, Db = 0.0;
+        for (int q = 0; q < npry; q++) {
+          if (ipry[q] < i) Da = Da + inc[q];
+          if (ipry[q] < i + 1) Db = Db + inc[q];
+        }
+        if (i > 0) ba = 1 - (P0[i] + Da) / nrm;
+        if (i + 1 < Nt - 1) bb = 1 - (P0[i + 1] + Db) / nrm;
+      }
+    }
     double db = sp ? -(sp[i] / nrm) : s->beta[i + 1] - s->beta[i];
     double logH = -db * (llb - lla);                                    /* :1463 */
     int accept = 1;
@@ -654,14 +677,15 @@ static void swap_phase(ptmo_pt* s, const ptmo_rng* rng, int w) {
       s->swap_accept_count[(size_t)w * (Nt - 1) + i]++;                   /* :1498 */
       if (sp) {                                                          /* :1501-1518 pry_temps({i}) */
         double sn = sp[i] * grow;                                        /* :1829 */
-        S = S + (sn - sp[i]);
+        ipry[npry] = i; inc[npry] = sn - sp[i];
+        S = S + inc[npry];
         sp[i] = sn;
         nrm = S / c1;                                                    /* :1833 */
         npry++;
       }
     }
     acc[j] = accept;
-    add_state_count(s, a); add_state_count(s, b);                        /* add_state on both rungs either way (:1487-1490,:1531-1534) */
+    add_state_count(s, a, ba); add_state_count(s, b, bb);                /* add_state on both rungs either way (:1487-1490,:1531-1534) */
     s->touched[a]++; s->touched[b]++;
     s->swap_count[(size_t)w * (Nt - 1) + i]++;                            /* :1536 */
   }
@@ -672,7 +696,7 @@ static void swap_phase(ptmo_pt* s, const ptmo_rng* rng, int w) {
     for (int k = 1; k < Nt - 1; k++) bw[k] = 1 - P[k] / nn;
     free(P);
   }
-  free(sp);
+  free(sp); free(P0); free(inc); free(ipry);
 }
 
 void ptmo_pt_step(ptmo_pt* s, const ptmo_problem* pb, const ptmo_proposal* props, const ptmo_rng* rng, int nthreads) {
@@ -831,7 +855,7 @@ void ptmo_init_from_prior(ptmo_pt* s, const ptmo_problem* pb, uint64_t seed) {
     }
     s->nhist[c] = 0; s->nsize[c] = 1;
     s->map_lpost[c] = -1e200;
-    map_update(s, c);
-    hist_push(s, c, 0);
+    map_update(s, c, chain_beta(s, (int)(c / s->Nt), (int)(c % s->Nt)));
+    hist_push(s, c, 0, chain_beta(s, (int)(c / s->Nt), (int)(c % s->Nt)));
   }
 }

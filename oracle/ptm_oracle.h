@@ -115,6 +115,7 @@ typedef struct {
    * (betaw NULL, beta[] rules). */
   double evolve_rate;
   double* betaw;       /* [W][Nt] */
+  double* hist_beta;   /* [W*Nt][hist_cap] the chain's inverse temperature when the row was pushed (MH_chain::invtemps, chain.cc:943) */
 } ptmo_pt;
 
 /* ---- RNG: Philox4x32-10 (Salmon et al., SC'11; Random123) -------------------------------- */
@@ -152,8 +153,7 @@ void ptmo_problem_set_user(ptmo_problem*, ptmo_loglike_fn fn, void* user);
 ptmo_pt* ptmo_pt_create(int D, int Nt, int W, const double* beta, double swap_rate, int add_every_N);
 void ptmo_pt_free(ptmo_pt*);
 /* evolve_temps(rate) with lpost_cut < 0 (the sampler's defaults, ptmcmc.cc:389-390,512).  History rows and MAP values taken
- * DURING a swap phase would need the rung's temperature between two pries of one step; that is not modelled (the engine
- * refuses history / MAP tracking together with evolving ladders). */
+ * DURING a swap phase see the rung's temperature between two pries of the step (swap_phase in ptm_oracle.c). */
 void ptmo_pt_evolve_temps(ptmo_pt*, double rate);
 /* exclusive prefix sums of v[0..n) in the order the engine uses: chunks of 32 summed left to right from 0, then the chunk
  * totals summed left to right; P (may be NULL) gets P[k] = offset[k/32] + local sum before k.  Returns the total. */

@@ -416,6 +416,21 @@ static int golden_trace(int id) {
       }
       js << "]";
     }
+    // what every rung's add_state calls pushed (MH_chain::lposts / llikes, chain.cc:935-946), raw history order
+    js << "],\n\"hist_lpost\":[";
+    for (int r = 0; r < Nt; r++) {
+      chain* c = ptc.subchain(r);
+      js << (r ? "," : "") << "\n [";
+      for (int e = 0; e < c->size(); e++) js << (e ? "," : "") << jnum(c->getLogPost(e, true));
+      js << "]";
+    }
+    js << "],\n\"hist_llike\":[";
+    for (int r = 0; r < Nt; r++) {
+      chain* c = ptc.subchain(r);
+      js << (r ? "," : "") << "\n [";
+      for (int e = 0; e < c->size(); e++) js << (e ? "," : "") << jnum(c->getLogLike(e, true));
+      js << "]";
+    }
     js << "],\n\"likelihood_calls\":" << tgt.ncalls << "}\n";
     globalRNG.reset();  // do not let the shared_ptr delete the master generator twice
   }

@@ -54,6 +54,8 @@ struct Decide {
   // apart (pry_temps, chain.cc:1501-1518,1809-1846), so each ladder owns its temperatures.  Whole-ladder shards only.
   double evolve_rate;   // 0: fixed ladder (beta[] rules)
   double* beta_w;       // [W][Nt] the ladders' inverse temperatures, rewritten after a step that pried
+  double* beta_add;     // [Nc] with history / MAP tracking: the temperature each touched rung had at its last add_state of
+                        // the phase (the sweep kernel saves that row); null otherwise
 };
 constexpr int HIST_DST = -(1 << 30);   // move-list destination code: HIST_DST - c = "into chain c's history"
 constexpr int MAP_DST = -(1 << 29);    //                             MAP_DST - c  = "chain c's new MAP" (c < 2^29)
@@ -120,10 +122,16 @@ __global__ __launch_bounds__(DECIDE_THREADS) void decide_kernel(const Decide p) 
   constexpr int FCAP = DECIDE_THREADS;
   int* lmv = reinterpret_cast<int*>(accf + ((ms + 7) & ~7));                  // [2][MVCAP]
   // evolving ladders only: gaps (in the end their local prefix sums), chunk totals / offsets, {normaliser, pries}
-  double* sp = reinterpret_cast<double*>(lmv + 2 * MVCAP);                    // [Nt]
-  double* ct = sp + Nt;                                                       // [2][(Nt + 31) / 32]
+  double* gap = reinterpret_cast<double*>(lmv + 2 * MVCAP);                   // [Nt]
+  double* ct = gap + Nt;                                                      // [2][(Nt + 31) / 32]
   double* ev = ct + 2 * ((Nt + 31) / 32);                                     // [2]
   double* lu = ev + 2;                                                        // [ms]  log of the picks' accept uniforms
+  // ... with history / MAP tracking on top (an add_state of the phase sees the temperature BETWEEN two pries of the step):
+  double* p0 = lu + ms;                                                       // [Nt]  prefix sums of the step's first gaps
+  double* nrmk = p0 + Nt;                                                     // [ms]  normaliser a pick saw (0: nothing pried yet)
+  double* dl = nrmk + ms;                                                     // [ms]  what the pick added to its gap
+  double* bklo = dl + ms;                                                     // [ms]  temperature of the pick's lower rung then
+  double* gb = bklo + ms;                                                     // [MVCAP] temperature for a HIST / MAP move
   double* llc = llc_ - wlo;                // indexed by global rung
   unsigned short* perm = perm_ - wlo;
   unsigned short* inv = inv_ - wlo;
@@ -145,10 +153,11 @@ __global__ __launch_bounds__(DECIDE_THREADS) void decide_kernel(const Decide p) 
     if (n >= 0) atomicMin(&first[n], k);
   }
   const bool evolve = p.evolve_rate > 0 && Nt > 1;
+  const bool evb = evolve && p.beta_add != nullptr;   // history / MAP tracking of evolving ladders
   if (evolve) {
     if (lane < 8 && ms + lane < ((ms + 7) & ~7)) alive[ms + lane] = 0;   // the trial walk reads alive[] eight at a time
     const double* bw = p.beta_w + (size_t)w * Nt;
-    for (int k = lane; k < Nt - 1; k += DECIDE_THREADS) sp[k] = bw[k] - bw[k + 1];   // chain.cc:1816
+    for (int k = lane; k < Nt - 1; k += DECIDE_THREADS) gap[k] = bw[k] - bw[k + 1];   // chain.cc:1816
     for (int k = lane; k < ms; k += DECIDE_THREADS) lu[k] = dlog_u01(ua[k]);         // (own slot: written by this thread above)
   }
   __syncthreads();
@@ -195,19 +204,22 @@ __global__ __launch_bounds__(DECIDE_THREADS) void decide_kernel(const Decide p) 
   __syncthreads();
   // -- evolving ladder: every accepted exchange changes the normalisation of ALL the gaps (pry_temps renormalises the
   //    ladder, chain.cc:1829-1844), so the trials are one chain in pick order.  The gaps stay lazily normalised: a pry is
-  //    sp[i] *= 1 + rate and S += the increase; the gap a later trial sees is sp[i] / (S / (1 - beta_last)) -- O(1) per
+  //    gap[i] *= 1 + rate and S += the increase; the gap a later trial sees is gap[i] / (S / (1 - beta_last)) -- O(1) per
   //    exchange, and the very bits of the stored temperatures until the step's first accepted exchange.
   if (evolve) {
     const int nch = (Nt - 1 + 31) / 32;
     for (int q = lane; q < nch; q += DECIDE_THREADS) {   // S: chunks of 32 left to right, then the chunk totals
       double loc = 0.0;
-      for (int k = 32 * q; k < Nt - 1 && k < 32 * q + 32; ++k) loc = loc + sp[k];
+      for (int k = 32 * q; k < Nt - 1 && k < 32 * q + 32; ++k) {
+        if (evb) p0[k] = loc;
+        loc = loc + gap[k];
+      }
       ct[q] = loc;
     }
     __syncthreads();
     if (lane == 0) {
       double S = 0.0;
-      for (int q = 0; q < nch; ++q) S = S + ct[q];
+      for (int q = 0; q < nch; ++q) { ct[nch + q] = S; S = S + ct[q]; }
       const double c1 = 1 - p.beta_w[(size_t)w * Nt + Nt - 1];   // chain.cc:1833
       const double grow = 1.0 + p.evolve_rate;
       double nrm = 1.0;
@@ -223,19 +235,22 @@ __global__ __launch_bounds__(DECIDE_THREADS) void decide_kernel(const Decide p) 
           if (!(lla > -1e200)) lla = -1e200;
           double llb = llc[i + 1];
           if (!(llb > -1e200)) llb = -1e200;
-          const double db = -(sp[i] / nrm);
+          const double db = -(gap[i] / nrm);
           const double logH = -db * (llb - lla);
           bool acc = true;
           if (logH < 0) acc = lu[kk] < logH;
+          if (evb) { nrmk[kk] = npry ? nrm : 0.0; dl[kk] = 0.0; }
           if (acc) {
             const double t = llc[i]; llc[i] = llc[i + 1]; llc[i + 1] = t;
             const unsigned short s_ = perm[i]; perm[i] = perm[i + 1]; perm[i + 1] = s_;
             accf[kk] = 1;
-            const double sn = sp[i] * grow;   // chain.cc:1829
-            S = S + (sn - sp[i]);
-            sp[i] = sn;
+            const double sn = gap[i] * grow;   // chain.cc:1829
+            const double inc = sn - gap[i];
+            S = S + inc;
+            gap[i] = sn;
             nrm = S / c1;
             ++npry;
+            if (evb) dl[kk] = inc;
           }
           if (PTM_ALIVE_RUNG(i - 1)) mid[i] = perm[i];   // the pick below (a later one) exchanges rung i again
         }
@@ -243,10 +258,35 @@ __global__ __launch_bounds__(DECIDE_THREADS) void decide_kernel(const Decide p) 
       ev[1] = (double)npry;
     }
     __syncthreads();
+    if (evb) {
+      // The temperature a rung had when a pick's add_state calls reached it (both rungs of the pair, before the pick's own
+      // pry; chain.cc:1487-1490,1531-1534): 1 - (P0 + D) / normaliser, P0 = prefix of the step's first gaps, D = what
+      // the earlier accepted picks added to the gaps below the rung, in pick order.  No gap between the pair's two rungs
+      // has been pried yet (a pair is tried once), so D is the same for both.
+      for (int k = lane; k < Nt - 1; k += DECIDE_THREADS) p0[k] = ct[nch + (k >> 5)] + p0[k];
+      __syncthreads();
+      const double* bw = p.beta_w + (size_t)w * Nt;
+      for (int j = lane; j < nl; j += DECIDE_THREADS) {
+        const int k = list[j];
+        const int i = cand[k];
+        double D = 0.0;
+        for (int k2 = 0; k2 < k; ++k2)
+          if (accf[k2] && cand[k2] < i) D = D + dl[k2];
+        const double nk = nrmk[k];
+        const double blo = (nk == 0.0 || i == 0) ? bw[i] : 1 - (p0[i] + D) / nk;
+        const double bhi = (nk == 0.0 || i + 1 == Nt - 1) ? bw[i + 1] : 1 - (p0[i + 1] + D) / nk;
+        bklo[k] = blo;
+        // last add of the phase: always for the upper rung (a pick on the pair above came earlier), for the lower rung
+        // unless a later pick exchanges it again
+        p.beta_add[(size_t)(i + 1) * p.W + w] = bhi;
+        if (!PTM_ALIVE_RUNG(i - 1)) p.beta_add[(size_t)i * p.W + w] = blo;
+      }
+      __syncthreads();
+    }
     if (ev[1] > 0) {   // the new temperatures (chain.cc:1834-1844): beta_k = 1 - P_k / (total / (1 - beta_last))
       for (int q = lane; q < nch; q += DECIDE_THREADS) {
         double loc = 0.0;
-        for (int k = 32 * q; k < Nt - 1 && k < 32 * q + 32; ++k) { const double g = sp[k]; sp[k] = loc; loc = loc + g; }
+        for (int k = 32 * q; k < Nt - 1 && k < 32 * q + 32; ++k) { const double g = gap[k]; gap[k] = loc; loc = loc + g; }
         ct[q] = loc;
       }
       __syncthreads();
@@ -257,7 +297,7 @@ __global__ __launch_bounds__(DECIDE_THREADS) void decide_kernel(const Decide p) 
       }
       __syncthreads();
       const double nn = ev[0];
-      for (int k = 1 + lane; k < Nt - 1; k += DECIDE_THREADS) p.beta_w[(size_t)w * Nt + k] = 1 - (ct[nch + (k >> 5)] + sp[k]) / nn;
+      for (int k = 1 + lane; k < Nt - 1; k += DECIDE_THREADS) p.beta_w[(size_t)w * Nt + k] = 1 - (ct[nch + (k >> 5)] + gap[k]) / nn;
     }
   }
   // -- trials (2): the top pick of each run of surviving rungs walks the run downwards (chain.cc:1436-1537)
@@ -347,13 +387,13 @@ __global__ __launch_bounds__(DECIDE_THREADS) void decide_kernel(const Decide p) 
   };
   // the same for MAP tracking: source slot of rung r's in-between row if its log-posterior at rung r's temperature
   // beats the rung's MAP (the first of the two add_state calls sees it, chain.cc:931-934), else -1
-  auto map_mid_src = [&](int r) -> int {
+  auto map_mid_src = [&](int r, double bmid) -> int {
     if (r - p.r0 >= p.map.rungs || r < p.r0 || r >= r1) return -1;
     if (!(r > 0 && PTM_ALIVE_RUNG(r - 1) && alive[first[r - 1]] == 1)) return -1;   // touched once only
     const int s1 = mid[r];
     if (s1 < p.r0 || s1 >= r1) { atomicOr(p.err, 16); return -1; }
     const int cs = (s1 - p.r0) * p.W + w;
-    const double t = beta[r] * p.ll[cs];
+    const double t = bmid * p.ll[cs];
     return (p.lp[cs] + t > p.map.lpost[(r - p.r0) * p.W + w]) ? cs : -1;
   };
   for (int j = lane; j < nl; j += DECIDE_THREADS) {
@@ -361,18 +401,19 @@ __global__ __launch_bounds__(DECIDE_THREADS) void decide_kernel(const Decide p) 
     if (alive[k] != 1) continue;
     const int i = cand[k];
     const int rtop = (PTM_ALIVE_RUNG(i + 1) && alive[first[i + 1]] == 1) ? i : i + 1;
+    const double bmid = evb ? bklo[k] : beta[i];   // rung i's temperature at this pick's add_state
     if (p.hist.rungs) {
       const int hs = hist_mid_src(i);
       if (hs >= 0) {
         const int m = atomicAdd(&cnt[1], 1);
-        if (m < MVCAP) { gs[m] = hs; gd[m] = HIST_DST - ((i - p.r0) * p.W + w); }
+        if (m < MVCAP) { gs[m] = hs; gd[m] = HIST_DST - ((i - p.r0) * p.W + w); if (evb) gb[m] = bmid; }
       }
     }
     if (p.map.rungs) {
-      const int ms_ = map_mid_src(i);
+      const int ms_ = map_mid_src(i, bmid);
       if (ms_ >= 0) {
         const int m = atomicAdd(&cnt[1], 1);
-        if (m < MVCAP) { gs[m] = ms_; gd[m] = MAP_DST - ((i - p.r0) * p.W + w); }
+        if (m < MVCAP) { gs[m] = ms_; gd[m] = MAP_DST - ((i - p.r0) * p.W + w); if (evb) gb[m] = bmid; }
       }
     }
     for (int r = i; r <= rtop; ++r) {
@@ -458,10 +499,11 @@ __global__ __launch_bounds__(DECIDE_THREADS) void decide_kernel(const Decide p) 
       else if (d <= HIST_DST) {
         const int c = HIST_DST - d;
         const long long hrow = 1 + (long long)(p.nhist[c] / (unsigned int)p.add_every_n);
-        hist_scalars(p.hist, hist_slot(p.hist, hrow, c), hrow, sl, sp, p.naccept[c], p.ntries[c], p.last_type[c]);
+        hist_scalars(p.hist, hist_slot(p.hist, hrow, c), hrow, sl, sp, p.naccept[c], p.ntries[c], p.last_type[c],
+                     evb ? gb[lane] : beta[p.r0 + c / p.W]);
       } else if (d <= MAP_DST) {
         const int c = MAP_DST - d;
-        const double t = beta[p.r0 + c / p.W] * sl;
+        const double t = (evb ? gb[lane] : beta[p.r0 + c / p.W]) * sl;
         p.map.lpost[c] = sp + t; p.map.ll[c] = sl; p.map.lp[c] = sp;
       } else if (d != -3) {
         const int e = -d - 4;
@@ -486,7 +528,7 @@ __global__ __launch_bounds__(DECIDE_THREADS) void decide_kernel(const Decide p) 
       const long long hrow = 1 + (long long)(p.nhist[c] / (unsigned int)p.add_every_n);
       const size_t o = hist_slot(p.hist, hrow, c);
       for (int d = 0; d < DP; ++d) p.hist.x[o * DP + d] = p.x[(size_t)hs * DP + d];
-      hist_scalars(p.hist, o, hrow, p.ll[hs], p.lp[hs], p.naccept[c], p.ntries[c], p.last_type[c]);
+      hist_scalars(p.hist, o, hrow, p.ll[hs], p.lp[hs], p.naccept[c], p.ntries[c], p.last_type[c], evb ? bklo[k] : beta[i]);
     }
     __syncthreads();
   }
@@ -495,10 +537,11 @@ __global__ __launch_bounds__(DECIDE_THREADS) void decide_kernel(const Decide p) 
       const int k = list[j];
       if (alive[k] != 1) continue;
       const int i = cand[k];
-      const int cs = map_mid_src(i);
+      const double bmid = evb ? bklo[k] : beta[i];
+      const int cs = map_mid_src(i, bmid);
       if (cs < 0) continue;
       const int c = (i - p.r0) * p.W + w;
-      const double t = beta[i] * p.ll[cs];
+      const double t = bmid * p.ll[cs];
       p.map.lpost[c] = p.lp[cs] + t; p.map.ll[c] = p.ll[cs]; p.map.lp[c] = p.lp[cs];
       for (int d = 0; d < DP; ++d) p.map.x[(size_t)c * DP + d] = p.x[(size_t)cs * DP + d];
     }
@@ -670,7 +713,8 @@ __global__ __launch_bounds__(64 * WPB, MV > 64 ? 1 : 4) void move_kernel(const M
     } else if (HIST && d <= HIST_DST) {
       const int c = HIST_DST - d;
       const long long hrow = 1 + (long long)(p.nhist[c] / (unsigned int)p.add_every_n);
-      hist_scalars(p.hist, hist_slot(p.hist, hrow, c), hrow, sl[q], sp[q], p.naccept[c], p.ntries[c], p.last_type[c]);
+      hist_scalars(p.hist, hist_slot(p.hist, hrow, c), hrow, sl[q], sp[q], p.naccept[c], p.ntries[c], p.last_type[c],
+                   p.beta[p.r0 + c / p.W]);   // (evolving ladders never come here: their exchange kernel moves the rows itself)
     } else if (d != -3) {
       const int e = -d - 4;
       double* row = ((e & 1) ? p.send_down : p.send_up) + MSG_HDR + (size_t)(e >> 1) * RD;
@@ -710,12 +754,18 @@ __global__ __launch_bounds__(256) void install_kernel(const Install p) {
 
 // history row 0: the initial state (MH_chain::initialize -> add_state, chain.cc:871-875)
 __global__ void hist_init_kernel(Hist h, int DP, const double* x, const double* ll, const double* lp, const int* naccept,
-                                 const int* ntries, const int* last_type) {
+                                 const int* ntries, const int* last_type, const double* beta, const double* betaC, int W, int r0) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= h.HC) return;
   const size_t o = hist_slot(h, 0, c);
   for (int d = 0; d < DP; ++d) h.x[o * DP + d] = x[(size_t)c * DP + d];
-  hist_scalars(h, o, 0, ll[c], lp[c], naccept[c], ntries[c], last_type[c]);
+  hist_scalars(h, o, 0, ll[c], lp[c], naccept[c], ntries[c], last_type[c], betaC ? betaC[c] : beta[r0 + c / W]);
+}
+// the ladders start to evolve with rows already saved: those rows were saved at the common ladder's temperatures
+__global__ void hist_beta_fill_kernel(Hist h, const double* beta, int W, int r0) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)h.cap * h.HC) return;
+  h.beta[i] = beta[r0 + (int)(i % h.HC) / W];
 }
 
 // MAP after initialize: the initial state, if its log-posterior beats -1e200 (chain.hh:69, chain.cc:931-934)

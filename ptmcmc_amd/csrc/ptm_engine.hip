@@ -60,7 +60,7 @@ struct ptm_engine {
   int mix_K = 0;
   // evolving ladders (ptm_set_evolve_temps): per-ladder inverse temperatures [W][Nt] and their chain-indexed image [Nc]
   double evolve_rate = 0;
-  double *beta_w = nullptr, *betaC = nullptr;
+  double *beta_w = nullptr, *betaC = nullptr, *beta_add = nullptr;
   // host copies / flags
   int has_bounds = 0, origin_valid = 1, all_uniform = 1, has_mean = 0, have_target = 0, have_ladder = 0,
       have_prop = 0, have_state = 0, prop_kind = KIND_DIAG, prop_stride = 0, any_oned = 0, bounds_box = 1;
@@ -243,7 +243,7 @@ extern "C" int ptm_engine_destroy(ptm_engine* e) {
   (void)hipStreamSynchronize(e->stream);
   void* ptrs[] = {e->x, e->ll, e->lp, e->ntries, e->naccept, e->last_type, e->arr_below, e->arr_above, e->mv_src, e->mv_dst, e->mv_n,
                   e->err, e->nhist, e->swap_try, e->swap_acc, e->touch, e->swap_log, e->hist.x, e->hist.ll, e->hist.lp, e->hist.meta, e->map.lpost, e->map.ll, e->map.lp, e->map.x, e->blo,
-                  e->bhi, e->ptype, e->bmin, e->bmax, e->plo, e->phi, e->pcoef, e->P2, e->mean, e->beta, e->prop, e->prop_tiles, e->P2_tiles, e->box_row, e->onedfrac, e->mix, e->beta_w, e->betaC, e->xprop, e->lprior_new, e->llike_new, e->gate};
+                  e->bhi, e->ptype, e->bmin, e->bmax, e->plo, e->phi, e->pcoef, e->P2, e->mean, e->beta, e->prop, e->prop_tiles, e->P2_tiles, e->box_row, e->onedfrac, e->mix, e->beta_w, e->betaC, e->beta_add, e->hist.beta, e->xprop, e->lprior_new, e->llike_new, e->gate};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (hipEvent_t ev : e->kev) (void)hipEventDestroy(ev);
@@ -428,14 +428,19 @@ extern "C" int ptm_set_evolve_temps(ptm_engine* e, double rate, double lpost_cut
   }
   if (lpost_cut >= 0) return fail(PTM_ERR_UNSUPPORTED, "evolve_temps with a posterior-ordering cut (lpost_cut >= 0) is not built");
   if (e->nloc != e->Nt) return fail(PTM_ERR_UNSUPPORTED, "evolving ladders need the whole ladder on one engine (every pry renormalises all rungs)");
-  if (e->hist.rungs || e->map.rungs)
-    return fail(PTM_ERR_UNSUPPORTED, "history / MAP tracking together with evolving ladders is not built (rows taken during the "
-                "exchange phase would need the rung's temperature between two pries of one step)");
   if (!e->have_ladder) return fail(PTM_ERR_INVALID, "set the ladder first (ptm_set_ladder)");
   int rc;
   if (!e->beta_w) {
     if ((rc = dalloc(&e->beta_w, (size_t)e->W * e->Nt)) || (rc = dalloc(&e->betaC, (size_t)e->Nc))) return rc;
     if ((rc = fill_evolving_ladders(e))) return rc;
+    // history / MAP tracking: an add_state of the exchange phase sees its rung's temperature between two pries of the step
+    if ((e->hist.rungs || e->map.rungs) && (rc = dalloc(&e->beta_add, (size_t)e->Nc))) return rc;
+    if (e->hist.rungs) {   // every saved row keeps the temperature it was saved at; the rows so far: the common ladder's
+      const size_t n = (size_t)e->hist.cap * e->hist.HC;
+      if ((rc = dalloc(&e->hist.beta, n))) return rc;
+      hipLaunchKernelGGL(hist_beta_fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->stream, e->hist, e->beta, e->W, e->r0);
+      HIPCHK(hipGetLastError());
+    }
   }
   e->evolve_rate = rate;
   return PTM_OK;
@@ -449,6 +454,20 @@ extern "C" int ptm_get_invtemps(ptm_engine* e, double* beta) {
     HIPCHK(hipMemcpy(beta, e->beta_w, (size_t)e->W * e->Nt * 8, hipMemcpyDeviceToHost));
   } else {
     for (int w = 0; w < e->W; ++w) std::copy(e->h_beta.begin(), e->h_beta.end(), beta + (size_t)w * e->Nt);
+  }
+  return PTM_OK;
+}
+
+extern "C" int ptm_get_history_invtemps(ptm_engine* e, double* beta) {
+  if (!e || !beta) return fail(PTM_ERR_INVALID, "null argument");
+  if (!e->hist.rungs) return fail(PTM_ERR_INVALID, "this engine keeps no history (ptm_config.history_rungs)");
+  if (!e->have_ladder) return fail(PTM_ERR_INVALID, "no ladder set");
+  const size_t n = (size_t)e->hist.cap * e->hist.HC;
+  if (e->hist.beta) {
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipMemcpy(beta, e->hist.beta, n * 8, hipMemcpyDeviceToHost));
+  } else {
+    for (size_t i = 0; i < n; ++i) beta[i] = e->h_beta[e->r0 + (int)(i % e->hist.HC) / e->W];
   }
   return PTM_OK;
 }
@@ -606,7 +625,7 @@ static Dev make_dev(ptm_engine* e) {
   p.P2 = e->P2; p.mean = e->mean; p.has_mean = e->has_mean; p.like0 = e->like0;
   p.beta = e->beta; p.prop = e->prop; p.prop_tiles = e->prop_tiles; p.P2_tiles = e->P2_tiles; p.box_row = e->box_row; p.onedfrac = e->onedfrac; p.prop_stride = e->prop_stride; p.any_oned = e->any_oned;
   p.mix_K = e->mix_K; p.mix = e->mix;
-  p.betaC = e->betaC;
+  p.betaC = e->betaC; p.beta_add = e->beta_add;
   p.x = e->x; p.ll = e->ll; p.lp = e->lp;
   p.ntries = e->ntries; p.naccept = e->naccept; p.last_type = e->last_type; p.nhist = e->nhist;
   p.touch = e->touch; p.err = e->err;
@@ -680,11 +699,11 @@ static int launch_sweep(ptm_engine* e, int rung0 = 0, int nr = -1, bool last = t
   return PTM_OK;
 }
 
-static size_t decide_lds_bytes(int Nt, int ms, int WN, bool evolve) {
+static size_t decide_lds_bytes(int Nt, int ms, int WN, bool evolve, bool evb) {
   // mirrors the carve at the top of decide_kernel
   return (size_t)WN * 8 + (size_t)((Nt + 1) & ~1) * 4 + (size_t)((ms + 1) & ~1) * 4 * 2 + 8 + (size_t)((WN + 3) & ~3) * 2 * 3 +
          (size_t)((ms + 3) & ~3) * 2 + (size_t)((ms + 7) & ~7) * 2 + (size_t)2 * MVCAP * 4 + 32 +
-         (evolve ? ((size_t)Nt + 2 * ((Nt + 31) / 32) + 2 + ms) * 8 : 0);
+         (evolve ? ((size_t)Nt + 2 * ((Nt + 31) / 32) + 2 + ms) * 8 : 0) + (evb ? ((size_t)Nt + 3 * ms + MVCAP) * 8 : 0);
 }
 
 // chain-indexed image of the evolving ladders' temperatures, for the sweep kernels
@@ -706,11 +725,14 @@ static int launch_decide(ptm_engine* e, const double* ll_below, const double* ll
   p.hist = e->hist; p.add_every_n = e->cfg.add_every_n; p.nhist = e->nhist;
   p.naccept = e->naccept; p.ntries = e->ntries; p.last_type = e->last_type;
   p.map = e->map;
-  p.evolve_rate = e->evolve_rate; p.beta_w = e->beta_w;
+  p.evolve_rate = e->evolve_rate; p.beta_w = e->beta_w; p.beta_add = e->beta_add;
   const int WN = e->nloc + (ll_below ? 1 : 0) + p.H;
-  const size_t lds = decide_lds_bytes(e->Nt, e->ms, WN, e->evolve_rate > 0);
+  const bool evb = e->evolve_rate > 0 && e->beta_add;
+  const size_t lds = decide_lds_bytes(e->Nt, e->ms, WN, e->evolve_rate > 0, evb);
   if (lds > 160 * 1024) return fail(PTM_ERR_UNSUPPORTED, "ladder too long for the LDS-resident exchange kernel (%zu B)", lds);
-  const bool wide = (double)e->ms * WN / e->Nt > 96.0;   // expected candidates inside the window
+  // expected candidates inside the window; evolving ladders with history / MAP tracking: the wide form alone carries the
+  // saved rows' temperatures through its own row moves
+  const bool wide = (double)e->ms * WN / e->Nt > 96.0 || evb;
   if (lds > 64 * 1024) {
     HIPCHK(hipFuncSetAttribute((const void*)decide_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     HIPCHK(hipFuncSetAttribute((const void*)decide_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -778,8 +800,9 @@ static int reset_counters(ptm_engine* e) {
   }
   if (e->hist.rungs) {   // history row 0 = the initial state (chain.cc:871-875)
     HIPCHK(hipMemsetAsync(e->hist.meta, 0xFF, (size_t)e->hist.cap * e->hist.HC * sizeof(int4), e->stream));
+    if (e->hist.beta && !e->have_ladder) return fail(PTM_ERR_INVALID, "set the ladder before the states (ptm_set_ladder)");
     hipLaunchKernelGGL(hist_init_kernel, dim3((e->hist.HC + 255) / 256), dim3(256), 0, e->stream, e->hist, e->DP, e->x, e->ll, e->lp,
-                       e->naccept, e->ntries, e->last_type);
+                       e->naccept, e->ntries, e->last_type, e->beta, e->betaC, e->W, e->r0);
     HIPCHK(hipGetLastError());
   }
   return PTM_OK;

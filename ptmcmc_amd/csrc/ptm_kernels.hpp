@@ -52,11 +52,15 @@ struct Hist {
   int rungs, cap, HC;   // rungs == 0: off; HC = rungs * W chains
   double *x, *ll, *lp;
   int4* meta;
+  double* beta;         // [slot][c] the chain's inverse temperature when the row was saved (MH_chain::invtemps,
+                        // chain.cc:943) -- kept only once the ladders evolve (else null: the ladder says it)
 };
 __device__ __forceinline__ size_t hist_slot(const Hist& h, long long row, int c) { return (size_t)(row % h.cap) * h.HC + c; }
-__device__ __forceinline__ void hist_scalars(const Hist& h, size_t o, long long row, double ll, double lp, int nacc, int ntry, int type) {
+__device__ __forceinline__ void hist_scalars(const Hist& h, size_t o, long long row, double ll, double lp, int nacc, int ntry, int type,
+                                             double beta) {
   h.ll[o] = ll; h.lp[o] = lp;
   h.meta[o] = make_int4(nacc, ntry, type, (int)row);
+  if (h.beta) h.beta[o] = beta;
 }
 
 // Optional MAP tracking of the first `rungs` local rungs: MH_chain::add_state keeps the state of the largest log-posterior
@@ -100,6 +104,8 @@ struct Dev {
   const double* beta;      // [Nt] global
   const double* betaC;     // [Nc] per-chain inverse temperatures once the ladders evolve (evolve_temps), else null; the
                            // SIMPLE / GEN 0 / GEN 1 builds never see it
+  const double* beta_add;  // [Nc] evolving ladders with history / MAP tracking: the inverse temperature a rung touched by the
+                           // exchange phase had at its LAST add_state of that phase (between two pries of the step)
   const double* prop;      // [nloc][prop_stride]  factor, dense column-major [col][row] (DP*DP), or sigmas (DP)
   // operand images of the MFMA kernel (DP == 32 only, ptm_mfma_kernel.hpp): 64-lane A tiles, and the box in row layout
   const double* prop_tiles;  // [nloc][16][64]  tile (half*4 + slot)*2 + rowtile, lane 16k+i: T[16 rowtile + i][16 half + 4k + slot]
@@ -429,11 +435,12 @@ __global__ __launch_bounds__(256, PTM_SWEEP_WAVES) void sweep_kernel(const Dev p
       const long long row = 1 + (long long)(a / (unsigned int)p.add_every_n);
       const size_t o = hist_slot(p.hist, row, c);
       for (int d = 0; d < DP; ++d) p.hist.x[o * DP + d] = p.x[(size_t)c * DP + d];
-      hist_scalars(p.hist, o, row, p.ll[c], p.lp[c], p.naccept[c], p.ntries[c], p.last_type[c]);
+      hist_scalars(p.hist, o, row, p.ll[c], p.lp[c], p.naccept[c], p.ntries[c], p.last_type[c],
+                   p.beta_add ? p.beta_add[c] : as_c(p.beta)[rg]);
     }
-    if (rl < p.map.rungs) {   // MAP: the row the last add saw, at this rung's temperature
+    if (rl < p.map.rungs) {   // MAP: the row the last add saw, at the temperature the rung had then
       const double tl = p.ll[c], tp = p.lp[c];
-      const double tb = as_c(p.beta)[rg] * tl;   // (MAP tracking and evolving ladders exclude each other)
+      const double tb = (p.beta_add ? p.beta_add[c] : as_c(p.beta)[rg]) * tl;
       if (map_try(p.map, c, tp + tb, tl, tp))
         for (int d = 0; d < DP; ++d) p.map.x[(size_t)c * DP + d] = p.x[(size_t)c * DP + d];
     }
@@ -573,15 +580,18 @@ __global__ __launch_bounds__(256, PTM_SWEEP_WAVES) void sweep_kernel(const Dev p
     if (accept) {
 #pragma unroll
       for (int d = 0; d < DP; ++d) p.hist.x[o * DP + row_pos<DP>(d)] = xn[d];
-      hist_scalars(p.hist, o, hrow, newlike, newlprior, p.naccept[c] + 1, ntries1, type);
+      hist_scalars(p.hist, o, hrow, newlike, newlprior, p.naccept[c] + 1, ntries1, type, beta);
     } else {
       for (int d = 0; d < DP; ++d) p.hist.x[o * DP + d] = row[d];
-      hist_scalars(p.hist, o, hrow, ll, lp, p.naccept[c], ntries1, p.last_type[c]);
+      hist_scalars(p.hist, o, hrow, ll, lp, p.naccept[c], ntries1, p.last_type[c], beta);
     }
   }
   if (accept && rl < p.map.rungs && map_try(p.map, c, newlpost, newlike, newlprior)) {   // MAP (chain.cc:931-934)
 #pragma unroll
     for (int d = 0; d < DP; ++d) p.map.x[(size_t)c * DP + row_pos<DP>(d)] = xn[d];
+  } else if (!SIMPLE && !accept && p.betaC && rl < p.map.rungs && map_try(p.map, c, cur_lpost, ll, lp)) {
+    // an evolving ladder: the state that stays is added at a NEW temperature and may beat the MAP with it
+    for (int d = 0; d < DP; ++d) p.map.x[(size_t)c * DP + d] = row[d];
   }
   if (accept) {
     p.naccept[c] += 1;

@@ -339,9 +339,13 @@ __global__ __launch_bounds__(256, PTM_MFMA_WAVES) void sweep_mfma32_kernel(const
         const unsigned int a = nhist0 + (unsigned int)tc - 1u;
         if (hist_on && a % (unsigned int)p.add_every_n == 0u) {
           hrow = 1 + (int)(a / (unsigned int)p.add_every_n);
-          hist_scalars(p.hist, hist_slot(p.hist, hrow, c), hrow, ll, lp, naccept0, ntries0, p.last_type[c]);
+          hist_scalars(p.hist, hist_slot(p.hist, hrow, c), hrow, ll, lp, naccept0, ntries0, p.last_type[c],
+                       (GEN == 2 && p.beta_add) ? p.beta_add[c] : beta);
         }
-        if (map_on) { const double tb = beta * ll; mapw = map_try(p.map, c, lp + tb, ll, lp); }
+        if (map_on) {   // at the temperature the rung had at that add (evolving ladders: between two pries of the step)
+          const double tb = ((GEN == 2 && p.beta_add) ? p.beta_add[c] : beta) * ll;
+          mapw = map_try(p.map, c, lp + tb, ll, lp);
+        }
       } else {
         const double bl = beta * ll;
         const double cur_lpost = lp + bl;
@@ -369,10 +373,12 @@ __global__ __launch_bounds__(256, PTM_MFMA_WAVES) void sweep_mfma32_kernel(const
         if (hist_on && nhist0 % (unsigned int)p.add_every_n == 0u) {
           hrow = 1 + (int)(nhist0 / (unsigned int)p.add_every_n);
           const size_t o = hist_slot(p.hist, hrow, c);
-          if (accept) hist_scalars(p.hist, o, hrow, newlike, newlprior, naccept0 + 1, ntries0 + 1, type);
-          else hist_scalars(p.hist, o, hrow, ll, lp, naccept0, ntries0 + 1, p.last_type[c]);
+          if (accept) hist_scalars(p.hist, o, hrow, newlike, newlprior, naccept0 + 1, ntries0 + 1, type, beta);
+          else hist_scalars(p.hist, o, hrow, ll, lp, naccept0, ntries0 + 1, p.last_type[c], beta);
         }
         if (map_on && accept) mapw = map_try(p.map, c, newlpost, newlike, newlprior);
+        // an evolving ladder: the state that stays is added at a NEW temperature and may beat the MAP with it
+        else if (map_on && GEN == 2 && p.betaC) mapw = map_try(p.map, c, cur_lpost, ll, lp);
         if (accept) {
           p.naccept[c] = naccept0 + 1;
           p.last_type[c] = type;

@@ -25,7 +25,7 @@ EXPORTS = [
     "ptm_set_bounds", "ptm_set_prior", "ptm_set_target_gaussian", "ptm_set_target_callback", "ptm_set_ladder", "ptm_set_evolve_temps", "ptm_get_invtemps", "ptm_set_invtemps",
     "ptm_set_proposals", "ptm_set_proposal_rung", "ptm_set_proposal_mixture", "ptm_set_states", "ptm_init_from_prior", "ptm_sweep", "ptm_step", "ptm_sync",
     "ptm_copy_llike", "ptm_llike_device_ptr", "ptm_exchange_decide", "ptm_exchange_finish_and_sweep", "ptm_exchange_install", "ptm_sweep_rungs", "ptm_exchange_buffer_doubles", "ptm_exchange_row_capacity", "ptm_get_states",
-    "ptm_get_array", "ptm_get_swap_counts", "ptm_get_last_swaps", "ptm_max_swaps_per_step", "ptm_get_history", "ptm_get_map", "ptm_restore", "ptm_step_count",
+    "ptm_get_array", "ptm_get_swap_counts", "ptm_get_last_swaps", "ptm_max_swaps_per_step", "ptm_get_history", "ptm_get_history_invtemps", "ptm_get_map", "ptm_restore", "ptm_step_count",
     "ptm_timer_start", "ptm_timer_stop", "ptm_get_kernel_times", "ptm_sweep_kernel_name", "ptm_debug_eval",
     "ptm_debug_philox", "ptm_debug_boxmuller", "ptm_debug_sqrt_scan", "ptm_debug_evaluate",
     "ptm_dev_alloc", "ptm_dev_free", "ptm_dev_copy",
@@ -105,6 +105,7 @@ def load():
     L.ptm_exchange_buffer_doubles.argtypes = [C.c_void_p]
     L.ptm_exchange_row_capacity.argtypes = [C.c_void_p]
     L.ptm_get_history.argtypes = [C.c_void_p, _dp, _dp, _dp, _i32p]
+    L.ptm_get_history_invtemps.argtypes = [C.c_void_p, _dp]
     L.ptm_get_map.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp]
     L.ptm_set_proposal_rung.argtypes = [C.c_void_p, C.c_int, _dp, C.c_double]
     L.ptm_set_proposal_mixture.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp]
@@ -366,14 +367,17 @@ class Engine:
 
     def history(self):
         """dict of arrays [cap][history_rungs*W](,D): x, llike, lprior, naccept, ntries, last_type, row (saved row number,
-        -1 = empty slot); saved row s of a chain sits in slot s % cap"""
+        -1 = empty slot), invtemp (the temperature the row was saved at); saved row s of a chain sits in slot s % cap"""
         n = self.hist_cap * self.hist_rungs * self.W
         X = np.empty((n, self.D)); ll = np.empty(n); lp = np.empty(n); meta = np.empty((n, 4), dtype=np.int32)
         _chk(self.L.ptm_get_history(self.h, X.ctypes.data_as(_dp), ll.ctypes.data_as(_dp), lp.ctypes.data_as(_dp),
                                     meta.ctypes.data_as(_i32p)))
         sh = (self.hist_cap, self.hist_rungs * self.W)
+        b = np.empty(n)
+        _chk(self.L.ptm_get_history_invtemps(self.h, b.ctypes.data_as(_dp)))
         return dict(x=X.reshape(sh + (self.D,)), llike=ll.reshape(sh), lprior=lp.reshape(sh), naccept=meta[:, 0].reshape(sh),
-                    ntries=meta[:, 1].reshape(sh), last_type=meta[:, 2].reshape(sh), row=meta[:, 3].reshape(sh))
+                    ntries=meta[:, 1].reshape(sh), last_type=meta[:, 2].reshape(sh), row=meta[:, 3].reshape(sh),
+                    invtemp=b.reshape(sh))
 
     @property
     def exchange_row_capacity(self):

@@ -484,6 +484,7 @@ class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:
   std::vector<double> hx, hl, hp;       // host copy of the history ring (dumpChain)
   std::vector<int32_t> hmeta;
   std::vector<int64_t> hnhist;
+  std::vector<double> hb;
   std::vector<proposal_distribution*> props;
 
   class rung_view : public chain {
@@ -497,7 +498,7 @@ class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:
     state getState(int = -1, bool = false) override { p->refresh(); return state(p->sp, std::vector<double>(p->X.begin() + at() * p->dim, p->X.begin() + (at() + 1) * p->dim)); }
     double getLogPost(int = -1, bool = false) override { p->refresh(); return p->lpost[at()]; }
     double getLogLike(int = -1, bool = false) override { p->refresh(); return p->llike[at()]; }
-    double invTemp() override { return 1 / p->temps[i]; }
+    double invTemp() override { return p->cur_beta(i, w); }
     int getStep() override { return p->nstep; }
     double getMAPlpost() override { p->refresh_map(); return p->mlpost[at()]; }
     state getMAPstate() override { p->refresh_map(); return state(p->sp, std::vector<double>(p->mX.begin() + at() * p->dim, p->mX.begin() + (at() + 1) * p->dim)); }
@@ -512,8 +513,20 @@ class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:
     ptm_check(ptm_get_map(eng, mX.data(), mlpost.data(), nullptr, nullptr), "parallel_tempering_chains");
     map_fresh = true;
   }
+  // evolve_temps (chain.hh:302-307): each replica's ladder owns its temperatures; betas [W][Ntemps] is their host copy
+  double ev_rate = 0, ev_cut = -1;
+  std::vector<double> betas;
+  double cur_beta(int i, int w) {
+    if (!(ev_rate > 0)) return 1 / temps[i];
+    refresh();
+    return betas[(size_t)w * Ntemps + i];
+  }
   void refresh() {
     if (fresh) return;
+    if (ev_rate > 0) {
+      betas.resize((size_t)W * Ntemps);
+      ptm_check(ptm_get_invtemps(eng, betas.data()), "parallel_tempering_chains");
+    }
     ptm_check(ptm_get_states(eng, X.data()), "parallel_tempering_chains");
     ptm_check(ptm_get_array(eng, PTM_ARR_LLIKE, llike.data()), "parallel_tempering_chains");
     ptm_check(ptm_get_array(eng, PTM_ARR_LPOST, lpost.data()), "parallel_tempering_chains");
@@ -550,6 +563,14 @@ class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:
     if (Ntemps > 0) { directions[0] = -1; directions[Ntemps - 1] = 1; }
     if (Ntemps == 1) directions[0] = -1;
   }
+  // parallel_tempering_chains::evolve_temps (chain.hh:302-307): after every accepted exchange the gap between the two
+  // temperatures is pried apart by (1 + rate) and the ladder renormalised (pry_temps, chain.cc:1501-1518,1809-1846).
+  // Before or after initialize().  The posterior-ordering cut (lpost_cut >= 0) is not built.
+  bool evolve_temps(double rate = 0.01, double lpost_cut = -1) {
+    ev_rate = rate; ev_cut = lpost_cut;
+    if (eng) { ptm_check(ptm_set_evolve_temps(eng, ev_rate, ev_cut), "evolve_temps"); fresh = false; }
+    return true;
+  }
   const std::vector<int>& getInstances() const { return instances; }
   const std::vector<int>& getDirections() const { return directions; }
   // parallel_tempering_chains::dumpTempStats (chain.cc:2025-2040): T, up fraction, swap acceptance of the pair above
@@ -562,7 +583,7 @@ class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:
       if (i == 0) up_frac = 1;
       else if (i == Ntemps - 1) up_frac = 0;
       else up_frac = tracking ? ups[i] / (double)(ups[i] + downs[i]) : 0.0 / 0.0;
-      os << temps[i] << " " << up_frac << " ";
+      os << 1 / cur_beta(i, 0) << " " << up_frac << " ";
       if (i < Ntemps - 1) os << acc[i] / (double)tries[i] << ": ";
       os << std::endl;
     }
@@ -596,6 +617,7 @@ class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:
     std::vector<double> beta(Ntemps);
     for (int i = 0; i < Ntemps; i++) beta[i] = 1 / temps[i];  // chain.cc:1340
     ptm_check(ptm_set_ladder(eng, beta.data()), "set_ladder");
+    if (ev_rate > 0) ptm_check(ptm_set_evolve_temps(eng, ev_rate, ev_cut), "evolve_temps");
     X.assign((size_t)Ntemps * W * dim, 0.0); llike.assign((size_t)Ntemps * W, 0.0); lpost.assign((size_t)Ntemps * W, 0.0);
     if (start_states) {
       ptm_check(ptm_set_states(eng, start_states->data(), nullptr), "set_states");
@@ -675,8 +697,9 @@ class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:
     if (hist_rows <= 0) { std::cout << "parallel_tempering_chains::dumpChain: call keep_history(rows) before initialize()" << std::endl; exit(1); }
     const size_t HC = (size_t)Ntemps * W, cap = hist_rows, at = (size_t)ichain * W + replica;
     if (!hist_fresh) {   // one read-back serves every rung / replica dumped at this step
-      hx.resize(cap * HC * dim); hl.resize(cap * HC); hp.resize(cap * HC); hmeta.resize(cap * HC * 4); hnhist.resize(HC);
+      hx.resize(cap * HC * dim); hl.resize(cap * HC); hp.resize(cap * HC); hmeta.resize(cap * HC * 4); hnhist.resize(HC); hb.resize(cap * HC);
       ptm_check(ptm_get_history(eng, hx.data(), hl.data(), hp.data(), hmeta.data()), "dumpChain");
+      ptm_check(ptm_get_history_invtemps(eng, hb.data()), "dumpChain");   // the temperature each row was saved at
       ptm_check(ptm_get_array(eng, PTM_ARR_NHIST, hnhist.data()), "dumpChain");
       hist_fresh = true;
     }
@@ -687,13 +710,13 @@ class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:
     for (int i = 0; i < dim; i++) os << (sp ? sp->get_name(i) : std::string("[unnamed]")) << " ";
     os << std::endl;
     if (Nburn + Ninit < 0) Nburn = -Ninit;
-    const double invtemp = 1 / temps[ichain];
+    const double invtemp = cur_beta(ichain, replica);   // the chain's CURRENT temperature on every row (chain.cc:1131)
     for (int i = Nburn; i < Nhist; i += ievery) {
       int idx = Ninit + i;                                          // chain.cc:1124-1125
       if (i >= 0) idx = Ninit + i / add_every_N;                    // get_state_idx, chain.cc:1041-1050 (Nzero = 0)
       const size_t o = (size_t)(idx % (int)cap) * HC + at;
       if (idx < 0 || meta[4 * o + 3] != idx) continue;              // not saved yet / overwritten in the ring
-      const double lpo = hp[o] + invtemp * hl[o];                   // chain.cc:928
+      const double lpo = hp[o] + hb[o] * hl[o];                     // chain.cc:928, at the temperature of that add_state
       os << i << " " << lpo << " " << hl[o] << " " << meta[4 * o] / (double)meta[4 * o + 1] << " " << meta[4 * o + 2] << ": ";
       for (int j = 0; j < dim - 1; j++) os << hx[o * dim + j] << " ";
       os << hx[o * dim + dim - 1];
@@ -716,7 +739,7 @@ class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:
     std::ostringstream s;
     for (int i = 0; i < Ntemps; i++) {   // replica 0
       const size_t c = (size_t)i * W;
-      s << "T=" << temps[i] << ": lpost=" << lpost[c] << " llike=" << llike[c] << " acc=" << (double)na[c] / nt[c] << "\n";
+      s << "T=" << 1 / cur_beta(i, 0) << ": lpost=" << lpost[c] << " llike=" << llike[c] << " acc=" << (double)na[c] / nt[c] << "\n";
     }
     return s.str();
   }
@@ -730,7 +753,7 @@ class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:
     const size_t c = (size_t)ichain * W + replica;
     os << nstep << " " << lpost[c] << " " << llike[c] << " " << (double)na[c] / nt[c] << " " << ty[c] << ": ";
     for (int j = 0; j < dim; j++) os << X[c * dim + j] << " ";
-    os << 1 / temps[ichain] << std::endl;
+    os << cur_beta(ichain, replica) << std::endl;
   }
 };
 
@@ -748,6 +771,7 @@ class ptmcmc_sampler {
     opt["nsteps"] = "5000"; opt["save_every"] = "10"; opt["nevery"] = "1000"; opt["pt"] = "20"; opt["pt_swap_rate"] = "0.10";
     opt["pt_Tmax"] = "1e9"; opt["chain_dprior_min"] = "-30"; opt["seed"] = "-1"; opt["outname"] = "mcmc_output";
     opt["nskip"] = "10"; opt["pt_dump_n"] = "1"; opt["nchains"] = "1";
+    opt["pt_evolve_rate"] = "0.01"; opt["pt_evolve_lpost_cut"] = "-1";   // ptmcmc.cc:389-390: the ladder evolves by default
   }
   void set(const std::string& name, const std::string& value) { opt[name] = value; }
   bool parse(int argc, char* argv[]) {  // --name=value / --name (options.hh semantics)
@@ -769,6 +793,7 @@ class ptmcmc_sampler {
     // interval saves (up to two add_state calls per step, every save_every-th saved)
     cc->keep_history(2 + 2 * (int)num("nevery") / std::max(1, (int)num("save_every")));
     cc->set_replicas((int)num("nchains"));   // the reference's Nchain repeats, all at once
+    if (num("pt_evolve_rate") > 0) cc->evolve_temps(num("pt_evolve_rate"), num("pt_evolve_lpost_cut"));   // ptmcmc.cc:512
     uint64_t seed = num("seed") >= 0 ? (uint64_t)(num("seed") * 4294967296.0) : 0x5EED0001ull;
     cc->initialize(chain_llike, chain_prior, 1, seed);
     cc->set_proposal(*cprop);

@@ -53,7 +53,7 @@ class _PT(C.Structure):
                 ("last_pairs", _ip), ("last_accept", _ip), ("touched", C.POINTER(C.c_uint8)),
                 ("hist_cap", C.c_int), ("hist_x", _dp), ("hist_ll", _dp), ("hist_lp", _dp),
                 ("hist_nacc", C.POINTER(C.c_int32)), ("hist_ntry", C.POINTER(C.c_int32)), ("hist_type", C.POINTER(C.c_int32)),
-                ("map_lpost", _dp), ("map_x", _dp), ("evolve_rate", C.c_double), ("betaw", _dp)]
+                ("map_lpost", _dp), ("map_x", _dp), ("evolve_rate", C.c_double), ("betaw", _dp), ("hist_beta", _dp)]
 
 
 _lib = None
@@ -334,7 +334,8 @@ class Ladder:
     def history(self):
         """dict of arrays [N][cap](,D): x, llike, lprior, naccept, ntries, last_type (oracle chain order w*Nt + r)"""
         c, cap = self.s.contents, self.s.contents.hist_cap
-        return dict(x=self._arr(c.hist_x, (self.N, cap, self.D), np.float64), llike=self._arr(c.hist_ll, (self.N, cap), np.float64),
+        return dict(invtemp=self._arr(c.hist_beta, (self.N, cap), np.float64),
+                    x=self._arr(c.hist_x, (self.N, cap, self.D), np.float64), llike=self._arr(c.hist_ll, (self.N, cap), np.float64),
                     lprior=self._arr(c.hist_lp, (self.N, cap), np.float64), naccept=self._arr(c.hist_nacc, (self.N, cap), np.int64),
                     ntries=self._arr(c.hist_ntry, (self.N, cap), np.int64), last_type=self._arr(c.hist_type, (self.N, cap), np.int64))
 

@@ -93,7 +93,7 @@ def test_sampler_driver_writes_the_reference_chain_files():
     with tempfile.TemporaryDirectory() as d:
         exe, base = os.path.join(d, "ex2"), os.path.join(d, "run")
         build(exe, "example_sampler.cc")
-        r = subprocess.run([exe, base], capture_output=True, text=True, timeout=600)
+        r = subprocess.run([exe, base, "--pt_evolve_rate=0"], capture_output=True, text=True, timeout=600)   # fixed ladder
         assert r.returncode == 0, r.stdout + r.stderr
         for ich, beta_expect in ((0, 1.0), (1, 50.0 ** (-1 / 5))):
             lines = open("%s_t%d.dat" % (base, ich)).read().splitlines()
@@ -120,7 +120,7 @@ def test_sampler_replicas_run_side_by_side_and_do_not_change_each_other():
         exe = os.path.join(d, "ex2")
         build(exe, "example_sampler.cc")
         one, many = os.path.join(d, "one"), os.path.join(d, "many")
-        for base, n in ((one, 1), (many, 64)):
+        for base, n in ((one, 1), (many, 64)):   # (the sampler's default: the ladders evolve, pt_evolve_rate = 0.01)
             r = subprocess.run([exe, base, "--nchains=%d" % n, "--nsteps=600", "--nevery=200"], capture_output=True, text=True, timeout=600)
             assert r.returncode == 0, r.stdout + r.stderr
         for ich in (0, 1):
@@ -129,3 +129,39 @@ def test_sampler_replicas_run_side_by_side_and_do_not_change_each_other():
         for w in (1, 17, 63):
             b = open("%s_c%d_t0.dat" % (many, w)).read()
             assert b != a and len(b.splitlines()) > 100
+
+
+@pytest.mark.gpu
+def test_sampler_default_run_evolves_the_ladder():
+    """The sampler's defaults switch temperature evolution on (pt_evolve_rate 0.01, ptmcmc.cc:389,512): every row of a
+    report carries the chain's temperature at the time of the report (chain.cc:1131), the cold chain stays at 1, the
+    next rung's temperature drifts from report to report, and the log-posterior column is the one add_state computed
+    at the temperature the rung had at that very add (lprior + beta*llike with beta between the reports' values)."""
+    with tempfile.TemporaryDirectory() as d:
+        exe, base = os.path.join(d, "ex2"), os.path.join(d, "run")
+        build(exe, "example_sampler.cc")
+        r = subprocess.run([exe, base], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        blocks = {}
+        for ich in (0, 1):
+            cur, out = None, []
+            for l in open("%s_t%d.dat" % (base, ich)).read().splitlines():
+                if l.startswith("#Ninit"):
+                    cur = []
+                    out.append(cur)
+                elif l and not l.startswith("#"):
+                    cur.append([float(v) for v in l.replace(":", " ").split()])
+            blocks[ich] = [np.array(b) for b in out if len(b)]
+        assert all(np.all(b[:, -1] == 1.0) for b in blocks[0])             # the cold chain never moves (chain.cc:1836)
+        b1 = [b[0, -1] for b in blocks[1]]
+        assert all(np.all(b[:, -1] == b[0, -1]) for b in blocks[1])        # one temperature per report ...
+        assert len(set(b1)) == len(b1) and all(0.2 < v < 0.8 for v in b1)  # ... that drifts (start: 50^(-1/5) = 0.457)
+        # lpost - llike*beta_row = lprior (a constant: uniform box) for SOME beta_row between the extremes seen
+        P = np.array([[2.0, 0.6, 0.0], [0.6, 1.0, -0.3], [0.0, -0.3, 1.5]])
+        allrows = np.concatenate(blocks[1])
+        ll = -0.5 * np.einsum("ni,ij,nj->n", allrows[:, 5:8], P, allrows[:, 5:8])
+        assert np.allclose(allrows[:, 2], ll, atol=1e-9)
+        lp0 = blocks[0][0][0, 1] - blocks[0][0][0, 2]                      # cold chain: lpost - llike = lprior
+        big = ll < -0.5
+        brow = (allrows[big, 1] - lp0) / ll[big]
+        assert brow.min() > 0.2 and brow.max() < 0.8 and brow.std() > 1e-4

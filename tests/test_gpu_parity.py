@@ -207,12 +207,18 @@ def test_add_every_n_history_counters():
     eng.close()
 
 
-@pytest.mark.parametrize("D,Nt,W,kind,N,sr", [(32, 8, 64, E.PROP_LOWER, 1, 0.45),    # MFMA kernel, every add saved
-                                              (32, 6, 128, E.PROP_DENSE, 3, 0.45),
-                                              (5, 7, 3, E.PROP_DENSE, 2, 0.45),     # general kernel, ragged sizes
-                                              (16, 12, 64, E.PROP_DIAG, 4, 0.3),
-                                              (4, 900, 64, E.PROP_DIAG, 2, 0.45)])  # > 256 moved rows: the slow exchange path
-def test_history_rows_match_the_oracle(D, Nt, W, kind, N, sr):
+@pytest.mark.parametrize("D,Nt,W,kind,N,sr,ev", [(32, 8, 64, E.PROP_LOWER, 1, 0.45, 0),   # MFMA kernel, every add saved
+                                                 (32, 6, 128, E.PROP_DENSE, 3, 0.45, 0),
+                                                 (5, 7, 3, E.PROP_DENSE, 2, 0.45, 0),    # general kernel, ragged sizes
+                                                 (16, 12, 64, E.PROP_DIAG, 4, 0.3, 0),
+                                                 (4, 900, 64, E.PROP_DIAG, 2, 0.45, 0),  # > 256 moved rows: the slow exchange path
+                                                 # evolving ladders (evolve_temps): rows saved in an exchange phase carry the
+                                                 # temperature their rung had between two pries of that step
+                                                 (32, 8, 64, E.PROP_LOWER, 1, 0.45, 0.03),
+                                                 (5, 7, 3, E.PROP_DENSE, 2, 0.45, 0.05),
+                                                 (16, 40, 64, E.PROP_DIAG, 3, 0.3, 0.01),
+                                                 (4, 900, 64, E.PROP_DIAG, 2, 0.45, 0.01)])
+def test_history_rows_match_the_oracle(D, Nt, W, kind, N, sr, ev):
     """What MH_chain::add_state pushes every add_every_N-th call (chain.cc:935-946): state, llike, lprior, Naccept,
     Ntries, last_type -- including the rows a rung holds BETWEEN two exchanges of one step (quirk Q6)."""
     from ptmcmc_amd.problems import GaussianProblem
@@ -228,15 +234,22 @@ def test_history_rows_match_the_oracle(D, Nt, W, kind, N, sr):
     lad.use_philox(0x5EED0001)
     lad.enable_history(cap)
     lad.set_states(PU.to_oracle_order(x0, Nt, W))
+    if ev:
+        eng.step(2); lad.pt_step(2)          # (rows saved before the ladders evolve keep the common ladder's temperatures)
+        eng.set_evolve_temps(ev); lad.evolve_temps(ev)
+        steps -= 2
     eng.step(steps); eng.sync()
     lad.pt_step(steps)
+    if ev:
+        steps += 2
+        assert np.array_equal(eng.invtemps(), lad.betaw)
     PU.assert_same_state(eng, lad, "after %d steps" % steps)
     he, ho = eng.history(), lad.history()
     nsize = eng.nsize
     assert nsize.max() <= cap and nsize.min() >= 2
     double_adds = int((eng.nhist > steps).sum())
     assert double_adds > 0                                  # some rungs made two add_state calls in one step
-    for name in ("x", "llike", "lprior", "naccept", "ntries", "last_type"):
+    for name in ("x", "llike", "lprior", "naccept", "ntries", "last_type", "invtemp"):
         a = he[name]                                        # [cap][Nt*W] engine order
         b = ho[name]                                        # [N][cap] oracle order
         for s_ in range(int(nsize.max())):
@@ -249,7 +262,11 @@ def test_history_rows_match_the_oracle(D, Nt, W, kind, N, sr):
     m = eng.map()
     assert np.array_equal(m["lpost"], PU.to_engine_order(lad.map_lpost, Nt, W))
     assert np.array_equal(m["x"], PU.to_engine_order(lad.map_x, Nt, W))
-    assert np.all(m["lpost"] >= eng.lpost)
+    if not ev:
+        assert np.all(m["lpost"] >= eng.lpost)
+    else:   # the rows of the exchange phases were saved at temperatures no ladder holds before or after the step
+        hb = he["invtemp"][:int(nsize.min())]
+        assert (np.abs(hb - np.repeat(pr.beta, W)) > 0).any()
     eng.close()
 
 
@@ -429,11 +446,6 @@ def test_evolving_ladders_checkpoint_resume_and_refusals():
     with pytest.raises(E.PtmError):
         a.set_evolve_temps(0.0)          # no way back (nor in the reference)
     a.close(); b.close()
-    c = E.Engine(D, Nt, W, swap_rate=0.4, history_rungs=1, history_capacity=8)
-    pr.configure(c, E.PROP_DENSE)
-    with pytest.raises(E.PtmError):
-        c.set_evolve_temps(0.01)         # history + evolution: not built
-    c.close()
     d = E.Engine(D, Nt, W, swap_rate=0.4)
     pr.configure(d, E.PROP_DENSE)
     with pytest.raises(E.PtmError):

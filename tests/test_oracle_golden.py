@@ -180,6 +180,7 @@ def test_reference_pt_trace(tid):
     assert lad.s.contents.maxswaps == g["maxswaps"]
     lad.set_proposals([(O.PROP_DIAG, np.ones(D), 0.0)] * Nt)   # unused: offsets come from the tape
     lad.use_tape(np.array(g["chain_tapes"]), np.array(g["pt_tape"])[None, :], np.array(g["deltas"]))
+    lad.enable_history(2 * ns + 4)
     lad.set_states(np.array([c["x"] for c in g["init"]]))
     evolve = g.get("evolve_rate", 0.0) > 0
     if evolve:
@@ -201,6 +202,16 @@ def test_reference_pt_trace(tid):
         if evolve:
             want = np.array([c["invtemp"] for c in g["steps"][k]])
             assert np.allclose(lad.betaw[0], want, rtol=1e-12, atol=0), (tid, k, lad.betaw[0] - want)
+    # what every add_state call pushed (MH_chain::lposts / llikes, chain.cc:935-946) -- with an evolving ladder the rows of
+    # an exchange phase carry the log-posterior at the temperature the rung had between two pries of that step
+    h = lad.history()
+    for r in range(Nt):
+        n = len(g["hist_lpost"][r])
+        assert n == lad.nsize[r]
+        for e in range(n):
+            assert close(h["llike"][r, e], g["hist_llike"][r][e]), (tid, r, e)
+            lpo = O.lib().ptmo_lpost(h["lprior"][r, e], h["invtemp"][r, e], h["llike"][r, e])
+            assert close(lpo, g["hist_lpost"][r][e]), (tid, r, e, lpo, g["hist_lpost"][r][e])
     assert nswapped > 5          # the trace really exercised accepted exchanges
     if evolve:
         moved = np.abs(lad.betaw[0] - np.array(g["invtemps"]))[1:-1]
