@@ -201,8 +201,9 @@ int ptm_get_last_swaps(ptm_engine* e, int32_t* pairs, int32_t* accepted);
  * PTM_ARR_LLIKE), the MH_chain counters (PTM_ARR_NTRIES / NACCEPT / LAST_TYPE / NHIST), the step count (the random
  * streams are counters of it) and, for the bookkeeping, the swap counters.  ptm_restore puts them back into an engine
  * configured like the one they came from (same seed, ladder, proposals, target); the run then continues bit for bit.
- * swap_tries / swap_accepts may be NULL (counters restart at 0).  Not built yet: restoring into an engine that keeps a
- * history ring (PTM_ERR_UNSUPPORTED). */
+ * swap_tries / swap_accepts may be NULL (counters restart at 0).  An engine that keeps a history ring or a MAP starts
+ * them afresh from the restored state; ptm_set_history / ptm_set_map (below) put saved ones back, and for an evolving
+ * run ptm_set_evolve_temps + ptm_set_invtemps the ladders. */
 int ptm_restore(ptm_engine* e, const double* X, const double* llike, const int32_t* ntries, const int32_t* naccept,
                 const int32_t* last_type, const int64_t* nhist, uint64_t step_count, const int64_t* swap_tries,
                 const int64_t* swap_accepts);
@@ -216,6 +217,11 @@ int ptm_get_history(ptm_engine* e, double* X, double* llike, double* lprior, int
 /* the inverse temperature each saved row was saved at (MH_chain::invtemps, chain.cc:943), beta[k*HC + index]: the
  * ladder's value while the ladder is fixed, the chain's own once the ladders evolve */
 int ptm_get_history_invtemps(ptm_engine* e, double* beta);
+/* put a saved ring / MAP back (after ptm_restore): the arrays exactly as ptm_get_history (+ ptm_get_history_invtemps;
+ * invtemps may be NULL while the ladder is fixed) and ptm_get_map returned them */
+int ptm_set_history(ptm_engine* e, const double* X, const double* llike, const double* lprior, const int32_t* meta,
+                    const double* invtemps);
+int ptm_set_map(ptm_engine* e, const double* X, const double* lpost, const double* llike, const double* lprior);
 /* MAP of the tracked rungs (ptm_config.map_rungs): chain (local rung r, walker w) at index r*W + w: X[index*dim ..], its
  * log-posterior at the rung's temperature (MH_chain::getMAPlpost / getMAPstate, chain.hh:116-117), llike, lprior.
  * lpost is -1e200 while no valid state was seen.  Any output pointer may be NULL. */

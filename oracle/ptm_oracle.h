@@ -10,7 +10,8 @@
  *   - golden vectors produced by the real reference compiled from /root/reference
  *     (oracle/Makefile target `ref`, generator tests/golden/make_golden.py):
  *     boundary::enforce tables, mixed_dist_product::evaluate_log tables, the ladder,
- *     and three full parallel_tempering_chains traces replayed from recorded RNG tapes;
+ *     and six full parallel_tempering_chains traces replayed from recorded RNG tapes (two of them with
+ *     evolve_temps on), every history row's log-posterior included;
  *   - the reference's own golden file test/exampleLISA/exampleLISA_test_0_t0.dat
  *     (31 prior-draw rows: lpost, llike, parameters);
  *   - the Random123 known-answer vectors for Philox4x32-10.

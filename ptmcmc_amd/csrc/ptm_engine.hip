@@ -1113,8 +1113,7 @@ extern "C" int ptm_restore(ptm_engine* e, const double* X, const double* llike, 
                            const int32_t* last_type, const int64_t* nhist, uint64_t step_count, const int64_t* swap_tries,
                            const int64_t* swap_accepts) {
   if (!e || !X || !llike || !ntries || !naccept || !last_type || !nhist) return fail(PTM_ERR_INVALID, "null argument");
-  if (e->hist.rungs || e->map.rungs)
-    return fail(PTM_ERR_UNSUPPORTED, "restoring into an engine that keeps a history ring or a MAP is not built yet (read them out with the checkpoint)");
+  // (a history ring / MAP restart from the restored state here; ptm_set_history / ptm_set_map put saved ones back)
   int rc = ptm_set_states(e, X, llike);   // enforces (a no-op on saved states), recomputes lprior, resets counters
   if (rc) return rc;
   const size_t Nc = e->Nc;
@@ -1132,6 +1131,35 @@ extern "C" int ptm_restore(ptm_engine* e, const double* X, const double* llike, 
   if (!swap_tries) HIPCHK(hipMemsetAsync(e->swap_try, 0, np * 8, e->stream));
   if (!swap_accepts) HIPCHK(hipMemsetAsync(e->swap_acc, 0, np * 8, e->stream));
   e->step = step_count;
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return PTM_OK;
+}
+
+extern "C" int ptm_set_map(ptm_engine* e, const double* X, const double* lpost, const double* llike, const double* lprior) {
+  if (!e || !X || !lpost || !llike || !lprior) return fail(PTM_ERR_INVALID, "null argument");
+  if (!e->map.rungs) return fail(PTM_ERR_INVALID, "MAP tracking is off (ptm_config.map_rungs)");
+  const size_t n = (size_t)e->map.MC;
+  const std::vector<double> rows = pad_rows(X, n, e->D, e->DP);
+  int rc;
+  if ((rc = upload(e->map.x, rows.data(), rows.size(), e->stream)) || (rc = upload(e->map.lpost, lpost, n, e->stream)) ||
+      (rc = upload(e->map.ll, llike, n, e->stream)) || (rc = upload(e->map.lp, lprior, n, e->stream)))
+    return rc;
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return PTM_OK;
+}
+
+extern "C" int ptm_set_history(ptm_engine* e, const double* X, const double* llike, const double* lprior, const int32_t* meta,
+                               const double* invtemps) {
+  if (!e || !X || !llike || !lprior || !meta) return fail(PTM_ERR_INVALID, "null argument");
+  if (!e->hist.rungs) return fail(PTM_ERR_INVALID, "history is off (ptm_config.history_rungs)");
+  if (e->hist.beta && !invtemps) return fail(PTM_ERR_INVALID, "an evolving run's history needs the rows' temperatures (ptm_get_history_invtemps)");
+  const size_t n = (size_t)e->hist.cap * e->hist.HC;
+  const std::vector<double> rows = pad_rows(X, n, e->D, e->DP);
+  int rc;
+  if ((rc = upload(e->hist.x, rows.data(), rows.size(), e->stream)) || (rc = upload(e->hist.ll, llike, n, e->stream)) ||
+      (rc = upload(e->hist.lp, lprior, n, e->stream)) || (rc = upload((int*)e->hist.meta, (const int*)meta, 4 * n, e->stream)))
+    return rc;
+  if (e->hist.beta && (rc = upload(e->hist.beta, invtemps, n, e->stream))) return rc;
   HIPCHK(hipStreamSynchronize(e->stream));
   return PTM_OK;
 }

@@ -25,7 +25,7 @@ EXPORTS = [
     "ptm_set_bounds", "ptm_set_prior", "ptm_set_target_gaussian", "ptm_set_target_callback", "ptm_set_ladder", "ptm_set_evolve_temps", "ptm_get_invtemps", "ptm_set_invtemps",
     "ptm_set_proposals", "ptm_set_proposal_rung", "ptm_set_proposal_mixture", "ptm_set_states", "ptm_init_from_prior", "ptm_sweep", "ptm_step", "ptm_sync",
     "ptm_copy_llike", "ptm_llike_device_ptr", "ptm_exchange_decide", "ptm_exchange_finish_and_sweep", "ptm_exchange_install", "ptm_sweep_rungs", "ptm_exchange_buffer_doubles", "ptm_exchange_row_capacity", "ptm_get_states",
-    "ptm_get_array", "ptm_get_swap_counts", "ptm_get_last_swaps", "ptm_max_swaps_per_step", "ptm_get_history", "ptm_get_history_invtemps", "ptm_get_map", "ptm_restore", "ptm_step_count",
+    "ptm_get_array", "ptm_get_swap_counts", "ptm_get_last_swaps", "ptm_max_swaps_per_step", "ptm_get_history", "ptm_get_history_invtemps", "ptm_set_history", "ptm_set_map", "ptm_get_map", "ptm_restore", "ptm_step_count",
     "ptm_timer_start", "ptm_timer_stop", "ptm_get_kernel_times", "ptm_sweep_kernel_name", "ptm_debug_eval",
     "ptm_debug_philox", "ptm_debug_boxmuller", "ptm_debug_sqrt_scan", "ptm_debug_evaluate",
     "ptm_dev_alloc", "ptm_dev_free", "ptm_dev_copy",
@@ -106,6 +106,8 @@ def load():
     L.ptm_exchange_row_capacity.argtypes = [C.c_void_p]
     L.ptm_get_history.argtypes = [C.c_void_p, _dp, _dp, _dp, _i32p]
     L.ptm_get_history_invtemps.argtypes = [C.c_void_p, _dp]
+    L.ptm_set_history.argtypes = [C.c_void_p, _dp, _dp, _dp, _i32p, _dp]
+    L.ptm_set_map.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp]
     L.ptm_get_map.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp]
     L.ptm_set_proposal_rung.argtypes = [C.c_void_p, C.c_int, _dp, C.c_double]
     L.ptm_set_proposal_mixture.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp]
@@ -352,7 +354,8 @@ class Engine:
     def checkpoint(self):
         """everything the run's future depends on (ptm_restore)"""
         t, a = self.swap_counts()
-        return dict(invtemps=self.invtemps() if self._evolving else None, x=self.states(), llike=self.llike, ntries=self.ntries.astype(np.int32), naccept=self.naccept.astype(np.int32),
+        return dict(invtemps=self.invtemps() if self._evolving else None, history=self.history() if self.hist_rungs else None,
+                    map=self.map() if self.map_rungs else None, x=self.states(), llike=self.llike, ntries=self.ntries.astype(np.int32), naccept=self.naccept.astype(np.int32),
                     last_type=self.last_type.astype(np.int32), nhist=self.nhist.astype(np.int64), step=self.step_count,
                     swap_tries=np.ascontiguousarray(t, dtype=np.int64), swap_accepts=np.ascontiguousarray(a, dtype=np.int64))
 
@@ -364,6 +367,14 @@ class Engine:
                                 i64(ck["nhist"]), int(ck["step"]), i64(ck["swap_tries"]), i64(ck["swap_accepts"])))
         if ck.get("invtemps") is not None:   # an evolving run: set_evolve_temps first, then the ladders as they were
             self.set_invtemps(ck["invtemps"])
+        h = ck.get("history")
+        if h is not None and self.hist_rungs:
+            meta = np.ascontiguousarray(np.stack([h["naccept"], h["ntries"], h["last_type"], h["row"]], axis=-1), dtype=np.int32)
+            _chk(self.L.ptm_set_history(self.h, f64(h["x"]), f64(h["llike"]), f64(h["lprior"]), meta.ctypes.data_as(_i32p),
+                                        f64(h["invtemp"])))
+        m = ck.get("map")
+        if m is not None and self.map_rungs:
+            _chk(self.L.ptm_set_map(self.h, f64(m["x"]), f64(m["lpost"]), f64(m["llike"]), f64(m["lprior"])))
 
     def history(self):
         """dict of arrays [cap][history_rungs*W](,D): x, llike, lprior, naccept, ntries, last_type, row (saved row number,

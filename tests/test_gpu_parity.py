@@ -336,6 +336,41 @@ def test_checkpoint_and_resume_continue_bit_for_bit(D, Nt, W, kind):
     a.close(); b.close()
 
 
+@pytest.mark.parametrize("D,Nt,W,kind,ev", [(32, 12, 64, E.PROP_LOWER, 0.0), (6, 9, 5, E.PROP_DENSE, 0.02), (32, 10, 64, E.PROP_DIAG, 0.05)])
+def test_checkpoint_and_resume_with_history_ring_and_map(D, Nt, W, kind, ev):
+    """ptm_restore + ptm_set_history + ptm_set_map (+ ptm_set_invtemps for evolving ladders): the resumed engine's history
+    ring (wrapping), MAP and temperatures equal those of the run that never stopped."""
+    from ptmcmc_amd.problems import GaussianProblem
+    pr = GaussianProblem(D, Nt, 1e3)
+    kw = dict(swap_rate=0.4, add_every_n=2, history_rungs=Nt, history_capacity=12, map_rungs=Nt)
+    def make():
+        e = E.Engine(D, Nt, W, **kw)
+        pr.configure(e, kind)
+        if ev:
+            e.set_evolve_temps(ev)
+        return e
+    a = make()
+    a.init_from_prior()
+    a.step(19); a.sync()
+    ck = a.checkpoint()
+    a.step(21); a.sync()
+    b = make()
+    b.restore(ck)
+    hb0, ha0 = b.history(), ck["history"]
+    assert all(np.array_equal(hb0[k], ha0[k]) for k in ha0)
+    b.step(21); b.sync()
+    assert np.array_equal(a.states(), b.states()) and np.array_equal(a.nhist, b.nhist)
+    ha, hb = a.history(), b.history()
+    for k in ha:
+        assert np.array_equal(ha[k], hb[k]), k
+    assert ha["row"].max() >= 12                       # the ring wrapped
+    ma, mb = a.map(), b.map()
+    for k in ma:
+        assert np.array_equal(ma[k], mb[k]), k
+    assert np.array_equal(a.invtemps(), b.invtemps())
+    a.close(); b.close()
+
+
 @pytest.mark.parametrize("D,W,kind", [(32, 64, E.PROP_LOWER), (6, 5, E.PROP_DENSE), (16, 64, E.PROP_DIAG)])
 def test_one_rung_gets_a_new_proposal_factor_mid_run(D, W, kind):
     """ptm_set_proposal_rung: what user_gaussian_prop::check_update does for one chain (proposal_distribution.cc:406-441);
