@@ -603,7 +603,7 @@ void ptmo_sweep(ptmo_pt* s, const ptmo_problem* pb, const ptmo_proposal* props, 
  * renormalises all the gaps so that they add up to 1 - beta_last again and resets every temperature (pry_temps,
  * chain.cc:1809-1846, lpost_cut < 0).  The same ladder is kept here in lazily normalised form: gaps sp[] and their sum S;
  * a pry is sp[i] *= 1 + rate, S += the increase; the gap a later trial of the step sees is sp[i] / (S / (1 - beta_last)) --
- * the reference's value up to rounding (O(1) per exchange instead of O(Nt); exact same bits until the step's first
+ * (its Metropolis test is taken with both sides multiplied by S) -- the reference's value up to rounding (O(1) per exchange instead of O(Nt); exact same bits until the step's first
  * accepted exchange).  At the end of the step the temperatures are rebuilt from the gaps' prefix sums
  * (ptmo_chunk_prefix), beta_k = 1 - P_k / (total / (1 - beta_last)) as the reference does (invtemp starts at 1).
  * ============================================================================================ */
@@ -661,12 +661,22 @@ static void swap_phase(ptmo_pt* s, const ptmo_rng* rng, int w) {
         if (i + 1 < Nt - 1) bb = 1 - (P0[i + 1] + Db) / nrm;
       }
     }
-    double db = sp ? -(sp[i] / nrm) : s->beta[i + 1] - s->beta[i];
-    double logH = -db * (llb - lla);                                    /* :1463 */
     int accept = 1;
-    if (logH < 0) {
-      double u = rng->pt_uniform(rng->ctx, w, s->step, j, 2);
-      accept = (ptmo_log(u) < logH);                                     /* :1464-1467 */
+    if (sp && npry) {
+      /* log u < logH with logH = (sp[i] / (S / c1)) * (llb - lla), both sides multiplied by S > 0 (no division in the chain
+       * of dependent trials) */
+      double t = (sp[i] * c1) * (llb - lla);
+      if (t < 0) {
+        double u = rng->pt_uniform(rng->ctx, w, s->step, j, 2);
+        accept = (ptmo_log(u) * S < t);
+      }
+    } else {
+      double db = sp ? -sp[i] : s->beta[i + 1] - s->beta[i];            /* (nothing pried yet: the stored temperatures' difference) */
+      double logH = -db * (llb - lla);                                  /* :1463 */
+      if (logH < 0) {
+        double u = rng->pt_uniform(rng->ctx, w, s->step, j, 2);
+        accept = (ptmo_log(u) < logH);                                   /* :1464-1467 */
+      }
     }
     if (accept) {                                                        /* :1487-1492 exchange states, temps stay */
       memcpy(tmp, s->x + a * D, D * sizeof(double));

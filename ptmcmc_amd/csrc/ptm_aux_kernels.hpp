@@ -121,17 +121,27 @@ __global__ __launch_bounds__(DECIDE_THREADS) void decide_kernel(const Decide p) 
   // row per 16-lane group); a longer list (64-thread form only) goes to move_kernel through global memory.
   constexpr int FCAP = DECIDE_THREADS;
   int* lmv = reinterpret_cast<int*>(accf + ((ms + 7) & ~7));                  // [2][MVCAP]
-  // evolving ladders only: gaps (in the end their local prefix sums), chunk totals / offsets, {normaliser, pries}
+  // evolving ladders only: gaps (in the end their local prefix sums), chunk totals / offsets, {normaliser, pries}, and the
+  // surviving picks in PICK ORDER (position t): what the chain of dependent trials needs, laid out for one lane to stream
+  const int msp = (ms + 3) & ~3;
   double* gap = reinterpret_cast<double*>(lmv + 2 * MVCAP);                   // [Nt]
   double* ct = gap + Nt;                                                      // [2][(Nt + 31) / 32]
   double* ev = ct + 2 * ((Nt + 31) / 32);                                     // [2]
-  double* lu = ev + 2;                                                        // [ms]  log of the picks' accept uniforms
+  double* tlu = ev + 2;                                                       // [ms]  log of the pick's accept uniform
+  double* tgap = tlu + msp;                                                   // [ms]  the pick's gap (a pair is tried once: never pried before)
+  double* tlla = tgap + msp;                                                  // [ms]  llike of the lower rung (nothing earlier can change it)
+  double* tllb = tlla + msp;                                                  // [ms]  llike of the upper rung (an earlier pick above may change it)
+  unsigned short* olist = reinterpret_cast<unsigned short*>(tllb + msp);      // [ms]  position -> pick
+  unsigned short* opos = olist + msp;                                         // [ms]  pick -> position
+  unsigned short* ti = opos + msp;                                            // [ms]  the pick's lower rung
+  short* tdep = reinterpret_cast<short*>(ti + msp);                           // [ms]  position of the (later) pick on the pair below, or -1
+  unsigned char* tacc = reinterpret_cast<unsigned char*>(tdep + msp);         // [ms]  accepted
   // ... with history / MAP tracking on top (an add_state of the phase sees the temperature BETWEEN two pries of the step):
-  double* p0 = lu + ms;                                                       // [Nt]  prefix sums of the step's first gaps
-  double* nrmk = p0 + Nt;                                                     // [ms]  normaliser a pick saw (0: nothing pried yet)
-  double* dl = nrmk + ms;                                                     // [ms]  what the pick added to its gap
-  double* bklo = dl + ms;                                                     // [ms]  temperature of the pick's lower rung then
-  double* gb = bklo + ms;                                                     // [MVCAP] temperature for a HIST / MAP move
+  double* p0 = reinterpret_cast<double*>(tacc + ((ms + 7) & ~7));             // [max(Nt, MVCAP)]  prefix sums of the step's first gaps
+  double* tS = p0 + (Nt > MVCAP ? Nt : MVCAP);                                // [ms]  sum of the gaps the pick saw (0: nothing pried yet)
+  double* tdl = tS + msp;                                                     // [ms]  what the pick added to its gap
+  double* bklo = tdl + msp;                                                   // [ms]  (by pick) temperature of the pick's lower rung then
+  double* gb = p0;                                                            // [MVCAP] temperature for a HIST / MAP move (p0 is done by then)
   double* llc = llc_ - wlo;                // indexed by global rung
   unsigned short* perm = perm_ - wlo;
   unsigned short* inv = inv_ - wlo;
@@ -155,10 +165,8 @@ __global__ __launch_bounds__(DECIDE_THREADS) void decide_kernel(const Decide p) 
   const bool evolve = p.evolve_rate > 0 && Nt > 1;
   const bool evb = evolve && p.beta_add != nullptr;   // history / MAP tracking of evolving ladders
   if (evolve) {
-    if (lane < 8 && ms + lane < ((ms + 7) & ~7)) alive[ms + lane] = 0;   // the trial walk reads alive[] eight at a time
     const double* bw = p.beta_w + (size_t)w * Nt;
     for (int k = lane; k < Nt - 1; k += DECIDE_THREADS) gap[k] = bw[k] - bw[k + 1];   // chain.cc:1816
-    for (int k = lane; k < ms; k += DECIDE_THREADS) lu[k] = dlog_u01(ua[k]);         // (own slot: written by this thread above)
   }
   __syncthreads();
   // -- filter (1): run heads walk their run upwards
@@ -205,9 +213,25 @@ __global__ __launch_bounds__(DECIDE_THREADS) void decide_kernel(const Decide p) 
   // -- evolving ladder: every accepted exchange changes the normalisation of ALL the gaps (pry_temps renormalises the
   //    ladder, chain.cc:1829-1844), so the trials are one chain in pick order.  The gaps stay lazily normalised: a pry is
   //    gap[i] *= 1 + rate and S += the increase; the gap a later trial sees is gap[i] / (S / (1 - beta_last)) -- O(1) per
-  //    exchange, and the very bits of the stored temperatures until the step's first accepted exchange.
+  //    exchange, and the very bits of the stored temperatures until the step's first accepted exchange.  The Metropolis
+  //    test is taken with both sides multiplied by S, so the chain of dependent trials holds no division.
   if (evolve) {
     const int nch = (Nt - 1 + 31) / 32;
+    // the surviving picks in pick order (one wave: ballot + prefix count)
+    if (lane < 64) {
+      int base = 0;
+      for (int k0 = 0; k0 < ms; k0 += 64) {
+        const int k = k0 + lane;
+        const bool f = k < ms && alive[k] == 1;
+        const unsigned long long m = __ballot(f);
+        if (f) {
+          const int t = base + __builtin_popcountll(m & ((1ull << lane) - 1ull));
+          olist[t] = (unsigned short)k;
+          opos[k] = (unsigned short)t;
+        }
+        base += __builtin_popcountll(m);
+      }
+    }
     for (int q = lane; q < nch; q += DECIDE_THREADS) {   // S: chunks of 32 left to right, then the chunk totals
       double loc = 0.0;
       for (int k = 32 * q; k < Nt - 1 && k < 32 * q + 32; ++k) {
@@ -217,47 +241,105 @@ __global__ __launch_bounds__(DECIDE_THREADS) void decide_kernel(const Decide p) 
       ct[q] = loc;
     }
     __syncthreads();
+    for (int t = lane; t < nl; t += DECIDE_THREADS) {
+      const int k = olist[t];
+      const int i = cand[k];
+      ti[t] = (unsigned short)i;
+      tlu[t] = dlog_u01(ua[k]);
+      tgap[t] = gap[i];
+      tlla[t] = llc[i];
+      tllb[t] = llc[i + 1];
+      tdep[t] = PTM_ALIVE_RUNG(i - 1) ? (short)opos[first[i - 1]] : (short)-1;
+      tacc[t] = 0;
+    }
+    __syncthreads();
     if (lane == 0) {
       double S = 0.0;
       for (int q = 0; q < nch; ++q) { ct[nch + q] = S; S = S + ct[q]; }
       const double c1 = 1 - p.beta_w[(size_t)w * Nt + Nt - 1];   // chain.cc:1833
       const double grow = 1.0 + p.evolve_rate;
-      double nrm = 1.0;
       int npry = 0;
-      for (int k8 = 0; k8 < ms; k8 += 8) {
-        unsigned long long av = *reinterpret_cast<const unsigned long long*>(alive + k8);
-        while (av) {
-          const int b = __builtin_ctzll(av) >> 3;
-          av &= ~(0xffull << (8 * b));
-          const int kk = k8 + b;
-          const int i = cand[kk];
-          double lla = llc[i];
-          if (!(lla > -1e200)) lla = -1e200;
-          double llb = llc[i + 1];
-          if (!(llb > -1e200)) llb = -1e200;
-          const double db = -(gap[i] / nrm);
-          const double logH = -db * (llb - lla);
-          bool acc = true;
-          if (logH < 0) acc = lu[kk] < logH;
-          if (evb) { nrmk[kk] = npry ? nrm : 0.0; dl[kk] = 0.0; }
-          if (acc) {
-            const double t = llc[i]; llc[i] = llc[i + 1]; llc[i + 1] = t;
-            const unsigned short s_ = perm[i]; perm[i] = perm[i + 1]; perm[i + 1] = s_;
-            accf[kk] = 1;
-            const double sn = gap[i] * grow;   // chain.cc:1829
-            const double inc = sn - gap[i];
-            S = S + inc;
-            gap[i] = sn;
-            nrm = S / c1;
-            ++npry;
-            if (evb) dl[kk] = inc;
-          }
-          if (PTM_ALIVE_RUNG(i - 1)) mid[i] = perm[i];   // the pick below (a later one) exchanges rung i again
+      // one lane streams the picks; the next pick's operands are asked for before this one is decided
+      double n_lu = 0, n_gap = 0, n_lla = 0, n_llb = 0, fwd = 0;
+      int n_dep = -1, n_i = 0, fwd_to = -1;
+      if (nl > 0) { n_lu = tlu[0]; n_gap = tgap[0]; n_lla = tlla[0]; n_llb = tllb[0]; n_dep = tdep[0]; n_i = ti[0]; }
+      for (int t = 0; t < nl; ++t) {
+        const double lu = n_lu, g = n_gap, lla_raw = n_lla, llb_raw = (fwd_to == t) ? fwd : n_llb;
+        const int dep = n_dep, i = n_i;
+        if (t + 1 < nl) { n_lu = tlu[t + 1]; n_gap = tgap[t + 1]; n_lla = tlla[t + 1]; n_llb = tllb[t + 1]; n_dep = tdep[t + 1]; n_i = ti[t + 1]; }
+        double lla = lla_raw;
+        if (!(lla > -1e200)) lla = -1e200;
+        double llb = llb_raw;
+        if (!(llb > -1e200)) llb = -1e200;
+        // log u < logH with logH = (gap / (S / c1)) * (llb - lla), both sides times S > 0: no division on this chain of
+        // dependent trials.  Until the step's first pry the gap is the stored temperatures' own difference.
+        bool acc = true;
+        if (npry) {
+          const double tt = (g * c1) * (llb - lla);
+          if (tt < 0) acc = lu * S < tt;
+        } else {
+          const double logH = g * (llb - lla);
+          if (logH < 0) acc = lu < logH;
+        }
+        if (evb) { tS[t] = npry ? S : 0.0; tdl[t] = 0.0; }
+        if (acc) {
+          tacc[t] = 1;
+          const double sn = g * grow;   // chain.cc:1829
+          const double inc = sn - g;
+          S = S + inc;
+          gap[i] = sn;
+          ++npry;
+          if (evb) tdl[t] = inc;
+          if (dep >= 0) { tllb[dep] = llb_raw; fwd = llb_raw; fwd_to = dep; }   // the row now on rung i came from rung i + 1
         }
       }
       ev[1] = (double)npry;
     }
     __syncthreads();
+  }
+  // -- trials (2): the top pick of each run of surviving rungs walks the run downwards (chain.cc:1436-1537); with an
+  //    evolving ladder the decisions are the ones just taken
+  for (int j = lane; j < nl; j += DECIDE_THREADS) {
+    const int n = cand[list[j]];
+    const bool up = PTM_ALIVE_RUNG(n + 1);
+    if (up && n + 1 < whi) continue;                             // not the top of a run (the pick above is in the list)
+    if (up) {
+      // the pick above decides the pair (whi, whi+1), outside the window, and may replace rung whi: the content of
+      // every rung of this run is then unknown here.  Harmless as long as the run ends above the shard's own rungs.
+      for (int i = n; i >= wlo; --i) {
+        if (i + 1 <= r1) atomicOr(p.err, 2);                     // would decide a local / straddling exchange blindly
+        alive[first[i]] = 2;
+        if (!PTM_ALIVE_RUNG(i - 1)) break;
+      }
+      continue;
+    }
+    for (int i = n; i >= wlo; --i) {                             // below the window nothing concerns us
+      const int kk = first[i];
+      bool acc = true;
+      if (evolve) {
+        acc = tacc[opos[kk]] != 0;
+      } else {
+        double lla = llc[i];
+        if (!(lla > -1e200)) lla = -1e200;
+        double llb = llc[i + 1];
+        if (!(llb > -1e200)) llb = -1e200;
+        const double logH = -(beta[i + 1] - beta[i]) * (llb - lla);
+        if (logH < 0) acc = dlog_u01(ua[kk]) < logH;
+      }
+      if (acc) {
+        // the row that leaves this shard downwards must be one of ours (else it crossed two boundaries in one step)
+        if (i + 1 == p.r0 && (perm[i + 1] < p.r0 || perm[i + 1] >= r1)) atomicOr(p.err, 1);
+        const double t = llc[i]; llc[i] = llc[i + 1]; llc[i + 1] = t;
+        const unsigned short s = perm[i]; perm[i] = perm[i + 1]; perm[i + 1] = s;
+        accf[kk] = 1;
+      }
+      if (!PTM_ALIVE_RUNG(i - 1)) break;
+      mid[i] = perm[i];   // the pick below exchanges rung i again: this is what it held in between
+    }
+  }
+  __syncthreads();
+  if (evolve) {
+    const int nch = (Nt - 1 + 31) / 32;
     if (evb) {
       // The temperature a rung had when a pick's add_state calls reached it (both rungs of the pair, before the pick's own
       // pry; chain.cc:1487-1490,1531-1534): 1 - (P0 + D) / normaliser, P0 = prefix of the step's first gaps, D = what
@@ -269,12 +351,14 @@ __global__ __launch_bounds__(DECIDE_THREADS) void decide_kernel(const Decide p) 
       for (int j = lane; j < nl; j += DECIDE_THREADS) {
         const int k = list[j];
         const int i = cand[k];
+        const int t = opos[k];
         double D = 0.0;
-        for (int k2 = 0; k2 < k; ++k2)
-          if (accf[k2] && cand[k2] < i) D = D + dl[k2];
-        const double nk = nrmk[k];
-        const double blo = (nk == 0.0 || i == 0) ? bw[i] : 1 - (p0[i] + D) / nk;
-        const double bhi = (nk == 0.0 || i + 1 == Nt - 1) ? bw[i + 1] : 1 - (p0[i + 1] + D) / nk;
+        for (int t2 = 0; t2 < t; ++t2)
+          if (tacc[t2] && ti[t2] < i) D = D + tdl[t2];
+        const double Sk = tS[t];
+        const double nk = Sk / (1 - bw[Nt - 1]);   // the normaliser then (chain.cc:1833)
+        const double blo = (Sk == 0.0 || i == 0) ? bw[i] : 1 - (p0[i] + D) / nk;
+        const double bhi = (Sk == 0.0 || i + 1 == Nt - 1) ? bw[i + 1] : 1 - (p0[i + 1] + D) / nk;
         bklo[k] = blo;
         // last add of the phase: always for the upper rung (a pick on the pair above came earlier), for the lower rung
         // unless a later pick exchanges it again
@@ -300,42 +384,6 @@ __global__ __launch_bounds__(DECIDE_THREADS) void decide_kernel(const Decide p) 
       for (int k = 1 + lane; k < Nt - 1; k += DECIDE_THREADS) p.beta_w[(size_t)w * Nt + k] = 1 - (ct[nch + (k >> 5)] + gap[k]) / nn;
     }
   }
-  // -- trials (2): the top pick of each run of surviving rungs walks the run downwards (chain.cc:1436-1537)
-  for (int j = lane; j < (evolve ? 0 : nl); j += DECIDE_THREADS) {
-    const int n = cand[list[j]];
-    const bool up = PTM_ALIVE_RUNG(n + 1);
-    if (up && n + 1 < whi) continue;                             // not the top of a run (the pick above is in the list)
-    if (up) {
-      // the pick above decides the pair (whi, whi+1), outside the window, and may replace rung whi: the content of
-      // every rung of this run is then unknown here.  Harmless as long as the run ends above the shard's own rungs.
-      for (int i = n; i >= wlo; --i) {
-        if (i + 1 <= r1) atomicOr(p.err, 2);                     // would decide a local / straddling exchange blindly
-        alive[first[i]] = 2;
-        if (!PTM_ALIVE_RUNG(i - 1)) break;
-      }
-      continue;
-    }
-    for (int i = n; i >= wlo; --i) {                             // below the window nothing concerns us
-      const int kk = first[i];
-      double lla = llc[i];
-      if (!(lla > -1e200)) lla = -1e200;
-      double llb = llc[i + 1];
-      if (!(llb > -1e200)) llb = -1e200;
-      const double logH = -(beta[i + 1] - beta[i]) * (llb - lla);
-      bool acc = true;
-      if (logH < 0) acc = dlog_u01(ua[kk]) < logH;
-      if (acc) {
-        // the row that leaves this shard downwards must be one of ours (else it crossed two boundaries in one step)
-        if (i + 1 == p.r0 && (perm[i + 1] < p.r0 || perm[i + 1] >= r1)) atomicOr(p.err, 1);
-        const double t = llc[i]; llc[i] = llc[i + 1]; llc[i + 1] = t;
-        const unsigned short s = perm[i]; perm[i] = perm[i + 1]; perm[i + 1] = s;
-        accf[kk] = 1;
-      }
-      if (!PTM_ALIVE_RUNG(i - 1)) break;
-      mid[i] = perm[i];   // the pick below exchanges rung i again: this is what it held in between
-    }
-  }
-  __syncthreads();
   // -- the step's log
 #if !(defined(PTM_DECIDE_ABLATE) && (PTM_DECIDE_ABLATE & 4))
   for (int k = lane; k < ms; k += DECIDE_THREADS)

@@ -703,7 +703,8 @@ static size_t decide_lds_bytes(int Nt, int ms, int WN, bool evolve, bool evb) {
   // mirrors the carve at the top of decide_kernel
   return (size_t)WN * 8 + (size_t)((Nt + 1) & ~1) * 4 + (size_t)((ms + 1) & ~1) * 4 * 2 + 8 + (size_t)((WN + 3) & ~3) * 2 * 3 +
          (size_t)((ms + 3) & ~3) * 2 + (size_t)((ms + 7) & ~7) * 2 + (size_t)2 * MVCAP * 4 + 32 +
-         (evolve ? ((size_t)Nt + 2 * ((Nt + 31) / 32) + 2 + ms) * 8 : 0) + (evb ? ((size_t)Nt + 3 * ms + MVCAP) * 8 : 0);
+         (evolve ? ((size_t)Nt + 2 * ((Nt + 31) / 32) + 2 + 4 * ((ms + 3) & ~3)) * 8 + (size_t)4 * ((ms + 3) & ~3) * 2 + ((ms + 7) & ~7) : 0) +
+         (evb ? ((size_t)(Nt > MVCAP ? Nt : MVCAP) + 3 * ((ms + 3) & ~3)) * 8 : 0);
 }
 
 // chain-indexed image of the evolving ladders' temperatures, for the sweep kernels
