@@ -639,7 +639,8 @@ static SweepSel sweep_sel(const ptm_engine* e) {
   SweepSel s;
   s.kind = e->prop_kind == PTM_PROP_DIAG ? KIND_DIAG : (e->prop_kind == PTM_PROP_LOWER ? KIND_LOWER : KIND_DENSE);
   s.uni = (e->W % 64) == 0;
-  s.simple = s.uni && !e->has_bounds && e->all_uniform && !e->has_mean && !e->any_oned && !e->cb && e->mix_K == 0 && !e->betaC;
+  s.plain = !e->has_bounds && e->all_uniform && !e->has_mean && !e->any_oned && !e->cb && e->mix_K == 0 && !e->betaC;
+  s.simple = s.uni && s.plain;
   s.callback = e->cb != nullptr;
   return s;
 }
@@ -1219,6 +1220,7 @@ extern "C" const char* ptm_sweep_kernel_name(ptm_engine* e) {
   if (e->DP == 32 && s.uni && !s.callback)
     snprintf(b, sizeof b, "sweep_mfma32_kernel<%d, %s, %d>", s.kind == KIND_DIAG ? KIND_LOWER : s.kind, (e->hist.rungs || e->map.rungs) ? "true" : "false",
              s.simple ? 0 : ((e->all_uniform && (!e->has_bounds || e->bounds_box) && !e->betaC) ? 1 : 2));
+  else if (!s.uni && s.plain && e->DP >= 16 && !getenv("PTM_FORCE_VALU") && (long long)e->Nc * e->DP <= PTM_LANES_MAX) snprintf(b, sizeof b, "sweep_lanes_kernel<%d, %d>", e->DP, s.kind);
   else snprintf(b, sizeof b, "sweep_kernel<%d, %d, %s, %s>", e->DP, s.kind, s.uni ? "true" : "false", s.simple ? "true" : "false");
   e->kname = b;
   return e->kname.c_str();

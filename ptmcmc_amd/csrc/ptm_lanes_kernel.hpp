@@ -1,0 +1,196 @@
+// ptm_lanes_kernel.hpp -- the sweep kernel of SMALL populations: one LANE PER DIMENSION of a chain.
+//
+// The general kernel (ptm_kernels.hpp) gives every chain one lane; when a wave's 64 chains do not share a rung (fewer
+// than 64 walkers per rung: the reference's own shape, one ladder of 1024 rungs) there are only a few waves in the
+// whole launch and each lane walks through a chain's ~4000 dependent f64 operations: 80 us per sweep of 1024 chains,
+// all of it latency.  Here a chain's DP dimensions sit on DP adjacent lanes (2 chains per wave at DP = 32, 4 at 16):
+// lane d draws normal d, accumulates row d of factor . z and row d of the precision matrix, and the two reductions
+// (box test, y.s) cross the chain's lanes through LDS.  The arithmetic of every number is the one of the other kernels
+// (same column order, same fma chains, same four interleaved partial sums), so the chains stay bit-identical.
+//
+// Built for the plain workload (open bounds, all-uniform prior, zero mean, no one-dimensional moves, no mixture, device
+// Gaussian target, fixed ladder) -- everything else takes the general kernel.  History and MAP tracking are carried.
+#pragma once
+#include "ptm_kernels.hpp"
+
+namespace ptm {
+
+template <int DP, int KIND>
+__global__ __launch_bounds__(256) void sweep_lanes_kernel(const Dev p) {
+  static_assert(DP == 16 || DP == 32, "lanes kernel: DP 16 or 32");
+  constexpr int CPW = 64 / DP;              // chains per wave
+  constexpr int NP2 = DP * (DP + 1) / 2;    // packed precision matrix
+  extern __shared__ __attribute__((aligned(16))) double lds_all[];
+  double* p2s = lds_all + BM_TABLE_DOUBLES;                     // [NP2 (+pad)]
+  double* wsc = p2s + ((NP2 + 1) & ~1) + (threadIdx.x >> 6) * (3 * 64 + 4 * CPW);   // this wave's scratch
+  double* vbuf = wsc;             // [CPW][DP] z, then y
+  double* sbuf = wsc + 64;        // [CPW][DP] s_i
+  double* tbuf = wsc + 128;       // [CPW][DP] unused tail / flags
+  double* pbuf = wsc + 192;       // [CPW][4]  partial sums
+#pragma unroll
+  for (int t = 0; t < BM_TABLE_DOUBLES / 512; ++t)
+    reinterpret_cast<bm_d2*>(lds_all)[threadIdx.x + 256 * t] = reinterpret_cast<const bm_d2*>(BM_TABLE)[threadIdx.x + 256 * t];
+  for (int k = threadIdx.x; k < NP2; k += 256) p2s[k] = p.P2[k];
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63;
+  const int d = lane % DP, g = lane / DP;
+  int c = p.c_begin + (blockIdx.x * 4 + (threadIdx.x >> 6)) * CPW + g;
+  const bool live = c < p.c_end;
+  if (!live) c = p.c_end - 1;   // dead lanes shadow the last chain and write nothing
+  const int rl = c / p.W;
+  const int w = c - rl * p.W;
+  const int rg = p.r0 + rl;
+  const bool lead = d == 0;
+  const int pos = row_pos<DP>(d);
+  double* __restrict__ row = p.x + (size_t)c * DP;
+  const bool hist_on = rl < p.hist.rungs, map_on = rl < p.map.rungs;
+  auto sync_wave = [] { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); };
+  // a flag of the chain's lead lane, for all its lanes
+  auto from_lead = [&](int v) { return __builtin_amdgcn_ds_bpermute(4 * (g * DP), v); };
+
+  const int tc = p.touch[c];  // > 0: the rung took part in that many exchange attempts => no MH move this step
+  if (tc) {
+    // one add_state per attempt (chain.cc:1487-1490,1531-1534,1554-1557); the LAST of them saw the row as it is now
+    const unsigned int nh0 = p.nhist[c];
+    const unsigned int a = nh0 + (unsigned int)tc - 1u;
+    if (hist_on && a % (unsigned int)p.add_every_n == 0u) {
+      const long long hrow = 1 + (long long)(a / (unsigned int)p.add_every_n);
+      const size_t o = hist_slot(p.hist, hrow, c);
+      if (live) p.hist.x[o * DP + d] = row[d];
+      if (live && lead) hist_scalars(p.hist, o, hrow, p.ll[c], p.lp[c], p.naccept[c], p.ntries[c], p.last_type[c], p.beta[rg]);
+    }
+    int mapw = 0;
+    if (map_on && lead && live) {
+      const double tl = p.ll[c], tp = p.lp[c];
+      const double tb = p.beta[rg] * tl;
+      mapw = map_try(p.map, c, tp + tb, tl, tp) ? 1 : 0;
+    }
+    if (map_on) {
+      mapw = from_lead(mapw);
+      if (mapw && live) p.map.x[(size_t)c * DP + d] = row[d];
+    }
+  }
+
+  // ---- MH_chain::step (chain.cc:966-1022); touched chains run along (their lanes would idle anyway) and write nothing
+  const uint32_t stream = (uint32_t)w * (uint32_t)p.Nt + (uint32_t)rg;
+  const u32x4 o0 = draw_block(p.seed, TAG_MH, stream, p.step, 0);
+  // normal d: slot d & 3 of Philox block 1 + d / 4 (two Box-Muller pairs per block)
+  double zd;
+  {
+    const u32x4 o = draw_block(p.seed, TAG_MH, stream, p.step, (uint32_t)((d >> 2) + 1));
+    const bool hi = (d & 2) != 0;
+    double z0, z1;
+    boxmuller(hi ? o.v2 : o.v0, hi ? o.v3 : o.v1, lds_all, z0, z1);
+    zd = (d & 1) ? z1 : z0;
+  }
+  // -- gaussian_prop::draw (proposal_distribution.hh:194-218): offset = factor * z, row d on lane d
+  double off;
+  if (KIND == KIND_DIAG) {
+    off = p.prop[(size_t)rl * p.prop_stride + d] * zd;
+  } else {
+    vbuf[g * DP + d] = zd;
+    const double* fac = p.prop + (size_t)rl * p.prop_stride + d;   // column-major [col][row]: T[d][j] at j * DP + d
+    double tcol[DP];
+#pragma unroll
+    for (int j = 0; j < DP; ++j) tcol[j] = fac[j * DP];
+    sync_wave();
+    double acc = 0.0;
+    // the shared column order: halves of 16 columns, inside a half s + 4k with s outer, k inner
+#pragma unroll
+    for (int h = 0; h < DP / 16; ++h)
+#pragma unroll
+      for (int sl = 0; sl < 4; ++sl)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int j = 16 * h + 4 * k + sl;
+          acc = __builtin_fma(tcol[j], vbuf[g * DP + j], acc);
+        }
+    off = acc;
+    sync_wave();   // vbuf is reused below
+  }
+  const double ll = p.ll[c], lp = p.lp[c];
+  const double xn = row[pos] + off;   // state::add (states.cc:205-214)
+  const double beta = p.beta[rg];
+  const double bl = beta * ll;
+  const double cur_lpost = lp + bl;
+  const double oldlprior = cur_lpost - bl;  // chain.cc:973
+  // -- the box of the all-uniform prior: every dimension of the chain inside
+  const bool okd = !(xn < p.plo[d]) && !(xn > p.phi[d]);
+  const unsigned long long okm = __builtin_amdgcn_ballot_w64(okd);
+  constexpr unsigned long long GM = DP == 32 ? 0xFFFFFFFFull : 0xFFFFull;
+  const bool in = ((okm >> (g * DP)) & GM) == GM;
+  const double newlprior = in ? p.lprior_const : -__builtin_inf();
+  const bool want_like = newlprior > -1e200 || newlprior - oldlprior > p.min_prior;  // chain.cc:980 (Q1)
+  // -- Gaussian likelihood: s_d = sum_{j<d} 2P_dj y_j + P_dd y_d (one fma chain, j ascending), then y.s in four interleaved
+  //    partial sums p_q = sum_{i = q mod 4} y_i s_i (i ascending), combined ((p0 + p1) + p2) + p3
+  vbuf[g * DP + d] = xn;
+  sync_wave();
+  {
+    const double* prow = p2s + d * (d + 1) / 2;
+    const double* y = vbuf + g * DP;
+    double s = 0.0;
+    for (int j = 0; j <= d; ++j) s = __builtin_fma(prow[j], y[j], s);
+    sbuf[g * DP + d] = s;
+  }
+  sync_wave();
+  if (d < 4) {
+    double pq = 0.0;
+#pragma unroll
+    for (int i = d; i < DP; i += 4) pq = __builtin_fma(vbuf[g * DP + i], sbuf[g * DP + i], pq);
+    pbuf[g * 4 + d] = pq;
+  }
+  sync_wave();
+  const double quad = ((pbuf[g * 4 + 0] + pbuf[g * 4 + 1]) + pbuf[g * 4 + 2]) + pbuf[g * 4 + 3];
+  double newlike = p.like0 - 0.5 * quad;
+  double newlpost = newlike * beta + newlprior;
+  if (!want_like) newlike = newlpost = -__builtin_inf();
+  const double logH = newlpost - cur_lpost;  // gaussian_prop: log_hastings_ratio() == 0
+  bool accept = true;
+  if (logH < 0) accept = dlog_u01(o0.v0) < logH;  // chain.cc:998-1001 (NaN stays accepted)
+  (void)tbuf;
+
+  const bool act = live && !tc;
+  int mapw = 0;
+  if (act) {
+    const int ntries1 = p.ntries[c] + 1;
+    const unsigned int nh0 = p.nhist[c];
+    const int nacc0 = p.naccept[c];
+    if (hist_on && nh0 % (unsigned int)p.add_every_n == 0u) {   // add_state saves this one (chain.cc:935-946)
+      const long long hrow = 1 + (long long)(nh0 / (unsigned int)p.add_every_n);
+      const size_t o = hist_slot(p.hist, hrow, c);
+      if (accept) p.hist.x[o * DP + pos] = xn;
+      else p.hist.x[o * DP + d] = row[d];
+      if (lead) {
+        if (accept) hist_scalars(p.hist, o, hrow, newlike, newlprior, nacc0 + 1, ntries1, 0, beta);
+        else hist_scalars(p.hist, o, hrow, ll, lp, nacc0, ntries1, p.last_type[c], beta);
+      }
+    }
+    if (map_on && lead && accept) mapw = map_try(p.map, c, newlpost, newlike, newlprior) ? 1 : 0;   // MAP (chain.cc:931-934)
+  }
+  if (map_on) {
+    mapw = from_lead(mapw);
+    if (mapw && act) p.map.x[(size_t)c * DP + pos] = xn;
+  }
+  if (act) {
+    // (every lane of the chain has read the counters above before the lead lane rewrites them: same wave, program order)
+    if (lead) {
+      p.ntries[c] += 1;
+      p.nhist[c] += 1u;
+    }
+    if (accept) {
+      row[pos] = xn;
+      if (lead) {
+        p.naccept[c] += 1;
+        p.last_type[c] = 0;
+        p.ll[c] = newlike;
+        p.lp[c] = newlprior;
+      }
+    }
+  } else if (live && tc && lead) {
+    p.nhist[c] += (unsigned int)tc;
+    p.touch[c] = 0;
+  }
+}
+
+}  // namespace ptm

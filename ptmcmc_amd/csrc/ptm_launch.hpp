@@ -6,11 +6,15 @@
 
 #include "ptm_kernels.hpp"
 
+// the lanes kernel (ptm_lanes_kernel.hpp) takes launches of at most this many lanes (chains x padded dimension)
+#define PTM_LANES_MAX (1ll << 20)
+
 namespace ptm {
 struct SweepSel {
   int kind;     // KIND_DENSE / KIND_DIAG / KIND_LOWER
   bool uni;     // W % 64 == 0: wave-uniform rung
-  bool simple;  // open bounds, all-uniform prior, zero mean, no 1-D moves
+  bool plain;   // open bounds, all-uniform prior, zero mean, no 1-D moves, no mixture, fixed ladder, device target
+  bool simple;  // uni && plain
   bool callback;  // host-callback likelihood (propose / accept passes): general VALU kernel only
 };
 #define PTM_DECL_DP(N)                                                                                              \

@@ -135,6 +135,9 @@ SWEEP_CASES = [
     (19, 5, 128, 1e2, E.PROP_DIAG, 0.5),     # ... with one-dimensional moves: the sampler's default Gaussian flavour
     (27, 5, 192, 1e2, E.PROP_DENSE, None),
     (16, 12, 64, 1e3, E.PROP_DIAG, 0.5),     # the sampler's default Gaussian flavour: diagonal + 1-D moves
+    (32, 9, 3, 1e3, E.PROP_DENSE, None),     # lanes kernel (a lane per dimension: fewer than 64 walkers per rung), dense
+    (13, 11, 5, 1e2, E.PROP_DIAG, None),     # lanes kernel, 13 -> 16 dimensions, diagonal; 55 chains: a ragged last wave
+    (29, 6, 70, 1e2, E.PROP_LOWER, None),    # lanes kernel, walkers not a multiple of 64
     (5, 7, 3, 1e2, E.PROP_DENSE, 0.3),       # padded dimension (5 -> 8), ragged sizes
     (3, 5, 70, 1e2, E.PROP_DIAG, None),      # W not a multiple of 64
     (1, 4, 2, 1e1, E.PROP_DIAG, 1.0),
@@ -210,6 +213,8 @@ def test_add_every_n_history_counters():
 @pytest.mark.parametrize("D,Nt,W,kind,N,sr,ev", [(32, 8, 64, E.PROP_LOWER, 1, 0.45, 0),   # MFMA kernel, every add saved
                                                  (32, 6, 128, E.PROP_DENSE, 3, 0.45, 0),
                                                  (5, 7, 3, E.PROP_DENSE, 2, 0.45, 0),    # general kernel, ragged sizes
+                                                 (20, 7, 3, E.PROP_DENSE, 2, 0.45, 0),   # lanes kernel (a lane per dimension)
+                                                 (16, 9, 5, E.PROP_LOWER, 1, 0.3, 0),
                                                  (16, 12, 64, E.PROP_DIAG, 4, 0.3, 0),
                                                  (4, 900, 64, E.PROP_DIAG, 2, 0.45, 0),  # > 256 moved rows: the slow exchange path
                                                  # evolving ladders (evolve_temps): rows saved in an exchange phase carry the
