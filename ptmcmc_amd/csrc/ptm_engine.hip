@@ -1220,7 +1220,8 @@ extern "C" const char* ptm_sweep_kernel_name(ptm_engine* e) {
   if (e->DP == 32 && s.uni && !s.callback)
     snprintf(b, sizeof b, "sweep_mfma32_kernel<%d, %s, %d>", s.kind == KIND_DIAG ? KIND_LOWER : s.kind, (e->hist.rungs || e->map.rungs) ? "true" : "false",
              s.simple ? 0 : ((e->all_uniform && (!e->has_bounds || e->bounds_box) && !e->betaC) ? 1 : 2));
-  else if (!s.uni && s.plain && e->DP >= 16 && !getenv("PTM_FORCE_VALU") && (long long)e->Nc * e->DP <= PTM_LANES_MAX) snprintf(b, sizeof b, "sweep_lanes_kernel<%d, %d>", e->DP, s.kind);
+  else if (!s.uni && !s.callback && e->DP >= 16 && !getenv("PTM_FORCE_VALU") && (long long)e->Nc * e->DP <= PTM_LANES_MAX)
+    snprintf(b, sizeof b, "sweep_lanes_kernel<%d, %d, %s>", e->DP, s.kind, s.plain ? "false" : "true");
   else snprintf(b, sizeof b, "sweep_kernel<%d, %d, %s, %s>", e->DP, s.kind, s.uni ? "true" : "false", s.simple ? "true" : "false");
   e->kname = b;
   return e->kname.c_str();

@@ -8,14 +8,16 @@
 // (box test, y.s) cross the chain's lanes through LDS.  The arithmetic of every number is the one of the other kernels
 // (same column order, same fma chains, same four interleaved partial sums), so the chains stay bit-identical.
 //
-// Built for the plain workload (open bounds, all-uniform prior, zero mean, no one-dimensional moves, no mixture, device
-// Gaussian target, fixed ladder) -- everything else takes the general kernel.  History and MAP tracking are carried.
+// GEN = false: the plain workload (open bounds, all-uniform prior, zero mean, no one-dimensional moves, no mixture, fixed
+// ladder); GEN = true: every state-space / prior / proposal flavour of the general kernel -- boundaries and prior factors
+// are per-dimension work and sit naturally on the dimension's lane.  The host-callback likelihood keeps the general
+// kernel.  History and MAP tracking are carried.
 #pragma once
 #include "ptm_kernels.hpp"
 
 namespace ptm {
 
-template <int DP, int KIND>
+template <int DP, int KIND, bool GEN>
 __global__ __launch_bounds__(256) void sweep_lanes_kernel(const Dev p) {
   static_assert(DP == 16 || DP == 32, "lanes kernel: DP 16 or 32");
   constexpr int CPW = 64 / DP;              // chains per wave
@@ -58,12 +60,14 @@ __global__ __launch_bounds__(256) void sweep_lanes_kernel(const Dev p) {
       const long long hrow = 1 + (long long)(a / (unsigned int)p.add_every_n);
       const size_t o = hist_slot(p.hist, hrow, c);
       if (live) p.hist.x[o * DP + d] = row[d];
-      if (live && lead) hist_scalars(p.hist, o, hrow, p.ll[c], p.lp[c], p.naccept[c], p.ntries[c], p.last_type[c], p.beta[rg]);
+      if (live && lead)
+        hist_scalars(p.hist, o, hrow, p.ll[c], p.lp[c], p.naccept[c], p.ntries[c], p.last_type[c],
+                     (GEN && p.beta_add) ? p.beta_add[c] : p.beta[rg]);
     }
     int mapw = 0;
     if (map_on && lead && live) {
       const double tl = p.ll[c], tp = p.lp[c];
-      const double tb = p.beta[rg] * tl;
+      const double tb = ((GEN && p.beta_add) ? p.beta_add[c] : p.beta[rg]) * tl;   // the temperature the rung had at that add
       mapw = map_try(p.map, c, tp + tb, tl, tp) ? 1 : 0;
     }
     if (map_on) {
@@ -75,6 +79,21 @@ __global__ __launch_bounds__(256) void sweep_lanes_kernel(const Dev p) {
   // ---- MH_chain::step (chain.cc:966-1022); touched chains run along (their lanes would idle anyway) and write nothing
   const uint32_t stream = (uint32_t)w * (uint32_t)p.Nt + (uint32_t)rg;
   const u32x4 o0 = draw_block(p.seed, TAG_MH, stream, p.step, 0);
+  int type = 0, axis = -1, kmix = 0;
+  double mix_scale = 1.0;
+  if (GEN) {
+    double f = p.onedfrac[rl];
+    if (p.mix_K > 0) {   // proposal_distribution_set::draw: one uniform picks the member (a set of one draws nothing)
+      const double* mx = p.mix + (size_t)rl * p.mix_K * 3;
+      const double xs = p.mix_K > 1 ? u01(o0.v3) : 0.0;
+      kmix = p.mix_K - 1;
+      for (int k = p.mix_K - 2; k >= 0; --k)
+        if (xs < mx[3 * k]) kmix = k;
+      mix_scale = mx[3 * kmix + 1];
+      f = mx[3 * kmix + 2];
+    }
+    if (p.any_oned && !tc && f > 0 && u01(o0.v1) < f) { axis = (int)(p.D * u01(o0.v2)); type = 1; }
+  }
   // normal d: slot d & 3 of Philox block 1 + d / 4 (two Box-Muller pairs per block)
   double zd;
   {
@@ -83,6 +102,7 @@ __global__ __launch_bounds__(256) void sweep_lanes_kernel(const Dev p) {
     double z0, z1;
     boxmuller(hi ? o.v2 : o.v0, hi ? o.v3 : o.v1, lds_all, z0, z1);
     zd = (d & 1) ? z1 : z0;
+    if (GEN && axis >= 0 && d != axis) zd = 0.0;   // one-dimensional move (proposal_distribution.hh:197-205)
   }
   // -- gaussian_prop::draw (proposal_distribution.hh:194-218): offset = factor * z, row d on lane d
   double off;
@@ -110,21 +130,51 @@ __global__ __launch_bounds__(256) void sweep_lanes_kernel(const Dev p) {
     sync_wave();   // vbuf is reused below
   }
   const double ll = p.ll[c], lp = p.lp[c];
-  const double xn = row[pos] + off;   // state::add (states.cc:205-214)
-  const double beta = p.beta[rg];
+  if (GEN && p.mix_K > 0) {
+    type = kmix + 10 * type;   // proposal_distribution.cc:117
+    off = mix_scale * off;     // the member is scale_k times the rung's factor
+  }
+  double xn = row[pos] + off;   // state::add (states.cc:205-214)
+  const double beta = (GEN && p.betaC) ? p.betaC[c] : p.beta[rg];
   const double bl = beta * ll;
   const double cur_lpost = lp + bl;
   const double oldlprior = cur_lpost - bl;  // chain.cc:973
-  // -- the box of the all-uniform prior: every dimension of the chain inside
-  const bool okd = !(xn < p.plo[d]) && !(xn > p.phi[d]);
-  const unsigned long long okm = __builtin_amdgcn_ballot_w64(okd);
   constexpr unsigned long long GM = DP == 32 ? 0xFFFFFFFFull : 0xFFFFull;
-  const bool in = ((okm >> (g * DP)) & GM) == GM;
-  const double newlprior = in ? p.lprior_const : -__builtin_inf();
-  const bool want_like = newlprior > -1e200 || newlprior - oldlprior > p.min_prior;  // chain.cc:980 (Q1)
+  auto all_of_chain = [&](bool v) { return ((__builtin_amdgcn_ballot_w64(v) >> (g * DP)) & GM) == GM; };
+  bool valid = true;
+  double newlprior;
+  if (!GEN || p.all_uniform) {
+    if (GEN) {
+      // stateSpace::enforce (states.cc:86-102), each dimension on its lane; Q9: the sum is built on an enforced zero state
+      bool vd = true;
+      if (p.has_bounds && d < p.D) vd = boundary_enforce(p.blo[d], p.bhi[d], p.bmin[d], p.bmax[d], xn);
+      valid = p.origin_valid != 0 && all_of_chain(vd);
+    }
+    // the box of the all-uniform prior: every dimension of the chain inside
+    const bool in = all_of_chain(!(xn < p.plo[d]) && !(xn > p.phi[d]));
+    newlprior = (valid && in) ? p.lprior_const : -__builtin_inf();
+  } else {
+    bool vd = true;
+    if (p.has_bounds && d < p.D) vd = boundary_enforce(p.blo[d], p.bhi[d], p.bmin[d], p.bmax[d], xn);
+    valid = p.origin_valid != 0 && all_of_chain(vd);
+    // mixed_dist_product::evaluate: the factors in four interleaved partial products, combined ((p0 p1) p2) p3
+    sbuf[g * DP + d] = d < p.D ? prior_pdf(p.ptype[d], p.plo[d], p.phi[d], p.pcoef[d], xn) : 1.0;
+    sync_wave();
+    if (d < 4) {
+      double pq = 1.0;
+#pragma unroll
+      for (int i = d; i < DP; i += 4) pq *= sbuf[g * DP + i];
+      pbuf[g * 4 + d] = pq;
+    }
+    sync_wave();
+    const double result = ((pbuf[g * 4 + 0] * pbuf[g * 4 + 1]) * pbuf[g * 4 + 2]) * pbuf[g * 4 + 3];
+    sync_wave();   // sbuf / pbuf are reused by the likelihood
+    newlprior = valid ? dlog(result) : -__builtin_inf();
+  }
+  const bool want_like = valid && (newlprior > -1e200 || newlprior - oldlprior > p.min_prior);  // chain.cc:980 (Q1)
   // -- Gaussian likelihood: s_d = sum_{j<d} 2P_dj y_j + P_dd y_d (one fma chain, j ascending), then y.s in four interleaved
   //    partial sums p_q = sum_{i = q mod 4} y_i s_i (i ascending), combined ((p0 + p1) + p2) + p3
-  vbuf[g * DP + d] = xn;
+  vbuf[g * DP + d] = (GEN && p.has_mean) ? xn - p.mean[d] : xn;
   sync_wave();
   {
     const double* prow = p2s + d * (d + 1) / 2;
@@ -146,8 +196,8 @@ __global__ __launch_bounds__(256) void sweep_lanes_kernel(const Dev p) {
   double newlpost = newlike * beta + newlprior;
   if (!want_like) newlike = newlpost = -__builtin_inf();
   const double logH = newlpost - cur_lpost;  // gaussian_prop: log_hastings_ratio() == 0
-  bool accept = true;
-  if (logH < 0) accept = dlog_u01(o0.v0) < logH;  // chain.cc:998-1001 (NaN stays accepted)
+  bool accept = valid;
+  if (accept && logH < 0) accept = dlog_u01(o0.v0) < logH;  // chain.cc:998-1001 (NaN stays accepted)
   (void)tbuf;
 
   const bool act = live && !tc;
@@ -162,15 +212,18 @@ __global__ __launch_bounds__(256) void sweep_lanes_kernel(const Dev p) {
       if (accept) p.hist.x[o * DP + pos] = xn;
       else p.hist.x[o * DP + d] = row[d];
       if (lead) {
-        if (accept) hist_scalars(p.hist, o, hrow, newlike, newlprior, nacc0 + 1, ntries1, 0, beta);
+        if (accept) hist_scalars(p.hist, o, hrow, newlike, newlprior, nacc0 + 1, ntries1, type, beta);
         else hist_scalars(p.hist, o, hrow, ll, lp, nacc0, ntries1, p.last_type[c], beta);
       }
     }
     if (map_on && lead && accept) mapw = map_try(p.map, c, newlpost, newlike, newlprior) ? 1 : 0;   // MAP (chain.cc:931-934)
+    // an evolving ladder: the state that stays is added at a NEW temperature and may beat the MAP with it
+    else if (GEN && map_on && lead && p.betaC) mapw = map_try(p.map, c, cur_lpost, ll, lp) ? 2 : 0;
   }
   if (map_on) {
     mapw = from_lead(mapw);
-    if (mapw && act) p.map.x[(size_t)c * DP + pos] = xn;
+    if (mapw == 1 && act) p.map.x[(size_t)c * DP + pos] = xn;
+    if (GEN && mapw == 2 && act) p.map.x[(size_t)c * DP + d] = row[d];
   }
   if (act) {
     // (every lane of the chain has read the counters above before the lead lane rewrites them: same wave, program order)
@@ -182,7 +235,7 @@ __global__ __launch_bounds__(256) void sweep_lanes_kernel(const Dev p) {
       row[pos] = xn;
       if (lead) {
         p.naccept[c] += 1;
-        p.last_type[c] = 0;
+        p.last_type[c] = type;
         p.ll[c] = newlike;
         p.lp[c] = newlprior;
       }
