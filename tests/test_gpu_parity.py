@@ -798,8 +798,9 @@ def test_default_row_capacity_tracks_swap_rate():
     e.close()
 
 
-def test_host_callback_likelihood_C5_exampleLISA():
-    """BASELINE configs[4]: a user plug-in likelihood (the reference's toy LISA likelihood, exampleLISA.cc:59-72,130-142)
+@pytest.mark.parametrize("ev", [0.0, 0.02])
+def test_host_callback_likelihood_C5_exampleLISA(ev):
+    """BASELINE configs[4] (ev > 0: with the ladder evolving, the sampler's default): a user plug-in likelihood (the reference's toy LISA likelihood, exampleLISA.cc:59-72,130-142)
     through the C-ABI callback, mixed uniform/polar/copolar prior with wrap + limit boundaries (exampleLISA.cc:528-593).
     The propose kernel, the host call and the accept kernel must reproduce the oracle's chain bit for bit."""
     import lisa_toy
@@ -826,10 +827,13 @@ def test_host_callback_likelihood_C5_exampleLISA():
     lad.set_proposals([(O.PROP_DIAG, fac[r], 0.5) for r in range(Nt)])
     lad.use_philox(0x5EED0001)
     lad.set_states(PU.to_oracle_order(x0, Nt, W))
+    if ev:
+        eng.set_evolve_temps(ev); lad.evolve_temps(ev)
     PU.assert_same_state(eng, lad, "start")
     for k in range(6):
         eng.step(5); eng.sync(); lad.pt_step(5)
         PU.assert_same_state(eng, lad, "after %d steps" % (5 * (k + 1)))
+        assert np.array_equal(eng.invtemps(), lad.betaw)
     assert eng.naccept.sum() - eng.Nc > 50
     assert (eng.last_type >= 0).any()
     eng.close()
