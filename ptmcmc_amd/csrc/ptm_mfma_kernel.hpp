@@ -43,7 +43,8 @@ typedef double mf_d2 __attribute__((ext_vector_type(2)));
 // (proposal_distribution.hh:196-206).  Both are compiled apart: the hot build (false, false) carries none of it.
 // All of the general work is per dimension, so it runs in the accumulator layout as it stands: a lane enforces and
 // prices its own eight dimensions of each chain, and the chain's four lanes meet in two more LDS reductions / ballots.
-template <int KIND, bool HIST, int GEN>   // GEN: 0 lean, 1 box boundaries + uniform prior (+ mean, 1-D moves), 2 everything
+// EV: a GEN 1 build that reads a per-chain beta (evolving ladders; the GEN 2 build always can)
+template <int KIND, bool HIST, int GEN, bool EV = false>   // GEN: 0 lean, 1 box boundaries + uniform prior (+ mean, 1-D moves), 2 everything
 __global__ __launch_bounds__(256, PTM_MFMA_WAVES) void sweep_mfma32_kernel(const Dev p) {
   constexpr int DP = 32;
   constexpr bool LOW = KIND == KIND_LOWER;
@@ -112,8 +113,9 @@ __global__ __launch_bounds__(256, PTM_MFMA_WAVES) void sweep_mfma32_kernel(const
   const double ll = p.ll[c], lp = p.lp[c];
   const int ntries0 = p.ntries[c], naccept0 = p.naccept[c];
   const unsigned int nhist0 = p.nhist[c];
-    // (evolving ladders run the GEN 2 build: a per-chain beta in the GEN 1 build costs its fixed-ladder users 4 %)
-  const double beta = (GEN == 2 && p.betaC) ? p.betaC[c] : as_c(p.beta)[rg];
+  // (a per-chain beta in the plain GEN 1 build would cost its fixed-ladder users 4 %: evolving ladders have their own)
+  constexpr bool PERCHAIN = GEN == 2 || EV;
+  const double beta = (PERCHAIN && p.betaC) ? p.betaC[c] : as_c(p.beta)[rg];
   // log of the chain's accept uniform (block 0 of its stream): drawn here once for all 64 chains -- the Metropolis test
   // itself runs per pass on half the lanes, and this is its expensive part.  (The reference draws the uniform only when
   // logH < 0, chain.cc:998; a counter-based stream makes the draw free of side effects, so drawing it always is the same.)
@@ -340,10 +342,10 @@ __global__ __launch_bounds__(256, PTM_MFMA_WAVES) void sweep_mfma32_kernel(const
         if (hist_on && a % (unsigned int)p.add_every_n == 0u) {
           hrow = 1 + (int)(a / (unsigned int)p.add_every_n);
           hist_scalars(p.hist, hist_slot(p.hist, hrow, c), hrow, ll, lp, naccept0, ntries0, p.last_type[c],
-                       (GEN == 2 && p.beta_add) ? p.beta_add[c] : beta);
+                       (PERCHAIN && p.beta_add) ? p.beta_add[c] : beta);
         }
         if (map_on) {   // at the temperature the rung had at that add (evolving ladders: between two pries of the step)
-          const double tb = ((GEN == 2 && p.beta_add) ? p.beta_add[c] : beta) * ll;
+          const double tb = ((PERCHAIN && p.beta_add) ? p.beta_add[c] : beta) * ll;
           mapw = map_try(p.map, c, lp + tb, ll, lp);
         }
       } else {
@@ -378,7 +380,7 @@ __global__ __launch_bounds__(256, PTM_MFMA_WAVES) void sweep_mfma32_kernel(const
         }
         if (map_on && accept) mapw = map_try(p.map, c, newlpost, newlike, newlprior);
         // an evolving ladder: the state that stays is added at a NEW temperature and may beat the MAP with it
-        else if (map_on && GEN == 2 && p.betaC) mapw = map_try(p.map, c, cur_lpost, ll, lp);
+        else if (map_on && PERCHAIN && p.betaC) mapw = map_try(p.map, c, cur_lpost, ll, lp);
         if (accept) {
           p.naccept[c] = naccept0 + 1;
           p.last_type[c] = type;
