@@ -49,7 +49,7 @@ struct ptm_engine {
   unsigned int* nhist = nullptr;
   long long *swap_try = nullptr, *swap_acc = nullptr;
   unsigned char* touch = nullptr;
-  Hist hist = {0, 0, 0, nullptr, nullptr, nullptr, nullptr};   // optional history ring (ptm_config.history_rungs)
+  Hist hist = {0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr};   // optional history ring (ptm_config.history_rungs)
   MapT map = {0, 0, nullptr, nullptr, nullptr, nullptr};       // optional MAP tracking (ptm_config.map_rungs)
   int* swap_log = nullptr;   // [W][ms] candidate log of the last step
   int row_cap = 0;           // row slots per boundary message
