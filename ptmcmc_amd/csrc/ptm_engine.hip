@@ -1220,7 +1220,7 @@ extern "C" const char* ptm_sweep_kernel_name(ptm_engine* e) {
   if (e->DP == 32 && s.uni && !s.callback)
     snprintf(b, sizeof b, "sweep_mfma32_kernel<%d, %s, %d%s>", s.kind == KIND_DIAG ? KIND_LOWER : s.kind, (e->hist.rungs || e->map.rungs) ? "true" : "false",
              s.simple ? 0 : ((e->all_uniform && (!e->has_bounds || e->bounds_box)) ? 1 : 2),
-             (!s.simple && e->all_uniform && (!e->has_bounds || e->bounds_box) && e->betaC) ? ", true" : "");
+             (!s.simple && e->all_uniform && (!e->has_bounds || e->bounds_box) && e->betaC) ? ", true" : ", false");   // as rocprofv3 prints it
   else if (!s.uni && !s.callback && e->DP >= 16 && !getenv("PTM_FORCE_VALU") && (long long)e->Nc * e->DP <= PTM_LANES_MAX)
     snprintf(b, sizeof b, "sweep_lanes_kernel<%d, %d, %s>", e->DP, s.kind, s.plain ? "false" : "true");
   else snprintf(b, sizeof b, "sweep_kernel<%d, %d, %s, %s>", e->DP, s.kind, s.uni ? "true" : "false", s.simple ? "true" : "false");

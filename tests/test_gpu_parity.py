@@ -564,7 +564,7 @@ def test_mfma_kernel_general_state_space_and_priors(kind, odf, with_mean, all_un
     pr, eng, lad = PU.make_pair(D, Nt, W, 50.0, kind=kind, bounds=(blo, bhi, bmin, bmax), prior=(types, cen, hw), swap_rate=0.3,
                                 x0=x0, mean=mean, one_d_frac=(odf if odf > 0 else None))
     if W == 64:
-        assert "mfma32_kernel" in eng.sweep_kernel_name and eng.sweep_kernel_name.endswith(", 2>")
+        assert "mfma32_kernel" in eng.sweep_kernel_name and ", 2, " in eng.sweep_kernel_name
     else:
         assert eng.sweep_kernel_name.startswith("sweep_lanes_kernel<32") and eng.sweep_kernel_name.endswith("true>")
     PU.assert_same_state(eng, lad, "start")
@@ -592,7 +592,7 @@ def test_mfma_kernel_limit_bounds_with_uniform_prior(kind, odf, with_mean):
     mean = rng.normal(size=D) * 0.1 if with_mean else None
     pr, eng, lad = PU.make_pair(D, Nt, W, 1e3, kind=kind, bounds=(blo, bhi, bmin, bmax), prior=prior, swap_rate=0.3, x0=x0, mean=mean,
                                 one_d_frac=(odf if odf > 0 else None))
-    assert eng.sweep_kernel_name.endswith(", 1>")
+    assert eng.sweep_kernel_name.endswith(", 1, false>")
     for k in range(5):
         eng.step(4); eng.sync(); lad.pt_step(4)
         PU.assert_same_state(eng, lad, "after %d steps" % (4 * (k + 1)))
