@@ -37,7 +37,7 @@ struct Decide {
   double* lp;
   unsigned char* touch;
   int *arr_below, *arr_above;      // [W]  landing slot of the row arriving across the lower / upper boundary, or -1
-  long long *swap_try, *swap_acc;  // [W][Nt-1]
+  long long* swap_cnt;             // [W][Nt-1][2]  {tries, accepts} of every pair, side by side
   int* swap_log;                   // [W][ms]  per candidate: -2 none/dropped, -3 not this shard's, else rung | accepted<<30
   double *send_up, *send_down;     // boundary messages or null
   int row_cap;
@@ -401,8 +401,9 @@ __global__ __launch_bounds__(DECIDE_THREADS) void decide_kernel(const Decide p) 
 #else
     if (i >= p.r0 && i < r1) {
 #endif
-      atomicAdd(reinterpret_cast<unsigned long long*>(p.swap_try) + (size_t)w * (Nt - 1) + i, 1ull);
-      if (accf[k]) atomicAdd(reinterpret_cast<unsigned long long*>(p.swap_acc) + (size_t)w * (Nt - 1) + i, 1ull);
+      unsigned long long* cn = reinterpret_cast<unsigned long long*>(p.swap_cnt) + 2 * ((size_t)w * (Nt - 1) + i);   // {tries, accepts}: one line
+      atomicAdd(cn, 1ull);
+      if (accf[k]) atomicAdd(cn + 1, 1ull);
     }
     const int rtop = (PTM_ALIVE_RUNG(i + 1) && alive[first[i + 1]] == 1) ? i : i + 1;  // rung i+1 belongs to the pick above, if ours
     for (int r = i; r <= rtop; ++r) {

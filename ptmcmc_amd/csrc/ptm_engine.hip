@@ -47,7 +47,7 @@ struct ptm_engine {
   int *arr_below = nullptr, *arr_above = nullptr;
   int *mv_src = nullptr, *mv_dst = nullptr, *mv_n = nullptr;   // per-ladder move lists (exchange kernel -> move kernel)
   unsigned int* nhist = nullptr;
-  long long *swap_try = nullptr, *swap_acc = nullptr;
+  long long* swap_cnt = nullptr;   // [W][Nt-1][2] {tries, accepts}
   unsigned char* touch = nullptr;
   Hist hist = {0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr};   // optional history ring (ptm_config.history_rungs)
   MapT map = {0, 0, nullptr, nullptr, nullptr, nullptr};       // optional MAP tracking (ptm_config.map_rungs)
@@ -203,10 +203,9 @@ static int build_engine(ptm_engine* e, const ptm_config* cfg) {
     HIPCHK(hipMemsetAsync(e->hist.meta, 0xFF, n * sizeof(int4), e->stream));   // saved row number -1: empty slot
   }
   const size_t np = (size_t)e->W * (e->Nt > 1 ? e->Nt - 1 : 1);
-  if ((rc = dalloc(&e->swap_try, np)) || (rc = dalloc(&e->swap_acc, np)) || (rc = dalloc(&e->swap_log, (size_t)e->W * e->ms)))
+  if ((rc = dalloc(&e->swap_cnt, 2 * np)) || (rc = dalloc(&e->swap_log, (size_t)e->W * e->ms)))
     return rc;
-  HIPCHK(hipMemsetAsync(e->swap_try, 0, np * 8, e->stream));
-  HIPCHK(hipMemsetAsync(e->swap_acc, 0, np * 8, e->stream));
+  HIPCHK(hipMemsetAsync(e->swap_cnt, 0, 2 * np * 8, e->stream));
   HIPCHK(hipMemsetAsync(e->swap_log, 0xFE, (size_t)e->W * e->ms * 4, e->stream));  // 0xFEFEFEFE < 0: "none"
   HIPCHK(hipMemsetAsync(e->err, 0, 16, e->stream));
   HIPCHK(hipMemsetAsync(e->mv_n, 0, (size_t)e->W * 4, e->stream));
@@ -242,7 +241,7 @@ extern "C" int ptm_engine_destroy(ptm_engine* e) {
   if (!e) return PTM_OK;
   (void)hipStreamSynchronize(e->stream);
   void* ptrs[] = {e->x, e->ll, e->lp, e->ntries, e->naccept, e->last_type, e->arr_below, e->arr_above, e->mv_src, e->mv_dst, e->mv_n,
-                  e->err, e->nhist, e->swap_try, e->swap_acc, e->touch, e->swap_log, e->hist.x, e->hist.ll, e->hist.lp, e->hist.meta, e->map.lpost, e->map.ll, e->map.lp, e->map.x, e->blo,
+                  e->err, e->nhist, e->swap_cnt, e->touch, e->swap_log, e->hist.x, e->hist.ll, e->hist.lp, e->hist.meta, e->map.lpost, e->map.ll, e->map.lp, e->map.x, e->blo,
                   e->bhi, e->ptype, e->bmin, e->bmax, e->plo, e->phi, e->pcoef, e->P2, e->mean, e->beta, e->prop, e->prop_tiles, e->P2_tiles, e->box_row, e->onedfrac, e->mix, e->beta_w, e->betaC, e->beta_add, e->hist.beta, e->xprop, e->lprior_new, e->llike_new, e->gate};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -721,7 +720,7 @@ static int launch_decide(ptm_engine* e, const double* ll_below, const double* ll
   p.DP = e->DP; p.Nt = e->Nt; p.r0 = e->r0; p.nloc = e->nloc; p.W = e->W; p.Nc = e->Nc; p.ms = e->ms;
   p.seed = e->cfg.seed; p.step = e->step; p.thresh = e->thresh;
   p.beta = e->beta; p.ll_below = ll_below; p.ll_above = ll_above; p.H = ll_above ? H : 0; p.x = e->x; p.ll = e->ll; p.lp = e->lp;
-  p.touch = e->touch; p.arr_below = e->arr_below; p.arr_above = e->arr_above; p.swap_try = e->swap_try; p.swap_acc = e->swap_acc;
+  p.touch = e->touch; p.arr_below = e->arr_below; p.arr_above = e->arr_above; p.swap_cnt = e->swap_cnt;
   p.swap_log = e->swap_log; p.send_up = send_up; p.send_down = send_down; p.row_cap = e->row_cap; p.err = e->err;
   p.mv_src = e->mv_src; p.mv_dst = e->mv_dst; p.mv_n = e->mv_n;
   p.hist = e->hist; p.add_every_n = e->cfg.add_every_n; p.nhist = e->nhist;
@@ -1076,8 +1075,12 @@ extern "C" int ptm_get_swap_counts(ptm_engine* e, int64_t* tries, int64_t* accep
   if (!e) return fail(PTM_ERR_INVALID, "null engine");
   const size_t np = (size_t)e->W * (e->Nt > 1 ? e->Nt - 1 : 1);
   HIPCHK(hipStreamSynchronize(e->stream));
-  if (tries) HIPCHK(hipMemcpy(tries, e->swap_try, np * 8, hipMemcpyDeviceToHost));
-  if (accepts) HIPCHK(hipMemcpy(accepts, e->swap_acc, np * 8, hipMemcpyDeviceToHost));
+  std::vector<long long> both(2 * np);
+  HIPCHK(hipMemcpy(both.data(), e->swap_cnt, 2 * np * 8, hipMemcpyDeviceToHost));
+  for (size_t i = 0; i < np; ++i) {
+    if (tries) tries[i] = both[2 * i];
+    if (accepts) accepts[i] = both[2 * i + 1];
+  }
   return PTM_OK;
 }
 
@@ -1128,10 +1131,15 @@ extern "C" int ptm_restore(ptm_engine* e, const double* X, const double* llike, 
       (rc = upload(e->last_type, last_type, Nc, e->stream)) || (rc = upload(e->nhist, nh.data(), Nc, e->stream)))
     return rc;
   const size_t np = (size_t)e->W * (e->Nt > 1 ? e->Nt - 1 : 1);
-  if (swap_tries && (rc = upload(e->swap_try, (const long long*)swap_tries, np, e->stream))) return rc;
-  if (swap_accepts && (rc = upload(e->swap_acc, (const long long*)swap_accepts, np, e->stream))) return rc;
-  if (!swap_tries) HIPCHK(hipMemsetAsync(e->swap_try, 0, np * 8, e->stream));
-  if (!swap_accepts) HIPCHK(hipMemsetAsync(e->swap_acc, 0, np * 8, e->stream));
+  {
+    std::vector<long long> both(2 * np, 0);
+    for (size_t i = 0; i < np; ++i) {
+      if (swap_tries) both[2 * i] = swap_tries[i];
+      if (swap_accepts) both[2 * i + 1] = swap_accepts[i];
+    }
+    if ((rc = upload(e->swap_cnt, both.data(), 2 * np, e->stream))) return rc;
+    HIPCHK(hipStreamSynchronize(e->stream));   // `both` leaves scope
+  }
   e->step = step_count;
   HIPCHK(hipStreamSynchronize(e->stream));
   return PTM_OK;
