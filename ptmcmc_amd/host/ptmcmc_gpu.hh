@@ -33,6 +33,8 @@
 #include <thread>
 #include <valarray>
 #include <vector>
+#include <sys/stat.h>
+#include <sys/types.h>
 
 #include "ptm_engine.h"
 
@@ -590,6 +592,104 @@ class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:
     os << "\n" << std::endl;
   }
   int replicas() const { return W; }
+  // chain::checkpoint / restart (chain.cc:1213-1290): everything the ladder's future depends on, into <path>chain0-cp/
+  // PTchain.cp.  The reference's files hold its own generators and growing vectors; this one holds the engine's arrays
+  // (states, llikes, MH_chain counters, step count = position of every random stream, exchange counters, evolving
+  // temperatures, history ring, MAPs, the exchange diagnostics) -- the continued run is the uninterrupted run, bit for bit.
+  void checkpoint(const std::string& path) {
+    const std::string dir = path + "chain0-cp/";
+    mkdir(dir.c_str(), 0777);
+    std::ofstream os((dir + "PTchain.cp").c_str(), std::ios::binary);
+    if (!os) { std::cout << "parallel_tempering_chains::checkpoint: cannot write " << dir << "PTchain.cp" << std::endl; exit(1); }
+    const size_t N = (size_t)Ntemps * W, np = (size_t)W * (Ntemps > 1 ? Ntemps - 1 : 1);
+    auto wr = [&](const void* ptr, size_t bytes) { os.write((const char*)ptr, (std::streamsize)bytes); };
+    const char magic[8] = {'P', 'T', 'M', 'G', 'P', 'U', '0', '1'};
+    int32_t hdr[8] = {Ntemps, W, dim, hist_rows, ev_rate > 0 ? 1 : 0, tracking ? 1 : 0, nstep, add_every_N};
+    uint64_t estep = ptm_step_count(eng);
+    wr(magic, 8); wr(hdr, sizeof hdr); wr(&estep, 8);
+    std::vector<double> x(N * dim), ll(N);
+    std::vector<int32_t> nt(N), na(N), ty(N);
+    std::vector<int64_t> nh(N), st(np), sa(np);
+    ptm_check(ptm_get_states(eng, x.data()), "checkpoint");
+    ptm_check(ptm_get_array(eng, PTM_ARR_LLIKE, ll.data()), "checkpoint");
+    ptm_check(ptm_get_array(eng, PTM_ARR_NTRIES, nt.data()), "checkpoint");
+    ptm_check(ptm_get_array(eng, PTM_ARR_NACCEPT, na.data()), "checkpoint");
+    ptm_check(ptm_get_array(eng, PTM_ARR_LAST_TYPE, ty.data()), "checkpoint");
+    ptm_check(ptm_get_array(eng, PTM_ARR_NHIST, nh.data()), "checkpoint");
+    ptm_check(ptm_get_swap_counts(eng, st.data(), sa.data()), "checkpoint");
+    wr(x.data(), x.size() * 8); wr(ll.data(), N * 8); wr(nt.data(), N * 4); wr(na.data(), N * 4); wr(ty.data(), N * 4);
+    wr(nh.data(), N * 8); wr(st.data(), np * 8); wr(sa.data(), np * 8);
+    if (ev_rate > 0) {
+      std::vector<double> b((size_t)W * Ntemps);
+      ptm_check(ptm_get_invtemps(eng, b.data()), "checkpoint");
+      wr(b.data(), b.size() * 8);
+    }
+    if (hist_rows > 0) {
+      const size_t n = (size_t)hist_rows * N;
+      std::vector<double> gx(n * dim), gl(n), gp(n), gb(n);
+      std::vector<int32_t> gm(n * 4);
+      ptm_check(ptm_get_history(eng, gx.data(), gl.data(), gp.data(), gm.data()), "checkpoint");
+      ptm_check(ptm_get_history_invtemps(eng, gb.data()), "checkpoint");
+      wr(gx.data(), gx.size() * 8); wr(gl.data(), n * 8); wr(gp.data(), n * 8); wr(gm.data(), gm.size() * 4); wr(gb.data(), n * 8);
+    }
+    {
+      std::vector<double> mx(N * dim), mp(N), ml(N), mr(N);
+      ptm_check(ptm_get_map(eng, mx.data(), mp.data(), ml.data(), mr.data()), "checkpoint");
+      wr(mx.data(), mx.size() * 8); wr(mp.data(), N * 8); wr(ml.data(), N * 8); wr(mr.data(), N * 8);
+    }
+    if (tracking) {
+      std::vector<int64_t> u(ups.begin(), ups.end()), d(downs.begin(), downs.end());
+      wr(directions.data(), (size_t)Ntemps * 4); wr(instances.data(), (size_t)Ntemps * 4); wr(u.data(), (size_t)Ntemps * 8); wr(d.data(), (size_t)Ntemps * 8);
+    }
+    if (!os) { std::cout << "parallel_tempering_chains::checkpoint: write failed" << std::endl; exit(1); }
+  }
+  // into a ladder set up exactly like the one that was saved (same sizes, seed, likelihood, prior, proposal, evolve_temps)
+  void restart(const std::string& path) {
+    const std::string fn = path + "chain0-cp/PTchain.cp";
+    std::ifstream is(fn.c_str(), std::ios::binary);
+    if (!is) { std::cout << "parallel_tempering_chains::restart: cannot read " << fn << std::endl; exit(1); }
+    auto rd = [&](void* ptr, size_t bytes) { is.read((char*)ptr, (std::streamsize)bytes); };
+    char magic[8]; int32_t hdr[8]; uint64_t estep;
+    rd(magic, 8); rd(hdr, sizeof hdr); rd(&estep, 8);
+    if (std::string(magic, 8) != "PTMGPU01" || hdr[0] != Ntemps || hdr[1] != W || hdr[2] != dim || hdr[3] != hist_rows ||
+        hdr[4] != (ev_rate > 0 ? 1 : 0) || hdr[7] != add_every_N) {
+      std::cout << "parallel_tempering_chains::restart: " << fn << " was written by a differently configured ladder" << std::endl;
+      exit(1);
+    }
+    const size_t N = (size_t)Ntemps * W, np = (size_t)W * (Ntemps > 1 ? Ntemps - 1 : 1);
+    std::vector<double> x(N * dim), ll(N);
+    std::vector<int32_t> nt(N), na(N), ty(N);
+    std::vector<int64_t> nh(N), st(np), sa(np);
+    rd(x.data(), x.size() * 8); rd(ll.data(), N * 8); rd(nt.data(), N * 4); rd(na.data(), N * 4); rd(ty.data(), N * 4);
+    rd(nh.data(), N * 8); rd(st.data(), np * 8); rd(sa.data(), np * 8);
+    ptm_check(ptm_restore(eng, x.data(), ll.data(), nt.data(), na.data(), ty.data(), nh.data(), estep, st.data(), sa.data()), "restart");
+    if (ev_rate > 0) {
+      std::vector<double> b((size_t)W * Ntemps);
+      rd(b.data(), b.size() * 8);
+      ptm_check(ptm_set_invtemps(eng, b.data()), "restart");
+    }
+    if (hist_rows > 0) {
+      const size_t n = (size_t)hist_rows * N;
+      std::vector<double> gx(n * dim), gl(n), gp(n), gb(n);
+      std::vector<int32_t> gm(n * 4);
+      rd(gx.data(), gx.size() * 8); rd(gl.data(), n * 8); rd(gp.data(), n * 8); rd(gm.data(), gm.size() * 4); rd(gb.data(), n * 8);
+      ptm_check(ptm_set_history(eng, gx.data(), gl.data(), gp.data(), gm.data(), gb.data()), "restart");
+    }
+    {
+      std::vector<double> mx(N * dim), mp(N), ml(N), mr(N);
+      rd(mx.data(), mx.size() * 8); rd(mp.data(), N * 8); rd(ml.data(), N * 8); rd(mr.data(), N * 8);
+      ptm_check(ptm_set_map(eng, mx.data(), mp.data(), ml.data(), mr.data()), "restart");
+    }
+    if (hdr[5]) {
+      track_exchanges(true);
+      std::vector<int64_t> u(Ntemps), d(Ntemps);
+      rd(directions.data(), (size_t)Ntemps * 4); rd(instances.data(), (size_t)Ntemps * 4); rd(u.data(), (size_t)Ntemps * 8); rd(d.data(), (size_t)Ntemps * 8);
+      ups.assign(u.begin(), u.end()); downs.assign(d.begin(), d.end());
+    }
+    if (!is) { std::cout << "parallel_tempering_chains::restart: " << fn << " is truncated" << std::endl; exit(1); }
+    nstep = hdr[6];
+    fresh = hist_fresh = map_fresh = false;
+  }
   // chain.cc:1281-1365: n prior draws per rung; the device draws them (uniform / gaussian dimensions)
   void initialize(bayes_likelihood* log_likelihood, const sampleable_probability_function* log_prior, int n = 1, uint64_t seed = 0x5EED0001ull,
                   const std::vector<double>* start_states = nullptr) {
@@ -772,6 +872,27 @@ class ptmcmc_sampler {
     opt["pt_Tmax"] = "1e9"; opt["chain_dprior_min"] = "-30"; opt["seed"] = "-1"; opt["outname"] = "mcmc_output";
     opt["nskip"] = "10"; opt["pt_dump_n"] = "1"; opt["nchains"] = "1";
     opt["pt_evolve_rate"] = "0.01"; opt["pt_evolve_lpost_cut"] = "-1";   // ptmcmc.cc:389-390: the ladder evolves by default
+    opt["checkp_at_step"] = "-1"; opt["restart_dir"] = "";                // ptmcmc.cc:377-379
+  }
+  // ptmcmc_sampler::checkpoint / restart (ptmcmc.cc:306-338): <path>/step_<istep>-cp/ptmcmc.cp + the ladder's own file
+  void checkpoint(const std::string& path, int istep) {
+    std::ostringstream ss;
+    ss << path << "/step_" << istep << "-cp/";
+    const std::string dir = ss.str();
+    std::cout << "Writing checkpoint files to dir:" << dir << std::endl;
+    mkdir(dir.c_str(), 0777);
+    std::ofstream os((dir + "ptmcmc.cp").c_str());
+    os << istep << std::endl;
+    cc->checkpoint(dir);
+  }
+  int restart(const std::string& path) {
+    std::cout << "Restarting from checkpoint files in dir:" << path << std::endl;
+    std::ifstream is((path + "/ptmcmc.cp").c_str());
+    int istep = -1;
+    is >> istep;
+    if (!is || istep < 0) { std::cout << "ptmcmc_sampler::restart: cannot read " << path << "/ptmcmc.cp" << std::endl; exit(1); }
+    cc->restart(path + "/");
+    return istep;
   }
   void set(const std::string& name, const std::string& value) { opt[name] = value; }
   bool parse(int argc, char* argv[]) {  // --name=value / --name (options.hh semantics)
@@ -807,6 +928,9 @@ class ptmcmc_sampler {
     int dump_n = (int)num("pt_dump_n");
     if (dump_n > cc->multiplicity() || dump_n <= 0) dump_n = cc->multiplicity();   // ptmcmc.cc:458
     const int nrep = cc->replicas();
+    const int checkp_at_step = (int)num("checkp_at_step");
+    const std::string restart_dir = opt.at("restart_dir");
+    const bool restarting = !restart_dir.empty();
     std::vector<std::unique_ptr<std::ofstream> > out;
     for (int w = 0; w < nrep; w++)
       for (int ich = 0; ich < dump_n; ich++) {   // ptmcmc.cc:547-554; replica w > 0: <base>_c<w>_t<ich>.dat
@@ -814,10 +938,18 @@ class ptmcmc_sampler {
         ss << base;
         if (w > 0) ss << "_c" << w;
         ss << "_t" << ich << ".dat";
-        out.emplace_back(new std::ofstream(ss.str().c_str()));
+        // a restarted run goes on writing where the first part stopped (ptmcmc.cc:538)
+        out.emplace_back(new std::ofstream(ss.str().c_str(), restarting ? std::ios::out | std::ios::app : std::ios::out));
         out.back()->precision(13);
       }
-    for (int istep = 0; istep <= Nstep; istep++) {   // ptmcmc.cc:565,599-607
+    int istep0 = 0;
+    if (restarting) istep0 = restart(restart_dir);   // ptmcmc.cc:564
+    for (int istep = istep0; istep <= Nstep; istep++) {   // ptmcmc.cc:565,599-607
+      if (istep == checkp_at_step) {   // ptmcmc.cc:567,593-596: write the checkpoint and stop
+        std::cout << "Checkpointing triggered." << std::endl;
+        checkpoint(".", istep);
+        return 0;
+      }
       cc->step();
       if (0 == istep % Nevery)
         for (int w = 0; w < nrep; w++)

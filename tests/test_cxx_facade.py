@@ -165,3 +165,31 @@ def test_sampler_default_run_evolves_the_ladder():
         big = ll < -0.5
         brow = (allrows[big, 1] - lp0) / ll[big]
         assert brow.min() > 0.2 and brow.max() < 0.8 and brow.std() > 1e-4
+
+
+@pytest.mark.gpu
+def test_sampler_checkpoint_and_restart_give_the_uninterrupted_chain_files():
+    """The reference's restart-identity test (test/exampleLISA/Makefile:14-17, cp-test): a run stopped by
+    --checkp_at_step (ptmcmc.cc:567,593-596; files under ./step_<n>-cp/) and continued with --restart_dir writes, byte
+    for byte, the chain files of the run that never stopped -- evolving ladder (the default), history ring, MAPs and all."""
+    with tempfile.TemporaryDirectory() as d:
+        exe = os.path.join(d, "ex2")
+        build(exe, "example_sampler.cc")
+        common = ["--nsteps=1200", "--nevery=300", "--nchains=2"]
+        def run(*args):
+            r = subprocess.run([exe, *args], capture_output=True, text=True, timeout=600, cwd=d)
+            assert r.returncode == 0, r.stdout + r.stderr
+            return r.stdout
+        run("whole", *common)
+        out1 = run("parts", *common, "--checkp_at_step=500")
+        assert "Checkpointing triggered." in out1 and os.path.exists(os.path.join(d, "step_500-cp", "ptmcmc.cp"))
+        assert os.path.exists(os.path.join(d, "step_500-cp", "chain0-cp", "PTchain.cp"))
+        part1 = open(os.path.join(d, "parts_t0.dat")).read()
+        out2 = run("parts", *common, "--restart_dir=step_500-cp")
+        assert "Restarting from checkpoint files" in out2
+        for name in ("_t0.dat", "_t1.dat", "_c1_t0.dat", "_c1_t1.dat"):
+            a = open(os.path.join(d, "whole" + name)).read()
+            b = open(os.path.join(d, "parts" + name)).read()
+            assert a == b, name
+        whole = open(os.path.join(d, "whole_t0.dat")).read()
+        assert whole.startswith(part1) and len(part1) < len(whole)
