@@ -137,7 +137,8 @@ int ptm_set_proposal_mixture(ptm_engine* e, int K, const double* cum_shares, con
 /* X[n_local_chains][D]; llike may be NULL (the device target evaluates it).  Resets counters the way
  * MH_chain::initialize(1) leaves them (chain.cc:649,846-876). */
 int ptm_set_states(ptm_engine* e, const double* X, const double* llike);
-/* MH_chain::initialize(1): draw each chain's start from the prior until valid (uniform/gaussian dims only) */
+/* MH_chain::initialize(1): draw each chain's start from the prior until valid and of finite likelihood (chain.cc:846-876);
+ * every mixed_dist_product type but the flat one can be drawn (PTM_ERR_UNSUPPORTED for a flat dimension) */
 int ptm_init_from_prior(ptm_engine* e);
 
 /* ---- the hot path ------------------------------------------------------------------------------------- */

@@ -839,6 +839,35 @@ void ptmo_rng_free(ptmo_rng* r) {
   free(r->ctx); free(r);
 }
 
+/* inverse cdfs of UniformPolarDist / UniformCoPolarDist (ProbabilityDist.h:108-110,149-151) by 64 bisections on the
+ * deterministic cos / sin above, and of UniformLogDist (:32-34): the engine's own draw procedure, restated */
+static double cos_0_pi(double x) { return x <= HPI_HI ? ptmo_cos_hpi(x) : -ptmo_cos_hpi((PI_HI - x) + PI_LO); }
+static double sin_hpi(double x) { return x >= 0 ? ptmo_sin_0_pi(x) : -ptmo_sin_0_pi(-x); }
+static double draw_polar(double u, double lo, double hi) {
+  double cl = cos_0_pi(lo), ch = cos_0_pi(hi);
+  double y = cl - u * (cl - ch);
+  double a = lo, b = hi;
+  for (int k = 0; k < 64; k++) {
+    double m = 0.5 * (a + b);
+    if (cos_0_pi(m) > y) a = m; else b = m;
+  }
+  return 0.5 * (a + b);
+}
+static double draw_copolar(double u, double lo, double hi) {
+  double sl = sin_hpi(lo), sh = sin_hpi(hi);
+  double y = sl + u * (sh - sl);
+  double a = lo, b = hi;
+  for (int k = 0; k < 64; k++) {
+    double m = 0.5 * (a + b);
+    if (sin_hpi(m) < y) a = m; else b = m;
+  }
+  return 0.5 * (a + b);
+}
+static double draw_log(double u, double lo, double hi) {
+  double l0 = ptmo_log(lo);
+  return ptmo_exp(u * (ptmo_log(hi) - l0) + l0);
+}
+
 /* MH_chain::initialize(1) (chain.cc:846-876): draw from the prior until valid with llike >= -1e100.
  * Dimension d of attempt a uses block d of stream (chain), step = a, tag INIT:
  * uniform dims x = u*(hi-lo)+lo (ProbabilityDist.h:94-97), gaussian dims x = z*sigma+x0 (ProbabilityDist.cxx:79). */
@@ -853,6 +882,9 @@ void ptmo_init_from_prior(ptmo_pt* s, const ptmo_problem* pb, uint64_t seed) {
         ptmo_draw_block(seed, PTMO_TAG_INIT, (uint32_t)c, a, (uint32_t)d, o);
         if (pb->ptype[d] == PTMO_UNIFORM) x[d] = ptmo_u01(o[0]) * (pb->phi[d] - pb->plo[d]) + pb->plo[d];
         else if (pb->ptype[d] == PTMO_GAUSSIAN) { double z0, z1; ptmo_boxmuller(o[0], o[1], &z0, &z1); x[d] = z0 * pb->phi[d] + pb->plo[d]; }
+        else if (pb->ptype[d] == PTMO_POLAR) x[d] = draw_polar(ptmo_u01(o[0]), pb->plo[d], pb->phi[d]);
+        else if (pb->ptype[d] == PTMO_COPOLAR) x[d] = draw_copolar(ptmo_u01(o[0]), pb->plo[d], pb->phi[d]);
+        else if (pb->ptype[d] == PTMO_LOG) x[d] = draw_log(ptmo_u01(o[0]), pb->plo[d], pb->phi[d]);
         else x[d] = NAN;
       }
       int valid = ptmo_enforce(pb, x);

@@ -166,6 +166,39 @@ __device__ __forceinline__ double dcos_hpi(double x) {
   return sin_k((HPI_HI - x) + HPI_LO);
 }
 
+// Prior draws of MH_chain::initialize (chain.cc:846-876) for the support types without a closed form in the functions
+// above: the inverse cdfs of UniformPolarDist / UniformCoPolarDist (ProbabilityDist.h:108-110,149-151: acos / asin of a
+// uniform in the cosines / sines of the limits) by 64 bisections on the monotone dcos / dsin -- set-up code, exactness of
+// the operation sequence (shared with the CPU checker) matters, speed does not; UniformLogDist::invcdf (:32-34) directly.
+__device__ __forceinline__ double dcos_0_pi(double x) { return x <= HPI_HI ? dcos_hpi(x) : -dcos_hpi((PI_HI - x) + PI_LO); }
+__device__ __forceinline__ double dsin_hpi(double x) { return x >= 0 ? dsin_0_pi(x) : -dsin_0_pi(-x); }
+__device__ __forceinline__ double draw_polar(double u, double lo, double hi) {
+  const double cl = dcos_0_pi(lo), ch = dcos_0_pi(hi);
+  const double y = cl - u * (cl - ch);
+  double a = lo, b = hi;
+#pragma unroll 1
+  for (int k = 0; k < 64; ++k) {
+    const double m = 0.5 * (a + b);
+    if (dcos_0_pi(m) > y) a = m; else b = m;
+  }
+  return 0.5 * (a + b);
+}
+__device__ __forceinline__ double draw_copolar(double u, double lo, double hi) {
+  const double sl = dsin_hpi(lo), sh = dsin_hpi(hi);
+  const double y = sl + u * (sh - sl);
+  double a = lo, b = hi;
+#pragma unroll 1
+  for (int k = 0; k < 64; ++k) {
+    const double m = 0.5 * (a + b);
+    if (dsin_hpi(m) < y) a = m; else b = m;
+  }
+  return 0.5 * (a + b);
+}
+__device__ __forceinline__ double draw_log(double u, double lo, double hi) {
+  const double l0 = dlog(lo);
+  return dexp(u * (dlog(hi) - l0) + l0);
+}
+
 // correctly rounded square root: the compiler's f64 sqrt expansion (faithful, <= 1 ulp) followed by one
 // exact-residual decision, so that the result is the IEEE value the CPU checker's sqrt() returns.
 //   r = a - g*g (sign exact via fma).  If r != 0 the root lies between g and its neighbour gn on that side; g is

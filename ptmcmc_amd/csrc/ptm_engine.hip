@@ -874,8 +874,8 @@ extern "C" int ptm_init_from_prior(ptm_engine* e) {
   if (!e) return fail(PTM_ERR_INVALID, "null engine");
   if (!e->have_target) return fail(PTM_ERR_INVALID, "set the target first");
   for (int d = 0; d < e->D; ++d)
-    if (e->h_ptype[d] != PTM_PRIOR_UNIFORM && e->h_ptype[d] != PTM_PRIOR_GAUSSIAN)
-      return fail(PTM_ERR_UNSUPPORTED, "device prior draws exist for uniform/gaussian dimensions only (dimension %d)", d);
+    if (e->h_ptype[d] == PTM_PRIOR_FLAT)
+      return fail(PTM_ERR_UNSUPPORTED, "a flat (improper) prior cannot be drawn from (dimension %d): pass start states", d);
   Dev p = make_dev(e);
   HIPCHK(hipMemsetAsync(e->err + 1, 0, 4, e->stream));
   int rc;

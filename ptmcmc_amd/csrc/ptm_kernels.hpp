@@ -650,6 +650,9 @@ __global__ __launch_bounds__(256) void init_prior_kernel(const Dev p, double* x_
         const u32x4 o = draw_block(p.seed, TAG_INIT, stream, a, (uint32_t)d);
         if (pt[d] == P_UNIFORM) x[d] = u01(o.v0) * (phi[d] - plo[d]) + plo[d];
         else if (pt[d] == P_GAUSSIAN) { double z0, z1; boxmuller(o.v0, o.v1, (const double*)BM_TABLE, z0, z1); x[d] = z0 * phi[d] + plo[d]; }
+        else if (pt[d] == P_POLAR) x[d] = draw_polar(u01(o.v0), plo[d], phi[d]);
+        else if (pt[d] == P_COPOLAR) x[d] = draw_copolar(u01(o.v0), plo[d], phi[d]);
+        else if (pt[d] == P_LOG) x[d] = draw_log(u01(o.v0), plo[d], phi[d]);
         else x[d] = __builtin_nan("");
       }
     }

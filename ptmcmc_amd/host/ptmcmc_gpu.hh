@@ -690,7 +690,7 @@ class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:
     nstep = hdr[6];
     fresh = hist_fresh = map_fresh = false;
   }
-  // chain.cc:1281-1365: n prior draws per rung; the device draws them (uniform / gaussian dimensions)
+  // chain.cc:1281-1365: n prior draws per rung; the device draws them (any prior type but the improper flat one)
   void initialize(bayes_likelihood* log_likelihood, const sampleable_probability_function* log_prior, int n = 1, uint64_t seed = 0x5EED0001ull,
                   const std::vector<double>* start_states = nullptr) {
     sp = log_prior->get_space();

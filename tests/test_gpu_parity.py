@@ -123,6 +123,40 @@ def test_init_from_prior_matches_oracle():
     eng.close()
 
 
+def test_init_from_prior_draws_every_support_type():
+    """MH_chain::initialize (chain.cc:846-876) with a mixed prior: uniform, gaussian, polar, copolar and log dimensions
+    (inverse cdfs of ProbabilityDist.h:32-34,108-110,149-151) drawn on the device, bit-identical to the oracle's
+    restatement of the same procedure, inside their supports and with the right marginals."""
+    import math
+    D, Nt, W = 5, 4, 4096
+    pi = math.pi
+    types = [1, 2, 3, 4, 5]
+    cen = [0.5, 0.3, pi / 2, 0.1, 3.0]
+    hw = [2.0, 1.5, pi / 2 - 0.2, 1.2, 2.5]          # polar on (0.2, pi - 0.2), copolar on (-1.1, 1.3), log on (1.2, 7.5)
+    pr, eng, lad = PU.make_pair(D, Nt, W, 1e2, kind=E.PROP_DIAG, prior=(types, cen, hw), x0=np.tile(cen, (Nt * W, 1)))
+    eng.init_from_prior()
+    lad2 = O.Ladder(lad.pb, pr.beta, W=W)
+    lad2.init_from_prior(0x5EED0001)
+    x = eng.states()
+    assert np.array_equal(PU.to_engine_order(lad2.x, Nt, W), x)
+    assert np.array_equal(PU.to_engine_order(lad2.llike, Nt, W), eng.llike)
+    assert np.isfinite(eng.lprior).all()
+    lo, hi = np.array(cen) - np.array(hw), np.array(cen) + np.array(hw)
+    lo[4], hi[4] = cen[4] / hw[4], cen[4] * hw[4]     # the log type's limits (probability_function.cc:219-262)
+    for d in (0, 2, 3, 4):
+        assert (x[:, d] >= lo[d]).all() and (x[:, d] <= hi[d]).all()
+    n = len(x)
+    # marginals: cdf of the draws at the support's midpoint against the analytic value (4 sigma of a binomial)
+    def check(d, cdf_mid):
+        got = (x[:, d] < cen[d]).mean()
+        assert abs(got - cdf_mid) < 4 * math.sqrt(cdf_mid * (1 - cdf_mid) / n), (d, got, cdf_mid)
+    check(0, 0.5)
+    check(2, (math.cos(lo[2]) - math.cos(cen[2])) / (math.cos(lo[2]) - math.cos(hi[2])))
+    check(3, (math.sin(cen[3]) - math.sin(lo[3])) / (math.sin(hi[3]) - math.sin(lo[3])))
+    check(4, (math.log(cen[4]) - math.log(lo[4])) / (math.log(hi[4]) - math.log(lo[4])))
+    eng.close()
+
+
 SWEEP_CASES = [
     # (D, Nt, W, Tmax, kind, oneDfrac)      BASELINE configs first
     (2, 8, 1, 1e2, E.PROP_LOWER, None),      # C1
