@@ -26,6 +26,8 @@ _u32p = C.POINTER(C.c_uint32)
 
 
 def build(force=False):
+    if os.environ.get("PTM_ORACLE_LIB"):     # e.g. a sanitizer build of the same source
+        return os.environ["PTM_ORACLE_LIB"]
     src = [os.path.join(ORACLE_DIR, f) for f in ("ptm_oracle.c", "ptm_oracle.h", "ptm_tables.inc")]
     stale = force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in src)
     if stale:
