@@ -517,29 +517,32 @@ __global__ __launch_bounds__(DECIDE_THREADS) void decide_kernel(const Decide p) 
     const int col = act ? 2 * sub : 0;      // idle lanes re-read column 0 (harmless) so that no load is predicated
     constexpr int GR = DECIDE_THREADS / 16;   // rows per round
     d2_t v[16];
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int j = GR * q + g;
-      v[q] = *reinterpret_cast<const d2_t*>(p.x + (size_t)(j < nmv ? gs[j] : 0) * DPm + col);   // past the list: row 0, never stored
-    }
     const int msrc = lane < nmv ? gs[lane] : 0;
     const double sl = p.ll[msrc], sp = p.lp[msrc];
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();   // every gather of every thread has landed before the first scatter
+    for (int hc = 0; hc < DPm; hc += 32) {   // (rows of 64 dimensions: their second 256 bytes the same way)
+      const int colh = col + hc;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int j = GR * q + g;
-      const int d = j < nmv ? gd[j] : -3;
-      if (d != -3 && act) {
-        double* dstp;
-        if (d >= 0) dstp = p.x + (size_t)d * DPm;
-        else if (d <= HIST_DST) {
-          const int c = HIST_DST - d;
-          dstp = p.hist.x + hist_slot(p.hist, 1 + (long long)(p.nhist[c] / (unsigned int)p.add_every_n), c) * DPm;
-        } else if (d <= MAP_DST) {
-          dstp = p.map.x + (size_t)(MAP_DST - d) * DPm;
-        } else { const int e = -d - 4; dstp = ((e & 1) ? p.send_down : p.send_up) + MSG_HDR + (size_t)(e >> 1) * RD; }
-        *reinterpret_cast<d2_t*>(dstp + col) = v[q];
+      for (int q = 0; q < 16; ++q) {
+        const int j = GR * q + g;
+        v[q] = *reinterpret_cast<const d2_t*>(p.x + (size_t)(j < nmv ? gs[j] : 0) * DPm + colh);   // past the list: row 0, never stored
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();   // every gather of every thread has landed before the first scatter
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int j = GR * q + g;
+        const int d = j < nmv ? gd[j] : -3;
+        if (d != -3 && act) {
+          double* dstp;
+          if (d >= 0) dstp = p.x + (size_t)d * DPm;
+          else if (d <= HIST_DST) {
+            const int c = HIST_DST - d;
+            dstp = p.hist.x + hist_slot(p.hist, 1 + (long long)(p.nhist[c] / (unsigned int)p.add_every_n), c) * DPm;
+          } else if (d <= MAP_DST) {
+            dstp = p.map.x + (size_t)(MAP_DST - d) * DPm;
+          } else { const int e = -d - 4; dstp = ((e & 1) ? p.send_down : p.send_up) + MSG_HDR + (size_t)(e >> 1) * RD; }
+          *reinterpret_cast<d2_t*>(dstp + colh) = v[q];
+        }
       }
     }
     if (lane < nmv) {
@@ -617,7 +620,7 @@ __global__ __launch_bounds__(DECIDE_THREADS) void decide_kernel(const Decide p) 
       if (!head) continue;
       double* X = p.x;
       const int c0 = (r - p.r0) * p.W + w;
-      double tmp[34];                                      // the head's old row {x[0..DP), llike, lprior}, DP <= 32
+      double tmp[66];                                      // the head's old row {x[0..DP), llike, lprior}, DP <= 64
       for (int d = 0; d < DP; ++d) tmp[d] = X[(size_t)c0 * DP + d];
       tmp[DP] = p.ll[c0];
       tmp[DP + 1] = p.lp[c0];
@@ -729,26 +732,29 @@ __global__ __launch_bounds__(64 * WPB, MV > 64 ? 1 : 4) void move_kernel(const M
   d2_t v[MV / 4];
   double sl[MV / 64], sp[MV / 64];
 #pragma unroll
-  for (int q = 0; q < MV / 4; ++q)        // unconditional loads: entries past the list read row 0 and are never stored
-    v[q] = *reinterpret_cast<const d2_t*>(p.x + (size_t)s_src[4 * q + g] * DP + col);
-#pragma unroll
   for (int q = 0; q < MV / 64; ++q) {
     sl[q] = p.ll[s_src[64 * q + lane]];
     sp[q] = p.lp[s_src[64 * q + lane]];
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every gather has landed before the first scatter
+  for (int hc = 0; hc < DP; hc += 32) {   // (rows of 64 dimensions: their second 256 bytes the same way)
+    const int colh = col + hc;
 #pragma unroll
-  for (int q = 0; q < MV / 4; ++q) {
-    const int d = s_dst[4 * q + g];
-    if (d != -3 && act) {
-      double* dstp;
-      if (d >= 0) dstp = p.x + (size_t)d * DP;
-      else if (HIST && d <= MAP_DST && d > HIST_DST) dstp = p.map.x + (size_t)(MAP_DST - d) * DP;
-      else if (HIST && d <= HIST_DST) {
-        const int c = HIST_DST - d;
-        dstp = p.hist.x + hist_slot(p.hist, 1 + (long long)(p.nhist[c] / (unsigned int)p.add_every_n), c) * DP;
-      } else { const int e = -d - 4; dstp = ((e & 1) ? p.send_down : p.send_up) + MSG_HDR + (size_t)(e >> 1) * RD; }
-      *reinterpret_cast<d2_t*>(dstp + col) = v[q];
+    for (int q = 0; q < MV / 4; ++q)        // unconditional loads: entries past the list read row 0 and are never stored
+      v[q] = *reinterpret_cast<const d2_t*>(p.x + (size_t)s_src[4 * q + g] * DP + colh);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every gather has landed before the first scatter
+#pragma unroll
+    for (int q = 0; q < MV / 4; ++q) {
+      const int d = s_dst[4 * q + g];
+      if (d != -3 && act) {
+        double* dstp;
+        if (d >= 0) dstp = p.x + (size_t)d * DP;
+        else if (HIST && d <= MAP_DST && d > HIST_DST) dstp = p.map.x + (size_t)(MAP_DST - d) * DP;
+        else if (HIST && d <= HIST_DST) {
+          const int c = HIST_DST - d;
+          dstp = p.hist.x + hist_slot(p.hist, 1 + (long long)(p.nhist[c] / (unsigned int)p.add_every_n), c) * DP;
+        } else { const int e = -d - 4; dstp = ((e & 1) ? p.send_down : p.send_up) + MSG_HDR + (size_t)(e >> 1) * RD; }
+        *reinterpret_cast<d2_t*>(dstp + colh) = v[q];
+      }
     }
   }
 #pragma unroll
@@ -797,7 +803,8 @@ __global__ __launch_bounds__(256) void install_kernel(const Install p) {
   const int w = (int)row[DP + 2];
   const int a = (w >= 0 && w < p.W) ? arr[w] : -1;
   if (a < 0) { atomicOr(p.err, 8); return; }  // a row nobody expects: the two shards disagree about the step
-  if (2 * sub < DP) *reinterpret_cast<d2_t*>(p.x + (size_t)a * DP + 2 * sub) = *reinterpret_cast<const d2_t*>(row + 2 * sub);
+  for (int col = 2 * sub; col < DP; col += 32)
+    *reinterpret_cast<d2_t*>(p.x + (size_t)a * DP + col) = *reinterpret_cast<const d2_t*>(row + col);
   if (sub == 0) { p.ll[a] = row[DP]; p.lp[a] = row[DP + 1]; }
 }
 

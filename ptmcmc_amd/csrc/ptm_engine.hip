@@ -130,7 +130,7 @@ extern "C" int ptm_engine_create(const ptm_config* cfg, ptm_engine** out) {
   if (!cfg || !out) return fail(PTM_ERR_INVALID, "null argument");
   if (cfg->struct_size != sizeof(ptm_config)) return fail(PTM_ERR_INVALID, "ptm_config size mismatch (ABI)");
   if (cfg->dim < 1) return fail(PTM_ERR_INVALID, "dim must be >= 1");
-  if (cfg->dim > 32) return fail(PTM_ERR_UNSUPPORTED, "dim > 32 is not built (kernels exist for padded dimensions 4, 8, 16, 32)");
+  if (cfg->dim > 64) return fail(PTM_ERR_UNSUPPORTED, "dim > 64 is not built (kernels exist for padded dimensions 4, 8, 16, 32, 64)");
   if (cfg->n_rungs < 1 || cfg->n_rungs > 65535) return fail(PTM_ERR_INVALID, "n_rungs must be in 1..65535");
   if (cfg->rung_begin < 0 || cfg->rung_count < 1 || cfg->rung_begin + cfg->rung_count > cfg->n_rungs)
     return fail(PTM_ERR_INVALID, "rung block out of range");
@@ -668,10 +668,11 @@ static int launch_sweep(ptm_engine* e, int rung0 = 0, int nr = -1, bool last = t
       case 8: return launch_sweep_8(q, sel, e->stream);
       case 16: return launch_sweep_16(q, sel, e->stream);
       case 32: return launch_sweep_32(q, sel, e->stream);
+      case 64: return launch_sweep_64(q, sel, e->stream);
     }
     return hipErrorInvalidValue;
   };
-  if (e->DP > 32) return fail(PTM_ERR_UNSUPPORTED, "dim > 32 is not built in this round");
+  if (e->DP > 32 && e->cb) return fail(PTM_ERR_UNSUPPORTED, "a host-callback likelihood with more than 32 dimensions is not built");
   if (!e->cb) {
     HIPCHK(launch(p));
   } else {
@@ -816,7 +817,8 @@ static int run_eval(ptm_engine* e, int n, double* x, int* valid, double* lp, dou
     case 8: HIPCHK(launch_eval_8(p, n, x, valid, lp, ll, eval_like, e->stream)); break;
     case 16: HIPCHK(launch_eval_16(p, n, x, valid, lp, ll, eval_like, e->stream)); break;
     case 32: HIPCHK(launch_eval_32(p, n, x, valid, lp, ll, eval_like, e->stream)); break;
-    default: return fail(PTM_ERR_UNSUPPORTED, "dim > 32 is not built in this round");
+    case 64: HIPCHK(launch_eval_64(p, n, x, valid, lp, ll, eval_like, e->stream)); break;
+    default: return fail(PTM_ERR_UNSUPPORTED, "dim > 64 is not built");
   }
   return PTM_OK;
 }
@@ -865,7 +867,8 @@ static int launch_init(ptm_engine* e, const Dev& p, long long attempt, unsigned 
     case 8: HIPCHK(launch_init_8(p, e->x, e->ll, e->lp, e->err + 1, attempt, pending, e->stream)); break;
     case 16: HIPCHK(launch_init_16(p, e->x, e->ll, e->lp, e->err + 1, attempt, pending, e->stream)); break;
     case 32: HIPCHK(launch_init_32(p, e->x, e->ll, e->lp, e->err + 1, attempt, pending, e->stream)); break;
-    default: return fail(PTM_ERR_UNSUPPORTED, "dim > 32 is not built in this round");
+    case 64: HIPCHK(launch_init_64(p, e->x, e->ll, e->lp, e->err + 1, attempt, pending, e->stream)); break;
+    default: return fail(PTM_ERR_UNSUPPORTED, "dim > 64 is not built");
   }
   return PTM_OK;
 }
@@ -1229,7 +1232,7 @@ extern "C" const char* ptm_sweep_kernel_name(ptm_engine* e) {
     snprintf(b, sizeof b, "sweep_mfma32_kernel<%d, %s, %d%s>", s.kind == KIND_DIAG ? KIND_LOWER : s.kind, (e->hist.rungs || e->map.rungs) ? "true" : "false",
              s.simple ? 0 : ((e->all_uniform && (!e->has_bounds || e->bounds_box)) ? 1 : 2),
              (!s.simple && e->all_uniform && (!e->has_bounds || e->bounds_box) && e->betaC) ? ", true" : ", false");   // as rocprofv3 prints it
-  else if (!s.uni && !s.callback && e->DP >= 16 && !getenv("PTM_FORCE_VALU") && (long long)e->Nc * e->DP <= PTM_LANES_MAX)
+  else if (e->DP == 64 || (!s.uni && !s.callback && e->DP >= 16 && !getenv("PTM_FORCE_VALU") && (long long)e->Nc * e->DP <= PTM_LANES_MAX))
     snprintf(b, sizeof b, "sweep_lanes_kernel<%d, %d, %s>", e->DP, s.kind, s.plain ? "false" : "true");
   else snprintf(b, sizeof b, "sweep_kernel<%d, %d, %s, %s>", e->DP, s.kind, s.uni ? "true" : "false", s.simple ? "true" : "false");
   e->kname = b;

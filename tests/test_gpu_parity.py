@@ -172,6 +172,9 @@ SWEEP_CASES = [
     (32, 9, 3, 1e3, E.PROP_DENSE, None),     # lanes kernel (a lane per dimension: fewer than 64 walkers per rung), dense
     (13, 11, 5, 1e2, E.PROP_DIAG, None),     # lanes kernel, 13 -> 16 dimensions, diagonal; 55 chains: a ragged last wave
     (29, 6, 70, 1e2, E.PROP_LOWER, None),    # lanes kernel, walkers not a multiple of 64
+    (40, 6, 3, 1e2, E.PROP_DENSE, None),     # 33..64 dimensions: the lanes kernel with one chain per wave
+    (64, 5, 64, 1e2, E.PROP_LOWER, None),
+    (50, 4, 70, 1e2, E.PROP_DIAG, 0.3),
     (18, 7, 3, 1e2, E.PROP_LOWER, 0.4),      # lanes kernel, general build: one-dimensional moves
     (32, 5, 2, 1e2, E.PROP_DIAG, 0.5),
     (5, 7, 3, 1e2, E.PROP_DENSE, 0.3),       # padded dimension (5 -> 8), ragged sizes
@@ -250,6 +253,8 @@ def test_add_every_n_history_counters():
                                                  (32, 6, 128, E.PROP_DENSE, 3, 0.45, 0),
                                                  (5, 7, 3, E.PROP_DENSE, 2, 0.45, 0),    # general kernel, ragged sizes
                                                  (20, 7, 3, E.PROP_DENSE, 2, 0.45, 0),   # lanes kernel (a lane per dimension)
+                                                 (40, 7, 3, E.PROP_DENSE, 2, 0.45, 0),   # 64-dimension rows
+                                                 (33, 300, 64, E.PROP_DIAG, 2, 0.45, 0.01),   # ... in every exchange path, evolving
                                                  (16, 9, 5, E.PROP_LOWER, 1, 0.3, 0),
                                                  (16, 12, 64, E.PROP_DIAG, 4, 0.3, 0),
                                                  (4, 900, 64, E.PROP_DIAG, 2, 0.45, 0),  # > 256 moved rows: the slow exchange path
@@ -753,7 +758,8 @@ class _DevShard:
 
 @pytest.mark.parametrize("overlap", [False, True])
 @pytest.mark.parametrize("D,Nt,W,G,halo,sr", [(32, 16, 64, 2, 4, 0.3), (8, 12, 64, 3, 4, 0.45), (5, 9, 3, 4, 3, 0.45),
-                                              (32, 64, 64, 8, 4, 0.1), (4, 6, 64, 6, 2, 0.5)])
+                                              (32, 64, 64, 8, 4, 0.1), (4, 6, 64, 6, 2, 0.5),
+                                              (40, 12, 5, 3, 3, 0.45)])   # 64-dimension rows through the messages
 def test_sharded_engines_match_single_engine(D, Nt, W, G, halo, sr, overlap):
     import shard_sim
     from ptmcmc_amd.parallel import shard_bounds
