@@ -1,0 +1,34 @@
+"""Long bit-exact runs of the engine against the CPU checker (test infrastructure: uses tests/oracle_lib.py), one per
+kernel family, ladders evolving: rare branches (exchange overflow paths, table edges, twice-touched rungs) get their turn.
+usage (GPU box): python tools/soak_parity.py [steps]"""
+import os
+import sys
+import time
+
+ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import parity_util as PU
+from ptmcmc_amd import engine as E
+
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 4000
+cases = [(6, 12, 5, E.PROP_DENSE, 0.3, 0.02, "general kernel"), (14, 24, 3, E.PROP_LOWER, 0.2, 0.01, "lanes kernel"),
+         (32, 10, 64, E.PROP_LOWER, 0.3, 0.01, "MFMA kernel"), (40, 8, 2, E.PROP_DIAG, 0.4, 0.0, "lanes kernel, 64-dim rows")]
+for D, Nt, W, kind, sr, ev, what in cases:
+    pr, eng, lad = PU.make_pair(D, Nt, W, 1e4, kind=kind, swap_rate=sr, one_d_frac=0.2)
+    if ev:
+        eng.set_evolve_temps(ev); lad.evolve_temps(ev)
+    t0 = time.time()
+    done = 0
+    while done < steps:
+        n = min(500, steps - done)
+        eng.step(n); eng.sync(); lad.pt_step(n)
+        done += n
+        PU.assert_same_state(eng, lad, "%s after %d steps" % (what, done))
+        assert np.array_equal(eng.invtemps(), lad.betaw)
+        print("  %-28s %6d steps ok (%.0fs)" % (what, done, time.time() - t0), flush=True)
+    t, a = eng.swap_counts()
+    print("%s: D=%d %dx%d, %d steps bit-identical; kernel %s; MH accept %.3f, swap accept %.3f" %
+          (what, D, Nt, W, steps, eng.sweep_kernel_name, (eng.naccept.sum() - eng.Nc) / max(1, eng.ntries.sum() - eng.Nc), a.sum() / max(1, t.sum())), flush=True)
+    eng.close()
