@@ -21,6 +21,11 @@
 #ifndef PTMCMC_GPU_HH
 #define PTMCMC_GPU_HH
 
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -202,6 +207,60 @@ class gaussian_dist_product : public mixed_dist_product {  // probability_functi
       : mixed_dist_product(space, std::valarray<int>(gaussian, x0s.size()), x0s, sigmas) {}
 };
 
+// A small persistent worker pool for the likelihood batches: starting and joining threads for every batch costs more than
+// a cheap plug-in's whole batch.  run(n, chunk, f) calls f(k0, k1) over [0, n) in chunks, on the workers and the caller.
+class eval_pool {
+  std::vector<std::thread> workers;
+  std::mutex m;
+  std::condition_variable cv_go, cv_done;
+  std::function<void(int, int)> job;
+  std::atomic<int> next{0};
+  int n = 0, chunk = 1, generation = 0, busy = 0;
+  bool stop = false;
+  void drain() {
+    for (;;) {
+      const int k0 = next.fetch_add(chunk);
+      if (k0 >= n) return;
+      job(k0, k0 + chunk < n ? k0 + chunk : n);
+    }
+  }
+  void loop() {
+    int seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> lk(m);
+        cv_go.wait(lk, [&] { return stop || generation != seen; });
+        if (stop) return;
+        seen = generation;
+      }
+      drain();
+      std::lock_guard<std::mutex> lk(m);
+      if (--busy == 0) cv_done.notify_one();
+    }
+  }
+
+ public:
+  ~eval_pool() {
+    { std::lock_guard<std::mutex> lk(m); stop = true; }
+    cv_go.notify_all();
+    for (auto& t : workers) t.join();
+  }
+  int size() const { return (int)workers.size(); }
+  void resize(int nworkers) {
+    while ((int)workers.size() < nworkers) workers.emplace_back([this] { loop(); });
+  }
+  void run(int n_, int chunk_, const std::function<void(int, int)>& f) {
+    {
+      std::lock_guard<std::mutex> lk(m);
+      job = f; n = n_; chunk = chunk_ < 1 ? 1 : chunk_; next = 0; busy = (int)workers.size(); ++generation;
+    }
+    cv_go.notify_all();
+    drain();
+    std::unique_lock<std::mutex> lk(m);
+    cv_done.wait(lk, [&] { return busy == 0; });
+  }
+};
+
 // ---- bayesian.hh: the likelihood plug-in -----------------------------------------------------------------------------
 class bayes_likelihood : public probability_function {  // bayesian.hh:307-581 (minimal interface)
  protected:
@@ -270,15 +329,25 @@ class bayes_likelihood : public probability_function {  // bayesian.hh:307-581 (
     };
     int nt = l->eval_threads > 0 ? l->eval_threads : (int)std::thread::hardware_concurrency();
     if (nt > n / 8) nt = n / 8;      // at least 8 states per thread
-    if (nt <= 1) { work(0, n); return; }
-    std::vector<std::thread> pool;
-    for (int t = 1; t < nt; t++) pool.emplace_back(work, (int)((long)n * t / nt), (int)((long)n * (t + 1) / nt));
-    work(0, n / nt);
-    for (auto& th : pool) th.join();
+    // starting and joining threads costs ~50 us: a batch that the measured cost per evaluation prices below ~4 such
+    // units stays on this thread (eval_threads == 0 only; an explicit thread count is obeyed)
+    if (l->eval_threads <= 0 && l->eval_ns >= 0 && l->eval_ns * n < 200e3) nt = 1;
+    if (nt <= 1) {
+      const auto t0 = std::chrono::steady_clock::now();
+      work(0, n);
+      const double ns = std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - t0).count();
+      if (n > 0) l->eval_ns = l->eval_ns < 0 ? ns / n : 0.8 * l->eval_ns + 0.2 * ns / n;
+      return;
+    }
+    if (!l->pool) l->pool.reset(new eval_pool);
+    l->pool->resize(nt - 1);   // the calling thread works too
+    l->pool->run(n, (n + 4 * nt - 1) / (4 * nt), work);
   }
 
  private:
   int eval_threads = 0;   // 0: all hardware threads
+  double eval_ns = 0;     // running estimate of one evaluation's cost (the first batch runs serially and measures it)
+  std::unique_ptr<eval_pool> pool;
 
  public:
 };
