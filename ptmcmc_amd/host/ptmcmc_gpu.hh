@@ -522,7 +522,7 @@ class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:
   const double Tmax, swap_rate, dpriormin;
   ptm_engine* eng;
   const stateSpace* sp;
-  int dim, nstep, hist_rows;
+  int dim, nstep, hist_rows, hist_rungs = 0;   // hist_rungs: the coldest rungs whose saved states are kept (0: all)
   int W;   // independent replicas of the ladder run side by side (the reference runs its Nchain repeats one after the
            // other, ptmcmc.cc main loop): chain (rung i, replica w) sits at index i*W + w of every engine array
   std::vector<double> temps, X, llike, lpost;
@@ -620,7 +620,13 @@ class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:
   // Keep what MH_chain::add_state saves (every add_every_N-th state of every rung, chain.cc:935-946) on the device, in a
   // ring of `rows_per_chain` rows per rung; call before initialize().  The reference keeps the whole history in host
   // vectors; dumpChain() below writes the same file from the ring.
-  void keep_history(int rows_per_chain) { hist_rows = rows_per_chain; }
+  // `coldest_rungs` > 0 keeps the history of that many rungs from the cold end only (what the sampler's pt_dump_n asks
+  // for): less device memory, smaller read-backs.
+  void keep_history(int rows_per_chain, int coldest_rungs = 0) {
+    hist_rows = rows_per_chain;
+    hist_rungs = coldest_rungs > 0 && coldest_rungs < Ntemps ? coldest_rungs : 0;
+  }
+  int history_rungs() const { return hist_rows > 0 ? (hist_rungs > 0 ? hist_rungs : Ntemps) : 0; }
   // Run `n` independent replicas of the ladder in one engine (call before initialize()).  Replica w uses the random
   // streams of walker w; every accessor below takes the replica as an optional last argument (default 0).  Multiples
   // of 64 fill whole wavefronts and take the fast kernels.
@@ -673,7 +679,7 @@ class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:
     const size_t N = (size_t)Ntemps * W, np = (size_t)W * (Ntemps > 1 ? Ntemps - 1 : 1);
     auto wr = [&](const void* ptr, size_t bytes) { os.write((const char*)ptr, (std::streamsize)bytes); };
     const char magic[8] = {'P', 'T', 'M', 'G', 'P', 'U', '0', '1'};
-    int32_t hdr[8] = {Ntemps, W, dim, hist_rows, ev_rate > 0 ? 1 : 0, tracking ? 1 : 0, nstep, add_every_N};
+    int32_t hdr[8] = {Ntemps, W, dim, hist_rows + 65536 * history_rungs(), ev_rate > 0 ? 1 : 0, tracking ? 1 : 0, nstep, add_every_N};
     uint64_t estep = ptm_step_count(eng);
     wr(magic, 8); wr(hdr, sizeof hdr); wr(&estep, 8);
     std::vector<double> x(N * dim), ll(N);
@@ -694,7 +700,7 @@ class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:
       wr(b.data(), b.size() * 8);
     }
     if (hist_rows > 0) {
-      const size_t n = (size_t)hist_rows * N;
+      const size_t n = (size_t)hist_rows * history_rungs() * W;
       std::vector<double> gx(n * dim), gl(n), gp(n), gb(n);
       std::vector<int32_t> gm(n * 4);
       ptm_check(ptm_get_history(eng, gx.data(), gl.data(), gp.data(), gm.data()), "checkpoint");
@@ -720,7 +726,7 @@ class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:
     auto rd = [&](void* ptr, size_t bytes) { is.read((char*)ptr, (std::streamsize)bytes); };
     char magic[8]; int32_t hdr[8]; uint64_t estep;
     rd(magic, 8); rd(hdr, sizeof hdr); rd(&estep, 8);
-    if (std::string(magic, 8) != "PTMGPU01" || hdr[0] != Ntemps || hdr[1] != W || hdr[2] != dim || hdr[3] != hist_rows ||
+    if (std::string(magic, 8) != "PTMGPU01" || hdr[0] != Ntemps || hdr[1] != W || hdr[2] != dim || hdr[3] != hist_rows + 65536 * history_rungs() ||
         hdr[4] != (ev_rate > 0 ? 1 : 0) || hdr[7] != add_every_N) {
       std::cout << "parallel_tempering_chains::restart: " << fn << " was written by a differently configured ladder" << std::endl;
       exit(1);
@@ -738,7 +744,7 @@ class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:
       ptm_check(ptm_set_invtemps(eng, b.data()), "restart");
     }
     if (hist_rows > 0) {
-      const size_t n = (size_t)hist_rows * N;
+      const size_t n = (size_t)hist_rows * history_rungs() * W;
       std::vector<double> gx(n * dim), gl(n), gp(n), gb(n);
       std::vector<int32_t> gm(n * 4);
       rd(gx.data(), gx.size() * 8); rd(gl.data(), n * 8); rd(gp.data(), n * 8); rd(gm.data(), gm.size() * 4); rd(gb.data(), n * 8);
@@ -768,7 +774,7 @@ class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:
     cfg.struct_size = sizeof cfg;
     cfg.dim = dim; cfg.n_rungs = Ntemps; cfg.rung_begin = 0; cfg.rung_count = Ntemps; cfg.n_walkers = W; cfg.seed = seed;
     cfg.swap_rate = swap_rate; cfg.add_every_n = add_every_N; cfg.min_prior = dpriormin; cfg.device = -1; cfg.stream = nullptr;
-    cfg.time_kernels = 0; cfg.swap_log_steps = 0; cfg.exchange_row_capacity = 0; cfg.history_rungs = hist_rows > 0 ? Ntemps : 0; cfg.history_capacity = hist_rows; cfg.map_rungs = Ntemps;
+    cfg.time_kernels = 0; cfg.swap_log_steps = 0; cfg.exchange_row_capacity = 0; cfg.history_rungs = history_rungs(); cfg.history_capacity = hist_rows; cfg.map_rungs = Ntemps;
     ptm_check(ptm_engine_create(&cfg, &eng), "parallel_tempering_chains::initialize");
     std::vector<int> lo(dim), hi(dim), types;
     std::vector<double> xmin(dim), xmax(dim), centers, halfwidths;
@@ -864,9 +870,10 @@ class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:
   // Rows that have already left the ring are skipped (the ring holds the newest rows_per_chain saved states).
   void dumpChain(int ichain, std::ostream& os, int Nburn = 0, int ievery = 1, int replica = 0) {
     if (hist_rows <= 0) { std::cout << "parallel_tempering_chains::dumpChain: call keep_history(rows) before initialize()" << std::endl; exit(1); }
-    const size_t HC = (size_t)Ntemps * W, cap = hist_rows, at = (size_t)ichain * W + replica;
+    if (ichain >= history_rungs()) { std::cout << "parallel_tempering_chains::dumpChain: rung " << ichain << " keeps no history (keep_history(rows, " << history_rungs() << "))" << std::endl; exit(1); }
+    const size_t HC = (size_t)history_rungs() * W, cap = hist_rows, at = (size_t)ichain * W + replica;
     if (!hist_fresh) {   // one read-back serves every rung / replica dumped at this step
-      hx.resize(cap * HC * dim); hl.resize(cap * HC); hp.resize(cap * HC); hmeta.resize(cap * HC * 4); hnhist.resize(HC); hb.resize(cap * HC);
+      hx.resize(cap * HC * dim); hl.resize(cap * HC); hp.resize(cap * HC); hmeta.resize(cap * HC * 4); hnhist.resize((size_t)Ntemps * W); hb.resize(cap * HC);
       ptm_check(ptm_get_history(eng, hx.data(), hl.data(), hp.data(), hmeta.data()), "dumpChain");
       ptm_check(ptm_get_history_invtemps(eng, hb.data()), "dumpChain");   // the temperature each row was saved at
       ptm_check(ptm_get_array(eng, PTM_ARR_NHIST, hnhist.data()), "dumpChain");
@@ -981,7 +988,11 @@ class ptmcmc_sampler {
     cc.reset(new parallel_tempering_chains((int)num("pt"), num("pt_Tmax"), num("pt_swap_rate"), (int)num("save_every"), false, false, num("chain_dprior_min")));
     // the chain files are written from the device's history ring, every "nevery" steps: it must hold what one such
     // interval saves (up to two add_state calls per step, every save_every-th saved)
-    cc->keep_history(2 + 2 * (int)num("nevery") / std::max(1, (int)num("save_every")));
+    {
+      int dump_n = (int)num("pt_dump_n");
+      if (dump_n > (int)num("pt") || dump_n <= 0) dump_n = (int)num("pt");   // ptmcmc.cc:458
+      cc->keep_history(2 + 2 * (int)num("nevery") / std::max(1, (int)num("save_every")), dump_n);
+    }
     cc->set_replicas((int)num("nchains"));   // the reference's Nchain repeats, all at once
     if (num("pt_evolve_rate") > 0) cc->evolve_temps(num("pt_evolve_rate"), num("pt_evolve_lpost_cut"));   // ptmcmc.cc:512
     uint64_t seed = num("seed") >= 0 ? (uint64_t)(num("seed") * 4294967296.0) : 0x5EED0001ull;
