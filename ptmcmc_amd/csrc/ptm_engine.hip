@@ -92,7 +92,7 @@ struct ptm_engine {
   unsigned char* gate = nullptr;
   pinned_vector<double> h_xprop, h_llnew;
   std::vector<double> h_batch, h_llbatch;
-  pinned_vector<unsigned char> h_gate;
+  unsigned char* h_gate = nullptr;   // view into h_xprop's tail
   // timing
   hipEvent_t t0 = nullptr, t1 = nullptr;
   std::vector<hipEvent_t> kev;  // pairs
@@ -261,7 +261,7 @@ extern "C" int ptm_engine_destroy(ptm_engine* e) {
   (void)hipStreamSynchronize(e->stream);
   void* ptrs[] = {e->x, e->ll, e->lp, e->ntries, e->naccept, e->last_type, e->arr_below, e->arr_above, e->mv_src, e->mv_dst, e->mv_n,
                   e->err, e->nhist, e->swap_cnt, e->touch, e->swap_log, e->hist.x, e->hist.ll, e->hist.lp, e->hist.meta, e->map.lpost, e->map.ll, e->map.lp, e->map.x, e->blo,
-                  e->bhi, e->ptype, e->bmin, e->bmax, e->plo, e->phi, e->pcoef, e->P2, e->mean, e->beta, e->prop, e->prop_tiles, e->P2_tiles, e->box_row, e->onedfrac, e->mix, e->beta_w, e->betaC, e->beta_add, e->hist.beta, e->xprop, e->lprior_new, e->llike_new, e->gate};
+                  e->bhi, e->ptype, e->bmin, e->bmax, e->plo, e->phi, e->pcoef, e->P2, e->mean, e->beta, e->prop, e->prop_tiles, e->P2_tiles, e->box_row, e->onedfrac, e->mix, e->beta_w, e->betaC, e->beta_add, e->hist.beta, e->xprop, e->lprior_new, e->llike_new};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (hipEvent_t ev : e->kev) (void)hipEventDestroy(ev);
@@ -397,10 +397,12 @@ extern "C" int ptm_set_target_callback(ptm_engine* e, ptm_loglike_batch_fn fn, v
   if (!e || !fn) return fail(PTM_ERR_INVALID, "null argument");
   const size_t Nc = e->Nc, DP = e->DP;
   int rc;
-  if (!e->xprop && ((rc = dalloc(&e->xprop, Nc * DP)) || (rc = dalloc(&e->lprior_new, Nc)) || (rc = dalloc(&e->llike_new, Nc)) ||
-                    (rc = dalloc(&e->gate, Nc))))
+  // (the gate bytes sit right behind the proposals: one device-to-host copy fetches both)
+  if (!e->xprop && ((rc = dalloc(&e->xprop, Nc * DP + (Nc + 7) / 8)) || (rc = dalloc(&e->lprior_new, Nc)) || (rc = dalloc(&e->llike_new, Nc))))
     return rc;
-  e->h_xprop.resize(Nc * DP); e->h_gate.resize(Nc); e->h_llnew.assign(Nc, 0.0);
+  e->gate = reinterpret_cast<unsigned char*>(e->xprop + Nc * DP);
+  e->h_xprop.resize(Nc * DP + (Nc + 7) / 8); e->h_llnew.assign(Nc, 0.0);
+  e->h_gate = reinterpret_cast<unsigned char*>(e->h_xprop.data() + Nc * DP);
   e->cb = fn; e->cb_user = user;
   e->have_target = 1;
   return PTM_OK;
@@ -699,10 +701,8 @@ static int launch_sweep(ptm_engine* e, int rung0 = 0, int nr = -1, bool last = t
     const size_t Nc = e->Nc, DP = e->DP;
     p.xprop = e->xprop; p.lprior_new = e->lprior_new; p.gate = e->gate; p.llike_new = e->llike_new;
     p.mode = 1;
-    HIPCHK(hipMemsetAsync(e->gate, 0, Nc, e->stream));
-    HIPCHK(launch(p));
-    HIPCHK(hipMemcpyAsync(e->h_gate.data(), e->gate, Nc, hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipMemcpyAsync(e->h_xprop.data(), e->xprop, Nc * DP * 8, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(launch(p));   // (the propose pass writes every chain's gate byte: 0 for the rungs that make no move)
+    HIPCHK(hipMemcpyAsync(e->h_xprop.data(), e->xprop, Nc * DP * 8 + Nc, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     std::vector<size_t> pick;
     for (size_t c = 0; c < Nc; ++c)
@@ -912,7 +912,7 @@ extern "C" int ptm_init_from_prior(ptm_engine* e) {
     size_t left = Nc;
     for (long long a = 0; left && a < 100000; ++a) {
       if ((rc = launch_init(e, p, a, e->gate))) return rc;
-      HIPCHK(hipMemcpyAsync(e->h_gate.data(), e->gate, Nc, hipMemcpyDeviceToHost, e->stream));
+      HIPCHK(hipMemcpyAsync(e->h_gate, e->gate, Nc, hipMemcpyDeviceToHost, e->stream));
       HIPCHK(hipMemcpyAsync(e->h_xprop.data(), e->x, Nc * DP * 8, hipMemcpyDeviceToHost, e->stream));
       HIPCHK(hipStreamSynchronize(e->stream));
       std::vector<size_t> pick;
@@ -926,7 +926,7 @@ extern "C" int ptm_init_from_prior(ptm_engine* e) {
         e->h_gate[pick[k]] = 2;
         left--;
       }
-      HIPCHK(hipMemcpyAsync(e->gate, e->h_gate.data(), Nc, hipMemcpyHostToDevice, e->stream));
+      HIPCHK(hipMemcpyAsync(e->gate, e->h_gate, Nc, hipMemcpyHostToDevice, e->stream));
     }
     if (left) return fail(PTM_ERR_INVALID, "could not draw a valid start state from the prior for some chain");
     if ((rc = upload(e->ll, llh.data(), Nc, e->stream))) return rc;

@@ -495,7 +495,10 @@ __global__ __launch_bounds__(256, PTM_SWEEP_WAVES) void sweep_kernel(const Dev p
     factor_product<DP, KIND>(dc, as_c(p.prop) + (size_t)rl * p.prop_stride, xn);
   }
 
-  if (tc) return;  // touched rung: no MH move (its add_state calls were counted above)
+  if (tc) {        // touched rung: no MH move (its add_state calls were counted above)
+    if (!SIMPLE && mode == 1) p.gate[c] = 0;   // propose pass of the host-callback path: nothing to evaluate
+    return;
+  }
 
   // -- current state: read only now (its registers are not live across the draw loops) and folded straight into the
   //    proposal.  The row is written back only if the move is accepted.

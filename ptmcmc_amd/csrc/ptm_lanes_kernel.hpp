@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) void sweep_lanes_kernel(const Dev p) {
     if (d < 4) {
       double pq = 1.0;
 #pragma unroll
-      for (int i = d; i < DP; i += 4) pq *= sbuf[g * DP + i];
+      for (int t = 0; t < DP / 4; ++t) pq *= sbuf[g * DP + d + 4 * t];
       pbuf[g * 4 + d] = pq;
     }
     sync_wave();
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256) void sweep_lanes_kernel(const Dev p) {
   if (d < 4) {
     double pq = 0.0;
 #pragma unroll
-    for (int i = d; i < DP; i += 4) pq = __builtin_fma(vbuf[g * DP + i], sbuf[g * DP + i], pq);
+    for (int t = 0; t < DP / 4; ++t) pq = __builtin_fma(vbuf[g * DP + d + 4 * t], sbuf[g * DP + d + 4 * t], pq);
     pbuf[g * 4 + d] = pq;
   }
   sync_wave();
