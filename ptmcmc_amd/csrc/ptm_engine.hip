@@ -693,7 +693,7 @@ static int launch_sweep(ptm_engine* e, int rung0 = 0, int nr = -1, bool last = t
     }
     return hipErrorInvalidValue;
   };
-  if (e->DP > 32 && e->cb) return fail(PTM_ERR_UNSUPPORTED, "a host-callback likelihood with more than 32 dimensions is not built");
+
   if (!e->cb) {
     HIPCHK(launch(p));
   } else {
@@ -1251,7 +1251,7 @@ extern "C" const char* ptm_sweep_kernel_name(ptm_engine* e) {
     snprintf(b, sizeof b, "sweep_mfma32_kernel<%d, %s, %d%s>", s.kind == KIND_DIAG ? KIND_LOWER : s.kind, (e->hist.rungs || e->map.rungs) ? "true" : "false",
              s.simple ? 0 : ((e->all_uniform && (!e->has_bounds || e->bounds_box)) ? 1 : 2),
              (!s.simple && e->all_uniform && (!e->has_bounds || e->bounds_box) && e->betaC) ? ", true" : ", false");   // as rocprofv3 prints it
-  else if (e->DP == 64 || (!s.uni && !s.callback && e->DP >= 16 && !getenv("PTM_FORCE_VALU") && (long long)e->Nc * e->DP <= PTM_LANES_MAX))
+  else if (e->DP == 64 || (!s.uni && e->DP >= 16 && !getenv("PTM_FORCE_VALU") && (long long)e->Nc * e->DP <= PTM_LANES_MAX))
     snprintf(b, sizeof b, "sweep_lanes_kernel<%d, %d, %s>", e->DP, s.kind, s.plain ? "false" : "true");
   else snprintf(b, sizeof b, "sweep_kernel<%d, %d, %s, %s>", e->DP, s.kind, s.uni ? "true" : "false", s.simple ? "true" : "false");
   e->kname = b;

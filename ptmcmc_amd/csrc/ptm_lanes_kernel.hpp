@@ -52,8 +52,11 @@ __global__ __launch_bounds__(256) void sweep_lanes_kernel(const Dev p) {
   // a flag of the chain's lead lane, for all its lanes
   auto from_lead = [&](int v) { return __builtin_amdgcn_ds_bpermute(4 * (g * DP), v); };
 
+  // host-callback likelihood (GEN build): mode 1 = propose pass (proposal, validity, prior -> xprop / lprior_new / gate, nothing
+  // else changes), mode 2 = accept pass with the host's llike_new; 0 = fused
+  const int mode = GEN ? p.mode : 0;
   const int tc = p.touch[c];  // > 0: the rung took part in that many exchange attempts => no MH move this step
-  if (tc) {
+  if (tc && mode != 1) {
     // one add_state per attempt (chain.cc:1487-1490,1531-1534,1554-1557); the LAST of them saw the row as it is now
     const unsigned int nh0 = p.nhist[c];
     const unsigned int a = nh0 + (unsigned int)tc - 1u;
@@ -106,8 +109,10 @@ __global__ __launch_bounds__(256) void sweep_lanes_kernel(const Dev p) {
     if (GEN && axis >= 0 && d != axis) zd = 0.0;   // one-dimensional move (proposal_distribution.hh:197-205)
   }
   // -- gaussian_prop::draw (proposal_distribution.hh:194-218): offset = factor * z, row d on lane d
-  double off;
-  if (KIND == KIND_DIAG) {
+  double off = 0.0;
+  if (mode == 2) {
+    // accept pass: the proposal was drawn and stored by the propose pass
+  } else if (KIND == KIND_DIAG) {
     off = p.prop[(size_t)rl * p.prop_stride + d] * zd;
   } else {
     vbuf[g * DP + d] = zd;
@@ -135,7 +140,7 @@ __global__ __launch_bounds__(256) void sweep_lanes_kernel(const Dev p) {
     type = kmix + 10 * type;   // proposal_distribution.cc:117
     off = mix_scale * off;     // the member is scale_k times the rung's factor
   }
-  double xn = row[pos] + off;   // state::add (states.cc:205-214)
+  double xn = mode == 2 ? p.xprop[(size_t)c * DP + pos] : row[pos] + off;   // state::add (states.cc:205-214)
   const double beta = (GEN && p.betaC) ? p.betaC[c] : p.beta[rg];
   const double bl = beta * ll;
   const double cur_lpost = lp + bl;
@@ -144,7 +149,10 @@ __global__ __launch_bounds__(256) void sweep_lanes_kernel(const Dev p) {
   auto all_of_chain = [&](bool v) { return ((__builtin_amdgcn_ballot_w64(v) >> (g * DP)) & GM) == GM; };
   bool valid = true;
   double newlprior;
-  if (!GEN || p.all_uniform) {
+  if (mode == 2) {
+    valid = (p.gate[c] & 1) != 0;
+    newlprior = p.lprior_new[c];
+  } else if (!GEN || p.all_uniform) {
     if (GEN) {
       // stateSpace::enforce (states.cc:86-102), each dimension on its lane; Q9: the sum is built on an enforced zero state
       bool vd = true;
@@ -173,27 +181,40 @@ __global__ __launch_bounds__(256) void sweep_lanes_kernel(const Dev p) {
     newlprior = valid ? dlog(result) : -__builtin_inf();
   }
   const bool want_like = valid && (newlprior > -1e200 || newlprior - oldlprior > p.min_prior);  // chain.cc:980 (Q1)
+  if (mode == 1) {   // hand the proposal to the host, change nothing else
+    if (live) {
+      if (!tc) p.xprop[(size_t)c * DP + pos] = xn;
+      if (lead) {
+        p.lprior_new[c] = newlprior;
+        p.gate[c] = tc ? (unsigned char)0 : (unsigned char)((valid ? 1 : 0) | (want_like ? 2 : 0));
+      }
+    }
+    return;
+  }
   // -- Gaussian likelihood: s_d = sum_{j<d} 2P_dj y_j + P_dd y_d (one fma chain, j ascending), then y.s in four interleaved
   //    partial sums p_q = sum_{i = q mod 4} y_i s_i (i ascending), combined ((p0 + p1) + p2) + p3
-  vbuf[g * DP + d] = (GEN && p.has_mean) ? xn - p.mean[d] : xn;
-  sync_wave();
-  {
-    const double* prow = p2s + d * (d + 1) / 2;
-    const double* y = vbuf + g * DP;
-    double s = 0.0;
-    for (int j = 0; j <= d; ++j) s = __builtin_fma(prow[j], y[j], s);
-    sbuf[g * DP + d] = s;
+  double quad = 0.0;
+  if (mode != 2) {
+    vbuf[g * DP + d] = (GEN && p.has_mean) ? xn - p.mean[d] : xn;
+    sync_wave();
+    {
+      const double* prow = p2s + d * (d + 1) / 2;
+      const double* y = vbuf + g * DP;
+      double s = 0.0;
+      for (int j = 0; j <= d; ++j) s = __builtin_fma(prow[j], y[j], s);
+      sbuf[g * DP + d] = s;
+    }
+    sync_wave();
+    if (d < 4) {
+      double pq = 0.0;
+  #pragma unroll
+      for (int t = 0; t < DP / 4; ++t) pq = __builtin_fma(vbuf[g * DP + d + 4 * t], sbuf[g * DP + d + 4 * t], pq);
+      pbuf[g * 4 + d] = pq;
+    }
+    sync_wave();
+    quad = ((pbuf[g * 4 + 0] + pbuf[g * 4 + 1]) + pbuf[g * 4 + 2]) + pbuf[g * 4 + 3];
   }
-  sync_wave();
-  if (d < 4) {
-    double pq = 0.0;
-#pragma unroll
-    for (int t = 0; t < DP / 4; ++t) pq = __builtin_fma(vbuf[g * DP + d + 4 * t], sbuf[g * DP + d + 4 * t], pq);
-    pbuf[g * 4 + d] = pq;
-  }
-  sync_wave();
-  const double quad = ((pbuf[g * 4 + 0] + pbuf[g * 4 + 1]) + pbuf[g * 4 + 2]) + pbuf[g * 4 + 3];
-  double newlike = p.like0 - 0.5 * quad;
+  double newlike = mode == 2 ? p.llike_new[c] : p.like0 - 0.5 * quad;
   double newlpost = newlike * beta + newlprior;
   if (!want_like) newlike = newlpost = -__builtin_inf();
   const double logH = newlpost - cur_lpost;  // gaussian_prop: log_hastings_ratio() == 0

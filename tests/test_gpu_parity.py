@@ -879,6 +879,51 @@ def test_host_callback_likelihood_C5_exampleLISA(ev):
     eng.close()
 
 
+@pytest.mark.parametrize("D,Nt,W,ev", [(12, 8, 3, 0.0), (20, 6, 5, 0.03), (40, 5, 2, 0.0)])
+def test_host_callback_likelihood_through_the_lanes_kernel(D, Nt, W, ev):
+    """A plug-in likelihood on a small population with more than 8 dimensions: the propose and accept passes of the lanes
+    kernel (a lane per dimension) around the host call -- bit for bit the oracle's chain, with a gaussian + uniform prior,
+    a wrapped dimension, one-dimensional moves and (ev > 0) an evolving ladder."""
+    import math
+    rng = np.random.default_rng(7)
+    sc = rng.uniform(0.5, 2.0, D)
+    def loglike(x):
+        x = np.asarray(x, dtype=np.float64)
+        return float(-0.5 * np.sum((x * sc) ** 2) - 0.1 * math.cos(3.0 * x[0]))
+    beta = E.geometric_ladder(Nt, 1e3)
+    blo, bhi, bmin, bmax = [0] * D, [0] * D, [0.0] * D, [0.0] * D
+    blo[1], bhi[1], bmin[1], bmax[1] = 3, 3, -2.0, 2.0                     # wrap
+    types, cen, hw = [1] * D, [0.0] * D, [4.0] * D
+    types[2], cen[2], hw[2] = 2, 0.2, 1.5                                   # gaussian
+    x0 = rng.uniform(-1.5, 1.5, size=(Nt * W, D))
+    sig = np.full(D, 0.4)
+    fac = np.tile(sig, (Nt, 1)) / np.sqrt(beta)[:, None].clip(1e-2)
+    eng = E.Engine(D, Nt, W, swap_rate=0.3)
+    eng.set_bounds(blo, bhi, bmin, bmax)
+    eng.set_prior(types, cen, hw)
+    eng.set_target_callback(loglike)
+    eng.set_ladder(beta)
+    eng.set_proposals(E.PROP_DIAG, fac, np.full(Nt, 0.3))
+    eng.set_states(x0)
+    assert eng.sweep_kernel_name.startswith("sweep_lanes_kernel<%d" % (16 if D <= 16 else 32 if D <= 32 else 64))
+    pb = O.Problem(D)
+    pb.set_bounds(blo, bhi, bmin, bmax)
+    pb.set_prior(types, cen, hw)
+    pb.set_user(loglike)
+    lad = O.Ladder(pb, beta, W=W, swap_rate=0.3)
+    lad.set_proposals([(O.PROP_DIAG, fac[r], 0.3) for r in range(Nt)])
+    lad.use_philox(0x5EED0001)
+    lad.set_states(PU.to_oracle_order(x0, Nt, W))
+    if ev:
+        eng.set_evolve_temps(ev); lad.evolve_temps(ev)
+    PU.assert_same_state(eng, lad, "start")
+    for k in range(5):
+        eng.step(6); eng.sync(); lad.pt_step(6)
+        PU.assert_same_state(eng, lad, "after %d steps" % (6 * (k + 1)))
+    assert eng.naccept.sum() - eng.Nc > 10 and (eng.last_type == 1).any()
+    eng.close()
+
+
 def test_exchange_overflow_path_many_moved_rows():
     """More than 256 rows of one ladder move in one step (high swap rate on a long ladder): the exchange kernel's
     in-kernel cycle walk must give the same chain as the register gather/scatter kernel does for smaller counts."""
