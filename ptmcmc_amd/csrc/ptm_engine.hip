@@ -1251,7 +1251,7 @@ extern "C" const char* ptm_sweep_kernel_name(ptm_engine* e) {
     snprintf(b, sizeof b, "sweep_mfma32_kernel<%d, %s, %d%s>", s.kind == KIND_DIAG ? KIND_LOWER : s.kind, (e->hist.rungs || e->map.rungs) ? "true" : "false",
              s.simple ? 0 : ((e->all_uniform && (!e->has_bounds || e->bounds_box)) ? 1 : 2),
              (!s.simple && e->all_uniform && (!e->has_bounds || e->bounds_box) && e->betaC) ? ", true" : ", false");   // as rocprofv3 prints it
-  else if (e->DP == 64 || (!s.uni && e->DP >= 16 && !getenv("PTM_FORCE_VALU") && (long long)e->Nc * e->DP <= PTM_LANES_MAX))
+  else if (e->DP == 64 || (!s.uni && !getenv("PTM_FORCE_VALU") && (long long)e->Nc * e->DP <= (e->DP >= 16 ? PTM_LANES_MAX : 4096ll * e->DP)))
     snprintf(b, sizeof b, "sweep_lanes_kernel<%d, %d, %s>", e->DP, s.kind, s.plain ? "false" : "true");
   else snprintf(b, sizeof b, "sweep_kernel<%d, %d, %s, %s>", e->DP, s.kind, s.uni ? "true" : "false", s.simple ? "true" : "false");
   e->kname = b;

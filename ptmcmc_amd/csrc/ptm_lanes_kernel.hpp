@@ -3,7 +3,7 @@
 // The general kernel (ptm_kernels.hpp) gives every chain one lane; when a wave's 64 chains do not share a rung (fewer
 // than 64 walkers per rung: the reference's own shape, one ladder of 1024 rungs) there are only a few waves in the
 // whole launch and each lane walks through a chain's ~4000 dependent f64 operations: 80 us per sweep of 1024 chains,
-// all of it latency.  Here a chain's DP dimensions sit on DP adjacent lanes (2 chains per wave at DP = 32, 4 at 16; at
+// all of it latency.  Here a chain's DP dimensions sit on DP adjacent lanes (2 chains per wave at DP = 32, 4 at 16, ...; at
 // DP = 64 -- 33..64 dimensions, which no other sweep kernel is built for -- a wave is one chain):
 // lane d draws normal d, accumulates row d of factor . z and row d of the precision matrix, and the two reductions
 // (box test, y.s) cross the chain's lanes through LDS.  The arithmetic of every number is the one of the other kernels
@@ -20,7 +20,7 @@ namespace ptm {
 
 template <int DP, int KIND, bool GEN>
 __global__ __launch_bounds__(256) void sweep_lanes_kernel(const Dev p) {
-  static_assert(DP == 16 || DP == 32 || DP == 64, "lanes kernel: DP 16, 32 or 64");
+  static_assert(DP == 4 || DP == 8 || DP == 16 || DP == 32 || DP == 64, "lanes kernel: DP 4 .. 64");
   constexpr int CPW = 64 / DP;              // chains per wave
   constexpr int NP2 = DP * (DP + 1) / 2;    // packed precision matrix
   extern __shared__ __attribute__((aligned(16))) double lds_all[];
@@ -122,16 +122,20 @@ __global__ __launch_bounds__(256) void sweep_lanes_kernel(const Dev p) {
     for (int j = 0; j < DP; ++j) tcol[j] = fac[j * DP];
     sync_wave();
     double acc = 0.0;
-    // the shared column order: halves of 16 columns, inside a half s + 4k with s outer, k inner
+    if constexpr (DP <= 8) {   // the shared column order: natural up to 8 dimensions ...
 #pragma unroll
-    for (int h = 0; h < DP / 16; ++h)
+      for (int j = 0; j < DP; ++j) acc = __builtin_fma(tcol[j], vbuf[g * DP + j], acc);
+    } else {                   // ... else halves of 16 columns, inside a half s + 4k with s outer, k inner
 #pragma unroll
-      for (int sl = 0; sl < 4; ++sl)
+      for (int h = 0; h < DP / 16; ++h)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int j = 16 * h + 4 * k + sl;
-          acc = __builtin_fma(tcol[j], vbuf[g * DP + j], acc);
-        }
+        for (int sl = 0; sl < 4; ++sl)
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int j = 16 * h + 4 * k + sl;
+            acc = __builtin_fma(tcol[j], vbuf[g * DP + j], acc);
+          }
+    }
     off = acc;
     sync_wave();   // vbuf is reused below
   }
@@ -145,7 +149,7 @@ __global__ __launch_bounds__(256) void sweep_lanes_kernel(const Dev p) {
   const double bl = beta * ll;
   const double cur_lpost = lp + bl;
   const double oldlprior = cur_lpost - bl;  // chain.cc:973
-  constexpr unsigned long long GM = DP == 64 ? ~0ull : (DP == 32 ? 0xFFFFFFFFull : 0xFFFFull);
+  constexpr unsigned long long GM = DP == 64 ? ~0ull : ((1ull << (DP & 63)) - 1ull);
   auto all_of_chain = [&](bool v) { return ((__builtin_amdgcn_ballot_w64(v) >> (g * DP)) & GM) == GM; };
   bool valid = true;
   double newlprior;
