@@ -766,6 +766,10 @@ static int launch_decide(ptm_engine* e, const double* ll_below, const double* ll
   HIPCHK(hipGetLastError());
   if (e->evolve_rate > 0) { int rc = launch_beta_transpose(e); if (rc) return rc; }
   if (wide) return PTM_OK;   // the 256-thread decide kernel has applied the moves itself
+  // a pick lists at most four row moves (two rungs, each a local move and / or a departure) and one in-between row each for
+  // the history and the MAP: short ladders
+  // can never overflow the 64-thread block's own moves
+  if (6 * e->ms <= 64) return PTM_OK;
   Move m;
   m.DP = e->DP; m.W = e->W; m.row_cap = e->row_cap; m.x = e->x; m.ll = e->ll; m.lp = e->lp; m.send_up = send_up; m.send_down = send_down;
   m.mv_src = e->mv_src; m.mv_dst = e->mv_dst; m.mv_n = e->mv_n; m.err = e->err;
