@@ -753,7 +753,9 @@ static int launch_decide(ptm_engine* e, const double* ll_below, const double* ll
   if (lds > 160 * 1024) return fail(PTM_ERR_UNSUPPORTED, "ladder too long for the LDS-resident exchange kernel (%zu B)", lds);
   // expected candidates inside the window; evolving ladders with history / MAP tracking: the wide form alone carries the
   // saved rows' temperatures through its own row moves
-  const bool wide = (double)e->ms * WN / e->Nt > 96.0 || evb;
+  // ... and a few ladders only (latency regime) whose moves may overflow the 64-thread block: one launch instead of two
+  const int per_pick = (e->nloc == e->Nt ? 2 : 4) + (e->hist.rungs ? 1 : 0) + (e->map.rungs ? 1 : 0);
+  const bool wide = (double)e->ms * WN / e->Nt > 96.0 || evb || (e->W <= 256 && per_pick * e->ms > 64);
   if (lds > 64 * 1024) {
     HIPCHK(hipFuncSetAttribute((const void*)decide_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     HIPCHK(hipFuncSetAttribute((const void*)decide_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -769,7 +771,7 @@ static int launch_decide(ptm_engine* e, const double* ll_below, const double* ll
   // a pick lists at most four row moves (two rungs, each a local move and / or a departure) and one in-between row each for
   // the history and the MAP: short ladders
   // can never overflow the 64-thread block's own moves
-  if (6 * e->ms <= 64) return PTM_OK;
+  if (per_pick * e->ms <= 64) return PTM_OK;
   Move m;
   m.DP = e->DP; m.W = e->W; m.row_cap = e->row_cap; m.x = e->x; m.ll = e->ll; m.lp = e->lp; m.send_up = send_up; m.send_down = send_down;
   m.mv_src = e->mv_src; m.mv_dst = e->mv_dst; m.mv_n = e->mv_n; m.err = e->err;
