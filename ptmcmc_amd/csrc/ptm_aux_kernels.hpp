@@ -54,6 +54,7 @@ struct Decide {
   // apart (pry_temps, chain.cc:1501-1518,1809-1846), so each ladder owns its temperatures.  Whole-ladder shards only.
   double evolve_rate;   // 0: fixed ladder (beta[] rules)
   double* beta_w;       // [W][Nt] the ladders' inverse temperatures, rewritten after a step that pried
+  double* betaC_direct; // [Nc] few ladders: the chain-indexed image is written here as well (no transposition launch); else null
   double* beta_add;     // [Nc] with history / MAP tracking: the temperature each touched rung had at its last add_state of
                         // the phase (the sweep kernel saves that row); null otherwise
 };
@@ -381,7 +382,11 @@ __global__ __launch_bounds__(DECIDE_THREADS) void decide_kernel(const Decide p) 
       }
       __syncthreads();
       const double nn = ev[0];
-      for (int k = 1 + lane; k < Nt - 1; k += DECIDE_THREADS) p.beta_w[(size_t)w * Nt + k] = 1 - (ct[nch + (k >> 5)] + gap[k]) / nn;
+      for (int k = 1 + lane; k < Nt - 1; k += DECIDE_THREADS) {
+        const double bk = 1 - (ct[nch + (k >> 5)] + gap[k]) / nn;
+        p.beta_w[(size_t)w * Nt + k] = bk;
+        if (p.betaC_direct) p.betaC_direct[(size_t)k * p.W + w] = bk;
+      }
     }
   }
   // -- the step's log

@@ -747,6 +747,8 @@ static int launch_decide(ptm_engine* e, const double* ll_below, const double* ll
   p.naccept = e->naccept; p.ntries = e->ntries; p.last_type = e->last_type;
   p.map = e->map;
   p.evolve_rate = e->evolve_rate; p.beta_w = e->beta_w; p.beta_add = e->beta_add;
+  const bool beta_direct = e->evolve_rate > 0 && e->W <= 64;   // few ladders: the exchange kernel scatters the new temperatures itself
+  p.betaC_direct = beta_direct ? e->betaC : nullptr;
   const int WN = e->nloc + (ll_below ? 1 : 0) + p.H;
   const bool evb = e->evolve_rate > 0 && e->beta_add;
   const size_t lds = decide_lds_bytes(e->Nt, e->ms, WN, e->evolve_rate > 0, evb);
@@ -766,7 +768,7 @@ static int launch_decide(ptm_engine* e, const double* ll_below, const double* ll
   if (wide) hipLaunchKernelGGL(decide_kernel<256>, dim3(e->W), dim3(256), lds, e->stream, p);
   else hipLaunchKernelGGL(decide_kernel<64>, dim3(e->W), dim3(64), lds, e->stream, p);
   HIPCHK(hipGetLastError());
-  if (e->evolve_rate > 0) { int rc = launch_beta_transpose(e); if (rc) return rc; }
+  if (e->evolve_rate > 0 && !beta_direct) { int rc = launch_beta_transpose(e); if (rc) return rc; }
   if (wide) return PTM_OK;   // the 256-thread decide kernel has applied the moves itself
   // a pick lists at most four row moves (two rungs, each a local move and / or a departure) and one in-between row each for
   // the history and the MAP: short ladders
