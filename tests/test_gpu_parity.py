@@ -179,6 +179,8 @@ SWEEP_CASES = [
     (32, 5, 2, 1e2, E.PROP_DIAG, 0.5),
     (5, 7, 3, 1e2, E.PROP_DENSE, 0.3),       # padded dimension (5 -> 8), ragged sizes
     (3, 5, 70, 1e2, E.PROP_DIAG, None),      # W not a multiple of 64
+    (3, 70, 70, 1e2, E.PROP_DENSE, 0.2),     # ... and past the lanes kernel's population limit: the general kernel, a rung per lane
+    (12, 260, 260, 1e3, E.PROP_LOWER, None), # (67600 chains x 16 lanes > 2^20)
     (1, 4, 2, 1e1, E.PROP_DIAG, 1.0),
     (9, 3, 64, 1e2, E.PROP_LOWER, 0.25),
     (3, 1, 64, 1.0, E.PROP_DENSE, None),     # a single rung: no exchange phase at all
