@@ -191,6 +191,12 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="take the torch.distributed path even with one rank (smoke test)")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started by hand without the launcher: run the ranks as child processes (nothing has touched the GPU yet)
+        import subprocess
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", os.environ.get("MASTER_PORT", "29533"), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
     if args.gpus > 1 or world > 1 or args.force_dist:
         from ptmcmc_amd import parallel
         return parallel.bench_main(args)
