@@ -13,7 +13,8 @@ import parity_util as PU
 from ptmcmc_amd import engine as E
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 4000
-cases = [(6, 12, 5, E.PROP_DENSE, 0.3, 0.02, "general kernel"), (14, 24, 3, E.PROP_LOWER, 0.2, 0.01, "lanes kernel"),
+cases = [(6, 12, 64, E.PROP_DENSE, 0.3, 0.02, "general kernel"), (5, 9, 5, E.PROP_DENSE, 0.3, 0.02, "lanes kernel (8)"),
+         (14, 24, 3, E.PROP_LOWER, 0.2, 0.01, "lanes kernel"),
          (32, 10, 64, E.PROP_LOWER, 0.3, 0.01, "MFMA kernel"), (40, 8, 2, E.PROP_DIAG, 0.4, 0.0, "lanes kernel, 64-dim rows")]
 for D, Nt, W, kind, sr, ev, what in cases:
     pr, eng, lad = PU.make_pair(D, Nt, W, 1e4, kind=kind, swap_rate=sr, one_d_frac=0.2)
