@@ -54,6 +54,8 @@ struct Decide {
   // apart (pry_temps, chain.cc:1501-1518,1809-1846), so each ladder owns its temperatures.  Whole-ladder shards only.
   double evolve_rate;   // 0: fixed ladder (beta[] rules)
   double* beta_w;       // [W][Nt] the ladders' inverse temperatures, rewritten after a step that pried
+  int lp_is_const;      // every chain's lprior is lp_const (all-uniform prior, every state inside the box): the exchange moves no lprior
+  double lp_const;
   double* betaC_direct; // [Nc] few ladders: the chain-indexed image is written here as well (no transposition launch); else null
   double* beta_add;     // [Nc] with history / MAP tracking: the temperature each touched rung had at its last add_state of
                         // the phase (the sweep kernel saves that row); null otherwise
@@ -523,7 +525,11 @@ __global__ __launch_bounds__(DECIDE_THREADS) void decide_kernel(const Decide p) 
     constexpr int GR = DECIDE_THREADS / 16;   // rows per round
     d2_t v[16];
     const int msrc = lane < nmv ? gs[lane] : 0;
-    const double sl = p.ll[msrc], sp = p.lp[msrc];
+    const int dme = lane < nmv ? gd[lane] : -3;
+    // the row's scalars: a local destination's llike is already in LDS (the exchanged view of its rung), an all-uniform
+    // prior's lprior is one constant -- most moves then touch no scalar line at all on the reading side
+    const double sl = dme >= 0 ? llc[p.r0 + dme / p.W] : p.ll[msrc];
+    const double sp = p.lp_is_const ? p.lp_const : p.lp[msrc];
     for (int hc = 0; hc < DPm; hc += 32) {   // (rows of 64 dimensions: their second 256 bytes the same way)
       const int colh = col + hc;
 #pragma unroll
@@ -552,7 +558,7 @@ __global__ __launch_bounds__(DECIDE_THREADS) void decide_kernel(const Decide p) 
     }
     if (lane < nmv) {
       const int d = gd[lane];
-      if (d >= 0) { p.ll[d] = sl; p.lp[d] = sp; }
+      if (d >= 0) { p.ll[d] = sl; if (!p.lp_is_const) p.lp[d] = sp; }
       else if (d <= HIST_DST) {
         const int c = HIST_DST - d;
         const long long hrow = 1 + (long long)(p.nhist[c] / (unsigned int)p.add_every_n);

@@ -83,6 +83,7 @@ struct ptm_engine {
   int has_bounds = 0, origin_valid = 1, all_uniform = 1, has_mean = 0, have_target = 0, have_ladder = 0,
       have_prop = 0, have_state = 0, prop_kind = KIND_DIAG, prop_stride = 0, any_oned = 0, bounds_box = 1;
   double lprior_const = 0, like0 = 0, thresh = 0;
+  bool lp_is_const = false;   // every chain's lprior equals lprior_const (checked when states are set; sweeps keep it so)
   std::vector<double> h_beta;
   std::vector<int> h_ptype;
   std::vector<double> h_plo, h_phi;
@@ -345,6 +346,7 @@ extern "C" int ptm_set_prior(ptm_engine* e, const int32_t* types, const double* 
     }
   }
   e->lprior_const = std::log(prod);  // the reference takes libm log of the product of these constants on every call
+  e->lp_is_const = false;            // (re-established when states are set)
   for (int d = 0; d < D; ++d) { e->h_ptype[d] = ty[d]; e->h_plo[d] = lo[d]; e->h_phi[d] = hi[d]; }
   int rc;
   if ((rc = upload(e->ptype, ty.data(), D, e->stream)) || (rc = upload(e->plo, lo.data(), D, e->stream)) ||
@@ -747,6 +749,7 @@ static int launch_decide(ptm_engine* e, const double* ll_below, const double* ll
   p.naccept = e->naccept; p.ntries = e->ntries; p.last_type = e->last_type;
   p.map = e->map;
   p.evolve_rate = e->evolve_rate; p.beta_w = e->beta_w; p.beta_add = e->beta_add;
+  p.lp_is_const = e->lp_is_const ? 1 : 0; p.lp_const = e->lprior_const;
   const bool beta_direct = e->evolve_rate > 0 && e->W <= 64;   // few ladders: the exchange kernel scatters the new temperatures itself
   p.betaC_direct = beta_direct ? e->betaC : nullptr;
   const int WN = e->nloc + (ll_below ? 1 : 0) + p.H;
@@ -808,6 +811,19 @@ static int ready(ptm_engine* e) {
 }
 
 // ---- state ------------------------------------------------------------------------------------------------------
+// all-uniform prior with every state inside the box: one lprior for all chains, and the sweeps keep it so (a move out of
+// the box is never accepted) -- the exchange kernel then moves no lprior
+static int check_lp_const(ptm_engine* e) {
+  e->lp_is_const = false;
+  if (!e->all_uniform) return PTM_OK;
+  std::vector<double> lp((size_t)e->Nc);
+  HIPCHK(hipStreamSynchronize(e->stream));
+  HIPCHK(hipMemcpy(lp.data(), e->lp, lp.size() * 8, hipMemcpyDeviceToHost));
+  for (double v : lp)
+    if (!(v == e->lprior_const)) return PTM_OK;
+  e->lp_is_const = true;
+  return PTM_OK;
+}
 static int reset_counters(ptm_engine* e) {
   const size_t Nc = e->Nc;
   std::vector<int> one(Nc, 1), m1(Nc, -1);
@@ -884,6 +900,7 @@ extern "C" int ptm_set_states(ptm_engine* e, const double* X, const double* llik
   }
   if ((rc = reset_counters(e))) return rc;
   HIPCHK(hipStreamSynchronize(e->stream));
+  if ((rc = check_lp_const(e))) return rc;
   e->have_state = 1;
   return PTM_OK;
 }
@@ -944,6 +961,7 @@ extern "C" int ptm_init_from_prior(ptm_engine* e) {
   int flag = 0;
   HIPCHK(hipMemcpy(&flag, e->err + 1, 4, hipMemcpyDeviceToHost));
   if (flag) return fail(PTM_ERR_INVALID, "could not draw a valid start state from the prior for some chain");
+  if ((rc = check_lp_const(e))) return rc;
   e->have_state = 1;
   return PTM_OK;
 }
