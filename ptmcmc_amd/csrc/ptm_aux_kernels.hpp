@@ -37,8 +37,8 @@ struct Decide {
   double* lp;
   unsigned char* touch;
   int *arr_below, *arr_above;      // [W]  landing slot of the row arriving across the lower / upper boundary, or -1
-  long long* swap_cnt;             // [W][Nt-1][2]  {tries, accepts} of every pair, side by side
-  int* swap_log;                   // [W][ms]  per candidate: -2 none/dropped, -3 not this shard's, else rung | accepted<<30
+  int* swap_log;                   // [W][ms]  this step's slot of the log ring; per candidate: -2 none/dropped, -3 not this
+                                   //          shard's, else rung | accepted<<30
   double *send_up, *send_down;     // boundary messages or null
   int row_cap;
   int *mv_src, *mv_dst, *mv_n;     // [W][MVCAP], [W][MVCAP], [W]: the ladder's row moves for move_kernel
@@ -401,17 +401,8 @@ __global__ __launch_bounds__(DECIDE_THREADS) void decide_kernel(const Decide p) 
     const int k = list[j];
     if (alive[k] != 1) continue;
     const int i = cand[k];
-    // swap_count / swap_accept_count (chain.cc:1498,1536); a pair is counted by the shard that owns its lower rung, so
-    // per-shard counters add up to the ladder's
-#if defined(PTM_DECIDE_ABLATE) && (PTM_DECIDE_ABLATE & 1)
-    if (false) {
-#else
-    if (i >= p.r0 && i < r1) {
-#endif
-      unsigned long long* cn = reinterpret_cast<unsigned long long*>(p.swap_cnt) + 2 * ((size_t)w * (Nt - 1) + i);   // {tries, accepts}: one line
-      atomicAdd(cn, 1ull);
-      if (accf[k]) atomicAdd(cn + 1, 1ull);
-    }
+    // (swap_count / swap_accept_count, chain.cc:1498,1536, are not touched here: 185 scattered read-modify-writes per
+    //  ladder and step.  fold_swap_log_kernel adds the logged steps to them every PTM_LOG_RING steps and on demand.)
     const int rtop = (PTM_ALIVE_RUNG(i + 1) && alive[first[i + 1]] == 1) ? i : i + 1;  // rung i+1 belongs to the pick above, if ours
     for (int r = i; r <= rtop; ++r) {
       if (r >= p.r0 && r < r1) {
@@ -666,6 +657,38 @@ __global__ __launch_bounds__(DECIDE_THREADS) void decide_kernel(const Decide p) 
   }
   if (lane == 0) p.mv_n[w] = 0;
 #undef PTM_ALIVE_RUNG
+}
+
+// swap_count / swap_accept_count (chain.cc:1498,1536; chain.hh:244-245) from the candidate logs of the last `nslots`
+// steps (a ring of PTM_LOG_RING slots): one block per ladder counts in LDS and adds to the ladder's counters, {tries,
+// accepts} side by side, with coalesced read-modify-writes.  A pair is counted by the shard that owns its lower rung, so
+// per-shard counters add up to the ladder's.
+constexpr int PTM_LOG_RING = 16;
+__global__ __launch_bounds__(256) void fold_swap_log_kernel(const int* __restrict__ ring, long long* __restrict__ cnt, int W, int ms, int Nt,
+                                                           int r0, int r1, int first_slot, int nslots) {
+  extern __shared__ int fold_sc[];   // [2][Nt - 1]
+  const int w = blockIdx.x, np = Nt - 1;
+  for (int i = threadIdx.x; i < 2 * np; i += 256) fold_sc[i] = 0;
+  __syncthreads();
+  for (int sidx = 0; sidx < nslots; ++sidx) {
+    const int slot = (first_slot + sidx) % PTM_LOG_RING;
+    const int* L = ring + ((size_t)slot * W + w) * ms;
+    for (int k = threadIdx.x; k < ms; k += 256) {
+      const int v = L[k];
+      if (v < 0) continue;
+      const int i = v & 0x3fffffff;
+      if (i < r0 || i >= r1) continue;
+      atomicAdd(&fold_sc[i], 1);
+      if (v & 0x40000000) atomicAdd(&fold_sc[np + i], 1);
+    }
+  }
+  __syncthreads();
+  long long* c = cnt + 2 * (size_t)w * np;
+  for (int i = threadIdx.x; i < np; i += 256) {
+    const int t = fold_sc[i], a = fold_sc[np + i];
+    if (t) c[2 * i] += t;
+    if (a) c[2 * i + 1] += a;
+  }
 }
 
 // [W][Nt] -> [Nt][W]: the exchange kernel keeps each evolving ladder's temperatures together, the sweep kernels read a

@@ -69,7 +69,8 @@ struct ptm_engine {
   unsigned char* touch = nullptr;
   Hist hist = {0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr};   // optional history ring (ptm_config.history_rungs)
   MapT map = {0, 0, nullptr, nullptr, nullptr, nullptr};       // optional MAP tracking (ptm_config.map_rungs)
-  int* swap_log = nullptr;   // [W][ms] candidate log of the last step
+  int* swap_log = nullptr;   // [PTM_LOG_RING][W][ms] candidate logs of the last steps; the swap counters lag behind by
+  int log_head = 0, log_pending = 0;   //  the `log_pending` newest of them (fold_swap_log)
   int row_cap = 0;           // row slots per boundary message
   // device problem description
   int *blo = nullptr, *bhi = nullptr, *ptype = nullptr;
@@ -223,10 +224,10 @@ static int build_engine(ptm_engine* e, const ptm_config* cfg) {
     HIPCHK(hipMemsetAsync(e->hist.meta, 0xFF, n * sizeof(int4), e->stream));   // saved row number -1: empty slot
   }
   const size_t np = (size_t)e->W * (e->Nt > 1 ? e->Nt - 1 : 1);
-  if ((rc = dalloc(&e->swap_cnt, 2 * np)) || (rc = dalloc(&e->swap_log, (size_t)e->W * e->ms)))
+  if ((rc = dalloc(&e->swap_cnt, 2 * np)) || (rc = dalloc(&e->swap_log, (size_t)PTM_LOG_RING * e->W * e->ms)))
     return rc;
   HIPCHK(hipMemsetAsync(e->swap_cnt, 0, 2 * np * 8, e->stream));
-  HIPCHK(hipMemsetAsync(e->swap_log, 0xFE, (size_t)e->W * e->ms * 4, e->stream));  // 0xFEFEFEFE < 0: "none"
+  HIPCHK(hipMemsetAsync(e->swap_log, 0xFE, (size_t)PTM_LOG_RING * e->W * e->ms * 4, e->stream));  // 0xFEFEFEFE < 0: "none"
   HIPCHK(hipMemsetAsync(e->err, 0, 16, e->stream));
   HIPCHK(hipMemsetAsync(e->mv_n, 0, (size_t)e->W * 4, e->stream));
   if ((rc = dalloc(&e->blo, D)) || (rc = dalloc(&e->bhi, D)) || (rc = dalloc(&e->ptype, D)) || (rc = dalloc(&e->bmin, D)) ||
@@ -721,6 +722,19 @@ static int launch_sweep(ptm_engine* e, int rung0 = 0, int nr = -1, bool last = t
   return PTM_OK;
 }
 
+// adds the logged, not yet counted steps to the swap counters
+static int fold_swap_log(ptm_engine* e) {
+  if (!e->log_pending) return PTM_OK;
+  const int first = ((e->log_head - e->log_pending) % PTM_LOG_RING + PTM_LOG_RING) % PTM_LOG_RING;
+  if (e->Nt > 1) {
+    hipLaunchKernelGGL(fold_swap_log_kernel, dim3(e->W), dim3(256), (size_t)2 * (e->Nt - 1) * sizeof(int), e->stream, e->swap_log, e->swap_cnt,
+                       e->W, e->ms, e->Nt, e->r0, e->r0 + e->nloc, first, e->log_pending);
+    HIPCHK(hipGetLastError());
+  }
+  e->log_pending = 0;
+  return PTM_OK;
+}
+
 static size_t decide_lds_bytes(int Nt, int ms, int WN, bool evolve, bool evb) {
   // mirrors the carve at the top of decide_kernel
   return (size_t)WN * 8 + (size_t)((Nt + 1) & ~1) * 4 + (size_t)((ms + 1) & ~1) * 4 * 2 + 8 + (size_t)((WN + 3) & ~3) * 2 * 3 +
@@ -742,8 +756,8 @@ static int launch_decide(ptm_engine* e, const double* ll_below, const double* ll
   p.DP = e->DP; p.Nt = e->Nt; p.r0 = e->r0; p.nloc = e->nloc; p.W = e->W; p.Nc = e->Nc; p.ms = e->ms;
   p.seed = e->cfg.seed; p.step = e->step; p.thresh = e->thresh;
   p.beta = e->beta; p.ll_below = ll_below; p.ll_above = ll_above; p.H = ll_above ? H : 0; p.x = e->x; p.ll = e->ll; p.lp = e->lp;
-  p.touch = e->touch; p.arr_below = e->arr_below; p.arr_above = e->arr_above; p.swap_cnt = e->swap_cnt;
-  p.swap_log = e->swap_log; p.send_up = send_up; p.send_down = send_down; p.row_cap = e->row_cap; p.err = e->err;
+  p.touch = e->touch; p.arr_below = e->arr_below; p.arr_above = e->arr_above;
+  p.swap_log = e->swap_log + (size_t)e->log_head * e->W * e->ms; p.send_up = send_up; p.send_down = send_down; p.row_cap = e->row_cap; p.err = e->err;
   p.mv_src = e->mv_src; p.mv_dst = e->mv_dst; p.mv_n = e->mv_n;
   p.hist = e->hist; p.add_every_n = e->cfg.add_every_n; p.nhist = e->nhist;
   p.naccept = e->naccept; p.ntries = e->ntries; p.last_type = e->last_type;
@@ -771,6 +785,8 @@ static int launch_decide(ptm_engine* e, const double* ll_below, const double* ll
   if (wide) hipLaunchKernelGGL(decide_kernel<256>, dim3(e->W), dim3(256), lds, e->stream, p);
   else hipLaunchKernelGGL(decide_kernel<64>, dim3(e->W), dim3(64), lds, e->stream, p);
   HIPCHK(hipGetLastError());
+  e->log_head = (e->log_head + 1) % PTM_LOG_RING;
+  if (++e->log_pending == PTM_LOG_RING) { int rc = fold_swap_log(e); if (rc) return rc; }
   if (e->evolve_rate > 0 && !beta_direct) { int rc = launch_beta_transpose(e); if (rc) return rc; }
   if (wide) return PTM_OK;   // the 256-thread decide kernel has applied the moves itself
   // a pick lists at most four row moves (two rungs, each a local move and / or a departure) and one in-between row each for
@@ -1123,6 +1139,8 @@ extern "C" int ptm_get_swap_counts(ptm_engine* e, int64_t* tries, int64_t* accep
   if (!e) return fail(PTM_ERR_INVALID, "null engine");
   const size_t np = (size_t)e->W * (e->Nt > 1 ? e->Nt - 1 : 1);
   HIPCHK(hipStreamSynchronize(e->stream));
+  { int rc = fold_swap_log(e); if (rc) return rc; }
+  HIPCHK(hipStreamSynchronize(e->stream));
   std::vector<long long> both(2 * np);
   HIPCHK(hipMemcpy(both.data(), e->swap_cnt, 2 * np * 8, hipMemcpyDeviceToHost));
   for (size_t i = 0; i < np; ++i) {
@@ -1137,7 +1155,8 @@ extern "C" int ptm_get_last_swaps(ptm_engine* e, int32_t* pairs, int32_t* accept
   const size_t n = (size_t)e->W * e->ms;
   HIPCHK(hipStreamSynchronize(e->stream));
   std::vector<int32_t> log(n);
-  HIPCHK(hipMemcpy(log.data(), e->swap_log, n * 4, hipMemcpyDeviceToHost));
+  const int newest = (e->log_head + PTM_LOG_RING - 1) % PTM_LOG_RING;
+  HIPCHK(hipMemcpy(log.data(), e->swap_log + (size_t)newest * n, n * 4, hipMemcpyDeviceToHost));
   for (size_t i = 0; i < n; ++i) {
     const int32_t v = log[i];
     if (pairs) pairs[i] = v < 0 ? (v == -3 ? -3 : -2) : (v & 0x3fffffff);
@@ -1185,6 +1204,7 @@ extern "C" int ptm_restore(ptm_engine* e, const double* X, const double* llike, 
       if (swap_tries) both[2 * i] = swap_tries[i];
       if (swap_accepts) both[2 * i + 1] = swap_accepts[i];
     }
+    e->log_pending = 0;   // (the counters are replaced: steps logged before belong to the run that is left)
     if ((rc = upload(e->swap_cnt, both.data(), 2 * np, e->stream))) return rc;
     HIPCHK(hipStreamSynchronize(e->stream));   // `both` leaves scope
   }
