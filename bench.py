@@ -185,7 +185,7 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--walkers", type=int, default=DEFAULT_WALKERS, help="independent ladders batched per GPU")
-    ap.add_argument("--halo", type=int, default=4, help="llike halo depth (rungs) between shards")
+    ap.add_argument("--halo", type=int, default=None, help="llike halo depth (rungs) between shards (default: ptmcmc_amd.parallel.DEFAULT_HALO)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-w1", action="store_true", help="skip the 1024-chain latency companion")
     ap.add_argument("--force-dist", action="store_true", help="take the torch.distributed path even with one rank (smoke test)")
@@ -199,6 +199,8 @@ def main():
         sys.exit(subprocess.call(cmd))
     if args.gpus > 1 or world > 1 or args.force_dist:
         from ptmcmc_amd import parallel
+        if args.halo is None:
+            args.halo = parallel.DEFAULT_HALO
         return parallel.bench_main(args)
     run_single(args)
 

@@ -726,6 +726,53 @@ void ptmo_pt_step(ptmo_pt* s, const ptmo_problem* pb, const ptmo_proposal* props
 }
 
 /* ============================================================================================
+ * Census of the candidate selection of parallel_tempering_chains::step (chain.cc:1410-1420), for the multi-GPU halo.
+ *
+ * A shard that holds rungs [.., b) replays the exchanges that reach it from above out of the llikes of the `H` rungs
+ * above b (ptm_exchange_decide).  That fails -- loudly -- exactly when the SURVIVING picks of a step cover every pair
+ * (b-1, b), (b, b+1), ..., (b-1+H, b+H): a run of H+1 consecutive surviving picks starting at rung b-1, accepted or not.
+ * This function replays the step's candidate draws of `W` ladders over `nsteps` steps with the engine's own ladder
+ * streams and counts, for every boundary b in bounds[nb], how often the run of consecutive surviving picks that starts at
+ * rung b-1 has length L: hist[i*(Lmax+1) + min(L, Lmax)].  (A pick n is dropped iff an earlier surviving pick is n or n-1,
+ * chain.cc:1417-1418: kept here as a per-rung flag instead of the reference's loop over the earlier picks.)
+ * ============================================================================================ */
+void ptmo_selection_run_census(uint64_t seed, int Nt, double swap_rate, int W, uint64_t step0, int nsteps, const int* bounds,
+                               int nb, int Lmax, int64_t* hist, int nthreads) {
+  const int ms = (int)(1 + 2 * swap_rate * Nt);                                      /* chain.cc:1192 */
+  const double thresh = (Nt - 1) * swap_rate / ms;                                   /* chain.cc:1413 */
+  (void)nthreads;
+#pragma omp parallel num_threads(nthreads) if (nthreads > 1)
+  {
+    unsigned char* alive = (unsigned char*)calloc((size_t)Nt + 1, 1);
+    int* picked = (int*)malloc((size_t)ms * sizeof(int));
+    int64_t* h = (int64_t*)calloc((size_t)nb * (Lmax + 1), sizeof(int64_t));
+#pragma omp for schedule(static)
+    for (int w = 0; w < W; w++)
+      for (int t = 0; t < nsteps; t++) {
+        int np = 0;
+        for (int k = 0; k < ms; k++) {
+          uint32_t o[4];
+          ptmo_draw_block(seed, PTMO_TAG_PT, (uint32_t)w, step0 + (uint64_t)t, (uint32_t)k, o);
+          if (!(Nt > 1 && ptmo_u01(o[0]) < thresh)) continue;                         /* :1413 */
+          int n = (int)(ptmo_u01(o[1]) * (Nt - 1));                                   /* :1415 */
+          if (alive[n] || (n > 0 && alive[n - 1])) continue;                          /* :1417-1418 */
+          alive[n] = 1;
+          picked[np++] = n;
+        }
+        for (int i = 0; i < nb; i++) {
+          int L = 0;
+          for (int r = bounds[i] - 1; r >= 0 && r < Nt - 1 && alive[r]; r++) L++;
+          h[(size_t)i * (Lmax + 1) + (L < Lmax ? L : Lmax)]++;
+        }
+        for (int k = 0; k < np; k++) alive[picked[k]] = 0;
+      }
+#pragma omp critical
+    for (int i = 0; i < nb * (Lmax + 1); i++) hist[i] += h[i];
+    free(alive); free(picked); free(h);
+  }
+}
+
+/* ============================================================================================
  * RNG providers
  * ============================================================================================ */
 typedef struct { uint64_t seed; int Nt; } philox_ctx;

@@ -170,6 +170,10 @@ void ptmo_pt_step(ptmo_pt*, const ptmo_problem*, const ptmo_proposal* props, con
 /* MH sweep only (no swap phase) */
 void ptmo_sweep(ptmo_pt*, const ptmo_problem*, const ptmo_proposal* props, const ptmo_rng*, int nthreads);
 
+/* run-length census of the surviving exchange picks above shard boundaries (sizes the multi-GPU llike halo; see the .c) */
+void ptmo_selection_run_census(uint64_t seed, int Nt, double swap_rate, int W, uint64_t step0, int nsteps, const int* bounds,
+                               int nb, int Lmax, int64_t* hist, int nthreads);
+
 /* Philox provider */
 ptmo_rng* ptmo_rng_philox(uint64_t seed, int Nt);
 /* tape provider: chain tapes [W*Nt][len_c], pt tapes [W][len_p], deltas [W*Nt][nsteps][D] */

@@ -23,10 +23,23 @@ There is no collective on the data path; swap bookkeeping stays where the refere
 per-pair counters each shard owns).  Chains are bit-identical for any number of shards: all random streams are keyed by
 global (seed, walker, rung, step).
 """
+import contextlib
 import os
+import sys
 import time
 
 import numpy as np
+
+# Depth of the llike halo a shard receives from the shard above it.  The exchange kernel cannot decide a shard's top
+# pairs when the step's SURVIVING picks (chain.cc:1417-1418; accepted or not) cover H+1 consecutive pairs starting at the
+# shard's top rung: it then raises PTM_ERR_FAR_MOVE (loud, never silently wrong).  A run of k consecutive surviving picks
+# needs k picked rungs whose first picks come in descending rung order: probability <= swap_rate^k / k! per boundary,
+# ladder and step (measured on the ladder streams themselves by tests/test_halo_depth.py: 9.1e-2, 4.2e-3, 1.3e-4, 3.1e-6,
+# 2e-8 for k = 1..5 at swap_rate 0.1).  H = 4 -- the first round's default -- fails every ~2e7 boundary-ladder-steps, i.e.
+# several times in ONE 8-GPU bench run (131072 ladders x 7 boundaries x 400 steps = 3.7e8); H = 8 makes it 0.1^9 / 9! =
+# 2.8e-15, < 1e-6 per bench run and ~1e-3 per 10^6-step production run of that size.  Cost: H x W doubles per boundary and
+# step (8.4 MB at W = 131072), sent while the interior rungs are swept.
+DEFAULT_HALO = 8
 
 
 def shard_bounds(n_rungs, world, rank):
@@ -39,13 +52,21 @@ def shard_bounds(n_rungs, world, rank):
 class EngineShard:
     """Backend of ShardedLadder on a GPU: a ptmcmc_amd Engine + torch tensors for the message buffers."""
 
-    def __init__(self, engine, torch, device):
-        self.e, self.torch, self.device = engine, torch, device
+    def __init__(self, engine, torch, device, stream=None):
+        """`stream`: the torch.cuda.Stream the engine was created on (Engine(stream=s.cuda_stream)).  Every message of the
+        sharded step is issued with that stream current, so the order engine kernel -> RCCL send / RCCL receive -> engine
+        kernel is the order of ONE stream (c10d's NCCL operations wait for the current stream when they are issued and
+        req.wait() makes the current stream wait for them) -- not a side effect of the legacy NULL stream."""
+        self.e, self.torch, self.device, self.stream = engine, torch, device, stream
         self.W, self.nloc, self.r0, self.Nt = engine.W, engine.nloc, engine.r0, engine.Nt
         self.row_doubles = engine.exchange_buffer_doubles
 
+    def stream_context(self):
+        return self.torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()
+
     def alloc(self, n):
-        return self.torch.empty(n, dtype=self.torch.float64, device=self.device)
+        with self.stream_context():     # (the caching allocator ties a block to the stream it was allocated on)
+            return self.torch.zeros(n, dtype=self.torch.float64, device=self.device)
 
     def copy_llike(self, first_rung, n_rungs, dst):
         self.e.copy_llike(first_rung, n_rungs, dst.data_ptr())
@@ -77,7 +98,7 @@ class ShardedLadder:
     """Drives one shard of a ladder that is spread over `world` ranks.  `backend` supplies the local compute
     (EngineShard on a GPU; the tests plug a CPU stand-in with the same five methods)."""
 
-    def __init__(self, backend, dist, rank, world, halo=4, sizes=None):
+    def __init__(self, backend, dist, rank, world, halo=DEFAULT_HALO, sizes=None):
         self.b, self.dist, self.rank, self.world = backend, dist, rank, world
         W = backend.W
         sizes = sizes or [shard_bounds(backend.Nt, world, r)[1] for r in range(world)]
@@ -154,19 +175,28 @@ class ShardedLadder:
         mid = lo + (hi - lo) // 2
         return (0, nb), (lo, mid - lo), (mid, hi - mid), (n - nt, nt)
 
+    def _ctx(self):
+        f = getattr(self.b, "stream_context", None)
+        return f() if f else contextlib.nullcontext()
+
     def step_simple(self, n=1):
         """the four phases one after the other (what the in-process simulator of the tests drives in lockstep)"""
-        for _ in range(n):
-            self.stage_halos()
-            self._exchange(self.halo_messages())
-            self.decide()
-            self._exchange(self.row_messages())
-            self.finish()
+        with self._ctx():
+            for _ in range(n):
+                self.stage_halos()
+                self._exchange(self.halo_messages())
+                self.decide()
+                self._exchange(self.row_messages())
+                self.finish()
 
     def step(self, n=1):
         """both message rounds behind arithmetic; the next step's halos are left in flight between calls"""
         if self.world == 1 or not getattr(self.b, "can_overlap", False):
             return self.step_simple(n)
+        with self._ctx():
+            self._step_overlapped(n)
+
+    def _step_overlapped(self, n):
         bottom, int_a, int_b, top = self.sweep_plan()
         for _ in range(n):
             if self._halo_reqs is None:                       # first step: nothing in flight yet
@@ -187,7 +217,8 @@ class ShardedLadder:
     def drain(self):
         """wait for the halos left in flight by step() (call before reading results or tearing down)"""
         if self._halo_reqs is not None:
-            self._wait(self._halo_reqs)
+            with self._ctx():
+                self._wait(self._halo_reqs)
             self._halo_reqs = []      # delivered and still valid for the next step
 
 
@@ -212,27 +243,36 @@ def bench_main(args):
     W = args.walkers * world            # weak scaling: chains per GPU stay 1024 * walkers
     r0, nloc = shard_bounds(NT, world, rank)
     pr = GaussianProblem(D, NT, B.TMAX)
-    stream = torch.cuda.current_stream().cuda_stream
-    eng = E.Engine(D, NT, W, seed=B.SEED, swap_rate=B.SWAP_RATE, add_every_n=100, rung_begin=r0, rung_count=nloc,
-                   device=local, stream=stream, time_kernels=True)
-    pr.configure(eng, E.PROP_LOWER)
-    eng.init_from_prior()
-    lad = ShardedLadder(EngineShard(eng, torch, dev), dist, rank, world, halo=args.halo)
-    lad.step(300)             # set-up (untimed, uncounted): clocks ramped, chains off their prior draws, RCCL channels open
-    lad.step(args.warmup)
-    lad.drain()
-    eng.sync()
-    eng.kernel_times()
-    dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    lad.step(args.steps)
-    lad.drain()
-    eng.sync()
-    torch.cuda.synchronize()
-    dist.barrier()
-    torch.cuda.synchronize()
-    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    # the engine works on an explicit torch stream, and every RCCL message of the step is issued with that stream current
+    # (EngineShard.stream_context): kernel -> send / receive -> kernel is then the order of one stream by construction
+    stream = torch.cuda.Stream(device=dev)
+    try:
+        eng = E.Engine(D, NT, W, seed=B.SEED, swap_rate=B.SWAP_RATE, add_every_n=100, rung_begin=r0, rung_count=nloc,
+                       device=local, stream=stream.cuda_stream, time_kernels=True)
+        pr.configure(eng, E.PROP_LOWER)
+        eng.init_from_prior()
+        lad = ShardedLadder(EngineShard(eng, torch, dev, stream), dist, rank, world, halo=args.halo)
+        lad.step(300)             # set-up (untimed, uncounted): clocks ramped, chains off their prior draws, RCCL channels open
+        lad.step(args.warmup)
+        lad.drain()
+        eng.sync()
+        eng.kernel_times()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        lad.step(args.steps)
+        lad.drain()
+        eng.sync()
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    except Exception as ex:
+        # a rank that fails (e.g. PTM_ERR_FAR_MOVE out of eng.sync()) must not leave its peers waiting in a receive or a
+        # barrier: leave at once with a non-zero code, the launcher then ends the other ranks
+        sys.stderr.write("[bench rank %d] %s: %s\n" % (rank, type(ex).__name__, ex))
+        sys.stderr.flush()
+        os._exit(17)
     dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     wall = float(dt.item())
     kt = eng.kernel_times()              # one entry per sweep launch; a step's sweep is up to four launches

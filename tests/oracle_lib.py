@@ -109,6 +109,8 @@ def lib():
     L.ptmo_rng_tape.argtypes = [C.c_int, C.c_int, C.c_int, _dp, C.c_int, _dp, C.c_int, _dp, C.c_int]
     L.ptmo_rng_free.argtypes = [C.c_void_p]
     L.ptmo_init_from_prior.argtypes = [C.POINTER(_PT), C.POINTER(_Problem), C.c_uint64]
+    L.ptmo_selection_run_census.argtypes = [C.c_uint64, C.c_int, C.c_double, C.c_int, C.c_uint64, C.c_int, _ip, C.c_int, C.c_int,
+                                            C.POINTER(C.c_int64), C.c_int]
     _lib = L
     return L
 
@@ -158,6 +160,15 @@ def ladder(nt, tmax):
     b = np.zeros(nt)
     lib().ptmo_ladder(nt, tmax, _d(b))
     return b
+
+
+def selection_run_census(seed, Nt, swap_rate, W, nsteps, bounds, Lmax=12, step0=0, nthreads=8):
+    """hist[boundary][L] of the runs of consecutive surviving exchange picks that start at rung b-1 (see ptm_oracle.c)"""
+    b = np.ascontiguousarray(bounds, dtype=np.int32)
+    h = np.zeros((len(b), Lmax + 1), dtype=np.int64)
+    lib().ptmo_selection_run_census(seed, Nt, swap_rate, W, step0, nsteps, _i(b), len(b), Lmax,
+                                    h.ctypes.data_as(C.POINTER(C.c_int64)), nthreads)
+    return h
 
 
 class Problem:

@@ -840,13 +840,15 @@ def test_default_row_capacity_tracks_swap_rate():
     e.close()
 
 
+@pytest.mark.parametrize("Nt,W", [(16, 4), (128, 1)])
 @pytest.mark.parametrize("ev", [0.0, 0.02])
-def test_host_callback_likelihood_C5_exampleLISA(ev):
-    """BASELINE configs[4] (ev > 0: with the ladder evolving, the sampler's default): a user plug-in likelihood (the reference's toy LISA likelihood, exampleLISA.cc:59-72,130-142)
+def test_host_callback_likelihood_C5_exampleLISA(ev, Nt, W):
+    """BASELINE configs[4] (ev > 0: with the ladder evolving, the sampler's default; Nt = 128, W = 1: the configuration's own
+    shape, 128 temperatures): a user plug-in likelihood (the reference's toy LISA likelihood, exampleLISA.cc:59-72,130-142)
     through the C-ABI callback, mixed uniform/polar/copolar prior with wrap + limit boundaries (exampleLISA.cc:528-593).
     The propose kernel, the host call and the accept kernel must reproduce the oracle's chain bit for bit."""
     import lisa_toy
-    D, Nt, W = 6, 16, 4
+    D = 6
     beta = E.geometric_ladder(Nt, 1e9)
     rng = np.random.default_rng(4)
     lo = np.array(lisa_toy.CENTERS) - np.array(lisa_toy.SCALES)

@@ -1,0 +1,118 @@
+"""Ladder sharding at the benchmark's shape, on the ONE GPU a test box has (-m gpu):
+  - the exchange kernel alone on a middle 128-rung shard of the 1024-rung ladder at the 8-GPU bench's 131072 ladders, with
+    the default halo (the first round's halo of 4 trips PTM_ERR_FAR_MOVE at this scale, tests/test_halo_depth.py);
+  - BASELINE configs[3] in process: 1024 rungs in 8 shards of 128, every shard an EngineShard on its own torch stream with
+    torch tensors as message buffers (the objects bench.py --gpus 8 uses), plain and overlapped order, against one engine;
+  - bench.py's torch.distributed / RCCL path with one rank."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from ptmcmc_amd import engine as E
+from ptmcmc_amd.parallel import DEFAULT_HALO, EngineShard, shard_bounds
+from ptmcmc_amd.problems import GaussianProblem
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _decide_only(H, W, nsteps):
+    """ptm_exchange_decide alone, `nsteps` steps, on the shard [512, 640) of the 1024-rung ladder; returns None or the error"""
+    D, Nt, G = 32, 1024, 8
+    nloc = Nt // G
+    r0 = nloc * (G // 2)
+    pr = GaussianProblem(D, Nt, 1e9)
+    eng = E.Engine(D, Nt, W, rung_begin=r0, rung_count=nloc, swap_rate=0.1)
+    pr.configure(eng, E.PROP_LOWER)
+    eng.init_from_prior()
+    n = eng.exchange_buffer_doubles
+    ll = eng.llike
+    lb, la = E.DeviceBuffer(8 * W), E.DeviceBuffer(8 * H * W)
+    su, sd = E.DeviceBuffer(8 * n), E.DeviceBuffer(8 * n)
+    fill = np.ascontiguousarray(np.resize(ll, H * W))        # plausible neighbour llikes
+    lb.copy_from(fill.ctypes.data, lb.nbytes)
+    la.copy_from(fill.ctypes.data, la.nbytes)
+    err = None
+    try:
+        for k in range(nsteps):
+            eng.exchange_decide(lb.ptr, la.ptr, H, su.ptr, sd.ptr)
+            eng.sweep_rungs(0, 0, True)                       # closes the step: the next one draws new candidates
+            if k % 50 == 49:
+                eng.sync()
+        eng.sync()
+    except E.PtmError as ex:
+        err = str(ex)
+    assert eng.step_count == nsteps or err
+    eng.close()
+    return err
+
+
+def test_exchange_decide_at_bench_scale_is_clean_with_the_default_halo():
+    W, nsteps = 131072, 400          # bench.py --gpus 8: 16384 x 8 ladders, 300 set-up + warm-up + timed steps
+    assert _decide_only(DEFAULT_HALO, W, nsteps) is None
+    err = _decide_only(4, W, nsteps)  # ~2-6e-8 per ladder-step => a few events expected in 5.2e7; not required to fire
+    if err is not None:
+        assert "halo" in err
+
+
+@pytest.mark.parametrize("overlap", [False, True])
+def test_1024_rungs_in_8_engine_shards_on_torch_streams(overlap):
+    """BASELINE configs[3] in process (D=32, 1024 rungs, 8 shards of 128, 64 ladders), through ptmcmc_amd.parallel.EngineShard
+    with torch tensors and one explicit torch stream per shard -- what bench.py --gpus 8 runs, minus the wire."""
+    import torch
+    import shard_sim
+    D, Nt, W, G, sr = 32, 1024, 64, 8, 0.1
+    dev = torch.device("cuda", 0)
+    pr = GaussianProblem(D, Nt, 1e9)
+    ref = E.Engine(D, Nt, W, swap_rate=sr)
+    pr.configure(ref, E.PROP_LOWER)
+    ref.init_from_prior()
+    x0 = ref.states()
+    shards, backs = [], []
+    for g in range(G):
+        r0, n = shard_bounds(Nt, G, g)
+        s = torch.cuda.Stream(device=dev)
+        e = E.Engine(D, Nt, W, swap_rate=sr, rung_begin=r0, rung_count=n, stream=s.cuda_stream)
+        pr.configure(e, E.PROP_LOWER)
+        e.set_states(x0[r0 * W:(r0 + n) * W])
+        shards.append(e)
+        backs.append(EngineShard(e, torch, dev, s))
+    lads = shard_sim.build(backs, halo=DEFAULT_HALO)
+
+    def copy(dst, src):                 # the wire: every shard was synchronised before, and is again before it reads
+        dst.copy_(src)
+        torch.cuda.synchronize()
+    nsteps = 30
+    for k in range(0, nsteps, 5):
+        ref.step(5)
+        (shard_sim.step_overlapped if overlap else shard_sim.step)(lads, copy, 5)
+        xs = np.concatenate([e.states() for e in shards])
+        assert np.array_equal(xs, ref.states()), "states differ after step %d" % (k + 5)
+    for name in ("llike", "lprior", "ntries", "naccept", "nhist", "last_type"):
+        assert np.array_equal(np.concatenate([getattr(e, name) for e in shards]), getattr(ref, name)), name
+    t = sum(e.swap_counts()[0] for e in shards)
+    a = sum(e.swap_counts()[1] for e in shards)
+    rt, ra = ref.swap_counts()
+    assert np.array_equal(t, rt) and np.array_equal(a, ra) and a.sum() > 0
+    # rows did cross every boundary
+    for g in range(G - 1):
+        b = shard_bounds(Nt, G, g + 1)[0]
+        assert ra[:, b - 1].sum() > 0
+    for e in shards + [ref]:
+        e.close()
+
+
+def test_bench_distributed_path_with_one_rank():
+    """bench.py --force-dist: init_process_group("nccl"), the engine on an explicit torch stream, EngineShard on torch
+    tensors, the all_reduces of the record -- the N > 1 code path with world size 1"""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--steps", "3", "--warmup", "1",
+                          "--walkers", "1024"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = json.loads(out.stdout.strip().splitlines()[-1])
+    assert rec["n_gpus"] == 1 and rec["steps"] == 3 and rec["value"] > 1e8
+    assert rec["config"]["chains"] == 1024 * 1024 and rec["roofline"]["kernel"].startswith("sweep_mfma32_kernel")

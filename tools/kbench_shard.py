@@ -20,7 +20,8 @@ pr = GaussianProblem(D, Nt, 1e9)
 eng = E.Engine(D, Nt, W, rung_begin=r0, rung_count=nloc, add_every_n=100, time_kernels=True)
 pr.configure(eng, E.PROP_LOWER)
 eng.init_from_prior()
-H = 4
+from ptmcmc_amd.parallel import DEFAULT_HALO
+H = DEFAULT_HALO
 first, last = r0 == 0, r0 + nloc == Nt
 bufs = {k: E.DeviceBuffer(8 * n) for k, n in dict(lb=W, la=H * W, su=eng.exchange_buffer_doubles, sd=eng.exchange_buffer_doubles,
                                                    rb=eng.exchange_buffer_doubles, ra=eng.exchange_buffer_doubles).items()}
@@ -50,10 +51,7 @@ def step():
     eng.sweep_rungs(mid, hi - mid, True)
 for _ in range(3):
     step()
-try:
-    eng.sync()
-except E.PtmError as ex:
-    print("note:", ex)
+eng.sync()
 eng.kernel_times()
 eng.timer_start()
 for _ in range(a.reps):
