@@ -6,6 +6,7 @@ MI355X the constructor raises.
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -53,6 +54,9 @@ _u32p = C.POINTER(C.c_uint32)
 LOGLIKE_BATCH_FN = C.CFUNCTYPE(None, C.c_void_p, _dp, C.c_int, C.c_int, _dp)
 
 
+TORCH_LOADED_FIRST = None
+
+
 def load():
     """dlopen the engine; raises if it has not been built (python __graft_entry__.py build)."""
     global _lib
@@ -60,6 +64,8 @@ def load():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise PtmError("HIP engine not built: %s is missing (run `python -c 'import __graft_entry__ as g; g.build()'`)" % LIB_PATH)
+    global TORCH_LOADED_FIRST
+    TORCH_LOADED_FIRST = "torch" in sys.modules      # (see ptmcmc_amd.parallel.EngineShard: one HIP runtime per process)
     L = C.CDLL(LIB_PATH)
     L.ptm_last_error.restype = C.c_char_p
     L.ptm_sweep_kernel_name.restype = C.c_char_p

@@ -57,6 +57,12 @@ class EngineShard:
         sharded step is issued with that stream current, so the order engine kernel -> RCCL send / RCCL receive -> engine
         kernel is the order of ONE stream (c10d's NCCL operations wait for the current stream when they are issued and
         req.wait() makes the current stream wait for them) -- not a side effect of the legacy NULL stream."""
+        from . import engine as _E
+        if _E.TORCH_LOADED_FIRST is False:
+            # the torch wheel carries its own HIP runtime and loads it by a name the dynamic loader does not match with the
+            # /opt/rocm one libptm_engine.so already brought in: the process would hold two runtimes, the second without a GPU
+            raise RuntimeError("import torch before the first ptmcmc_amd engine call in a process that uses both "
+                               "(libptm_engine.so then binds to the HIP runtime torch loaded)")
         self.e, self.torch, self.device, self.stream = engine, torch, device, stream
         self.W, self.nloc, self.r0, self.Nt = engine.W, engine.nloc, engine.r0, engine.Nt
         self.row_doubles = engine.exchange_buffer_doubles
