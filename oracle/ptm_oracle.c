@@ -454,6 +454,7 @@ ptmo_pt* ptmo_pt_create(int D, int Nt, int W, const double* beta, double swap_ra
   s->last_pairs = (int*)calloc((size_t)W * s->maxswaps, sizeof(int));
   s->last_accept = (int*)calloc((size_t)W * s->maxswaps, sizeof(int));
   s->touched = (uint8_t*)calloc(N, 1);
+  s->last_accept_mh = (uint8_t*)calloc(N, 1);
   s->map_lpost = (double*)malloc(N * sizeof(double));
   s->map_x = (double*)calloc(N * D, sizeof(double));
   for (size_t c = 0; c < N; c++) s->map_lpost[c] = -1e200;        /* chain.hh:69 */
@@ -463,7 +464,7 @@ void ptmo_pt_free(ptmo_pt* s) {
   if (!s) return;
   free(s->beta); free(s->x); free(s->llike); free(s->lprior); free(s->ntries); free(s->naccept); free(s->last_type);
   free(s->nhist); free(s->nsize); free(s->swap_count); free(s->swap_accept_count); free(s->last_pairs); free(s->last_accept);
-  free(s->touched); free(s->map_lpost); free(s->map_x); free(s->betaw);
+  free(s->touched); free(s->last_accept_mh); free(s->map_lpost); free(s->map_x); free(s->betaw);
   free(s->hist_x); free(s->hist_ll); free(s->hist_lp); free(s->hist_beta); free(s->hist_nacc); free(s->hist_ntry); free(s->hist_type);
   free(s);
 }
@@ -553,9 +554,19 @@ int ptmo_mh_step(ptmo_pt* s, const ptmo_problem* pb, const ptmo_proposal* prop, 
   double cur_lpost = ptmo_lpost(cur_lprior, beta, cur_llike);
   double oldlprior = cur_lpost - beta * cur_llike;                       /* :973 */
   double xn[64], off[64];
-  int type = rng->draw_offset(rng->ctx, w, r, s->step, prop, D, off);   /* :975 prop.draw */
-  for (int i = 0; i < D; i++) xn[i] = x[i] + off[i];                     /* state::add, states.cc:205-214 */
-  int valid = pb->origin_valid;                                          /* Q9 */
+  double hast = 0.0;
+  int type, valid;
+  if (s->host_prop) {                                                    /* :975 prop.draw -- any proposal, evaluated by the caller */
+    int32_t rr = r, ww = w, ty = 0, va = 1;
+    s->host_prop(s->host_prop_user, 1, D, x, &rr, &ww, s->step, xn, &hast, &ty, &va);
+    type = ty;
+    valid = va != 0;                                                     /* the returned state's own validity (state::invalid()) */
+  } else {
+    type = rng->draw_offset(rng->ctx, w, r, s->step, prop, D, off);     /* :975 prop.draw (gaussian_prop / scripted offsets) */
+    if (rng->log_hastings) hast = rng->log_hastings(rng->ctx, w, r, s->step);
+    for (int i = 0; i < D; i++) xn[i] = x[i] + off[i];                   /* state::add, states.cc:205-214 */
+    valid = pb->origin_valid;                                            /* Q9 */
+  }
   if (valid) valid = ptmo_enforce(pb, xn);                               /* :976 newstate.enforce() */
   double newlprior = ptmo_lprior(pb, xn, valid);                         /* :977 */
   double newlike, newlpost;
@@ -566,8 +577,9 @@ int ptmo_mh_step(ptmo_pt* s, const ptmo_problem* pb, const ptmo_proposal* prop, 
   } else {
     newlike = newlpost = -INFINITY;                                      /* :986 */
   }
-  double logH = 0.0;                                                     /* gaussian_prop: log_hastings = 0 */
+  double logH = hast;                                                    /* :989 prop.log_hastings_ratio() (gaussian_prop: 0) */
   int accept = 1;
+  if (isnan(logH)) accept = 0;                                           /* :990-993 */
   logH += newlpost - cur_lpost;                                          /* :994 */
   if (!valid) accept = 0;                                                /* :996 */
   if (accept && logH < 0) {                                              /* :998 (NaN => stays accepted) */
@@ -582,8 +594,11 @@ int ptmo_mh_step(ptmo_pt* s, const ptmo_problem* pb, const ptmo_proposal* prop, 
     s->llike[c] = newlike; s->lprior[c] = newlprior;
   }
   add_state_count(s, c, beta);
+  s->last_accept_mh[c] = (uint8_t)accept;
   return accept;
 }
+
+void ptmo_pt_set_host_proposal(ptmo_pt* s, ptmo_propose_fn fn, void* user) { s->host_prop = fn; s->host_prop_user = user; }
 
 void ptmo_sweep(ptmo_pt* s, const ptmo_problem* pb, const ptmo_proposal* props, const ptmo_rng* rng, int nthreads) {
   long N = (long)s->Nt * s->W;
@@ -718,7 +733,7 @@ void ptmo_pt_step(ptmo_pt* s, const ptmo_problem* pb, const ptmo_proposal* props
   /* :1544-1559 MH move for every rung not involved in a swap attempt this step */
 #pragma omp parallel for schedule(static) num_threads(nthreads) if (nthreads > 1)
   for (long c = 0; c < N; c++) {
-    if (s->touched[c]) continue;
+    if (s->touched[c]) { s->last_accept_mh[c] = 2; continue; }
     int w = (int)(c / s->Nt), r = (int)(c % s->Nt);
     ptmo_mh_step(s, pb, &props[r], rng, w, r);
   }
@@ -853,6 +868,8 @@ typedef struct {
   int W, Nt, D, len_c, len_p, nsteps;
   const double *chain_tapes, *pt_tapes, *deltas;
   int *cpos, *ppos, *dpos;
+  const double* hastings;   /* [W*Nt][nsteps] scripted log-Hastings ratio of offset k of the chain, or NULL */
+  const int32_t* types;     /* [W*Nt][nsteps] its type code, or NULL (0) */
 } tape_ctx;
 static double tp_chain_uniform(void* v, int w, int r, uint64_t step, int slot) {
   tape_ctx* t = (tape_ctx*)v; (void)step; (void)slot;
@@ -862,9 +879,20 @@ static double tp_chain_uniform(void* v, int w, int r, uint64_t step, int slot) {
 static int tp_draw_offset(void* v, int w, int r, uint64_t step, const ptmo_proposal* p, int D, double* off) {
   tape_ctx* t = (tape_ctx*)v; (void)step; (void)p;
   size_t c = (size_t)w * t->Nt + r;
-  const double* d = t->deltas + (c * t->nsteps + t->dpos[c]++) * D;
+  const int k = t->dpos[c]++;
+  const double* d = t->deltas + (c * t->nsteps + k) * D;
   for (int i = 0; i < D; i++) off[i] = d[i];
-  return 0;
+  return t->types ? t->types[c * t->nsteps + k] : 0;
+}
+static double tp_log_hastings(void* v, int w, int r, uint64_t step) {   /* of the offset drawn last */
+  tape_ctx* t = (tape_ctx*)v; (void)step;
+  size_t c = (size_t)w * t->Nt + r;
+  return t->hastings[c * t->nsteps + t->dpos[c] - 1];
+}
+void ptmo_rng_tape_hastings(ptmo_rng* r, const double* log_hastings, const int32_t* types) {
+  tape_ctx* t = (tape_ctx*)r->ctx;
+  t->hastings = log_hastings; t->types = types;
+  r->log_hastings = log_hastings ? tp_log_hastings : NULL;
 }
 static double tp_pt_uniform(void* v, int w, uint64_t step, int k, int slot) {
   tape_ctx* t = (tape_ctx*)v; (void)step; (void)k; (void)slot;

@@ -83,7 +83,17 @@ typedef struct ptmo_rng {
   int (*draw_offset)(void* ctx, int w, int r, uint64_t step, const ptmo_proposal* p, int D, double* offset);
   /* uniform of the ladder-level generator of walker w; k = candidate slot, slot 0 try,1 pick,2 accept */
   double (*pt_uniform)(void* ctx, int w, uint64_t step, int k, int slot);
+  /* proposal_distribution::log_hastings_ratio() of the offset just drawn (proposal_distribution.hh:68; MH_chain::step,
+   * chain.cc:989-994); NULL = 0 (every gaussian_prop) */
+  double (*log_hastings)(void* ctx, int w, int r, uint64_t step);
 } ptmo_rng;
+
+/* A proposal evaluated by the CALLER (the engine's ptm_propose_batch_fn, include/ptm_engine.h): any
+ * proposal_distribution::draw(state&, chain*) (proposal_distribution.hh:65-87).  For n chains: current states X_cur[n][dim],
+ * their global rung and walker, the PT step -> proposed states X_prop[n][dim] (whole states, not offsets), the proposals'
+ * log-Hastings ratios, type codes (proposal_distribution::type()) and validity (state::invalid(); preset to 1). */
+typedef void (*ptmo_propose_fn)(void* user, int n, int dim, const double* X_cur, const int32_t* rung, const int32_t* walker, uint64_t step,
+                                double* X_prop, double* log_hastings, int32_t* type, int32_t* valid);
 
 typedef struct {
   int D, Nt, W;        /* Nt = GLOBAL number of rungs; chain (w,r) lives at index w*Nt + r */
@@ -117,6 +127,10 @@ typedef struct {
   double evolve_rate;
   double* betaw;       /* [W][Nt] */
   double* hist_beta;   /* [W*Nt][hist_cap] the chain's inverse temperature when the row was pushed (MH_chain::invtemps, chain.cc:943) */
+  /* optional caller-evaluated proposal (replaces the rng's draw_offset / props[] in ptmo_mh_step) */
+  ptmo_propose_fn host_prop;
+  void* host_prop_user;
+  uint8_t* last_accept_mh; /* [W*Nt] outcome of the last step's MH move: 1 accepted, 0 rejected, 2 no move (exchanged rung) */
 } ptmo_pt;
 
 /* ---- RNG: Philox4x32-10 (Salmon et al., SC'11; Random123) -------------------------------- */
@@ -179,6 +193,9 @@ ptmo_rng* ptmo_rng_philox(uint64_t seed, int Nt);
 /* tape provider: chain tapes [W*Nt][len_c], pt tapes [W][len_p], deltas [W*Nt][nsteps][D] */
 ptmo_rng* ptmo_rng_tape(int W, int Nt, int D, const double* chain_tapes, int len_c, const double* pt_tapes, int len_p,
                         const double* deltas, int nsteps);
+/* scripted log-Hastings ratios and type codes for the tape provider's offsets: [W*Nt][nsteps] each (types may be NULL) */
+void ptmo_rng_tape_hastings(ptmo_rng*, const double* log_hastings, const int32_t* types);
+void ptmo_pt_set_host_proposal(ptmo_pt*, ptmo_propose_fn fn, void* user);
 void ptmo_rng_free(ptmo_rng*);
 
 /* prior draw used by init (uniform / gaussian dims only; others return NaN) */

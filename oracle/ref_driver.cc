@@ -10,6 +10,8 @@
 // Sub-commands
 //   golden-basic            JSON on stdout: boundary::enforce cases, prior
 //                           evaluate_log tables, ladder values, swap log-Hastings.
+//   golden-eigen            JSON on stdout: gaussian_prop(covar)'s eigenvector transform and
+//                           sigmas for fixed covariances (as its constructor prints them).
 //   golden-trace <id>       JSON on stdout: a full parallel_tempering_chains run
 //                           with *scripted* proposals and *recorded* RNG tapes, so
 //                           that a CPU restatement fed the same tapes must land on
@@ -255,15 +257,17 @@ static double gauss_eval(void* obj, const state& s) {
 // offset (state::add of a space-less offset state, proposal_distribution.hh:217)
 struct tape_prop : public proposal_distribution {
   const std::vector<std::vector<std::vector<double>>>* deltas;  // [rung][call][D]
+  const std::vector<std::vector<double>>* hastings;             // [rung][call] scripted log-Hastings ratios, or null (0)
   int rung;
   mutable int* nextrung;
   size_t ncall;
-  tape_prop(const std::vector<std::vector<std::vector<double>>>* d, int* nextrung_)
-      : deltas(d), rung(-1), nextrung(nextrung_), ncall(0) {}
+  tape_prop(const std::vector<std::vector<std::vector<double>>>* d, int* nextrung_, const std::vector<std::vector<double>>* h = nullptr)
+      : deltas(d), hastings(h), rung(-1), nextrung(nextrung_), ncall(0) {}
   state draw(state& s, chain* caller) override {
-    const std::vector<double>& d = (*deltas)[rung][ncall++];
-    last_type = 0;
-    log_hastings = 0;
+    const std::vector<double>& d = (*deltas)[rung][ncall];
+    last_type = hastings ? (int)(ncall % 3) : 0;   // (a type code that varies, to check MH_chain's last_type bookkeeping)
+    log_hastings = hastings ? (*hastings)[rung][ncall] : 0;
+    ncall++;
     return s.add(state(nullptr, d));
   }
   tape_prop* clone() const override {
@@ -289,6 +293,11 @@ static int golden_trace(int id) {
   // --- problem definitions -------------------------------------------------------------------
   int D, Nt, nsteps, Ninit = 1;
   double Tmax, swap_rate, step_scale, minPrior = -30, evolve = 0;
+  // compact fixtures (ids 7..9): the scripted offsets are not stored -- the test regenerates them from the helper stream's
+  // state ("delta_state", splitmix64 as above) -- and the full states are stored every `xstride`-th step only (llike, lpost,
+  // history size on every step: a state that differed would show in its llike)
+  bool compact = false, with_hastings = false;
+  const int xstride = 5;
   std::vector<std::string> types;
   std::vector<double> centers, scales;
   std::vector<int> blo, bhi;
@@ -323,9 +332,25 @@ static int golden_trace(int id) {
     D = 3; Nt = 7; nsteps = 160; Tmax = 30; swap_rate = 0.45; step_scale = 2.5; evolve = 0.01;
     types = {"uni", "uni", "uni"}; centers = {0.5, 0, -0.5}; scales = {4, 3, 5};
     blo = {O, O, O}; bhi = {O, O, O}; bmin = {0, 0, 0}; bmax = {0, 0, 0};
+  } else if (id == 7) {  // BASELINE configs[1]: D=16 Gaussian, 64 temperatures (compact fixture: see below)
+    D = 16; Nt = 64; nsteps = 40; Tmax = 1e4; swap_rate = 0.1; step_scale = 0.35; compact = true;
+  } else if (id == 8) {  // D=32 (the headline dimension), 64 temperatures
+    D = 32; Nt = 64; nsteps = 30; Tmax = 1e6; swap_rate = 0.1; step_scale = 0.25; compact = true;
+  } else if (id == 9) {  // the swap phase at the headline ladder length: 1024 rungs, maxswapsperstep = 205
+    D = 2; Nt = 1024; nsteps = 8; Tmax = 1e9; swap_rate = 0.1; step_scale = 1.2; compact = true;
+  } else if (id == 10) {  // a proposal with a non-zero log-Hastings ratio (MH_chain::step, chain.cc:989-994)
+    D = 3; Nt = 6; nsteps = 160; Tmax = 50; swap_rate = 0.3; step_scale = 1.6; with_hastings = true;
+    types = {"uni", "gauss", "uni"}; centers = {0.5, 0, -0.5}; scales = {4, 1.5, 5};
+    blo = {O, O, R}; bhi = {O, O, R}; bmin = {0, 0, -5.5}; bmax = {0, 0, 4.5};
   } else {
     fprintf(stderr, "unknown trace id %d\n", id);
     return 2;
+  }
+  if (compact) {  // uniform box prior with open boundaries, as the BASELINE workloads
+    for (int i = 0; i < D; i++) {
+      types.push_back("uni"); centers.push_back(0.0); scales.push_back(20.0 + (i % 5));
+      blo.push_back(O); bhi.push_back(O); bmin.push_back(0); bmax.push_back(0);
+    }
   }
   // target: zero-mean correlated Gaussian, precision P = inv(A^T A / D + 0.1 I) built directly as
   // P = B^T B + 0.5 I with small-integer-ish B so the fixture is self-contained
@@ -364,6 +389,7 @@ static int golden_trace(int id) {
     if (evolve > 0) ptc.evolve_temps(evolve);
 
     // scripted proposal offsets
+    const unsigned long long delta_state = g.s;
     std::vector<std::vector<std::vector<double>>> deltas(Nt);
     for (int r = 0; r < Nt; r++) {
       double beta = ptc.subchain(r)->invTemp();
@@ -374,8 +400,14 @@ static int golden_trace(int id) {
         for (int d = 0; d < D; d++) deltas[r][k][d] = g.sym() * sc;
       }
     }
+    std::vector<std::vector<double>> hast(Nt);
+    if (with_hastings)
+      for (int r = 0; r < Nt; r++) {
+        hast[r].resize(nsteps);
+        for (int k = 0; k < nsteps; k++) hast[r][k] = (k % 7 == 3) ? 0.0 : 1.5 * g.sym();
+      }
     int nextrung = 0;
-    tape_prop prop(&deltas, &nextrung);
+    tape_prop prop(&deltas, &nextrung, with_hastings ? &hast : nullptr);
     ptc.set_proposal(prop);
 
     int maxswaps = 1 + 2 * swap_rate * Nt;  // chain.cc:1192
@@ -399,20 +431,32 @@ static int golden_trace(int id) {
     }
     js << "],\n\"pt_tape\":" << jarr(pt_tape) << ",\n\"chain_tapes\":[";
     for (int r = 0; r < Nt; r++) js << (r ? "," : "") << "\n " << jarr(ch_tape[r]);
-    js << "],\n\"deltas\":[";
-    for (int r = 0; r < Nt; r++) {
-      js << (r ? "," : "") << "\n [";
-      for (int k = 0; k < nsteps; k++) js << (k ? "," : "") << jarr(deltas[r][k]);
-      js << "]";
+    if (compact) {
+      js << "],\n\"delta_state\":\"" << delta_state << "\",\"step_scale\":" << jnum(step_scale) << ",\"xstride\":" << xstride
+         << ",\n\"steps\":[";
+    } else {
+      js << "],\n\"deltas\":[";
+      for (int r = 0; r < Nt; r++) {
+        js << (r ? "," : "") << "\n [";
+        for (int k = 0; k < nsteps; k++) js << (k ? "," : "") << jarr(deltas[r][k]);
+        js << "]";
+      }
+      if (with_hastings) {
+        js << "],\n\"log_hastings\":[";
+        for (int r = 0; r < Nt; r++) js << (r ? "," : "") << "\n " << jarr(hast[r]);
+      }
+      js << "],\n\"steps\":[";
     }
-    js << "],\n\"steps\":[";
     for (int k = 0; k < nsteps; k++) {
       ptc.step();
       js << (k ? "," : "") << "\n [";
       for (int r = 0; r < Nt; r++) {
         chain* c = ptc.subchain(r);
-        js << (r ? "," : "") << "{\"x\":" << jarr(c->getState().get_params_vector()) << ",\"llike\":" << jnum(c->getLogLike())
-           << ",\"lpost\":" << jnum(c->getLogPost()) << ",\"size\":" << c->size() << ",\"invtemp\":" << jnum(c->invTemp()) << "}";
+        js << (r ? "," : "") << "{";
+        if (!compact || k % xstride == xstride - 1 || k == nsteps - 1) js << "\"x\":" << jarr(c->getState().get_params_vector()) << ",";
+        js << "\"llike\":" << jnum(c->getLogLike()) << ",\"lpost\":" << jnum(c->getLogPost()) << ",\"size\":" << c->size();
+        if (!compact) js << ",\"invtemp\":" << jnum(c->invTemp());
+        js << "}";
       }
       js << "]";
     }
@@ -431,9 +475,75 @@ static int golden_trace(int id) {
       for (int e = 0; e < c->size(); e++) js << (e ? "," : "") << jnum(c->getLogLike(e, true));
       js << "]";
     }
+    if (with_hastings) {
+      // the proposal type MH_chain::add_state pushed with every row (chain.cc:943), read back from MH_chain::dumpChain's
+      // rows "i lpost llike acceptance_ratio type: ..." (chain.cc:1127); rows 1.. of the raw history (row 0 = the initial state)
+      js << "],\n\"hist_type\":[";
+      for (int r = 0; r < Nt; r++) {
+        std::ostringstream dump;
+        dynamic_cast<MH_chain*>(ptc.subchain(r))->dumpChain(dump, 0, 1);
+        std::istringstream in(dump.str());
+        std::string line;
+        js << (r ? "," : "") << "\n [";
+        bool first = true;
+        while (std::getline(in, line)) {
+          if (line.empty() || line[0] == '#') continue;
+          std::istringstream ls(line);
+          std::string a, b, c2, d2, t;
+          ls >> a >> b >> c2 >> d2 >> t;
+          if (t.empty()) continue;
+          js << (first ? "" : ",") << atoi(t.c_str());
+          first = false;
+        }
+        js << "]";
+      }
+    }
     js << "],\n\"likelihood_calls\":" << tgt.ncalls << "}\n";
     globalRNG.reset();  // do not let the shared_ptr delete the master generator twice
   }
+  std::cout << js.str();
+  return 0;
+}
+
+// ----------------------------------------------------------------------------------------------
+// golden-eigen: gaussian_prop(covar)'s transform (proposal_distribution.hh:165-187).  diagTransform and sigmas are
+// private; the constructor prints them (hh:184-186: " Eigenvalues=", " transform=") -- captured here at 17 digits.
+// ----------------------------------------------------------------------------------------------
+static int golden_eigen() {
+  std::ostringstream js;
+  js << "{\"cases\":[";
+  const int dims[] = {2, 3, 5, 16, 32};
+  for (int ic = 0; ic < 5; ic++) {
+    const int D = dims[ic];
+    splitmix g(0xE16E4 + D);
+    Eigen::MatrixXd A(D, D), cov(D, D);
+    for (int i = 0; i < D; i++) for (int j = 0; j < D; j++) A(i, j) = g.sym();
+    cov = A.transpose() * A / D + 0.1 * Eigen::MatrixXd::Identity(D, D);   // the synthetic covariance's shape
+    for (int i = 0; i < D; i++) for (int j = 0; j < i; j++) cov(i, j) = cov(j, i);
+    std::string text;
+    {
+      cout_mute m;
+      std::cout.precision(17);
+      void* mem = calloc(1, sizeof(gaussian_prop));   // (quirk Q4: the constructor copies its own uninitialised `sigmas`)
+      gaussian_prop* gp = new (mem) gaussian_prop(cov);
+      (void)gp;
+      text = m.sink.str();
+    }
+    std::cout.precision(6);
+    size_t pe = text.find(" Eigenvalues="), pt = text.find(" transform="), ps = text.find(" test=");
+    if (pe == std::string::npos || pt == std::string::npos || ps == std::string::npos) { fprintf(stderr, "golden-eigen: constructor printout not found\n"); return 2; }
+    std::vector<double> ev, tr, cv;
+    { std::istringstream in(text.substr(pe + 13, pt - pe - 13)); double v; while (in >> v) ev.push_back(v); }
+    { std::istringstream in(text.substr(pt + 11, ps - pt - 11)); double v; while (in >> v) tr.push_back(v); }
+    if ((int)ev.size() != D || (int)tr.size() != D * D) { fprintf(stderr, "golden-eigen: parsed %zu eigenvalues, %zu transform entries for D=%d\n", ev.size(), tr.size(), D); return 2; }
+    for (int i = 0; i < D; i++) for (int j = 0; j < D; j++) cv.push_back(cov(i, j));
+    // offset = diagTransform * (sigmas o z) (hh:207-213): the factor is diagTransform * diag(sqrt(eigenvalues)), row-major
+    std::vector<double> fac(D * D);
+    for (int i = 0; i < D; i++) for (int j = 0; j < D; j++) fac[i * D + j] = tr[i * D + j] * std::sqrt(ev[j]);
+    js << (ic ? "," : "") << "\n {\"D\":" << D << ",\"cov\":" << jarr(cv) << ",\"eigenvalues\":" << jarr(ev) << ",\"transform\":" << jarr(tr)
+       << ",\"factor\":" << jarr(fac) << "}";
+  }
+  js << "]}\n";
   std::cout << js.str();
   return 0;
 }
@@ -514,7 +624,8 @@ int main(int argc, char** argv) {
     return 0;
   }
   if (argc >= 3 && !strcmp(argv[1], "golden-trace")) return golden_trace(atoi(argv[2]));
+  if (argc >= 2 && !strcmp(argv[1], "golden-eigen")) return golden_eigen();
   if (argc >= 3 && !strcmp(argv[1], "bench")) return bench(argv[2]);
-  fprintf(stderr, "usage: %s golden-basic | golden-trace <1..6> | bench <specfile>\n", argv[0]);
+  fprintf(stderr, "usage: %s golden-basic | golden-trace <1..10> | golden-eigen | bench <specfile>\n", argv[0]);
   return 2;
 }

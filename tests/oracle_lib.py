@@ -55,7 +55,8 @@ class _PT(C.Structure):
                 ("last_pairs", _ip), ("last_accept", _ip), ("touched", C.POINTER(C.c_uint8)),
                 ("hist_cap", C.c_int), ("hist_x", _dp), ("hist_ll", _dp), ("hist_lp", _dp),
                 ("hist_nacc", C.POINTER(C.c_int32)), ("hist_ntry", C.POINTER(C.c_int32)), ("hist_type", C.POINTER(C.c_int32)),
-                ("map_lpost", _dp), ("map_x", _dp), ("evolve_rate", C.c_double), ("betaw", _dp), ("hist_beta", _dp)]
+                ("map_lpost", _dp), ("map_x", _dp), ("evolve_rate", C.c_double), ("betaw", _dp), ("hist_beta", _dp),
+                ("host_prop", C.c_void_p), ("host_prop_user", C.c_void_p), ("last_accept_mh", C.POINTER(C.c_uint8))]
 
 
 _lib = None
@@ -108,6 +109,8 @@ def lib():
     L.ptmo_rng_tape.restype = C.c_void_p
     L.ptmo_rng_tape.argtypes = [C.c_int, C.c_int, C.c_int, _dp, C.c_int, _dp, C.c_int, _dp, C.c_int]
     L.ptmo_rng_free.argtypes = [C.c_void_p]
+    L.ptmo_rng_tape_hastings.argtypes = [C.c_void_p, _dp, C.POINTER(C.c_int32)]
+    L.ptmo_pt_set_host_proposal.argtypes = [C.POINTER(_PT), C.c_void_p, C.c_void_p]
     L.ptmo_init_from_prior.argtypes = [C.POINTER(_PT), C.POINTER(_Problem), C.c_uint64]
     L.ptmo_selection_run_census.argtypes = [C.c_uint64, C.c_int, C.c_double, C.c_int, C.c_uint64, C.c_int, _ip, C.c_int, C.c_int,
                                             C.POINTER(C.c_int64), C.c_int]
@@ -124,6 +127,24 @@ def _i(a):
 
 
 LOGLIKE_FN = C.CFUNCTYPE(C.c_double, C.c_void_p, _dp, C.c_int)
+_i32p = C.POINTER(C.c_int32)
+# the engine's ptm_propose_batch_fn (include/ptm_engine.h) == the oracle's ptmo_propose_fn
+PROPOSE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int, _dp, _i32p, _i32p, C.c_uint64, _dp, _dp, _i32p, _i32p)
+
+
+def make_propose_fn(pyfunc):
+    """pyfunc(X_cur[n][dim], rung[n], walker[n], step) -> (X_prop[n][dim], log_hastings[n], type[n], valid[n]); returns the
+    C callback both the oracle and the engine take (keep a reference to it while it is registered)"""
+    def tramp(user, n, dim, xc, rung, walker, step, xp, lh, ty, va):
+        X = np.ctypeslib.as_array(xc, shape=(n, dim)).copy()
+        r = np.ctypeslib.as_array(rung, shape=(n,)).copy()
+        w = np.ctypeslib.as_array(walker, shape=(n,)).copy()
+        P, H, T, V = pyfunc(X, r, w, int(step))
+        np.ctypeslib.as_array(xp, shape=(n, dim))[:] = P
+        np.ctypeslib.as_array(lh, shape=(n,))[:] = H
+        np.ctypeslib.as_array(ty, shape=(n,))[:] = T
+        np.ctypeslib.as_array(va, shape=(n,))[:] = V
+    return PROPOSE_FN(tramp)
 
 
 def philox(ctr, key):
@@ -273,6 +294,22 @@ class Ladder:
         dl = np.ascontiguousarray(deltas, dtype=np.float64).reshape(self.N, -1, self.D)
         self._keep += [ct, pt, dl]
         self.rng = lib().ptmo_rng_tape(self.W, self.Nt, self.D, _d(ct), ct.shape[1], _d(pt), pt.shape[1], _d(dl), dl.shape[1])
+
+    def tape_hastings(self, log_hastings, types=None):
+        """scripted log-Hastings ratios / type codes of the tape's offsets, [N][nsteps]"""
+        h = np.ascontiguousarray(log_hastings, dtype=np.float64).reshape(self.N, -1)
+        t = None if types is None else np.ascontiguousarray(types, dtype=np.int32).reshape(self.N, -1)
+        self._keep += [h, t]
+        lib().ptmo_rng_tape_hastings(self.rng, _d(h), None if t is None else t.ctypes.data_as(_i32p))
+
+    def set_host_proposal(self, cfn):
+        """cfn: a PROPOSE_FN (make_propose_fn) -- replaces the proposals of set_proposals in every MH step"""
+        self._keep.append(cfn)
+        lib().ptmo_pt_set_host_proposal(self.s, C.cast(cfn, C.c_void_p), None)
+
+    @property
+    def last_accept_mh(self):
+        return self._arr(self.s.contents.last_accept_mh, (self.N,), np.int64)
 
     def set_states(self, x, llike=None):
         x = np.ascontiguousarray(x, dtype=np.float64).reshape(self.N, self.D)
