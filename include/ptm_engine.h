@@ -84,6 +84,20 @@ typedef struct ptm_config {
  * (bayesian.hh:536-552: double(*)(void* object, const state& s)).  X is [n][dim] row-major. */
 typedef void (*ptm_loglike_batch_fn)(void* user, const double* X, int n, int dim, double* out_llike);
 
+/* A proposal evaluated on the HOST: the C shape of proposal_distribution::draw(state&, chain*) + log_hastings_ratio() +
+ * type() (proposal_distribution.hh:65-87), batched over the chains that make a Metropolis move this step (rungs touched by
+ * an exchange attempt make none, chain.cc:1553-1557).  In: current states X_cur[n][dim] row-major, each chain's GLOBAL rung
+ * and walker, the PT step number (ptm_step_count).  Out: proposed states X_prop[n][dim] -- whole states, not offsets; the
+ * engine enforces the boundaries, prices prior and likelihood and takes the Metropolis test on the device with
+ * logH = log_hastings + newlpost - current_lpost (chain.cc:976-1002; a NaN log_hastings rejects, :990-993) --,
+ * log_hastings[n], type[n] (what MH_chain::last_type becomes on acceptance) and valid[n] (preset to 1; 0 = the proposed
+ * state is invalid as state::invalid() says, e.g. state::add on a space whose origin violates a `limit` bound). */
+typedef void (*ptm_propose_batch_fn)(void* user, int n, int dim, const double* X_cur, const int32_t* rung, const int32_t* walker,
+                                     uint64_t step, double* X_prop, double* log_hastings, int32_t* type, int32_t* valid);
+/* proposal_distribution::accept() / reject() (proposal_distribution.hh:70-71; MH_chain::step, chain.cc:1009,1015): the
+ * outcome of the moves proposed by the last ptm_propose_batch_fn call, same n / order; accepted[i] in {0, 1} */
+typedef void (*ptm_proposal_result_fn)(void* user, int n, const int32_t* rung, const int32_t* walker, const int32_t* accepted);
+
 const char* ptm_last_error(void);
 int ptm_abi_version(void);
 /* number of usable gfx950 devices (0 if none); never fails */
@@ -132,6 +146,14 @@ int ptm_set_proposal_rung(ptm_engine* e, int local_rung, const double* factor, d
  * scales, oneDfracs.  offset = scale_k * (factor z); last_type = k + 10 * (1 if the move was one-dimensional).
  * K = 0 removes the mixture. */
 int ptm_set_proposal_mixture(ptm_engine* e, int K, const double* cum_shares, const double* scales, const double* one_d_fracs);
+
+/* Host-side proposals -- the "host fallback step" for everything that is not a Gaussian the device can draw itself
+ * (differential evolution from the chain history, involutions, adaptive sets, user proposals with callbacks ...):
+ * every sweep fetches the current states, calls `propose` once for all moving chains, and runs the rest of
+ * MH_chain::step on the device.  `result` (may be NULL) is told the outcomes after the accept kernel.  Replaces the
+ * proposals of ptm_set_proposals; propose == NULL goes back to them.  Whole-shard sweeps only (ptm_sweep, ptm_step,
+ * ptm_exchange_finish_and_sweep; not ptm_sweep_rungs). */
+int ptm_set_proposal_callback(ptm_engine* e, ptm_propose_batch_fn propose, ptm_proposal_result_fn result, void* user);
 
 /* ---- state ------------------------------------------------------------------------------------------ */
 /* X[n_local_chains][D]; llike may be NULL (the device target evaluates it).  Resets counters the way

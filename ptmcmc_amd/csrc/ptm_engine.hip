@@ -90,6 +90,19 @@ struct ptm_engine {
   std::vector<double> h_plo, h_phi;
   ptm_loglike_batch_fn cb = nullptr;
   void* cb_user = nullptr;
+  // host-side proposals (ptm_set_proposal_callback)
+  ptm_propose_batch_fn pcb = nullptr;
+  ptm_proposal_result_fn pres = nullptr;
+  void* pcb_user = nullptr;
+  double* hastings = nullptr;
+  int* htype = nullptr;
+  unsigned char *hvalid = nullptr, *acc_out = nullptr;
+  pinned_vector<double> h_rows, h_hast;
+  pinned_vector<int> h_type;
+  pinned_vector<unsigned char> h_valid, h_touch, h_acc;
+  std::vector<double> p_xcur, p_xprop, p_hast;
+  std::vector<int32_t> p_rung, p_walker, p_type, p_valid, p_acc;
+  std::vector<size_t> p_pick;
   double *xprop = nullptr, *lprior_new = nullptr, *llike_new = nullptr;  // device buffers of the callback path
   unsigned char* gate = nullptr;
   pinned_vector<double> h_xprop, h_llnew;
@@ -263,7 +276,7 @@ extern "C" int ptm_engine_destroy(ptm_engine* e) {
   (void)hipStreamSynchronize(e->stream);
   void* ptrs[] = {e->x, e->ll, e->lp, e->ntries, e->naccept, e->last_type, e->arr_below, e->arr_above, e->mv_src, e->mv_dst, e->mv_n,
                   e->err, e->nhist, e->swap_cnt, e->touch, e->swap_log, e->hist.x, e->hist.ll, e->hist.lp, e->hist.meta, e->map.lpost, e->map.ll, e->map.lp, e->map.x, e->blo,
-                  e->bhi, e->ptype, e->bmin, e->bmax, e->plo, e->phi, e->pcoef, e->P2, e->mean, e->beta, e->prop, e->prop_tiles, e->P2_tiles, e->box_row, e->onedfrac, e->mix, e->beta_w, e->betaC, e->beta_add, e->hist.beta, e->xprop, e->lprior_new, e->llike_new};
+                  e->bhi, e->ptype, e->bmin, e->bmax, e->plo, e->phi, e->pcoef, e->P2, e->mean, e->beta, e->prop, e->prop_tiles, e->P2_tiles, e->box_row, e->onedfrac, e->mix, e->beta_w, e->betaC, e->beta_add, e->hist.beta, e->xprop, e->lprior_new, e->llike_new, e->hastings, e->htype, e->hvalid, e->acc_out};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (hipEvent_t ev : e->kev) (void)hipEventDestroy(ev);
@@ -396,18 +409,44 @@ extern "C" int ptm_set_target_gaussian(ptm_engine* e, const double* mean, const 
   return PTM_OK;
 }
 
-extern "C" int ptm_set_target_callback(ptm_engine* e, ptm_loglike_batch_fn fn, void* user) {
-  if (!e || !fn) return fail(PTM_ERR_INVALID, "null argument");
+// the proposal hand-over buffers both host paths use (callback likelihood: propose pass -> host; host-side proposals: host ->
+// kernel): proposed states in row layout, the gate bytes right behind them (one device-to-host copy fetches both)
+static int alloc_proposal_buffers(ptm_engine* e) {
   const size_t Nc = e->Nc, DP = e->DP;
   int rc;
-  // (the gate bytes sit right behind the proposals: one device-to-host copy fetches both)
   if (!e->xprop && ((rc = dalloc(&e->xprop, Nc * DP + (Nc + 7) / 8)) || (rc = dalloc(&e->lprior_new, Nc)) || (rc = dalloc(&e->llike_new, Nc))))
     return rc;
   e->gate = reinterpret_cast<unsigned char*>(e->xprop + Nc * DP);
   e->h_xprop.resize(Nc * DP + (Nc + 7) / 8); e->h_llnew.assign(Nc, 0.0);
   e->h_gate = reinterpret_cast<unsigned char*>(e->h_xprop.data() + Nc * DP);
+  return PTM_OK;
+}
+
+extern "C" int ptm_set_target_callback(ptm_engine* e, ptm_loglike_batch_fn fn, void* user) {
+  if (!e || !fn) return fail(PTM_ERR_INVALID, "null argument");
+  int rc = alloc_proposal_buffers(e);
+  if (rc) return rc;
   e->cb = fn; e->cb_user = user;
   e->have_target = 1;
+  return PTM_OK;
+}
+
+extern "C" int ptm_set_proposal_callback(ptm_engine* e, ptm_propose_batch_fn propose, ptm_proposal_result_fn result, void* user) {
+  if (!e) return fail(PTM_ERR_INVALID, "null engine");
+  if (!propose) {   // back to the device proposals, if any were set
+    e->pcb = nullptr; e->pres = nullptr; e->pcb_user = nullptr;
+    e->have_prop = e->prop ? 1 : 0;
+    return PTM_OK;
+  }
+  const size_t Nc = e->Nc, DP = e->DP;
+  int rc = alloc_proposal_buffers(e);
+  if (rc) return rc;
+  if (!e->hastings && ((rc = dalloc(&e->hastings, Nc)) || (rc = dalloc(&e->htype, Nc)) || (rc = dalloc(&e->hvalid, Nc)) || (rc = dalloc(&e->acc_out, Nc))))
+    return rc;
+  e->h_rows.resize(Nc * DP); e->h_hast.assign(Nc, 0.0); e->h_type.assign(Nc, 0); e->h_valid.assign(Nc, 0); e->h_touch.assign(Nc, 0); e->h_acc.assign(Nc, 0);
+  if (!e->onedfrac) return fail(PTM_ERR_INVALID, "engine not built");
+  e->pcb = propose; e->pres = result; e->pcb_user = user;
+  e->have_prop = 1;
   return PTM_OK;
 }
 
@@ -655,6 +694,7 @@ static Dev make_dev(ptm_engine* e) {
   p.hist = e->hist;
   p.map = e->map;
   p.c_begin = 0; p.c_end = e->Nc;
+  p.host_prop = e->pcb ? 1 : 0; p.hastings = e->hastings; p.htype = e->htype; p.hvalid = e->hvalid; p.acc_out = e->acc_out;
   return p;
 }
 
@@ -662,7 +702,9 @@ static SweepSel sweep_sel(const ptm_engine* e) {
   SweepSel s;
   s.kind = e->prop_kind == PTM_PROP_DIAG ? KIND_DIAG : (e->prop_kind == PTM_PROP_LOWER ? KIND_LOWER : KIND_DENSE);
   s.uni = (e->W % 64) == 0;
-  s.plain = !e->has_bounds && e->all_uniform && !e->has_mean && !e->any_oned && !e->cb && e->mix_K == 0 && !e->betaC;
+  s.host_prop = e->pcb != nullptr;
+  if (s.host_prop) s.kind = KIND_DIAG;   // (no factor is read: any instantiation serves)
+  s.plain = !e->has_bounds && e->all_uniform && !e->has_mean && !e->any_oned && !e->cb && e->mix_K == 0 && !e->betaC && !s.host_prop;
   s.simple = s.uni && s.plain;
   s.callback = e->cb != nullptr;
   return s;
@@ -674,7 +716,7 @@ static int launch_sweep(ptm_engine* e, int rung0 = 0, int nr = -1, bool last = t
   if (nr < 0) nr = e->nloc - rung0;
   if (rung0 < 0 || nr < 0 || rung0 + nr > e->nloc) return fail(PTM_ERR_INVALID, "rung range out of the shard");
   p.c_begin = rung0 * e->W; p.c_end = (rung0 + nr) * e->W;
-  if (e->cb && (rung0 != 0 || nr != e->nloc)) return fail(PTM_ERR_UNSUPPORTED, "partial sweeps with a host-callback likelihood are not built");
+  if ((e->cb || e->pcb) && (rung0 != 0 || nr != e->nloc)) return fail(PTM_ERR_UNSUPPORTED, "partial sweeps with a host-callback likelihood or host-side proposals are not built");
   if (nr == 0) { if (last) e->step += 1; return PTM_OK; }
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   if (e->cfg.time_kernels) {
@@ -697,6 +739,41 @@ static int launch_sweep(ptm_engine* e, int rung0 = 0, int nr = -1, bool last = t
     return hipErrorInvalidValue;
   };
 
+  size_t npick = 0;
+  if (e->pcb) {
+    // host-side proposals: fetch the rows and the exchange phase's touch flags, let the host propose for every chain that
+    // moves this step, hand the proposals (whole states), their log-Hastings ratios, types and validity to the kernel
+    const size_t Nc = e->Nc, D = e->D, DP = e->DP;
+    HIPCHK(hipMemcpyAsync(e->h_rows.data(), e->x, Nc * DP * 8, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(e->h_touch.data(), e->touch, Nc, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    e->p_pick.clear();
+    for (size_t c = 0; c < Nc; ++c)
+      if (!e->h_touch[c]) e->p_pick.push_back(c);
+    npick = e->p_pick.size();
+    e->p_xcur.resize(npick * D); e->p_xprop.assign(npick * D, 0.0); e->p_hast.assign(npick, 0.0);
+    e->p_rung.resize(npick); e->p_walker.resize(npick); e->p_type.assign(npick, 0); e->p_valid.assign(npick, 1);
+    for (size_t k = 0; k < npick; ++k) {
+      const size_t c = e->p_pick[k];
+      for (size_t d = 0; d < D; ++d) e->p_xcur[k * D + d] = e->h_rows[c * DP + host_row_pos(DP, d)];
+      e->p_rung[k] = e->r0 + (int)(c / e->W); e->p_walker[k] = (int)(c % e->W);
+    }
+    if (npick)
+      e->pcb(e->pcb_user, (int)npick, (int)D, e->p_xcur.data(), e->p_rung.data(), e->p_walker.data(), e->step, e->p_xprop.data(),
+             e->p_hast.data(), e->p_type.data(), e->p_valid.data());
+    // (rows of chains that make no move keep whatever the buffer held: the kernel never uses them)
+    for (size_t k = 0; k < npick; ++k) {
+      const size_t c = e->p_pick[k];
+      for (size_t d = 0; d < DP; ++d) e->h_xprop[c * DP + d] = 0.0;
+      for (size_t d = 0; d < D; ++d) e->h_xprop[c * DP + host_row_pos(DP, d)] = e->p_xprop[k * D + d];
+      e->h_hast[c] = e->p_hast[k]; e->h_type[c] = e->p_type[k]; e->h_valid[c] = e->p_valid[k] ? 1 : 0;
+    }
+    HIPCHK(hipMemcpyAsync(e->xprop, e->h_xprop.data(), Nc * DP * 8, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->hastings, e->h_hast.data(), Nc * 8, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->htype, e->h_type.data(), Nc * 4, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->hvalid, e->h_valid.data(), Nc, hipMemcpyHostToDevice, e->stream));
+    p.xprop = e->xprop; p.lprior_new = e->lprior_new; p.gate = e->gate; p.llike_new = e->llike_new;
+  }
   if (!e->cb) {
     HIPCHK(launch(p));
   } else {
@@ -716,6 +793,13 @@ static int launch_sweep(ptm_engine* e, int rung0 = 0, int nr = -1, bool last = t
     HIPCHK(hipMemcpyAsync(e->llike_new, e->h_llnew.data(), Nc * 8, hipMemcpyHostToDevice, e->stream));
     p.mode = 2;
     HIPCHK(launch(p));
+  }
+  if (e->pcb && e->pres && npick) {   // proposal_distribution::accept() / reject() (chain.cc:1009,1015)
+    HIPCHK(hipMemcpyAsync(e->h_acc.data(), e->acc_out, (size_t)e->Nc, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    e->p_acc.resize(npick);
+    for (size_t k = 0; k < npick; ++k) e->p_acc[k] = e->h_acc[e->p_pick[k]] == 1 ? 1 : 0;
+    e->pres(e->pcb_user, (int)npick, e->p_rung.data(), e->p_walker.data(), e->p_acc.data());
   }
   if (ev1) HIPCHK(hipEventRecord(ev1, e->stream));
   if (last) e->step += 1;
@@ -1293,11 +1377,11 @@ extern "C" const char* ptm_sweep_kernel_name(ptm_engine* e) {
   if (!e) return "";
   char b[96];
   const SweepSel s = sweep_sel(e);
-  if (e->DP == 32 && s.uni && !s.callback)
+  if (e->DP == 32 && s.uni && !s.callback && !s.host_prop)
     snprintf(b, sizeof b, "sweep_mfma32_kernel<%d, %s, %d%s>", s.kind == KIND_DIAG ? KIND_LOWER : s.kind, (e->hist.rungs || e->map.rungs) ? "true" : "false",
              s.simple ? 0 : ((e->all_uniform && (!e->has_bounds || e->bounds_box)) ? 1 : 2),
              (!s.simple && e->all_uniform && (!e->has_bounds || e->bounds_box) && e->betaC) ? ", true" : ", false");   // as rocprofv3 prints it
-  else if (e->DP == 64 || (!s.uni && !getenv("PTM_FORCE_VALU") && (long long)e->Nc * e->DP <= (e->DP >= 16 ? PTM_LANES_MAX : 4096ll * e->DP)))
+  else if (e->DP == 64 || s.host_prop || (!s.uni && !getenv("PTM_FORCE_VALU") && (long long)e->Nc * e->DP <= (e->DP >= 16 ? PTM_LANES_MAX : 4096ll * e->DP)))
     snprintf(b, sizeof b, "sweep_lanes_kernel<%d, %d, %s>", e->DP, s.kind, s.plain ? "false" : "true");
   else snprintf(b, sizeof b, "sweep_kernel<%d, %d, %s, %s>", e->DP, s.kind, s.uni ? "true" : "false", s.simple ? "true" : "false");
   e->kname = b;

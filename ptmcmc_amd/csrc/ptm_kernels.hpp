@@ -132,6 +132,13 @@ struct Dev {
   double* lprior_new;       // [Nc]
   unsigned char* gate;      // [Nc] bit0: state valid, bit1: likelihood wanted (chain.cc:980)
   const double* llike_new;  // [Nc] filled by the host for gated chains
+  // host-side proposals (ptm_set_proposal_callback; lanes kernel, general build): the proposed states arrive in xprop
+  // (whole states, row layout) with their log-Hastings ratio, type code and validity; acc_out gets the outcome
+  int host_prop;
+  const double* hastings;        // [Nc]
+  const int* htype;              // [Nc]
+  const unsigned char* hvalid;   // [Nc]
+  unsigned char* acc_out;        // [Nc] 1 accepted, 0 rejected, 2 no move (exchanged rung)
 };
 
 // ------------------------------------------------------------------------------------------------

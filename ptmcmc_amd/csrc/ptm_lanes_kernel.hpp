@@ -55,6 +55,8 @@ __global__ __launch_bounds__(256) void sweep_lanes_kernel(const Dev p) {
   // host-callback likelihood (GEN build): mode 1 = propose pass (proposal, validity, prior -> xprop / lprior_new / gate, nothing
   // else changes), mode 2 = accept pass with the host's llike_new; 0 = fused
   const int mode = GEN ? p.mode : 0;
+  // host-side proposal (GEN build): the proposed state is in xprop already, with its log-Hastings ratio, type and validity
+  const bool hp = GEN && p.host_prop != 0;
   const int tc = p.touch[c];  // > 0: the rung took part in that many exchange attempts => no MH move this step
   if (tc && mode != 1) {
     // one add_state per attempt (chain.cc:1487-1490,1531-1534,1554-1557); the LAST of them saw the row as it is now
@@ -85,7 +87,7 @@ __global__ __launch_bounds__(256) void sweep_lanes_kernel(const Dev p) {
   const u32x4 o0 = draw_block(p.seed, TAG_MH, stream, p.step, 0);
   int type = 0, axis = -1, kmix = 0;
   double mix_scale = 1.0;
-  if (GEN) {
+  if (GEN && !hp) {
     double f = p.onedfrac[rl];
     if (p.mix_K > 0) {   // proposal_distribution_set::draw: one uniform picks the member (a set of one draws nothing)
       const double* mx = p.mix + (size_t)rl * p.mix_K * 3;
@@ -99,8 +101,8 @@ __global__ __launch_bounds__(256) void sweep_lanes_kernel(const Dev p) {
     if (p.any_oned && !tc && f > 0 && u01(o0.v1) < f) { axis = (int)(p.D * u01(o0.v2)); type = 1; }
   }
   // normal d: slot d & 3 of Philox block 1 + d / 4 (two Box-Muller pairs per block)
-  double zd;
-  {
+  double zd = 0.0;
+  if (!hp) {
     const u32x4 o = draw_block(p.seed, TAG_MH, stream, p.step, (uint32_t)((d >> 2) + 1));
     const bool hi = (d & 2) != 0;
     double z0, z1;
@@ -110,8 +112,8 @@ __global__ __launch_bounds__(256) void sweep_lanes_kernel(const Dev p) {
   }
   // -- gaussian_prop::draw (proposal_distribution.hh:194-218): offset = factor * z, row d on lane d
   double off = 0.0;
-  if (mode == 2) {
-    // accept pass: the proposal was drawn and stored by the propose pass
+  if (mode == 2 || hp) {
+    // accept pass: the proposal was drawn and stored by the propose pass; host-side proposal: it was drawn by the host
   } else if (KIND == KIND_DIAG) {
     off = p.prop[(size_t)rl * p.prop_stride + d] * zd;
   } else {
@@ -140,11 +142,15 @@ __global__ __launch_bounds__(256) void sweep_lanes_kernel(const Dev p) {
     sync_wave();   // vbuf is reused below
   }
   const double ll = p.ll[c], lp = p.lp[c];
-  if (GEN && p.mix_K > 0) {
+  if (GEN && p.mix_K > 0 && !hp) {
     type = kmix + 10 * type;   // proposal_distribution.cc:117
     off = mix_scale * off;     // the member is scale_k times the rung's factor
   }
-  double xn = mode == 2 ? p.xprop[(size_t)c * DP + pos] : row[pos] + off;   // state::add (states.cc:205-214)
+  if (hp) type = p.htype[c];   // proposal_distribution::type()
+  double xn = (mode == 2 || hp) ? p.xprop[(size_t)c * DP + pos] : row[pos] + off;   // state::add (states.cc:205-214)
+  // what the state is worth before enforcing: Q9 for a sum built by state::add (on an enforced zero state); a host-side
+  // proposal brings its own validity (state::invalid())
+  const bool valid0 = hp ? p.hvalid[c] != 0 : p.origin_valid != 0;
   const double beta = (GEN && p.betaC) ? p.betaC[c] : p.beta[rg];
   const double bl = beta * ll;
   const double cur_lpost = lp + bl;
@@ -161,7 +167,7 @@ __global__ __launch_bounds__(256) void sweep_lanes_kernel(const Dev p) {
       // stateSpace::enforce (states.cc:86-102), each dimension on its lane; Q9: the sum is built on an enforced zero state
       bool vd = true;
       if (p.has_bounds && d < p.D) vd = boundary_enforce(p.blo[d], p.bhi[d], p.bmin[d], p.bmax[d], xn);
-      valid = p.origin_valid != 0 && all_of_chain(vd);
+      valid = valid0 && all_of_chain(vd);
     }
     // the box of the all-uniform prior: every dimension of the chain inside
     const bool in = all_of_chain(!(xn < p.plo[d]) && !(xn > p.phi[d]));
@@ -169,7 +175,7 @@ __global__ __launch_bounds__(256) void sweep_lanes_kernel(const Dev p) {
   } else {
     bool vd = true;
     if (p.has_bounds && d < p.D) vd = boundary_enforce(p.blo[d], p.bhi[d], p.bmin[d], p.bmax[d], xn);
-    valid = p.origin_valid != 0 && all_of_chain(vd);
+    valid = valid0 && all_of_chain(vd);
     // mixed_dist_product::evaluate: the factors in four interleaved partial products, combined ((p0 p1) p2) p3
     sbuf[g * DP + d] = d < p.D ? prior_pdf(p.ptype[d], p.plo[d], p.phi[d], p.pcoef[d], xn) : 1.0;
     sync_wave();
@@ -221,10 +227,16 @@ __global__ __launch_bounds__(256) void sweep_lanes_kernel(const Dev p) {
   double newlike = mode == 2 ? p.llike_new[c] : p.like0 - 0.5 * quad;
   double newlpost = newlike * beta + newlprior;
   if (!want_like) newlike = newlpost = -__builtin_inf();
-  const double logH = newlpost - cur_lpost;  // gaussian_prop: log_hastings_ratio() == 0
+  double logH = newlpost - cur_lpost;  // gaussian_prop: log_hastings_ratio() == 0
   bool accept = valid;
+  if (hp) {                            // chain.cc:989-994: prop.log_hastings_ratio(), NaN => reject
+    const double hast = p.hastings[c];
+    if (hast != hast) accept = false;
+    logH = hast + logH;
+  }
   if (accept && logH < 0) accept = dlog_u01(o0.v0) < logH;  // chain.cc:998-1001 (NaN stays accepted)
   (void)tbuf;
+  if (hp && live && lead) p.acc_out[c] = tc ? (unsigned char)2 : (unsigned char)(accept ? 1 : 0);
 
   const bool act = live && !tc;
   int mapw = 0;

@@ -16,6 +16,7 @@ struct SweepSel {
   bool plain;   // open bounds, all-uniform prior, zero mean, no 1-D moves, no mixture, fixed ladder, device target
   bool simple;  // uni && plain
   bool callback;  // host-callback likelihood (propose / accept passes): general VALU kernel only
+  bool host_prop; // host-side proposals (ptm_set_proposal_callback): the lanes kernel's general build, whatever the population
 };
 #define PTM_DECL_DP(N)                                                                                              \
   hipError_t launch_sweep_##N(const Dev& p, SweepSel s, hipStream_t st);                                            \

@@ -24,7 +24,7 @@ PRIOR_NAMES = {"uni": 1, "uniform": 1, "gauss": 2, "gaussian": 2, "pol": 3, "pol
 EXPORTS = [
     "ptm_last_error", "ptm_abi_version", "ptm_device_count", "ptm_engine_create", "ptm_engine_destroy",
     "ptm_set_bounds", "ptm_set_prior", "ptm_set_target_gaussian", "ptm_set_target_callback", "ptm_set_ladder", "ptm_set_evolve_temps", "ptm_get_invtemps", "ptm_set_invtemps",
-    "ptm_set_proposals", "ptm_set_proposal_rung", "ptm_set_proposal_mixture", "ptm_set_states", "ptm_init_from_prior", "ptm_sweep", "ptm_step", "ptm_sync",
+    "ptm_set_proposals", "ptm_set_proposal_rung", "ptm_set_proposal_mixture", "ptm_set_proposal_callback", "ptm_set_states", "ptm_init_from_prior", "ptm_sweep", "ptm_step", "ptm_sync",
     "ptm_copy_llike", "ptm_llike_device_ptr", "ptm_exchange_decide", "ptm_exchange_finish_and_sweep", "ptm_exchange_install", "ptm_sweep_rungs", "ptm_exchange_buffer_doubles", "ptm_exchange_row_capacity", "ptm_get_states",
     "ptm_get_array", "ptm_get_swap_counts", "ptm_get_last_swaps", "ptm_max_swaps_per_step", "ptm_get_history", "ptm_get_history_invtemps", "ptm_set_history", "ptm_set_map", "ptm_get_map", "ptm_restore", "ptm_step_count",
     "ptm_timer_start", "ptm_timer_stop", "ptm_get_kernel_times", "ptm_sweep_kernel_name", "ptm_debug_eval",
@@ -52,6 +52,9 @@ _i64p = C.POINTER(C.c_int64)
 _u32p = C.POINTER(C.c_uint32)
 
 LOGLIKE_BATCH_FN = C.CFUNCTYPE(None, C.c_void_p, _dp, C.c_int, C.c_int, _dp)
+# ptm_propose_batch_fn / ptm_proposal_result_fn (include/ptm_engine.h)
+PROPOSE_BATCH_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int, _dp, _i32p, _i32p, C.c_uint64, _dp, _dp, _i32p, _i32p)
+PROPOSAL_RESULT_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int, _i32p, _i32p, _i32p)
 
 
 TORCH_LOADED_FIRST = None
@@ -117,6 +120,7 @@ def load():
     L.ptm_get_map.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp]
     L.ptm_set_proposal_rung.argtypes = [C.c_void_p, C.c_int, _dp, C.c_double]
     L.ptm_set_proposal_mixture.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp]
+    L.ptm_set_proposal_callback.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.ptm_restore.argtypes = [C.c_void_p, _dp, _dp, _i32p, _i32p, _i32p, C.POINTER(C.c_int64), C.c_uint64, C.POINTER(C.c_int64),
                               C.POINTER(C.c_int64)]
     L.ptm_debug_sqrt_scan.argtypes = [C.c_int, C.POINTER(C.c_uint64)]
@@ -271,6 +275,37 @@ class Engine:
         cb = LOGLIKE_BATCH_FN(tramp)
         self._keep.append(cb)
         _chk(self.L.ptm_set_target_callback(self.h, C.cast(cb, C.c_void_p), None))
+
+    def set_proposal_callback(self, propose, result=None):
+        """host-side proposals (ptm_set_proposal_callback): the C shape of proposal_distribution::draw / log_hastings_ratio /
+        type and accept / reject (proposal_distribution.hh:65-87).
+        propose: a C callback (PROPOSE_BATCH_FN or any ctypes function pointer of that signature), or a Python function
+          propose(X_cur[n][D], rung[n], walker[n], step) -> (X_prop[n][D], log_hastings[n], type[n], valid[n]);
+        result:  optional Python function result(rung[n], walker[n], accepted[n]) called after every sweep."""
+        if propose is None:
+            _chk(self.L.ptm_set_proposal_callback(self.h, None, None, None))
+            return
+        if not isinstance(propose, C._CFuncPtr):
+            fn = propose
+
+            def tramp(user, n, dim, xc, rung, walker, step, xp, lh, ty, va):
+                P, H, T, V = fn(np.ctypeslib.as_array(xc, shape=(n, dim)).copy(), np.ctypeslib.as_array(rung, shape=(n,)).copy(),
+                                np.ctypeslib.as_array(walker, shape=(n,)).copy(), int(step))
+                np.ctypeslib.as_array(xp, shape=(n, dim))[:] = P
+                np.ctypeslib.as_array(lh, shape=(n,))[:] = H
+                np.ctypeslib.as_array(ty, shape=(n,))[:] = T
+                np.ctypeslib.as_array(va, shape=(n,))[:] = V
+            propose = PROPOSE_BATCH_FN(tramp)
+        rcb = None
+        if result is not None:
+            rf = result
+
+            def rtramp(user, n, rung, walker, acc):
+                rf(np.ctypeslib.as_array(rung, shape=(n,)).copy(), np.ctypeslib.as_array(walker, shape=(n,)).copy(),
+                   np.ctypeslib.as_array(acc, shape=(n,)).copy())
+            rcb = PROPOSAL_RESULT_FN(rtramp)
+        self._keep += [propose, rcb]
+        _chk(self.L.ptm_set_proposal_callback(self.h, C.cast(propose, C.c_void_p), None if rcb is None else C.cast(rcb, C.c_void_p), None))
 
     def set_ladder(self, beta):
         b = np.ascontiguousarray(beta, dtype=np.float64)
