@@ -1,14 +1,24 @@
-// example_lisa.cc -- BASELINE configs[4]: a USER plug-in likelihood through the reference's own interface
-// (bayes_likelihood::register_evaluate_log, bayesian.hh:544-552), a mixed uniform / polar / co-polar prior with limit and
-// wrap boundaries (the set-up of the reference's exampleLISA.cc:528-593), the ptmcmc_sampler driver loop
-// (ptmcmc.cc:489-679) with its defaults (evolving ladder, chain files) -- all against ptmcmc_gpu.hh.
-// The likelihood is the toy LISA extrinsic-parameter model of that example (antenna responses, exampleLISA.cc:59-72;
-// log-likelihood :130-142), written here from its formulas; parameters: d, phi, inc, lambda, beta, psi.
+// example_lisa.cc -- BASELINE configs[4] through the DRIVER, call for call as a program written against the reference:
+// the sequence of its exampleLISA.cc main() (:698-822)
+//
+//     ptmcmc_sampler::Init(argc, argv);  Options opt;  ptmcmc_sampler mcmc;  bayes_sampler* s0 = &mcmc;
+//     [likelihood]  s0->addOptions(opt);  like->addOptions(opt);  opt.add(Option("nchains" | "seed" | "precision" | "outname"));
+//     opt.parse(argc, argv);  ProbabilityDist::setSeed(seed);  mcmc.setup(*like, precision);  mcmc.select_proposal();
+//     for (ic < Nchain) { bayes_sampler* s = s0->clone();  s->initialize();  s->run(base, ic);  delete s; }
+//
+// against ptmcmc_gpu.hh ("one include and one using").  The likelihood is a USER plug-in registered through
+// bayes_likelihood::register_evaluate_log (bayesian.hh:544-552): the toy LISA extrinsic-parameter model of that example
+// (antenna responses exampleLISA.cc:59-72, log-likelihood :130-142), written here from its formulas; parameters d, phi, inc,
+// lambda, beta, psi with the mixed uniform / polar / co-polar prior and limit / wrap boundaries of :528-593.
+// select_proposal() builds the reference's default recipe (ptmcmc.cc:15-183): 80 % differential evolution + six diagonal
+// Gaussians -- a host-side proposal (the engine's host-proposal step); --gauss_draw_frac=1 makes it all Gaussian, fused on
+// the device.
 //   build: g++ -std=c++11 -O2 -pthread -Iinclude -Iptmcmc_amd/host examples/example_lisa.cc -Lptmcmc_amd -lptm_engine -Wl,-rpath,$PWD/ptmcmc_amd
-//   usage: example_lisa <outbase> [--nsteps=N] [--pt=Ntemps] [--nchains=R] [--option=value ...]
+//   usage: example_lisa [--outname=base] [--nsteps=N] [--pt=Ntemps] [--nchains=R] [--replicas=W] [--seed=s] [--option=value ...]
 #include <cmath>
 #include <complex>
 #include <cstdio>
+#include <ctime>
 #include <vector>
 
 #include "ptmcmc_gpu.hh"
@@ -37,8 +47,8 @@ static double lisa_loglike(void*, const state& s) {
   return -0.5 * FACTOR * (std::norm(sa - SA_INJ) + std::norm(se - SE_INJ));
 }
 
-int main(int argc, char** argv) {
-  if (argc < 2) { printf("usage: %s <outbase> [--option=value ...]\n", argv[0]); return 2; }
+// the likelihood's set-up (the reference's simple_likelihood_setup_nc, exampleLISA.cc:528-593, in this program's words)
+static void setup_likelihood(bayes_likelihood* like) {
   const int D = 6;
   const double PI = M_PI;
   stateSpace space(D);
@@ -49,34 +59,76 @@ int main(int argc, char** argv) {
   space.set_bound(3, boundary(boundary::wrap, boundary::wrap, 0, 2 * PI));
   space.set_bound(4, boundary(boundary::limit, boundary::limit, -PI / 2, PI / 2));
   space.set_bound(5, boundary(boundary::wrap, boundary::wrap, 0, PI));
-  bayes_likelihood like;
-  like.register_evaluate_log(lisa_loglike);
-  std::vector<std::string> types = {"uni", "uni", "pol", "uni", "cpol", "uni"};
-  std::vector<double> centers = {1.667, PI, PI / 2, PI, 0, PI / 2}, scales = {1.333, PI, PI / 2, PI, PI / 2, PI / 2};
-  like.basic_setup(&space, types, centers, scales);
-  // the sampler's default Gaussian recipe (ptmcmc.cc:117-139), without its differential-evolution part
-  std::vector<proposal_distribution*> gset;
-  std::vector<double> gshares;
-  double fac = 1.0, share = 1;
-  for (int i = 0; i < 6; i++) {
-    std::vector<double> sig(D);
-    for (int d = 0; d < D; d++) sig[d] = scales[d] / fac;
-    gset.push_back(new gaussian_prop(sig, 0.2));
-    fac *= 4.0;
-    share *= 2;
-    gshares.push_back(share);
-  }
-  proposal_distribution_set prop(gset, gshares);
-  for (auto g : gset) delete g;
+  like->register_evaluate_log(lisa_loglike);
+  const std::vector<std::string> types = {"uni", "uni", "pol", "uni", "cpol", "uni"};
+  const std::vector<double> centers = {1.667, PI, PI / 2, PI, 0, PI / 2}, scales = {1.333, PI, PI / 2, PI, PI / 2, PI / 2};
+  like->basic_setup(&space, types, centers, scales);
+}
+
+int main(int argc, char* argv[]) {
+  ptmcmc_sampler::Init(argc, argv);
+  Options opt(true);
+  // create the sampler
   ptmcmc_sampler mcmc;
-  mcmc.set("nsteps", "4000"); mcmc.set("pt", "20"); mcmc.set("pt_Tmax", "1e9"); mcmc.set("save_every", "4");
-  mcmc.set("nevery", "1000"); mcmc.set("nskip", "4"); mcmc.set("pt_dump_n", "1");
-  if (!mcmc.parse(argc - 1, argv + 1)) { printf("bad option\n"); return 2; }
-  mcmc.setup(like);
-  mcmc.select_proposal(prop);
-  mcmc.initialize();   // prior draws on the device (uniform / polar / co-polar), the plug-in prices them on the host
-  mcmc.run(argv[1]);
-  printf("%s", mcmc.chains()->status().c_str());
-  printf("MAP: lpost = %.6f at %s\n", mcmc.chains()->getMAPlpost(), mcmc.chains()->getMAPstate().get_string().c_str());
+  bayes_sampler* s0 = &mcmc;
+  // create the likelihood
+  bayes_likelihood* like = new bayes_likelihood();
+  setup_likelihood(like);
+
+  // prep command-line options
+  s0->addOptions(opt);
+  like->addOptions(opt);
+  opt.add(Option("nchains", "Number of consequtive chain runs. Default 1", "1"));
+  opt.add(Option("seed", "Pseudo random number grenerator seed in [0,1). (Default=-1, use clock to seed.)", "-1"));
+  opt.add(Option("precision", "Set output precision digits. (Default 13).", "13"));
+  opt.add(Option("outname", "Base name for output files (Default 'mcmc_output').", "mcmc_output"));
+  const bool parseBAD = opt.parse(argc, argv);
+  if (parseBAD) {
+    std::cout << "Usage:\n example_lisa [--options=vals] " << std::endl;
+    std::cout << opt.print_usage() << std::endl;
+    return 1;
+  }
+  std::cout << "flags=\n" << opt.report() << std::endl;
+  like->setup();
+
+  double seed;
+  int Nchain, output_precision;
+  std::string outname;
+  std::istringstream(opt.value("nchains")) >> Nchain;
+  std::istringstream(opt.value("seed")) >> seed;
+  if (seed < 0) seed = std::fmod(time(NULL) / 3.0e7, 1);   // seed from the clock
+  std::istringstream(opt.value("precision")) >> output_precision;
+  std::istringstream(opt.value("outname")) >> outname;
+  if (argc > 1) outname = argv[1];   // (a bare first argument names the output too)
+  std::cout.precision(output_precision);
+  std::cout << "\noutname = '" << outname << "'" << std::endl;
+  std::cout << "seed=" << seed << std::endl;
+  ProbabilityDist::setSeed(seed);
+
+  // the space / prior, for the report
+  const stateSpace space = *like->getObjectStateSpace();
+  std::cout << "like.nativeSpace=\n" << space.show() << std::endl;
+  std::shared_ptr<const sampleable_probability_function> prior = like->getObjectPrior();
+  std::cout << "Prior is:\n" << prior->show() << std::endl;
+  std::cout << "Npar=" << space.size() << std::endl;
+
+  // Bayesian sampling: set up the sampler and its proposal distribution
+  mcmc.setup(*like, output_precision);
+  mcmc.select_proposal();
+
+  const std::string base = outname;
+  for (int ic = 0; ic < Nchain; ic++) {
+    bayes_sampler* s = s0->clone();
+    s->initialize();
+    s->run(base, ic);
+    ptmcmc_sampler* ps = dynamic_cast<ptmcmc_sampler*>(s);
+    std::cout << ps->chains()->status();
+    std::cout << "MAP: lpost = " << ps->chains()->getMAPlpost() << " at " << ps->chains()->getMAPstate().get_string() << std::endl;
+    std::cout << "proposals drawn on the " << (ps->chains()->proposals_on_host() ? "host" : "device") << std::endl;
+    delete s;
+  }
+  // summary
+  std::cout << "best_post " << like->bestPost() << ", state=" << like->bestState().get_string() << std::endl;
+  delete like;
   return 0;
 }

@@ -33,7 +33,6 @@ int main(int argc, char** argv) {
     gshares.push_back(share);
   }
   proposal_distribution_set prop(gset, gshares);
-  for (auto g : gset) delete g;
   ptmcmc_sampler mcmc;
   mcmc.set("nsteps", "2000"); mcmc.set("pt", "6"); mcmc.set("pt_Tmax", "50"); mcmc.set("save_every", "2");
   mcmc.set("nevery", "500"); mcmc.set("nskip", "4"); mcmc.set("pt_dump_n", "2"); mcmc.set("pt_swap_rate", "0.3");

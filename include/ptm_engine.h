@@ -162,6 +162,11 @@ int ptm_set_states(ptm_engine* e, const double* X, const double* llike);
 /* MH_chain::initialize(1): draw each chain's start from the prior until valid and of finite likelihood (chain.cc:846-876);
  * every mixed_dist_product type but the flat one can be drawn (PTM_ERR_UNSUPPORTED for a flat dimension) */
 int ptm_init_from_prior(ptm_engine* e);
+/* MH_chain::initialize(n) draws n states per chain (chain.cc:846-876); each of them is add_state'd, the last is where the chain
+ * starts.  ptm_init_from_prior_k draws the k-th of them (k = 0: what ptm_init_from_prior draws) from its own slice of the
+ * chain's initialisation stream, so a caller that wants n initial samples (the history seed of differential evolution,
+ * ptmcmc.cc:86) calls it for k = n-1 .. 0, reading the states back in between.  Resets the counters like ptm_set_states. */
+int ptm_init_from_prior_k(ptm_engine* e, int k);
 
 /* ---- the hot path ------------------------------------------------------------------------------------- */
 /* n x { MH_chain::step for every chain } -- no exchange phase */

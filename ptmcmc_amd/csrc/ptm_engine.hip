@@ -1017,13 +1017,17 @@ static int launch_init(ptm_engine* e, const Dev& p, long long attempt, unsigned 
   return PTM_OK;
 }
 
-extern "C" int ptm_init_from_prior(ptm_engine* e) {
+extern "C" int ptm_init_from_prior(ptm_engine* e) { return ptm_init_from_prior_k(e, 0); }
+
+extern "C" int ptm_init_from_prior_k(ptm_engine* e, int kdraw) {
   if (!e) return fail(PTM_ERR_INVALID, "null engine");
+  if (kdraw < 0 || kdraw > 8191) return fail(PTM_ERR_INVALID, "initial draw index out of range (0..8191)");
   if (!e->have_target) return fail(PTM_ERR_INVALID, "set the target first");
   for (int d = 0; d < e->D; ++d)
     if (e->h_ptype[d] == PTM_PRIOR_FLAT)
       return fail(PTM_ERR_UNSUPPORTED, "a flat (improper) prior cannot be drawn from (dimension %d): pass start states", d);
   Dev p = make_dev(e);
+  p.init_base = (uint64_t)kdraw << 17;   // attempts of draw k count from k * 2^17 (a draw gives up after 100000 < 2^17 attempts)
   HIPCHK(hipMemsetAsync(e->err + 1, 0, 4, e->stream));
   int rc;
   if (!e->cb) {

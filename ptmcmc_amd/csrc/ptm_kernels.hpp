@@ -134,6 +134,7 @@ struct Dev {
   const double* llike_new;  // [Nc] filled by the host for gated chains
   // host-side proposals (ptm_set_proposal_callback; lanes kernel, general build): the proposed states arrive in xprop
   // (whole states, row layout) with their log-Hastings ratio, type code and validity; acc_out gets the outcome
+  uint64_t init_base;            // init_prior_kernel: first attempt number of this initial draw (ptm_init_from_prior_k)
   int host_prop;
   const double* hastings;        // [Nc]
   const int* htype;              // [Nc]
@@ -651,7 +652,7 @@ __global__ __launch_bounds__(256) void init_prior_kernel(const Dev p, double* x_
   double x[DP];
   double ll = 0, lp = 0;
   bool done = false;
-  const uint64_t a_begin = cb_attempt >= 0 ? (uint64_t)cb_attempt : 0, a_end = cb_attempt >= 0 ? a_begin + 1 : 100000;
+  const uint64_t a_begin = p.init_base + (cb_attempt >= 0 ? (uint64_t)cb_attempt : 0), a_end = cb_attempt >= 0 ? a_begin + 1 : p.init_base + 100000;
   for (uint64_t a = a_begin; a < a_end && !done; ++a) {
 #pragma unroll
     for (int d = 0; d < DP; ++d) {

@@ -21,6 +21,7 @@
 #ifndef PTMCMC_GPU_HH
 #define PTMCMC_GPU_HH
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -63,6 +64,34 @@ class boundary {  // states.hh:29-48
       : lowertype(lowertype), uppertype(uppertype), xmin(min), xmax(max) {}
   void getDomainLimits(double& xmin_, double& xmax_) const { xmin_ = xmin; xmax_ = xmax; }
   bool isWrapped() const { return lowertype == wrap && uppertype == wrap; }
+  // boundary::enforce (states.cc:11-58), on the host for states the HOST builds (proposals drawn on the host side); the
+  // device enforces every proposal again with the same rules (ptm_kernels.hpp boundary_enforce)
+  bool enforce(double& x) const {
+    if ((lowertype == wrap) != (uppertype == wrap)) return false;
+    if (lowertype == wrap) {
+      const double width = xmax - xmin;
+      if (width <= 0) return false;
+      double xt = std::fmod(x - xmin, width);
+      if (xt < 0) xt += width;
+      x = xmin + xt;
+      return true;
+    }
+    if (lowertype == reflect && uppertype == reflect) {
+      const double halfwidth = xmax - xmin;
+      if (halfwidth <= 0) return false;
+      const double width = 2 * halfwidth;
+      double xt = std::fmod(x - xmin, width);
+      if (xt < 0) xt += width;
+      if (xt >= halfwidth) xt = halfwidth - xt;   // as the reference folds it (states.cc:41)
+      x = xmin + xt;
+      return true;
+    }
+    if (lowertype == reflect && x < xmin) x = xmin + (xmin - x);
+    else if (uppertype == reflect && x > xmax) x = xmax - (x - xmax);
+    if (lowertype == limit && x < xmin) return false;
+    if (uppertype == limit && x > xmax) return false;
+    return true;
+  }
   int lower() const { return lowertype; }
   int upper() const { return uppertype; }
   std::string show() const {
@@ -100,6 +129,12 @@ class stateSpace {  // states.hh:60-145 (names, bounds; symmetries are out of sc
   }
   void set_names(const std::string n[]) { set_names(std::vector<std::string>(n, n + dim)); }
   std::string get_name(int i) const { return have_names && i < dim ? names[i] : "[unnamed]"; }
+  bool enforce(std::valarray<double>& params) const {   // states.cc:86-102
+    if ((int)params.size() != dim) { std::cout << "stateSpace::enforce:  Dimension error.  Expected " << dim << " params, but given " << params.size() << "." << std::endl; exit(1); }
+    for (int i = 0; i < dim; i++)
+      if (!bounds[i].enforce(params[i])) return false;
+    return true;
+  }
   int get_index(const std::string& name) const { return have_names && index.count(name) ? index.at(name) : -1; }
   int requireIndex(const std::string& name) const {
     int i = get_index(name);
@@ -114,15 +149,24 @@ class stateSpace {  // states.hh:60-145 (names, bounds; symmetries are out of sc
   }
 };
 
-class state {  // states.hh:147-234: a host value (parameters + space); validity is decided on the device
+class state {  // states.hh:147-234, states.cc:161-253
   const stateSpace* space;
   std::valarray<double> params;
   bool valid;
 
  public:
-  state(const stateSpace* space = nullptr, int n = 0) : space(space), params(0.0, n), valid(space != nullptr) {}
-  state(const stateSpace* sp, const std::valarray<double>& a) : space(sp), params(a), valid(sp != nullptr) {}
-  state(const stateSpace* sp, const std::vector<double>& a) : space(sp), params(a.data(), a.size()), valid(sp != nullptr) {}
+  // state(space, n): the zero vector, ENFORCED (states.cc:168-176) -- quirk Q9: if zero violates a `limit` bound the state is
+  // born invalid, and every state::add() result with it
+  state(const stateSpace* space = nullptr, int n = 0) : space(space), params(0.0, n), valid(space != nullptr) { if (space) enforce(); }
+  state(const stateSpace* sp, const std::valarray<double>& a) : space(sp), params(a), valid(sp != nullptr) { enforce(); }
+  state(const stateSpace* sp, const std::vector<double>& a) : space(sp), params(a.data(), a.size()), valid(sp != nullptr) { enforce(); }
+  // values the engine hands back: enforced on the device already
+  static state from_engine(const stateSpace* sp, const double* x, int n) { state s; s.space = sp; s.params = std::valarray<double>(x, n); s.valid = sp != nullptr; return s; }
+  void enforce() {   // states.cc:161-166
+    if (!space) valid = false;
+    if (!valid) return;
+    valid = space->enforce(params);
+  }
   int size() const { return params.size(); }
   double get_param(int i) const { return params[i]; }
   double get_param(const std::string& name) const { return params[space->requireIndex(name)]; }
@@ -131,12 +175,210 @@ class state {  // states.hh:147-234: a host value (parameters + space); validity
   std::vector<double> get_params_vector() const { return std::vector<double>(std::begin(params), std::end(params)); }
   const stateSpace* getSpace() const { return space; }
   bool invalid() const { return !valid; }
+  // the vector-space operations some proposals rely on (states.cc:194-253; extra_enforcement is off in the reference)
+  state add(const state& other) const {
+    state result(space, size());
+    if (other.size() != size()) { std::cout << "state::add: Sizes mismatch. (" << size() << "!=" << other.size() << ")\n"; exit(1); }
+    for (int i = 0; i < size(); i++) result.params[i] = params[i] + other.params[i];
+    return result;
+  }
+  state scalar_mult(double x) const {
+    state result(space, size());
+    for (int i = 0; i < size(); i++) result.params[i] = params[i] * x;
+    return result;
+  }
+  double innerprod(const state& other, bool constrained = false) const {
+    if (constrained && !(valid && other.valid)) return NAN;
+    if (other.size() != size()) { std::cout << "state::innerprod: sizes mismatch.\n"; exit(1); }
+    double result = 0;
+    for (int i = 0; i < size(); i++) result += params[i] * other.params[i];
+    return result;
+  }
+  std::vector<int> projection_indices_by_name(const stateSpace* subspace) const {   // states.cc:256-264
+    std::vector<int> idx;
+    for (int isub = 0; isub < subspace->size(); isub++) idx.push_back(space ? space->get_index(subspace->get_name(isub)) : -1);
+    return idx;
+  }
   std::string get_string(int prec = -1) const {
     std::ostringstream s;
     if (prec > 0) s.precision(prec);
     for (int i = 0; i < size(); i++) s << (i ? ", " : "") << params[i];
     return s.str();
   }
+};
+
+// ---- ProbabilityDist / newran: what the plug-in surface sees of the random numbers ----------------------------------------
+// The reference hands every chain its own newran generator and proposals pull uniforms with caller->getPRNG()->Next()
+// (chain.hh:44-75).  Here a chain's host-side generator is one more counter-based Philox4x32-10 stream -- keyed like the
+// device streams by (seed, walker, rung, step), in a tag domain of its own -- so host-side proposals are as reproducible and
+// as independent of the launch geometry as the device's.
+class Random {
+ public:
+  virtual ~Random() {}
+  virtual double Next() = 0;   // uniform in (0, 1)
+};
+
+namespace detail {
+inline void philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {   // Salmon et al., SC'11
+  uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3], k0 = key[0], k1 = key[1];
+  for (int r = 0; r < 10; r++) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+}  // namespace detail
+
+class philox_random : public Random {   // counter: (block, stream, step[31:0], step[55:32] | tag << 24), tag 3 = host proposals
+  uint64_t seed, step;
+  uint32_t stream, block, buf[4];
+  int have;
+
+ public:
+  philox_random() : seed(0), step(0), stream(0), block(0), have(0) {}
+  void reseat(uint64_t seed_, uint32_t stream_, uint64_t step_) { seed = seed_; stream = stream_; step = step_; block = 0; have = 0; }
+  double Next() override {
+    if (!have) {
+      const uint32_t ctr[4] = {block++, stream, (uint32_t)step, ((uint32_t)(step >> 32) & 0x00FFFFFFu) | (3u << 24)};
+      const uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+      detail::philox4x32_10(ctr, key, buf);
+      have = 4;
+    }
+    return ((double)buf[4 - have--] + 0.5) * (1.0 / 4294967296.0);   // newran's open-interval map (newran1.cxx:432)
+  }
+  // a standard normal (Box-Muller on two uniforms; the device has its own table-driven form for its own draws)
+  double Normal() {
+    const double u1 = Next(), u2 = Next();
+    return std::sqrt(-2.0 * std::log(u1)) * std::cos(6.283185307179586 * u2);
+  }
+};
+
+class ProbabilityDist {   // ProbabilityDist.h:37-48: the master seed every chain's generator descends from
+ public:
+  static double& seed_ref() { static double s = -1; return s; }
+  static void setSeed(double seed) { seed_ref() = seed; }
+  static double getSeed() { return seed_ref(); }
+  // the engine's Philox key for a seed in [0, 1) (< 0: the fixed default)
+  static uint64_t engineSeed() { const double s = seed_ref(); return s >= 0 ? (uint64_t)(s * 4294967296.0) : 0x5EED0001ull; }
+  // The reference seeds every chain from the master generator in construction order (chain.hh:58-62), so the ladders a
+  // program builds one after the other (its loop over clone() / initialize() / run()) differ.  Here: the n-th ladder of the
+  // process gets the master key with n folded into the upper word (the first one the master key itself).
+  static int& ladders_made() { static int n = 0; return n; }
+  static uint64_t nextLadderSeed() { const uint64_t n = (uint64_t)ladders_made()++; return engineSeed() ^ (n * 0x9E3779B97F4A7C15ull << 32); }
+};
+
+// ---- options.hh: "--name=value" flags shared by the program's components -------------------------------------------------
+// Own implementation of the reference's interface (options.hh:17-241): Option(name, info, default), Options::add / parse /
+// set / value / print_usage / report, and the Optioned mix-in (addOptions, optValue, optSet).
+class Options;
+class Option {
+  friend class Options;
+  std::string name, info, value;
+  bool have_default, is_set;
+
+ public:
+  Option() : have_default(false), is_set(false) {}
+  Option(const std::string& name, const std::string& info, const std::string& vdefault = "<no default>")
+      : name(name), info(info), value(vdefault), have_default(vdefault != "<no default>"), is_set(false) {}
+  std::string describe() const { return name + "('" + info + "')=" + (have_default ? value : std::string("<no value>")); }
+};
+
+class Options {
+  std::map<std::string, Option> flags;
+  bool dash_dash;
+
+ public:
+  Options(bool dash_dash = true) : dash_dash(dash_dash) {}
+  void add(const Option& opt) {
+    if (exists(opt.name)) {
+      if (opt.describe() != flags[opt.name].describe())
+        std::cout << "Options::add: Warning! Attempt to re-add an option with same name but non-identical information.\n  Retaining original option ("
+                  << flags[opt.name].describe() << ")" << std::endl;
+      return;
+    }
+    flags[opt.name] = opt;
+  }
+  bool exists(const std::string& name) const { return flags.count(name) > 0; }
+  bool set(const std::string& name, std::string& return_value) const {
+    std::map<std::string, Option>::const_iterator it = flags.find(name);
+    if (it == flags.end()) { std::cerr << "Options: Error no option '" << name << "'." << std::endl; return false; }
+    if (it->second.is_set || it->second.have_default) { return_value = it->second.value; return true; }
+    return false;
+  }
+  bool set(const std::string& name) const { std::string dummy; return set(name, dummy); }
+  std::string value(const std::string& name) const { std::string v(""); set(name, v); return v; }
+  std::string print_usage() const {
+    std::ostringstream os;
+    os << "Options:\n";
+    for (std::map<std::string, Option>::const_iterator i = flags.begin(); i != flags.end(); ++i) {
+      const std::string flag = std::string(dash_dash ? "  --" : "  -") + i->second.name;
+      os << flag << std::string(flag.size() < 24 ? 24 - flag.size() : 1, ' ') << "\t" << i->second.info << "\n";
+    }
+    return os.str();
+  }
+  // recognised flags are recorded and removed from argv; returns true if an unknown flag was met (as the reference: "fail")
+  bool parse(int& argc, char* argv[], bool verbose = true) {
+    bool fail = false;
+    int i = 1;
+    while (i < argc) {
+      const std::string a(argv[i]);
+      if (a.empty() || a[0] != '-' || (dash_dash && (a.size() <= 1 || a[1] != '-'))) { i++; continue; }
+      const std::string flag = a.substr(dash_dash ? 2 : 1);
+      const size_t pos = flag.find('=');
+      const std::string name = flag.substr(0, pos);
+      if (!flags.count(name)) {
+        if (verbose) std::cerr << "Option '" << name << "' not recognized." << std::endl;
+        fail = true;
+        i++;
+        continue;
+      }
+      Option& o = flags[name];
+      o.is_set = true;
+      o.value = pos == std::string::npos ? std::string("true") : flag.substr(pos + 1);
+      for (int ic = i; ic < argc - 1; ic++) argv[ic] = argv[ic + 1];
+      argc--;
+    }
+    return fail;
+  }
+  std::string report() const {
+    std::ostringstream s;
+    for (std::map<std::string, Option>::const_iterator it = flags.begin(); it != flags.end(); ++it)
+      s << " " << it->first << ':' << (it->second.is_set ? it->second.value : std::string("(not set)")) << '\n';
+    return s.str();
+  }
+};
+
+class Optioned {   // options.hh:196-240
+  std::string prefix;
+  Options* opt;
+  bool have_options;
+
+ protected:
+  void copyOptioned(const Optioned& other) { prefix = other.prefix; opt = other.opt; have_options = other.have_options; }
+  void check_opt() const {
+    if (!have_options) { std::cout << "Optioned::check_opt: Must call Optioned::addOptions() before using options." << std::endl; exit(1); }
+  }
+  void addOption(const std::string& name, const std::string& info, const std::string& vdefault = "<no default>") {
+    check_opt();
+    opt->add(Option(prefix + name, info, vdefault));
+  }
+
+ public:
+  Optioned() : opt(nullptr), have_options(false) {}
+  virtual ~Optioned() {}
+  virtual void addOptions(Options& opts, const std::string& prefix_ = "") { opt = &opts; prefix = prefix_; have_options = true; }
+  bool haveOptions() const { return have_options; }
+  std::unique_ptr<std::istringstream> optValue(const std::string& name) {
+    check_opt();
+    return std::unique_ptr<std::istringstream>(new std::istringstream(opt->value(prefix + name)));
+  }
+  void optGetValue(const std::string& name, int& val) { *optValue(name) >> val; }
+  void optGetValue(const std::string& name, double& val) { *optValue(name) >> val; }
+  void optGetValue(const std::string& name, std::string& val) { *optValue(name) >> val; }
+  bool optSet(const std::string& name) { check_opt(); return opt->set(prefix + name); }
+  std::string reportOptions() { check_opt(); return opt->report(); }
 };
 
 // ---- probability_function.hh --------------------------------------------------------------------------------------
@@ -159,6 +401,13 @@ class sampleable_probability_function : public probability_function {  // probab
   sampleable_probability_function(const stateSpace* space) : probability_function(space), dim(0) {}
   virtual int getDim() const { return dim; }
   virtual void getScales(std::valarray<double>& out) const {}
+  virtual void getScales(std::vector<double>& out) const { std::valarray<double> v; getScales(v); out.assign(std::begin(v), std::end(v)); }
+  // host-side evaluation and sampling (probability_function.hh:48-83), for proposals that draw from the prior and for the
+  // likelihood's best-posterior bookkeeping; the chain's own prior values are computed on the device
+  virtual double evaluate(state& s) const { return 1; }
+  virtual double evaluate_log(state& s) const { return std::log(evaluate(s)); }   // probability_function.hh:59
+  virtual state drawSample(Random& rng) const { std::cout << "sampleable_probability_function::drawSample: not defined for this prior" << std::endl; exit(1); }
+  virtual std::string show() const { return "UnspecifiedSampleableProbabilityFunction()"; }
   // engine description: per-dimension (type, center, halfwidth), types as mixed_dist_product::{uniform,...}
   virtual void describe(std::vector<int>& types, std::vector<double>& centers, std::vector<double>& halfwidths) const = 0;
 };
@@ -185,6 +434,47 @@ class mixed_dist_product : public sampleable_probability_function {  // probabil
       }
   }
   void getScales(std::valarray<double>& out) const override { out = halfwidths; }
+  // mixed_dist_product::evaluate (probability_function.cc:281-304): the product of the 1-D pdfs of ProbabilityDist.h:76-257;
+  // an invalid state has probability 0
+  double evaluate(state& s) const override {
+    if (s.invalid()) return 0;
+    double result = 1;
+    for (unsigned i = 0; i < dim; i++) result *= pdf1(i, s.get_param(i));
+    return result;
+  }
+  // ... and its drawSample (probability_function.cc:264-279): one draw per dimension from the 1-D distribution's inverse cdf
+  // (uniform / log / polar / copolar) or a normal (gaussian)
+  state drawSample(Random& rng) const override {
+    std::valarray<double> x(dim);
+    for (unsigned i = 0; i < dim; i++) {
+      const double c = centers[i], h = halfwidths[i];
+      switch (types[i]) {
+        case uniform: x[i] = rng.Next() * (2 * h) + (c - h); break;
+        case gaussian: { const double u1 = rng.Next(), u2 = rng.Next(); x[i] = std::sqrt(-2.0 * std::log(u1)) * std::cos(6.283185307179586 * u2) * h + c; break; }
+        case polar: { double a = c - h, b = c + h; if (a < 0) a = 0; if (b > M_PI) b = M_PI; const double ca = std::cos(a), cb = std::cos(b); x[i] = std::acos(ca - rng.Next() * (ca - cb)); break; }
+        case copolar: { double a = c - h, b = c + h; if (a < -M_PI / 2) a = -M_PI / 2; if (b > M_PI / 2) b = M_PI / 2; const double sa = std::sin(a), sb = std::sin(b); x[i] = std::asin(sa + rng.Next() * (sb - sa)); break; }
+        case log: { const double l0 = std::log(c / h), l1 = std::log(c * h); x[i] = std::exp(rng.Next() * (l1 - l0) + l0); break; }
+        default: x[i] = NAN;
+      }
+    }
+    return state(space, x);
+  }
+  std::string show() const override {
+    std::ostringstream ss;
+    ss << "MixedDistProduct(dim=" << dim << ")";
+    return ss.str();
+  }
+  double pdf1(unsigned i, double x) const {
+    const double c = centers[i], h = halfwidths[i];
+    switch (types[i]) {
+      case uniform: return (x < c - h || x > c + h) ? 0 : 1 / (2 * h);
+      case gaussian: { const double xn = (x - c) / h; return std::exp(-xn * xn / 2) / std::sqrt(2 * M_PI) / h; }
+      case polar: { double a = c - h, b = c + h; if (x < a || x > b) return 0; if (a < 0) a = 0; if (b > M_PI) b = M_PI; return std::sin(x) / (-std::cos(b) + std::cos(a)); }
+      case copolar: { double a = c - h, b = c + h; if (x < a || x > b) return 0; if (a < -M_PI / 2) a = -M_PI / 2; if (b > M_PI / 2) b = M_PI / 2; return std::cos(x) / (std::sin(b) - std::sin(a)); }
+      case log: { const double a = c / h, b = c * h; if (x < a || x > b) return 0; return 1 / (std::log(b) - std::log(a)) / x; }
+    }
+    return NAN;
+  }
   void describe(std::vector<int>& t, std::vector<double>& c, std::vector<double>& h) const override {
     t.assign(std::begin(types), std::end(types));
     c.assign(std::begin(centers), std::end(centers));
@@ -207,6 +497,659 @@ class gaussian_dist_product : public mixed_dist_product {  // probability_functi
       : mixed_dist_product(space, std::valarray<int>(gaussian, x0s.size()), x0s, sigmas) {}
 };
 
+// ---- chain.hh: the base interface (what proposals and the driver see of a chain) -------------------------------------------
+class proposal_distribution;
+class chain {  // chain.hh:34-141
+ public:
+  virtual ~chain() {}
+  virtual void step() = 0;
+  virtual state getState(int elem = -1, bool raw_indexing = false) = 0;
+  virtual double getLogPost(int elem = -1, bool raw_indexing = false) = 0;
+  virtual double getLogLike(int elem = -1, bool raw_indexing = false) = 0;
+  virtual double invTemp() { return 1.0; }
+  virtual int multiplicity() { return 1; }
+  virtual chain* subchain(int index) { return this; }
+  virtual int getStep() = 0;
+  virtual int size() { return getStep() + 1; }                       // saved history rows (chain.hh:86)
+  virtual int getDim() { return 0; }
+  virtual int get_id() { return 0; }
+  virtual std::shared_ptr<Random> getPRNG() { return std::shared_ptr<Random>(); }   // chain.hh:75
+  virtual double getMAPlpost() { return -1e200; }                    // chain.hh:116-117
+  virtual state getMAPstate() { return getState(); }
+  virtual std::string status() { return ""; }
+  virtual std::string report_prop(int style = 0) { return ""; }
+};
+
+// ---- proposal_distribution.hh ---------------------------------------------------------------------------------------
+// The whole plug-in surface of proposal_distribution.hh:38-88: draw(state&, chain*), log_hastings_ratio(), type(), accept() /
+// reject(), clone(), set_chain(), is_ready(), support_mixing().  A proposal that can describe itself as a Gaussian with a fixed
+// factor (device_describe) is drawn ON the device, fused into the sweep kernel; every other proposal -- differential
+// evolution, sets of mixed members, user proposals with callbacks -- runs through the engine's host-proposal step
+// (ptm_set_proposal_callback): draw() is called here, once per moving chain and step, and the device does the rest of
+// MH_chain::step (enforce, prior, likelihood, Metropolis test).
+class proposal_distribution {
+ protected:
+  int id;
+  double log_hastings;
+  int last_type, accept_count, reject_count;
+  chain* ch;
+  void* user_parent_object;
+  void* user_instance_object;
+  void* (*new_user_instance_object_function)(void* object, int id);
+  static int& idcount() { static int n = 0; return n; }
+  void set_instance() {   // proposal_distribution.hh:49-56
+    if (user_parent_object && new_user_instance_object_function) user_instance_object = new_user_instance_object_function(user_parent_object, id);
+    else user_instance_object = nullptr;
+  }
+
+ public:
+  virtual ~proposal_distribution() {}
+  proposal_distribution(void* user_parent_object = nullptr, void* (*new_user_instance_object_function)(void* object, int id) = nullptr)
+      : log_hastings(0), last_type(0), accept_count(0), reject_count(0), ch(nullptr), user_parent_object(user_parent_object),
+        user_instance_object(nullptr), new_user_instance_object_function(new_user_instance_object_function) {
+    id = idcount()++;
+    set_instance();
+  }
+  virtual double log_hastings_ratio() { return log_hastings; }   // proposal part of the Hastings ratio of the most recent draw
+  virtual void set_chain(chain* c) { ch = c; }
+  virtual state draw(state& s, chain* caller) { return s; }      // the base class is not useful
+  virtual bool is_ready() { return true; }
+  virtual proposal_distribution* clone() const { return new proposal_distribution(*this); }
+  virtual std::string show() { return "UnspecifiedProposal()"; }
+  virtual int type() { return last_type; }
+  virtual bool support_mixing() { return false; }
+  virtual void accept() { accept_count++; }
+  virtual void reject() { reject_count++; }
+  virtual void accept(int count) { accept_count = count; }
+  virtual void reject(int count) { reject_count = count; }
+  virtual void checkpoint(std::string path) {}
+  virtual void restart(std::string path) {}
+  virtual std::string report(int style = 0) {
+    std::ostringstream ss;
+    if (style == 0) ss << accept_count * 1.0 / (accept_count + reject_count) << "(" << accept_count << ")";
+    return ss.str();
+  }
+  // ---- device description (this build's addition): a Gaussian with a fixed factor is drawn by the sweep kernel itself
+  virtual bool device_describe(int dim, int& kind, std::vector<double>& factor, double& oneDfrac) const { return false; }
+  // a set of Gaussian members that are scalar multiples of one factor: cumulative shares, scales, oneDfracs (else false)
+  virtual bool device_describe_mixture(int dim, std::vector<double>& cum, std::vector<double>& scales, std::vector<double>& odfs) const { return false; }
+};
+
+namespace detail {
+// a standard normal from a chain's generator (the reference: newran's Normal, newran2.cxx:164-217; replaced, not reproduced)
+inline double normal_from(Random& rng) {
+  const double u1 = rng.Next(), u2 = rng.Next();
+  return std::sqrt(-2.0 * std::log(u1)) * std::cos(6.283185307179586 * u2);
+}
+// symmetric eigen-decomposition by cyclic Jacobi (the reference uses Eigen::SelfAdjointEigenSolver): eigenvalues ascending in
+// `lambda`, eigenvectors in the columns of V (row-major n x n).  Pinned against the reference's gaussian_prop(covar) by
+// tests/golden/eigen.json.gz.
+inline void jacobi_eigen(std::vector<double> A, int n, std::vector<double>& lambda, std::vector<double>& V) {
+  std::vector<double> Q(n * n, 0.0);
+  for (int i = 0; i < n; i++) Q[i * n + i] = 1;
+  for (int sweep = 0; sweep < 100; sweep++) {
+    double off = 0;
+    for (int p = 0; p < n; p++) for (int q = p + 1; q < n; q++) off += A[p * n + q] * A[p * n + q];
+    if (off < 1e-300) break;
+    for (int p = 0; p < n; p++)
+      for (int q = p + 1; q < n; q++) {
+        if (std::fabs(A[p * n + q]) < 1e-300) continue;
+        double theta = (A[q * n + q] - A[p * n + p]) / (2 * A[p * n + q]);
+        double t = (theta >= 0 ? 1 : -1) / (std::fabs(theta) + std::sqrt(theta * theta + 1));
+        double c = 1 / std::sqrt(t * t + 1), sn = t * c;
+        for (int k = 0; k < n; k++) { double a = A[k * n + p], b = A[k * n + q]; A[k * n + p] = c * a - sn * b; A[k * n + q] = sn * a + c * b; }
+        for (int k = 0; k < n; k++) { double a = A[p * n + k], b = A[q * n + k]; A[p * n + k] = c * a - sn * b; A[q * n + k] = sn * a + c * b; }
+        for (int k = 0; k < n; k++) { double a = Q[k * n + p], b = Q[k * n + q]; Q[k * n + p] = c * a - sn * b; Q[k * n + q] = sn * a + c * b; }
+      }
+  }
+  std::vector<int> order(n);
+  for (int i = 0; i < n; i++) order[i] = i;
+  for (int i = 0; i < n; i++) for (int j = i + 1; j < n; j++) if (A[order[j] * n + order[j]] < A[order[i] * n + order[i]]) std::swap(order[i], order[j]);
+  lambda.assign(n, 0.0); V.assign(n * n, 0.0);
+  for (int j = 0; j < n; j++) {
+    lambda[j] = A[order[j] * n + order[j]];
+    for (int i = 0; i < n; i++) V[i * n + j] = Q[i * n + order[j]];
+  }
+}
+}  // namespace detail
+
+class gaussian_prop : public proposal_distribution {  // proposal_distribution.hh:145-227
+  bool identity_trans;
+  std::vector<double> factor;  // DIAG: sigmas; else dense D x D row-major V*diag(sqrt(lambda))
+  int ndim;
+  double oneDfrac;
+
+  // factor = V * diag(sqrt(lambda)) so that offset = factor * z as in hh:207-213 (eigenvalues ascending, hh:173-176)
+  static void eigen_factor(const std::vector<double>& A, int n, std::vector<double>& F) {
+    std::vector<double> lam, V;
+    detail::jacobi_eigen(A, n, lam, V);
+    F.assign(n * n, 0.0);
+    for (int j = 0; j < n; j++) {
+      const double sg = std::sqrt(lam[j] > 0 ? lam[j] : 0.0);
+      for (int i = 0; i < n; i++) F[i * n + j] = V[i * n + j] * sg;
+    }
+  }
+
+ public:
+  gaussian_prop(const std::valarray<double>& sigmas, double oneDfrac = 0.0, bool scaleWithTemp = false)
+      : identity_trans(true), factor(std::begin(sigmas), std::end(sigmas)), ndim(sigmas.size()), oneDfrac(oneDfrac) { check(); }
+  gaussian_prop(const std::vector<double>& sigmas, double oneDfrac = 0.0, bool scaleWithTemp = false)
+      : identity_trans(true), factor(sigmas), ndim(sigmas.size()), oneDfrac(oneDfrac) { check(); }
+  // covariance, row-major ndim x ndim (the reference takes an Eigen::MatrixXd, hh:165)
+  gaussian_prop(const std::vector<double>& covar, int ndim, double oneDfrac = 0.0, bool scaleWithTemp = false)
+      : identity_trans(false), ndim(ndim), oneDfrac(oneDfrac) {
+    if ((int)covar.size() != ndim * ndim) { std::cout << "gaussian_prop(constructor II): covar must be a square matrix!" << std::endl; exit(-1); }
+    eigen_factor(covar, ndim, factor);
+    check();
+  }
+  void check() const {
+    if (oneDfrac < 0 || oneDfrac > 1) { std::cout << "gaussian_prop(constructor): We require 0<=oneDfrac<=1. " << std::endl; exit(1); }
+  }
+  gaussian_prop* clone() const override { return new gaussian_prop(*this); }
+  std::string show() override {
+    std::ostringstream ss;
+    ss << "StepBy" << (identity_trans ? "" : "Covar") << "[dim=" << ndim << "](1Dfrac=" << oneDfrac << ")";
+    return ss.str();
+  }
+  // gaussian_prop::draw on the host (hh:194-218) -- used when this proposal is a member of a set that cannot go to the device
+  // as a whole: ndim normals first, then the optional one-dimensional move, then the transform (quirk Q4: scaleWithTemp has no
+  // effect in the reference)
+  state draw(state& s, chain* caller) override {
+    Random& rng = *caller->getPRNG();
+    std::vector<double> z(ndim);
+    for (int i = 0; i < ndim; i++) z[i] = detail::normal_from(rng) * (identity_trans ? factor[i] : 1.0);
+    double x = 1;
+    if (oneDfrac > 0) x = rng.Next();
+    if (oneDfrac > 0 && x < oneDfrac) {
+      const int i = (int)(ndim * rng.Next());
+      for (int j = 0; j < ndim; j++) if (j != i) z[j] = 0;
+      last_type = 1;
+    } else last_type = 0;
+    std::vector<double> off(ndim, 0.0);
+    if (identity_trans) off = z;
+    else
+      for (int i = 0; i < ndim; i++) { double a = 0; for (int j = 0; j < ndim; j++) a += factor[i * ndim + j] * z[j]; off[i] = a; }
+    log_hastings = 0;
+    return s.add(state(nullptr, off));
+  }
+  bool device_describe(int dim, int& kind, std::vector<double>& f, double& odf) const override {
+    if (dim != ndim) { std::cout << "gaussian_prop: dimension mismatch with the chain (" << ndim << " vs " << dim << ")" << std::endl; exit(1); }
+    kind = identity_trans ? PTM_PROP_DIAG : PTM_PROP_DENSE;
+    f = factor;
+    odf = oneDfrac;
+    return true;
+  }
+};
+
+// draw_from_dist (proposal_distribution.hh:119-132): an independence proposal from a sampleable distribution (the prior)
+class draw_from_dist : public proposal_distribution {
+  const sampleable_probability_function& dist;
+
+ public:
+  draw_from_dist(const sampleable_probability_function& dist) : dist(dist) {}
+  state draw(state& s, chain* caller) override {
+    state newstate = dist.drawSample(*caller->getPRNG());
+    log_hastings = dist.evaluate_log(s) - dist.evaluate_log(newstate);   // likelier to draw the new state than the old one
+    return newstate;
+  }
+  draw_from_dist* clone() const override { return new draw_from_dist(*this); }
+  std::string show() override { return "DrawFrom[" + dist.show() + "]()"; }
+};
+
+// user_gaussian_prop (proposal_distribution.hh:236-304, .cc:259-474): a Gaussian step on a named sub-space whose covariance a
+// user callback may replace before any draw.  The covariance comes as a vector: ndim variances, or the ndim (ndim+1)/2 entries of
+// the upper triangle row by row; it is rescaled to the correlation matrix, diagonalised, and the step is
+// diag(sigma) V (sqrt(lambda) o z) (reset_dist, .cc:340-403; negative eigenvalues are set to zero).
+class user_gaussian_prop : public proposal_distribution {
+ public:
+  typedef bool (*check_update_prototype)(const void* parent_object, void* instance_object, const state& s, double invtemp,
+                                         const std::vector<double>& randoms, std::vector<double>& covarvec);
+  typedef void (*checkpoint_restart_prototype)(const void* parent_object, void* instance_object, const std::string path);
+  typedef void (*accept_reject_prototype)(const void* parent_object, void* instance_object);
+
+ private:
+  std::vector<double> diagTransform;   // ndim x ndim row-major: diag(sqrt(cov_ii)) * eigenvectors of the correlation matrix
+  std::vector<double> sigmas, covar_vec;
+  int ndim;
+  std::string label;
+  check_update_prototype user_check_update;
+  bool check_update_registered;
+  checkpoint_restart_prototype user_checkpoint, user_restart;
+  bool checkpoint_restart_registered;
+  accept_reject_prototype user_accept, user_reject;
+  bool accept_reject_registered;
+  std::vector<int> idx_map;
+  int nrand;
+  bool have_dist, isverbose;
+
+ protected:
+  stateSpace domainSpace;
+  void reset_dist(const std::vector<double>& covarvec) {   // .cc:340-403
+    covar_vec = covarvec;
+    std::vector<double> cov((size_t)ndim * ndim, 0.0);
+    const int ULsize = ndim * (ndim + 1) / 2;
+    if ((int)covarvec.size() == ndim) {
+      for (int i = 0; i < ndim; i++) cov[i * ndim + i] = covarvec[i];
+    } else if ((int)covarvec.size() == ULsize) {
+      int ic = 0;
+      for (int i = 0; i < ndim; i++)
+        for (int j = i; j < ndim; j++) { cov[i * ndim + j] = cov[j * ndim + i] = covarvec[ic++]; }
+    } else {
+      std::cout << "gaussian_prop:reset_dist Covar vector has unexpeced size,ndim=" << ndim << ", UL size=" << ULsize << " but got " << covarvec.size() << " " << std::endl;
+      if (have_dist) { std::cout << " Skipping update!" << std::endl; return; }
+      std::cout << " Setting to identity matrix!" << std::endl;
+      for (int i = 0; i < ndim; i++) cov[i * ndim + i] = 1;
+    }
+    std::vector<double> corr((size_t)ndim * ndim), lam, V;
+    for (int i = 0; i < ndim; i++)
+      for (int j = 0; j < ndim; j++) corr[i * ndim + j] = cov[i * ndim + j] / std::sqrt(cov[i * ndim + i]) / std::sqrt(cov[j * ndim + j]);
+    detail::jacobi_eigen(corr, ndim, lam, V);
+    diagTransform.assign((size_t)ndim * ndim, 0.0);
+    sigmas.assign(ndim, 0.0);
+    for (int i = 0; i < ndim; i++)
+      for (int j = 0; j < ndim; j++) diagTransform[i * ndim + j] = std::sqrt(cov[i * ndim + i]) * V[i * ndim + j];
+    for (int i = 0; i < ndim; i++) {
+      if (lam[i] < 0) {
+        std::cout << "user_gaussian_prop[" + label + "]: Warning. Negative covariance eigenvalue[" << i << "]=" << lam[i] << " set to zero." << std::endl;
+        lam[i] = 0;
+      }
+      sigmas[i] = std::sqrt(lam[i]);
+    }
+    have_dist = true;
+  }
+  bool check_update(const state& s, chain* caller) {   // .cc:406-441
+    if (!check_update_registered) return false;
+    std::vector<double> randoms(nrand);
+    for (auto& x : randoms) x = caller->getPRNG()->Next();
+    std::vector<double> covarvec;
+    const double beta = caller->invTemp();
+    if (!user_check_update(user_parent_object, user_instance_object, s, beta, randoms, covarvec)) return false;
+    reset_dist(covarvec);
+    return true;
+  }
+
+ public:
+  user_gaussian_prop(const stateSpace& sp, const std::vector<double>& covarvec = std::vector<double>(), int nrand = 0, const std::string label = "",
+                     void* user_parent_object = nullptr, void* (*new_user_instance_object_function)(void* object, int id) = nullptr)
+      : proposal_distribution(user_parent_object, new_user_instance_object_function), ndim(sp.size()), label(label), user_check_update(nullptr),
+        check_update_registered(false), user_checkpoint(nullptr), user_restart(nullptr), checkpoint_restart_registered(false),
+        user_accept(nullptr), user_reject(nullptr), accept_reject_registered(false), nrand(nrand), have_dist(false), isverbose(false), domainSpace(sp) {
+    reset_dist(covarvec);
+  }
+  user_gaussian_prop(void* user_parent_object, check_update_prototype function, const stateSpace& sp, const std::vector<double>& covarvec = std::vector<double>(),
+                     int nrand = 0, const std::string label = "", void* (*new_user_instance_object_function)(void* object, int id) = nullptr)
+      : user_gaussian_prop(sp, covarvec, nrand, label, user_parent_object, new_user_instance_object_function) { register_check_update(function); }
+  user_gaussian_prop* clone() const override {   // .cc:278-287: a clone asks the parent object for its own instance object
+    user_gaussian_prop* c = new user_gaussian_prop(*this);
+    c->id = idcount()++;
+    c->set_instance();
+    return c;
+  }
+  std::string get_label() const { return label; }
+  void verbose(bool set_to = false) { isverbose = set_to; }
+  void register_check_update(check_update_prototype function) { user_check_update = function; check_update_registered = true; }
+  void register_checkpoint_restart(checkpoint_restart_prototype checkpointfn, checkpoint_restart_prototype restartfn) {
+    user_checkpoint = checkpointfn; user_restart = restartfn; checkpoint_restart_registered = true;
+  }
+  void register_accept_reject(accept_reject_prototype acceptfn, accept_reject_prototype rejectfn) {
+    user_accept = acceptfn; user_reject = rejectfn; accept_reject_registered = true;
+  }
+  state draw(state& s, chain* caller) override {   // .cc:289-338
+    if (idx_map.empty()) idx_map = s.projection_indices_by_name(&domainSpace);
+    std::vector<double> sparams(domainSpace.size(), 0.0);
+    for (int i = 0; i < ndim; i++) if (idx_map[i] >= 0) sparams[i] = s.get_param(idx_map[i]);
+    state ss = state(&domainSpace, sparams);
+    last_type = check_update(ss, caller);
+    Random& rng = *caller->getPRNG();
+    std::vector<double> z(ndim), vec(ndim, 0.0);
+    for (int i = 0; i < ndim; i++) z[i] = detail::normal_from(rng) * sigmas[i];
+    for (int i = 0; i < ndim; i++) { double a = 0; for (int j = 0; j < ndim; j++) a += diagTransform[i * ndim + j] * z[j]; vec[i] = a; }
+    state newstate = s.scalar_mult(0);
+    for (int i = 0; i < ndim; i++) if (idx_map[i] >= 0) newstate.set_param(idx_map[i], vec[i]);
+    log_hastings = 0;
+    return s.add(newstate);
+  }
+  std::string show() override { return "StepByUserCovar[" + label + "]"; }
+  void accept() override { if (accept_reject_registered) user_accept(user_parent_object, user_instance_object); accept_count++; }
+  void reject() override { if (accept_reject_registered) user_reject(user_parent_object, user_instance_object); reject_count++; }
+  void checkpoint(std::string path) override {   // .cc:443-458 (the covariance vector; the user's own data through its callback)
+    std::ostringstream ss;
+    ss << path << "user_gaussian_proposal=" << id << ".cp/";
+    mkdir(ss.str().c_str(), 0777);
+    std::ofstream os((ss.str() + "core_data.cp").c_str(), std::ios::binary);
+    const size_t n = covar_vec.size();
+    os.write((const char*)&n, sizeof n);
+    os.write((const char*)covar_vec.data(), (std::streamsize)(n * 8));
+    if (checkpoint_restart_registered) user_checkpoint(user_parent_object, user_instance_object, ss.str());
+  }
+  void restart(std::string path) override {
+    std::ostringstream ss;
+    ss << path << "user_gaussian_proposal=" << id << ".cp/";
+    std::ifstream is((ss.str() + "core_data.cp").c_str(), std::ios::binary);
+    size_t n = 0;
+    is.read((char*)&n, sizeof n);
+    std::vector<double> cv(n);
+    is.read((char*)cv.data(), (std::streamsize)(n * 8));
+    if (is) reset_dist(cv);
+    if (checkpoint_restart_registered) user_restart(user_parent_object, user_instance_object, ss.str());
+  }
+  // without a callback the step is one fixed Gaussian: the device can draw it (factor embedded in the chain's space by
+  // parameter names; rows / columns of dimensions outside the sub-space stay zero)
+  bool device_describe_in(const stateSpace* full, int dim, int& kind, std::vector<double>& f, double& odf) const {
+    if (check_update_registered || !full) return false;
+    std::vector<int> map;
+    for (int i = 0; i < ndim; i++) map.push_back(full->get_index(domainSpace.get_name(i)));
+    kind = PTM_PROP_DENSE;
+    f.assign((size_t)dim * dim, 0.0);
+    for (int i = 0; i < ndim; i++)
+      for (int j = 0; j < ndim; j++)
+        if (map[i] >= 0 && map[j] >= 0) f[(size_t)map[i] * dim + map[j]] = diagTransform[i * ndim + j] * sigmas[j];
+    odf = 0;
+    return true;
+  }
+};
+
+// proposal_distribution_set (proposal_distribution.hh:306-349, .cc:37-166): draws member i with probability share_i; shares may
+// adapt to the members' acceptance (adapt_rate) and change with the chain's temperature (Tpow, hot_shares).
+// On the device: members that are all gaussian_props and scalar multiples of the first one (the sampler's default Gaussian
+// recipe, ptmcmc.cc:117-139, is exactly that) -- the rung keeps ONE factor and a table of scales; anything else is drawn here.
+class proposal_distribution_set : public proposal_distribution {
+  int Nsize;
+  std::vector<proposal_distribution*> proposals;
+  std::vector<double> shares, bin_max;
+  double adapt_rate;
+  std::vector<bool> last_accepted;
+  int adapt_count, adapt_every, last_dist;
+  bool own_pointers;
+  double Tpow;
+  std::vector<double> hot_shares;
+  void reset_bins() {   // .cc:37-59
+    double Tfac = 0;
+    if (Tpow > 0) {
+      if (!ch) std::cout << "proposal_distribution_set::reset_bins(): Thermal scaling requires that chain must be set for proposal." << std::endl;
+      else Tfac = 1 - std::pow(ch->invTemp(), Tpow);
+    }
+    double sum = 0;
+    for (int i = 0; i < Nsize; i++) sum += shares[i];
+    double last = 0;
+    for (int i = 0; i < Nsize; i++) {
+      shares[i] /= sum;
+      bin_max[i] = last + shares[i];
+      if (Tpow > 0) bin_max[i] += (hot_shares[i] - shares[i]) * Tfac;
+      last = bin_max[i];
+    }
+    for (auto& bin : bin_max) bin /= bin_max.back();
+  }
+
+ public:
+  // takes the pointers (as the reference does with take_pointers = true, its default); clone() deep-copies the members
+  proposal_distribution_set(const std::vector<proposal_distribution*>& props, const std::vector<double>& shares_, double adapt_rate = 0, double Tpow = 0,
+                            std::vector<double> hot_shares_ = std::vector<double>(), bool take_pointers = true)
+      : shares(shares_), adapt_rate(adapt_rate), own_pointers(take_pointers), Tpow(Tpow), hot_shares(hot_shares_) {
+    if (props.size() != shares.size() || props.empty()) { std::cout << "proposal_distribution_set(constructor): Array sizes mismatched.\n"; exit(1); }
+    Nsize = shares.size();
+    if (Tpow > 0) {
+      double sum = 0;
+      for (size_t i = 0; i < hot_shares.size(); i++) sum += hot_shares[i];
+      if ((int)hot_shares.size() != Nsize || sum <= 0) { std::cout << "proposal_distirubtion_set::With Tpow>0 need to provide hot_shares with sum>0" << std::endl; hot_shares = shares; }
+      else for (int i = 0; i < Nsize; i++) hot_shares[i] /= sum;
+    }
+    bin_max.resize(Nsize);
+    reset_bins();
+    for (int i = 0; i < Nsize; i++) proposals.push_back(props[i]);
+    last_type = 0; last_dist = 0;
+    last_accepted.resize(Nsize, true);
+    adapt_count = 0;
+    adapt_every = 10 * Nsize;
+  }
+  ~proposal_distribution_set() { if (own_pointers) for (auto p : proposals) delete p; }
+  proposal_distribution_set(const proposal_distribution_set&) = delete;
+  proposal_distribution_set* clone() const override {   // .cc:28-35
+    std::vector<proposal_distribution*> copies;
+    for (auto p : proposals) copies.push_back(p->clone());
+    proposal_distribution_set* c = new proposal_distribution_set(copies, shares, adapt_rate, Tpow, hot_shares, true);
+    c->last_accepted = last_accepted; c->adapt_count = adapt_count;
+    return c;
+  }
+  void set_chain(chain* c) override { ch = c; for (int i = 0; i < Nsize; i++) proposals[i]->set_chain(c); reset_bins(); }
+  bool support_mixing() override { for (auto p : proposals) if (p->support_mixing()) return true; return false; }
+  // .cc:99-129: one uniform picks the first READY member with x < bin_max; type = member + 10 * (member's type)
+  state draw(state& s, chain* caller) override {
+    Random& rng = *caller->getPRNG();
+    int count = 0;
+    while (true) {
+      double x = 0;
+      if (Nsize > 1) x = rng.Next();
+      for (int i = 0; i < Nsize; i++) {
+        if (proposals[i]->is_ready() && x < bin_max[i]) {
+          state out = proposals[i]->draw(s, caller);
+          log_hastings = proposals[i]->log_hastings_ratio();
+          last_type = i + 10 * proposals[i]->type();
+          last_dist = i;
+          return out;
+        }
+      }
+      if (++count > 100) { std::cout << "propsal_distribution_set::draw: Hmmm... Seems that (nearly?) none of the proposals are ready;\n"; exit(1); }
+    }
+  }
+  void accept() override {   // .cc:131-148
+    proposal_distribution::accept();
+    if (adapt_rate == 0) { proposals[last_dist]->accept(); return; }
+    if (last_accepted[last_dist]) shares[last_dist] *= 1 - adapt_rate * 0.25;
+    last_accepted[last_dist] = true;
+    if (++adapt_count >= adapt_every) reset_bins();
+    proposals[last_dist]->accept();
+  }
+  void reject() override {   // .cc:150-166
+    proposal_distribution::reject();
+    if (adapt_rate == 0) { proposals[last_dist]->reject(); return; }
+    if (!last_accepted[last_dist]) shares[last_dist] *= 1 - adapt_rate * 0.25;
+    last_accepted[last_dist] = false;
+    if (++adapt_count >= adapt_every) reset_bins();
+    proposals[last_dist]->reject();
+  }
+  void checkpoint(std::string path) override { for (auto p : proposals) p->checkpoint(path); }
+  void restart(std::string path) override { for (auto p : proposals) p->restart(path); }
+  std::string show() override {
+    std::ostringstream ss;
+    ss << "ChooseFrom(";
+    double last = 0;
+    for (int i = 0; i < Nsize; i++) { ss << "  " << (bin_max[i] - last) * 100. << "% : " << proposals[i]->show() << "\n"; last = bin_max[i]; }
+    ss << ")\n";
+    return ss.str();
+  }
+  std::string report(int style = 0) override {   // .cc:212-240
+    std::ostringstream ss;
+    if (style == 0) {
+      ss << proposal_distribution::report(style) << ":[" << proposals[0]->report(style);
+      for (int i = 1; i < Nsize; i++) ss << "," << proposals[i]->report(style);
+      ss << "]";
+    } else if (style == 1) {
+      ss << "shares=[" << bin_max[0];
+      for (int i = 1; i < Nsize; i++) ss << "," << bin_max[i] - bin_max[i - 1];
+      ss << "]";
+    }
+    return ss.str();
+  }
+  std::vector<proposal_distribution*> members() const { return proposals; }
+  bool device_describe(int dim, int& kind, std::vector<double>& f, double& odf) const override {
+    if (adapt_rate != 0 || Tpow > 0) return false;   // shares that move are the host's business
+    if (!proposals[0]->device_describe(dim, kind, f, odf)) return false;
+    std::vector<double> cum, sc, od;
+    if (!device_describe_mixture(dim, cum, sc, od)) return false;
+    odf = 0;   // the members' oneDfracs live in the mixture table
+    return true;
+  }
+  bool device_describe_mixture(int dim, std::vector<double>& cum, std::vector<double>& scales, std::vector<double>& odfs) const override {
+    if (adapt_rate != 0 || Tpow > 0) return false;
+    int kind0; double odf0; std::vector<double> f0;
+    if (!proposals[0]->device_describe(dim, kind0, f0, odf0)) return false;
+    cum.clear(); scales.clear(); odfs.clear();
+    for (size_t i = 0; i < proposals.size(); i++) {
+      int kind; double odf; std::vector<double> f;
+      if (!proposals[i]->device_describe(dim, kind, f, odf) || kind != kind0 || f.size() != f0.size()) return false;
+      double sc = 0;
+      for (size_t k = 0; k < f.size(); k++) if (f0[k] != 0) { sc = f[k] / f0[k]; break; }
+      for (size_t k = 0; k < f.size(); k++)
+        if (std::fabs(f[k] - sc * f0[k]) > 1e-12 * (std::fabs(f[k]) + std::fabs(sc * f0[k])) + 1e-300) return false;   // not a multiple
+      cum.push_back(i + 1 == proposals.size() ? 1.0 : bin_max[i]);
+      scales.push_back(sc);
+      odfs.push_back(odf);
+    }
+    return true;
+  }
+};
+
+// differential_evolution (proposal_distribution.hh:351-414, .cc:476-801; ter Braak & Vrugt 2008): jumps along the difference of
+// two states drawn from the chain's own history, optionally the "snooker" variant with its non-trivial Hastings ratio.  Needs
+// the chain history -- on this build the ladder keeps a host mirror of what MH_chain::add_state saves when a host-side proposal
+// is in use (parallel_tempering_chains::sync_history).
+class differential_evolution : public proposal_distribution {
+  bool have_chain;
+  int dim;
+  double gamma_one_frac, reduce_gamma_fac, b_small, ignore_frac, unlikely_alpha, snooker;
+  bool do_support_mixing;
+  double temperature_mixing_factor;
+  int get_min_start_size() { return dim * 10; }
+  int get_min_cut_size() { return dim * 100; }
+
+  int draw_i_from_chain(chain* caller, chain* c) {   // .cc:742-778
+    Random& rng = *caller->getPRNG();
+    if (!is_ready()) { std::cout << "differential_evolution:draw_i_from_chain: Chain is not ready. Verify readiness with is_ready() before drawing.\n"; exit(1); }
+    const int size = c->size();
+    int start = 0;
+    const int mins = get_min_start_size(), minc = get_min_cut_size();
+    if ((size - minc) * (1 - ignore_frac) > mins) start = (int)((size - minc) * ignore_frac);
+    const double lpost0 = ch->getMAPlpost() - ch->getDim();
+    double alpha = unlikely_alpha;
+    while (true) {
+      double xrnd = rng.Next();
+      const int index = (int)(start + (size - start) * xrnd);
+      const double lpost = ch->getLogPost(index, true);
+      if (alpha > 0 && lpost0 > lpost) {
+        const double p = std::exp(alpha * (lpost - lpost0));
+        xrnd = rng.Next();
+        if (xrnd < p) return index;
+        alpha *= 0.9;
+      } else return index;
+    }
+  }
+  state draw_from_chain(chain* caller) {   // .cc:593-740
+    Random& rng = *caller->getPRNG();
+    if (!is_ready()) { std::cout << "differential_evolution:draw_from_chain: Chain is not ready. Verify readiness with is_ready() before drawing.\n"; exit(1); }
+    const int nchains = ch->multiplicity();
+    if (nchains == 1 || !do_support_mixing) {
+      const int index = draw_i_from_chain(caller, ch);
+      return ch->getState(index, true);
+    }
+    // mixing of history from the parallel chains: weight chain i by an estimate of how much of its typical region matters at
+    // the caller's temperature (.cc:607-700)
+    std::vector<double> k(nchains + 1);
+    const int Nmean = 10, Nmedian = 10;
+    const double pmix = temperature_mixing_factor;
+    std::vector<double> l0(Nmean);
+    const double beta = caller->invTemp();
+    k[0] = 0;
+    int ithis = 0;
+    chain* ci = nullptr;
+    for (int i = 0; i < nchains; i++) {
+      ci = ch->subchain(i);
+      double l0max = -1e100, l0min = 1e100;
+      for (int j = 0, guard = 0; j < Nmean && guard < 10000; j++, guard++) {
+        const int index = draw_i_from_chain(caller, ci);
+        const double dl = caller->getLogLike(index, true);
+        if (std::isfinite(dl)) { if (dl > l0max) l0max = dl; if (dl < l0min) l0min = dl; l0[j] = dl; }
+        else j--;
+      }
+      const double alpha = ci->invTemp();
+      double amb = -(alpha - beta);
+      if (amb == 0) ithis = i;
+      double sum = 0;
+      const double l0scale = amb < 0 ? l0min : l0max;
+      for (int ii = 0; ii < Nmean; ii++) sum += std::exp((l0[ii] - l0scale) * amb);
+      const double ll0 = std::log(sum / Nmean) + l0scale * amb;
+      std::vector<double> l(Nmedian);
+      for (int j = 0; j < Nmedian; j++) { const int index = draw_i_from_chain(caller, ci); l[j] = ci->getLogLike(index, true); }
+      std::sort(l.begin(), l.end());
+      const double ll = l[Nmedian / 2];
+      double lk = -(ll0 - ll * amb);
+      lk /= pmix;
+      if (lk > 0) lk = 0;
+      k[i + 1] = k[i] + std::exp(lk);
+    }
+    int ipick = ithis;
+    const double xrnd = rng.Next() * k[nchains];
+    for (int i = 0; i < nchains; i++) if (xrnd <= k[i + 1]) { ipick = i; break; }
+    ci = ch->subchain(ipick);
+    const int index = draw_i_from_chain(caller, ci);
+    return ci->getState(index, true);
+  }
+  state draw_standard(state& s, chain* caller) {   // .cc:488-532, ter Braak 08 eq. 2
+    Random& rng = *caller->getPRNG();
+    double gamma = 1.68 / std::sqrt((double)dim) / reduce_gamma_fac;
+    const double xgamma = rng.Next();
+    if (xgamma < gamma_one_frac) gamma = 1;
+    state s1 = draw_from_chain(caller);
+    state s2 = draw_from_chain(caller);
+    std::vector<double> e(dim);
+    for (int i = 0; i < dim; i++) e[i] = detail::normal_from(rng);   // drawn as in the reference; its small jump is then
+    state prop = s;                                                  // DISCARDED there (prop.add(...) result unused, .cc:523)
+    prop = prop.add(s1.scalar_mult(gamma));
+    prop = prop.add(s2.scalar_mult(-gamma));
+    log_hastings = 0;
+    last_type = 0;
+    return prop;
+  }
+  state draw_snooker(state& s, chain* caller) {   // .cc:534-591, ter Braak 08 eq. 3-4
+    Random& rng = *caller->getPRNG();
+    const double xgamma = rng.Next();
+    const double gamma = (1.2 + xgamma) / reduce_gamma_fac;
+    double smznorm2 = 0;
+    state minusz = s, smz = s;
+    int isafe = 0;
+    while (smznorm2 == 0) {
+      state z = draw_from_chain(caller);
+      minusz = z.scalar_mult(-1);
+      smz = s.add(minusz);
+      smznorm2 = smz.innerprod(smz);
+      if (++isafe > 1000) { std::cout << "differential_evolution::draw_snooker: We seem to be stuck in an infinite loop.  Bailing out!" << std::endl; exit(1); }
+    }
+    state s1 = draw_from_chain(caller);
+    state s2 = draw_from_chain(caller);
+    state ds12 = s1.scalar_mult(gamma);
+    ds12 = ds12.add(s2.scalar_mult(-gamma));
+    state prop = s;
+    prop = prop.add(smz.scalar_mult(ds12.innerprod(smz) / smznorm2));
+    state pmz = prop.add(minusz);
+    log_hastings = (std::log(pmz.innerprod(pmz)) - std::log(smznorm2)) * (dim - 1) / 2.0;
+    last_type = 1;
+    return prop;
+  }
+
+ public:
+  differential_evolution(double snooker = 0.0, double gamma_one_frac = 0.1, double b_small = 0.0001, double ignore_frac = 0.3, double unlikely_alpha = 0)
+      : have_chain(false), dim(0), gamma_one_frac(gamma_one_frac), reduce_gamma_fac(1), b_small(b_small), ignore_frac(ignore_frac),
+        unlikely_alpha(unlikely_alpha), snooker(snooker), do_support_mixing(false), temperature_mixing_factor(1) {}
+  void reduce_gamma(double factor) { reduce_gamma_fac = factor; }
+  void mix_temperatures_more(double factor) { temperature_mixing_factor = factor; }
+  void set_chain(chain* c) override { ch = c; have_chain = true; dim = ch->getDim(); }
+  bool is_ready() override { return have_chain && ch->size() >= get_min_start_size(); }
+  state draw(state& s, chain* caller) override {   // .cc:789-801
+    Random& rng = *caller->getPRNG();
+    const double x = rng.Next();
+    if (snooker > x) return draw_snooker(s, caller);
+    return draw_standard(s, caller);
+  }
+  differential_evolution* clone() const override { return new differential_evolution(*this); }
+  std::string show() override {
+    std::ostringstream ss;
+    ss << "DifferentialEvolution(snooker=" << snooker << ", gamma_one_frac=" << gamma_one_frac << ", b_small=" << b_small << ", ignore_frac=" << ignore_frac << ")\n";
+    return ss.str();
+  }
+  bool support_mixing(bool do_it) { do_support_mixing = do_it; return do_it; }
+  bool support_mixing() override { return do_support_mixing; }
+};
+
 // A small persistent worker pool for the likelihood batches: starting and joining threads for every batch costs more than
 // a cheap plug-in's whole batch.  run(n, chunk, f) calls f(k0, k1) over [0, n) in chunks, on the workers and the caller.
 class eval_pool {
@@ -224,8 +1167,7 @@ class eval_pool {
       job(k0, k0 + chunk < n ? k0 + chunk : n);
     }
   }
-  void loop() {
-    int seen = 0;
+  void loop(int seen) {   // `seen`: the generation current when this worker was created (resize() holds the mutex)
     for (;;) {
       {
         std::unique_lock<std::mutex> lk(m);
@@ -247,7 +1189,11 @@ class eval_pool {
   }
   int size() const { return (int)workers.size(); }
   void resize(int nworkers) {
-    while ((int)workers.size() < nworkers) workers.emplace_back([this] { loop(); });
+    std::lock_guard<std::mutex> lk(m);   // a new worker starts from the current generation: it waits for the NEXT run
+    while ((int)workers.size() < nworkers) {
+      const int g = generation;
+      workers.emplace_back([this, g] { loop(g); });
+    }
   }
   void run(int n_, int chunk_, const std::function<void(int, int)>& f) {
     {
@@ -262,7 +1208,7 @@ class eval_pool {
 };
 
 // ---- bayesian.hh: the likelihood plug-in -----------------------------------------------------------------------------
-class bayes_likelihood : public probability_function {  // bayesian.hh:307-581 (minimal interface)
+class bayes_likelihood : public probability_function, public Optioned {  // bayesian.hh:307-581 (minimal interface)
  protected:
   stateSpace nativeSpace;
   std::shared_ptr<const sampleable_probability_function> nativePrior;
@@ -270,15 +1216,40 @@ class bayes_likelihood : public probability_function {  // bayesian.hh:307-581 (
   void* user_object;
   bool evaluate_log_registered;
   double best_post;
+  state best;
+  std::mutex best_mutex;
+  std::vector<double> likelyScales;
+  bool have_scales;
+  std::vector<proposal_distribution*> proposals;   // likelihood-associated proposals (bayesian.hh:784-790), owned
+  std::vector<double> prop_shares;
 
  public:
   bool check_posterior;
   bayes_likelihood() : probability_function(nullptr), user_evaluate_log(nullptr), user_object(nullptr),
-                       evaluate_log_registered(false), best_post(-INFINITY), check_posterior(true) {}
+                       evaluate_log_registered(false), best_post(-INFINITY), have_scales(false), check_posterior(true) {}
+  ~bayes_likelihood() { for (auto p : proposals) delete p; }
+  bayes_likelihood(const bayes_likelihood&) = delete;
+  void addOptions(Options& opt, const std::string& prefix = "") override { Optioned::addOptions(opt, prefix); }
+  virtual void setup() {}   // the minimal interface has nothing to set up after basic_setup (bayesian.hh:394-405 is for data + signal)
+  virtual void reset() {    // bayesian.hh:407-412
+    best_post = -INFINITY;
+    if (space) best = state(space, space->size()).scalar_mult(0);
+  }
+  virtual state bestState() { return best; }
+  virtual double bestPost() { return best_post; }
+  virtual void getScales(std::vector<double>& scales) {   // bayesian.hh:384-391
+    if (have_scales) scales = likelyScales;
+    else getObjectPrior()->getScales(scales);
+  }
+  void addProposal(const proposal_distribution* proposal, double share = 1) { proposals.push_back(proposal->clone()); prop_shares.push_back(share); }
+  std::vector<proposal_distribution*> get_proposals() const { return proposals; }
+  std::vector<double> get_prop_shares() const { return prop_shares; }
   void basic_setup(const stateSpace* sp, sampleable_probability_function* prior) {  // bayesian.hh:345-358
     nativeSpace = *sp;
     nativePrior.reset(prior);
     space = &nativeSpace;
+    best = state(space, space->size());
+    reset();
   }
   void basic_setup(const stateSpace* sp, const std::vector<std::string>& types, const std::vector<double>& centers,
                    const std::vector<double>& priorScales) {  // bayesian.hh:360-381
@@ -306,11 +1277,23 @@ class bayes_likelihood : public probability_function {  // bayesian.hh:307-581 (
     return nativePrior;
   }
   const stateSpace* getObjectStateSpace() const { return &nativeSpace; }
-  // host evaluation of the plug-in (bayesian.hh:553-581; the prior part of the posterior check happens on the device)
+  // host evaluation of the plug-in (bayesian.hh:553-581), with the reference's best-posterior bookkeeping (quirk Q8: the
+  // prior is evaluated again here, on the host, and the best log-posterior seen so far and its state are kept under a lock;
+  // a posterior that is not finite turns the likelihood into -inf -- the reference also prints a warning for every such
+  // state, this build only for NaN / +inf: a -inf likelihood outside the support is ordinary)
   double evaluate_log(state& s) override {
     if (!evaluate_log_registered) { std::cout << "bayes_component::panic!\nNo evaluate_log function is registered" << std::endl; exit(1); }
     double result = (*user_evaluate_log)(user_object, s);
-    if (check_posterior && !std::isfinite(result) && !(result < 0)) result = -INFINITY;  // NaN/+inf -> -inf (bayesian.hh:569-575)
+    if (check_posterior) {
+      const double lprior = nativePrior ? nativePrior->evaluate_log(s) : 0.0;
+      const double post = result + lprior;
+      std::lock_guard<std::mutex> lk(best_mutex);
+      if (!(post <= best_post)) { best_post = post; best = s; }
+      if (!std::isfinite(post)) {
+        if (!(post < 0)) std::cout << "Logpost is NAN!\n  params=" << s.get_string() << "\n  like=" << result << "  post=" << post << std::endl;
+        result = -INFINITY;
+      }
+    }
     return result;
   }
   // device-resident targets override this and return true after describing themselves to the engine
@@ -323,7 +1306,7 @@ class bayes_likelihood : public probability_function {  // bayesian.hh:307-581 (
     bayes_likelihood* l = (bayes_likelihood*)self;
     auto work = [l, X, dim, out](int k0, int k1) {
       for (int k = k0; k < k1; k++) {
-        state s(l->getObjectStateSpace(), std::valarray<double>(X + (size_t)k * dim, dim));
+        state s = state::from_engine(l->getObjectStateSpace(), X + (size_t)k * dim, dim);   // (enforced on the device already)
         out[k] = l->evaluate_log(s);
       }
     };
@@ -374,149 +1357,6 @@ class gaussian_likelihood : public bayes_likelihood {
   }
 };
 
-// ---- proposal_distribution.hh ---------------------------------------------------------------------------------------
-class proposal_distribution {  // proposal_distribution.hh:38-88 (what the device path needs of it)
- public:
-  virtual ~proposal_distribution() {}
-  virtual proposal_distribution* clone() const = 0;
-  virtual std::string show() { return "UnspecifiedProposal()"; }
-  virtual bool device_describe(int dim, int& kind, std::vector<double>& factor, double& oneDfrac) const { return false; }
-  // a set of Gaussian members that are scalar multiples of one factor: cumulative shares, scales, oneDfracs (else false)
-  virtual bool device_describe_mixture(int dim, std::vector<double>& cum, std::vector<double>& scales, std::vector<double>& odfs) const { return false; }
-};
-
-class gaussian_prop : public proposal_distribution {  // proposal_distribution.hh:145-227
-  bool identity_trans;
-  std::vector<double> factor;  // DIAG: sigmas; else dense D x D row-major V*diag(sqrt(lambda))
-  int ndim;
-  double oneDfrac;
-
-  // symmetric eigen-decomposition by cyclic Jacobi (the reference uses Eigen::SelfAdjointEigenSolver, hh:173-176);
-  // eigenvalues ascending, factor = V * diag(sqrt(lambda)) so that offset = factor * z as in hh:207-213
-  static void eigen_factor(std::vector<double> A, int n, std::vector<double>& F) {
-    std::vector<double> V(n * n, 0.0);
-    for (int i = 0; i < n; i++) V[i * n + i] = 1;
-    for (int sweep = 0; sweep < 100; sweep++) {
-      double off = 0;
-      for (int p = 0; p < n; p++) for (int q = p + 1; q < n; q++) off += A[p * n + q] * A[p * n + q];
-      if (off < 1e-300) break;
-      for (int p = 0; p < n; p++)
-        for (int q = p + 1; q < n; q++) {
-          if (std::fabs(A[p * n + q]) < 1e-300) continue;
-          double theta = (A[q * n + q] - A[p * n + p]) / (2 * A[p * n + q]);
-          double t = (theta >= 0 ? 1 : -1) / (std::fabs(theta) + std::sqrt(theta * theta + 1));
-          double c = 1 / std::sqrt(t * t + 1), s = t * c;
-          for (int k = 0; k < n; k++) { double a = A[k * n + p], b = A[k * n + q]; A[k * n + p] = c * a - s * b; A[k * n + q] = s * a + c * b; }
-          for (int k = 0; k < n; k++) { double a = A[p * n + k], b = A[q * n + k]; A[p * n + k] = c * a - s * b; A[q * n + k] = s * a + c * b; }
-          for (int k = 0; k < n; k++) { double a = V[k * n + p], b = V[k * n + q]; V[k * n + p] = c * a - s * b; V[k * n + q] = s * a + c * b; }
-        }
-    }
-    std::vector<int> order(n);
-    for (int i = 0; i < n; i++) order[i] = i;
-    for (int i = 0; i < n; i++) for (int j = i + 1; j < n; j++) if (A[order[j] * n + order[j]] < A[order[i] * n + order[i]]) std::swap(order[i], order[j]);
-    F.assign(n * n, 0.0);
-    for (int j = 0; j < n; j++) {
-      double lam = A[order[j] * n + order[j]];
-      double sg = std::sqrt(lam > 0 ? lam : 0.0);
-      for (int i = 0; i < n; i++) F[i * n + j] = V[i * n + order[j]] * sg;
-    }
-  }
-
- public:
-  gaussian_prop(const std::valarray<double>& sigmas, double oneDfrac = 0.0, bool scaleWithTemp = false)
-      : identity_trans(true), factor(std::begin(sigmas), std::end(sigmas)), ndim(sigmas.size()), oneDfrac(oneDfrac) { check(); }
-  gaussian_prop(const std::vector<double>& sigmas, double oneDfrac = 0.0, bool scaleWithTemp = false)
-      : identity_trans(true), factor(sigmas), ndim(sigmas.size()), oneDfrac(oneDfrac) { check(); }
-  // covariance, row-major ndim x ndim (the reference takes an Eigen::MatrixXd, hh:165)
-  gaussian_prop(const std::vector<double>& covar, int ndim, double oneDfrac = 0.0, bool scaleWithTemp = false)
-      : identity_trans(false), ndim(ndim), oneDfrac(oneDfrac) {
-    if ((int)covar.size() != ndim * ndim) { std::cout << "gaussian_prop(constructor II): covar must be a square matrix!" << std::endl; exit(-1); }
-    eigen_factor(covar, ndim, factor);
-    check();
-  }
-  void check() const {
-    if (oneDfrac < 0 || oneDfrac > 1) { std::cout << "gaussian_prop(constructor): We require 0<=oneDfrac<=1. " << std::endl; exit(1); }
-  }
-  gaussian_prop* clone() const override { return new gaussian_prop(*this); }
-  std::string show() override {
-    std::ostringstream ss;
-    ss << "StepBy" << (identity_trans ? "" : "Covar") << "[dim=" << ndim << "](1Dfrac=" << oneDfrac << ")";
-    return ss.str();
-  }
-  bool device_describe(int dim, int& kind, std::vector<double>& f, double& odf) const override {
-    if (dim != ndim) { std::cout << "gaussian_prop: dimension mismatch with the chain (" << ndim << " vs " << dim << ")" << std::endl; exit(1); }
-    kind = identity_trans ? PTM_PROP_DIAG : PTM_PROP_DENSE;
-    f = factor;
-    odf = oneDfrac;
-    return true;
-  }
-};
-
-// proposal_distribution_set (proposal_distribution.hh:90-143, .cc:99-129): draws a member with probability share_i.
-// On the device: members must be gaussian_props that are scalar multiples of the first one (the sampler's default
-// Gaussian recipe, ptmcmc.cc:117-139, is exactly that) -- the rung keeps ONE factor and a table of scales.
-class proposal_distribution_set : public proposal_distribution {
-  std::vector<proposal_distribution*> proposals;   // owned
-  std::vector<double> shares;
-
- public:
-  proposal_distribution_set(const std::vector<proposal_distribution*>& props, const std::vector<double>& shares_) : shares(shares_) {
-    if (props.size() != shares.size() || props.empty()) { std::cout << "proposal_distribution_set: need one share per proposal" << std::endl; exit(1); }
-    for (auto p : props) proposals.push_back(p->clone());
-  }
-  ~proposal_distribution_set() { for (auto p : proposals) delete p; }
-  proposal_distribution* clone() const override { return new proposal_distribution_set(proposals, shares); }
-  std::string show() override {
-    std::ostringstream ss;
-    ss << "ProposalSet(";
-    for (size_t i = 0; i < proposals.size(); i++) ss << shares[i] << " : " << proposals[i]->show() << (i + 1 < proposals.size() ? ", " : ")");
-    return ss.str();
-  }
-  bool device_describe(int dim, int& kind, std::vector<double>& f, double& odf) const override {
-    if (!proposals[0]->device_describe(dim, kind, f, odf)) return false;
-    odf = 0;   // the members' oneDfracs live in the mixture table
-    return true;
-  }
-  bool device_describe_mixture(int dim, std::vector<double>& cum, std::vector<double>& scales, std::vector<double>& odfs) const override {
-    int kind0; double odf0; std::vector<double> f0;
-    if (!proposals[0]->device_describe(dim, kind0, f0, odf0)) return false;
-    double sum = 0;
-    for (double sh : shares) sum += sh;
-    double run = 0;
-    cum.clear(); scales.clear(); odfs.clear();
-    for (size_t i = 0; i < proposals.size(); i++) {
-      int kind; double odf; std::vector<double> f;
-      if (!proposals[i]->device_describe(dim, kind, f, odf) || kind != kind0 || f.size() != f0.size()) return false;
-      double sc = 0;
-      for (size_t k = 0; k < f.size(); k++) if (f0[k] != 0) { sc = f[k] / f0[k]; break; }
-      for (size_t k = 0; k < f.size(); k++)
-        if (std::fabs(f[k] - sc * f0[k]) > 1e-12 * (std::fabs(f[k]) + std::fabs(sc * f0[k])) + 1e-300) return false;   // not a multiple
-      run += shares[i] / sum;                                  // bin_max (proposal_distribution.cc reset_bins)
-      cum.push_back(i + 1 == proposals.size() ? 1.0 : run);
-      scales.push_back(sc);
-      odfs.push_back(odf);
-    }
-    return true;
-  }
-};
-
-// ---- chain.hh ----------------------------------------------------------------------------------------------------------
-class chain {  // chain.hh:34-141 (the part of the interface the driver uses)
- public:
-  virtual ~chain() {}
-  virtual void step() = 0;
-  virtual state getState(int elem = -1, bool raw_indexing = false) = 0;
-  virtual double getLogPost(int elem = -1, bool raw_indexing = false) = 0;
-  virtual double getLogLike(int elem = -1, bool raw_indexing = false) = 0;
-  virtual double invTemp() { return 1.0; }
-  virtual int multiplicity() { return 1; }
-  virtual chain* subchain(int index) { return this; }
-  virtual int getStep() = 0;
-  virtual double getMAPlpost() { return -1e200; }                    // chain.hh:116-117
-  virtual state getMAPstate() { return getState(); }
-  virtual std::string status() { return ""; }
-};
-
 class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:1163-1571
   const int Ntemps, add_every_N;
   const double Tmax, swap_rate, dpriormin;
@@ -558,23 +1398,142 @@ class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:
   std::vector<double> hb;
   std::vector<proposal_distribution*> props;
 
+  // ---- host-side proposals (anything set_proposal cannot describe to the device as a fixed Gaussian) --------------------
+  // The engine calls back once per sweep with the current states of every chain that moves (ptm_set_proposal_callback);
+  // each chain's own clone of the proposal draws for it, with the chain's view as `caller`.  A host MIRROR of what
+  // MH_chain::add_state saves (chain.cc:935-946) is kept for the proposals that read the chain history (differential
+  // evolution): all Ninit initial draws, then every saved row, pulled from the device's short history ring after each step.
+  bool host_mode = false, want_host = false;
+  int ring_rows = 0, ring_rungs = 0;   // the device history ring as the engine was created with it
+  uint64_t eng_seed = 0;
+  struct mirror_t {   // one chain's saved history, raw indexing as MH_chain::states / lposts / llikes (chain.hh:155-163)
+    std::vector<double> x, llike, lprior, beta;
+    std::vector<int32_t> meta;   // {Naccept, Ntries, type} per row
+    size_t rows() const { return llike.size(); }
+  };
+  std::vector<mirror_t> mirror;        // [i*W + w]
+  std::vector<int64_t> mirror_seen;    // device ring rows already copied (row numbers < this)
+  int Ninit_rows = 1;
+  std::vector<std::vector<double> > init_x;            // the extra initial draws of initialize(n > 1): [k][chain*dim]
+  std::vector<std::vector<double> > init_ll, init_lp;  // [k][chain]
+
   class rung_view : public chain {
     parallel_tempering_chains* p;
     int i, w;
+    std::shared_ptr<philox_random> rng;
 
    public:
-    rung_view(parallel_tempering_chains* p, int i, int w = 0) : p(p), i(i), w(w) {}
+    rung_view(parallel_tempering_chains* p, int i, int w = 0) : p(p), i(i), w(w), rng(new philox_random) {}
     void step() override { std::cout << "rung_view::step: step the ladder, not a rung" << std::endl; exit(1); }
     size_t at() const { return (size_t)i * p->W + w; }
-    state getState(int = -1, bool = false) override { p->refresh(); return state(p->sp, std::vector<double>(p->X.begin() + at() * p->dim, p->X.begin() + (at() + 1) * p->dim)); }
-    double getLogPost(int = -1, bool = false) override { p->refresh(); return p->lpost[at()]; }
-    double getLogLike(int = -1, bool = false) override { p->refresh(); return p->llike[at()]; }
+    // elem < 0 (or out of range): the current state; raw indexing: row `elem` of the saved history (host mirror, kept when
+    // host-side proposals are in use); nominal indexing: step `elem` -> row Ninit + elem / add_every_N (chain.cc:1041-1050)
+    bool hist_row(int elem, bool raw, size_t& row) {
+      if (!p->host_mode || elem < 0) return false;
+      const mirror_t& m = p->mirror[at()];
+      const long r = raw ? elem : p->Ninit_rows + elem / p->add_every_N;
+      if (r < 0 || (size_t)r >= m.rows()) return false;
+      row = (size_t)r;
+      return true;
+    }
+    state getState(int elem = -1, bool raw = false) override {
+      size_t r;
+      if (hist_row(elem, raw, r)) return state::from_engine(p->sp, p->mirror[at()].x.data() + r * p->dim, p->dim);
+      p->refresh();
+      return state::from_engine(p->sp, p->X.data() + at() * p->dim, p->dim);
+    }
+    double getLogPost(int elem = -1, bool raw = false) override {
+      size_t r;
+      if (hist_row(elem, raw, r)) { const mirror_t& m = p->mirror[at()]; const double t = m.beta[r] * m.llike[r]; return m.lprior[r] + t; }
+      p->refresh();
+      return p->lpost[at()];
+    }
+    double getLogLike(int elem = -1, bool raw = false) override {
+      size_t r;
+      if (hist_row(elem, raw, r)) return p->mirror[at()].llike[r];
+      p->refresh();
+      return p->llike[at()];
+    }
     double invTemp() override { return p->cur_beta(i, w); }
     int getStep() override { return p->nstep; }
+    int size() override { return p->host_mode ? (int)p->mirror[at()].rows() : p->nstep + 1; }
+    int getDim() override { return p->dim; }
+    int get_id() override { return (int)(w * p->Ntemps + i); }
+    std::shared_ptr<Random> getPRNG() override { return rng; }
+    void reseat(uint64_t seed, uint64_t step) { rng->reseat(seed, (uint32_t)((uint64_t)w * p->Ntemps + i), step); }
     double getMAPlpost() override { p->refresh_map(); return p->mlpost[at()]; }
-    state getMAPstate() override { p->refresh_map(); return state(p->sp, std::vector<double>(p->mX.begin() + at() * p->dim, p->mX.begin() + (at() + 1) * p->dim)); }
+    state getMAPstate() override { p->refresh_map(); return state::from_engine(p->sp, p->mX.data() + at() * p->dim, p->dim); }
   };
   std::vector<rung_view> views;
+  // one replica's ladder as a chain: what a proposal that mixes the parallel chains' histories is given (chain.cc:1376-1378)
+  class ladder_view : public chain {
+    parallel_tempering_chains* p;
+    int w;
+
+   public:
+    ladder_view(parallel_tempering_chains* p, int w) : p(p), w(w) {}
+    void step() override { std::cout << "ladder_view::step: step the ladder itself" << std::endl; exit(1); }
+    chain* cold() { return &p->views[(size_t)w * p->Ntemps]; }
+    state getState(int elem = -1, bool raw = false) override { return cold()->getState(elem, raw); }
+    double getLogPost(int elem = -1, bool raw = false) override { return cold()->getLogPost(elem, raw); }
+    double getLogLike(int elem = -1, bool raw = false) override { return cold()->getLogLike(elem, raw); }
+    int getStep() override { return p->nstep; }
+    int size() override { return cold()->size(); }
+    int getDim() override { return p->dim; }
+    int multiplicity() override { return p->Ntemps; }
+    chain* subchain(int index) override { return &p->views[(size_t)w * p->Ntemps + index]; }
+    double getMAPlpost() override { return cold()->getMAPlpost(); }
+    state getMAPstate() override { return cold()->getMAPstate(); }
+  };
+  std::vector<ladder_view> ladders;
+
+  // the engine's callbacks (ptm_propose_batch_fn / ptm_proposal_result_fn)
+  static void propose_trampoline(void* self, int n, int dim, const double* X_cur, const int32_t* rung, const int32_t* walker, uint64_t step,
+                                 double* X_prop, double* log_hastings, int32_t* type, int32_t* valid) {
+    parallel_tempering_chains* p = (parallel_tempering_chains*)self;
+    p->fresh = false;   // (the temperatures an evolving ladder shows its proposals are this step's)
+    for (int k = 0; k < n; k++) {
+      const size_t v = (size_t)walker[k] * p->Ntemps + rung[k];
+      rung_view& view = p->views[v];
+      view.reseat(p->eng_seed, step);
+      state s = state::from_engine(p->sp, X_cur + (size_t)k * dim, dim);
+      proposal_distribution* prop = p->props[v];
+      state out = prop->draw(s, &view);
+      for (int d = 0; d < dim; d++) X_prop[(size_t)k * dim + d] = out.get_param(d);
+      log_hastings[k] = prop->log_hastings_ratio();
+      type[k] = prop->type();
+      valid[k] = out.invalid() ? 0 : 1;
+    }
+  }
+  static void result_trampoline(void* self, int n, const int32_t* rung, const int32_t* walker, const int32_t* accepted) {
+    parallel_tempering_chains* p = (parallel_tempering_chains*)self;
+    for (int k = 0; k < n; k++) {
+      proposal_distribution* prop = p->props[(size_t)walker[k] * p->Ntemps + rung[k]];
+      if (accepted[k]) prop->accept(); else prop->reject();   // chain.cc:1009,1015
+    }
+  }
+  // append what the last step(s) saved to the host mirror (rows the ring has not lost yet: call after every step)
+  std::vector<double> rx, rl, rp, rb;
+  std::vector<int32_t> rmeta;
+  std::vector<int64_t> rnsize;
+  void sync_history() {
+    const size_t HC = (size_t)Ntemps * W, cap = ring_rows;
+    rx.resize(cap * HC * dim); rl.resize(cap * HC); rp.resize(cap * HC); rb.resize(cap * HC); rmeta.resize(cap * HC * 4); rnsize.resize(HC);
+    ptm_check(ptm_get_array(eng, PTM_ARR_NSIZE, rnsize.data()), "sync_history");
+    ptm_check(ptm_get_history(eng, rx.data(), rl.data(), rp.data(), rmeta.data()), "sync_history");
+    ptm_check(ptm_get_history_invtemps(eng, rb.data()), "sync_history");
+    for (size_t c = 0; c < HC; c++) {
+      mirror_t& m = mirror[c];
+      for (int64_t row = mirror_seen[c]; row < rnsize[c]; row++) {
+        const size_t o = (size_t)(row % (int64_t)cap) * HC + c;
+        if (rmeta[4 * o + 3] != (int32_t)row) { std::cout << "parallel_tempering_chains: the history ring lost rows before they were mirrored (step() n > ring / 2?)" << std::endl; exit(1); }
+        m.x.insert(m.x.end(), rx.begin() + o * dim, rx.begin() + (o + 1) * dim);
+        m.llike.push_back(rl[o]); m.lprior.push_back(rp[o]); m.beta.push_back(rb[o]);
+        m.meta.push_back(rmeta[4 * o]); m.meta.push_back(rmeta[4 * o + 1]); m.meta.push_back(rmeta[4 * o + 2]);
+      }
+      mirror_seen[c] = rnsize[c];
+    }
+  }
 
   std::vector<double> mX, mlpost;   // host copy of the MAP states (chain.cc:931-934), all rungs / replicas
   bool map_fresh = false;
@@ -765,16 +1724,38 @@ class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:
     nstep = hdr[6];
     fresh = hist_fresh = map_fresh = false;
   }
-  // chain.cc:1281-1365: n prior draws per rung; the device draws them (any prior type but the improper flat one)
+  // chain.cc:1281-1365: n prior draws per rung (the device draws them: any prior type but the improper flat one); the last one
+  // is the chain's start, the others seed the history that history-reading proposals draw from (ptmcmc.cc:86: de_ni * Npar)
+  bayes_likelihood* init_like = nullptr;
+  const sampleable_probability_function* init_prior = nullptr;
+  std::vector<double> init_start;
+  bool have_start = false;
+  // tell the ladder BEFORE initialize() that its proposal will be drawn on the host (saves building the engine twice)
+  void use_host_proposals(bool on = true) { want_host = on; }
   void initialize(bayes_likelihood* log_likelihood, const sampleable_probability_function* log_prior, int n = 1, uint64_t seed = 0x5EED0001ull,
                   const std::vector<double>* start_states = nullptr) {
+    init_like = log_likelihood; init_prior = log_prior; Ninit_rows = n < 1 ? 1 : n; eng_seed = seed;
+    have_start = start_states != nullptr;
+    if (have_start) init_start = *start_states;
+    build_engine(want_host);
+  }
+
+ private:
+  void build_engine(bool host) {
+    if (eng) { ptm_engine_destroy(eng); eng = nullptr; }
+    bayes_likelihood* log_likelihood = init_like;
+    const sampleable_probability_function* log_prior = init_prior;
     sp = log_prior->get_space();
     dim = log_prior->getDim();
+    host_mode = host;
+    // host-side proposals: every rung's saved rows pass through a SHORT device ring into the host mirror after each step
+    ring_rows = host ? 8 : hist_rows;
+    ring_rungs = host ? Ntemps : history_rungs();
     ptm_config cfg;
     cfg.struct_size = sizeof cfg;
-    cfg.dim = dim; cfg.n_rungs = Ntemps; cfg.rung_begin = 0; cfg.rung_count = Ntemps; cfg.n_walkers = W; cfg.seed = seed;
+    cfg.dim = dim; cfg.n_rungs = Ntemps; cfg.rung_begin = 0; cfg.rung_count = Ntemps; cfg.n_walkers = W; cfg.seed = eng_seed;
     cfg.swap_rate = swap_rate; cfg.add_every_n = add_every_N; cfg.min_prior = dpriormin; cfg.device = -1; cfg.stream = nullptr;
-    cfg.time_kernels = 0; cfg.swap_log_steps = 0; cfg.exchange_row_capacity = 0; cfg.history_rungs = history_rungs(); cfg.history_capacity = hist_rows; cfg.map_rungs = Ntemps;
+    cfg.time_kernels = 0; cfg.swap_log_steps = 0; cfg.exchange_row_capacity = 0; cfg.history_rungs = ring_rungs; cfg.history_capacity = ring_rows; cfg.map_rungs = Ntemps;
     ptm_check(ptm_engine_create(&cfg, &eng), "parallel_tempering_chains::initialize");
     std::vector<int> lo(dim), hi(dim), types;
     std::vector<double> xmin(dim), xmax(dim), centers, halfwidths;
@@ -793,47 +1774,106 @@ class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:
     for (int i = 0; i < Ntemps; i++) beta[i] = 1 / temps[i];  // chain.cc:1340
     ptm_check(ptm_set_ladder(eng, beta.data()), "set_ladder");
     if (ev_rate > 0) ptm_check(ptm_set_evolve_temps(eng, ev_rate, ev_cut), "evolve_temps");
-    X.assign((size_t)Ntemps * W * dim, 0.0); llike.assign((size_t)Ntemps * W, 0.0); lpost.assign((size_t)Ntemps * W, 0.0);
-    if (start_states) {
-      ptm_check(ptm_set_states(eng, start_states->data(), nullptr), "set_states");
+    const size_t N = (size_t)Ntemps * W;
+    X.assign(N * dim, 0.0); llike.assign(N, 0.0); lpost.assign(N, 0.0);
+    init_x.clear(); init_ll.clear(); init_lp.clear();
+    if (have_start) {
+      ptm_check(ptm_set_states(eng, init_start.data(), nullptr), "set_states");
+      Ninit_rows = 1;
     } else {
-      int rc = ptm_init_from_prior(eng);
-      if (rc == PTM_ERR_UNSUPPORTED) {
-        std::cout << "parallel_tempering_chains::initialize: " << ptm_last_error() << "; pass start states" << std::endl;
-        exit(1);
+      // draws 1 .. n-1 first (kept for the mirror), draw 0 last: it is the chain's start, whatever n is
+      for (int k = host ? Ninit_rows - 1 : 0; k >= 0; k--) {
+        int rc = ptm_init_from_prior_k(eng, k);
+        if (rc == PTM_ERR_UNSUPPORTED) {
+          std::cout << "parallel_tempering_chains::initialize: " << ptm_last_error() << "; pass start states" << std::endl;
+          exit(1);
+        }
+        ptm_check(rc, "init_from_prior");
+        if (k > 0) {
+          std::vector<double> x(N * dim), ll(N), lp(N);
+          ptm_check(ptm_get_states(eng, x.data()), "initialize");
+          ptm_check(ptm_get_array(eng, PTM_ARR_LLIKE, ll.data()), "initialize");
+          ptm_check(ptm_get_array(eng, PTM_ARR_LPRIOR, lp.data()), "initialize");
+          init_x.push_back(x); init_ll.push_back(ll); init_lp.push_back(lp);
+        }
       }
-      ptm_check(rc, "init_from_prior");
     }
-    views.clear();
-    for (int w = 0; w < W; w++)
+    views.clear(); ladders.clear();
+    for (int w = 0; w < W; w++) {
       for (int i = 0; i < Ntemps; i++) views.push_back(rung_view(this, i, w));   // views[w*Ntemps + i]
-    fresh = false;
+      ladders.push_back(ladder_view(this, w));
+    }
+    fresh = hist_fresh = map_fresh = false;
+    if (host) {
+      // the mirror starts with the initial draws (MH_chain::initialize adds every one of them, chain.cc:846-876)
+      mirror.assign(N, mirror_t());
+      mirror_seen.assign(N, 0);
+      for (size_t c = 0; c < N; c++) {
+        const int i = (int)(c / W);
+        for (size_t k = 0; k < init_x.size(); k++) {
+          mirror_t& m = mirror[c];
+          m.x.insert(m.x.end(), init_x[k].begin() + c * dim, init_x[k].begin() + (c + 1) * dim);
+          m.llike.push_back(init_ll[k][c]); m.lprior.push_back(init_lp[k][c]); m.beta.push_back(beta[i]);
+          m.meta.push_back(1); m.meta.push_back(1); m.meta.push_back(-1);
+        }
+      }
+      sync_history();   // row 0 of the ring: the start state
+    } else {
+      Ninit_rows = 1;
+    }
   }
-  // chain.cc:1367-1386: one clone per rung
+
+ public:
+  // chain.cc:1367-1386: one clone per rung (and replica); a proposal that supports mixing is given the whole ladder as its
+  // chain, any other its own rung (set_chain).  Gaussians with a fixed factor -- and sets of scalar multiples of one -- are
+  // drawn on the device; everything else through the host-proposal step.
   void set_proposal(proposal_distribution& proposal) {
+    for (auto p : props) delete p;
+    props.clear();
     int kind = 0;
     double odf = 0;
     std::vector<double> f, all, odfs(Ntemps);
-    for (int i = 0; i < Ntemps; i++) {
-      props.push_back(proposal.clone());
-      if (!props.back()->device_describe(dim, kind, f, odf)) {
-        std::cout << "parallel_tempering_chains::set_proposal: " << proposal.show() << " has no device form (only gaussian_prop in this build)" << std::endl;
-        exit(1);
-      }
+    bool on_device = true;
+    for (int i = 0; i < Ntemps && on_device; i++) {
+      const user_gaussian_prop* ug = dynamic_cast<const user_gaussian_prop*>(&proposal);
+      if (!(ug ? ug->device_describe_in(sp, dim, kind, f, odf) : proposal.device_describe(dim, kind, f, odf))) { on_device = false; break; }
       all.insert(all.end(), f.begin(), f.end());
       odfs[i] = odf;
     }
-    ptm_check(ptm_set_proposals(eng, kind, all.data(), odfs.data()), "set_proposals");
-    std::vector<double> cum, sc, od;
-    if (proposal.device_describe_mixture(dim, cum, sc, od)) {   // a proposal_distribution_set of scaled Gaussians
-      const int K = (int)cum.size();
-      std::vector<double> C((size_t)Ntemps * K), S(C.size()), O(C.size());
-      for (int i = 0; i < Ntemps; i++)
-        for (int k = 0; k < K; k++) { C[(size_t)i * K + k] = cum[k]; S[(size_t)i * K + k] = sc[k]; O[(size_t)i * K + k] = od[k]; }
-      ptm_check(ptm_set_proposal_mixture(eng, K, C.data(), S.data(), O.data()), "set_proposal_mixture");
-    } else {
-      ptm_check(ptm_set_proposal_mixture(eng, 0, nullptr, nullptr, nullptr), "set_proposal_mixture");
+    if (on_device) {
+      if (host_mode) build_engine(false);
+      for (int i = 0; i < Ntemps; i++) props.push_back(proposal.clone());
+      ptm_check(ptm_set_proposals(eng, kind, all.data(), odfs.data()), "set_proposals");
+      std::vector<double> cum, sc, od;
+      if (proposal.device_describe_mixture(dim, cum, sc, od)) {   // a proposal_distribution_set of scaled Gaussians
+        const int K = (int)cum.size();
+        std::vector<double> C((size_t)Ntemps * K), S(C.size()), O(C.size());
+        for (int i = 0; i < Ntemps; i++)
+          for (int k = 0; k < K; k++) { C[(size_t)i * K + k] = cum[k]; S[(size_t)i * K + k] = sc[k]; O[(size_t)i * K + k] = od[k]; }
+        ptm_check(ptm_set_proposal_mixture(eng, K, C.data(), S.data(), O.data()), "set_proposal_mixture");
+      } else {
+        ptm_check(ptm_set_proposal_mixture(eng, 0, nullptr, nullptr, nullptr), "set_proposal_mixture");
+      }
+      ptm_check(ptm_set_proposal_callback(eng, nullptr, nullptr, nullptr), "set_proposal_callback");
+      return;
     }
+    if (!host_mode) build_engine(true);   // (initialize() did not know: the engine is set up again, with the same draws)
+    for (int w = 0; w < W; w++)
+      for (int i = 0; i < Ntemps; i++) {
+        proposal_distribution* c = proposal.clone();
+        if (c->support_mixing()) c->set_chain(&ladders[w]);
+        else c->set_chain(&views[(size_t)w * Ntemps + i]);
+        props.push_back(c);   // props[w*Ntemps + i]
+      }
+    ptm_check(ptm_set_proposal_callback(eng, &parallel_tempering_chains::propose_trampoline, &parallel_tempering_chains::result_trampoline, this),
+              "set_proposal_callback");
+  }
+  bool proposals_on_host() const { return host_mode; }
+  // chain::report_prop (chain.cc:2096-2109 flavour): every rung's proposal report, replica 0
+  std::string report_prop(int style = 0) override {
+    std::ostringstream ss;
+    for (int i = 0; i < Ntemps && i < (int)props.size(); i++) ss << "  T=" << 1 / cur_beta(i, 0) << ": " << props[i]->report(style) << "\n";
+    return ss.str();
   }
   // per-rung factors for proposals that differ by rung (what user_gaussian_prop's check_update achieves in the reference)
   void set_proposal_factors(int kind, const std::vector<double>& factors, const std::vector<double>& oneDfracs = std::vector<double>()) {
@@ -843,10 +1883,11 @@ class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:
     ptm_check(ptm_step(eng, 1), "parallel_tempering_chains::step");
     nstep++;
     fresh = hist_fresh = map_fresh = false;
+    if (host_mode) sync_history();
     if (tracking) replay_step();
   }
   void step(int n) {
-    if (tracking) { for (int k = 0; k < n; k++) step(); return; }
+    if (tracking || host_mode) { for (int k = 0; k < n; k++) step(); return; }
     ptm_check(ptm_step(eng, n), "parallel_tempering_chains::step");
     nstep += n;
     fresh = hist_fresh = map_fresh = false;
@@ -869,6 +1910,29 @@ class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:
   //   i lpost llike acceptance_ratio prop_type: p0 ... pD-1 invtemp
   // Rows that have already left the ring are skipped (the ring holds the newest rows_per_chain saved states).
   void dumpChain(int ichain, std::ostream& os, int Nburn = 0, int ievery = 1, int replica = 0) {
+    if (host_mode) {   // host-side proposals: the whole saved history is in the host mirror
+      const size_t at = (size_t)ichain * W + replica;
+      const mirror_t& m = mirror[at];
+      std::vector<int64_t> nh((size_t)Ntemps * W);
+      ptm_check(ptm_get_array(eng, PTM_ARR_NHIST, nh.data()), "dumpChain");
+      const int Ninit = Ninit_rows, Nhist = (int)nh[at];
+      os << "#Ninit=" << Ninit << ", Nburn=" << Nburn << "\n";
+      os << "#eval: log(posterior) log(likelihood) acceptance_ratio prop_type: ";
+      for (int i = 0; i < dim; i++) os << (sp ? sp->get_name(i) : std::string("[unnamed]")) << " ";
+      os << std::endl;
+      if (Nburn + Ninit < 0) Nburn = -Ninit;
+      const double invtemp = cur_beta(ichain, replica);
+      for (int i = Nburn; i < Nhist; i += ievery) {
+        int idx = Ninit + i;
+        if (i >= 0) idx = Ninit + i / add_every_N;
+        if (idx < 0 || (size_t)idx >= m.rows()) continue;
+        const double t = m.beta[idx] * m.llike[idx];
+        os << i << " " << m.lprior[idx] + t << " " << m.llike[idx] << " " << m.meta[3 * idx] / (double)m.meta[3 * idx + 1] << " " << m.meta[3 * idx + 2] << ": ";
+        for (int j = 0; j < dim - 1; j++) os << m.x[(size_t)idx * dim + j] << " ";
+        os << m.x[(size_t)idx * dim + dim - 1] << " " << invtemp << std::endl;
+      }
+      return;
+    }
     if (hist_rows <= 0) { std::cout << "parallel_tempering_chains::dumpChain: call keep_history(rows) before initialize()" << std::endl; exit(1); }
     if (ichain >= history_rungs()) { std::cout << "parallel_tempering_chains::dumpChain: rung " << ichain << " keeps no history (keep_history(rows, " << history_rungs() << "))" << std::endl; exit(1); }
     const size_t HC = (size_t)history_rungs() * W, cap = hist_rows, at = (size_t)ichain * W + replica;
@@ -933,109 +1997,457 @@ class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:
   }
 };
 
-// ---- ptmcmc.hh: the driver, reduced to the run loop around cc->step() (ptmcmc.cc:530-679) ---------------------------------
-class ptmcmc_sampler {
-  std::map<std::string, std::string> opt;
-  bayes_likelihood* chain_llike;
-  const sampleable_probability_function* chain_prior;
-  proposal_distribution* cprop;
-  std::unique_ptr<parallel_tempering_chains> cc;
+// ---- bayesian.hh:795-821 / ptmcmc.hh: the driver ------------------------------------------------------------------------------
+class bayes_sampler : public Optioned {   // bayesian.hh:795-821
+ protected:
+  std::string paramfile;
+  bool have_paramfile;
+  void processOptions() {
+    *optValue("stateFile") >> paramfile;
+    if (!(paramfile == "")) have_paramfile = true;
+  }
 
  public:
-  ptmcmc_sampler() : chain_llike(nullptr), chain_prior(nullptr), cprop(nullptr) {
-    // flag names and defaults of ptmcmc.cc:375-427 that shape this path
-    opt["nsteps"] = "5000"; opt["save_every"] = "10"; opt["nevery"] = "1000"; opt["pt"] = "20"; opt["pt_swap_rate"] = "0.10";
-    opt["pt_Tmax"] = "1e9"; opt["chain_dprior_min"] = "-30"; opt["seed"] = "-1"; opt["outname"] = "mcmc_output";
-    opt["nskip"] = "10"; opt["pt_dump_n"] = "1"; opt["nchains"] = "1";
-    opt["pt_evolve_rate"] = "0.01"; opt["pt_evolve_lpost_cut"] = "-1";   // ptmcmc.cc:389-390: the ladder evolves by default
-    opt["checkp_at_step"] = "-1"; opt["restart_dir"] = "";                // ptmcmc.cc:377-379
+  bayes_sampler() : have_paramfile(false) {}
+  virtual bayes_sampler* clone() = 0;
+  virtual int initialize() = 0;
+  virtual int run(const std::string& base, int ic = 0) = 0;
+  virtual int analyze(const std::string& base, int ic, int Nsigma, int Nbest, bayes_likelihood& like) = 0;
+  virtual bool haveParfile() { return have_paramfile; }
+  virtual state getState() = 0;
+  void addOptions(Options& opt, const std::string& prefix = "") override {
+    Optioned::addOptions(opt, prefix);
+    addOption("stateFile", "File with initialization state parameters", "");
   }
+  virtual void setup(bayes_likelihood& llike, const sampleable_probability_function& prior, int output_precision = 15) = 0;
+};
+
+// ptmcmc_sampler (ptmcmc.hh:12-97, ptmcmc.cc): same calls in the same order as a reference main()
+// (exampleLISA.cc:699-822):
+//     ptmcmc_sampler::Init(argc, argv);  Options opt;  ptmcmc_sampler mcmc;  bayes_sampler* s0 = &mcmc;
+//     s0->addOptions(opt);  like->addOptions(opt);  opt.add(Option(...));  opt.parse(argc, argv);
+//     ProbabilityDist::setSeed(seed);  mcmc.setup(*like, precision);  mcmc.select_proposal();
+//     for (ic...) { bayes_sampler* s = s0->clone();  s->initialize();  s->run(base, ic);  delete s; }
+// select_proposal() builds the reference's default recipe (ptmcmc.cc:15-183): differential evolution + six diagonal Gaussians
+// a factor gauss_step_fac apart with doubling shares (+ prior draws, + the likelihood's own proposals).  With
+// --gauss_draw_frac=1 the recipe is all Gaussian and runs fused on the device; with its default (0.2) the differential-
+// evolution part makes it a host-side proposal (the engine's host-proposal step).
+class ptmcmc_sampler : public bayes_sampler {
+  Options own_opt;   // used when the program never called addOptions (the convenience calls set() / parse() below)
+  chain* cc_base;
+  std::unique_ptr<parallel_tempering_chains> cc;
+  proposal_distribution* cprop;
+  bool have_cc, have_cprop, own_cprop;
+  bayes_likelihood* chain_llike;
+  const sampleable_probability_function* chain_prior;
+  bool have_setup;
+  int chain_Nstep, chain_Ninit, chain_nburn, output_precision;
+  double swap_rate, pt_evolve_rate, pt_evolve_lpost_cut, Tmax;
+  int Nstep, Nskip, Nptc, Nevery, save_every, dump_n;
+  double nburn_frac;
+  bool parallel_tempering;
+  int istep;
+  bool restarting;
+  std::string restart_dir;
+  int checkp_at_step;
+  double ess_stop, prop_adapt_rate, dpriormin;
+  int nreplicas;
+
+  void ensure_options() { if (!haveOptions()) addOptions(own_opt); }
+  void processOptions() {   // ptmcmc.cc:430-473
+    ensure_options();
+    bayes_sampler::processOptions();
+    *optValue("checkp_at_step") >> checkp_at_step;
+    restart_dir = ""; *optValue("restart_dir") >> restart_dir;
+    restarting = restart_dir.size() != 0;
+    *optValue("nevery") >> Nevery;
+    *optValue("save_every") >> save_every;
+    *optValue("nsteps") >> Nstep;
+    *optValue("nskip") >> Nskip;
+    *optValue("burn_frac") >> nburn_frac;
+    *optValue("pt") >> Nptc;
+    parallel_tempering = Nptc > 1;
+    *optValue("pt_evolve_rate") >> pt_evolve_rate;
+    *optValue("pt_evolve_lpost_cut") >> pt_evolve_lpost_cut;
+    *optValue("pt_swap_rate") >> swap_rate;
+    *optValue("pt_Tmax") >> Tmax;
+    *optValue("pt_dump_n") >> dump_n;
+    if (dump_n > Nptc || dump_n < 0) dump_n = Nptc;
+    if (Nptc == 0) dump_n = 1;
+    *optValue("prop_adapt_rate") >> prop_adapt_rate;
+    *optValue("chain_ess_stop") >> ess_stop;
+    *optValue("chain_dprior_min") >> dpriormin;
+    nreplicas = 1;
+    if (optSet("replicas")) *optValue("replicas") >> nreplicas;
+  }
+
+ public:
+  ptmcmc_sampler() : cc_base(nullptr), cprop(nullptr), have_cc(false), have_cprop(false), own_cprop(false), chain_llike(nullptr), chain_prior(nullptr),
+                     have_setup(false), chain_Nstep(0), chain_Ninit(1), chain_nburn(0), output_precision(13), swap_rate(0.1), pt_evolve_rate(0.01),
+                     pt_evolve_lpost_cut(-1), Tmax(1e9), Nstep(5000), Nskip(10), Nptc(0), Nevery(5000), save_every(1), dump_n(1), nburn_frac(0.5),
+                     parallel_tempering(false), istep(0), restarting(false), checkp_at_step(-1), ess_stop(-1), prop_adapt_rate(0), dpriormin(-30), nreplicas(1) {}
+  ~ptmcmc_sampler() { if (own_cprop) delete cprop; }
+  // ptmcmc.cc:250-275: MPI start-up / shut-down in the reference; here the process already owns its GPU
+  static void Init() { std::cout << "Running on the MI355X step engine (no MPI; ladders shard over GPUs through ptmcmc_amd.parallel)." << std::endl; }
+  static void Init(int& argc, char* argv[]) { (void)argc; (void)argv; Init(); }
+  static void setRNGseed(double seed) { ProbabilityDist::setSeed(seed); }
+  static void Quit() { exit(0); }
+  static bool static_reporting() { return true; }
+  bool reporting() { return true; }
+
+  // the flags of ptmcmc.cc:375-427, same names and defaults.  Flags of features outside this build's scope (pt_reboot_*,
+  // pt_stop_evid_err, covariance_file, sym_prop_frac, prop_test_index, chain_init_file, checkp_at_time, checkp_on_sigterm_within)
+  // are accepted so that command lines written for the reference parse, and refused at setup if they ask for the feature.
+  void addOptions(Options& opt, const std::string& prefix = "") override {
+    bayes_sampler::addOptions(opt, prefix);
+    addOption("checkp_at_step", "Step at which to checkpoint and stop", "-1");
+    addOption("checkp_at_time", "Elapsed walltime (hours) after which to checkpoint and stop", "-1");
+    addOption("restart_dir", "Directory with checkpoint data to restart from.", "");
+    addOption("nevery", "Frequency to dump chain info. Default=5000.", "5000");
+    addOption("save_every", "Frequency to store chain info. Default=1.", "1");
+    addOption("nsteps", "How long to run the chain. Default=5000.", "5000");
+    addOption("nskip", "Only dump every nskipth element. Default=10.", "10");
+    addOption("burn_frac", "Portion of chain to disregard as burn-in for some calculations. Default=0.5", "0.5");
+    addOption("pt", "Number of parallel tempering chains. Default off.", "0");
+    addOption("pt_swap_rate", "Frequency of parallel tempering swap_trials. Default 0.10", "0.10");
+    addOption("pt_Tmax", "Max temp of parallel tempering chains. Default 1e9", "1e9");
+    addOption("pt_evolve_rate", "Rate at which parallel tempering temps should be allowed to evolve. Default none.", "0.01");
+    addOption("pt_evolve_lpost_cut", "Tolerance limit for disordered log-posterior values in temperature evolution. Default no limit.", "-1");
+    addOption("pt_reboot_rate", "Max frequency of rebooting poorly performing parallel tempering chains. Default 0", "0");
+    addOption("pt_reboot_every", "How often to test for rebooting poorly performing parallel tempering chains. Default 0", "0");
+    addOption("pt_reboot_grace", "Grace period protecting infant instances reboot. Default 0", "0");
+    addOption("pt_reboot_cut", "Posterior difference cutoff defining poorly performing parallel tempering chains. Default 100", "100");
+    addOption("pt_reboot_thermal", "Temperature dependent cutoff term in defining poorly performing parallel tempering chains. Default 0", "0");
+    addOption("pt_reboot_blindly", "Do aggressive random rebooting at some level even if no gaps are found. Default 0", "0");
+    addOption("pt_reboot_grad", "Let the reboot grace period depend linearly on temp level with given mean. (colder->longer)");
+    addOption("pt_dump_n", "How many of the coldest chains to dump; 0 for all. (default 1)", "1");
+    addOption("pt_stop_evid_err", "Set a value to specify a stopping criterion based on evidence consistency. (default 0)", "0");
+    addOption("prop", "Defunct.", "");
+    addOption("gauss_1d_frac", "With Gaussian proposal distribution variants, specify a fraction which should be taken in one random parameter direction. Default=0.5", "0.5");
+    addOption("gauss_draw_frac", "With Gaussian proposal distribution variants, specify a fraction of Gaussian draws. Default=0.20", "0.20");
+    addOption("prior_draw_frac", "Add prior draws to general proposal (prop7). Default=0", "0");
+    addOption("prior_draw_Tpow", "Power for thermal_weighting of any prior draws in proposal. Default=0", "0");
+    addOption("gauss_step_fac", "With Gaussian proposal distribution variants, specify scale-spacing of Gaussian components. Default=2", "2");
+    addOption("gauss_temp_scaled", "With Gaussian proposal distribution variants, scale (co)variance with chain-temp. Default=not");
+    addOption("cov_draw_frac", "With Gaussian proposal dist variants and a covariance file set, specify a fraction of Gaussian draws with defined covariance. Default=0.50", "0.50");
+    addOption("covariance_file", "Specify file with covariance data for relevant proposal distribution optoins.Default=none", "");
+    addOption("prop_adapt_rate", "Specify a scaling rate (eg 1e-3) for adaptation of sub-proposal fractions, Default=0", "0");
+    addOption("prop_adapt_more", "Adapt more broadly, not just Gaussian mixtures");
+    addOption("sym_prop_frac", "Fractional rate at which to apply and stateSpace symmetries as proposals. (Default=0)", "0");
+    addOption("like_prop_frac", "Fractional rate at which to apply proposal defined by likelihood. (Default=0)", "0");
+    addOption("de_ni", "Differential-Evolution number of initialization elements per dimension. Default=50.", "50");
+    addOption("de_eps", "Differential-Evolution gaussian scale. Default=1e-4.", "1e-4");
+    addOption("de_reduce_gamma", "Differential Evolution reduce gamma parameter by some factor from nominal value. Default=4.", "4");
+    addOption("de_g1_frac", "Differential Evolution reduce fraction of times gamma parameter set to 1. Default=0.3.", "0.3");
+    addOption("de_mixing", "Differential-Evolution support mixing of parallel chains.");
+    addOption("de_Tmix", "Differential-Evolution degree to encourage mixing info from different temps.(default=300)", "300");
+    addOption("de_unlikely_alpha", "Scaling power for rejecting unlikely past states in differential evolution draws.(Default 0, ie none)", "0");
+    addOption("prop_test_index", "String providing (multi-)index value indicating proposal to test. (Default: no test)", "");
+    addOption("chain_init_file", "Specify chain file from which to draw initializtion points, rather than from prior.", "");
+    addOption("chain_ess_stop", "Stop MCMC sampling the first time the specified effective sample size is reached. (default never)", "-1.0");
+    addOption("chain_ess_limit", "Look for efficiencies in ESS calculation based on assumed limit. (default -1=no limit, 0=based on ess_limit,or as given)", "-1.0");
+    addOption("checkp_on_sigterm_within", "Set to n to check every n steps for SIGTERM and checkpoint if recieved. (Default 0, don't checkpoint on SIGTERM", "0");
+    addOption("chain_dprior_min", "Specify a minimum change in log prior beyond which proposal will be rejected without evaluating the likelihood. (Default=-30)", "-30");
+    // this build's addition: independent replicas of the ladder side by side in one engine (the reference runs its repeats
+    // one after the other: the caller's loop over clone() / initialize() / run())
+    addOption("replicas", "Independent replicas of the ladder run side by side on the device (files <base>_c<w>_t<k>.dat). Default 1", "1");
+  }
+
+  // ---- convenience for programs without an Options object of their own (examples/example_sampler.cc)
+  void set(const std::string& name, const std::string& value) {
+    ensure_options();
+    std::string arg = "--" + name + "=" + value;
+    std::vector<char> buf(arg.begin(), arg.end());
+    buf.push_back(0);
+    char* argv[2] = {nullptr, buf.data()};
+    int argc = 2;
+    if (own_opt.parse(argc, argv, false)) { std::cout << "ptmcmc_sampler::set: unknown option '" << name << "'" << std::endl; exit(1); }
+  }
+  bool parse(int argc, char* argv[]) {  // --name=value / --name; true when every flag was understood
+    ensure_options();
+    if (!own_opt.exists("seed")) {
+      own_opt.add(Option("seed", "Pseudo random number grenerator seed in [0,1). (Default=-1: the engine's fixed default key)", "-1"));
+      own_opt.add(Option("outname", "Base name for output files (Default 'mcmc_output').", "mcmc_output"));
+      own_opt.add(Option("nchains", "Replicas of the ladder run side by side (alias of --replicas).", "1"));
+    }
+    int n = argc;
+    const bool bad = own_opt.parse(n, argv, true);
+    double seed = -1;
+    std::istringstream(own_opt.value("seed")) >> seed;
+    if (seed >= 0) ProbabilityDist::setSeed(seed);
+    int nch = 1;
+    std::istringstream(own_opt.value("nchains")) >> nch;
+    if (nch > 1) set("replicas", own_opt.value("nchains"));
+    return !bad;
+  }
+  double num(const std::string& n) { double v = 0; *optValue(n) >> v; return v; }
+
+  // ptmcmc.cc:476-506
+  void setup(int Ninit, bayes_likelihood& llike, const sampleable_probability_function& prior, proposal_distribution& prop, int output_precision_ = 15) {
+    processOptions();
+    chain_Nstep = Nstep; chain_Ninit = Ninit; chain_nburn = (int)(Nstep * nburn_frac); output_precision = output_precision_;
+    cprop = &prop; own_cprop = false; chain_prior = &prior; chain_llike = &llike; have_setup = true; have_cprop = true;
+  }
+  void setup(bayes_likelihood& llike, const sampleable_probability_function& prior, int output_precision_ = 15) override {
+    processOptions();
+    chain_Nstep = Nstep; chain_nburn = (int)(Nstep * nburn_frac); output_precision = output_precision_;
+    chain_prior = &prior; chain_llike = &llike; have_setup = true;
+    refuse_unbuilt();
+  }
+  void setup(bayes_likelihood& llike, int output_precision_ = 15) { setup(llike, *llike.getObjectPrior(), output_precision_); }
+  void refuse_unbuilt() {
+    double v = 0; std::string sv;
+    *optValue("pt_reboot_rate") >> v;
+    if (v > 0) { std::cout << "ptmcmc_sampler: pt_reboot_rate > 0 (rebooting laggard chains) is not built in the GPU step engine." << std::endl; exit(1); }
+    *optValue("pt_stop_evid_err") >> v;
+    if (v > 0) { std::cout << "ptmcmc_sampler: pt_stop_evid_err > 0 (evidence integration) is not built in the GPU step engine." << std::endl; exit(1); }
+    *optValue("chain_init_file") >> sv;
+    if (!sv.empty()) { std::cout << "ptmcmc_sampler: chain_init_file is not built in the GPU step engine." << std::endl; exit(1); }
+    if (ess_stop > 0) { std::cout << "ptmcmc_sampler: chain_ess_stop (the autocorrelation analysis of chain.cc:126-643) is not built in the GPU step engine." << std::endl; exit(1); }
+    if (Nptc < 2) { std::cout << "ptmcmc_sampler: this build drives parallel-tempering ladders: set --pt=N with N >= 2." << std::endl; exit(1); }
+  }
+  // a proposal of the caller's (the convenience path of examples/example_sampler.cc; the reference's deprecated setup(Ninit, ...))
+  void select_proposal(proposal_distribution& p) { if (own_cprop) delete cprop; cprop = &p; own_cprop = false; have_cprop = true; }
+
+  // ptmcmc.cc:15-183: the default recipe
+  void select_proposal() {
+    if (!have_setup) { std::cout << "ptmcmc_sampler::select_proposal.  Must call setup() first!" << std::endl; exit(1); }
+    std::vector<double> scalesvec;
+    chain_llike->getScales(scalesvec);
+    const int Npar = chain_prior->get_space() ? chain_prior->get_space()->size() : chain_prior->getDim();
+    int SpecNinit;
+    double tmixfac, reduce_gamma_by, de_g1_frac, de_eps, gauss_1d_frac, prior_draw_frac, prior_draw_Tpow, gauss_draw_frac, gauss_step_fac, cov_draw_frac,
+        sym_prop_frac, like_prop_frac, unlikely_alpha;
+    std::string covariance_file;
+    *optValue("prior_draw_frac") >> prior_draw_frac;
+    *optValue("prior_draw_Tpow") >> prior_draw_Tpow;
+    *optValue("gauss_1d_frac") >> gauss_1d_frac;
+    *optValue("gauss_draw_frac") >> gauss_draw_frac;
+    *optValue("gauss_step_fac") >> gauss_step_fac;
+    *optValue("cov_draw_frac") >> cov_draw_frac;
+    *optValue("sym_prop_frac") >> sym_prop_frac;
+    *optValue("like_prop_frac") >> like_prop_frac;
+    *optValue("covariance_file") >> covariance_file;
+    const bool adapt_more = optSet("prop_adapt_more");
+    if (prior_draw_frac < 0) prior_draw_frac = 0;
+    if (prior_draw_frac > 1) prior_draw_frac = 1;
+    if (gauss_1d_frac < 0) gauss_1d_frac = 0;
+    if (gauss_1d_frac > 1) gauss_1d_frac = 1;
+    if (gauss_draw_frac < 0) gauss_draw_frac = 0;
+    if (gauss_draw_frac > 1) gauss_draw_frac = 1;
+    if (gauss_step_fac < 1) gauss_step_fac = 1;
+    if (covariance_file == "") cov_draw_frac = 0;
+    else { std::cout << "ptmcmc_sampler::select_proposal: covariance_file is an empty stub in the reference too (ptmcmc.cc:761-764); ignored." << std::endl; cov_draw_frac = 0; }
+    if (prior_draw_frac + gauss_draw_frac + cov_draw_frac > 1) {
+      const double scale = gauss_draw_frac + cov_draw_frac;
+      gauss_draw_frac /= scale;
+      cov_draw_frac /= scale;
+    }
+    if (sym_prop_frac > 0) std::cout << "ptmcmc_sampler::select_proposal: stateSpace symmetries (sym_prop_frac) are out of this build's scope; ignored." << std::endl;
+    *optValue("de_ni") >> SpecNinit;
+    *optValue("de_eps") >> de_eps;
+    *optValue("de_reduce_gamma") >> reduce_gamma_by;
+    *optValue("de_g1_frac") >> de_g1_frac;
+    *optValue("de_Tmix") >> tmixfac;
+    *optValue("de_unlikely_alpha") >> unlikely_alpha;
+    const bool gauss_temp_scaled = optSet("gauss_temp_scaled");   // (no effect in the reference either: quirk Q4)
+    const bool de_mixing = optSet("de_mixing");
+
+    const int Ng = 6;
+    int Nprop_set = 1 + Ng;
+    if (prop_adapt_rate > 0) Nprop_set = 2;   // hierarchical: only the Gaussian portion adapts
+    std::vector<proposal_distribution*> set(Nprop_set, nullptr);
+    std::vector<double> shares(Nprop_set), hot_shares(Nprop_set);
+    double Tpow = 0;
+    int iprop = 0;
+    const double gshare = gauss_draw_frac;
+    shares[0] = 1 - gshare - cov_draw_frac - prior_draw_frac;
+    if (shares[0] < 0) shares[0] = 0;
+    // a differential-evolution member with share 0 can never be drawn (x < bin_max[0] = 0 never holds, .cc:107-118) and draws
+    // no random number: leaving it out gives the same chain and lets an all-Gaussian recipe run on the device
+    const bool with_de = shares[0] > 0;
+    if (with_de) {
+      differential_evolution* de = new differential_evolution(0.1, de_g1_frac, de_eps, 0.0, unlikely_alpha);
+      de->reduce_gamma(reduce_gamma_by);
+      if (de_mixing) de->support_mixing(true);
+      de->mix_temperatures_more(tmixfac);
+      chain_Ninit = SpecNinit * Npar;
+      set[iprop] = de;
+      iprop++;
+    } else {
+      chain_Ninit = 1;
+      set.erase(set.begin()); shares.erase(shares.begin()); hot_shares.erase(hot_shares.begin());
+      Nprop_set--;
+    }
+    if (prior_draw_frac > 0) {
+      set.insert(set.begin() + iprop, new draw_from_dist(*chain_prior));
+      shares.insert(shares.begin() + iprop, prior_draw_frac);
+      hot_shares.insert(hot_shares.begin() + iprop, 1.0);
+      Tpow = prior_draw_Tpow;
+      iprop++;
+      Nprop_set++;
+    }
+    std::vector<proposal_distribution*> gset(Ng, nullptr);
+    std::vector<double> gshares(Ng);
+    const double sum = std::pow(2.0, Ng + 1) - 2, stepfac = gauss_step_fac;
+    double fac = std::pow(2.0 / gauss_step_fac, 4.0), sharefac = 1;
+    auto scaled = [&](double f) { std::vector<double> sg(scalesvec.size()); for (size_t i = 0; i < sg.size(); i++) sg[i] = scalesvec[i] / 100.0 / f; return sg; };
+    if (prop_adapt_rate > 0) {
+      for (int i = 0; i < Ng; i++) {
+        fac *= stepfac;
+        gset[i] = new gaussian_prop(scaled(fac), gauss_1d_frac, gauss_temp_scaled);
+        sharefac *= 2;
+        gshares[i] = sharefac / sum;
+      }
+      set[iprop] = new proposal_distribution_set(gset, gshares, prop_adapt_rate);
+      shares[iprop] = gshare;
+    } else {
+      for (int i = iprop; i < Nprop_set; i++) {
+        fac *= stepfac;
+        set[i] = new gaussian_prop(scaled(fac), gauss_1d_frac, gauss_temp_scaled);
+        sharefac *= 2;
+        shares[i] = sharefac / sum * gshare;
+      }
+    }
+    if (own_cprop) delete cprop;
+    cprop = new proposal_distribution_set(set, shares, adapt_more ? prop_adapt_rate : 0, Tpow, hot_shares);
+    own_cprop = true;
+    std::cout << "ptmcmc_sampler::set_proposal: Tpow=" << Tpow << ":" << std::endl;
+    if (like_prop_frac > 0 && chain_llike->get_proposals().size() > 0) {   // ptmcmc.cc:162-170
+      std::cout << "Adding likelihood-based elements to proposal." << std::endl;
+      std::vector<proposal_distribution*> lp;
+      for (auto q : chain_llike->get_proposals()) lp.push_back(q->clone());
+      proposal_distribution_set* likeprops = new proposal_distribution_set(lp, chain_llike->get_prop_shares(), adapt_more ? prop_adapt_rate : 0);
+      std::vector<proposal_distribution*> add_on_props = {cprop, likeprops};
+      double s0 = 1 - like_prop_frac;
+      if (s0 < 0) s0 = 0;
+      cprop = new proposal_distribution_set(add_on_props, std::vector<double>{s0, like_prop_frac}, prop_adapt_rate);
+    }
+    std::cout << "Proposal distribution is:\n" << cprop->show() << std::endl;
+    have_cprop = true;
+  }
+
+  bayes_sampler* clone() override {   // ptmcmc.hh:57-76
+    if (have_cc) { std::cout << "ptmcmc_sampler::clone(): Cannot clone after instantiating chain/prop." << std::endl; exit(1); }
+    ptmcmc_sampler* s = new ptmcmc_sampler();
+    s->copyOptioned(*this);
+    if (!haveOptions()) { s->own_opt = own_opt; s->Optioned::addOptions(s->own_opt); }
+    if (have_setup) s->setup(*chain_llike, *chain_prior, output_precision);
+    if (have_cprop) {
+      s->cprop = cprop->clone();
+      s->own_cprop = true;
+      s->have_cprop = true;
+      s->chain_Ninit = chain_Ninit;
+    }
+    return s;
+  }
+  ptmcmc_sampler* clone_ptmcmc_sampler() { return dynamic_cast<ptmcmc_sampler*>(clone()); }
+  state getState() override {
+    if (!have_setup) { std::cout << "ptmcmc_sampler::getState.  Must call setup() before getState!" << std::endl; exit(1); }
+    if (have_cc) return cc->getState();
+    philox_random r;
+    r.reseat(ProbabilityDist::engineSeed(), 0xFFFFFFFFu, 0);
+    return chain_prior->drawSample(r);
+  }
+
   // ptmcmc_sampler::checkpoint / restart (ptmcmc.cc:306-338): <path>/step_<istep>-cp/ptmcmc.cp + the ladder's own file
-  void checkpoint(const std::string& path, int istep) {
+  void checkpoint(const std::string& path, int istep_) {
     std::ostringstream ss;
-    ss << path << "/step_" << istep << "-cp/";
+    ss << path << "/step_" << istep_ << "-cp/";
     const std::string dir = ss.str();
     std::cout << "Writing checkpoint files to dir:" << dir << std::endl;
     mkdir(dir.c_str(), 0777);
     std::ofstream os((dir + "ptmcmc.cp").c_str());
-    os << istep << std::endl;
+    os << istep_ << std::endl;
     cc->checkpoint(dir);
   }
   int restart(const std::string& path) {
     std::cout << "Restarting from checkpoint files in dir:" << path << std::endl;
     std::ifstream is((path + "/ptmcmc.cp").c_str());
-    int istep = -1;
-    is >> istep;
-    if (!is || istep < 0) { std::cout << "ptmcmc_sampler::restart: cannot read " << path << "/ptmcmc.cp" << std::endl; exit(1); }
+    int istep_ = -1;
+    is >> istep_;
+    if (!is || istep_ < 0) { std::cout << "ptmcmc_sampler::restart: cannot read " << path << "/ptmcmc.cp" << std::endl; exit(1); }
     cc->restart(path + "/");
-    return istep;
+    return istep_;
   }
-  void set(const std::string& name, const std::string& value) { opt[name] = value; }
-  bool parse(int argc, char* argv[]) {  // --name=value / --name (options.hh semantics)
-    for (int i = 1; i < argc; i++) {
-      std::string a = argv[i];
-      if (a.compare(0, 2, "--")) return false;
-      size_t eq = a.find('=');
-      opt[a.substr(2, eq == std::string::npos ? std::string::npos : eq - 2)] = eq == std::string::npos ? "true" : a.substr(eq + 1);
-    }
-    return true;
-  }
-  double num(const std::string& n) const { return atof(opt.at(n).c_str()); }
-  void setup(bayes_likelihood& llike) { chain_llike = &llike; chain_prior = llike.getObjectPrior().get(); }
-  void select_proposal(proposal_distribution& p) { cprop = &p; }
-  int initialize() {
-    if (!chain_llike || !cprop) { std::cout << "ptmcmc_sampler::initialize.  Must call setup() and set proposal before initialization!" << std::endl; exit(1); }
-    cc.reset(new parallel_tempering_chains((int)num("pt"), num("pt_Tmax"), num("pt_swap_rate"), (int)num("save_every"), false, false, num("chain_dprior_min")));
+
+  int initialize() override {   // ptmcmc.cc:497-528
+    if (!have_setup || !have_cprop) { std::cout << "ptmcmc_sampler::initialize.  Must call setup() and set proposal before initialization!" << std::endl; exit(1); }
+    if (!parallel_tempering) { std::cout << "ptmcmc_sampler::initialize: this build drives parallel-tempering ladders: set --pt=N with N >= 2." << std::endl; exit(1); }
+    int Ninit = chain_Ninit;
+    if (restarting || Nstep <= 0) Ninit = 1;
+    cc.reset(new parallel_tempering_chains(Nptc, Tmax, swap_rate, save_every, false, false, dpriormin));
+    cc_base = cc.get();
+    have_cc = true;
     // the chain files are written from the device's history ring, every "nevery" steps: it must hold what one such
     // interval saves (up to two add_state calls per step, every save_every-th saved)
-    {
-      int dump_n = (int)num("pt_dump_n");
-      if (dump_n > (int)num("pt") || dump_n <= 0) dump_n = (int)num("pt");   // ptmcmc.cc:458
-      cc->keep_history(2 + 2 * (int)num("nevery") / std::max(1, (int)num("save_every")), dump_n);
-    }
-    cc->set_replicas((int)num("nchains"));   // the reference's Nchain repeats, all at once
-    if (num("pt_evolve_rate") > 0) cc->evolve_temps(num("pt_evolve_rate"), num("pt_evolve_lpost_cut"));   // ptmcmc.cc:512
-    uint64_t seed = num("seed") >= 0 ? (uint64_t)(num("seed") * 4294967296.0) : 0x5EED0001ull;
-    cc->initialize(chain_llike, chain_prior, 1, seed);
+    int dn = dump_n;
+    if (dn > Nptc || dn <= 0) dn = Nptc;   // ptmcmc.cc:458
+    cc->keep_history(2 + 2 * Nevery / std::max(1, save_every), dn);
+    cc->set_replicas(nreplicas);
+    if (pt_evolve_rate > 0) cc->evolve_temps(pt_evolve_rate, pt_evolve_lpost_cut);   // ptmcmc.cc:512
+    int kind; double odf; std::vector<double> f;
+    const int dim = chain_prior->getDim();
+    const bool host = !cprop->device_describe(dim, kind, f, odf) && !dynamic_cast<user_gaussian_prop*>(cprop);
+    cc->use_host_proposals(host);
+    cc->initialize(chain_llike, chain_prior, host ? Ninit : 1, ProbabilityDist::nextLadderSeed());
     cc->set_proposal(*cprop);
     return 0;
   }
+
   // ptmcmc_sampler::run (ptmcmc.cc:530-679): step; every "nevery" steps append what the coldest pt_dump_n chains saved
   // since the last report to <base>_t<k>.dat (k = 0 the coldest), as dumpChain writes it
-  int run(const std::string& base, int ic = 0) {
-    (void)ic;
-    const int Nstep = (int)num("nsteps"), Nevery = std::max(1, (int)num("nevery")), Nskip = std::max(1, (int)num("nskip"));
-    int dump_n = (int)num("pt_dump_n");
-    if (dump_n > cc->multiplicity() || dump_n <= 0) dump_n = cc->multiplicity();   // ptmcmc.cc:458
-    const int nrep = cc->replicas();
-    const int checkp_at_step = (int)num("checkp_at_step");
-    const std::string restart_dir = opt.at("restart_dir");
-    const bool restarting = !restart_dir.empty();
+  int run(const std::string& base, int ic = 0) override {
+    if (!have_cc && chain_Nstep > 0) { std::cout << "ptmcmc_sampler::run.  Must call initialize() before running!" << std::endl; exit(1); }
+    if (ic > 0 && restarting) { std::cout << "ptmcmc_sampler::run: Can't restart except for single chain ic=0." << std::endl; exit(1); }
+    int dn = dump_n;
+    if (dn > cc->multiplicity() || dn <= 0) dn = cc->multiplicity();   // ptmcmc.cc:458
+    const int nrep = cc->replicas(), every = std::max(1, Nevery), skip = std::max(1, Nskip);
+    std::ios_base::openmode mode = std::ios::out;
+    if (ic > 0 || restarting) mode = mode | std::ios::app;   // ptmcmc.cc:538
     std::vector<std::unique_ptr<std::ofstream> > out;
     for (int w = 0; w < nrep; w++)
-      for (int ich = 0; ich < dump_n; ich++) {   // ptmcmc.cc:547-554; replica w > 0: <base>_c<w>_t<ich>.dat
+      for (int ich = 0; ich < dn; ich++) {   // ptmcmc.cc:547-554; replica w > 0: <base>_c<w>_t<ich>.dat
         std::ostringstream ss;
         ss << base;
         if (w > 0) ss << "_c" << w;
         ss << "_t" << ich << ".dat";
-        // a restarted run goes on writing where the first part stopped (ptmcmc.cc:538)
-        out.emplace_back(new std::ofstream(ss.str().c_str(), restarting ? std::ios::out | std::ios::app : std::ios::out));
-        out.back()->precision(13);
+        out.emplace_back(new std::ofstream(ss.str().c_str(), mode));
+        out.back()->precision(output_precision);
       }
+    std::cout << "\nRunning chain " << ic << " for up to " << chain_Nstep << " steps." << std::endl;
+    chain_llike->reset();   // ptmcmc.cc:558
     int istep0 = 0;
     if (restarting) istep0 = restart(restart_dir);   // ptmcmc.cc:564
-    for (int istep = istep0; istep <= Nstep; istep++) {   // ptmcmc.cc:565,599-607
+    for (istep = istep0; istep <= chain_Nstep; istep++) {   // ptmcmc.cc:565,599-607
       if (istep == checkp_at_step) {   // ptmcmc.cc:567,593-596: write the checkpoint and stop
         std::cout << "Checkpointing triggered." << std::endl;
         checkpoint(".", istep);
         return 0;
       }
       cc->step();
-      if (0 == istep % Nevery)
+      bool stop = false;
+      if (0 == istep % every) {
+        std::cout << "chain " << ic << " step " << istep << std::endl;
+        std::cout << "   MaxPosterior=" << chain_llike->bestPost() << std::endl;
         for (int w = 0; w < nrep; w++)
-          for (int ich = 0; ich < dump_n; ich++) cc->dumpChain(ich, *out[(size_t)w * dump_n + ich], istep - Nevery + 1, Nskip, w);
+          for (int ich = 0; ich < dn; ich++) cc->dumpChain(ich, *out[(size_t)w * dn + ich], istep - every + 1, skip, w);
+        if (0 == istep % (every * 4)) {   // ptmcmc.cc:620-651
+          std::cout << "Proposal report:\n" << cc->report_prop(1) << "\nacceptance report:\n" << cc->report_prop(0) << std::endl;
+        }
+      }
+      if (stop) break;
     }
     for (size_t k = 0; k < out.size(); k++) *out[k] << "\n" << std::endl;   // ptmcmc.cc:665
+    std::cout << "Finished running chain " << ic << "." << std::endl;
+    return 0;
+  }
+  // ptmcmc_sampler::analyze (ptmcmc.cc:681-755): the 1-sigma sample files of the reference need bayes_likelihood::write /
+  // writeFine (signal / data modelling, out of this build's scope); what remains is its summary line
+  int analyze(const std::string& base, int ic, int Nsigma, int Nbest, bayes_likelihood& like) override {
+    (void)base; (void)Nsigma; (void)Nbest; (void)like;
+    if (!have_cc) { std::cout << "ptmcmc_sampler::analyze.  Must call initialize() before analyze()!" << std::endl; exit(1); }
+    std::cout << "chain " << ic << ": best_post " << chain_llike->bestPost() << ", state=" << chain_llike->bestState().get_string() << std::endl;
     return 0;
   }
   parallel_tempering_chains* chains() { return cc.get(); }
