@@ -1413,7 +1413,7 @@ class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:
   };
   std::vector<mirror_t> mirror;        // [i*W + w]
   std::vector<int64_t> mirror_seen;    // device ring rows already copied (row numbers < this)
-  int Ninit_rows = 1;
+  int Ninit_rows = 1, Ninit_asked = 1;   // initial rows in the mirror / initial draws initialize() was asked for
   std::vector<std::vector<double> > init_x;            // the extra initial draws of initialize(n > 1): [k][chain*dim]
   std::vector<std::vector<double> > init_ll, init_lp;  // [k][chain]
 
@@ -1734,7 +1734,7 @@ class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:
   void use_host_proposals(bool on = true) { want_host = on; }
   void initialize(bayes_likelihood* log_likelihood, const sampleable_probability_function* log_prior, int n = 1, uint64_t seed = 0x5EED0001ull,
                   const std::vector<double>* start_states = nullptr) {
-    init_like = log_likelihood; init_prior = log_prior; Ninit_rows = n < 1 ? 1 : n; eng_seed = seed;
+    init_like = log_likelihood; init_prior = log_prior; Ninit_asked = n < 1 ? 1 : n; eng_seed = seed;
     have_start = start_states != nullptr;
     if (have_start) init_start = *start_states;
     build_engine(want_host);
@@ -1748,6 +1748,7 @@ class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:
     sp = log_prior->get_space();
     dim = log_prior->getDim();
     host_mode = host;
+    Ninit_rows = host ? Ninit_asked : 1;
     // host-side proposals: every rung's saved rows pass through a SHORT device ring into the host mirror after each step
     ring_rows = host ? 8 : hist_rows;
     ring_rungs = host ? Ntemps : history_rungs();
@@ -1818,8 +1819,6 @@ class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:
         }
       }
       sync_history();   // row 0 of the ring: the start state
-    } else {
-      Ninit_rows = 1;
     }
   }
 
