@@ -77,6 +77,77 @@ __device__ __forceinline__ int xcd_walker(int b, int W) {
   return xcd * q + (xcd < rem ? xcd : rem) + (b >> 3);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Partition of a sweep's chains (lean MFMA build on big populations): ~1/6 of a long ladder's chains took part in an exchange
+// attempt this step and make no Metropolis move (chain.cc:1553-1557).  Riding along they cost a full chain's arithmetic (the
+// kernel is bound by instruction issue, not by memory).  This pass packs, for every local rung, the walkers that DO move into
+// cidx[rl * W ..) (any order: a chain's random stream is keyed by its identity, not by its place) and settles the others --
+// one add_state per attempt, nothing to record in this build -- so the sweep visits moving chains only.
+// One block per rung (and 16384 walkers): 16 touch bytes per thread in one load, a block-wide prefix count, one atomic per block.
+// ------------------------------------------------------------------------------------------------
+constexpr int PART_CHUNK = 16384;   // walkers per block: 1024 threads x 16 touch bytes (one 16-byte load each)
+// nhist is NOT advanced here or by the compacted sweep for the chains that make exactly one add_state call this step (every
+// moving chain, every rung exchanged once): the engine counts those steps and adds them to all of nhist in one pass when
+// somebody needs the array (nhist_flush_kernel).  Only a rung exchanged twice in the step gets its extra add at once.
+__global__ __launch_bounds__(1024) void partition_kernel(int W, int rung0, int nchunk, unsigned char* __restrict__ touch,
+                                                         unsigned int* __restrict__ nhist, int* __restrict__ cidx, int* __restrict__ ccnt) {
+  extern __shared__ int plist[];   // [PART_CHUNK] the block's listed walkers, then written out in one coalesced sweep
+  __shared__ int wsum[16];
+  __shared__ int sbase, stotal;
+  const int rl = rung0 + blockIdx.x / nchunk, ch = blockIdx.x % nchunk;
+  const int w0 = ch * PART_CHUNK + threadIdx.x * 16;      // this thread's 16 walkers (W is a multiple of 64: all or none)
+  const size_t c0 = (size_t)rl * W + w0;
+  uint4 v = make_uint4(0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u);   // past the end: "touched", nothing to list
+  const bool in = w0 < W;
+  if (in) v = *reinterpret_cast<const uint4*>(touch + c0);
+  const unsigned int word[4] = {v.x, v.y, v.z, v.w};
+  int mine = 0;
+  unsigned int zmask = 0, twice = 0;   // bit k: walker w0 + k moves / was exchanged twice
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const unsigned int t = (word[k >> 2] >> (8 * (k & 3))) & 0xFFu;
+    zmask |= (t == 0u ? 1u : 0u) << k;
+    twice |= (t > 1u ? 1u : 0u) << k;
+    mine += t == 0u ? 1 : 0;
+  }
+  // block-wide exclusive prefix of `mine`: inclusive scan inside the wave (shuffles), then the 16 wave totals
+  int incl = mine;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int up = __shfl_up(incl, d, 64);
+    if ((int)(threadIdx.x & 63) >= d) incl += up;
+  }
+  if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int k = 0; k < 16; ++k) { const int t = wsum[k]; wsum[k] = run; run += t; }
+    stotal = run;
+    sbase = run ? atomicAdd(&ccnt[rl], run) : 0;    // (several chunks of a long rung share the rung's list)
+  }
+  __syncthreads();
+  if (in) {
+    int pos = wsum[threadIdx.x >> 6] + incl - mine;
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+      if ((zmask >> k) & 1u) plist[pos++] = w0 + k;
+    if (zmask != 0xFFFFu) *reinterpret_cast<uint4*>(touch + c0) = make_uint4(0, 0, 0, 0);
+    if (twice) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k)
+        if ((twice >> k) & 1u) nhist[c0 + k] += ((word[k >> 2] >> (8 * (k & 3))) & 0xFFu) - 1u;
+    }
+  }
+  __syncthreads();
+  int* out = cidx + (size_t)rl * W + sbase;
+  for (int i = threadIdx.x; i < stotal; i += 1024) out[i] = plist[i];
+}
+// adds `n` to every chain's add_state counter (the steps the compacted sweep did not count one by one)
+__global__ __launch_bounds__(256) void nhist_flush_kernel(unsigned int* __restrict__ nhist, size_t Nc, unsigned int n) {
+  const size_t c = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (c < Nc) nhist[c] += n;
+}
+
 constexpr int MVCAP = 256;  // rows one ladder can move per step on the register path (move_kernel)
 typedef double d2_t __attribute__((ext_vector_type(2)));  // (HIP's double2 struct does not stay in registers as an array)
 

@@ -94,6 +94,12 @@ struct ptm_engine {
   ptm_propose_batch_fn pcb = nullptr;
   ptm_proposal_result_fn pres = nullptr;
   void* pcb_user = nullptr;
+  // compacted sweep (partition_kernel): per-rung lists of the walkers that move, their counts; touched = an exchange phase
+  // ran since the last sweep
+  int *cidx = nullptr, *ccnt = nullptr;
+  bool touched = false;
+  bool compact_step = false;   // this step's (partial) sweeps are compacted
+  unsigned int nhist_pending = 0;   // steps whose one-add-per-chain the compacted sweep left uncounted (flush_nhist)
   double* hastings = nullptr;
   int* htype = nullptr;
   unsigned char *hvalid = nullptr, *acc_out = nullptr;
@@ -276,7 +282,7 @@ extern "C" int ptm_engine_destroy(ptm_engine* e) {
   (void)hipStreamSynchronize(e->stream);
   void* ptrs[] = {e->x, e->ll, e->lp, e->ntries, e->naccept, e->last_type, e->arr_below, e->arr_above, e->mv_src, e->mv_dst, e->mv_n,
                   e->err, e->nhist, e->swap_cnt, e->touch, e->swap_log, e->hist.x, e->hist.ll, e->hist.lp, e->hist.meta, e->map.lpost, e->map.ll, e->map.lp, e->map.x, e->blo,
-                  e->bhi, e->ptype, e->bmin, e->bmax, e->plo, e->phi, e->pcoef, e->P2, e->mean, e->beta, e->prop, e->prop_tiles, e->P2_tiles, e->box_row, e->onedfrac, e->mix, e->beta_w, e->betaC, e->beta_add, e->hist.beta, e->xprop, e->lprior_new, e->llike_new, e->hastings, e->htype, e->hvalid, e->acc_out};
+                  e->bhi, e->ptype, e->bmin, e->bmax, e->plo, e->phi, e->pcoef, e->P2, e->mean, e->beta, e->prop, e->prop_tiles, e->P2_tiles, e->box_row, e->onedfrac, e->mix, e->beta_w, e->betaC, e->beta_add, e->hist.beta, e->xprop, e->lprior_new, e->llike_new, e->hastings, e->htype, e->hvalid, e->acc_out, e->cidx, e->ccnt};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (hipEvent_t ev : e->kev) (void)hipEventDestroy(ev);
@@ -710,6 +716,15 @@ static SweepSel sweep_sel(const ptm_engine* e) {
   return s;
 }
 
+// the compacted sweep counts a step's add_state calls for all chains at once: bring nhist up to date before anything reads it
+static int flush_nhist(ptm_engine* e) {
+  if (!e->nhist_pending) return PTM_OK;
+  hipLaunchKernelGGL(nhist_flush_kernel, dim3((unsigned)(((size_t)e->Nc + 255) / 256)), dim3(256), 0, e->stream, e->nhist, (size_t)e->Nc, e->nhist_pending);
+  HIPCHK(hipGetLastError());
+  e->nhist_pending = 0;
+  return PTM_OK;
+}
+
 // one fused MH sweep over local rungs [rung0, rung0 + nr); `last` closes the step (the step count is the RNG position)
 static int launch_sweep(ptm_engine* e, int rung0 = 0, int nr = -1, bool last = true) {
   Dev p = make_dev(e);
@@ -717,7 +732,11 @@ static int launch_sweep(ptm_engine* e, int rung0 = 0, int nr = -1, bool last = t
   if (rung0 < 0 || nr < 0 || rung0 + nr > e->nloc) return fail(PTM_ERR_INVALID, "rung range out of the shard");
   p.c_begin = rung0 * e->W; p.c_end = (rung0 + nr) * e->W;
   if ((e->cb || e->pcb) && (rung0 != 0 || nr != e->nloc)) return fail(PTM_ERR_UNSUPPORTED, "partial sweeps with a host-callback likelihood or host-side proposals are not built");
-  if (nr == 0) { if (last) e->step += 1; return PTM_OK; }
+  auto close_step = [&]() {
+    e->step += 1; e->touched = false;
+    if (e->compact_step) { e->nhist_pending += 1; e->compact_step = false; }
+  };
+  if (nr == 0) { if (last) close_step(); return PTM_OK; }
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   if (e->cfg.time_kernels) {
     if (e->kev_used + 2 > e->kev.size()) {
@@ -728,6 +747,22 @@ static int launch_sweep(ptm_engine* e, int rung0 = 0, int nr = -1, bool last = t
     HIPCHK(hipEventRecord(ev0, e->stream));
   }
   const SweepSel sel = sweep_sel(e);
+  // Compacted sweep: after an exchange phase ~1/6 of a long ladder's chains make no move; the lean MFMA build on a big
+  // population then visits the moving chains only (partition_kernel packs them per rung).  PTM_COMPACT=0 switches it off.
+  static const bool compact_ok = [] { const char* v = getenv("PTM_COMPACT"); return !(v && *v == '0'); }();
+  const bool compact = compact_ok && e->touched && e->DP == 32 && sel.simple && !e->hist.rungs && !e->map.rungs && !getenv("PTM_FORCE_VALU") &&
+                       e->W >= 1024 && e->nloc <= 4096;   // (the same answer for every partial sweep of a step)
+  if (!compact) { int rc = flush_nhist(e); if (rc) return rc; }
+  if (compact) {
+    if (!e->cidx) { int rc; if ((rc = dalloc(&e->cidx, (size_t)e->Nc)) || (rc = dalloc(&e->ccnt, (size_t)e->nloc))) return rc; }
+    HIPCHK(hipMemsetAsync(e->ccnt + rung0, 0, (size_t)nr * sizeof(int), e->stream));
+    const int nchunk = (e->W + PART_CHUNK - 1) / PART_CHUNK;
+    hipLaunchKernelGGL(partition_kernel, dim3((unsigned)((size_t)nr * nchunk)), dim3(1024), (size_t)PART_CHUNK * sizeof(int), e->stream, e->W, rung0, nchunk, e->touch, e->nhist,
+                       e->cidx, e->ccnt);
+    e->compact_step = true;   // (every partial sweep of this step goes the same way: the step is counted once, at its end)
+    HIPCHK(hipGetLastError());
+    p.cidx = e->cidx; p.ccnt = e->ccnt;
+  }
   auto launch = [&](const Dev& q) -> hipError_t {
     switch (e->DP) {
       case 4: return launch_sweep_4(q, sel, e->stream);
@@ -802,7 +837,7 @@ static int launch_sweep(ptm_engine* e, int rung0 = 0, int nr = -1, bool last = t
     e->pres(e->pcb_user, (int)npick, e->p_rung.data(), e->p_walker.data(), e->p_acc.data());
   }
   if (ev1) HIPCHK(hipEventRecord(ev1, e->stream));
-  if (last) e->step += 1;
+  if (last) close_step();
   return PTM_OK;
 }
 
@@ -850,6 +885,7 @@ static int launch_decide(ptm_engine* e, const double* ll_below, const double* ll
   p.lp_is_const = e->lp_is_const ? 1 : 0; p.lp_const = e->lprior_const;
   const bool beta_direct = e->evolve_rate > 0 && e->W <= 64;   // few ladders: the exchange kernel scatters the new temperatures itself
   p.betaC_direct = beta_direct ? e->betaC : nullptr;
+  e->touched = true;
   const int WN = e->nloc + (ll_below ? 1 : 0) + p.H;
   const bool evb = e->evolve_rate > 0 && e->beta_add;
   const size_t lds = decide_lds_bytes(e->Nt, e->ms, WN, e->evolve_rate > 0, evb);
@@ -896,6 +932,7 @@ static int launch_install(ptm_engine* e, const double* recv_below, const double*
   Install q;
   q.DP = e->DP; q.W = e->W; q.row_cap = e->row_cap; q.x = e->x; q.ll = e->ll; q.lp = e->lp;
   q.recv_below = recv_below; q.recv_above = recv_above; q.arr_below = e->arr_below; q.arr_above = e->arr_above; q.err = e->err;
+  e->touched = true;
   hipLaunchKernelGGL(install_kernel, dim3((e->row_cap + 15) / 16, 2), dim3(256), 0, e->stream, q);
   HIPCHK(hipGetLastError());
   return PTM_OK;
@@ -933,6 +970,7 @@ static int reset_counters(ptm_engine* e) {
       (rc = upload(e->last_type, m1.data(), Nc, e->stream)) ||
       (rc = upload(e->nhist, z.data(), Nc, e->stream)))                                                        // chain.cc:871-875
     return rc;
+  e->nhist_pending = 0; e->compact_step = false; e->touched = false;
   HIPCHK(hipMemsetAsync(e->touch, 0, Nc, e->stream));
   HIPCHK(hipMemsetAsync(e->arr_below, 0xFF, (size_t)e->W * 4, e->stream));
   HIPCHK(hipMemsetAsync(e->arr_above, 0xFF, (size_t)e->W * 4, e->stream));
@@ -1210,6 +1248,8 @@ extern "C" int ptm_get_array(ptm_engine* e, int which, void* out) {
     case PTM_ARR_LAST_TYPE: HIPCHK(hipMemcpy(out, e->last_type, Nc * 4, hipMemcpyDeviceToHost)); break;
     case PTM_ARR_NHIST:
     case PTM_ARR_NSIZE: {
+      { int rc = flush_nhist(e); if (rc) return rc; }
+      HIPCHK(hipStreamSynchronize(e->stream));
       std::vector<unsigned int> h(Nc);
       HIPCHK(hipMemcpy(h.data(), e->nhist, Nc * 4, hipMemcpyDeviceToHost));
       int64_t* o = (int64_t*)out;
@@ -1381,10 +1421,13 @@ extern "C" const char* ptm_sweep_kernel_name(ptm_engine* e) {
   if (!e) return "";
   char b[96];
   const SweepSel s = sweep_sel(e);
-  if (e->DP == 32 && s.uni && !s.callback && !s.host_prop)
-    snprintf(b, sizeof b, "sweep_mfma32_kernel<%d, %s, %d%s>", s.kind == KIND_DIAG ? KIND_LOWER : s.kind, (e->hist.rungs || e->map.rungs) ? "true" : "false",
+  if (e->DP == 32 && s.uni && !s.callback && !s.host_prop) {
+    const char* cv = getenv("PTM_COMPACT");
+    const bool cpt = !(cv && *cv == '0') && s.simple && !e->hist.rungs && !e->map.rungs && e->W >= 1024 && e->nloc <= 4096;   // (in PT steps; plain sweeps visit every chain)
+    snprintf(b, sizeof b, "sweep_mfma32_kernel<%d, %s, %d%s, %s>", s.kind == KIND_DIAG ? KIND_LOWER : s.kind, (e->hist.rungs || e->map.rungs) ? "true" : "false",
              s.simple ? 0 : ((e->all_uniform && (!e->has_bounds || e->bounds_box)) ? 1 : 2),
-             (!s.simple && e->all_uniform && (!e->has_bounds || e->bounds_box) && e->betaC) ? ", true" : ", false");   // as rocprofv3 prints it
+             (!s.simple && e->all_uniform && (!e->has_bounds || e->bounds_box) && e->betaC) ? ", true" : ", false", cpt ? "true" : "false");   // as rocprofv3 prints it
+  }
   else if (e->DP == 64 || s.host_prop || (!s.uni && !getenv("PTM_FORCE_VALU") && (long long)e->Nc * e->DP <= (e->DP >= 16 ? PTM_LANES_MAX : 4096ll * e->DP)))
     snprintf(b, sizeof b, "sweep_lanes_kernel<%d, %d, %s>", e->DP, s.kind, s.plain ? "false" : "true");
   else snprintf(b, sizeof b, "sweep_kernel<%d, %d, %s, %s>", e->DP, s.kind, s.uni ? "true" : "false", s.simple ? "true" : "false");

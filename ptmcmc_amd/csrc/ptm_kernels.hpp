@@ -134,6 +134,10 @@ struct Dev {
   const double* llike_new;  // [Nc] filled by the host for gated chains
   // host-side proposals (ptm_set_proposal_callback; lanes kernel, general build): the proposed states arrive in xprop
   // (whole states, row layout) with their log-Hastings ratio, type code and validity; acc_out gets the outcome
+  // compacted sweep (lean MFMA build, ptm_mfma_kernel.hpp): per local rung the walkers that make a Metropolis move this
+  // step, packed at cidx[rl * W ..) by partition_kernel; ccnt[rl] of them.  null: every chain is visited in place.
+  const int* cidx;
+  const int* ccnt;
   uint64_t init_base;            // init_prior_kernel: first attempt number of this initial draw (ptm_init_from_prior_k)
   int host_prop;
   const double* hastings;        // [Nc]

@@ -44,8 +44,12 @@ typedef double mf_d2 __attribute__((ext_vector_type(2)));
 // All of the general work is per dimension, so it runs in the accumulator layout as it stands: a lane enforces and
 // prices its own eight dimensions of each chain, and the chain's four lanes meet in two more LDS reductions / ballots.
 // EV: a GEN 1 build that reads a per-chain beta (evolving ladders; the GEN 2 build always can)
-template <int KIND, bool HIST, int GEN, bool EV = false>   // GEN: 0 lean, 1 box boundaries + uniform prior (+ mean, 1-D moves), 2 everything
+// CPT (lean build only): the sweep visits the moving chains alone, through the per-rung lists of partition_kernel
+// (ptm_kernels.hpp) -- tiles of 256 LISTED walkers of one rung, enumerated rung by rung; lane l of a wave works for the l-th
+// listed walker of its group instead of walker w0 + l.
+template <int KIND, bool HIST, int GEN, bool EV = false, bool CPT = false>   // GEN: 0 lean, 1 box boundaries + uniform prior (+ mean, 1-D moves), 2 everything
 __global__ __launch_bounds__(256, PTM_MFMA_WAVES) void sweep_mfma32_kernel(const Dev p) {
+  static_assert(!CPT || (GEN == 0 && !HIST && !EV), "the compacted sweep exists for the lean build");
   constexpr int DP = 32;
   constexpr bool LOW = KIND == KIND_LOWER;
   // LDS: [2560] Box-Muller tables | [12][64] precision tiles | [64] prior box (all shared by the block's waves) |
@@ -106,15 +110,64 @@ __global__ __launch_bounds__(256, PTM_MFMA_WAVES) void sweep_mfma32_kernel(const
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   }
 
-  const int ntiles = (p.c_end - p.c_begin + 255) >> 8;   // 256-chain tiles of this launch (ranges are multiples of 64)
+  // CPT: the launch's rungs, their listed-walker counts as an inclusive prefix of 256-walker tiles (LDS, after everything else)
+  const int rung0 = p.c_begin / p.W, nrung = (p.c_end - p.c_begin) / p.W;
+  int* tpre = reinterpret_cast<int*>(ebox + 64);   // [nrung] (CPT; the host sizes the LDS for it)
+  int ntiles = (p.c_end - p.c_begin + 255) >> 8;   // 256-chain tiles of this launch (ranges are multiples of 64)
+  if constexpr (CPT) {
+    // inclusive scan of ceil(count / 256) over the rungs: each thread sums a contiguous chunk, one wave scans the chunk totals
+    const int per = (nrung + 255) / 256;
+    int loc = 0;
+    for (int k = 0; k < per; ++k) {
+      const int r = threadIdx.x * per + k;
+      if (r < nrung) { loc += (p.ccnt[rung0 + r] + 255) >> 8; tpre[r] = loc; }
+    }
+    int* tsum = tpre + nrung;                       // [256] chunk totals -> exclusive offsets
+    tsum[threadIdx.x] = loc;
+    __syncthreads();
+    if (threadIdx.x == 0) { int run = 0; for (int t = 0; t < 256; ++t) { const int v = tsum[t]; tsum[t] = run; run += v; } tsum[256] = run; }
+    __syncthreads();
+    const int off = tsum[threadIdx.x];
+    for (int k = 0; k < per; ++k) {
+      const int r = threadIdx.x * per + k;
+      if (r < nrung) tpre[r] += off;
+    }
+    __syncthreads();
+    ntiles = tsum[256];
+  }
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-  const int c0 = p.c_begin + (tile * 4 + wave) * 64;   // first chain of the wave
-  if (c0 >= p.c_end) continue;                           // (only wave-level barriers below)
+  int c0, rl, w0, nact = 64, lbase = 0;
+  if constexpr (CPT) {
+    // the rung of compacted tile `tile`: first r with tpre[r] > tile (wave-uniform binary search in LDS)
+    int lo = 0, hi = nrung - 1;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (tpre[mid] > tile) hi = mid; else lo = mid + 1; }
+    const int r = __builtin_amdgcn_readfirstlane(lo);
+    const int kb = tile - (r ? tpre[r - 1] : 0);
+    rl = rung0 + r;
+    const int start = (kb * 4 + wave) * 64, cnt = p.ccnt[rl];
+    if (start >= cnt) continue;                        // (only wave-level barriers below)
+    nact = cnt - start < 64 ? cnt - start : 64;
+    lbase = rl * p.W + start;                           // this wave's slice of the rung's list
+    c0 = rl * p.W; w0 = 0;
+  } else {
+    c0 = p.c_begin + (tile * 4 + wave) * 64;   // first chain of the wave
+    if (c0 >= p.c_end) continue;                           // (only wave-level barriers below)
+    rl = __builtin_amdgcn_readfirstlane(c0 / p.W);
+    w0 = c0 - rl * p.W;
+  }
   const int c0s = c0;
-  const int rl = __builtin_amdgcn_readfirstlane(c0s / p.W);
-  const int w0 = c0s - rl * p.W;
   const int rg = p.r0 + rl;
-  const int c = c0s + l;   // "my" chain for the per-chain work
+  // walker of wave-chain index i (0..63): listed (CPT; lanes past the list shadow its last entry and write nothing) or in place
+  auto walker_of = [&](int i) -> int {
+    if constexpr (CPT) return p.cidx[lbase + (i < nact ? i : nact - 1)];
+    else return w0 + i;
+  };
+  const int wl = walker_of(l);
+  const bool dead = CPT && l >= nact;
+  const int c = CPT ? rl * p.W + wl : c0s + l;   // "my" chain for the per-chain work
+  int wq[4];   // the walkers this lane works for in the matrix products: chain 16 g + j of the wave, g = 0..3
+#pragma unroll
+  for (int g = 0; g < 4; ++g) wq[g] = walker_of(16 * g + j);
   const double* timg = p.prop_tiles + (size_t)rl * (16 * 64) + l;   // tile t = (half*4 + slot)*2 + row tile
 
   // A tile's 64 chains are worked in two passes of two 16-chain groups (g = 2 gp + gg): every live set is halved.
@@ -123,24 +176,24 @@ __global__ __launch_bounds__(256, PTM_MFMA_WAVES) void sweep_mfma32_kernel(const
   auto ask_rows = [&](int gpp, mf_d2 (&rv)[2][4], mf_d2* (&rp)[2]) {
 #pragma unroll
     for (int gg = 0; gg < 2; ++gg) {
-      rp[gg] = reinterpret_cast<mf_d2*>(p.x + (size_t)(c0s + 16 * (2 * gpp + gg) + j) * DP) + q;   // piece t at [4t]
+      rp[gg] = reinterpret_cast<mf_d2*>(p.x + ((size_t)rl * p.W + wq[2 * gpp + gg]) * DP) + q;   // piece t at [4t]
 #pragma unroll
       for (int t = 0; t < 4; ++t) rv[gg][t] = rp[gg][4 * t];
     }
   };
   ask_rows(0, rowv, rowp);
   // per-chain scalars: used at the very end
-  const int tc = p.touch[c];  // > 0: the rung took part in that many exchange attempts => no MH move this step
+  const int tc = CPT ? 0 : p.touch[c];  // > 0: the rung took part in that many exchange attempts => no MH move this step
   const double ll = p.ll[c], lp = p.lp[c];
   const int ntries0 = p.ntries[c], naccept0 = p.naccept[c];
-  const unsigned int nhist0 = p.nhist[c];
+  const unsigned int nhist0 = CPT ? 0u : p.nhist[c];
   // (a per-chain beta in the plain GEN 1 build would cost its fixed-ladder users 4 %: evolving ladders have their own)
   constexpr bool PERCHAIN = GEN == 2 || EV;
   const double beta = (PERCHAIN && p.betaC) ? p.betaC[c] : as_c(p.beta)[rg];
   // log of the chain's accept uniform (block 0 of its stream): drawn here once for all 64 chains -- the Metropolis test
   // itself runs per pass on half the lanes, and this is its expensive part.  (The reference draws the uniform only when
   // logH < 0, chain.cc:998; a counter-based stream makes the draw free of side effects, so drawing it always is the same.)
-  const u32x4 o0 = draw_block(p.seed, TAG_MH, (uint32_t)(w0 + l) * (uint32_t)p.Nt + (uint32_t)rg, p.step, 0);
+  const u32x4 o0 = draw_block(p.seed, TAG_MH, (uint32_t)wl * (uint32_t)p.Nt + (uint32_t)rg, p.step, 0);
   const double log_u = dlog_u01(o0.v0);
   // one-dimensional move of "my" chain (proposal_distribution.hh:196-206): its axis, or -1
   int my_axis = -1, my_kmix = 0;
@@ -200,7 +253,7 @@ __global__ __launch_bounds__(256, PTM_MFMA_WAVES) void sweep_mfma32_kernel(const
       double z[2][4];
 #pragma unroll
       for (int gg = 0; gg < 2; ++gg) {
-        const uint32_t stream = (uint32_t)(w0 + 16 * (2 * gp + gg) + j) * (uint32_t)p.Nt + (uint32_t)rg;
+        const uint32_t stream = (uint32_t)wq[2 * gp + gg] * (uint32_t)p.Nt + (uint32_t)rg;
         const u32x4 o = draw_block(p.seed, TAG_MH, stream, p.step, (uint32_t)(1 + 4 * hb + q));
 #if defined(PTM_ABLATE) && (PTM_ABLATE & 1)   // timing experiment: no Box-Muller
         z[gg][0] = u01(o.v0); z[gg][1] = u01(o.v1); z[gg][2] = u01(o.v2); z[gg][3] = u01(o.v3);
@@ -335,7 +388,7 @@ __global__ __launch_bounds__(256, PTM_MFMA_WAVES) void sweep_mfma32_kernel(const
     bool mapw = false;   // this add_state call sets a new MAP (chain.cc:931-934): the row is copied below
     const bool hist_on = HIST && rl < p.hist.rungs;
     const bool map_on = HIST && rl < p.map.rungs;
-    if ((q >> 1) == gp) {
+    if ((q >> 1) == gp && !dead) {
       const double* mine = red + ((q & 1) * 4) * 16 + j;
       const double quad = ((mine[0] + mine[16]) + mine[32]) + mine[48];
       if (tc) {
@@ -375,7 +428,7 @@ __global__ __launch_bounds__(256, PTM_MFMA_WAVES) void sweep_mfma32_kernel(const
         int type = (GEN && my_axis >= 0) ? 1 : 0;
         if (GEN && p.mix_K > 0) type = my_kmix + 10 * type;   // proposal_distribution.cc:117
         p.ntries[c] = ntries0 + 1;
-        p.nhist[c] = nhist0 + 1u;
+        if (!CPT) p.nhist[c] = nhist0 + 1u;   // (compacted: the engine counts the step for everybody, ptm_aux_kernels.hpp)
         if (hist_on && nhist0 % (unsigned int)p.add_every_n == 0u) {
           hrow = 1 + (int)(nhist0 / (unsigned int)p.add_every_n);
           const size_t o = hist_slot(p.hist, hrow, c);

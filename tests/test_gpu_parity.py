@@ -633,7 +633,7 @@ def test_mfma_kernel_limit_bounds_with_uniform_prior(kind, odf, with_mean):
     mean = rng.normal(size=D) * 0.1 if with_mean else None
     pr, eng, lad = PU.make_pair(D, Nt, W, 1e3, kind=kind, bounds=(blo, bhi, bmin, bmax), prior=prior, swap_rate=0.3, x0=x0, mean=mean,
                                 one_d_frac=(odf if odf > 0 else None))
-    assert eng.sweep_kernel_name.endswith(", 1, false>")
+    assert eng.sweep_kernel_name.endswith(", 1, false, false>")
     for k in range(5):
         eng.step(4); eng.sync(); lad.pt_step(4)
         PU.assert_same_state(eng, lad, "after %d steps" % (4 * (k + 1)))
@@ -939,3 +939,64 @@ def test_exchange_overflow_path_many_moved_rows():
         moved_max = max(moved_max, int(2 * eng.last_swaps()[1].sum(axis=1).max()))
     assert moved_max > 256, moved_max
     eng.close()
+
+
+@pytest.mark.parametrize("kind", [E.PROP_LOWER, E.PROP_DENSE])
+def test_compacted_sweep_of_big_populations_matches_the_oracle(kind):
+    """From 1024 walkers per rung on, the lean MFMA build visits only the chains that make a move after an exchange phase
+    (partition_kernel + the compacted tile walk), and counts every chain's one add_state of the step lazily.  Same chains as
+    the oracle bit for bit -- with plain sweeps (every chain visited in place, the pending counts flushed first) in between,
+    counters read back mid-run, and a checkpoint / resume across the lazy count."""
+    D, Nt, W, sr = 32, 12, 1024, 0.3
+    pr, eng, lad = PU.make_pair(D, Nt, W, 1e3, kind=kind, swap_rate=sr)
+    assert eng.sweep_kernel_name.endswith(", 0, false, true>")
+    eng.step(3); eng.sync(); lad.pt_step(3)
+    PU.assert_same_state(eng, lad, "after 3 compacted steps")
+    eng.sweep(2); eng.sync(); lad.sweep(2)                  # no exchange phase: nothing to compact
+    PU.assert_same_state(eng, lad, "after plain sweeps")
+    eng.step(4); lad.pt_step(4)
+    ck = eng.checkpoint()                                    # (reads nhist: flushes the lazy count)
+    PU.assert_same_state(eng, lad, "after 7 steps")
+    assert int((eng.nhist > 9).sum()) > 0                    # rungs exchanged twice in one step got their extra add
+    e2 = E.Engine(D, Nt, W, swap_rate=sr)
+    pr.configure(e2, kind)
+    e2.restore(ck)
+    for e in (eng, e2):
+        e.step(5); e.sync()
+    lad.pt_step(5)
+    PU.assert_same_state(eng, lad, "after 12 steps")
+    PU.assert_same_state(e2, lad, "resumed engine after 12 steps")
+    t, a = eng.swap_counts()
+    assert np.array_equal(t, lad.swap_count) and np.array_equal(a, lad.swap_accept_count)
+    eng.close(); e2.close()
+
+
+@pytest.mark.parametrize("overlap", [False, True])
+def test_compacted_sweep_in_sharded_engines(overlap):
+    """the compacted sweep through the sharded step's partial sweeps (interior / boundary rungs separately)"""
+    import shard_sim
+    from ptmcmc_amd.parallel import shard_bounds
+    from ptmcmc_amd.problems import GaussianProblem
+    D, Nt, W, G, sr = 32, 24, 1024, 3, 0.3
+    pr = GaussianProblem(D, Nt, 1e3)
+    ref = E.Engine(D, Nt, W, swap_rate=sr)
+    pr.configure(ref, E.PROP_LOWER)
+    ref.init_from_prior()
+    x0 = ref.states()
+    shards = []
+    for g in range(G):
+        r0, n = shard_bounds(Nt, G, g)
+        e = E.Engine(D, Nt, W, swap_rate=sr, rung_begin=r0, rung_count=n)
+        pr.configure(e, E.PROP_LOWER)
+        e.set_states(x0[r0 * W:(r0 + n) * W])
+        shards.append(e)
+    lads = shard_sim.build([_DevShard(e) for e in shards], halo=4)
+    copy = lambda dst, src: dst.copy_from(src.ptr)
+    for k in range(3):
+        ref.step(4)
+        (shard_sim.step_overlapped if overlap else shard_sim.step)(lads, copy, 4)
+        assert np.array_equal(np.concatenate([e.states() for e in shards]), ref.states()), "states differ after step %d" % (4 * k + 4)
+    for name in ("llike", "ntries", "naccept", "nhist", "last_type"):
+        assert np.array_equal(np.concatenate([getattr(e, name) for e in shards]), getattr(ref, name)), name
+    for e in shards + [ref]:
+        e.close()
