@@ -36,7 +36,13 @@ typedef double mf_d2 __attribute__((ext_vector_type(2)));
 #define PTM_STAGE() __builtin_amdgcn_sched_barrier(0)
 
 #ifndef PTM_MFMA_WAVES
-#define PTM_MFMA_WAVES 3   // waves per SIMD the register budget is cut for
+#define PTM_MFMA_WAVES 3   // waves per SIMD the register budget is cut for (lean build)
+#endif
+#ifndef PTM_MFMA_GEN_WAVES
+#define PTM_MFMA_GEN_WAVES 3   // ... of the general builds
+#endif
+#ifndef PTM_MFMA_GEN_PERSIST
+#define PTM_MFMA_GEN_PERSIST 0   // 1: the general builds walk several tiles per block too (measured: 15-25 % slower -- spills)
 #endif
 // HIST: the engine keeps a history.  GEN > 0: the general state space / prior / target -- boundaries of any kind
 // (boundary::enforce, states.cc:11-58), mixed priors (probability_function.cc:281-304), a mean, one-dimensional moves
@@ -48,7 +54,8 @@ typedef double mf_d2 __attribute__((ext_vector_type(2)));
 // (ptm_kernels.hpp) -- tiles of 256 LISTED walkers of one rung, enumerated rung by rung; lane l of a wave works for the l-th
 // listed walker of its group instead of walker w0 + l.
 template <int KIND, bool HIST, int GEN, bool EV = false, bool CPT = false>   // GEN: 0 lean, 1 box boundaries + uniform prior (+ mean, 1-D moves), 2 everything
-__global__ __launch_bounds__(256, PTM_MFMA_WAVES) void sweep_mfma32_kernel(const Dev p) {
+__global__ __launch_bounds__(256, (GEN == 0 ? PTM_MFMA_WAVES : PTM_MFMA_GEN_WAVES)) void sweep_mfma32_kernel(const Dev p) {
+  constexpr bool PERSIST = GEN == 0 || PTM_MFMA_GEN_PERSIST != 0;
   static_assert(!CPT || (GEN == 0 && !HIST && !EV), "the compacted sweep exists for the lean build");
   constexpr int DP = 32;
   constexpr bool LOW = KIND == KIND_LOWER;
@@ -73,26 +80,28 @@ __global__ __launch_bounds__(256, PTM_MFMA_WAVES) void sweep_mfma32_kernel(const
   // ---- the block's tables: staged ONCE.  The grid is persistent -- a block per resident slot of the chip, each walking
   //      the launch's 256-chain tiles with stride gridDim.x -- so the 26 KB of tables (Box-Muller, precision tiles, box) are
   //      read once per resident block instead of once per 256 chains (65536 times per sweep of the benchmark).
-  {
-    bm_d2 st_bm[BM_TABLE_DOUBLES / 512];
+  //      The general builds keep one tile per block (PERSIST false): their live sets are larger, and there the tables' loads
+  //      travel together with the tile's first rows / scalars and go to LDS only when those have been asked for.
+  bm_d2 st_bm[BM_TABLE_DOUBLES / 512];
 #pragma unroll
-    for (int t = 0; t < BM_TABLE_DOUBLES / 512; ++t) st_bm[t] = reinterpret_cast<const bm_d2*>(BM_TABLE)[threadIdx.x + 256 * t];
-    double st_p[3];
+  for (int t = 0; t < BM_TABLE_DOUBLES / 512; ++t) st_bm[t] = reinterpret_cast<const bm_d2*>(BM_TABLE)[threadIdx.x + 256 * t];
+  double st_p[3];
 #pragma unroll
-    for (int t = 0; t < 3; ++t) {
-      const int e = threadIdx.x + 256 * t, tile = e >> 6;
-      const int src = tile < 8 ? (tile * 2 + 1) : ((tile - 8) * 2 + 0);
-      st_p[t] = p.P2_tiles[src * 64 + (e & 63)];
-    }
-    const double st_box = p.box_row[threadIdx.x & 63];
-    double st_g[6] = {0, 0, 0, 0, 0, 0};
-    int st_i[3] = {0, 0, 0};
-    if (GEN && threadIdx.x < 32) {
-      const int d = threadIdx.x;
-      st_g[0] = p.bmin[d]; st_g[1] = p.bmax[d]; st_g[2] = p.plo[d]; st_g[3] = p.phi[d]; st_g[4] = p.pcoef[d];
-      st_g[5] = p.has_mean ? p.mean[d] : 0.0;
-      st_i[0] = p.blo[d]; st_i[1] = p.bhi[d]; st_i[2] = p.ptype[d];
-    }
+  for (int t = 0; t < 3; ++t) {
+    const int e = threadIdx.x + 256 * t, tile = e >> 6;
+    const int src = tile < 8 ? (tile * 2 + 1) : ((tile - 8) * 2 + 0);
+    st_p[t] = p.P2_tiles[src * 64 + (e & 63)];
+  }
+  const double st_box = p.box_row[threadIdx.x & 63];
+  double st_g[6] = {0, 0, 0, 0, 0, 0};
+  int st_i[3] = {0, 0, 0};
+  if (GEN && threadIdx.x < 32) {
+    const int d = threadIdx.x;
+    st_g[0] = p.bmin[d]; st_g[1] = p.bmax[d]; st_g[2] = p.plo[d]; st_g[3] = p.phi[d]; st_g[4] = p.pcoef[d];
+    st_g[5] = p.has_mean ? p.mean[d] : 0.0;
+    st_i[0] = p.blo[d]; st_i[1] = p.bhi[d]; st_i[2] = p.ptype[d];
+  }
+  auto stage_tables = [&]() {
 #pragma unroll
     for (int t = 0; t < BM_TABLE_DOUBLES / 512; ++t) reinterpret_cast<bm_d2*>(lds_all)[threadIdx.x + 256 * t] = st_bm[t];
 #pragma unroll
@@ -108,7 +117,8 @@ __global__ __launch_bounds__(256, PTM_MFMA_WAVES) void sweep_mfma32_kernel(const
       ebox[32 + pos] = st_i[1] == B_LIMIT ? st_g[1] : __builtin_inf();
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-  }
+  };
+  if (PERSIST) stage_tables();
 
   // CPT: the launch's rungs, their listed-walker counts as an inclusive prefix of 256-walker tiles (LDS, after everything else)
   const int rung0 = p.c_begin / p.W, nrung = (p.c_end - p.c_begin) / p.W;
@@ -137,6 +147,7 @@ __global__ __launch_bounds__(256, PTM_MFMA_WAVES) void sweep_mfma32_kernel(const
   }
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
   int c0, rl, w0, nact = 64, lbase = 0;
+  bool live = true;
   if constexpr (CPT) {
     // the rung of compacted tile `tile`: first r with tpre[r] > tile (wave-uniform binary search in LDS)
     int lo = 0, hi = nrung - 1;
@@ -151,7 +162,10 @@ __global__ __launch_bounds__(256, PTM_MFMA_WAVES) void sweep_mfma32_kernel(const
     c0 = rl * p.W; w0 = 0;
   } else {
     c0 = p.c_begin + (tile * 4 + wave) * 64;   // first chain of the wave
-    if (c0 >= p.c_end) continue;                           // (only wave-level barriers below)
+    if (c0 >= p.c_end) {
+      if (PERSIST) continue;                               // (only wave-level barriers below)
+      c0 = p.c_begin; live = false;                        // one tile per block: a wave past the end still helps to stage the tables
+    }
     rl = __builtin_amdgcn_readfirstlane(c0 / p.W);
     w0 = c0 - rl * p.W;
   }
@@ -212,6 +226,10 @@ __global__ __launch_bounds__(256, PTM_MFMA_WAVES) void sweep_mfma32_kernel(const
     if (p.any_oned && f > 0 && u01(o0.v1) < f) my_axis = (int)(p.D * u01(o0.v2));
   }
 
+  if (!PERSIST) {   // the tables go to LDS behind the tile's first loads; the block meets once
+    stage_tables();
+    if (!live) break;
+  }
   // (a generic lambda called with compile-time pass numbers: `#pragma unroll` gives up on a body of this size in the
   //  general build, and a pass number known only at run time costs dynamic register indexing)
   auto pass = [&](auto gpc) {
@@ -501,6 +519,7 @@ __global__ __launch_bounds__(256, PTM_MFMA_WAVES) void sweep_mfma32_kernel(const
   };
   pass(std::integral_constant<int, 0>{});
   pass(std::integral_constant<int, 1>{});
+  if (!PERSIST) break;   // (one tile per block: the launch gives every tile its own block)
   }   // tiles
 }
 #undef PTM_STAGE
