@@ -188,6 +188,9 @@ def main():
     ap.add_argument("--halo", type=int, default=None, help="llike halo depth (rungs) between shards (default: ptmcmc_amd.parallel.DEFAULT_HALO)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-w1", action="store_true", help="skip the 1024-chain latency companion")
+    ap.add_argument("--shard", choices=("rungs", "walkers"), default="rungs",
+                    help="N > 1: how the population is spread -- contiguous rung blocks with neighbour exchanges over RCCL (BASELINE's "
+                         "configuration, the default), or whole ladders per GPU (no message at all; the form evolving ladders need)")
     ap.add_argument("--force-dist", action="store_true", help="take the torch.distributed path even with one rank (smoke test)")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))

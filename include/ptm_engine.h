@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PTM_ABI_VERSION 1
+#define PTM_ABI_VERSION 2   /* 2: ptm_config.walker_begin (a v1 caller's shorter struct is still accepted: walker_begin = 0) */
 
 typedef struct ptm_engine ptm_engine;
 
@@ -78,6 +78,11 @@ typedef struct ptm_config {
   int32_t history_capacity; /* rows per chain kept on the device (a ring: saved row s sits in slot s % capacity) */
   int32_t map_rungs;        /* >0: track the MAP state MH_chain::add_state keeps (chain.cc:931-934) for the first map_rungs
                              * rungs held by this engine (the ladder's MAP is rung 0's, chain.cc:1570-1571); 0 = off */
+  int32_t walker_begin;     /* (ABI 2) GLOBAL index of this engine's first walker: the engine holds walkers [walker_begin,
+                             * walker_begin + n_walkers) of a larger population of independent ladders, and every random stream
+                             * is keyed by the global walker -- so a population split by WALKERS over several engines / GPUs
+                             * (whole ladders each: no exchange between engines at all, evolving ladders included) gives the
+                             * very chains of one engine holding them all.  0 for a single engine. */
 } ptm_config;
 
 /* user plug-in likelihood, batched: the C shape of bayes_likelihood::register_evaluate_log

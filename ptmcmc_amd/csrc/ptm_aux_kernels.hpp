@@ -26,6 +26,7 @@ __device__ __forceinline__ double* claim_row(double* buf, int cap, int RD, int* 
 
 struct Decide {
   int DP, Nt, r0, nloc, W, Nc, ms;
+  int w_off;                  // global index of local walker 0: the ladder streams are keyed by the global walker
   uint64_t seed, step;
   double thresh;              // (Ntemps-1)*swap_rate/maxswapsperstep (chain.cc:1413)
   const double* beta;         // [Nt]
@@ -227,7 +228,7 @@ __global__ __launch_bounds__(DECIDE_THREADS) void decide_kernel(const Decide p) 
   __syncthreads();
   // -- candidate draws (chain.cc:1410-1416): block k of the ladder stream gives {u_try, u_pick, u_accept}
   for (int k = lane; k < ms; k += DECIDE_THREADS) {
-    const u32x4 o = draw_block(p.seed, TAG_PT, (uint32_t)w, p.step, (uint32_t)k);
+    const u32x4 o = draw_block(p.seed, TAG_PT, (uint32_t)(w + p.w_off), p.step, (uint32_t)k);
     int n = -2;
     if (Nt > 1 && u01(o.v0) < p.thresh) n = (int)(u01(o.v1) * (Nt - 1));
     cand[k] = n;

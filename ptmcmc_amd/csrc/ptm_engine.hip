@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstddef>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -168,7 +169,14 @@ static int fill_evolving_ladders(ptm_engine* e);
 
 extern "C" int ptm_engine_create(const ptm_config* cfg, ptm_engine** out) {
   if (!cfg || !out) return fail(PTM_ERR_INVALID, "null argument");
-  if (cfg->struct_size != sizeof(ptm_config)) return fail(PTM_ERR_INVALID, "ptm_config size mismatch (ABI)");
+  // ABI evolution: a caller built against an older header hands a shorter struct; the fields it does not know are zero
+  ptm_config cfg_full;
+  memset(&cfg_full, 0, sizeof cfg_full);
+  if (cfg->struct_size > sizeof(ptm_config) || cfg->struct_size < offsetof(ptm_config, walker_begin)) return fail(PTM_ERR_INVALID, "ptm_config size mismatch (ABI)");
+  memcpy(&cfg_full, cfg, cfg->struct_size);
+  cfg_full.struct_size = sizeof(ptm_config);
+  cfg = &cfg_full;
+  if (cfg->walker_begin < 0) return fail(PTM_ERR_INVALID, "walker_begin must be >= 0");
   if (cfg->dim < 1) return fail(PTM_ERR_INVALID, "dim must be >= 1");
   if (cfg->dim > 64) return fail(PTM_ERR_UNSUPPORTED, "dim > 64 is not built (kernels exist for padded dimensions 4, 8, 16, 32, 64)");
   if (cfg->n_rungs < 1 || cfg->n_rungs > 65535) return fail(PTM_ERR_INVALID, "n_rungs must be in 1..65535");
@@ -177,7 +185,8 @@ extern "C" int ptm_engine_create(const ptm_config* cfg, ptm_engine** out) {
   if (cfg->n_walkers < 1) return fail(PTM_ERR_INVALID, "n_walkers must be >= 1");
   if (cfg->add_every_n < 1) return fail(PTM_ERR_INVALID, "add_every_n must be >= 1");
   if ((double)cfg->rung_count * cfg->n_walkers > 2.0e9) return fail(PTM_ERR_INVALID, "too many chains for one engine");
-  if ((double)cfg->n_rungs * cfg->n_walkers > 4.0e9) return fail(PTM_ERR_INVALID, "too many chains for 32-bit stream ids");
+  // a chain's random stream id is (global walker) * n_rungs + (global rung), 32 bits
+  if (((double)cfg->walker_begin + cfg->n_walkers) * cfg->n_rungs > 4294967296.0) return fail(PTM_ERR_INVALID, "too many chains for 32-bit stream ids: (walker_begin + n_walkers) * n_rungs must stay below 2^32");
   int rc = need_device();
   if (rc) return rc;
   ptm_engine* e = new ptm_engine();
@@ -684,7 +693,7 @@ extern "C" int ptm_set_proposal_rung(ptm_engine* e, int local_rung, const double
 static Dev make_dev(ptm_engine* e) {
   Dev p;
   memset(&p, 0, sizeof p);
-  p.D = e->D; p.DP = e->DP; p.Nt = e->Nt; p.r0 = e->r0; p.nloc = e->nloc; p.W = e->W; p.Nc = e->Nc;
+  p.D = e->D; p.DP = e->DP; p.Nt = e->Nt; p.r0 = e->r0; p.nloc = e->nloc; p.W = e->W; p.Nc = e->Nc; p.w_off = e->cfg.walker_begin;
   p.seed = e->cfg.seed; p.step = e->step; p.add_every_n = e->cfg.add_every_n; p.min_prior = e->cfg.min_prior;
   p.has_bounds = e->has_bounds; p.origin_valid = e->origin_valid; p.bounds_box = e->bounds_box;
   p.blo = e->blo; p.bhi = e->bhi; p.bmin = e->bmin; p.bmax = e->bmax;
@@ -872,7 +881,7 @@ static int launch_beta_transpose(ptm_engine* e) {
 static int launch_decide(ptm_engine* e, const double* ll_below, const double* ll_above, int H, double* send_up, double* send_down) {
   Decide p;
   memset(&p, 0, sizeof p);
-  p.DP = e->DP; p.Nt = e->Nt; p.r0 = e->r0; p.nloc = e->nloc; p.W = e->W; p.Nc = e->Nc; p.ms = e->ms;
+  p.DP = e->DP; p.Nt = e->Nt; p.r0 = e->r0; p.nloc = e->nloc; p.W = e->W; p.Nc = e->Nc; p.ms = e->ms; p.w_off = e->cfg.walker_begin;
   p.seed = e->cfg.seed; p.step = e->step; p.thresh = e->thresh;
   p.beta = e->beta; p.ll_below = ll_below; p.ll_above = ll_above; p.H = ll_above ? H : 0; p.x = e->x; p.ll = e->ll; p.lp = e->lp;
   p.touch = e->touch; p.arr_below = e->arr_below; p.arr_above = e->arr_above;

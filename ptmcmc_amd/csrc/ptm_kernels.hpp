@@ -79,6 +79,7 @@ __device__ __forceinline__ bool map_try(const MapT& m, int c, double lpost, doub
 
 struct Dev {
   int D, DP, Nt, r0, nloc, W, Nc;
+  int w_off;            // global index of local walker 0 (ptm_config.walker_begin): random streams are keyed by the global walker
   int c_begin, c_end;   // chains [c_begin, c_end) are swept by this launch (whole rungs; the full range is [0, Nc))
   Hist hist;
   MapT map;
@@ -458,7 +459,7 @@ __global__ __launch_bounds__(256, PTM_SWEEP_WAVES) void sweep_kernel(const Dev p
     }
   }
   // ---- MH_chain::step for the untouched rungs; touched lanes idle through the draw loops
-  const uint32_t stream = (uint32_t)w * (uint32_t)p.Nt + (uint32_t)rg;
+  const uint32_t stream = (uint32_t)(w + p.w_off) * (uint32_t)p.Nt + (uint32_t)rg;
   const u32x4 o0 = draw_block(p.seed, TAG_MH, stream, p.step, 0);
 
   // -- gaussian_prop::draw: D normals, optional one-dimensional move, offset = factor * z
@@ -650,7 +651,7 @@ __global__ __launch_bounds__(256) void init_prior_kernel(const Dev p, double* x_
   if (c >= p.Nc) return;
   if (cb_attempt >= 0 && pending[c] == 2) return;
   const int rl = c / p.W, w = c - rl * p.W;
-  const uint32_t stream = (uint32_t)w * (uint32_t)p.Nt + (uint32_t)(p.r0 + rl);
+  const uint32_t stream = (uint32_t)(w + p.w_off) * (uint32_t)p.Nt + (uint32_t)(p.r0 + rl);
   cip pt = as_c(p.ptype);
   cdp plo = as_c(p.plo), phi = as_c(p.phi);
   double x[DP];

@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void sweep_lanes_kernel(const Dev p) {
   }
 
   // ---- MH_chain::step (chain.cc:966-1022); touched chains run along (their lanes would idle anyway) and write nothing
-  const uint32_t stream = (uint32_t)w * (uint32_t)p.Nt + (uint32_t)rg;
+  const uint32_t stream = (uint32_t)(w + p.w_off) * (uint32_t)p.Nt + (uint32_t)rg;
   const u32x4 o0 = draw_block(p.seed, TAG_MH, stream, p.step, 0);
   int type = 0, axis = -1, kmix = 0;
   double mix_scale = 1.0;

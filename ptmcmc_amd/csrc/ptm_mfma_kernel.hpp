@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256, (GEN == 0 ? PTM_MFMA_WAVES : PTM_MFMA_GEN_WAVE
   // log of the chain's accept uniform (block 0 of its stream): drawn here once for all 64 chains -- the Metropolis test
   // itself runs per pass on half the lanes, and this is its expensive part.  (The reference draws the uniform only when
   // logH < 0, chain.cc:998; a counter-based stream makes the draw free of side effects, so drawing it always is the same.)
-  const u32x4 o0 = draw_block(p.seed, TAG_MH, (uint32_t)wl * (uint32_t)p.Nt + (uint32_t)rg, p.step, 0);
+  const u32x4 o0 = draw_block(p.seed, TAG_MH, (uint32_t)(wl + p.w_off) * (uint32_t)p.Nt + (uint32_t)rg, p.step, 0);
   const double log_u = dlog_u01(o0.v0);
   // one-dimensional move of "my" chain (proposal_distribution.hh:196-206): its axis, or -1
   int my_axis = -1, my_kmix = 0;
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256, (GEN == 0 ? PTM_MFMA_WAVES : PTM_MFMA_GEN_WAVE
       double z[2][4];
 #pragma unroll
       for (int gg = 0; gg < 2; ++gg) {
-        const uint32_t stream = (uint32_t)wq[2 * gp + gg] * (uint32_t)p.Nt + (uint32_t)rg;
+        const uint32_t stream = (uint32_t)(wq[2 * gp + gg] + p.w_off) * (uint32_t)p.Nt + (uint32_t)rg;
         const u32x4 o = draw_block(p.seed, TAG_MH, stream, p.step, (uint32_t)(1 + 4 * hb + q));
 #if defined(PTM_ABLATE) && (PTM_ABLATE & 1)   // timing experiment: no Box-Muller
         z[gg][0] = u01(o.v0); z[gg][1] = u01(o.v1); z[gg][2] = u01(o.v2); z[gg][3] = u01(o.v3);

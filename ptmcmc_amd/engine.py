@@ -38,7 +38,7 @@ class PtmConfig(C.Structure):
                 ("rung_count", C.c_int32), ("n_walkers", C.c_int32), ("seed", C.c_uint64), ("swap_rate", C.c_double),
                 ("add_every_n", C.c_int32), ("min_prior", C.c_double), ("device", C.c_int32), ("stream", C.c_void_p),
                 ("time_kernels", C.c_int32), ("swap_log_steps", C.c_int32), ("exchange_row_capacity", C.c_int32), ("history_rungs", C.c_int32),
-                ("history_capacity", C.c_int32), ("map_rungs", C.c_int32)]
+                ("history_capacity", C.c_int32), ("map_rungs", C.c_int32), ("walker_begin", C.c_int32)]
 
 
 class PtmError(RuntimeError):
@@ -214,7 +214,7 @@ class Engine:
 
     def __init__(self, dim, n_rungs, n_walkers=1, seed=0x5EED0001, swap_rate=0.1, add_every_n=1, min_prior=-30.0,
                  rung_begin=0, rung_count=None, device=-1, stream=None, time_kernels=False, exchange_row_capacity=0, history_rungs=0,
-                 history_capacity=0, map_rungs=0):
+                 history_capacity=0, map_rungs=0, walker_begin=0):
         L = load()
         cfg = PtmConfig()
         cfg.struct_size = C.sizeof(PtmConfig)
@@ -230,6 +230,8 @@ class Engine:
         self.hist_rungs, self.hist_cap = history_rungs, history_capacity
         cfg.map_rungs = map_rungs
         self.map_rungs = map_rungs
+        cfg.walker_begin = walker_begin
+        self.walker_begin = walker_begin
         h = C.c_void_p()
         _chk(L.ptm_engine_create(C.byref(cfg), C.byref(h)))
         self.h, self.L = h, L

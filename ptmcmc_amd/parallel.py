@@ -228,6 +228,33 @@ class ShardedLadder:
             self._halo_reqs = []      # delivered and still valid for the next step
 
 
+def walker_bounds(n_walkers, world, rank):
+    """block of independent ladders (walkers) of `rank`: sizes differ by at most one"""
+    base, rem = divmod(n_walkers, world)
+    lo = rank * base + min(rank, rem)
+    return lo, base + (1 if rank < rem else 0)
+
+
+class WalkerShardedLadders:
+    """The other way to spread a population over GPUs: whole ladders per GPU.  Walkers are independent ladders, so a rank
+    that holds walkers [w0, w0 + n) of the population steps them with no message at all -- exchange phases, evolving ladders
+    (evolve_temps, the sampler's default, which rung sharding cannot do: every accepted exchange renormalises the whole
+    ladder within the step), histories and MAPs included.  The engine keys every random stream by the GLOBAL walker
+    (ptm_config.walker_begin), so the chains are those of one engine holding the whole population.
+    Rung sharding (ShardedLadder) is for ladders too long for one GPU, or a single ladder (W = 1) as the reference runs it."""
+
+    def __init__(self, make_engine, n_walkers, rank, world):
+        """make_engine(walker_begin, n_walkers) -> a configured ptmcmc_amd.engine.Engine holding the whole ladder"""
+        self.w0, self.n = walker_bounds(n_walkers, world, rank)
+        self.e = make_engine(self.w0, self.n)
+
+    def step(self, n=1):
+        self.e.step(n)
+
+    def sync(self):
+        self.e.sync()
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 # bench.py --gpus N  (launched by torch.distributed.run, one rank per GPU)
 # ----------------------------------------------------------------------------------------------------------------------
@@ -252,12 +279,26 @@ def bench_main(args):
     # the engine works on an explicit torch stream, and every RCCL message of the step is issued with that stream current
     # (EngineShard.stream_context): kernel -> send / receive -> kernel is then the order of one stream by construction
     stream = torch.cuda.Stream(device=dev)
+    by_walkers = getattr(args, "shard", "rungs") == "walkers"
     try:
-        eng = E.Engine(D, NT, W, seed=B.SEED, swap_rate=B.SWAP_RATE, add_every_n=100, rung_begin=r0, rung_count=nloc,
-                       device=local, stream=stream.cuda_stream, time_kernels=True)
-        pr.configure(eng, E.PROP_LOWER)
-        eng.init_from_prior()
-        lad = ShardedLadder(EngineShard(eng, torch, dev, stream), dist, rank, world, halo=args.halo)
+        if by_walkers:
+            # whole ladders per GPU: rank r holds walkers [r * walkers, (r + 1) * walkers) of the population; no message in a step
+            class _Whole:
+                def __init__(self, e): self.e = e
+                def step(self, n): self.e.step(n)
+                def drain(self): pass
+            r0, nloc = 0, NT
+            eng = E.Engine(D, NT, args.walkers, seed=B.SEED, swap_rate=B.SWAP_RATE, add_every_n=100, device=local, stream=stream.cuda_stream,
+                           time_kernels=True, walker_begin=rank * args.walkers)
+            pr.configure(eng, E.PROP_LOWER)
+            eng.init_from_prior()
+            lad = _Whole(eng)
+        else:
+            eng = E.Engine(D, NT, W, seed=B.SEED, swap_rate=B.SWAP_RATE, add_every_n=100, rung_begin=r0, rung_count=nloc,
+                           device=local, stream=stream.cuda_stream, time_kernels=True)
+            pr.configure(eng, E.PROP_LOWER)
+            eng.init_from_prior()
+            lad = ShardedLadder(EngineShard(eng, torch, dev, stream), dist, rank, world, halo=args.halo)
         lad.step(300)             # set-up (untimed, uncounted): clocks ramped, chains off their prior draws, RCCL channels open
         lad.step(args.warmup)
         lad.drain()
@@ -287,7 +328,7 @@ def bench_main(args):
     nchains = NT * W
     if rank == 0:
         kavg_ms = float(kavg.item())
-        per_gpu_bytes = B.algorithmic_bytes(D) * nloc * W
+        per_gpu_bytes = B.algorithmic_bytes(D) * nloc * (args.walkers if by_walkers else W)
         achieved = per_gpu_bytes / (kavg_ms * 1e-3) / 1e9
         out = {
             "metric": "ladder-wide MH steps/sec (D=32 Gaussian, 1024 temps)",
@@ -297,8 +338,8 @@ def bench_main(args):
             "config": {"workload": "D=32 correlated Gaussian, 1024-rung ladder (Tmax=1e9, swap_rate=0.1) x %d walkers; "
                                    "per-rung Cholesky proposal factors; uniform box prior" % W,
                        "dim": D, "rungs": NT, "walkers": W, "chains": nchains,
-                       "sharding": "%d contiguous rung blocks of %d rungs; llike halo %d rungs; neighbour p2p over RCCL"
-                                   % (world, nloc, args.halo)},
+                       "sharding": ("%d blocks of %d whole ladders (walkers), no message in a step" % (world, args.walkers)) if by_walkers else
+                                   ("%d contiguous rung blocks of %d rungs; llike halo %d rungs; neighbour p2p over RCCL" % (world, nloc, args.halo))},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": B.HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / B.HBM_PEAK_GBS, "traffic": None, "kernel": eng.sweep_kernel_name,
                          "kernel_avg_ms": kavg_ms, "per_gpu": True, "bytes_per_mh_step": B.algorithmic_bytes(D)},

@@ -80,3 +80,61 @@ def test_bench_distributed_path_with_one_rank():
     rec = json.loads(out.stdout.strip().splitlines()[-1])
     assert rec["n_gpus"] == 1 and rec["steps"] == 3 and rec["value"] > 1e8
     assert rec["config"]["chains"] == 1024 * 1024 and rec["roofline"]["kernel"].startswith("sweep_mfma32_kernel")
+
+
+@pytest.mark.parametrize("D,Nt,W,ev,hist", [(32, 16, 256, 0.02, False), (6, 12, 10, 0.03, True), (32, 8, 2048, 0.0, False)])
+def test_population_split_by_walkers_gives_the_single_engine_chains(D, Nt, W, ev, hist):
+    """ptm_config.walker_begin: engines that hold whole ladders for blocks of the walkers (no message between them) reproduce
+    the one-engine population bit for bit -- evolving ladders (what rung sharding refuses), histories and MAPs included; the
+    third case goes through the compacted sweep."""
+    from ptmcmc_amd.parallel import walker_bounds
+    G, sr = 3, 0.3
+    pr = GaussianProblem(D, Nt, 1e3)
+    kw = dict(history_rungs=Nt, history_capacity=40, map_rungs=Nt) if hist else {}
+    ref = E.Engine(D, Nt, W, swap_rate=sr, **kw)
+    pr.configure(ref, E.PROP_LOWER)
+    if ev: ref.set_evolve_temps(ev)
+    ref.init_from_prior()
+    parts = []
+    for g in range(G):
+        w0, n = walker_bounds(W, G, g)
+        e = E.Engine(D, Nt, n, swap_rate=sr, walker_begin=w0, **kw)
+        pr.configure(e, E.PROP_LOWER)
+        if ev: e.set_evolve_temps(ev)
+        e.init_from_prior()               # the prior draws are keyed by the global walker too
+        parts.append((w0, n, e))
+    def gather(name):
+        full = np.array(getattr(ref, name)) if name != "x" else ref.states()
+        got = np.empty_like(full)
+        g3 = got.reshape((Nt, W) + full.shape[1:])
+        for w0, n, e in parts:
+            a = e.states() if name == "x" else getattr(e, name)
+            g3[:, w0:w0 + n] = a.reshape((Nt, n) + full.shape[1:])
+        return got, full
+    got, full = gather("x")
+    assert np.array_equal(got, full), "prior draws"
+    for k in range(4):
+        ref.step(5)
+        for _, _, e in parts: e.step(5)
+        got, full = gather("x")
+        assert np.array_equal(got, full), "states after %d steps" % (5 * k + 5)
+    for name in ("llike", "lprior", "ntries", "naccept", "nhist", "last_type"):
+        got, full = gather(name)
+        assert np.array_equal(got, full), name
+    if ev:
+        b = ref.invtemps()
+        for w0, n, e in parts:
+            assert np.array_equal(e.invtemps(), b[w0:w0 + n])
+        assert (np.abs(b[:, 1:-1] - pr.beta[1:-1]) > 0).any()
+    if hist:
+        hr, mr = ref.history(), ref.map()
+        for w0, n, e in parts:
+            he, me = e.history(), e.map()
+            used = hr["row"].reshape(40, Nt, W)[:, :, w0:w0 + n] >= 0          # (ring slots never written hold no row)
+            assert np.array_equal(he["row"].reshape(40, Nt, n) >= 0, used) and used.sum() > 20 * Nt * n
+            for key in ("x", "llike", "naccept", "last_type", "invtemp", "row"):
+                a = hr[key].reshape((40, Nt, W) + hr[key].shape[2:])[:, :, w0:w0 + n]
+                assert np.array_equal(he[key].reshape(a.shape)[used], a[used]), key
+            assert np.array_equal(me["lpost"].reshape(Nt, n), mr["lpost"].reshape(Nt, W)[:, w0:w0 + n])
+    for _, _, e in parts: e.close()
+    ref.close()
