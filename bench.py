@@ -60,7 +60,7 @@ def cpu_baseline(problem, budget_s=15.0):
     nsteps = 300   # 1024 rungs x 300 steps ~ 3e5 reference MH steps ~ 10 s at the ~3e4 steps/s measured in BASELINE.md
     if os.path.exists(drv):
         with tempfile.NamedTemporaryFile("w", suffix=".spec", delete=False) as f:
-            f.write("%d %d %d %.17g %.17g %.17g\n" % (D, NT, nsteps, TMAX, SWAP_RATE, 0.012556))
+            f.write("%d %d %d %.17g %.17g %.17g %.17g\n" % (D, NT, nsteps, TMAX, SWAP_RATE, 0.012556, problem.basescale_fac))
             for row in problem.cov:
                 f.write(" ".join("%.17g" % v for v in row) + "\n")
             f.write(" ".join("%.17g" % v for v in problem.halfwidths) + "\n")
@@ -69,13 +69,19 @@ def cpu_baseline(problem, budget_s=15.0):
             out = subprocess.check_output([drv, "bench", spec], timeout=600).decode().strip().splitlines()[-1]
             r = json.loads(out)
             return {"value": r["steps_per_s"], "unit": "MH steps/s", "cores": 1, "kind": "reference",
-                    "sample": "parallel_tempering_chains::step, D=%d, %d rungs x 1 ladder, %d steps after %d warm-up, "
-                              "gaussian_prop(cov), OpenMP inert as written (1 thread)" % (D, NT, nsteps, nsteps // 10 + 1)}
+                    "sample": "parallel_tempering_chains::step, D=%d, %d rungs x 1 ladder, %d steps after %d warm-up, one "
+                              "gaussian_prop(cov_r) per rung (the GPU workload's per-rung covariances), OpenMP inert as written "
+                              "(1 thread)" % (D, NT, nsteps, nsteps // 10 + 1)}
         except Exception as ex:  # fall through to the port
             sys.stderr.write("[bench] reference driver failed (%s); timing the C port instead\n" % ex)
         finally:
             os.unlink(spec)
-    # fallback: the C restatement, all host cores
+    return cpu_port(problem, budget_s)   # fallback: the C restatement, all host cores
+
+
+def cpu_port(problem, budget_s=8.0):
+    """the oracle's C restatement of the same step (oracle/ptm_oracle.c), OpenMP over chains on ALL host cores: what a
+    straightforward multi-core CPU implementation with a counter-based RNG reaches on this box"""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
     ncore = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
@@ -175,6 +181,8 @@ def run_single(args):
     }
     if not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(pr)
+        if out["cpu_baseline"]["kind"] == "reference":
+            out["cpu_port_all_cores"] = cpu_port(pr)
     eng.close()
     print(json.dumps(out), flush=True)
 

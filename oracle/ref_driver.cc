@@ -551,13 +551,38 @@ static int golden_eigen() {
 // ----------------------------------------------------------------------------------------------
 // bench: the reference's own classes on the correlated-Gaussian ladder, timed
 // ----------------------------------------------------------------------------------------------
+// One gaussian_prop(cov_r) per rung, as the GPU workload has them (cython/exampleGaussian.py:88-95,145:
+// cov_r = inv(beta_r * invcov + diag((f h_i)^-2)) * 2.38^2 / D).  parallel_tempering_chains::set_proposal clones ONE proposal
+// for every rung in rung order (chain.cc:1368-1372), so this wrapper's clone() builds the next rung's gaussian_prop.
+struct per_rung_gaussian : public proposal_distribution {
+  const std::vector<Eigen::MatrixXd>* covs;
+  mutable int* nextrung;
+  gaussian_prop* gp;
+  per_rung_gaussian(const std::vector<Eigen::MatrixXd>* c, int* next) : covs(c), nextrung(next), gp(nullptr) {}
+  state draw(state& s, chain* caller) override {
+    state out = gp->draw(s, caller);
+    last_type = gp->type();
+    log_hastings = gp->log_hastings_ratio();
+    return out;
+  }
+  per_rung_gaussian* clone() const override {
+    per_rung_gaussian* c = new per_rung_gaussian(*this);
+    Eigen::MatrixXd cov = (*covs)[(*nextrung)++];
+    void* mem = calloc(1, sizeof(gaussian_prop));   // (quirk Q4, as below)
+    c->gp = new (mem) gaussian_prop(cov);
+    return c;
+  }
+  string show() override { return "PerRungGaussian()"; }
+};
+
 static int bench(const char* specfile) {
-  // spec file (text): D Nt nsteps Tmax swap_rate seed  / then D*D covariance (row-major) / then D prior half-widths
+  // spec file (text): D Nt nsteps Tmax swap_rate seed fbase / then D*D covariance (row-major) / then D prior half-widths
+  // fbase > 0: per-rung proposal covariances inv(beta_r invcov + diag((fbase h_i)^-2)) 2.38^2/D; 0: one gaussian_prop(cov 2.38^2/D)
   std::ifstream in(specfile);
   if (!in) { fprintf(stderr, "cannot open %s\n", specfile); return 2; }
   int D, Nt, nsteps;
-  double Tmax, swap_rate, seed;
-  in >> D >> Nt >> nsteps >> Tmax >> swap_rate >> seed;
+  double Tmax, swap_rate, seed, fbase;
+  in >> D >> Nt >> nsteps >> Tmax >> swap_rate >> seed >> fbase;
   Eigen::MatrixXd cov(D, D);
   for (int i = 0; i < D; i++) for (int j = 0; j < D; j++) in >> cov(i, j);
   std::vector<double> hw(D);
@@ -592,7 +617,20 @@ static int bench(const char* specfile) {
     gaussian_prop& prop = *new (prop_mem) gaussian_prop(pcov);
     parallel_tempering_chains ptc(Nt, Tmax, swap_rate, 100, false, false, -30);
     ptc.initialize(&like, prior, 1);
-    ptc.set_proposal(prop);
+    std::vector<Eigen::MatrixXd> covs;
+    int nextrung = 0;
+    per_rung_gaussian rprop(&covs, &nextrung);
+    if (fbase > 0) {
+      Eigen::MatrixXd B = Eigen::MatrixXd::Zero(D, D);
+      for (int i = 0; i < D; i++) B(i, i) = 1.0 / ((fbase * hw[i]) * (fbase * hw[i]));
+      for (int r = 0; r < Nt; r++) {
+        Eigen::MatrixXd S = (ptc.subchain(r)->invTemp() * P + B).inverse() * (2.38 * 2.38 / D);
+        covs.push_back(0.5 * (S + S.transpose()));
+      }
+      ptc.set_proposal(rprop);
+    } else {
+      ptc.set_proposal(prop);
+    }
     int warm = nsteps / 10 + 1;
     for (int k = 0; k < warm; k++) ptc.step();
     auto t0 = std::chrono::steady_clock::now();

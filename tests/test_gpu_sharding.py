@@ -138,3 +138,13 @@ def test_population_split_by_walkers_gives_the_single_engine_chains(D, Nt, W, ev
             assert np.array_equal(me["lpost"].reshape(Nt, n), mr["lpost"].reshape(Nt, W)[:, w0:w0 + n])
     for _, _, e in parts: e.close()
     ref.close()
+
+
+def test_bench_distributed_path_by_walkers_with_one_rank():
+    """bench.py --shard walkers: whole ladders per rank, streams keyed by the global walker -- world size 1 over nccl"""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29542", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--shard", "walkers", "--steps", "3",
+                          "--warmup", "1", "--walkers", "1024"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = json.loads(out.stdout.strip().splitlines()[-1])
+    assert rec["n_gpus"] == 1 and rec["value"] > 1e8 and "whole ladders" in rec["config"]["sharding"]
