@@ -1752,7 +1752,7 @@ class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:
     // host-side proposals: every rung's saved rows pass through a SHORT device ring into the host mirror after each step
     ring_rows = host ? 8 : hist_rows;
     ring_rungs = host ? Ntemps : history_rungs();
-    ptm_config cfg;
+    ptm_config cfg = ptm_config();   // (zeroed: fields a newer ABI adds default to 0)
     cfg.struct_size = sizeof cfg;
     cfg.dim = dim; cfg.n_rungs = Ntemps; cfg.rung_begin = 0; cfg.rung_count = Ntemps; cfg.n_walkers = W; cfg.seed = eng_seed;
     cfg.swap_rate = swap_rate; cfg.add_every_n = add_every_N; cfg.min_prior = dpriormin; cfg.device = -1; cfg.stream = nullptr;
@@ -1962,6 +1962,135 @@ class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:
       os << " " << invtemp;
       os << std::endl;
     }
+  }
+  // ---- effective sample size of the cold chain (chain::report_effective_samples, chain.cc:126-643; the sampler's
+  // chain_ess_stop criterion, ptmcmc.cc:628-649).  The reference's estimator, restated: the saved history of each parameter
+  // (the first 20) is cut into windows of `width` steps aligned to the end of the chain, sampled every `every` steps;
+  // per window and lag (logarithmically spaced, factor 1.1) the lagged covariance about the mean of the two lagged series;
+  // for the last nwin windows rho(lag) = sum(count (cov + dmean^2)) / sum(count (var + dmean0^2)); the autocorrelation
+  // length 1 + 2 sum (lag_k - lag_k-1) rho_k, cut at the second consecutive negative rho ("initially positive sequence");
+  // ess = nwin width / aclen (an aclen below the sampling stride is distrusted: ess = nwin width / (3 every)); the minimum
+  // over parameters, maximised over nwin.  Returns (ess, useful chain length).  Needs the cold chain's whole saved history:
+  // the host mirror (host-side proposals) or a history ring as long as the run (keep_history).
+  bool cold_row(int step, std::vector<double>& out, int replica = 0) {   // state the cold chain saved for nominal step `step`
+    const size_t at = (size_t)replica;
+    if (step < 0) return false;
+    if (host_mode) {
+      const mirror_t& m = mirror[at];
+      const size_t r = (size_t)Ninit_rows + step / add_every_N;
+      if (r >= m.rows()) return false;
+      out.assign(m.x.begin() + r * dim, m.x.begin() + (r + 1) * dim);
+      return true;
+    }
+    if (hist_rows <= 0) return false;
+    const size_t HC = (size_t)history_rungs() * W, cap = hist_rows;
+    if (!hist_fresh) {
+      hx.resize(cap * HC * dim); hl.resize(cap * HC); hp.resize(cap * HC); hmeta.resize(cap * HC * 4); hnhist.resize((size_t)Ntemps * W); hb.resize(cap * HC);
+      ptm_check(ptm_get_history(eng, hx.data(), hl.data(), hp.data(), hmeta.data()), "report_effective_samples");
+      ptm_check(ptm_get_history_invtemps(eng, hb.data()), "report_effective_samples");
+      ptm_check(ptm_get_array(eng, PTM_ARR_NHIST, hnhist.data()), "report_effective_samples");
+      hist_fresh = true;
+    }
+    const int idx = 1 + step / add_every_N;
+    const size_t o = (size_t)(idx % (int)cap) * HC + at;
+    if (hmeta[4 * o + 3] != idx) return false;
+    out.assign(hx.begin() + o * dim, hx.begin() + (o + 1) * dim);
+    return true;
+  }
+  int cold_steps(int replica = 0) {   // MH_chain::getStep() of the cold chain: its add_state calls
+    std::vector<int64_t> nh((size_t)Ntemps * W);
+    ptm_check(ptm_get_array(eng, PTM_ARR_NHIST, nh.data()), "report_effective_samples");
+    return (int)nh[(size_t)replica];
+  }
+  std::pair<double, int> report_effective_samples(int imax = -1, int width = 40000, int every = 100, double esslimit = -1, bool reporting = true) {
+    (void)esslimit;   // (the reference's coarse-to-fine search for long chains, chain.cc:478-531, is an efficiency device: same estimator)
+    const int istep = cold_steps();
+    while (width < istep * 0.05) width *= 2;                       // chain.cc:537
+    if (imax < 0 || imax > dim) imax = dim;
+    if (imax > 20) imax = 20;
+    if (every < 1) every = 1;
+    const int minburn = 2, minbin = 1000, maxbins = 20;
+    int burn = minburn;
+    if (width < 0) width = every * minbin;
+    while ((long)width * (maxbins + burn) < istep) width *= 2;      // chain.cc:470-474
+    // ---- compute_autocovar_windows (chain.cc:126-283), log-spaced lags, for every feature at once
+    if (width <= 1) width = 2;
+    const int swidth = width / every;
+    width = swidth * every;
+    const int max_lag = burn;
+    int Nwin = istep / width - burn;
+    if (Nwin < 0) Nwin = 0;
+    const int istart = istep - Nwin * width;
+    std::vector<int> lags;
+    lags.push_back(0);
+    { double fac = 1; int idx = 1; while (idx < max_lag * swidth) { lags.push_back(every * idx); const int last = idx; while (last == idx) { fac *= 1.1; idx = (int)fac; } } }
+    const int Nlag = (int)lags.size();
+    if (Nwin < 1 || swidth < 2) { if (reporting) std::cout << "Effective sample size: chain too short (" << istep << " steps, window " << width << ")" << std::endl; return std::make_pair(0.0, 0); }
+    // the sampled series, from the earliest lagged sample on
+    const int first = istart - lags.back();
+    const int nsamp = (istep - first + every - 1) / every + 1;
+    std::vector<std::vector<double> > ser(imax, std::vector<double>(nsamp, 0.0));
+    std::vector<char> have(nsamp, 0);
+    std::vector<double> row;
+    for (int k = 0; k < nsamp; k++) {
+      const int st = first + k * every;
+      if (st >= 0 && st < istep && cold_row(st, row)) { have[k] = 1; for (int f = 0; f < imax; f++) ser[f][k] = row[f]; }
+    }
+    auto at_step = [&](int st) { return (st - first) / every; };
+    std::vector<std::vector<std::vector<double> > > covar(imax, std::vector<std::vector<double> >(Nwin, std::vector<double>(Nlag, 0.0))), means = covar;
+    std::vector<std::vector<int> > counts(Nwin, std::vector<int>(Nlag, 0));
+    for (int k = 0; k < Nwin; k++)
+      for (int j = 0; j < Nlag; j++) {
+        int cnt = 0;
+        std::vector<double> xs(imax, 0.0), xx(imax, 0.0);
+        for (int i = 0; i < swidth; i++) {
+          const int a = at_step(istart + k * width + i * every), b = at_step(istart + k * width + i * every - lags[j]);
+          if (a < 0 || b < 0 || a >= nsamp || b >= nsamp || !have[a] || !have[b]) continue;
+          cnt++;
+          for (int f = 0; f < imax; f++) { xs[f] += ser[f][a] + ser[f][b]; xx[f] += ser[f][a] * ser[f][b]; }
+        }
+        counts[k][j] = cnt;
+        for (int f = 0; f < imax; f++) {
+          const double m = cnt ? xs[f] / cnt / 2 : 0.0;
+          means[f][k][j] = m;
+          covar[f][k][j] = cnt ? xx[f] / cnt - m * m : 0.0;
+        }
+      }
+    // ---- compute_effective_samples (chain.cc:285-455)
+    const double oversmall_aclen_fac = 3.0;
+    double ess_max = 0;
+    int nwin_max = 0;
+    for (int nwin = 1; nwin <= Nwin; nwin++) {
+      double ess = 1e100;
+      for (int f = 0; f < imax; f++) {
+        double sum = 0;
+        for (int i = Nwin - nwin; i < Nwin; i++) sum += means[f][i][0];
+        const double mean = sum / nwin;
+        int last_lag = 0;
+        double ac_len = 1.0, lastcorr = 1, dacl = 0;
+        for (int il = 1; il < Nlag; il++) {
+          double num = 0, den = 0;
+          for (int iw = Nwin - nwin; iw < Nwin; iw++) {
+            const double dm = mean - means[f][iw][il], dm0 = mean - means[f][iw][0];
+            num += (covar[f][iw][il] + dm * dm) * counts[iw][il];
+            den += (covar[f][iw][0] + dm0 * dm0) * counts[iw][il];
+          }
+          const double corr = num / den;
+          if (lastcorr < 0 && corr < 0) { ac_len -= dacl; break; }   // keep the initially positive sequence only
+          lastcorr = corr;
+          dacl = 2.0 * (lags[il] - last_lag) * corr;
+          ac_len += dacl;
+          last_lag = lags[il];
+        }
+        double essi = nwin * (double)width / ac_len;
+        if (ac_len < every) essi = nwin * (double)width / oversmall_aclen_fac / every;
+        if (essi < ess) ess = essi;
+      }
+      if (ess > ess_max) { ess_max = ess; nwin_max = nwin; }
+    }
+    if (reporting)
+      std::cout << "Over " << imax << " pars: ess=" << ess_max << "  useful chain length is: " << width * nwin_max << " autocorrlen=" << (ess_max > 0 ? width * nwin_max / ess_max : 0.0) << std::endl;
+    return std::make_pair(ess_max, width * nwin_max);
   }
   // swap_count / swap_accept_count (chain.hh:244-245)
   void swap_counts(std::vector<int64_t>& tries, std::vector<int64_t>& accepts) {
@@ -2202,7 +2331,6 @@ class ptmcmc_sampler : public bayes_sampler {
     if (v > 0) { std::cout << "ptmcmc_sampler: pt_stop_evid_err > 0 (evidence integration) is not built in the GPU step engine." << std::endl; exit(1); }
     *optValue("chain_init_file") >> sv;
     if (!sv.empty()) { std::cout << "ptmcmc_sampler: chain_init_file is not built in the GPU step engine." << std::endl; exit(1); }
-    if (ess_stop > 0) { std::cout << "ptmcmc_sampler: chain_ess_stop (the autocorrelation analysis of chain.cc:126-643) is not built in the GPU step engine." << std::endl; exit(1); }
     if (Nptc < 2) { std::cout << "ptmcmc_sampler: this build drives parallel-tempering ladders: set --pt=N with N >= 2." << std::endl; exit(1); }
   }
   // a proposal of the caller's (the convenience path of examples/example_sampler.cc; the reference's deprecated setup(Ninit, ...))
@@ -2382,7 +2510,8 @@ class ptmcmc_sampler : public bayes_sampler {
     // interval saves (up to two add_state calls per step, every save_every-th saved)
     int dn = dump_n;
     if (dn > Nptc || dn <= 0) dn = Nptc;   // ptmcmc.cc:458
-    cc->keep_history(2 + 2 * Nevery / std::max(1, save_every), dn);
+    // ... and with an effective-sample-size stop (chain_ess_stop) the cold chain's whole saved history
+    cc->keep_history(2 + 2 * (ess_stop > 0 ? std::max(Nevery, Nstep) : Nevery) / std::max(1, save_every), dn);
     cc->set_replicas(nreplicas);
     if (pt_evolve_rate > 0) cc->evolve_temps(pt_evolve_rate, pt_evolve_lpost_cut);   // ptmcmc.cc:512
     int kind; double odf; std::vector<double> f;
@@ -2433,6 +2562,16 @@ class ptmcmc_sampler : public bayes_sampler {
           for (int ich = 0; ich < dn; ich++) cc->dumpChain(ich, *out[(size_t)w * dn + ich], istep - every + 1, skip, w);
         if (0 == istep % (every * 4)) {   // ptmcmc.cc:620-651
           std::cout << "Proposal report:\n" << cc->report_prop(1) << "\nacceptance report:\n" << cc->report_prop(0) << std::endl;
+          if (ess_stop > 0) {   // ptmcmc.cc:628-649
+            double esslimit = -1;
+            *optValue("chain_ess_limit") >> esslimit;
+            std::cout << "Effective sample size test" << std::endl;
+            const std::pair<double, int> ess_len = cc->report_effective_samples(-1, save_every * 1000, save_every, esslimit);
+            if (ess_len.first > ess_stop) {
+              stop = true;
+              std::cout << "ptmcmc_sampler::run: Stopping based on chain_ess_stop Effective Sample Size criterion." << std::endl;
+            }
+          }
         }
       }
       if (stop) break;
