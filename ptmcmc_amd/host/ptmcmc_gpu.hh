@@ -30,8 +30,10 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <fstream>
 #include <iostream>
+#include <iterator>
 #include <map>
 #include <memory>
 #include <sstream>
@@ -1627,9 +1629,19 @@ class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:
   }
   int replicas() const { return W; }
   // chain::checkpoint / restart (chain.cc:1213-1290): everything the ladder's future depends on, into <path>chain0-cp/
-  // PTchain.cp.  The reference's files hold its own generators and growing vectors; this one holds the engine's arrays
-  // (states, llikes, MH_chain counters, step count = position of every random stream, exchange counters, evolving
-  // temperatures, history ring, MAPs, the exchange diagnostics) -- the continued run is the uninterrupted run, bit for bit.
+  // PTchain.cp.  NOT interchangeable with the reference's checkpoint files: those hold its newran generators and growing
+  // history vectors; this one holds the engine's arrays (states, llikes, MH_chain counters, step count = position of every
+  // random stream, exchange counters, evolving temperatures, history ring, MAPs, the exchange diagnostics, and -- with
+  // host-side proposals -- the host history mirror; the proposals checkpoint themselves beside it as in the reference) --
+  // the continued run is the uninterrupted run, bit for bit.  The header names the format version and every parameter a
+  // restart must share (sizes, seed, swap rate, add_every_N, ring shape, evolution, proposal placement); the whole file is
+  // read and checked BEFORE anything is applied to the engine.
+  struct cp_header {
+    char magic[8];
+    int32_t version, Ntemps, W, dim, add_every_N, ring_rows, ring_rungs, evolving, tracking, host_mode, Ninit_rows, nstep;
+    uint64_t seed, engine_step;
+    double swap_rate, Tmax;
+  };
   void checkpoint(const std::string& path) {
     const std::string dir = path + "chain0-cp/";
     mkdir(dir.c_str(), 0777);
@@ -1637,10 +1649,13 @@ class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:
     if (!os) { std::cout << "parallel_tempering_chains::checkpoint: cannot write " << dir << "PTchain.cp" << std::endl; exit(1); }
     const size_t N = (size_t)Ntemps * W, np = (size_t)W * (Ntemps > 1 ? Ntemps - 1 : 1);
     auto wr = [&](const void* ptr, size_t bytes) { os.write((const char*)ptr, (std::streamsize)bytes); };
-    const char magic[8] = {'P', 'T', 'M', 'G', 'P', 'U', '0', '1'};
-    int32_t hdr[8] = {Ntemps, W, dim, hist_rows + 65536 * history_rungs(), ev_rate > 0 ? 1 : 0, tracking ? 1 : 0, nstep, add_every_N};
-    uint64_t estep = ptm_step_count(eng);
-    wr(magic, 8); wr(hdr, sizeof hdr); wr(&estep, 8);
+    cp_header h;
+    memset(&h, 0, sizeof h);
+    memcpy(h.magic, "PTMGPU02", 8);
+    h.version = 2; h.Ntemps = Ntemps; h.W = W; h.dim = dim; h.add_every_N = add_every_N; h.ring_rows = ring_rows; h.ring_rungs = ring_rungs;
+    h.evolving = ev_rate > 0 ? 1 : 0; h.tracking = tracking ? 1 : 0; h.host_mode = host_mode ? 1 : 0; h.Ninit_rows = Ninit_rows; h.nstep = nstep;
+    h.seed = eng_seed; h.engine_step = ptm_step_count(eng); h.swap_rate = swap_rate; h.Tmax = Tmax;
+    wr(&h, sizeof h);
     std::vector<double> x(N * dim), ll(N);
     std::vector<int32_t> nt(N), na(N), ty(N);
     std::vector<int64_t> nh(N), st(np), sa(np);
@@ -1658,8 +1673,8 @@ class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:
       ptm_check(ptm_get_invtemps(eng, b.data()), "checkpoint");
       wr(b.data(), b.size() * 8);
     }
-    if (hist_rows > 0) {
-      const size_t n = (size_t)hist_rows * history_rungs() * W;
+    if (ring_rows > 0) {
+      const size_t n = (size_t)ring_rows * ring_rungs * W;
       std::vector<double> gx(n * dim), gl(n), gp(n), gb(n);
       std::vector<int32_t> gm(n * 4);
       ptm_check(ptm_get_history(eng, gx.data(), gl.data(), gp.data(), gm.data()), "checkpoint");
@@ -1675,53 +1690,78 @@ class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:
       std::vector<int64_t> u(ups.begin(), ups.end()), d(downs.begin(), downs.end());
       wr(directions.data(), (size_t)Ntemps * 4); wr(instances.data(), (size_t)Ntemps * 4); wr(u.data(), (size_t)Ntemps * 8); wr(d.data(), (size_t)Ntemps * 8);
     }
+    if (host_mode) {
+      for (size_t c = 0; c < N; c++) {
+        const mirror_t& m = mirror[c];
+        const uint64_t rows = m.rows();
+        wr(&rows, 8); wr(&mirror_seen[c], 8);
+        wr(m.x.data(), m.x.size() * 8); wr(m.llike.data(), rows * 8); wr(m.lprior.data(), rows * 8); wr(m.beta.data(), rows * 8); wr(m.meta.data(), m.meta.size() * 4);
+      }
+      for (auto pp : props) pp->checkpoint(dir);
+    }
     if (!os) { std::cout << "parallel_tempering_chains::checkpoint: write failed" << std::endl; exit(1); }
   }
   // into a ladder set up exactly like the one that was saved (same sizes, seed, likelihood, prior, proposal, evolve_temps)
   void restart(const std::string& path) {
-    const std::string fn = path + "chain0-cp/PTchain.cp";
+    const std::string dir = path + "chain0-cp/", fn = dir + "PTchain.cp";
     std::ifstream is(fn.c_str(), std::ios::binary);
     if (!is) { std::cout << "parallel_tempering_chains::restart: cannot read " << fn << std::endl; exit(1); }
-    auto rd = [&](void* ptr, size_t bytes) { is.read((char*)ptr, (std::streamsize)bytes); };
-    char magic[8]; int32_t hdr[8]; uint64_t estep;
-    rd(magic, 8); rd(hdr, sizeof hdr); rd(&estep, 8);
-    if (std::string(magic, 8) != "PTMGPU01" || hdr[0] != Ntemps || hdr[1] != W || hdr[2] != dim || hdr[3] != hist_rows + 65536 * history_rungs() ||
-        hdr[4] != (ev_rate > 0 ? 1 : 0) || hdr[7] != add_every_N) {
-      std::cout << "parallel_tempering_chains::restart: " << fn << " was written by a differently configured ladder" << std::endl;
+    std::vector<char> buf((std::istreambuf_iterator<char>(is)), std::istreambuf_iterator<char>());
+    size_t pos = 0;
+    bool ok = true;
+    auto rd = [&](void* ptr, size_t bytes) { if (pos + bytes > buf.size()) { ok = false; return; } memcpy(ptr, buf.data() + pos, bytes); pos += bytes; };
+    cp_header h;
+    rd(&h, sizeof h);
+    if (!ok || std::string(h.magic, 8) != "PTMGPU02" || h.version != 2) { std::cout << "parallel_tempering_chains::restart: " << fn << " is not a checkpoint of this build (format 2)" << std::endl; exit(1); }
+    if (h.Ntemps != Ntemps || h.W != W || h.dim != dim || h.add_every_N != add_every_N || h.ring_rows != ring_rows || h.ring_rungs != ring_rungs ||
+        h.evolving != (ev_rate > 0 ? 1 : 0) || h.host_mode != (host_mode ? 1 : 0) || h.seed != eng_seed || h.swap_rate != swap_rate || h.Tmax != Tmax) {
+      std::cout << "parallel_tempering_chains::restart: " << fn << " was written by a differently configured ladder (sizes, seed, swap rate, Tmax, "
+                << "history ring, evolution and proposal placement must all match)" << std::endl;
       exit(1);
     }
     const size_t N = (size_t)Ntemps * W, np = (size_t)W * (Ntemps > 1 ? Ntemps - 1 : 1);
-    std::vector<double> x(N * dim), ll(N);
-    std::vector<int32_t> nt(N), na(N), ty(N);
-    std::vector<int64_t> nh(N), st(np), sa(np);
+    std::vector<double> x(N * dim), ll(N), b, gx, gl, gp, gb, mx(N * dim), mp(N), ml(N), mr(N);
+    std::vector<int32_t> nt(N), na(N), ty(N), gm, dir_(Ntemps), ins_(Ntemps);
+    std::vector<int64_t> nh(N), st(np), sa(np), u(Ntemps), d(Ntemps);
     rd(x.data(), x.size() * 8); rd(ll.data(), N * 8); rd(nt.data(), N * 4); rd(na.data(), N * 4); rd(ty.data(), N * 4);
     rd(nh.data(), N * 8); rd(st.data(), np * 8); rd(sa.data(), np * 8);
-    ptm_check(ptm_restore(eng, x.data(), ll.data(), nt.data(), na.data(), ty.data(), nh.data(), estep, st.data(), sa.data()), "restart");
-    if (ev_rate > 0) {
-      std::vector<double> b((size_t)W * Ntemps);
-      rd(b.data(), b.size() * 8);
-      ptm_check(ptm_set_invtemps(eng, b.data()), "restart");
+    if (ev_rate > 0) { b.resize((size_t)W * Ntemps); rd(b.data(), b.size() * 8); }
+    const size_t nring = (size_t)ring_rows * ring_rungs * W;
+    if (ring_rows > 0) {
+      gx.resize(nring * dim); gl.resize(nring); gp.resize(nring); gb.resize(nring); gm.resize(nring * 4);
+      rd(gx.data(), gx.size() * 8); rd(gl.data(), nring * 8); rd(gp.data(), nring * 8); rd(gm.data(), gm.size() * 4); rd(gb.data(), nring * 8);
     }
-    if (hist_rows > 0) {
-      const size_t n = (size_t)hist_rows * history_rungs() * W;
-      std::vector<double> gx(n * dim), gl(n), gp(n), gb(n);
-      std::vector<int32_t> gm(n * 4);
-      rd(gx.data(), gx.size() * 8); rd(gl.data(), n * 8); rd(gp.data(), n * 8); rd(gm.data(), gm.size() * 4); rd(gb.data(), n * 8);
-      ptm_check(ptm_set_history(eng, gx.data(), gl.data(), gp.data(), gm.data(), gb.data()), "restart");
+    rd(mx.data(), mx.size() * 8); rd(mp.data(), N * 8); rd(ml.data(), N * 8); rd(mr.data(), N * 8);
+    if (h.tracking) { rd(dir_.data(), (size_t)Ntemps * 4); rd(ins_.data(), (size_t)Ntemps * 4); rd(u.data(), (size_t)Ntemps * 8); rd(d.data(), (size_t)Ntemps * 8); }
+    std::vector<mirror_t> mir;
+    std::vector<int64_t> seen;
+    if (host_mode) {
+      mir.resize(N); seen.resize(N);
+      for (size_t c = 0; c < N && ok; c++) {
+        uint64_t rows = 0;
+        rd(&rows, 8); rd(&seen[c], 8);
+        if (!ok || rows > buf.size()) { ok = false; break; }
+        mirror_t& m = mir[c];
+        m.x.resize(rows * dim); m.llike.resize(rows); m.lprior.resize(rows); m.beta.resize(rows); m.meta.resize(rows * 3);
+        rd(m.x.data(), m.x.size() * 8); rd(m.llike.data(), rows * 8); rd(m.lprior.data(), rows * 8); rd(m.beta.data(), rows * 8); rd(m.meta.data(), m.meta.size() * 4);
+      }
     }
-    {
-      std::vector<double> mx(N * dim), mp(N), ml(N), mr(N);
-      rd(mx.data(), mx.size() * 8); rd(mp.data(), N * 8); rd(ml.data(), N * 8); rd(mr.data(), N * 8);
-      ptm_check(ptm_set_map(eng, mx.data(), mp.data(), ml.data(), mr.data()), "restart");
-    }
-    if (hdr[5]) {
+    if (!ok || pos != buf.size()) { std::cout << "parallel_tempering_chains::restart: " << fn << " is truncated or has trailing bytes; nothing was applied" << std::endl; exit(1); }
+    // ---- the file is whole and matches: apply
+    ptm_check(ptm_restore(eng, x.data(), ll.data(), nt.data(), na.data(), ty.data(), nh.data(), h.engine_step, st.data(), sa.data()), "restart");
+    if (ev_rate > 0) ptm_check(ptm_set_invtemps(eng, b.data()), "restart");
+    if (ring_rows > 0) ptm_check(ptm_set_history(eng, gx.data(), gl.data(), gp.data(), gm.data(), gb.data()), "restart");
+    ptm_check(ptm_set_map(eng, mx.data(), mp.data(), ml.data(), mr.data()), "restart");
+    if (h.tracking) {
       track_exchanges(true);
-      std::vector<int64_t> u(Ntemps), d(Ntemps);
-      rd(directions.data(), (size_t)Ntemps * 4); rd(instances.data(), (size_t)Ntemps * 4); rd(u.data(), (size_t)Ntemps * 8); rd(d.data(), (size_t)Ntemps * 8);
+      directions.assign(dir_.begin(), dir_.end()); instances.assign(ins_.begin(), ins_.end());
       ups.assign(u.begin(), u.end()); downs.assign(d.begin(), d.end());
     }
-    if (!is) { std::cout << "parallel_tempering_chains::restart: " << fn << " is truncated" << std::endl; exit(1); }
-    nstep = hdr[6];
+    if (host_mode) {
+      mirror.swap(mir); mirror_seen.swap(seen); Ninit_rows = h.Ninit_rows;
+      for (auto pp : props) pp->restart(dir);
+    }
+    nstep = h.nstep;
     fresh = hist_fresh = map_fresh = false;
   }
   // chain.cc:1281-1365: n prior draws per rung (the device draws them: any prior type but the improper flat one); the last one
