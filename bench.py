@@ -199,6 +199,10 @@ def main():
     ap.add_argument("--shard", choices=("rungs", "walkers"), default="rungs",
                     help="N > 1: how the population is spread -- contiguous rung blocks with neighbour exchanges over RCCL (BASELINE's "
                          "configuration, the default), or whole ladders per GPU (no message at all; the form evolving ladders need)")
+    ap.add_argument("--native-rccl", action="store_true",
+                    help="N > 1, --shard rungs: drive the sharded step through the engine library's own RCCL calls (ptm_shard_*: the C/C++ "
+                         "host's path; torch.distributed only hands the communicator id round and times the run) instead of "
+                         "ptmcmc_amd.parallel.ShardedLadder over torch.distributed")
     ap.add_argument("--force-dist", action="store_true", help="take the torch.distributed path even with one rank (smoke test)")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))

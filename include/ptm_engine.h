@@ -212,6 +212,23 @@ int ptm_sweep_rungs(ptm_engine* e, int first_local_rung, int n_rungs, int closes
 int ptm_exchange_buffer_doubles(ptm_engine* e);
 int ptm_exchange_row_capacity(ptm_engine* e);
 
+/* ---- the same, driven natively over RCCL (for hosts that stay C/C++; ptmcmc_amd/parallel.py is the torch.distributed twin) --
+ * One engine per process and GPU holds a contiguous rung block (rung_begin / rung_count); ptm_shard_step runs the whole sharded
+ * PT step: llike halos and boundary rows travel as ncclSend / ncclRecv pairs between NEIGHBOUR ranks on a side stream, hidden
+ * behind the sweep of the interior rungs (halos of the next step behind the second half).  RCCL is loaded at run time
+ * (dlopen "librccl.so.1") by the first of these calls; nothing else in the library needs it.
+ *   rank 0:   ptm_shard_unique_id(id)  -> hand the 128 bytes to every rank (file, socket, MPI, a launcher's environment ...)
+ *   all:      ptm_shard_init(e, id, rank, world, rung_counts, halo)   rung_counts[world]: every rank's block length
+ *             (rank r holds the block after rank r-1's; must agree with this engine's rung_begin / rung_count); halo <= 0: 8
+ *             ptm_shard_step(e, n) ... ptm_sync(e) ...   ptm_shard_finalize(e) before ptm_engine_destroy
+ * Replaces the reference's MPI layer for this path: rank/size `chain.cc:1199-1209`, the cyclic rung map `:1298-1309` and the
+ * three MPI_Allgathers of every step `:1433-1435,1879-1972`. */
+#define PTM_SHARD_ID_BYTES 128
+int ptm_shard_unique_id(void* id_out);
+int ptm_shard_init(ptm_engine* e, const void* id, int rank, int world, const int32_t* rung_counts, int halo_rungs);
+int ptm_shard_step(ptm_engine* e, int n);
+int ptm_shard_finalize(ptm_engine* e);
+
 /* ---- read-back ------------------------------------------------------------------------------------------ */
 enum {
   PTM_ARR_LLIKE = 0,  /* double */

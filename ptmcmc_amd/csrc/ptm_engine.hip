@@ -16,6 +16,7 @@
 #include "../../include/ptm_engine.h"
 #include "ptm_aux_kernels.hpp"
 #include "ptm_launch.hpp"
+#include "ptm_shard_rccl.hpp"
 
 using namespace ptm;
 
@@ -100,6 +101,7 @@ struct ptm_engine {
   int *cidx = nullptr, *ccnt = nullptr;
   bool touched = false;
   bool compact_step = false;   // this step's (partial) sweeps are compacted
+  ShardComm* shard = nullptr;   // native RCCL sharding (ptm_shard_*)
   unsigned int nhist_pending = 0;   // steps whose one-add-per-chain the compacted sweep left uncounted (flush_nhist)
   double* hastings = nullptr;
   int* htype = nullptr;
@@ -163,6 +165,7 @@ static int need_device() {
 }
 
 extern "C" int ptm_engine_destroy(ptm_engine* e);
+extern "C" int ptm_shard_finalize(ptm_engine* e);
 static int build_engine(ptm_engine* e, const ptm_config* cfg);
 static int launch_beta_transpose(ptm_engine* e);
 static int fill_evolving_ladders(ptm_engine* e);
@@ -288,6 +291,7 @@ static int build_engine(ptm_engine* e, const ptm_config* cfg) {
 
 extern "C" int ptm_engine_destroy(ptm_engine* e) {
   if (!e) return PTM_OK;
+  (void)ptm_shard_finalize(e);
   (void)hipStreamSynchronize(e->stream);
   void* ptrs[] = {e->x, e->ll, e->lp, e->ntries, e->naccept, e->last_type, e->arr_below, e->arr_above, e->mv_src, e->mv_dst, e->mv_n,
                   e->err, e->nhist, e->swap_cnt, e->touch, e->swap_log, e->hist.x, e->hist.ll, e->hist.lp, e->hist.meta, e->map.lpost, e->map.ll, e->map.lp, e->map.x, e->blo,
@@ -1140,6 +1144,7 @@ extern "C" int ptm_step(ptm_engine* e, int n) {
 extern "C" int ptm_sync(ptm_engine* e) {
   if (!e) return fail(PTM_ERR_INVALID, "null engine");
   HIPCHK(hipStreamSynchronize(e->stream));
+  if (e->shard && e->shard->cstream) HIPCHK(hipStreamSynchronize(e->shard->cstream));   // (halos left in flight for the next step)
   int flag = 0;
   HIPCHK(hipMemcpy(&flag, e->err, 4, hipMemcpyDeviceToHost));
   if (flag & 1) return fail(PTM_ERR_FAR_MOVE, "a state crossed more than one shard boundary in one step (neighbour exchange mode)");
@@ -1218,6 +1223,147 @@ extern "C" int ptm_exchange_finish_and_sweep(ptm_engine* e, const void* recv_bel
   if ((!first && !recv_below) || (!last && !recv_above)) return fail(PTM_ERR_INVALID, "missing boundary message from a neighbour shard");
   if ((rc = launch_install(e, first ? nullptr : (const double*)recv_below, last ? nullptr : (const double*)recv_above))) return rc;
   return launch_sweep(e);
+}
+
+
+// ---- native RCCL sharding -----------------------------------------------------------------------------------------------------
+#define NCCLCHK(x)                                                                                                     \
+  do {                                                                                                                 \
+    ncclResult_t _r = (x);                                                                                             \
+    if (_r != ncclSuccess) return fail(PTM_ERR_HIP, "%s failed: %s (%s:%d)", #x, rccl().GetErrorString(_r), __FILE__, __LINE__); \
+  } while (0)
+
+extern "C" int ptm_shard_unique_id(void* id_out) {
+  if (!id_out) return fail(PTM_ERR_INVALID, "null argument");
+  const char* why = rccl().load();
+  if (why) return fail(PTM_ERR_UNSUPPORTED, "RCCL is not available: %s", why);
+  static_assert(sizeof(ncclUniqueId) == PTM_SHARD_ID_BYTES, "ncclUniqueId size");
+  ncclUniqueId id;
+  NCCLCHK(rccl().GetUniqueId(&id));
+  memcpy(id_out, &id, sizeof id);
+  return PTM_OK;
+}
+
+extern "C" int ptm_shard_finalize(ptm_engine* e) {
+  if (!e || !e->shard) return PTM_OK;
+  ShardComm* s = e->shard;
+  (void)hipStreamSynchronize(e->stream);
+  if (s->cstream) (void)hipStreamSynchronize(s->cstream);
+  if (s->comm) (void)rccl().CommDestroy(s->comm);
+  double* bufs[] = {s->ll_top, s->ll_bottom, s->ll_below, s->ll_above, s->send_up, s->recv_above, s->send_down, s->recv_below};
+  for (double* b : bufs) if (b) (void)hipFree(b);
+  if (s->ev_ready) (void)hipEventDestroy(s->ev_ready);
+  if (s->ev_rows) (void)hipEventDestroy(s->ev_rows);
+  if (s->ev_halo) (void)hipEventDestroy(s->ev_halo);
+  if (s->cstream) (void)hipStreamDestroy(s->cstream);
+  delete s;
+  e->shard = nullptr;
+  return PTM_OK;
+}
+
+extern "C" int ptm_shard_init(ptm_engine* e, const void* id, int rank, int world, const int32_t* rung_counts, int halo_rungs) {
+  if (!e || !id || !rung_counts) return fail(PTM_ERR_INVALID, "null argument");
+  if (world < 1 || rank < 0 || rank >= world) return fail(PTM_ERR_INVALID, "bad rank / world size");
+  if (e->shard) return fail(PTM_ERR_INVALID, "this engine is sharded already (ptm_shard_finalize first)");
+  if (e->evolve_rate > 0) return fail(PTM_ERR_UNSUPPORTED, "evolving ladders cannot be sharded by rungs (split the population by walkers: ptm_config.walker_begin)");
+  int begin = 0, total = 0;
+  for (int r = 0; r < world; ++r) { if (rung_counts[r] < 1) return fail(PTM_ERR_INVALID, "every rank needs at least one rung"); if (r < rank) begin += rung_counts[r]; total += rung_counts[r]; }
+  if (total != e->Nt || begin != e->r0 || rung_counts[rank] != e->nloc)
+    return fail(PTM_ERR_INVALID, "rung_counts do not describe this engine's block (rank %d: expected rungs %d..%d of %d, the engine holds %d..%d of %d)", rank, begin,
+                begin + rung_counts[rank], total, e->r0, e->r0 + e->nloc, e->Nt);
+  const char* why = rccl().load();
+  if (why) return fail(PTM_ERR_UNSUPPORTED, "RCCL is not available: %s", why);
+  ShardComm* s = new ShardComm();
+  e->shard = s;
+  s->rank = rank; s->world = world; s->halo = halo_rungs > 0 ? halo_rungs : 8;
+  s->up = rank + 1 < world ? rank + 1 : -1;
+  s->down = rank > 0 ? rank - 1 : -1;
+  s->h_recv = s->up >= 0 ? (s->halo < rung_counts[rank + 1] ? s->halo : rung_counts[rank + 1]) : 0;   // what I receive from above is limited by the
+  s->h_send = s->down >= 0 ? (s->halo < rung_counts[rank] ? s->halo : rung_counts[rank]) : 0;         // neighbour's size, what I send down by mine
+  s->row_doubles = (size_t)ptm_exchange_buffer_doubles(e);
+  HIPCHK(hipSetDevice(e->device));
+  ncclUniqueId uid;
+  memcpy(&uid, id, sizeof uid);
+  NCCLCHK(rccl().CommInitRank(&s->comm, world, uid, rank));
+  HIPCHK(hipStreamCreateWithFlags(&s->cstream, hipStreamNonBlocking));
+  HIPCHK(hipEventCreateWithFlags(&s->ev_ready, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&s->ev_rows, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&s->ev_halo, hipEventDisableTiming));
+  const size_t W = (size_t)e->W;
+  int rc;
+  if (s->up >= 0 && ((rc = dalloc(&s->ll_top, W)) || (rc = dalloc(&s->ll_above, (size_t)s->h_recv * W)) || (rc = dalloc(&s->send_up, s->row_doubles)) ||
+                     (rc = dalloc(&s->recv_above, s->row_doubles))))
+    return rc;
+  if (s->down >= 0 && ((rc = dalloc(&s->ll_bottom, (size_t)s->h_send * W)) || (rc = dalloc(&s->ll_below, W)) || (rc = dalloc(&s->send_down, s->row_doubles)) ||
+                       (rc = dalloc(&s->recv_below, s->row_doubles))))
+    return rc;
+  double* zero[] = {s->send_up, s->recv_above, s->send_down, s->recv_below};
+  for (double* b : zero) if (b) HIPCHK(hipMemsetAsync(b, 0, s->row_doubles * 8, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return PTM_OK;
+}
+
+// One message round on the side stream: it starts when the engine's stream has reached `after`, and `done` marks its end.
+// up_* / down_*: what goes to / comes from the upper / lower neighbour (counts in doubles).
+static int shard_exchange(ptm_engine* e, const double* up_send, size_t up_ns, double* up_recv, size_t up_nr, const double* down_send, size_t down_ns,
+                          double* down_recv, size_t down_nr, hipEvent_t done) {
+  ShardComm* s = e->shard;
+  HIPCHK(hipEventRecord(s->ev_ready, e->stream));
+  HIPCHK(hipStreamWaitEvent(s->cstream, s->ev_ready, 0));
+  NCCLCHK(rccl().GroupStart());
+  if (s->up >= 0) {
+    NCCLCHK(rccl().Send(up_send, up_ns, ncclDouble, s->up, s->comm, s->cstream));
+    NCCLCHK(rccl().Recv(up_recv, up_nr, ncclDouble, s->up, s->comm, s->cstream));
+  }
+  if (s->down >= 0) {
+    NCCLCHK(rccl().Send(down_send, down_ns, ncclDouble, s->down, s->comm, s->cstream));
+    NCCLCHK(rccl().Recv(down_recv, down_nr, ncclDouble, s->down, s->comm, s->cstream));
+  }
+  NCCLCHK(rccl().GroupEnd());
+  HIPCHK(hipEventRecord(done, s->cstream));
+  return PTM_OK;
+}
+static int shard_stage_and_start_halos(ptm_engine* e) {
+  ShardComm* s = e->shard;
+  int rc;
+  if (s->up >= 0 && (rc = ptm_copy_llike(e, e->nloc - 1, 1, s->ll_top))) return rc;
+  if (s->down >= 0 && (rc = ptm_copy_llike(e, 0, s->h_send, s->ll_bottom))) return rc;
+  const size_t W = (size_t)e->W;
+  if ((rc = shard_exchange(e, s->ll_top, W, s->ll_above, (size_t)s->h_recv * W, s->ll_bottom, (size_t)s->h_send * W, s->ll_below, W, s->ev_halo))) return rc;
+  s->halos_in_flight = true;
+  return PTM_OK;
+}
+
+extern "C" int ptm_shard_step(ptm_engine* e, int n) {
+  int rc = ready(e);
+  if (rc) return rc;
+  if (!e->shard) return fail(PTM_ERR_INVALID, "ptm_shard_init first");
+  if (e->cb || e->pcb) return fail(PTM_ERR_UNSUPPORTED, "sharded steps with a host-callback likelihood or host-side proposals are not built");
+  ShardComm* s = e->shard;
+  const bool overlap = !e->hist.rungs && !e->map.rungs;   // (a recorded exchanged rung reads its final row: needs the arrivals first)
+  // sweep plan: the boundary rungs are the ones whose llikes the neighbours need as halos (bottom h_send rungs, the top rung)
+  const int nl = e->nloc, nb = s->h_send < nl ? s->h_send : nl, nt = (s->up >= 0 && nl > nb) ? 1 : 0;
+  const int lo = nb, hi = nl - nt, mid = lo + (hi - lo) / 2;
+  for (int k = 0; k < n; ++k) {
+    if (!s->halos_in_flight && (rc = shard_stage_and_start_halos(e))) return rc;
+    HIPCHK(hipStreamWaitEvent(e->stream, s->ev_halo, 0));
+    s->halos_in_flight = false;
+    if ((rc = ptm_exchange_decide(e, s->ll_below, s->ll_above, s->h_recv, s->send_up, s->send_down))) return rc;
+    if ((rc = shard_exchange(e, s->send_up, s->row_doubles, s->recv_above, s->row_doubles, s->send_down, s->row_doubles, s->recv_below, s->row_doubles, s->ev_rows))) return rc;
+    if (!overlap) {
+      HIPCHK(hipStreamWaitEvent(e->stream, s->ev_rows, 0));
+      if ((rc = ptm_exchange_finish_and_sweep(e, s->recv_below, s->recv_above))) return rc;
+      continue;
+    }
+    if ((rc = ptm_sweep_rungs(e, lo, mid - lo, 0))) return rc;            // ... while the boundary rows travel
+    HIPCHK(hipStreamWaitEvent(e->stream, s->ev_rows, 0));
+    if ((rc = ptm_exchange_install(e, s->recv_below, s->recv_above))) return rc;
+    if ((rc = ptm_sweep_rungs(e, 0, nb, 0))) return rc;
+    if ((rc = ptm_sweep_rungs(e, nl - nt, nt, 0))) return rc;
+    if ((rc = shard_stage_and_start_halos(e))) return rc;                 // the NEXT step's halos ...
+    if ((rc = ptm_sweep_rungs(e, mid, hi - mid, 1))) return rc;           // ... travel behind the second half of the interior
+  }
+  return PTM_OK;
 }
 
 // ---- read-back ------------------------------------------------------------------------------------------------------

@@ -25,7 +25,7 @@ EXPORTS = [
     "ptm_last_error", "ptm_abi_version", "ptm_device_count", "ptm_engine_create", "ptm_engine_destroy",
     "ptm_set_bounds", "ptm_set_prior", "ptm_set_target_gaussian", "ptm_set_target_callback", "ptm_set_ladder", "ptm_set_evolve_temps", "ptm_get_invtemps", "ptm_set_invtemps",
     "ptm_set_proposals", "ptm_set_proposal_rung", "ptm_set_proposal_mixture", "ptm_set_proposal_callback", "ptm_set_states", "ptm_init_from_prior", "ptm_init_from_prior_k", "ptm_sweep", "ptm_step", "ptm_sync",
-    "ptm_copy_llike", "ptm_llike_device_ptr", "ptm_exchange_decide", "ptm_exchange_finish_and_sweep", "ptm_exchange_install", "ptm_sweep_rungs", "ptm_exchange_buffer_doubles", "ptm_exchange_row_capacity", "ptm_get_states",
+    "ptm_copy_llike", "ptm_llike_device_ptr", "ptm_exchange_decide", "ptm_exchange_finish_and_sweep", "ptm_exchange_install", "ptm_sweep_rungs", "ptm_exchange_buffer_doubles", "ptm_exchange_row_capacity", "ptm_shard_unique_id", "ptm_shard_init", "ptm_shard_step", "ptm_shard_finalize", "ptm_get_states",
     "ptm_get_array", "ptm_get_swap_counts", "ptm_get_last_swaps", "ptm_max_swaps_per_step", "ptm_get_history", "ptm_get_history_invtemps", "ptm_set_history", "ptm_set_map", "ptm_get_map", "ptm_restore", "ptm_step_count",
     "ptm_timer_start", "ptm_timer_stop", "ptm_get_kernel_times", "ptm_sweep_kernel_name", "ptm_debug_eval",
     "ptm_debug_philox", "ptm_debug_boxmuller", "ptm_debug_sqrt_scan", "ptm_debug_evaluate",
@@ -122,6 +122,10 @@ def load():
     L.ptm_set_proposal_rung.argtypes = [C.c_void_p, C.c_int, _dp, C.c_double]
     L.ptm_set_proposal_mixture.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp]
     L.ptm_set_proposal_callback.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.ptm_shard_unique_id.argtypes = [C.c_void_p]
+    L.ptm_shard_init.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, _i32p, C.c_int]
+    L.ptm_shard_step.argtypes = [C.c_void_p, C.c_int]
+    L.ptm_shard_finalize.argtypes = [C.c_void_p]
     L.ptm_restore.argtypes = [C.c_void_p, _dp, _dp, _i32p, _i32p, _i32p, C.POINTER(C.c_int64), C.c_uint64, C.POINTER(C.c_int64),
                               C.POINTER(C.c_int64)]
     L.ptm_debug_sqrt_scan.argtypes = [C.c_int, C.POINTER(C.c_uint64)]
@@ -343,6 +347,23 @@ class Engine:
         X = np.ascontiguousarray(X, dtype=np.float64).reshape(self.Nc, self.D)
         ll = None if llike is None else np.ascontiguousarray(llike, dtype=np.float64)
         _chk(self.L.ptm_set_states(self.h, _d(X), None if ll is None else _d(ll)))
+
+    # -- native RCCL sharding (ptm_shard_*): the C/C++ host's form of ptmcmc_amd.parallel.ShardedLadder
+    @staticmethod
+    def shard_unique_id():
+        buf = C.create_string_buffer(128)
+        _chk(load().ptm_shard_unique_id(buf))
+        return buf.raw
+
+    def shard_init(self, uid, rank, world, rung_counts, halo=0):
+        rc = np.ascontiguousarray(rung_counts, dtype=np.int32)
+        _chk(self.L.ptm_shard_init(self.h, C.c_char_p(uid), rank, world, rc.ctypes.data_as(_i32p), halo))
+
+    def shard_step(self, n=1):
+        _chk(self.L.ptm_shard_step(self.h, n))
+
+    def shard_finalize(self):
+        _chk(self.L.ptm_shard_finalize(self.h))
 
     def init_from_prior(self, k=0):
         """the k-th initial draw of every chain (k = 0: MH_chain::initialize(1)'s; ptm_init_from_prior_k)"""

@@ -298,7 +298,17 @@ def bench_main(args):
                            device=local, stream=stream.cuda_stream, time_kernels=True)
             pr.configure(eng, E.PROP_LOWER)
             eng.init_from_prior()
-            lad = ShardedLadder(EngineShard(eng, torch, dev, stream), dist, rank, world, halo=args.halo)
+            if getattr(args, "native_rccl", False):
+                class _Native:   # the engine library's own RCCL step (ptm_shard_*)
+                    def __init__(self, e): self.e = e
+                    def step(self, n): self.e.shard_step(n)
+                    def drain(self): pass
+                ids = [E.Engine.shard_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(ids, src=0)
+                eng.shard_init(ids[0], rank, world, [shard_bounds(NT, world, r)[1] for r in range(world)], args.halo)
+                lad = _Native(eng)
+            else:
+                lad = ShardedLadder(EngineShard(eng, torch, dev, stream), dist, rank, world, halo=args.halo)
         lad.step(300)             # set-up (untimed, uncounted): clocks ramped, chains off their prior draws, RCCL channels open
         lad.step(args.warmup)
         lad.drain()
@@ -339,7 +349,8 @@ def bench_main(args):
                                    "per-rung Cholesky proposal factors; uniform box prior" % W,
                        "dim": D, "rungs": NT, "walkers": W, "chains": nchains,
                        "sharding": ("%d blocks of %d whole ladders (walkers), no message in a step" % (world, args.walkers)) if by_walkers else
-                                   ("%d contiguous rung blocks of %d rungs; llike halo %d rungs; neighbour p2p over RCCL" % (world, nloc, args.halo))},
+                                   ("%d contiguous rung blocks of %d rungs; llike halo %d rungs; neighbour p2p over RCCL (%s)"
+                                    % (world, nloc, args.halo, "ptm_shard_*: native ncclSend/ncclRecv" if getattr(args, "native_rccl", False) else "torch.distributed"))},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": B.HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / B.HBM_PEAK_GBS, "traffic": None, "kernel": eng.sweep_kernel_name,
                          "kernel_avg_ms": kavg_ms, "per_gpu": True, "bytes_per_mh_step": B.algorithmic_bytes(D)},

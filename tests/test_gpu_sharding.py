@@ -148,3 +148,41 @@ def test_bench_distributed_path_by_walkers_with_one_rank():
     assert out.returncode == 0, out.stderr[-2000:]
     rec = json.loads(out.stdout.strip().splitlines()[-1])
     assert rec["n_gpus"] == 1 and rec["value"] > 1e8 and "whole ladders" in rec["config"]["sharding"]
+
+
+def test_native_rccl_sharded_step_with_one_rank():
+    """ptm_shard_*: the sharded step driven by the engine library itself over RCCL (dlopen'ed at the first call).  With one
+    rank there is nobody to talk to, but everything else runs: communicator, side stream and events, the overlapped launch
+    order over interior / boundary rung ranges (through the compacted sweep at this size) -- and must give ptm_step's chains."""
+    D, Nt, W, sr = 32, 24, 1024, 0.3
+    pr = GaussianProblem(D, Nt, 1e3)
+    ref = E.Engine(D, Nt, W, swap_rate=sr)
+    pr.configure(ref, E.PROP_LOWER)
+    ref.init_from_prior()
+    eng = E.Engine(D, Nt, W, swap_rate=sr)
+    pr.configure(eng, E.PROP_LOWER)
+    eng.set_states(ref.states())
+    uid = E.Engine.shard_unique_id()
+    assert len(uid) == 128 and any(uid)
+    with pytest.raises(E.PtmError, match="rung_counts"):
+        eng.shard_init(uid, 0, 1, [Nt - 1])
+    eng.shard_init(uid, 0, 1, [Nt])
+    for k in range(3):
+        ref.step(4); eng.shard_step(4)
+        eng.sync()
+        assert np.array_equal(eng.states(), ref.states()), k
+    for name in ("llike", "ntries", "naccept", "nhist", "last_type"):
+        assert np.array_equal(getattr(eng, name), getattr(ref, name)), name
+    eng.shard_finalize()
+    eng.step(2); ref.step(2)                       # back to the plain step
+    assert np.array_equal(eng.states(), ref.states())
+    eng.close(); ref.close()
+
+
+def test_bench_native_rccl_path_with_one_rank():
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29543", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--native-rccl", "--steps", "3",
+                          "--warmup", "1", "--walkers", "1024"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = json.loads(out.stdout.strip().splitlines()[-1])
+    assert rec["n_gpus"] == 1 and rec["value"] > 1e8 and "native ncclSend" in rec["config"]["sharding"]
