@@ -17,7 +17,7 @@ TOL = 1e-10
 
 def test_device_present_and_abi():
     assert E.device_count() >= 1
-    assert E.load().ptm_abi_version() == 1
+    assert E.load().ptm_abi_version() == 2
 
 
 def test_philox_on_device_matches_known_answers_and_oracle():
