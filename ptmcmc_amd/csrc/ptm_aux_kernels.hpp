@@ -1,82 +1,9 @@
 // ptm_aux_kernels.hpp -- non-template kernels (exchange phase, verification hooks); included by ptm_engine.hip only.
 #pragma once
 #include "ptm_kernels.hpp"
+#include "ptm_decide.hpp"
 
 namespace ptm {
-
-// ------------------------------------------------------------------------------------------------
-// exchange phase of parallel_tempering_chains::step (chain.cc:1410-1537), one block per walker-ladder.
-// decide_kernel replays the step's candidate draws, decides every exchange that concerns the shard and lists the row
-// moves; move_kernel applies them in place (whole contiguous rows) and packs the rows that leave the shard;
-// install_kernel lands the rows that arrive from the adjacent shards.  touch[] tells the sweep kernel which rungs skip
-// their MH move.
-//
-// Boundary message (one per direction and step): an int32 row count in the first 8 bytes (+8 bytes padding), then
-// `row_cap` slots of RD = DP+4 doubles {x[DP], llike, lprior, walker, 0}.  Rows are appended in no particular order.
-// ------------------------------------------------------------------------------------------------
-constexpr int MSG_HDR = 2;    // doubles before the first row slot
-constexpr int ROW_EXTRA = 4;  // {llike, lprior, walker, pad}: keeps row slots 32-byte multiples
-
-// claims the next slot of a boundary message; null (and error bit 4) when the message is full
-__device__ __forceinline__ double* claim_row(double* buf, int cap, int RD, int* err) {
-  const int slot = atomicAdd(reinterpret_cast<int*>(buf), 1);
-  if (slot >= cap) { atomicOr(err, 4); return nullptr; }
-  return buf + MSG_HDR + (size_t)slot * RD;
-}
-
-struct Decide {
-  int DP, Nt, r0, nloc, W, Nc, ms;
-  int w_off;                  // global index of local walker 0: the ladder streams are keyed by the global walker
-  uint64_t seed, step;
-  double thresh;              // (Ntemps-1)*swap_rate/maxswapsperstep (chain.cc:1413)
-  const double* beta;         // [Nt]
-  const double* ll_below;     // [W]      llike of rung r0-1 (top rung of the shard below), null on the first shard
-  const double* ll_above;     // [H][W]   llike of rungs r1 .. r1+H-1 (bottom rungs of the shard above), null on the last
-  int H;                      // halo depth actually available above (0 on the last shard)
-  double* x;                  // [Nc][DP] rows (only the overflow path moves rows here)
-  double* ll;
-  double* lp;
-  unsigned char* touch;
-  int *arr_below, *arr_above;      // [W]  landing slot of the row arriving across the lower / upper boundary, or -1
-  int* swap_log;                   // [W][ms]  this step's slot of the log ring; per candidate: -2 none/dropped, -3 not this
-                                   //          shard's, else rung | accepted<<30
-  double *send_up, *send_down;     // boundary messages or null
-  int row_cap;
-  int *mv_src, *mv_dst, *mv_n;     // [W][MVCAP], [W][MVCAP], [W]: the ladder's row moves for move_kernel
-  int* err;
-  // history (Hist, ptm_kernels.hpp): a rung touched twice in one step makes two add_state calls; the first one sees the
-  // row the rung held BETWEEN its two exchanges.  If that call is one that saves, the row is copied by move_kernel.
-  Hist hist;
-  int add_every_n;
-  const unsigned int* nhist;
-  const int *naccept, *ntries, *last_type;
-  MapT map;   // MAP tracking: the in-between row is a candidate too (its log-posterior at this rung's temperature)
-  // evolving ladders (parallel_tempering_chains::evolve_temps, chain.hh:302-307): every accepted exchange pries its gap
-  // apart (pry_temps, chain.cc:1501-1518,1809-1846), so each ladder owns its temperatures.  Whole-ladder shards only.
-  double evolve_rate;   // 0: fixed ladder (beta[] rules)
-  double* beta_w;       // [W][Nt] the ladders' inverse temperatures, rewritten after a step that pried
-  int lp_is_const;      // every chain's lprior is lp_const (all-uniform prior, every state inside the box): the exchange moves no lprior
-  double lp_const;
-  double* betaC_direct; // [Nc] few ladders: the chain-indexed image is written here as well (no transposition launch); else null
-  double* beta_add;     // [Nc] with history / MAP tracking: the temperature each touched rung had at its last add_state of
-                        // the phase (the sweep kernel saves that row); null otherwise
-};
-constexpr int HIST_DST = -(1 << 30);   // move-list destination code: HIST_DST - c = "into chain c's history"
-constexpr int MAP_DST = -(1 << 29);    //                             MAP_DST - c  = "chain c's new MAP" (c < 2^29)
-
-// llike of global rung r for walker w, r inside the shard's window
-__device__ __forceinline__ double win_llike(const Decide& p, int r, int w) {
-  const int r1 = p.r0 + p.nloc;
-  if (r < p.r0) return p.ll_below[w];
-  if (r >= r1) return p.ll_above[(size_t)(r - r1) * p.W + w];
-  return p.ll[(size_t)(r - p.r0) * p.W + w];
-}
-
-// bijection block -> walker that gives XCD k (blocks k, k+8, ...) the k-th contiguous eighth of the walkers
-__device__ __forceinline__ int xcd_walker(int b, int W) {
-  const int q = W >> 3, rem = W & 7, xcd = b & 7;
-  return xcd * q + (xcd < rem ? xcd : rem) + (b >> 3);
-}
 
 // ------------------------------------------------------------------------------------------------
 // Partition of a sweep's chains (lean MFMA build on big populations): ~1/6 of a long ladder's chains took part in an exchange
@@ -149,593 +76,11 @@ __global__ __launch_bounds__(256) void nhist_flush_kernel(unsigned int* __restri
   if (c < Nc) nhist[c] += n;
 }
 
-constexpr int MVCAP = 256;  // rows one ladder can move per step on the register path (move_kernel)
-typedef double d2_t __attribute__((ext_vector_type(2)));  // (HIP's double2 struct does not stay in registers as an array)
-
-// The reference decides the candidates strictly in pick order (chain.cc:1410-1537).  Two facts make that order
-// parallel over the ladder without changing any outcome:
-//   (1) filter: a pick n is dropped iff an earlier SURVIVING pick is n or n-1 (chain.cc:1417-1418).  Only the first
-//       pick of a rung value can survive, and alive[n] = !(alive[n-1] && first[n-1] < first[n]): a recurrence along
-//       RUNS of consecutive picked rungs, independent between runs;
-//   (2) trials: two surviving picks on adjacent rungs (n, n+1) exist only if n+1 was picked first, and only then does
-//       pick n see an updated upper rung -- so each run of consecutive surviving rungs is decided top-down, and runs
-//       are independent of each other.
-// One lane walks each run; everything else (draws, counters, move list) is parallel over picks.  The draws and the
-// filter cover the whole ladder (they are replicated on every shard); everything after them runs over the compacted
-// list of the surviving picks inside the shard's window, on LDS arrays indexed by window rung.
-// DECIDE_THREADS = 256 when the shard sees most of the ladder (~200 candidates and ~100 survivors in ONE pass per phase),
-// 64 for a short shard of many ladders, where the per-block fixed costs are what counts.
-template <int DECIDE_THREADS>
-__global__ __launch_bounds__(DECIDE_THREADS) void decide_kernel(const Decide p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  // walker of this block.  Consecutive workgroups go round the 8 XCDs, each with its own L2, while ll / lp / touch are
-  // [rung][walker]: a 128-byte line holds 16 (128 for touch) neighbouring walkers.  Handing each XCD a contiguous range of
-  // walkers keeps the ladders that share those lines on one L2.
-  const int w = xcd_walker(blockIdx.x, p.W);
-  const int lane = threadIdx.x;
-  const int Nt = p.Nt, ms = p.ms;
-  const int NONE = 0x7fffffff;
-  const int r1 = p.r0 + p.nloc;
-  // window of rungs whose llike this shard knows: its own, one below, H above
-  const int wlo = p.r0 - (p.ll_below ? 1 : 0), whi = r1 - 1 + p.H;
-  const int WN = whi - wlo + 1;
-  // LDS carve (mirrored by decide_lds_bytes on the host; all offsets multiples of 8)
-  double* llc_ = reinterpret_cast<double*>(smem);                             // [WN]  llike view of the touched rungs
-  int* first = reinterpret_cast<int*>(llc_ + WN);                             // [Nt]  first pick of each rung value
-  int* cand = first + ((Nt + 1) & ~1);                                        // [ms]  rung of the pick / -2 none or dropped
-  uint32_t* ua = reinterpret_cast<uint32_t*>(cand + ((ms + 1) & ~1));         // [ms]  accept uniform of the pick (raw)
-  int* cnt = reinterpret_cast<int*>(ua + ((ms + 1) & ~1));                    // [2]   list length, move count
-  unsigned short* perm_ = reinterpret_cast<unsigned short*>(cnt + 2);         // [WN]  source rung of the row now at a rung
-  unsigned short* inv_ = perm_ + ((WN + 3) & ~3);                             // [WN]  inverse of perm
-  unsigned short* list = inv_ + ((WN + 3) & ~3);                              // [ms]  surviving picks that are ours
-  unsigned short* mid_ = list + ((ms + 3) & ~3);                              // [WN]  row a twice-touched rung held in between
-  unsigned char* alive = reinterpret_cast<unsigned char*>(mid_ + ((WN + 3) & ~3));  // [ms] 0 dropped, 1 survives and is
-                                                                                    //      ours, 2 survives, not ours
-  unsigned char* accf = alive + ((ms + 7) & ~7);                              // [ms]
-  // The block applies the ladder's row moves itself (below) from a list kept in LDS, up to FCAP rows (16 rounds of one
-  // row per 16-lane group); a longer list (64-thread form only) goes to move_kernel through global memory.
-  constexpr int FCAP = DECIDE_THREADS;
-  int* lmv = reinterpret_cast<int*>(accf + ((ms + 7) & ~7));                  // [2][MVCAP]
-  // evolving ladders only: gaps (in the end their local prefix sums), chunk totals / offsets, {normaliser, pries}, and the
-  // surviving picks in PICK ORDER (position t): what the chain of dependent trials needs, laid out for one lane to stream
-  const int msp = (ms + 3) & ~3;
-  double* gap = reinterpret_cast<double*>(lmv + 2 * MVCAP);                   // [Nt]
-  double* ct = gap + Nt;                                                      // [2][(Nt + 31) / 32]
-  double* ev = ct + 2 * ((Nt + 31) / 32);                                     // [2]
-  double* tlu = ev + 2;                                                       // [ms]  log of the pick's accept uniform
-  double* tgap = tlu + msp;                                                   // [ms]  the pick's gap (a pair is tried once: never pried before)
-  double* tlla = tgap + msp;                                                  // [ms]  llike of the lower rung (nothing earlier can change it)
-  double* tllb = tlla + msp;                                                  // [ms]  llike of the upper rung (an earlier pick above may change it)
-  unsigned short* olist = reinterpret_cast<unsigned short*>(tllb + msp);      // [ms]  position -> pick
-  unsigned short* opos = olist + msp;                                         // [ms]  pick -> position
-  unsigned short* ti = opos + msp;                                            // [ms]  the pick's lower rung
-  short* tdep = reinterpret_cast<short*>(ti + msp);                           // [ms]  position of the (later) pick on the pair below, or -1
-  unsigned char* tacc = reinterpret_cast<unsigned char*>(tdep + msp);         // [ms]  accepted
-  // ... with history / MAP tracking on top (an add_state of the phase sees the temperature BETWEEN two pries of the step):
-  double* p0 = reinterpret_cast<double*>(tacc + ((ms + 7) & ~7));             // [max(Nt, MVCAP)]  prefix sums of the step's first gaps
-  double* tS = p0 + (Nt > MVCAP ? Nt : MVCAP);                                // [ms]  sum of the gaps the pick saw (0: nothing pried yet)
-  double* tdl = tS + msp;                                                     // [ms]  what the pick added to its gap
-  double* bklo = tdl + msp;                                                   // [ms]  (by pick) temperature of the pick's lower rung then
-  double* gb = p0;                                                            // [MVCAP] temperature for a HIST / MAP move (p0 is done by then)
-  double* llc = llc_ - wlo;                // indexed by global rung
-  unsigned short* perm = perm_ - wlo;
-  unsigned short* inv = inv_ - wlo;
-  unsigned short* mid = mid_ - wlo;
-  cdp beta = as_c(p.beta);
-
-  for (int i = lane; i < Nt; i += DECIDE_THREADS) first[i] = NONE;
-  if (lane == 0) { cnt[0] = 0; cnt[1] = 0; p.arr_below[w] = -1; p.arr_above[w] = -1; }
-  __syncthreads();
-  // -- candidate draws (chain.cc:1410-1416): block k of the ladder stream gives {u_try, u_pick, u_accept}
-  for (int k = lane; k < ms; k += DECIDE_THREADS) {
-    const u32x4 o = draw_block(p.seed, TAG_PT, (uint32_t)(w + p.w_off), p.step, (uint32_t)k);
-    int n = -2;
-    if (Nt > 1 && u01(o.v0) < p.thresh) n = (int)(u01(o.v1) * (Nt - 1));
-    cand[k] = n;
-    ua[k] = o.v2;  // the accept uniform's slot is reserved whether or not it is needed (cf. Q5)
-    alive[k] = 0;
-    accf[k] = 0;
-    if (n >= 0) atomicMin(&first[n], k);
-  }
-  const bool evolve = p.evolve_rate > 0 && Nt > 1;
-  const bool evb = evolve && p.beta_add != nullptr;   // history / MAP tracking of evolving ladders
-  if (evolve) {
-    const double* bw = p.beta_w + (size_t)w * Nt;
-    for (int k = lane; k < Nt - 1; k += DECIDE_THREADS) gap[k] = bw[k] - bw[k + 1];   // chain.cc:1816
-  }
-  __syncthreads();
-  // -- filter (1): run heads walk their run upwards
-  for (int k = lane; k < ms; k += DECIDE_THREADS) {
-    const int n = cand[k];
-    if (n < 0 || first[n] != k) continue;                      // repeated rung value: dropped
-    if (n > 0 && first[n - 1] != NONE) continue;               // not a run head
-    bool a = true;
-    for (int m = n;; ++m) {
-      alive[first[m]] = a ? 1 : 0;
-      if (m + 1 > Nt - 2 || first[m + 1] == NONE) break;
-      a = !(a && first[m] < first[m + 1]);
-    }
-  }
-  __syncthreads();
-#define PTM_ALIVE_RUNG(r) ((r) >= 0 && (r) <= Nt - 2 && first[(r)] != NONE && alive[first[(r)]])
-  // -- compaction: the surviving picks whose pair lies inside the window
-  for (int k = lane; k < ms; k += DECIDE_THREADS) {
-    const int n = cand[k];
-    if (n < 0) continue;
-    if (!alive[k]) { cand[k] = -2; continue; }
-    if (n < wlo || n + 1 > whi) { alive[k] = 2; continue; }     // survives, but is not this shard's to decide
-    list[atomicAdd(&cnt[0], 1)] = (unsigned short)k;
-  }
-  __syncthreads();
-  const int nl = cnt[0];
-  // -- working copy of the touched rungs (gather_llikes, chain.cc:1434); each touched rung is set up by exactly one
-  //    lane: the pick whose lower rung it is, or -- for the top of a run -- the pick just below it
-  for (int j = lane; j < nl; j += DECIDE_THREADS) {
-    const int n = cand[list[j]];
-    const bool top = !PTM_ALIVE_RUNG(n + 1) || n + 2 > whi;    // (an alive pick above that lies outside the window sets up nothing)
-    const double a = win_llike(p, n, w);
-    const double b = top ? win_llike(p, n + 1, w) : 0.0;
-    llc[n] = a;
-    perm[n] = (unsigned short)n;
-    inv[n] = (unsigned short)n;
-    if (top) {
-      llc[n + 1] = b;
-      perm[n + 1] = (unsigned short)(n + 1);
-      inv[n + 1] = (unsigned short)(n + 1);
-    }
-  }
-  __syncthreads();
-  // -- evolving ladder: every accepted exchange changes the normalisation of ALL the gaps (pry_temps renormalises the
-  //    ladder, chain.cc:1829-1844), so the trials are one chain in pick order.  The gaps stay lazily normalised: a pry is
-  //    gap[i] *= 1 + rate and S += the increase; the gap a later trial sees is gap[i] / (S / (1 - beta_last)) -- O(1) per
-  //    exchange, and the very bits of the stored temperatures until the step's first accepted exchange.  The Metropolis
-  //    test is taken with both sides multiplied by S, so the chain of dependent trials holds no division.
-  if (evolve) {
-    const int nch = (Nt - 1 + 31) / 32;
-    // the surviving picks in pick order (one wave: ballot + prefix count)
-    if (lane < 64) {
-      int base = 0;
-      for (int k0 = 0; k0 < ms; k0 += 64) {
-        const int k = k0 + lane;
-        const bool f = k < ms && alive[k] == 1;
-        const unsigned long long m = __ballot(f);
-        if (f) {
-          const int t = base + __builtin_popcountll(m & ((1ull << lane) - 1ull));
-          olist[t] = (unsigned short)k;
-          opos[k] = (unsigned short)t;
-        }
-        base += __builtin_popcountll(m);
-      }
-    }
-    for (int q = lane; q < nch; q += DECIDE_THREADS) {   // S: chunks of 32 left to right, then the chunk totals
-      double loc = 0.0;
-      for (int k = 32 * q; k < Nt - 1 && k < 32 * q + 32; ++k) {
-        if (evb) p0[k] = loc;
-        loc = loc + gap[k];
-      }
-      ct[q] = loc;
-    }
-    __syncthreads();
-    for (int t = lane; t < nl; t += DECIDE_THREADS) {
-      const int k = olist[t];
-      const int i = cand[k];
-      ti[t] = (unsigned short)i;
-      tlu[t] = dlog_u01(ua[k]);
-      tgap[t] = gap[i];
-      tlla[t] = llc[i];
-      tllb[t] = llc[i + 1];
-      tdep[t] = PTM_ALIVE_RUNG(i - 1) ? (short)opos[first[i - 1]] : (short)-1;
-      tacc[t] = 0;
-    }
-    __syncthreads();
-    if (lane == 0) {
-      double S = 0.0;
-      for (int q = 0; q < nch; ++q) { ct[nch + q] = S; S = S + ct[q]; }
-      const double c1 = 1 - p.beta_w[(size_t)w * Nt + Nt - 1];   // chain.cc:1833
-      const double grow = 1.0 + p.evolve_rate;
-      int npry = 0;
-      // one lane streams the picks; the next pick's operands are asked for before this one is decided
-      double n_lu = 0, n_gap = 0, n_lla = 0, n_llb = 0, fwd = 0;
-      int n_dep = -1, n_i = 0, fwd_to = -1;
-      if (nl > 0) { n_lu = tlu[0]; n_gap = tgap[0]; n_lla = tlla[0]; n_llb = tllb[0]; n_dep = tdep[0]; n_i = ti[0]; }
-      for (int t = 0; t < nl; ++t) {
-        const double lu = n_lu, g = n_gap, lla_raw = n_lla, llb_raw = (fwd_to == t) ? fwd : n_llb;
-        const int dep = n_dep, i = n_i;
-        if (t + 1 < nl) { n_lu = tlu[t + 1]; n_gap = tgap[t + 1]; n_lla = tlla[t + 1]; n_llb = tllb[t + 1]; n_dep = tdep[t + 1]; n_i = ti[t + 1]; }
-        double lla = lla_raw;
-        if (!(lla > -1e200)) lla = -1e200;
-        double llb = llb_raw;
-        if (!(llb > -1e200)) llb = -1e200;
-        // log u < logH with logH = (gap / (S / c1)) * (llb - lla), both sides times S > 0: no division on this chain of
-        // dependent trials.  Until the step's first pry the gap is the stored temperatures' own difference.
-        bool acc = true;
-        if (npry) {
-          const double tt = (g * c1) * (llb - lla);
-          if (tt < 0) acc = lu * S < tt;
-        } else {
-          const double logH = g * (llb - lla);
-          if (logH < 0) acc = lu < logH;
-        }
-        if (evb) { tS[t] = npry ? S : 0.0; tdl[t] = 0.0; }
-        if (acc) {
-          tacc[t] = 1;
-          const double sn = g * grow;   // chain.cc:1829
-          const double inc = sn - g;
-          S = S + inc;
-          gap[i] = sn;
-          ++npry;
-          if (evb) tdl[t] = inc;
-          if (dep >= 0) { tllb[dep] = llb_raw; fwd = llb_raw; fwd_to = dep; }   // the row now on rung i came from rung i + 1
-        }
-      }
-      ev[1] = (double)npry;
-    }
-    __syncthreads();
-  }
-  // -- trials (2): the top pick of each run of surviving rungs walks the run downwards (chain.cc:1436-1537); with an
-  //    evolving ladder the decisions are the ones just taken
-  for (int j = lane; j < nl; j += DECIDE_THREADS) {
-    const int n = cand[list[j]];
-    const bool up = PTM_ALIVE_RUNG(n + 1);
-    if (up && n + 1 < whi) continue;                             // not the top of a run (the pick above is in the list)
-    if (up) {
-      // the pick above decides the pair (whi, whi+1), outside the window, and may replace rung whi: the content of
-      // every rung of this run is then unknown here.  Harmless as long as the run ends above the shard's own rungs.
-      for (int i = n; i >= wlo; --i) {
-        if (i + 1 <= r1) atomicOr(p.err, 2);                     // would decide a local / straddling exchange blindly
-        alive[first[i]] = 2;
-        if (!PTM_ALIVE_RUNG(i - 1)) break;
-      }
-      continue;
-    }
-    for (int i = n; i >= wlo; --i) {                             // below the window nothing concerns us
-      const int kk = first[i];
-      bool acc = true;
-      if (evolve) {
-        acc = tacc[opos[kk]] != 0;
-      } else {
-        double lla = llc[i];
-        if (!(lla > -1e200)) lla = -1e200;
-        double llb = llc[i + 1];
-        if (!(llb > -1e200)) llb = -1e200;
-        const double logH = -(beta[i + 1] - beta[i]) * (llb - lla);
-        if (logH < 0) acc = dlog_u01(ua[kk]) < logH;
-      }
-      if (acc) {
-        // the row that leaves this shard downwards must be one of ours (else it crossed two boundaries in one step)
-        if (i + 1 == p.r0 && (perm[i + 1] < p.r0 || perm[i + 1] >= r1)) atomicOr(p.err, 1);
-        const double t = llc[i]; llc[i] = llc[i + 1]; llc[i + 1] = t;
-        const unsigned short s = perm[i]; perm[i] = perm[i + 1]; perm[i + 1] = s;
-        accf[kk] = 1;
-      }
-      if (!PTM_ALIVE_RUNG(i - 1)) break;
-      mid[i] = perm[i];   // the pick below exchanges rung i again: this is what it held in between
-    }
-  }
-  __syncthreads();
-  if (evolve) {
-    const int nch = (Nt - 1 + 31) / 32;
-    if (evb) {
-      // The temperature a rung had when a pick's add_state calls reached it (both rungs of the pair, before the pick's own
-      // pry; chain.cc:1487-1490,1531-1534): 1 - (P0 + D) / normaliser, P0 = prefix of the step's first gaps, D = what
-      // the earlier accepted picks added to the gaps below the rung, in pick order.  No gap between the pair's two rungs
-      // has been pried yet (a pair is tried once), so D is the same for both.
-      for (int k = lane; k < Nt - 1; k += DECIDE_THREADS) p0[k] = ct[nch + (k >> 5)] + p0[k];
-      __syncthreads();
-      const double* bw = p.beta_w + (size_t)w * Nt;
-      for (int j = lane; j < nl; j += DECIDE_THREADS) {
-        const int k = list[j];
-        const int i = cand[k];
-        const int t = opos[k];
-        double D = 0.0;
-        for (int t2 = 0; t2 < t; ++t2)
-          if (tacc[t2] && ti[t2] < i) D = D + tdl[t2];
-        const double Sk = tS[t];
-        const double nk = Sk / (1 - bw[Nt - 1]);   // the normaliser then (chain.cc:1833)
-        const double blo = (Sk == 0.0 || i == 0) ? bw[i] : 1 - (p0[i] + D) / nk;
-        const double bhi = (Sk == 0.0 || i + 1 == Nt - 1) ? bw[i + 1] : 1 - (p0[i + 1] + D) / nk;
-        bklo[k] = blo;
-        // last add of the phase: always for the upper rung (a pick on the pair above came earlier), for the lower rung
-        // unless a later pick exchanges it again
-        p.beta_add[(size_t)(i + 1) * p.W + w] = bhi;
-        if (!PTM_ALIVE_RUNG(i - 1)) p.beta_add[(size_t)i * p.W + w] = blo;
-      }
-      __syncthreads();
-    }
-    if (ev[1] > 0) {   // the new temperatures (chain.cc:1834-1844): beta_k = 1 - P_k / (total / (1 - beta_last))
-      for (int q = lane; q < nch; q += DECIDE_THREADS) {
-        double loc = 0.0;
-        for (int k = 32 * q; k < Nt - 1 && k < 32 * q + 32; ++k) { const double g = gap[k]; gap[k] = loc; loc = loc + g; }
-        ct[q] = loc;
-      }
-      __syncthreads();
-      if (lane == 0) {
-        double off = 0.0;
-        for (int q = 0; q < nch; ++q) { ct[nch + q] = off; off = off + ct[q]; }
-        ev[0] = off / (1 - p.beta_w[(size_t)w * Nt + Nt - 1]);
-      }
-      __syncthreads();
-      const double nn = ev[0];
-      for (int k = 1 + lane; k < Nt - 1; k += DECIDE_THREADS) {
-        const double bk = 1 - (ct[nch + (k >> 5)] + gap[k]) / nn;
-        p.beta_w[(size_t)w * Nt + k] = bk;
-        if (p.betaC_direct) p.betaC_direct[(size_t)k * p.W + w] = bk;
-      }
-    }
-  }
-  // -- the step's log
-#if !(defined(PTM_DECIDE_ABLATE) && (PTM_DECIDE_ABLATE & 4))
-  for (int k = lane; k < ms; k += DECIDE_THREADS)
-    p.swap_log[(size_t)w * ms + k] = alive[k] == 1 ? (cand[k] | (accf[k] ? 0x40000000 : 0)) : (alive[k] == 2 ? -3 : -2);
-#endif
-  // -- counters, the touch counts of the local rungs and the inverse permutation
-  for (int j = lane; j < nl; j += DECIDE_THREADS) {
-    const int k = list[j];
-    if (alive[k] != 1) continue;
-    const int i = cand[k];
-    // (swap_count / swap_accept_count, chain.cc:1498,1536, are not touched here: 185 scattered read-modify-writes per
-    //  ladder and step.  fold_swap_log_kernel adds the logged steps to them every PTM_LOG_RING steps and on demand.)
-    const int rtop = (PTM_ALIVE_RUNG(i + 1) && alive[first[i + 1]] == 1) ? i : i + 1;  // rung i+1 belongs to the pick above, if ours
-    for (int r = i; r <= rtop; ++r) {
-      if (r >= p.r0 && r < r1) {
-        const int below_alive = (r > 0 && PTM_ALIVE_RUNG(r - 1) && alive[first[r - 1]] == 1) ? 1 : 0;
-        const int self_alive = (r == i) ? 1 : 0;
-#if !(defined(PTM_DECIDE_ABLATE) && (PTM_DECIDE_ABLATE & 2))
-        p.touch[(r - p.r0) * p.W + w] = (unsigned char)(below_alive + self_alive);
-#endif
-      }
-      const int s = perm[r];
-      if (s != r) inv[s] = (unsigned short)r;             // the row that started at s ends at r
-    }
-  }
-  __syncthreads();
-  // -- the row moves.  The phase's net effect on the touched rungs is a permutation of rows: new row[r] =
-  //    old row[perm[r]].  List every move (source slot -> destination slot, or -> boundary message for a row that
-  //    leaves the shard) for move_kernel; the hole an arrival will fill is named in arr_above / arr_below.
-  int* gs = lmv;
-  int* gd = lmv + MVCAP;
-  // source slot of the in-between row of rung r if its FIRST add_state of this step is one that saves, else -1
-  auto hist_mid_src = [&](int r) -> int {
-    if (r - p.r0 >= p.hist.rungs || r < p.r0 || r >= r1) return -1;
-    if (!(r > 0 && PTM_ALIVE_RUNG(r - 1) && alive[first[r - 1]] == 1)) return -1;   // touched once only
-    const int c = (r - p.r0) * p.W + w;
-    if (p.nhist[c] % (unsigned int)p.add_every_n != 0u) return -1;
-    const int s1 = mid[r];
-    if (s1 < p.r0 || s1 >= r1) { atomicOr(p.err, 16); return -1; }   // (the host keeps recorded rungs away from shard tops)
-    return (s1 - p.r0) * p.W + w;
-  };
-  // the same for MAP tracking: source slot of rung r's in-between row if its log-posterior at rung r's temperature
-  // beats the rung's MAP (the first of the two add_state calls sees it, chain.cc:931-934), else -1
-  auto map_mid_src = [&](int r, double bmid) -> int {
-    if (r - p.r0 >= p.map.rungs || r < p.r0 || r >= r1) return -1;
-    if (!(r > 0 && PTM_ALIVE_RUNG(r - 1) && alive[first[r - 1]] == 1)) return -1;   // touched once only
-    const int s1 = mid[r];
-    if (s1 < p.r0 || s1 >= r1) { atomicOr(p.err, 16); return -1; }
-    const int cs = (s1 - p.r0) * p.W + w;
-    const double t = bmid * p.ll[cs];
-    return (p.lp[cs] + t > p.map.lpost[(r - p.r0) * p.W + w]) ? cs : -1;
-  };
-  for (int j = lane; j < nl; j += DECIDE_THREADS) {
-    const int k = list[j];
-    if (alive[k] != 1) continue;
-    const int i = cand[k];
-    const int rtop = (PTM_ALIVE_RUNG(i + 1) && alive[first[i + 1]] == 1) ? i : i + 1;
-    const double bmid = evb ? bklo[k] : beta[i];   // rung i's temperature at this pick's add_state
-    if (p.hist.rungs) {
-      const int hs = hist_mid_src(i);
-      if (hs >= 0) {
-        const int m = atomicAdd(&cnt[1], 1);
-        if (m < MVCAP) { gs[m] = hs; gd[m] = HIST_DST - ((i - p.r0) * p.W + w); if (evb) gb[m] = bmid; }
-      }
-    }
-    if (p.map.rungs) {
-      const int ms_ = map_mid_src(i, bmid);
-      if (ms_ >= 0) {
-        const int m = atomicAdd(&cnt[1], 1);
-        if (m < MVCAP) { gs[m] = ms_; gd[m] = MAP_DST - ((i - p.r0) * p.W + w); if (evb) gb[m] = bmid; }
-      }
-    }
-    for (int r = i; r <= rtop; ++r) {
-      if (r < p.r0 || r >= r1 || perm[r] == r) continue;
-      const int s = perm[r], to = inv[r];
-      const int cr = (r - p.r0) * p.W + w;
-      if (s >= p.r0 && s < r1) {                            // local -> local
-        const int m = atomicAdd(&cnt[1], 1);
-        if (m < MVCAP) { gs[m] = (s - p.r0) * p.W + w; gd[m] = cr; }
-      } else {
-        (s >= r1 ? p.arr_above : p.arr_below)[w] = cr;       // the hole: an arrival from the adjacent shard lands here
-      }
-      if (to < p.r0 || to >= r1) {                           // rung r's old row leaves the shard
-        const int m = atomicAdd(&cnt[1], 1);
-        if (m < MVCAP) { gs[m] = cr; gd[m] = (to >= r1) ? -1 : -2; }
-        if (!((to >= r1) ? p.send_up : p.send_down)) atomicOr(p.err, 1);
-      }
-    }
-  }
-  __syncthreads();
-#if defined(PTM_DECIDE_ABLATE) && (PTM_DECIDE_ABLATE & 8)
-  const int nmv = 0;
-#else
-  const int nmv = cnt[1];
-#endif
-  if (nmv > FCAP && nmv <= MVCAP) {   // too long for this block's registers: move_kernel takes it from here
-    for (int j = lane; j < nmv; j += DECIDE_THREADS) {
-      p.mv_src[(size_t)w * MVCAP + j] = gs[j];
-      p.mv_dst[(size_t)w * MVCAP + j] = gd[j];
-    }
-    if (lane == 0) p.mv_n[w] = nmv;
-    return;
-  }
-  if (nmv <= FCAP) {
-    // ---- the moves, in place, by this block: GATHER every moved row into registers (16 lanes x 16 B = one 256-B row,
-    //      one row per 16-lane group and round, up to 16 rounds), wait for all loads of all threads, then SCATTER.  With every read
-    //      finished before the first write no ordering between the moves is needed (they form cycles over this ladder's
-    //      own rows; other ladders' rows are never touched).
-    const int DPm = p.DP, RD = DPm + ROW_EXTRA;
-    for (int j = lane; j < nmv; j += DECIDE_THREADS) {
-      const int dv = gd[j];
-      if (dv == -1 || dv == -2) {   // a row that leaves the shard: claim its slot in the boundary message
-        const int dir = dv == -1 ? 0 : 1;
-        const int slot = atomicAdd(reinterpret_cast<int*>(dir ? p.send_down : p.send_up), 1);
-        if (slot >= p.row_cap) { atomicOr(p.err, 4); gd[j] = -3; }
-        else gd[j] = -4 - (2 * slot + dir);
-      }
-    }
-    __syncthreads();
-    const int g = lane >> 4, sub = lane & 15;
-    const bool act = 2 * sub < DPm;         // DP/2 lanes of 16 carry a row (16 B each)
-    const int col = act ? 2 * sub : 0;      // idle lanes re-read column 0 (harmless) so that no load is predicated
-    constexpr int GR = DECIDE_THREADS / 16;   // rows per round
-    d2_t v[16];
-    const int msrc = lane < nmv ? gs[lane] : 0;
-    const int dme = lane < nmv ? gd[lane] : -3;
-    // the row's scalars: a local destination's llike is already in LDS (the exchanged view of its rung), an all-uniform
-    // prior's lprior is one constant -- most moves then touch no scalar line at all on the reading side
-    const double sl = dme >= 0 ? llc[p.r0 + dme / p.W] : p.ll[msrc];
-    const double sp = p.lp_is_const ? p.lp_const : p.lp[msrc];
-    for (int hc = 0; hc < DPm; hc += 32) {   // (rows of 64 dimensions: their second 256 bytes the same way)
-      const int colh = col + hc;
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int j = GR * q + g;
-        v[q] = *reinterpret_cast<const d2_t*>(p.x + (size_t)(j < nmv ? gs[j] : 0) * DPm + colh);   // past the list: row 0, never stored
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();   // every gather of every thread has landed before the first scatter
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int j = GR * q + g;
-        const int d = j < nmv ? gd[j] : -3;
-        if (d != -3 && act) {
-          double* dstp;
-          if (d >= 0) dstp = p.x + (size_t)d * DPm;
-          else if (d <= HIST_DST) {
-            const int c = HIST_DST - d;
-            dstp = p.hist.x + hist_slot(p.hist, 1 + (long long)(p.nhist[c] / (unsigned int)p.add_every_n), c) * DPm;
-          } else if (d <= MAP_DST) {
-            dstp = p.map.x + (size_t)(MAP_DST - d) * DPm;
-          } else { const int e = -d - 4; dstp = ((e & 1) ? p.send_down : p.send_up) + MSG_HDR + (size_t)(e >> 1) * RD; }
-          *reinterpret_cast<d2_t*>(dstp + colh) = v[q];
-        }
-      }
-    }
-    if (lane < nmv) {
-      const int d = gd[lane];
-      if (d >= 0) { p.ll[d] = sl; if (!p.lp_is_const) p.lp[d] = sp; }
-      else if (d <= HIST_DST) {
-        const int c = HIST_DST - d;
-        const long long hrow = 1 + (long long)(p.nhist[c] / (unsigned int)p.add_every_n);
-        hist_scalars(p.hist, hist_slot(p.hist, hrow, c), hrow, sl, sp, p.naccept[c], p.ntries[c], p.last_type[c],
-                     evb ? gb[lane] : beta[p.r0 + c / p.W]);
-      } else if (d <= MAP_DST) {
-        const int c = MAP_DST - d;
-        const double t = (evb ? gb[lane] : beta[p.r0 + c / p.W]) * sl;
-        p.map.lpost[c] = sp + t; p.map.ll[c] = sl; p.map.lp[c] = sp;
-      } else if (d != -3) {
-        const int e = -d - 4;
-        double* row = ((e & 1) ? p.send_down : p.send_up) + MSG_HDR + (size_t)(e >> 1) * RD;
-        row[DPm] = sl; row[DPm + 1] = sp; row[DPm + 2] = (double)w; row[DPm + 3] = 0.0;
-      }
-    }
-    return;
-  }
-  // rare overflow of the register path (more than MVCAP moved rows in one ladder and step): the permutation
-  // decomposes into disjoint closed cycles inside the shard and at most two open paths through its boundaries;
-  // one lane walks each in path order, so plain loads and stores are safe.  Slow, correct.
-  const int DP = p.DP;
-  if (p.hist.rungs) {   // in-between rows first: they are read from rows nobody has moved yet
-    for (int j = lane; j < nl; j += DECIDE_THREADS) {
-      const int k = list[j];
-      if (alive[k] != 1) continue;
-      const int i = cand[k];
-      const int hs = hist_mid_src(i);
-      if (hs < 0) continue;
-      const int c = (i - p.r0) * p.W + w;
-      const long long hrow = 1 + (long long)(p.nhist[c] / (unsigned int)p.add_every_n);
-      const size_t o = hist_slot(p.hist, hrow, c);
-      for (int d = 0; d < DP; ++d) p.hist.x[o * DP + d] = p.x[(size_t)hs * DP + d];
-      hist_scalars(p.hist, o, hrow, p.ll[hs], p.lp[hs], p.naccept[c], p.ntries[c], p.last_type[c], evb ? bklo[k] : beta[i]);
-    }
-    __syncthreads();
-  }
-  if (p.map.rungs) {
-    for (int j = lane; j < nl; j += DECIDE_THREADS) {
-      const int k = list[j];
-      if (alive[k] != 1) continue;
-      const int i = cand[k];
-      const double bmid = evb ? bklo[k] : beta[i];
-      const int cs = map_mid_src(i, bmid);
-      if (cs < 0) continue;
-      const int c = (i - p.r0) * p.W + w;
-      const double t = bmid * p.ll[cs];
-      p.map.lpost[c] = p.lp[cs] + t; p.map.ll[c] = p.ll[cs]; p.map.lp[c] = p.lp[cs];
-      for (int d = 0; d < DP; ++d) p.map.x[(size_t)c * DP + d] = p.x[(size_t)cs * DP + d];
-    }
-    __syncthreads();
-  }
-  for (int j = lane; j < nl; j += DECIDE_THREADS) {
-    const int k = list[j];
-    if (alive[k] != 1) continue;
-    const int i = cand[k];
-    const int rtop = (PTM_ALIVE_RUNG(i + 1) && alive[first[i + 1]] == 1) ? i : i + 1;
-    for (int r = i; r <= rtop; ++r) {
-      if (r < p.r0 || r >= r1 || perm[r] == r) continue;
-      const int to = inv[r];
-      const bool departs = to < p.r0 || to >= r1;
-      bool head = departs;
-      if (!departs) {                                     // closed cycle? then the lowest member leads
-        head = true;
-        int cc = perm[r], guard = 0;
-        while (cc != r) {
-          if (cc < p.r0 || cc >= r1 || cc < r || ++guard > Nt) { head = false; break; }
-          cc = perm[cc];
-        }
-      }
-      if (!head) continue;
-      double* X = p.x;
-      const int c0 = (r - p.r0) * p.W + w;
-      double tmp[66];                                      // the head's old row {x[0..DP), llike, lprior}, DP <= 64
-      for (int d = 0; d < DP; ++d) tmp[d] = X[(size_t)c0 * DP + d];
-      tmp[DP] = p.ll[c0];
-      tmp[DP + 1] = p.lp[c0];
-      if (departs) {
-        double* sb = (to >= r1) ? p.send_up : p.send_down;
-        if (!sb) continue;
-        double* row = claim_row(sb, p.row_cap, DP + ROW_EXTRA, p.err);
-        if (row) {
-          for (int d = 0; d < DP + 2; ++d) row[d] = tmp[d];
-          row[DP + 2] = (double)w;
-          row[DP + 3] = 0.0;
-        }
-      }
-      int cur = r;
-      for (int guard = 0; guard <= Nt; ++guard) {
-        const int src = perm[cur];
-        const int cc = (cur - p.r0) * p.W + w;
-        if (src == r) {
-          for (int d = 0; d < DP; ++d) X[(size_t)cc * DP + d] = tmp[d];
-          p.ll[cc] = tmp[DP];
-          p.lp[cc] = tmp[DP + 1];
-          break;
-        }
-        if (src < p.r0 || src >= r1) break;                // the hole (named above)
-        const int cs = (src - p.r0) * p.W + w;
-        for (int d = 0; d < DP; ++d) X[(size_t)cc * DP + d] = X[(size_t)cs * DP + d];
-        p.ll[cc] = p.ll[cs];
-        p.lp[cc] = p.lp[cs];
-        cur = src;
-      }
-    }
-  }
-  if (lane == 0) p.mv_n[w] = 0;
-#undef PTM_ALIVE_RUNG
-}
 
 // swap_count / swap_accept_count (chain.cc:1498,1536; chain.hh:244-245) from the candidate logs of the last `nslots`
 // steps (a ring of PTM_LOG_RING slots): one block per ladder counts in LDS and adds to the ladder's counters, {tries,
 // accepts} side by side, with coalesced read-modify-writes.  A pair is counted by the shard that owns its lower rung, so
 // per-shard counters add up to the ladder's.
-constexpr int PTM_LOG_RING = 16;
 __global__ __launch_bounds__(256) void fold_swap_log_kernel(const int* __restrict__ ring, long long* __restrict__ cnt, int W, int ms, int Nt,
                                                            int r0, int r1, int first_slot, int nslots) {
   extern __shared__ int fold_sc[];   // [2][Nt - 1]

@@ -5,6 +5,7 @@
 // fallback -- without a gfx950 device every entry point that computes returns PTM_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstddef>
 #include <cstdarg>
@@ -867,14 +868,6 @@ static int fold_swap_log(ptm_engine* e) {
   return PTM_OK;
 }
 
-static size_t decide_lds_bytes(int Nt, int ms, int WN, bool evolve, bool evb) {
-  // mirrors the carve at the top of decide_kernel
-  return (size_t)WN * 8 + (size_t)((Nt + 1) & ~1) * 4 + (size_t)((ms + 1) & ~1) * 4 * 2 + 8 + (size_t)((WN + 3) & ~3) * 2 * 3 +
-         (size_t)((ms + 3) & ~3) * 2 + (size_t)((ms + 7) & ~7) * 2 + (size_t)2 * MVCAP * 4 + 32 +
-         (evolve ? ((size_t)Nt + 2 * ((Nt + 31) / 32) + 2 + 4 * ((ms + 3) & ~3)) * 8 + (size_t)4 * ((ms + 3) & ~3) * 2 + ((ms + 7) & ~7) : 0) +
-         (evb ? ((size_t)(Nt > MVCAP ? Nt : MVCAP) + 3 * ((ms + 3) & ~3)) * 8 : 0);
-}
-
 // chain-indexed image of the evolving ladders' temperatures, for the sweep kernels
 static int launch_beta_transpose(ptm_engine* e) {
   hipLaunchKernelGGL(beta_transpose_kernel, dim3((e->Nt + 31) / 32, (e->W + 31) / 32), dim3(256), 0, e->stream, e->beta_w, e->betaC, e->W, e->Nt);
@@ -882,7 +875,7 @@ static int launch_beta_transpose(ptm_engine* e) {
   return PTM_OK;
 }
 
-static int launch_decide(ptm_engine* e, const double* ll_below, const double* ll_above, int H, double* send_up, double* send_down) {
+static Decide make_decide(ptm_engine* e, const double* ll_below, const double* ll_above, int H, double* send_up, double* send_down) {
   Decide p;
   memset(&p, 0, sizeof p);
   p.DP = e->DP; p.Nt = e->Nt; p.r0 = e->r0; p.nloc = e->nloc; p.W = e->W; p.Nc = e->Nc; p.ms = e->ms; p.w_off = e->cfg.walker_begin;
@@ -898,6 +891,12 @@ static int launch_decide(ptm_engine* e, const double* ll_below, const double* ll
   p.lp_is_const = e->lp_is_const ? 1 : 0; p.lp_const = e->lprior_const;
   const bool beta_direct = e->evolve_rate > 0 && e->W <= 64;   // few ladders: the exchange kernel scatters the new temperatures itself
   p.betaC_direct = beta_direct ? e->betaC : nullptr;
+  return p;
+}
+
+static int launch_decide(ptm_engine* e, const double* ll_below, const double* ll_above, int H, double* send_up, double* send_down) {
+  const Decide p = make_decide(e, ll_below, ll_above, H, send_up, send_down);
+  const bool beta_direct = p.betaC_direct != nullptr;
   e->touched = true;
   const int WN = e->nloc + (ll_below ? 1 : 0) + p.H;
   const bool evb = e->evolve_rate > 0 && e->beta_add;
@@ -1130,10 +1129,50 @@ extern "C" int ptm_sweep(ptm_engine* e, int n) {
   return PTM_OK;
 }
 
+// Small ladders (rungs x padded dimensions <= the 1024 lanes of one workgroup, device target and proposals): whole PT steps in
+// ONE launch per batch, a block per walker-ladder looping over the steps (ptm_fused_kernel.hpp).  PTM_FUSED=0 keeps the
+// two-launch path.  Returns the steps taken (0: not this engine's case), or a negative status.
+static int fused_steps(ptm_engine* e, int n) {
+  static const bool fused_ok = [] { const char* v = getenv("PTM_FUSED"); return !(v && *v == '0'); }();
+  if (!fused_ok || e->DP > 16 || (long long)e->Nt * e->DP > 1024 || e->cb || e->pcb || e->cfg.time_kernels) return 0;
+  if (e->evolve_rate > 0 && e->W > 64) return 0;   // (the new temperatures' chain-indexed image is then a separate launch)
+  const bool evb = e->evolve_rate > 0 && e->beta_add;
+  const size_t dlds = decide_lds_bytes(e->Nt, e->ms, e->Nt, e->evolve_rate > 0, evb);
+  if (dlds > 96 * 1024) return 0;
+  int rc = flush_nhist(e);
+  if (rc) return rc;
+  int done = 0;
+  while (done < n) {
+    const int k = std::min(n - done, PTM_LOG_RING - e->log_pending);   // the candidate logs of at most a ring's worth of steps
+    Dev p = make_dev(e);
+    const Decide d = make_decide(e, nullptr, nullptr, 0, nullptr, nullptr);
+    const bool diag = e->prop_kind == PTM_PROP_DIAG;
+    hipError_t he;
+    switch (e->DP) {
+      case 4: he = launch_fused_4(p, d, diag, k, e->swap_log, e->log_head, dlds, e->stream); break;
+      case 8: he = launch_fused_8(p, d, diag, k, e->swap_log, e->log_head, dlds, e->stream); break;
+      default: he = launch_fused_16(p, d, diag, k, e->swap_log, e->log_head, dlds, e->stream); break;
+    }
+    HIPCHK(he);
+    e->step += (uint64_t)k;
+    e->log_head = (e->log_head + k) % PTM_LOG_RING;
+    e->log_pending += k;
+    if (e->log_pending >= PTM_LOG_RING && (rc = fold_swap_log(e))) return rc;
+    done += k;
+  }
+  e->touched = false;
+  return done;
+}
+
 extern "C" int ptm_step(ptm_engine* e, int n) {
   int rc = ready(e);
   if (rc) return rc;
   if (e->nloc != e->Nt) return fail(PTM_ERR_INVALID, "ptm_step needs the whole ladder on this engine; sharded engines use ptm_exchange_*");
+  if (n > 0) {
+    const int f = fused_steps(e, n);
+    if (f < 0) return f;
+    n -= f;
+  }
   for (int k = 0; k < n; ++k) {
     if (e->Nt > 1 && (rc = launch_decide(e, nullptr, nullptr, 0, nullptr, nullptr))) return rc;
     if ((rc = launch_sweep(e))) return rc;

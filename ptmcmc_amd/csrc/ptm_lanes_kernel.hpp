@@ -18,29 +18,41 @@
 
 namespace ptm {
 
+// LDS of the lanes kernels, in doubles: Box-Muller tables | packed precision matrix | per-wave scratch
+template <int DP>
+constexpr int lanes_lds_doubles(int waves) { return BM_TABLE_DOUBLES + ((DP * (DP + 1) / 2 + 1) & ~1) + waves * (3 * 64 + 4 * (64 / DP)); }
+
+// the block's tables into LDS (all threads of the block; ends with a barrier)
+template <int DP>
+__device__ __forceinline__ void lanes_stage(const Dev& p, double* lds_all) {
+  constexpr int NP2 = DP * (DP + 1) / 2;
+  double* p2s = lds_all + BM_TABLE_DOUBLES;
+  for (int i = threadIdx.x; i < BM_TABLE_DOUBLES / 2; i += blockDim.x) reinterpret_cast<bm_d2*>(lds_all)[i] = reinterpret_cast<const bm_d2*>(BM_TABLE)[i];
+  for (int k = threadIdx.x; k < NP2; k += blockDim.x) p2s[k] = p.P2[k];
+  __syncthreads();
+}
+
+// One MH_chain::step for the chains of this block's waves: wave `wslot0 + (threadIdx.x >> 6)` of the launch works for CPW
+// chains; the k-th chain of the launch is chain cbase + k * cstride (k < nslots).  The plain launch walks a contiguous range
+// (cbase = c_begin, cstride = 1); the fused small-ladder kernel walks ONE walker's rungs (cbase = walker, cstride = W).
 template <int DP, int KIND, bool GEN>
-__global__ __launch_bounds__(256) void sweep_lanes_kernel(const Dev p) {
+__device__ __forceinline__ void lanes_body(const Dev& p, double* lds_all, const int wslot0, const int cbase, const int cstride, const int nslots) {
   static_assert(DP == 4 || DP == 8 || DP == 16 || DP == 32 || DP == 64, "lanes kernel: DP 4 .. 64");
   constexpr int CPW = 64 / DP;              // chains per wave
   constexpr int NP2 = DP * (DP + 1) / 2;    // packed precision matrix
-  extern __shared__ __attribute__((aligned(16))) double lds_all[];
   double* p2s = lds_all + BM_TABLE_DOUBLES;                     // [NP2 (+pad)]
   double* wsc = p2s + ((NP2 + 1) & ~1) + (threadIdx.x >> 6) * (3 * 64 + 4 * CPW);   // this wave's scratch
   double* vbuf = wsc;             // [CPW][DP] z, then y
   double* sbuf = wsc + 64;        // [CPW][DP] s_i
   double* tbuf = wsc + 128;       // [CPW][DP] unused tail / flags
   double* pbuf = wsc + 192;       // [CPW][4]  partial sums
-#pragma unroll
-  for (int t = 0; t < BM_TABLE_DOUBLES / 512; ++t)
-    reinterpret_cast<bm_d2*>(lds_all)[threadIdx.x + 256 * t] = reinterpret_cast<const bm_d2*>(BM_TABLE)[threadIdx.x + 256 * t];
-  for (int k = threadIdx.x; k < NP2; k += 256) p2s[k] = p.P2[k];
-  __syncthreads();
 
   const int lane = threadIdx.x & 63;
   const int d = lane % DP, g = lane / DP;
-  int c = p.c_begin + (blockIdx.x * 4 + (threadIdx.x >> 6)) * CPW + g;
-  const bool live = c < p.c_end;
-  if (!live) c = p.c_end - 1;   // dead lanes shadow the last chain and write nothing
+  int slot = (wslot0 + (threadIdx.x >> 6)) * CPW + g;
+  const bool live = slot < nslots;
+  if (!live) slot = nslots - 1;   // dead lanes shadow the last chain and write nothing
+  const int c = cbase + slot * cstride;
   const int rl = c / p.W;
   const int w = c - rl * p.W;
   const int rg = p.r0 + rl;
@@ -282,6 +294,13 @@ __global__ __launch_bounds__(256) void sweep_lanes_kernel(const Dev p) {
     p.nhist[c] += (unsigned int)tc;
     p.touch[c] = 0;
   }
+}
+
+template <int DP, int KIND, bool GEN>
+__global__ __launch_bounds__(256) void sweep_lanes_kernel(const Dev p) {
+  extern __shared__ __attribute__((aligned(16))) double lds_all[];
+  lanes_stage<DP>(p, lds_all);
+  lanes_body<DP, KIND, GEN>(p, lds_all, blockIdx.x * 4, p.c_begin, 1, p.c_end - p.c_begin);
 }
 
 }  // namespace ptm

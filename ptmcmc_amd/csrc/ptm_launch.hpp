@@ -4,6 +4,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "ptm_decide.hpp"
 #include "ptm_kernels.hpp"
 
 // the lanes kernel (ptm_lanes_kernel.hpp) takes launches of at most this many lanes (chains x padded dimension)
@@ -24,6 +25,13 @@ struct SweepSel {
                              hipStream_t st);                                                                       \
   hipError_t launch_init_##N(const Dev& p, double* x, double* ll, double* lp, int* fail, long long cb_attempt,          \
                              unsigned char* pending, hipStream_t st);
+// small ladders: nsteps whole PT steps per launch, one block per walker-ladder (ptm_fused_kernel.hpp; built for DP <= 16)
+#define PTM_DECL_FUSED(N) \
+  hipError_t launch_fused_##N(const Dev& p, const Decide& d, bool diag, int nsteps, int* swap_log_base, int log_head, size_t decide_lds, hipStream_t st);
+PTM_DECL_FUSED(4)
+PTM_DECL_FUSED(8)
+PTM_DECL_FUSED(16)
+#undef PTM_DECL_FUSED
 PTM_DECL_DP(4)
 PTM_DECL_DP(8)
 PTM_DECL_DP(16)
