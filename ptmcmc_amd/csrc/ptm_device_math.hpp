@@ -18,24 +18,31 @@ namespace ptm {
 // ------------------------------------------------------------------------------------------------
 struct u32x4 { uint32_t v0, v1, v2, v3; };
 
+// one round and its key bump (a kernel that spreads a block's ten rounds over its schedule calls this itself)
+struct philox_state { uint32_t c0, c1, c2, c3, k0, k1; };
+__device__ __forceinline__ void philox_round(philox_state& s) {
+  const uint64_t p0 = (uint64_t)0xD2511F53u * s.c0;
+  const uint64_t p1 = (uint64_t)0xCD9E8D57u * s.c2;
+  const uint32_t n0 = (uint32_t)(p1 >> 32) ^ s.c1 ^ s.k0;
+  const uint32_t n1 = (uint32_t)p1;
+  const uint32_t n2 = (uint32_t)(p0 >> 32) ^ s.c3 ^ s.k1;
+  const uint32_t n3 = (uint32_t)p0;
+  s.c0 = n0; s.c1 = n1; s.c2 = n2; s.c3 = n3;
+  s.k0 += 0x9E3779B9u; s.k1 += 0xBB67AE85u;
+}
 __device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
                                                 uint32_t k1) {
+  philox_state s = {c0, c1, c2, c3, k0, k1};
 #pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
-    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
-    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
-    const uint32_t n1 = (uint32_t)p1;
-    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
-    const uint32_t n3 = (uint32_t)p0;
-    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-  }
-  return {c0, c1, c2, c3};
+  for (int r = 0; r < 10; ++r) philox_round(s);
+  return {s.c0, s.c1, s.c2, s.c3};
 }
 
 // counter layout of the engine: c0 = block, c1 = stream, c2 = step[31:0], c3 = step[55:32] | tag << 24
 enum { TAG_MH = 0, TAG_PT = 1, TAG_INIT = 2 };
+__device__ __forceinline__ philox_state draw_block_begin(uint64_t seed, int tag, uint32_t stream, uint64_t step, uint32_t block) {
+  return {block, stream, (uint32_t)step, ((uint32_t)(step >> 32) & 0x00FFFFFFu) | ((uint32_t)tag << 24), (uint32_t)seed, (uint32_t)(seed >> 32)};
+}
 __device__ __forceinline__ u32x4 draw_block(uint64_t seed, int tag, uint32_t stream, uint64_t step, uint32_t block) {
   return philox4x32_10(block, stream, (uint32_t)step, ((uint32_t)(step >> 32) & 0x00FFFFFFu) | ((uint32_t)tag << 24),
                        (uint32_t)seed, (uint32_t)(seed >> 32));
@@ -75,13 +82,33 @@ __device__ __forceinline__ double dlog(double x) {
   return dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
 }
 
+// A 64-bit constant that lives in a scalar register pair made where it is used.  A v_fma_f64 cannot carry a 64-bit literal,
+// so the compiler hoists such constants out of the caller's main loop into VECTOR registers and keeps (or spills) them there
+// for the whole kernel -- fourteen VGPRs for the log polynomial of ONE accept uniform per tile in the hot kernel, which is
+// at its register cap.  The volatile statement cannot be hoisted; two s_mov per constant per use cost nothing.
+template <uint32_t HI, uint32_t LO>
+__device__ __forceinline__ double sconst() {
+  uint32_t a, b;
+  asm volatile("s_mov_b32 %0, %2\n\ts_mov_b32 %1, %3" : "=s"(a), "=s"(b) : "n"(LO), "n"(HI));
+  return __longlong_as_double((long long)(((uint64_t)b << 32) | a));
+}
+
+// A copy of x the optimiser knows nothing about: what is computed from it stays where it is written instead of being hoisted
+// out of the enclosing loop into registers that live for the whole kernel (e.g. the first Philox round of a lane-constant
+// counter word: ten VGPRs in the hot kernel).
+__device__ __forceinline__ int opaque_copy(int x) {
+  asm volatile("" : "+v"(x));
+  return x;
+}
+
 // log of an open-interval uniform u = (k+0.5)/2^32: u is a positive normal number in [2^-33, 1), so none of
 // dlog()'s special cases can fire; this is the same operation sequence without them (bit-identical results).
 __device__ __forceinline__ double dlog_u01(uint32_t k) {
-  const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
-  const double L1 = 6.666666666666735130e-01, L2 = 3.999999999940941908e-01, L3 = 2.857142874366239149e-01,
-               L4 = 2.222219843214978396e-01, L5 = 1.818357216161805012e-01, L6 = 1.531383769920937332e-01,
-               L7 = 1.479819860511658591e-01;
+  // (the values of dlog(): ln2_hi 6.93147180369123816490e-01, ln2_lo 1.90821492927058770002e-10, L1..L7 of e_log.c)
+  const double ln2_hi = sconst<0x3fe62e42u, 0xfee00000u>(), ln2_lo = sconst<0x3dea39efu, 0x35793c76u>();
+  const double L1 = sconst<0x3fe55555u, 0x55555593u>(), L2 = sconst<0x3fd99999u, 0x9997fa04u>(), L3 = sconst<0x3fd24924u, 0x94229359u>(),
+               L4 = sconst<0x3fcc71c5u, 0x1d8e78afu>(), L5 = sconst<0x3fc74664u, 0x96cb03deu>(), L6 = sconst<0x3fc39a09u, 0xd078c69fu>(),
+               L7 = sconst<0x3fc2f112u, 0xdf3e5244u>();
   const double x = u01(k);
   const uint64_t b = (uint64_t)__double_as_longlong(x);
   int e = (int)(b >> 52) - 1023;
@@ -274,8 +301,7 @@ __device__ __forceinline__ double bm_sqrt(double a) {
 //   sin(a+d) = S + (S (cos d - 1) + C sin d),   cos(a+d) = C + (C (cos d - 1) - S sin d),
 //   sin d = d + d^3 (-1/6 + d^2/120),  cos d - 1 = d^2 (-1/2 + d^2/24)        (truncation < 2^-65).
 template <class Tab>   // Tab: pointer to the BM_TABLE image (LDS or global)
-__device__ __forceinline__ void boxmuller(uint32_t k1, uint32_t k2, Tab tab, double& z0, double& z1) {
-  double r = bm_sqrt(bm_neg2log(k1, tab));
+__device__ __forceinline__ void boxmuller_finish(double r, uint32_t k2, Tab tab, double& z0, double& z1) {
   const uint32_t idx = (k2 >> 21) & 1023u;
   const bm_d2 sc = *reinterpret_cast<const bm_d2*>(tab + 512 + 2 * idx);
   const double d = ((double)((int)(k2 & 0x1FFFFFu) - (1 << 20)) + 0.5) * 1.4629180792671596e-09;  // 2 pi / 2^32
@@ -287,6 +313,11 @@ __device__ __forceinline__ void boxmuller(uint32_t k1, uint32_t k2, Tab tab, dou
   r = __longlong_as_double(__double_as_longlong(r) ^ ((long long)(k2 >> 31) << 63));
   z0 = r * cs;
   z1 = r * sn;
+}
+// (the two halves apart, for a kernel that places them itself: radius = bm_sqrt(bm_neg2log(k1)), then boxmuller_finish)
+template <typename Tab>
+__device__ __forceinline__ void boxmuller(uint32_t k1, uint32_t k2, Tab tab, double& z0, double& z1) {
+  boxmuller_finish(bm_sqrt(bm_neg2log(k1, tab)), k2, tab, z0, z1);
 }
 
 // fmod restated for the boundary wrap (states.cc:24,39): exact for |x/w| < 2^52

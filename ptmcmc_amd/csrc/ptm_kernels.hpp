@@ -110,7 +110,7 @@ struct Dev {
   const double* prop;      // [nloc][prop_stride]  factor, dense column-major [col][row] (DP*DP), or sigmas (DP)
   // operand images of the MFMA kernel (DP == 32 only, ptm_mfma_kernel.hpp): 64-lane A tiles, and the box in row layout
   const double* prop_tiles;  // [nloc][16][64]  tile (half*4 + slot)*2 + rowtile, lane 16k+i: T[16 rowtile + i][16 half + 4k + slot]
-  const double* P2_tiles;    // [16][64]        tile step*2 + rowtile, lane 16k+i: P2[16 rowtile + i][4 step + k] (lower, doubled)
+  const double* P2_tiles;    // [16][64]        tile step*2 + rowtile, lane 16k+i: P2[16 rowtile + i][4 step + k] (lower, doubled); then [36][16] 4x4 blocks (R,C), [k][i]
   const double* box_row;     // [2][32]         prior box lo | hi at row_pos
   const double* onedfrac;  // [nloc]
   // optional scale mixture (a proposal_distribution_set of Gaussian members that are scalar multiples of the rung's

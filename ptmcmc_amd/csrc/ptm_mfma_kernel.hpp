@@ -41,6 +41,21 @@ typedef double mf_d2 __attribute__((ext_vector_type(2)));
 #ifndef PTM_MFMA_GEN_WAVES
 #define PTM_MFMA_GEN_WAVES 3   // ... of the general builds
 #endif
+#ifndef PTM_MFMA_P2_BLOCKS
+#define PTM_MFMA_P2_BLOCKS 0   // 1: S = P2 X' as 4x4 blocks (v_mfma_f64_4x4x4_4b_f64), the blocks above the diagonal never issued
+#endif
+#ifndef PTM_MFMA_GG
+#define PTM_MFMA_GG 0          // 16-chain groups worked together in a pass (2: two passes of 32 chains; 1: four passes of 16 -- half the live
+                               // set, four waves per SIMD); 0: by build -- 1 for the everything-general build (0.90 -> 0.70 ms), 2 for the others
+                               // (the lean build loses 5 % with 1: twice the operand reads and pass overheads, and occupancy buys it nothing)
+#endif
+#ifndef PTM_MFMA_ASK_AT
+#define PTM_MFMA_ASK_AT 4      // block product: the second pass's rows are asked for before column block ASK_AT (-1: before the product)
+#endif
+#ifndef PTM_MFMA_PRIO
+#define PTM_MFMA_PRIO 2        // 1: a wave raises its issue priority over its matrix blocks (measured: nothing); 2: over its vector (draw)
+                               // blocks instead (1.3-3 % on the benchmark sizes)
+#endif
 #ifndef PTM_MFMA_GEN_PERSIST
 #define PTM_MFMA_GEN_PERSIST 0   // 1: the general builds walk several tiles per block too (measured: 15-25 % slower -- spills)
 #endif
@@ -54,10 +69,11 @@ typedef double mf_d2 __attribute__((ext_vector_type(2)));
 // (ptm_kernels.hpp) -- tiles of 256 LISTED walkers of one rung, enumerated rung by rung; lane l of a wave works for the l-th
 // listed walker of its group instead of walker w0 + l.
 template <int KIND, bool HIST, int GEN, bool EV = false, bool CPT = false>   // GEN: 0 lean, 1 box boundaries + uniform prior (+ mean, 1-D moves), 2 everything
-__global__ __launch_bounds__(256, (GEN == 0 ? PTM_MFMA_WAVES : PTM_MFMA_GEN_WAVES)) void sweep_mfma32_kernel(const Dev p) {
+__global__ __launch_bounds__(256, (GEN == 0 ? PTM_MFMA_WAVES : ((PTM_MFMA_GG == 0 && GEN == 2 && KIND == KIND_LOWER) ? 4 : PTM_MFMA_GEN_WAVES))) void sweep_mfma32_kernel(const Dev p) {
   constexpr bool PERSIST = GEN == 0 || PTM_MFMA_GEN_PERSIST != 0;
   static_assert(!CPT || (GEN == 0 && !HIST && !EV), "the compacted sweep exists for the lean build");
   constexpr int DP = 32;
+  constexpr int GG = PTM_MFMA_GG ? PTM_MFMA_GG : (GEN == 2 ? 1 : 2), NP = 4 / GG, PL = 16 * GG;   // groups per pass, passes per tile, chains (= stage-5 lanes) per pass
   constexpr bool LOW = KIND == KIND_LOWER;
   // LDS: [2560] Box-Muller tables | [12][64] precision tiles | [64] prior box (all shared by the block's waves) |
   //      128 doubles per wave
@@ -74,6 +90,7 @@ __global__ __launch_bounds__(256, (GEN == 0 ? PTM_MFMA_WAVES : PTM_MFMA_GEN_WAVE
   double* ebox = reinterpret_cast<double*>(gint + 3 * 32) + 4 * 128;
   const int q = l >> 4, j = l & 15;
   const double* pimg = ptile + l;
+  const double* pblk = ptile + 4 * q + (j & 3);   // 4x4 block image: element [k][i] of a block at 4k + i (every 4-chain block reads the same)
   const mf_d2* box = reinterpret_cast<const mf_d2*>(lbox) + q;   // lo piece t at 4t, hi piece t at 16 + 4t (row layout)
   const mf_d2* ebx = reinterpret_cast<const mf_d2*>(ebox) + q;
 
@@ -90,7 +107,7 @@ __global__ __launch_bounds__(256, (GEN == 0 ? PTM_MFMA_WAVES : PTM_MFMA_GEN_WAVE
   for (int t = 0; t < 3; ++t) {
     const int e = threadIdx.x + 256 * t, tile = e >> 6;
     const int src = tile < 8 ? (tile * 2 + 1) : ((tile - 8) * 2 + 0);
-    st_p[t] = p.P2_tiles[src * 64 + (e & 63)];
+    st_p[t] = PTM_MFMA_P2_BLOCKS ? p.P2_tiles[16 * 64 + e] : p.P2_tiles[src * 64 + (e & 63)];   // (36 blocks of 16 in 768 slots)
   }
   const double st_box = p.box_row[threadIdx.x & 63];
   double st_g[6] = {0, 0, 0, 0, 0, 0};
@@ -122,7 +139,7 @@ __global__ __launch_bounds__(256, (GEN == 0 ? PTM_MFMA_WAVES : PTM_MFMA_GEN_WAVE
 
   // CPT: the launch's rungs, their listed-walker counts as an inclusive prefix of 256-walker tiles (LDS, after everything else)
   const int rung0 = p.c_begin / p.W, nrung = (p.c_end - p.c_begin) / p.W;
-  int* tpre = reinterpret_cast<int*>(ebox + 64);   // [nrung] (CPT; the host sizes the LDS for it)
+  int* tpre = reinterpret_cast<int*>(GEN == 0 ? lbox + 64 + 4 * 128 : ebox + 64);   // [nrung] (CPT; the host sizes the LDS for it; the lean build has no general tables)
   int ntiles = (p.c_end - p.c_begin + 255) >> 8;   // 256-chain tiles of this launch (ranges are multiples of 64)
   if constexpr (CPT) {
     // inclusive scan of ceil(count / 256) over the rungs: each thread sums a contiguous chunk, one wave scans the chunk totals
@@ -185,12 +202,12 @@ __global__ __launch_bounds__(256, (GEN == 0 ? PTM_MFMA_WAVES : PTM_MFMA_GEN_WAVE
   const double* timg = p.prop_tiles + (size_t)rl * (16 * 64) + l;   // tile t = (half*4 + slot)*2 + row tile
 
   // A tile's 64 chains are worked in two passes of two 16-chain groups (g = 2 gp + gg): every live set is halved.
-  mf_d2 rowv[2][4];   // the pass's rows, asked for one pass ahead
-  mf_d2* rowp[2];
-  auto ask_rows = [&](int gpp, mf_d2 (&rv)[2][4], mf_d2* (&rp)[2]) {
+  mf_d2 rowv[GG][4];   // the pass's rows, asked for one pass ahead
+  mf_d2* rowp[GG];
+  auto ask_rows = [&](int gpp, mf_d2 (&rv)[GG][4], mf_d2* (&rp)[GG]) {
 #pragma unroll
-    for (int gg = 0; gg < 2; ++gg) {
-      rp[gg] = reinterpret_cast<mf_d2*>(p.x + ((size_t)rl * p.W + wq[2 * gpp + gg]) * DP) + q;   // piece t at [4t]
+    for (int gg = 0; gg < GG; ++gg) {
+      rp[gg] = reinterpret_cast<mf_d2*>(p.x + ((size_t)rl * p.W + wq[GG * gpp + gg]) * DP) + q;   // piece t at [4t]
 #pragma unroll
       for (int t = 0; t < 4; ++t) rv[gg][t] = rp[gg][4 * t];
     }
@@ -234,6 +251,8 @@ __global__ __launch_bounds__(256, (GEN == 0 ? PTM_MFMA_WAVES : PTM_MFMA_GEN_WAVE
   //  general build, and a pass number known only at run time costs dynamic register indexing)
   auto pass = [&](auto gpc) {
     constexpr int gp = decltype(gpc)::value;
+    const int qd = opaque_copy(q);   // (the draws' counter word: not to be pre-multiplied outside the tile loop)
+    if (PTM_MFMA_PRIO == 2) __builtin_amdgcn_s_setprio(2);
     // ---- stage 1: ask for the first half's factor tiles (L2-resident; behind them the first draw)
     double ta[4][2];
 #pragma unroll
@@ -243,24 +262,26 @@ __global__ __launch_bounds__(256, (GEN == 0 ? PTM_MFMA_WAVES : PTM_MFMA_GEN_WAVE
     }
     PTM_STAGE();
     // ---- stage 2: T x Z, one 16-column half at a time (the half's normals: one Philox block per chain)
-    mf_d4 acc[2][2];
+    mf_d4 acc[GG][2];
+    double tb[4][2];
+    int axis[GG];        // GEN: the one-dimensional move's axis of chain (GG gp + gg, j), from its own lane
+    double mscale[GG];   // GEN: the chain's mixture scale
 #pragma unroll
-    for (int gg = 0; gg < 2; ++gg) {
+    for (int gg = 0; gg < GG; ++gg) {
       acc[gg][0] = mf_d4{0.0, 0.0, 0.0, 0.0};
       acc[gg][1] = mf_d4{0.0, 0.0, 0.0, 0.0};
+      axis[gg] = -1;
+      mscale[gg] = 1.0;
     }
-    double tb[4][2];
-    int axis[2] = {-1, -1};   // GEN: the one-dimensional move's axis of chain (2 gp + gg, j), from its own lane
-    double mscale[2] = {1.0, 1.0};   // GEN: the chain's mixture scale
     if (GEN && p.any_oned) {
 #pragma unroll
-      for (int gg = 0; gg < 2; ++gg) axis[gg] = __builtin_amdgcn_ds_bpermute(4 * (32 * gp + 16 * gg + j), my_axis);
+      for (int gg = 0; gg < GG; ++gg) axis[gg] = __builtin_amdgcn_ds_bpermute(4 * (PL * gp + 16 * gg + j), my_axis);
     }
     if (GEN && p.mix_K > 0) {
 #pragma unroll
-      for (int gg = 0; gg < 2; ++gg) {
+      for (int gg = 0; gg < GG; ++gg) {
         const long long b = __double_as_longlong(my_scale);
-        const int src = 4 * (32 * gp + 16 * gg + j);
+        const int src = 4 * (PL * gp + 16 * gg + j);
         const unsigned int lo = (unsigned int)__builtin_amdgcn_ds_bpermute(src, (int)(unsigned int)b);
         const unsigned int hi = (unsigned int)__builtin_amdgcn_ds_bpermute(src, (int)(unsigned int)(b >> 32));
         mscale[gg] = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
@@ -268,11 +289,11 @@ __global__ __launch_bounds__(256, (GEN == 0 ? PTM_MFMA_WAVES : PTM_MFMA_GEN_WAVE
     }
 #pragma unroll
     for (int hb = 0; hb < 2; ++hb) {
-      double z[2][4];
+      double z[GG][4];
 #pragma unroll
-      for (int gg = 0; gg < 2; ++gg) {
-        const uint32_t stream = (uint32_t)(wq[2 * gp + gg] + p.w_off) * (uint32_t)p.Nt + (uint32_t)rg;
-        const u32x4 o = draw_block(p.seed, TAG_MH, stream, p.step, (uint32_t)(1 + 4 * hb + q));
+      for (int gg = 0; gg < GG; ++gg) {
+        const uint32_t stream = (uint32_t)(wq[GG * gp + gg] + p.w_off) * (uint32_t)p.Nt + (uint32_t)rg;
+        const u32x4 o = draw_block(p.seed, TAG_MH, stream, p.step, (uint32_t)(1 + 4 * hb + qd));
 #if defined(PTM_ABLATE) && (PTM_ABLATE & 1)   // timing experiment: no Box-Muller
         z[gg][0] = u01(o.v0); z[gg][1] = u01(o.v1); z[gg][2] = u01(o.v2); z[gg][3] = u01(o.v3);
 #elif defined(PTM_ABLATE) && (PTM_ABLATE & 8)  // timing experiment: no random numbers at all
@@ -288,6 +309,8 @@ __global__ __launch_bounds__(256, (GEN == 0 ? PTM_MFMA_WAVES : PTM_MFMA_GEN_WAVE
         }
         PTM_STAGE();   // one chain's draw at a time: the temporaries of two interleaved draws cost 40 registers
       }
+      if (PTM_MFMA_PRIO == 1) __builtin_amdgcn_s_setprio(2);
+      if (PTM_MFMA_PRIO == 2) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
       for (int sl = 0; sl < 4; ++sl) {
 #pragma unroll
@@ -295,7 +318,7 @@ __global__ __launch_bounds__(256, (GEN == 0 ? PTM_MFMA_WAVES : PTM_MFMA_GEN_WAVE
           if (LOW && hb == 1 && rt == 0) continue;   // columns >= 16 never reach rows < 16
           const double a = hb == 0 ? ta[sl][rt] : tb[sl][rt];
 #pragma unroll
-          for (int gg = 0; gg < 2; ++gg) {
+          for (int gg = 0; gg < GG; ++gg) {
 #if defined(PTM_ABLATE) && (PTM_ABLATE & 2)   // timing experiment: no T x Z
             acc[gg][rt][sl] += a * z[gg][sl];
 #else
@@ -304,6 +327,8 @@ __global__ __launch_bounds__(256, (GEN == 0 ? PTM_MFMA_WAVES : PTM_MFMA_GEN_WAVE
           }
         }
       }
+      if (PTM_MFMA_PRIO == 1) __builtin_amdgcn_s_setprio(0);
+      if (PTM_MFMA_PRIO == 2) __builtin_amdgcn_s_setprio(2);
       if (hb == 0) {   // ask for the second half's tiles while the second half's normals are drawn
 #pragma unroll
         for (int sl = 0; sl < 4; ++sl) {
@@ -314,12 +339,12 @@ __global__ __launch_bounds__(256, (GEN == 0 ? PTM_MFMA_WAVES : PTM_MFMA_GEN_WAVE
       PTM_STAGE();
     }
     // ---- stage 3: x' = x + offset (state::add, states.cc:205-214); boundaries; the prior
-    double xp[2][8];
-    uint64_t inbox = 0;     // bit 16 gg + j: chain (2 gp + gg, j) is inside the box of an all-uniform prior
+    double xp[GG][8];
+    uint64_t inbox = 0;     // bit 16 gg + j: chain (GG gp + gg, j) is inside the box of an all-uniform prior
     uint64_t validb = ~0ull; // GEN: bit 16 gg + j: the chain's state is valid (stateSpace::enforce, states.cc:86-102)
     const bool boxed = GEN < 2 || p.all_uniform;
 #pragma unroll
-    for (int gg = 0; gg < 2; ++gg) {
+    for (int gg = 0; gg < GG; ++gg) {
       bool ok = true, vok = true;
       double pp = 1.0;      // GEN: this lane's partial product of the prior's factors (its dimensions, ascending)
 #pragma unroll
@@ -362,15 +387,53 @@ __global__ __launch_bounds__(256, (GEN == 0 ? PTM_MFMA_WAVES : PTM_MFMA_GEN_WAVE
     }
     PTM_STAGE();
     // the second pass's rows are asked for here: the registers of the first pass's rows have just been freed
-    mf_d2 rown[2][4];
-    mf_d2* rowpn[2] = {rowp[0], rowp[1]};
-    if (gp == 0) ask_rows(1, rown, rowpn);
+    // (with the 4x4-block product: in the middle of it, where the operand pipeline has drained to a few registers)
+    mf_d2 rown[GG][4];
+    mf_d2* rowpn[GG];
+#pragma unroll
+    for (int gg = 0; gg < GG; ++gg) rowpn[gg] = rowp[gg];
+    if (gp + 1 < NP && (!PTM_MFMA_P2_BLOCKS || PTM_MFMA_ASK_AT < 0)) ask_rows(gp + 1, rown, rowpn);
     PTM_STAGE();
     // ---- stage 4: S = P2 x Y, Y = X' (- mean), and the four partial dot products of each chain
+    if (PTM_MFMA_PRIO == 1) __builtin_amdgcn_s_setprio(2);
+    if (PTM_MFMA_PRIO == 2) __builtin_amdgcn_s_setprio(0);
     auto yv = [&](int gg, int m) -> double { return (GEN && p.has_mean) ? xp[gg][m] - gtab[160 + q + 4 * m] : xp[gg][m]; };
-    mf_d4 sacc[2][2];
+#if PTM_MFMA_P2_BLOCKS
+    // rows 4R..4R+3 (register R of the lane group that owns the residue) x columns 4m..4m+3: the 36 blocks on and under the
+    // diagonal, each a 16-cycle v_mfma_f64_4x4x4_4b_f64 whose four 4-chain blocks all take the same A (measured:
+    // tools/probes/mfma_f64_4x4_probe.hip -- A[i][k] of block b on lane 16k+4b+i, B[k][n] on 16k+4b+n, D[i][n] on 16i+4b+n,
+    // i.e. with chain j = 4b+n the very lane roles of the 16x16x4 shape; k-ascending fma chain on C, as that shape)
+    double sacc[GG][8];
 #pragma unroll
-    for (int gg = 0; gg < 2; ++gg) {
+    for (int gg = 0; gg < GG; ++gg)
+#pragma unroll
+      for (int m = 0; m < 8; ++m) sacc[gg][m] = 0.0;
+    // software pipeline: column block m + 1's operands are read from LDS while column block m's 2 (8 - m) independent
+    // instructions issue; the fences keep the scheduler from regrouping the product by rows (one dependent chain per row,
+    // every LDS read waited for in full)
+    double pa[2][8];
+#pragma unroll
+    for (int R = 0; R < 8; ++R) pa[0][R] = pblk[(R * (R + 1) / 2) * 16];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      if (gp + 1 < NP && m == PTM_MFMA_ASK_AT) ask_rows(gp + 1, rown, rowpn);
+      if (m < 7) {
+#pragma unroll
+        for (int R = m + 1; R < 8; ++R) pa[(m + 1) & 1][R] = pblk[(R * (R + 1) / 2 + m + 1) * 16];
+      }
+      PTM_STAGE();
+#pragma unroll
+      for (int R = m; R < 8; ++R) {
+#pragma unroll
+        for (int gg = 0; gg < GG; ++gg) sacc[gg][R] = __builtin_amdgcn_mfma_f64_4x4x4f64(pa[m & 1][R], yv(gg, m), sacc[gg][R], 0, 0, 0);
+      }
+      PTM_STAGE();
+    }
+#define PTM_SACC(gg, m) sacc[gg][m]
+#else
+    mf_d4 sacc[GG][2];
+#pragma unroll
+    for (int gg = 0; gg < GG; ++gg) {
       sacc[gg][0] = mf_d4{0.0, 0.0, 0.0, 0.0};
       sacc[gg][1] = mf_d4{0.0, 0.0, 0.0, 0.0};
     }
@@ -381,7 +444,7 @@ __global__ __launch_bounds__(256, (GEN == 0 ? PTM_MFMA_WAVES : PTM_MFMA_GEN_WAVE
         if (rt == 0 && m >= 4) continue;
         const double a = pimg[(rt ? m : 8 + m) * 64];
 #pragma unroll
-        for (int gg = 0; gg < 2; ++gg) {
+        for (int gg = 0; gg < GG; ++gg) {
 #if defined(PTM_ABLATE) && (PTM_ABLATE & 4)   // timing experiment: no P2 x X'
           sacc[gg][rt][m & 3] += a * xp[gg][m];
 #else
@@ -390,24 +453,27 @@ __global__ __launch_bounds__(256, (GEN == 0 ? PTM_MFMA_WAVES : PTM_MFMA_GEN_WAVE
         }
       }
     }
+#define PTM_SACC(gg, m) sacc[gg][(m) >> 2][(m) & 3]
+#endif
+    if (PTM_MFMA_PRIO == 1) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
-    for (int gg = 0; gg < 2; ++gg) {
+    for (int gg = 0; gg < GG; ++gg) {
       double pq = 0.0;
 #pragma unroll
-      for (int m = 0; m < 8; ++m) pq = __builtin_fma(yv(gg, m), sacc[gg][m >> 2][m & 3], pq);
+      for (int m = 0; m < 8; ++m) pq = __builtin_fma(yv(gg, m), PTM_SACC(gg, m), pq);
       // chain (g, j)'s four partial sums sit on lanes (0..3, j): hand them to lane 16 g + j through this wave's LDS
       red[(gg * 4 + q) * 16 + j] = pq;
     }
     __builtin_amdgcn_wave_barrier();
-    // ---- stage 5, lanes 32 gp .. 32 gp + 31 (chain = lane): Metropolis test and add_state counters
+    // ---- stage 5, lanes PL gp .. PL gp + PL - 1 (chain = lane): Metropolis test and add_state counters
     //      (chain.cc:973-1019, 916-949)
     bool accept = false;
     int hrow = -1;   // >= 0: this add_state call saves a history row (chain.cc:935-946), the ring row index
     bool mapw = false;   // this add_state call sets a new MAP (chain.cc:931-934): the row is copied below
     const bool hist_on = HIST && rl < p.hist.rungs;
     const bool map_on = HIST && rl < p.map.rungs;
-    if ((q >> 1) == gp && !dead) {
-      const double* mine = red + ((q & 1) * 4) * 16 + j;
+    if (l / PL == gp && !dead) {
+      const double* mine = red + ((q % GG) * 4) * 16 + j;
       const double quad = ((mine[0] + mine[16]) + mine[32]) + mine[48];
       if (tc) {
         p.nhist[c] = nhist0 + (unsigned int)tc;
@@ -427,12 +493,12 @@ __global__ __launch_bounds__(256, (GEN == 0 ? PTM_MFMA_WAVES : PTM_MFMA_GEN_WAVE
         const double bl = beta * ll;
         const double cur_lpost = lp + bl;
         const double oldlprior = cur_lpost - bl;  // chain.cc:973
-        const bool in = ((inbox >> (l & 31)) & 1ull) != 0;
+        const bool in = ((inbox >> (l & (PL - 1))) & 1ull) != 0;
         // Q9: state::add builds on an enforced zero state -- an origin outside a `limit` bound invalidates every proposal
-        const bool valid = !GEN || (p.origin_valid != 0 && ((validb >> (l & 31)) & 1ull) != 0);
+        const bool valid = !GEN || (p.origin_valid != 0 && ((validb >> (l & (PL - 1))) & 1ull) != 0);
         double newlprior = in ? p.lprior_const : -__builtin_inf();
         if (GEN == 2 && !p.all_uniform) {   // log of the product of the factors, ((p0 p1) p2) p3 (probability_function.hh:59)
-          const double* pm = red2 + ((q & 1) * 4) * 16 + j;
+          const double* pm = red2 + ((q % GG) * 4) * 16 + j;
           newlprior = dlog(((pm[0] * pm[16]) * pm[32]) * pm[48]);
         }
         if (!valid) newlprior = -__builtin_inf();
@@ -465,9 +531,9 @@ __global__ __launch_bounds__(256, (GEN == 0 ? PTM_MFMA_WAVES : PTM_MFMA_GEN_WAVE
       }
     }
     // ---- accepted proposals replace their rows; each of a chain's four lanes writes its 64 bytes
-    const uint64_t acc_bits = __builtin_amdgcn_ballot_w64(accept) >> (32 * gp);
+    const uint64_t acc_bits = __builtin_amdgcn_ballot_w64(accept) >> (PL * gp);
 #pragma unroll
-    for (int gg = 0; gg < 2; ++gg) {
+    for (int gg = 0; gg < GG; ++gg) {
       if ((acc_bits >> (16 * gg + j)) & 1ull) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) rowp[gg][4 * t] = mf_d2{xp[gg][2 * t], xp[gg][2 * t + 1]};
@@ -476,11 +542,11 @@ __global__ __launch_bounds__(256, (GEN == 0 ? PTM_MFMA_WAVES : PTM_MFMA_GEN_WAVE
     // ---- history rows (rare: every add_every_N-th add of the recorded rungs): the chain's four lanes copy the state
     //      the add saw -- the proposal if it was accepted, else the row as it stands in memory
     if (hist_on) {
-      const uint64_t rec_bits = __builtin_amdgcn_ballot_w64(hrow >= 0) >> (32 * gp);
-      if (rec_bits & 0xFFFFFFFFull) {
+      const uint64_t rec_bits = __builtin_amdgcn_ballot_w64(hrow >= 0) >> (PL * gp);
+      if (rec_bits & ((1ull << PL) - 1ull)) {
 #pragma unroll
-        for (int gg = 0; gg < 2; ++gg) {
-          const int src_lane = 32 * gp + 16 * gg + j;
+        for (int gg = 0; gg < GG; ++gg) {
+          const int src_lane = PL * gp + 16 * gg + j;
           const int hr = __builtin_amdgcn_ds_bpermute(4 * src_lane, hrow);
           if ((rec_bits >> (16 * gg + j)) & 1ull) {
             const int cg = c0 + src_lane;
@@ -493,12 +559,12 @@ __global__ __launch_bounds__(256, (GEN == 0 ? PTM_MFMA_WAVES : PTM_MFMA_GEN_WAVE
       }
     }
     if (map_on) {   // the new MAP's row: the proposal if it was accepted, else (an exchanged rung) the row in memory
-      const uint64_t mb = __builtin_amdgcn_ballot_w64(mapw) >> (32 * gp);
-      if (mb & 0xFFFFFFFFull) {
+      const uint64_t mb = __builtin_amdgcn_ballot_w64(mapw) >> (PL * gp);
+      if (mb & ((1ull << PL) - 1ull)) {
 #pragma unroll
-        for (int gg = 0; gg < 2; ++gg) {
+        for (int gg = 0; gg < GG; ++gg) {
           if ((mb >> (16 * gg + j)) & 1ull) {
-            const int cg = c0 + 32 * gp + 16 * gg + j;
+            const int cg = c0 + PL * gp + 16 * gg + j;
             mf_d2* dst = reinterpret_cast<mf_d2*>(p.map.x + (size_t)cg * DP) + q;
             const bool took = (acc_bits >> (16 * gg + j)) & 1ull;
 #pragma unroll
@@ -508,9 +574,9 @@ __global__ __launch_bounds__(256, (GEN == 0 ? PTM_MFMA_WAVES : PTM_MFMA_GEN_WAVE
       }
     }
     __builtin_amdgcn_wave_barrier();   // the next pass reuses the LDS slots
-    if (gp == 0) {
+    if (gp + 1 < NP) {
 #pragma unroll
-      for (int gg = 0; gg < 2; ++gg) {
+      for (int gg = 0; gg < GG; ++gg) {
         rowp[gg] = rowpn[gg];
 #pragma unroll
         for (int t = 0; t < 4; ++t) rowv[gg][t] = rown[gg][t];
@@ -519,9 +585,14 @@ __global__ __launch_bounds__(256, (GEN == 0 ? PTM_MFMA_WAVES : PTM_MFMA_GEN_WAVE
   };
   pass(std::integral_constant<int, 0>{});
   pass(std::integral_constant<int, 1>{});
+  if constexpr (NP == 4) {
+    pass(std::integral_constant<int, 2>{});
+    pass(std::integral_constant<int, 3>{});
+  }
   if (!PERSIST) break;   // (one tile per block: the launch gives every tile its own block)
   }   // tiles
 }
 #undef PTM_STAGE
+#undef PTM_SACC
 
 }  // namespace ptm
