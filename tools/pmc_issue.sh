@@ -21,7 +21,8 @@ for G in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES" \
   echo "pass $i: $G"
   rocprofv3 --pmc $G --output-format csv -d $OUT/g$i -- python3 $ARGS > $OUT/g$i.json 2> $OUT/g$i.err || echo "group $i failed"
 done
-python3 - $OUT $R/gpurun_out/${TAG}_pmc_issue_summary.json   # (copy it into profiles/ afterwards: only gpurun_out/ comes back from the GPU box) <<'PY'
+# (copy the summary into profiles/ afterwards: only gpurun_out/ comes back from the GPU box)
+python3 - $OUT $R/gpurun_out/${TAG}_pmc_issue_summary.json <<'PY'
 import csv, glob, sys, collections, json
 out, dst = sys.argv[1], sys.argv[2]
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
