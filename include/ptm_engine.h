@@ -122,6 +122,17 @@ int ptm_set_prior(ptm_engine* e, const int32_t* types, const double* centers, co
 int ptm_set_target_gaussian(ptm_engine* e, const double* mean, const double* precision, double like0);
 /* user likelihood evaluated on the host between a propose and an accept kernel */
 int ptm_set_target_callback(ptm_engine* e, ptm_loglike_batch_fn fn, void* user);
+/* A PRIOR evaluated on the host: the C shape of probability_function::evaluate_log(state&) (probability_function.hh:31-44,59)
+ * for priors ptm_set_prior cannot describe -- independent_dist_product, transformed_dist, chain_distribution
+ * (probability_function.hh:184-246) or a user's own subclass.  Batched like the likelihood (X [n][dim] row-major, one log-prior
+ * each; -inf = outside the support).  The engine calls it for the VALID proposals of a step (stateSpace::enforce stays on the
+ * device, and an invalid state has probability 0 without asking: probability_function.cc:283) before the likelihood, applies the
+ * reference's prior gate (chain.cc:980) to the answer, and for every state it is handed by ptm_set_states / ptm_restore.  Needs
+ * the host-callback likelihood (ptm_set_target_callback): the step is then propose kernel -> prior -> likelihood -> accept kernel.
+ * The device-side prior (ptm_set_prior) is ignored while a prior callback is set, and ptm_init_from_prior refuses: draw the start
+ * states with the prior's own drawSample and hand them over with ptm_set_states.  fn = NULL removes it. */
+typedef void (*ptm_logprior_batch_fn)(void* user, const double* X, int n, int dim, double* out_lprior);
+int ptm_set_prior_callback(ptm_engine* e, ptm_logprior_batch_fn fn, void* user);
 /* inverse temperatures of the GLOBAL ladder, beta[n_rungs] (chain.cc:1181-1183,1340) */
 int ptm_set_ladder(ptm_engine* e, const double* beta);
 /* parallel_tempering_chains::evolve_temps(rate, lpost_cut) (chain.hh:302-307; default-on in the sampler with rate 0.01,

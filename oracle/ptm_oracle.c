@@ -292,6 +292,7 @@ static double pdf1(const ptmo_problem* pb, int i, double x) {
 
 double ptmo_lprior(const ptmo_problem* pb, const double* x, int valid) {
   if (!valid) return -INFINITY;                          /* evaluate() returns 0 for an invalid state */
+  if (pb->prior_fn) return pb->prior_fn(pb->prior_user, x, pb->D);
   if (pb->all_uniform) {
     for (int i = 0; i < pb->D; i++) {
       if (x[i] < pb->plo[i]) return -INFINITY;
@@ -434,6 +435,7 @@ void ptmo_problem_set_gauss(ptmo_problem* p, const double* mean, const double* P
       p->P2[i * D + j] = (j < i) ? (P[i * D + j] + P[j * D + i]) : (j == i ? P[i * D + i] : 0.0);
 }
 void ptmo_problem_set_user(ptmo_problem* p, ptmo_loglike_fn fn, void* user) { p->user_fn = fn; p->user = user; }
+void ptmo_problem_set_user_prior(ptmo_problem* p, ptmo_loglike_fn fn, void* user) { p->prior_fn = fn; p->prior_user = user; }
 
 /* ============================================================================================
  * ladder state

@@ -60,6 +60,8 @@ typedef struct {
   ptmo_loglike_fn user_fn;
   void* user;
   double minPrior;    /* MH_chain ctor arg (chain.cc:647), sampler default -30 */
+  ptmo_loglike_fn prior_fn;   /* a prior the checker is handed as a function (probability_function::evaluate_log of any subclass, */
+  void* prior_user;           /* probability_function.hh:31-44): replaces the per-dimension description above for VALID states     */
 } ptmo_problem;
 
 typedef struct {
@@ -152,6 +154,7 @@ double ptmo_cos_hpi(double x);       /* x in [-pi/2, pi/2]  */
 /* ---- reference restatements -------------------------------------------------------------- */
 int ptmo_boundary_enforce(int lo, int hi, double xmin, double xmax, double* x); /* states.cc:11-58 */
 int ptmo_enforce(const ptmo_problem* pb, double* x);                              /* states.cc:86-102 */
+void ptmo_problem_set_user_prior(ptmo_problem* p, ptmo_loglike_fn fn, void* user);
 double ptmo_lprior(const ptmo_problem* pb, const double* x, int valid);          /* probability_function.hh:59, .cc:281-304 */
 double ptmo_llike(const ptmo_problem* pb, const double* x);
 double ptmo_lpost(double lprior, double beta, double llike);

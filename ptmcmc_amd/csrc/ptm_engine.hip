@@ -93,6 +93,8 @@ struct ptm_engine {
   std::vector<double> h_plo, h_phi;
   ptm_loglike_batch_fn cb = nullptr;
   void* cb_user = nullptr;
+  ptm_logprior_batch_fn prior_cb = nullptr;   // host-evaluated prior (ptm_set_prior_callback)
+  void* prior_user = nullptr;
   // host-side proposals (ptm_set_proposal_callback)
   ptm_propose_batch_fn pcb = nullptr;
   ptm_proposal_result_fn pres = nullptr;
@@ -460,6 +462,13 @@ extern "C" int ptm_set_target_callback(ptm_engine* e, ptm_loglike_batch_fn fn, v
   return PTM_OK;
 }
 
+extern "C" int ptm_set_prior_callback(ptm_engine* e, ptm_logprior_batch_fn fn, void* user) {
+  if (!e) return fail(PTM_ERR_INVALID, "null engine");
+  e->prior_cb = fn; e->prior_user = fn ? user : nullptr;
+  e->lp_is_const = false;
+  return PTM_OK;
+}
+
 extern "C" int ptm_set_proposal_callback(ptm_engine* e, ptm_propose_batch_fn propose, ptm_proposal_result_fn result, void* user) {
   if (!e) return fail(PTM_ERR_INVALID, "null engine");
   if (!propose) {   // back to the device proposals, if any were set
@@ -489,6 +498,33 @@ static int call_user(ptm_engine* e, const pinned_vector<double>& rows, const std
     for (size_t d = 0; d < D; ++d) e->h_batch[k * D + d] = rows[pick[k] * DP + host_row_pos(DP, d)];
   e->cb(e->cb_user, e->h_batch.data(), (int)n, (int)D, out.data());
   return PTM_OK;
+}
+
+// the user's batched log-prior on the chains picked by `pick`
+static int call_user_prior(ptm_engine* e, const pinned_vector<double>& rows, const std::vector<size_t>& pick, std::vector<double>& out) {
+  const size_t D = e->D, DP = e->DP, n = pick.size();
+  out.assign(n, 0.0);
+  if (!n) return PTM_OK;
+  e->h_batch.resize(n * D);
+  for (size_t k = 0; k < n; ++k)
+    for (size_t d = 0; d < D; ++d) e->h_batch[k * D + d] = rows[pick[k] * DP + host_row_pos(DP, d)];
+  e->prior_cb(e->prior_user, e->h_batch.data(), (int)n, (int)D, out.data());
+  return PTM_OK;
+}
+// host prior: the log-priors of the states now in e->x (their rows in e->h_xprop) replace what the device prior gave -- except
+// where that is -inf by the state's invalidity (the device's flat stand-in prior has no other way to say -inf)
+static int host_prior_of_states(ptm_engine* e) {
+  const size_t Nc = e->Nc;
+  std::vector<double> lp(Nc), out;
+  HIPCHK(hipStreamSynchronize(e->stream));
+  HIPCHK(hipMemcpy(lp.data(), e->lp, Nc * 8, hipMemcpyDeviceToHost));
+  std::vector<size_t> pick;
+  for (size_t c = 0; c < Nc; ++c)
+    if (lp[c] > -__builtin_inf()) pick.push_back(c);
+  int rc = call_user_prior(e, e->h_xprop, pick, out);
+  if (rc) return rc;
+  for (size_t k = 0; k < pick.size(); ++k) lp[pick[k]] = out[k];
+  return upload(e->lp, lp.data(), Nc, e->stream);
 }
 
 extern "C" int ptm_set_ladder(ptm_engine* e, const double* beta) {
@@ -842,6 +878,34 @@ static int launch_sweep(ptm_engine* e, int rung0 = 0, int nr = -1, bool last = t
     HIPCHK(launch(p));   // (the propose pass writes every chain's gate byte: 0 for the rungs that make no move)
     HIPCHK(hipMemcpyAsync(e->h_xprop.data(), e->xprop, Nc * DP * 8 + Nc, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
+    if (e->prior_cb) {
+      // host-evaluated prior: the valid proposals' log-priors, then the reference's prior gate on them -- want_like (chain.cc:980)
+      // with oldlprior = current_lpost - invtemp * current_llike (:973), rounded as the kernels round it
+      std::vector<double> hll(Nc), hlp(Nc), hbeta(Nc), out;
+      HIPCHK(hipMemcpy(hll.data(), e->ll, Nc * 8, hipMemcpyDeviceToHost));
+      HIPCHK(hipMemcpy(hlp.data(), e->lp, Nc * 8, hipMemcpyDeviceToHost));
+      if (e->betaC) HIPCHK(hipMemcpy(hbeta.data(), e->betaC, Nc * 8, hipMemcpyDeviceToHost));
+      std::vector<size_t> vp;
+      for (size_t c = 0; c < Nc; ++c)
+        if (e->h_gate[c] & 1) vp.push_back(c);
+      int rcp = call_user_prior(e, e->h_xprop, vp, out);
+      if (rcp) return rcp;
+      std::vector<double> lpn(Nc, -__builtin_inf());
+      for (size_t k = 0; k < vp.size(); ++k) {
+        const size_t c = vp[k];
+        const double beta = e->betaC ? hbeta[c] : e->h_beta[e->r0 + c / e->W];
+        const double bl = beta * hll[c];
+        const double cur_lpost = hlp[c] + bl;
+        const double oldlprior = cur_lpost - bl;
+        const double nl = out[k];
+        lpn[c] = nl;
+        const bool want = nl > -1e200 || nl - oldlprior > e->cfg.min_prior;
+        e->h_gate[c] = (unsigned char)(1 | (want ? 2 : 0));
+      }
+      HIPCHK(hipMemcpyAsync(e->lprior_new, lpn.data(), Nc * 8, hipMemcpyHostToDevice, e->stream));
+      HIPCHK(hipMemcpyAsync(e->gate, e->h_gate, Nc, hipMemcpyHostToDevice, e->stream));
+      HIPCHK(hipStreamSynchronize(e->stream));   // (lpn is a local)
+    }
     std::vector<size_t> pick;
     for (size_t c = 0; c < Nc; ++c)
       if (e->h_gate[c] & 2) pick.push_back(c);
@@ -973,7 +1037,7 @@ static int ready(ptm_engine* e) {
 // the box is never accepted) -- the exchange kernel then moves no lprior
 static int check_lp_const(ptm_engine* e) {
   e->lp_is_const = false;
-  if (!e->all_uniform) return PTM_OK;
+  if (!e->all_uniform || e->prior_cb) return PTM_OK;
   std::vector<double> lp((size_t)e->Nc);
   HIPCHK(hipStreamSynchronize(e->stream));
   HIPCHK(hipMemcpy(lp.data(), e->lp, lp.size() * 8, hipMemcpyDeviceToHost));
@@ -1057,6 +1121,12 @@ extern "C" int ptm_set_states(ptm_engine* e, const double* X, const double* llik
     if ((rc = call_user(e, e->h_xprop, all, e->h_llbatch))) return rc;
     if ((rc = upload(e->ll, e->h_llbatch.data(), Nc, e->stream))) return rc;
   }
+  if (e->prior_cb) {
+    if (!e->cb) return fail(PTM_ERR_UNSUPPORTED, "a host-evaluated prior needs the host-callback likelihood (ptm_set_target_callback)");
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipMemcpy(e->h_xprop.data(), e->x, Nc * DP * 8, hipMemcpyDeviceToHost));
+    if ((rc = host_prior_of_states(e))) return rc;
+  }
   if ((rc = reset_counters(e))) return rc;
   HIPCHK(hipStreamSynchronize(e->stream));
   if ((rc = check_lp_const(e))) return rc;
@@ -1082,6 +1152,7 @@ extern "C" int ptm_init_from_prior_k(ptm_engine* e, int kdraw) {
   if (!e) return fail(PTM_ERR_INVALID, "null engine");
   if (kdraw < 0 || kdraw > 8191) return fail(PTM_ERR_INVALID, "initial draw index out of range (0..8191)");
   if (!e->have_target) return fail(PTM_ERR_INVALID, "set the target first");
+  if (e->prior_cb) return fail(PTM_ERR_UNSUPPORTED, "a host-evaluated prior cannot be drawn from here: draw the start states with its drawSample and pass them to ptm_set_states");
   for (int d = 0; d < e->D; ++d)
     if (e->h_ptype[d] == PTM_PRIOR_FLAT)
       return fail(PTM_ERR_UNSUPPORTED, "a flat (improper) prior cannot be drawn from (dimension %d): pass start states", d);

@@ -23,7 +23,7 @@ PRIOR_NAMES = {"uni": 1, "uniform": 1, "gauss": 2, "gaussian": 2, "pol": 3, "pol
 
 EXPORTS = [
     "ptm_last_error", "ptm_abi_version", "ptm_device_count", "ptm_engine_create", "ptm_engine_destroy",
-    "ptm_set_bounds", "ptm_set_prior", "ptm_set_target_gaussian", "ptm_set_target_callback", "ptm_set_ladder", "ptm_set_evolve_temps", "ptm_get_invtemps", "ptm_set_invtemps",
+    "ptm_set_bounds", "ptm_set_prior", "ptm_set_target_gaussian", "ptm_set_target_callback", "ptm_set_prior_callback", "ptm_set_ladder", "ptm_set_evolve_temps", "ptm_get_invtemps", "ptm_set_invtemps",
     "ptm_set_proposals", "ptm_set_proposal_rung", "ptm_set_proposal_mixture", "ptm_set_proposal_callback", "ptm_set_states", "ptm_init_from_prior", "ptm_init_from_prior_k", "ptm_sweep", "ptm_step", "ptm_sync",
     "ptm_copy_llike", "ptm_llike_device_ptr", "ptm_exchange_decide", "ptm_exchange_finish_and_sweep", "ptm_exchange_install", "ptm_sweep_rungs", "ptm_exchange_buffer_doubles", "ptm_exchange_row_capacity", "ptm_shard_unique_id", "ptm_shard_init", "ptm_shard_step", "ptm_shard_finalize", "ptm_get_states",
     "ptm_get_array", "ptm_get_swap_counts", "ptm_get_last_swaps", "ptm_max_swaps_per_step", "ptm_get_history", "ptm_get_history_invtemps", "ptm_set_history", "ptm_set_map", "ptm_get_map", "ptm_restore", "ptm_step_count",
@@ -81,6 +81,7 @@ def load():
     L.ptm_set_prior.argtypes = [C.c_void_p, _i32p, _dp, _dp]
     L.ptm_set_target_gaussian.argtypes = [C.c_void_p, _dp, _dp, C.c_double]
     L.ptm_set_target_callback.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.ptm_set_prior_callback.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.ptm_set_ladder.argtypes = [C.c_void_p, _dp]
     L.ptm_set_evolve_temps.argtypes = [C.c_void_p, C.c_double, C.c_double]
     L.ptm_get_invtemps.argtypes = [C.c_void_p, _dp]
@@ -282,6 +283,25 @@ class Engine:
         cb = LOGLIKE_BATCH_FN(tramp)
         self._keep.append(cb)
         _chk(self.L.ptm_set_target_callback(self.h, C.cast(cb, C.c_void_p), None))
+
+    def set_prior_callback(self, fn, batched=False):
+        """a prior evaluated on the host (ptm_set_prior_callback): the C shape of probability_function::evaluate_log
+        (probability_function.hh:31-44) for priors ptm_set_prior cannot describe.  fn(x[D]) -> log-prior (-inf outside the
+        support), or with batched=True fn(X[n][D]) -> array of n.  Needs set_target_callback; start states come from set_states."""
+        if fn is None:
+            _chk(self.L.ptm_set_prior_callback(self.h, None, None))
+            return
+        def tramp(user, Xp, n, dim, outp):
+            X = np.ctypeslib.as_array(Xp, shape=(n, dim))
+            out = np.ctypeslib.as_array(outp, shape=(n,))
+            if batched:
+                out[:] = fn(X)
+            else:
+                for k in range(n):
+                    out[k] = fn(X[k])
+        cb = LOGLIKE_BATCH_FN(tramp)
+        self._keep.append(cb)
+        _chk(self.L.ptm_set_prior_callback(self.h, C.cast(cb, C.c_void_p), None))
 
     def set_proposal_callback(self, propose, result=None):
         """host-side proposals (ptm_set_proposal_callback): the C shape of proposal_distribution::draw / log_hastings_ratio /

@@ -410,8 +410,11 @@ class sampleable_probability_function : public probability_function {  // probab
   virtual double evaluate_log(state& s) const { return std::log(evaluate(s)); }   // probability_function.hh:59
   virtual state drawSample(Random& rng) const { std::cout << "sampleable_probability_function::drawSample: not defined for this prior" << std::endl; exit(1); }
   virtual std::string show() const { return "UnspecifiedSampleableProbabilityFunction()"; }
-  // engine description: per-dimension (type, center, halfwidth), types as mixed_dist_product::{uniform,...}
-  virtual void describe(std::vector<int>& types, std::vector<double>& centers, std::vector<double>& halfwidths) const = 0;
+  // engine description: per-dimension (type, center, halfwidth), types as mixed_dist_product::{uniform,...}; true if the prior
+  // IS such a product -- it is then evaluated and drawn from on the device.  Any other prior (false, the default: a subclass
+  // need only give evaluate / evaluate_log and drawSample, as in the reference) is evaluated on the host, through the engine's
+  // prior callback (ptm_set_prior_callback), and the chains' start states are drawn with its drawSample.
+  virtual bool describe(std::vector<int>& types, std::vector<double>& centers, std::vector<double>& halfwidths) const { return false; }
 };
 
 class mixed_dist_product : public sampleable_probability_function {  // probability_function.hh:141-170, .cc:219-262
@@ -477,10 +480,11 @@ class mixed_dist_product : public sampleable_probability_function {  // probabil
     }
     return NAN;
   }
-  void describe(std::vector<int>& t, std::vector<double>& c, std::vector<double>& h) const override {
+  bool describe(std::vector<int>& t, std::vector<double>& c, std::vector<double>& h) const override {
     t.assign(std::begin(types), std::end(types));
     c.assign(std::begin(centers), std::end(centers));
     h.assign(std::begin(halfwidths), std::end(halfwidths));
+    return true;
   }
 };
 
@@ -497,6 +501,105 @@ class gaussian_dist_product : public mixed_dist_product {  // probability_functi
  public:
   gaussian_dist_product(const stateSpace* space, const std::valarray<double>& x0s, const std::valarray<double>& sigmas)
       : mixed_dist_product(space, std::valarray<int>(gaussian, x0s.size()), x0s, sigmas) {}
+};
+
+// A prior on a direct product of independent state spaces (probability_function.hh:181-215, .cc:346-452): the product-space
+// parameters are matched to the subspaces BY NAME; evaluate() is the product of the subspace priors on the projected states,
+// drawSample() the direct product of subspace samples.  As in the reference the j-th parameter handed to subspace k is the
+// j-th product-space parameter found in it, in PRODUCT-space order (.cc:387-405,443-447) -- name the subspaces' parameters in the
+// order the product space lists them.  If every factor is a per-dimension product the whole is one and lives on the device.
+class independent_dist_product : public sampleable_probability_function {
+  std::vector<const sampleable_probability_function*> ss_dists;
+  std::vector<const stateSpace*> ss;
+  std::vector<int> index_ss, index_ss_index;      // product index -> subspace, index within it
+  std::vector<std::vector<int> > ss_indices;      // subspace -> product indices found in it, in product order
+
+ public:
+  independent_dist_product(const stateSpace* product_space, const std::vector<const sampleable_probability_function*>& subspace_dists)
+      : sampleable_probability_function(product_space) {
+    dim = product_space->size();
+    int dim_count = 0;
+    for (size_t i = 0; i < subspace_dists.size(); i++)
+      if (subspace_dists[i]->getDim() > 0) {   // empty subspaces are skipped
+        ss_dists.push_back(subspace_dists[i]);
+        ss.push_back(subspace_dists[i]->get_space());
+        dim_count += subspace_dists[i]->getDim();
+      }
+    if ((int)dim != dim_count) {
+      std::cout << "independent_dist_product(constructor): Total dimension of subspaces does not match product space dimension:" << std::endl;
+      exit(1);
+    }
+    ss_indices.resize(ss.size());
+    index_ss.resize(dim); index_ss_index.resize(dim);
+    for (unsigned i = 0; i < dim; i++) {
+      const std::string name = product_space->get_name(i);
+      bool found = false;
+      for (size_t j = 0; j < ss.size(); j++) {
+        const int idx = ss[j]->get_index(name);
+        if (idx < 0) continue;
+        if (found) { std::cout << "independent_dist_product(constructor): Found name '" << name << "' in multiple spaces." << std::endl; exit(1); }
+        found = true;
+        index_ss[i] = (int)j; index_ss_index[i] = idx;
+        ss_indices[j].push_back((int)i);
+      }
+      if (!found) { std::cout << "independent_dist_product(constructor): Did not find name '" << name << "' among subspace names." << std::endl; exit(1); }
+    }
+  }
+  independent_dist_product(const stateSpace* product_space, const sampleable_probability_function* d1, const sampleable_probability_function* d2)
+      : independent_dist_product(product_space, std::vector<const sampleable_probability_function*>{d1, d2}) {}
+  independent_dist_product(const stateSpace* product_space, const sampleable_probability_function* d1, const sampleable_probability_function* d2,
+                           const sampleable_probability_function* d3)
+      : independent_dist_product(product_space, std::vector<const sampleable_probability_function*>{d1, d2, d3}) {}
+  independent_dist_product(const stateSpace* product_space, const sampleable_probability_function* d1, const sampleable_probability_function* d2,
+                           const sampleable_probability_function* d3, const sampleable_probability_function* d4)
+      : independent_dist_product(product_space, std::vector<const sampleable_probability_function*>{d1, d2, d3, d4}) {}
+  state drawSample(Random& rng) const override {
+    std::vector<state> sub;
+    for (size_t k = 0; k < ss.size(); k++) sub.push_back(ss_dists[k]->drawSample(rng));
+    std::valarray<double> v(dim);
+    for (unsigned i = 0; i < dim; i++) v[i] = sub[index_ss[i]].get_param(index_ss_index[i]);
+    return state(space, v);
+  }
+  double evaluate(state& s) const override {
+    if (s.invalid()) return 0;
+    if ((int)dim != s.size()) { std::cout << "independent_dist_product:evaluate: State size mismatch.\n"; exit(1); }
+    double result = 1;
+    for (size_t k = 0; k < ss.size(); k++) {
+      std::valarray<double> v(ss[k]->size());
+      for (int j = 0; j < ss[k]->size(); j++) v[j] = s.get_param(ss_indices[k][j]);
+      state sub(ss[k], v);
+      result *= ss_dists[k]->evaluate(sub);
+    }
+    return result;
+  }
+  void getScales(std::valarray<double>& out) const override {
+    out.resize(dim);
+    int count = 0;
+    for (size_t k = 0; k < ss.size(); k++) {
+      std::valarray<double> sc;
+      ss_dists[k]->getScales(sc);
+      for (size_t j = 0; j < sc.size(); j++) out[count++] = sc[j];
+    }
+  }
+  std::string show() const override {
+    std::ostringstream o;
+    o << "IndependentDistProduct(";
+    for (size_t k = 0; k < ss.size(); k++) o << (k ? ", " : "") << ss_dists[k]->show();
+    o << ")";
+    return o.str();
+  }
+  bool describe(std::vector<int>& t, std::vector<double>& c, std::vector<double>& h) const override {
+    t.assign(dim, 0); c.assign(dim, 0.0); h.assign(dim, 0.0);
+    for (size_t k = 0; k < ss.size(); k++) {
+      std::vector<int> tk;
+      std::vector<double> ck, hk;
+      if (!ss_dists[k]->describe(tk, ck, hk)) return false;
+      for (size_t j = 0; j < tk.size() && j < ss_indices[k].size(); j++) {
+        t[ss_indices[k][j]] = tk[j]; c[ss_indices[k][j]] = ck[j]; h[ss_indices[k][j]] = hk[j];
+      }
+    }
+    return true;
+  }
 };
 
 // ---- chain.hh: the base interface (what proposals and the driver see of a chain) -------------------------------------------
@@ -1768,6 +1871,15 @@ class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:
   // is the chain's start, the others seed the history that history-reading proposals draw from (ptmcmc.cc:86: de_ni * Npar)
   bayes_likelihood* init_like = nullptr;
   const sampleable_probability_function* init_prior = nullptr;
+  bool prior_on_host = false;   // the prior is not a per-dimension product: evaluated through ptm_set_prior_callback
+  // C-ABI trampoline of a host-evaluated prior: probability_function::evaluate_log on every (valid) state of the batch
+  static void prior_trampoline(void* self, const double* X, int n, int dim, double* out) {
+    const sampleable_probability_function* pr = (const sampleable_probability_function*)self;
+    for (int k = 0; k < n; k++) {
+      state s = state::from_engine(pr->get_space(), X + (size_t)k * dim, dim);   // (enforced on the device already)
+      out[k] = pr->evaluate_log(s);
+    }
+  }
   std::vector<double> init_start;
   bool have_start = false;
   // tell the ladder BEFORE initialize() that its proposal will be drawn on the host (saves building the engine twice)
@@ -1807,10 +1919,17 @@ class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:
       if (lo[i] == boundary::open && hi[i] == boundary::open) xmin[i] = xmax[i] = 0;
     }
     ptm_check(ptm_set_bounds(eng, lo.data(), hi.data(), xmin.data(), xmax.data()), "set_bounds");
-    log_prior->describe(types, centers, halfwidths);
-    ptm_check(ptm_set_prior(eng, types.data(), centers.data(), halfwidths.data()), "set_prior");
-    if (!log_likelihood->describe_device_target(eng))
+    prior_on_host = !log_prior->describe(types, centers, halfwidths);
+    if (!prior_on_host) {
+      ptm_check(ptm_set_prior(eng, types.data(), centers.data(), halfwidths.data()), "set_prior");
+      if (!log_likelihood->describe_device_target(eng))
+        ptm_check(ptm_set_target_callback(eng, &bayes_likelihood::batch_trampoline, log_likelihood), "set_target_callback");
+    } else {
+      // a prior that is not a per-dimension product: evaluated on the host between the propose and the accept kernel, and so
+      // is the likelihood then (whatever it is: its evaluate_log)
       ptm_check(ptm_set_target_callback(eng, &bayes_likelihood::batch_trampoline, log_likelihood), "set_target_callback");
+      ptm_check(ptm_set_prior_callback(eng, &parallel_tempering_chains::prior_trampoline, (void*)log_prior), "set_prior_callback");
+    }
     std::vector<double> beta(Ntemps);
     for (int i = 0; i < Ntemps; i++) beta[i] = 1 / temps[i];  // chain.cc:1340
     ptm_check(ptm_set_ladder(eng, beta.data()), "set_ladder");
@@ -1821,6 +1940,30 @@ class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:
     if (have_start) {
       ptm_check(ptm_set_states(eng, init_start.data(), nullptr), "set_states");
       Ninit_rows = 1;
+    } else if (prior_on_host) {
+      // MH_chain::initialize (chain.cc:846-876) on the host: every start state is a draw of the prior's own drawSample with the
+      // chain's generator, redrawn while the likelihood is below -1e100 (:856-869); draws 1 .. n-1 are kept for the mirror
+      std::vector<double> x0(N * dim);
+      for (int k = host ? Ninit_rows - 1 : 0; k >= 0; k--) {
+        std::vector<double> x(N * dim), ll(N), lp(N);
+        for (size_t c = 0; c < N; c++) {
+          philox_random rng;
+          rng.reseat(eng_seed, (uint32_t)((c % W) * Ntemps + c / W), ((uint64_t)1 << 40) + (uint64_t)k);   // (a step no sweep reaches)
+          for (int attempt = 0;; attempt++) {
+            state s = log_prior->drawSample(rng);
+            const double l = s.invalid() ? -INFINITY : log_likelihood->evaluate_log(s);
+            if (!(l < -1e100)) {
+              for (int d = 0; d < dim; d++) x[c * dim + d] = s.get_param(d);
+              ll[c] = l; lp[c] = log_prior->evaluate_log(s);
+              break;
+            }
+            if (attempt >= 100000) { std::cout << "parallel_tempering_chains::initialize: no valid start state drawn from the prior" << std::endl; exit(1); }
+          }
+        }
+        if (k > 0) { init_x.push_back(x); init_ll.push_back(ll); init_lp.push_back(lp); }
+        else x0 = x;
+      }
+      ptm_check(ptm_set_states(eng, x0.data(), nullptr), "set_states");
     } else {
       // draws 1 .. n-1 first (kept for the mirror), draw 0 last: it is the chain's start, whatever n is
       for (int k = host ? Ninit_rows - 1 : 0; k >= 0; k--) {
@@ -1908,6 +2051,7 @@ class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:
               "set_proposal_callback");
   }
   bool proposals_on_host() const { return host_mode; }
+  bool prior_evaluated_on_host() const { return prior_on_host; }   // the prior is not a per-dimension product (describe() == false)
   // chain::report_prop (chain.cc:2096-2109 flavour): every rung's proposal report, replica 0
   std::string report_prop(int style = 0) override {
     std::ostringstream ss;

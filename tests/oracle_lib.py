@@ -39,7 +39,8 @@ class _Problem(C.Structure):
     _fields_ = [("D", C.c_int), ("blo", _ip), ("bhi", _ip), ("bmin", _dp), ("bmax", _dp), ("origin_valid", C.c_int),
                 ("ptype", _ip), ("plo", _dp), ("phi", _dp), ("pcoef", _dp), ("all_uniform", C.c_int),
                 ("lprior_const", C.c_double), ("have_gauss", C.c_int), ("mean", _dp), ("P2", _dp),
-                ("like0", C.c_double), ("user_fn", C.c_void_p), ("user", C.c_void_p), ("minPrior", C.c_double)]
+                ("like0", C.c_double), ("user_fn", C.c_void_p), ("user", C.c_void_p), ("minPrior", C.c_double),
+                ("prior_fn", C.c_void_p), ("prior_user", C.c_void_p)]
 
 
 class _Proposal(C.Structure):  # (fields below; K, mix appended for scale mixtures)
@@ -93,6 +94,7 @@ def lib():
     L.ptmo_problem_set_prior.argtypes = [C.POINTER(_Problem), _ip, _dp, _dp]
     L.ptmo_problem_set_gauss.argtypes = [C.POINTER(_Problem), _dp, _dp, C.c_double]
     L.ptmo_problem_set_user.argtypes = [C.POINTER(_Problem), C.c_void_p, C.c_void_p]
+    L.ptmo_problem_set_user_prior.argtypes = [C.POINTER(_Problem), C.c_void_p, C.c_void_p]
     L.ptmo_pt_create.restype = C.POINTER(_PT)
     L.ptmo_pt_create.argtypes = [C.c_int, C.c_int, C.c_int, _dp, C.c_double, C.c_int]
     L.ptmo_pt_free.argtypes = [C.POINTER(_PT)]
@@ -225,6 +227,14 @@ class Problem:
         cb = LOGLIKE_FN(tramp)
         self._keep.append(cb)
         lib().ptmo_problem_set_user(self.p, C.cast(cb, C.c_void_p), None)
+
+    def set_user_prior(self, pyfunc):
+        """a prior handed over as a function of the (valid) state: log-prior, -inf outside the support"""
+        def tramp(user, xp, dim):
+            return float(pyfunc(np.ctypeslib.as_array(xp, shape=(dim,)).copy()))
+        cb = LOGLIKE_FN(tramp)
+        self._keep.append(cb)
+        lib().ptmo_problem_set_user_prior(self.p, C.cast(cb, C.c_void_p), None)
 
     def enforce(self, x):
         x = np.array(x, dtype=np.float64)

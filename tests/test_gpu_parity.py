@@ -928,6 +928,64 @@ def test_host_callback_likelihood_through_the_lanes_kernel(D, Nt, W, ev):
     eng.close()
 
 
+@pytest.mark.parametrize("D,Nt,W,ev", [(3, 6, 4, 0.0), (12, 8, 3, 0.02), (20, 5, 2, 0.0)])
+def test_host_evaluated_prior_matches_the_oracle(D, Nt, W, ev):
+    """A prior ptm_set_prior cannot describe (here: a correlated Gaussian times a hard disc in the first two dimensions -- what
+    an independent_dist_product / transformed_dist / user subclass of probability_function may be) through
+    ptm_set_prior_callback: propose kernel -> host prior -> prior gate (chain.cc:980) -> host likelihood -> accept kernel.
+    Bit for bit the chain of the oracle handed the same function as its prior; wrap + limit boundaries stay on the device
+    (an invalid state is never shown to the prior); the exchange phase carries the log-priors with the rows."""
+    import math
+    rng = np.random.default_rng(11)
+    sc = rng.uniform(0.5, 2.0, D)
+    def loglike(x):
+        x = np.asarray(x, dtype=np.float64)
+        return float(-0.5 * np.sum((x * sc) ** 2) - 0.1 * math.cos(3.0 * x[0]))
+    calls = {"n": 0, "bad": 0}
+    def logprior(x):
+        x = np.asarray(x, dtype=np.float64)
+        calls["n"] += 1
+        if abs(x[1]) > 2.0 + 1e-12 or x[2] < -3.0 - 1e-12 or x[2] > 3.0 + 1e-12:
+            calls["bad"] += 1               # never asked about a state outside the boundaries
+        if x[0] * x[0] + x[1] * x[1] > 6.0:
+            return -math.inf                # hard support
+        return float(-0.5 * (x[0] - 0.3 * x[1]) ** 2 - 0.05 * np.sum(x[2:] ** 2) - 1.234)
+    beta = E.geometric_ladder(Nt, 1e3)
+    blo, bhi, bmin, bmax = [0] * D, [0] * D, [0.0] * D, [0.0] * D
+    blo[1], bhi[1], bmin[1], bmax[1] = 3, 3, -2.0, 2.0                     # wrap
+    blo[2], bhi[2], bmin[2], bmax[2] = 1, 1, -3.0, 3.0                     # limit: proposals beyond it are invalid
+    x0 = rng.uniform(-1.2, 1.2, size=(Nt * W, D))
+    fac = np.tile(np.full(D, 0.6), (Nt, 1)) / np.sqrt(beta)[:, None].clip(1e-2)
+    eng = E.Engine(D, Nt, W, swap_rate=0.3)
+    eng.set_bounds(blo, bhi, bmin, bmax)
+    eng.set_target_callback(loglike)
+    eng.set_prior_callback(logprior)
+    eng.set_ladder(beta)
+    eng.set_proposals(E.PROP_DIAG, fac, np.full(Nt, 0.2))
+    with pytest.raises(E.PtmError):
+        eng.init_from_prior()               # a host prior is drawn from on the host
+    eng.set_states(x0)
+    pb = O.Problem(D)
+    pb.set_bounds(blo, bhi, bmin, bmax)
+    pb.set_user(loglike)
+    pb.set_user_prior(logprior)
+    lad = O.Ladder(pb, beta, W=W, swap_rate=0.3)
+    lad.set_proposals([(O.PROP_DIAG, fac[r], 0.2) for r in range(Nt)])
+    lad.use_philox(0x5EED0001)
+    lad.set_states(PU.to_oracle_order(x0, Nt, W))
+    if ev:
+        eng.set_evolve_temps(ev); lad.evolve_temps(ev)
+    PU.assert_same_state(eng, lad, "start")
+    for k in range(6):
+        eng.step(5); eng.sync(); lad.pt_step(5)
+        PU.assert_same_state(eng, lad, "after %d steps" % (5 * (k + 1)))
+    assert calls["bad"] == 0 and calls["n"] > Nt * W
+    lp = eng.lprior
+    assert np.isfinite(lp).all() and len(np.unique(lp)) > Nt * W // 2      # the host's values, not a constant
+    assert eng.naccept.sum() - eng.Nc > 10
+    eng.close()
+
+
 def test_exchange_overflow_path_many_moved_rows():
     """More than 256 rows of one ladder move in one step (high swap rate on a long ladder): the exchange kernel's
     in-kernel cycle walk must give the same chain as the register gather/scatter kernel does for smaller counts."""

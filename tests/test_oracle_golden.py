@@ -235,3 +235,44 @@ def test_reference_pt_trace(tid):
         assert pb.origin_valid == 0 and lad.naccept.sum() == Nt
     else:
         assert pb.origin_valid == 1 and lad.naccept.sum() > Nt + 20
+
+
+def test_prior_given_as_a_function_equals_the_described_prior():
+    """ptmo_problem_set_user_prior (the checker's side of ptm_set_prior_callback): a prior handed over as a function of the valid
+    state replaces the per-dimension description.  Handing over the mixed uniform / polar / copolar prior of exampleLISA as
+    a function (the checker's own ptmo_lprior of a second, described problem) must give the very chain the description gives --
+    the reference's prior gate (chain.cc:980) and exchange phase see the same numbers either way."""
+    D, Nt, W = 6, 5, 2
+    beta = O.geometric_ladder(Nt, 1e4) if hasattr(O, "geometric_ladder") else np.exp(-np.log(1e4) * np.arange(Nt) / (Nt - 1))
+    rng = np.random.default_rng(3)
+    lo = np.array(lisa_toy.CENTERS) - np.array(lisa_toy.SCALES)
+    hi = np.array(lisa_toy.CENTERS) + np.array(lisa_toy.SCALES)
+    x0 = rng.uniform(lo + 0.05, hi - 0.05, size=(Nt * W, D))
+    sig = np.array(lisa_toy.SCALES) / 10.0
+    fac = np.tile(sig, (Nt, 1)) / np.sqrt(beta)[:, None].clip(1e-3)
+    described = O.Problem(D)
+    described.set_bounds(lisa_toy.BLO, lisa_toy.BHI, lisa_toy.BMIN, lisa_toy.BMAX)
+    described.set_prior(lisa_toy.TYPES, lisa_toy.CENTERS, lisa_toy.SCALES)
+    described.set_user(lisa_toy.loglike)
+    handed = O.Problem(D)
+    handed.set_bounds(lisa_toy.BLO, lisa_toy.BHI, lisa_toy.BMIN, lisa_toy.BMAX)
+    handed.set_user(lisa_toy.loglike)
+    asked = []
+    def prior(x):
+        asked.append(x.copy())
+        return described.lprior(x, 1)
+    handed.set_user_prior(prior)
+    lads = []
+    for pb in (described, handed):
+        lad = O.Ladder(pb, beta, W=W, swap_rate=0.3)
+        lad.set_proposals([(O.PROP_DIAG, fac[r], 0.3) for r in range(Nt)])
+        lad.use_philox(0x5EED0001)
+        lad.set_states(x0)
+        lad.pt_step(40)
+        lads.append(lad)
+    a, b = lads
+    assert np.array_equal(a.x, b.x) and np.array_equal(a.lprior, b.lprior) and np.array_equal(a.llike, b.llike)
+    assert np.array_equal(a.naccept, b.naccept) and a.naccept.sum() > Nt * W
+    assert len(asked) > Nt * W     # start states, then the valid proposals
+    X = np.array(asked)
+    assert (X[:, 0] >= lisa_toy.BMIN[0]).all() and (X[:, 0] <= lisa_toy.BMAX[0]).all()   # never asked about an invalid state
