@@ -809,7 +809,9 @@ static int launch_sweep(ptm_engine* e, int rung0 = 0, int nr = -1, bool last = t
   // Compacted sweep: after an exchange phase ~1/6 of a long ladder's chains make no move; the lean MFMA build on a big
   // population then visits the moving chains only (partition_kernel packs them per rung).  PTM_COMPACT=0 switches it off.
   static const bool compact_ok = [] { const char* v = getenv("PTM_COMPACT"); return !(v && *v == '0'); }();
-  const bool compact = compact_ok && e->touched && e->DP == 32 && sel.simple && !e->hist.rungs && !e->map.rungs && !getenv("PTM_FORCE_VALU") &&
+  // ... and the box-bounds build (uniform priors, open / limit bounds, a mean, one-dimensional moves, scale mixtures, evolving ladders)
+  const bool gen1 = sel.uni && !sel.callback && !sel.host_prop && e->all_uniform && (!e->has_bounds || e->bounds_box);
+  const bool compact = compact_ok && e->touched && e->DP == 32 && (sel.simple || gen1) && !e->hist.rungs && !e->map.rungs && !getenv("PTM_FORCE_VALU") &&
                        e->W >= 1024 && e->nloc <= 4096;   // (the same answer for every partial sweep of a step)
   if (!compact) { int rc = flush_nhist(e); if (rc) return rc; }
   if (compact) {
@@ -1697,7 +1699,8 @@ extern "C" const char* ptm_sweep_kernel_name(ptm_engine* e) {
   const SweepSel s = sweep_sel(e);
   if (e->DP == 32 && s.uni && !s.callback && !s.host_prop) {
     const char* cv = getenv("PTM_COMPACT");
-    const bool cpt = !(cv && *cv == '0') && s.simple && !e->hist.rungs && !e->map.rungs && e->W >= 1024 && e->nloc <= 4096;   // (in PT steps; plain sweeps visit every chain)
+    const bool g1 = !s.simple && e->all_uniform && (!e->has_bounds || e->bounds_box);
+    const bool cpt = !(cv && *cv == '0') && (s.simple || g1) && !e->hist.rungs && !e->map.rungs && e->W >= 1024 && e->nloc <= 4096;   // (in PT steps; plain sweeps visit every chain)
     const char* lv = getenv("PTM_LEAN_PIPE");
     if (s.simple && !e->hist.rungs && !e->map.rungs && lv && *lv && *lv != '0')
       snprintf(b, sizeof b, "sweep_mfma32_lean_kernel<%d, %s>", s.kind == KIND_DIAG ? KIND_LOWER : s.kind, cpt ? "true" : "false");

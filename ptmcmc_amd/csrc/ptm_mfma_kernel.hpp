@@ -49,6 +49,12 @@ typedef double mf_d2 __attribute__((ext_vector_type(2)));
                                // set, four waves per SIMD); 0: by build -- 1 for the everything-general build (0.90 -> 0.70 ms), 2 for the others
                                // (the lean build loses 5 % with 1: twice the operand reads and pass overheads, and occupancy buys it nothing)
 #endif
+#ifndef PTM_MFMA_G1C_GG
+#define PTM_MFMA_G1C_GG 2      // groups per pass of the compacted box-bounds build
+#endif
+#ifndef PTM_MFMA_G1C_WAVES
+#define PTM_MFMA_G1C_WAVES 3
+#endif
 #ifndef PTM_MFMA_ASK_AT
 #define PTM_MFMA_ASK_AT 4      // block product: the second pass's rows are asked for before column block ASK_AT (-1: before the product)
 #endif
@@ -65,15 +71,15 @@ typedef double mf_d2 __attribute__((ext_vector_type(2)));
 // All of the general work is per dimension, so it runs in the accumulator layout as it stands: a lane enforces and
 // prices its own eight dimensions of each chain, and the chain's four lanes meet in two more LDS reductions / ballots.
 // EV: a GEN 1 build that reads a per-chain beta (evolving ladders; the GEN 2 build always can)
-// CPT (lean build only): the sweep visits the moving chains alone, through the per-rung lists of partition_kernel
+// CPT (lean and GEN 1 builds without history): the sweep visits the moving chains alone, through the per-rung lists of partition_kernel
 // (ptm_kernels.hpp) -- tiles of 256 LISTED walkers of one rung, enumerated rung by rung; lane l of a wave works for the l-th
 // listed walker of its group instead of walker w0 + l.
 template <int KIND, bool HIST, int GEN, bool EV = false, bool CPT = false>   // GEN: 0 lean, 1 box boundaries + uniform prior (+ mean, 1-D moves), 2 everything
-__global__ __launch_bounds__(256, (GEN == 0 ? PTM_MFMA_WAVES : ((PTM_MFMA_GG == 0 && GEN == 2 && KIND == KIND_LOWER) ? 4 : PTM_MFMA_GEN_WAVES))) void sweep_mfma32_kernel(const Dev p) {
-  constexpr bool PERSIST = GEN == 0 || PTM_MFMA_GEN_PERSIST != 0;
-  static_assert(!CPT || (GEN == 0 && !HIST && !EV), "the compacted sweep exists for the lean build");
+__global__ __launch_bounds__(256, (GEN == 0 ? PTM_MFMA_WAVES : ((PTM_MFMA_GG == 0 && GEN == 2 && KIND == KIND_LOWER) ? 4 : ((GEN == 1 && CPT) ? PTM_MFMA_G1C_WAVES : PTM_MFMA_GEN_WAVES)))) void sweep_mfma32_kernel(const Dev p) {
+  constexpr bool PERSIST = GEN == 0 || PTM_MFMA_GEN_PERSIST != 0 || CPT;   // (a compacted sweep walks its tiles: an idle tile must cost nothing)
+  static_assert(!CPT || (GEN <= 1 && !HIST), "the compacted sweep exists for the lean and the box-bounds builds, without history");
   constexpr int DP = 32;
-  constexpr int GG = PTM_MFMA_GG ? PTM_MFMA_GG : (GEN == 2 ? 1 : 2), NP = 4 / GG, PL = 16 * GG;   // groups per pass, passes per tile, chains (= stage-5 lanes) per pass
+  constexpr int GG = PTM_MFMA_GG ? PTM_MFMA_GG : (GEN == 2 ? 1 : ((GEN == 1 && CPT) ? PTM_MFMA_G1C_GG : 2)), NP = 4 / GG, PL = 16 * GG;   // groups per pass, passes per tile, chains (= stage-5 lanes) per pass
   constexpr bool LOW = KIND == KIND_LOWER;
   // LDS: [2560] Box-Muller tables | [12][64] precision tiles | [64] prior box (all shared by the block's waves) |
   //      128 doubles per wave

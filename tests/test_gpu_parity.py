@@ -1029,6 +1029,41 @@ def test_compacted_sweep_of_big_populations_matches_the_oracle(kind):
     eng.close(); e2.close()
 
 
+@pytest.mark.parametrize("kind,odf,with_mean,ev", [(E.PROP_LOWER, 0.0, False, 0.0), (E.PROP_DENSE, 0.4, True, 0.0), (E.PROP_LOWER, 0.3, False, 0.02)])
+def test_compacted_sweep_of_the_box_bounds_build_matches_the_oracle(kind, odf, with_mean, ev):
+    """The usual real-world state space (uniform priors, `limit` / open boundaries, a mean, one-dimensional moves, an evolving
+    ladder) on a big population without history: its MFMA build walks the moving chains only, like the lean one.  Narrow
+    limits, so that a good share of the proposals is invalid; bit for bit the oracle's chains, counters and temperatures."""
+    D, Nt, W = 30, 8, 1024
+    rng = np.random.default_rng(35)
+    blo = [1 if d % 3 else 0 for d in range(D)]
+    bhi = [1 if d % 2 else 0 for d in range(D)]
+    bmin = list(rng.uniform(-2.5, -1.5, D)); bmax = list(rng.uniform(1.5, 2.5, D))
+    prior = ([1] * D, [0.0] * D, list(rng.uniform(3.0, 6.0, D)))
+    x0 = rng.uniform(-1.4, 1.4, size=(Nt * W, D))
+    mean = rng.normal(size=D) * 0.1 if with_mean else None
+    pr, eng, lad = PU.make_pair(D, Nt, W, 1e3, kind=kind, bounds=(blo, bhi, bmin, bmax), prior=prior, swap_rate=0.3, x0=x0, mean=mean,
+                                one_d_frac=(odf if odf > 0 else None))
+    if ev:
+        eng.set_evolve_temps(ev); lad.evolve_temps(ev)
+    assert eng.sweep_kernel_name.endswith(", 1, %s, true>" % ("true" if ev else "false"))
+    for k in range(3):
+        eng.step(3); eng.sync(); lad.pt_step(3)
+        PU.assert_same_state(eng, lad, "after %d compacted steps" % (3 * (k + 1)))
+        if ev:
+            assert np.array_equal(eng.invtemps(), lad.betaw)
+        if k == 0:
+            eng.sweep(2); eng.sync(); lad.sweep(2)          # plain sweeps in between: every chain visited in place
+            PU.assert_same_state(eng, lad, "after plain sweeps")
+    tries, acc = eng.ntries.sum() - eng.Nc, eng.naccept.sum() - eng.Nc
+    assert 0 < acc < 0.8 * tries
+    if odf > 0:
+        assert (eng.last_type == 1).any()
+    t, a = eng.swap_counts()
+    assert np.array_equal(t, lad.swap_count) and np.array_equal(a, lad.swap_accept_count)
+    eng.close()
+
+
 @pytest.mark.parametrize("overlap", [False, True])
 def test_compacted_sweep_in_sharded_engines(overlap):
     """the compacted sweep through the sharded step's partial sweeps (interior / boundary rungs separately)"""
