@@ -333,9 +333,9 @@ double ptmo_llike(const ptmo_problem* pb, const double* x) {
 
 /* order in which the columns of a proposal factor are accumulated (the kernels' tile order): natural for padded
  * dimension <= 8; otherwise in halves of 16 columns, inside a half s + 4k with s = 0..3 outer, k = 0..3 inner.
- * Padded dimension = D rounded up to 4, 8, 16, 32, 64. */
+ * Padded dimension = D rounded up to 4, 8, 16, 32, 64, 128. */
 int ptmo_column_order(int D, int* ord) {
-  int DP = D <= 4 ? 4 : (D <= 8 ? 8 : (D <= 16 ? 16 : (D <= 32 ? 32 : 64)));
+  int DP = D <= 4 ? 4 : (D <= 8 ? 8 : (D <= 16 ? 16 : (D <= 32 ? 32 : (D <= 64 ? 64 : 128))));
   int n = 0;
   if (DP <= 8) {
     for (int j = 0; j < D; j++) ord[n++] = j;
@@ -555,7 +555,7 @@ int ptmo_mh_step(ptmo_pt* s, const ptmo_problem* pb, const ptmo_proposal* prop, 
   double cur_llike = s->llike[c], cur_lprior = s->lprior[c];
   double cur_lpost = ptmo_lpost(cur_lprior, beta, cur_llike);
   double oldlprior = cur_lpost - beta * cur_llike;                       /* :973 */
-  double xn[64], off[64];
+  double xn[PTMO_MAX_DIM], off[PTMO_MAX_DIM];
   double hast = 0.0;
   int type, valid;
   if (s->host_prop) {                                                    /* :975 prop.draw -- any proposal, evaluated by the caller */
@@ -641,7 +641,7 @@ static void swap_phase(ptmo_pt* s, const ptmo_rng* rng, int w) {
     }
   }
   /* :1436-1537 trials, in pick order, on the in-place updated view */
-  double tmp[64];
+  double tmp[PTMO_MAX_DIM];
   double *bw = NULL, *sp = NULL, *P0 = NULL, *inc = NULL, S = 0.0, c1 = 0.0, nrm = 1.0;
   int* ipry = NULL;
   const double grow = 1.0 + s->evolve_rate;
@@ -803,7 +803,7 @@ static double ph_chain_uniform(void* vctx, int w, int r, uint64_t step, int slot
 static int ph_draw_offset(void* vctx, int w, int r, uint64_t step, const ptmo_proposal* p, int D, double* off) {
   philox_ctx* c = (philox_ctx*)vctx;
   uint32_t stream = (uint32_t)((uint64_t)w * c->Nt + r);
-  double z[64 + 4];
+  double z[PTMO_MAX_DIM + 4];
   for (int b = 0; 4 * b < D; b++) {                       /* gaussian_dist_product::drawSample: D normals (probability_function.cc:37-47) */
     uint32_t o[4];
     ptmo_draw_block(c->seed, PTMO_TAG_MH, stream, step, (uint32_t)(b + 1), o);
@@ -838,7 +838,7 @@ static int ph_draw_offset(void* vctx, int w, int r, uint64_t step, const ptmo_pr
   if (p->kind == PTMO_PROP_DIAG) {
     for (int i = 0; i < D; i++) off[i] = p->M[i] * z[i];
   } else {
-    int ord[64];
+    int ord[PTMO_MAX_DIM];
     int n = ptmo_column_order(D, ord);
     for (int i = 0; i < D; i++) {
       double a = 0.0;

@@ -622,7 +622,7 @@ __device__ __forceinline__ void decide_body(const Decide& p, unsigned char* smem
       if (!head) continue;
       double* X = p.x;
       const int c0 = (r - p.r0) * p.W + w;
-      double tmp[66];                                      // the head's old row {x[0..DP), llike, lprior}, DP <= 64
+      double tmp[130];                                     // the head's old row {x[0..DP), llike, lprior}, DP <= 128
       for (int d = 0; d < DP; ++d) tmp[d] = X[(size_t)c0 * DP + d];
       tmp[DP] = p.ll[c0];
       tmp[DP + 1] = p.lp[c0];

@@ -132,7 +132,8 @@ static int round_dp(int D) {
   if (D <= 8) return 8;
   if (D <= 16) return 16;
   if (D <= 32) return 32;
-  return 64;
+  if (D <= 64) return 64;
+  return 128;
 }
 
 template <class T>
@@ -184,7 +185,7 @@ extern "C" int ptm_engine_create(const ptm_config* cfg, ptm_engine** out) {
   cfg = &cfg_full;
   if (cfg->walker_begin < 0) return fail(PTM_ERR_INVALID, "walker_begin must be >= 0");
   if (cfg->dim < 1) return fail(PTM_ERR_INVALID, "dim must be >= 1");
-  if (cfg->dim > 64) return fail(PTM_ERR_UNSUPPORTED, "dim > 64 is not built (kernels exist for padded dimensions 4, 8, 16, 32, 64)");
+  if (cfg->dim > 128) return fail(PTM_ERR_UNSUPPORTED, "dim > 128 is not built (kernels exist for padded dimensions 4, 8, 16, 32, 64, 128)");
   if (cfg->n_rungs < 1 || cfg->n_rungs > 65535) return fail(PTM_ERR_INVALID, "n_rungs must be in 1..65535");
   if (cfg->rung_begin < 0 || cfg->rung_count < 1 || cfg->rung_begin + cfg->rung_count > cfg->n_rungs)
     return fail(PTM_ERR_INVALID, "rung block out of range");
@@ -831,6 +832,7 @@ static int launch_sweep(ptm_engine* e, int rung0 = 0, int nr = -1, bool last = t
       case 16: return launch_sweep_16(q, sel, e->stream);
       case 32: return launch_sweep_32(q, sel, e->stream);
       case 64: return launch_sweep_64(q, sel, e->stream);
+      case 128: return launch_sweep_128(q, sel, e->stream);
     }
     return hipErrorInvalidValue;
   };
@@ -1086,7 +1088,8 @@ static int run_eval(ptm_engine* e, int n, double* x, int* valid, double* lp, dou
     case 16: HIPCHK(launch_eval_16(p, n, x, valid, lp, ll, eval_like, e->stream)); break;
     case 32: HIPCHK(launch_eval_32(p, n, x, valid, lp, ll, eval_like, e->stream)); break;
     case 64: HIPCHK(launch_eval_64(p, n, x, valid, lp, ll, eval_like, e->stream)); break;
-    default: return fail(PTM_ERR_UNSUPPORTED, "dim > 64 is not built");
+    case 128: HIPCHK(launch_eval_128(p, n, x, valid, lp, ll, eval_like, e->stream)); break;
+    default: return fail(PTM_ERR_UNSUPPORTED, "dim > 128 is not built");
   }
   return PTM_OK;
 }
@@ -1143,7 +1146,8 @@ static int launch_init(ptm_engine* e, const Dev& p, long long attempt, unsigned 
     case 16: HIPCHK(launch_init_16(p, e->x, e->ll, e->lp, e->err + 1, attempt, pending, e->stream)); break;
     case 32: HIPCHK(launch_init_32(p, e->x, e->ll, e->lp, e->err + 1, attempt, pending, e->stream)); break;
     case 64: HIPCHK(launch_init_64(p, e->x, e->ll, e->lp, e->err + 1, attempt, pending, e->stream)); break;
-    default: return fail(PTM_ERR_UNSUPPORTED, "dim > 64 is not built");
+    case 128: HIPCHK(launch_init_128(p, e->x, e->ll, e->lp, e->err + 1, attempt, pending, e->stream)); break;
+    default: return fail(PTM_ERR_UNSUPPORTED, "dim > 128 is not built");
   }
   return PTM_OK;
 }
@@ -1709,7 +1713,7 @@ extern "C" const char* ptm_sweep_kernel_name(ptm_engine* e) {
              s.simple ? 0 : ((e->all_uniform && (!e->has_bounds || e->bounds_box)) ? 1 : 2),
              (!s.simple && e->all_uniform && (!e->has_bounds || e->bounds_box) && e->betaC) ? ", true" : ", false", cpt ? "true" : "false");   // as rocprofv3 prints it
   }
-  else if (e->DP == 64 || s.host_prop || (!s.uni && !getenv("PTM_FORCE_VALU") && (long long)e->Nc * e->DP <= (e->DP >= 16 ? PTM_LANES_MAX : 4096ll * e->DP)))
+  else if (e->DP >= 64 || s.host_prop || (!s.uni && !getenv("PTM_FORCE_VALU") && (long long)e->Nc * e->DP <= (e->DP >= 16 ? PTM_LANES_MAX : 4096ll * e->DP)))
     snprintf(b, sizeof b, "sweep_lanes_kernel<%d, %d, %s>", e->DP, s.kind, s.plain ? "false" : "true");
   else snprintf(b, sizeof b, "sweep_kernel<%d, %d, %s, %s>", e->DP, s.kind, s.uni ? "true" : "false", s.simple ? "true" : "false");
   e->kname = b;

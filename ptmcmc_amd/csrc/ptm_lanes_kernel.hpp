@@ -4,7 +4,8 @@
 // than 64 walkers per rung: the reference's own shape, one ladder of 1024 rungs) there are only a few waves in the
 // whole launch and each lane walks through a chain's ~4000 dependent f64 operations: 80 us per sweep of 1024 chains,
 // all of it latency.  Here a chain's DP dimensions sit on DP adjacent lanes (2 chains per wave at DP = 32, 4 at 16, ...; at
-// DP = 64 -- 33..64 dimensions, which no other sweep kernel is built for -- a wave is one chain):
+// DP = 64 -- 33..64 dimensions, which no other sweep kernel is built for -- a wave is one chain; at DP = 128, 65..128
+// dimensions, a wave is one chain still and every lane carries TWO dimensions, lane and lane + 64):
 // lane d draws normal d, accumulates row d of factor . z and row d of the precision matrix, and the two reductions
 // (box test, y.s) cross the chain's lanes through LDS.  The arithmetic of every number is the one of the other kernels
 // (same column order, same fma chains, same four interleaved partial sums), so the chains stay bit-identical.
@@ -20,7 +21,7 @@ namespace ptm {
 
 // LDS of the lanes kernels, in doubles: Box-Muller tables | packed precision matrix | per-wave scratch
 template <int DP>
-constexpr int lanes_lds_doubles(int waves) { return BM_TABLE_DOUBLES + ((DP * (DP + 1) / 2 + 1) & ~1) + waves * (3 * 64 + 4 * (64 / DP)); }
+constexpr int lanes_lds_doubles(int waves) { return BM_TABLE_DOUBLES + ((DP * (DP + 1) / 2 + 1) & ~1) + waves * (3 * (DP > 64 ? DP : 64) + 4 * (DP > 64 ? 1 : 64 / DP)); }
 
 // the block's tables into LDS (all threads of the block; ends with a barrier)
 template <int DP>
@@ -37,18 +38,21 @@ __device__ __forceinline__ void lanes_stage(const Dev& p, double* lds_all) {
 // (cbase = c_begin, cstride = 1); the fused small-ladder kernel walks ONE walker's rungs (cbase = walker, cstride = W).
 template <int DP, int KIND, bool GEN>
 __device__ __forceinline__ void lanes_body(const Dev& p, double* lds_all, const int wslot0, const int cbase, const int cstride, const int nslots) {
-  static_assert(DP == 4 || DP == 8 || DP == 16 || DP == 32 || DP == 64, "lanes kernel: DP 4 .. 64");
-  constexpr int CPW = 64 / DP;              // chains per wave
+  static_assert(DP == 4 || DP == 8 || DP == 16 || DP == 32 || DP == 64 || DP == 128, "lanes kernel: DP 4 .. 128");
+  constexpr int E = DP > 64 ? DP / 64 : 1;  // dimensions per lane: lane's d, d + 64, ...
+  constexpr int LPC = DP / E;               // lanes per chain
+  constexpr int CPW = 64 / LPC;             // chains per wave
+  constexpr int WS = DP > 64 ? DP : 64;     // one scratch array of a wave
   constexpr int NP2 = DP * (DP + 1) / 2;    // packed precision matrix
   double* p2s = lds_all + BM_TABLE_DOUBLES;                     // [NP2 (+pad)]
-  double* wsc = p2s + ((NP2 + 1) & ~1) + (threadIdx.x >> 6) * (3 * 64 + 4 * CPW);   // this wave's scratch
+  double* wsc = p2s + ((NP2 + 1) & ~1) + (threadIdx.x >> 6) * (3 * WS + 4 * CPW);   // this wave's scratch
   double* vbuf = wsc;             // [CPW][DP] z, then y
-  double* sbuf = wsc + 64;        // [CPW][DP] s_i
-  double* tbuf = wsc + 128;       // [CPW][DP] unused tail / flags
-  double* pbuf = wsc + 192;       // [CPW][4]  partial sums
+  double* sbuf = wsc + WS;        // [CPW][DP] s_i
+  double* tbuf = wsc + 2 * WS;    // [CPW][DP] unused tail / flags
+  double* pbuf = wsc + 3 * WS;    // [CPW][4]  partial sums
 
   const int lane = threadIdx.x & 63;
-  const int d = lane % DP, g = lane / DP;
+  const int d = lane % LPC, g = lane / LPC;   // (E > 1: this lane's dimensions are d + 64 e)
   int slot = (wslot0 + (threadIdx.x >> 6)) * CPW + g;
   const bool live = slot < nslots;
   if (!live) slot = nslots - 1;   // dead lanes shadow the last chain and write nothing
@@ -57,12 +61,12 @@ __device__ __forceinline__ void lanes_body(const Dev& p, double* lds_all, const 
   const int w = c - rl * p.W;
   const int rg = p.r0 + rl;
   const bool lead = d == 0;
-  const int pos = row_pos<DP>(d);
+  const int pos = row_pos<DP>(d);   // (the identity but for DP = 32; dimension d + 64 e sits at pos + 64 e)
   double* __restrict__ row = p.x + (size_t)c * DP;
   const bool hist_on = rl < p.hist.rungs, map_on = rl < p.map.rungs;
   auto sync_wave = [] { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); };
   // a flag of the chain's lead lane, for all its lanes
-  auto from_lead = [&](int v) { return __builtin_amdgcn_ds_bpermute(4 * (g * DP), v); };
+  auto from_lead = [&](int v) { return __builtin_amdgcn_ds_bpermute(4 * (g * LPC), v); };
 
   // host-callback likelihood (GEN build): mode 1 = propose pass (proposal, validity, prior -> xprop / lprior_new / gate, nothing
   // else changes), mode 2 = accept pass with the host's llike_new; 0 = fused
@@ -77,7 +81,9 @@ __device__ __forceinline__ void lanes_body(const Dev& p, double* lds_all, const 
     if (hist_on && a % (unsigned int)p.add_every_n == 0u) {
       const long long hrow = 1 + (long long)(a / (unsigned int)p.add_every_n);
       const size_t o = hist_slot(p.hist, hrow, c);
-      if (live) p.hist.x[o * DP + d] = row[d];
+#pragma unroll
+      for (int e = 0; e < E; ++e)
+        if (live) p.hist.x[o * DP + d + 64 * e] = row[d + 64 * e];
       if (live && lead)
         hist_scalars(p.hist, o, hrow, p.ll[c], p.lp[c], p.naccept[c], p.ntries[c], p.last_type[c],
                      (GEN && p.beta_add) ? p.beta_add[c] : p.beta[rg]);
@@ -90,7 +96,9 @@ __device__ __forceinline__ void lanes_body(const Dev& p, double* lds_all, const 
     }
     if (map_on) {
       mapw = from_lead(mapw);
-      if (mapw && live) p.map.x[(size_t)c * DP + d] = row[d];
+#pragma unroll
+      for (int e = 0; e < E; ++e)
+        if (mapw && live) p.map.x[(size_t)c * DP + d + 64 * e] = row[d + 64 * e];
     }
   }
 
@@ -113,23 +121,31 @@ __device__ __forceinline__ void lanes_body(const Dev& p, double* lds_all, const 
     if (p.any_oned && !tc && f > 0 && u01(o0.v1) < f) { axis = (int)(p.D * u01(o0.v2)); type = 1; }
   }
   // normal d: slot d & 3 of Philox block 1 + d / 4 (two Box-Muller pairs per block)
-  double zd = 0.0;
-  if (!hp) {
-    const u32x4 o = draw_block(p.seed, TAG_MH, stream, p.step, (uint32_t)((d >> 2) + 1));
-    const bool hi = (d & 2) != 0;
-    double z0, z1;
-    boxmuller(hi ? o.v2 : o.v0, hi ? o.v3 : o.v1, lds_all, z0, z1);
-    zd = (d & 1) ? z1 : z0;
-    if (GEN && axis >= 0 && d != axis) zd = 0.0;   // one-dimensional move (proposal_distribution.hh:197-205)
+  double zd[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int de = d + 64 * e;
+    zd[e] = 0.0;
+    if (!hp) {
+      const u32x4 o = draw_block(p.seed, TAG_MH, stream, p.step, (uint32_t)((de >> 2) + 1));
+      const bool hi = (de & 2) != 0;
+      double z0, z1;
+      boxmuller(hi ? o.v2 : o.v0, hi ? o.v3 : o.v1, lds_all, z0, z1);
+      zd[e] = (de & 1) ? z1 : z0;
+      if (GEN && axis >= 0 && de != axis) zd[e] = 0.0;   // one-dimensional move (proposal_distribution.hh:197-205)
+    }
   }
   // -- gaussian_prop::draw (proposal_distribution.hh:194-218): offset = factor * z, row d on lane d
-  double off = 0.0;
+  double off[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) off[e] = 0.0;
   if (mode == 2 || hp) {
     // accept pass: the proposal was drawn and stored by the propose pass; host-side proposal: it was drawn by the host
   } else if (KIND == KIND_DIAG) {
-    off = p.prop[(size_t)rl * p.prop_stride + d] * zd;
-  } else {
-    vbuf[g * DP + d] = zd;
+#pragma unroll
+    for (int e = 0; e < E; ++e) off[e] = p.prop[(size_t)rl * p.prop_stride + d + 64 * e] * zd[e];
+  } else if constexpr (E == 1) {
+    vbuf[g * DP + d] = zd[0];
     const double* fac = p.prop + (size_t)rl * p.prop_stride + d;   // column-major [col][row]: T[d][j] at j * DP + d
     double tcol[DP];
 #pragma unroll
@@ -150,16 +166,36 @@ __device__ __forceinline__ void lanes_body(const Dev& p, double* lds_all, const 
             acc = __builtin_fma(tcol[j], vbuf[g * DP + j], acc);
           }
     }
-    off = acc;
+    off[0] = acc;
     sync_wave();   // vbuf is reused below
+  } else {
+    // more than 64 dimensions: the factor's column entries come from memory as they are used (no register image of a row)
+#pragma unroll
+    for (int e = 0; e < E; ++e) vbuf[d + 64 * e] = zd[e];
+    sync_wave();
+    const double* fac = p.prop + (size_t)rl * p.prop_stride + d;
+    for (int h = 0; h < DP / 16; ++h)
+      for (int sl = 0; sl < 4; ++sl)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int j = 16 * h + 4 * k + sl;
+          const double zj = vbuf[j];
+#pragma unroll
+          for (int e = 0; e < E; ++e) off[e] = __builtin_fma(fac[(size_t)j * DP + 64 * e], zj, off[e]);
+        }
+    sync_wave();
   }
   const double ll = p.ll[c], lp = p.lp[c];
   if (GEN && p.mix_K > 0 && !hp) {
     type = kmix + 10 * type;   // proposal_distribution.cc:117
-    off = mix_scale * off;     // the member is scale_k times the rung's factor
+#pragma unroll
+    for (int e = 0; e < E; ++e) off[e] = mix_scale * off[e];     // the member is scale_k times the rung's factor
   }
   if (hp) type = p.htype[c];   // proposal_distribution::type()
-  double xn = (mode == 2 || hp) ? p.xprop[(size_t)c * DP + pos] : row[pos] + off;   // state::add (states.cc:205-214)
+  double xn[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e)
+    xn[e] = (mode == 2 || hp) ? p.xprop[(size_t)c * DP + pos + 64 * e] : row[pos + 64 * e] + off[e];   // state::add (states.cc:205-214)
   // what the state is worth before enforcing: Q9 for a sum built by state::add (on an enforced zero state); a host-side
   // proposal brings its own validity (state::invalid())
   const bool valid0 = hp ? p.hvalid[c] != 0 : p.origin_valid != 0;
@@ -167,8 +203,8 @@ __device__ __forceinline__ void lanes_body(const Dev& p, double* lds_all, const 
   const double bl = beta * ll;
   const double cur_lpost = lp + bl;
   const double oldlprior = cur_lpost - bl;  // chain.cc:973
-  constexpr unsigned long long GM = DP == 64 ? ~0ull : ((1ull << (DP & 63)) - 1ull);
-  auto all_of_chain = [&](bool v) { return ((__builtin_amdgcn_ballot_w64(v) >> (g * DP)) & GM) == GM; };
+  constexpr unsigned long long GM = LPC == 64 ? ~0ull : ((1ull << (LPC & 63)) - 1ull);
+  auto all_of_chain = [&](bool v) { return ((__builtin_amdgcn_ballot_w64(v) >> (g * LPC)) & GM) == GM; };
   bool valid = true;
   double newlprior;
   if (mode == 2) {
@@ -178,18 +214,33 @@ __device__ __forceinline__ void lanes_body(const Dev& p, double* lds_all, const 
     if (GEN) {
       // stateSpace::enforce (states.cc:86-102), each dimension on its lane; Q9: the sum is built on an enforced zero state
       bool vd = true;
-      if (p.has_bounds && d < p.D) vd = boundary_enforce(p.blo[d], p.bhi[d], p.bmin[d], p.bmax[d], xn);
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const int de = d + 64 * e;
+        if (p.has_bounds && de < p.D) vd = boundary_enforce(p.blo[de], p.bhi[de], p.bmin[de], p.bmax[de], xn[e]) && vd;
+      }
       valid = valid0 && all_of_chain(vd);
     }
     // the box of the all-uniform prior: every dimension of the chain inside
-    const bool in = all_of_chain(!(xn < p.plo[d]) && !(xn > p.phi[d]));
+    bool ind = true;
+#pragma unroll
+    for (int e = 0; e < E; ++e) ind = ind && !(xn[e] < p.plo[d + 64 * e]) && !(xn[e] > p.phi[d + 64 * e]);
+    const bool in = all_of_chain(ind);
     newlprior = (valid && in) ? p.lprior_const : -__builtin_inf();
   } else {
     bool vd = true;
-    if (p.has_bounds && d < p.D) vd = boundary_enforce(p.blo[d], p.bhi[d], p.bmin[d], p.bmax[d], xn);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int de = d + 64 * e;
+      if (p.has_bounds && de < p.D) vd = boundary_enforce(p.blo[de], p.bhi[de], p.bmin[de], p.bmax[de], xn[e]) && vd;
+    }
     valid = valid0 && all_of_chain(vd);
     // mixed_dist_product::evaluate: the factors in four interleaved partial products, combined ((p0 p1) p2) p3
-    sbuf[g * DP + d] = d < p.D ? prior_pdf(p.ptype[d], p.plo[d], p.phi[d], p.pcoef[d], xn) : 1.0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int de = d + 64 * e;
+      sbuf[g * DP + de] = de < p.D ? prior_pdf(p.ptype[de], p.plo[de], p.phi[de], p.pcoef[de], xn[e]) : 1.0;
+    }
     sync_wave();
     if (d < 4) {
       double pq = 1.0;
@@ -205,7 +256,9 @@ __device__ __forceinline__ void lanes_body(const Dev& p, double* lds_all, const 
   const bool want_like = valid && (newlprior > -1e200 || newlprior - oldlprior > p.min_prior);  // chain.cc:980 (Q1)
   if (mode == 1) {   // hand the proposal to the host, change nothing else
     if (live) {
-      if (!tc) p.xprop[(size_t)c * DP + pos] = xn;
+#pragma unroll
+      for (int e = 0; e < E; ++e)
+        if (!tc) p.xprop[(size_t)c * DP + pos + 64 * e] = xn[e];
       if (lead) {
         p.lprior_new[c] = newlprior;
         p.gate[c] = tc ? (unsigned char)0 : (unsigned char)((valid ? 1 : 0) | (want_like ? 2 : 0));
@@ -217,14 +270,17 @@ __device__ __forceinline__ void lanes_body(const Dev& p, double* lds_all, const 
   //    partial sums p_q = sum_{i = q mod 4} y_i s_i (i ascending), combined ((p0 + p1) + p2) + p3
   double quad = 0.0;
   if (mode != 2) {
-    vbuf[g * DP + d] = (GEN && p.has_mean) ? xn - p.mean[d] : xn;
+#pragma unroll
+    for (int e = 0; e < E; ++e) vbuf[g * DP + d + 64 * e] = (GEN && p.has_mean) ? xn[e] - p.mean[d + 64 * e] : xn[e];
     sync_wave();
-    {
-      const double* prow = p2s + d * (d + 1) / 2;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int de = d + 64 * e;
+      const double* prow = p2s + de * (de + 1) / 2;
       const double* y = vbuf + g * DP;
       double s = 0.0;
-      for (int j = 0; j <= d; ++j) s = __builtin_fma(prow[j], y[j], s);
-      sbuf[g * DP + d] = s;
+      for (int j = 0; j <= de; ++j) s = __builtin_fma(prow[j], y[j], s);
+      sbuf[g * DP + de] = s;
     }
     sync_wave();
     if (d < 4) {
@@ -259,8 +315,11 @@ __device__ __forceinline__ void lanes_body(const Dev& p, double* lds_all, const 
     if (hist_on && nh0 % (unsigned int)p.add_every_n == 0u) {   // add_state saves this one (chain.cc:935-946)
       const long long hrow = 1 + (long long)(nh0 / (unsigned int)p.add_every_n);
       const size_t o = hist_slot(p.hist, hrow, c);
-      if (accept) p.hist.x[o * DP + pos] = xn;
-      else p.hist.x[o * DP + d] = row[d];
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        if (accept) p.hist.x[o * DP + pos + 64 * e] = xn[e];
+        else p.hist.x[o * DP + d + 64 * e] = row[d + 64 * e];
+      }
       if (lead) {
         if (accept) hist_scalars(p.hist, o, hrow, newlike, newlprior, nacc0 + 1, ntries1, type, beta);
         else hist_scalars(p.hist, o, hrow, ll, lp, nacc0, ntries1, p.last_type[c], beta);
@@ -272,8 +331,11 @@ __device__ __forceinline__ void lanes_body(const Dev& p, double* lds_all, const 
   }
   if (map_on) {
     mapw = from_lead(mapw);
-    if (mapw == 1 && act) p.map.x[(size_t)c * DP + pos] = xn;
-    if (GEN && mapw == 2 && act) p.map.x[(size_t)c * DP + d] = row[d];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      if (mapw == 1 && act) p.map.x[(size_t)c * DP + pos + 64 * e] = xn[e];
+      if (GEN && mapw == 2 && act) p.map.x[(size_t)c * DP + d + 64 * e] = row[d + 64 * e];
+    }
   }
   if (act) {
     // (every lane of the chain has read the counters above before the lead lane rewrites them: same wave, program order)
@@ -282,7 +344,8 @@ __device__ __forceinline__ void lanes_body(const Dev& p, double* lds_all, const 
       p.nhist[c] += 1u;
     }
     if (accept) {
-      row[pos] = xn;
+#pragma unroll
+      for (int e = 0; e < E; ++e) row[pos + 64 * e] = xn[e];
       if (lead) {
         p.naccept[c] += 1;
         p.last_type[c] = type;

@@ -175,6 +175,9 @@ SWEEP_CASES = [
     (40, 6, 3, 1e2, E.PROP_DENSE, None),     # 33..64 dimensions: the lanes kernel with one chain per wave
     (64, 5, 64, 1e2, E.PROP_LOWER, None),
     (50, 4, 70, 1e2, E.PROP_DIAG, 0.3),
+    (100, 5, 3, 1e2, E.PROP_LOWER, None),    # 65..128 dimensions: the lanes kernel, two dimensions per lane
+    (128, 4, 64, 1e2, E.PROP_DENSE, 0.3),
+    (65, 6, 5, 1e2, E.PROP_DIAG, 0.4),
     (18, 7, 3, 1e2, E.PROP_LOWER, 0.4),      # lanes kernel, general build: one-dimensional moves
     (32, 5, 2, 1e2, E.PROP_DIAG, 0.5),
     (5, 7, 3, 1e2, E.PROP_DENSE, 0.3),       # padded dimension (5 -> 8), ragged sizes
@@ -257,6 +260,8 @@ def test_add_every_n_history_counters():
                                                  (20, 7, 3, E.PROP_DENSE, 2, 0.45, 0),   # lanes kernel (a lane per dimension)
                                                  (40, 7, 3, E.PROP_DENSE, 2, 0.45, 0),   # 64-dimension rows
                                                  (33, 300, 64, E.PROP_DIAG, 2, 0.45, 0.01),   # ... in every exchange path, evolving
+                                                 (100, 6, 3, E.PROP_LOWER, 2, 0.45, 0),   # 128-dimension rows (two dimensions per lane)
+                                                 (70, 300, 64, E.PROP_DIAG, 2, 0.45, 0.01),
                                                  (16, 9, 5, E.PROP_LOWER, 1, 0.3, 0),
                                                  (16, 12, 64, E.PROP_DIAG, 4, 0.3, 0),
                                                  (4, 900, 64, E.PROP_DIAG, 2, 0.45, 0),  # > 256 moved rows: the slow exchange path
@@ -883,7 +888,7 @@ def test_host_callback_likelihood_C5_exampleLISA(ev, Nt, W):
     eng.close()
 
 
-@pytest.mark.parametrize("D,Nt,W,ev", [(12, 8, 3, 0.0), (20, 6, 5, 0.03), (40, 5, 2, 0.0)])
+@pytest.mark.parametrize("D,Nt,W,ev", [(12, 8, 3, 0.0), (20, 6, 5, 0.03), (40, 5, 2, 0.0), (70, 4, 3, 0.02)])
 def test_host_callback_likelihood_through_the_lanes_kernel(D, Nt, W, ev):
     """A plug-in likelihood on a small population with more than 8 dimensions: the propose and accept passes of the lanes
     kernel (a lane per dimension) around the host call -- bit for bit the oracle's chain, with a gaussian + uniform prior,
@@ -909,7 +914,7 @@ def test_host_callback_likelihood_through_the_lanes_kernel(D, Nt, W, ev):
     eng.set_ladder(beta)
     eng.set_proposals(E.PROP_DIAG, fac, np.full(Nt, 0.3))
     eng.set_states(x0)
-    assert eng.sweep_kernel_name.startswith("sweep_lanes_kernel<%d" % (16 if D <= 16 else 32 if D <= 32 else 64))
+    assert eng.sweep_kernel_name.startswith("sweep_lanes_kernel<%d" % (16 if D <= 16 else 32 if D <= 32 else 64 if D <= 64 else 128))
     pb = O.Problem(D)
     pb.set_bounds(blo, bhi, bmin, bmax)
     pb.set_prior(types, cen, hw)
