@@ -15,15 +15,22 @@ from ptmcmc_amd import engine as E
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 4000
 cases = [(6, 12, 64, E.PROP_DENSE, 0.3, 0.02, "general kernel"), (5, 9, 5, E.PROP_DENSE, 0.3, 0.02, "lanes kernel (8)"),
          (14, 24, 3, E.PROP_LOWER, 0.2, 0.01, "lanes kernel"),
-         (32, 10, 64, E.PROP_LOWER, 0.3, 0.01, "MFMA kernel"), (40, 8, 2, E.PROP_DIAG, 0.4, 0.0, "lanes kernel, 64-dim rows")]
+         (32, 10, 64, E.PROP_LOWER, 0.3, 0.01, "MFMA kernel"), (40, 8, 2, E.PROP_DIAG, 0.4, 0.0, "lanes kernel, 64-dim rows"),
+         (90, 6, 2, E.PROP_LOWER, 0.4, 0.01, "lanes kernel, 128-dim rows"),
+         (32, 6, 1024, E.PROP_LOWER, 0.3, 0.0, "MFMA kernel, compacted"), (28, 6, 1024, E.PROP_DENSE, 0.3, 0.01, "MFMA kernel, box-bounds build, compacted")]
 for D, Nt, W, kind, sr, ev, what in cases:
-    pr, eng, lad = PU.make_pair(D, Nt, W, 1e4, kind=kind, swap_rate=sr, one_d_frac=0.2)
+    lean = what == "MFMA kernel, compacted"
+    pr, eng, lad = PU.make_pair(D, Nt, W, 1e4, kind=kind, swap_rate=sr, one_d_frac=None if lean else 0.2)
+    if W >= 1024:
+        steps_case = min(steps, 600)   # (the checker walks 6144 chains per step on one core)
+    else:
+        steps_case = steps
     if ev:
         eng.set_evolve_temps(ev); lad.evolve_temps(ev)
     t0 = time.time()
     done = 0
-    while done < steps:
-        n = min(500, steps - done)
+    while done < steps_case:
+        n = min(500 if W < 1024 else 100, steps_case - done)
         eng.step(n); eng.sync(); lad.pt_step(n)
         done += n
         PU.assert_same_state(eng, lad, "%s after %d steps" % (what, done))
@@ -31,5 +38,5 @@ for D, Nt, W, kind, sr, ev, what in cases:
         print("  %-28s %6d steps ok (%.0fs)" % (what, done, time.time() - t0), flush=True)
     t, a = eng.swap_counts()
     print("%s: D=%d %dx%d, %d steps bit-identical; kernel %s; MH accept %.3f, swap accept %.3f" %
-          (what, D, Nt, W, steps, eng.sweep_kernel_name, (eng.naccept.sum() - eng.Nc) / max(1, eng.ntries.sum() - eng.Nc), a.sum() / max(1, t.sum())), flush=True)
+          (what, D, Nt, W, steps_case, eng.sweep_kernel_name, (eng.naccept.sum() - eng.Nc) / max(1, eng.ntries.sum() - eng.Nc), a.sum() / max(1, t.sum())), flush=True)
     eng.close()
