@@ -1468,6 +1468,7 @@ class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:
   ptm_engine* eng;
   const stateSpace* sp;
   int dim, nstep, hist_rows, hist_rungs = 0;   // hist_rungs: the coldest rungs whose saved states are kept (0: all)
+  int Woff = 0, eng_device = -1;   // first GLOBAL replica of this engine, its device (set_replica_range)
   int W;   // independent replicas of the ladder run side by side (the reference runs its Nchain repeats one after the
            // other, ptmcmc.cc main loop): chain (rung i, replica w) sits at index i*W + w of every engine array
   std::vector<double> temps, X, llike, lpost;
@@ -1565,7 +1566,7 @@ class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:
     int getDim() override { return p->dim; }
     int get_id() override { return (int)(w * p->Ntemps + i); }
     std::shared_ptr<Random> getPRNG() override { return rng; }
-    void reseat(uint64_t seed, uint64_t step) { rng->reseat(seed, (uint32_t)((uint64_t)w * p->Ntemps + i), step); }
+    void reseat(uint64_t seed, uint64_t step) { rng->reseat(seed, (uint32_t)((uint64_t)(w + p->Woff) * p->Ntemps + i), step); }
     double getMAPlpost() override { p->refresh_map(); return p->mlpost[at()]; }
     state getMAPstate() override { p->refresh_map(); return state::from_engine(p->sp, p->mX.data() + at() * p->dim, p->dim); }
   };
@@ -1695,6 +1696,13 @@ class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:
   // streams of walker w; every accessor below takes the replica as an optional last argument (default 0).  Multiples
   // of 64 fill whole wavefronts and take the fast kernels.
   void set_replicas(int n) { W = n < 1 ? 1 : n; }
+  // Several GPUs: one process per GPU, each with its own share of the replicas -- replicas `begin .. begin + n - 1` of the
+  // population (call before initialize(); `device` < 0: the process's current device, e.g. through HIP_VISIBLE_DEVICES).
+  // Replicas are independent ladders, so there is nothing to exchange between the processes, and a replica's chains are the
+  // very ones a single engine holding the whole population gives it (ptm_config.walker_begin: its random streams are those of
+  // the GLOBAL replica index) -- evolving ladders and host-side proposals included.
+  void set_replica_range(int begin, int n, int device = -1) { Woff = begin < 0 ? 0 : begin; W = n < 1 ? 1 : n; eng_device = device; }
+  int replica_begin() const { return Woff; }
   // Keep the reference's exchange diagnostics (which instance sits on which rung, round-trip directions, ups / downs)
   // for replica 0: costs one read-back of the step's candidate log per step, so it is off by default.
   void track_exchanges(bool on) {
@@ -1907,7 +1915,8 @@ class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:
     ptm_config cfg = ptm_config();   // (zeroed: fields a newer ABI adds default to 0)
     cfg.struct_size = sizeof cfg;
     cfg.dim = dim; cfg.n_rungs = Ntemps; cfg.rung_begin = 0; cfg.rung_count = Ntemps; cfg.n_walkers = W; cfg.seed = eng_seed;
-    cfg.swap_rate = swap_rate; cfg.add_every_n = add_every_N; cfg.min_prior = dpriormin; cfg.device = -1; cfg.stream = nullptr;
+    cfg.swap_rate = swap_rate; cfg.add_every_n = add_every_N; cfg.min_prior = dpriormin; cfg.device = eng_device; cfg.stream = nullptr;
+    cfg.walker_begin = Woff;
     cfg.time_kernels = 0; cfg.swap_log_steps = 0; cfg.exchange_row_capacity = 0; cfg.history_rungs = ring_rungs; cfg.history_capacity = ring_rows; cfg.map_rungs = Ntemps;
     ptm_check(ptm_engine_create(&cfg, &eng), "parallel_tempering_chains::initialize");
     std::vector<int> lo(dim), hi(dim), types;
@@ -1948,7 +1957,7 @@ class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:
         std::vector<double> x(N * dim), ll(N), lp(N);
         for (size_t c = 0; c < N; c++) {
           philox_random rng;
-          rng.reseat(eng_seed, (uint32_t)((c % W) * Ntemps + c / W), ((uint64_t)1 << 40) + (uint64_t)k);   // (a step no sweep reaches)
+          rng.reseat(eng_seed, (uint32_t)((c % W + Woff) * Ntemps + c / W), ((uint64_t)1 << 40) + (uint64_t)k);   // (a step no sweep reaches)
           for (int attempt = 0;; attempt++) {
             state s = log_prior->drawSample(rng);
             const double l = s.invalid() ? -INFINITY : log_likelihood->evaluate_log(s);
@@ -2363,7 +2372,7 @@ class ptmcmc_sampler : public bayes_sampler {
   std::string restart_dir;
   int checkp_at_step;
   double ess_stop, prop_adapt_rate, dpriormin;
-  int nreplicas;
+  int nreplicas, replica_begin = 0, device = -1;
 
   void ensure_options() { if (!haveOptions()) addOptions(own_opt); }
   void processOptions() {   // ptmcmc.cc:430-473
@@ -2391,6 +2400,9 @@ class ptmcmc_sampler : public bayes_sampler {
     *optValue("chain_dprior_min") >> dpriormin;
     nreplicas = 1;
     if (optSet("replicas")) *optValue("replicas") >> nreplicas;
+    replica_begin = 0; device = -1;
+    if (optSet("replica_begin")) *optValue("replica_begin") >> replica_begin;
+    if (optSet("device")) *optValue("device") >> device;
   }
 
  public:
@@ -2463,6 +2475,9 @@ class ptmcmc_sampler : public bayes_sampler {
     // this build's addition: independent replicas of the ladder side by side in one engine (the reference runs its repeats
     // one after the other: the caller's loop over clone() / initialize() / run())
     addOption("replicas", "Independent replicas of the ladder run side by side on the device (files <base>_c<w>_t<k>.dat). Default 1", "1");
+    // ... and over several GPUs: one process per GPU, each told which replicas of the population are its own
+    addOption("replica_begin", "Global index of this process's first replica (several GPUs: one process each, disjoint ranges). Default 0", "0");
+    addOption("device", "GPU of this process (-1: the current device, e.g. by HIP_VISIBLE_DEVICES). Default -1", "-1");
   }
 
   // ---- convenience for programs without an Options object of their own (examples/example_sampler.cc)
@@ -2696,7 +2711,7 @@ class ptmcmc_sampler : public bayes_sampler {
     if (dn > Nptc || dn <= 0) dn = Nptc;   // ptmcmc.cc:458
     // ... and with an effective-sample-size stop (chain_ess_stop) the cold chain's whole saved history
     cc->keep_history(2 + 2 * (ess_stop > 0 ? std::max(Nevery, Nstep) : Nevery) / std::max(1, save_every), dn);
-    cc->set_replicas(nreplicas);
+    cc->set_replica_range(replica_begin, nreplicas, device);
     if (pt_evolve_rate > 0) cc->evolve_temps(pt_evolve_rate, pt_evolve_lpost_cut);   // ptmcmc.cc:512
     int kind; double odf; std::vector<double> f;
     const int dim = chain_prior->getDim();
@@ -2722,7 +2737,7 @@ class ptmcmc_sampler : public bayes_sampler {
       for (int ich = 0; ich < dn; ich++) {   // ptmcmc.cc:547-554; replica w > 0: <base>_c<w>_t<ich>.dat
         std::ostringstream ss;
         ss << base;
-        if (w > 0) ss << "_c" << w;
+        if (w + cc->replica_begin() > 0) ss << "_c" << (w + cc->replica_begin());   // (the GLOBAL replica index)
         ss << "_t" << ich << ".dat";
         out.emplace_back(new std::ofstream(ss.str().c_str(), mode));
         out.back()->precision(output_precision);

@@ -22,10 +22,12 @@ ap.add_argument("--tag", default="")
 ap.add_argument("--bounds", action="store_true", help="limit bounds on every dimension, uniform prior: the general build's cheap case")
 ap.add_argument("--general", action="store_true", help="limit bounds on every dimension + one gaussian prior factor: the general build")
 ap.add_argument("--evolve", type=float, default=0.0, help="evolve_temps rate (per-ladder temperatures, sequential exchange decisions)")
+ap.add_argument("--history", type=int, default=0, help="rungs with a saved history (and MAP tracking on every rung): the sampler's engine")
 a = ap.parse_args()
 kind = {"lower": E.PROP_LOWER, "dense": E.PROP_DENSE, "diag": E.PROP_DIAG}[a.kind]
 pr = GaussianProblem(a.dim, a.rungs, a.tmax)
-eng = E.Engine(a.dim, a.rungs, a.walkers, add_every_n=100, time_kernels=True)
+eng = E.Engine(a.dim, a.rungs, a.walkers, add_every_n=100, time_kernels=True, history_rungs=a.history, history_capacity=64 if a.history else 0,
+               map_rungs=a.rungs if a.history else 0)
 pr.configure(eng, kind)
 if a.bounds:
     eng.set_bounds([1] * a.dim, [1] * a.dim, [-1e3] * a.dim, [1e3] * a.dim)
