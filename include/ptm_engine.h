@@ -142,7 +142,10 @@ int ptm_set_ladder(ptm_engine* e, const double* beta);
  * gaps lazily normalised inside a step (same values up to rounding, pinned against the reference by tests/golden traces
  * 5 and 6) and rebuilds the temperatures once per step.  Call after ptm_set_ladder.  History rows and MAP values taken
  * during an exchange phase carry the temperature their rung had at that add_state, between two pries of the step, as in
- * the reference (chain.cc:1487-1490,1531-1534).  Not built: lpost_cut >= 0, sharded ladders (PTM_ERR_UNSUPPORTED). */
+ * the reference (chain.cc:1487-1490,1531-1534).  lpost_cut >= 0 (chain.cc:1819-1827): every pry also widens each gap whose two
+ * chains' current log-posteriors are out of order by more than lpost_cut * invtemp; the exchange kernel then decides a
+ * ladder's picks one after the other and goes over all its gaps after every accepted exchange (pinned against the reference by
+ * traces 11 and 12).  Not built: sharded ladders (PTM_ERR_UNSUPPORTED). */
 int ptm_set_evolve_temps(ptm_engine* e, double rate, double lpost_cut);
 /* every ladder's inverse temperatures, beta[n_walkers][n_rungs] (the common ladder repeated while nothing evolves);
  * ptm_set_invtemps puts them back (checkpoint / resume of an evolving run; needs ptm_set_evolve_temps first) */

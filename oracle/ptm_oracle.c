@@ -444,6 +444,7 @@ ptmo_pt* ptmo_pt_create(int D, int Nt, int W, const double* beta, double swap_ra
   ptmo_pt* s = (ptmo_pt*)calloc(1, sizeof *s);
   size_t N = (size_t)Nt * W;
   s->D = D; s->Nt = Nt; s->W = W; s->swap_rate = swap_rate; s->add_every_N = add_every_N;
+  s->evolve_cut = -1;
   s->maxswaps = (int)(1 + 2 * swap_rate * Nt);                  /* chain.cc:1192 (int = double truncation) */
   s->beta = (double*)malloc(Nt * sizeof(double)); memcpy(s->beta, beta, Nt * sizeof(double));
   s->x = (double*)calloc(N * D, sizeof(double));
@@ -470,6 +471,7 @@ void ptmo_pt_free(ptmo_pt* s) {
   free(s->hist_x); free(s->hist_ll); free(s->hist_lp); free(s->hist_beta); free(s->hist_nacc); free(s->hist_ntry); free(s->hist_type);
   free(s);
 }
+void ptmo_pt_evolve_lpost_cut(ptmo_pt* s, double cut) { s->evolve_cut = cut; }
 void ptmo_pt_evolve_temps(ptmo_pt* s, double rate) {
   s->evolve_rate = rate;
   free(s->betaw);
@@ -646,6 +648,10 @@ static void swap_phase(ptmo_pt* s, const ptmo_rng* rng, int w) {
   int* ipry = NULL;
   const double grow = 1.0 + s->evolve_rate;
   int npry = 0;
+  /* evolve_temp_lpost_cut >= 0 (chain.cc:1819-1827): every pry ALSO widens each gap whose two chains' log-posteriors are out
+   * of order by more than cut * invtemp -- any gap of the ladder, so nothing stays lazy: after every accepted exchange the
+   * gaps' prefix sums P0 and their total are rebuilt (ptmo_chunk_prefix), and a rung's temperature is 1 - P0 / normaliser */
+  const int cutmode = s->evolve_cut >= 0;
   if (s->betaw && Nt > 1) {
     bw = s->betaw + base;
     sp = (double*)malloc((size_t)Nt * sizeof(double));
@@ -668,7 +674,10 @@ static void swap_phase(ptmo_pt* s, const ptmo_rng* rng, int w) {
     double ba = s->beta[i], bb = s->beta[i + 1];
     if (sp) {
       ba = bw[i]; bb = bw[i + 1];
-      if (npry) {
+      if (npry && cutmode) {
+        if (i > 0) ba = 1 - P0[i] / nrm;
+        if (i + 1 < Nt - 1) bb = 1 - P0[i + 1] / nrm;
+      } else if (npry) {
         double Da = 0.0, Db = 0.0;
         for (int q = 0; q < npry; q++) {
           if (ipry[q] < i) Da = Da + inc[q];
@@ -702,7 +711,21 @@ static void swap_phase(ptmo_pt* s, const ptmo_rng* rng, int w) {
       double t = s->llike[a]; s->llike[a] = s->llike[b]; s->llike[b] = t;
       t = s->lprior[a]; s->lprior[a] = s->lprior[b]; s->lprior[b] = t;   /* lprior is a pure function of the state */
       s->swap_accept_count[(size_t)w * (Nt - 1) + i]++;                   /* :1498 */
-      if (sp) {                                                          /* :1501-1518 pry_temps({i}) */
+      if (sp && cutmode) {                                               /* :1516-1517 pry_temps({i}, rate, invtemps, gather_lposts()) */
+        /* the chains' current log-posteriors: lprior + invtemp * llike at the temperatures of this moment (every pry resets
+         * them, MH_chain::resetTemp chain.cc:1088-1091), the exchanged pair already in place */
+        double lpk = 0.0, bk = 0.0;
+        for (int k = 0; k < Nt; k++) {
+          double bnext = (k == 0 || k == Nt - 1 || !npry) ? bw[k] : 1 - P0[k] / nrm;
+          double lnext = ptmo_lpost(s->lprior[base + k], bnext, s->llike[base + k]);
+          if (k > 0 && lpk - lnext > s->evolve_cut * bk) sp[k - 1] = sp[k - 1] * grow;   /* :1819-1827, pow(1+rate, 1) */
+          lpk = lnext; bk = bnext;
+        }
+        sp[i] = sp[i] * grow;                                            /* :1829 */
+        S = ptmo_chunk_prefix(sp, Nt - 1, P0);
+        nrm = S / c1;                                                    /* :1833 */
+        npry++;
+      } else if (sp) {                                                   /* :1501-1518 pry_temps({i}) */
         double sn = sp[i] * grow;                                        /* :1829 */
         ipry[npry] = i; inc[npry] = sn - sp[i];
         S = S + inc[npry];
@@ -716,7 +739,9 @@ static void swap_phase(ptmo_pt* s, const ptmo_rng* rng, int w) {
     s->touched[a]++; s->touched[b]++;
     s->swap_count[(size_t)w * (Nt - 1) + i]++;                            /* :1536 */
   }
-  if (npry) {                                                            /* :1834-1844 the new temperatures */
+  if (npry && cutmode) {
+    for (int k = 1; k < Nt - 1; k++) bw[k] = 1 - P0[k] / nrm;            /* :1834-1844 */
+  } else if (npry) {                                                     /* :1834-1844 the new temperatures */
     double* P = (double*)malloc((size_t)Nt * sizeof(double));
     double total = ptmo_chunk_prefix(sp, Nt - 1, P);
     double nn = total / c1;

@@ -135,6 +135,7 @@ typedef struct {
   ptmo_propose_fn host_prop;
   void* host_prop_user;
   uint8_t* last_accept_mh; /* [W*Nt] outcome of the last step's MH move: 1 accepted, 0 rejected, 2 no move (exchanged rung) */
+  double evolve_cut;       /* evolve_temp_lpost_cut (chain.hh:254,302-307): < 0 off (the default) */
 } ptmo_pt;
 
 /* ---- RNG: Philox4x32-10 (Salmon et al., SC'11; Random123) -------------------------------- */
@@ -175,6 +176,8 @@ void ptmo_pt_free(ptmo_pt*);
 /* evolve_temps(rate) with lpost_cut < 0 (the sampler's defaults, ptmcmc.cc:389-390,512).  History rows and MAP values taken
  * DURING a swap phase see the rung's temperature between two pries of the step (swap_phase in ptm_oracle.c). */
 void ptmo_pt_evolve_temps(ptmo_pt*, double rate);
+/* evolve_temps(rate, lpost_cut) with lpost_cut >= 0 (chain.cc:1819-1827): call before or after ptmo_pt_evolve_temps */
+void ptmo_pt_evolve_lpost_cut(ptmo_pt*, double cut);
 /* exclusive prefix sums of v[0..n) in the order the engine uses: chunks of 32 summed left to right from 0, then the chunk
  * totals summed left to right; P (may be NULL) gets P[k] = offset[k/32] + local sum before k.  Returns the total. */
 double ptmo_chunk_prefix(const double* v, int n, double* P);

@@ -292,7 +292,7 @@ static std::vector<double> peek_tape(chain* c, int n) {
 static int golden_trace(int id) {
   // --- problem definitions -------------------------------------------------------------------
   int D, Nt, nsteps, Ninit = 1;
-  double Tmax, swap_rate, step_scale, minPrior = -30, evolve = 0;
+  double Tmax, swap_rate, step_scale, minPrior = -30, evolve = 0, evolve_cut = -1;
   // compact fixtures (ids 7..9): the scripted offsets are not stored -- the test regenerates them from the helper stream's
   // state ("delta_state", splitmix64 as above) -- and the full states are stored every `xstride`-th step only (llike, lpost,
   // history size on every step: a state that differed would show in its llike)
@@ -332,6 +332,16 @@ static int golden_trace(int id) {
     D = 3; Nt = 7; nsteps = 160; Tmax = 30; swap_rate = 0.45; step_scale = 2.5; evolve = 0.01;
     types = {"uni", "uni", "uni"}; centers = {0.5, 0, -0.5}; scales = {4, 3, 5};
     blo = {O, O, O}; bhi = {O, O, O}; bmin = {0, 0, 0}; bmax = {0, 0, 0};
+  } else if (id == 11) {  // trace 6 with evolve_temp_lpost_cut = 0: every pry also widens the gaps whose chains' posteriors are out of order (chain.cc:1819-1827)
+    D = 3; Nt = 7; nsteps = 160; Tmax = 30; swap_rate = 0.45; step_scale = 2.5; evolve = 0.01; evolve_cut = 0.0;
+    types = {"uni", "uni", "uni"}; centers = {0.5, 0, -0.5}; scales = {4, 3, 5};
+    blo = {O, O, O}; bhi = {O, O, O}; bmin = {0, 0, 0}; bmax = {0, 0, 0};
+  } else if (id == 12) {  // ... and with a tolerance (cut = 1.5), on the mixed-prior problem of trace 4
+    D = 5; Nt = 6; nsteps = 160; Tmax = 1e3; swap_rate = 0.3; step_scale = 0.9; evolve = 0.03; evolve_cut = 1.5;
+    types = {"gauss", "log", "uni", "pol", "cpol"};
+    centers = {0.5, 3.0, 1.0, M_PI / 2, 0.0}; scales = {2.0, 4.0, 2.5, M_PI / 2, M_PI / 2};
+    blo = {O, L, W, L, R}; bhi = {O, O, W, L, R};
+    bmin = {0, -0.5, -1.5, 0, -M_PI / 2}; bmax = {0, 0, 3.5, M_PI, M_PI / 2};
   } else if (id == 7) {  // BASELINE configs[1]: D=16 Gaussian, 64 temperatures (compact fixture: see below)
     D = 16; Nt = 64; nsteps = 40; Tmax = 1e4; swap_rate = 0.1; step_scale = 0.35; compact = true;
   } else if (id == 8) {  // D=32 (the headline dimension), 64 temperatures
@@ -386,7 +396,7 @@ static int golden_trace(int id) {
 
     parallel_tempering_chains ptc(Nt, Tmax, swap_rate, 1, false, false, minPrior);
     ptc.initialize(&like, prior, Ninit);
-    if (evolve > 0) ptc.evolve_temps(evolve);
+    if (evolve > 0) ptc.evolve_temps(evolve, evolve_cut);
 
     // scripted proposal offsets
     const unsigned long long delta_state = g.s;
@@ -417,7 +427,7 @@ static int golden_trace(int id) {
 
     js << "{\"id\":" << id << ",\"D\":" << D << ",\"Nt\":" << Nt << ",\"nsteps\":" << nsteps << ",\"Tmax\":" << jnum(Tmax)
        << ",\"swap_rate\":" << jnum(swap_rate) << ",\"maxswaps\":" << maxswaps << ",\"minPrior\":" << jnum(minPrior)
-       << ",\"add_every_N\":1,\"evolve_rate\":" << jnum(evolve) << ",\n\"types\":[";
+       << ",\"add_every_N\":1,\"evolve_rate\":" << jnum(evolve) << ",\"evolve_lpost_cut\":" << jnum(evolve_cut) << ",\n\"types\":[";
     for (int i = 0; i < D; i++) js << (i ? "," : "") << "\"" << types[i] << "\"";
     js << "],\"centers\":" << jarr(centers) << ",\"scales\":" << jarr(scales) << ",\"blo\":" << jarr_i(blo)
        << ",\"bhi\":" << jarr_i(bhi) << ",\"bmin\":" << jarr(bmin) << ",\"bmax\":" << jarr(bmax)
@@ -664,6 +674,6 @@ int main(int argc, char** argv) {
   if (argc >= 3 && !strcmp(argv[1], "golden-trace")) return golden_trace(atoi(argv[2]));
   if (argc >= 2 && !strcmp(argv[1], "golden-eigen")) return golden_eigen();
   if (argc >= 3 && !strcmp(argv[1], "bench")) return bench(argv[2]);
-  fprintf(stderr, "usage: %s golden-basic | golden-trace <1..10> | golden-eigen | bench <specfile>\n", argv[0]);
+  fprintf(stderr, "usage: %s golden-basic | golden-trace <1..12> | golden-eigen | bench <specfile>\n", argv[0]);
   return 2;
 }

@@ -55,6 +55,7 @@ struct Decide {
   // evolving ladders (parallel_tempering_chains::evolve_temps, chain.hh:302-307): every accepted exchange pries its gap
   // apart (pry_temps, chain.cc:1501-1518,1809-1846), so each ladder owns its temperatures.  Whole-ladder shards only.
   double evolve_rate;   // 0: fixed ladder (beta[] rules)
+  double evolve_cut;    // evolve_temp_lpost_cut (chain.hh:254,302-307; chain.cc:1819-1827): < 0 off, the default
   double* beta_w;       // [W][Nt] the ladders' inverse temperatures, rewritten after a step that pried
   int lp_is_const;      // every chain's lprior is lp_const (all-uniform prior, every state inside the box): the exchange moves no lprior
   double lp_const;
@@ -145,6 +146,10 @@ __device__ __forceinline__ void decide_body(const Decide& p, unsigned char* smem
   double* tdl = tS + msp;                                                     // [ms]  what the pick added to its gap
   double* bklo = tdl + msp;                                                   // [ms]  (by pick) temperature of the pick's lower rung then
   double* gb = p0;                                                            // [MVCAP] temperature for a HIST / MAP move (p0 is done by then)
+  // ... with a posterior-ordering cut (evolve_cut >= 0; the carve above is then taken as with history): the current llike and
+  // lprior of EVERY rung, exchanged as the picks are decided
+  double* llv = bklo + msp;                                                   // [Nt]
+  double* lpv = llv + Nt;                                                     // [Nt]
   double* llc = llc_ - wlo;                // indexed by global rung
   unsigned short* perm = perm_ - wlo;
   unsigned short* inv = inv_ - wlo;
@@ -167,6 +172,7 @@ __device__ __forceinline__ void decide_body(const Decide& p, unsigned char* smem
   }
   const bool evolve = p.evolve_rate > 0 && Nt > 1;
   const bool evb = evolve && p.beta_add != nullptr;   // history / MAP tracking of evolving ladders
+  const bool cutmode = evolve && p.evolve_cut >= 0;   // ... with a posterior-ordering cut
   if (evolve) {
     const double* bw = p.beta_w + (size_t)w * Nt;
     for (int k = lane; k < Nt - 1; k += DECIDE_THREADS) gap[k] = bw[k] - bw[k + 1];   // chain.cc:1816
@@ -238,7 +244,7 @@ __device__ __forceinline__ void decide_body(const Decide& p, unsigned char* smem
     for (int q = lane; q < nch; q += DECIDE_THREADS) {   // S: chunks of 32 left to right, then the chunk totals
       double loc = 0.0;
       for (int k = 32 * q; k < Nt - 1 && k < 32 * q + 32; ++k) {
-        if (evb) p0[k] = loc;
+        if (evb || cutmode) p0[k] = loc;
         loc = loc + gap[k];
       }
       ct[q] = loc;
@@ -256,7 +262,93 @@ __device__ __forceinline__ void decide_body(const Decide& p, unsigned char* smem
       tacc[t] = 0;
     }
     __syncthreads();
-    if (lane == 0) {
+    if (cutmode) {
+      // evolve_temp_lpost_cut >= 0 (chain.cc:1819-1827): every pry also widens each gap whose two chains' log-posteriors are out
+      // of order by more than cut * invtemp -- any gap of the ladder, so nothing stays lazy: the picks are decided one after the
+      // other in pick order, and after every accepted exchange the block goes over all the gaps and rebuilds their prefix sums
+      // (chunks of 32 left to right, then the chunk totals: ptmo_chunk_prefix).  Once something was pried a rung's temperature
+      // is 1 - P0 / normaliser.  ev[0]: the gaps' running total, ev[1]: pries so far.
+      const double* bw = p.beta_w + (size_t)w * Nt;
+      for (int r = lane; r < Nt; r += DECIDE_THREADS) { llv[r] = p.ll[(size_t)r * p.W + w]; lpv[r] = p.lp[(size_t)r * p.W + w]; }
+      if (lane == 0) {
+        double S = 0.0;
+        for (int q = 0; q < nch; ++q) { ct[nch + q] = S; S = S + ct[q]; }
+        ev[0] = S; ev[1] = 0.0;
+      }
+      __syncthreads();
+      for (int k = lane; k < Nt - 1; k += DECIDE_THREADS) p0[k] = ct[nch + (k >> 5)] + p0[k];
+      __syncthreads();
+      const double c1 = 1 - bw[Nt - 1];   // chain.cc:1833
+      const double grow = 1.0 + p.evolve_rate;
+      for (int t = 0; t < nl; ++t) {
+        const int k = olist[t], i = ti[t];
+        if (lane == 0) {
+          const double S = ev[0];
+          const bool pried = ev[1] > 0;
+          const double nrm = S / c1;
+          double lla = llv[i];
+          if (!(lla > -1e200)) lla = -1e200;
+          double llb = llv[i + 1];
+          if (!(llb > -1e200)) llb = -1e200;
+          const double g = gap[i];
+          bool acc = true;
+          if (pried) {
+            const double tt = (g * c1) * (llb - lla);
+            if (tt < 0) acc = tlu[t] * S < tt;
+          } else {
+            const double logH = g * (llb - lla);
+            if (logH < 0) acc = tlu[t] < logH;
+          }
+          tacc[t] = acc ? 1 : 0;
+          if (evb) {   // the two rungs' temperatures as this pick's add_state calls see them (before its own pry)
+            double ba = bw[i], bb = bw[i + 1];
+            if (pried) {
+              if (i > 0) ba = 1 - p0[i] / nrm;
+              if (i + 1 < Nt - 1) bb = 1 - p0[i + 1] / nrm;
+            }
+            bklo[k] = ba;
+            p.beta_add[(size_t)(i + 1) * p.W + w] = bb;
+            if (!PTM_ALIVE_RUNG(i - 1)) p.beta_add[(size_t)i * p.W + w] = ba;
+          }
+          if (acc) {
+            const double a = llv[i]; llv[i] = llv[i + 1]; llv[i + 1] = a;
+            const double b = lpv[i]; lpv[i] = lpv[i + 1]; lpv[i + 1] = b;
+          }
+        }
+        __syncthreads();
+        if (tacc[t]) {   // pry_temps({i}, rate, invtemps, gather_lposts()): chain.cc:1516-1517,1809-1846
+          const double S = ev[0];
+          const bool pried = ev[1] > 0;
+          const double nrm = S / c1;
+          for (int kk = lane; kk < Nt - 1; kk += DECIDE_THREADS) {
+            const double b0 = (kk == 0 || !pried) ? bw[kk] : 1 - p0[kk] / nrm;
+            const double b1 = (kk + 1 == Nt - 1 || !pried) ? bw[kk + 1] : 1 - p0[kk + 1] / nrm;
+            const double t0 = b0 * llv[kk], t1 = b1 * llv[kk + 1];
+            const double l0 = lpv[kk] + t0, l1 = lpv[kk + 1] + t1;   // the chains' current log-posteriors (MH_chain::resetTemp, chain.cc:1088-1091)
+            double gk = gap[kk];
+            if (l0 - l1 > p.evolve_cut * b0) gk = gk * grow;          // :1819-1827
+            if (kk == i) gk = gk * grow;                              // :1829
+            gap[kk] = gk;
+          }
+          __syncthreads();
+          for (int q = lane; q < nch; q += DECIDE_THREADS) {
+            double loc = 0.0;
+            for (int kk = 32 * q; kk < Nt - 1 && kk < 32 * q + 32; ++kk) { p0[kk] = loc; loc = loc + gap[kk]; }
+            ct[q] = loc;
+          }
+          __syncthreads();
+          if (lane == 0) {
+            double S2 = 0.0;
+            for (int q = 0; q < nch; ++q) { ct[nch + q] = S2; S2 = S2 + ct[q]; }
+            ev[0] = S2; ev[1] = ev[1] + 1.0;
+          }
+          __syncthreads();
+          for (int kk = lane; kk < Nt - 1; kk += DECIDE_THREADS) p0[kk] = ct[nch + (kk >> 5)] + p0[kk];
+          __syncthreads();
+        }
+      }
+    }
+    if (!cutmode && lane == 0) {
       double S = 0.0;
       for (int q = 0; q < nch; ++q) { ct[nch + q] = S; S = S + ct[q]; }
       const double c1 = 1 - p.beta_w[(size_t)w * Nt + Nt - 1];   // chain.cc:1833
@@ -343,7 +435,7 @@ __device__ __forceinline__ void decide_body(const Decide& p, unsigned char* smem
   __syncthreads();
   if (evolve) {
     const int nch = (Nt - 1 + 31) / 32;
-    if (evb) {
+    if (evb && !cutmode) {
       // The temperature a rung had when a pick's add_state calls reached it (both rungs of the pair, before the pick's own
       // pry; chain.cc:1487-1490,1531-1534): 1 - (P0 + D) / normaliser, P0 = prefix of the step's first gaps, D = what
       // the earlier accepted picks added to the gaps below the rung, in pick order.  No gap between the pair's two rungs
@@ -669,7 +761,8 @@ __global__ __launch_bounds__(DECIDE_THREADS) void decide_kernel(const Decide p) 
 }
 
 // dynamic LDS of decide_body (host side)
-inline size_t decide_lds_bytes(int Nt, int ms, int WN, bool evolve, bool evb) {
+inline size_t decide_lds_bytes(int Nt, int ms, int WN, bool evolve, bool evb, bool cut = false) {
+  if (cut) return decide_lds_bytes(Nt, ms, WN, evolve, true) + (size_t)2 * Nt * 8;   // (the history carve + every rung's llike, lprior)
   // mirrors the carve at the top of decide_kernel
   return (size_t)WN * 8 + (size_t)((Nt + 1) & ~1) * 4 + (size_t)((ms + 1) & ~1) * 4 * 2 + 8 + (size_t)((WN + 3) & ~3) * 2 * 3 +
          (size_t)((ms + 3) & ~3) * 2 + (size_t)((ms + 7) & ~7) * 2 + (size_t)2 * MVCAP * 4 + 32 +

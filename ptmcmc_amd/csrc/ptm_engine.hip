@@ -81,7 +81,7 @@ struct ptm_engine {
   double *P2 = nullptr, *mean = nullptr, *beta = nullptr, *prop = nullptr, *prop_tiles = nullptr, *P2_tiles = nullptr, *box_row = nullptr, *onedfrac = nullptr, *mix = nullptr;
   int mix_K = 0;
   // evolving ladders (ptm_set_evolve_temps): per-ladder inverse temperatures [W][Nt] and their chain-indexed image [Nc]
-  double evolve_rate = 0;
+  double evolve_rate = 0, evolve_cut = -1;
   double *beta_w = nullptr, *betaC = nullptr, *beta_add = nullptr;
   // host copies / flags
   int has_bounds = 0, origin_valid = 1, all_uniform = 1, has_mean = 0, have_target = 0, have_ladder = 0,
@@ -554,7 +554,6 @@ extern "C" int ptm_set_evolve_temps(ptm_engine* e, double rate, double lpost_cut
     if (e->evolve_rate > 0) return fail(PTM_ERR_UNSUPPORTED, "an evolving ladder cannot be frozen again (the reference has no such call either)");
     return PTM_OK;   // evolve_temps is never called with rate <= 0 (ptmcmc.cc:512)
   }
-  if (lpost_cut >= 0) return fail(PTM_ERR_UNSUPPORTED, "evolve_temps with a posterior-ordering cut (lpost_cut >= 0) is not built");
   if (e->nloc != e->Nt) return fail(PTM_ERR_UNSUPPORTED, "evolving ladders need the whole ladder on one engine (every pry renormalises all rungs)");
   if (!e->have_ladder) return fail(PTM_ERR_INVALID, "set the ladder first (ptm_set_ladder)");
   int rc;
@@ -571,6 +570,7 @@ extern "C" int ptm_set_evolve_temps(ptm_engine* e, double rate, double lpost_cut
     }
   }
   e->evolve_rate = rate;
+  e->evolve_cut = lpost_cut >= 0 ? lpost_cut : -1;
   return PTM_OK;
 }
 
@@ -964,7 +964,7 @@ static Decide make_decide(ptm_engine* e, const double* ll_below, const double* l
   p.hist = e->hist; p.add_every_n = e->cfg.add_every_n; p.nhist = e->nhist;
   p.naccept = e->naccept; p.ntries = e->ntries; p.last_type = e->last_type;
   p.map = e->map;
-  p.evolve_rate = e->evolve_rate; p.beta_w = e->beta_w; p.beta_add = e->beta_add;
+  p.evolve_rate = e->evolve_rate; p.evolve_cut = e->evolve_cut; p.beta_w = e->beta_w; p.beta_add = e->beta_add;
   p.lp_is_const = e->lp_is_const ? 1 : 0; p.lp_const = e->lprior_const;
   const bool beta_direct = e->evolve_rate > 0 && e->W <= 64;   // few ladders: the exchange kernel scatters the new temperatures itself
   p.betaC_direct = beta_direct ? e->betaC : nullptr;
@@ -977,13 +977,14 @@ static int launch_decide(ptm_engine* e, const double* ll_below, const double* ll
   e->touched = true;
   const int WN = e->nloc + (ll_below ? 1 : 0) + p.H;
   const bool evb = e->evolve_rate > 0 && e->beta_add;
-  const size_t lds = decide_lds_bytes(e->Nt, e->ms, WN, e->evolve_rate > 0, evb);
+  const bool cut = e->evolve_rate > 0 && e->evolve_cut >= 0;
+  const size_t lds = decide_lds_bytes(e->Nt, e->ms, WN, e->evolve_rate > 0, evb, cut);
   if (lds > 160 * 1024) return fail(PTM_ERR_UNSUPPORTED, "ladder too long for the LDS-resident exchange kernel (%zu B)", lds);
   // expected candidates inside the window; evolving ladders with history / MAP tracking: the wide form alone carries the
   // saved rows' temperatures through its own row moves
   // ... and a few ladders only (latency regime) whose moves may overflow the 64-thread block: one launch instead of two
   const int per_pick = (e->nloc == e->Nt ? 2 : 4) + (e->hist.rungs ? 1 : 0) + (e->map.rungs ? 1 : 0);
-  const bool wide = (double)e->ms * WN / e->Nt > 96.0 || evb || (e->W <= 256 && per_pick * e->ms > 64);
+  const bool wide = (double)e->ms * WN / e->Nt > 96.0 || evb || cut || (e->W <= 256 && per_pick * e->ms > 64);
   if (lds > 64 * 1024) {
     HIPCHK(hipFuncSetAttribute((const void*)decide_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     HIPCHK(hipFuncSetAttribute((const void*)decide_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1221,7 +1222,7 @@ extern "C" int ptm_sweep(ptm_engine* e, int n) {
 static int fused_steps(ptm_engine* e, int n) {
   static const bool fused_ok = [] { const char* v = getenv("PTM_FUSED"); return !(v && *v == '0'); }();
   if (!fused_ok || e->DP > 16 || (long long)e->Nt * e->DP > 1024 || e->cb || e->pcb || e->cfg.time_kernels) return 0;
-  if (e->evolve_rate > 0 && e->W > 64) return 0;   // (the new temperatures' chain-indexed image is then a separate launch)
+  if (e->evolve_rate > 0 && (e->W > 64 || e->evolve_cut >= 0)) return 0;   // (the new temperatures' chain-indexed image is then a separate launch)
   const bool evb = e->evolve_rate > 0 && e->beta_add;
   const size_t dlds = decide_lds_bytes(e->Nt, e->ms, e->Nt, e->evolve_rate > 0, evb);
   if (dlds > 96 * 1024) return 0;

@@ -1714,7 +1714,7 @@ class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:
   }
   // parallel_tempering_chains::evolve_temps (chain.hh:302-307): after every accepted exchange the gap between the two
   // temperatures is pried apart by (1 + rate) and the ladder renormalised (pry_temps, chain.cc:1501-1518,1809-1846).
-  // Before or after initialize().  The posterior-ordering cut (lpost_cut >= 0) is not built.
+  // Before or after initialize().  lpost_cut >= 0: the posterior-ordering cut (chain.cc:1819-1827).
   bool evolve_temps(double rate = 0.01, double lpost_cut = -1) {
     ev_rate = rate; ev_cut = lpost_cut;
     if (eng) { ptm_check(ptm_set_evolve_temps(eng, ev_rate, ev_cut), "evolve_temps"); fresh = false; }

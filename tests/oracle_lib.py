@@ -57,7 +57,8 @@ class _PT(C.Structure):
                 ("hist_cap", C.c_int), ("hist_x", _dp), ("hist_ll", _dp), ("hist_lp", _dp),
                 ("hist_nacc", C.POINTER(C.c_int32)), ("hist_ntry", C.POINTER(C.c_int32)), ("hist_type", C.POINTER(C.c_int32)),
                 ("map_lpost", _dp), ("map_x", _dp), ("evolve_rate", C.c_double), ("betaw", _dp), ("hist_beta", _dp),
-                ("host_prop", C.c_void_p), ("host_prop_user", C.c_void_p), ("last_accept_mh", C.POINTER(C.c_uint8))]
+                ("host_prop", C.c_void_p), ("host_prop_user", C.c_void_p), ("last_accept_mh", C.POINTER(C.c_uint8)),
+                ("evolve_cut", C.c_double)]
 
 
 _lib = None
@@ -100,6 +101,7 @@ def lib():
     L.ptmo_pt_free.argtypes = [C.POINTER(_PT)]
     L.ptmo_pt_enable_history.argtypes = [C.POINTER(_PT), C.c_int]
     L.ptmo_pt_evolve_temps.argtypes = [C.POINTER(_PT), C.c_double]
+    L.ptmo_pt_evolve_lpost_cut.argtypes = [C.POINTER(_PT), C.c_double]
     L.ptmo_chunk_prefix.restype = C.c_double
     L.ptmo_chunk_prefix.argtypes = [_dp, C.c_int, _dp]
     L.ptmo_pt_set_states.argtypes = [C.POINTER(_PT), C.POINTER(_Problem), _dp, _dp]
@@ -352,8 +354,9 @@ class Ladder:
     def lprior(self):
         return self._arr(self.s.contents.lprior, (self.N,), np.float64)
 
-    def evolve_temps(self, rate):
+    def evolve_temps(self, rate, lpost_cut=-1.0):
         lib().ptmo_pt_evolve_temps(self.s, float(rate))
+        lib().ptmo_pt_evolve_lpost_cut(self.s, float(lpost_cut))
 
     @property
     def betaw(self):

@@ -271,12 +271,20 @@ def test_add_every_n_history_counters():
                                                  (5, 7, 3, E.PROP_DENSE, 2, 0.45, 0.05),
                                                  (18, 8, 5, E.PROP_LOWER, 2, 0.45, 0.03),   # lanes kernel
                                                  (16, 40, 64, E.PROP_DIAG, 3, 0.3, 0.01),
-                                                 (4, 900, 64, E.PROP_DIAG, 2, 0.45, 0.01)])
+                                                 (4, 900, 64, E.PROP_DIAG, 2, 0.45, 0.01),
+                                                 # ... with a posterior-ordering cut: (rate, lpost_cut)
+                                                 (32, 8, 64, E.PROP_LOWER, 1, 0.45, (0.03, 0.5)),
+                                                 (5, 7, 3, E.PROP_DENSE, 2, 0.45, (0.05, 0.0)),
+                                                 (18, 8, 5, E.PROP_LOWER, 2, 0.45, (0.03, 1.0)),
+                                                 (4, 900, 64, E.PROP_DIAG, 2, 0.45, (0.01, 0.0))])
 def test_history_rows_match_the_oracle(D, Nt, W, kind, N, sr, ev):
     """What MH_chain::add_state pushes every add_every_N-th call (chain.cc:935-946): state, llike, lprior, Naccept,
     Ntries, last_type -- including the rows a rung holds BETWEEN two exchanges of one step (quirk Q6)."""
     from ptmcmc_amd.problems import GaussianProblem
     steps, cap = (10 if Nt > 100 else 24), 64
+    cut = -1.0
+    if isinstance(ev, tuple):
+        ev, cut = ev
     pr = GaussianProblem(D, Nt, 1e3)
     eng = E.Engine(D, Nt, W, swap_rate=sr, add_every_n=N, history_rungs=Nt, history_capacity=cap, map_rungs=Nt)
     fac = pr.configure(eng, kind)
@@ -290,7 +298,7 @@ def test_history_rows_match_the_oracle(D, Nt, W, kind, N, sr, ev):
     lad.set_states(PU.to_oracle_order(x0, Nt, W))
     if ev:
         eng.step(2); lad.pt_step(2)          # (rows saved before the ladders evolve keep the common ladder's temperatures)
-        eng.set_evolve_temps(ev); lad.evolve_temps(ev)
+        eng.set_evolve_temps(ev, lpost_cut=cut); lad.evolve_temps(ev, cut)
         steps -= 2
     eng.step(steps); eng.sync()
     lad.pt_step(steps)
@@ -513,6 +521,37 @@ def test_evolving_ladders_match_the_oracle(D, Nt, W, kind, sr, rate):
     eng.close()
 
 
+@pytest.mark.parametrize("D,Nt,W,kind,sr,rate,cut", [(4, 8, 3, E.PROP_DENSE, 0.3, 0.05, 0.0), (32, 40, 64, E.PROP_LOWER, 0.45, 0.01, 2.0),
+                                                     (3, 7, 5, E.PROP_DIAG, 0.45, 0.02, 0.0), (20, 9, 3, E.PROP_DENSE, 0.3, 0.05, 1.0),
+                                                     (2, 300, 2, E.PROP_DIAG, 0.3, 0.01, 0.0), (6, 1100, 1, E.PROP_DIAG, 0.1, 0.01, 3.0)])
+def test_evolving_ladders_with_a_posterior_ordering_cut_match_the_oracle(D, Nt, W, kind, sr, rate, cut):
+    """evolve_temps(rate, lpost_cut >= 0) (chain.hh:302-307; pry_temps chain.cc:1809-1846): every pry ALSO widens each gap whose
+    two chains' current log-posteriors are out of order by more than cut * invtemp (:1819-1827) -- any gap of the ladder, so
+    the exchange kernel decides the picks one after the other and goes over all the gaps after every accepted exchange.
+    States, counters, decisions and temperatures are bit-identical to the oracle, which tests/test_oracle_golden.py pins
+    against the real reference with a cut (traces 11, 12); test_history_rows_match_the_oracle has the saved rows' temperatures."""
+    pr, eng, lad = PU.make_pair(D, Nt, W, 1e3, kind=kind, swap_rate=sr)
+    eng.set_evolve_temps(rate, lpost_cut=cut)
+    lad.evolve_temps(rate, cut)
+    nsteps = 3 if Nt >= 300 else 8
+    for k in range(3):
+        eng.step(nsteps); eng.sync(); lad.pt_step(nsteps)
+        PU.assert_same_state(eng, lad, "after %d steps" % (nsteps * (k + 1)))
+        be, bo = eng.invtemps(), lad.betaw
+        assert np.array_equal(be, bo), (np.abs(be - bo).max(), np.argwhere(be != bo)[:4].tolist())
+        assert np.array_equal(eng.lpost, PU.to_engine_order(lad.lpost, Nt, W))
+    t, a = eng.swap_counts()
+    assert np.array_equal(a, np.asarray(lad._arr(lad.s.contents.swap_accept_count, (W, max(Nt - 1, 1)), np.int64))) and a.sum() > 0
+    be = eng.invtemps()
+    assert (be[:, 0] == pr.beta[0]).all() and (be[:, -1] == pr.beta[-1]).all() and (np.diff(be, axis=1) < 0).all()
+    # the cut did something: without it the same run ends on other ladders
+    pr2, eng2, lad2 = PU.make_pair(D, Nt, W, 1e3, kind=kind, swap_rate=sr)
+    eng2.set_evolve_temps(rate)
+    eng2.step(3 * nsteps); eng2.sync()
+    assert not np.array_equal(eng2.invtemps(), be)
+    eng.close(); eng2.close()
+
+
 def test_evolving_ladders_checkpoint_resume_and_refusals():
     """checkpoint / resume of an evolving run carries the ladders (ptm_get_invtemps / ptm_set_invtemps); the combinations
     that are not built are refused loudly."""
@@ -539,8 +578,6 @@ def test_evolving_ladders_checkpoint_resume_and_refusals():
     a.close(); b.close()
     d = E.Engine(D, Nt, W, swap_rate=0.4)
     pr.configure(d, E.PROP_DENSE)
-    with pytest.raises(E.PtmError):
-        d.set_evolve_temps(0.01, lpost_cut=0.5)
     with pytest.raises(E.PtmError):
         d.set_invtemps(np.tile(pr.beta, (W, 1)))   # only once the ladders evolve
     d.close()

@@ -163,7 +163,7 @@ def test_reference_exampleLISA_golden_rows():
         assert abs(lp - (r["lpost"] - r["llike"])) < 5e-7
 
 
-@pytest.mark.parametrize("tid", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
+@pytest.mark.parametrize("tid", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12])
 def test_reference_pt_trace(tid):
     """Replay a real parallel_tempering_chains run: same initial states, same uniforms (recorded tapes of the
     reference's MotherOfAll generators), same scripted proposal offsets => the restatement must hold the same
@@ -189,7 +189,9 @@ def test_reference_pt_trace(tid):
     if evolve:
         # traces 5, 6: evolve_temps(rate) -- pry_temps after every accepted exchange (chain.cc:1501-1518,1809-1846).  The
         # restatement keeps the gaps lazily normalised, so temperatures agree to rounding, not to the bit.
-        lad.evolve_temps(g["evolve_rate"])
+        # traces 11, 12: with evolve_temp_lpost_cut >= 0 every pry also widens the gaps whose chains' posteriors are out of
+        # order by more than cut * invtemp (chain.cc:1819-1827)
+        lad.evolve_temps(g["evolve_rate"], g.get("evolve_lpost_cut", -1.0))
     for r, c in enumerate(g["init"]):
         assert close(lad.llike[r], c["llike"]) and close(lad.lpost[r], c["lpost"])
     nswapped = 0
