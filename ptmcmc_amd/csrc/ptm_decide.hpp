@@ -99,7 +99,7 @@ typedef double d2_t __attribute__((ext_vector_type(2)));  // (HIP's double2 stru
 // 64 for a short shard of many ladders, where the per-block fixed costs are what counts.
 // The body is a device function of the block's DECIDE_THREADS threads working for ladder (walker) w on `smem`: decide_kernel
 // below is its plain launch; the fused small-ladder kernel (ptm_fused_kernel.hpp) calls it once per step from inside its loop.
-template <int DECIDE_THREADS>
+template <int DECIDE_THREADS, bool CUT = false>   // CUT: the build that knows evolve_temps' posterior-ordering cut (the others carry none of it)
 __device__ __forceinline__ void decide_body(const Decide& p, unsigned char* smem, const int w) {
   const int lane = threadIdx.x;
   const int Nt = p.Nt, ms = p.ms;
@@ -172,7 +172,7 @@ __device__ __forceinline__ void decide_body(const Decide& p, unsigned char* smem
   }
   const bool evolve = p.evolve_rate > 0 && Nt > 1;
   const bool evb = evolve && p.beta_add != nullptr;   // history / MAP tracking of evolving ladders
-  const bool cutmode = evolve && p.evolve_cut >= 0;   // ... with a posterior-ordering cut
+  const bool cutmode = CUT && evolve && p.evolve_cut >= 0;   // ... with a posterior-ordering cut
   if (evolve) {
     const double* bw = p.beta_w + (size_t)w * Nt;
     for (int k = lane; k < Nt - 1; k += DECIDE_THREADS) gap[k] = bw[k] - bw[k + 1];   // chain.cc:1816
@@ -714,36 +714,33 @@ __device__ __forceinline__ void decide_body(const Decide& p, unsigned char* smem
       if (!head) continue;
       double* X = p.x;
       const int c0 = (r - p.r0) * p.W + w;
-      double tmp[130];                                     // the head's old row {x[0..DP), llike, lprior}, DP <= 128
-      for (int d = 0; d < DP; ++d) tmp[d] = X[(size_t)c0 * DP + d];
-      tmp[DP] = p.ll[c0];
-      tmp[DP + 1] = p.lp[c0];
       if (departs) {
         double* sb = (to >= r1) ? p.send_up : p.send_down;
         if (!sb) continue;
         double* row = claim_row(sb, p.row_cap, DP + ROW_EXTRA, p.err);
         if (row) {
-          for (int d = 0; d < DP + 2; ++d) row[d] = tmp[d];
+          for (int d = 0; d < DP; ++d) row[d] = X[(size_t)c0 * DP + d];
+          row[DP] = p.ll[c0];
+          row[DP + 1] = p.lp[c0];
           row[DP + 2] = (double)w;
           row[DP + 3] = 0.0;
         }
       }
-      int cur = r;
-      for (int guard = 0; guard <= Nt; ++guard) {
-        const int src = perm[cur];
-        const int cc = (cur - p.r0) * p.W + w;
-        if (src == r) {
-          for (int d = 0; d < DP; ++d) X[(size_t)cc * DP + d] = tmp[d];
-          p.ll[cc] = tmp[DP];
-          p.lp[cc] = tmp[DP + 1];
-          break;
+      // one element of the row at a time (x[0..DP), llike, lprior), the head's old value carried in a register: no private
+      // array -- a row-sized one would cost EVERY launch of this kernel a kilobyte of scratch per lane
+      for (int el = 0; el < DP + 2; ++el) {
+        auto at = [&](int c) -> double* { return el < DP ? X + (size_t)c * DP + el : (el == DP ? p.ll + c : p.lp + c); };
+        const double carry = *at(c0);
+        int cur = r;
+        for (int guard = 0; guard <= Nt; ++guard) {
+          const int src = perm[cur];
+          const int cc = (cur - p.r0) * p.W + w;
+          if (src == r) { *at(cc) = carry; break; }
+          if (src < p.r0 || src >= r1) break;                // the hole (named above)
+          const int cs = (src - p.r0) * p.W + w;
+          *at(cc) = *at(cs);
+          cur = src;
         }
-        if (src < p.r0 || src >= r1) break;                // the hole (named above)
-        const int cs = (src - p.r0) * p.W + w;
-        for (int d = 0; d < DP; ++d) X[(size_t)cc * DP + d] = X[(size_t)cs * DP + d];
-        p.ll[cc] = p.ll[cs];
-        p.lp[cc] = p.lp[cs];
-        cur = src;
       }
     }
   }
@@ -751,13 +748,13 @@ __device__ __forceinline__ void decide_body(const Decide& p, unsigned char* smem
 #undef PTM_ALIVE_RUNG
 }
 
-template <int DECIDE_THREADS>
+template <int DECIDE_THREADS, bool CUT = false>
 __global__ __launch_bounds__(DECIDE_THREADS) void decide_kernel(const Decide p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // walker of this block.  Consecutive workgroups go round the 8 XCDs, each with its own L2, while ll / lp / touch are
   // [rung][walker]: a 128-byte line holds 16 (128 for touch) neighbouring walkers.  Handing each XCD a contiguous range of
   // walkers keeps the ladders that share those lines on one L2.
-  decide_body<DECIDE_THREADS>(p, smem, xcd_walker(blockIdx.x, p.W));
+  decide_body<DECIDE_THREADS, CUT>(p, smem, xcd_walker(blockIdx.x, p.W));
 }
 
 // dynamic LDS of decide_body (host side)

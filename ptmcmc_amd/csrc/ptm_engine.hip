@@ -992,7 +992,10 @@ static int launch_decide(ptm_engine* e, const double* ll_below, const double* ll
   // the boundary messages start empty (the row count lives in their first word)
   if (send_up) HIPCHK(hipMemsetAsync(send_up, 0, 16, e->stream));
   if (send_down) HIPCHK(hipMemsetAsync(send_down, 0, 16, e->stream));
-  if (wide) hipLaunchKernelGGL(decide_kernel<256>, dim3(e->W), dim3(256), lds, e->stream, p);
+  if (cut) {   // (always the wide form)
+    if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void*)decide_kernel<256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((decide_kernel<256, true>), dim3(e->W), dim3(256), lds, e->stream, p);
+  } else if (wide) hipLaunchKernelGGL(decide_kernel<256>, dim3(e->W), dim3(256), lds, e->stream, p);
   else hipLaunchKernelGGL(decide_kernel<64>, dim3(e->W), dim3(64), lds, e->stream, p);
   HIPCHK(hipGetLastError());
   e->log_head = (e->log_head + 1) % PTM_LOG_RING;

@@ -81,7 +81,8 @@ def load():
     L.ptm_set_prior.argtypes = [C.c_void_p, _i32p, _dp, _dp]
     L.ptm_set_target_gaussian.argtypes = [C.c_void_p, _dp, _dp, C.c_double]
     L.ptm_set_target_callback.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
-    L.ptm_set_prior_callback.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    if hasattr(L, "ptm_set_prior_callback"):   # (absent from older builds handed over through PTM_ENGINE_LIB for A/B timing)
+        L.ptm_set_prior_callback.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.ptm_set_ladder.argtypes = [C.c_void_p, _dp]
     L.ptm_set_evolve_temps.argtypes = [C.c_void_p, C.c_double, C.c_double]
     L.ptm_get_invtemps.argtypes = [C.c_void_p, _dp]
