@@ -258,6 +258,45 @@ class WalkerShardedLadders:
 # ----------------------------------------------------------------------------------------------------------------------
 # bench.py --gpus N  (launched by torch.distributed.run, one rank per GPU)
 # ----------------------------------------------------------------------------------------------------------------------
+def preflight_neighbour_messages(dist, torch, rank, world, device, stream=None, sabotage=False, wait_s=60.0):
+    """The step's message pattern once, with stamped records: the very calls of ShardedLadder._exchange (a batch of
+    isend / irecv to both neighbours), on `stream` when given.  Returns 0 if every record arrived from the right rank, else 1
+    (an exception included; a record that has not arrived after `wait_s` seconds is one).  `sabotage` makes this rank fail on
+    purpose before it sends anything (tests): its neighbours then time out instead of waiting for ever."""
+    import datetime
+    bad = 0
+    try:
+        if sabotage:
+            raise RuntimeError("sabotaged on purpose")
+        ctx = torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()
+        with ctx:
+            up = rank + 1 if rank + 1 < world else None
+            down = rank - 1 if rank > 0 else None
+            for it in range(3):
+                mine = torch.full((256,), float(1000 * it + rank), dtype=torch.float64, device=device)
+                got_up = torch.zeros(256, dtype=torch.float64, device=device)
+                got_down = torch.zeros(256, dtype=torch.float64, device=device)
+                ops = []
+                for send, recv, peer in ((mine, got_up, up), (mine, got_down, down)):
+                    if peer is None:
+                        continue
+                    ops.append(dist.P2POp(dist.isend, send, peer))
+                    ops.append(dist.P2POp(dist.irecv, recv, peer))
+                if ops:
+                    for r in dist.batch_isend_irecv(ops):
+                        r.wait(timeout=datetime.timedelta(seconds=wait_s))
+                if stream is not None:
+                    stream.synchronize()
+                if up is not None and float(got_up[0]) != 1000 * it + up:
+                    bad = 1
+                if down is not None and float(got_down[255]) != 1000 * it + down:
+                    bad = 1
+    except Exception as ex:   # noqa: BLE001
+        sys.stderr.write("[rank %d] pre-flight of the neighbour messages failed: %s: %s\n" % (rank, type(ex).__name__, ex))
+        bad = 1
+    return bad
+
+
 def bench_main(args):
     import json
     import torch
@@ -271,7 +310,8 @@ def bench_main(args):
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    dist.init_process_group("nccl", device_id=dev)
+    import datetime
+    dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(seconds=300))   # (a message that never arrives ends the run, not the node's patience)
     D, NT = B.D, B.NT
     W = args.walkers * world            # weak scaling: chains per GPU stay 1024 * walkers
     r0, nloc = shard_bounds(NT, world, rank)
@@ -280,6 +320,20 @@ def bench_main(args):
     # (EngineShard.stream_context): kernel -> send / receive -> kernel is then the order of one stream by construction
     stream = torch.cuda.Stream(device=dev)
     by_walkers = getattr(args, "shard", "rungs") == "walkers"
+    fallback = ""
+    if not by_walkers and world > 1 and not getattr(args, "native_rccl", False):
+        # pre-flight of the step's message pattern (the very calls of ShardedLadder._exchange, on the engine's stream): every
+        # rank sends a stamped record to both neighbours and checks what it receives.  If torch.distributed cannot do that here
+        # every rank learns it through one all-reduce and the run continues with the population split by WALKERS (whole ladders
+        # per GPU, no message in a step) -- said in config.sharding and on stderr -- instead of dying inside the timed region.
+        bad = preflight_neighbour_messages(dist, torch, rank, world, dev, stream)
+        flag = torch.tensor([bad], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if int(flag.item()):
+            fallback = "FALLBACK (the pre-flight of the neighbour messages failed on some rank): "
+            by_walkers = True
+            if rank == 0:
+                sys.stderr.write("[bench] rung sharding is not available here; the population is split by walkers instead\n")
     try:
         if by_walkers:
             # whole ladders per GPU: rank r holds walkers [r * walkers, (r + 1) * walkers) of the population; no message in a step
@@ -348,7 +402,7 @@ def bench_main(args):
             "config": {"workload": "D=32 correlated Gaussian, 1024-rung ladder (Tmax=1e9, swap_rate=0.1) x %d walkers; "
                                    "per-rung Cholesky proposal factors; uniform box prior" % W,
                        "dim": D, "rungs": NT, "walkers": W, "chains": nchains,
-                       "sharding": ("%d blocks of %d whole ladders (walkers), no message in a step" % (world, args.walkers)) if by_walkers else
+                       "sharding": (fallback + "%d blocks of %d whole ladders (walkers), no message in a step" % (world, args.walkers)) if by_walkers else
                                    ("%d contiguous rung blocks of %d rungs; llike halo %d rungs; neighbour p2p over RCCL (%s)"
                                     % (world, nloc, args.halo, "ptm_shard_*: native ncclSend/ncclRecv" if getattr(args, "native_rccl", False) else "torch.distributed"))},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": B.HBM_PEAK_GBS, "unit": "GB/s",

@@ -61,3 +61,22 @@ def test_shard_bounds_cover_the_ladder():
             assert blocks[0][0] == 0 and sum(n for _, n in blocks) == nt
             for (a, n), (b, _) in zip(blocks, blocks[1:]):
                 assert a + n == b
+
+
+@pytest.mark.parametrize("world,sabotage", [(3, -1), (3, -2), (2, -1)])
+def test_bench_preflight_of_the_neighbour_messages(world, sabotage):
+    """bench.py --gpus N checks the step's message pattern before its timed region (stamped records to both neighbours through
+    the calls ShardedLadder._exchange makes) and all ranks agree on the verdict through one all-reduce; if the calls fail
+    (every rank alike: the failure such a check can survive -- a rank that dies alone takes the process group with it, and the
+    run ends on the group's timeout) the bench goes on with the walker split.  Here over gloo: a clean ring agrees on 0,
+    ranks that all fail before sending (sabotage -2) agree on 1."""
+    port = free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "preflight_worker.py"), str(sabotage)], env=env, stdout=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    want = 1 if sabotage == -2 else 0
+    for r, o in enumerate(outs):
+        assert "rank %d bad %d agreed %d" % (r, want, want) in o, outs
