@@ -1705,7 +1705,8 @@ extern "C" const char* ptm_sweep_kernel_name(ptm_engine* e) {
   if (!e) return "";
   char b[96];
   const SweepSel s = sweep_sel(e);
-  if (e->DP == 32 && s.uni && !s.callback && !s.host_prop) {
+  const char* fv = getenv("PTM_FORCE_VALU");
+  if (e->DP == 32 && s.uni && !s.callback && !s.host_prop && !(fv && *fv && *fv != '0')) {
     const char* cv = getenv("PTM_COMPACT");
     const bool g1 = !s.simple && e->all_uniform && (!e->has_bounds || e->bounds_box);
     const bool cpt = !(cv && *cv == '0') && (s.simple || g1) && !e->hist.rungs && !e->map.rungs && e->W >= 1024 && e->nloc <= 4096;   // (in PT steps; plain sweeps visit every chain)

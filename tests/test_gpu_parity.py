@@ -1135,3 +1135,22 @@ def test_compacted_sweep_in_sharded_engines(overlap):
         assert np.array_equal(np.concatenate([getattr(e, name) for e in shards]), getattr(ref, name)), name
     for e in shards + [ref]:
         e.close()
+
+
+@pytest.mark.parametrize("env,D,Nt,W,kind,want", [({"PTM_LEAN_PIPE": "1"}, 32, 6, 1024, "lower", "sweep_mfma32_lean_kernel<2, true>"),
+                                                 ({"PTM_LEAN_PIPE": "1"}, 24, 5, 128, "dense", "sweep_mfma32_lean_kernel<0, false>"),
+                                                 ({"PTM_COMPACT": "0"}, 32, 6, 1024, "lower", "sweep_mfma32_kernel<2, false, 0, false, false>"),
+                                                 ({"PTM_FORCE_VALU": "1"}, 32, 5, 64, "lower", "sweep_kernel<32"),
+                                                 ({"PTM_FUSED": "0"}, 6, 12, 3, "dense", "sweep_lanes_kernel<8")])
+def test_switched_off_variants_stay_bit_exact(env, D, Nt, W, kind, want):
+    """The engine's environment switches select code that the default run never reaches: the software-pipelined lean kernel
+    (a measured, switched-off experiment: DESIGN.md section 3.1), the un-compacted sweep of a big population, the general VALU
+    kernel on the MFMA workload, the two-launch step of small ladders.  Each in a process of its own (the switches are read
+    once), each bit for bit the oracle's chains."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, os.path.join(here, "variant_worker.py"), str(D), str(Nt), str(W), kind, "4", want],
+                       env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.startswith("ok "), r.stdout[-2000:] + r.stderr[-3000:]

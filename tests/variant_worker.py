@@ -1,0 +1,24 @@
+"""Runs one small bit-exact comparison of the engine against the CPU checker in a process of its own, so that an environment
+switch of the engine (read once per process: PTM_LEAN_PIPE, PTM_COMPACT, PTM_FORCE_VALU, PTM_FUSED ...) can be exercised by
+the test suite.  usage: python variant_worker.py D Nt W kind nsteps expected_kernel_substring"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import parity_util as PU
+from ptmcmc_amd import engine as E
+
+if __name__ == "__main__":
+    D, Nt, W = (int(v) for v in sys.argv[1:4])
+    kind = {"lower": E.PROP_LOWER, "dense": E.PROP_DENSE, "diag": E.PROP_DIAG}[sys.argv[4]]
+    nsteps, want = int(sys.argv[5]), sys.argv[6]
+    pr, eng, lad = PU.make_pair(D, Nt, W, 1e3, kind=kind, swap_rate=0.3)
+    assert want in eng.sweep_kernel_name, eng.sweep_kernel_name
+    for k in range(3):
+        eng.step(nsteps); eng.sync(); lad.pt_step(nsteps)
+        PU.assert_same_state(eng, lad, "after %d steps" % (nsteps * (k + 1)))
+    eng.sweep(2); eng.sync(); lad.sweep(2)
+    PU.assert_same_state(eng, lad, "after plain sweeps")
+    print("ok %s accepts %d" % (eng.sweep_kernel_name, int(eng.naccept.sum() - eng.Nc)))
+    eng.close()
