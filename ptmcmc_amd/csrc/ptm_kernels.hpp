@@ -208,8 +208,13 @@ __device__ __forceinline__ double prior_pdf(int type, double lo, double hi, doub
 // stateSpace::enforce (states.cc:86-102) + sampleable_probability_function::evaluate_log (probability_function.hh:59).
 // Runs over the true dimensions only (pad dimensions are open/flat by construction); not unrolled: this is the
 // general path, the lean kernels (SIMPLE) never reach it.
+#ifndef PTM_ENFORCE_INLINE_MAX
+#define PTM_ENFORCE_INLINE_MAX 32   // padded dimensions up to which enforce_and_lprior is inlined: a call keeps the state array and the parameter block in scratch -- 0.6-1.1 KB per lane that every launch of a general kernel paid for, and twice the registers (DP = 8: 130 -> 76 VGPRs)
+#endif
 template <int DP>
-__device__ __noinline__ double enforce_and_lprior(const Dev& p, double (&x)[DP], bool& valid) {
+__device__ __attribute__((noinline)) double enforce_and_lprior_call(const Dev& p, double (&x)[DP], bool& valid);
+template <int DP>
+__device__ __forceinline__ double enforce_and_lprior_body(const Dev& p, double (&x)[DP], bool& valid) {
   cip blo = as_c(p.blo), bhi = as_c(p.bhi), pt = as_c(p.ptype);
   cdp bmin = as_c(p.bmin), bmax = as_c(p.bmax), plo = as_c(p.plo), phi = as_c(p.phi), pco = as_c(p.pcoef);
   if (valid && p.has_bounds) {
@@ -232,6 +237,13 @@ __device__ __noinline__ double enforce_and_lprior(const Dev& p, double (&x)[DP],
     if (d < p.D) pq[d & 3] *= prior_pdf(pt[d], plo[d], phi[d], pco[d], x[d]);
   const double result = ((pq[0] * pq[1]) * pq[2]) * pq[3];
   return dlog(result);
+}
+template <int DP>
+__device__ __attribute__((noinline)) double enforce_and_lprior_call(const Dev& p, double (&x)[DP], bool& valid) { return enforce_and_lprior_body<DP>(p, x, valid); }
+template <int DP>
+__device__ __forceinline__ double enforce_and_lprior(const Dev& p, double (&x)[DP], bool& valid) {
+  if constexpr (DP <= PTM_ENFORCE_INLINE_MAX) return enforce_and_lprior_body<DP>(p, x, valid);
+  else return enforce_and_lprior_call<DP>(p, x, valid);
 }
 
 // like0 - 1/2 y^T P y in the order shared by every path (and the CPU checker): s_i = P_ii y_i + sum_{j<i} 2P_ij y_j as
