@@ -100,7 +100,9 @@ typedef double d2_t __attribute__((ext_vector_type(2)));  // (HIP's double2 stru
 // The body is a device function of the block's DECIDE_THREADS threads working for ladder (walker) w on `smem`: decide_kernel
 // below is its plain launch; the fused small-ladder kernel (ptm_fused_kernel.hpp) calls it once per step from inside its loop.
 template <int DECIDE_THREADS, bool CUT = false>   // CUT: the build that knows evolve_temps' posterior-ordering cut (the others carry none of it)
-__device__ __forceinline__ void decide_body(const Decide& p, unsigned char* smem, const int w) {
+__device__ __forceinline__ void decide_body(const Decide& p, unsigned char* smem, const int w, const uint64_t step, int* const swap_log) {
+  // (step and swap_log are parameters of their own: a caller that walks several steps -- the fused small-ladder kernel -- must
+  //  not write into its copy of the parameter block, which would then live in vector registers)
   const int lane = threadIdx.x;
   const int Nt = p.Nt, ms = p.ms;
   const int NONE = 0x7fffffff;
@@ -161,7 +163,7 @@ __device__ __forceinline__ void decide_body(const Decide& p, unsigned char* smem
   __syncthreads();
   // -- candidate draws (chain.cc:1410-1416): block k of the ladder stream gives {u_try, u_pick, u_accept}
   for (int k = lane; k < ms; k += DECIDE_THREADS) {
-    const u32x4 o = draw_block(p.seed, TAG_PT, (uint32_t)(w + p.w_off), p.step, (uint32_t)k);
+    const u32x4 o = draw_block(p.seed, TAG_PT, (uint32_t)(w + p.w_off), step, (uint32_t)k);
     int n = -2;
     if (Nt > 1 && u01(o.v0) < p.thresh) n = (int)(u01(o.v1) * (Nt - 1));
     cand[k] = n;
@@ -486,7 +488,7 @@ __device__ __forceinline__ void decide_body(const Decide& p, unsigned char* smem
   // -- the step's log
 #if !(defined(PTM_DECIDE_ABLATE) && (PTM_DECIDE_ABLATE & 4))
   for (int k = lane; k < ms; k += DECIDE_THREADS)
-    p.swap_log[(size_t)w * ms + k] = alive[k] == 1 ? (cand[k] | (accf[k] ? 0x40000000 : 0)) : (alive[k] == 2 ? -3 : -2);
+    swap_log[(size_t)w * ms + k] = alive[k] == 1 ? (cand[k] | (accf[k] ? 0x40000000 : 0)) : (alive[k] == 2 ? -3 : -2);
 #endif
   // -- counters, the touch counts of the local rungs and the inverse permutation
   for (int j = lane; j < nl; j += DECIDE_THREADS) {
@@ -606,7 +608,8 @@ __device__ __forceinline__ void decide_body(const Decide& p, unsigned char* smem
     const bool act = 2 * sub < DPm;         // DP/2 lanes of 16 carry a row (16 B each)
     const int col = act ? 2 * sub : 0;      // idle lanes re-read column 0 (harmless) so that no load is predicated
     constexpr int GR = DECIDE_THREADS / 16;   // rows per round
-    d2_t v[16];
+    constexpr int NQ = (FCAP + GR - 1) / GR;  // rounds that can hold a listed row (16 for 64 and 256 threads, 4 for the fused kernel's 1024)
+    d2_t v[NQ];
     const int msrc = lane < nmv ? gs[lane] : 0;
     const int dme = lane < nmv ? gd[lane] : -3;
     // the row's scalars: a local destination's llike is already in LDS (the exchanged view of its rung), an all-uniform
@@ -616,14 +619,14 @@ __device__ __forceinline__ void decide_body(const Decide& p, unsigned char* smem
     for (int hc = 0; hc < DPm; hc += 32) {   // (rows of 64 dimensions: their second 256 bytes the same way)
       const int colh = col + hc;
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {
+      for (int q = 0; q < NQ; ++q) {
         const int j = GR * q + g;
         v[q] = *reinterpret_cast<const d2_t*>(p.x + (size_t)(j < nmv ? gs[j] : 0) * DPm + colh);   // past the list: row 0, never stored
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();   // every gather of every thread has landed before the first scatter
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {
+      for (int q = 0; q < NQ; ++q) {
         const int j = GR * q + g;
         const int d = j < nmv ? gd[j] : -3;
         if (d != -3 && act) {
@@ -754,7 +757,7 @@ __global__ __launch_bounds__(DECIDE_THREADS) void decide_kernel(const Decide p) 
   // walker of this block.  Consecutive workgroups go round the 8 XCDs, each with its own L2, while ll / lp / touch are
   // [rung][walker]: a 128-byte line holds 16 (128 for touch) neighbouring walkers.  Handing each XCD a contiguous range of
   // walkers keeps the ladders that share those lines on one L2.
-  decide_body<DECIDE_THREADS, CUT>(p, smem, xcd_walker(blockIdx.x, p.W));
+  decide_body<DECIDE_THREADS, CUT>(p, smem, xcd_walker(blockIdx.x, p.W), p.step, p.swap_log);
 }
 
 // dynamic LDS of decide_body (host side)

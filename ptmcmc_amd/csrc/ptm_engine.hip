@@ -1224,7 +1224,7 @@ extern "C" int ptm_sweep(ptm_engine* e, int n) {
 // two-launch path.  Returns the steps taken (0: not this engine's case), or a negative status.
 static int fused_steps(ptm_engine* e, int n) {
   static const bool fused_ok = [] { const char* v = getenv("PTM_FUSED"); return !(v && *v == '0'); }();
-  if (!fused_ok || e->DP > 16 || (long long)e->Nt * e->DP > 1024 || e->cb || e->pcb || e->cfg.time_kernels) return 0;
+  if (!fused_ok || e->DP > 16 || (long long)e->Nt * e->DP > 256 || e->cb || e->pcb || e->cfg.time_kernels) return 0;
   if (e->evolve_rate > 0 && (e->W > 64 || e->evolve_cut >= 0)) return 0;   // (the new temperatures' chain-indexed image is then a separate launch)
   const bool evb = e->evolve_rate > 0 && e->beta_add;
   const size_t dlds = decide_lds_bytes(e->Nt, e->ms, e->Nt, e->evolve_rate > 0, evb);

@@ -37,7 +37,8 @@ __device__ __forceinline__ void lanes_stage(const Dev& p, double* lds_all) {
 // chains; the k-th chain of the launch is chain cbase + k * cstride (k < nslots).  The plain launch walks a contiguous range
 // (cbase = c_begin, cstride = 1); the fused small-ladder kernel walks ONE walker's rungs (cbase = walker, cstride = W).
 template <int DP, int KIND, bool GEN>
-__device__ __forceinline__ void lanes_body(const Dev& p, double* lds_all, const int wslot0, const int cbase, const int cstride, const int nslots) {
+__device__ __forceinline__ void lanes_body(const Dev& p, double* lds_all, const int wslot0, const int cbase, const int cstride, const int nslots,
+                                           const uint64_t step) {   // (the step: a parameter of its own, see decide_body)
   static_assert(DP == 4 || DP == 8 || DP == 16 || DP == 32 || DP == 64 || DP == 128, "lanes kernel: DP 4 .. 128");
   constexpr int E = DP > 64 ? DP / 64 : 1;  // dimensions per lane: lane's d, d + 64, ...
   constexpr int LPC = DP / E;               // lanes per chain
@@ -104,7 +105,7 @@ __device__ __forceinline__ void lanes_body(const Dev& p, double* lds_all, const 
 
   // ---- MH_chain::step (chain.cc:966-1022); touched chains run along (their lanes would idle anyway) and write nothing
   const uint32_t stream = (uint32_t)(w + p.w_off) * (uint32_t)p.Nt + (uint32_t)rg;
-  const u32x4 o0 = draw_block(p.seed, TAG_MH, stream, p.step, 0);
+  const u32x4 o0 = draw_block(p.seed, TAG_MH, stream, step, 0);
   int type = 0, axis = -1, kmix = 0;
   double mix_scale = 1.0;
   if (GEN && !hp) {
@@ -127,7 +128,7 @@ __device__ __forceinline__ void lanes_body(const Dev& p, double* lds_all, const 
     const int de = d + 64 * e;
     zd[e] = 0.0;
     if (!hp) {
-      const u32x4 o = draw_block(p.seed, TAG_MH, stream, p.step, (uint32_t)((de >> 2) + 1));
+      const u32x4 o = draw_block(p.seed, TAG_MH, stream, step, (uint32_t)((de >> 2) + 1));
       const bool hi = (de & 2) != 0;
       double z0, z1;
       boxmuller(hi ? o.v2 : o.v0, hi ? o.v3 : o.v1, lds_all, z0, z1);
@@ -363,7 +364,7 @@ template <int DP, int KIND, bool GEN>
 __global__ __launch_bounds__(256) void sweep_lanes_kernel(const Dev p) {
   extern __shared__ __attribute__((aligned(16))) double lds_all[];
   lanes_stage<DP>(p, lds_all);
-  lanes_body<DP, KIND, GEN>(p, lds_all, blockIdx.x * 4, p.c_begin, 1, p.c_end - p.c_begin);
+  lanes_body<DP, KIND, GEN>(p, lds_all, blockIdx.x * 4, p.c_begin, 1, p.c_end - p.c_begin, p.step);
 }
 
 }  // namespace ptm
