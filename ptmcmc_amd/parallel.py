@@ -99,6 +99,13 @@ class EngineShard:
     def sync(self):
         self.e.sync()
 
+    def before_messages(self):
+        """Rehearsal over gloo only (PTM_BENCH_REHEARSAL=1, bench_main): gloo reads and writes device buffers from the host with
+        no regard for streams, so everything the engine has queued must have run before a message starts.  RCCL needs none of
+        this: its operations are ordered with the engine's stream (see __init__)."""
+        if os.environ.get("PTM_BENCH_REHEARSAL", "") == "1":
+            self.e.sync_stream() if hasattr(self.e, "sync_stream") else self.torch.cuda.synchronize()
+
 
 class ShardedLadder:
     """Drives one shard of a ladder that is spread over `world` ranks.  `backend` supplies the local compute
@@ -146,7 +153,13 @@ class ShardedLadder:
     def finish(self):
         self.b.finish_and_sweep(self.recv_below, self.recv_above)
 
+    def _before_messages(self):
+        f = getattr(self.b, "before_messages", None)
+        if f:
+            f()
+
     def _exchange(self, msgs):
+        self._before_messages()
         ops = []
         for send, recv, peer in msgs:
             if peer is None:
@@ -158,6 +171,7 @@ class ShardedLadder:
                 r.wait()
 
     def _start(self, msgs):
+        self._before_messages()
         ops = []
         for send, recv, peer in msgs:
             if peer is None:
@@ -308,10 +322,18 @@ def bench_main(args):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", str(args.gpus)))
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    # rehearsal on a box with ONE GPU (tests): every rank on device 0 and the messages over gloo, which takes device tensors --
+    # the ranks' engines, torch tensors and message pattern are the real ones, only the transport is not RCCL
+    rehearsal = os.environ.get("PTM_BENCH_REHEARSAL", "") == "1"
+    if rehearsal:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import datetime
-    dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(seconds=300))   # (a message that never arrives ends the run, not the node's patience)
+    if rehearsal:
+        dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=300))
+    else:
+        dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(seconds=300))   # (a message that never arrives ends the run, not the node's patience)
     D, NT = B.D, B.NT
     W = args.walkers * world            # weak scaling: chains per GPU stay 1024 * walkers
     r0, nloc = shard_bounds(NT, world, rank)

@@ -70,6 +70,44 @@ def test_1024_rungs_in_8_engine_shards_on_torch_streams(overlap):
     assert "OK" in out.stdout
 
 
+@pytest.mark.parametrize("world,D,Nt,W,halo,sr", [(2, 32, 16, 64, 4, 0.3), (3, 32, 48, 128, 8, 0.1), (4, 8, 24, 5, 4, 0.45)])
+def test_sharded_ladder_between_processes_on_the_gpu(world, D, Nt, W, halo, sr):
+    """The N > 1 path with real engines in separate PROCESSES: every rank an EngineShard on its own torch stream, the sharded
+    (overlapped) step of ShardedLadder, its messages between the processes -- over gloo on the one GPU this box has (RCCL refuses
+    two ranks on one device; tests/gpu_dist_worker.py says what differs).  The blocks put together are, bit for bit, the ladder
+    of one engine: states, llikes, counters, swap bookkeeping."""
+    import socket
+    import tempfile
+    from ptmcmc_amd.parallel import shard_bounds
+    s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]; s_.close()
+    nsteps = 25
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "rank%d.npz")
+        procs = []
+        for r in range(world):
+            env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+            procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "gpu_dist_worker.py"), str(D), str(Nt), str(W), str(nsteps),
+                                           str(halo), str(sr), out], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+        res = [p.communicate(timeout=600) for p in procs]
+        assert all(p.returncode == 0 for p in procs), [r[1][-1500:] for r in res]
+        parts = [np.load(out % r) for r in range(world)]
+    pr = GaussianProblem(D, Nt, 1e6)
+    ref = E.Engine(D, Nt, W, swap_rate=sr)
+    pr.configure(ref, E.PROP_LOWER)
+    ref.init_from_prior()
+    ref.step(nsteps); ref.sync()
+    assert np.array_equal(np.concatenate([p["x"] for p in parts]), ref.states())
+    assert np.array_equal(np.concatenate([p["ll"] for p in parts]), ref.llike)
+    assert np.array_equal(np.concatenate([p["nacc"] for p in parts]), ref.naccept)
+    assert np.array_equal(np.concatenate([p["nhist"] for p in parts]), ref.nhist)
+    t, a = ref.swap_counts()
+    assert np.array_equal(sum(p["st"] for p in parts), t) and np.array_equal(sum(p["sa"] for p in parts), a)
+    for g in range(world - 1):              # rows did cross every boundary
+        b = shard_bounds(Nt, world, g + 1)[0]
+        assert a[:, b - 1].sum() > 0, b
+    ref.close()
+
+
 def test_bench_distributed_path_with_one_rank():
     """bench.py --force-dist: init_process_group("nccl"), the engine on an explicit torch stream, EngineShard on torch
     tensors, the all_reduces of the record -- the N > 1 code path with world size 1"""
