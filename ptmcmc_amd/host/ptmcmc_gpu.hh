@@ -2078,6 +2078,16 @@ class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:
     if (host_mode) sync_history();
     if (tracking) replay_step();
   }
+  // n steps in ONE engine call when nothing on the host has to look in between (no host-side proposals, no exchange tracking):
+  // small ladders then run many steps per kernel launch (ptm_fused_kernel.hpp) instead of paying the launch and the tables'
+  // staging for every step.  Same chains as n calls of step().
+  void step_n(int n) {
+    if (n <= 0) return;
+    if (host_mode || tracking) { for (int k = 0; k < n; k++) step(); return; }
+    ptm_check(ptm_step(eng, n), "parallel_tempering_chains::step_n");
+    nstep += n;
+    fresh = hist_fresh = map_fresh = false;
+  }
   void step(int n) {
     if (tracking || host_mode) { for (int k = 0; k < n; k++) step(); return; }
     ptm_check(ptm_step(eng, n), "parallel_tempering_chains::step");
@@ -2752,7 +2762,12 @@ class ptmcmc_sampler : public bayes_sampler {
         checkpoint(".", istep);
         return 0;
       }
-      cc->step();
+      // up to the next step somebody looks at the chains: a report / dump (every `every` steps), the checkpoint, the end
+      int last = istep + (every - istep % every) % every;
+      if (last > chain_Nstep) last = chain_Nstep;
+      if (checkp_at_step > istep && checkp_at_step <= last) last = checkp_at_step - 1;
+      cc->step_n(last - istep + 1);
+      istep = last;
       bool stop = false;
       if (0 == istep % every) {
         std::cout << "chain " << ic << " step " << istep << std::endl;
