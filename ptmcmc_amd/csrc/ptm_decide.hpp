@@ -204,6 +204,9 @@ __device__ __forceinline__ void decide_body(const Decide& p, unsigned char* smem
   }
   __syncthreads();
   const int nl = cnt[0];
+#if defined(PTM_DECIDE_ABLATE) && (PTM_DECIDE_ABLATE & 16)   // timing experiment: draws + filter + compaction only
+  if (nl >= 0) return;
+#endif
   // -- working copy of the touched rungs (gather_llikes, chain.cc:1434); each touched rung is set up by exactly one
   //    lane: the pick whose lower rung it is, or -- for the top of a run -- the pick just below it
   for (int j = lane; j < nl; j += DECIDE_THREADS) {
@@ -485,6 +488,9 @@ __device__ __forceinline__ void decide_body(const Decide& p, unsigned char* smem
       }
     }
   }
+#if defined(PTM_DECIDE_ABLATE) && (PTM_DECIDE_ABLATE & 64)   // timing experiment: ... + llike gather + trials
+  if (nl >= 0) return;
+#endif
   // -- the step's log
 #if !(defined(PTM_DECIDE_ABLATE) && (PTM_DECIDE_ABLATE & 4))
   for (int k = lane; k < ms; k += DECIDE_THREADS)
