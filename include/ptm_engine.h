@@ -261,6 +261,14 @@ int ptm_get_array(ptm_engine* e, int which, void* out);
 int ptm_get_swap_counts(ptm_engine* e, int64_t* tries, int64_t* accepts);
 /* candidates of the most recent step: pairs[W][maxswaps] (lower rung or -2), accepted[W][maxswaps] */
 int ptm_get_last_swaps(ptm_engine* e, int32_t* pairs, int32_t* accepted);
+/* Several reads with one wait.  Every ptm_get_* call is an asynchronous copy on the engine's stream plus a wait; a host that
+ * reads several arrays after every step (the facade's history mirror for host-side proposals: chain.cc:935-946 rows, the
+ * swap log, the temperatures) brackets them: between ptm_batch_begin and ptm_batch_end the ptm_get_* calls only queue
+ * their copies (each sees the engine as it is at the time of ITS call) and return at once; the output buffers are filled
+ * when ptm_batch_end returns (possibly earlier).  Brackets nest.  No counterpart in the reference (its arrays are host
+ * memory); it exists because a wait on the device costs what ~10 small copies do. */
+int ptm_batch_begin(ptm_engine* e);
+int ptm_batch_end(ptm_engine* e);
 /* Checkpoint / resume.  Everything a run's future depends on is: the states and their llikes (ptm_get_states,
  * PTM_ARR_LLIKE), the MH_chain counters (PTM_ARR_NTRIES / NACCEPT / LAST_TYPE / NHIST), the step count (the random
  * streams are counters of it) and, for the bookkeeping, the swap counters.  ptm_restore puts them back into an engine

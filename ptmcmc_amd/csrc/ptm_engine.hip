@@ -11,6 +11,8 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <functional>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -46,7 +48,7 @@ struct PinnedAlloc {
   template <class U> PinnedAlloc(const PinnedAlloc<U>&) {}
   T* allocate(size_t n) {
     void* p = nullptr;
-    if (hipHostMalloc(&p, n * sizeof(T), hipHostMallocDefault) != hipSuccess) throw std::bad_alloc();
+    if (hipHostMalloc(&p, n * sizeof(T), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) throw std::bad_alloc();
     return (T*)p;
   }
   void deallocate(T* p, size_t) { (void)hipHostFree(p); }
@@ -116,6 +118,15 @@ struct ptm_engine {
   std::vector<int32_t> p_rung, p_walker, p_type, p_valid, p_acc;
   std::vector<size_t> p_pick;
   double *xprop = nullptr, *lprior_new = nullptr, *llike_new = nullptr;  // device buffers of the callback path
+  // reads of device arrays by the ptm_get_* calls: asynchronous copies into one pinned arena, finished by ONE wait (a
+  // synchronous hipMemcpy into pageable memory costs ~20 us whatever its size); between ptm_batch_begin and ptm_batch_end the
+  // calls only queue, and their output buffers are filled by ptm_batch_end
+  pinned_vector<unsigned char> fetch_arena;
+  size_t fetch_used = 0;
+  int fetch_depth = 0;
+  std::vector<std::function<void()>> fetch_after;
+  std::vector<std::shared_ptr<std::vector<unsigned char>>> fetch_big;
+  bool shared_handover = false;   // ... or, for a small population, the pinned host images themselves (mapped into the device)
   unsigned char* gate = nullptr;
   pinned_vector<double> h_xprop, h_llnew;
   std::vector<double> h_batch, h_llbatch;
@@ -141,6 +152,16 @@ static int dalloc(T** p, size_t n) {
   HIPCHK(hipMalloc((void**)p, (n ? n : 1) * sizeof(T)));
   return PTM_OK;
 }
+// a copy between a device buffer and its host image; nothing to do when the two are one (small populations keep the
+// hand-over buffers of the host paths in mapped host memory, alloc_proposal_buffers)
+static hipError_t copy_unless_shared(void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t s) {
+  if (dst == src) return hipSuccess;
+  return hipMemcpyAsync(dst, src, bytes, kind, s);
+}
+struct ptm_engine;
+static int fetch_flush(ptm_engine* e);
+static int fetch(ptm_engine* e, const void* dev, size_t bytes, const unsigned char** staged);
+static int fetch_done(ptm_engine* e);
 template <class T>
 static int upload(T* d, const T* h, size_t n, hipStream_t s) {
   HIPCHK(hipMemcpyAsync(d, h, n * sizeof(T), hipMemcpyHostToDevice, s));
@@ -293,10 +314,54 @@ static int build_engine(ptm_engine* e, const ptm_config* cfg) {
   return PTM_OK;
 }
 
+// ---- batched reads (see ptm_engine::fetch_arena) ------------------------------------------------------------------------
+static const size_t FETCH_ARENA = (size_t)4 << 20;
+static int fetch_flush(ptm_engine* e) {
+  HIPCHK(hipStreamSynchronize(e->stream));
+  for (auto& f : e->fetch_after) f();
+  e->fetch_after.clear(); e->fetch_big.clear(); e->fetch_used = 0;
+  return PTM_OK;
+}
+// queues the copy of `bytes` at device address `dev` (ordered on the engine's stream, so it sees the state at the time of the
+// call); *staged is where the bytes will be once fetch_flush has waited -- valid until that flush returns
+static int fetch(ptm_engine* e, const void* dev, size_t bytes, const unsigned char** staged) {
+  if (e->fetch_arena.empty()) e->fetch_arena.resize(FETCH_ARENA);
+  const size_t need = (bytes + 63) & ~(size_t)63;
+  if (need > FETCH_ARENA / 2) {   // a big array: its own buffer, copied at once (bandwidth, not call latency, is its cost)
+    auto buf = std::make_shared<std::vector<unsigned char>>(bytes);
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipMemcpy(buf->data(), dev, bytes, hipMemcpyDeviceToHost));
+    e->fetch_big.push_back(buf);
+    *staged = buf->data();
+    return PTM_OK;
+  }
+  if (e->fetch_used + need > FETCH_ARENA) { int rc = fetch_flush(e); if (rc) return rc; }   // (outputs queued so far are filled early)
+  unsigned char* at = e->fetch_arena.data() + e->fetch_used;
+  HIPCHK(hipMemcpyAsync(at, dev, bytes, hipMemcpyDeviceToHost, e->stream));
+  e->fetch_used += need;
+  *staged = at;
+  return PTM_OK;
+}
+static int fetch_done(ptm_engine* e) { return e->fetch_depth > 0 ? PTM_OK : fetch_flush(e); }
+#define FETCH(ptr, dev, bytes) do { int _rc = fetch(e, (dev), (bytes), &(ptr)); if (_rc) return _rc; } while (0)
+
+extern "C" int ptm_batch_begin(ptm_engine* e) {
+  if (!e) return fail(PTM_ERR_INVALID, "null engine");
+  e->fetch_depth++;
+  return PTM_OK;
+}
+extern "C" int ptm_batch_end(ptm_engine* e) {
+  if (!e) return fail(PTM_ERR_INVALID, "null engine");
+  if (e->fetch_depth <= 0) return fail(PTM_ERR_INVALID, "ptm_batch_end without ptm_batch_begin");
+  if (--e->fetch_depth > 0) return PTM_OK;
+  return fetch_flush(e);
+}
+
 extern "C" int ptm_engine_destroy(ptm_engine* e) {
   if (!e) return PTM_OK;
   (void)ptm_shard_finalize(e);
   (void)hipStreamSynchronize(e->stream);
+  if (e->shared_handover) e->xprop = e->llike_new = nullptr, e->hastings = nullptr, e->htype = nullptr, e->hvalid = e->acc_out = nullptr;   // (these are the pinned vectors)
   void* ptrs[] = {e->x, e->ll, e->lp, e->ntries, e->naccept, e->last_type, e->arr_below, e->arr_above, e->mv_src, e->mv_dst, e->mv_n,
                   e->err, e->nhist, e->swap_cnt, e->touch, e->swap_log, e->hist.x, e->hist.ll, e->hist.lp, e->hist.meta, e->map.lpost, e->map.ll, e->map.lp, e->map.x, e->blo,
                   e->bhi, e->ptype, e->bmin, e->bmax, e->plo, e->phi, e->pcoef, e->P2, e->mean, e->beta, e->prop, e->prop_tiles, e->P2_tiles, e->box_row, e->onedfrac, e->mix, e->beta_w, e->betaC, e->beta_add, e->hist.beta, e->xprop, e->lprior_new, e->llike_new, e->hastings, e->htype, e->hvalid, e->acc_out, e->cidx, e->ccnt};
@@ -446,11 +511,20 @@ extern "C" int ptm_set_target_gaussian(ptm_engine* e, const double* mean, const 
 static int alloc_proposal_buffers(ptm_engine* e) {
   const size_t Nc = e->Nc, DP = e->DP;
   int rc;
-  if (!e->xprop && ((rc = dalloc(&e->xprop, Nc * DP + (Nc + 7) / 8)) || (rc = dalloc(&e->lprior_new, Nc)) || (rc = dalloc(&e->llike_new, Nc))))
-    return rc;
-  e->gate = reinterpret_cast<unsigned char*>(e->xprop + Nc * DP);
+  // A small population's step on the host paths is a chain of copies and waits, each ~5-10 us of runtime calls for a few
+  // kilobytes: there the kernels read and write the pinned host images directly (coherent mapped memory; a kernel's writes are
+  // on the host when its stream has drained, the host's are there for the next launch) and the copies fall away.
+  const char* zc = getenv("PTM_SHARED_HANDOVER");
+  if (!e->xprop) e->shared_handover = Nc * DP * 8 <= ((size_t)1 << 20) && !(zc && *zc == '0');
   e->h_xprop.resize(Nc * DP + (Nc + 7) / 8); e->h_llnew.assign(Nc, 0.0);
   e->h_gate = reinterpret_cast<unsigned char*>(e->h_xprop.data() + Nc * DP);
+  if (e->shared_handover) {
+    HIPCHK(hipHostGetDevicePointer((void**)&e->xprop, e->h_xprop.data(), 0));
+    HIPCHK(hipHostGetDevicePointer((void**)&e->llike_new, e->h_llnew.data(), 0));
+    if (!e->lprior_new && (rc = dalloc(&e->lprior_new, Nc))) return rc;
+  } else if (!e->xprop && ((rc = dalloc(&e->xprop, Nc * DP + (Nc + 7) / 8)) || (rc = dalloc(&e->lprior_new, Nc)) || (rc = dalloc(&e->llike_new, Nc))))
+    return rc;
+  e->gate = reinterpret_cast<unsigned char*>(e->xprop + Nc * DP);
   return PTM_OK;
 }
 
@@ -480,9 +554,14 @@ extern "C" int ptm_set_proposal_callback(ptm_engine* e, ptm_propose_batch_fn pro
   const size_t Nc = e->Nc, DP = e->DP;
   int rc = alloc_proposal_buffers(e);
   if (rc) return rc;
-  if (!e->hastings && ((rc = dalloc(&e->hastings, Nc)) || (rc = dalloc(&e->htype, Nc)) || (rc = dalloc(&e->hvalid, Nc)) || (rc = dalloc(&e->acc_out, Nc))))
-    return rc;
   e->h_rows.resize(Nc * DP); e->h_hast.assign(Nc, 0.0); e->h_type.assign(Nc, 0); e->h_valid.assign(Nc, 0); e->h_touch.assign(Nc, 0); e->h_acc.assign(Nc, 0);
+  if (e->shared_handover) {
+    HIPCHK(hipHostGetDevicePointer((void**)&e->hastings, e->h_hast.data(), 0));
+    HIPCHK(hipHostGetDevicePointer((void**)&e->htype, e->h_type.data(), 0));
+    HIPCHK(hipHostGetDevicePointer((void**)&e->hvalid, e->h_valid.data(), 0));
+    HIPCHK(hipHostGetDevicePointer((void**)&e->acc_out, e->h_acc.data(), 0));
+  } else if (!e->hastings && ((rc = dalloc(&e->hastings, Nc)) || (rc = dalloc(&e->htype, Nc)) || (rc = dalloc(&e->hvalid, Nc)) || (rc = dalloc(&e->acc_out, Nc))))
+    return rc;
   if (!e->onedfrac) return fail(PTM_ERR_INVALID, "engine not built");
   e->pcb = propose; e->pres = result; e->pcb_user = user;
   e->have_prop = 1;
@@ -578,11 +657,13 @@ extern "C" int ptm_get_invtemps(ptm_engine* e, double* beta) {
   if (!e || !beta) return fail(PTM_ERR_INVALID, "null argument");
   if (!e->have_ladder) return fail(PTM_ERR_INVALID, "no ladder set");
   if (e->beta_w) {
-    HIPCHK(hipStreamSynchronize(e->stream));
-    HIPCHK(hipMemcpy(beta, e->beta_w, (size_t)e->W * e->Nt * 8, hipMemcpyDeviceToHost));
-  } else {
-    for (int w = 0; w < e->W; ++w) std::copy(e->h_beta.begin(), e->h_beta.end(), beta + (size_t)w * e->Nt);
+    const size_t n = (size_t)e->W * e->Nt * 8;
+    const unsigned char* s;
+    FETCH(s, e->beta_w, n);
+    e->fetch_after.push_back([=] { memcpy(beta, s, n); });
+    return fetch_done(e);
   }
+  for (int w = 0; w < e->W; ++w) std::copy(e->h_beta.begin(), e->h_beta.end(), beta + (size_t)w * e->Nt);
   return PTM_OK;
 }
 
@@ -592,11 +673,12 @@ extern "C" int ptm_get_history_invtemps(ptm_engine* e, double* beta) {
   if (!e->have_ladder) return fail(PTM_ERR_INVALID, "no ladder set");
   const size_t n = (size_t)e->hist.cap * e->hist.HC;
   if (e->hist.beta) {
-    HIPCHK(hipStreamSynchronize(e->stream));
-    HIPCHK(hipMemcpy(beta, e->hist.beta, n * 8, hipMemcpyDeviceToHost));
-  } else {
-    for (size_t i = 0; i < n; ++i) beta[i] = e->h_beta[e->r0 + (int)(i % e->hist.HC) / e->W];
+    const unsigned char* s;
+    FETCH(s, e->hist.beta, n * 8);
+    e->fetch_after.push_back([=] { memcpy(beta, s, n * 8); });
+    return fetch_done(e);
   }
+  for (size_t i = 0; i < n; ++i) beta[i] = e->h_beta[e->r0 + (int)(i % e->hist.HC) / e->W];
   return PTM_OK;
 }
 
@@ -866,10 +948,10 @@ static int launch_sweep(ptm_engine* e, int rung0 = 0, int nr = -1, bool last = t
       for (size_t d = 0; d < D; ++d) e->h_xprop[c * DP + host_row_pos(DP, d)] = e->p_xprop[k * D + d];
       e->h_hast[c] = e->p_hast[k]; e->h_type[c] = e->p_type[k]; e->h_valid[c] = e->p_valid[k] ? 1 : 0;
     }
-    HIPCHK(hipMemcpyAsync(e->xprop, e->h_xprop.data(), Nc * DP * 8, hipMemcpyHostToDevice, e->stream));
-    HIPCHK(hipMemcpyAsync(e->hastings, e->h_hast.data(), Nc * 8, hipMemcpyHostToDevice, e->stream));
-    HIPCHK(hipMemcpyAsync(e->htype, e->h_type.data(), Nc * 4, hipMemcpyHostToDevice, e->stream));
-    HIPCHK(hipMemcpyAsync(e->hvalid, e->h_valid.data(), Nc, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(copy_unless_shared(e->xprop, e->h_xprop.data(), Nc * DP * 8, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(copy_unless_shared(e->hastings, e->h_hast.data(), Nc * 8, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(copy_unless_shared(e->htype, e->h_type.data(), Nc * 4, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(copy_unless_shared(e->hvalid, e->h_valid.data(), Nc, hipMemcpyHostToDevice, e->stream));
     p.xprop = e->xprop; p.lprior_new = e->lprior_new; p.gate = e->gate; p.llike_new = e->llike_new;
   }
   if (!e->cb) {
@@ -880,7 +962,7 @@ static int launch_sweep(ptm_engine* e, int rung0 = 0, int nr = -1, bool last = t
     p.xprop = e->xprop; p.lprior_new = e->lprior_new; p.gate = e->gate; p.llike_new = e->llike_new;
     p.mode = 1;
     HIPCHK(launch(p));   // (the propose pass writes every chain's gate byte: 0 for the rungs that make no move)
-    HIPCHK(hipMemcpyAsync(e->h_xprop.data(), e->xprop, Nc * DP * 8 + Nc, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(copy_unless_shared(e->h_xprop.data(), e->xprop, Nc * DP * 8 + Nc, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     if (e->prior_cb) {
       // host-evaluated prior: the valid proposals' log-priors, then the reference's prior gate on them -- want_like (chain.cc:980)
@@ -907,7 +989,7 @@ static int launch_sweep(ptm_engine* e, int rung0 = 0, int nr = -1, bool last = t
         e->h_gate[c] = (unsigned char)(1 | (want ? 2 : 0));
       }
       HIPCHK(hipMemcpyAsync(e->lprior_new, lpn.data(), Nc * 8, hipMemcpyHostToDevice, e->stream));
-      HIPCHK(hipMemcpyAsync(e->gate, e->h_gate, Nc, hipMemcpyHostToDevice, e->stream));
+      HIPCHK(copy_unless_shared(e->gate, e->h_gate, Nc, hipMemcpyHostToDevice, e->stream));
       HIPCHK(hipStreamSynchronize(e->stream));   // (lpn is a local)
     }
     std::vector<size_t> pick;
@@ -916,12 +998,12 @@ static int launch_sweep(ptm_engine* e, int rung0 = 0, int nr = -1, bool last = t
     int rc = call_user(e, e->h_xprop, pick, e->h_llbatch);
     if (rc) return rc;
     for (size_t k = 0; k < pick.size(); ++k) e->h_llnew[pick[k]] = e->h_llbatch[k];
-    HIPCHK(hipMemcpyAsync(e->llike_new, e->h_llnew.data(), Nc * 8, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(copy_unless_shared(e->llike_new, e->h_llnew.data(), Nc * 8, hipMemcpyHostToDevice, e->stream));
     p.mode = 2;
     HIPCHK(launch(p));
   }
   if (e->pcb && e->pres && npick) {   // proposal_distribution::accept() / reject() (chain.cc:1009,1015)
-    HIPCHK(hipMemcpyAsync(e->h_acc.data(), e->acc_out, (size_t)e->Nc, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(copy_unless_shared(e->h_acc.data(), e->acc_out, (size_t)e->Nc, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     e->p_acc.resize(npick);
     for (size_t k = 0; k < npick; ++k) e->p_acc[k] = e->h_acc[e->p_pick[k]] == 1 ? 1 : 0;
@@ -1107,10 +1189,11 @@ static std::vector<double> pad_rows(const double* X, size_t n, size_t D, size_t 
     for (size_t d = 0; d < D; ++d) r[c * DP + host_row_pos(DP, d)] = X[c * D + d];
   return r;
 }
-static void unpad_rows(const std::vector<double>& r, size_t n, size_t D, size_t DP, double* X) {
+static void unpad_rows(const double* r, size_t n, size_t D, size_t DP, double* X) {
   for (size_t c = 0; c < n; ++c)
     for (size_t d = 0; d < D; ++d) X[c * D + d] = r[c * DP + host_row_pos(DP, d)];
 }
+static void unpad_rows(const std::vector<double>& r, size_t n, size_t D, size_t DP, double* X) { unpad_rows(r.data(), n, D, DP, X); }
 
 extern "C" int ptm_set_states(ptm_engine* e, const double* X, const double* llike) {
   if (!e || !X) return fail(PTM_ERR_INVALID, "null argument");
@@ -1181,7 +1264,7 @@ extern "C" int ptm_init_from_prior_k(ptm_engine* e, int kdraw) {
     size_t left = Nc;
     for (long long a = 0; left && a < 100000; ++a) {
       if ((rc = launch_init(e, p, a, e->gate))) return rc;
-      HIPCHK(hipMemcpyAsync(e->h_gate, e->gate, Nc, hipMemcpyDeviceToHost, e->stream));
+      HIPCHK(copy_unless_shared(e->h_gate, e->gate, Nc, hipMemcpyDeviceToHost, e->stream));
       HIPCHK(hipMemcpyAsync(e->h_xprop.data(), e->x, Nc * DP * 8, hipMemcpyDeviceToHost, e->stream));
       HIPCHK(hipStreamSynchronize(e->stream));
       std::vector<size_t> pick;
@@ -1195,7 +1278,7 @@ extern "C" int ptm_init_from_prior_k(ptm_engine* e, int kdraw) {
         e->h_gate[pick[k]] = 2;
         left--;
       }
-      HIPCHK(hipMemcpyAsync(e->gate, e->h_gate, Nc, hipMemcpyHostToDevice, e->stream));
+      HIPCHK(copy_unless_shared(e->gate, e->h_gate, Nc, hipMemcpyHostToDevice, e->stream));
     }
     if (left) return fail(PTM_ERR_INVALID, "could not draw a valid start state from the prior for some chain");
     if ((rc = upload(e->ll, llh.data(), Nc, e->stream))) return rc;
@@ -1499,98 +1582,99 @@ extern "C" int ptm_shard_step(ptm_engine* e, int n) {
 extern "C" int ptm_get_states(ptm_engine* e, double* X) {
   if (!e || !X) return fail(PTM_ERR_INVALID, "null argument");
   const size_t Nc = e->Nc, D = e->D, DP = e->DP;
-  std::vector<double> rows(Nc * DP);
-  HIPCHK(hipStreamSynchronize(e->stream));
-  HIPCHK(hipMemcpy(rows.data(), e->x, Nc * DP * 8, hipMemcpyDeviceToHost));
-  unpad_rows(rows, Nc, D, DP, X);
-  return PTM_OK;
+  const unsigned char* s;
+  FETCH(s, e->x, Nc * DP * 8);
+  e->fetch_after.push_back([=] { unpad_rows((const double*)s, Nc, D, DP, X); });
+  return fetch_done(e);
 }
 
 extern "C" int ptm_get_array(ptm_engine* e, int which, void* out) {
   if (!e || !out) return fail(PTM_ERR_INVALID, "null argument");
   const size_t Nc = e->Nc;
-  HIPCHK(hipStreamSynchronize(e->stream));
+  const unsigned char* s;
   switch (which) {
-    case PTM_ARR_LLIKE: HIPCHK(hipMemcpy(out, e->ll, Nc * 8, hipMemcpyDeviceToHost)); break;
-    case PTM_ARR_LPRIOR: HIPCHK(hipMemcpy(out, e->lp, Nc * 8, hipMemcpyDeviceToHost)); break;
+    case PTM_ARR_LLIKE: FETCH(s, e->ll, Nc * 8); e->fetch_after.push_back([=] { memcpy(out, s, Nc * 8); }); break;
+    case PTM_ARR_LPRIOR: FETCH(s, e->lp, Nc * 8); e->fetch_after.push_back([=] { memcpy(out, s, Nc * 8); }); break;
     case PTM_ARR_LPOST: {
       if (!e->have_ladder) return fail(PTM_ERR_INVALID, "no ladder set");
-      std::vector<double> ll(Nc), lp(Nc);
-      HIPCHK(hipMemcpy(ll.data(), e->ll, Nc * 8, hipMemcpyDeviceToHost));
-      HIPCHK(hipMemcpy(lp.data(), e->lp, Nc * 8, hipMemcpyDeviceToHost));
-      double* o = (double*)out;
-      std::vector<double> bc;
-      if (e->betaC) { bc.resize(Nc); HIPCHK(hipMemcpy(bc.data(), e->betaC, Nc * 8, hipMemcpyDeviceToHost)); }
-      for (size_t c = 0; c < Nc; ++c) {
-        volatile double t = (e->betaC ? bc[c] : e->h_beta[e->r0 + c / e->W]) * ll[c];  // product rounded before the sum (chain.cc:928)
-        o[c] = lp[c] + t;
-      }
+      const unsigned char *sl, *sp, *sb = nullptr;
+      FETCH(sl, e->ll, Nc * 8);
+      FETCH(sp, e->lp, Nc * 8);
+      if (e->betaC) FETCH(sb, e->betaC, Nc * 8);
+      e->fetch_after.push_back([=] {
+        const double *ll = (const double*)sl, *lp = (const double*)sp, *bc = (const double*)sb;
+        double* o = (double*)out;
+        for (size_t c = 0; c < Nc; ++c) {
+          volatile double t = (bc ? bc[c] : e->h_beta[e->r0 + c / e->W]) * ll[c];  // product rounded before the sum (chain.cc:928)
+          o[c] = lp[c] + t;
+        }
+      });
       break;
     }
-    case PTM_ARR_NTRIES: HIPCHK(hipMemcpy(out, e->ntries, Nc * 4, hipMemcpyDeviceToHost)); break;
-    case PTM_ARR_NACCEPT: HIPCHK(hipMemcpy(out, e->naccept, Nc * 4, hipMemcpyDeviceToHost)); break;
-    case PTM_ARR_LAST_TYPE: HIPCHK(hipMemcpy(out, e->last_type, Nc * 4, hipMemcpyDeviceToHost)); break;
+    case PTM_ARR_NTRIES: FETCH(s, e->ntries, Nc * 4); e->fetch_after.push_back([=] { memcpy(out, s, Nc * 4); }); break;
+    case PTM_ARR_NACCEPT: FETCH(s, e->naccept, Nc * 4); e->fetch_after.push_back([=] { memcpy(out, s, Nc * 4); }); break;
+    case PTM_ARR_LAST_TYPE: FETCH(s, e->last_type, Nc * 4); e->fetch_after.push_back([=] { memcpy(out, s, Nc * 4); }); break;
     case PTM_ARR_NHIST:
     case PTM_ARR_NSIZE: {
       { int rc = flush_nhist(e); if (rc) return rc; }
-      HIPCHK(hipStreamSynchronize(e->stream));
-      std::vector<unsigned int> h(Nc);
-      HIPCHK(hipMemcpy(h.data(), e->nhist, Nc * 4, hipMemcpyDeviceToHost));
-      int64_t* o = (int64_t*)out;
+      FETCH(s, e->nhist, Nc * 4);
       const int64_t N = e->cfg.add_every_n;
       // add k (k = 0,1,..) appends a row iff k % N == 0 (chain.cc:935-946); one row exists after initialize(1)
-      for (size_t c = 0; c < Nc; ++c) o[c] = which == PTM_ARR_NHIST ? (int64_t)h[c] : 1 + ((int64_t)h[c] + N - 1) / N;
+      e->fetch_after.push_back([=] {
+        const unsigned int* h = (const unsigned int*)s;
+        int64_t* o = (int64_t*)out;
+        for (size_t c = 0; c < Nc; ++c) o[c] = which == PTM_ARR_NHIST ? (int64_t)h[c] : 1 + ((int64_t)h[c] + N - 1) / N;
+      });
       break;
     }
     default: return fail(PTM_ERR_INVALID, "unknown array id %d", which);
   }
-  return PTM_OK;
+  return fetch_done(e);
 }
 
 extern "C" int ptm_get_swap_counts(ptm_engine* e, int64_t* tries, int64_t* accepts) {
   if (!e) return fail(PTM_ERR_INVALID, "null engine");
   const size_t np = (size_t)e->W * (e->Nt > 1 ? e->Nt - 1 : 1);
-  HIPCHK(hipStreamSynchronize(e->stream));
   { int rc = fold_swap_log(e); if (rc) return rc; }
-  HIPCHK(hipStreamSynchronize(e->stream));
-  std::vector<long long> both(2 * np);
-  HIPCHK(hipMemcpy(both.data(), e->swap_cnt, 2 * np * 8, hipMemcpyDeviceToHost));
-  for (size_t i = 0; i < np; ++i) {
-    if (tries) tries[i] = both[2 * i];
-    if (accepts) accepts[i] = both[2 * i + 1];
-  }
-  return PTM_OK;
+  const unsigned char* s;
+  FETCH(s, e->swap_cnt, 2 * np * 8);
+  e->fetch_after.push_back([=] {
+    const long long* both = (const long long*)s;
+    for (size_t i = 0; i < np; ++i) {
+      if (tries) tries[i] = both[2 * i];
+      if (accepts) accepts[i] = both[2 * i + 1];
+    }
+  });
+  return fetch_done(e);
 }
 
 extern "C" int ptm_get_last_swaps(ptm_engine* e, int32_t* pairs, int32_t* accepted) {
   if (!e) return fail(PTM_ERR_INVALID, "null engine");
   const size_t n = (size_t)e->W * e->ms;
-  HIPCHK(hipStreamSynchronize(e->stream));
-  std::vector<int32_t> log(n);
   const int newest = (e->log_head + PTM_LOG_RING - 1) % PTM_LOG_RING;
-  HIPCHK(hipMemcpy(log.data(), e->swap_log + (size_t)newest * n, n * 4, hipMemcpyDeviceToHost));
-  for (size_t i = 0; i < n; ++i) {
-    const int32_t v = log[i];
-    if (pairs) pairs[i] = v < 0 ? (v == -3 ? -3 : -2) : (v & 0x3fffffff);
-    if (accepted) accepted[i] = (v >= 0 && (v & 0x40000000)) ? 1 : 0;
-  }
-  return PTM_OK;
+  const unsigned char* s;
+  FETCH(s, e->swap_log + (size_t)newest * n, n * 4);
+  e->fetch_after.push_back([=] {
+    const int32_t* log = (const int32_t*)s;
+    for (size_t i = 0; i < n; ++i) {
+      const int32_t v = log[i];
+      if (pairs) pairs[i] = v < 0 ? (v == -3 ? -3 : -2) : (v & 0x3fffffff);
+      if (accepted) accepted[i] = (v >= 0 && (v & 0x40000000)) ? 1 : 0;
+    }
+  });
+  return fetch_done(e);
 }
 
 extern "C" int ptm_get_map(ptm_engine* e, double* X, double* lpost, double* llike, double* lprior) {
   if (!e) return fail(PTM_ERR_INVALID, "null engine");
   if (!e->map.rungs) return fail(PTM_ERR_INVALID, "MAP tracking is off (ptm_config.map_rungs)");
   const size_t n = (size_t)e->map.MC, D = e->D, DP = e->DP;
-  HIPCHK(hipStreamSynchronize(e->stream));
-  if (X) {
-    std::vector<double> rows(n * DP);
-    HIPCHK(hipMemcpy(rows.data(), e->map.x, n * DP * 8, hipMemcpyDeviceToHost));
-    unpad_rows(rows, n, D, DP, X);
-  }
-  if (lpost) HIPCHK(hipMemcpy(lpost, e->map.lpost, n * 8, hipMemcpyDeviceToHost));
-  if (llike) HIPCHK(hipMemcpy(llike, e->map.ll, n * 8, hipMemcpyDeviceToHost));
-  if (lprior) HIPCHK(hipMemcpy(lprior, e->map.lp, n * 8, hipMemcpyDeviceToHost));
-  return PTM_OK;
+  const unsigned char* s;
+  if (X) { FETCH(s, e->map.x, n * DP * 8); e->fetch_after.push_back([=] { unpad_rows((const double*)s, n, D, DP, X); }); }
+  if (lpost) { FETCH(s, e->map.lpost, n * 8); e->fetch_after.push_back([=] { memcpy(lpost, s, n * 8); }); }
+  if (llike) { FETCH(s, e->map.ll, n * 8); e->fetch_after.push_back([=] { memcpy(llike, s, n * 8); }); }
+  if (lprior) { FETCH(s, e->map.lp, n * 8); e->fetch_after.push_back([=] { memcpy(lprior, s, n * 8); }); }
+  return fetch_done(e);
 }
 
 extern "C" int ptm_restore(ptm_engine* e, const double* X, const double* llike, const int32_t* ntries, const int32_t* naccept,
@@ -1660,16 +1744,12 @@ extern "C" int ptm_get_history(ptm_engine* e, double* X, double* llike, double* 
   if (!e) return fail(PTM_ERR_INVALID, "null engine");
   if (!e->hist.rungs) return fail(PTM_ERR_INVALID, "history is off (ptm_config.history_rungs)");
   const size_t n = (size_t)e->hist.cap * e->hist.HC, D = e->D, DP = e->DP;
-  HIPCHK(hipStreamSynchronize(e->stream));
-  if (X) {
-    std::vector<double> rows(n * DP);
-    HIPCHK(hipMemcpy(rows.data(), e->hist.x, n * DP * 8, hipMemcpyDeviceToHost));
-    unpad_rows(rows, n, D, DP, X);
-  }
-  if (llike) HIPCHK(hipMemcpy(llike, e->hist.ll, n * 8, hipMemcpyDeviceToHost));
-  if (lprior) HIPCHK(hipMemcpy(lprior, e->hist.lp, n * 8, hipMemcpyDeviceToHost));
-  if (meta) HIPCHK(hipMemcpy(meta, e->hist.meta, n * 16, hipMemcpyDeviceToHost));
-  return PTM_OK;
+  const unsigned char* s;
+  if (X) { FETCH(s, e->hist.x, n * DP * 8); e->fetch_after.push_back([=] { unpad_rows((const double*)s, n, D, DP, X); }); }
+  if (llike) { FETCH(s, e->hist.ll, n * 8); e->fetch_after.push_back([=] { memcpy(llike, s, n * 8); }); }
+  if (lprior) { FETCH(s, e->hist.lp, n * 8); e->fetch_after.push_back([=] { memcpy(lprior, s, n * 8); }); }
+  if (meta) { FETCH(s, e->hist.meta, n * 16); e->fetch_after.push_back([=] { memcpy(meta, s, n * 16); }); }
+  return fetch_done(e);
 }
 extern "C" uint64_t ptm_step_count(ptm_engine* e) { return e ? e->step : 0; }
 

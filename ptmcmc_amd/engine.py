@@ -25,7 +25,7 @@ EXPORTS = [
     "ptm_last_error", "ptm_abi_version", "ptm_device_count", "ptm_engine_create", "ptm_engine_destroy",
     "ptm_set_bounds", "ptm_set_prior", "ptm_set_target_gaussian", "ptm_set_target_callback", "ptm_set_prior_callback", "ptm_set_ladder", "ptm_set_evolve_temps", "ptm_get_invtemps", "ptm_set_invtemps",
     "ptm_set_proposals", "ptm_set_proposal_rung", "ptm_set_proposal_mixture", "ptm_set_proposal_callback", "ptm_set_states", "ptm_init_from_prior", "ptm_init_from_prior_k", "ptm_sweep", "ptm_step", "ptm_sync",
-    "ptm_copy_llike", "ptm_llike_device_ptr", "ptm_exchange_decide", "ptm_exchange_finish_and_sweep", "ptm_exchange_install", "ptm_sweep_rungs", "ptm_exchange_buffer_doubles", "ptm_exchange_row_capacity", "ptm_shard_unique_id", "ptm_shard_init", "ptm_shard_step", "ptm_shard_finalize", "ptm_get_states",
+    "ptm_copy_llike", "ptm_llike_device_ptr", "ptm_exchange_decide", "ptm_exchange_finish_and_sweep", "ptm_exchange_install", "ptm_sweep_rungs", "ptm_exchange_buffer_doubles", "ptm_exchange_row_capacity", "ptm_shard_unique_id", "ptm_shard_init", "ptm_shard_step", "ptm_shard_finalize", "ptm_get_states", "ptm_batch_begin", "ptm_batch_end",
     "ptm_get_array", "ptm_get_swap_counts", "ptm_get_last_swaps", "ptm_max_swaps_per_step", "ptm_get_history", "ptm_get_history_invtemps", "ptm_set_history", "ptm_set_map", "ptm_get_map", "ptm_restore", "ptm_step_count",
     "ptm_timer_start", "ptm_timer_stop", "ptm_get_kernel_times", "ptm_sweep_kernel_name", "ptm_debug_eval",
     "ptm_debug_philox", "ptm_debug_boxmuller", "ptm_debug_sqrt_scan", "ptm_debug_evaluate",
@@ -104,6 +104,9 @@ def load():
     L.ptm_exchange_install.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.ptm_sweep_rungs.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
     L.ptm_get_states.argtypes = [C.c_void_p, _dp]
+    if hasattr(L, "ptm_batch_begin"):
+        L.ptm_batch_begin.argtypes = [C.c_void_p]
+        L.ptm_batch_end.argtypes = [C.c_void_p]
     L.ptm_get_array.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     L.ptm_get_swap_counts.argtypes = [C.c_void_p, _i64p, _i64p]
     L.ptm_get_last_swaps.argtypes = [C.c_void_p, _i32p, _i32p]

@@ -1479,10 +1479,13 @@ class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:
   std::vector<int> directions, instances;
   std::vector<long> ups, downs;
   std::vector<int32_t> log_pairs, log_acc;
-  void replay_step() {   // the loop of chain.cc:1436-1537, bookkeeping part, in pick order
+  void fetch_swaps() {
     const int ms = ptm_max_swaps_per_step(eng);
     log_pairs.resize((size_t)W * ms); log_acc.resize((size_t)W * ms);
     ptm_check(ptm_get_last_swaps(eng, log_pairs.data(), log_acc.data()), "replay_step");
+  }
+  void replay_swaps() {   // the loop of chain.cc:1436-1537, bookkeeping part, in pick order
+    const int ms = ptm_max_swaps_per_step(eng);
     for (int j = 0; j < ms; j++) {
       const int i = log_pairs[j];
       if (i < 0) continue;
@@ -1622,12 +1625,16 @@ class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:
   std::vector<double> rx, rl, rp, rb;
   std::vector<int32_t> rmeta;
   std::vector<int64_t> rnsize;
-  void sync_history() {
+  void sync_history() { fetch_history(); append_history(); }
+  void fetch_history() {
     const size_t HC = (size_t)Ntemps * W, cap = ring_rows;
     rx.resize(cap * HC * dim); rl.resize(cap * HC); rp.resize(cap * HC); rb.resize(cap * HC); rmeta.resize(cap * HC * 4); rnsize.resize(HC);
     ptm_check(ptm_get_array(eng, PTM_ARR_NSIZE, rnsize.data()), "sync_history");
     ptm_check(ptm_get_history(eng, rx.data(), rl.data(), rp.data(), rmeta.data()), "sync_history");
     ptm_check(ptm_get_history_invtemps(eng, rb.data()), "sync_history");
+  }
+  void append_history() {
+    const size_t HC = (size_t)Ntemps * W, cap = ring_rows;
     for (size_t c = 0; c < HC; c++) {
       mirror_t& m = mirror[c];
       for (int64_t row = mirror_seen[c]; row < rnsize[c]; row++) {
@@ -1659,6 +1666,7 @@ class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:
   }
   void refresh() {
     if (fresh) return;
+    ptm_check(ptm_batch_begin(eng), "parallel_tempering_chains");
     if (ev_rate > 0) {
       betas.resize((size_t)W * Ntemps);
       ptm_check(ptm_get_invtemps(eng, betas.data()), "parallel_tempering_chains");
@@ -1666,6 +1674,7 @@ class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:
     ptm_check(ptm_get_states(eng, X.data()), "parallel_tempering_chains");
     ptm_check(ptm_get_array(eng, PTM_ARR_LLIKE, llike.data()), "parallel_tempering_chains");
     ptm_check(ptm_get_array(eng, PTM_ARR_LPOST, lpost.data()), "parallel_tempering_chains");
+    ptm_check(ptm_batch_end(eng), "parallel_tempering_chains");
     fresh = true;
   }
 
@@ -2075,8 +2084,14 @@ class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:
     ptm_check(ptm_step(eng, 1), "parallel_tempering_chains::step");
     nstep++;
     fresh = hist_fresh = map_fresh = false;
-    if (host_mode) sync_history();
-    if (tracking) replay_step();
+    if (host_mode || tracking) {   // what the host needs of this step, read with ONE wait on the device
+      ptm_check(ptm_batch_begin(eng), "parallel_tempering_chains::step");
+      if (host_mode) fetch_history();
+      if (tracking) fetch_swaps();
+      ptm_check(ptm_batch_end(eng), "parallel_tempering_chains::step");
+      if (host_mode) append_history();
+      if (tracking) replay_swaps();
+    }
   }
   // n steps in ONE engine call when nothing on the host has to look in between (no host-side proposals, no exchange tracking):
   // small ladders then run many steps per kernel launch (ptm_fused_kernel.hpp) instead of paying the launch and the tables'
