@@ -264,8 +264,8 @@ int ptm_get_last_swaps(ptm_engine* e, int32_t* pairs, int32_t* accepted);
 /* Several reads with one wait.  Every ptm_get_* call is an asynchronous copy on the engine's stream plus a wait; a host that
  * reads several arrays after every step (the facade's history mirror for host-side proposals: chain.cc:935-946 rows, the
  * swap log, the temperatures) brackets them: between ptm_batch_begin and ptm_batch_end the ptm_get_* calls only queue
- * their copies (each sees the engine as it is at the time of ITS call) and return at once; the output buffers are filled
- * when ptm_batch_end returns (possibly earlier).  Brackets nest.  No counterpart in the reference (its arrays are host
+ * their copies and return at once; the output buffers are filled when ptm_batch_end returns (possibly earlier).  Only
+ * reads go between the two (ptm_step there is refused).  Brackets nest.  No counterpart in the reference (its arrays are host
  * memory); it exists because a wait on the device costs what ~10 small copies do. */
 int ptm_batch_begin(ptm_engine* e);
 int ptm_batch_end(ptm_engine* e);

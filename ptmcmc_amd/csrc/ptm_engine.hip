@@ -126,7 +126,8 @@ struct ptm_engine {
   int fetch_depth = 0;
   std::vector<std::function<void()>> fetch_after;
   std::vector<std::shared_ptr<std::vector<unsigned char>>> fetch_big;
-  bool shared_handover = false;   // ... or, for a small population, the pinned host images themselves (mapped into the device)
+  std::vector<std::pair<unsigned char*, size_t>> host_blocks;   // arrays kept in mapped host memory (a small history ring): read in place
+  bool shared_handover = false, hist_on_host = false;   // ... or, for a small population, the pinned host images themselves (mapped into the device)
   unsigned char* gate = nullptr;
   pinned_vector<double> h_xprop, h_llnew;
   std::vector<double> h_batch, h_llbatch;
@@ -162,9 +163,17 @@ struct ptm_engine;
 static int fetch_flush(ptm_engine* e);
 static int fetch(ptm_engine* e, const void* dev, size_t bytes, const unsigned char** staged);
 static int fetch_done(ptm_engine* e);
+// small write-only outputs of the kernels that the host reads after every step (the history ring of a small population):
+// mapped, coherent host memory -- the kernels' writes go over the bus as they happen, the host reads them with no copy
+static bool small_outputs_on_host(size_t bytes) {
+  const char* z = getenv("PTM_SHARED_HANDOVER");
+  return bytes <= ((size_t)1 << 20) && !(z && *z == '0');
+}
+template <class T>
+static int halloc(ptm_engine* e, T** p, size_t n);
 template <class T>
 static int upload(T* d, const T* h, size_t n, hipStream_t s) {
-  HIPCHK(hipMemcpyAsync(d, h, n * sizeof(T), hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(d, h, n * sizeof(T), hipMemcpyDefault, s));
   HIPCHK(hipStreamSynchronize(s));
   return PTM_OK;
 }
@@ -275,7 +284,11 @@ static int build_engine(ptm_engine* e, const ptm_config* cfg) {
   }
   if (e->hist.rungs) {
     const size_t n = (size_t)e->hist.cap * e->hist.HC;
-    if ((rc = dalloc(&e->hist.x, n * D)) || (rc = dalloc(&e->hist.ll, n)) || (rc = dalloc(&e->hist.lp, n)) || (rc = dalloc(&e->hist.meta, n)))
+    e->hist_on_host = small_outputs_on_host(n * D * 8);
+    if (e->hist_on_host) {
+      if ((rc = halloc(e, &e->hist.x, n * D)) || (rc = halloc(e, &e->hist.ll, n)) || (rc = halloc(e, &e->hist.lp, n)) || (rc = halloc(e, &e->hist.meta, n)))
+        return rc;
+    } else if ((rc = dalloc(&e->hist.x, n * D)) || (rc = dalloc(&e->hist.ll, n)) || (rc = dalloc(&e->hist.lp, n)) || (rc = dalloc(&e->hist.meta, n)))
       return rc;
     HIPCHK(hipMemsetAsync(e->hist.meta, 0xFF, n * sizeof(int4), e->stream));   // saved row number -1: empty slot
   }
@@ -314,6 +327,16 @@ static int build_engine(ptm_engine* e, const ptm_config* cfg) {
   return PTM_OK;
 }
 
+template <class T>
+static int halloc(ptm_engine* e, T** p, size_t n) {
+  void* h = nullptr;
+  const size_t bytes = (n ? n : 1) * sizeof(T);
+  HIPCHK(hipHostMalloc(&h, bytes, hipHostMallocMapped | hipHostMallocCoherent));
+  e->host_blocks.push_back(std::make_pair((unsigned char*)h, bytes));
+  *p = (T*)h;
+  return PTM_OK;
+}
+
 // ---- batched reads (see ptm_engine::fetch_arena) ------------------------------------------------------------------------
 static const size_t FETCH_ARENA = (size_t)4 << 20;
 static int fetch_flush(ptm_engine* e) {
@@ -325,6 +348,11 @@ static int fetch_flush(ptm_engine* e) {
 // queues the copy of `bytes` at device address `dev` (ordered on the engine's stream, so it sees the state at the time of the
 // call); *staged is where the bytes will be once fetch_flush has waited -- valid until that flush returns
 static int fetch(ptm_engine* e, const void* dev, size_t bytes, const unsigned char** staged) {
+  for (const auto& b : e->host_blocks)
+    if ((const unsigned char*)dev >= b.first && (const unsigned char*)dev < b.first + b.second) {   // already on the host: the flush's wait is all it needs
+      *staged = (const unsigned char*)dev;
+      return PTM_OK;
+    }
   if (e->fetch_arena.empty()) e->fetch_arena.resize(FETCH_ARENA);
   const size_t need = (bytes + 63) & ~(size_t)63;
   if (need > FETCH_ARENA / 2) {   // a big array: its own buffer, copied at once (bandwidth, not call latency, is its cost)
@@ -362,6 +390,8 @@ extern "C" int ptm_engine_destroy(ptm_engine* e) {
   (void)ptm_shard_finalize(e);
   (void)hipStreamSynchronize(e->stream);
   if (e->shared_handover) e->xprop = e->llike_new = nullptr, e->hastings = nullptr, e->htype = nullptr, e->hvalid = e->acc_out = nullptr;   // (these are the pinned vectors)
+  if (e->hist_on_host) e->hist.x = e->hist.ll = e->hist.lp = e->hist.beta = nullptr, e->hist.meta = nullptr;
+  for (auto& b : e->host_blocks) (void)hipHostFree(b.first);
   void* ptrs[] = {e->x, e->ll, e->lp, e->ntries, e->naccept, e->last_type, e->arr_below, e->arr_above, e->mv_src, e->mv_dst, e->mv_n,
                   e->err, e->nhist, e->swap_cnt, e->touch, e->swap_log, e->hist.x, e->hist.ll, e->hist.lp, e->hist.meta, e->map.lpost, e->map.ll, e->map.lp, e->map.x, e->blo,
                   e->bhi, e->ptype, e->bmin, e->bmax, e->plo, e->phi, e->pcoef, e->P2, e->mean, e->beta, e->prop, e->prop_tiles, e->P2_tiles, e->box_row, e->onedfrac, e->mix, e->beta_w, e->betaC, e->beta_add, e->hist.beta, e->xprop, e->lprior_new, e->llike_new, e->hastings, e->htype, e->hvalid, e->acc_out, e->cidx, e->ccnt};
@@ -643,7 +673,7 @@ extern "C" int ptm_set_evolve_temps(ptm_engine* e, double rate, double lpost_cut
     if ((e->hist.rungs || e->map.rungs) && (rc = dalloc(&e->beta_add, (size_t)e->Nc))) return rc;
     if (e->hist.rungs) {   // every saved row keeps the temperature it was saved at; the rows so far: the common ladder's
       const size_t n = (size_t)e->hist.cap * e->hist.HC;
-      if ((rc = dalloc(&e->hist.beta, n))) return rc;
+      if ((rc = e->hist_on_host ? halloc(e, &e->hist.beta, n) : dalloc(&e->hist.beta, n))) return rc;
       hipLaunchKernelGGL(hist_beta_fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->stream, e->hist, e->beta, e->W, e->r0);
       HIPCHK(hipGetLastError());
     }
@@ -1341,6 +1371,7 @@ extern "C" int ptm_step(ptm_engine* e, int n) {
   int rc = ready(e);
   if (rc) return rc;
   if (e->nloc != e->Nt) return fail(PTM_ERR_INVALID, "ptm_step needs the whole ladder on this engine; sharded engines use ptm_exchange_*");
+  if (e->fetch_depth > 0) return fail(PTM_ERR_INVALID, "ptm_step between ptm_batch_begin and ptm_batch_end (only reads go there)");
   if (n > 0) {
     const int f = fused_steps(e, n);
     if (f < 0) return f;
