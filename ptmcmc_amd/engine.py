@@ -476,9 +476,9 @@ class Engine:
         sh = (self.hist_cap, self.hist_rungs * self.W)
         b = np.empty(n)
         _chk(self.L.ptm_get_history_invtemps(self.h, b.ctypes.data_as(_dp)))
-        return dict(x=X.reshape(sh + (self.D,)), llike=ll.reshape(sh), lprior=lp.reshape(sh), naccept=meta[:, 0].reshape(sh),
-                    ntries=meta[:, 1].reshape(sh), last_type=meta[:, 2].reshape(sh), row=meta[:, 3].reshape(sh),
-                    invtemp=b.reshape(sh))
+        m = meta.reshape(sh + (4,))   # (views, not copies: inside a batch() the arrays are filled later)
+        return dict(x=X.reshape(sh + (self.D,)), llike=ll.reshape(sh), lprior=lp.reshape(sh), naccept=m[..., 0],
+                    ntries=m[..., 1], last_type=m[..., 2], row=m[..., 3], invtemp=b.reshape(sh))
 
     @property
     def exchange_row_capacity(self):
@@ -488,6 +488,18 @@ class Engine:
         _chk(self.L.ptm_exchange_finish_and_sweep(self.h, recv_below_dev, recv_above_dev))
 
     # -- read-back
+    def batch(self):
+        """context manager: the reads inside only queue their copies; the arrays they returned are filled when the block ends
+        (ptm_batch_begin / ptm_batch_end: one wait on the device for all of them).  Keep the returned arrays alive until then."""
+        eng = self
+        class _Batch:
+            def __enter__(self):
+                _chk(eng.L.ptm_batch_begin(eng.h))
+            def __exit__(self, *exc):
+                _chk(eng.L.ptm_batch_end(eng.h))
+                return False
+        return _Batch()
+
     def states(self):
         X = np.empty((self.Nc, self.D))
         _chk(self.L.ptm_get_states(self.h, _d(X)))

@@ -1154,3 +1154,37 @@ def test_switched_off_variants_stay_bit_exact(env, D, Nt, W, kind, want):
     r = subprocess.run([sys.executable, os.path.join(here, "variant_worker.py"), str(D), str(Nt), str(W), kind, "4", want],
                        env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and r.stdout.startswith("ok "), r.stdout[-2000:] + r.stderr[-3000:]
+
+
+@pytest.mark.parametrize("W,cap", [(3, 6), (4096, 4)])
+def test_reads_in_one_batch_equal_the_same_reads_one_by_one(W, cap):
+    """ptm_batch_begin / ptm_batch_end: the reads between them return what the same calls return outside a bracket (small
+    population: history ring in mapped host memory, read in place; large: ring on the device, the states through the big-array
+    path), a step inside a bracket is refused, and so is an end without a begin."""
+    from ptmcmc_amd.problems import GaussianProblem
+    D, Nt = 7, 9
+    pr = GaussianProblem(D, Nt, 1e3)
+    e = E.Engine(D, Nt, W, swap_rate=0.4, history_rungs=Nt, history_capacity=cap, map_rungs=Nt)
+    pr.configure(e, E.PROP_DENSE)
+    e.set_evolve_temps(0.02)
+    e.init_from_prior()
+    e.step(11); e.sync()
+    one = dict(x=e.states(), ll=e.llike, lpost=e.array(E.ARR_LPOST), nsize=e.nsize, hist=e.history(), swaps=e.last_swaps(),
+               counts=e.swap_counts(), beta=e.invtemps(), map=e.map())
+    with e.batch():
+        got = dict(x=e.states(), ll=e.llike, lpost=e.array(E.ARR_LPOST), nsize=e.nsize, hist=e.history(), swaps=e.last_swaps(),
+                   counts=e.swap_counts(), beta=e.invtemps(), map=e.map())
+        with pytest.raises(E.PtmError):
+            e.step(1)
+    def same(a, b):
+        if isinstance(a, dict):
+            return all(same(a[k], b[k]) for k in a)
+        if isinstance(a, tuple):
+            return all(same(u, v) for u, v in zip(a, b))
+        return np.array_equal(a, b)
+    for k in one:
+        assert same(one[k], got[k]), k
+    with pytest.raises(E.PtmError):
+        E._chk(e.L.ptm_batch_end(e.h))
+    e.step(3); e.sync()                                  # the engine goes on as if nothing happened
+    assert e.history()["row"].max() >= cap
