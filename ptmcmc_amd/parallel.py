@@ -274,11 +274,14 @@ class WalkerShardedLadders:
 # ----------------------------------------------------------------------------------------------------------------------
 def preflight_neighbour_messages(dist, torch, rank, world, device, stream=None, sabotage=False, wait_s=60.0):
     """The step's message pattern once, with stamped records: the very calls of ShardedLadder._exchange (a batch of
-    isend / irecv to both neighbours), on `stream` when given.  Returns 0 if every record arrived from the right rank, else 1
-    (an exception included; a record that has not arrived after `wait_s` seconds is one).  `sabotage` makes this rank fail on
-    purpose before it sends anything (tests): its neighbours then time out instead of waiting for ever."""
+    isend / irecv to both neighbours), on `stream` when given.  Returns 0 if every record arrived from the right rank, 1 if
+    not (an exception included), 2 if the messages had not completed on the device after `wait_s` seconds -- the stream is
+    then still busy with them and must not be used again (the host polls it, it never blocks on it: with RCCL a wait on a
+    stuck message would last until the watchdog ends the process).  `sabotage` makes this rank fail on purpose before it
+    sends anything (tests): its neighbours then time out instead of waiting for ever."""
     import datetime
     bad = 0
+    deadline = time.monotonic() + wait_s
     try:
         if sabotage:
             raise RuntimeError("sabotaged on purpose")
@@ -300,7 +303,11 @@ def preflight_neighbour_messages(dist, torch, rank, world, device, stream=None, 
                     for r in dist.batch_isend_irecv(ops):
                         r.wait(timeout=datetime.timedelta(seconds=wait_s))
                 if stream is not None:
-                    stream.synchronize()
+                    while not stream.query():
+                        if time.monotonic() > deadline:
+                            sys.stderr.write("[rank %d] pre-flight: the neighbour messages did not complete within %.0f s\n" % (rank, wait_s))
+                            return 2
+                        time.sleep(0.0005)
                 if up is not None and float(got_up[0]) != 1000 * it + up:
                     bad = 1
                 if down is not None and float(got_down[255]) != 1000 * it + down:
@@ -343,17 +350,25 @@ def bench_main(args):
     stream = torch.cuda.Stream(device=dev)
     by_walkers = getattr(args, "shard", "rungs") == "walkers"
     fallback = ""
+    stuck = False   # some rank's pre-flight messages never completed: RCCL is not touched again, the run ends through os._exit
+    ctl = None      # host-side group (gloo) for what the ranks must agree on whatever state RCCL is in
     if not by_walkers and world > 1 and not getattr(args, "native_rccl", False):
         # pre-flight of the step's message pattern (the very calls of ShardedLadder._exchange, on the engine's stream): every
         # rank sends a stamped record to both neighbours and checks what it receives.  If torch.distributed cannot do that here
         # every rank learns it through one all-reduce and the run continues with the population split by WALKERS (whole ladders
         # per GPU, no message in a step) -- said in config.sharding and on stderr -- instead of dying inside the timed region.
-        bad = preflight_neighbour_messages(dist, torch, rank, world, dev, stream)
-        flag = torch.tensor([bad], dtype=torch.int32, device=dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        # The verdict is agreed over a HOST-side group: it must get through even when a device message is stuck.
+        ctl = dist.group.WORLD if rehearsal else dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=300))
+        sab = os.environ.get("PTM_PREFLIGHT_SABOTAGE", "")   # rehearsals: "fail" = every rank's pre-flight fails, "stall" = ... never completes
+        bad = 2 if sab == "stall" else preflight_neighbour_messages(dist, torch, rank, world, dev, stream, sabotage=(sab == "fail"))
+        flag = torch.tensor([bad], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=ctl)
         if int(flag.item()):
-            fallback = "FALLBACK (the pre-flight of the neighbour messages failed on some rank): "
+            stuck = int(flag.item()) >= 2
+            fallback = "FALLBACK (the pre-flight of the neighbour messages %s on some rank): " % ("never completed" if stuck else "failed")
             by_walkers = True
+            if stuck:
+                stream = torch.cuda.Stream(device=dev)   # (the first one may be waiting on a message for ever)
             if rank == 0:
                 sys.stderr.write("[bench] rung sharding is not available here; the population is split by walkers instead\n")
     try:
@@ -385,32 +400,41 @@ def bench_main(args):
                 lad = _Native(eng)
             else:
                 lad = ShardedLadder(EngineShard(eng, torch, dev, stream), dist, rank, world, halo=args.halo)
+        # after a fallback the ranks meet over the host-side group and wait for the ENGINE's stream only (eng.sync): a device-wide
+        # wait would include whatever RCCL left behind
+        def meet():
+            if fallback:
+                eng.sync()
+                dist.barrier(group=ctl)
+                eng.sync()
+            else:
+                torch.cuda.synchronize()
+                dist.barrier()
+                torch.cuda.synchronize()
         lad.step(300)             # set-up (untimed, uncounted): clocks ramped, chains off their prior draws, RCCL channels open
         lad.step(args.warmup)
         lad.drain()
         eng.sync()
         eng.kernel_times()
-        dist.barrier()
-        torch.cuda.synchronize()
+        meet()
         t0 = time.perf_counter()
         lad.step(args.steps)
         lad.drain()
         eng.sync()
-        torch.cuda.synchronize()
-        dist.barrier()
-        torch.cuda.synchronize()
-        dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        meet()
+        dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=None if fallback else dev)
     except Exception as ex:
         # a rank that fails (e.g. PTM_ERR_FAR_MOVE out of eng.sync()) must not leave its peers waiting in a receive or a
         # barrier: leave at once with a non-zero code, the launcher then ends the other ranks
         sys.stderr.write("[bench rank %d] %s: %s\n" % (rank, type(ex).__name__, ex))
         sys.stderr.flush()
         os._exit(17)
-    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    grp = ctl if fallback else None
+    dist.all_reduce(dt, op=dist.ReduceOp.MAX, group=grp)
     wall = float(dt.item())
     kt = eng.kernel_times()              # one entry per sweep launch; a step's sweep is up to four launches
-    kavg = torch.tensor([float(kt.sum()) / args.steps], dtype=torch.float64, device=dev)
-    dist.all_reduce(kavg, op=dist.ReduceOp.MAX)
+    kavg = torch.tensor([float(kt.sum()) / args.steps], dtype=torch.float64, device=None if fallback else dev)
+    dist.all_reduce(kavg, op=dist.ReduceOp.MAX, group=grp)
     nchains = NT * W
     if rank == 0:
         kavg_ms = float(kavg.item())
@@ -432,5 +456,9 @@ def bench_main(args):
                          "kernel_avg_ms": kavg_ms, "per_gpu": True, "bytes_per_mh_step": B.algorithmic_bytes(D)},
         }
         print(json.dumps(out), flush=True)
+    if stuck:   # RCCL still holds a message that will never complete: freeing device memory or closing the group would wait for it
+        dist.barrier(group=ctl)
+        sys.stdout.flush(); sys.stderr.flush()
+        os._exit(0)
     eng.close()
     dist.destroy_process_group()
