@@ -120,6 +120,27 @@ def test_bench_distributed_path_with_one_rank():
     assert rec["config"]["chains"] == 1024 * 1024 and rec["roofline"]["kernel"].startswith("sweep_mfma32_kernel")
 
 
+@pytest.mark.parametrize("sabotage,expect", [("", "contiguous rung blocks"), ("fail", "FALLBACK"), ("stall", "never completed")])
+def test_bench_with_two_ranks_rehearsed_on_one_gpu(sabotage, expect):
+    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one process per rank), rehearsed on the one GPU of
+    this box: both ranks on device 0, messages over gloo (PTM_BENCH_REHEARSAL=1 -- RCCL refuses two ranks on one device).  The
+    rung-sharded step; a pre-flight of the neighbour messages that fails on every rank; one whose messages never complete: the
+    last two must end in the walker split, with ONE record and exit code 0."""
+    import socket
+    s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]; s_.close()
+    env = dict(os.environ, PTM_BENCH_REHEARSAL="1", PTM_PREFLIGHT_SABOTAGE=sabotage, OMP_NUM_THREADS="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--walkers", "1024", "--steps", "6", "--warmup", "2"],
+                         env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    recs = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(recs) == 1
+    rec = recs[0]
+    assert rec["n_gpus"] == 2 and rec["steps"] == 6 and rec["scaling"] == "weak" and rec["value"] > 1e7
+    assert rec["config"]["walkers"] == 2048 and rec["config"]["chains"] == 2 * 1024 * 1024
+    assert expect in rec["config"]["sharding"], rec["config"]["sharding"]
+
+
 @pytest.mark.parametrize("D,Nt,W,ev,hist", [(32, 16, 256, 0.02, False), (6, 12, 10, 0.03, True), (32, 8, 2048, 0.0, False)])
 def test_population_split_by_walkers_gives_the_single_engine_chains(D, Nt, W, ev, hist):
     """ptm_config.walker_begin: engines that hold whole ladders for blocks of the walkers (no message between them) reproduce
