@@ -350,7 +350,7 @@ def bench_main(args):
     stream = torch.cuda.Stream(device=dev)
     by_walkers = getattr(args, "shard", "rungs") == "walkers"
     fallback = ""
-    stuck = False   # some rank's pre-flight messages never completed: RCCL is not touched again, the run ends through os._exit
+    stuck = False   # the pre-flight did not pass: RCCL is not touched again, the run ends through os._exit
     ctl = None      # host-side group (gloo) for what the ranks must agree on whatever state RCCL is in
     if not by_walkers and world > 1 and not getattr(args, "native_rccl", False):
         # pre-flight of the step's message pattern (the very calls of ShardedLadder._exchange, on the engine's stream): every
@@ -364,11 +364,13 @@ def bench_main(args):
         flag = torch.tensor([bad], dtype=torch.int32)
         dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=ctl)
         if int(flag.item()):
-            stuck = int(flag.item()) >= 2
-            fallback = "FALLBACK (the pre-flight of the neighbour messages %s on some rank): " % ("never completed" if stuck else "failed")
+            # Whatever went wrong, RCCL is not touched again: a failed message may have left the communicator (and the stream it
+            # was issued on) waiting for ever, so the engine gets a fresh stream, the ranks meet over the host-side group, and
+            # the processes leave through os._exit once the record is printed.
+            stuck = True
+            fallback = "FALLBACK (the pre-flight of the neighbour messages %s on some rank): " % ("never completed" if int(flag.item()) >= 2 else "failed")
             by_walkers = True
-            if stuck:
-                stream = torch.cuda.Stream(device=dev)   # (the first one may be waiting on a message for ever)
+            stream = torch.cuda.Stream(device=dev)
             if rank == 0:
                 sys.stderr.write("[bench] rung sharding is not available here; the population is split by walkers instead\n")
     try:
@@ -456,7 +458,7 @@ def bench_main(args):
                          "kernel_avg_ms": kavg_ms, "per_gpu": True, "bytes_per_mh_step": B.algorithmic_bytes(D)},
         }
         print(json.dumps(out), flush=True)
-    if stuck:   # RCCL still holds a message that will never complete: freeing device memory or closing the group would wait for it
+    if stuck:   # RCCL may still hold a message that will never complete: freeing device memory or closing the group would wait for it
         dist.barrier(group=ctl)
         sys.stdout.flush(); sys.stderr.flush()
         os._exit(0)
