@@ -272,9 +272,9 @@ class WalkerShardedLadders:
 # ----------------------------------------------------------------------------------------------------------------------
 # bench.py --gpus N  (launched by torch.distributed.run, one rank per GPU)
 # ----------------------------------------------------------------------------------------------------------------------
-def preflight_neighbour_messages(dist, torch, rank, world, device, stream=None, sabotage=False, wait_s=60.0):
+def preflight_neighbour_messages(dist, torch, rank, world, device, stream=None, sabotage=False, wait_s=60.0, sizes=(256, 1 << 20, 1 << 20)):
     """The step's message pattern once, with stamped records: the very calls of ShardedLadder._exchange (a batch of
-    isend / irecv to both neighbours), on `stream` when given.  Returns 0 if every record arrived from the right rank, 1 if
+    isend / irecv to both neighbours), on `stream` when given; `sizes`: doubles per message and round.  Returns 0 if every record arrived from the right rank, 1 if
     not (an exception included), 2 if the messages had not completed on the device after `wait_s` seconds -- the stream is
     then still busy with them and must not be used again (the host polls it, it never blocks on it: with RCCL a wait on a
     stuck message would last until the watchdog ends the process).  `sabotage` makes this rank fail on purpose before it
@@ -289,10 +289,10 @@ def preflight_neighbour_messages(dist, torch, rank, world, device, stream=None, 
         with ctx:
             up = rank + 1 if rank + 1 < world else None
             down = rank - 1 if rank > 0 else None
-            for it in range(3):
-                mine = torch.full((256,), float(1000 * it + rank), dtype=torch.float64, device=device)
-                got_up = torch.zeros(256, dtype=torch.float64, device=device)
-                got_down = torch.zeros(256, dtype=torch.float64, device=device)
+            for it, n in enumerate(sizes):   # (the step's messages are megabytes: RCCL picks its protocol by size)
+                mine = torch.full((n,), float(1000 * it + rank), dtype=torch.float64, device=device)
+                got_up = torch.zeros(n, dtype=torch.float64, device=device)
+                got_down = torch.zeros(n, dtype=torch.float64, device=device)
                 ops = []
                 for send, recv, peer in ((mine, got_up, up), (mine, got_down, down)):
                     if peer is None:
@@ -310,7 +310,7 @@ def preflight_neighbour_messages(dist, torch, rank, world, device, stream=None, 
                         time.sleep(0.0005)
                 if up is not None and float(got_up[0]) != 1000 * it + up:
                     bad = 1
-                if down is not None and float(got_down[255]) != 1000 * it + down:
+                if down is not None and float(got_down[n - 1]) != 1000 * it + down:
                     bad = 1
     except Exception as ex:   # noqa: BLE001
         sys.stderr.write("[rank %d] pre-flight of the neighbour messages failed: %s: %s\n" % (rank, type(ex).__name__, ex))
