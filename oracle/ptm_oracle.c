@@ -333,9 +333,10 @@ double ptmo_llike(const ptmo_problem* pb, const double* x) {
 
 /* order in which the columns of a proposal factor are accumulated (the kernels' tile order): natural for padded
  * dimension <= 8; otherwise in halves of 16 columns, inside a half s + 4k with s = 0..3 outer, k = 0..3 inner.
- * Padded dimension = D rounded up to 4, 8, 16, 32, 64, 128. */
+ * Padded dimension = D rounded up to 4, 8, 16, ..., 512. */
 int ptmo_column_order(int D, int* ord) {
-  int DP = D <= 4 ? 4 : (D <= 8 ? 8 : (D <= 16 ? 16 : (D <= 32 ? 32 : (D <= 64 ? 64 : 128))));
+  int DP = 4;
+  while (DP < D) DP *= 2;
   int n = 0;
   if (DP <= 8) {
     for (int j = 0; j < D; j++) ord[n++] = j;

@@ -21,7 +21,9 @@ namespace ptm {
 
 // LDS of the lanes kernels, in doubles: Box-Muller tables | packed precision matrix | per-wave scratch
 template <int DP>
-constexpr int lanes_lds_doubles(int waves) { return BM_TABLE_DOUBLES + ((DP * (DP + 1) / 2 + 1) & ~1) + waves * (3 * (DP > 64 ? DP : 64) + 4 * (DP > 64 ? 1 : 64 / DP)); }
+constexpr int lanes_p2_doubles() { return DP > 128 ? 0 : ((DP * (DP + 1) / 2 + 1) & ~1); }   // (beyond 128 dimensions the matrix stays in memory: 263 KB at 256)
+template <int DP>
+constexpr int lanes_lds_doubles(int waves) { return BM_TABLE_DOUBLES + lanes_p2_doubles<DP>() + waves * (3 * (DP > 64 ? DP : 64) + 4 * (DP > 64 ? 1 : 64 / DP)); }
 
 // the block's tables into LDS (all threads of the block; ends with a barrier)
 template <int DP>
@@ -29,7 +31,8 @@ __device__ __forceinline__ void lanes_stage(const Dev& p, double* lds_all) {
   constexpr int NP2 = DP * (DP + 1) / 2;
   double* p2s = lds_all + BM_TABLE_DOUBLES;
   for (int i = threadIdx.x; i < BM_TABLE_DOUBLES / 2; i += blockDim.x) reinterpret_cast<bm_d2*>(lds_all)[i] = reinterpret_cast<const bm_d2*>(BM_TABLE)[i];
-  for (int k = threadIdx.x; k < NP2; k += blockDim.x) p2s[k] = p.P2[k];
+  if constexpr (DP <= 128)
+    for (int k = threadIdx.x; k < NP2; k += blockDim.x) p2s[k] = p.P2[k];
   __syncthreads();
 }
 
@@ -39,14 +42,14 @@ __device__ __forceinline__ void lanes_stage(const Dev& p, double* lds_all) {
 template <int DP, int KIND, bool GEN>
 __device__ __forceinline__ void lanes_body(const Dev& p, double* lds_all, const int wslot0, const int cbase, const int cstride, const int nslots,
                                            const uint64_t step) {   // (the step: a parameter of its own, see decide_body)
-  static_assert(DP == 4 || DP == 8 || DP == 16 || DP == 32 || DP == 64 || DP == 128, "lanes kernel: DP 4 .. 128");
+  static_assert(DP == 4 || DP == 8 || DP == 16 || DP == 32 || DP == 64 || DP == 128 || DP == 256 || DP == 512, "lanes kernel: DP 4 .. 512");
   constexpr int E = DP > 64 ? DP / 64 : 1;  // dimensions per lane: lane's d, d + 64, ...
   constexpr int LPC = DP / E;               // lanes per chain
   constexpr int CPW = 64 / LPC;             // chains per wave
   constexpr int WS = DP > 64 ? DP : 64;     // one scratch array of a wave
   constexpr int NP2 = DP * (DP + 1) / 2;    // packed precision matrix
   double* p2s = lds_all + BM_TABLE_DOUBLES;                     // [NP2 (+pad)]
-  double* wsc = p2s + ((NP2 + 1) & ~1) + (threadIdx.x >> 6) * (3 * WS + 4 * CPW);   // this wave's scratch
+  double* wsc = p2s + lanes_p2_doubles<DP>() + (threadIdx.x >> 6) * (3 * WS + 4 * CPW);   // this wave's scratch
   double* vbuf = wsc;             // [CPW][DP] z, then y
   double* sbuf = wsc + WS;        // [CPW][DP] s_i
   double* tbuf = wsc + 2 * WS;    // [CPW][DP] unused tail / flags
@@ -277,7 +280,7 @@ __device__ __forceinline__ void lanes_body(const Dev& p, double* lds_all, const 
 #pragma unroll
     for (int e = 0; e < E; ++e) {
       const int de = d + 64 * e;
-      const double* prow = p2s + de * (de + 1) / 2;
+      const double* prow = (DP > 128 ? p.P2 : p2s) + (size_t)de * (de + 1) / 2;
       const double* y = vbuf + g * DP;
       double s = 0.0;
       for (int j = 0; j <= de; ++j) s = __builtin_fma(prow[j], y[j], s);

@@ -1,5 +1,5 @@
 // ptm_launch.hpp -- host-side launch entry points of the per-dimension translation units.
-// The fused sweep kernel is instantiated for DP in {4,8,16,32,64,128}; each DP lives in its own .hip file so the
+// The fused sweep kernel is instantiated for DP in {4,8,16,32,64,128,256,512}; each DP lives in its own .hip file so the
 // (large, fully unrolled) kernels compile in parallel.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -38,5 +38,7 @@ PTM_DECL_DP(16)
 PTM_DECL_DP(32)
 PTM_DECL_DP(64)
 PTM_DECL_DP(128)
+PTM_DECL_DP(256)
+PTM_DECL_DP(512)
 #undef PTM_DECL_DP
 }  // namespace ptm

@@ -17,9 +17,9 @@ def covariance(D, key=0xC0FFEE):
 class GaussianProblem:
     """Everything the engine needs for the correlated-Gaussian ladder, as plain arrays."""
 
-    def __init__(self, D, n_rungs, tmax, prior_scale=100.0, basescale_fac=0.5, key=0xC0FFEE):
+    def __init__(self, D, n_rungs, tmax, prior_scale=100.0, basescale_fac=0.5, key=0xC0FFEE, cov_scale=1.0):
         self.D, self.Nt, self.tmax = D, n_rungs, tmax
-        self.cov = covariance(D, key)
+        self.cov = covariance(D, key) * cov_scale
         self.P = np.linalg.inv(self.cov)
         self.P = 0.5 * (self.P + self.P.T)
         # exampleGaussian.py:53-54: like0 = -0.5*(npar*log(2 pi) + ln det cov)

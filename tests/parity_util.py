@@ -34,10 +34,20 @@ def oracle_problem(pr, bounds=None, prior=None, mean=None, min_prior=-30.0):
     return pb
 
 
+def problem_for(D, Nt, tmax):
+    """The synthetic Gaussian problem of the parity tests.  Up to 128 dimensions the reference example's box (100 sigma,
+    exampleGaussian.py:71-76).  Beyond, the PRODUCT of such uniform densities underflows to 0 -- log-prior -inf, every move
+    accepted, as the reference would do (probability_function.cc:281-304 multiplies, then takes the log) -- so the
+    high-dimensional cases use a small target (sigma ~ 0.01-0.04) in a box of 20 sigma, whose densities are of order one."""
+    if D <= 128:
+        return GaussianProblem(D, Nt, tmax)
+    return GaussianProblem(D, Nt, tmax, prior_scale=20.0, cov_scale=1e-3)
+
+
 def make_pair(D, Nt, W, tmax, kind=E.PROP_LOWER, seed=0x5EED0001, swap_rate=0.1, one_d_frac=None, add_every_n=1,
               bounds=None, prior=None, mean=None, min_prior=-30.0, init="prior", x0=None):
     """An engine and its oracle twin on the same synthetic Gaussian problem and the same start states."""
-    pr = GaussianProblem(D, Nt, tmax)
+    pr = problem_for(D, Nt, tmax)
     eng = E.Engine(D, Nt, W, seed=seed, swap_rate=swap_rate, add_every_n=add_every_n, min_prior=min_prior)
     odf = None if one_d_frac is None else np.full(Nt, one_d_frac)
     fac = pr.configure(eng, kind, odf)

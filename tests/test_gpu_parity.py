@@ -178,6 +178,11 @@ SWEEP_CASES = [
     (100, 5, 3, 1e2, E.PROP_LOWER, None),    # 65..128 dimensions: the lanes kernel, two dimensions per lane
     (128, 4, 64, 1e2, E.PROP_DENSE, 0.3),
     (65, 6, 5, 1e2, E.PROP_DIAG, 0.4),
+    (129, 4, 3, 1e2, E.PROP_LOWER, None),    # 129..256 dimensions: four dimensions per lane, the precision matrix read from memory
+    (200, 3, 5, 1e2, E.PROP_DENSE, 0.3),
+    (256, 4, 2, 1e2, E.PROP_DIAG, 0.4),
+    (300, 3, 2, 1e2, E.PROP_LOWER, None),    # 257..512: eight per lane
+    (512, 2, 3, 1e2, E.PROP_DENSE, 0.3),
     (18, 7, 3, 1e2, E.PROP_LOWER, 0.4),      # lanes kernel, general build: one-dimensional moves
     (32, 5, 2, 1e2, E.PROP_DIAG, 0.5),
     (5, 7, 3, 1e2, E.PROP_DENSE, 0.3),       # padded dimension (5 -> 8), ragged sizes
@@ -261,6 +266,8 @@ def test_add_every_n_history_counters():
                                                  (40, 7, 3, E.PROP_DENSE, 2, 0.45, 0),   # 64-dimension rows
                                                  (33, 300, 64, E.PROP_DIAG, 2, 0.45, 0.01),   # ... in every exchange path, evolving
                                                  (100, 6, 3, E.PROP_LOWER, 2, 0.45, 0),   # 128-dimension rows (two dimensions per lane)
+                                                 (150, 5, 3, E.PROP_LOWER, 2, 0.45, 0),   # 256-dimension rows
+                                                 (260, 40, 2, E.PROP_DIAG, 2, 0.45, 0.01),  # 512-dimension rows, evolving
                                                  (70, 300, 64, E.PROP_DIAG, 2, 0.45, 0.01),
                                                  (16, 9, 5, E.PROP_LOWER, 1, 0.3, 0),
                                                  (16, 12, 64, E.PROP_DIAG, 4, 0.3, 0),
@@ -285,7 +292,7 @@ def test_history_rows_match_the_oracle(D, Nt, W, kind, N, sr, ev):
     cut = -1.0
     if isinstance(ev, tuple):
         ev, cut = ev
-    pr = GaussianProblem(D, Nt, 1e3)
+    pr = PU.problem_for(D, Nt, 1e3)
     eng = E.Engine(D, Nt, W, swap_rate=sr, add_every_n=N, history_rungs=Nt, history_capacity=cap, map_rungs=Nt)
     fac = pr.configure(eng, kind)
     eng.init_from_prior()
@@ -925,7 +932,7 @@ def test_host_callback_likelihood_C5_exampleLISA(ev, Nt, W):
     eng.close()
 
 
-@pytest.mark.parametrize("D,Nt,W,ev", [(12, 8, 3, 0.0), (20, 6, 5, 0.03), (40, 5, 2, 0.0), (70, 4, 3, 0.02)])
+@pytest.mark.parametrize("D,Nt,W,ev", [(12, 8, 3, 0.0), (20, 6, 5, 0.03), (40, 5, 2, 0.0), (70, 4, 3, 0.02), (140, 4, 2, 0.0)])
 def test_host_callback_likelihood_through_the_lanes_kernel(D, Nt, W, ev):
     """A plug-in likelihood on a small population with more than 8 dimensions: the propose and accept passes of the lanes
     kernel (a lane per dimension) around the host call -- bit for bit the oracle's chain, with a gaussian + uniform prior,
@@ -951,7 +958,7 @@ def test_host_callback_likelihood_through_the_lanes_kernel(D, Nt, W, ev):
     eng.set_ladder(beta)
     eng.set_proposals(E.PROP_DIAG, fac, np.full(Nt, 0.3))
     eng.set_states(x0)
-    assert eng.sweep_kernel_name.startswith("sweep_lanes_kernel<%d" % (16 if D <= 16 else 32 if D <= 32 else 64 if D <= 64 else 128))
+    assert eng.sweep_kernel_name.startswith("sweep_lanes_kernel<%d" % (16 if D <= 16 else 32 if D <= 32 else 64 if D <= 64 else 128 if D <= 128 else 256))
     pb = O.Problem(D)
     pb.set_bounds(blo, bhi, bmin, bmax)
     pb.set_prior(types, cen, hw)
