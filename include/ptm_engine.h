@@ -57,7 +57,7 @@ enum {
 
 typedef struct ptm_config {
   uint32_t struct_size;   /* sizeof(ptm_config), for ABI evolution */
-  int32_t dim;            /* D, 1..512 (PTM_ERR_UNSUPPORTED above; 33..512: functional, not tuned) */
+  int32_t dim;            /* D, 1..1024 (PTM_ERR_UNSUPPORTED above; 33..1024: functional, not tuned) */
   int32_t n_rungs;        /* global ladder length (Ntemps) */
   int32_t rung_begin;     /* first global rung held by this engine */
   int32_t rung_count;     /* rungs held by this engine (== n_rungs on one GPU) */

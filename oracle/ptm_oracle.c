@@ -333,7 +333,7 @@ double ptmo_llike(const ptmo_problem* pb, const double* x) {
 
 /* order in which the columns of a proposal factor are accumulated (the kernels' tile order): natural for padded
  * dimension <= 8; otherwise in halves of 16 columns, inside a half s + 4k with s = 0..3 outer, k = 0..3 inner.
- * Padded dimension = D rounded up to 4, 8, 16, ..., 512. */
+ * Padded dimension = D rounded up to 4, 8, 16, ..., 1024. */
 int ptmo_column_order(int D, int* ord) {
   int DP = 4;
   while (DP < D) DP *= 2;

@@ -38,7 +38,7 @@ enum { PTMO_TAG_MH = 0, PTMO_TAG_PT = 1, PTMO_TAG_INIT = 2 };
 
 typedef double (*ptmo_loglike_fn)(void* user, const double* x, int dim);
 
-#define PTMO_MAX_DIM 512   /* the engine pads a state to 4 .. 512 dimensions */
+#define PTMO_MAX_DIM 1024   /* the engine pads a state to 4 .. 1024 dimensions */
 
 typedef struct {
   int D;

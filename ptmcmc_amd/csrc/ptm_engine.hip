@@ -147,7 +147,8 @@ static int round_dp(int D) {
   if (D <= 64) return 64;
   if (D <= 128) return 128;
   if (D <= 256) return 256;
-  return 512;
+  if (D <= 512) return 512;
+  return 1024;
 }
 
 template <class T>
@@ -217,7 +218,7 @@ extern "C" int ptm_engine_create(const ptm_config* cfg, ptm_engine** out) {
   cfg = &cfg_full;
   if (cfg->walker_begin < 0) return fail(PTM_ERR_INVALID, "walker_begin must be >= 0");
   if (cfg->dim < 1) return fail(PTM_ERR_INVALID, "dim must be >= 1");
-  if (cfg->dim > 512) return fail(PTM_ERR_UNSUPPORTED, "dim > 512 is not built (kernels exist for padded dimensions 4, 8, 16, 32, 64, 128, 256, 512)");
+  if (cfg->dim > 1024) return fail(PTM_ERR_UNSUPPORTED, "dim > 1024 is not built (kernels exist for padded dimensions 4, 8, 16, ..., 1024)");
   if (cfg->n_rungs < 1 || cfg->n_rungs > 65535) return fail(PTM_ERR_INVALID, "n_rungs must be in 1..65535");
   if (cfg->rung_begin < 0 || cfg->rung_count < 1 || cfg->rung_begin + cfg->rung_count > cfg->n_rungs)
     return fail(PTM_ERR_INVALID, "rung block out of range");
@@ -949,6 +950,7 @@ static int launch_sweep(ptm_engine* e, int rung0 = 0, int nr = -1, bool last = t
       case 128: return launch_sweep_128(q, sel, e->stream);
       case 256: return launch_sweep_256(q, sel, e->stream);
       case 512: return launch_sweep_512(q, sel, e->stream);
+      case 1024: return launch_sweep_1024(q, sel, e->stream);
     }
     return hipErrorInvalidValue;
   };
@@ -1211,7 +1213,8 @@ static int run_eval(ptm_engine* e, int n, double* x, int* valid, double* lp, dou
     case 128: HIPCHK(launch_eval_128(p, n, x, valid, lp, ll, eval_like, e->stream)); break;
     case 256: HIPCHK(launch_eval_256(p, n, x, valid, lp, ll, eval_like, e->stream)); break;
     case 512: HIPCHK(launch_eval_512(p, n, x, valid, lp, ll, eval_like, e->stream)); break;
-    default: return fail(PTM_ERR_UNSUPPORTED, "dim > 512 is not built");
+    case 1024: HIPCHK(launch_eval_1024(p, n, x, valid, lp, ll, eval_like, e->stream)); break;
+    default: return fail(PTM_ERR_UNSUPPORTED, "dim > 1024 is not built");
   }
   return PTM_OK;
 }
@@ -1272,7 +1275,8 @@ static int launch_init(ptm_engine* e, const Dev& p, long long attempt, unsigned 
     case 128: HIPCHK(launch_init_128(p, e->x, e->ll, e->lp, e->err + 1, attempt, pending, e->stream)); break;
     case 256: HIPCHK(launch_init_256(p, e->x, e->ll, e->lp, e->err + 1, attempt, pending, e->stream)); break;
     case 512: HIPCHK(launch_init_512(p, e->x, e->ll, e->lp, e->err + 1, attempt, pending, e->stream)); break;
-    default: return fail(PTM_ERR_UNSUPPORTED, "dim > 512 is not built");
+    case 1024: HIPCHK(launch_init_1024(p, e->x, e->ll, e->lp, e->err + 1, attempt, pending, e->stream)); break;
+    default: return fail(PTM_ERR_UNSUPPORTED, "dim > 1024 is not built");
   }
   return PTM_OK;
 }

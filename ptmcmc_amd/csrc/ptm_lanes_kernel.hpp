@@ -42,7 +42,7 @@ __device__ __forceinline__ void lanes_stage(const Dev& p, double* lds_all) {
 template <int DP, int KIND, bool GEN>
 __device__ __forceinline__ void lanes_body(const Dev& p, double* lds_all, const int wslot0, const int cbase, const int cstride, const int nslots,
                                            const uint64_t step) {   // (the step: a parameter of its own, see decide_body)
-  static_assert(DP == 4 || DP == 8 || DP == 16 || DP == 32 || DP == 64 || DP == 128 || DP == 256 || DP == 512, "lanes kernel: DP 4 .. 512");
+  static_assert(DP == 4 || DP == 8 || DP == 16 || DP == 32 || DP == 64 || DP == 128 || DP == 256 || DP == 512 || DP == 1024, "lanes kernel: DP 4 .. 1024");
   constexpr int E = DP > 64 ? DP / 64 : 1;  // dimensions per lane: lane's d, d + 64, ...
   constexpr int LPC = DP / E;               // lanes per chain
   constexpr int CPW = 64 / LPC;             // chains per wave

@@ -1,5 +1,5 @@
 // ptm_launch.hpp -- host-side launch entry points of the per-dimension translation units.
-// The fused sweep kernel is instantiated for DP in {4,8,16,32,64,128,256,512}; each DP lives in its own .hip file so the
+// The fused sweep kernel is instantiated for DP in {4,8,16,32,64,128,256,512,1024}; each DP lives in its own .hip file so the
 // (large, fully unrolled) kernels compile in parallel.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -40,5 +40,6 @@ PTM_DECL_DP(64)
 PTM_DECL_DP(128)
 PTM_DECL_DP(256)
 PTM_DECL_DP(512)
+PTM_DECL_DP(1024)
 #undef PTM_DECL_DP
 }  // namespace ptm

@@ -183,6 +183,8 @@ SWEEP_CASES = [
     (256, 4, 2, 1e2, E.PROP_DIAG, 0.4),
     (300, 3, 2, 1e2, E.PROP_LOWER, None),    # 257..512: eight per lane
     (512, 2, 3, 1e2, E.PROP_DENSE, 0.3),
+    (600, 3, 2, 1e2, E.PROP_DIAG, None),     # 513..1024: sixteen per lane
+    (1024, 2, 2, 1e2, E.PROP_LOWER, 0.3),
     (18, 7, 3, 1e2, E.PROP_LOWER, 0.4),      # lanes kernel, general build: one-dimensional moves
     (32, 5, 2, 1e2, E.PROP_DIAG, 0.5),
     (5, 7, 3, 1e2, E.PROP_DENSE, 0.3),       # padded dimension (5 -> 8), ragged sizes
@@ -268,6 +270,7 @@ def test_add_every_n_history_counters():
                                                  (100, 6, 3, E.PROP_LOWER, 2, 0.45, 0),   # 128-dimension rows (two dimensions per lane)
                                                  (150, 5, 3, E.PROP_LOWER, 2, 0.45, 0),   # 256-dimension rows
                                                  (260, 40, 2, E.PROP_DIAG, 2, 0.45, 0.01),  # 512-dimension rows, evolving
+                                                 (700, 4, 2, E.PROP_LOWER, 1, 0.45, 0),     # 1024-dimension rows
                                                  (70, 300, 64, E.PROP_DIAG, 2, 0.45, 0.01),
                                                  (16, 9, 5, E.PROP_LOWER, 1, 0.3, 0),
                                                  (16, 12, 64, E.PROP_DIAG, 4, 0.3, 0),

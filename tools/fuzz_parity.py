@@ -21,7 +21,7 @@ t0 = time.time()
 n = 0
 kernels = {}
 while time.time() - t0 < budget:
-    D = int(rng.choice([1, 2, 3, 5, 8, 9, 13, 16, 17, 24, 31, 32, 33, 48, 64, 65, 100, 128, 130, 200, 300]))
+    D = int(rng.choice([1, 2, 3, 5, 8, 9, 13, 16, 17, 24, 31, 32, 33, 48, 64, 65, 100, 128, 130, 200, 300, 600]))
     W = int(rng.choice([1, 2, 3, 5, 64, 64, 70, 128, 192, 1024]))
     Nt = int(rng.choice([1, 2, 3, 5, 8, 13, 40, 200] if W < 1024 else [3, 5, 8]))
     if D > 32 and W >= 1024:
