@@ -207,7 +207,7 @@ __device__ __forceinline__ double prior_pdf(int type, double lo, double hi, doub
 
 // stateSpace::enforce (states.cc:86-102) + sampleable_probability_function::evaluate_log (probability_function.hh:59).
 // Runs over the true dimensions only (pad dimensions are open/flat by construction).  Beyond 64 padded dimensions the
-// per-lane loops of this file stay loops (`#pragma unroll (DP > 64 ? 1 : DP)`): only the set-up kernels (evaluate / init) get
+// per-lane loops of this file stay loops (`#pragma unroll DP_UNROLL`): only the set-up kernels (evaluate / init) get
 // there, and their unrolled forms were hundreds of kilobytes of code and minutes of compile time.
 #ifndef PTM_ENFORCE_INLINE_MAX
 #define PTM_ENFORCE_INLINE_MAX 32   // padded dimensions up to which enforce_and_lprior is inlined: a call keeps the state array and the parameter block in scratch -- 0.6-1.1 KB per lane that every launch of a general kernel paid for, and twice the registers (DP = 8: 130 -> 76 VGPRs)
@@ -216,24 +216,25 @@ template <int DP>
 __device__ __attribute__((noinline)) double enforce_and_lprior_call(const Dev& p, double (&x)[DP], bool& valid);
 template <int DP>
 __device__ __forceinline__ double enforce_and_lprior_body(const Dev& p, double (&x)[DP], bool& valid) {
+  constexpr int DP_UNROLL = DP > 64 ? 1 : DP;   // (beyond 64 padded dimensions the per-dimension loops stay loops)
   cip blo = as_c(p.blo), bhi = as_c(p.bhi), pt = as_c(p.ptype);
   cdp bmin = as_c(p.bmin), bmax = as_c(p.bmax), plo = as_c(p.plo), phi = as_c(p.phi), pco = as_c(p.pcoef);
   if (valid && p.has_bounds) {
-#pragma unroll (DP > 64 ? 1 : DP)
+#pragma unroll DP_UNROLL
     for (int d = 0; d < DP; ++d)
       if (d < p.D && valid) valid = boundary_enforce(blo[d], bhi[d], bmin[d], bmax[d], x[d]);
   }
   if (!valid) return -__builtin_inf();
   if (p.all_uniform) {
     bool in = true;
-#pragma unroll (DP > 64 ? 1 : DP)
+#pragma unroll DP_UNROLL
     for (int d = 0; d < DP; ++d)
       if (d < p.D) in = in && !(x[d] < plo[d]) && !(x[d] > phi[d]);
     return in ? p.lprior_const : -__builtin_inf();
   }
   // four interleaved partial products, combined as ((p0 p1) p2) p3: the order every path and the CPU checker share
   double pq[4] = {1.0, 1.0, 1.0, 1.0};
-#pragma unroll (DP > 64 ? 1 : DP)
+#pragma unroll DP_UNROLL
   for (int d = 0; d < DP; ++d)
     if (d < p.D) pq[d & 3] *= prior_pdf(pt[d], plo[d], phi[d], pco[d], x[d]);
   const double result = ((pq[0] * pq[1]) * pq[2]) * pq[3];
@@ -252,13 +253,14 @@ __device__ __forceinline__ double enforce_and_lprior(const Dev& p, double (&x)[D
 // in four interleaved partial sums p_q = sum_{i = q mod 4} y_i s_i combined as ((p0 + p1) + p2) + p3.
 template <int DP, bool MEAN, class XV>
 __device__ __forceinline__ double gauss_llike(const Dev& p, const XV& x) {
+  constexpr int DP_UNROLL = DP > 64 ? 1 : DP;   // (beyond 64 padded dimensions the per-dimension loops stay loops)
   double pq[4] = {0.0, 0.0, 0.0, 0.0};
   cdp row = as_c(p.P2);
   cdp mean = as_c(p.mean);
-#pragma unroll (DP > 64 ? 1 : DP)
+#pragma unroll DP_UNROLL
   for (int i = 0; i < DP; ++i) {
     double s = 0;
-#pragma unroll (DP > 64 ? 1 : DP)
+#pragma unroll DP_UNROLL
     for (int j = 0; j < i; ++j) {
       const double yj = MEAN ? x[j] - mean[j] : x[j];
       s = __builtin_fma(row[j], yj, s);
@@ -638,14 +640,15 @@ __global__ __launch_bounds__(256, PTM_SWEEP_WAVES) void sweep_kernel(const Dev p
 template <int DP>
 __global__ __launch_bounds__(256) void evaluate_kernel(const Dev p, int n, double* x_io /*[n][DP]*/, int* valid_out,
                                                         double* lprior_out, double* llike_out, int eval_like) {
+  constexpr int DP_UNROLL = DP > 64 ? 1 : DP;   // (beyond 64 padded dimensions the per-dimension loops stay loops)
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= n) return;
   double x[DP];
-#pragma unroll (DP > 64 ? 1 : DP)
+#pragma unroll DP_UNROLL
   for (int d = 0; d < DP; ++d) x[d] = x_io[(size_t)c * DP + row_pos<DP>(d)];
   bool valid = true;  // state(space, values) constructor: valid unless enforce fails (states.cc:194-199)
   const double lp = enforce_and_lprior<DP>(p, x, valid);
-#pragma unroll (DP > 64 ? 1 : DP)
+#pragma unroll DP_UNROLL
   for (int d = 0; d < DP; ++d) x_io[(size_t)c * DP + row_pos<DP>(d)] = x[d];
   if (valid_out) valid_out[c] = valid ? 1 : 0;
   lprior_out[c] = lp;
@@ -660,6 +663,7 @@ __global__ __launch_bounds__(256) void evaluate_kernel(const Dev p, int n, doubl
 template <int DP>
 __global__ __launch_bounds__(256) void init_prior_kernel(const Dev p, double* x_out, double* ll_out, double* lp_out,
                                                           int* fail, long long cb_attempt, unsigned char* pending) {
+  constexpr int DP_UNROLL = DP > 64 ? 1 : DP;   // (beyond 64 padded dimensions the per-dimension loops stay loops)
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= p.Nc) return;
   if (cb_attempt >= 0 && pending[c] == 2) return;
@@ -672,7 +676,7 @@ __global__ __launch_bounds__(256) void init_prior_kernel(const Dev p, double* x_
   bool done = false;
   const uint64_t a_begin = p.init_base + (cb_attempt >= 0 ? (uint64_t)cb_attempt : 0), a_end = cb_attempt >= 0 ? a_begin + 1 : p.init_base + 100000;
   for (uint64_t a = a_begin; a < a_end && !done; ++a) {
-#pragma unroll (DP > 64 ? 1 : DP)
+#pragma unroll DP_UNROLL
     for (int d = 0; d < DP; ++d) {
       x[d] = 0.0;
       if (d < p.D) {
@@ -697,7 +701,7 @@ __global__ __launch_bounds__(256) void init_prior_kernel(const Dev p, double* x_
     pending[c] = done ? 1 : 0;
     if (!done) return;
   } else if (!done) atomicOr(fail, 1);
-#pragma unroll (DP > 64 ? 1 : DP)
+#pragma unroll DP_UNROLL
   for (int d = 0; d < DP; ++d) x_out[(size_t)c * DP + row_pos<DP>(d)] = x[d];
   ll_out[c] = ll;
   lp_out[c] = lp;
