@@ -11,9 +11,11 @@ With N GPUs the ladder is sharded in contiguous rung blocks (1024/N rungs per GP
 with N so that per-GPU work is fixed (weak scaling); accepted exchanges across a shard boundary travel as
 point-to-point messages between neighbouring ranks.
 
-Prints ONE JSON line (rank 0).  roofline.achieved = algorithmic bytes per launch (16*D+44 B per MH step x chains,
-SURVEY.md section 8(d)) / mean sweep-kernel duration from HIP events recorded around each launch on the engine's
-stream inside the timed region.  cpu_baseline = the real reference's own parallel_tempering_chains::step
+Prints ONE JSON line (rank 0).  roofline.achieved = algorithmic bytes per launch (16*D+44 B per MH step, SURVEY.md
+section 8(d), x the chains the sweep kernel works on in that launch -- the compacted sweep skips the rungs an exchange
+attempt touched; counted from MH_chain::Ntries) / mean duration of that kernel from HIP events recorded around each of
+its launches on the engine's stream inside the timed region (roofline_record() has the definitions of frac, step_frac,
+traffic_frac).  cpu_baseline = the real reference's own parallel_tempering_chains::step
 (oracle/_ref/ptm_ref_driver, built from /root/reference) on this host, 1 thread, bounded sample.
 """
 import argparse
@@ -30,11 +32,42 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 D, NT, TMAX, SWAP_RATE, SEED = 32, 1024, 1e9, 0.1, 0x5EED0001
+LAYOUT_NOTE = ("states are contiguous rows per chain (AoS, in MFMA accumulator order), updated in place; the rung's proposal factor "
+               "and the precision matrix are read as MFMA operand tiles from L2 / LDS (north_star names SoA planes and an LDS-staged "
+               "factor: both were measured and lost, DESIGN.md section 2 / 3.1)")
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
 
 def algorithmic_bytes(dim):
     return 16 * dim + 44   # r+w state, beta, r+w lpost & llike, accept/type flag
+
+
+def roofline_record(kernel, kernel_avg_ms, launches, moved_per_launch, chains_per_gpu, value, n_gpus, traffic):
+    """The roofline object of the JSON line, for the dominant kernel (the fused MH sweep).
+
+    achieved   = B(D) x (chains the kernel actually worked on per launch) / (its mean launch duration, HIP events on the engine's
+                 stream around that kernel alone -- the same kernel, by name, whose average rocprofv3 --kernel-trace --stats
+                 reports in profiles/).  The compacted sweep visits only the chains that make a Metropolis move this step (a rung
+                 touched by an exchange attempt makes none, chain.cc:1553-1557): they are counted from MH_chain::Ntries, not
+                 assumed.  frac = achieved / peak.
+    step_frac  = value x B(D) / (n_gpus x peak): SURVEY 8(d)'s own step-level formula (every chain of the ladder, whole step).
+    traffic    = HBM bytes per launch of that kernel from the committed PMC passes (profiles/*_pmc_summary.json), or null;
+                 traffic_frac = traffic / kernel time / peak: the real HBM rate."""
+    B = algorithmic_bytes(D)
+    achieved = B * moved_per_launch / (kernel_avg_ms * 1e-3) / 1e9
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": (traffic["bytes"] if traffic else None),
+            "traffic_frac": (traffic["bytes"] / (kernel_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if traffic else None),
+            "traffic_detail": traffic,
+            "definition": "frac = bytes_per_mh_step x chains_processed_per_launch / kernel_avg_ms / peak (the chains the kernel "
+                          "visits, from Ntries); step_frac = value x bytes_per_mh_step / (n_gpus x peak)",
+            "step_frac": value * B / (n_gpus * HBM_PEAK_GBS * 1e9),
+            "kernel": kernel, "kernel_avg_ms": kernel_avg_ms, "launches": launches,
+            "timed_bracket": [kernel], "outside_the_bracket": ["partition_kernel (the compacted sweep's list build)",
+                                                               "decide_kernel (exchange phase)", "fold_swap_log_kernel"],
+            "chains_processed_per_launch": moved_per_launch, "chains_per_gpu": chains_per_gpu,
+            "moving_fraction": moved_per_launch / float(chains_per_gpu),
+            "algorithmic_bytes": B * moved_per_launch, "bytes_per_mh_step": B}
 
 
 def measured_traffic(kernel_name):
@@ -136,6 +169,7 @@ def run_single(args):
     eng.step(args.warmup)
     eng.sync()
     eng.kernel_times()   # drop warm-up records
+    tries0 = int(eng.ntries.astype(np.int64).sum())   # MH_chain::Ntries counts the Metropolis moves made (chain.cc:1005); exchanged rungs make none
     eng.timer_start()
     t0 = time.perf_counter()
     eng.step(args.steps)
@@ -143,11 +177,11 @@ def run_single(args):
     eng.sync()
     wall = time.perf_counter() - t0
     kt = eng.kernel_times()
+    moved = (int(eng.ntries.astype(np.int64).sum()) - tries0) / float(args.steps)   # chains the sweep kernel worked on, per launch
     nchains = NT * W
     value = nchains * args.steps / wall
-    kavg_ms = float(kt.mean())
-    achieved = algorithmic_bytes(D) * nchains / (kavg_ms * 1e-3) / 1e9
-    tr = measured_traffic(eng.sweep_kernel_name) if W == DEFAULT_WALKERS else None
+    roof = roofline_record(eng.sweep_kernel_name, float(kt.mean()), int(kt.size), moved, nchains, value, 1,
+                           measured_traffic(eng.sweep_kernel_name) if W == DEFAULT_WALKERS else None)
     acc = float((eng.naccept.sum() - eng.Nc)) / max(1, float((eng.ntries.sum() - eng.Nc)))
     t, a = eng.swap_counts()
     # latency-bound companion: the bare 1024-chain ladder (W=1)
@@ -170,11 +204,9 @@ def run_single(args):
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": "D=32 correlated Gaussian, 1024-rung ladder (Tmax=1e9, swap_rate=0.1) x %d walkers; "
                                "per-rung Cholesky proposal factors; uniform box prior" % W,
+                   "layout": LAYOUT_NOTE,
                    "dim": D, "rungs": NT, "walkers": W, "chains": nchains, "sharding": "1 GPU holds the whole ladder"},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": (tr["bytes"] if tr else None),
-                     "traffic_detail": tr, "algorithmic_bytes": algorithmic_bytes(D) * nchains, "kernel": eng.sweep_kernel_name,
-                     "kernel_avg_ms": kavg_ms, "launches": int(kt.size), "bytes_per_mh_step": algorithmic_bytes(D)},
+        "roofline": roof,
         "device_ms_per_step": ms_dev / args.steps,
         "mh_accept_rate": acc, "swap_accept_rate": float(a.sum()) / max(1, float(t.sum())),
         "w1": w1,

@@ -350,7 +350,7 @@ static int fetch_flush(ptm_engine* e) {
 }
 // queues the copy of `bytes` at device address `dev` (ordered on the engine's stream, so it sees the state at the time of the
 // call); *staged is where the bytes will be once fetch_flush has waited -- valid until that flush returns
-static int fetch(ptm_engine* e, const void* dev, size_t bytes, const unsigned char** staged) {
+static int fetch_raw(ptm_engine* e, const void* dev, size_t bytes, const unsigned char** staged) {
   for (const auto& b : e->host_blocks)
     if ((const unsigned char*)dev >= b.first && (const unsigned char*)dev < b.first + b.second) {   // already on the host: the flush's wait is all it needs
       *staged = (const unsigned char*)dev;
@@ -358,7 +358,10 @@ static int fetch(ptm_engine* e, const void* dev, size_t bytes, const unsigned ch
     }
   if (e->fetch_arena.empty()) e->fetch_arena.resize(FETCH_ARENA);
   const size_t need = (bytes + 63) & ~(size_t)63;
-  if (need > FETCH_ARENA / 2) {   // a big array: its own buffer, copied at once (bandwidth, not call latency, is its cost)
+  // A big array, or one the arena has no room left for: its own buffer, copied at once (for a big array bandwidth, not call
+  // latency, is the cost).  The arena is never recycled before the flush: pointers staged earlier in the same call or the same
+  // ptm_batch_begin / ptm_batch_end bracket stay valid until their lambdas have run.
+  if (need > FETCH_ARENA / 2 || e->fetch_used + need > FETCH_ARENA) {
     auto buf = std::make_shared<std::vector<unsigned char>>(bytes);
     HIPCHK(hipStreamSynchronize(e->stream));
     HIPCHK(hipMemcpy(buf->data(), dev, bytes, hipMemcpyDeviceToHost));
@@ -366,14 +369,23 @@ static int fetch(ptm_engine* e, const void* dev, size_t bytes, const unsigned ch
     *staged = buf->data();
     return PTM_OK;
   }
-  if (e->fetch_used + need > FETCH_ARENA) { int rc = fetch_flush(e); if (rc) return rc; }   // (outputs queued so far are filled early)
   unsigned char* at = e->fetch_arena.data() + e->fetch_used;
   HIPCHK(hipMemcpyAsync(at, dev, bytes, hipMemcpyDeviceToHost, e->stream));
   e->fetch_used += need;
   *staged = at;
   return PTM_OK;
 }
+// a read that fails cancels everything queued (the outputs of this call and of an open bracket are then never written: no
+// lambda is left pointing at a caller's buffer)
+static int fetch(ptm_engine* e, const void* dev, size_t bytes, const unsigned char** staged) {
+  const int rc = fetch_raw(e, dev, bytes, staged);
+  if (rc) { e->fetch_after.clear(); e->fetch_big.clear(); e->fetch_used = 0; }
+  return rc;
+}
 static int fetch_done(ptm_engine* e) { return e->fetch_depth > 0 ? PTM_OK : fetch_flush(e); }
+// Between ptm_batch_begin and ptm_batch_end only reads are allowed: a queued read of mapped host memory (a small population's
+// history ring) is served in place at the flush, so nothing may change the engine's arrays in between.
+#define NO_BATCH(e, name) do { if ((e) && (e)->fetch_depth > 0) return fail(PTM_ERR_INVALID, name " between ptm_batch_begin and ptm_batch_end (only reads go there)"); } while (0)
 #define FETCH(ptr, dev, bytes) do { int _rc = fetch(e, (dev), (bytes), &(ptr)); if (_rc) return _rc; } while (0)
 
 extern "C" int ptm_batch_begin(ptm_engine* e) {
@@ -641,6 +653,7 @@ static int host_prior_of_states(ptm_engine* e) {
 }
 
 extern "C" int ptm_set_ladder(ptm_engine* e, const double* beta) {
+  NO_BATCH(e, "ptm_set_ladder");
   if (!e || !beta) return fail(PTM_ERR_INVALID, "null argument");
   e->h_beta.assign(beta, beta + e->Nt);
   int rc = upload(e->beta, beta, (size_t)e->Nt, e->stream);
@@ -716,6 +729,7 @@ extern "C" int ptm_get_history_invtemps(ptm_engine* e, double* beta) {
 }
 
 extern "C" int ptm_set_invtemps(ptm_engine* e, const double* beta) {
+  NO_BATCH(e, "ptm_set_invtemps");
   if (!e || !beta) return fail(PTM_ERR_INVALID, "null argument");
   if (!e->beta_w) return fail(PTM_ERR_INVALID, "per-ladder temperatures exist only once the ladders evolve (ptm_set_evolve_temps)");
   HIPCHK(hipStreamSynchronize(e->stream));
@@ -919,7 +933,6 @@ static int launch_sweep(ptm_engine* e, int rung0 = 0, int nr = -1, bool last = t
     }
     ev0 = e->kev[e->kev_used]; ev1 = e->kev[e->kev_used + 1];
     e->kev_used += 2;
-    HIPCHK(hipEventRecord(ev0, e->stream));
   }
   const SweepSel sel = sweep_sel(e);
   // Compacted sweep: after an exchange phase ~1/6 of a long ladder's chains make no move; the lean MFMA build on a big
@@ -940,6 +953,9 @@ static int launch_sweep(ptm_engine* e, int rung0 = 0, int nr = -1, bool last = t
     HIPCHK(hipGetLastError());
     p.cidx = e->cidx; p.ccnt = e->ccnt;
   }
+  // the timed bracket holds the sweep kernel alone (its name: ptm_sweep_kernel_name): the list fill and partition_kernel of a
+  // compacted sweep stay outside, so that the events' mean is what rocprofv3 reports for that kernel
+  if (ev0) HIPCHK(hipEventRecord(ev0, e->stream));
   auto launch = [&](const Dev& q) -> hipError_t {
     switch (e->DP) {
       case 4: return launch_sweep_4(q, sel, e->stream);
@@ -972,7 +988,7 @@ static int launch_sweep(ptm_engine* e, int rung0 = 0, int nr = -1, bool last = t
     for (size_t k = 0; k < npick; ++k) {
       const size_t c = e->p_pick[k];
       for (size_t d = 0; d < D; ++d) e->p_xcur[k * D + d] = e->h_rows[c * DP + host_row_pos(DP, d)];
-      e->p_rung[k] = e->r0 + (int)(c / e->W); e->p_walker[k] = (int)(c % e->W);
+      e->p_rung[k] = e->r0 + (int)(c / e->W); e->p_walker[k] = e->cfg.walker_begin + (int)(c % e->W);   // GLOBAL rung and walker (ptm_engine.h)
     }
     if (npick)
       e->pcb(e->pcb_user, (int)npick, (int)D, e->p_xcur.data(), e->p_rung.data(), e->p_walker.data(), e->step, e->p_xprop.data(),
@@ -1235,6 +1251,7 @@ static void unpad_rows(const double* r, size_t n, size_t D, size_t DP, double* X
 static void unpad_rows(const std::vector<double>& r, size_t n, size_t D, size_t DP, double* X) { unpad_rows(r.data(), n, D, DP, X); }
 
 extern "C" int ptm_set_states(ptm_engine* e, const double* X, const double* llike) {
+  NO_BATCH(e, "ptm_set_states");
   if (!e || !X) return fail(PTM_ERR_INVALID, "null argument");
   if (!e->have_target && !llike) return fail(PTM_ERR_INVALID, "set the target first (or pass llike)");
   const size_t Nc = e->Nc, D = e->D, DP = e->DP;
@@ -1284,6 +1301,7 @@ static int launch_init(ptm_engine* e, const Dev& p, long long attempt, unsigned 
 extern "C" int ptm_init_from_prior(ptm_engine* e) { return ptm_init_from_prior_k(e, 0); }
 
 extern "C" int ptm_init_from_prior_k(ptm_engine* e, int kdraw) {
+  NO_BATCH(e, "ptm_init_from_prior");
   if (!e) return fail(PTM_ERR_INVALID, "null engine");
   if (kdraw < 0 || kdraw > 8191) return fail(PTM_ERR_INVALID, "initial draw index out of range (0..8191)");
   if (!e->have_target) return fail(PTM_ERR_INVALID, "set the target first");
@@ -1337,6 +1355,7 @@ extern "C" int ptm_init_from_prior_k(ptm_engine* e, int kdraw) {
 
 // ---- hot path ----------------------------------------------------------------------------------------------------
 extern "C" int ptm_sweep(ptm_engine* e, int n) {
+  NO_BATCH(e, "ptm_sweep");
   int rc = ready(e);
   if (rc) return rc;
   for (int k = 0; k < n; ++k)
@@ -1383,7 +1402,7 @@ extern "C" int ptm_step(ptm_engine* e, int n) {
   int rc = ready(e);
   if (rc) return rc;
   if (e->nloc != e->Nt) return fail(PTM_ERR_INVALID, "ptm_step needs the whole ladder on this engine; sharded engines use ptm_exchange_*");
-  if (e->fetch_depth > 0) return fail(PTM_ERR_INVALID, "ptm_step between ptm_batch_begin and ptm_batch_end (only reads go there)");
+  NO_BATCH(e, "ptm_step");
   if (n > 0) {
     const int f = fused_steps(e, n);
     if (f < 0) return f;
@@ -1419,6 +1438,7 @@ extern "C" int ptm_llike_device_ptr(ptm_engine* e, void** p) {
 
 extern "C" int ptm_exchange_decide(ptm_engine* e, const void* ll_below, const void* ll_above, int halo_rungs, void* send_up,
                                    void* send_down) {
+  NO_BATCH(e, "ptm_exchange_decide");
   int rc = ready(e);
   if (rc) return rc;
   const bool first = e->r0 == 0, last = e->r0 + e->nloc == e->Nt;
@@ -1456,6 +1476,7 @@ extern "C" int ptm_dev_copy(void* dst, const void* src, size_t bytes) {
 }
 
 extern "C" int ptm_exchange_install(ptm_engine* e, const void* recv_below, const void* recv_above) {
+  NO_BATCH(e, "ptm_exchange_install");
   int rc = ready(e);
   if (rc) return rc;
   const bool first = e->r0 == 0, last = e->r0 + e->nloc == e->Nt;
@@ -1463,6 +1484,7 @@ extern "C" int ptm_exchange_install(ptm_engine* e, const void* recv_below, const
   return launch_install(e, first ? nullptr : (const double*)recv_below, last ? nullptr : (const double*)recv_above);
 }
 extern "C" int ptm_sweep_rungs(ptm_engine* e, int first_local_rung, int n_rungs, int closes_step) {
+  NO_BATCH(e, "ptm_sweep_rungs");
   int rc = ready(e);
   if (rc) return rc;
   return launch_sweep(e, first_local_rung, n_rungs, closes_step != 0);
@@ -1472,6 +1494,7 @@ extern "C" int ptm_exchange_buffer_doubles(ptm_engine* e) { return e ? MSG_HDR +
 extern "C" int ptm_exchange_row_capacity(ptm_engine* e) { return e ? e->row_cap : 0; }
 
 extern "C" int ptm_exchange_finish_and_sweep(ptm_engine* e, const void* recv_below, const void* recv_above) {
+  NO_BATCH(e, "ptm_exchange_finish_and_sweep");
   int rc = ready(e);
   if (rc) return rc;
   const bool first = e->r0 == 0, last = e->r0 + e->nloc == e->Nt;
@@ -1590,6 +1613,7 @@ static int shard_stage_and_start_halos(ptm_engine* e) {
 }
 
 extern "C" int ptm_shard_step(ptm_engine* e, int n) {
+  NO_BATCH(e, "ptm_shard_step");
   int rc = ready(e);
   if (rc) return rc;
   if (!e->shard) return fail(PTM_ERR_INVALID, "ptm_shard_init first");
@@ -1723,6 +1747,7 @@ extern "C" int ptm_get_map(ptm_engine* e, double* X, double* lpost, double* llik
 extern "C" int ptm_restore(ptm_engine* e, const double* X, const double* llike, const int32_t* ntries, const int32_t* naccept,
                            const int32_t* last_type, const int64_t* nhist, uint64_t step_count, const int64_t* swap_tries,
                            const int64_t* swap_accepts) {
+  NO_BATCH(e, "ptm_restore");
   if (!e || !X || !llike || !ntries || !naccept || !last_type || !nhist) return fail(PTM_ERR_INVALID, "null argument");
   // (a history ring / MAP restart from the restored state here; ptm_set_history / ptm_set_map put saved ones back)
   int rc = ptm_set_states(e, X, llike);   // enforces (a no-op on saved states), recomputes lprior, resets counters
@@ -1753,6 +1778,7 @@ extern "C" int ptm_restore(ptm_engine* e, const double* X, const double* llike, 
 }
 
 extern "C" int ptm_set_map(ptm_engine* e, const double* X, const double* lpost, const double* llike, const double* lprior) {
+  NO_BATCH(e, "ptm_set_map");
   if (!e || !X || !lpost || !llike || !lprior) return fail(PTM_ERR_INVALID, "null argument");
   if (!e->map.rungs) return fail(PTM_ERR_INVALID, "MAP tracking is off (ptm_config.map_rungs)");
   const size_t n = (size_t)e->map.MC;
@@ -1767,6 +1793,7 @@ extern "C" int ptm_set_map(ptm_engine* e, const double* X, const double* lpost, 
 
 extern "C" int ptm_set_history(ptm_engine* e, const double* X, const double* llike, const double* lprior, const int32_t* meta,
                                const double* invtemps) {
+  NO_BATCH(e, "ptm_set_history");
   if (!e || !X || !llike || !lprior || !meta) return fail(PTM_ERR_INVALID, "null argument");
   if (!e->hist.rungs) return fail(PTM_ERR_INVALID, "history is off (ptm_config.history_rungs)");
   if (e->hist.beta && !invtemps) return fail(PTM_ERR_INVALID, "an evolving run's history needs the rows' temperatures (ptm_get_history_invtemps)");

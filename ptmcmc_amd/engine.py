@@ -249,6 +249,7 @@ class Engine:
         self.Nc = self.nloc * n_walkers
         self._evolving = False
         self._keep = []
+        self._batch_depth, self._batch_keep = 0, []
 
     def close(self):
         if getattr(self, "h", None):
@@ -350,7 +351,7 @@ class Engine:
 
     def invtemps(self):
         """[W][Nt] inverse temperatures of every ladder"""
-        b = np.empty((self.W, self.Nt))
+        b = self._out(np.empty((self.W, self.Nt)))
         _chk(self.L.ptm_get_invtemps(self.h, b.ctypes.data_as(_dp)))
         return b
 
@@ -437,7 +438,7 @@ class Engine:
     def map(self):
         """MAP of the tracked rungs: dict x [map_rungs*W][D], lpost, llike, lprior [map_rungs*W]"""
         n = self.map_rungs * self.W
-        X = np.empty((n, self.D)); lpo = np.empty(n); ll = np.empty(n); lp = np.empty(n)
+        X = self._out(np.empty((n, self.D))); lpo = self._out(np.empty(n)); ll = self._out(np.empty(n)); lp = self._out(np.empty(n))
         _chk(self.L.ptm_get_map(self.h, X.ctypes.data_as(_dp), lpo.ctypes.data_as(_dp), ll.ctypes.data_as(_dp), lp.ctypes.data_as(_dp)))
         return dict(x=X, lpost=lpo, llike=ll, lprior=lp)
 
@@ -470,11 +471,11 @@ class Engine:
         """dict of arrays [cap][history_rungs*W](,D): x, llike, lprior, naccept, ntries, last_type, row (saved row number,
         -1 = empty slot), invtemp (the temperature the row was saved at); saved row s of a chain sits in slot s % cap"""
         n = self.hist_cap * self.hist_rungs * self.W
-        X = np.empty((n, self.D)); ll = np.empty(n); lp = np.empty(n); meta = np.empty((n, 4), dtype=np.int32)
+        X = self._out(np.empty((n, self.D))); ll = self._out(np.empty(n)); lp = self._out(np.empty(n)); meta = self._out(np.empty((n, 4), dtype=np.int32))
         _chk(self.L.ptm_get_history(self.h, X.ctypes.data_as(_dp), ll.ctypes.data_as(_dp), lp.ctypes.data_as(_dp),
                                     meta.ctypes.data_as(_i32p)))
         sh = (self.hist_cap, self.hist_rungs * self.W)
-        b = np.empty(n)
+        b = self._out(np.empty(n))
         _chk(self.L.ptm_get_history_invtemps(self.h, b.ctypes.data_as(_dp)))
         m = meta.reshape(sh + (4,))   # (views, not copies: inside a batch() the arrays are filled later)
         return dict(x=X.reshape(sh + (self.D,)), llike=ll.reshape(sh), lprior=lp.reshape(sh), naccept=m[..., 0],
@@ -495,20 +496,33 @@ class Engine:
         class _Batch:
             def __enter__(self):
                 _chk(eng.L.ptm_batch_begin(eng.h))
+                eng._batch_depth += 1
             def __exit__(self, *exc):
-                _chk(eng.L.ptm_batch_end(eng.h))
+                try:
+                    _chk(eng.L.ptm_batch_end(eng.h))
+                finally:
+                    eng._batch_depth -= 1
+                    if eng._batch_depth == 0:
+                        eng._batch_keep.clear()     # the outputs are filled: temporaries may go now
                 return False
         return _Batch()
 
+    def _out(self, arr):
+        """inside a batch() the C side fills an output when the bracket ends: hold a reference to every array handed out until
+        then, so that a temporary (eng.naccept.sum()) or a discarded return value is not freed under the pending write"""
+        if self._batch_depth > 0:
+            self._batch_keep.append(arr)
+        return arr
+
     def states(self):
-        X = np.empty((self.Nc, self.D))
+        X = self._out(np.empty((self.Nc, self.D)))
         _chk(self.L.ptm_get_states(self.h, _d(X)))
         return X
 
     def array(self, which):
         dt = {ARR_LLIKE: np.float64, ARR_LPRIOR: np.float64, ARR_LPOST: np.float64, ARR_NTRIES: np.int32,
               ARR_NACCEPT: np.int32, ARR_LAST_TYPE: np.int32, ARR_NHIST: np.int64, ARR_NSIZE: np.int64}[which]
-        out = np.empty(self.Nc, dtype=dt)
+        out = self._out(np.empty(self.Nc, dtype=dt))
         _chk(self.L.ptm_get_array(self.h, which, out.ctypes.data_as(C.c_void_p)))
         return out
 
@@ -523,13 +537,13 @@ class Engine:
 
     def swap_counts(self):
         n = self.W * max(self.Nt - 1, 1)
-        t, a = np.empty(n, dtype=np.int64), np.empty(n, dtype=np.int64)
+        t, a = self._out(np.empty(n, dtype=np.int64)), self._out(np.empty(n, dtype=np.int64))
         _chk(self.L.ptm_get_swap_counts(self.h, t.ctypes.data_as(_i64p), a.ctypes.data_as(_i64p)))
         return t.reshape(self.W, -1), a.reshape(self.W, -1)
 
     def last_swaps(self):
         ms = self.max_swaps
-        p, a = np.empty(self.W * ms, dtype=np.int32), np.empty(self.W * ms, dtype=np.int32)
+        p, a = self._out(np.empty(self.W * ms, dtype=np.int32)), self._out(np.empty(self.W * ms, dtype=np.int32))
         _chk(self.L.ptm_get_last_swaps(self.h, p.ctypes.data_as(_i32p), a.ctypes.data_as(_i32p)))
         return p.reshape(self.W, ms), a.reshape(self.W, ms)
 

@@ -1602,7 +1602,7 @@ class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:
     parallel_tempering_chains* p = (parallel_tempering_chains*)self;
     p->fresh = false;   // (the temperatures an evolving ladder shows its proposals are this step's)
     for (int k = 0; k < n; k++) {
-      const size_t v = (size_t)walker[k] * p->Ntemps + rung[k];
+      const size_t v = (size_t)(walker[k] - p->Woff) * p->Ntemps + rung[k];   // (the engine names the GLOBAL walker)
       rung_view& view = p->views[v];
       view.reseat(p->eng_seed, step);
       state s = state::from_engine(p->sp, X_cur + (size_t)k * dim, dim);
@@ -1617,7 +1617,7 @@ class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:
   static void result_trampoline(void* self, int n, const int32_t* rung, const int32_t* walker, const int32_t* accepted) {
     parallel_tempering_chains* p = (parallel_tempering_chains*)self;
     for (int k = 0; k < n; k++) {
-      proposal_distribution* prop = p->props[(size_t)walker[k] * p->Ntemps + rung[k]];
+      proposal_distribution* prop = p->props[(size_t)(walker[k] - p->Woff) * p->Ntemps + rung[k]];
       if (accepted[k]) prop->accept(); else prop->reject();   // chain.cc:1009,1015
     }
   }

@@ -418,6 +418,19 @@ def bench_main(args):
         lad.drain()
         eng.sync()
         eng.kernel_times()
+        tries0 = int(eng.ntries.astype(np.int64).sum())
+        # evidence of the transport, outside the timed region: what RCCL itself makes of "one from every rank"
+        evidence = {"backend": dist.get_backend(), "world_size": dist.get_world_size()}
+        if not fallback:
+            ones = torch.ones(1, dtype=torch.float64, device=dev)
+            dist.all_reduce(ones)
+            evidence["all_reduce_of_ones"] = float(ones.item())
+            props = torch.cuda.get_device_properties(local)
+            mine = {"rank": rank, "device": local, "name": props.name, "uuid": str(getattr(props, "uuid", "")),
+                    "rungs": [int(r0), int(r0 + nloc)], "walkers": int(eng.W), "walker_begin": int(eng.walker_begin)}
+            seen = [None] * world
+            dist.all_gather_object(seen, mine)
+            evidence["ranks"] = seen
         meet()
         t0 = time.perf_counter()
         lad.step(args.steps)
@@ -435,28 +448,43 @@ def bench_main(args):
     dist.all_reduce(dt, op=dist.ReduceOp.MAX, group=grp)
     wall = float(dt.item())
     kt = eng.kernel_times()              # one entry per sweep launch; a step's sweep is up to four launches
+    moved = (int(eng.ntries.astype(np.int64).sum()) - tries0) / float(args.steps)   # chains this rank's sweeps worked on, per step
     kavg = torch.tensor([float(kt.sum()) / args.steps], dtype=torch.float64, device=None if fallback else dev)
     dist.all_reduce(kavg, op=dist.ReduceOp.MAX, group=grp)
     nchains = NT * W
     if rank == 0:
         kavg_ms = float(kavg.item())
-        per_gpu_bytes = B.algorithmic_bytes(D) * nloc * (args.walkers if by_walkers else W)
-        achieved = per_gpu_bytes / (kavg_ms * 1e-3) / 1e9
+        value = nchains * args.steps / wall
+        roof = B.roofline_record(eng.sweep_kernel_name, kavg_ms, int(kt.size), moved, eng.Nc, value, world, None)
+        roof["per_gpu"] = True
+        roof["kernel_avg_ms_is"] = "sum of the rank's sweep launches of a step (up to four partial sweeps), max over ranks; chains_processed of rank 0"
+        how = "walkers" if by_walkers else "rungs"
         out = {
             "metric": "ladder-wide MH steps/sec (D=32 Gaussian, 1024 temps)",
-            "value": nchains * args.steps / wall, "unit": "MH steps/s", "n_gpus": world, "steps": args.steps,
+            "value": value, "unit": "MH steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "D=32 correlated Gaussian, 1024-rung ladder (Tmax=1e9, swap_rate=0.1) x %d walkers; "
                                    "per-rung Cholesky proposal factors; uniform box prior" % W,
+                       "layout": B.LAYOUT_NOTE,
                        "dim": D, "rungs": NT, "walkers": W, "chains": nchains,
+                       # what was measured, unmistakably: "rung-sharded" is BASELINE's configuration (neighbour exchanges over
+                       # RCCL); "fallback" means the pre-flight of those messages did not pass and this line is NOT that measurement
+                       "measured": "fallback" if fallback else ("rung-sharded" if not by_walkers else "walker-split (asked for: --shard walkers)"),
+                       "data_path_messages": "none" if by_walkers else "llike halos + boundary rows, point-to-point between neighbour ranks",
+                       "transport": evidence,
                        "sharding": (fallback + "%d blocks of %d whole ladders (walkers), no message in a step" % (world, args.walkers)) if by_walkers else
                                    ("%d contiguous rung blocks of %d rungs; llike halo %d rungs; neighbour p2p over RCCL (%s)"
                                     % (world, nloc, args.halo, "ptm_shard_*: native ncclSend/ncclRecv" if getattr(args, "native_rccl", False) else "torch.distributed"))},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": B.HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / B.HBM_PEAK_GBS, "traffic": None, "kernel": eng.sweep_kernel_name,
-                         "kernel_avg_ms": kavg_ms, "per_gpu": True, "bytes_per_mh_step": B.algorithmic_bytes(D)},
+            "roofline": roof,
         }
+        if not getattr(args, "no_cpu", False) and not stuck:
+            # the CPU baseline of the same workload on this box's host cores, rank 0 only, after the timed region (the other ranks
+            # wait at the final barrier; bounded: ~10-30 s)
+            try:
+                out["cpu_baseline"] = B.cpu_baseline(pr)
+            except Exception as ex:   # noqa: BLE001
+                sys.stderr.write("[bench] cpu_baseline failed: %s\n" % ex)
         print(json.dumps(out), flush=True)
     if stuck:   # RCCL may still hold a message that will never complete: freeing device memory or closing the group would wait for it
         dist.barrier(group=ctl)

@@ -147,3 +147,37 @@ def test_host_proposals_refuse_partial_sweeps():
     with pytest.raises(E.PtmError, match="partial sweeps"):
         eng.sweep_rungs(0, 2, True)
     eng.close()
+
+
+def test_host_proposals_name_the_global_walker_in_a_population_split():
+    """ptm_propose_batch_fn / ptm_proposal_result_fn are handed each chain's GLOBAL rung and walker (include/ptm_engine.h): a
+    population split by walkers (ptm_config.walker_begin > 0) with a proposal keyed by (rung, walker, step) then walks the very
+    chains of one engine holding every ladder."""
+    D, Nt, W, sr, seed = 6, 7, 5, 0.3, 0x5EED0001
+    pr = GaussianProblem(D, Nt, 1e3)
+    scale = 2.0 / np.sqrt(D) / np.sqrt(np.maximum(pr.beta, 0.02)) * np.sqrt(np.diag(pr.cov).mean())
+    rng = np.random.default_rng(11)
+    x0 = (rng.uniform(-1.0, 1.0, size=(Nt * W, D)) * np.sqrt(np.diag(pr.cov))).reshape(Nt, W, D)
+
+    def run(w0, n):
+        seen = []
+        eng = E.Engine(D, Nt, n, seed=seed, swap_rate=sr, walker_begin=w0)
+        pr.configure(eng, E.PROP_DIAG)
+        fn = scripted_proposal(scale)
+
+        def propose(X, rung, walker, step):
+            seen.append(walker.copy())
+            return fn(X, rung, walker, step)
+        eng.set_proposal_callback(propose, result=lambda r, w, a: seen.append(w.copy()))
+        eng.set_states(x0[:, w0:w0 + n].reshape(Nt * n, D))
+        eng.step(12); eng.sync()
+        out = eng.states().reshape(Nt, n, D), eng.llike.reshape(Nt, n), eng.naccept.reshape(Nt, n)
+        eng.close()
+        allw = np.concatenate(seen)
+        assert allw.min() >= w0 and allw.max() < w0 + n and (n == 1 or allw.max() > w0)
+        return out
+
+    whole = run(0, W)
+    lo, hi = run(0, 3), run(3, 2)
+    for k in range(3):
+        assert np.array_equal(whole[k][:, :3], lo[k]) and np.array_equal(whole[k][:, 3:], hi[k]), k
