@@ -78,10 +78,10 @@ int main(int argc, char* argv[]) {
   // prep command-line options
   s0->addOptions(opt);
   like->addOptions(opt);
-  opt.add(Option("nchains", "Number of consequtive chain runs. Default 1", "1"));
-  opt.add(Option("seed", "Pseudo random number grenerator seed in [0,1). (Default=-1, use clock to seed.)", "-1"));
-  opt.add(Option("precision", "Set output precision digits. (Default 13).", "13"));
-  opt.add(Option("outname", "Base name for output files (Default 'mcmc_output').", "mcmc_output"));
+  opt.add(Option("nchains", "How many chains to run, one after the other. [1]", "1"));
+  opt.add(Option("seed", "Seed of the random streams, a number in [0,1). [-1: seed from the clock]", "-1"));
+  opt.add(Option("precision", "Significant digits in the chain files. [13]", "13"));
+  opt.add(Option("outname", "Stem of the output file names. [mcmc_output]", "mcmc_output"));
   const bool parseBAD = opt.parse(argc, argv);
   if (parseBAD) {
     std::cout << "Usage:\n example_lisa [--options=vals] " << std::endl;

@@ -16,6 +16,9 @@
 //                           with *scripted* proposals and *recorded* RNG tapes, so
 //                           that a CPU restatement fed the same tapes must land on
 //                           the same states after every PT step.
+//   golden-de               JSON on stdout: differential_evolution::draw (standard, snooker, unlikely_alpha, temperature
+//                           mixing) on the histories of a real ladder, with the uniforms each draw consumed.
+//   golden-ess              JSON on stdout: chain::report_effective_samples on fixed AR(1) series.
 //   bench <spec-file>       time parallel_tempering_chains::step() on the
 //                           correlated-Gaussian problem described in spec-file;
 //                           prints one JSON line (cpu_baseline, kind "reference").
@@ -28,6 +31,8 @@
 //   parallel_tempering_chains ctor/initialize/set_proposal/step
 //                                         chain.cc:1163-1211,1281-1386,1393-1571
 //   gaussian_prop(cov)                    proposal_distribution.hh:165-218
+//   differential_evolution::draw          proposal_distribution.cc:476-801
+//   chain::report_effective_samples       chain.cc:126-643
 
 #include <chrono>
 #include <new>
@@ -657,6 +662,189 @@ static int bench(const char* specfile) {
   return 0;
 }
 
+
+// ----------------------------------------------------------------------------------------------
+// golden-de: the reference's differential_evolution (proposal_distribution.cc:476-801) on the history of a real ladder.
+// A parallel_tempering_chains run with scripted proposals builds the histories; then, for a list of parameter sets, clones
+// of differential_evolution draw for several rungs.  Recorded per draw: the uniforms the caller's generator delivered
+// during the draw (peeked before, their number found afterwards from where the generator stands), the current state, and
+// the proposal's outputs (proposed state, validity, log-Hastings ratio, type).  Together with the dumped histories
+// (states, log-posteriors, log-likelihoods by RAW index; MAP log-posteriors; temperatures) a restatement fed the same
+// uniforms must propose the same states.
+// ----------------------------------------------------------------------------------------------
+static int golden_de() {
+  std::ostringstream js;
+  js << "{\"cases\":[";
+  struct lcase { int D, Nt, Ninit, nsteps; double Tmax, swap_rate, step_scale; };
+  // case 0: short histories (every raw row is eligible); case 1: histories long enough for the ignored early fraction
+  // ((size - 100 dim)(1 - ignore_frac) > 10 dim, proposal_distribution.cc:753-756)
+  const lcase lcs[] = {{3, 4, 32, 40, 50.0, 0.3, 1.1}, {2, 3, 25, 270, 20.0, 0.25, 0.9}};
+  struct vcase { double snooker, g1, bsmall, ignore, alpha, reduce; bool mix; double pmix; };
+  const vcase vcs[] = {
+      {0.0, 0.1, 1e-4, 0.3, 0.0, 1.0, false, 1.0},     // standard moves, the constructor's defaults
+      {1.0, 0.3, 1e-4, 0.3, 0.0, 4.0, false, 1.0},     // snooker moves, reduced gamma
+      {0.1, 0.3, 1e-4, 0.0, 2.0, 4.0, false, 1.0},     // the sampler's recipe (ptmcmc.cc:81-91) with unlikely_alpha on
+      {0.5, 0.3, 1e-4, 0.3, 1.5, 4.0, true, 1.0},      // mixing over the ladder's rungs
+      {0.5, 0.5, 1e-4, 0.2, 0.0, 2.0, true, 3.0},      // ... with mix_temperatures_more
+  };
+  for (size_t ic = 0; ic < sizeof lcs / sizeof lcs[0]; ic++) {
+    const lcase& L = lcs[ic];
+    const int D = L.D, Nt = L.Nt;
+    splitmix g(0xDE0000 + ic);
+    gauss_target tgt;
+    tgt.D = D; tgt.ncalls = 0; tgt.P.assign(D * D, 0.0);
+    {
+      std::vector<double> B(D * D);
+      for (auto& b : B) b = g.sym();
+      for (int i = 0; i < D; i++)
+        for (int j = 0; j < D; j++) {
+          double a = 0;
+          for (int k = 0; k < D; k++) a += B[k * D + i] * B[k * D + j];
+          tgt.P[i * D + j] = a + (i == j ? 0.5 : 0.0);
+        }
+      tgt.like0 = -1.25 * D;
+    }
+    cout_mute mute;
+    ProbabilityDist::setSeed(0.31337 + 0.01 * ic);
+    globalRNG.reset(ProbabilityDist::getPRNG());
+    stateSpace space(D);
+    std::vector<std::string> names, types(D, "uni");
+    std::vector<double> centers(D, 0.0), scales(D);
+    for (int i = 0; i < D; i++) { names.push_back("x" + std::to_string(i)); scales[i] = 6.0 + i; }
+    space.set_names(names);
+    bayes_likelihood like;
+    like.register_reference_object(&tgt);
+    like.register_evaluate_log(gauss_eval);
+    like.basic_setup(&space, types, centers, scales);
+    const sampleable_probability_function* prior = like.getObjectPrior().get();
+    parallel_tempering_chains ptc(Nt, L.Tmax, L.swap_rate, 1, false, false, -30);
+    ptc.initialize(&like, prior, L.Ninit);
+    std::vector<std::vector<std::vector<double>>> deltas(Nt);
+    for (int r = 0; r < Nt; r++) {
+      const double sc = L.step_scale / std::sqrt(std::max(ptc.subchain(r)->invTemp(), 0.02));
+      deltas[r].resize(L.nsteps);
+      for (int k = 0; k < L.nsteps; k++) { deltas[r][k].resize(D); for (int d = 0; d < D; d++) deltas[r][k][d] = g.sym() * sc; }
+    }
+    int nextrung = 0;
+    tape_prop tp(&deltas, &nextrung);
+    ptc.set_proposal(tp);
+    for (int k = 0; k < L.nsteps; k++) ptc.step();
+    js << (ic ? "," : "") << "\n{\"D\":" << D << ",\"Nt\":" << Nt << ",\"ladder_MAPlpost\":" << jnum(ptc.getMAPlpost())
+       << ",\"ladder_dim\":" << ptc.getDim() << ",\"ladder_size\":" << ptc.size() << ",\"scales\":" << jarr(scales) << ",\n\"rungs\":[";
+    for (int r = 0; r < Nt; r++) {
+      chain* c = ptc.subchain(r);
+      js << (r ? "," : "") << "\n {\"invtemp\":" << jnum(c->invTemp()) << ",\"size\":" << c->size() << ",\"MAPlpost\":" << jnum(c->getMAPlpost())
+         << ",\"dim\":" << c->getDim()
+         // what an index outside the saved rows reads (MH_chain::getState / getLogPost / getLogLike, chain.cc:1056-1086): the current values
+         << ",\"cur_x\":" << jarr(c->getState().get_params_vector()) << ",\"cur_lpost\":" << jnum(c->getLogPost()) << ",\"cur_llike\":" << jnum(c->getLogLike())
+         << ",\"x\":[";
+      for (int e = 0; e < c->size(); e++) js << (e ? "," : "") << jarr(c->getState(e, true).get_params_vector());
+      js << "],\"lpost\":[";
+      for (int e = 0; e < c->size(); e++) js << (e ? "," : "") << jnum(c->getLogPost(e, true));
+      js << "],\"llike\":[";
+      for (int e = 0; e < c->size(); e++) js << (e ? "," : "") << jnum(c->getLogLike(e, true));
+      js << "]}";
+    }
+    js << "],\n\"draws\":[";
+    bool firstdraw = true;
+    for (size_t iv = 0; iv < sizeof vcs / sizeof vcs[0]; iv++) {
+      const vcase& V = vcs[iv];
+      for (int r = 0; r < Nt; r++) {
+        differential_evolution de(V.snooker, V.g1, V.bsmall, V.ignore, V.alpha);
+        de.reduce_gamma(V.reduce);
+        de.support_mixing(V.mix);
+        de.mix_temperatures_more(V.pmix);
+        chain* me = ptc.subchain(r);
+        de.set_chain(V.mix ? (chain*)&ptc : me);   // parallel_tempering_chains::set_proposal's rule (chain.cc:1373-1381)
+        const int reps = V.mix ? 3 : 4;
+        for (int rep = 0; rep < reps; rep++) {
+          const int TAPE = 6000;
+          std::vector<double> before = peek_tape(me, TAPE);
+          state s = me->getState();
+          state out = de.draw(s, me);
+          std::vector<double> after = peek_tape(me, 2);
+          int used = -1;
+          for (int p = 0; p + 1 < TAPE; p++) if (before[p] == after[0] && before[p + 1] == after[1]) { used = p; break; }
+          if (used < 0) { fprintf(stderr, "golden-de: a draw consumed more than %d uniforms\n", TAPE); return 2; }
+          std::vector<double> ks(used);
+          for (int p = 0; p < used; p++) ks[p] = before[p] * 4294967296.0 - 0.5;   // MotherOfAll::Next = (k + 0.5) / 2^32: k is exact
+          js << (firstdraw ? "" : ",") << "\n {\"variant\":" << iv << ",\"rung\":" << r << ",\"snooker\":" << jnum(V.snooker) << ",\"gamma_one_frac\":" << jnum(V.g1)
+             << ",\"b_small\":" << jnum(V.bsmall) << ",\"ignore_frac\":" << jnum(V.ignore) << ",\"unlikely_alpha\":" << jnum(V.alpha)
+             << ",\"reduce_gamma\":" << jnum(V.reduce) << ",\"mixing\":" << (V.mix ? 1 : 0) << ",\"mix_factor\":" << jnum(V.pmix)
+             << ",\"uniform_k\":" << jarr(ks) << ",\"x\":" << jarr(s.get_params_vector()) << ",\"proposed\":" << jarr(out.get_params_vector())
+             << ",\"valid\":" << (out.invalid() ? 0 : 1) << ",\"log_hastings\":" << jnum(de.log_hastings_ratio()) << ",\"type\":" << de.type() << "}";
+          firstdraw = false;
+        }
+      }
+    }
+    js << "]}";
+    globalRNG.reset();
+  }
+  js << "]}\n";
+  std::cout << js.str();
+  return 0;
+}
+
+// ----------------------------------------------------------------------------------------------
+// golden-ess: chain::report_effective_samples (chain.cc:126-643) on fixed series.  A minimal chain subclass serves a
+// synthetic history (one saved state per step): AR(1) processes x_t = phi x_(t-1) + e_t per parameter, innovations from
+// the helper stream (so the test regenerates the series from the recorded parameters); expected: (ess, useful length)
+// for several (width, every, esslimit) calls, the coarse-to-fine search of esslimit >= 0 included.
+// ----------------------------------------------------------------------------------------------
+struct series_chain : public chain {
+  const stateSpace* sp;
+  std::vector<std::vector<double>> rows;   // [step][dim]
+  series_chain(const stateSpace* sp_, int dim_) : sp(sp_) { dim = dim_; Nsize = 0; Ninit = 0; Nearliest = 0; reporting = false; }
+  void finish() { Nsize = (int)rows.size(); }
+  int getStep() override { return (int)rows.size(); }
+  state getState(int elem = -1, bool raw_indexing = false) override {
+    if (elem < 0) elem = (int)rows.size() - 1;
+    return state(sp, rows[elem]);
+  }
+};
+
+static int golden_ess() {
+  std::ostringstream js;
+  js << "{\"cases\":[";
+  struct scase { int dim, n; double phi[3]; unsigned long long seed; };
+  const scase scs[] = {{2, 60000, {0.9, 0.5, 0}, 0xE55001ULL}, {3, 150000, {0.98, 0.8, 0.0}, 0xE55002ULL}, {1, 30000, {0.995, 0, 0}, 0xE55003ULL}};
+  struct qcase { int width, every; double esslimit; };
+  const qcase qcs[] = {{40000, 100, -1.0}, {1000, 1, -1.0}, {10000, 10, -1.0}, {1000, 1, 1000.0}, {1000, 1, 2000.0}, {2000, 2, 5000.0}, {500, 5, 700.0}, {3000, 3, 400.0}};
+  for (size_t ic = 0; ic < sizeof scs / sizeof scs[0]; ic++) {
+    const scase& S = scs[ic];
+    std::vector<std::pair<double, int>> res;
+    {
+      cout_mute mute;
+      ProbabilityDist::setSeed(0.5);
+      stateSpace sp(S.dim);
+      series_chain c(&sp, S.dim);
+      splitmix g(S.seed);
+      std::vector<double> x(S.dim, 0.0);
+      for (int t = 0; t < S.n; t++) {
+        for (int d = 0; d < S.dim; d++) {
+          // innovation: sum of four uniforms on (-1, 1) (bell-shaped, exactly reproducible)
+          double e = 0;
+          for (int q = 0; q < 4; q++) e += g.sym();
+          x[d] = S.phi[d] * x[d] + e;
+        }
+        c.rows.push_back(x);
+      }
+      c.finish();
+      for (size_t iq = 0; iq < sizeof qcs / sizeof qcs[0]; iq++) res.push_back(c.report_effective_samples(-1, qcs[iq].width, qcs[iq].every, qcs[iq].esslimit));
+    }
+    js << (ic ? "," : "") << "\n{\"dim\":" << S.dim << ",\"n\":" << S.n << ",\"seed\":\"" << S.seed << "\",\"phi\":[";
+    for (int d = 0; d < S.dim; d++) js << (d ? "," : "") << jnum(S.phi[d]);
+    js << "],\"queries\":[";
+    for (size_t iq = 0; iq < sizeof qcs / sizeof qcs[0]; iq++)
+      js << (iq ? "," : "") << "\n {\"width\":" << qcs[iq].width << ",\"every\":" << qcs[iq].every << ",\"esslimit\":" << jnum(qcs[iq].esslimit)
+         << ",\"ess\":" << jnum(res[iq].first) << ",\"length\":" << res[iq].second << "}";
+    js << "]}";
+  }
+  js << "]}\n";
+  std::cout << js.str();
+  return 0;
+}
+
 int main(int argc, char** argv) {
   if (argc >= 2 && !strcmp(argv[1], "golden-basic")) {
     ProbabilityDist::setSeed(0.224);  // chain() constructors draw their seed from the master generator (chain.hh:58-62)
@@ -673,7 +861,9 @@ int main(int argc, char** argv) {
   }
   if (argc >= 3 && !strcmp(argv[1], "golden-trace")) return golden_trace(atoi(argv[2]));
   if (argc >= 2 && !strcmp(argv[1], "golden-eigen")) return golden_eigen();
+  if (argc >= 2 && !strcmp(argv[1], "golden-de")) return golden_de();
+  if (argc >= 2 && !strcmp(argv[1], "golden-ess")) return golden_ess();
   if (argc >= 3 && !strcmp(argv[1], "bench")) return bench(argv[2]);
-  fprintf(stderr, "usage: %s golden-basic | golden-trace <1..12> | golden-eigen | bench <specfile>\n", argv[0]);
+  fprintf(stderr, "usage: %s golden-basic | golden-trace <1..12> | golden-eigen | golden-de | golden-ess | bench <specfile>\n", argv[0]);
   return 2;
 }

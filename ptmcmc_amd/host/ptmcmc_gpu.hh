@@ -177,6 +177,13 @@ class state {  // states.hh:147-234, states.cc:161-253
   std::vector<double> get_params_vector() const { return std::vector<double>(std::begin(params), std::end(params)); }
   const stateSpace* getSpace() const { return space; }
   bool invalid() const { return !valid; }
+  // The state a chain of state::scalar_mult / state::add operations starting from this one ends in (states.cc:183-214): those
+  // build on the ENFORCED ORIGIN of the space -- valid iff the origin is (quirk Q9) -- and do not enforce their result.
+  state moved_to(const std::vector<double>& x) const {
+    state r(space, size());
+    for (int i = 0; i < size() && i < (int)x.size(); i++) r.params[i] = x[i];
+    return r;
+  }
   // the vector-space operations some proposals rely on (states.cc:194-253; extra_enforcement is off in the reference)
   state add(const state& other) const {
     state result(space, size());
@@ -271,116 +278,153 @@ class ProbabilityDist {   // ProbabilityDist.h:37-48: the master seed every chai
   static uint64_t nextLadderSeed() { const uint64_t n = (uint64_t)ladders_made()++; return engineSeed() ^ (n * 0x9E3779B97F4A7C15ull << 32); }
 };
 
-// ---- options.hh: "--name=value" flags shared by the program's components -------------------------------------------------
-// Own implementation of the reference's interface (options.hh:17-241): Option(name, info, default), Options::add / parse /
-// set / value / print_usage / report, and the Optioned mix-in (addOptions, optValue, optSet).
+// ---- command-line flags ("--name=value", bare "--name" = "true") ------------------------------------------------------------
+// The reference's programs declare their flags through three small classes (options.hh): every component registers
+// Option(name, help, default) objects in one shared Options table (Optioned::addOptions / addOption), main() adds its own and
+// calls Options::parse(argc, argv), and the components read their values back by name (optValue / optSet).  Only that calling
+// surface -- the class and method names and the flag syntax -- is kept; the table below is this build's own: entries in one
+// vector in order of declaration, a name index beside it, and argv compacted in a single pass.
 class Options;
 class Option {
   friend class Options;
-  std::string name, info, value;
-  bool have_default, is_set;
+  enum origin { none, preset, command_line };
+  std::string key, help, text;
+  origin from;
 
  public:
-  Option() : have_default(false), is_set(false) {}
+  Option() : from(none) {}
   Option(const std::string& name, const std::string& info, const std::string& vdefault = "<no default>")
-      : name(name), info(info), value(vdefault), have_default(vdefault != "<no default>"), is_set(false) {}
-  std::string describe() const { return name + "('" + info + "')=" + (have_default ? value : std::string("<no value>")); }
+      : key(name), help(info), text(vdefault == "<no default>" ? std::string() : vdefault), from(vdefault == "<no default>" ? none : preset) {}
+  // one line that identifies the declaration (two declarations of a flag must agree in it)
+  std::string describe() const { return key + "('" + help + "')=" + (from == none ? std::string("<no value>") : text); }
 };
 
 class Options {
-  std::map<std::string, Option> flags;
-  bool dash_dash;
+  std::vector<Option> table;
+  std::map<std::string, size_t> where;
+  std::string lead;   // "--" or "-"
+
+  const Option* find(const std::string& name) const {
+    std::map<std::string, size_t>::const_iterator it = where.find(name);
+    return it == where.end() ? nullptr : &table[it->second];
+  }
+  // is `word` a flag of this table's syntax?  If so its name and, after '=', its value ("true" for a bare flag)
+  bool as_flag(const std::string& word, std::string& name, std::string& val) const {
+    if (word.size() <= lead.size() || word.compare(0, lead.size(), lead) != 0) return false;
+    const size_t eq = word.find('=', lead.size());
+    name = word.substr(lead.size(), eq == std::string::npos ? std::string::npos : eq - lead.size());
+    val = eq == std::string::npos ? std::string("true") : word.substr(eq + 1);
+    return true;
+  }
+  // records a recognised flag; false (and a complaint, if wanted) for one nobody declared
+  bool take(const std::string& name, const std::string& val, bool verbose) {
+    std::map<std::string, size_t>::iterator it = where.find(name);
+    if (it == where.end()) {
+      if (verbose) std::cerr << "Option '" << name << "' not recognized." << std::endl;
+      return false;
+    }
+    table[it->second].text = val;
+    table[it->second].from = Option::command_line;
+    return true;
+  }
 
  public:
-  Options(bool dash_dash = true) : dash_dash(dash_dash) {}
+  Options(bool dash_dash = true) : lead(dash_dash ? "--" : "-") {}
   void add(const Option& opt) {
-    if (exists(opt.name)) {
-      if (opt.describe() != flags[opt.name].describe())
-        std::cout << "Options::add: Warning! Attempt to re-add an option with same name but non-identical information.\n  Retaining original option ("
-                  << flags[opt.name].describe() << ")" << std::endl;
+    if (const Option* have = find(opt.key)) {   // the first declaration stands; a different second one is worth a warning
+      if (have->describe() != opt.describe())
+        std::cout << "Options::add: flag '" << opt.key << "' is declared twice with different help / default; keeping " << have->describe() << std::endl;
       return;
     }
-    flags[opt.name] = opt;
+    where[opt.key] = table.size();
+    table.push_back(opt);
   }
-  bool exists(const std::string& name) const { return flags.count(name) > 0; }
+  bool exists(const std::string& name) const { return find(name) != nullptr; }
+  // true if the flag has a value (given, or a default); the value goes to return_value
   bool set(const std::string& name, std::string& return_value) const {
-    std::map<std::string, Option>::const_iterator it = flags.find(name);
-    if (it == flags.end()) { std::cerr << "Options: Error no option '" << name << "'." << std::endl; return false; }
-    if (it->second.is_set || it->second.have_default) { return_value = it->second.value; return true; }
-    return false;
+    const Option* o = find(name);
+    if (!o) { std::cerr << "Options: Error no option '" << name << "'." << std::endl; return false; }
+    if (o->from == Option::none) return false;
+    return_value = o->text;
+    return true;
   }
-  bool set(const std::string& name) const { std::string dummy; return set(name, dummy); }
-  std::string value(const std::string& name) const { std::string v(""); set(name, v); return v; }
+  bool set(const std::string& name) const { std::string unused; return set(name, unused); }
+  std::string value(const std::string& name) const { std::string v; set(name, v); return v; }
   std::string print_usage() const {
     std::ostringstream os;
     os << "Options:\n";
-    for (std::map<std::string, Option>::const_iterator i = flags.begin(); i != flags.end(); ++i) {
-      const std::string flag = std::string(dash_dash ? "  --" : "  -") + i->second.name;
-      os << flag << std::string(flag.size() < 24 ? 24 - flag.size() : 1, ' ') << "\t" << i->second.info << "\n";
+    for (std::map<std::string, size_t>::const_iterator it = where.begin(); it != where.end(); ++it) {   // by name
+      std::string head = "  " + lead + it->first;
+      if (head.size() < 26) head.resize(26, ' ');
+      os << head << "  " << table[it->second].help << "\n";
     }
     return os.str();
   }
-  // recognised flags are recorded and removed from argv; returns true if an unknown flag was met (as the reference: "fail")
+  // Flags this table knows are recorded and taken out of argv (argc shrinks); every other word stays where it is, in order.
+  // Returns true if some word looked like a flag but was not declared (the caller may have a second table for those).
   bool parse(int& argc, char* argv[], bool verbose = true) {
-    bool fail = false;
-    int i = 1;
-    while (i < argc) {
-      const std::string a(argv[i]);
-      if (a.empty() || a[0] != '-' || (dash_dash && (a.size() <= 1 || a[1] != '-'))) { i++; continue; }
-      const std::string flag = a.substr(dash_dash ? 2 : 1);
-      const size_t pos = flag.find('=');
-      const std::string name = flag.substr(0, pos);
-      if (!flags.count(name)) {
-        if (verbose) std::cerr << "Option '" << name << "' not recognized." << std::endl;
-        fail = true;
-        i++;
-        continue;
+    bool unknown = false;
+    int kept = argc > 0 ? 1 : 0;
+    for (int i = kept; i < argc; i++) {
+      std::string name, val;
+      if (as_flag(argv[i], name, val)) {
+        if (take(name, val, verbose)) continue;
+        unknown = true;
       }
-      Option& o = flags[name];
-      o.is_set = true;
-      o.value = pos == std::string::npos ? std::string("true") : flag.substr(pos + 1);
-      for (int ic = i; ic < argc - 1; ic++) argv[ic] = argv[ic + 1];
-      argc--;
+      argv[kept++] = argv[i];
     }
-    return fail;
+    argc = kept;
+    return unknown;
+  }
+  // the same on a vector of words that does not start with the program name
+  bool parse(std::vector<std::string>& words, bool verbose = true) {
+    bool unknown = false;
+    std::vector<std::string> rest;
+    for (size_t i = 0; i < words.size(); i++) {
+      std::string name, val;
+      if (as_flag(words[i], name, val)) {
+        if (take(name, val, verbose)) continue;
+        unknown = true;
+      }
+      rest.push_back(words[i]);
+    }
+    words.swap(rest);
+    return unknown;
   }
   std::string report() const {
     std::ostringstream s;
-    for (std::map<std::string, Option>::const_iterator it = flags.begin(); it != flags.end(); ++it)
-      s << " " << it->first << ':' << (it->second.is_set ? it->second.value : std::string("(not set)")) << '\n';
+    for (std::map<std::string, size_t>::const_iterator it = where.begin(); it != where.end(); ++it) {
+      const Option& o = table[it->second];
+      s << " " << it->first << ':' << (o.from == Option::command_line ? o.text : std::string("(not set)")) << '\n';
+    }
     return s.str();
   }
 };
 
-class Optioned {   // options.hh:196-240
-  std::string prefix;
-  Options* opt;
-  bool have_options;
+// mix-in of every component that declares flags: addOptions(table, prefix) binds it to the program's table, addOption declares,
+// optValue / optGetValue / optSet read back
+class Optioned {
+  Options* bound;
+  std::string scope;   // prefix of this component's flag names
+
+  Options& options() const {
+    if (!bound) { std::cout << "Optioned: addOptions() has not been called for this object; it has no flags to read." << std::endl; exit(1); }
+    return *bound;
+  }
 
  protected:
-  void copyOptioned(const Optioned& other) { prefix = other.prefix; opt = other.opt; have_options = other.have_options; }
-  void check_opt() const {
-    if (!have_options) { std::cout << "Optioned::check_opt: Must call Optioned::addOptions() before using options." << std::endl; exit(1); }
-  }
-  void addOption(const std::string& name, const std::string& info, const std::string& vdefault = "<no default>") {
-    check_opt();
-    opt->add(Option(prefix + name, info, vdefault));
-  }
+  void copyOptioned(const Optioned& other) { bound = other.bound; scope = other.scope; }
+  void addOption(const std::string& name, const std::string& info, const std::string& vdefault = "<no default>") { options().add(Option(scope + name, info, vdefault)); }
 
  public:
-  Optioned() : opt(nullptr), have_options(false) {}
+  Optioned() : bound(nullptr) {}
   virtual ~Optioned() {}
-  virtual void addOptions(Options& opts, const std::string& prefix_ = "") { opt = &opts; prefix = prefix_; have_options = true; }
-  bool haveOptions() const { return have_options; }
-  std::unique_ptr<std::istringstream> optValue(const std::string& name) {
-    check_opt();
-    return std::unique_ptr<std::istringstream>(new std::istringstream(opt->value(prefix + name)));
-  }
-  void optGetValue(const std::string& name, int& val) { *optValue(name) >> val; }
-  void optGetValue(const std::string& name, double& val) { *optValue(name) >> val; }
-  void optGetValue(const std::string& name, std::string& val) { *optValue(name) >> val; }
-  bool optSet(const std::string& name) { check_opt(); return opt->set(prefix + name); }
-  std::string reportOptions() { check_opt(); return opt->report(); }
+  virtual void addOptions(Options& opts, const std::string& prefix_ = "") { bound = &opts; scope = prefix_; }
+  bool haveOptions() const { return bound != nullptr; }
+  std::unique_ptr<std::istringstream> optValue(const std::string& name) { return std::unique_ptr<std::istringstream>(new std::istringstream(options().value(scope + name))); }
+  template <class T> void optGetValue(const std::string& name, T& val) { *optValue(name) >> val; }
+  bool optSet(const std::string& name) { return options().set(scope + name); }
+  std::string reportOptions() { return options().report(); }
 };
 
 // ---- probability_function.hh --------------------------------------------------------------------------------------
@@ -954,150 +998,181 @@ class user_gaussian_prop : public proposal_distribution {
   }
 };
 
-// proposal_distribution_set (proposal_distribution.hh:306-349, .cc:37-166): draws member i with probability share_i; shares may
-// adapt to the members' acceptance (adapt_rate) and change with the chain's temperature (Tpow, hot_shares).
+// proposal_distribution_set (the interface of proposal_distribution.hh:306-349): a weighted mixture of proposals.  One uniform
+// of the caller's stream picks a member; its draw, log-Hastings ratio and type (reported as member + 10 x type) become the
+// set's.  The weights may adapt to the members' acceptance (adapt_rate: a member that repeats its last outcome -- two accepts
+// or two rejects in a row -- loses a little weight, which steers every member towards a mid-range acceptance rate; the pick
+// thresholds are rebuilt every 10 x members outcomes) and may depend on the chain's temperature (Tpow, hot_shares: weight
+// share + (hot_share - share)(1 - beta^Tpow)).
 // On the device: members that are all gaussian_props and scalar multiples of the first one (the sampler's default Gaussian
-// recipe, ptmcmc.cc:117-139, is exactly that) -- the rung keeps ONE factor and a table of scales; anything else is drawn here.
+// recipe is exactly that) -- the rung keeps ONE factor and a table of scales; anything else is drawn here, on the host.
 class proposal_distribution_set : public proposal_distribution {
-  int Nsize;
-  std::vector<proposal_distribution*> proposals;
-  std::vector<double> shares, bin_max;
-  double adapt_rate;
-  std::vector<bool> last_accepted;
-  int adapt_count, adapt_every, last_dist;
-  bool own_pointers;
-  double Tpow;
-  std::vector<double> hot_shares;
-  void reset_bins() {   // .cc:37-59
-    double Tfac = 0;
-    if (Tpow > 0) {
-      if (!ch) std::cout << "proposal_distribution_set::reset_bins(): Thermal scaling requires that chain must be set for proposal." << std::endl;
-      else Tfac = 1 - std::pow(ch->invTemp(), Tpow);
+  struct slot {
+    proposal_distribution* prop;
+    double weight;       // cold share, kept normalised
+    double hot_weight;   // share in the hot limit (thermal sets only)
+    bool repeated;       // outcome of this member's previous proposal (accepted?)
+  };
+  std::vector<slot> slots;
+  std::vector<double> upper;   // pick thresholds: member i is taken by a uniform below upper[i]; upper.back() == 1
+  double adapt_rate, thermal_power;
+  int outcomes_seen, rebuild_after, current;
+  bool owner;
+
+  // weights -> thresholds.  The weights are renormalised in place; a thermal set moves each threshold towards the hot share by
+  // the chain's (1 - beta^Tpow) and then rescales so that the last threshold is exactly 1.
+  void rebuild_thresholds() {
+    double warm = 0;
+    if (thermal_power > 0) {
+      if (ch) warm = 1 - std::pow(ch->invTemp(), thermal_power);
+      else std::cout << "proposal_distribution_set: temperature-dependent shares need the chain (set_chain) -- using the cold shares." << std::endl;
     }
-    double sum = 0;
-    for (int i = 0; i < Nsize; i++) sum += shares[i];
-    double last = 0;
-    for (int i = 0; i < Nsize; i++) {
-      shares[i] /= sum;
-      bin_max[i] = last + shares[i];
-      if (Tpow > 0) bin_max[i] += (hot_shares[i] - shares[i]) * Tfac;
-      last = bin_max[i];
+    double total = 0;
+    for (size_t i = 0; i < slots.size(); i++) total += slots[i].weight;
+    double edge = 0;
+    for (size_t i = 0; i < slots.size(); i++) {
+      slot& m = slots[i];
+      m.weight /= total;
+      edge = edge + m.weight;
+      if (thermal_power > 0) edge += (m.hot_weight - m.weight) * warm;
+      upper[i] = edge;
     }
-    for (auto& bin : bin_max) bin /= bin_max.back();
+    const double top = upper.back();
+    for (size_t i = 0; i < upper.size(); i++) upper[i] /= top;
+  }
+  // bookkeeping shared by accept() and reject()
+  void outcome(bool accepted) {
+    slot& m = slots[current];
+    if (adapt_rate != 0) {
+      if (m.repeated == accepted) m.weight *= 1 - adapt_rate * 0.25;
+      m.repeated = accepted;
+      if (++outcomes_seen >= rebuild_after) rebuild_thresholds();
+    }
+    if (accepted) m.prop->accept(); else m.prop->reject();
+  }
+  std::vector<double> weights(bool hot) const {
+    std::vector<double> w(slots.size());
+    for (size_t i = 0; i < slots.size(); i++) w[i] = hot ? slots[i].hot_weight : slots[i].weight;
+    return w;
   }
 
  public:
-  // takes the pointers (as the reference does with take_pointers = true, its default); clone() deep-copies the members
+  // takes the pointers (take_pointers = true, the reference's default: the set deletes its members); clone() deep-copies
   proposal_distribution_set(const std::vector<proposal_distribution*>& props, const std::vector<double>& shares_, double adapt_rate = 0, double Tpow = 0,
                             std::vector<double> hot_shares_ = std::vector<double>(), bool take_pointers = true)
-      : shares(shares_), adapt_rate(adapt_rate), own_pointers(take_pointers), Tpow(Tpow), hot_shares(hot_shares_) {
-    if (props.size() != shares.size() || props.empty()) { std::cout << "proposal_distribution_set(constructor): Array sizes mismatched.\n"; exit(1); }
-    Nsize = shares.size();
+      : adapt_rate(adapt_rate), thermal_power(Tpow), outcomes_seen(0), rebuild_after(10 * (int)props.size()), current(0), owner(take_pointers) {
+    if (props.empty() || props.size() != shares_.size()) { std::cout << "proposal_distribution_set: " << props.size() << " proposals but " << shares_.size() << " shares." << std::endl; exit(1); }
+    bool hot_ok = false;
+    double hot_total = 0;
     if (Tpow > 0) {
-      double sum = 0;
-      for (size_t i = 0; i < hot_shares.size(); i++) sum += hot_shares[i];
-      if ((int)hot_shares.size() != Nsize || sum <= 0) { std::cout << "proposal_distirubtion_set::With Tpow>0 need to provide hot_shares with sum>0" << std::endl; hot_shares = shares; }
-      else for (int i = 0; i < Nsize; i++) hot_shares[i] /= sum;
+      for (size_t i = 0; i < hot_shares_.size(); i++) hot_total += hot_shares_[i];
+      hot_ok = hot_shares_.size() == props.size() && hot_total > 0;
+      if (!hot_ok) std::cout << "proposal_distribution_set: Tpow > 0 needs one hot share per member with a positive sum -- using the cold shares." << std::endl;
     }
-    bin_max.resize(Nsize);
-    reset_bins();
-    for (int i = 0; i < Nsize; i++) proposals.push_back(props[i]);
-    last_type = 0; last_dist = 0;
-    last_accepted.resize(Nsize, true);
-    adapt_count = 0;
-    adapt_every = 10 * Nsize;
+    for (size_t i = 0; i < props.size(); i++) {
+      slot m;
+      m.prop = props[i]; m.weight = shares_[i]; m.repeated = true;
+      m.hot_weight = Tpow > 0 ? (hot_ok ? hot_shares_[i] / hot_total : shares_[i]) : 0.0;
+      slots.push_back(m);
+    }
+    upper.assign(slots.size(), 0.0);
+    rebuild_thresholds();
+    last_type = 0;
   }
-  ~proposal_distribution_set() { if (own_pointers) for (auto p : proposals) delete p; }
+  ~proposal_distribution_set() { if (owner) for (size_t i = 0; i < slots.size(); i++) delete slots[i].prop; }
   proposal_distribution_set(const proposal_distribution_set&) = delete;
-  proposal_distribution_set* clone() const override {   // .cc:28-35
+  proposal_distribution_set* clone() const override {
     std::vector<proposal_distribution*> copies;
-    for (auto p : proposals) copies.push_back(p->clone());
-    proposal_distribution_set* c = new proposal_distribution_set(copies, shares, adapt_rate, Tpow, hot_shares, true);
-    c->last_accepted = last_accepted; c->adapt_count = adapt_count;
+    for (size_t i = 0; i < slots.size(); i++) copies.push_back(slots[i].prop->clone());
+    proposal_distribution_set* c = new proposal_distribution_set(copies, weights(false), adapt_rate, thermal_power, weights(true), true);
+    for (size_t i = 0; i < slots.size(); i++) c->slots[i].repeated = slots[i].repeated;
+    c->outcomes_seen = outcomes_seen;
     return c;
   }
-  void set_chain(chain* c) override { ch = c; for (int i = 0; i < Nsize; i++) proposals[i]->set_chain(c); reset_bins(); }
-  bool support_mixing() override { for (auto p : proposals) if (p->support_mixing()) return true; return false; }
-  // .cc:99-129: one uniform picks the first READY member with x < bin_max; type = member + 10 * (member's type)
+  void set_chain(chain* c) override {
+    ch = c;
+    for (size_t i = 0; i < slots.size(); i++) slots[i].prop->set_chain(c);
+    rebuild_thresholds();   // (a thermal set now knows its temperature)
+  }
+  bool support_mixing() override {
+    for (size_t i = 0; i < slots.size(); i++) if (slots[i].prop->support_mixing()) return true;
+    return false;
+  }
+  // The pick: a set of one member draws no uniform (so that it IS its member, random stream included); otherwise the first
+  // member that is ready and whose threshold lies above the uniform.  If the uniform falls to members that are not ready
+  // (differential evolution before its history is long enough) another uniform is drawn -- a hundred times at most.
   state draw(state& s, chain* caller) override {
     Random& rng = *caller->getPRNG();
-    int count = 0;
-    while (true) {
-      double x = 0;
-      if (Nsize > 1) x = rng.Next();
-      for (int i = 0; i < Nsize; i++) {
-        if (proposals[i]->is_ready() && x < bin_max[i]) {
-          state out = proposals[i]->draw(s, caller);
-          log_hastings = proposals[i]->log_hastings_ratio();
-          last_type = i + 10 * proposals[i]->type();
-          last_dist = i;
-          return out;
-        }
+    for (int attempt = 0; attempt <= 100; attempt++) {
+      const double u = slots.size() > 1 ? rng.Next() : 0.0;
+      for (size_t i = 0; i < slots.size(); i++) {
+        proposal_distribution* p = slots[i].prop;
+        if (!(u < upper[i]) || !p->is_ready()) continue;
+        state proposed = p->draw(s, caller);
+        log_hastings = p->log_hastings_ratio();
+        last_type = (int)i + 10 * p->type();
+        current = (int)i;
+        return proposed;
       }
-      if (++count > 100) { std::cout << "propsal_distribution_set::draw: Hmmm... Seems that (nearly?) none of the proposals are ready;\n"; exit(1); }
     }
+    std::cout << "proposal_distribution_set::draw: no member was ready to draw in 100 attempts." << std::endl;
+    exit(1);
   }
-  void accept() override {   // .cc:131-148
-    proposal_distribution::accept();
-    if (adapt_rate == 0) { proposals[last_dist]->accept(); return; }
-    if (last_accepted[last_dist]) shares[last_dist] *= 1 - adapt_rate * 0.25;
-    last_accepted[last_dist] = true;
-    if (++adapt_count >= adapt_every) reset_bins();
-    proposals[last_dist]->accept();
-  }
-  void reject() override {   // .cc:150-166
-    proposal_distribution::reject();
-    if (adapt_rate == 0) { proposals[last_dist]->reject(); return; }
-    if (!last_accepted[last_dist]) shares[last_dist] *= 1 - adapt_rate * 0.25;
-    last_accepted[last_dist] = false;
-    if (++adapt_count >= adapt_every) reset_bins();
-    proposals[last_dist]->reject();
-  }
-  void checkpoint(std::string path) override { for (auto p : proposals) p->checkpoint(path); }
-  void restart(std::string path) override { for (auto p : proposals) p->restart(path); }
+  void accept() override { proposal_distribution::accept(); outcome(true); }
+  void reject() override { proposal_distribution::reject(); outcome(false); }
+  void checkpoint(std::string path) override { for (size_t i = 0; i < slots.size(); i++) slots[i].prop->checkpoint(path); }
+  void restart(std::string path) override { for (size_t i = 0; i < slots.size(); i++) slots[i].prop->restart(path); }
   std::string show() override {
     std::ostringstream ss;
     ss << "ChooseFrom(";
-    double last = 0;
-    for (int i = 0; i < Nsize; i++) { ss << "  " << (bin_max[i] - last) * 100. << "% : " << proposals[i]->show() << "\n"; last = bin_max[i]; }
+    for (size_t i = 0; i < slots.size(); i++) ss << "  " << (upper[i] - (i ? upper[i - 1] : 0.0)) * 100. << "% : " << slots[i].prop->show() << "\n";
     ss << ")\n";
     return ss.str();
   }
-  std::string report(int style = 0) override {   // .cc:212-240
+  // style 0: acceptance of the set and of every member; style 1: the current pick probabilities
+  std::string report(int style = 0) override {
     std::ostringstream ss;
     if (style == 0) {
-      ss << proposal_distribution::report(style) << ":[" << proposals[0]->report(style);
-      for (int i = 1; i < Nsize; i++) ss << "," << proposals[i]->report(style);
+      ss << proposal_distribution::report(0) << ":[";
+      for (size_t i = 0; i < slots.size(); i++) ss << (i ? "," : "") << slots[i].prop->report(0);
       ss << "]";
     } else if (style == 1) {
-      ss << "shares=[" << bin_max[0];
-      for (int i = 1; i < Nsize; i++) ss << "," << bin_max[i] - bin_max[i - 1];
+      ss << "shares=[";
+      for (size_t i = 0; i < slots.size(); i++) {
+        ss << (i ? "," : "") << upper[i] - (i ? upper[i - 1] : 0.0);
+        const std::string inner = slots[i].prop->report(1);
+        if (!inner.empty()) ss << ":" << inner;
+      }
       ss << "]";
     }
     return ss.str();
   }
-  std::vector<proposal_distribution*> members() const { return proposals; }
+  std::vector<proposal_distribution*> members() const {
+    std::vector<proposal_distribution*> v;
+    for (size_t i = 0; i < slots.size(); i++) v.push_back(slots[i].prop);
+    return v;
+  }
   bool device_describe(int dim, int& kind, std::vector<double>& f, double& odf) const override {
-    if (adapt_rate != 0 || Tpow > 0) return false;   // shares that move are the host's business
-    if (!proposals[0]->device_describe(dim, kind, f, odf)) return false;
+    if (adapt_rate != 0 || thermal_power > 0) return false;   // shares that move are the host's business
+    if (!slots[0].prop->device_describe(dim, kind, f, odf)) return false;
     std::vector<double> cum, sc, od;
     if (!device_describe_mixture(dim, cum, sc, od)) return false;
     odf = 0;   // the members' oneDfracs live in the mixture table
     return true;
   }
   bool device_describe_mixture(int dim, std::vector<double>& cum, std::vector<double>& scales, std::vector<double>& odfs) const override {
-    if (adapt_rate != 0 || Tpow > 0) return false;
+    if (adapt_rate != 0 || thermal_power > 0) return false;
     int kind0; double odf0; std::vector<double> f0;
-    if (!proposals[0]->device_describe(dim, kind0, f0, odf0)) return false;
+    if (!slots[0].prop->device_describe(dim, kind0, f0, odf0)) return false;
     cum.clear(); scales.clear(); odfs.clear();
-    for (size_t i = 0; i < proposals.size(); i++) {
+    for (size_t i = 0; i < slots.size(); i++) {
       int kind; double odf; std::vector<double> f;
-      if (!proposals[i]->device_describe(dim, kind, f, odf) || kind != kind0 || f.size() != f0.size()) return false;
+      if (!slots[i].prop->device_describe(dim, kind, f, odf) || kind != kind0 || f.size() != f0.size()) return false;
       double sc = 0;
       for (size_t k = 0; k < f.size(); k++) if (f0[k] != 0) { sc = f[k] / f0[k]; break; }
       for (size_t k = 0; k < f.size(); k++)
         if (std::fabs(f[k] - sc * f0[k]) > 1e-12 * (std::fabs(f[k]) + std::fabs(sc * f0[k])) + 1e-300) return false;   // not a multiple
-      cum.push_back(i + 1 == proposals.size() ? 1.0 : bin_max[i]);
+      cum.push_back(i + 1 == slots.size() ? 1.0 : upper[i]);
       scales.push_back(sc);
       odfs.push_back(odf);
     }
@@ -1105,154 +1180,313 @@ class proposal_distribution_set : public proposal_distribution {
   }
 };
 
-// differential_evolution (proposal_distribution.hh:351-414, .cc:476-801; ter Braak & Vrugt 2008): jumps along the difference of
-// two states drawn from the chain's own history, optionally the "snooker" variant with its non-trivial Hastings ratio.  Needs
-// the chain history -- on this build the ladder keeps a host mirror of what MH_chain::add_state saves when a host-side proposal
-// is in use (parallel_tempering_chains::sync_history).
+// differential_evolution (the interface of proposal_distribution.hh:351-414): DE-MC with sampling from the past, ter Braak &
+// Vrugt, Stat. Comput. 18 (2008) 435 -- the jump is a multiple of the difference of two states drawn from the saved history.
+//   parallel-direction move (eq. 2):  x* = x + gamma (z1 - z2),  gamma = 1.68 / sqrt(d) / reduce_gamma, or 1 with probability
+//                                     gamma_one_frac (unit jumps hop between modes); symmetric, log-Hastings 0, type 0
+//   snooker move (eq. 3-4):           z drawn from the history (until z != x), x* = x + gamma ((z1 - z2) . e) e / |e|^2 with
+//                                     e = x - z, gamma uniform on (1.2, 2.2) / reduce_gamma; log-Hastings
+//                                     (d - 1)/2 (ln |x* - z|^2 - ln |x - z|^2), type 1
+// How the reference's implementation behaves (proposal_distribution.cc:476-801), and this one with it -- pinned draw by draw
+// against the reference by tests/golden/trace13.json.gz:
+//   * rows are taken uniformly from the RAW history [start, size): start > 0 only once (size - 100 d)(1 - ignore_frac) > 10 d,
+//     then start = (size - 100 d) ignore_frac; the proposal is ready when the history holds 10 d rows;
+//   * unlikely_alpha > 0: a row whose log-posterior lies below (MAP - d) is kept with probability exp(alpha (lpost - MAP + d)),
+//     alpha shrinking by 0.9 per refusal.  The MAP and the log-posteriors are those of the proposal's OWN chain (set_chain),
+//     also when the row index was drawn for the length of another rung's history;
+//   * support_mixing: each history state comes from a rung of the ladder picked with weight exp(min(0, -(L0 - a Lmed) / mix)),
+//     a = beta_caller - beta_rung, L0 = ln mean exp(a l) over ten rows (log-likelihoods read from the CALLER's history at
+//     indices drawn for the rung's length, non-finite ones redrawn), Lmed the median (6th of 10, sorted) of ten of the rung's
+//     own log-likelihoods;
+//   * the small Gaussian jump of eq. 2 (b_small) is drawn by the reference and then dropped (its sum is never assigned), so no
+//     proposal depends on it: it is not drawn here.
+// Needs the chain history -- on this build the ladder keeps a host mirror of what MH_chain::add_state saves when a host-side
+// proposal is in use (parallel_tempering_chains::sync_history).
 class differential_evolution : public proposal_distribution {
-  bool have_chain;
-  int dim;
-  double gamma_one_frac, reduce_gamma_fac, b_small, ignore_frac, unlikely_alpha, snooker;
-  bool do_support_mixing;
-  double temperature_mixing_factor;
-  int get_min_start_size() { return dim * 10; }
-  int get_min_cut_size() { return dim * 100; }
+  double p_snooker, p_unit_gamma, jump_noise, skip_early, discount, gamma_divisor, mix_strength;
+  bool mixing, bound_to_chain;
+  int d;
 
-  int draw_i_from_chain(chain* caller, chain* c) {   // .cc:742-778
-    Random& rng = *caller->getPRNG();
-    if (!is_ready()) { std::cout << "differential_evolution:draw_i_from_chain: Chain is not ready. Verify readiness with is_ready() before drawing.\n"; exit(1); }
-    const int size = c->size();
-    int start = 0;
-    const int mins = get_min_start_size(), minc = get_min_cut_size();
-    if ((size - minc) * (1 - ignore_frac) > mins) start = (int)((size - minc) * ignore_frac);
-    const double lpost0 = ch->getMAPlpost() - ch->getDim();
-    double alpha = unlikely_alpha;
-    while (true) {
-      double xrnd = rng.Next();
-      const int index = (int)(start + (size - start) * xrnd);
-      const double lpost = ch->getLogPost(index, true);
-      if (alpha > 0 && lpost0 > lpost) {
-        const double p = std::exp(alpha * (lpost - lpost0));
-        xrnd = rng.Next();
-        if (xrnd < p) return index;
-        alpha *= 0.9;
-      } else return index;
+  int rows_to_start() const { return 10 * d; }
+  int rows_before_skipping() const { return 100 * d; }
+  void must_be_ready() {
+    if (is_ready()) return;
+    if (bound_to_chain) std::cout << "differential_evolution: the history holds " << ch->size() << " rows, " << rows_to_start() << " are needed" << std::endl;
+    else std::cout << "differential_evolution: no chain was set" << std::endl;
+    std::cout << "differential_evolution: drawing before is_ready() -- check is_ready() first." << std::endl;
+    exit(1);
+  }
+  // a raw row index of `source`'s history, by the uniforms of `who`
+  int pick_row(chain* who, chain* source) {
+    must_be_ready();
+    Random& u = *who->getPRNG();
+    const int rows = source->size();
+    const int spare = rows - rows_before_skipping();
+    const int first = spare * (1 - skip_early) > rows_to_start() ? (int)(spare * skip_early) : 0;
+    const double floor_lpost = ch->getMAPlpost() - ch->getDim();
+    for (double strictness = discount;; strictness *= 0.9) {
+      const int row = (int)(first + (rows - first) * u.Next());
+      if (!(strictness > 0)) return row;
+      const double lpost = ch->getLogPost(row, true);
+      if (!(floor_lpost > lpost)) return row;
+      if (u.Next() < std::exp(strictness * (lpost - floor_lpost))) return row;
     }
   }
-  state draw_from_chain(chain* caller) {   // .cc:593-740
-    Random& rng = *caller->getPRNG();
-    if (!is_ready()) { std::cout << "differential_evolution:draw_from_chain: Chain is not ready. Verify readiness with is_ready() before drawing.\n"; exit(1); }
-    const int nchains = ch->multiplicity();
-    if (nchains == 1 || !do_support_mixing) {
-      const int index = draw_i_from_chain(caller, ch);
-      return ch->getState(index, true);
+  // weight of rung `rung` as a source of history for a caller at inverse temperature beta_caller
+  double rung_weight(chain* who, chain* rung, double beta_caller, bool& same_temperature) {
+    const int nprobe = 10;
+    double probe[nprobe], lo = 1e100, hi = -1e100;
+    for (int got = 0; got < nprobe;) {
+      const double l = who->getLogLike(pick_row(who, rung), true);
+      if (!std::isfinite(l)) continue;
+      if (l > hi) hi = l;
+      if (l < lo) lo = l;
+      probe[got++] = l;
     }
-    // mixing of history from the parallel chains: weight chain i by an estimate of how much of its typical region matters at
-    // the caller's temperature (.cc:607-700)
-    std::vector<double> k(nchains + 1);
-    const int Nmean = 10, Nmedian = 10;
-    const double pmix = temperature_mixing_factor;
-    std::vector<double> l0(Nmean);
-    const double beta = caller->invTemp();
-    k[0] = 0;
-    int ithis = 0;
-    chain* ci = nullptr;
-    for (int i = 0; i < nchains; i++) {
-      ci = ch->subchain(i);
-      double l0max = -1e100, l0min = 1e100;
-      for (int j = 0, guard = 0; j < Nmean && guard < 10000; j++, guard++) {
-        const int index = draw_i_from_chain(caller, ci);
-        const double dl = caller->getLogLike(index, true);
-        if (std::isfinite(dl)) { if (dl > l0max) l0max = dl; if (dl < l0min) l0min = dl; l0[j] = dl; }
-        else j--;
-      }
-      const double alpha = ci->invTemp();
-      double amb = -(alpha - beta);
-      if (amb == 0) ithis = i;
-      double sum = 0;
-      const double l0scale = amb < 0 ? l0min : l0max;
-      for (int ii = 0; ii < Nmean; ii++) sum += std::exp((l0[ii] - l0scale) * amb);
-      const double ll0 = std::log(sum / Nmean) + l0scale * amb;
-      std::vector<double> l(Nmedian);
-      for (int j = 0; j < Nmedian; j++) { const int index = draw_i_from_chain(caller, ci); l[j] = ci->getLogLike(index, true); }
-      std::sort(l.begin(), l.end());
-      const double ll = l[Nmedian / 2];
-      double lk = -(ll0 - ll * amb);
-      lk /= pmix;
-      if (lk > 0) lk = 0;
-      k[i + 1] = k[i] + std::exp(lk);
-    }
-    int ipick = ithis;
-    const double xrnd = rng.Next() * k[nchains];
-    for (int i = 0; i < nchains; i++) if (xrnd <= k[i + 1]) { ipick = i; break; }
-    ci = ch->subchain(ipick);
-    const int index = draw_i_from_chain(caller, ci);
-    return ci->getState(index, true);
+    const double a = -(rung->invTemp() - beta_caller);
+    same_temperature = a == 0;
+    const double pivot = a < 0 ? lo : hi;   // keeps every exponent below <= 0
+    double acc = 0;
+    for (int i = 0; i < nprobe; i++) acc += std::exp((probe[i] - pivot) * a);
+    const double log_mean = std::log(acc / nprobe) + pivot * a;
+    std::vector<double> own(nprobe);
+    for (int i = 0; i < nprobe; i++) own[i] = rung->getLogLike(pick_row(who, rung), true);
+    std::sort(own.begin(), own.end());
+    double lw = -(log_mean - own[nprobe / 2] * a);
+    lw /= mix_strength;
+    return std::exp(lw > 0 ? 0.0 : lw);
   }
-  state draw_standard(state& s, chain* caller) {   // .cc:488-532, ter Braak 08 eq. 2
-    Random& rng = *caller->getPRNG();
-    double gamma = 1.68 / std::sqrt((double)dim) / reduce_gamma_fac;
-    const double xgamma = rng.Next();
-    if (xgamma < gamma_one_frac) gamma = 1;
-    state s1 = draw_from_chain(caller);
-    state s2 = draw_from_chain(caller);
-    std::vector<double> e(dim);
-    for (int i = 0; i < dim; i++) e[i] = detail::normal_from(rng);   // drawn as in the reference; its small jump is then
-    state prop = s;                                                  // DISCARDED there (prop.add(...) result unused, .cc:523)
-    prop = prop.add(s1.scalar_mult(gamma));
-    prop = prop.add(s2.scalar_mult(-gamma));
+  // one state of the history, as a parameter vector
+  std::vector<double> pick_state(chain* who) {
+    must_be_ready();
+    const int nrungs = ch->multiplicity();
+    if (nrungs == 1 || !mixing) return ch->getState(pick_row(who, ch), true).get_params_vector();
+    std::vector<double> reach(nrungs + 1, 0.0);
+    const double beta = who->invTemp();
+    int own_rung = 0;
+    for (int r = 0; r < nrungs; r++) {
+      bool same = false;
+      reach[r + 1] = reach[r] + rung_weight(who, ch->subchain(r), beta, same);
+      if (same) own_rung = r;
+    }
+    const double mark = who->getPRNG()->Next() * reach[nrungs];
+    int from = own_rung;
+    for (int r = 0; r < nrungs; r++) if (mark <= reach[r + 1]) { from = r; break; }
+    chain* rung = ch->subchain(from);
+    return rung->getState(pick_row(who, rung), true).get_params_vector();
+  }
+  static double dot(const std::vector<double>& a, const std::vector<double>& b) {
+    double t = 0;
+    for (size_t i = 0; i < a.size(); i++) t += a[i] * b[i];
+    return t;
+  }
+  // v + c w, elementwise (the product rounded before the sum, as state::scalar_mult followed by state::add does it)
+  static std::vector<double> plus_scaled(const std::vector<double>& v, const std::vector<double>& w, double c) {
+    std::vector<double> r(v.size());
+    for (size_t i = 0; i < v.size(); i++) { const double t = w[i] * c; r[i] = v[i] + t; }
+    return r;
+  }
+  state parallel_move(state& s, chain* who) {
+    Random& u = *who->getPRNG();
+    const double gamma = u.Next() < p_unit_gamma ? 1.0 : 1.68 / std::sqrt((double)d) / gamma_divisor;
+    const std::vector<double> z1 = pick_state(who), z2 = pick_state(who);
+    std::vector<double> x = plus_scaled(s.get_params_vector(), z1, gamma);
+    x = plus_scaled(x, z2, -gamma);
     log_hastings = 0;
     last_type = 0;
-    return prop;
+    return s.moved_to(x);
   }
-  state draw_snooker(state& s, chain* caller) {   // .cc:534-591, ter Braak 08 eq. 3-4
-    Random& rng = *caller->getPRNG();
-    const double xgamma = rng.Next();
-    const double gamma = (1.2 + xgamma) / reduce_gamma_fac;
-    double smznorm2 = 0;
-    state minusz = s, smz = s;
-    int isafe = 0;
-    while (smznorm2 == 0) {
-      state z = draw_from_chain(caller);
-      minusz = z.scalar_mult(-1);
-      smz = s.add(minusz);
-      smznorm2 = smz.innerprod(smz);
-      if (++isafe > 1000) { std::cout << "differential_evolution::draw_snooker: We seem to be stuck in an infinite loop.  Bailing out!" << std::endl; exit(1); }
+  state snooker_move(state& s, chain* who) {
+    const double gamma = (1.2 + who->getPRNG()->Next()) / gamma_divisor;
+    const std::vector<double> x = s.get_params_vector();
+    std::vector<double> z, axis;
+    double axis2 = 0;
+    for (int tries = 0; axis2 == 0; tries++) {   // the history repeats states: the projection needs a z that is not x itself
+      if (tries > 1000) { std::cout << "differential_evolution: a thousand history states in a row equal the current state; giving up." << std::endl; exit(1); }
+      z = pick_state(who);
+      axis = plus_scaled(x, z, -1.0);
+      axis2 = dot(axis, axis);
     }
-    state s1 = draw_from_chain(caller);
-    state s2 = draw_from_chain(caller);
-    state ds12 = s1.scalar_mult(gamma);
-    ds12 = ds12.add(s2.scalar_mult(-gamma));
-    state prop = s;
-    prop = prop.add(smz.scalar_mult(ds12.innerprod(smz) / smznorm2));
-    state pmz = prop.add(minusz);
-    log_hastings = (std::log(pmz.innerprod(pmz)) - std::log(smznorm2)) * (dim - 1) / 2.0;
+    const std::vector<double> z1 = pick_state(who), z2 = pick_state(who);
+    std::vector<double> diff(x.size());
+    for (size_t i = 0; i < diff.size(); i++) { const double a = z1[i] * gamma, b = z2[i] * (-gamma); diff[i] = a + b; }
+    const std::vector<double> y = plus_scaled(x, axis, dot(diff, axis) / axis2);
+    const std::vector<double> from_z = plus_scaled(y, z, -1.0);
+    log_hastings = (std::log(dot(from_z, from_z)) - std::log(axis2)) * (d - 1) / 2.0;
     last_type = 1;
-    return prop;
+    return s.moved_to(y);
   }
 
  public:
   differential_evolution(double snooker = 0.0, double gamma_one_frac = 0.1, double b_small = 0.0001, double ignore_frac = 0.3, double unlikely_alpha = 0)
-      : have_chain(false), dim(0), gamma_one_frac(gamma_one_frac), reduce_gamma_fac(1), b_small(b_small), ignore_frac(ignore_frac),
-        unlikely_alpha(unlikely_alpha), snooker(snooker), do_support_mixing(false), temperature_mixing_factor(1) {}
-  void reduce_gamma(double factor) { reduce_gamma_fac = factor; }
-  void mix_temperatures_more(double factor) { temperature_mixing_factor = factor; }
-  void set_chain(chain* c) override { ch = c; have_chain = true; dim = ch->getDim(); }
-  bool is_ready() override { return have_chain && ch->size() >= get_min_start_size(); }
-  state draw(state& s, chain* caller) override {   // .cc:789-801
-    Random& rng = *caller->getPRNG();
-    const double x = rng.Next();
-    if (snooker > x) return draw_snooker(s, caller);
-    return draw_standard(s, caller);
-  }
+      : p_snooker(snooker), p_unit_gamma(gamma_one_frac), jump_noise(b_small), skip_early(ignore_frac), discount(unlikely_alpha), gamma_divisor(1),
+        mix_strength(1), mixing(false), bound_to_chain(false), d(0) {}
+  void reduce_gamma(double factor) { gamma_divisor = factor; }
+  void mix_temperatures_more(double factor) { mix_strength = factor; }
+  void set_chain(chain* c) override { ch = c; bound_to_chain = true; d = c->getDim(); }
+  bool is_ready() override { return bound_to_chain && ch->size() >= rows_to_start(); }
+  state draw(state& s, chain* caller) override { return p_snooker > caller->getPRNG()->Next() ? snooker_move(s, caller) : parallel_move(s, caller); }
   differential_evolution* clone() const override { return new differential_evolution(*this); }
   std::string show() override {
     std::ostringstream ss;
-    ss << "DifferentialEvolution(snooker=" << snooker << ", gamma_one_frac=" << gamma_one_frac << ", b_small=" << b_small << ", ignore_frac=" << ignore_frac << ")\n";
+    ss << "DifferentialEvolution(snooker=" << p_snooker << ", gamma_one_frac=" << p_unit_gamma << ", b_small=" << jump_noise << ", ignore_frac=" << skip_early << ")\n";
     return ss.str();
   }
-  bool support_mixing(bool do_it) { do_support_mixing = do_it; return do_it; }
-  bool support_mixing() override { return do_support_mixing; }
+  bool support_mixing(bool do_it) { mixing = do_it; return do_it; }
+  bool support_mixing() override { return mixing; }
+};
+
+// ---- effective sample size of a saved series ---------------------------------------------------------------------------------
+// The estimator behind chain::report_effective_samples (chain.cc:126-643) and the sampler's --chain_ess_stop, restated on a
+// plain series so that it can be checked on its own (tests/golden/ess.json.gz holds the reference's answers for fixed AR(1)
+// series).  In the manner of Geyer (1992), "Practical Markov chain Monte Carlo", sec. 3:
+//   * the last part of the series is cut into windows of `width` steps that end at the newest step, each sampled every
+//     `every` steps; `burn` more windows in front of them only feed the lagged samples;
+//   * per window and lag L (0, then every, 2 every, ... spaced by factors of 1.1 up to burn windows): the mean m of the
+//     samples and their L-lagged partners taken together, and the lagged covariance about m;
+//   * for the newest n windows together: rho(L) = sum count (cov_L + (M - m_L)^2) / sum count (cov_0 + (M - m_0)^2), M the mean
+//     of the window means; autocorrelation length 1 + 2 sum (L_k - L_(k-1)) rho(L_k), stopped -- and the last term taken back --
+//     at the second negative rho in a row (the initially positive sequence);
+//   * ess(n) = n width / length (a length below the sampling stride is not believed: 3 strides are assumed instead), the
+//     minimum over the features; the answer is the best n: early windows lengthen the correlation more than they add samples.
+// report() chooses width / stride like the reference: windows doubled until at most 20 + 2 of them cover the series, or, given
+// a limit on the ess worth resolving, a search from coarse to fine strides.
+class ess_estimator {
+ public:
+  // features of the state saved for nominal step `step` (false: none, the sample is skipped)
+  typedef std::function<bool(int step, std::vector<double>& features)> reader;
+
+ private:
+  int steps, nfeat;
+  reader read;
+  bool sample(int step, std::vector<double>& v) const { return step >= 0 && step < steps && read(step, v) && (int)v.size() >= nfeat; }
+
+  struct cell { double mean, cov; int count; };
+
+ public:
+  ess_estimator(int steps, int nfeat, reader read) : steps(steps), nfeat(nfeat), read(read) {}
+
+  // one pass with fixed windows: ess and the number of windows that gave it
+  void windowed(int width, int every, int burn, double& ess_out, int& nwin_out) const {
+    ess_out = 0; nwin_out = 0;
+    if (width < 2) width = 2;
+    if (every < 1) every = 1;
+    if (burn < 1) burn = 1;
+    const int per_window = width / every, span = per_window * every;   // samples per window, steps they cover
+    if (per_window < 1) return;
+    int nwin = steps / span - burn;
+    if (nwin < 1) return;
+    const int origin = steps - nwin * span;
+    std::vector<int> lags(1, 0);
+    {
+      double grow = 1;
+      for (int k = 1; k < burn * per_window;) {
+        lags.push_back(every * k);
+        const int was = k;
+        while (k == was) { grow *= 1.1; k = (int)grow; }
+      }
+    }
+    const int nlag = (int)lags.size();
+    // table[f][w][l]
+    std::vector<std::vector<std::vector<cell> > > table(nfeat, std::vector<std::vector<cell> >(nwin, std::vector<cell>(nlag)));
+    std::vector<double> now, then;
+    std::vector<std::vector<double> > base(per_window);
+    std::vector<char> have(per_window);
+    for (int w = 0; w < nwin; w++) {
+      const int w0 = origin + w * span;
+      for (int i = 0; i < per_window; i++) have[i] = sample(w0 + i * every, base[i]) ? 1 : 0;
+      for (int l = 0; l < nlag; l++) {
+        std::vector<double> s1(nfeat, 0.0), s2(nfeat, 0.0);
+        int n = 0;
+        for (int i = 0; i < per_window; i++) {
+          if (!have[i]) continue;
+          if (l == 0) {
+            for (int f = 0; f < nfeat; f++) { s1[f] += base[i][f]; s2[f] += base[i][f] * base[i][f]; }
+          } else {
+            if (!sample(w0 + i * every - lags[l], then)) continue;
+            for (int f = 0; f < nfeat; f++) { s1[f] += then[f] + base[i][f]; s2[f] += then[f] * base[i][f]; }
+          }
+          n++;
+        }
+        for (int f = 0; f < nfeat; f++) {
+          cell& c = table[f][w][l];
+          c.count = n;
+          c.mean = l == 0 ? s1[f] / n : s1[f] / n / 2;
+          c.cov = s2[f] / n - c.mean * c.mean;
+        }
+      }
+    }
+    for (int n = 1; n <= nwin; n++) {
+      double worst = 1e100;
+      for (int f = 0; f < nfeat; f++) {
+        double msum = 0;
+        for (int w = nwin - n; w < nwin; w++) msum += table[f][w][0].mean;
+        const double M = msum / n;
+        double length = 1.0, last_term = 0, previous = 1;
+        int last_lag = 0;
+        for (int l = 1; l < nlag; l++) {
+          double top = 0, bottom = 0;
+          for (int w = nwin - n; w < nwin; w++) {
+            const cell &c = table[f][w][l], &c0 = table[f][w][0];
+            const double dm = M - c.mean, dm0 = M - c0.mean;
+            const double cv = c.cov + dm * dm, var = c0.cov + dm0 * dm0;
+            top += cv * c.count;
+            bottom += var * c.count;
+          }
+          const double rho = top / bottom;
+          if (previous < 0 && rho < 0) { length -= last_term; break; }
+          previous = rho;
+          last_term = 2.0 * (lags[l] - last_lag) * rho;
+          length += last_term;
+          last_lag = lags[l];
+        }
+        double e = n * width / length;
+        if (length < every) e = n * width / 3.0 / every;
+        if (e < worst) worst = e;
+      }
+      if (worst > ess_out) { ess_out = worst; nwin_out = n; }
+    }
+  }
+
+  // (ess, useful length of the series in steps).  width: first guess of the window; every: sampling stride (< 0: the stride the
+  // series was saved with, from its rows and its initial rows); esslimit < 0: no limit
+  std::pair<double, int> report(int width, int every, double esslimit, int rows = 0, int initial_rows = 0) const {
+    const int min_burn = 2, min_per_window = 1000, max_windows = 20;
+    while (width < steps * 0.05) width *= 2;
+    if (every < 0) every = rows > initial_rows ? (int)(0.5 + ((double)steps - initial_rows) / (rows - initial_rows)) : 1;
+    if (every < 1) every = 1;
+    double ess = 0, best_width = 0;
+    int nwin = 0;
+    if (esslimit < 0) {
+      if (width < 0) width = every * min_per_window;
+      while (width * (max_windows + min_burn) < steps) width *= 2;
+      windowed(width, every, min_burn, ess, nwin);
+      best_width = width;
+    } else {
+      // An ess above the limit need not be resolved, so a long series is first looked at with a coarse stride (cheap) and the
+      // stride refined only while the limit, not the series' length, decides the window: a window should hold ~1000 samples,
+      // the newest <= 20 windows are used, and limit x 3 strides is the longest stretch whose ess could still matter.
+      const double length = steps, reach = esslimit * 3.0;
+      for (bool last_round = false; !last_round; every *= 2) {
+        int windows = (int)(length / (min_per_window * every));
+        if (windows > max_windows) windows = max_windows;
+        if (windows < 1) break;
+        width = (int)(length / windows);
+        if (width * (windows - 1) > reach * every) {
+          windows = (int)(reach / min_per_window + 1);
+          if (windows > max_windows) windows = max_windows;
+          if (windows > 1) width = (int)((reach * every) / (windows - 1));
+          else { windows = 1; width = min_per_window * every; }
+        } else last_round = true;
+        if ((length - length / (max_windows + min_burn)) * 0.5 < windows * width) {
+          double e; int n;
+          windowed(width, every, (int)(length / width - windows), e, n);
+          if (e > ess) { ess = e; nwin = n; best_width = width; }
+        }
+      }
+    }
+    return std::make_pair(ess, (int)best_width * nwin);
+  }
 };
 
 // A small persistent worker pool for the likelihood batches: starting and joining threads for every batch costs more than
@@ -2181,15 +2415,10 @@ class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:
       os << std::endl;
     }
   }
-  // ---- effective sample size of the cold chain (chain::report_effective_samples, chain.cc:126-643; the sampler's
-  // chain_ess_stop criterion, ptmcmc.cc:628-649).  The reference's estimator, restated: the saved history of each parameter
-  // (the first 20) is cut into windows of `width` steps aligned to the end of the chain, sampled every `every` steps;
-  // per window and lag (logarithmically spaced, factor 1.1) the lagged covariance about the mean of the two lagged series;
-  // for the last nwin windows rho(lag) = sum(count (cov + dmean^2)) / sum(count (var + dmean0^2)); the autocorrelation
-  // length 1 + 2 sum (lag_k - lag_k-1) rho_k, cut at the second consecutive negative rho ("initially positive sequence");
-  // ess = nwin width / aclen (an aclen below the sampling stride is distrusted: ess = nwin width / (3 every)); the minimum
-  // over parameters, maximised over nwin.  Returns (ess, useful chain length).  Needs the cold chain's whole saved history:
-  // the host mirror (host-side proposals) or a history ring as long as the run (keep_history).
+  // ---- effective sample size of the cold chain (chain::report_effective_samples, chain.cc:457-643; the sampler's
+  // chain_ess_stop criterion, ptmcmc.cc:628-649): ess_estimator (above) on the cold chain's saved history, the first 20
+  // parameters as features.  Returns (ess, useful chain length).  Needs the cold chain's whole saved history: the host mirror
+  // (host-side proposals) or a history ring as long as the run (keep_history).
   bool cold_row(int step, std::vector<double>& out, int replica = 0) {   // state the cold chain saved for nominal step `step`
     const size_t at = (size_t)replica;
     if (step < 0) return false;
@@ -2221,94 +2450,14 @@ class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:
     return (int)nh[(size_t)replica];
   }
   std::pair<double, int> report_effective_samples(int imax = -1, int width = 40000, int every = 100, double esslimit = -1, bool reporting = true) {
-    (void)esslimit;   // (the reference's coarse-to-fine search for long chains, chain.cc:478-531, is an efficiency device: same estimator)
-    const int istep = cold_steps();
-    while (width < istep * 0.05) width *= 2;                       // chain.cc:537
     if (imax < 0 || imax > dim) imax = dim;
-    if (imax > 20) imax = 20;
-    if (every < 1) every = 1;
-    const int minburn = 2, minbin = 1000, maxbins = 20;
-    int burn = minburn;
-    if (width < 0) width = every * minbin;
-    while ((long)width * (maxbins + burn) < istep) width *= 2;      // chain.cc:470-474
-    // ---- compute_autocovar_windows (chain.cc:126-283), log-spaced lags, for every feature at once
-    if (width <= 1) width = 2;
-    const int swidth = width / every;
-    width = swidth * every;
-    const int max_lag = burn;
-    int Nwin = istep / width - burn;
-    if (Nwin < 0) Nwin = 0;
-    const int istart = istep - Nwin * width;
-    std::vector<int> lags;
-    lags.push_back(0);
-    { double fac = 1; int idx = 1; while (idx < max_lag * swidth) { lags.push_back(every * idx); const int last = idx; while (last == idx) { fac *= 1.1; idx = (int)fac; } } }
-    const int Nlag = (int)lags.size();
-    if (Nwin < 1 || swidth < 2) { if (reporting) std::cout << "Effective sample size: chain too short (" << istep << " steps, window " << width << ")" << std::endl; return std::make_pair(0.0, 0); }
-    // the sampled series, from the earliest lagged sample on
-    const int first = istart - lags.back();
-    const int nsamp = (istep - first + every - 1) / every + 1;
-    std::vector<std::vector<double> > ser(imax, std::vector<double>(nsamp, 0.0));
-    std::vector<char> have(nsamp, 0);
-    std::vector<double> row;
-    for (int k = 0; k < nsamp; k++) {
-      const int st = first + k * every;
-      if (st >= 0 && st < istep && cold_row(st, row)) { have[k] = 1; for (int f = 0; f < imax; f++) ser[f][k] = row[f]; }
-    }
-    auto at_step = [&](int st) { return (st - first) / every; };
-    std::vector<std::vector<std::vector<double> > > covar(imax, std::vector<std::vector<double> >(Nwin, std::vector<double>(Nlag, 0.0))), means = covar;
-    std::vector<std::vector<int> > counts(Nwin, std::vector<int>(Nlag, 0));
-    for (int k = 0; k < Nwin; k++)
-      for (int j = 0; j < Nlag; j++) {
-        int cnt = 0;
-        std::vector<double> xs(imax, 0.0), xx(imax, 0.0);
-        for (int i = 0; i < swidth; i++) {
-          const int a = at_step(istart + k * width + i * every), b = at_step(istart + k * width + i * every - lags[j]);
-          if (a < 0 || b < 0 || a >= nsamp || b >= nsamp || !have[a] || !have[b]) continue;
-          cnt++;
-          for (int f = 0; f < imax; f++) { xs[f] += ser[f][a] + ser[f][b]; xx[f] += ser[f][a] * ser[f][b]; }
-        }
-        counts[k][j] = cnt;
-        for (int f = 0; f < imax; f++) {
-          const double m = cnt ? xs[f] / cnt / 2 : 0.0;
-          means[f][k][j] = m;
-          covar[f][k][j] = cnt ? xx[f] / cnt - m * m : 0.0;
-        }
-      }
-    // ---- compute_effective_samples (chain.cc:285-455)
-    const double oversmall_aclen_fac = 3.0;
-    double ess_max = 0;
-    int nwin_max = 0;
-    for (int nwin = 1; nwin <= Nwin; nwin++) {
-      double ess = 1e100;
-      for (int f = 0; f < imax; f++) {
-        double sum = 0;
-        for (int i = Nwin - nwin; i < Nwin; i++) sum += means[f][i][0];
-        const double mean = sum / nwin;
-        int last_lag = 0;
-        double ac_len = 1.0, lastcorr = 1, dacl = 0;
-        for (int il = 1; il < Nlag; il++) {
-          double num = 0, den = 0;
-          for (int iw = Nwin - nwin; iw < Nwin; iw++) {
-            const double dm = mean - means[f][iw][il], dm0 = mean - means[f][iw][0];
-            num += (covar[f][iw][il] + dm * dm) * counts[iw][il];
-            den += (covar[f][iw][0] + dm0 * dm0) * counts[iw][il];
-          }
-          const double corr = num / den;
-          if (lastcorr < 0 && corr < 0) { ac_len -= dacl; break; }   // keep the initially positive sequence only
-          lastcorr = corr;
-          dacl = 2.0 * (lags[il] - last_lag) * corr;
-          ac_len += dacl;
-          last_lag = lags[il];
-        }
-        double essi = nwin * (double)width / ac_len;
-        if (ac_len < every) essi = nwin * (double)width / oversmall_aclen_fac / every;
-        if (essi < ess) ess = essi;
-      }
-      if (ess > ess_max) { ess_max = ess; nwin_max = nwin; }
-    }
+    if (imax > 20) imax = 20;   // (the reference's simplified interface looks at the first 20 parameters)
+    const int nf = imax;
+    ess_estimator est(cold_steps(), nf, [this](int step, std::vector<double>& row) { return cold_row(step, row); });
+    const std::pair<double, int> r = est.report(width, every, esslimit, views.empty() ? 0 : views[0].size(), Ninit_rows);
     if (reporting)
-      std::cout << "Over " << imax << " pars: ess=" << ess_max << "  useful chain length is: " << width * nwin_max << " autocorrlen=" << (ess_max > 0 ? width * nwin_max / ess_max : 0.0) << std::endl;
-    return std::make_pair(ess_max, width * nwin_max);
+      std::cout << "Over " << nf << " pars: ess=" << r.first << "  useful chain length is: " << r.second << " autocorrlen=" << (r.first > 0 ? r.second / r.first : 0.0) << std::endl;
+    return r;
   }
   // swap_count / swap_accept_count (chain.hh:244-245)
   void swap_counts(std::vector<int64_t>& tries, std::vector<int64_t>& accepts) {
@@ -2399,35 +2548,35 @@ class ptmcmc_sampler : public bayes_sampler {
   double ess_stop, prop_adapt_rate, dpriormin;
   int nreplicas, replica_begin = 0, device = -1;
 
+  // every flag read into a typed value (a flag without a value reads as T())
+  template <class T> T flag(const std::string& name) { T v = T(); *optValue(name) >> v; return v; }
   void ensure_options() { if (!haveOptions()) addOptions(own_opt); }
-  void processOptions() {   // ptmcmc.cc:430-473
+  void processOptions() {   // the run-shaping flags (the reference reads them in ptmcmc_sampler::processOptions, ptmcmc.cc:430-473)
     ensure_options();
     bayes_sampler::processOptions();
-    *optValue("checkp_at_step") >> checkp_at_step;
-    restart_dir = ""; *optValue("restart_dir") >> restart_dir;
-    restarting = restart_dir.size() != 0;
-    *optValue("nevery") >> Nevery;
-    *optValue("save_every") >> save_every;
-    *optValue("nsteps") >> Nstep;
-    *optValue("nskip") >> Nskip;
-    *optValue("burn_frac") >> nburn_frac;
-    *optValue("pt") >> Nptc;
+    checkp_at_step = flag<int>("checkp_at_step");
+    restart_dir = flag<std::string>("restart_dir");
+    restarting = !restart_dir.empty();
+    Nevery = flag<int>("nevery");
+    save_every = flag<int>("save_every");
+    Nstep = flag<int>("nsteps");
+    Nskip = flag<int>("nskip");
+    nburn_frac = flag<double>("burn_frac");
+    Nptc = flag<int>("pt");
     parallel_tempering = Nptc > 1;
-    *optValue("pt_evolve_rate") >> pt_evolve_rate;
-    *optValue("pt_evolve_lpost_cut") >> pt_evolve_lpost_cut;
-    *optValue("pt_swap_rate") >> swap_rate;
-    *optValue("pt_Tmax") >> Tmax;
-    *optValue("pt_dump_n") >> dump_n;
-    if (dump_n > Nptc || dump_n < 0) dump_n = Nptc;
+    pt_evolve_rate = flag<double>("pt_evolve_rate");
+    pt_evolve_lpost_cut = flag<double>("pt_evolve_lpost_cut");
+    swap_rate = flag<double>("pt_swap_rate");
+    Tmax = flag<double>("pt_Tmax");
+    dump_n = flag<int>("pt_dump_n");
+    if (dump_n < 0 || dump_n > Nptc) dump_n = Nptc;   // "0 for all" is resolved where the files are opened
     if (Nptc == 0) dump_n = 1;
-    *optValue("prop_adapt_rate") >> prop_adapt_rate;
-    *optValue("chain_ess_stop") >> ess_stop;
-    *optValue("chain_dprior_min") >> dpriormin;
-    nreplicas = 1;
-    if (optSet("replicas")) *optValue("replicas") >> nreplicas;
-    replica_begin = 0; device = -1;
-    if (optSet("replica_begin")) *optValue("replica_begin") >> replica_begin;
-    if (optSet("device")) *optValue("device") >> device;
+    prop_adapt_rate = flag<double>("prop_adapt_rate");
+    ess_stop = flag<double>("chain_ess_stop");
+    dpriormin = flag<double>("chain_dprior_min");
+    nreplicas = optSet("replicas") ? flag<int>("replicas") : 1;
+    replica_begin = optSet("replica_begin") ? flag<int>("replica_begin") : 0;
+    device = optSet("device") ? flag<int>("device") : -1;
   }
 
  public:
@@ -2436,7 +2585,7 @@ class ptmcmc_sampler : public bayes_sampler {
                      pt_evolve_lpost_cut(-1), Tmax(1e9), Nstep(5000), Nskip(10), Nptc(0), Nevery(5000), save_every(1), dump_n(1), nburn_frac(0.5),
                      parallel_tempering(false), istep(0), restarting(false), checkp_at_step(-1), ess_stop(-1), prop_adapt_rate(0), dpriormin(-30), nreplicas(1) {}
   ~ptmcmc_sampler() { if (own_cprop) delete cprop; }
-  // ptmcmc.cc:250-275: MPI start-up / shut-down in the reference; here the process already owns its GPU
+  // MPI start-up / shut-down in the reference (ptmcmc.cc:250-275); here the process already owns its GPU
   static void Init() { std::cout << "Running on the MI355X step engine (no MPI; ladders shard over GPUs through ptmcmc_amd.parallel)." << std::endl; }
   static void Init(int& argc, char* argv[]) { (void)argc; (void)argv; Init(); }
   static void setRNGseed(double seed) { ProbabilityDist::setSeed(seed); }
@@ -2444,65 +2593,76 @@ class ptmcmc_sampler : public bayes_sampler {
   static bool static_reporting() { return true; }
   bool reporting() { return true; }
 
-  // the flags of ptmcmc.cc:375-427, same names and defaults.  Flags of features outside this build's scope (pt_reboot_*,
-  // pt_stop_evid_err, covariance_file, sym_prop_frac, prop_test_index, chain_init_file, checkp_at_time, checkp_on_sigterm_within)
-  // are accepted so that command lines written for the reference parse, and refused at setup if they ask for the feature.
+  // The sampler's flags: the NAMES and DEFAULTS are the reference's (ptmcmc.cc:375-427) -- command lines and scripts written for
+  // it must parse and mean the same -- the descriptions are this build's.  "" as default: the flag has no value until given.
+  // Flags of features outside this build's scope are declared too, so that such command lines parse; setup() refuses the ones
+  // that would change the run (refuse_unbuilt).
   void addOptions(Options& opt, const std::string& prefix = "") override {
     bayes_sampler::addOptions(opt, prefix);
-    addOption("checkp_at_step", "Step at which to checkpoint and stop", "-1");
-    addOption("checkp_at_time", "Elapsed walltime (hours) after which to checkpoint and stop", "-1");
-    addOption("restart_dir", "Directory with checkpoint data to restart from.", "");
-    addOption("nevery", "Frequency to dump chain info. Default=5000.", "5000");
-    addOption("save_every", "Frequency to store chain info. Default=1.", "1");
-    addOption("nsteps", "How long to run the chain. Default=5000.", "5000");
-    addOption("nskip", "Only dump every nskipth element. Default=10.", "10");
-    addOption("burn_frac", "Portion of chain to disregard as burn-in for some calculations. Default=0.5", "0.5");
-    addOption("pt", "Number of parallel tempering chains. Default off.", "0");
-    addOption("pt_swap_rate", "Frequency of parallel tempering swap_trials. Default 0.10", "0.10");
-    addOption("pt_Tmax", "Max temp of parallel tempering chains. Default 1e9", "1e9");
-    addOption("pt_evolve_rate", "Rate at which parallel tempering temps should be allowed to evolve. Default none.", "0.01");
-    addOption("pt_evolve_lpost_cut", "Tolerance limit for disordered log-posterior values in temperature evolution. Default no limit.", "-1");
-    addOption("pt_reboot_rate", "Max frequency of rebooting poorly performing parallel tempering chains. Default 0", "0");
-    addOption("pt_reboot_every", "How often to test for rebooting poorly performing parallel tempering chains. Default 0", "0");
-    addOption("pt_reboot_grace", "Grace period protecting infant instances reboot. Default 0", "0");
-    addOption("pt_reboot_cut", "Posterior difference cutoff defining poorly performing parallel tempering chains. Default 100", "100");
-    addOption("pt_reboot_thermal", "Temperature dependent cutoff term in defining poorly performing parallel tempering chains. Default 0", "0");
-    addOption("pt_reboot_blindly", "Do aggressive random rebooting at some level even if no gaps are found. Default 0", "0");
-    addOption("pt_reboot_grad", "Let the reboot grace period depend linearly on temp level with given mean. (colder->longer)");
-    addOption("pt_dump_n", "How many of the coldest chains to dump; 0 for all. (default 1)", "1");
-    addOption("pt_stop_evid_err", "Set a value to specify a stopping criterion based on evidence consistency. (default 0)", "0");
-    addOption("prop", "Defunct.", "");
-    addOption("gauss_1d_frac", "With Gaussian proposal distribution variants, specify a fraction which should be taken in one random parameter direction. Default=0.5", "0.5");
-    addOption("gauss_draw_frac", "With Gaussian proposal distribution variants, specify a fraction of Gaussian draws. Default=0.20", "0.20");
-    addOption("prior_draw_frac", "Add prior draws to general proposal (prop7). Default=0", "0");
-    addOption("prior_draw_Tpow", "Power for thermal_weighting of any prior draws in proposal. Default=0", "0");
-    addOption("gauss_step_fac", "With Gaussian proposal distribution variants, specify scale-spacing of Gaussian components. Default=2", "2");
-    addOption("gauss_temp_scaled", "With Gaussian proposal distribution variants, scale (co)variance with chain-temp. Default=not");
-    addOption("cov_draw_frac", "With Gaussian proposal dist variants and a covariance file set, specify a fraction of Gaussian draws with defined covariance. Default=0.50", "0.50");
-    addOption("covariance_file", "Specify file with covariance data for relevant proposal distribution optoins.Default=none", "");
-    addOption("prop_adapt_rate", "Specify a scaling rate (eg 1e-3) for adaptation of sub-proposal fractions, Default=0", "0");
-    addOption("prop_adapt_more", "Adapt more broadly, not just Gaussian mixtures");
-    addOption("sym_prop_frac", "Fractional rate at which to apply and stateSpace symmetries as proposals. (Default=0)", "0");
-    addOption("like_prop_frac", "Fractional rate at which to apply proposal defined by likelihood. (Default=0)", "0");
-    addOption("de_ni", "Differential-Evolution number of initialization elements per dimension. Default=50.", "50");
-    addOption("de_eps", "Differential-Evolution gaussian scale. Default=1e-4.", "1e-4");
-    addOption("de_reduce_gamma", "Differential Evolution reduce gamma parameter by some factor from nominal value. Default=4.", "4");
-    addOption("de_g1_frac", "Differential Evolution reduce fraction of times gamma parameter set to 1. Default=0.3.", "0.3");
-    addOption("de_mixing", "Differential-Evolution support mixing of parallel chains.");
-    addOption("de_Tmix", "Differential-Evolution degree to encourage mixing info from different temps.(default=300)", "300");
-    addOption("de_unlikely_alpha", "Scaling power for rejecting unlikely past states in differential evolution draws.(Default 0, ie none)", "0");
-    addOption("prop_test_index", "String providing (multi-)index value indicating proposal to test. (Default: no test)", "");
-    addOption("chain_init_file", "Specify chain file from which to draw initializtion points, rather than from prior.", "");
-    addOption("chain_ess_stop", "Stop MCMC sampling the first time the specified effective sample size is reached. (default never)", "-1.0");
-    addOption("chain_ess_limit", "Look for efficiencies in ESS calculation based on assumed limit. (default -1=no limit, 0=based on ess_limit,or as given)", "-1.0");
-    addOption("checkp_on_sigterm_within", "Set to n to check every n steps for SIGTERM and checkpoint if recieved. (Default 0, don't checkpoint on SIGTERM", "0");
-    addOption("chain_dprior_min", "Specify a minimum change in log prior beyond which proposal will be rejected without evaluating the likelihood. (Default=-30)", "-30");
-    // this build's addition: independent replicas of the ladder side by side in one engine (the reference runs its repeats
-    // one after the other: the caller's loop over clone() / initialize() / run())
-    addOption("replicas", "Independent replicas of the ladder run side by side on the device (files <base>_c<w>_t<k>.dat). Default 1", "1");
-    // ... and over several GPUs: one process per GPU, each told which replicas of the population are its own
-    addOption("replica_begin", "Global index of this process's first replica (several GPUs: one process each, disjoint ranges). Default 0", "0");
-    addOption("device", "GPU of this process (-1: the current device, e.g. by HIP_VISIBLE_DEVICES). Default -1", "-1");
+    struct decl { const char *name, *preset, *about; };
+    static const char* const no_value = "<no default>";
+    static const decl flags[] = {
+        // run length and output
+        {"nsteps", "5000", "Steps to run each chain for. [5000]"},
+        {"save_every", "1", "Keep every n-th state in the chain history. [1]"},
+        {"nevery", "5000", "Report and write chain-file rows every n steps. [5000]"},
+        {"nskip", "10", "Of the saved states, write only every n-th to the chain files. [10]"},
+        {"burn_frac", "0.5", "Leading fraction of the run treated as burn-in by the summaries. [0.5]"},
+        // checkpointing
+        {"checkp_at_step", "-1", "Write a checkpoint at this step and stop. [-1: never]"},
+        {"checkp_at_time", "-1", "Write a checkpoint after this many hours of wall time and stop (not built here). [-1: never]"},
+        {"checkp_on_sigterm_within", "0", "Look for a termination signal every n steps and checkpoint on it (not built here). [0: off]"},
+        {"restart_dir", "", "Continue from the checkpoint in this directory."},
+        // the temperature ladder
+        {"pt", "0", "Number of temperatures of the parallel-tempering ladder. [0: no tempering]"},
+        {"pt_Tmax", "1e9", "Temperature of the hottest rung. [1e9]"},
+        {"pt_swap_rate", "0.10", "Exchange attempts per rung pair and step. [0.10]"},
+        {"pt_evolve_rate", "0.01", "Every accepted exchange widens its temperature gap by this fraction (0: fixed ladder). [0.01]"},
+        {"pt_evolve_lpost_cut", "-1", "While the ladder evolves, also widen gaps whose log-posteriors are out of order by more than this. [-1: off]"},
+        {"pt_dump_n", "1", "Write chain files for the n coldest rungs (0: all of them). [1]"},
+        {"pt_reboot_rate", "0", "Highest rate of restarting lagging hot chains (not built here). [0]"},
+        {"pt_reboot_every", "0", "Steps between tests for lagging hot chains (not built here). [0]"},
+        {"pt_reboot_grace", "0", "Steps a restarted chain is left alone (not built here). [0]"},
+        {"pt_reboot_cut", "100", "Log-posterior deficit that marks a lagging chain (not built here). [100]"},
+        {"pt_reboot_thermal", "0", "Temperature-dependent part of that deficit (not built here). [0]"},
+        {"pt_reboot_blindly", "0", "Restart at random at this level even without a deficit (not built here). [0]"},
+        {"pt_reboot_grad", no_value, "Make the grace period grow towards the cold rungs, with this mean (not built here)."},
+        {"pt_stop_evid_err", "0", "Stop once the evidence estimate is consistent to this error (not built here). [0: off]"},
+        // the default proposal recipe
+        {"prop", "", "No longer used."},
+        {"gauss_draw_frac", "0.20", "Share of Gaussian steps in the default proposal mixture. [0.20]"},
+        {"gauss_1d_frac", "0.5", "Fraction of the Gaussian steps that move one randomly chosen parameter only. [0.5]"},
+        {"gauss_step_fac", "2", "Ratio between the widths of successive Gaussian members. [2]"},
+        {"gauss_temp_scaled", no_value, "Scale the Gaussian widths with the chain temperature."},
+        {"prior_draw_frac", "0", "Share of independent draws from the prior in the mixture. [0]"},
+        {"prior_draw_Tpow", "0", "Let the prior-draw share grow towards the hot rungs as 1 - T^-p. [0: same at every rung]"},
+        {"cov_draw_frac", "0.50", "Share of Gaussian steps with the covariance of --covariance_file, if one is given. [0.50]"},
+        {"covariance_file", "", "File holding a proposal covariance."},
+        {"prop_adapt_rate", "0", "Rate (e.g. 1e-3) at which the Gaussian members' shares adapt to their acceptance. [0: fixed]"},
+        {"prop_adapt_more", no_value, "Adapt the shares of the whole mixture, not of the Gaussian members alone."},
+        {"sym_prop_frac", "0", "Share of state-space symmetry moves (not built here). [0]"},
+        {"like_prop_frac", "0", "Share of the proposals the likelihood object brings along. [0]"},
+        {"de_ni", "50", "Differential evolution: initial history rows per parameter. [50]"},
+        {"de_eps", "1e-4", "Differential evolution: width of the small random jump. [1e-4]"},
+        {"de_reduce_gamma", "4", "Differential evolution: divide the nominal jump scale by this. [4]"},
+        {"de_g1_frac", "0.3", "Differential evolution: fraction of jumps made with unit scale. [0.3]"},
+        {"de_mixing", no_value, "Differential evolution: draw history states from every rung of the ladder."},
+        {"de_Tmix", "300", "Differential evolution: how readily other rungs' histories are used. [300]"},
+        {"de_unlikely_alpha", "0", "Differential evolution: power with which improbable history states are passed over. [0: never]"},
+        {"prop_test_index", "", "Index of a proposal to test in isolation (not built here)."},
+        // chains
+        {"chain_init_file", "", "Take the start states from this chain file instead of the prior (not built here)."},
+        {"chain_ess_stop", "-1.0", "Stop as soon as the cold chain's effective sample size exceeds this. [-1: never]"},
+        {"chain_ess_limit", "-1.0", "Largest effective sample size worth resolving; speeds the estimate up on long chains. [-1: none]"},
+        {"chain_dprior_min", "-30", "Reject, without asking the likelihood, a proposal whose log-prior drops by more than this. [-30]"},
+        // this build's additions.  Replicas: independent copies of the ladder side by side in one engine (the reference runs
+        // its repeats one after the other, the caller's loop over clone() / initialize() / run()); over several GPUs one
+        // process per GPU, each told which replicas of the population are its own
+        {"replicas", "1", "Independent replicas of the ladder run side by side on the device (files <base>_c<w>_t<k>.dat). [1]"},
+        {"replica_begin", "0", "Global index of this process's first replica (one process per GPU, disjoint ranges). [0]"},
+        {"device", "-1", "GPU of this process. [-1: the current device, e.g. by HIP_VISIBLE_DEVICES]"},
+    };
+    for (size_t i = 0; i < sizeof flags / sizeof flags[0]; i++) addOption(flags[i].name, flags[i].about, flags[i].preset);
   }
 
   // ---- convenience for programs without an Options object of their own (examples/example_sampler.cc)
@@ -2518,8 +2678,8 @@ class ptmcmc_sampler : public bayes_sampler {
   bool parse(int argc, char* argv[]) {  // --name=value / --name; true when every flag was understood
     ensure_options();
     if (!own_opt.exists("seed")) {
-      own_opt.add(Option("seed", "Pseudo random number grenerator seed in [0,1). (Default=-1: the engine's fixed default key)", "-1"));
-      own_opt.add(Option("outname", "Base name for output files (Default 'mcmc_output').", "mcmc_output"));
+      own_opt.add(Option("seed", "Seed of the random streams, a number in [0,1). [-1: the engine's fixed default key]", "-1"));
+      own_opt.add(Option("outname", "Stem of the output file names. [mcmc_output]", "mcmc_output"));
       own_opt.add(Option("nchains", "Replicas of the ladder run side by side (alias of --replicas).", "1"));
     }
     int n = argc;
@@ -2560,119 +2720,109 @@ class ptmcmc_sampler : public bayes_sampler {
   // a proposal of the caller's (the convenience path of examples/example_sampler.cc; the reference's deprecated setup(Ninit, ...))
   void select_proposal(proposal_distribution& p) { if (own_cprop) delete cprop; cprop = &p; own_cprop = false; have_cprop = true; }
 
-  // ptmcmc.cc:15-183: the default recipe
+  // ---- the default proposal (what ptmcmc_sampler::select_proposal() of the reference builds from the flags, ptmcmc.cc:15-183) -----
+  // A mixture of, in this order:
+  //   differential evolution   share 1 - gauss - cov - prior (not below 0): differential_evolution(snooker 0.1, de_g1_frac,
+  //                            de_eps, ignore_frac 0, de_unlikely_alpha), reduce_gamma(de_reduce_gamma), optional rung mixing;
+  //                            its history is seeded with de_ni initial draws per parameter
+  //   prior draws              share prior_draw_frac (hot share 1, power prior_draw_Tpow), when asked for
+  //   six Gaussian steps       share gauss_draw_frac split 2 : 4 : ... : 64; widths scale_i / 100 / f with
+  //                            f = (2/s)^4 s, (2/s)^4 s^2, ..., s = gauss_step_fac (2: f = 2, 4, ..., 64); each moves a single
+  //                            random parameter with probability gauss_1d_frac.  With prop_adapt_rate > 0 the six form a set
+  //                            of their own whose inner shares adapt.
+  // and, around that, the likelihood's own proposals with share like_prop_frac.
+  struct recipe {
+    double gauss, gauss_1d, gauss_ratio, prior, prior_power, like_share, de_unit_frac, de_noise, de_divisor, de_mix, de_alpha;
+    int de_rows_per_dim;
+    bool de_mixing, adapt_all, gauss_temp_scaled;
+  };
+  static double unit_interval(double v) { return v < 0 ? 0.0 : (v > 1 ? 1.0 : v); }
+  recipe read_recipe() {
+    recipe r;
+    r.prior = unit_interval(flag<double>("prior_draw_frac"));
+    r.prior_power = flag<double>("prior_draw_Tpow");
+    r.gauss_1d = unit_interval(flag<double>("gauss_1d_frac"));
+    r.gauss = unit_interval(flag<double>("gauss_draw_frac"));
+    r.gauss_ratio = std::max(1.0, flag<double>("gauss_step_fac"));
+    r.like_share = flag<double>("like_prop_frac");
+    r.de_rows_per_dim = flag<int>("de_ni");
+    r.de_noise = flag<double>("de_eps");
+    r.de_divisor = flag<double>("de_reduce_gamma");
+    r.de_unit_frac = flag<double>("de_g1_frac");
+    r.de_mix = flag<double>("de_Tmix");
+    r.de_alpha = flag<double>("de_unlikely_alpha");
+    r.de_mixing = optSet("de_mixing");
+    r.adapt_all = optSet("prop_adapt_more");
+    r.gauss_temp_scaled = optSet("gauss_temp_scaled");   // (without effect in the reference as well: quirk Q4)
+    // a covariance file is read by a function that is empty in the reference (ptmcmc.cc:761-764): its share is always 0 here
+    if (!flag<std::string>("covariance_file").empty())
+      std::cout << "ptmcmc_sampler::select_proposal: --covariance_file is not read (nor is it by the reference, whose reader is an empty stub); no covariance steps." << std::endl;
+    if (r.prior + r.gauss > 1) r.gauss = 1.0;   // over-subscribed: the Gaussian share is renormalised against itself
+    if (flag<double>("sym_prop_frac") > 0)
+      std::cout << "ptmcmc_sampler::select_proposal: state-space symmetry moves (--sym_prop_frac) are outside this build's scope; none are added." << std::endl;
+    return r;
+  }
+  // the six Gaussian members and their relative weights 2, 4, ..., 64 (sum 126)
+  void gaussian_members(const recipe& r, const std::vector<double>& scales, std::vector<proposal_distribution*>& members, std::vector<double>& weights) {
+    const int count = 6;
+    const double total = std::pow(2.0, count + 1) - 2;
+    double divisor = std::pow(2.0 / r.gauss_ratio, 4.0), weight = 1;
+    for (int k = 0; k < count; k++) {
+      divisor *= r.gauss_ratio;
+      weight *= 2;
+      std::vector<double> sigma(scales.size());
+      for (size_t i = 0; i < sigma.size(); i++) sigma[i] = scales[i] / 100.0 / divisor;
+      members.push_back(new gaussian_prop(sigma, r.gauss_1d, r.gauss_temp_scaled));
+      weights.push_back(weight / total);
+    }
+  }
   void select_proposal() {
     if (!have_setup) { std::cout << "ptmcmc_sampler::select_proposal.  Must call setup() first!" << std::endl; exit(1); }
-    std::vector<double> scalesvec;
-    chain_llike->getScales(scalesvec);
-    const int Npar = chain_prior->get_space() ? chain_prior->get_space()->size() : chain_prior->getDim();
-    int SpecNinit;
-    double tmixfac, reduce_gamma_by, de_g1_frac, de_eps, gauss_1d_frac, prior_draw_frac, prior_draw_Tpow, gauss_draw_frac, gauss_step_fac, cov_draw_frac,
-        sym_prop_frac, like_prop_frac, unlikely_alpha;
-    std::string covariance_file;
-    *optValue("prior_draw_frac") >> prior_draw_frac;
-    *optValue("prior_draw_Tpow") >> prior_draw_Tpow;
-    *optValue("gauss_1d_frac") >> gauss_1d_frac;
-    *optValue("gauss_draw_frac") >> gauss_draw_frac;
-    *optValue("gauss_step_fac") >> gauss_step_fac;
-    *optValue("cov_draw_frac") >> cov_draw_frac;
-    *optValue("sym_prop_frac") >> sym_prop_frac;
-    *optValue("like_prop_frac") >> like_prop_frac;
-    *optValue("covariance_file") >> covariance_file;
-    const bool adapt_more = optSet("prop_adapt_more");
-    if (prior_draw_frac < 0) prior_draw_frac = 0;
-    if (prior_draw_frac > 1) prior_draw_frac = 1;
-    if (gauss_1d_frac < 0) gauss_1d_frac = 0;
-    if (gauss_1d_frac > 1) gauss_1d_frac = 1;
-    if (gauss_draw_frac < 0) gauss_draw_frac = 0;
-    if (gauss_draw_frac > 1) gauss_draw_frac = 1;
-    if (gauss_step_fac < 1) gauss_step_fac = 1;
-    if (covariance_file == "") cov_draw_frac = 0;
-    else { std::cout << "ptmcmc_sampler::select_proposal: covariance_file is an empty stub in the reference too (ptmcmc.cc:761-764); ignored." << std::endl; cov_draw_frac = 0; }
-    if (prior_draw_frac + gauss_draw_frac + cov_draw_frac > 1) {
-      const double scale = gauss_draw_frac + cov_draw_frac;
-      gauss_draw_frac /= scale;
-      cov_draw_frac /= scale;
+    const recipe r = read_recipe();
+    std::vector<double> scales;
+    chain_llike->getScales(scales);
+    const int npar = chain_prior->get_space() ? chain_prior->get_space()->size() : chain_prior->getDim();
+    std::vector<proposal_distribution*> members;
+    std::vector<double> cold, hot;
+    double thermal_power = 0;
+    // A differential-evolution member with share 0 is never picked (no uniform lies below a threshold of 0) and draws nothing:
+    // leaving it out gives the same chain, and an all-Gaussian recipe can then run on the device.
+    const double de_share = std::max(0.0, 1 - r.gauss - r.prior);
+    if (de_share > 0) {
+      differential_evolution* de = new differential_evolution(0.1, r.de_unit_frac, r.de_noise, 0.0, r.de_alpha);
+      de->reduce_gamma(r.de_divisor);
+      if (r.de_mixing) de->support_mixing(true);
+      de->mix_temperatures_more(r.de_mix);
+      members.push_back(de); cold.push_back(de_share); hot.push_back(0.0);
+      chain_Ninit = r.de_rows_per_dim * npar;
+    } else chain_Ninit = 1;
+    if (r.prior > 0) {
+      members.push_back(new draw_from_dist(*chain_prior)); cold.push_back(r.prior); hot.push_back(1.0);
+      thermal_power = r.prior_power;
     }
-    if (sym_prop_frac > 0) std::cout << "ptmcmc_sampler::select_proposal: stateSpace symmetries (sym_prop_frac) are out of this build's scope; ignored." << std::endl;
-    *optValue("de_ni") >> SpecNinit;
-    *optValue("de_eps") >> de_eps;
-    *optValue("de_reduce_gamma") >> reduce_gamma_by;
-    *optValue("de_g1_frac") >> de_g1_frac;
-    *optValue("de_Tmix") >> tmixfac;
-    *optValue("de_unlikely_alpha") >> unlikely_alpha;
-    const bool gauss_temp_scaled = optSet("gauss_temp_scaled");   // (no effect in the reference either: quirk Q4)
-    const bool de_mixing = optSet("de_mixing");
-
-    const int Ng = 6;
-    int Nprop_set = 1 + Ng;
-    if (prop_adapt_rate > 0) Nprop_set = 2;   // hierarchical: only the Gaussian portion adapts
-    std::vector<proposal_distribution*> set(Nprop_set, nullptr);
-    std::vector<double> shares(Nprop_set), hot_shares(Nprop_set);
-    double Tpow = 0;
-    int iprop = 0;
-    const double gshare = gauss_draw_frac;
-    shares[0] = 1 - gshare - cov_draw_frac - prior_draw_frac;
-    if (shares[0] < 0) shares[0] = 0;
-    // a differential-evolution member with share 0 can never be drawn (x < bin_max[0] = 0 never holds, .cc:107-118) and draws
-    // no random number: leaving it out gives the same chain and lets an all-Gaussian recipe run on the device
-    const bool with_de = shares[0] > 0;
-    if (with_de) {
-      differential_evolution* de = new differential_evolution(0.1, de_g1_frac, de_eps, 0.0, unlikely_alpha);
-      de->reduce_gamma(reduce_gamma_by);
-      if (de_mixing) de->support_mixing(true);
-      de->mix_temperatures_more(tmixfac);
-      chain_Ninit = SpecNinit * Npar;
-      set[iprop] = de;
-      iprop++;
-    } else {
-      chain_Ninit = 1;
-      set.erase(set.begin()); shares.erase(shares.begin()); hot_shares.erase(hot_shares.begin());
-      Nprop_set--;
-    }
-    if (prior_draw_frac > 0) {
-      set.insert(set.begin() + iprop, new draw_from_dist(*chain_prior));
-      shares.insert(shares.begin() + iprop, prior_draw_frac);
-      hot_shares.insert(hot_shares.begin() + iprop, 1.0);
-      Tpow = prior_draw_Tpow;
-      iprop++;
-      Nprop_set++;
-    }
-    std::vector<proposal_distribution*> gset(Ng, nullptr);
-    std::vector<double> gshares(Ng);
-    const double sum = std::pow(2.0, Ng + 1) - 2, stepfac = gauss_step_fac;
-    double fac = std::pow(2.0 / gauss_step_fac, 4.0), sharefac = 1;
-    auto scaled = [&](double f) { std::vector<double> sg(scalesvec.size()); for (size_t i = 0; i < sg.size(); i++) sg[i] = scalesvec[i] / 100.0 / f; return sg; };
-    if (prop_adapt_rate > 0) {
-      for (int i = 0; i < Ng; i++) {
-        fac *= stepfac;
-        gset[i] = new gaussian_prop(scaled(fac), gauss_1d_frac, gauss_temp_scaled);
-        sharefac *= 2;
-        gshares[i] = sharefac / sum;
-      }
-      set[iprop] = new proposal_distribution_set(gset, gshares, prop_adapt_rate);
-      shares[iprop] = gshare;
-    } else {
-      for (int i = iprop; i < Nprop_set; i++) {
-        fac *= stepfac;
-        set[i] = new gaussian_prop(scaled(fac), gauss_1d_frac, gauss_temp_scaled);
-        sharefac *= 2;
-        shares[i] = sharefac / sum * gshare;
-      }
-    }
+    std::vector<proposal_distribution*> gaussians;
+    std::vector<double> gweights;
+    gaussian_members(r, scales, gaussians, gweights);
+    if (prop_adapt_rate > 0) {   // the Gaussian part as one member whose inner shares adapt
+      members.push_back(new proposal_distribution_set(gaussians, gweights, prop_adapt_rate)); cold.push_back(r.gauss); hot.push_back(0.0);
+    } else
+      for (size_t k = 0; k < gaussians.size(); k++) { members.push_back(gaussians[k]); cold.push_back(gweights[k] * r.gauss); hot.push_back(0.0); }
     if (own_cprop) delete cprop;
-    cprop = new proposal_distribution_set(set, shares, adapt_more ? prop_adapt_rate : 0, Tpow, hot_shares);
+    const double outer_rate = r.adapt_all ? prop_adapt_rate : 0.0;
+    cprop = new proposal_distribution_set(members, cold, outer_rate, thermal_power, hot);
     own_cprop = true;
-    std::cout << "ptmcmc_sampler::set_proposal: Tpow=" << Tpow << ":" << std::endl;
-    if (like_prop_frac > 0 && chain_llike->get_proposals().size() > 0) {   // ptmcmc.cc:162-170
+    std::cout << "ptmcmc_sampler::set_proposal: Tpow=" << thermal_power << ":" << std::endl;
+    if (r.like_share > 0 && chain_llike->get_proposals().size() > 0) {
       std::cout << "Adding likelihood-based elements to proposal." << std::endl;
-      std::vector<proposal_distribution*> lp;
-      for (auto q : chain_llike->get_proposals()) lp.push_back(q->clone());
-      proposal_distribution_set* likeprops = new proposal_distribution_set(lp, chain_llike->get_prop_shares(), adapt_more ? prop_adapt_rate : 0);
-      std::vector<proposal_distribution*> add_on_props = {cprop, likeprops};
-      double s0 = 1 - like_prop_frac;
-      if (s0 < 0) s0 = 0;
-      cprop = new proposal_distribution_set(add_on_props, std::vector<double>{s0, like_prop_frac}, prop_adapt_rate);
+      std::vector<proposal_distribution*> theirs;
+      for (auto q : chain_llike->get_proposals()) theirs.push_back(q->clone());   // (the likelihood keeps its own objects)
+      std::vector<proposal_distribution*> both;
+      both.push_back(cprop);
+      both.push_back(new proposal_distribution_set(theirs, chain_llike->get_prop_shares(), outer_rate));
+      std::vector<double> split;
+      split.push_back(std::max(0.0, 1 - r.like_share));
+      split.push_back(r.like_share);
+      cprop = new proposal_distribution_set(both, split, prop_adapt_rate);
     }
     std::cout << "Proposal distribution is:\n" << cprop->show() << std::endl;
     have_cprop = true;
