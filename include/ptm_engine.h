@@ -308,6 +308,10 @@ int ptm_timer_stop(ptm_engine* e, float* elapsed_ms); /* synchronises on the sto
 int ptm_get_kernel_times(ptm_engine* e, float* ms, int capacity, int* count);
 /* name of the sweep kernel variant in use (for matching rocprofv3 traces) */
 const char* ptm_sweep_kernel_name(ptm_engine* e);
+/* what a ptm_step call of this engine launches: one kernel for many steps -- "ladder_steps_kernel<..>" (small ladders, a block per
+ * ladder) or "ladder_persistent_kernel<..>" (long ladders of few walkers: resident workgroups, chains in registers) -- or
+ * "decide_kernel + <sweep kernel>" per step */
+const char* ptm_step_kernel_name(ptm_engine* e);
 
 /* ---- verification hooks (used by tests/ only; evaluate device functions on arrays) ---------------------- */
 enum { PTM_FN_LOG = 0, PTM_FN_EXP = 1, PTM_FN_SIN_0_PI = 2, PTM_FN_COS_HPI = 3, PTM_FN_SQRT = 4, PTM_FN_DIV = 5,

@@ -107,6 +107,12 @@ struct ptm_engine {
   bool touched = false;
   bool compact_step = false;   // this step's (partial) sweeps are compacted
   ShardComm* shard = nullptr;   // native RCCL sharding (ptm_shard_*)
+  // persistent ladder kernel (ptm_ladder_kernel.hpp): published rows / llikes / lpriors by step parity, the workgroups' flags
+  double *pub_x = nullptr, *pub_ll = nullptr, *pub_lp = nullptr;   // (one allocation: pub_x)
+  int *lad_flags = nullptr, *lad_ctl = nullptr;                     // (one allocation: lad_flags)
+  long long* lad_prof = nullptr;
+  int lad_capacity = -1;        // workgroups of that kernel the device holds at once (-1: not asked yet)
+  long long ladder_launches = 0, ladder_whole_steps = 0;   // launches of that kernel; steps (of walker 0) whose exchange phase needed the whole ladder
   unsigned int nhist_pending = 0;   // steps whose one-add-per-chain the compacted sweep left uncounted (flush_nhist)
   double* hastings = nullptr;
   int* htype = nullptr;
@@ -409,7 +415,8 @@ extern "C" int ptm_engine_destroy(ptm_engine* e) {
   for (auto& b : e->host_blocks) (void)hipHostFree(b.first);
   void* ptrs[] = {e->x, e->ll, e->lp, e->ntries, e->naccept, e->last_type, e->arr_below, e->arr_above, e->mv_src, e->mv_dst, e->mv_n,
                   e->err, e->nhist, e->swap_cnt, e->touch, e->swap_log, e->hist.x, e->hist.ll, e->hist.lp, e->hist.meta, e->map.lpost, e->map.ll, e->map.lp, e->map.x, e->blo,
-                  e->bhi, e->ptype, e->bmin, e->bmax, e->plo, e->phi, e->pcoef, e->P2, e->mean, e->beta, e->prop, e->prop_tiles, e->P2_tiles, e->box_row, e->onedfrac, e->mix, e->beta_w, e->betaC, e->beta_add, e->hist.beta, e->xprop, e->lprior_new, e->llike_new, e->hastings, e->htype, e->hvalid, e->acc_out, e->cidx, e->ccnt};
+                  e->bhi, e->ptype, e->bmin, e->bmax, e->plo, e->phi, e->pcoef, e->P2, e->mean, e->beta, e->prop, e->prop_tiles, e->P2_tiles, e->box_row, e->onedfrac, e->mix, e->beta_w, e->betaC, e->beta_add, e->hist.beta, e->xprop, e->lprior_new, e->llike_new, e->hastings, e->htype, e->hvalid, e->acc_out, e->cidx, e->ccnt,
+                  e->pub_x, e->lad_flags, e->lad_prof};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (hipEvent_t ev : e->kev) (void)hipEventDestroy(ev);
@@ -1398,15 +1405,118 @@ static int fused_steps(ptm_engine* e, int n) {
   return done;
 }
 
+// Long ladders of few walkers (the reference's own shape: one ladder of 1024 rungs): the steps of a ptm_step(n) call in ONE launch
+// of resident workgroups that keep the chains in registers and talk to their neighbours through flags (ptm_ladder_kernel.hpp).
+// Plain workload only; PTM_LADDER=0 keeps the two-launch path.  Returns the steps taken (0: not this engine's case), or a negative
+// status.
+// does a ptm_step call of this engine go through the persistent ladder kernel?  (grid: its workgroups; lds: their LDS)
+static bool ladder_applies(ptm_engine* e, long long* grid_out = nullptr, size_t* lds_out = nullptr) {
+  static const bool ladder_ok = [] { const char* v = getenv("PTM_LADDER"); return !(v && *v == '0'); }();
+  if (!ladder_ok || (e->DP != 16 && e->DP != 32) || e->Nt < 2 || e->nloc != e->Nt || e->cfg.time_kernels || e->evolve_rate > 0 || e->hist.rungs ||
+      e->map.rungs || e->shard)
+    return false;
+  const SweepSel sel = sweep_sel(e);
+  // the plain workload; populations with whole waves per rung keep the throughput kernels
+  if (!sel.plain || sel.uni) return false;
+  const int R = 256 / e->DP, NB = (e->Nt + R - 1) / R;
+  const long long grid = (long long)e->W * NB;
+  const bool diag = e->prop_kind == PTM_PROP_DIAG;
+  const size_t lds = e->DP == 16 ? ladder_lds_16(e->Nt, e->ms) : ladder_lds_32(e->Nt, e->ms);
+  if (lds > 160 * 1024) return false;
+  if (e->lad_capacity < 0) e->lad_capacity = e->DP == 16 ? ladder_blocks_16(diag, lds) : ladder_blocks_32(diag, lds);
+  // every workgroup must be resident at once (they wait for each other)
+  if (grid > e->lad_capacity || grid > 1024) return false;
+  if (grid_out) *grid_out = grid;
+  if (lds_out) *lds_out = lds;
+  return true;
+}
+static int ladder_steps(ptm_engine* e, int n) {
+  long long grid = 0;
+  size_t lds = 0;
+  if (!ladder_applies(e, &grid, &lds)) return 0;
+  const int R = 256 / e->DP, NB = (e->Nt + R - 1) / R;
+  const bool diag = e->prop_kind == PTM_PROP_DIAG;
+  static const int max_run = [] { const char* v = getenv("PTM_LADDER_MAXRUN"); const int m = v && *v ? atoi(v) : LADDER_H; return m < 1 ? 1 : (m > LADDER_H ? LADDER_H : m); }();
+  int rc = flush_nhist(e);
+  if (rc) return rc;
+  const size_t Nc = e->Nc;
+  if (!e->pub_x) {
+    // what the workgroups publish for each other: fine-grained device memory where the runtime has it (a little faster across
+    // XCDs: tools/probes/flag_pingpong_probe.hip), else ordinary -- the accesses are agent-scope atomics either way
+    const size_t doubles = 2 * Nc * e->DP + 4 * Nc;
+    void* buf = nullptr;
+    if (hipExtMallocWithFlags(&buf, doubles * sizeof(double), hipDeviceMallocFinegrained) != hipSuccess) {
+      (void)hipGetLastError();
+      HIPCHK(hipMalloc(&buf, doubles * sizeof(double)));
+    }
+    e->pub_x = (double*)buf; e->pub_ll = e->pub_x + 2 * Nc * e->DP; e->pub_lp = e->pub_ll + 2 * Nc;
+    void* fl = nullptr;
+    const size_t flbytes = ((size_t)grid + 16 + (size_t)e->W) * sizeof(int);
+    if (hipExtMallocWithFlags(&fl, flbytes, hipDeviceMallocFinegrained) != hipSuccess) {
+      (void)hipGetLastError();
+      HIPCHK(hipMalloc(&fl, flbytes));
+    }
+    e->lad_flags = (int*)fl; e->lad_ctl = e->lad_flags + grid;   // [grid] flags | [16] control words | [W] whole-ladder barrier counters
+  }
+  static const bool prof_on = [] { const char* v = getenv("PTM_LADDER_PROF"); return v && *v && *v != '0'; }();
+  if (prof_on && !e->lad_prof && (rc = dalloc(&e->lad_prof, (size_t)grid * 8))) return rc;
+  int done = 0;
+  while (done < n) {
+    const int k = n - done;
+    Dev p = make_dev(e);
+    LadderArgs a;
+    a.nsteps = k; a.NB = NB; a.ms = e->ms; a.thresh = e->thresh;
+    a.pub_x = e->pub_x; a.pub_ll = e->pub_ll; a.pub_lp = e->pub_lp; a.flags = e->lad_flags; a.ctl = e->lad_ctl; a.slow_done = e->lad_ctl + 16;
+    a.swap_cnt = e->swap_cnt; a.swap_log = e->swap_log + (size_t)e->log_head * e->W * e->ms;
+    a.max_run = max_run;
+    a.prof = e->lad_prof;
+    if ((rc = fold_swap_log(e))) return rc;   // (the kernel adds to the swap counters itself: nothing logged may be pending behind it)
+    a.spin_limit = 300000000ll;   // 3 s of the 100 MHz wall clock: a neighbour that is not there by then never will be
+    HIPCHK(hipMemsetAsync(e->lad_flags, 0, ((size_t)grid + 16 + (size_t)e->W) * sizeof(int), e->stream));
+    HIPCHK(e->DP == 16 ? launch_ladder_16(p, a, diag, (int)grid, lds, e->stream) : launch_ladder_32(p, a, diag, (int)grid, lds, e->stream));
+    int ctl[4] = {0, 0, 0, 0};
+    HIPCHK(hipMemcpyAsync(ctl, e->lad_ctl, sizeof ctl, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    e->ladder_launches++;
+    if (e->lad_prof && ctl[1] > 0) {   // diagnostics: mean microseconds per step and phase over the workgroups, and the slowest workgroup's
+      std::vector<long long> pr((size_t)grid * 8);
+      HIPCHK(hipMemcpy(pr.data(), e->lad_prof, pr.size() * 8, hipMemcpyDeviceToHost));
+      static const char* const phase[7] = {"", "publish", "draws+moves", "wait", "window", "trials", "rows"};
+      fprintf(stderr, "[ladder kernel] %d steps, %lld workgroups; us per step (mean / max over workgroups):", ctl[1], grid);
+      for (int k = 1; k < 7; ++k) {
+        double sum = 0, mx = 0;
+        for (long long g2 = 0; g2 < grid; ++g2) { const double v = pr[(size_t)g2 * 8 + k] * 0.01 / ctl[1]; sum += v; if (v > mx) mx = v; }
+        fprintf(stderr, " %s %.2f/%.2f", phase[k], sum / grid, mx);
+      }
+      fprintf(stderr, "\n");
+    }
+    if (ctl[0] != 0 || ctl[1] < 0) return fail(PTM_ERR_HIP, "the persistent ladder kernel gave up waiting for a neighbouring workgroup (is the device shared?); "
+                                                             "PTM_LADDER=0 selects the two-launch path");
+    const int took = ctl[1];
+    e->ladder_whole_steps += ctl[2];
+    if (took != k) return fail(PTM_ERR_HIP, "the persistent ladder kernel returned after %d of %d steps", took, k);
+    e->step += (uint64_t)took;
+    done += took;
+    e->log_head = (e->log_head + 1) % PTM_LOG_RING;   // (the last step's candidate log sits in the slot handed over)
+  }
+  e->touched = false;
+  return done;
+}
+
 extern "C" int ptm_step(ptm_engine* e, int n) {
   int rc = ready(e);
   if (rc) return rc;
   if (e->nloc != e->Nt) return fail(PTM_ERR_INVALID, "ptm_step needs the whole ladder on this engine; sharded engines use ptm_exchange_*");
   NO_BATCH(e, "ptm_step");
   if (n > 0) {
-    const int f = fused_steps(e, n);
+    int f = fused_steps(e, n);
     if (f < 0) return f;
     n -= f;
+    if (n > 0) {
+      f = ladder_steps(e, n);
+      if (f < 0) return f;
+      n -= f;
+    }
   }
   for (int k = 0; k < n; ++k) {
     if (e->Nt > 1 && (rc = launch_decide(e, nullptr, nullptr, 0, nullptr, nullptr))) return rc;
@@ -1873,6 +1983,20 @@ extern "C" const char* ptm_sweep_kernel_name(ptm_engine* e) {
   else snprintf(b, sizeof b, "sweep_kernel<%d, %d, %s, %s>", e->DP, s.kind, s.uni ? "true" : "false", s.simple ? "true" : "false");
   e->kname = b;
   return e->kname.c_str();
+}
+
+extern "C" const char* ptm_step_kernel_name(ptm_engine* e) {
+  if (!e) return "";
+  static thread_local std::string name;
+  char b[160];
+  const bool fused = e->DP <= 16 && (long long)e->Nt * e->DP <= 256 && !e->cb && !e->pcb && !e->cfg.time_kernels && !(getenv("PTM_FUSED") && *getenv("PTM_FUSED") == '0') &&
+                     !(e->evolve_rate > 0 && (e->W > 64 || e->evolve_cut >= 0));
+  if (e->nloc != e->Nt) snprintf(b, sizeof b, "(sharded: ptm_exchange_* / ptm_shard_step) decide_kernel + %s", ptm_sweep_kernel_name(e));
+  else if (fused) snprintf(b, sizeof b, "ladder_steps_kernel<%d, %d, %d>", e->DP, e->prop_kind == PTM_PROP_DIAG ? KIND_DIAG : KIND_DENSE, (long long)e->Nt * e->DP <= 64 ? 64 : 256);
+  else if (ladder_applies(e)) snprintf(b, sizeof b, "ladder_persistent_kernel<%d, %d>", e->DP, e->prop_kind == PTM_PROP_DIAG ? KIND_DIAG : KIND_DENSE);
+  else snprintf(b, sizeof b, "decide_kernel + %s", ptm_sweep_kernel_name(e));
+  name = b;
+  return name.c_str();
 }
 
 // ---- verification hooks ------------------------------------------------------------------------------------------------

@@ -1,0 +1,35 @@
+// ptm_ladder_args.hpp -- argument block and LDS sizes of the persistent ladder kernel (ptm_ladder_kernel.hpp), shared with the host
+#pragma once
+#include <stddef.h>
+
+namespace ptm {
+
+constexpr int LADDER_H = 8;   // halo depth in rungs (parallel.DEFAULT_HALO has the run-length statistics)
+
+struct LadderArgs {
+  int nsteps;           // steps asked for
+  int NB;               // workgroups per walker-ladder
+  int ms;               // maxswapsperstep (chain.cc:1192)
+  double thresh;        // (Ntemps-1)*swap_rate/maxswapsperstep (chain.cc:1413)
+  double* pub_x;        // [2][Nc][DP]  published rows (dimension d at d), by step parity
+  double* pub_ll;       // [2][Nc]
+  double* pub_lp;       // [2][Nc]
+  int* flags;           // [W * NB]  steps published by each workgroup since the launch began
+  int* ctl;             // [0] abort (a neighbour never showed up), [1] steps done (set by workgroup 0), [2] whole-ladder steps taken
+  int* slow_done;       // [W] workgroups that finished a whole-ladder exchange (a barrier of the ladder's workgroups)
+  long long* swap_cnt;  // [W][Nt-1][2] {tries, accepts} (chain.hh:244-245)
+  int* swap_log;        // [W][ms] candidate log of the LAST step asked for (ptm_get_last_swaps)
+  long long spin_limit; // wall-clock ticks a workgroup waits for a neighbour before it gives up
+  long long* prof;      // null, or [W * NB][8] phase clocks (diagnostics)
+  int max_run;          // longest run of surviving picks on consecutive rungs a step may hold (<= LADDER_H; tests lower it)
+};
+
+// LDS of the decide replay (bytes): first[Nt] | cand[ms] | ua[ms] | alive[ms] (+pad) | flag words
+inline size_t ladder_decide_lds_bytes(int Nt, int ms) { return (size_t)((Nt + 1) & ~1) * 4 + (size_t)((ms + 1) & ~1) * 8 + (size_t)((ms + 7) & ~7) + 32 + (size_t)Nt * 12 + 16; }
+// ... and of the window: llike (working + original), lprior, rows, perm | tries / accepts of the own pairs
+inline size_t ladder_window_lds_bytes(int DP) {
+  const int R = 256 / DP, WN = 1 + R + LADDER_H;
+  return (size_t)WN * 8 * 3 + (size_t)WN * DP * 8 + (size_t)((WN + 3) & ~3) * 4 + (size_t)R * 8 + 64;
+}
+
+}  // namespace ptm

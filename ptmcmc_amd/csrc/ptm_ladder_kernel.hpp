@@ -1,0 +1,421 @@
+// ptm_ladder_kernel.hpp -- LONG LADDERS OF FEW WALKERS: many parallel_tempering_chains::step calls in ONE launch, the chains'
+// state resident in registers.
+//
+// The reference's own shape -- ONE ladder of 1024 rungs (BASELINE: D = 32, 1024 temperatures) -- is 512 waves of work per
+// step and all latency: as two launches per step (exchange kernel, lanes kernel) it costs ~19 us, most of it launch
+// boundaries and the ~10 dependent trips to memory between them.  Here a grid of resident workgroups walks the steps of a
+// ptm_step(n) call without returning to the host (the caller's loop this replaces: ptmcmc.cc:563-599):
+//
+//   * a workgroup of 256 lanes owns R = 256 / DP consecutive rungs of one walker's ladder (8 at DP = 32), a lane per
+//     dimension as in the lanes kernel (ptm_lanes_kernel.hpp): the state row sits in ONE register per lane, llike / lprior /
+//     the MH_chain counters in registers too, the rung's row of the proposal factor (it never changes) in 32 registers,
+//     tables in LDS -- loaded once per launch;
+//   * every workgroup replays the step's candidate draws and the survivor filter of the WHOLE ladder (chain.cc:1410-1418: they
+//     depend on the ladder's random stream only), exactly as the shards of a multi-GPU run do (ptm_decide.hpp), and decides the
+//     exchanges that can change its own rungs from its own llikes, the top rung of the workgroup below and the bottom H = 8
+//     rungs of the workgroup above;
+//   * after its Metropolis moves a workgroup PUBLISHES its rows, llikes and lpriors (a double buffer by step parity) and raises
+//     its flag; before the trials of the next step it waits for the flags of its two NEIGHBOURS only -- no grid-wide barrier --
+//     and reads their published rungs (the halo llikes and the rows that may move in: exchanges propagate downwards only,
+//     chain.cc:1417-1418, so a row comes from at most H rungs above or one below).  The candidate draws, the filter, the
+//     step's normals and the product factor . z do not depend on anybody's state: they are computed while the flags travel;
+//   * a run of H + 1 surviving picks on consecutive rungs would reach past a halo (probability ~ swap_rate^9 / 9! per rung and
+//     step).  It is a property of the draws alone and every workgroup of the ladder sees it: that step's exchange phase is then
+//     taken from the WHOLE ladder's publications -- all the ladder's workgroups wait for each other, replay every trial, and
+//     nobody publishes again before everybody has read.  Nothing is ever decided blindly, and no step leaves the kernel.
+//   * the Metropolis moves of a step are made BEFORE its exchange phase is looked at: which rungs an exchange attempt touches
+//     (they make no move) is known from the draws, the moves of the others need nothing of the neighbours -- the flags travel
+//     meanwhile.
+//
+// Arithmetic: the operation sequences of lanes_body / decide_body, number for number -- the chains are bit-identical to the
+// two-launch path and to the CPU checker (the parity suite runs through this kernel wherever it applies).
+// Scope: the plain workload (open bounds, all-uniform prior, zero mean, no one-dimensional moves, no mixture, fixed ladder,
+// device target), no history / MAP tracking, DP = 16 or 32.
+#pragma once
+#include "ptm_decide.hpp"
+#include "ptm_ladder_args.hpp"
+#include "ptm_lanes_kernel.hpp"
+
+namespace ptm {
+
+template <int DP, int KIND>
+__global__ __launch_bounds__(256) void ladder_persistent_kernel(const Dev p, const LadderArgs a) {
+  static_assert(DP == 16 || DP == 32, "persistent ladder kernel: DP 16 or 32");
+  constexpr int R = 256 / DP;            // rungs per workgroup
+  constexpr int CPW = 64 / DP;           // chains per wave
+  constexpr int H = LADDER_H;
+  constexpr int WNMAX = 1 + R + H;
+  static_assert(R >= H, "a halo must fit the neighbouring workgroup");
+  extern __shared__ __attribute__((aligned(16))) double lds_all[];
+  const int tid = threadIdx.x;
+  const int Nt = p.Nt, ms = a.ms, NB = a.NB;
+  const int NONE = 0x7fffffff;
+
+  // -- which ladder, which rungs.  Consecutive workgroup ids go round the 8 XCDs; neighbours in the ladder should share an L2.
+  const int G = gridDim.x;
+  int L = blockIdx.x;
+  if ((G & 7) == 0) L = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+  const int w = L / NB, b = L - w * NB;
+  const int r0 = b * R;
+  const int r1 = r0 + R < Nt ? r0 + R : Nt;
+  const int wlo = r0 > 0 ? r0 - 1 : 0;
+  const int whi = (r1 - 1 + H < Nt - 1) ? r1 - 1 + H : Nt - 1;
+  const int WN = whi - wlo + 1;
+
+  // -- LDS carve
+  double* p2s = lds_all + BM_TABLE_DOUBLES;
+  double* wsc = p2s + lanes_p2_doubles<DP>() + (tid >> 6) * (3 * 64 + 4 * CPW);
+  double* vbuf = wsc;
+  double* sbuf = wsc + 64;
+  double* pbuf = wsc + 3 * 64;
+  unsigned char* dsm = reinterpret_cast<unsigned char*>(lds_all + ((lanes_lds_doubles<DP>(4) + 1) & ~1));
+  int* first = reinterpret_cast<int*>(dsm);                               // [Nt]
+  int* cand = first + ((Nt + 1) & ~1);                                    // [ms]
+  uint32_t* ua = reinterpret_cast<uint32_t*>(cand + ((ms + 1) & ~1));     // [ms]
+  unsigned char* alive = reinterpret_cast<unsigned char*>(ua + ((ms + 1) & ~1));   // [ms]
+  int* sflag = reinterpret_cast<int*>(alive + ((ms + 7) & ~7));           // [0] run longer than the halo, [1], [2] gave up waiting
+  double* wll = reinterpret_cast<double*>(sflag + 8);                     // [WN] llike view, exchanged as the picks are decided
+  double* wll0 = wll + WNMAX;                                             // [WN] llikes as published
+  double* wlp0 = wll0 + WNMAX;                                            // [WN] lpriors as published
+  double* wx = wlp0 + WNMAX;                                              // [WN][DP] rows as published
+  int* wperm = reinterpret_cast<int*>(wx + WNMAX * DP);                   // [WN] source rung of the row now at a rung
+  int* ptry = wperm + ((WNMAX + 3) & ~3);                                 // [R] exchange attempts of the own pairs (lower rung here)
+  int* pacc = ptry + R;                                                   // [R] ... accepted
+  double* llall = reinterpret_cast<double*>(pacc + R + ((2 * R) & 1));    // [Nt] whole-ladder llike view (steps with a run longer than the halo)
+  int* permall = reinterpret_cast<int*>(llall + Nt);                      // [Nt] ... and row map
+
+  lanes_stage<DP>(p, lds_all);
+  for (int i = tid; i < Nt; i += 256) first[i] = NONE;
+  if (tid < R) { ptry[tid] = 0; pacc[tid] = 0; }
+  if (tid < 4) sflag[tid] = 0;
+
+  // -- this lane's chain
+  const int lane = tid & 63;
+  const int d = lane % DP, g = lane / DP;
+  const int slot = (tid >> 6) * CPW + g;        // rung of the workgroup
+  const bool live = r0 + slot < r1;
+  const int rg = live ? r0 + slot : r1 - 1;     // dead lanes shadow the last rung and write nothing
+  const int c = rg * p.W + w;
+  const bool lead = d == 0;
+  const int pos = row_pos<DP>(d);
+  auto sync_wave = [] { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); };
+  constexpr unsigned long long GM = DP == 64 ? ~0ull : ((1ull << (DP & 63)) - 1ull);
+  auto all_of_chain = [&](bool v) { return ((__builtin_amdgcn_ballot_w64(v) >> (g * DP)) & GM) == GM; };
+
+  double xd = p.x[(size_t)c * DP + pos];
+  double ll = p.ll[c], lp = p.lp[c];
+  int ntries = p.ntries[c], naccept = p.naccept[c], last_type = p.last_type[c];
+  unsigned int nhist = p.nhist[c];
+  const double beta = p.beta[rg];
+  const double plo = p.plo[d], phi = p.phi[d];
+  const uint32_t stream = (uint32_t)(w + p.w_off) * (uint32_t)Nt + (uint32_t)rg;
+  // row d of the rung's factor (column-major [col][row]); the sigma of a diagonal proposal
+  double tcol[KIND == KIND_DIAG ? 1 : DP];
+  if (KIND == KIND_DIAG) tcol[0] = p.prop[(size_t)rg * p.prop_stride + d];
+  else {
+#pragma unroll
+    for (int j = 0; j < DP; ++j) tcol[KIND == KIND_DIAG ? 0 : j] = p.prop[(size_t)rg * p.prop_stride + (size_t)j * DP + d];
+  }
+  const double* prow = p2s + (size_t)d * (d + 1) / 2;
+  const size_t NcDP = (size_t)p.Nc * DP;
+  const int blk = w * NB + b;
+  __syncthreads();
+
+  // optional phase clock (a.prof != null: PTM_LADDER_PROF=1, tools/w1_probe.py): 100 MHz ticks per phase, summed over the steps
+  long long tick_sum[7] = {0, 0, 0, 0, 0, 0, 0}, tick_last = 0;
+#define PTM_LADDER_TICK(k) do { if (a.prof && tid == 0) { const long long t_ = wall_clock64(); if ((k) > 0) tick_sum[(k)] += t_ - tick_last; tick_last = t_; } } while (0)
+#define PTM_LADDER_ALIVE(r) ((r) >= 0 && (r) <= Nt - 2 && first[(r)] != NONE && alive[first[(r)]])
+  // one trial (chain.cc:1459-1467) on a llike view `lv` / row map `pm` indexed from rung `base`; own pairs are counted and logged
+  auto trial = [&](double* lv, int* pm, int base, int i, bool last_step) {
+    const int kk = first[i];
+    double lla = lv[i - base];
+    if (!(lla > -1e200)) lla = -1e200;
+    double llb = lv[i + 1 - base];
+    if (!(llb > -1e200)) llb = -1e200;
+    const double logH = -(p.beta[i + 1] - p.beta[i]) * (llb - lla);
+    bool acc = true;
+    if (logH < 0) acc = dlog_u01(ua[kk]) < logH;
+    if (acc) {
+      const double t = lv[i - base]; lv[i - base] = lv[i + 1 - base]; lv[i + 1 - base] = t;
+      const int q = pm[i - base]; pm[i - base] = pm[i + 1 - base]; pm[i + 1 - base] = q;
+    }
+    if (i >= r0 && i < r1) {                              // an own pair: its counters, its line of the log
+      ptry[i - r0] += 1;
+      if (acc) pacc[i - r0] += 1;
+      if (last_step) a.swap_log[(size_t)w * ms + kk] = i | (acc ? 0x40000000 : 0);
+    }
+  };
+  // thread 0 waits until workgroup `nb` of this ladder has published step s (false: gave up)
+  auto wait_for = [&](int nb, int s, long long t0) {
+    int* f = &a.flags[w * NB + nb];
+    while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < s + 1) {
+      if (__hip_atomic_load(&a.ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 || wall_clock64() - t0 > a.spin_limit) return false;
+      __builtin_amdgcn_s_sleep(1);
+    }
+    return true;
+  };
+  int done = 0, nslow = 0;
+  bool aborted = false;
+  for (int s = 0; s < a.nsteps; ++s) {
+    const uint64_t step = p.step + (uint64_t)s;
+    const int par = s & 1;
+    const bool last_step = s == a.nsteps - 1;
+    // ---- 1. publish the state this step starts from, raise the flag.  Every published word and every flag is written and read
+    //      with agent-scope atomics (sc1 accesses: coherent across the XCDs' L2s by themselves, no cache-wide write-back or
+    //      invalidate); a wave's stores have completed before it reaches the barrier, the flag goes out after the barrier
+    //      (tools/probes/flag_pingpong_probe.hip: 0.8-1.2 us per hand-over, against 0.4 us for every __threadfence on top)
+    PTM_LADDER_TICK(0);
+    if (live) {
+      __hip_atomic_store(&a.pub_x[par * NcDP + (size_t)c * DP + d], xd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (lead) {
+        __hip_atomic_store(&a.pub_ll[(size_t)par * p.Nc + c], ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&a.pub_lp[(size_t)par * p.Nc + c], lp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(&a.flags[blk], s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    PTM_LADDER_TICK(1);
+
+    // ---- 2. what does not depend on anybody's state
+    // candidate draws (chain.cc:1410-1416) and survivor filter (:1417-1418) of the whole ladder: decide_body's, verbatim
+    for (int k = tid; k < ms; k += 256) {
+      const u32x4 o = draw_block(p.seed, TAG_PT, (uint32_t)(w + p.w_off), step, (uint32_t)k);
+      int n = -2;
+      if (Nt > 1 && u01(o.v0) < a.thresh) n = (int)(u01(o.v1) * (Nt - 1));
+      cand[k] = n;
+      ua[k] = o.v2;
+      alive[k] = 0;
+      if (n >= 0) atomicMin(&first[n], k);
+    }
+    __syncthreads();
+    for (int k = tid; k < ms; k += 256) {
+      const int n = cand[k];
+      if (n < 0 || first[n] != k) continue;                      // repeated rung value: dropped
+      if (n > 0 && first[n - 1] != NONE) continue;               // not a run head
+      bool al = true;
+      for (int m = n;; ++m) {
+        alive[first[m]] = al ? 1 : 0;
+        if (m + 1 > Nt - 2 || first[m + 1] == NONE) break;
+        al = !(al && first[m] < first[m + 1]);
+      }
+    }
+    __syncthreads();
+    // a run of more than H surviving picks on consecutive rungs anywhere in the ladder: the halos do not cover this step (every
+    // workgroup of the ladder sees the same draws): it takes the whole-ladder form below
+    for (int k = tid; k < ms; k += 256) {
+      const int n = cand[k];
+      if (n < 0 || !alive[k] || PTM_LADDER_ALIVE(n - 1)) continue;   // bottoms of runs of surviving picks
+      int len = 1;
+      while (PTM_LADDER_ALIVE(n + len)) ++len;
+      if (len > a.max_run) sflag[0] = 1;
+    }
+    // rungs an exchange attempt touches make no Metropolis move this step, one add_state per attempt (chain.cc:1487-1490,
+    // 1531-1534,1553-1557): known from the draws alone
+    const int tc = (PTM_LADDER_ALIVE(rg) ? 1 : 0) + (PTM_LADDER_ALIVE(rg - 1) ? 1 : 0);
+
+    // ---- 3. MH_chain::step (chain.cc:966-1022) for the rungs no exchange touches -- they need nothing of the neighbours, whose
+    //      flags travel meanwhile; touched chains' lanes run along and change nothing
+    {
+      const u32x4 o0 = draw_block(p.seed, TAG_MH, stream, step, 0);
+      double off;   // offset = factor . z of this lane's rung (gaussian_prop::draw, proposal_distribution.hh:194-218)
+      {
+        const u32x4 o = draw_block(p.seed, TAG_MH, stream, step, (uint32_t)((d >> 2) + 1));
+        const bool hi = (d & 2) != 0;
+        double z0, z1;
+        boxmuller(hi ? o.v2 : o.v0, hi ? o.v3 : o.v1, lds_all, z0, z1);
+        const double zd = (d & 1) ? z1 : z0;
+        if (KIND == KIND_DIAG) off = tcol[0] * zd;
+        else {
+          vbuf[g * DP + d] = zd;
+          sync_wave();
+          double acc = 0.0;
+#pragma unroll
+          for (int h = 0; h < DP / 16; ++h)
+#pragma unroll
+            for (int sl = 0; sl < 4; ++sl)
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                const int j = 16 * h + 4 * k + sl;
+                acc = __builtin_fma(tcol[KIND == KIND_DIAG ? 0 : j], vbuf[g * DP + j], acc);
+              }
+          off = acc;
+          sync_wave();
+        }
+      }
+      const double xn = xd + off;                                 // state::add (states.cc:205-214)
+      const double bl = beta * ll;
+      const double cur_lpost = lp + bl;
+      const double oldlprior = cur_lpost - bl;                    // chain.cc:973
+      const bool ind = !(xn < plo) && !(xn > phi);
+      const bool in = all_of_chain(ind);
+      const double newlprior = in ? p.lprior_const : -__builtin_inf();
+      const bool want_like = newlprior > -1e200 || newlprior - oldlprior > p.min_prior;   // chain.cc:980 (Q1)
+      vbuf[g * DP + d] = xn;
+      sync_wave();
+      {
+        const double* y = vbuf + g * DP;
+        double sacc = 0.0;
+        for (int j = 0; j <= d; ++j) sacc = __builtin_fma(prow[j], y[j], sacc);
+        sbuf[g * DP + d] = sacc;
+      }
+      sync_wave();
+      if (d < 4) {
+        double pq = 0.0;
+#pragma unroll
+        for (int t = 0; t < DP / 4; ++t) pq = __builtin_fma(vbuf[g * DP + d + 4 * t], sbuf[g * DP + d + 4 * t], pq);
+        pbuf[g * 4 + d] = pq;
+      }
+      sync_wave();
+      const double quad = ((pbuf[g * 4 + 0] + pbuf[g * 4 + 1]) + pbuf[g * 4 + 2]) + pbuf[g * 4 + 3];
+      sync_wave();   // (vbuf / pbuf are rewritten by the next step's draw)
+      double newlike = p.like0 - 0.5 * quad;
+      double newlpost = newlike * beta + newlprior;
+      if (!want_like) newlike = newlpost = -__builtin_inf();
+      const double logH = newlpost - cur_lpost;
+      bool accept = true;
+      if (logH < 0) accept = dlog_u01(o0.v0) < logH;              // chain.cc:998-1001 (NaN stays accepted)
+      if (!tc) {
+        ntries += 1;
+        nhist += 1u;
+        if (accept) { xd = xn; ll = newlike; lp = newlprior; naccept += 1; last_type = 0; }
+      } else nhist += (unsigned int)tc;
+    }
+    __syncthreads();
+    PTM_LADDER_TICK(2);
+
+    if (!sflag[0]) {
+      // ---- 4. the exchange phase from the neighbours' publications.  First their flags
+      if (tid == 0) {
+        const long long t0 = wall_clock64();
+        bool ok = true;
+        if (b > 0) ok = wait_for(b - 1, s, t0);
+        if (ok && b + 1 < NB) ok = wait_for(b + 1, s, t0);
+        if (!ok) { __hip_atomic_store(&a.ctl[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); sflag[1] = 1; }
+      }
+      __syncthreads();
+      if (sflag[1]) { aborted = true; break; }
+      PTM_LADDER_TICK(3);
+      // the window: llikes, lpriors and rows of rungs wlo .. whi as published for this step
+      {
+        const double* px = a.pub_x + par * NcDP;
+        const double* pl = a.pub_ll + (size_t)par * p.Nc;
+        const double* pp = a.pub_lp + (size_t)par * p.Nc;
+        for (int i = tid; i < WN * DP; i += 256) {
+          const int r = wlo + i / DP, dd = i % DP;
+          wx[i] = __hip_atomic_load(px + (size_t)(r * p.W + w) * DP + dd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (tid < WN) {
+          const int cc = (wlo + tid) * p.W + w;
+          const double v = __hip_atomic_load(pl + cc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          wll[tid] = v; wll0[tid] = v;
+          wlp0[tid] = __hip_atomic_load(pp + cc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          wperm[tid] = wlo + tid;
+        }
+      }
+      __syncthreads();
+      PTM_LADDER_TICK(4);
+      // trials (chain.cc:1436-1537): the top pick of each run of surviving picks inside the window walks it downwards
+      if (tid < WN - 1) {
+        const int n = wlo + tid;                                   // pair (n, n + 1), both inside the window
+        // A pick above that is inside the window walks this pick too.  One that lies outside (n + 1 == whi) may replace rung
+        // whi, so the run below it is unknown here -- and it has at most H picks (checked above): it ends above this
+        // workgroup's rungs.  Somebody else's.
+        if (PTM_LADDER_ALIVE(n) && !PTM_LADDER_ALIVE(n + 1))
+          for (int i = n; i >= wlo; --i) {
+            trial(wll, wperm, wlo, i, last_step);
+            if (!PTM_LADDER_ALIVE(i - 1)) break;
+          }
+      }
+      __syncthreads();
+      PTM_LADDER_TICK(5);
+      // the rows the exchanges brought
+      if (tc) {
+        const int src = wperm[rg - wlo];
+        if (src != rg) { xd = wx[(src - wlo) * DP + d]; ll = wll0[src - wlo]; lp = wlp0[src - wlo]; }
+      }
+    } else {
+      // ---- 4'. the same from the WHOLE ladder's publications (a run of surviving picks longer than the halo: rare).  Every
+      //      workgroup of the ladder waits for all of them, replays every trial of the ladder on a full llike view, takes the rows
+      //      of its own rungs from wherever they come, and nobody goes on before everybody has read.
+      nslow += 1;
+      if (tid == 0) sflag[2] = 0;
+      __syncthreads();
+      {
+        const long long t0 = wall_clock64();
+        bool ok = true;
+        for (int nb = tid; nb < NB && ok; nb += 256)
+          if (nb != b) ok = wait_for(nb, s, t0);
+        if (!ok) sflag[2] = 1;
+      }
+      __syncthreads();
+      if (sflag[2]) { if (tid == 0) __hip_atomic_store(&a.ctl[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); aborted = true; break; }
+      const double* pl = a.pub_ll + (size_t)par * p.Nc;
+      for (int r = tid; r < Nt; r += 256) {
+        llall[r] = __hip_atomic_load(pl + (size_t)r * p.W + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        permall[r] = r;
+      }
+      __syncthreads();
+      for (int k = tid; k < ms; k += 256) {
+        const int n = cand[k];
+        if (n < 0 || !alive[k] || PTM_LADDER_ALIVE(n + 1)) continue;   // tops of runs of surviving picks
+        for (int i = n; i >= 0; --i) {
+          trial(llall, permall, 0, i, last_step);
+          if (!PTM_LADDER_ALIVE(i - 1)) break;
+        }
+      }
+      __syncthreads();
+      if (tc) {
+        const int src = permall[rg];
+        if (src != rg) {
+          const size_t cs = (size_t)src * p.W + w;
+          xd = __hip_atomic_load(a.pub_x + par * NcDP + cs * DP + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ll = __hip_atomic_load(pl + cs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          lp = __hip_atomic_load(a.pub_lp + (size_t)par * p.Nc + cs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) {   // everybody has read: only then may anybody publish again
+        sflag[0] = 0;
+        __hip_atomic_fetch_add(&a.slow_done[w], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const long long t0 = wall_clock64();
+        while (__hip_atomic_load(&a.slow_done[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < NB * nslow) {
+          if (__hip_atomic_load(&a.ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 || wall_clock64() - t0 > a.spin_limit) { sflag[2] = 1; break; }
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
+      __syncthreads();
+      if (sflag[2]) { if (tid == 0) __hip_atomic_store(&a.ctl[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); aborted = true; break; }
+    }
+    if (last_step && b == 0)                                      // the log lines of the picks that did not survive
+      for (int k = tid; k < ms; k += 256)
+        if (!alive[k]) a.swap_log[(size_t)w * ms + k] = -2;
+    __syncthreads();   // (first / alive / window are rewritten by the next step)
+    for (int k = tid; k < ms; k += 256) { const int n = cand[k]; if (n >= 0) first[n] = NONE; }
+    PTM_LADDER_TICK(6);
+    done = s + 1;
+  }
+#undef PTM_LADDER_ALIVE
+
+  // -- back to the engine's arrays
+  if (!aborted && live) {
+    p.x[(size_t)c * DP + pos] = xd;
+    if (lead) {
+      p.ll[c] = ll; p.lp[c] = lp;
+      p.ntries[c] = ntries; p.naccept[c] = naccept; p.last_type[c] = last_type; p.nhist[c] = nhist;
+    }
+  }
+  __syncthreads();
+  if (!aborted && tid < R && r0 + tid < Nt - 1 && r0 + tid < r1) {
+    long long* sc = a.swap_cnt + ((size_t)w * (Nt - 1) + (r0 + tid)) * 2;
+    sc[0] += ptry[tid];
+    sc[1] += pacc[tid];
+  }
+  if (a.prof && tid == 0)
+    for (int k = 0; k < 7; ++k) a.prof[(size_t)blk * 8 + k] = tick_sum[k];
+#undef PTM_LADDER_TICK
+  if (L == 0 && tid == 0) { a.ctl[1] = aborted ? -1 : done; a.ctl[2] = nslow; }
+}
+
+}  // namespace ptm

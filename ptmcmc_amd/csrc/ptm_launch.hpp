@@ -6,6 +6,7 @@
 
 #include "ptm_decide.hpp"
 #include "ptm_kernels.hpp"
+#include "ptm_ladder_args.hpp"
 
 // the lanes kernel (ptm_lanes_kernel.hpp) takes launches of at most this many lanes (chains x padded dimension)
 #define PTM_LANES_MAX (1ll << 20)
@@ -32,6 +33,15 @@ PTM_DECL_FUSED(4)
 PTM_DECL_FUSED(8)
 PTM_DECL_FUSED(16)
 #undef PTM_DECL_FUSED
+// long ladders of few walkers: many PT steps per launch on a grid of resident workgroups (ptm_ladder_kernel.hpp; DP 16 and 32).
+// ladder_blocks_N: how many of its workgroups the device holds at once (0: the kernel cannot run); launch_ladder_N: the launch
+#define PTM_DECL_LADDER(N)                                  \
+  size_t ladder_lds_##N(int Nt, int ms);                    \
+  int ladder_blocks_##N(bool diag, size_t lds);             \
+  hipError_t launch_ladder_##N(const Dev& p, const LadderArgs& a, bool diag, int grid, size_t lds, hipStream_t st);
+PTM_DECL_LADDER(16)
+PTM_DECL_LADDER(32)
+#undef PTM_DECL_LADDER
 PTM_DECL_DP(4)
 PTM_DECL_DP(8)
 PTM_DECL_DP(16)

@@ -27,7 +27,7 @@ EXPORTS = [
     "ptm_set_proposals", "ptm_set_proposal_rung", "ptm_set_proposal_mixture", "ptm_set_proposal_callback", "ptm_set_states", "ptm_init_from_prior", "ptm_init_from_prior_k", "ptm_sweep", "ptm_step", "ptm_sync",
     "ptm_copy_llike", "ptm_llike_device_ptr", "ptm_exchange_decide", "ptm_exchange_finish_and_sweep", "ptm_exchange_install", "ptm_sweep_rungs", "ptm_exchange_buffer_doubles", "ptm_exchange_row_capacity", "ptm_shard_unique_id", "ptm_shard_init", "ptm_shard_step", "ptm_shard_finalize", "ptm_get_states", "ptm_batch_begin", "ptm_batch_end",
     "ptm_get_array", "ptm_get_swap_counts", "ptm_get_last_swaps", "ptm_max_swaps_per_step", "ptm_get_history", "ptm_get_history_invtemps", "ptm_set_history", "ptm_set_map", "ptm_get_map", "ptm_restore", "ptm_step_count",
-    "ptm_timer_start", "ptm_timer_stop", "ptm_get_kernel_times", "ptm_sweep_kernel_name", "ptm_debug_eval",
+    "ptm_timer_start", "ptm_timer_stop", "ptm_get_kernel_times", "ptm_sweep_kernel_name", "ptm_step_kernel_name", "ptm_debug_eval",
     "ptm_debug_philox", "ptm_debug_boxmuller", "ptm_debug_sqrt_scan", "ptm_debug_evaluate",
     "ptm_dev_alloc", "ptm_dev_free", "ptm_dev_copy",
 ]
@@ -73,6 +73,9 @@ def load():
     L.ptm_last_error.restype = C.c_char_p
     L.ptm_sweep_kernel_name.restype = C.c_char_p
     L.ptm_sweep_kernel_name.argtypes = [C.c_void_p]
+    if hasattr(L, "ptm_step_kernel_name"):
+        L.ptm_step_kernel_name.restype = C.c_char_p
+        L.ptm_step_kernel_name.argtypes = [C.c_void_p]
     L.ptm_step_count.restype = C.c_uint64
     L.ptm_step_count.argtypes = [C.c_void_p]
     L.ptm_engine_create.argtypes = [C.POINTER(PtmConfig), C.POINTER(C.c_void_p)]
@@ -580,3 +583,8 @@ class Engine:
     @property
     def sweep_kernel_name(self):
         return self.L.ptm_sweep_kernel_name(self.h).decode()
+
+    @property
+    def step_kernel_name(self):
+        """what step() launches (ptm_step_kernel_name)"""
+        return self.L.ptm_step_kernel_name(self.h).decode()

@@ -1151,11 +1151,17 @@ def test_compacted_sweep_in_sharded_engines(overlap):
                                                  ({"PTM_LEAN_PIPE": "1"}, 24, 5, 128, "dense", "sweep_mfma32_lean_kernel<0, false>"),
                                                  ({"PTM_COMPACT": "0"}, 32, 6, 1024, "lower", "sweep_mfma32_kernel<2, false, 0, false, false>"),
                                                  ({"PTM_FORCE_VALU": "1"}, 32, 5, 64, "lower", "sweep_kernel<32"),
-                                                 ({"PTM_FUSED": "0"}, 6, 12, 3, "dense", "sweep_lanes_kernel<8")])
+                                                 ({"PTM_FUSED": "0"}, 6, 12, 3, "dense", "sweep_lanes_kernel<8"),
+                                                 ({"PTM_LADDER": "0"}, 32, 40, 2, "lower", "decide_kernel + sweep_lanes_kernel<32"),
+                                                 ({"PTM_LADDER": "0"}, 12, 70, 3, "diag", "decide_kernel + sweep_lanes_kernel<16"),
+                                                 ({"PTM_LADDER_MAXRUN": "1"}, 32, 64, 2, "lower", "ladder_persistent_kernel<32"),
+                                                 ({"PTM_LADDER_MAXRUN": "2"}, 10, 90, 3, "dense", "ladder_persistent_kernel<16")])
 def test_switched_off_variants_stay_bit_exact(env, D, Nt, W, kind, want):
     """The engine's environment switches select code that the default run never reaches: the software-pipelined lean kernel
     (a measured, switched-off experiment: DESIGN.md section 3.1), the un-compacted sweep of a big population, the general VALU
-    kernel on the MFMA workload, the two-launch step of small ladders.  Each in a process of its own (the switches are read
+    kernel on the MFMA workload, the two-launch step of small and of long ladders, and the persistent ladder kernel with its longest
+    admissible run of surviving picks lowered to 1 / 2 -- every few steps the launch then ends early, the step is taken by the
+    two-launch path and the kernel relaunched (with the halo's 8 that path is a once-in-10^12-steps event).  Each in a process of its own (the switches are read
     once), each bit for bit the oracle's chains."""
     import os
     import subprocess
@@ -1198,3 +1204,45 @@ def test_reads_in_one_batch_equal_the_same_reads_one_by_one(W, cap):
         E._chk(e.L.ptm_batch_end(e.h))
     e.step(3); e.sync()                                  # the engine goes on as if nothing happened
     assert e.history()["row"].max() >= cap
+
+
+LADDER_CASES = [
+    # D, Nt, W, kind, swap_rate: long ladders of few walkers -> ladder_persistent_kernel (ptm_ladder_kernel.hpp)
+    (32, 1024, 1, E.PROP_LOWER, 0.1),     # the reference's own shape: BASELINE's D = 32, 1024 temperatures, one ladder
+    (32, 100, 2, E.PROP_LOWER, 0.1),      # 13 workgroups per ladder, the last one ragged (4 rungs)
+    (32, 256, 4, E.PROP_DENSE, 0.25),     # C3's population
+    (20, 37, 1, E.PROP_DENSE, 0.35),      # padded dimensions, a ragged last workgroup, many exchanges per step
+    (16, 70, 3, E.PROP_DIAG, 0.3),        # 16 rungs per workgroup, diagonal proposals
+    (9, 41, 2, E.PROP_LOWER, 0.2),        # 9 -> 16 dimensions
+    (32, 8, 5, E.PROP_LOWER, 0.35),       # one workgroup per ladder: no neighbour at all
+    (32, 9, 1, E.PROP_DIAG, 0.35),        # two workgroups, the second holds one rung
+]
+
+
+@pytest.mark.parametrize("D,Nt,W,kind,sr", LADDER_CASES)
+def test_persistent_ladder_kernel_matches_the_oracle(D, Nt, W, kind, sr):
+    """Long ladders of few walkers step through ONE launch per ptm_step(n) call: resident workgroups of 8 (16) rungs keep their
+    chains in registers, replay the whole ladder's candidate draws and talk to their two neighbours through flags
+    (ptm_ladder_kernel.hpp).  Bit for bit the oracle's chains -- states, llikes, MH_chain counters, swap counters, the last
+    step's candidate log -- step by step and over many steps per launch."""
+    pr, eng, lad = PU.make_pair(D, Nt, W, 1e6, kind=kind, swap_rate=sr)
+    assert eng.step_kernel_name.startswith("ladder_persistent_kernel<%d" % (16 if D <= 16 else 32)), eng.step_kernel_name
+    for k in range(4):
+        eng.step(1); eng.sync(); lad.pt_step(1)
+        PU.assert_same_state(eng, lad, "after PT step %d" % (k + 1))
+        pairs, acc = eng.last_swaps()
+        assert np.array_equal(pairs, lad.last_pairs) and np.array_equal(acc, lad.last_accept), k
+    for n in (2, 3, 150):
+        eng.step(n); eng.sync(); lad.pt_step(n)
+        PU.assert_same_state(eng, lad, "after %d more PT steps in one launch" % n)
+        pairs, acc = eng.last_swaps()
+        assert np.array_equal(pairs, lad.last_pairs) and np.array_equal(acc, lad.last_accept), n
+    t, a = eng.swap_counts()
+    assert np.array_equal(t, lad.swap_count) and np.array_equal(a, lad.swap_accept_count)
+    assert a.sum() > 0 and eng.naccept.sum() > eng.Nc
+    # plain sweeps and the two-launch building blocks still work on the state the kernel left
+    eng.sweep(3); eng.sync(); lad.sweep(3)
+    PU.assert_same_state(eng, lad, "after plain sweeps")
+    eng.step(5); eng.sync(); lad.pt_step(5)
+    PU.assert_same_state(eng, lad, "after PT steps again")
+    eng.close()

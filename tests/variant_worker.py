@@ -14,11 +14,13 @@ if __name__ == "__main__":
     kind = {"lower": E.PROP_LOWER, "dense": E.PROP_DENSE, "diag": E.PROP_DIAG}[sys.argv[4]]
     nsteps, want = int(sys.argv[5]), sys.argv[6]
     pr, eng, lad = PU.make_pair(D, Nt, W, 1e3, kind=kind, swap_rate=0.3)
-    assert want in eng.sweep_kernel_name, eng.sweep_kernel_name
+    assert want in eng.sweep_kernel_name or want in eng.step_kernel_name, (eng.sweep_kernel_name, eng.step_kernel_name)
     for k in range(3):
         eng.step(nsteps); eng.sync(); lad.pt_step(nsteps)
         PU.assert_same_state(eng, lad, "after %d steps" % (nsteps * (k + 1)))
     eng.sweep(2); eng.sync(); lad.sweep(2)
     PU.assert_same_state(eng, lad, "after plain sweeps")
-    print("ok %s accepts %d" % (eng.sweep_kernel_name, int(eng.naccept.sum() - eng.Nc)))
+    t, a = eng.swap_counts()
+    assert (t == lad.swap_count).all() and (a == lad.swap_accept_count).all()
+    print("ok %s | %s accepts %d" % (eng.sweep_kernel_name, eng.step_kernel_name, int(eng.naccept.sum() - eng.Nc)))
     eng.close()
