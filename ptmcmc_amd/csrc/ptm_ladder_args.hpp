@@ -29,7 +29,7 @@ inline size_t ladder_decide_lds_bytes(int Nt, int ms) { return (size_t)((Nt + 1)
 // ... and of the window: llike (working + original), lprior, rows, perm | tries / accepts of the own pairs
 inline size_t ladder_window_lds_bytes(int DP) {
   const int R = 256 / DP, WN = 1 + R + LADDER_H;
-  return (size_t)WN * 8 * 3 + (size_t)WN * DP * 8 + (size_t)((WN + 3) & ~3) * 4 + (size_t)R * 8 + 64;
+  return (size_t)WN * 8 * 5 + (size_t)WN * DP * 8 + (size_t)((WN + 3) & ~3) * 4 + (size_t)R * 8 + 64;
 }
 
 }  // namespace ptm

@@ -77,7 +77,9 @@ __global__ __launch_bounds__(256) void ladder_persistent_kernel(const Dev p, con
   double* wll = reinterpret_cast<double*>(sflag + 8);                     // [WN] llike view, exchanged as the picks are decided
   double* wll0 = wll + WNMAX;                                             // [WN] llikes as published
   double* wlp0 = wll0 + WNMAX;                                            // [WN] lpriors as published
-  double* wx = wlp0 + WNMAX;                                              // [WN][DP] rows as published
+  double* wdb = wlp0 + WNMAX;                                             // [WN] -(beta[n+1] - beta[n]) of the window's pairs
+  double* wlu = wdb + WNMAX;                                              // [WN] log of the accept uniform of the pair's surviving pick
+  double* wx = wlu + WNMAX;                                               // [WN][DP] rows as published
   int* wperm = reinterpret_cast<int*>(wx + WNMAX * DP);                   // [WN] source rung of the row now at a rung
   int* ptry = wperm + ((WNMAX + 3) & ~3);                                 // [R] exchange attempts of the own pairs (lower rung here)
   int* pacc = ptry + R;                                                   // [R] ... accepted
@@ -88,6 +90,7 @@ __global__ __launch_bounds__(256) void ladder_persistent_kernel(const Dev p, con
   for (int i = tid; i < Nt; i += 256) first[i] = NONE;
   if (tid < R) { ptry[tid] = 0; pacc[tid] = 0; }
   if (tid < 4) sflag[tid] = 0;
+  if (tid < WN - 1) wdb[tid] = -(p.beta[wlo + tid + 1] - p.beta[wlo + tid]);   // chain.cc:1463
 
   // -- this lane's chain
   const int lane = tid & 63;
@@ -116,7 +119,10 @@ __global__ __launch_bounds__(256) void ladder_persistent_kernel(const Dev p, con
 #pragma unroll
     for (int j = 0; j < DP; ++j) tcol[KIND == KIND_DIAG ? 0 : j] = p.prop[(size_t)rg * p.prop_stride + (size_t)j * DP + d];
   }
-  const double* prow = p2s + (size_t)d * (d + 1) / 2;
+  // row d of the packed precision matrix {2P_d0 .. 2P_d,d-1, P_dd}, zeros behind it (fma(0, y, s) == s: the chain below runs over all DP)
+  double prow[DP];
+#pragma unroll
+  for (int j = 0; j < DP; ++j) prow[j] = j <= d ? p2s[(size_t)d * (d + 1) / 2 + j] : 0.0;
   const size_t NcDP = (size_t)p.Nc * DP;
   const int blk = w * NB + b;
   __syncthreads();
@@ -126,15 +132,15 @@ __global__ __launch_bounds__(256) void ladder_persistent_kernel(const Dev p, con
 #define PTM_LADDER_TICK(k) do { if (a.prof && tid == 0) { const long long t_ = wall_clock64(); if ((k) > 0) tick_sum[(k)] += t_ - tick_last; tick_last = t_; } } while (0)
 #define PTM_LADDER_ALIVE(r) ((r) >= 0 && (r) <= Nt - 2 && first[(r)] != NONE && alive[first[(r)]])
   // one trial (chain.cc:1459-1467) on a llike view `lv` / row map `pm` indexed from rung `base`; own pairs are counted and logged
-  auto trial = [&](double* lv, int* pm, int base, int i, bool last_step) {
+  auto trial = [&](double* lv, int* pm, int base, int i, bool last_step, double dbeta, double lu) {
     const int kk = first[i];
     double lla = lv[i - base];
     if (!(lla > -1e200)) lla = -1e200;
     double llb = lv[i + 1 - base];
     if (!(llb > -1e200)) llb = -1e200;
-    const double logH = -(p.beta[i + 1] - p.beta[i]) * (llb - lla);
+    const double logH = dbeta * (llb - lla);
     bool acc = true;
-    if (logH < 0) acc = dlog_u01(ua[kk]) < logH;
+    if (logH < 0) acc = lu < logH;
     if (acc) {
       const double t = lv[i - base]; lv[i - base] = lv[i + 1 - base]; lv[i + 1 - base] = t;
       const int q = pm[i - base]; pm[i - base] = pm[i + 1 - base]; pm[i + 1 - base] = q;
@@ -213,9 +219,44 @@ __global__ __launch_bounds__(256) void ladder_persistent_kernel(const Dev p, con
     // rungs an exchange attempt touches make no Metropolis move this step, one add_state per attempt (chain.cc:1487-1490,
     // 1531-1534,1553-1557): known from the draws alone
     const int tc = (PTM_LADDER_ALIVE(rg) ? 1 : 0) + (PTM_LADDER_ALIVE(rg - 1) ? 1 : 0);
+    // log of the accept uniform of every surviving pick in the window (the uniform's slot is the pick's whether needed or not: Q5),
+    // taken off the chain of dependent trials: the last wave's first lanes, which hold the workgroup's last rungs or nothing
+    if (tid >= 256 - 32 && tid - (256 - 32) < WN - 1) {
+      const int n = wlo + tid - (256 - 32);
+      if (PTM_LADDER_ALIVE(n)) wlu[n - wlo] = dlog_u01(ua[first[n]]);
+    }
 
-    // ---- 3. MH_chain::step (chain.cc:966-1022) for the rungs no exchange touches -- they need nothing of the neighbours, whose
-    //      flags travel meanwhile; touched chains' lanes run along and change nothing
+    // ---- 3. MH_chain::step (chain.cc:966-1022) for the rungs no exchange touches -- they need nothing of the neighbours.  The
+    //      hand-over rides behind it: every wave asks for the neighbours' flags now, looks at the answer after the proposal's
+    //      offset is computed (a microsecond later) and, if both neighbours have published, asks for its share of the window --
+    //      which is there when the Metropolis tests are done.  Touched chains' lanes run along and change nothing.
+    int fl_lo = s + 1, fl_hi = s + 1;
+    auto ask_flags = [&] {
+      if (lane == 0) {
+        if (b > 0) fl_lo = __hip_atomic_load(&a.flags[blk - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (b + 1 < NB) fl_hi = __hip_atomic_load(&a.flags[blk + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    };
+    auto flags_up = [&] { return __builtin_amdgcn_readfirstlane(fl_lo) >= s + 1 && __builtin_amdgcn_readfirstlane(fl_hi) >= s + 1; };
+    // the window: rows, llikes and lpriors of rungs wlo .. whi as published for this step, NWR words per thread
+    constexpr int NWR = (WNMAX * DP + 2 * WNMAX + 255) / 256;
+    double wr[NWR];
+    auto ask_window = [&] {
+      const double* px = a.pub_x + par * NcDP;
+      const double* pl = a.pub_ll + (size_t)par * p.Nc;
+      const double* pp = a.pub_lp + (size_t)par * p.Nc;
+#pragma unroll
+      for (int q = 0; q < NWR; ++q) {
+        const int i = tid + 256 * q;
+        const double* src = nullptr;
+        if (i < WN * DP) src = px + (size_t)((wlo + i / DP) * p.W + w) * DP + i % DP;
+        else if (i < WN * DP + WN) src = pl + (size_t)(wlo + i - WN * DP) * p.W + w;
+        else if (i < WN * DP + 2 * WN) src = pp + (size_t)(wlo + i - WN * DP - WN) * p.W + w;
+        wr[q] = src ? __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+      }
+    };
+    ask_flags();
+    bool have_window = false;
     {
       const u32x4 o0 = draw_block(p.seed, TAG_MH, stream, step, 0);
       double off;   // offset = factor . z of this lane's rung (gaussian_prop::draw, proposal_distribution.hh:194-218)
@@ -243,6 +284,8 @@ __global__ __launch_bounds__(256) void ladder_persistent_kernel(const Dev p, con
           sync_wave();
         }
       }
+      if (flags_up()) { ask_window(); have_window = true; }
+      else ask_flags();
       const double xn = xd + off;                                 // state::add (states.cc:205-214)
       const double bl = beta * ll;
       const double cur_lpost = lp + bl;
@@ -254,9 +297,14 @@ __global__ __launch_bounds__(256) void ladder_persistent_kernel(const Dev p, con
       vbuf[g * DP + d] = xn;
       sync_wave();
       {
+        // s_d = sum_{j<=d} P2_dj y_j, one fma chain with j ascending (gauss_llike's order); the terms behind the diagonal add
+        // fma(0, y_j, s) = s exactly for finite y_j, and change nothing -- they keep the loop free of a lane-dependent trip count,
+        // so that the operand reads run ahead of the chain.  A non-finite proposal never gets here with a wanted likelihood:
+        // the prior box has rejected it (want_like false => the likelihood is dropped below).
         const double* y = vbuf + g * DP;
         double sacc = 0.0;
-        for (int j = 0; j <= d; ++j) sacc = __builtin_fma(prow[j], y[j], sacc);
+#pragma unroll
+        for (int j = 0; j < DP; ++j) sacc = __builtin_fma(prow[j], y[j], sacc);
         sbuf[g * DP + d] = sacc;
       }
       sync_wave();
@@ -281,40 +329,35 @@ __global__ __launch_bounds__(256) void ladder_persistent_kernel(const Dev p, con
         if (accept) { xd = xn; ll = newlike; lp = newlprior; naccept += 1; last_type = 0; }
       } else nhist += (unsigned int)tc;
     }
-    __syncthreads();
     PTM_LADDER_TICK(2);
+    // the window into LDS (a wave whose neighbours had not published when it looked waits for them now)
+    if (!have_window) {
+      if (!flags_up()) {
+        if (lane == 0) {
+          const long long t0 = wall_clock64();
+          bool ok = true;
+          if (b > 0) ok = wait_for(b - 1, s, t0);
+          if (ok && b + 1 < NB) ok = wait_for(b + 1, s, t0);
+          if (!ok) { __hip_atomic_store(&a.ctl[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); sflag[1] = 1; }
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+      ask_window();
+    }
+    PTM_LADDER_TICK(3);
+#pragma unroll
+    for (int q = 0; q < NWR; ++q) {
+      const int i = tid + 256 * q;
+      if (i < WN * DP) wx[i] = wr[q];
+      else if (i < WN * DP + WN) { wll[i - WN * DP] = wr[q]; wll0[i - WN * DP] = wr[q]; wperm[i - WN * DP] = wlo + i - WN * DP; }
+      else if (i < WN * DP + 2 * WN) wlp0[i - WN * DP - WN] = wr[q];
+    }
+    __syncthreads();
+    if (sflag[1]) { aborted = true; break; }
+    PTM_LADDER_TICK(4);
 
     if (!sflag[0]) {
-      // ---- 4. the exchange phase from the neighbours' publications.  First their flags
-      if (tid == 0) {
-        const long long t0 = wall_clock64();
-        bool ok = true;
-        if (b > 0) ok = wait_for(b - 1, s, t0);
-        if (ok && b + 1 < NB) ok = wait_for(b + 1, s, t0);
-        if (!ok) { __hip_atomic_store(&a.ctl[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); sflag[1] = 1; }
-      }
-      __syncthreads();
-      if (sflag[1]) { aborted = true; break; }
-      PTM_LADDER_TICK(3);
-      // the window: llikes, lpriors and rows of rungs wlo .. whi as published for this step
-      {
-        const double* px = a.pub_x + par * NcDP;
-        const double* pl = a.pub_ll + (size_t)par * p.Nc;
-        const double* pp = a.pub_lp + (size_t)par * p.Nc;
-        for (int i = tid; i < WN * DP; i += 256) {
-          const int r = wlo + i / DP, dd = i % DP;
-          wx[i] = __hip_atomic_load(px + (size_t)(r * p.W + w) * DP + dd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (tid < WN) {
-          const int cc = (wlo + tid) * p.W + w;
-          const double v = __hip_atomic_load(pl + cc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          wll[tid] = v; wll0[tid] = v;
-          wlp0[tid] = __hip_atomic_load(pp + cc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          wperm[tid] = wlo + tid;
-        }
-      }
-      __syncthreads();
-      PTM_LADDER_TICK(4);
+      // ---- 4. the exchange phase from the neighbours' publications
       // trials (chain.cc:1436-1537): the top pick of each run of surviving picks inside the window walks it downwards
       if (tid < WN - 1) {
         const int n = wlo + tid;                                   // pair (n, n + 1), both inside the window
@@ -323,7 +366,7 @@ __global__ __launch_bounds__(256) void ladder_persistent_kernel(const Dev p, con
         // workgroup's rungs.  Somebody else's.
         if (PTM_LADDER_ALIVE(n) && !PTM_LADDER_ALIVE(n + 1))
           for (int i = n; i >= wlo; --i) {
-            trial(wll, wperm, wlo, i, last_step);
+            trial(wll, wperm, wlo, i, last_step, wdb[i - wlo], wlu[i - wlo]);
             if (!PTM_LADDER_ALIVE(i - 1)) break;
           }
       }
@@ -360,7 +403,7 @@ __global__ __launch_bounds__(256) void ladder_persistent_kernel(const Dev p, con
         const int n = cand[k];
         if (n < 0 || !alive[k] || PTM_LADDER_ALIVE(n + 1)) continue;   // tops of runs of surviving picks
         for (int i = n; i >= 0; --i) {
-          trial(llall, permall, 0, i, last_step);
+          trial(llall, permall, 0, i, last_step, -(p.beta[i + 1] - p.beta[i]), dlog_u01(ua[first[i]]));
           if (!PTM_LADDER_ALIVE(i - 1)) break;
         }
       }
