@@ -233,7 +233,7 @@ int ptm_exchange_row_capacity(ptm_engine* e);
  * (dlopen "librccl.so.1") by the first of these calls; nothing else in the library needs it.
  *   rank 0:   ptm_shard_unique_id(id)  -> hand the 128 bytes to every rank (file, socket, MPI, a launcher's environment ...)
  *   all:      ptm_shard_init(e, id, rank, world, rung_counts, halo)   rung_counts[world]: every rank's block length
- *             (rank r holds the block after rank r-1's; must agree with this engine's rung_begin / rung_count); halo <= 0: 8
+ *             (rank r holds the block after rank r-1's; must agree with this engine's rung_begin / rung_count); halo <= 0: 12
  *             ptm_shard_step(e, n) ... ptm_sync(e) ...   ptm_shard_finalize(e) before ptm_engine_destroy
  * Replaces the reference's MPI layer for this path: rank/size `chain.cc:1199-1209`, the cyclic rung map `:1298-1309` and the
  * three MPI_Allgathers of every step `:1433-1435,1879-1972`. */

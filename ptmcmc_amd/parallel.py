@@ -36,10 +36,14 @@ import numpy as np
 # needs k picked rungs whose first picks come in descending rung order: probability <= swap_rate^k / k! per boundary,
 # ladder and step (measured on the ladder streams themselves by tests/test_halo_depth.py: 9.1e-2, 4.2e-3, 1.3e-4, 3.1e-6,
 # 2e-8 for k = 1..5 at swap_rate 0.1).  H = 4 -- the first round's default -- fails every ~2e7 boundary-ladder-steps, i.e.
-# several times in ONE 8-GPU bench run (131072 ladders x 7 boundaries x 400 steps = 3.7e8); H = 8 makes it 0.1^9 / 9! =
-# 2.8e-15, < 1e-6 per bench run and ~1e-3 per 10^6-step production run of that size.  Cost: H x W doubles per boundary and
-# step (8.4 MB at W = 131072), sent while the interior rungs are swept.
-DEFAULT_HALO = 8
+# several times in ONE 8-GPU bench run (131072 ladders x 7 boundaries x 400 steps = 3.7e8); H = 8 (round 2) makes it 0.1^9 / 9! =
+# 2.8e-15: < 1e-6 per bench run but still ~3e-3 per 10^6-step production run of that size -- a run that dies after days.
+# H = 12: 0.1^13 / 13! = 1.6e-23 per boundary, ladder and step, 1.5e-11 per such production run -- never, for any run anybody
+# will make (and every shard needs 12 rungs at most from the shard above, so shards of 12 rungs and more never look past their
+# neighbour).  Cost: H x W doubles per boundary and step (12.6 MB at W = 131072: ~0.25 ms of xGMI), sent while the interior
+# rungs are swept.  The condition is a property of the candidate draws alone (every shard replays them): a step that would
+# need more is still detected and reported loudly (PTM_ERR_FAR_MOVE), never decided blindly.
+DEFAULT_HALO = 12
 
 
 def shard_bounds(n_rungs, world, rank):

@@ -173,7 +173,11 @@ SWEEP_CASES = [
     (13, 11, 5, 1e2, E.PROP_DIAG, None),     # lanes kernel, 13 -> 16 dimensions, diagonal; 55 chains: a ragged last wave
     (29, 6, 70, 1e2, E.PROP_LOWER, None),    # lanes kernel, walkers not a multiple of 64
     (40, 6, 3, 1e2, E.PROP_DENSE, None),     # 33..64 dimensions: the lanes kernel with one chain per wave
-    (64, 5, 64, 1e2, E.PROP_LOWER, None),
+    (64, 5, 64, 1e2, E.PROP_LOWER, None),    # ... and with whole waves per rung: the 64-dimensional MFMA kernel (4 x 4 tiles of 16)
+    (64, 6, 128, 1e2, E.PROP_DENSE, None),   # dense factor tiles
+    (40, 5, 64, 1e2, E.PROP_DIAG, None),     # 24 pad dimensions, diagonal sigmas as the diagonal matrix they are
+    (33, 4, 192, 1e3, E.PROP_LOWER, None),
+    (50, 3, 64, 1e2, E.PROP_DENSE, None),
     (50, 4, 70, 1e2, E.PROP_DIAG, 0.3),
     (100, 5, 3, 1e2, E.PROP_LOWER, None),    # 65..128 dimensions: the lanes kernel, two dimensions per lane
     (128, 4, 64, 1e2, E.PROP_DENSE, 0.3),

@@ -30,10 +30,11 @@ def test_runs_of_surviving_picks_above_a_shard_boundary():
     # 8-GPU bench run -- too rare for this sample to pin (a handful of events), never seen beyond 6
     assert ge[5] <= 30 and ge[7] == 0
     # what the default halo assumes
-    assert DEFAULT_HALO >= 8
+    assert DEFAULT_HALO >= 12
     p_fail = sr ** (DEFAULT_HALO + 1) / math.factorial(DEFAULT_HALO + 1)
     bench_bws = 16384 * 8 * (G - 1) * (300 + 100 + 10)        # ladders x boundaries x steps of bench.py --gpus 8
     assert p_fail * bench_bws < 2e-6
+    assert p_fail * 16384 * 8 * (G - 1) * 1e6 < 1e-9          # ... and a 10^6-step production run of that size: never
     old = sr ** 5 / math.factorial(5)
     assert old * bench_bws > 5                                # ... and what the old default of 4 meant
 
