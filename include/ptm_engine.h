@@ -145,7 +145,8 @@ int ptm_set_ladder(ptm_engine* e, const double* beta);
  * the reference (chain.cc:1487-1490,1531-1534).  lpost_cut >= 0 (chain.cc:1819-1827): every pry also widens each gap whose two
  * chains' current log-posteriors are out of order by more than lpost_cut * invtemp; the exchange kernel then decides a
  * ladder's picks one after the other and goes over all its gaps after every accepted exchange (pinned against the reference by
- * traces 11 and 12).  Not built: sharded ladders (PTM_ERR_UNSUPPORTED). */
+ * traces 11 and 12).  On a rung shard (no history / MAP there): the exchange phase must then be fed the whole ladder's llikes,
+ * ptm_exchange_decide_gathered. */
 int ptm_set_evolve_temps(ptm_engine* e, double rate, double lpost_cut);
 /* every ladder's inverse temperatures, beta[n_walkers][n_rungs] (the common ladder repeated while nothing evolves);
  * ptm_set_invtemps puts them back (checkpoint / resume of an evolving run; needs ptm_set_evolve_temps first) */
@@ -213,6 +214,17 @@ int ptm_llike_device_ptr(ptm_engine* e, void** dev_ptr);
  * ll_below_dev: [W] (ignored on the first shard); ll_above_dev: [halo_rungs][W] (ignored on the last shard). */
 int ptm_exchange_decide(ptm_engine* e, const void* ll_below_dev, const void* ll_above_dev, int halo_rungs, void* send_up_dev,
                         void* send_down_dev);
+/* The exchange phase of a shard from the WHOLE ladder's llikes -- what the reference's MPI ranks work from (gather_llikes /
+ * gather_lposts: an MPI_Allgather per step, chain.cc:1433-1435,1905-1972).  ll_all_dev: [n_rungs][W] doubles, every shard's llike
+ * array in rung order (the caller gathers them: ptm_copy_llike of each shard, an all-gather); lp_all_dev: the lpriors the same way
+ * (ptm_copy_lprior), needed only with a posterior-ordering cut (else NULL).  No halo, no run of picks can reach past the view --
+ * and it is the form EVOLVING ladders need on rung shards (ptm_set_evolve_temps): every accepted exchange renormalises all gaps
+ * and every later trial of the step sees it, so every shard replays the whole ladder's trials and keeps the whole ladder's
+ * temperatures.  Costs an all-gather of n_rungs x W doubles per step instead of two neighbour messages: for populations, prefer
+ * splitting by walkers (ptm_config.walker_begin).  Boundary rows travel as with ptm_exchange_decide. */
+int ptm_exchange_decide_gathered(ptm_engine* e, const void* ll_all_dev, const void* lp_all_dev, void* send_up_dev, void* send_down_dev);
+/* ptm_copy_llike's twin for the lpriors */
+int ptm_copy_lprior(ptm_engine* e, int first_local_rung, int n_rungs, void* dst_dev);
 /* exchange phase, part 2 + MH sweep: lands the rows of the neighbours' messages (device buffers of the same size; the
  * message from below is required unless this is the first shard, the one from above unless it is the last) */
 int ptm_exchange_finish_and_sweep(ptm_engine* e, const void* recv_from_below_dev, const void* recv_from_above_dev);

@@ -752,6 +752,14 @@ static void swap_phase(ptmo_pt* s, const ptmo_rng* rng, int w) {
   free(sp); free(P0); free(inc); free(ipry);
 }
 
+/* the exchange phase of a step alone (chain.cc:1410-1537) -- for the CPU stand-in of a rung shard (tests/oracle_shard.py), which
+ * runs it on a replica of the whole ladder and makes the Metropolis moves of its own rungs itself */
+void ptmo_exchange_phase(ptmo_pt* s, const ptmo_rng* rng) {
+  long N = (long)s->Nt * s->W;
+  memset(s->touched, 0, (size_t)N);
+  for (int w = 0; w < s->W; w++) swap_phase(s, rng, w);
+}
+
 void ptmo_pt_step(ptmo_pt* s, const ptmo_problem* pb, const ptmo_proposal* props, const ptmo_rng* rng, int nthreads) {
   long N = (long)s->Nt * s->W;
   memset(s->touched, 0, (size_t)N);

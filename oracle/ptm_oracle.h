@@ -189,6 +189,7 @@ void ptmo_pt_set_states(ptmo_pt*, const ptmo_problem*, const double* x, const do
 int ptmo_mh_step(ptmo_pt*, const ptmo_problem*, const ptmo_proposal* prop, const ptmo_rng*, int w, int r);
 /* one parallel_tempering_chains::step for every walker (chain.cc:1393-1571); props[Nt] per rung */
 void ptmo_pt_step(ptmo_pt*, const ptmo_problem*, const ptmo_proposal* props, const ptmo_rng*, int nthreads);
+void ptmo_exchange_phase(ptmo_pt*, const ptmo_rng*);   /* the exchange phase of ptmo_pt_step alone (the step count stays) */
 /* MH sweep only (no swap phase) */
 void ptmo_sweep(ptmo_pt*, const ptmo_problem*, const ptmo_proposal* props, const ptmo_rng*, int nthreads);
 

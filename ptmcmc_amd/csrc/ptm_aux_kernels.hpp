@@ -127,6 +127,14 @@ __global__ __launch_bounds__(256) void beta_transpose_kernel(const double* __res
   }
 }
 
+// the same for a rung shard of evolving ladders: the chain-indexed temperatures of its own rungs [r0, r0 + nloc)
+__global__ __launch_bounds__(256) void beta_local_kernel(const double* __restrict__ in, double* __restrict__ out, int W, int Nt, int r0, int nloc) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (size_t)nloc * W) return;
+  const int rl = (int)(i / W), w = (int)(i - (size_t)rl * W);
+  out[i] = in[(size_t)w * Nt + r0 + rl];
+}
+
 // ------------------------------------------------------------------------------------------------
 // applies one ladder's row moves IN PLACE, one wave per ladder: GATHER every moved row into registers (16 lanes x 16 B =
 // one 256-B row per quarter wave, four rows per load instruction, up to MV rows), wait for all loads, then SCATTER.

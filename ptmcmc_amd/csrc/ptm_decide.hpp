@@ -34,6 +34,12 @@ struct Decide {
   const double* ll_below;     // [W]      llike of rung r0-1 (top rung of the shard below), null on the first shard
   const double* ll_above;     // [H][W]   llike of rungs r1 .. r1+H-1 (bottom rungs of the shard above), null on the last
   int H;                      // halo depth actually available above (0 on the last shard)
+  // The whole ladder's llikes (and lpriors) [Nt][W], gathered from all shards by the caller -- what the reference's MPI ranks
+  // have after gather_llikes / gather_lposts (chain.cc:1433-1435,1950-1972).  With them the window is the ladder: no halo, no
+  // run can reach past it, and an EVOLVING ladder (whose every accepted exchange renormalises all gaps, so that every later trial
+  // of the step depends on it) can be replayed exactly on every shard.  null: the halo form.
+  const double* ll_all;
+  const double* lp_all;       // needed by the posterior-ordering cut only
   double* x;                  // [Nc][DP] rows (only the overflow path moves rows here)
   double* ll;
   double* lp;
@@ -68,6 +74,7 @@ constexpr int MAP_DST = -(1 << 29);    //                             MAP_DST - 
 
 // llike of global rung r for walker w, r inside the shard's window
 __device__ __forceinline__ double win_llike(const Decide& p, int r, int w) {
+  if (p.ll_all) return p.ll_all[(size_t)r * p.W + w];
   const int r1 = p.r0 + p.nloc;
   if (r < p.r0) return p.ll_below[w];
   if (r >= r1) return p.ll_above[(size_t)(r - r1) * p.W + w];
@@ -108,7 +115,7 @@ __device__ __forceinline__ void decide_body(const Decide& p, unsigned char* smem
   const int NONE = 0x7fffffff;
   const int r1 = p.r0 + p.nloc;
   // window of rungs whose llike this shard knows: its own, one below, H above
-  const int wlo = p.r0 - (p.ll_below ? 1 : 0), whi = r1 - 1 + p.H;
+  const int wlo = p.ll_all ? 0 : p.r0 - (p.ll_below ? 1 : 0), whi = p.ll_all ? Nt - 1 : r1 - 1 + p.H;
   const int WN = whi - wlo + 1;
   // LDS carve (mirrored by decide_lds_bytes on the host; all offsets multiples of 8)
   double* llc_ = reinterpret_cast<double*>(smem);                             // [WN]  llike view of the touched rungs
@@ -274,7 +281,11 @@ __device__ __forceinline__ void decide_body(const Decide& p, unsigned char* smem
       // (chunks of 32 left to right, then the chunk totals: ptmo_chunk_prefix).  Once something was pried a rung's temperature
       // is 1 - P0 / normaliser.  ev[0]: the gaps' running total, ev[1]: pries so far.
       const double* bw = p.beta_w + (size_t)w * Nt;
-      for (int r = lane; r < Nt; r += DECIDE_THREADS) { llv[r] = p.ll[(size_t)r * p.W + w]; lpv[r] = p.lp[(size_t)r * p.W + w]; }
+      {
+        const double* lla = p.ll_all ? p.ll_all : p.ll;   // (a whole-ladder engine's own arrays ARE the whole ladder's)
+        const double* lpa = p.ll_all ? p.lp_all : p.lp;
+        for (int r = lane; r < Nt; r += DECIDE_THREADS) { llv[r] = lla[(size_t)r * p.W + w]; lpv[r] = lpa[(size_t)r * p.W + w]; }
+      }
       if (lane == 0) {
         double S = 0.0;
         for (int q = 0; q < nch; ++q) { ct[nch + q] = S; S = S + ct[q]; }
@@ -484,7 +495,7 @@ __device__ __forceinline__ void decide_body(const Decide& p, unsigned char* smem
       for (int k = 1 + lane; k < Nt - 1; k += DECIDE_THREADS) {
         const double bk = 1 - (ct[nch + (k >> 5)] + gap[k]) / nn;
         p.beta_w[(size_t)w * Nt + k] = bk;
-        if (p.betaC_direct) p.betaC_direct[(size_t)k * p.W + w] = bk;
+        if (p.betaC_direct && k >= p.r0 && k < r1) p.betaC_direct[(size_t)(k - p.r0) * p.W + w] = bk;
       }
     }
   }

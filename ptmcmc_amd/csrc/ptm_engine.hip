@@ -702,7 +702,16 @@ extern "C" int ptm_set_evolve_temps(ptm_engine* e, double rate, double lpost_cut
     if (e->evolve_rate > 0) return fail(PTM_ERR_UNSUPPORTED, "an evolving ladder cannot be frozen again (the reference has no such call either)");
     return PTM_OK;   // evolve_temps is never called with rate <= 0 (ptmcmc.cc:512)
   }
-  if (e->nloc != e->Nt) return fail(PTM_ERR_UNSUPPORTED, "evolving ladders need the whole ladder on one engine (every pry renormalises all rungs)");
+  if (e->nloc != e->Nt) {
+    // A rung shard: every accepted exchange renormalises ALL gaps and every later trial of the step sees it, so each shard replays
+    // the whole ladder's trials -- from the whole ladder's llikes, which the caller gathers each step (ptm_exchange_decide_gathered;
+    // the reference's MPI ranks do exactly that: gather_llikes, chain.cc:1433-1435,1950-1972).  Every shard keeps every ladder's
+    // temperatures [W][Nt]; the gathered llikes (+ lpriors with a posterior-ordering cut) are [Nt][W] doubles per step.
+    if (e->hist.rungs || e->map.rungs) return fail(PTM_ERR_UNSUPPORTED, "evolving ladders on a rung shard: history / MAP tracking is not built (track them on whole-ladder engines)");
+    if ((double)e->W * e->Nt * 16.0 > 512.0 * 1024 * 1024)
+      return fail(PTM_ERR_UNSUPPORTED, "evolving ladders on a rung shard gather %d x %d llikes (and lpriors) per step: more than 512 MB -- split such a population by walkers "
+                                       "(ptm_config.walker_begin)", e->Nt, e->W);
+  }
   if (!e->have_ladder) return fail(PTM_ERR_INVALID, "set the ladder first (ptm_set_ladder)");
   int rc;
   if (!e->beta_w) {
@@ -1133,14 +1142,21 @@ static int fold_swap_log(ptm_engine* e) {
 
 // chain-indexed image of the evolving ladders' temperatures, for the sweep kernels
 static int launch_beta_transpose(ptm_engine* e) {
+  if (e->nloc != e->Nt) {   // a rung shard: its own rungs' temperatures out of the whole ladders'
+    hipLaunchKernelGGL(beta_local_kernel, dim3((unsigned)(((size_t)e->Nc + 255) / 256)), dim3(256), 0, e->stream, e->beta_w, e->betaC, e->W, e->Nt, e->r0, e->nloc);
+    HIPCHK(hipGetLastError());
+    return PTM_OK;
+  }
   hipLaunchKernelGGL(beta_transpose_kernel, dim3((e->Nt + 31) / 32, (e->W + 31) / 32), dim3(256), 0, e->stream, e->beta_w, e->betaC, e->W, e->Nt);
   HIPCHK(hipGetLastError());
   return PTM_OK;
 }
 
-static Decide make_decide(ptm_engine* e, const double* ll_below, const double* ll_above, int H, double* send_up, double* send_down) {
+static Decide make_decide(ptm_engine* e, const double* ll_below, const double* ll_above, int H, double* send_up, double* send_down,
+                          const double* ll_all = nullptr, const double* lp_all = nullptr) {
   Decide p;
   memset(&p, 0, sizeof p);
+  p.ll_all = ll_all; p.lp_all = lp_all;
   p.DP = e->DP; p.Nt = e->Nt; p.r0 = e->r0; p.nloc = e->nloc; p.W = e->W; p.Nc = e->Nc; p.ms = e->ms; p.w_off = e->cfg.walker_begin;
   p.seed = e->cfg.seed; p.step = e->step; p.thresh = e->thresh;
   p.beta = e->beta; p.ll_below = ll_below; p.ll_above = ll_above; p.H = ll_above ? H : 0; p.x = e->x; p.ll = e->ll; p.lp = e->lp;
@@ -1157,11 +1173,12 @@ static Decide make_decide(ptm_engine* e, const double* ll_below, const double* l
   return p;
 }
 
-static int launch_decide(ptm_engine* e, const double* ll_below, const double* ll_above, int H, double* send_up, double* send_down) {
-  const Decide p = make_decide(e, ll_below, ll_above, H, send_up, send_down);
+static int launch_decide(ptm_engine* e, const double* ll_below, const double* ll_above, int H, double* send_up, double* send_down,
+                         const double* ll_all = nullptr, const double* lp_all = nullptr) {
+  const Decide p = make_decide(e, ll_below, ll_above, H, send_up, send_down, ll_all, lp_all);
   const bool beta_direct = p.betaC_direct != nullptr;
   e->touched = true;
-  const int WN = e->nloc + (ll_below ? 1 : 0) + p.H;
+  const int WN = ll_all ? e->Nt : e->nloc + (ll_below ? 1 : 0) + p.H;
   const bool evb = e->evolve_rate > 0 && e->beta_add;
   const bool cut = e->evolve_rate > 0 && e->evolve_cut >= 0;
   const size_t lds = decide_lds_bytes(e->Nt, e->ms, WN, e->evolve_rate > 0, evb, cut);
@@ -1596,6 +1613,8 @@ extern "C" int ptm_exchange_decide(ptm_engine* e, const void* ll_below, const vo
   NO_BATCH(e, "ptm_exchange_decide");
   int rc = ready(e);
   if (rc) return rc;
+  if (e->evolve_rate > 0 && e->nloc != e->Nt)
+    return fail(PTM_ERR_INVALID, "an evolving ladder's shard decides from the whole ladder's llikes: ptm_exchange_decide_gathered");
   const bool first = e->r0 == 0, last = e->r0 + e->nloc == e->Nt;
   if ((!first && !ll_below) || (!last && (!ll_above || halo_rungs < 1)))
     return fail(PTM_ERR_INVALID, "missing llike halo: a shard needs the top rung below it and >= 1 rung above it");
@@ -1603,6 +1622,27 @@ extern "C" int ptm_exchange_decide(ptm_engine* e, const void* ll_below, const vo
   if (e->Nt > 1)
     return launch_decide(e, first ? nullptr : (const double*)ll_below, last ? nullptr : (const double*)ll_above, halo_rungs,
                          last ? nullptr : (double*)send_up, first ? nullptr : (double*)send_down);
+  return PTM_OK;
+}
+
+extern "C" int ptm_exchange_decide_gathered(ptm_engine* e, const void* ll_all, const void* lp_all, void* send_up, void* send_down) {
+  NO_BATCH(e, "ptm_exchange_decide_gathered");
+  int rc = ready(e);
+  if (rc) return rc;
+  if (!ll_all) return fail(PTM_ERR_INVALID, "null argument");
+  if (e->evolve_rate > 0 && e->evolve_cut >= 0 && !lp_all) return fail(PTM_ERR_INVALID, "a posterior-ordering cut needs the whole ladder's lpriors too");
+  const bool first = e->r0 == 0, last = e->r0 + e->nloc == e->Nt;
+  if ((!last && !send_up) || (!first && !send_down)) return fail(PTM_ERR_INVALID, "missing boundary message buffer");
+  if (e->Nt > 1)
+    return launch_decide(e, nullptr, nullptr, 0, last ? nullptr : (double*)send_up, first ? nullptr : (double*)send_down, (const double*)ll_all,
+                         (const double*)lp_all);
+  return PTM_OK;
+}
+
+extern "C" int ptm_copy_lprior(ptm_engine* e, int first_local_rung, int n_rungs, void* dst_dev) {
+  if (!e || !dst_dev) return fail(PTM_ERR_INVALID, "null argument");
+  if (first_local_rung < 0 || n_rungs < 1 || first_local_rung + n_rungs > e->nloc) return fail(PTM_ERR_INVALID, "rung range out of the shard");
+  HIPCHK(hipMemcpyAsync(dst_dev, e->lp + (size_t)first_local_rung * e->W, (size_t)n_rungs * e->W * 8, hipMemcpyDeviceToDevice, e->stream));
   return PTM_OK;
 }
 
@@ -1683,7 +1723,8 @@ extern "C" int ptm_shard_finalize(ptm_engine* e) {
   (void)hipStreamSynchronize(e->stream);
   if (s->cstream) (void)hipStreamSynchronize(s->cstream);
   if (s->comm) (void)rccl().CommDestroy(s->comm);
-  double* bufs[] = {s->ll_top, s->ll_bottom, s->ll_below, s->ll_above, s->send_up, s->recv_above, s->send_down, s->recv_below};
+  double* bufs[] = {s->ll_top, s->ll_bottom, s->ll_below, s->ll_above, s->send_up, s->recv_above, s->send_down, s->recv_below, s->gsend, s->grecv, s->ll_all, s->lp_all};
+  if (s->ev_gather) (void)hipEventDestroy(s->ev_gather);
   for (double* b : bufs) if (b) (void)hipFree(b);
   if (s->ev_ready) (void)hipEventDestroy(s->ev_ready);
   if (s->ev_rows) (void)hipEventDestroy(s->ev_rows);
@@ -1698,7 +1739,6 @@ extern "C" int ptm_shard_init(ptm_engine* e, const void* id, int rank, int world
   if (!e || !id || !rung_counts) return fail(PTM_ERR_INVALID, "null argument");
   if (world < 1 || rank < 0 || rank >= world) return fail(PTM_ERR_INVALID, "bad rank / world size");
   if (e->shard) return fail(PTM_ERR_INVALID, "this engine is sharded already (ptm_shard_finalize first)");
-  if (e->evolve_rate > 0) return fail(PTM_ERR_UNSUPPORTED, "evolving ladders cannot be sharded by rungs (split the population by walkers: ptm_config.walker_begin)");
   int begin = 0, total = 0;
   for (int r = 0; r < world; ++r) { if (rung_counts[r] < 1) return fail(PTM_ERR_INVALID, "every rank needs at least one rung"); if (r < rank) begin += rung_counts[r]; total += rung_counts[r]; }
   if (total != e->Nt || begin != e->r0 || rung_counts[rank] != e->nloc)
@@ -1730,6 +1770,9 @@ extern "C" int ptm_shard_init(ptm_engine* e, const void* id, int rank, int world
   if (s->down >= 0 && ((rc = dalloc(&s->ll_bottom, (size_t)s->h_send * W)) || (rc = dalloc(&s->ll_below, W)) || (rc = dalloc(&s->send_down, s->row_doubles)) ||
                        (rc = dalloc(&s->recv_below, s->row_doubles))))
     return rc;
+  s->counts.assign(rung_counts, rung_counts + world);
+  for (int r = 0; r < world; ++r) s->maxn = rung_counts[r] > s->maxn ? rung_counts[r] : s->maxn;
+  HIPCHK(hipEventCreateWithFlags(&s->ev_gather, hipEventDisableTiming));
   double* zero[] = {s->send_up, s->recv_above, s->send_down, s->recv_below};
   for (double* b : zero) if (b) HIPCHK(hipMemsetAsync(b, 0, s->row_doubles * 8, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
@@ -1774,6 +1817,35 @@ extern "C" int ptm_shard_step(ptm_engine* e, int n) {
   if (!e->shard) return fail(PTM_ERR_INVALID, "ptm_shard_init first");
   if (e->cb || e->pcb) return fail(PTM_ERR_UNSUPPORTED, "sharded steps with a host-callback likelihood or host-side proposals are not built");
   ShardComm* s = e->shard;
+  if (e->evolve_rate > 0) {
+    // Evolving ladders: every shard replays the whole ladder's trials from the whole ladder's llikes (and lpriors, with a
+    // posterior-ordering cut) -- one ncclAllGather per step, the reference's gather_llikes / gather_lposts (chain.cc:1433-1435,
+    // 1950-1972) -- then the boundary rows travel between neighbours as ever.  No overlap: the trials need the gathered view.
+    const size_t W = (size_t)e->W, slab = (size_t)s->maxn * W;
+    if (!s->gsend && ((rc = dalloc(&s->gsend, 2 * slab)) || (rc = dalloc(&s->grecv, (size_t)s->world * 2 * slab)) || (rc = dalloc(&s->ll_all, (size_t)e->Nt * W)) ||
+                      (rc = dalloc(&s->lp_all, (size_t)e->Nt * W))))
+      return rc;
+    for (int k = 0; k < n; ++k) {
+      if ((rc = ptm_copy_llike(e, 0, e->nloc, s->gsend)) || (rc = ptm_copy_lprior(e, 0, e->nloc, s->gsend + slab))) return rc;
+      HIPCHK(hipEventRecord(s->ev_ready, e->stream));
+      HIPCHK(hipStreamWaitEvent(s->cstream, s->ev_ready, 0));
+      NCCLCHK(rccl().AllGather(s->gsend, s->grecv, 2 * slab, ncclDouble, s->comm, s->cstream));
+      HIPCHK(hipEventRecord(s->ev_gather, s->cstream));
+      HIPCHK(hipStreamWaitEvent(e->stream, s->ev_gather, 0));
+      size_t at = 0;
+      for (int r = 0; r < s->world; ++r) {   // the shards' slabs, unpadded, in rung order
+        const size_t cnt = (size_t)s->counts[r] * W;
+        HIPCHK(hipMemcpyAsync(s->ll_all + at, s->grecv + (size_t)r * 2 * slab, cnt * 8, hipMemcpyDeviceToDevice, e->stream));
+        HIPCHK(hipMemcpyAsync(s->lp_all + at, s->grecv + (size_t)r * 2 * slab + slab, cnt * 8, hipMemcpyDeviceToDevice, e->stream));
+        at += cnt;
+      }
+      if ((rc = ptm_exchange_decide_gathered(e, s->ll_all, s->lp_all, s->send_up, s->send_down))) return rc;
+      if ((rc = shard_exchange(e, s->send_up, s->row_doubles, s->recv_above, s->row_doubles, s->send_down, s->row_doubles, s->recv_below, s->row_doubles, s->ev_rows))) return rc;
+      HIPCHK(hipStreamWaitEvent(e->stream, s->ev_rows, 0));
+      if ((rc = ptm_exchange_finish_and_sweep(e, s->recv_below, s->recv_above))) return rc;
+    }
+    return PTM_OK;
+  }
   const bool overlap = !e->hist.rungs && !e->map.rungs;   // (a recorded exchanged rung reads its final row: needs the arrivals first)
   // sweep plan: the boundary rungs are the ones whose llikes the neighbours need as halos (bottom h_send rungs, the top rung)
   const int nl = e->nloc, nb = s->h_send < nl ? s->h_send : nl, nt = (s->up >= 0 && nl > nb) ? 1 : 0;

@@ -9,6 +9,8 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <vector>
+
 namespace ptm {
 
 struct RcclApi {
@@ -20,6 +22,7 @@ struct RcclApi {
   ncclResult_t (*GroupEnd)() = nullptr;
   ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
   const char* load() {   // null on success, else what failed
     if (lib) return nullptr;
@@ -37,6 +40,7 @@ struct RcclApi {
     PTM_SYM(GroupEnd, "ncclGroupEnd")
     PTM_SYM(Send, "ncclSend")
     PTM_SYM(Recv, "ncclRecv")
+    PTM_SYM(AllGather, "ncclAllGather")
     PTM_SYM(GetErrorString, "ncclGetErrorString")
 #undef PTM_SYM
     return nullptr;
@@ -55,6 +59,12 @@ struct ShardComm {
   double *send_up = nullptr, *recv_above = nullptr, *send_down = nullptr, *recv_below = nullptr;   // boundary row messages
   size_t row_doubles = 0;
   bool halos_in_flight = false;
+  // evolving ladders (ptm_set_evolve_temps on a rung shard): the whole ladder's llikes / lpriors, all-gathered each step --
+  // gsend [2][maxn * W] this shard's (padded to the largest shard), grecv [world][2][maxn * W], ll_all / lp_all [Nt][W]
+  std::vector<int> counts;
+  int maxn = 0;
+  double *gsend = nullptr, *grecv = nullptr, *ll_all = nullptr, *lp_all = nullptr;
+  hipEvent_t ev_gather = nullptr;
 };
 
 }  // namespace ptm

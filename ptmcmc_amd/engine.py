@@ -25,7 +25,7 @@ EXPORTS = [
     "ptm_last_error", "ptm_abi_version", "ptm_device_count", "ptm_engine_create", "ptm_engine_destroy",
     "ptm_set_bounds", "ptm_set_prior", "ptm_set_target_gaussian", "ptm_set_target_callback", "ptm_set_prior_callback", "ptm_set_ladder", "ptm_set_evolve_temps", "ptm_get_invtemps", "ptm_set_invtemps",
     "ptm_set_proposals", "ptm_set_proposal_rung", "ptm_set_proposal_mixture", "ptm_set_proposal_callback", "ptm_set_states", "ptm_init_from_prior", "ptm_init_from_prior_k", "ptm_sweep", "ptm_step", "ptm_sync",
-    "ptm_copy_llike", "ptm_llike_device_ptr", "ptm_exchange_decide", "ptm_exchange_finish_and_sweep", "ptm_exchange_install", "ptm_sweep_rungs", "ptm_exchange_buffer_doubles", "ptm_exchange_row_capacity", "ptm_shard_unique_id", "ptm_shard_init", "ptm_shard_step", "ptm_shard_finalize", "ptm_get_states", "ptm_batch_begin", "ptm_batch_end",
+    "ptm_copy_llike", "ptm_copy_lprior", "ptm_llike_device_ptr", "ptm_exchange_decide", "ptm_exchange_decide_gathered", "ptm_exchange_finish_and_sweep", "ptm_exchange_install", "ptm_sweep_rungs", "ptm_exchange_buffer_doubles", "ptm_exchange_row_capacity", "ptm_shard_unique_id", "ptm_shard_init", "ptm_shard_step", "ptm_shard_finalize", "ptm_get_states", "ptm_batch_begin", "ptm_batch_end",
     "ptm_get_array", "ptm_get_swap_counts", "ptm_get_last_swaps", "ptm_max_swaps_per_step", "ptm_get_history", "ptm_get_history_invtemps", "ptm_set_history", "ptm_set_map", "ptm_get_map", "ptm_restore", "ptm_step_count",
     "ptm_timer_start", "ptm_timer_stop", "ptm_get_kernel_times", "ptm_sweep_kernel_name", "ptm_step_kernel_name", "ptm_debug_eval",
     "ptm_debug_philox", "ptm_debug_boxmuller", "ptm_debug_sqrt_scan", "ptm_debug_evaluate",
@@ -100,6 +100,9 @@ def load():
     L.ptm_llike_device_ptr.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
     L.ptm_exchange_decide.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     L.ptm_copy_llike.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    if hasattr(L, "ptm_copy_lprior"):
+        L.ptm_copy_lprior.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.ptm_exchange_decide_gathered.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.ptm_dev_alloc.argtypes = [C.c_size_t, C.POINTER(C.c_void_p)]
     L.ptm_dev_free.argtypes = [C.c_void_p]
     L.ptm_dev_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
@@ -209,6 +212,27 @@ class DeviceBuffer:
 
     __del__ = free
 
+    def slice(self, offset_bytes, nbytes):
+        """a view of part of the allocation (the parent keeps the memory)"""
+        assert 0 <= offset_bytes and offset_bytes + nbytes <= self.nbytes
+        return _DeviceView(self, offset_bytes, nbytes)
+
+
+class _DeviceView:
+    def __init__(self, parent, offset, nbytes):
+        self.parent, self.ptr, self.nbytes = parent, parent.ptr + offset, nbytes
+
+    def data_ptr(self):
+        return self.ptr
+
+    def copy_from(self, src_ptr, nbytes=None):
+        _chk(load().ptm_dev_copy(self.ptr, src_ptr, self.nbytes if nbytes is None else nbytes))
+
+    def to_numpy(self, dtype=np.float64):
+        out = np.empty(self.nbytes // np.dtype(dtype).itemsize, dtype=dtype)
+        _chk(load().ptm_dev_copy(out.ctypes.data_as(C.c_void_p), self.ptr, self.nbytes))
+        return out
+
 
 def geometric_ladder(n_rungs, tmax):
     """beta of parallel_tempering_chains' constructor + initialize (chain.cc:1181-1183,1340): host constants."""
@@ -251,6 +275,7 @@ class Engine:
         self.r0, self.nloc = rung_begin, cfg.rung_count
         self.Nc = self.nloc * n_walkers
         self._evolving = False
+        self._evolve_cut = -1.0
         self._keep = []
         self._batch_depth, self._batch_keep = 0, []
 
@@ -351,6 +376,7 @@ class Engine:
         """parallel_tempering_chains::evolve_temps (chain.hh:302-307): every accepted exchange pries its gap apart"""
         _chk(self.L.ptm_set_evolve_temps(self.h, float(rate), float(lpost_cut)))
         self._evolving = self._evolving or rate > 0
+        self._evolve_cut = lpost_cut if lpost_cut >= 0 else -1.0
 
     def invtemps(self):
         """[W][Nt] inverse temperatures of every ladder"""
@@ -414,6 +440,13 @@ class Engine:
 
     def copy_llike(self, first_local_rung, n_rungs, dst_dev):
         _chk(self.L.ptm_copy_llike(self.h, first_local_rung, n_rungs, dst_dev))
+
+    def copy_lprior(self, first_local_rung, n_rungs, dst_dev):
+        _chk(self.L.ptm_copy_lprior(self.h, first_local_rung, n_rungs, dst_dev))
+
+    def exchange_decide_gathered(self, ll_all_dev, lp_all_dev, send_up_dev, send_down_dev):
+        """the exchange phase from the whole ladder's llikes [Nt][W] (and lpriors, with a posterior-ordering cut)"""
+        _chk(self.L.ptm_exchange_decide_gathered(self.h, ll_all_dev, lp_all_dev, send_up_dev, send_down_dev))
 
     def exchange_decide(self, ll_below_dev, ll_above_dev, halo_rungs, send_up_dev, send_down_dev):
         _chk(self.L.ptm_exchange_decide(self.h, ll_below_dev, ll_above_dev, halo_rungs, send_up_dev, send_down_dev))

@@ -100,6 +100,30 @@ class EngineShard:
     def can_overlap(self):
         return self.e.hist_rungs == 0 and self.e.map_rungs == 0   # (a recorded exchanged rung reads its final row: needs the arrivals first)
 
+    @property
+    def gathered(self):
+        """evolving ladders: the exchange phase needs the whole ladder's llikes (ShardedLadder.step_gathered)"""
+        return bool(getattr(self.e, "_evolving", False))
+
+    @property
+    def needs_lprior(self):
+        return getattr(self.e, "_evolve_cut", -1.0) >= 0
+
+    def copy_lprior(self, first_rung, n_rungs, dst):
+        self.e.copy_lprior(first_rung, n_rungs, dst.data_ptr())
+
+    @staticmethod
+    def sub(buf, off, n):
+        return buf[off:off + n]
+
+    @staticmethod
+    def dcopy(dst, src):
+        dst.copy_(src)
+
+    def exchange_decide_gathered(self, ll_all, lp_all, send_up, send_down):
+        p = lambda t: None if t is None else t.data_ptr()
+        self.e.exchange_decide_gathered(p(ll_all), p(lp_all), p(send_up), p(send_down))
+
     def sync(self):
         self.e.sync()
 
@@ -135,6 +159,48 @@ class ShardedLadder:
         self.send_down = a(n) if self.down is not None else None
         self.recv_below = a(n) if self.down is not None else None
         self._halo_reqs = None
+        # evolving ladders (gathered form): this shard's llikes | lpriors padded to the largest shard, everybody's, and the
+        # whole ladder's [Nt][W] views the exchange kernel reads
+        self.sizes = list(sizes)
+        self.gathered = bool(getattr(backend, "gathered", False))
+        if self.gathered:
+            self.maxn = max(self.sizes)
+            self.g_send = a(2 * self.maxn * W)
+            self.g_recv = a(world * 2 * self.maxn * W)
+            self.ll_all = a(backend.Nt * W)
+            self.lp_all = a(backend.Nt * W)
+
+    # -- evolving ladders: the exchange phase from the whole ladder's llikes (the reference's gather_llikes / gather_lposts,
+    #    chain.cc:1433-1435,1950-1972: an all-gather per step), then the boundary rows between neighbours as ever
+    def stage_gather(self):
+        b, slab = self.b, self.maxn * self.b.W
+        b.copy_llike(0, b.nloc, b.sub(self.g_send, 0, b.nloc * b.W))
+        b.copy_lprior(0, b.nloc, b.sub(self.g_send, slab, b.nloc * b.W))
+
+    def assemble_gathered(self):
+        """the shards' slabs, unpadded, in rung order -> ll_all / lp_all"""
+        b, W, slab, at = self.b, self.b.W, self.maxn * self.b.W, 0
+        for r, n in enumerate(self.sizes):
+            b.dcopy(b.sub(self.ll_all, at, n * W), b.sub(self.g_recv, r * 2 * slab, n * W))
+            b.dcopy(b.sub(self.lp_all, at, n * W), b.sub(self.g_recv, r * 2 * slab + slab, n * W))
+            at += n * W
+
+    def decide_gathered(self):
+        self.b.exchange_decide_gathered(self.ll_all, self.lp_all if getattr(self.b, "needs_lprior", True) else None, self.send_up, self.send_down)
+
+    def step_gathered(self, n=1):
+        with self._ctx():
+            for _ in range(n):
+                self.stage_gather()
+                self._before_messages()
+                if self.world > 1:
+                    self.dist.all_gather_into_tensor(self.g_recv, self.g_send)
+                else:
+                    self.b.dcopy(self.g_recv, self.g_send)
+                self.assemble_gathered()
+                self.decide_gathered()
+                self._exchange(self.row_messages())
+                self.finish()
 
     # -- the step, in phases (the in-process shard simulator of the tests drives the same phases in lockstep)
     def stage_halos(self):
@@ -205,6 +271,8 @@ class ShardedLadder:
 
     def step_simple(self, n=1):
         """the four phases one after the other (what the in-process simulator of the tests drives in lockstep)"""
+        if self.gathered:
+            return self.step_gathered(n)
         with self._ctx():
             for _ in range(n):
                 self.stage_halos()
@@ -215,6 +283,8 @@ class ShardedLadder:
 
     def step(self, n=1):
         """both message rounds behind arithmetic; the next step's halos are left in flight between calls"""
+        if self.gathered:
+            return self.step_gathered(n)
         if self.world == 1 or not getattr(self.b, "can_overlap", False):
             return self.step_simple(n)
         with self._ctx():

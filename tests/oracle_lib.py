@@ -108,6 +108,7 @@ def lib():
     L.ptmo_mh_step.argtypes = [C.POINTER(_PT), C.POINTER(_Problem), C.POINTER(_Proposal), C.c_void_p, C.c_int, C.c_int]
     L.ptmo_pt_step.argtypes = [C.POINTER(_PT), C.POINTER(_Problem), C.POINTER(_Proposal), C.c_void_p, C.c_int]
     L.ptmo_sweep.argtypes = [C.POINTER(_PT), C.POINTER(_Problem), C.POINTER(_Proposal), C.c_void_p, C.c_int]
+    L.ptmo_exchange_phase.argtypes = [C.POINTER(_PT), C.c_void_p]
     L.ptmo_rng_philox.restype = C.c_void_p
     L.ptmo_rng_philox.argtypes = [C.c_uint64, C.c_int]
     L.ptmo_rng_tape.restype = C.c_void_p

@@ -144,6 +144,66 @@ class OracleShard:
 
     can_overlap = True
 
+    # ---- evolving ladders: the gathered form (ShardedLadder.step_gathered).  The stand-in runs the oracle's own exchange phase
+    #      on its replica of the WHOLE ladder: the other shards' llikes / lpriors come from the gathered views, their rows are
+    #      tags (NaN, rung number in the first entry) -- a tag that lands on an own rung names the neighbour a row arrives from,
+    #      a real row that lands on a foreign rung is one that leaves.
+    @property
+    def gathered(self):
+        return self.lad.s.contents.evolve_rate > 0
+
+    needs_lprior = True
+
+    def copy_lprior(self, first, n, dst):
+        out = dst.numpy().reshape(n, self.W)
+        for k in range(n):
+            for w in range(self.W):
+                out[k, w] = self.lp[self.idx(w, self.r0 + first + k)]
+
+    @staticmethod
+    def sub(buf, off, n):
+        return buf[off:off + n]
+
+    @staticmethod
+    def dcopy(dst, src):
+        dst.copy_(src)
+
+    def exchange_decide_gathered(self, ll_all, lp_all, send_up, send_down):
+        r0, r1, Nt, W, D = self.r0, self.r0 + self.nloc, self.Nt, self.W, self.D
+        assert D >= 2
+        la = ll_all.numpy().reshape(Nt, W)
+        lpa = None if lp_all is None else lp_all.numpy().reshape(Nt, W)
+        su = None if send_up is None else send_up.numpy().reshape(D + 2, W)
+        sd = None if send_down is None else send_down.numpy().reshape(D + 2, W)
+        for w in range(W):
+            for r in list(range(0, r0)) + list(range(r1, Nt)):
+                c = self.idx(w, r)
+                self.ll[c] = la[r, w]
+                self.lp[c] = 0.0 if lpa is None else lpa[r, w]
+                self.x[c, :] = np.nan
+                self.x[c, 0] = r
+        s = self.lad.s.contents
+        st = np.ctypeslib.as_array(s.swap_count, shape=(W, Nt - 1))
+        sa = np.ctypeslib.as_array(s.swap_accept_count, shape=(W, Nt - 1))
+        t0, a0 = st.copy(), sa.copy()
+        O.lib().ptmo_exchange_phase(self.lad.s, self.lad.rng)        # touch counts, add_state counts, temperatures: in place
+        self.swap_try[:, r0:min(r1, Nt - 1)] += (st - t0)[:, r0:min(r1, Nt - 1)]
+        self.swap_acc[:, r0:min(r1, Nt - 1)] += (sa - a0)[:, r0:min(r1, Nt - 1)]
+        self.counted = True                                           # (the phase counted the touched rungs' add_state calls itself)
+        self.arrive = []
+        for w in range(W):
+            for r in range(r0, r1):
+                c = self.idx(w, r)
+                if np.isnan(self.x[c, -1]):
+                    src = int(self.x[c, 0])
+                    assert src == r0 - 1 or r1 <= src, src
+                    self.arrive.append((c, "above" if src >= r1 else "below", w))
+            for r in list(range(0, r0)) + list(range(r1, Nt)):
+                c = self.idx(w, r)
+                if not np.isnan(self.x[c, -1]):                       # an own row that left
+                    buf = su if r >= r1 else sd
+                    buf[:D, w] = self.x[c]; buf[D, w] = self.ll[c]; buf[D + 1, w] = self.lp[c]
+
     def install(self, recv_below, recv_above):
         """rows that arrived from the neighbours land in the holes the decisions named"""
         D, W = self.D, self.W
@@ -161,8 +221,9 @@ class OracleShard:
             for r in range(self.r0 + first, self.r0 + first + n):
                 c = self.idx(w, r)
                 if self.touched[c]:
-                    for _ in range(int(self.touched[c])):
-                        self._add_state(c)
+                    if not getattr(self, "counted", False):
+                        for _ in range(int(self.touched[c])):
+                            self._add_state(c)
                     self.touched[c] = 0
                     continue
                 L.ptmo_mh_step(lad.s, lad.pb.p, C.byref(lad._props[r]), lad.rng, w, r)

@@ -24,7 +24,32 @@ def _deliver(ladders, kind, copy):
             copy(pm[1 - idx][1], send)
 
 
+def step_gathered(ladders, copy, n=1):
+    """evolving ladders: every shard's llikes / lpriors to every shard (the all-gather, by plain copies), then the usual rounds"""
+    for _ in range(n):
+        for lad in ladders:
+            lad.stage_gather()
+        for lad in ladders:
+            lad.b.sync()
+        for lad in ladders:
+            slab2 = 2 * lad.maxn * lad.b.W
+            for r, src in enumerate(ladders):
+                copy(lad.b.sub(lad.g_recv, r * slab2, slab2), src.g_send)
+            lad.assemble_gathered()
+        for lad in ladders:
+            lad.decide_gathered()
+        for lad in ladders:
+            lad.b.sync()
+        _deliver(ladders, "rows", copy)
+        for lad in ladders:
+            lad.finish()
+        for lad in ladders:
+            lad.b.sync()
+
+
 def step(ladders, copy, n=1):
+    if ladders and ladders[0].gathered:
+        return step_gathered(ladders, copy, n)
     for _ in range(n):
         for lad in ladders:
             lad.stage_halos()

@@ -51,6 +51,40 @@ def test_sharded_ladder_over_gloo_matches_single_process(world, D, Nt, W, halo, 
     assert ref.swap_accept_count.sum() > 0
 
 
+@pytest.mark.parametrize("world,D,Nt,W,sr,rate,cut", [(2, 4, 10, 3, 0.4, 0.05, -1.0), (3, 3, 13, 2, 0.45, 0.02, 0.0)])
+def test_evolving_sharded_ladder_over_gloo_matches_single_process(world, D, Nt, W, sr, rate, cut):
+    """evolve_temps on a rung-sharded ladder over torch.distributed (gloo): ShardedLadder.step_gathered -- an all-gather of every
+    shard's llikes / lpriors per step (the reference's gather_llikes / gather_lposts, chain.cc:1433-1435,1950-1972), every rank
+    replaying the whole ladder's trials, boundary rows between neighbours -- against the single-process oracle: states, llikes,
+    counters, swap counts and the evolved temperatures (every rank holds them all)."""
+    sys.path.insert(0, HERE)
+    import dist_worker
+    nsteps = 25
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "rank%d.npz")
+        port = free_port()
+        procs = []
+        for r in range(world):
+            env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                       OMP_NUM_THREADS="1")
+            procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "dist_worker.py"), str(D), str(Nt), str(W),
+                                           str(nsteps), "4", str(sr), out, str(rate), str(cut)], env=env))
+        for p in procs:
+            assert p.wait(timeout=300) == 0
+        parts = [np.load(out % r) for r in range(world)]
+    ref = dist_worker.make_ladder(D, Nt, W, sr, 0x5EED0001, rate, cut)
+    ref.pt_step(nsteps)
+    assert np.array_equal(np.concatenate([p["x"] for p in parts]), PU.to_engine_order(ref.x, Nt, W))
+    assert np.array_equal(np.concatenate([p["ll"] for p in parts]), PU.to_engine_order(ref.llike, Nt, W))
+    assert np.array_equal(np.concatenate([p["nhist"] for p in parts]), PU.to_engine_order(ref.nhist, Nt, W))
+    assert np.array_equal(np.concatenate([p["nacc"] for p in parts]), PU.to_engine_order(ref.naccept, Nt, W))
+    assert np.array_equal(sum(p["st"] for p in parts), ref.swap_count)
+    assert np.array_equal(sum(p["sa"] for p in parts), ref.swap_accept_count)
+    for p in parts:
+        assert np.array_equal(p["betaw"], ref.betaw)
+    assert ref.swap_accept_count.sum() > 0 and not np.array_equal(ref.betaw[0], ref.beta)
+
+
 def test_shard_bounds_cover_the_ladder():
     from ptmcmc_amd.parallel import shard_bounds
     for nt in (1024, 10, 7):

@@ -595,11 +595,11 @@ def test_evolving_ladders_checkpoint_resume_and_refusals():
     with pytest.raises(E.PtmError):
         d.set_invtemps(np.tile(pr.beta, (W, 1)))   # only once the ladders evolve
     d.close()
-    s = E.Engine(D, Nt, W, swap_rate=0.4, rung_begin=0, rung_count=4)
+    s = E.Engine(D, Nt, W, swap_rate=0.4, rung_begin=0, rung_count=4, history_rungs=2, history_capacity=8)
     s.set_ladder(pr.beta)
-    with pytest.raises(E.PtmError):
-        s.set_evolve_temps(0.01)         # a shard of the ladder
-    s.close()
+    with pytest.raises(E.PtmError, match="history"):
+        s.set_evolve_temps(0.01)         # a shard of the ladder that records a history: not built (plain shards evolve:
+    s.close()                            #  test_evolving_ladders_on_rung_shards_match_the_single_engine)
 
 
 def test_bounds_and_mixed_prior_path_bit_exact():
@@ -813,6 +813,30 @@ class _DevShard:
     def sync(self):
         self.e.sync()
 
+    # evolving ladders: the gathered form (ShardedLadder.step_gathered)
+    @property
+    def gathered(self):
+        return bool(self.e._evolving)
+
+    @property
+    def needs_lprior(self):
+        return self.e._evolve_cut >= 0
+
+    def copy_lprior(self, first, n, dst):
+        self.e.copy_lprior(first, n, dst.ptr)
+
+    def exchange_decide_gathered(self, ll_all, lp_all, su, sd):
+        p = lambda b: None if b is None else b.ptr
+        self.e.exchange_decide_gathered(p(ll_all), p(lp_all), p(su), p(sd))
+
+    @staticmethod
+    def sub(buf, off, n):
+        return buf.slice(off * 8, n * 8)
+
+    def dcopy(self, dst, src):
+        self.e.sync()
+        dst.copy_from(src.ptr, min(dst.nbytes, src.nbytes))
+
 
 @pytest.mark.parametrize("overlap", [False, True])
 @pytest.mark.parametrize("D,Nt,W,G,halo,sr", [(32, 16, 64, 2, 4, 0.3), (8, 12, 64, 3, 4, 0.45), (5, 9, 3, 4, 3, 0.45),
@@ -856,6 +880,53 @@ def test_sharded_engines_match_single_engine(D, Nt, W, G, halo, sr, overlap):
         assert a.sum() > 0
     else:
         assert min(e.nloc for e in shards) <= 2   # only tiny shards may trip the halo / far-move guard in 40 steps
+    for e in shards + [ref]:
+        e.close()
+
+
+@pytest.mark.parametrize("D,Nt,W,G,sr,rate,cut", [(6, 12, 3, 2, 0.4, 0.05, -1.0), (32, 24, 64, 3, 0.3, 0.01, -1.0), (5, 17, 4, 4, 0.45, 0.03, 0.0),
+                                                  (16, 40, 2, 5, 0.2, 0.01, 1.5), (40, 9, 5, 3, 0.45, 0.02, -1.0)])
+def test_evolving_ladders_on_rung_shards_match_the_single_engine(D, Nt, W, G, sr, rate, cut):
+    """evolve_temps on a ladder sharded by rungs: every accepted exchange renormalises all gaps and every later trial of the step
+    sees it, so every shard replays the whole ladder's trials -- from the whole ladder's llikes (and lpriors, with a
+    posterior-ordering cut), gathered each step as the reference's MPI ranks gather them (gather_llikes / gather_lposts,
+    chain.cc:1433-1435,1950-1972; ptm_exchange_decide_gathered).  G shards, driven in lockstep with the all-gather done by plain
+    copies, must walk the single engine's chains bit for bit, temperatures included."""
+    import shard_sim
+    from ptmcmc_amd.parallel import shard_bounds
+    from ptmcmc_amd.problems import GaussianProblem
+    pr = GaussianProblem(D, Nt, 1e3)
+    ref = E.Engine(D, Nt, W, swap_rate=sr)
+    pr.configure(ref, E.PROP_LOWER)
+    ref.set_evolve_temps(rate, cut)
+    ref.init_from_prior()
+    x0 = ref.states()
+    shards = []
+    for g in range(G):
+        r0, n = shard_bounds(Nt, G, g)
+        e = E.Engine(D, Nt, W, swap_rate=sr, rung_begin=r0, rung_count=n)
+        pr.configure(e, E.PROP_LOWER)
+        e.set_evolve_temps(rate, cut)
+        e.set_states(x0[r0 * W:(r0 + n) * W])
+        with pytest.raises(E.PtmError, match="gathered"):      # the halo form cannot serve an evolving ladder
+            e.exchange_decide(None, None, 1, None, None)
+        shards.append(e)
+    lads = shard_sim.build([_DevShard(e) for e in shards], halo=4)
+    assert all(l.gathered for l in lads)
+    copy = lambda dst, src: dst.copy_from(src.ptr, min(dst.nbytes, src.nbytes))
+    for k in range(40):
+        ref.step(1)
+        shard_sim.step(lads, copy, 1)
+        xs = np.concatenate([e.states() for e in shards])
+        assert np.array_equal(xs, ref.states()), "states differ after step %d" % (k + 1)
+        for e in shards:                                        # every shard keeps the whole ladders' temperatures
+            assert np.array_equal(e.invtemps(), ref.invtemps()), "temperatures differ after step %d" % (k + 1)
+    assert not np.array_equal(ref.invtemps()[0], pr.beta)       # ... and they did evolve
+    for name in ("llike", "lprior", "lpost", "ntries", "naccept", "nhist", "nsize", "last_type"):
+        assert np.array_equal(np.concatenate([getattr(e, name) for e in shards]), getattr(ref, name)), name
+    t = sum(e.swap_counts()[0] for e in shards); a = sum(e.swap_counts()[1] for e in shards)
+    rt, ra = ref.swap_counts()
+    assert np.array_equal(t, rt) and np.array_equal(a, ra) and a.sum() > 0
     for e in shards + [ref]:
         e.close()
 
