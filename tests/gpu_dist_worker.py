@@ -22,6 +22,7 @@ from ptmcmc_amd.problems import GaussianProblem
 if __name__ == "__main__":
     D, Nt, W, nsteps, halo = (int(v) for v in sys.argv[1:6])
     sr, out = float(sys.argv[6]), sys.argv[7]
+    evolve = float(sys.argv[8]) if len(sys.argv) > 8 else 0.0
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     os.environ["PTM_BENCH_REHEARSAL"] = "1"
     dev = torch.device("cuda", 0)
@@ -37,6 +38,8 @@ if __name__ == "__main__":
     stream = torch.cuda.Stream(device=dev)
     eng = E.Engine(D, Nt, W, swap_rate=sr, rung_begin=r0, rung_count=n, stream=stream.cuda_stream)
     pr.configure(eng, E.PROP_LOWER)
+    if evolve > 0:
+        eng.set_evolve_temps(evolve)      # evolving ladders: ShardedLadder.step_gathered (an all-gather of the llikes per step)
     eng.set_states(x0[r0 * W:(r0 + n) * W])
     lad = ShardedLadder(EngineShard(eng, torch, dev, stream), dist, rank, world, halo=halo)
     lad.step(7)              # as bench.py drives it: several calls, halos left in flight between them, drained at the end
@@ -45,7 +48,7 @@ if __name__ == "__main__":
     lad.drain()
     eng.sync()
     t, a = eng.swap_counts()
-    np.savez(out % rank, x=eng.states(), ll=eng.llike, nacc=eng.naccept, nhist=eng.nhist, st=t, sa=a)
+    np.savez(out % rank, x=eng.states(), ll=eng.llike, nacc=eng.naccept, nhist=eng.nhist, st=t, sa=a, invtemps=eng.invtemps())
     dist.barrier()
     eng.close()
     dist.destroy_process_group()

@@ -70,12 +70,14 @@ def test_1024_rungs_in_8_engine_shards_on_torch_streams(overlap):
     assert "OK" in out.stdout
 
 
-@pytest.mark.parametrize("world,D,Nt,W,halo,sr", [(2, 32, 16, 64, 4, 0.3), (3, 32, 48, 128, 8, 0.1), (4, 8, 24, 5, 4, 0.45)])
-def test_sharded_ladder_between_processes_on_the_gpu(world, D, Nt, W, halo, sr):
+@pytest.mark.parametrize("world,D,Nt,W,halo,sr,evolve", [(2, 32, 16, 64, 4, 0.3, 0.0), (3, 32, 48, 128, 8, 0.1, 0.0), (4, 8, 24, 5, 4, 0.45, 0.0),
+                                                         (3, 32, 25, 64, 4, 0.3, 0.01), (2, 6, 11, 3, 4, 0.45, 0.05)])
+def test_sharded_ladder_between_processes_on_the_gpu(world, D, Nt, W, halo, sr, evolve):
     """The N > 1 path with real engines in separate PROCESSES: every rank an EngineShard on its own torch stream, the sharded
     (overlapped) step of ShardedLadder, its messages between the processes -- over gloo on the one GPU this box has (RCCL refuses
     two ranks on one device; tests/gpu_dist_worker.py says what differs).  The blocks put together are, bit for bit, the ladder
-    of one engine: states, llikes, counters, swap bookkeeping."""
+    of one engine: states, llikes, counters, swap bookkeeping -- for fixed ladders (llike halos between neighbours) and evolving
+    ones (an all-gather of the llikes per step, ShardedLadder.step_gathered)."""
     import socket
     import tempfile
     from ptmcmc_amd.parallel import shard_bounds
@@ -87,15 +89,21 @@ def test_sharded_ladder_between_processes_on_the_gpu(world, D, Nt, W, halo, sr):
         for r in range(world):
             env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
             procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "gpu_dist_worker.py"), str(D), str(Nt), str(W), str(nsteps),
-                                           str(halo), str(sr), out], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+                                           str(halo), str(sr), out, str(evolve)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
         res = [p.communicate(timeout=600) for p in procs]
         assert all(p.returncode == 0 for p in procs), [r[1][-1500:] for r in res]
         parts = [np.load(out % r) for r in range(world)]
     pr = GaussianProblem(D, Nt, 1e6)
     ref = E.Engine(D, Nt, W, swap_rate=sr)
     pr.configure(ref, E.PROP_LOWER)
+    if evolve > 0:     # (evolving ladders: the gathered form of the sharded step, every rank keeps the whole ladders' temperatures)
+        ref.set_evolve_temps(evolve)
     ref.init_from_prior()
     ref.step(nsteps); ref.sync()
+    if evolve > 0:
+        for p in parts:
+            assert np.array_equal(p["invtemps"], ref.invtemps())
+        assert not np.array_equal(ref.invtemps()[0], pr.beta)
     assert np.array_equal(np.concatenate([p["x"] for p in parts]), ref.states())
     assert np.array_equal(np.concatenate([p["ll"] for p in parts]), ref.llike)
     assert np.array_equal(np.concatenate([p["nacc"] for p in parts]), ref.naccept)
