@@ -122,8 +122,8 @@ __device__ __forceinline__ void decide_body(const Decide& p, unsigned char* smem
   int* first = reinterpret_cast<int*>(llc_ + WN);                             // [Nt]  first pick of each rung value
   int* cand = first + ((Nt + 1) & ~1);                                        // [ms]  rung of the pick / -2 none or dropped
   uint32_t* ua = reinterpret_cast<uint32_t*>(cand + ((ms + 1) & ~1));         // [ms]  accept uniform of the pick (raw)
-  int* cnt = reinterpret_cast<int*>(ua + ((ms + 1) & ~1));                    // [2]   list length, move count
-  unsigned short* perm_ = reinterpret_cast<unsigned short*>(cnt + 2);         // [WN]  source rung of the row now at a rung
+  int* cnt = reinterpret_cast<int*>(ua + ((ms + 1) & ~1));                    // [4]   list length, move count, ambiguous trial seen, pries
+  unsigned short* perm_ = reinterpret_cast<unsigned short*>(cnt + 4);         // [WN]  source rung of the row now at a rung
   unsigned short* inv_ = perm_ + ((WN + 3) & ~3);                             // [WN]  inverse of perm
   unsigned short* list = inv_ + ((WN + 3) & ~3);                              // [ms]  surviving picks that are ours
   unsigned short* mid_ = list + ((ms + 3) & ~3);                              // [WN]  row a twice-touched rung held in between
@@ -364,7 +364,69 @@ __device__ __forceinline__ void decide_body(const Decide& p, unsigned char* smem
         }
       }
     }
-    if (!cutmode && lane == 0) {
+    // The trials of an evolving ladder are ONE chain in pick order only through the normaliser S, and S moves little: by
+    // rate x (the pried gaps) -- a relative 1e-3 at most.  So first every run of surviving picks is walked by its own lane
+    // (as for a fixed ladder) with S known only to lie in [S0, S0 + all the increments any pick could add]: lu S is
+    // monotone in S, so a trial that passes at S0 passes for every S of the interval and one that fails at the upper end fails
+    // everywhere -- and as long as it also gives the same answer by the first-trial form (nothing pried yet: no S at all) the
+    // decision is the sequential walk's, whatever came before it.  Only a ladder with a trial inside that window (about one
+    // in fifty at 1024 rungs) takes the sequential walk below.  (Not with history / MAP tracking: their rows want S itself.)
+    bool walked = false;
+    if (!cutmode && !evb) {
+      const double c1 = 1 - p.beta_w[(size_t)w * Nt + Nt - 1];   // chain.cc:1833
+      const double grow = 1.0 + p.evolve_rate;
+      if (lane == 0) {
+        double S = 0.0;
+        for (int q = 0; q < nch; ++q) { ct[nch + q] = S; S = S + ct[q]; }
+        ev[0] = S; ev[1] = 0.0;
+        cnt[2] = 0; cnt[3] = 0;
+      }
+      __syncthreads();
+      {   // an upper bound of every increment together (any order: it is a bound, taken with a margin)
+        double part = 0.0;
+        for (int t = lane; t < nl; t += DECIDE_THREADS) part += tgap[t] * grow - tgap[t];
+        if (part != 0.0) atomicAdd(&ev[1], part);
+      }
+      __syncthreads();
+      const double S_lo = ev[0], S_hi = (ev[0] + ev[1]) * (1.0 + 1e-12);
+      for (int j = lane; j < nl; j += DECIDE_THREADS) {
+        const int n = cand[list[j]];
+        if (PTM_ALIVE_RUNG(n + 1)) continue;                       // not the top of a run
+        bool carried = false;
+        double carry = 0.0;
+        for (int i = n;; --i) {
+          const int t = opos[first[i]];
+          const double lu = tlu[t], g = tgap[t];
+          const double llb_raw = carried ? carry : tllb[t];
+          double lla = tlla[t];
+          if (!(lla > -1e200)) lla = -1e200;
+          double llb = llb_raw;
+          if (!(llb > -1e200)) llb = -1e200;
+          const double dl = llb - lla;
+          const double logH = g * dl, tt = (g * c1) * dl;
+          const bool accA = !(logH < 0) || lu < logH;               // nothing pried yet (chain.cc:1463-1467 on the stored temperatures)
+          const bool acc_lo = !(tt < 0) || lu * S_lo < tt;          // the hardest S to pass
+          const bool acc_hi = !(tt < 0) || lu * S_hi < tt;          // the easiest
+          if (accA != acc_lo || accA != acc_hi) { cnt[2] = 1; break; }   // inside the window: this ladder walks in order
+          tacc[t] = accA ? 1 : 0;
+          carried = accA;
+          carry = llb_raw;                                          // the row now on rung i came from rung i + 1
+          if (!PTM_ALIVE_RUNG(i - 1)) break;
+        }
+      }
+      __syncthreads();
+      if (cnt[2] == 0) {
+        for (int t = lane; t < nl; t += DECIDE_THREADS)
+          if (tacc[t]) { gap[ti[t]] = tgap[t] * grow; atomicAdd(&cnt[3], 1); }   // chain.cc:1829
+        __syncthreads();
+        if (lane == 0) ev[1] = (double)cnt[3];
+        walked = true;
+      } else {
+        for (int t = lane; t < nl; t += DECIDE_THREADS) tacc[t] = 0;
+      }
+      __syncthreads();
+    }
+    if (!cutmode && !walked && lane == 0) {
       double S = 0.0;
       for (int q = 0; q < nch; ++q) { ct[nch + q] = S; S = S + ct[q]; }
       const double c1 = 1 - p.beta_w[(size_t)w * Nt + Nt - 1];   // chain.cc:1833

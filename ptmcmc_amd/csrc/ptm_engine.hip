@@ -1168,7 +1168,11 @@ static Decide make_decide(ptm_engine* e, const double* ll_below, const double* l
   p.map = e->map;
   p.evolve_rate = e->evolve_rate; p.evolve_cut = e->evolve_cut; p.beta_w = e->beta_w; p.beta_add = e->beta_add;
   p.lp_is_const = e->lp_is_const ? 1 : 0; p.lp_const = e->lprior_const;
-  const bool beta_direct = e->evolve_rate > 0 && e->W <= 64;   // few ladders: the exchange kernel scatters the new temperatures itself
+  // few ladders: the exchange kernel scatters the new temperatures into their chain-indexed image itself.  For populations the
+  // scattered 8-byte stores cost the kernel what the transposition launch costs (measured at 1024 rungs x 16384 ladders: 0.621 ms
+  // against 0.564 + 0.049; PTM_BETA_DIRECT=1 selects it anyway)
+  static const bool direct_all = [] { const char* v = getenv("PTM_BETA_DIRECT"); return v && *v == '1'; }();
+  const bool beta_direct = e->evolve_rate > 0 && (e->W <= 64 || direct_all);
   p.betaC_direct = beta_direct ? e->betaC : nullptr;
   return p;
 }
