@@ -211,9 +211,6 @@ __device__ __forceinline__ void decide_body(const Decide& p, unsigned char* smem
   }
   __syncthreads();
   const int nl = cnt[0];
-#if defined(PTM_DECIDE_ABLATE) && (PTM_DECIDE_ABLATE & 16)   // timing experiment: draws + filter + compaction only
-  if (nl >= 0) return;
-#endif
   // -- working copy of the touched rungs (gather_llikes, chain.cc:1434); each touched rung is set up by exactly one
   //    lane: the pick whose lower rung it is, or -- for the top of a run -- the pick just below it
   for (int j = lane; j < nl; j += DECIDE_THREADS) {
@@ -561,14 +558,9 @@ __device__ __forceinline__ void decide_body(const Decide& p, unsigned char* smem
       }
     }
   }
-#if defined(PTM_DECIDE_ABLATE) && (PTM_DECIDE_ABLATE & 64)   // timing experiment: ... + llike gather + trials
-  if (nl >= 0) return;
-#endif
   // -- the step's log
-#if !(defined(PTM_DECIDE_ABLATE) && (PTM_DECIDE_ABLATE & 4))
   for (int k = lane; k < ms; k += DECIDE_THREADS)
     swap_log[(size_t)w * ms + k] = alive[k] == 1 ? (cand[k] | (accf[k] ? 0x40000000 : 0)) : (alive[k] == 2 ? -3 : -2);
-#endif
   // -- counters, the touch counts of the local rungs and the inverse permutation
   for (int j = lane; j < nl; j += DECIDE_THREADS) {
     const int k = list[j];
@@ -581,9 +573,7 @@ __device__ __forceinline__ void decide_body(const Decide& p, unsigned char* smem
       if (r >= p.r0 && r < r1) {
         const int below_alive = (r > 0 && PTM_ALIVE_RUNG(r - 1) && alive[first[r - 1]] == 1) ? 1 : 0;
         const int self_alive = (r == i) ? 1 : 0;
-#if !(defined(PTM_DECIDE_ABLATE) && (PTM_DECIDE_ABLATE & 2))
         p.touch[(r - p.r0) * p.W + w] = (unsigned char)(below_alive + self_alive);
-#endif
       }
       const int s = perm[r];
       if (s != r) inv[s] = (unsigned short)r;             // the row that started at s ends at r
@@ -654,11 +644,7 @@ __device__ __forceinline__ void decide_body(const Decide& p, unsigned char* smem
     }
   }
   __syncthreads();
-#if defined(PTM_DECIDE_ABLATE) && (PTM_DECIDE_ABLATE & 8)
-  const int nmv = 0;
-#else
   const int nmv = cnt[1];
-#endif
   if (nmv > FCAP && nmv <= MVCAP) {   // too long for this block's registers: move_kernel takes it from here
     for (int j = lane; j < nmv; j += DECIDE_THREADS) {
       p.mv_src[(size_t)w * MVCAP + j] = gs[j];

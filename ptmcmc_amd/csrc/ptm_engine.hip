@@ -532,9 +532,7 @@ extern "C" int ptm_set_target_gaussian(ptm_engine* e, const double* mean, const 
   if ((rc = upload(e->P2, packed.data(), packed.size(), e->stream))) return rc;
   if (DP == 32) {
     // A-operand tiles of the MFMA kernel: tile t = step*2 + rowtile, lane 16k + i holds P2[16 rowtile + i][4 step + k]
-    // and, behind the sixteen tiles, the 36 blocks of 4x4 on and under the diagonal: block (R, C) at R(R+1)/2 + C, its
-    // element [k][i] at 4k + i holds P2[4R + i][4C + k] (the A operand of v_mfma_f64_4x4x4_4b_f64, the same for its four blocks)
-    std::vector<double> tiles(16 * 64 + 12 * 64, 0.0);
+    std::vector<double> tiles(16 * 64, 0.0);
     for (int t = 0; t < 16; ++t) {
       const int rt = t & 1, m = t >> 1;
       for (int k = 0; k < 4; ++k)
@@ -543,13 +541,6 @@ extern "C" int ptm_set_target_gaussian(ptm_engine* e, const double* mean, const 
           if (row < D && col <= row) tiles[(size_t)t * 64 + 16 * k + i] = packed[(size_t)row * (row + 1) / 2 + col];
         }
     }
-    for (int R = 0; R < 8; ++R)
-      for (int C = 0; C <= R; ++C)
-        for (int k = 0; k < 4; ++k)
-          for (int i = 0; i < 4; ++i) {
-            const int row = 4 * R + i, col = 4 * C + k;
-            if (row < D && col <= row) tiles[16 * 64 + (size_t)(R * (R + 1) / 2 + C) * 16 + 4 * k + i] = packed[(size_t)row * (row + 1) / 2 + col];
-          }
     if ((rc = upload(e->P2_tiles, tiles.data(), tiles.size(), e->stream))) return rc;
   }
   if (DP == 64) {
@@ -2091,10 +2082,6 @@ extern "C" const char* ptm_sweep_kernel_name(ptm_engine* e) {
     const char* cv = getenv("PTM_COMPACT");
     const bool g1 = !s.simple && e->all_uniform && (!e->has_bounds || e->bounds_box);
     const bool cpt = !(cv && *cv == '0') && (s.simple || g1) && !e->hist.rungs && !e->map.rungs && e->W >= 1024 && e->nloc <= 4096;   // (in PT steps; plain sweeps visit every chain)
-    const char* lv = getenv("PTM_LEAN_PIPE");
-    if (s.simple && !e->hist.rungs && !e->map.rungs && lv && *lv && *lv != '0')
-      snprintf(b, sizeof b, "sweep_mfma32_lean_kernel<%d, %s>", s.kind == KIND_DIAG ? KIND_LOWER : s.kind, cpt ? "true" : "false");
-    else
     snprintf(b, sizeof b, "sweep_mfma32_kernel<%d, %s, %d%s, %s>", s.kind == KIND_DIAG ? KIND_LOWER : s.kind, (e->hist.rungs || e->map.rungs) ? "true" : "false",
              s.simple ? 0 : ((e->all_uniform && (!e->has_bounds || e->bounds_box)) ? 1 : 2),
              (!s.simple && e->all_uniform && (!e->has_bounds || e->bounds_box) && e->betaC) ? ", true" : ", false", cpt ? "true" : "false");   // as rocprofv3 prints it

@@ -291,14 +291,8 @@ struct DrawCtx {
 };
 __device__ __forceinline__ void draw4(const DrawCtx& dc, int b, double (&z)[4]) {
   const u32x4 o = draw_block(dc.seed, TAG_MH, dc.stream, dc.step, (uint32_t)(b + 1));
-#if defined(PTM_ABLATE) && (PTM_ABLATE & 1)
-  z[0] = 0.1 * (dc.stream & 7); z[1] = 0.2; z[2] = -0.1; z[3] = 0.05 * b;
-#elif defined(PTM_ABLATE) && (PTM_ABLATE & 8)
-  z[0] = u01(o.v0); z[1] = u01(o.v1); z[2] = u01(o.v2); z[3] = u01(o.v3);
-#else
   boxmuller(o.v0, o.v1, dc.bmtab, z[0], z[1]);
   boxmuller(o.v2, o.v3, dc.bmtab, z[2], z[3]);
-#endif
   if (dc.axis >= 0) {
 #pragma unroll
     for (int t = 0; t < 4; ++t)
@@ -589,11 +583,7 @@ __global__ __launch_bounds__(256, PTM_SWEEP_WAVES) void sweep_kernel(const Dev p
     newlike = want_like ? p.llike_new[c] : -__builtin_inf();
     newlpost = want_like ? newlike * beta + newlprior : -__builtin_inf();
   } else if (want_like) {
-#if defined(PTM_ABLATE) && (PTM_ABLATE & 4)
-    newlike = xn[0] + xn[DP - 1];  // ablation: no quadratic form
-#else
     newlike = (!SIMPLE && p.has_mean) ? gauss_llike<DP, true>(p, xn) : gauss_llike<DP, false>(p, xn);
-#endif
     newlpost = newlike * beta + newlprior;
   } else {
     newlike = newlpost = -__builtin_inf();

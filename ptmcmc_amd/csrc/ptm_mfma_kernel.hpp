@@ -41,9 +41,6 @@ typedef double mf_d2 __attribute__((ext_vector_type(2)));
 #ifndef PTM_MFMA_GEN_WAVES
 #define PTM_MFMA_GEN_WAVES 3   // ... of the general builds
 #endif
-#ifndef PTM_MFMA_P2_BLOCKS
-#define PTM_MFMA_P2_BLOCKS 0   // 1: S = P2 X' as 4x4 blocks (v_mfma_f64_4x4x4_4b_f64), the blocks above the diagonal never issued
-#endif
 #ifndef PTM_MFMA_GG
 #define PTM_MFMA_GG 0          // 16-chain groups worked together in a pass (2: two passes of 32 chains; 1: four passes of 16 -- half the live
                                // set, four waves per SIMD); 0: by build -- 1 for the everything-general build (0.90 -> 0.70 ms), 2 for the others
@@ -54,9 +51,6 @@ typedef double mf_d2 __attribute__((ext_vector_type(2)));
 #endif
 #ifndef PTM_MFMA_G1C_WAVES
 #define PTM_MFMA_G1C_WAVES 3
-#endif
-#ifndef PTM_MFMA_ASK_AT
-#define PTM_MFMA_ASK_AT 4      // block product: the second pass's rows are asked for before column block ASK_AT (-1: before the product)
 #endif
 #ifndef PTM_MFMA_PRIO
 #define PTM_MFMA_PRIO 2        // 1: a wave raises its issue priority over its matrix blocks (measured: nothing); 2: over its vector (draw)
@@ -96,7 +90,6 @@ __global__ __launch_bounds__(256, (GEN == 0 ? PTM_MFMA_WAVES : ((PTM_MFMA_GG == 
   double* ebox = reinterpret_cast<double*>(gint + 3 * 32) + 4 * 128;
   const int q = l >> 4, j = l & 15;
   const double* pimg = ptile + l;
-  const double* pblk = ptile + 4 * q + (j & 3);   // 4x4 block image: element [k][i] of a block at 4k + i (every 4-chain block reads the same)
   const mf_d2* box = reinterpret_cast<const mf_d2*>(lbox) + q;   // lo piece t at 4t, hi piece t at 16 + 4t (row layout)
   const mf_d2* ebx = reinterpret_cast<const mf_d2*>(ebox) + q;
 
@@ -113,7 +106,7 @@ __global__ __launch_bounds__(256, (GEN == 0 ? PTM_MFMA_WAVES : ((PTM_MFMA_GG == 
   for (int t = 0; t < 3; ++t) {
     const int e = threadIdx.x + 256 * t, tile = e >> 6;
     const int src = tile < 8 ? (tile * 2 + 1) : ((tile - 8) * 2 + 0);
-    st_p[t] = PTM_MFMA_P2_BLOCKS ? p.P2_tiles[16 * 64 + e] : p.P2_tiles[src * 64 + (e & 63)];   // (36 blocks of 16 in 768 slots)
+    st_p[t] = p.P2_tiles[src * 64 + (e & 63)];
   }
   const double st_box = p.box_row[threadIdx.x & 63];
   double st_g[6] = {0, 0, 0, 0, 0, 0};
@@ -300,14 +293,8 @@ __global__ __launch_bounds__(256, (GEN == 0 ? PTM_MFMA_WAVES : ((PTM_MFMA_GG == 
       for (int gg = 0; gg < GG; ++gg) {
         const uint32_t stream = (uint32_t)(wq[GG * gp + gg] + p.w_off) * (uint32_t)p.Nt + (uint32_t)rg;
         const u32x4 o = draw_block(p.seed, TAG_MH, stream, p.step, (uint32_t)(1 + 4 * hb + qd));
-#if defined(PTM_ABLATE) && (PTM_ABLATE & 1)   // timing experiment: no Box-Muller
-        z[gg][0] = u01(o.v0); z[gg][1] = u01(o.v1); z[gg][2] = u01(o.v2); z[gg][3] = u01(o.v3);
-#elif defined(PTM_ABLATE) && (PTM_ABLATE & 8)  // timing experiment: no random numbers at all
-        z[gg][0] = 0.1 * q; z[gg][1] = 0.2; z[gg][2] = 0.3 * j; z[gg][3] = 0.4 + (double)stream * 0;
-#else
         boxmuller(o.v0, o.v1, (const double*)lds_all, z[gg][0], z[gg][1]);
         boxmuller(o.v2, o.v3, (const double*)lds_all, z[gg][2], z[gg][3]);
-#endif
         if (GEN && axis[gg] >= 0) {
 #pragma unroll
           for (int sl = 0; sl < 4; ++sl)
@@ -325,11 +312,7 @@ __global__ __launch_bounds__(256, (GEN == 0 ? PTM_MFMA_WAVES : ((PTM_MFMA_GG == 
           const double a = hb == 0 ? ta[sl][rt] : tb[sl][rt];
 #pragma unroll
           for (int gg = 0; gg < GG; ++gg) {
-#if defined(PTM_ABLATE) && (PTM_ABLATE & 2)   // timing experiment: no T x Z
-            acc[gg][rt][sl] += a * z[gg][sl];
-#else
             acc[gg][rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, z[gg][sl], acc[gg][rt], 0, 0, 0);
-#endif
           }
         }
       }
@@ -393,50 +376,16 @@ __global__ __launch_bounds__(256, (GEN == 0 ? PTM_MFMA_WAVES : ((PTM_MFMA_GG == 
     }
     PTM_STAGE();
     // the second pass's rows are asked for here: the registers of the first pass's rows have just been freed
-    // (with the 4x4-block product: in the middle of it, where the operand pipeline has drained to a few registers)
     mf_d2 rown[GG][4];
     mf_d2* rowpn[GG];
 #pragma unroll
     for (int gg = 0; gg < GG; ++gg) rowpn[gg] = rowp[gg];
-    if (gp + 1 < NP && (!PTM_MFMA_P2_BLOCKS || PTM_MFMA_ASK_AT < 0)) ask_rows(gp + 1, rown, rowpn);
+    if (gp + 1 < NP) ask_rows(gp + 1, rown, rowpn);
     PTM_STAGE();
     // ---- stage 4: S = P2 x Y, Y = X' (- mean), and the four partial dot products of each chain
     if (PTM_MFMA_PRIO == 1) __builtin_amdgcn_s_setprio(2);
     if (PTM_MFMA_PRIO == 2) __builtin_amdgcn_s_setprio(0);
     auto yv = [&](int gg, int m) -> double { return (GEN && p.has_mean) ? xp[gg][m] - gtab[160 + q + 4 * m] : xp[gg][m]; };
-#if PTM_MFMA_P2_BLOCKS
-    // rows 4R..4R+3 (register R of the lane group that owns the residue) x columns 4m..4m+3: the 36 blocks on and under the
-    // diagonal, each a 16-cycle v_mfma_f64_4x4x4_4b_f64 whose four 4-chain blocks all take the same A (measured:
-    // tools/probes/mfma_f64_4x4_probe.hip -- A[i][k] of block b on lane 16k+4b+i, B[k][n] on 16k+4b+n, D[i][n] on 16i+4b+n,
-    // i.e. with chain j = 4b+n the very lane roles of the 16x16x4 shape; k-ascending fma chain on C, as that shape)
-    double sacc[GG][8];
-#pragma unroll
-    for (int gg = 0; gg < GG; ++gg)
-#pragma unroll
-      for (int m = 0; m < 8; ++m) sacc[gg][m] = 0.0;
-    // software pipeline: column block m + 1's operands are read from LDS while column block m's 2 (8 - m) independent
-    // instructions issue; the fences keep the scheduler from regrouping the product by rows (one dependent chain per row,
-    // every LDS read waited for in full)
-    double pa[2][8];
-#pragma unroll
-    for (int R = 0; R < 8; ++R) pa[0][R] = pblk[(R * (R + 1) / 2) * 16];
-#pragma unroll
-    for (int m = 0; m < 8; ++m) {
-      if (gp + 1 < NP && m == PTM_MFMA_ASK_AT) ask_rows(gp + 1, rown, rowpn);
-      if (m < 7) {
-#pragma unroll
-        for (int R = m + 1; R < 8; ++R) pa[(m + 1) & 1][R] = pblk[(R * (R + 1) / 2 + m + 1) * 16];
-      }
-      PTM_STAGE();
-#pragma unroll
-      for (int R = m; R < 8; ++R) {
-#pragma unroll
-        for (int gg = 0; gg < GG; ++gg) sacc[gg][R] = __builtin_amdgcn_mfma_f64_4x4x4f64(pa[m & 1][R], yv(gg, m), sacc[gg][R], 0, 0, 0);
-      }
-      PTM_STAGE();
-    }
-#define PTM_SACC(gg, m) sacc[gg][m]
-#else
     mf_d4 sacc[GG][2];
 #pragma unroll
     for (int gg = 0; gg < GG; ++gg) {
@@ -451,16 +400,11 @@ __global__ __launch_bounds__(256, (GEN == 0 ? PTM_MFMA_WAVES : ((PTM_MFMA_GG == 
         const double a = pimg[(rt ? m : 8 + m) * 64];
 #pragma unroll
         for (int gg = 0; gg < GG; ++gg) {
-#if defined(PTM_ABLATE) && (PTM_ABLATE & 4)   // timing experiment: no P2 x X'
-          sacc[gg][rt][m & 3] += a * xp[gg][m];
-#else
           sacc[gg][rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, yv(gg, m), sacc[gg][rt], 0, 0, 0);
-#endif
         }
       }
     }
 #define PTM_SACC(gg, m) sacc[gg][(m) >> 2][(m) & 3]
-#endif
     if (PTM_MFMA_PRIO == 1) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
     for (int gg = 0; gg < GG; ++gg) {

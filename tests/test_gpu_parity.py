@@ -1222,9 +1222,7 @@ def test_compacted_sweep_in_sharded_engines(overlap):
         e.close()
 
 
-@pytest.mark.parametrize("env,D,Nt,W,kind,want", [({"PTM_LEAN_PIPE": "1"}, 32, 6, 1024, "lower", "sweep_mfma32_lean_kernel<2, true>"),
-                                                 ({"PTM_LEAN_PIPE": "1"}, 24, 5, 128, "dense", "sweep_mfma32_lean_kernel<0, false>"),
-                                                 ({"PTM_COMPACT": "0"}, 32, 6, 1024, "lower", "sweep_mfma32_kernel<2, false, 0, false, false>"),
+@pytest.mark.parametrize("env,D,Nt,W,kind,want", [({"PTM_COMPACT": "0"}, 32, 6, 1024, "lower", "sweep_mfma32_kernel<2, false, 0, false, false>"),
                                                  ({"PTM_FORCE_VALU": "1"}, 32, 5, 64, "lower", "sweep_kernel<32"),
                                                  ({"PTM_FUSED": "0"}, 6, 12, 3, "dense", "sweep_lanes_kernel<8"),
                                                  ({"PTM_LADDER": "0"}, 32, 40, 2, "lower", "decide_kernel + sweep_lanes_kernel<32"),
@@ -1232,8 +1230,7 @@ def test_compacted_sweep_in_sharded_engines(overlap):
                                                  ({"PTM_LADDER_MAXRUN": "1"}, 32, 64, 2, "lower", "ladder_persistent_kernel<32"),
                                                  ({"PTM_LADDER_MAXRUN": "2"}, 10, 90, 3, "dense", "ladder_persistent_kernel<16")])
 def test_switched_off_variants_stay_bit_exact(env, D, Nt, W, kind, want):
-    """The engine's environment switches select code that the default run never reaches: the software-pipelined lean kernel
-    (a measured, switched-off experiment: DESIGN.md section 3.1), the un-compacted sweep of a big population, the general VALU
+    """The engine's environment switches select code that the default run never reaches: the un-compacted sweep of a big population, the general VALU
     kernel on the MFMA workload, the two-launch step of small and of long ladders, and the persistent ladder kernel with its longest
     admissible run of surviving picks lowered to 1 / 2 -- every few steps the launch then ends early, the step is taken by the
     two-launch path and the kernel relaunched (with the halo's 8 that path is a once-in-10^12-steps event).  Each in a process of its own (the switches are read
