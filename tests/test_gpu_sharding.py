@@ -147,6 +147,18 @@ def test_bench_with_two_ranks_rehearsed_on_one_gpu(sabotage, expect):
     assert rec["n_gpus"] == 2 and rec["steps"] == 6 and rec["scaling"] == "weak" and rec["value"] > 1e7
     assert rec["config"]["walkers"] == 2048 and rec["config"]["chains"] == 2 * 1024 * 1024
     assert expect in rec["config"]["sharding"], rec["config"]["sharding"]
+    # what was measured is said unmistakably, with the transport's own evidence, the CPU baseline and an honest roofline
+    assert rec["config"]["measured"] == ("rung-sharded" if sabotage == "" else "fallback")
+    ev = rec["config"]["transport"]
+    assert ev["world_size"] == 2
+    if sabotage == "":
+        assert ev["all_reduce_of_ones"] == 2.0 and [r["rank"] for r in ev["ranks"]] == [0, 1]
+        assert [r["rungs"] for r in ev["ranks"]] == [[0, 512], [512, 1024]]
+    if sabotage != "stall":
+        assert rec["cpu_baseline"]["value"] > 0 and rec["cpu_baseline"]["kind"] in ("reference", "port")
+    rf = rec["roofline"]
+    assert 0.5 < rf["moving_fraction"] < 1.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    assert abs(rf["step_frac"] - rec["value"] * rf["bytes_per_mh_step"] / (2 * rf["peak"] * 1e9)) < 1e-9
 
 
 @pytest.mark.parametrize("D,Nt,W,ev,hist", [(32, 16, 256, 0.02, False), (6, 12, 10, 0.03, True), (32, 8, 2048, 0.0, False)])

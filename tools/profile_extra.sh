@@ -5,7 +5,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/w1 -- python3 $R/tool
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ev -- python3 $R/tools/kbench.py --walkers 16384 --evolve 0.01 > $O/ev.out 2> $O/ev.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/d64 -- python3 $R/tools/kbench.py --dim 64 --rungs 1024 --walkers 4096 > $O/d64.out 2> $O/d64.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/g1 -- python3 $R/tools/kbench.py --walkers 16384 --bounds > $O/g1.out 2> $O/g1.err
-find $O -name "*kernel_stats.csv"
+find $O -name "*kernel_stats.csv"   # (gpurun_out/ keeps earlier rounds' runs too: copy the NEWEST file of each directory into profiles/)
 # one rank of the 8-GPU weak-scaling shape (128 of 1024 rungs x 131072 ladders), its launch sequence without the messages
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/shard -- python3 $R/tools/kbench_shard.py --walkers 16384 --gpus 8 > $O/shard.out 2> $O/shard.err
 find $O/shard -name "*kernel_stats.csv"
