@@ -223,6 +223,18 @@ int ptm_exchange_decide(ptm_engine* e, const void* ll_below_dev, const void* ll_
  * temperatures.  Costs an all-gather of n_rungs x W doubles per step instead of two neighbour messages: for populations, prefer
  * splitting by walkers (ptm_config.walker_begin).  Boundary rows travel as with ptm_exchange_decide. */
 int ptm_exchange_decide_gathered(ptm_engine* e, const void* ll_all_dev, const void* lp_all_dev, void* send_up_dev, void* send_down_dev);
+/* RECOVERY of a run of surviving picks longer than a halo (instead of PTM_ERR_FAR_MOVE).  Whether some shard of a ladder is blind
+ * in a step is a property of the step's candidate draws, which every shard replays: told the whole shard map (every shard's rung
+ * count, in order, and the halo depth all of them ask for), ptm_exchange_decide leaves such a ladder alone ON EVERY SHARD -- the same
+ * ladders everywhere, no message needed to agree -- and counts it.  The caller asks for the count after the decide pass
+ * (ptm_exchange_redo_count: one wait on the device); if it is not zero -- on every rank alike -- it gathers the whole ladder's llikes
+ * as for ptm_exchange_decide_gathered (the arrays of the ladders left alone are untouched) and ptm_exchange_redo decides those ladders
+ * from the full view, appending their boundary rows to the same messages.  Then the step goes on as ever.  The reference never
+ * fails here: its ranks gather everything every step (chain.cc:1905-1967).  ptmcmc_amd.parallel.ShardedLadder(recover=True) is the
+ * driver; without a shard map a blind shard still says so loudly (PTM_ERR_FAR_MOVE). */
+int ptm_set_shard_map(ptm_engine* e, int n_shards, const int32_t* rung_counts, int halo_rungs);
+int ptm_exchange_redo_count(ptm_engine* e, int* n_ladders);
+int ptm_exchange_redo(ptm_engine* e, const void* ll_all_dev, const void* lp_all_dev, void* send_up_dev, void* send_down_dev);
 /* ptm_copy_llike's twin for the lpriors */
 int ptm_copy_lprior(ptm_engine* e, int first_local_rung, int n_rungs, void* dst_dev);
 /* exchange phase, part 2 + MH sweep: lands the rows of the neighbours' messages (device buffers of the same size; the

@@ -40,6 +40,15 @@ struct Decide {
   // of the step depends on it) can be replayed exactly on every shard.  null: the halo form.
   const double* ll_all;
   const double* lp_all;       // needed by the posterior-ordering cut only
+  // Recovery of a run of surviving picks longer than a halo (ptm_set_shard_map).  Whether ANY shard of the ladder is blind in a
+  // step is a property of the candidate draws, which every shard replays: with the shards' boundaries known, every shard finds
+  // the same ladders.  Such a ladder is left alone by every shard in the halo pass (flagged, counted) and decided afterwards
+  // from the whole ladder's llikes (redo_only: the gathered form, for the flagged ladders alone).
+  const int* shard_ends;      // [nshards] global rung where each shard ends (the last one = Nt), or null: no recovery
+  int nshards, halo_nominal;  // the halo depth every shard asks for (a shard's own is clipped to the shard above it)
+  int* redo_flag;             // [W]
+  int* redo_count;            // [1]
+  int redo_only;
   double* x;                  // [Nc][DP] rows (only the overflow path moves rows here)
   double* ll;
   double* lp;
@@ -165,6 +174,7 @@ __device__ __forceinline__ void decide_body(const Decide& p, unsigned char* smem
   unsigned short* mid = mid_ - wlo;
   cdp beta = as_c(p.beta);
 
+  if (p.redo_only && !p.redo_flag[w]) return;          // the second pass works for the ladders the halo pass left alone
   for (int i = lane; i < Nt; i += DECIDE_THREADS) first[i] = NONE;
   if (lane == 0) { cnt[0] = 0; cnt[1] = 0; p.arr_below[w] = -1; p.arr_above[w] = -1; }
   __syncthreads();
@@ -201,6 +211,28 @@ __device__ __forceinline__ void decide_body(const Decide& p, unsigned char* smem
   }
   __syncthreads();
 #define PTM_ALIVE_RUNG(r) ((r) >= 0 && (r) <= Nt - 2 && first[(r)] != NONE && alive[first[(r)]])
+  if (p.redo_only) {
+    if (lane == 0) p.redo_flag[w] = 0;
+  } else if (p.shard_ends && !p.ll_all) {
+    // is some shard of this ladder blind this step?  Shard k (ending at rung B) sees the llikes of h = min(halo, size of shard
+    // k + 1) rungs above it; it cannot decide its top pairs iff the picks B - 1 .. B - 1 + h all survive (see the trials below)
+    if (lane == 0) cnt[2] = 0;
+    __syncthreads();
+    for (int k = lane; k + 1 < p.nshards; k += DECIDE_THREADS) {
+      const int B = p.shard_ends[k];
+      const int above = p.shard_ends[k + 1] - B;
+      const int h = p.halo_nominal < above ? p.halo_nominal : above;
+      bool all = true;
+      for (int t = 0; t <= h && all; ++t) all = PTM_ALIVE_RUNG(B - 1 + t);
+      if (all) cnt[2] = 1;
+    }
+    __syncthreads();
+    if (cnt[2]) {                                      // every shard leaves this ladder to the gathered pass
+      if (lane == 0) { p.redo_flag[w] = 1; atomicAdd(p.redo_count, 1); }
+      for (int k = lane; k < ms; k += DECIDE_THREADS) swap_log[(size_t)w * ms + k] = -2;   // (nothing of this ladder is logged by this pass)
+      return;
+    }
+  }
   // -- compaction: the surviving picks whose pair lies inside the window
   for (int k = lane; k < ms; k += DECIDE_THREADS) {
     const int n = cand[k];

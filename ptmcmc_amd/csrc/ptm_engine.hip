@@ -107,6 +107,11 @@ struct ptm_engine {
   bool touched = false;
   bool compact_step = false;   // this step's (partial) sweeps are compacted
   ShardComm* shard = nullptr;   // native RCCL sharding (ptm_shard_*)
+  // recovery of runs longer than a halo (ptm_set_shard_map): the shards' ends, the nominal halo, per-ladder flags | count
+  int* shard_ends = nullptr;
+  int nshards = 0, halo_nominal = 0;
+  int* redo_flag = nullptr;     // [W] flags, then [1] the count
+  long long redo_total = 0;     // ladders decided by the gathered second pass so far
   // persistent ladder kernel (ptm_ladder_kernel.hpp): published rows / llikes / lpriors by step parity, the workgroups' flags
   double *pub_x = nullptr, *pub_ll = nullptr, *pub_lp = nullptr;   // (one allocation: pub_x)
   int *lad_flags = nullptr, *lad_ctl = nullptr;                     // (one allocation: lad_flags)
@@ -417,7 +422,7 @@ extern "C" int ptm_engine_destroy(ptm_engine* e) {
   void* ptrs[] = {e->x, e->ll, e->lp, e->ntries, e->naccept, e->last_type, e->arr_below, e->arr_above, e->mv_src, e->mv_dst, e->mv_n,
                   e->err, e->nhist, e->swap_cnt, e->touch, e->swap_log, e->hist.x, e->hist.ll, e->hist.lp, e->hist.meta, e->map.lpost, e->map.ll, e->map.lp, e->map.x, e->blo,
                   e->bhi, e->ptype, e->bmin, e->bmax, e->plo, e->phi, e->pcoef, e->P2, e->mean, e->beta, e->prop, e->prop_tiles, e->P2_tiles, e->box_row, e->onedfrac, e->mix, e->beta_w, e->betaC, e->beta_add, e->hist.beta, e->xprop, e->lprior_new, e->llike_new, e->hastings, e->htype, e->hvalid, e->acc_out, e->cidx, e->ccnt,
-                  e->pub_x, e->lad_flags, e->lad_prof};
+                  e->pub_x, e->lad_flags, e->lad_prof, e->shard_ends, e->redo_flag};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (hipEvent_t ev : e->kev) (void)hipEventDestroy(ev);
@@ -1148,6 +1153,8 @@ static Decide make_decide(ptm_engine* e, const double* ll_below, const double* l
   Decide p;
   memset(&p, 0, sizeof p);
   p.ll_all = ll_all; p.lp_all = lp_all;
+  p.shard_ends = e->shard_ends; p.nshards = e->nshards; p.halo_nominal = e->halo_nominal;
+  p.redo_flag = e->redo_flag; p.redo_count = e->redo_flag ? e->redo_flag + e->W : nullptr;
   p.DP = e->DP; p.Nt = e->Nt; p.r0 = e->r0; p.nloc = e->nloc; p.W = e->W; p.Nc = e->Nc; p.ms = e->ms; p.w_off = e->cfg.walker_begin;
   p.seed = e->cfg.seed; p.step = e->step; p.thresh = e->thresh;
   p.beta = e->beta; p.ll_below = ll_below; p.ll_above = ll_above; p.H = ll_above ? H : 0; p.x = e->x; p.ll = e->ll; p.lp = e->lp;
@@ -1169,8 +1176,14 @@ static Decide make_decide(ptm_engine* e, const double* ll_below, const double* l
 }
 
 static int launch_decide(ptm_engine* e, const double* ll_below, const double* ll_above, int H, double* send_up, double* send_down,
-                         const double* ll_all = nullptr, const double* lp_all = nullptr) {
-  const Decide p = make_decide(e, ll_below, ll_above, H, send_up, send_down, ll_all, lp_all);
+                         const double* ll_all = nullptr, const double* lp_all = nullptr, bool redo = false) {
+  Decide p = make_decide(e, ll_below, ll_above, H, send_up, send_down, ll_all, lp_all);
+  p.redo_only = redo ? 1 : 0;
+  if (!redo && e->log_pending >= PTM_LOG_RING) { int rc = fold_swap_log(e); if (rc) return rc; }
+  if (redo) {   // the second pass of the SAME step: the log slot, the messages and the move lists are the first pass's
+    const int slot = (e->log_head + PTM_LOG_RING - 1) % PTM_LOG_RING;
+    p.swap_log = e->swap_log + (size_t)slot * e->W * e->ms;
+  }
   const bool beta_direct = p.betaC_direct != nullptr;
   e->touched = true;
   const int WN = ll_all ? e->Nt : e->nloc + (ll_below ? 1 : 0) + p.H;
@@ -1188,16 +1201,18 @@ static int launch_decide(ptm_engine* e, const double* ll_below, const double* ll
     HIPCHK(hipFuncSetAttribute((const void*)decide_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }
   // the boundary messages start empty (the row count lives in their first word)
-  if (send_up) HIPCHK(hipMemsetAsync(send_up, 0, 16, e->stream));
-  if (send_down) HIPCHK(hipMemsetAsync(send_down, 0, 16, e->stream));
+  if (send_up && !redo) HIPCHK(hipMemsetAsync(send_up, 0, 16, e->stream));
+  if (send_down && !redo) HIPCHK(hipMemsetAsync(send_down, 0, 16, e->stream));
   if (cut) {   // (always the wide form)
     if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void*)decide_kernel<256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL((decide_kernel<256, true>), dim3(e->W), dim3(256), lds, e->stream, p);
   } else if (wide) hipLaunchKernelGGL(decide_kernel<256>, dim3(e->W), dim3(256), lds, e->stream, p);
   else hipLaunchKernelGGL(decide_kernel<64>, dim3(e->W), dim3(64), lds, e->stream, p);
   HIPCHK(hipGetLastError());
-  e->log_head = (e->log_head + 1) % PTM_LOG_RING;
-  if (++e->log_pending == PTM_LOG_RING) { int rc = fold_swap_log(e); if (rc) return rc; }
+  if (!redo) {   // (the ring is folded when the NEXT step finds it full: a second pass of this step still finds its slot pending)
+    e->log_head = (e->log_head + 1) % PTM_LOG_RING;
+    ++e->log_pending;
+  }
   if (e->evolve_rate > 0 && !beta_direct) { int rc = launch_beta_transpose(e); if (rc) return rc; }
   if (wide) return PTM_OK;   // the 256-thread decide kernel has applied the moves itself
   // a pick lists at most four row moves (two rungs, each a local move and / or a departure) and one in-between row each for
@@ -1439,6 +1454,7 @@ static int fused_steps(ptm_engine* e, int n) {
   if (dlds > 96 * 1024) return 0;
   int rc = flush_nhist(e);
   if (rc) return rc;
+  if (e->log_pending >= PTM_LOG_RING && (rc = fold_swap_log(e))) return rc;
   int done = 0;
   while (done < n) {
     const int k = std::min(n - done, PTM_LOG_RING - e->log_pending);   // the candidate logs of at most a ring's worth of steps
@@ -1634,6 +1650,56 @@ extern "C" int ptm_exchange_decide_gathered(ptm_engine* e, const void* ll_all, c
   return PTM_OK;
 }
 
+extern "C" int ptm_set_shard_map(ptm_engine* e, int n_shards, const int32_t* rung_counts, int halo_rungs) {
+  NO_BATCH(e, "ptm_set_shard_map");
+  if (!e || !rung_counts || n_shards < 1 || halo_rungs < 1) return fail(PTM_ERR_INVALID, "bad argument");
+  std::vector<int> ends(n_shards);
+  int at = 0, mine = -1;
+  for (int k = 0; k < n_shards; ++k) {
+    if (rung_counts[k] < 1) return fail(PTM_ERR_INVALID, "every shard needs at least one rung");
+    if (at == e->r0 && rung_counts[k] == e->nloc) mine = k;
+    at += rung_counts[k];
+    ends[k] = at;
+  }
+  if (at != e->Nt || mine < 0) return fail(PTM_ERR_INVALID, "the shard map does not describe this engine's block of the ladder");
+  int rc;
+  if (e->shard_ends) { HIPCHK(hipStreamSynchronize(e->stream)); HIPCHK(hipFree(e->shard_ends)); e->shard_ends = nullptr; }
+  if ((rc = dalloc(&e->shard_ends, (size_t)n_shards)) || (rc = upload(e->shard_ends, ends.data(), (size_t)n_shards, e->stream))) return rc;
+  if (!e->redo_flag) {
+    if ((rc = dalloc(&e->redo_flag, (size_t)e->W + 4))) return rc;
+    HIPCHK(hipMemsetAsync(e->redo_flag, 0, ((size_t)e->W + 4) * sizeof(int), e->stream));
+  }
+  e->nshards = n_shards; e->halo_nominal = halo_rungs;
+  return PTM_OK;
+}
+
+extern "C" int ptm_exchange_redo_count(ptm_engine* e, int* n) {
+  if (!e || !n) return fail(PTM_ERR_INVALID, "null argument");
+  *n = 0;
+  if (!e->redo_flag) return PTM_OK;
+  HIPCHK(hipMemcpyAsync(n, e->redo_flag + e->W, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return PTM_OK;
+}
+
+extern "C" int ptm_exchange_redo(ptm_engine* e, const void* ll_all, const void* lp_all, void* send_up, void* send_down) {
+  NO_BATCH(e, "ptm_exchange_redo");
+  int rc = ready(e);
+  if (rc) return rc;
+  if (!e->redo_flag) return fail(PTM_ERR_INVALID, "ptm_set_shard_map first");
+  if (!ll_all) return fail(PTM_ERR_INVALID, "null argument");
+  int n = 0;
+  if ((rc = ptm_exchange_redo_count(e, &n))) return rc;
+  if (n == 0) return PTM_OK;
+  e->redo_total += n;
+  const bool first = e->r0 == 0, last = e->r0 + e->nloc == e->Nt;
+  if ((!last && !send_up) || (!first && !send_down)) return fail(PTM_ERR_INVALID, "missing boundary message buffer");
+  rc = launch_decide(e, nullptr, nullptr, 0, last ? nullptr : (double*)send_up, first ? nullptr : (double*)send_down, (const double*)ll_all, (const double*)lp_all, true);
+  if (rc) return rc;
+  HIPCHK(hipMemsetAsync(e->redo_flag + e->W, 0, sizeof(int), e->stream));
+  return PTM_OK;
+}
+
 extern "C" int ptm_copy_lprior(ptm_engine* e, int first_local_rung, int n_rungs, void* dst_dev) {
   if (!e || !dst_dev) return fail(PTM_ERR_INVALID, "null argument");
   if (first_local_rung < 0 || n_rungs < 1 || first_local_rung + n_rungs > e->nloc) return fail(PTM_ERR_INVALID, "rung range out of the shard");
@@ -1768,6 +1834,11 @@ extern "C" int ptm_shard_init(ptm_engine* e, const void* id, int rank, int world
   s->counts.assign(rung_counts, rung_counts + world);
   for (int r = 0; r < world; ++r) s->maxn = rung_counts[r] > s->maxn ? rung_counts[r] : s->maxn;
   HIPCHK(hipEventCreateWithFlags(&s->ev_gather, hipEventDisableTiming));
+  // a halo shallower than the default depth turns the recovery of longer runs on (PTM_SHARD_RECOVER=0/1 overrides; evolving
+  // ladders gather every step anyway)
+  const char* rv = getenv("PTM_SHARD_RECOVER");
+  s->recover = world > 1 && e->evolve_rate <= 0 && (rv ? atoi(rv) != 0 : s->halo < 12);
+  if (s->recover && (rc = ptm_set_shard_map(e, world, rung_counts, s->halo))) return rc;
   double* zero[] = {s->send_up, s->recv_above, s->send_down, s->recv_below};
   for (double* b : zero) if (b) HIPCHK(hipMemsetAsync(b, 0, s->row_doubles * 8, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
@@ -1805,6 +1876,42 @@ static int shard_stage_and_start_halos(ptm_engine* e) {
   return PTM_OK;
 }
 
+// the whole ladder's llikes and lpriors on every shard: one ncclAllGather of the shards' (padded) slabs, unpacked in rung order
+// into ll_all / lp_all [Nt][W] on the engine's stream
+static int shard_gather_ladder(ptm_engine* e) {
+  ShardComm* s = e->shard;
+  int rc;
+  const size_t W = (size_t)e->W, slab = (size_t)s->maxn * W;
+  if (!s->gsend && ((rc = dalloc(&s->gsend, 2 * slab)) || (rc = dalloc(&s->grecv, (size_t)s->world * 2 * slab)) || (rc = dalloc(&s->ll_all, (size_t)e->Nt * W)) ||
+                    (rc = dalloc(&s->lp_all, (size_t)e->Nt * W))))
+    return rc;
+  if ((rc = ptm_copy_llike(e, 0, e->nloc, s->gsend)) || (rc = ptm_copy_lprior(e, 0, e->nloc, s->gsend + slab))) return rc;
+  HIPCHK(hipEventRecord(s->ev_ready, e->stream));
+  HIPCHK(hipStreamWaitEvent(s->cstream, s->ev_ready, 0));
+  NCCLCHK(rccl().AllGather(s->gsend, s->grecv, 2 * slab, ncclDouble, s->comm, s->cstream));
+  HIPCHK(hipEventRecord(s->ev_gather, s->cstream));
+  HIPCHK(hipStreamWaitEvent(e->stream, s->ev_gather, 0));
+  size_t at = 0;
+  for (int r = 0; r < s->world; ++r) {   // the shards' slabs, unpadded, in rung order
+    const size_t cnt = (size_t)s->counts[r] * W;
+    HIPCHK(hipMemcpyAsync(s->ll_all + at, s->grecv + (size_t)r * 2 * slab, cnt * 8, hipMemcpyDeviceToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(s->lp_all + at, s->grecv + (size_t)r * 2 * slab + slab, cnt * 8, hipMemcpyDeviceToDevice, e->stream));
+    at += cnt;
+  }
+  return PTM_OK;
+}
+
+// Runs of surviving picks longer than the halo (ptm_set_shard_map): every shard left the same ladders alone; if there are any
+// (one wait on the stream per step to know), the ladder is gathered and they are decided from the full view.
+static int shard_recover(ptm_engine* e) {
+  ShardComm* s = e->shard;
+  if (!s->recover) return PTM_OK;
+  int rc, pending = 0;
+  if ((rc = ptm_exchange_redo_count(e, &pending)) || !pending) return rc;
+  if ((rc = shard_gather_ladder(e))) return rc;
+  return ptm_exchange_redo(e, s->ll_all, s->lp_all, s->send_up, s->send_down);
+}
+
 extern "C" int ptm_shard_step(ptm_engine* e, int n) {
   NO_BATCH(e, "ptm_shard_step");
   int rc = ready(e);
@@ -1816,24 +1923,8 @@ extern "C" int ptm_shard_step(ptm_engine* e, int n) {
     // Evolving ladders: every shard replays the whole ladder's trials from the whole ladder's llikes (and lpriors, with a
     // posterior-ordering cut) -- one ncclAllGather per step, the reference's gather_llikes / gather_lposts (chain.cc:1433-1435,
     // 1950-1972) -- then the boundary rows travel between neighbours as ever.  No overlap: the trials need the gathered view.
-    const size_t W = (size_t)e->W, slab = (size_t)s->maxn * W;
-    if (!s->gsend && ((rc = dalloc(&s->gsend, 2 * slab)) || (rc = dalloc(&s->grecv, (size_t)s->world * 2 * slab)) || (rc = dalloc(&s->ll_all, (size_t)e->Nt * W)) ||
-                      (rc = dalloc(&s->lp_all, (size_t)e->Nt * W))))
-      return rc;
     for (int k = 0; k < n; ++k) {
-      if ((rc = ptm_copy_llike(e, 0, e->nloc, s->gsend)) || (rc = ptm_copy_lprior(e, 0, e->nloc, s->gsend + slab))) return rc;
-      HIPCHK(hipEventRecord(s->ev_ready, e->stream));
-      HIPCHK(hipStreamWaitEvent(s->cstream, s->ev_ready, 0));
-      NCCLCHK(rccl().AllGather(s->gsend, s->grecv, 2 * slab, ncclDouble, s->comm, s->cstream));
-      HIPCHK(hipEventRecord(s->ev_gather, s->cstream));
-      HIPCHK(hipStreamWaitEvent(e->stream, s->ev_gather, 0));
-      size_t at = 0;
-      for (int r = 0; r < s->world; ++r) {   // the shards' slabs, unpadded, in rung order
-        const size_t cnt = (size_t)s->counts[r] * W;
-        HIPCHK(hipMemcpyAsync(s->ll_all + at, s->grecv + (size_t)r * 2 * slab, cnt * 8, hipMemcpyDeviceToDevice, e->stream));
-        HIPCHK(hipMemcpyAsync(s->lp_all + at, s->grecv + (size_t)r * 2 * slab + slab, cnt * 8, hipMemcpyDeviceToDevice, e->stream));
-        at += cnt;
-      }
+      if ((rc = shard_gather_ladder(e))) return rc;
       if ((rc = ptm_exchange_decide_gathered(e, s->ll_all, s->lp_all, s->send_up, s->send_down))) return rc;
       if ((rc = shard_exchange(e, s->send_up, s->row_doubles, s->recv_above, s->row_doubles, s->send_down, s->row_doubles, s->recv_below, s->row_doubles, s->ev_rows))) return rc;
       HIPCHK(hipStreamWaitEvent(e->stream, s->ev_rows, 0));
@@ -1850,6 +1941,7 @@ extern "C" int ptm_shard_step(ptm_engine* e, int n) {
     HIPCHK(hipStreamWaitEvent(e->stream, s->ev_halo, 0));
     s->halos_in_flight = false;
     if ((rc = ptm_exchange_decide(e, s->ll_below, s->ll_above, s->h_recv, s->send_up, s->send_down))) return rc;
+    if ((rc = shard_recover(e))) return rc;
     if ((rc = shard_exchange(e, s->send_up, s->row_doubles, s->recv_above, s->row_doubles, s->send_down, s->row_doubles, s->recv_below, s->row_doubles, s->ev_rows))) return rc;
     if (!overlap) {
       HIPCHK(hipStreamWaitEvent(e->stream, s->ev_rows, 0));

@@ -59,6 +59,7 @@ struct ShardComm {
   double *send_up = nullptr, *recv_above = nullptr, *send_down = nullptr, *recv_below = nullptr;   // boundary row messages
   size_t row_doubles = 0;
   bool halos_in_flight = false;
+  bool recover = false;                    // runs longer than the halo are decided by a gathered second pass (ptm_set_shard_map)
   // evolving ladders (ptm_set_evolve_temps on a rung shard): the whole ladder's llikes / lpriors, all-gathered each step --
   // gsend [2][maxn * W] this shard's (padded to the largest shard), grecv [world][2][maxn * W], ll_all / lp_all [Nt][W]
   std::vector<int> counts;

@@ -25,7 +25,7 @@ EXPORTS = [
     "ptm_last_error", "ptm_abi_version", "ptm_device_count", "ptm_engine_create", "ptm_engine_destroy",
     "ptm_set_bounds", "ptm_set_prior", "ptm_set_target_gaussian", "ptm_set_target_callback", "ptm_set_prior_callback", "ptm_set_ladder", "ptm_set_evolve_temps", "ptm_get_invtemps", "ptm_set_invtemps",
     "ptm_set_proposals", "ptm_set_proposal_rung", "ptm_set_proposal_mixture", "ptm_set_proposal_callback", "ptm_set_states", "ptm_init_from_prior", "ptm_init_from_prior_k", "ptm_sweep", "ptm_step", "ptm_sync",
-    "ptm_copy_llike", "ptm_copy_lprior", "ptm_llike_device_ptr", "ptm_exchange_decide", "ptm_exchange_decide_gathered", "ptm_exchange_finish_and_sweep", "ptm_exchange_install", "ptm_sweep_rungs", "ptm_exchange_buffer_doubles", "ptm_exchange_row_capacity", "ptm_shard_unique_id", "ptm_shard_init", "ptm_shard_step", "ptm_shard_finalize", "ptm_get_states", "ptm_batch_begin", "ptm_batch_end",
+    "ptm_copy_llike", "ptm_copy_lprior", "ptm_llike_device_ptr", "ptm_exchange_decide", "ptm_exchange_decide_gathered", "ptm_set_shard_map", "ptm_exchange_redo_count", "ptm_exchange_redo", "ptm_exchange_finish_and_sweep", "ptm_exchange_install", "ptm_sweep_rungs", "ptm_exchange_buffer_doubles", "ptm_exchange_row_capacity", "ptm_shard_unique_id", "ptm_shard_init", "ptm_shard_step", "ptm_shard_finalize", "ptm_get_states", "ptm_batch_begin", "ptm_batch_end",
     "ptm_get_array", "ptm_get_swap_counts", "ptm_get_last_swaps", "ptm_max_swaps_per_step", "ptm_get_history", "ptm_get_history_invtemps", "ptm_set_history", "ptm_set_map", "ptm_get_map", "ptm_restore", "ptm_step_count",
     "ptm_timer_start", "ptm_timer_stop", "ptm_get_kernel_times", "ptm_sweep_kernel_name", "ptm_step_kernel_name", "ptm_debug_eval",
     "ptm_debug_philox", "ptm_debug_boxmuller", "ptm_debug_sqrt_scan", "ptm_debug_evaluate",
@@ -103,6 +103,10 @@ def load():
     if hasattr(L, "ptm_copy_lprior"):
         L.ptm_copy_lprior.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.ptm_exchange_decide_gathered.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    if hasattr(L, "ptm_set_shard_map"):
+        L.ptm_set_shard_map.argtypes = [C.c_void_p, C.c_int, _i32p, C.c_int]
+        L.ptm_exchange_redo_count.argtypes = [C.c_void_p, _i32p]
+        L.ptm_exchange_redo.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.ptm_dev_alloc.argtypes = [C.c_size_t, C.POINTER(C.c_void_p)]
     L.ptm_dev_free.argtypes = [C.c_void_p]
     L.ptm_dev_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
@@ -447,6 +451,19 @@ class Engine:
     def exchange_decide_gathered(self, ll_all_dev, lp_all_dev, send_up_dev, send_down_dev):
         """the exchange phase from the whole ladder's llikes [Nt][W] (and lpriors, with a posterior-ordering cut)"""
         _chk(self.L.ptm_exchange_decide_gathered(self.h, ll_all_dev, lp_all_dev, send_up_dev, send_down_dev))
+
+    def set_shard_map(self, rung_counts, halo):
+        """recovery of runs longer than a halo (ptm_set_shard_map): every shard's rung count, the halo depth all ask for"""
+        rc = np.ascontiguousarray(rung_counts, dtype=np.int32)
+        _chk(self.L.ptm_set_shard_map(self.h, rc.size, rc.ctypes.data_as(_i32p), int(halo)))
+
+    def exchange_redo_count(self):
+        n = C.c_int32()
+        _chk(self.L.ptm_exchange_redo_count(self.h, C.byref(n)))
+        return n.value
+
+    def exchange_redo(self, ll_all_dev, lp_all_dev, send_up_dev, send_down_dev):
+        _chk(self.L.ptm_exchange_redo(self.h, ll_all_dev, lp_all_dev, send_up_dev, send_down_dev))
 
     def exchange_decide(self, ll_below_dev, ll_above_dev, halo_rungs, send_up_dev, send_down_dev):
         _chk(self.L.ptm_exchange_decide(self.h, ll_below_dev, ll_above_dev, halo_rungs, send_up_dev, send_down_dev))

@@ -120,6 +120,16 @@ class EngineShard:
     def dcopy(dst, src):
         dst.copy_(src)
 
+    def set_shard_map(self, sizes, halo):
+        self.e.set_shard_map(sizes, halo)
+
+    def exchange_redo_count(self):
+        return self.e.exchange_redo_count()
+
+    def exchange_redo(self, ll_all, lp_all, send_up, send_down):
+        p = lambda t: None if t is None else t.data_ptr()
+        self.e.exchange_redo(p(ll_all), p(lp_all), p(send_up), p(send_down))
+
     def exchange_decide_gathered(self, ll_all, lp_all, send_up, send_down):
         p = lambda t: None if t is None else t.data_ptr()
         self.e.exchange_decide_gathered(p(ll_all), p(lp_all), p(send_up), p(send_down))
@@ -139,7 +149,13 @@ class ShardedLadder:
     """Drives one shard of a ladder that is spread over `world` ranks.  `backend` supplies the local compute
     (EngineShard on a GPU; the tests plug a CPU stand-in with the same five methods)."""
 
-    def __init__(self, backend, dist, rank, world, halo=DEFAULT_HALO, sizes=None):
+    def __init__(self, backend, dist, rank, world, halo=DEFAULT_HALO, sizes=None, recover=None):
+        """recover: RECOVER from a run of surviving picks longer than the halo instead of failing on it (PTM_ERR_FAR_MOVE).  Every
+        shard replays the step's candidate draws, so -- told the whole shard map -- every shard finds the same ladders that some
+        shard could not decide and leaves them alone; the step then asks for their number (one wait on the device per step: what
+        this costs), and if there are any, every rank gathers the whole ladder's llikes and decides those ladders from the full view
+        (ptm_exchange_redo) before the boundary rows travel.  None: on when the halo is shallower than DEFAULT_HALO (at the default
+        depth a blind shard is a 1e-23 event per boundary, ladder and step)."""
         self.b, self.dist, self.rank, self.world = backend, dist, rank, world
         W = backend.W
         sizes = sizes or [shard_bounds(backend.Nt, world, r)[1] for r in range(world)]
@@ -163,7 +179,13 @@ class ShardedLadder:
         # whole ladder's [Nt][W] views the exchange kernel reads
         self.sizes = list(sizes)
         self.gathered = bool(getattr(backend, "gathered", False))
-        if self.gathered:
+        self.recover = (halo < DEFAULT_HALO) if recover is None else bool(recover)
+        if self.gathered or world == 1 or not hasattr(backend, "set_shard_map"):
+            self.recover = False
+        self.recovered = 0            # ladders decided by the second pass so far
+        if self.recover:
+            backend.set_shard_map(self.sizes, halo)
+        if self.gathered or self.recover:
             self.maxn = max(self.sizes)
             self.g_send = a(2 * self.maxn * W)
             self.g_recv = a(world * 2 * self.maxn * W)
@@ -216,6 +238,24 @@ class ShardedLadder:
 
     def decide(self):
         self.b.exchange_decide(self.ll_below, self.ll_above, self.h_recv, self.send_up, self.send_down)
+
+    # -- recovery (see __init__): the ladders this step's halo pass left alone, on every rank the same
+    def redo_pending(self):
+        return self.b.exchange_redo_count() if self.recover else 0
+
+    def redo(self):
+        self.b.exchange_redo(self.ll_all, self.lp_all, self.send_up, self.send_down)
+
+    def _recover_step(self):
+        n = self.redo_pending()
+        if not n:
+            return
+        self.recovered += n
+        self.stage_gather()          # (the llikes of the ladders left alone are untouched: only their columns matter)
+        self._before_messages()
+        self.dist.all_gather_into_tensor(self.g_recv, self.g_send)
+        self.assemble_gathered()
+        self.redo()
 
     def row_messages(self):
         return [(self.send_up, self.recv_above, self.up), (self.send_down, self.recv_below, self.down)]
@@ -278,6 +318,7 @@ class ShardedLadder:
                 self.stage_halos()
                 self._exchange(self.halo_messages())
                 self.decide()
+                self._recover_step()
                 self._exchange(self.row_messages())
                 self.finish()
 
@@ -298,6 +339,7 @@ class ShardedLadder:
                 self._halo_reqs = self._start(self.halo_messages())
             self._wait(self._halo_reqs)
             self.decide()
+            self._recover_step()
             reqs = self._start(self.row_messages())
             self.b.sweep_rungs(int_a[0], int_a[1], False)     # ... while the boundary messages travel
             self._wait(reqs)
@@ -424,6 +466,8 @@ def bench_main(args):
     stream = torch.cuda.Stream(device=dev)
     by_walkers = getattr(args, "shard", "rungs") == "walkers"
     fallback = ""
+    stalled = False # ... because a message never completed (the record is printed without the CPU leg: nothing that takes time happens
+                    #     between a message that hangs and the exit)
     stuck = False   # the pre-flight did not pass: RCCL is not touched again, the run ends through os._exit
     ctl = None      # host-side group (gloo) for what the ranks must agree on whatever state RCCL is in
     if not by_walkers and world > 1 and not getattr(args, "native_rccl", False):
@@ -442,6 +486,7 @@ def bench_main(args):
             # was issued on) waiting for ever, so the engine gets a fresh stream, the ranks meet over the host-side group, and
             # the processes leave through os._exit once the record is printed.
             stuck = True
+            stalled = int(flag.item()) >= 2
             fallback = "FALLBACK (the pre-flight of the neighbour messages %s on some rank): " % ("never completed" if int(flag.item()) >= 2 else "failed")
             by_walkers = True
             stream = torch.cuda.Stream(device=dev)
@@ -552,7 +597,7 @@ def bench_main(args):
                                     % (world, nloc, args.halo, "ptm_shard_*: native ncclSend/ncclRecv" if getattr(args, "native_rccl", False) else "torch.distributed"))},
             "roofline": roof,
         }
-        if not getattr(args, "no_cpu", False) and not stuck:
+        if not getattr(args, "no_cpu", False) and not stalled:
             # the CPU baseline of the same workload on this box's host cores, rank 0 only, after the timed region (the other ranks
             # wait at the final barrier; bounded: ~10-30 s)
             try:

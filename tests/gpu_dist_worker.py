@@ -48,7 +48,7 @@ if __name__ == "__main__":
     lad.drain()
     eng.sync()
     t, a = eng.swap_counts()
-    np.savez(out % rank, x=eng.states(), ll=eng.llike, nacc=eng.naccept, nhist=eng.nhist, st=t, sa=a, invtemps=eng.invtemps())
+    np.savez(out % rank, x=eng.states(), ll=eng.llike, nacc=eng.naccept, nhist=eng.nhist, st=t, sa=a, invtemps=eng.invtemps(), recovered=lad.recovered)
     dist.barrier()
     eng.close()
     dist.destroy_process_group()

@@ -50,6 +50,52 @@ class OracleShard:
             self.nsize[c] += 1
         self.nhist[c] += 1
 
+    # ---- recovery of runs longer than the halo (ptm_set_shard_map / ptm_exchange_redo_count / ptm_exchange_redo)
+    def set_shard_map(self, sizes, halo):
+        ends = np.cumsum(sizes)
+        self.blind_spans = []             # per inner boundary: the picks that, all surviving, blind the shard below it
+        for k in range(len(sizes) - 1):
+            B, h = int(ends[k]), min(halo, sizes[k + 1])
+            self.blind_spans.append(range(B - 1, B + h))
+        self.redo_ws = []
+
+    def exchange_redo_count(self):
+        return len(self.redo_ws)
+
+    def exchange_redo(self, ll_all, lp_all, send_up, send_down):
+        """the ladders exchange_decide left alone, decided on the whole ladder's llikes"""
+        Nt, W, D = self.Nt, self.W, self.D
+        la = ll_all.numpy().reshape(Nt, W)
+        su = None if send_up is None else send_up.numpy().reshape(D + 2, W)
+        sd = None if send_down is None else send_down.numpy().reshape(D + 2, W)
+        for w, cand, lu in self.redo_ws:
+            own = lambda r, w=w: self.ll[self.idx(w, r)] if self.r0 <= r < self.r0 + self.nloc else la[r, w]
+            self._decide_ladder(w, cand, lu, 0, Nt - 1, own, su, sd)
+        self.redo_ws = []
+        self._apply_moves()
+
+    def _draws(self, w, step):
+        Nt = self.Nt
+        cand, lu = [], []
+        for k in range(self.ms):
+            o = O.draw_block(self.seed, 1, w, step, k)
+            n = -2
+            if Nt > 1 and O.lib().ptmo_u01(o[0]) < self.thresh:
+                n = int(O.lib().ptmo_u01(o[1]) * (Nt - 1))
+                for j in cand:
+                    if j == n or j + 1 == n:
+                        n = -2
+                        break
+            cand.append(n)
+            lu.append(O.lib().ptmo_log(O.lib().ptmo_u01(o[2])))
+        return cand, lu
+
+    def _apply_moves(self):
+        # rows that stay inside the shard move now (the engine's move kernel); arrivals wait for install()
+        for c, x, ll, lp in self.moves:
+            self.x[c] = x; self.ll[c] = ll; self.lp[c] = lp
+        self.moves = []
+
     def exchange_decide(self, ll_below, ll_above, H, send_up, send_down):
         r0, r1, Nt, W, D = self.r0, self.r0 + self.nloc, self.Nt, self.W, self.D
         step = self.lad.step
@@ -62,27 +108,27 @@ class OracleShard:
         self.touched[:] = 0
         self.moves = []        # (dst chain, row) applied in finish
         self.arrive = []       # (dst chain, "above"/"below", w)
-        beta = self.lad.beta
+        self.redo_ws = []
         for w in range(W):
-            cand, lu = [], []
-            for k in range(self.ms):
-                o = O.draw_block(self.seed, 1, w, step, k)
-                n = -2
-                if Nt > 1 and O.lib().ptmo_u01(o[0]) < self.thresh:
-                    n = int(O.lib().ptmo_u01(o[1]) * (Nt - 1))
-                    for j in cand:
-                        if j == n or j + 1 == n:
-                            n = -2
-                            break
-                cand.append(n)
-                lu.append(O.lib().ptmo_log(O.lib().ptmo_u01(o[2])))
+            cand, lu = self._draws(w, step)
+            alive = set(i for i in cand if i >= 0)
+            if any(all(i in alive for i in span) for span in getattr(self, "blind_spans", [])):
+                self.redo_ws.append((w, cand, lu))      # some shard cannot decide this ladder from its halo: all leave it alone
+                continue
 
-            def llike0(r):
+            def llike0(r, w=w):
                 if r < r0:
                     return lb[w]
                 if r >= r1:
                     return la[r - r1, w]
                 return self.ll[self.idx(w, r)]
+            self._decide_ladder(w, cand, lu, wlo, whi, llike0, su, sd)
+        self._apply_moves()
+
+    def _decide_ladder(self, w, cand, lu, wlo, whi, llike0, su, sd):
+        r0, r1, Nt, D = self.r0, self.r0 + self.nloc, self.Nt, self.D
+        beta = self.lad.beta
+        if True:
             cur = {}      # rung -> (llike, source rung) view of the window
             def get(r):
                 if r not in cur:
@@ -137,10 +183,6 @@ class OracleShard:
                             self.moves.append((c, self.x[cs].copy(), self.ll[cs], self.lp[cs]))
                     else:
                         self.arrive.append((c, "above" if s >= r1 else "below", w))
-        # rows that stay inside the shard move now (the engine's move kernel); arrivals wait for install()
-        for c, x, ll, lp in self.moves:
-            self.x[c] = x; self.ll[c] = ll; self.lp[c] = lp
-        self.moves = []
 
     can_overlap = True
 

@@ -7,10 +7,10 @@ class _NoDist:
     pass
 
 
-def build(backends, halo=4):
+def build(backends, halo=4, recover=False):
     world = len(backends)
     sizes = [b.nloc for b in backends]
-    return [ShardedLadder(b, _NoDist(), r, world, halo=halo, sizes=sizes) for r, b in enumerate(backends)]
+    return [ShardedLadder(b, _NoDist(), r, world, halo=halo, sizes=sizes, recover=recover) for r, b in enumerate(backends)]
 
 
 def _deliver(ladders, kind, copy):
@@ -47,6 +47,27 @@ def step_gathered(ladders, copy, n=1):
             lad.b.sync()
 
 
+def _recover(ladders, copy):
+    """the second pass of ShardedLadder._recover_step in lockstep: every shard must have left the SAME ladders alone"""
+    counts = [lad.redo_pending() for lad in ladders]
+    assert len(set(counts)) == 1, counts
+    if not counts[0]:
+        return 0
+    for lad in ladders:
+        lad.recovered += counts[0]
+        lad.stage_gather()
+    for lad in ladders:
+        lad.b.sync()
+    for lad in ladders:
+        slab2 = 2 * lad.maxn * lad.b.W
+        for r, src in enumerate(ladders):
+            copy(lad.b.sub(lad.g_recv, r * slab2, slab2), src.g_send)
+        lad.assemble_gathered()
+    for lad in ladders:
+        lad.redo()
+    return counts[0]
+
+
 def step(ladders, copy, n=1):
     if ladders and ladders[0].gathered:
         return step_gathered(ladders, copy, n)
@@ -58,6 +79,7 @@ def step(ladders, copy, n=1):
         _deliver(ladders, "halo", copy)
         for lad in ladders:
             lad.decide()
+        _recover(ladders, copy)
         for lad in ladders:
             lad.b.sync()
         _deliver(ladders, "rows", copy)
@@ -84,6 +106,7 @@ def step_overlapped(ladders, copy, n=1):
         plans = [lad.sweep_plan() for lad in ladders]
         for lad in ladders:
             lad.decide()
+        _recover(ladders, copy)
         for lad, (bottom, int_a, int_b, top) in zip(ladders, plans):
             lad.b.sweep_rungs(int_a[0], int_a[1], False)
         for lad in ladders:

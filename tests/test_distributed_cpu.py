@@ -51,6 +51,52 @@ def test_sharded_ladder_over_gloo_matches_single_process(world, D, Nt, W, halo, 
     assert ref.swap_accept_count.sum() > 0
 
 
+def _run_ranks(world, args, timeout=300):
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "rank%d.npz")
+        port = free_port()
+        procs = []
+        for r in range(world):
+            env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                       OMP_NUM_THREADS="1")
+            a = [str(v) for v in args]
+            procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "dist_worker.py")] + a[:6] + [out] + a[6:], env=env,
+                                          stderr=subprocess.DEVNULL if "quiet" in os.environ.get("PTM_TEST_WORKER", "") else None))
+        codes = [p.wait(timeout=timeout) for p in procs]
+        parts = [np.load(out % r) for r in range(world)] if not any(codes) else None
+    return codes, parts
+
+
+@pytest.mark.parametrize("world,D,Nt,W,sr", [(2, 4, 12, 3, 0.5), (3, 3, 12, 4, 0.5)])
+def test_a_run_longer_than_the_halo_is_recovered_over_gloo(world, D, Nt, W, sr):
+    """Halo of ONE rung on a 12-rung ladder, many exchange attempts per step: within the first steps some shard meets a run of
+    surviving picks it cannot decide from its halo.  (1) Without recovery the ranks stop loudly -- the run provably comes.  (2) With
+    it (ShardedLadder(recover=True), what a halo below the default depth turns on) every rank finds the same ladders from the
+    replayed draws, leaves them alone, all-gathers the ladder's llikes and decides them from the full view: the sharded run equals
+    the single-process oracle bit for bit, and the second pass was taken."""
+    sys.path.insert(0, HERE)
+    import dist_worker
+    nsteps = 60
+    os.environ["PTM_TEST_WORKER"] = "quiet"
+    try:
+        codes, _ = _run_ranks(world, [D, Nt, W, nsteps, 1, sr, 0.0, -1.0, 0])
+    finally:
+        del os.environ["PTM_TEST_WORKER"]
+    assert any(codes), "the configuration does not meet a run longer than the halo: the test below would prove nothing"
+    codes, parts = _run_ranks(world, [D, Nt, W, nsteps, 1, sr, 0.0, -1.0, 1])
+    assert not any(codes)
+    rec = [int(p["recovered"]) for p in parts]
+    assert rec[0] > 0 and len(set(rec)) == 1
+    ref = dist_worker.make_ladder(D, Nt, W, sr, 0x5EED0001)
+    ref.pt_step(nsteps)
+    assert np.array_equal(np.concatenate([p["x"] for p in parts]), PU.to_engine_order(ref.x, Nt, W))
+    assert np.array_equal(np.concatenate([p["ll"] for p in parts]), PU.to_engine_order(ref.llike, Nt, W))
+    assert np.array_equal(np.concatenate([p["nhist"] for p in parts]), PU.to_engine_order(ref.nhist, Nt, W))
+    assert np.array_equal(np.concatenate([p["nacc"] for p in parts]), PU.to_engine_order(ref.naccept, Nt, W))
+    assert np.array_equal(sum(p["st"] for p in parts), ref.swap_count)
+    assert np.array_equal(sum(p["sa"] for p in parts), ref.swap_accept_count)
+
+
 @pytest.mark.parametrize("world,D,Nt,W,sr,rate,cut", [(2, 4, 10, 3, 0.4, 0.05, -1.0), (3, 3, 13, 2, 0.45, 0.02, 0.0)])
 def test_evolving_sharded_ladder_over_gloo_matches_single_process(world, D, Nt, W, sr, rate, cut):
     """evolve_temps on a rung-sharded ladder over torch.distributed (gloo): ShardedLadder.step_gathered -- an all-gather of every

@@ -829,6 +829,16 @@ class _DevShard:
         p = lambda b: None if b is None else b.ptr
         self.e.exchange_decide_gathered(p(ll_all), p(lp_all), p(su), p(sd))
 
+    def set_shard_map(self, sizes, halo):
+        self.e.set_shard_map(sizes, halo)
+
+    def exchange_redo_count(self):
+        return self.e.exchange_redo_count()
+
+    def exchange_redo(self, ll_all, lp_all, su, sd):
+        p = lambda b: None if b is None else b.ptr
+        self.e.exchange_redo(p(ll_all), p(lp_all), p(su), p(sd))
+
     @staticmethod
     def sub(buf, off, n):
         return buf.slice(off * 8, n * 8)
@@ -927,6 +937,55 @@ def test_evolving_ladders_on_rung_shards_match_the_single_engine(D, Nt, W, G, sr
     t = sum(e.swap_counts()[0] for e in shards); a = sum(e.swap_counts()[1] for e in shards)
     rt, ra = ref.swap_counts()
     assert np.array_equal(t, rt) and np.array_equal(a, ra) and a.sum() > 0
+    for e in shards + [ref]:
+        e.close()
+
+
+@pytest.mark.parametrize("overlap", [False, True])
+@pytest.mark.parametrize("D,Nt,W,G,halo,sr", [(4, 12, 64, 3, 1, 0.5), (32, 16, 64, 2, 1, 0.45), (5, 12, 3, 4, 1, 0.5), (8, 24, 70, 3, 2, 0.45)])
+def test_runs_longer_than_the_halo_are_recovered_not_fatal(D, Nt, W, G, halo, sr, overlap):
+    """With a halo of ONE rung and many exchange attempts per step, shards meet runs of surviving picks they cannot decide every
+    few steps.  Without recovery that is PTM_ERR_FAR_MOVE (loud, fatal: test_sharded_engines_match_single_engine).  With the shard
+    map (ptm_set_shard_map; ShardedLadder(recover=True)) every shard finds the same ladders -- the condition is a property of the
+    replayed candidate draws -- leaves them alone, and they are decided from the gathered llikes by a second pass
+    (ptm_exchange_redo): the sharded ladder walks the single engine's chains bit for bit, and the path was provably taken."""
+    import shard_sim
+    from ptmcmc_amd.parallel import shard_bounds
+    from ptmcmc_amd.problems import GaussianProblem
+    pr = GaussianProblem(D, Nt, 1e3)
+    ref = E.Engine(D, Nt, W, swap_rate=sr)
+    pr.configure(ref, E.PROP_LOWER)
+    ref.init_from_prior()
+    x0 = ref.states()
+    shards = []
+    for g in range(G):
+        r0, n = shard_bounds(Nt, G, g)
+        e = E.Engine(D, Nt, W, swap_rate=sr, rung_begin=r0, rung_count=n)
+        pr.configure(e, E.PROP_LOWER)
+        e.set_states(x0[r0 * W:(r0 + n) * W])
+        shards.append(e)
+    lads = shard_sim.build([_DevShard(e) for e in shards], halo=halo, recover=True)
+    assert all(l.recover for l in lads)
+    copy = lambda dst, src: dst.copy_from(src.ptr, min(dst.nbytes, src.nbytes))
+    for k in range(40):
+        ref.step(1)
+        (shard_sim.step_overlapped if overlap else shard_sim.step)(lads, copy, 1)
+        xs = np.concatenate([e.states() for e in shards])
+        assert np.array_equal(xs, ref.states()), "states differ after step %d" % (k + 1)
+        for e in shards:
+            e.sync()                     # no deferred error: nothing was decided blindly
+    assert lads[0].recovered > 0 and len({l.recovered for l in lads}) == 1   # the path was taken, by all shards alike
+    for name in ("llike", "lprior", "ntries", "naccept", "nhist", "nsize", "last_type"):
+        assert np.array_equal(np.concatenate([getattr(e, name) for e in shards]), getattr(ref, name)), name
+    t = sum(e.swap_counts()[0] for e in shards); a = sum(e.swap_counts()[1] for e in shards)
+    rt, ra = ref.swap_counts()
+    assert np.array_equal(t, rt) and np.array_equal(a, ra)
+    pairs = [e.last_swaps() for e in shards]                # the last step's candidate log: a ladder of the halo pass has every pick
+    rp, racc = ref.last_swaps()                             # logged by its one owner, a recovered ladder by every shard (the counters
+    for pk, ac in pairs:                                    # above take a pick from the shard that owns its lower rung either way)
+        m = pk >= 0
+        assert np.array_equal(pk[m], rp[m]) and np.array_equal(ac[m], racc[m])
+    assert np.array_equal(np.stack([p[0] >= 0 for p in pairs]).any(axis=0), rp >= 0)
     for e in shards + [ref]:
         e.close()
 

@@ -71,13 +71,16 @@ def test_1024_rungs_in_8_engine_shards_on_torch_streams(overlap):
 
 
 @pytest.mark.parametrize("world,D,Nt,W,halo,sr,evolve", [(2, 32, 16, 64, 4, 0.3, 0.0), (3, 32, 48, 128, 8, 0.1, 0.0), (4, 8, 24, 5, 4, 0.45, 0.0),
-                                                         (3, 32, 25, 64, 4, 0.3, 0.01), (2, 6, 11, 3, 4, 0.45, 0.05)])
+                                                         (3, 32, 25, 64, 4, 0.3, 0.01), (2, 6, 11, 3, 4, 0.45, 0.05),
+                                                         (3, 8, 12, 64, 1, 0.5, 0.0)])
 def test_sharded_ladder_between_processes_on_the_gpu(world, D, Nt, W, halo, sr, evolve):
     """The N > 1 path with real engines in separate PROCESSES: every rank an EngineShard on its own torch stream, the sharded
     (overlapped) step of ShardedLadder, its messages between the processes -- over gloo on the one GPU this box has (RCCL refuses
     two ranks on one device; tests/gpu_dist_worker.py says what differs).  The blocks put together are, bit for bit, the ladder
     of one engine: states, llikes, counters, swap bookkeeping -- for fixed ladders (llike halos between neighbours) and evolving
-    ones (an all-gather of the llikes per step, ShardedLadder.step_gathered)."""
+    ones (an all-gather of the llikes per step, ShardedLadder.step_gathered).  The last case has a halo of ONE rung: runs of
+    surviving picks longer than that come every few steps and are recovered (every rank leaves the same ladders alone, gathers
+    the ladder's llikes and decides them from the full view -- ShardedLadder._recover_step)."""
     import socket
     import tempfile
     from ptmcmc_amd.parallel import shard_bounds
@@ -93,6 +96,9 @@ def test_sharded_ladder_between_processes_on_the_gpu(world, D, Nt, W, halo, sr, 
         res = [p.communicate(timeout=600) for p in procs]
         assert all(p.returncode == 0 for p in procs), [r[1][-1500:] for r in res]
         parts = [np.load(out % r) for r in range(world)]
+    if halo == 1:
+        rec = [int(p["recovered"]) for p in parts]
+        assert rec[0] > 0 and len(set(rec)) == 1, rec
     pr = GaussianProblem(D, Nt, 1e6)
     ref = E.Engine(D, Nt, W, swap_rate=sr)
     pr.configure(ref, E.PROP_LOWER)
@@ -155,6 +161,7 @@ def test_bench_with_two_ranks_rehearsed_on_one_gpu(sabotage, expect):
         assert ev["all_reduce_of_ones"] == 2.0 and [r["rank"] for r in ev["ranks"]] == [0, 1]
         assert [r["rungs"] for r in ev["ranks"]] == [[0, 512], [512, 1024]]
     if sabotage != "stall":
+        assert "cpu_baseline" in rec, out.stderr[-3000:]
         assert rec["cpu_baseline"]["value"] > 0 and rec["cpu_baseline"]["kind"] in ("reference", "port")
     rf = rec["roofline"]
     assert 0.5 < rf["moving_fraction"] < 1.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
