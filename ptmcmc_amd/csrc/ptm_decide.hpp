@@ -100,6 +100,22 @@ constexpr int PTM_LOG_RING = 16;   // steps of candidate logs kept before they a
 constexpr int MVCAP = 256;  // rows one ladder can move per step on the register path (move_kernel)
 typedef double d2_t __attribute__((ext_vector_type(2)));  // (HIP's double2 struct does not stay in registers as an array)
 
+// do perm / inv / the move list share the space of an evolving ladder's trial operands (decide_body's carve)?  Host and device agree.
+__host__ __device__ inline bool decide_aliased(int ms, int WN, bool evolve) {
+  return evolve && (size_t)2 * ((WN + 3) & ~3) * 2 + (size_t)2 * MVCAP * 4 <= (size_t)4 * ((ms + 3) & ~3) * 8;
+}
+// atomic minimum of a 16-bit LDS entry (ds_cmpst on the word that holds it; contention: two picks of one rung pair, rare)
+__device__ __forceinline__ void lds_min_u16(unsigned short* a, int idx, unsigned int v) {
+  unsigned int* wd = reinterpret_cast<unsigned int*>(a) + (idx >> 1);
+  const int sh = (idx & 1) * 16;
+  unsigned int old = *wd;
+  while (((old >> sh) & 0xffffu) > v) {
+    const unsigned int prev = atomicCAS(wd, old, (old & ~(0xffffu << sh)) | (v << sh));
+    if (prev == old) break;
+    old = prev;
+  }
+}
+
 // The reference decides the candidates strictly in pick order (chain.cc:1410-1537).  Two facts make that order
 // parallel over the ladder without changing any outcome:
 //   (1) filter: a pick n is dropped iff an earlier SURVIVING pick is n or n-1 (chain.cc:1417-1418).  Only the first
@@ -121,22 +137,28 @@ __device__ __forceinline__ void decide_body(const Decide& p, unsigned char* smem
   //  not write into its copy of the parameter block, which would then live in vector registers)
   const int lane = threadIdx.x;
   const int Nt = p.Nt, ms = p.ms;
-  const int NONE = 0x7fffffff;
+  const int NONE = 0xffff;
   const int r1 = p.r0 + p.nloc;
   // window of rungs whose llike this shard knows: its own, one below, H above
   const int wlo = p.ll_all ? 0 : p.r0 - (p.ll_below ? 1 : 0), whi = p.ll_all ? Nt - 1 : r1 - 1 + p.H;
   const int WN = whi - wlo + 1;
   // LDS carve (mirrored by decide_lds_bytes on the host; all offsets multiples of 8)
   double* llc_ = reinterpret_cast<double*>(smem);                             // [WN]  llike view of the touched rungs
-  int* first = reinterpret_cast<int*>(llc_ + WN);                             // [Nt]  first pick of each rung value
-  int* cand = first + ((Nt + 1) & ~1);                                        // [ms]  rung of the pick / -2 none or dropped
+  unsigned short* first = reinterpret_cast<unsigned short*>(llc_ + WN);       // [Nt]  first pick of each rung value (NONE: not picked)
+  int* cand = reinterpret_cast<int*>(first + ((Nt + 3) & ~3));                // [ms]  rung of the pick / -2 none or dropped
   uint32_t* ua = reinterpret_cast<uint32_t*>(cand + ((ms + 1) & ~1));         // [ms]  accept uniform of the pick (raw)
   int* cnt = reinterpret_cast<int*>(ua + ((ms + 1) & ~1));                    // [4]   list length, move count, ambiguous trial seen, pries
-  unsigned short* perm_ = reinterpret_cast<unsigned short*>(cnt + 4);         // [WN]  source rung of the row now at a rung
-  unsigned short* inv_ = perm_ + ((WN + 3) & ~3);                             // [WN]  inverse of perm
-  unsigned short* list = inv_ + ((WN + 3) & ~3);                              // [ms]  surviving picks that are ours
-  unsigned short* mid_ = list + ((ms + 3) & ~3);                              // [WN]  row a twice-touched rung held in between
-  unsigned char* alive = reinterpret_cast<unsigned char*>(mid_ + ((WN + 3) & ~3));  // [ms] 0 dropped, 1 survives and is
+  // perm [WN] (source rung of the row now at a rung), inv [WN] (its inverse) and the move list [2][MVCAP] are not needed before
+  // the trials of an evolving ladder are over, whose operand arrays (tlu .. tllb below) are dead by then: they share that space
+  // when it is big enough (decide_aliased) -- 6 KB less per block, a fifth block per CU for 1024-rung ladders
+  const bool al = decide_aliased(ms, WN, p.evolve_rate > 0);
+  const int WNp = (WN + 3) & ~3;
+  unsigned short* perm_ = reinterpret_cast<unsigned short*>(cnt + 4);         // [WN]
+  unsigned short* inv_ = perm_ + (al ? 0 : WNp);                              // [WN]
+  unsigned short* list = inv_ + (al ? 0 : WNp);                               // [ms]  surviving picks that are ours
+  unsigned short* midk = list + ((ms + 3) & ~3);                              // [ms]  (by pick) row the pick's lower rung held before a later pick
+                                                                              //       on the pair below exchanged it again
+  unsigned char* alive = reinterpret_cast<unsigned char*>(midk + ((ms + 3) & ~3));  // [ms] 0 dropped, 1 survives and is
                                                                                     //      ours, 2 survives, not ours
   unsigned char* accf = alive + ((ms + 7) & ~7);                              // [ms]
   // The block applies the ladder's row moves itself (below) from a list kept in LDS, up to FCAP rows (16 rounds of one
@@ -146,7 +168,7 @@ __device__ __forceinline__ void decide_body(const Decide& p, unsigned char* smem
   // evolving ladders only: gaps (in the end their local prefix sums), chunk totals / offsets, {normaliser, pries}, and the
   // surviving picks in PICK ORDER (position t): what the chain of dependent trials needs, laid out for one lane to stream
   const int msp = (ms + 3) & ~3;
-  double* gap = reinterpret_cast<double*>(lmv + 2 * MVCAP);                   // [Nt]
+  double* gap = reinterpret_cast<double*>(lmv + (al ? 0 : 2 * MVCAP));        // [Nt]
   double* ct = gap + Nt;                                                      // [2][(Nt + 31) / 32]
   double* ev = ct + 2 * ((Nt + 31) / 32);                                     // [2]
   double* tlu = ev + 2;                                                       // [ms]  log of the pick's accept uniform
@@ -168,14 +190,18 @@ __device__ __forceinline__ void decide_body(const Decide& p, unsigned char* smem
   // lprior of EVERY rung, exchanged as the picks are decided
   double* llv = bklo + msp;                                                   // [Nt]
   double* lpv = llv + Nt;                                                     // [Nt]
+  if (al) {
+    inv_ = reinterpret_cast<unsigned short*>(tlu);
+    perm_ = inv_ + WNp;
+    lmv = reinterpret_cast<int*>(perm_ + WNp);
+  }
   double* llc = llc_ - wlo;                // indexed by global rung
   unsigned short* perm = perm_ - wlo;
   unsigned short* inv = inv_ - wlo;
-  unsigned short* mid = mid_ - wlo;
   cdp beta = as_c(p.beta);
 
   if (p.redo_only && !p.redo_flag[w]) return;          // the second pass works for the ladders the halo pass left alone
-  for (int i = lane; i < Nt; i += DECIDE_THREADS) first[i] = NONE;
+  for (int i = lane; i < ((Nt + 3) & ~3) / 2; i += DECIDE_THREADS) reinterpret_cast<uint32_t*>(first)[i] = 0xffffffffu;
   if (lane == 0) { cnt[0] = 0; cnt[1] = 0; p.arr_below[w] = -1; p.arr_above[w] = -1; }
   __syncthreads();
   // -- candidate draws (chain.cc:1410-1416): block k of the ladder stream gives {u_try, u_pick, u_accept}
@@ -187,7 +213,7 @@ __device__ __forceinline__ void decide_body(const Decide& p, unsigned char* smem
     ua[k] = o.v2;  // the accept uniform's slot is reserved whether or not it is needed (cf. Q5)
     alive[k] = 0;
     accf[k] = 0;
-    if (n >= 0) atomicMin(&first[n], k);
+    if (n >= 0) lds_min_u16(first, n, (unsigned int)k);
   }
   const bool evolve = p.evolve_rate > 0 && Nt > 1;
   const bool evb = evolve && p.beta_add != nullptr;   // history / MAP tracking of evolving ladders
@@ -251,12 +277,10 @@ __device__ __forceinline__ void decide_body(const Decide& p, unsigned char* smem
     const double a = win_llike(p, n, w);
     const double b = top ? win_llike(p, n + 1, w) : 0.0;
     llc[n] = a;
-    perm[n] = (unsigned short)n;
-    inv[n] = (unsigned short)n;
+    if (!al) perm[n] = (unsigned short)n;                      // (sharing the trial operands' space: set up after the trials)
     if (top) {
       llc[n + 1] = b;
-      perm[n + 1] = (unsigned short)(n + 1);
-      inv[n + 1] = (unsigned short)(n + 1);
+      if (!al) perm[n + 1] = (unsigned short)(n + 1);
     }
   }
   __syncthreads();
@@ -498,6 +522,14 @@ __device__ __forceinline__ void decide_body(const Decide& p, unsigned char* smem
       ev[1] = (double)npry;
     }
     __syncthreads();
+    if (al) {   // the trial operands are dead: perm moves in
+      for (int j = lane; j < nl; j += DECIDE_THREADS) {
+        const int n = cand[list[j]];
+        perm[n] = (unsigned short)n;
+        if (!PTM_ALIVE_RUNG(n + 1) || n + 2 > whi) perm[n + 1] = (unsigned short)(n + 1);
+      }
+      __syncthreads();
+    }
   }
   // -- trials (2): the top pick of each run of surviving rungs walks the run downwards (chain.cc:1436-1537); with an
   //    evolving ladder the decisions are the ones just taken
@@ -536,7 +568,7 @@ __device__ __forceinline__ void decide_body(const Decide& p, unsigned char* smem
         accf[kk] = 1;
       }
       if (!PTM_ALIVE_RUNG(i - 1)) break;
-      mid[i] = perm[i];   // the pick below exchanges rung i again: this is what it held in between
+      midk[kk] = perm[i];   // the pick below exchanges rung i again: this is what it held in between
     }
   }
   __syncthreads();
@@ -607,8 +639,7 @@ __device__ __forceinline__ void decide_body(const Decide& p, unsigned char* smem
         const int self_alive = (r == i) ? 1 : 0;
         p.touch[(r - p.r0) * p.W + w] = (unsigned char)(below_alive + self_alive);
       }
-      const int s = perm[r];
-      if (s != r) inv[s] = (unsigned short)r;             // the row that started at s ends at r
+      inv[perm[r]] = (unsigned short)r;                   // the row that started at perm[r] ends at r (perm permutes the touched rungs)
     }
   }
   __syncthreads();
@@ -623,7 +654,7 @@ __device__ __forceinline__ void decide_body(const Decide& p, unsigned char* smem
     if (!(r > 0 && PTM_ALIVE_RUNG(r - 1) && alive[first[r - 1]] == 1)) return -1;   // touched once only
     const int c = (r - p.r0) * p.W + w;
     if (p.nhist[c] % (unsigned int)p.add_every_n != 0u) return -1;
-    const int s1 = mid[r];
+    const int s1 = midk[first[r]];
     if (s1 < p.r0 || s1 >= r1) { atomicOr(p.err, 16); return -1; }   // (the host keeps recorded rungs away from shard tops)
     return (s1 - p.r0) * p.W + w;
   };
@@ -632,7 +663,7 @@ __device__ __forceinline__ void decide_body(const Decide& p, unsigned char* smem
   auto map_mid_src = [&](int r, double bmid) -> int {
     if (r - p.r0 >= p.map.rungs || r < p.r0 || r >= r1) return -1;
     if (!(r > 0 && PTM_ALIVE_RUNG(r - 1) && alive[first[r - 1]] == 1)) return -1;   // touched once only
-    const int s1 = mid[r];
+    const int s1 = midk[first[r]];
     if (s1 < p.r0 || s1 >= r1) { atomicOr(p.err, 16); return -1; }
     const int cs = (s1 - p.r0) * p.W + w;
     const double t = bmid * p.ll[cs];
@@ -860,11 +891,13 @@ __global__ __launch_bounds__(DECIDE_THREADS) void decide_kernel(const Decide p) 
 // dynamic LDS of decide_body (host side)
 inline size_t decide_lds_bytes(int Nt, int ms, int WN, bool evolve, bool evb, bool cut = false) {
   if (cut) return decide_lds_bytes(Nt, ms, WN, evolve, true) + (size_t)2 * Nt * 8;   // (the history carve + every rung's llike, lprior)
-  // mirrors the carve at the top of decide_kernel
-  return (size_t)WN * 8 + (size_t)((Nt + 1) & ~1) * 4 + (size_t)((ms + 1) & ~1) * 4 * 2 + 8 + (size_t)((WN + 3) & ~3) * 2 * 3 +
-         (size_t)((ms + 3) & ~3) * 2 + (size_t)((ms + 7) & ~7) * 2 + (size_t)2 * MVCAP * 4 + 32 +
-         (evolve ? ((size_t)Nt + 2 * ((Nt + 31) / 32) + 2 + 4 * ((ms + 3) & ~3)) * 8 + (size_t)4 * ((ms + 3) & ~3) * 2 + ((ms + 7) & ~7) : 0) +
-         (evb ? ((size_t)(Nt > MVCAP ? Nt : MVCAP) + 3 * ((ms + 3) & ~3)) * 8 : 0);
+  // mirrors the carve at the top of decide_body
+  const bool al = decide_aliased(ms, WN, evolve);
+  const size_t msp = (size_t)((ms + 3) & ~3), WNp = (size_t)((WN + 3) & ~3);
+  return (size_t)WN * 8 + (size_t)((Nt + 3) & ~3) * 2 + (size_t)((ms + 1) & ~1) * 4 * 2 + 16 + (al ? 0 : 2 * WNp * 2) + 2 * msp * 2 +
+         (size_t)((ms + 7) & ~7) * 2 + (al ? 0 : (size_t)2 * MVCAP * 4) + 32 +
+         (evolve ? ((size_t)Nt + 2 * ((Nt + 31) / 32) + 2 + 4 * msp) * 8 + 4 * msp * 2 + ((ms + 7) & ~7) : 0) +
+         (evb ? ((size_t)(Nt > MVCAP ? Nt : MVCAP) + 3 * msp) * 8 : 0);
 }
 
 
