@@ -316,14 +316,14 @@ static int build_engine(ptm_engine* e, const ptm_config* cfg) {
   if ((rc = dalloc(&e->blo, D)) || (rc = dalloc(&e->bhi, D)) || (rc = dalloc(&e->ptype, D)) || (rc = dalloc(&e->bmin, D)) ||
       (rc = dalloc(&e->bmax, D)) || (rc = dalloc(&e->plo, D)) || (rc = dalloc(&e->phi, D)) || (rc = dalloc(&e->pcoef, D)) ||
       (rc = dalloc(&e->P2, D * (D + 1) / 2)) || (rc = dalloc(&e->mean, D)) || (rc = dalloc(&e->beta, (size_t)e->Nt)) ||
-      (rc = dalloc(&e->onedfrac, (size_t)e->nloc)) || (rc = dalloc(&e->P2_tiles, 40 * 64)) || (rc = dalloc(&e->box_row, 128)))
+      (rc = dalloc(&e->onedfrac, (size_t)e->nloc)) || (rc = dalloc(&e->P2_tiles, 144 * 64)) || (rc = dalloc(&e->box_row, 256)))
     return rc;
   {
-    const int bd = e->DP == 64 ? 64 : 32;
-    std::vector<double> box(128);
+    const int bd = e->DP == 128 ? 128 : (e->DP == 64 ? 64 : 32);
+    std::vector<double> box(256);
     for (int d = 0; d < bd; ++d) { box[d] = -INFINITY; box[bd + d] = INFINITY; }
-    if ((rc = upload(e->box_row, box.data(), 128, e->stream))) return rc;
-    HIPCHK(hipMemsetAsync(e->P2_tiles, 0, (40 * 64) * 8, e->stream));
+    if ((rc = upload(e->box_row, box.data(), 256, e->stream))) return rc;
+    HIPCHK(hipMemsetAsync(e->P2_tiles, 0, (144 * 64) * 8, e->stream));
   }
   // defaults (and the permanent content of the pad dimensions): open bounds, flat prior with unbounded support
   std::vector<int> zi(D, 0);
@@ -512,7 +512,7 @@ extern "C" int ptm_set_prior(ptm_engine* e, const int32_t* types, const double* 
   if ((rc = upload(e->ptype, ty.data(), D, e->stream)) || (rc = upload(e->plo, lo.data(), D, e->stream)) ||
       (rc = upload(e->phi, hi.data(), D, e->stream)) || (rc = upload(e->pcoef, coef.data(), D, e->stream)))
     return rc;
-  if (e->DP == 32 || e->DP == 64) {   // the box in row layout, for the MFMA kernels (pad dimensions stay unbounded)
+  if (e->DP == 32 || e->DP == 64 || e->DP == 128) {   // the box in row layout, for the MFMA kernels (pad dimensions stay unbounded)
     const int bd = e->DP;
     std::vector<double> box(2 * bd);
     for (int d = 0; d < bd; ++d) {
@@ -548,17 +548,18 @@ extern "C" int ptm_set_target_gaussian(ptm_engine* e, const double* mean, const 
     }
     if ((rc = upload(e->P2_tiles, tiles.data(), tiles.size(), e->stream))) return rc;
   }
-  if (DP == 64) {
-    // A-operand tiles of ptm_mfma64_kernel.hpp: (row tile rt, step m) with m <= 4 rt + 3 at base(rt) + m, base = 0, 4, 12, 24;
-    // lane 16k + i holds P2[16 rt + i][4 m + k] (lower triangle, off-diagonals doubled; zeros above the diagonal)
-    std::vector<double> tiles(40 * 64, 0.0);
-    const int base[4] = {0, 4, 12, 24};
-    for (int rt = 0; rt < 4; ++rt)
+  if (DP == 64 || DP == 128) {
+    // A-operand tiles of ptm_mfma64_kernel.hpp / ptm_mfma128_kernel.hpp: (row tile rt, step m) with m <= 4 rt + 3 at base(rt) + m,
+    // base(rt) = 2 rt (rt + 1) = 0, 4, 12, 24, ..; lane 16k + i holds P2[16 rt + i][4 m + k] (lower triangle, off-diagonals doubled;
+    // zeros above the diagonal)
+    const int NT = DP / 16;
+    std::vector<double> tiles((size_t)2 * NT * (NT + 1) * 64, 0.0);
+    for (int rt = 0; rt < NT; ++rt)
       for (int m = 0; m <= 4 * rt + 3; ++m)
         for (int k = 0; k < 4; ++k)
           for (int i = 0; i < 16; ++i) {
             const int row = 16 * rt + i, col = 4 * m + k;
-            if (row < D && col <= row) tiles[(size_t)(base[rt] + m) * 64 + 16 * k + i] = packed[(size_t)row * (row + 1) / 2 + col];
+            if (row < D && col <= row) tiles[(size_t)(2 * rt * (rt + 1) + m) * 64 + 16 * k + i] = packed[(size_t)row * (row + 1) / 2 + col];
           }
     if ((rc = upload(e->P2_tiles, tiles.data(), tiles.size(), e->stream))) return rc;
   }
@@ -812,17 +813,19 @@ extern "C" int ptm_set_proposals(ptm_engine* e, int kind, const double* factors,
       }
     if ((rc = dalloc(&e->prop_tiles, tiles.size())) || (rc = upload(e->prop_tiles, tiles.data(), tiles.size(), e->stream))) return rc;
   }
-  if (DP == 64) {
-    // A-operand tiles of ptm_mfma64_kernel.hpp: tile t = (half*4 + slot)*4 + rowtile, lane 16k + i holds T[16 rowtile + i][16 half + 4k + slot]
-    std::vector<double> tiles((size_t)nloc * 64 * 64, 0.0);
+  if (DP == 64 || DP == 128) {
+    // A-operand tiles of ptm_mfma64_kernel.hpp / ptm_mfma128_kernel.hpp: tile t = (half*4 + slot)*NT + rowtile (NT = DP / 16 row
+    // tiles), lane 16k + i holds T[16 rowtile + i][16 half + 4k + slot]
+    const int NT = DP / 16, ntile = NT * NT * 4;
+    std::vector<double> tiles((size_t)nloc * ntile * 64, 0.0);
     for (int r = 0; r < nloc; ++r)
-      for (int t = 0; t < 64; ++t) {
-        const int rt = t & 3, sl = (t >> 2) & 3, hb = t >> 4;
+      for (int t = 0; t < ntile; ++t) {
+        const int rt = t % NT, sl = (t / NT) & 3, hb = t / (4 * NT);
         for (int k = 0; k < 4; ++k)
           for (int i = 0; i < 16; ++i) {
             const int row = 16 * rt + i, col = 16 * hb + 4 * k + sl;
             if (row < D && col < D)
-              tiles[((size_t)r * 64 + t) * 64 + 16 * k + i] =
+              tiles[((size_t)r * ntile + t) * 64 + 16 * k + i] =
                   kind == PTM_PROP_DIAG ? (row == col ? factors[(size_t)r * D + row] : 0.0) : factors[(size_t)r * D * D + (size_t)row * D + col];
           }
       }
@@ -905,10 +908,11 @@ extern "C" int ptm_set_proposal_rung(ptm_engine* e, int local_rung, const double
     }
     if ((rc = upload(e->prop_tiles + (size_t)local_rung * 16 * 64, tiles.data(), tiles.size(), e->stream))) return rc;
   }
-  if (DP == 64) {
-    std::vector<double> tiles(64 * 64, 0.0);
-    for (int t = 0; t < 64; ++t) {
-      const int rt = t & 3, sl = (t >> 2) & 3, hb = t >> 4;
+  if (DP == 64 || DP == 128) {
+    const int NT = DP / 16, ntile = NT * NT * 4;
+    std::vector<double> tiles((size_t)ntile * 64, 0.0);
+    for (int t = 0; t < ntile; ++t) {
+      const int rt = t % NT, sl = (t / NT) & 3, hb = t / (4 * NT);
       for (int k = 0; k < 4; ++k)
         for (int i = 0; i < 16; ++i) {
           const int row = 16 * rt + i, col = 16 * hb + 4 * k + sl;
@@ -916,7 +920,7 @@ extern "C" int ptm_set_proposal_rung(ptm_engine* e, int local_rung, const double
             tiles[(size_t)t * 64 + 16 * k + i] = kind == PTM_PROP_DIAG ? (row == col ? factor[row] : 0.0) : factor[(size_t)row * D + col];
         }
     }
-    if ((rc = upload(e->prop_tiles + (size_t)local_rung * 64 * 64, tiles.data(), tiles.size(), e->stream))) return rc;
+    if ((rc = upload(e->prop_tiles + (size_t)local_rung * ntile * 64, tiles.data(), tiles.size(), e->stream))) return rc;
   }
   if (one_d_frac >= 0) {
     if (one_d_frac > 1) return fail(PTM_ERR_INVALID, "oneDfrac must be in [0,1]");
@@ -1314,9 +1318,9 @@ static int run_eval(ptm_engine* e, int n, double* x, int* valid, double* lp, dou
   return PTM_OK;
 }
 
-// host rows [n][D] -> device row image [n][DP]: padded, and for DP == 32 / 64 with dimension d at position row_pos(d)
+// host rows [n][D] -> device row image [n][DP]: padded, and for DP == 32 / 64 / 128 with dimension d at position row_pos(d)
 // (ptm_kernels.hpp: the MFMA accumulator layout)
-static inline size_t host_row_pos(size_t DP, size_t d) { return (DP == 32 || DP == 64) ? 8 * ((d >> 2) >> 1) + 2 * (d & 3) + ((d >> 2) & 1) : d; }
+static inline size_t host_row_pos(size_t DP, size_t d) { return (DP == 32 || DP == 64 || DP == 128) ? 8 * ((d >> 2) >> 1) + 2 * (d & 3) + ((d >> 2) & 1) : d; }
 static std::vector<double> pad_rows(const double* X, size_t n, size_t D, size_t DP) {
   std::vector<double> r(n * DP, 0.0);
   for (size_t c = 0; c < n; ++c)
@@ -2178,8 +2182,8 @@ extern "C" const char* ptm_sweep_kernel_name(ptm_engine* e) {
              s.simple ? 0 : ((e->all_uniform && (!e->has_bounds || e->bounds_box)) ? 1 : 2),
              (!s.simple && e->all_uniform && (!e->has_bounds || e->bounds_box) && e->betaC) ? ", true" : ", false", cpt ? "true" : "false");   // as rocprofv3 prints it
   }
-  else if (e->DP == 64 && s.simple && !e->hist.rungs && !e->map.rungs && !(fv && *fv && *fv != '0'))
-    snprintf(b, sizeof b, "sweep_mfma64_kernel<%d>", s.kind == KIND_DIAG ? KIND_LOWER : s.kind);
+  else if ((e->DP == 64 || e->DP == 128) && s.uni && s.simple && !s.callback && !s.host_prop && !e->hist.rungs && !e->map.rungs && !(fv && *fv && *fv != '0'))
+    snprintf(b, sizeof b, "sweep_mfma%d_kernel<%d>", e->DP, s.kind == KIND_DIAG ? KIND_LOWER : s.kind);
   else if (e->DP >= 64 || s.host_prop || (!s.uni && !getenv("PTM_FORCE_VALU") && (long long)e->Nc * e->DP <= (e->DP >= 16 ? PTM_LANES_MAX : 4096ll * e->DP)))
     snprintf(b, sizeof b, "sweep_lanes_kernel<%d, %d, %s>", e->DP, s.kind, s.plain ? "false" : "true");
   else snprintf(b, sizeof b, "sweep_kernel<%d, %d, %s, %s>", e->DP, s.kind, s.uni ? "true" : "false", s.simple ? "true" : "false");

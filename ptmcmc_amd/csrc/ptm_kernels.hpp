@@ -6,7 +6,7 @@
 // Data layout in HBM (per engine = per GPU shard), Nc = rung_count * W chains, chain c = rung_local * W + walker:
 //   x      [Nc][DP]  double   one contiguous ROW per chain (DP = dimension padded to 4/8/16/32; pad entries stay 0,
 //                             pad factor rows / precision rows are 0), updated IN PLACE; position of dimension d
-//                             inside the row: row_pos (identity except for DP = 32 and 64)
+//                             inside the row: row_pos (identity except for DP = 32, 64 and 128)
 //   llike, lprior [Nc] double (lpost is always fl(lprior + fl(beta*llike)), chain.cc:928)
 //   ntries, naccept, last_type [Nc] int32; nhist [Nc] uint32          (MH_chain counters, chain.hh:150-170;
 //                             Nsize is a function of Nhist: 1 + ceil(nhist / add_every_N), chain.cc:935-947)
@@ -110,9 +110,9 @@ struct Dev {
   const double* prop;      // [nloc][prop_stride]  factor, dense column-major [col][row] (DP*DP), or sigmas (DP)
   // operand images of the MFMA kernel (DP == 32 only, ptm_mfma_kernel.hpp): 64-lane A tiles, and the box in row layout
   const double* prop_tiles;  // [nloc][16][64]  tile (half*4 + slot)*2 + rowtile, lane 16k+i: T[16 rowtile + i][16 half + 4k + slot]
-                             // (DP == 64: [nloc][64][64], tile (half*4 + slot)*4 + rowtile, ptm_mfma64_kernel.hpp)
+                             // (DP == 64 / 128: [nloc][NT*NT*4][64], NT = DP / 16, tile (half*4 + slot)*NT + rowtile, ptm_mfma64 / 128_kernel.hpp)
   const double* P2_tiles;    // [16][64]        tile step*2 + rowtile, lane 16k+i: P2[16 rowtile + i][4 step + k] (lower, doubled); then [36][16] 4x4 blocks (R,C), [k][i]
-  const double* box_row;     // [2][32]         prior box lo | hi at row_pos  (DP == 64: [2][64])
+  const double* box_row;     // [2][32]         prior box lo | hi at row_pos  (DP == 64 / 128: [2][DP])
   const double* onedfrac;  // [nloc]
   // optional scale mixture (a proposal_distribution_set of Gaussian members that are scalar multiples of the rung's
   // factor, proposal_distribution.cc:99-129, the sampler's default Gaussian recipe ptmcmc.cc:117-139):
@@ -300,7 +300,7 @@ __device__ __forceinline__ void draw4(const DrawCtx& dc, int b, double (&z)[4]) 
   }
 }
 
-// Position of dimension d inside a stored row.  For DP == 32 and DP == 64 rows are kept in the accumulator layout of the f64 MFMA
+// Position of dimension d inside a stored row.  For DP == 32, 64 and 128 rows are kept in the accumulator layout of the f64 MFMA
 // kernel: lane group q of a wave owns the eight dimensions d = q + 4m of a chain and moves them as four 16-byte
 // pieces {m = 2t, 2t+1}; piece t of lane group q sits at 16-byte slot 4t + q, so that ONE load instruction of the
 // chain's four lanes covers 64 contiguous bytes (a quarter of the row) instead of four scattered 16-byte pieces.
@@ -308,7 +308,7 @@ __device__ __forceinline__ void draw4(const DrawCtx& dc, int b, double (&z)[4]) 
 // host converts on set / get.
 template <int DP>
 __device__ __forceinline__ constexpr int row_pos(int d) {
-  return (DP == 32 || DP == 64) ? 8 * ((d >> 2) >> 1) + 2 * (d & 3) + ((d >> 2) & 1) : d;
+  return (DP == 32 || DP == 64 || DP == 128) ? 8 * ((d >> 2) >> 1) + 2 * (d & 3) + ((d >> 2) & 1) : d;
 }
 
 // Column order of the product (shared with the CPU checker and the MFMA kernel, whose tile steps fix it): natural for

@@ -66,7 +66,10 @@ __global__ __launch_bounds__(256, 2) void sweep_mfma64_kernel(const Dev p) {
     const int w0 = c0 - rl * p.W;
     const int rg = p.r0 + rl;
     const int c = c0 + l;                                 // "my" chain for the per-chain work
-    const double* timg = p.prop_tiles + (size_t)rl * (64 * 64) + l;   // tile (hb * 4 + sl) * 4 + rt
+    // tile (hb * 4 + sl) * 4 + rt of the rung's factor: a wave-uniform base (scalar registers) + the lane's 8 bytes -- a tile load is
+    // `global_load v, v_lane, s[base] offset:..`, the 32 KB of tile offsets fold into scalar adds instead of per-lane 64-bit pointers
+    const char* const tbase = reinterpret_cast<const char*>(p.prop_tiles + (size_t)rl * (64 * 64));
+    const unsigned int lb8 = 8u * (unsigned int)l;
 
     // per-chain scalars: used at the very end
     const int tc = p.touch[c];  // > 0: the rung took part in that many exchange attempts => no MH move this step
@@ -80,6 +83,7 @@ __global__ __launch_bounds__(256, 2) void sweep_mfma64_kernel(const Dev p) {
     auto pass = [&](auto gc) {
       constexpr int g = decltype(gc)::value;
       const int qd = opaque_copy(q);
+      const unsigned int lane8 = (unsigned int)opaque_copy((int)lb8);   // (a value of this pass: the passes must not share tile addresses)
       const uint32_t stream = (uint32_t)(w0 + 16 * g + j + p.w_off) * (uint32_t)p.Nt + (uint32_t)rg;
       m64_d2* const rowp = reinterpret_cast<m64_d2*>(p.x + (size_t)(c0 + 16 * g + j) * DP) + q;   // the group's rows: piece t at [4t]
       m64_d2 rowv[8];
@@ -91,7 +95,7 @@ __global__ __launch_bounds__(256, 2) void sweep_mfma64_kernel(const Dev p) {
       double ta[4][4];   // [sl][rt]
       auto ask_tiles = [&](int hb, int sl) {
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt) ta[sl][rt] = (LOW && hb > rt) ? 0.0 : timg[((hb * 4 + sl) * 4 + rt) * 64];
+        for (int rt = 0; rt < 4; ++rt) ta[sl][rt] = (LOW && hb > rt) ? 0.0 : *reinterpret_cast<const double*>(tbase + ((hb * 4 + sl) * 4 + rt) * 512 + lane8);
       };
 #pragma unroll
       for (int sl = 0; sl < 4; ++sl) ask_tiles(0, sl);

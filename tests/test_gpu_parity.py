@@ -182,6 +182,11 @@ SWEEP_CASES = [
     (100, 5, 3, 1e2, E.PROP_LOWER, None),    # 65..128 dimensions: the lanes kernel, two dimensions per lane
     (128, 4, 64, 1e2, E.PROP_DENSE, 0.3),
     (65, 6, 5, 1e2, E.PROP_DIAG, 0.4),
+    (128, 4, 64, 1e2, E.PROP_LOWER, None),   # ... and with whole waves per rung, the plain workload: the 128-dimensional MFMA kernel (8 x 8 tiles)
+    (128, 3, 128, 1e2, E.PROP_DENSE, None),  # dense factor tiles
+    (100, 5, 64, 1e2, E.PROP_LOWER, None),   # 28 pad dimensions
+    (65, 3, 192, 1e2, E.PROP_DIAG, None),    # diagonal sigmas as the diagonal matrix they are
+    (90, 4, 64, 1e2, E.PROP_DENSE, None),
     (129, 4, 3, 1e2, E.PROP_LOWER, None),    # 129..256 dimensions: four dimensions per lane, the precision matrix read from memory
     (200, 3, 5, 1e2, E.PROP_DENSE, 0.3),
     (256, 4, 2, 1e2, E.PROP_DIAG, 0.4),
@@ -239,21 +244,22 @@ def test_pt_steps_bit_exact(D, Nt, W, tmax, kind, odf):
     eng.close()
 
 
-def test_mfma_kernel_with_a_tight_prior_box():
-    """The MFMA kernel's box test (ballots over the four lanes of a chain): a uniform prior so narrow that a large share
+@pytest.mark.parametrize("D", [32, 64, 128])
+def test_mfma_kernel_with_a_tight_prior_box(D):
+    """The MFMA kernels' box test (ballots over the four lanes of a chain): a uniform prior so narrow that a large share
     of the proposals leaves it on some dimension; accept stream, states and counters must still match the oracle."""
-    D, Nt, W = 32, 6, 128
+    Nt, W = (6, 128) if D == 32 else (4, 64)
     rng = np.random.default_rng(12)
     prior = ([1] * D, list(rng.uniform(-0.2, 0.2, D)), list(rng.uniform(0.8, 1.6, D)))   # uniform: centers, halfwidths
     pr, eng, lad = PU.make_pair(D, Nt, W, 1e4, kind=E.PROP_LOWER, prior=prior, swap_rate=0.3)
-    assert "mfma" in eng.sweep_kernel_name
+    assert "mfma%d" % D in eng.sweep_kernel_name
     for k in range(10):
         eng.step(2); eng.sync()
         lad.pt_step(2)
         PU.assert_same_state(eng, lad, "after PT step %d" % (2 * (k + 1)))
     tries = eng.ntries.sum() - eng.Nc
     acc = eng.naccept.sum() - eng.Nc
-    assert 0 < acc < 0.8 * tries          # the box (and the target) reject a good share
+    assert acc < 0.8 * tries and (acc > 0 or D > 32)   # the box (and the target) reject a good share (at 128 dimensions nearly everything)
     eng.close()
 
 

@@ -66,7 +66,8 @@ while time.time() - t0 < budget:
                 PU.assert_same_state(eng, lad, "plain sweeps")
         t, a = eng.swap_counts()
         assert np.array_equal(t, lad.swap_count) and np.array_equal(a, lad.swap_accept_count)
-        kernels[eng.sweep_kernel_name] = kernels.get(eng.sweep_kernel_name, 0) + 1
+        for nm in {eng.sweep_kernel_name, eng.step_kernel_name}:      # (the step of a long ladder of few walkers is ONE kernel)
+            kernels[nm] = kernels.get(nm, 0) + 1
         eng.close()
     except Exception:
         print("FAILED case", case, flush=True)
