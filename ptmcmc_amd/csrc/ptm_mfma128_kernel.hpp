@@ -38,16 +38,17 @@ constexpr int M128_KS = 32;          // k-steps of 4 columns
 constexpr int M128_P2_TILES = 144;   // (row tile rt, step m) with m <= 4 rt + 3: at m128_p2_base(rt) + m
 __host__ __device__ constexpr int m128_p2_base(int rt) { return 2 * rt * (rt + 1); }
 // LDS in doubles: Box-Muller tables | precision tiles | prior box lo | hi (row layout) | 64 reduction slots per wave
-constexpr int m128_lds_doubles() { return BM_TABLE_DOUBLES + M128_P2_TILES * 64 + 256 + 4 * 64; }
+constexpr int M128_THREADS = 512;     // eight waves share the block's tables: two per SIMD at 256 registers each
+constexpr int m128_lds_doubles() { return BM_TABLE_DOUBLES + M128_P2_TILES * 64 + 256 + (M128_THREADS / 64) * 64; }
 
 #define PTM_M128_STAGE() __builtin_amdgcn_sched_barrier(0)
 
 template <int KIND>
-__global__ __launch_bounds__(256, 1) void sweep_mfma128_kernel(const Dev p) {
+__global__ __launch_bounds__(M128_THREADS, 1) void sweep_mfma128_kernel(const Dev p) {
   constexpr int DP = 128;
   constexpr int NT = M128_NT;
   constexpr bool LOW = KIND == KIND_LOWER;
-  constexpr int RING = 4;   // k-step slots of factor tiles in flight
+  constexpr int RING = 3;   // k-step slots of factor tiles in flight
   extern __shared__ __attribute__((aligned(16))) double lds_all[];
   double* ptile = lds_all + BM_TABLE_DOUBLES;
   double* lbox = ptile + M128_P2_TILES * 64;
@@ -57,15 +58,15 @@ __global__ __launch_bounds__(256, 1) void sweep_mfma128_kernel(const Dev p) {
   const double* pimg = ptile + l;
   const m128_d2* box = reinterpret_cast<const m128_d2*>(lbox) + q;   // lo piece t at [4t], hi piece t at [64 + 4t]
 
-  // the block's tables, once: the grid is persistent (a block per CU walks the launch's 256-chain tiles)
-  for (int i = threadIdx.x; i < BM_TABLE_DOUBLES / 2; i += 256) reinterpret_cast<bm_d2*>(lds_all)[i] = reinterpret_cast<const bm_d2*>(BM_TABLE)[i];
-  for (int i = threadIdx.x; i < M128_P2_TILES * 64; i += 256) ptile[i] = p.P2_tiles[i];
-  lbox[threadIdx.x] = p.box_row[threadIdx.x];
+  // the block's tables, once: the grid is persistent (a block per CU walks the launch's 512-chain tiles)
+  for (int i = threadIdx.x; i < BM_TABLE_DOUBLES / 2; i += M128_THREADS) reinterpret_cast<bm_d2*>(lds_all)[i] = reinterpret_cast<const bm_d2*>(BM_TABLE)[i];
+  for (int i = threadIdx.x; i < M128_P2_TILES * 64; i += M128_THREADS) ptile[i] = p.P2_tiles[i];
+  if (threadIdx.x < 256) lbox[threadIdx.x] = p.box_row[threadIdx.x];
   __syncthreads();
 
-  const int ntiles = (p.c_end - p.c_begin + 255) >> 8;
+  const int ntiles = (p.c_end - p.c_begin + M128_THREADS - 1) / M128_THREADS;
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int c0 = p.c_begin + (tile * 4 + wave) * 64;   // first chain of the wave (ranges are multiples of 64)
+    const int c0 = p.c_begin + (tile * (M128_THREADS / 64) + wave) * 64;   // first chain of the wave (ranges are multiples of 64)
     if (c0 >= p.c_end) continue;                          // (only wave-level barriers below)
     const int rl = __builtin_amdgcn_readfirstlane(c0 / p.W);
     const int w0 = c0 - rl * p.W;

@@ -4,6 +4,7 @@ O=$R/gpurun_out/prof_extra; rm -rf $O; mkdir -p $O
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/w1 -- python3 $R/tools/w1_probe.py > $O/w1.out 2> $O/w1.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ev -- python3 $R/tools/kbench.py --walkers 16384 --evolve 0.01 > $O/ev.out 2> $O/ev.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/d64 -- python3 $R/tools/kbench.py --dim 64 --rungs 1024 --walkers 4096 > $O/d64.out 2> $O/d64.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/d128 -- python3 $R/tools/kbench.py --dim 128 --rungs 256 --walkers 4096 > $O/d128.out 2> $O/d128.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/g1 -- python3 $R/tools/kbench.py --walkers 16384 --bounds > $O/g1.out 2> $O/g1.err
 find $O -name "*kernel_stats.csv"   # (gpurun_out/ keeps earlier rounds' runs too: copy the NEWEST file of each directory into profiles/)
 # one rank of the 8-GPU weak-scaling shape (128 of 1024 rungs x 131072 ladders), its launch sequence without the messages
