@@ -352,9 +352,11 @@ def test_history_rows_match_the_oracle(D, Nt, W, kind, N, sr, ev):
     eng.close()
 
 
-def test_history_ring_wraps_and_sharded_cold_chain():
+@pytest.mark.parametrize("halo", [4, 1])
+def test_history_ring_wraps_and_sharded_cold_chain(halo):
     """(1) a ring shorter than the run keeps the newest rows; (2) the cold rung recorded on the first of two shards equals
-    the single-engine history (the shard's top rung cannot be recorded: loud)."""
+    the single-engine history (the shard's top rung cannot be recorded: loud) -- also with a halo of ONE rung, where the ladders
+    some shard cannot decide are left to the gathered second pass (ptm_exchange_redo), saved rows included."""
     import shard_sim
     from ptmcmc_amd.parallel import shard_bounds
     from ptmcmc_amd.problems import GaussianProblem
@@ -376,10 +378,14 @@ def test_history_ring_wraps_and_sharded_cold_chain():
         shards.append(e)
     with pytest.raises(E.PtmError, match="top rung"):
         E.Engine(D, Nt, W, rung_begin=0, rung_count=4, history_rungs=4, history_capacity=8)
-    lads = shard_sim.build([_DevShard(e) for e in shards], halo=4)
-    copy = lambda dst, src: dst.copy_from(src.ptr)
+    lads = shard_sim.build([_DevShard(e) for e in shards], halo=halo, recover=halo < 4)
+    copy = lambda dst, src: dst.copy_from(src.ptr, min(dst.nbytes, src.nbytes))
     ref.step(steps); small.step(steps); shard_sim.step(lads, copy, steps)
     ref.sync(); small.sync()
+    for e in shards:
+        e.sync()
+    assert (lads[0].recovered > 0) == (halo < 4)
+    assert np.array_equal(np.concatenate([e.states() for e in shards]), ref.states())
     hr, hs, h0 = ref.history(), small.history(), shards[0].history()
     ns = ref.nsize
     for name in ("x", "llike", "lprior", "naccept", "ntries", "last_type", "row"):
