@@ -17,6 +17,7 @@ struct SweepSel {
   bool uni;     // W % 64 == 0: wave-uniform rung
   bool plain;   // open bounds, all-uniform prior, zero mean, no 1-D moves, no mixture, fixed ladder, device target
   bool simple;  // uni && plain
+  bool lean_ev; // uni, and plain but for evolving ladders (per-chain temperatures): the lean MFMA build that reads them
   bool callback;  // host-callback likelihood (propose / accept passes): general VALU kernel only
   bool host_prop; // host-side proposals (ptm_set_proposal_callback): the lanes kernel's general build, whatever the population
 };
