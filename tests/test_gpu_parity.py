@@ -1303,9 +1303,9 @@ def test_compacted_sweep_in_sharded_engines(overlap):
 def test_switched_off_variants_stay_bit_exact(env, D, Nt, W, kind, want):
     """The engine's environment switches select code that the default run never reaches: the un-compacted sweep of a big population, the general VALU
     kernel on the MFMA workload, the two-launch step of small and of long ladders, and the persistent ladder kernel with its longest
-    admissible run of surviving picks lowered to 1 / 2 -- every few steps the launch then ends early, the step is taken by the
-    two-launch path and the kernel relaunched (with the halo's 8 that path is a once-in-10^12-steps event).  Each in a process of its own (the switches are read
-    once), each bit for bit the oracle's chains."""
+    admissible run of surviving picks lowered to 1 / 2 -- every few steps the ladder's workgroups then take the exchange phase
+    from the whole ladder's publications (with the halo's 8 that path is a once-in-10^12-steps event).  Each in a process of its
+    own (the switches are read once), each bit for bit the oracle's chains."""
     import os
     import subprocess
     import sys
@@ -1313,6 +1313,28 @@ def test_switched_off_variants_stay_bit_exact(env, D, Nt, W, kind, want):
     r = subprocess.run([sys.executable, os.path.join(here, "variant_worker.py"), str(D), str(Nt), str(W), kind, "4", want],
                        env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and r.stdout.startswith("ok "), r.stdout[-2000:] + r.stderr[-3000:]
+
+
+@pytest.mark.parametrize("D,Nt,W,kind,kernel", [(128, 64, 1024, "lower", "sweep_mfma128_kernel<2>"), (100, 48, 512, "dense", "sweep_mfma128_kernel<0>"),
+                                                (64, 64, 2048, "lower", "sweep_mfma64_kernel<2>"), (32, 128, 2048, "lower", "sweep_mfma32_kernel<2, false, 0, false, true>")])
+def test_matrix_core_kernels_equal_the_vector_kernels_at_sizes_the_checker_cannot_walk(D, Nt, W, kind, kernel):
+    """A size-independent property: at 65536+ chains the MFMA kernels (32 / 64 / 128 dimensions; the 32-dimensional one compacted)
+    and the vector kernels that PTM_FORCE_VALU=1 selects walk the SAME chains -- digest of states, llikes, lpriors, counters and swap
+    bookkeeping after 12 PT steps and two plain sweeps, each engine in a process of its own (the switch is read once).  The vector
+    kernels are the ones the CPU checker pins at small sizes (SWEEP_CASES), so this carries that pin to full size."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    outs = []
+    for env in ({}, {"PTM_FORCE_VALU": "1"}):
+        r = subprocess.run([sys.executable, os.path.join(here, "hash_worker.py"), str(D), str(Nt), str(W), kind, "12"],
+                           env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0 and r.stdout.startswith("ok "), r.stdout[-2000:] + r.stderr[-3000:]
+        outs.append(r.stdout.split())
+    assert kernel in " ".join(outs[0][2:]) and "mfma" not in " ".join(outs[1][2:]), (outs[0], outs[1])
+    assert outs[0][1] == outs[1][1], (outs[0], outs[1])
+    assert int(outs[0][outs[0].index("accepts") + 1]) > 0 and int(outs[0][outs[0].index("swaps") + 1]) > 0
 
 
 @pytest.mark.parametrize("W,cap", [(3, 6), (4096, 4)])
