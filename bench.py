@@ -82,7 +82,8 @@ def measured_traffic(kernel_name):
         except Exception:
             continue
         for k, v in ks.items():
-            if kernel_name.replace(" ", "") in k.replace(" ", ""):
+            # (only summaries of the HBM traffic passes carry these keys: other counter summaries under profiles/ are not for here)
+            if kernel_name.replace(" ", "") in k.replace(" ", "") and isinstance(v, dict) and all(q in v for q in ("hbm_bytes", "hbm_read_bytes", "hbm_write_bytes")):
                 best = {"bytes": v["hbm_bytes"], "read": v["hbm_read_bytes"], "write": v["hbm_write_bytes"], "source": os.path.basename(f)}
     return best
 

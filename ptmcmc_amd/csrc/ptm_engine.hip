@@ -2181,7 +2181,7 @@ extern "C" const char* ptm_sweep_kernel_name(ptm_engine* e) {
     const bool g1 = !s.simple && e->all_uniform && (!e->has_bounds || e->bounds_box);
     const bool cpt = !(cv && *cv == '0') && (s.simple || g1) && !e->hist.rungs && !e->map.rungs && e->W >= 1024 && e->nloc <= 4096;   // (in PT steps; plain sweeps visit every chain)
     snprintf(b, sizeof b, "sweep_mfma32_kernel<%d, %s, %d%s, %s>", s.kind == KIND_DIAG ? KIND_LOWER : s.kind, (e->hist.rungs || e->map.rungs) ? "true" : "false",
-             (s.simple || s.lean_ev) ? 0 : ((e->all_uniform && (!e->has_bounds || e->bounds_box)) ? 1 : 2),
+             (s.simple || s.lean_ev) ? 0 : ((e->all_uniform && (!e->has_bounds || e->bounds_box)) ? ((cpt && !e->has_mean && !e->any_oned && e->mix_K == 0) ? 3 : 1) : 2),
              (!s.simple && e->all_uniform && (!e->has_bounds || e->bounds_box) && e->betaC) ? ", true" : ", false", cpt ? "true" : "false");   // as rocprofv3 prints it
   }
   else if ((e->DP == 64 || e->DP == 128) && s.uni && s.simple && !s.callback && !s.host_prop && !e->hist.rungs && !e->map.rungs && !(fv && *fv && *fv != '0'))

@@ -68,12 +68,14 @@ typedef double mf_d2 __attribute__((ext_vector_type(2)));
 // CPT (lean and GEN 1 builds without history): the sweep visits the moving chains alone, through the per-rung lists of partition_kernel
 // (ptm_kernels.hpp) -- tiles of 256 LISTED walkers of one rung, enumerated rung by rung; lane l of a wave works for the l-th
 // listed walker of its group instead of walker w0 + l.
-template <int KIND, bool HIST, int GEN, bool EV = false, bool CPT = false>   // GEN: 0 lean, 1 box boundaries + uniform prior (+ mean, 1-D moves), 2 everything
-__global__ __launch_bounds__(256, (GEN == 0 ? PTM_MFMA_WAVES : ((PTM_MFMA_GG == 0 && GEN == 2 && KIND == KIND_LOWER) ? 4 : ((GEN == 1 && CPT) ? PTM_MFMA_G1C_WAVES : PTM_MFMA_GEN_WAVES)))) void sweep_mfma32_kernel(const Dev p) {
+template <int KIND, bool HIST, int GEN, bool EV = false, bool CPT = false>   // GEN: 0 lean, 1 box boundaries + uniform prior (+ mean, 1-D moves, mixtures), 2 everything,
+                                                                            //      3 box boundaries + uniform prior and nothing else (GEN 1 without what it only carries)
+__global__ __launch_bounds__(256, (GEN == 0 ? PTM_MFMA_WAVES : ((PTM_MFMA_GG == 0 && GEN == 2 && KIND == KIND_LOWER) ? 4 : (((GEN == 1 || GEN == 3) && CPT) ? PTM_MFMA_G1C_WAVES : PTM_MFMA_GEN_WAVES)))) void sweep_mfma32_kernel(const Dev p) {
   constexpr bool PERSIST = GEN == 0 || PTM_MFMA_GEN_PERSIST != 0 || CPT;   // (a compacted sweep walks its tiles: an idle tile must cost nothing)
-  static_assert(!CPT || (GEN <= 1 && !HIST), "the compacted sweep exists for the lean and the box-bounds builds, without history");
+  static_assert(!CPT || ((GEN <= 1 || GEN == 3) && !HIST), "the compacted sweep exists for the lean and the box-bounds builds, without history");
+  constexpr bool GENX = GEN == 1 || GEN == 2;   // the builds that carry a mean, one-dimensional moves and scale mixtures
   constexpr int DP = 32;
-  constexpr int GG = PTM_MFMA_GG ? PTM_MFMA_GG : (GEN == 2 ? 1 : ((GEN == 1 && CPT) ? PTM_MFMA_G1C_GG : 2)), NP = 4 / GG, PL = 16 * GG;   // groups per pass, passes per tile, chains (= stage-5 lanes) per pass
+  constexpr int GG = PTM_MFMA_GG ? PTM_MFMA_GG : (GEN == 2 ? 1 : (((GEN == 1 || GEN == 3) && CPT) ? PTM_MFMA_G1C_GG : 2)), NP = 4 / GG, PL = 16 * GG;   // groups per pass, passes per tile, chains (= stage-5 lanes) per pass
   constexpr bool LOW = KIND == KIND_LOWER;
   // LDS: [2560] Box-Muller tables | [12][64] precision tiles | [64] prior box (all shared by the block's waves) |
   //      128 doubles per wave
@@ -228,7 +230,7 @@ __global__ __launch_bounds__(256, (GEN == 0 ? PTM_MFMA_WAVES : ((PTM_MFMA_GG == 
   // one-dimensional move of "my" chain (proposal_distribution.hh:196-206): its axis, or -1
   int my_axis = -1, my_kmix = 0;
   double my_scale = 1.0;   // scale mixture: "my" chain's member (proposal_distribution_set::draw, proposal_distribution.cc:99-129)
-  if (GEN) {
+  if (GENX) {
     double f = as_c(p.onedfrac)[rl];
     if (p.mix_K > 0) {
       cdp mx = as_c(p.mix) + (size_t)rl * p.mix_K * 3;
@@ -272,11 +274,11 @@ __global__ __launch_bounds__(256, (GEN == 0 ? PTM_MFMA_WAVES : ((PTM_MFMA_GG == 
       axis[gg] = -1;
       mscale[gg] = 1.0;
     }
-    if (GEN && p.any_oned) {
+    if (GENX && p.any_oned) {
 #pragma unroll
       for (int gg = 0; gg < GG; ++gg) axis[gg] = __builtin_amdgcn_ds_bpermute(4 * (PL * gp + 16 * gg + j), my_axis);
     }
-    if (GEN && p.mix_K > 0) {
+    if (GENX && p.mix_K > 0) {
 #pragma unroll
       for (int gg = 0; gg < GG; ++gg) {
         const long long b = __double_as_longlong(my_scale);
@@ -295,7 +297,7 @@ __global__ __launch_bounds__(256, (GEN == 0 ? PTM_MFMA_WAVES : ((PTM_MFMA_GG == 
         const u32x4 o = draw_block(p.seed, TAG_MH, stream, p.step, (uint32_t)(1 + 4 * hb + qd));
         boxmuller(o.v0, o.v1, (const double*)lds_all, z[gg][0], z[gg][1]);
         boxmuller(o.v2, o.v3, (const double*)lds_all, z[gg][2], z[gg][3]);
-        if (GEN && axis[gg] >= 0) {
+        if (GENX && axis[gg] >= 0) {
 #pragma unroll
           for (int sl = 0; sl < 4; ++sl)
             if (16 * hb + 4 * q + sl != axis[gg]) z[gg][sl] = 0.0;
@@ -331,7 +333,7 @@ __global__ __launch_bounds__(256, (GEN == 0 ? PTM_MFMA_WAVES : ((PTM_MFMA_GG == 
     double xp[GG][8];
     uint64_t inbox = 0;     // bit 16 gg + j: chain (GG gp + gg, j) is inside the box of an all-uniform prior
     uint64_t validb = ~0ull; // GEN: bit 16 gg + j: the chain's state is valid (stateSpace::enforce, states.cc:86-102)
-    const bool boxed = GEN < 2 || p.all_uniform;
+    const bool boxed = GEN != 2 || p.all_uniform;
 #pragma unroll
     for (int gg = 0; gg < GG; ++gg) {
       bool ok = true, vok = true;
@@ -340,7 +342,7 @@ __global__ __launch_bounds__(256, (GEN == 0 ? PTM_MFMA_WAVES : ((PTM_MFMA_GG == 
       for (int t = 0; t < 4; ++t) {
         const mf_d2 v = rowv[gg][t], lo = box[4 * t], hi = box[16 + 4 * t];
         const int m = 2 * t;   // registers m, m+1 <-> dimensions q + 4m, q + 4m + 4
-        if (GEN && p.mix_K > 0) {   // the member is scale_k times the rung's factor
+        if (GENX && p.mix_K > 0) {   // the member is scale_k times the rung's factor
           xp[gg][m] = v.x + mscale[gg] * acc[gg][m >> 2][m & 3];
           xp[gg][m + 1] = v.y + mscale[gg] * acc[gg][(m + 1) >> 2][(m + 1) & 3];
         } else {
@@ -385,7 +387,7 @@ __global__ __launch_bounds__(256, (GEN == 0 ? PTM_MFMA_WAVES : ((PTM_MFMA_GG == 
     // ---- stage 4: S = P2 x Y, Y = X' (- mean), and the four partial dot products of each chain
     if (PTM_MFMA_PRIO == 1) __builtin_amdgcn_s_setprio(2);
     if (PTM_MFMA_PRIO == 2) __builtin_amdgcn_s_setprio(0);
-    auto yv = [&](int gg, int m) -> double { return (GEN && p.has_mean) ? xp[gg][m] - gtab[160 + q + 4 * m] : xp[gg][m]; };
+    auto yv = [&](int gg, int m) -> double { return (GENX && p.has_mean) ? xp[gg][m] - gtab[160 + q + 4 * m] : xp[gg][m]; };
     mf_d4 sacc[GG][2];
 #pragma unroll
     for (int gg = 0; gg < GG; ++gg) {
@@ -459,8 +461,8 @@ __global__ __launch_bounds__(256, (GEN == 0 ? PTM_MFMA_WAVES : ((PTM_MFMA_GG == 
         const double logH = newlpost - cur_lpost;
         accept = valid;
         if (accept && logH < 0) accept = log_u < logH;  // chain.cc:998-1001 (NaN stays accepted)
-        int type = (GEN && my_axis >= 0) ? 1 : 0;
-        if (GEN && p.mix_K > 0) type = my_kmix + 10 * type;   // proposal_distribution.cc:117
+        int type = (GENX && my_axis >= 0) ? 1 : 0;
+        if (GENX && p.mix_K > 0) type = my_kmix + 10 * type;   // proposal_distribution.cc:117
         p.ntries[c] = ntries0 + 1;
         if (!CPT) p.nhist[c] = nhist0 + 1u;   // (compacted: the engine counts the step for everybody, ptm_aux_kernels.hpp)
         if (hist_on && nhist0 % (unsigned int)p.add_every_n == 0u) {

@@ -54,3 +54,23 @@ def test_config_validation_happens_before_device_use():
     h = C.c_void_p()
     assert E.load().ptm_engine_create(C.byref(cfg), C.byref(h)) == -1
     assert b"size mismatch" in E.load().ptm_last_error()
+
+
+def test_bench_record_helpers_accept_every_committed_profile():
+    """bench.py reads the HBM traffic of its kernel from the committed counter summaries (profiles/*_pmc_summary.json): any other JSON
+    that lands under profiles/ must not break the record (a summary of a different counter set once did), and the roofline arithmetic
+    of the record must hold together."""
+    import glob
+    import json
+    import sys
+    root = ROOT
+    sys.path.insert(0, root)
+    import bench
+    for f in glob.glob(os.path.join(root, "profiles", "*.json")):
+        json.load(open(f))                                   # every committed JSON parses
+    t = bench.measured_traffic("sweep_mfma32_kernel<2, false, 0, false, true>")
+    assert t is None or (t["bytes"] > 0 and t["read"] > 0 and t["write"] > 0)
+    assert bench.measured_traffic("no_such_kernel") is None
+    r = bench.roofline_record("k", 1.5, 20, 13_800_000, 16_777_216, 9.0e9, 1, t)
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0.5 < r["frac"] < 0.8
+    assert abs(r["step_frac"] - 9.0e9 * r["bytes_per_mh_step"] / (r["peak"] * 1e9)) < 1e-12
