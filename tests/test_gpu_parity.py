@@ -1227,7 +1227,8 @@ def test_compacted_sweep_of_big_populations_matches_the_oracle(kind):
     eng.close(); e2.close()
 
 
-@pytest.mark.parametrize("kind,odf,with_mean,ev", [(E.PROP_LOWER, 0.0, False, 0.0), (E.PROP_DENSE, 0.4, True, 0.0), (E.PROP_LOWER, 0.3, False, 0.02)])
+@pytest.mark.parametrize("kind,odf,with_mean,ev", [(E.PROP_LOWER, 0.0, False, 0.0), (E.PROP_DENSE, 0.4, True, 0.0), (E.PROP_LOWER, 0.3, False, 0.02),
+                                                   (E.PROP_DENSE, 0.0, False, 0.02)])
 def test_compacted_sweep_of_the_box_bounds_build_matches_the_oracle(kind, odf, with_mean, ev):
     """The usual real-world state space (uniform priors, `limit` / open boundaries, a mean, one-dimensional moves, an evolving
     ladder) on a big population without history: its MFMA build walks the moving chains only, like the lean one.  Narrow
@@ -1244,7 +1245,8 @@ def test_compacted_sweep_of_the_box_bounds_build_matches_the_oracle(kind, odf, w
                                 one_d_frac=(odf if odf > 0 else None))
     if ev:
         eng.set_evolve_temps(ev); lad.evolve_temps(ev)
-    assert eng.sweep_kernel_name.endswith(", 1, %s, true>" % ("true" if ev else "false"))
+    # bounds and nothing else: the build that carries no mean / one-dimensional moves / mixtures (GEN 3); else the box-bounds build
+    assert eng.sweep_kernel_name.endswith(", %d, %s, true>" % (1 if (odf > 0 or with_mean) else 3, "true" if ev else "false"))
     for k in range(3):
         eng.step(3); eng.sync(); lad.pt_step(3)
         PU.assert_same_state(eng, lad, "after %d compacted steps" % (3 * (k + 1)))
