@@ -20,7 +20,8 @@
 // half s + 4 k with s outer, k inner = the MFMA's own k order; the precision rows j ascending), structural zeros of a Cholesky
 // factor / above the precision's diagonal are skipped or stored as zeros (fma(0, z, acc) == acc): chains are bit-identical to the
 // lanes kernel's and the checker's.
-// Lean build only: open bounds, uniform box prior, zero mean, no one-dimensional moves, no mixture, fixed ladder, no history
+// Builds: uniform box prior, zero mean, no one-dimensional moves, no mixture, no history; open bounds or (BND) open / `limit`
+// bounds; a fixed ladder or (EV) per-chain temperatures of evolving ladders
 // (everything else at 33..64 dimensions keeps the lanes kernel).
 #pragma once
 #include <type_traits>
@@ -35,11 +36,11 @@ typedef double m64_d2 __attribute__((ext_vector_type(2)));
 constexpr int M64_P2_TILES = 40;   // (row tile rt, step m) with m <= 4 rt + 3: at m64_p2_base(rt) + m
 __host__ __device__ constexpr int m64_p2_base(int rt) { return rt == 0 ? 0 : (rt == 1 ? 4 : (rt == 2 ? 12 : 24)); }
 // LDS in doubles: Box-Muller tables | precision tiles | prior box lo | hi (row layout) | 64 reduction slots per wave
-constexpr int m64_lds_doubles() { return BM_TABLE_DOUBLES + M64_P2_TILES * 64 + 128 + 4 * 64; }
+constexpr int m64_lds_doubles() { return BM_TABLE_DOUBLES + M64_P2_TILES * 64 + 128 + 4 * 64 + 128; }   // (... | boundary box lo | hi)
 
 #define PTM_M64_STAGE() __builtin_amdgcn_sched_barrier(0)
 
-template <int KIND>
+template <int KIND, bool BND = false, bool EV = false>   // BND: open / `limit` boundaries on top of the prior's box; EV: per-chain temperatures (evolving ladders)
 __global__ __launch_bounds__(256, 2) void sweep_mfma64_kernel(const Dev p) {
   constexpr int DP = 64;
   constexpr bool LOW = KIND == KIND_LOWER;
@@ -48,14 +49,21 @@ __global__ __launch_bounds__(256, 2) void sweep_mfma64_kernel(const Dev p) {
   double* lbox = ptile + M64_P2_TILES * 64;
   const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
   double* red = lbox + 128 + wave * 64;
+  double* lebox = lbox + 128 + 4 * 64;   // [2][64] boundary::enforce for open / limit sides (states.cc:53-55) as a box, row layout
   const int q = l >> 4, j = l & 15;
   const double* pimg = ptile + l;
   const m64_d2* box = reinterpret_cast<const m64_d2*>(lbox) + q;   // lo piece t at [4t], hi piece t at [32 + 4t]
+  const m64_d2* ebx = reinterpret_cast<const m64_d2*>(lebox) + q;
 
   // the block's tables, once: the grid is persistent (a block per resident slot walks the launch's 256-chain tiles)
   for (int i = threadIdx.x; i < BM_TABLE_DOUBLES / 2; i += 256) reinterpret_cast<bm_d2*>(lds_all)[i] = reinterpret_cast<const bm_d2*>(BM_TABLE)[i];
   for (int i = threadIdx.x; i < M64_P2_TILES * 64; i += 256) ptile[i] = p.P2_tiles[i];
   if (threadIdx.x < 128) lbox[threadIdx.x] = p.box_row[threadIdx.x];
+  if (BND && threadIdx.x < 64) {
+    const int d = threadIdx.x, pos = row_pos<64>(d);
+    lebox[pos] = p.blo[d] == B_LIMIT ? p.bmin[d] : -__builtin_inf();
+    lebox[64 + pos] = p.bhi[d] == B_LIMIT ? p.bmax[d] : __builtin_inf();
+  }
   __syncthreads();
 
   const int ntiles = (p.c_end - p.c_begin + 255) >> 8;
@@ -76,7 +84,7 @@ __global__ __launch_bounds__(256, 2) void sweep_mfma64_kernel(const Dev p) {
     const double ll = p.ll[c], lp = p.lp[c];
     const int ntries0 = p.ntries[c], naccept0 = p.naccept[c];
     const unsigned int nhist0 = p.nhist[c];
-    const double beta = as_c(p.beta)[rg];
+    const double beta = EV ? p.betaC[c] : as_c(p.beta)[rg];
     const u32x4 o0 = draw_block(p.seed, TAG_MH, (uint32_t)(w0 + l + p.w_off) * (uint32_t)p.Nt + (uint32_t)rg, p.step, 0);
     const double log_u = dlog_u01(o0.v0);
 
@@ -127,7 +135,7 @@ __global__ __launch_bounds__(256, 2) void sweep_mfma64_kernel(const Dev p) {
       }
       // ---- x' = x + offset (state::add, states.cc:205-214) and the box of the uniform prior
       double xp[16];
-      bool ok = true;
+      bool ok = true, vok = true;
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
         const m64_d2 v = rowv[t], lo = box[4 * t], hi = box[32 + 4 * t];
@@ -135,10 +143,20 @@ __global__ __launch_bounds__(256, 2) void sweep_mfma64_kernel(const Dev p) {
         xp[m] = v.x + acc[m >> 2][m & 3];
         xp[m + 1] = v.y + acc[(m + 1) >> 2][(m + 1) & 3];
         ok = ok & !(xp[m] < lo.x) & !(xp[m] > hi.x) & !(xp[m + 1] < lo.y) & !(xp[m + 1] > hi.y);
+        if (BND) {
+          const m64_d2 el = ebx[4 * t], eh = ebx[32 + 4 * t];
+          vok = vok & !(xp[m] < el.x) & !(xp[m] > eh.x) & !(xp[m + 1] < el.y) & !(xp[m + 1] > eh.y);
+        }
       }
       uint64_t inb = __builtin_amdgcn_ballot_w64(ok);
       inb &= inb >> 32;
       inb &= inb >> 16;                                  // bit jj: all four lanes (q, jj) of chain (g, jj) are inside
+      uint64_t vb = ~0ull;                                // BND: bit jj: the chain's state is valid (stateSpace::enforce, states.cc:86-102)
+      if (BND) {
+        vb = __builtin_amdgcn_ballot_w64(vok);
+        vb &= vb >> 32;
+        vb &= vb >> 16;
+      }
       PTM_M64_STAGE();
       // ---- S = P2 x X' (the accumulator layout of x' is the B operand's) and the lane's part of x'.S
       m64_d4 sacc[4];
@@ -182,14 +200,17 @@ __global__ __launch_bounds__(256, 2) void sweep_mfma64_kernel(const Dev p) {
           const double cur_lpost = lp + bl;
           const double oldlprior = cur_lpost - bl;  // chain.cc:973
           const bool in = ((inb >> j) & 1ull) != 0;
-          const double newlprior = in ? p.lprior_const : -__builtin_inf();
-          const bool want_like = newlprior > -1e200 || newlprior - oldlprior > p.min_prior;  // chain.cc:980 (Q1)
+          // Q9: state::add builds on an enforced zero state -- an origin outside a `limit` bound invalidates every proposal
+          const bool valid = !BND || (p.origin_valid != 0 && ((vb >> j) & 1ull) != 0);
+          double newlprior = in ? p.lprior_const : -__builtin_inf();
+          if (!valid) newlprior = -__builtin_inf();
+          const bool want_like = valid && (newlprior > -1e200 || newlprior - oldlprior > p.min_prior);  // chain.cc:980 (Q1)
           double newlike = p.like0 - 0.5 * quad;
           double newlpost = newlike * beta + newlprior;
           if (!want_like) newlike = newlpost = -__builtin_inf();
           const double logH = newlpost - cur_lpost;
-          accept = true;
-          if (logH < 0) accept = log_u < logH;  // chain.cc:998-1001 (NaN stays accepted)
+          accept = valid;
+          if (accept && logH < 0) accept = log_u < logH;  // chain.cc:998-1001 (NaN stays accepted)
           p.ntries[c] = ntries0 + 1;
           p.nhist[c] = nhist0 + 1u;
           if (accept) {

@@ -263,6 +263,40 @@ def test_mfma_kernel_with_a_tight_prior_box(D):
     eng.close()
 
 
+@pytest.mark.parametrize("D,Nt,W,kind,bounds,ev", [(64, 5, 64, E.PROP_LOWER, True, 0.0), (50, 6, 128, E.PROP_DENSE, False, 0.03), (40, 5, 64, E.PROP_DIAG, True, 0.02),
+                                                   (128, 4, 64, E.PROP_LOWER, True, 0.0), (100, 5, 64, E.PROP_DENSE, False, 0.03), (70, 4, 128, E.PROP_LOWER, True, 0.02)])
+def test_high_dimension_mfma_kernels_with_bounds_and_evolving_ladders(D, Nt, W, kind, bounds, ev):
+    """The 64- and 128-dimension MFMA kernels' other builds: open / `limit` boundaries on top of the prior's box (narrow limits, so
+    that a good share of the proposals is invalid) and the per-chain temperatures of evolving ladders -- the sampler's default --
+    bit for bit the oracle's chains, counters and temperatures."""
+    rng = np.random.default_rng(77)
+    bnd = prior = x0 = None
+    if bounds:
+        blo = [1 if d % 3 else 0 for d in range(D)]
+        bhi = [1 if d % 2 else 0 for d in range(D)]
+        bnd = (blo, bhi, list(rng.uniform(-2.5, -1.5, D)), list(rng.uniform(1.5, 2.5, D)))
+        prior = ([1] * D, [0.0] * D, list(rng.uniform(3.0, 6.0, D)))
+        x0 = rng.uniform(-1.2, 1.2, size=(Nt * W, D))
+    pr, eng, lad = PU.make_pair(D, Nt, W, 1e2, kind=kind, bounds=bnd, prior=prior, swap_rate=0.3, x0=x0)
+    if ev:
+        eng.set_evolve_temps(ev); lad.evolve_temps(ev)
+    assert eng.sweep_kernel_name.startswith("sweep_mfma%d_kernel<" % (64 if D <= 64 else 128))
+    assert eng.sweep_kernel_name.endswith("%s, %s>" % ("true" if bounds else "false", "true" if ev else "false")), eng.sweep_kernel_name
+    for k in range(4):
+        eng.step(3); eng.sync(); lad.pt_step(3)
+        PU.assert_same_state(eng, lad, "after %d PT steps" % (3 * (k + 1)))
+        if ev:
+            assert np.array_equal(eng.invtemps(), lad.betaw)
+        if k == 1:
+            eng.sweep(2); eng.sync(); lad.sweep(2)
+            PU.assert_same_state(eng, lad, "after plain sweeps")
+    tries, acc = eng.ntries.sum() - eng.Nc, eng.naccept.sum() - eng.Nc
+    assert acc < 0.9 * tries
+    t, a = eng.swap_counts()
+    assert np.array_equal(t, lad.swap_count) and np.array_equal(a, lad.swap_accept_count)
+    eng.close()
+
+
 def test_add_every_n_history_counters():
     pr, eng, lad = PU.make_pair(4, 9, 64, 1e2, swap_rate=0.4, add_every_n=3)
     eng.step(40); eng.sync(); lad.pt_step(40)
@@ -1317,8 +1351,8 @@ def test_switched_off_variants_stay_bit_exact(env, D, Nt, W, kind, want):
     assert r.returncode == 0 and r.stdout.startswith("ok "), r.stdout[-2000:] + r.stderr[-3000:]
 
 
-@pytest.mark.parametrize("D,Nt,W,kind,kernel", [(128, 64, 1024, "lower", "sweep_mfma128_kernel<2>"), (100, 48, 512, "dense", "sweep_mfma128_kernel<0>"),
-                                                (64, 64, 2048, "lower", "sweep_mfma64_kernel<2>"), (32, 128, 2048, "lower", "sweep_mfma32_kernel<2, false, 0, false, true>")])
+@pytest.mark.parametrize("D,Nt,W,kind,kernel", [(128, 64, 1024, "lower", "sweep_mfma128_kernel<2, false, false>"), (100, 48, 512, "dense", "sweep_mfma128_kernel<0, false, false>"),
+                                                (64, 64, 2048, "lower", "sweep_mfma64_kernel<2, false, false>"), (32, 128, 2048, "lower", "sweep_mfma32_kernel<2, false, 0, false, true>")])
 def test_matrix_core_kernels_equal_the_vector_kernels_at_sizes_the_checker_cannot_walk(D, Nt, W, kind, kernel):
     """A size-independent property: at 65536+ chains the MFMA kernels (32 / 64 / 128 dimensions; the 32-dimensional one compacted)
     and the vector kernels that PTM_FORCE_VALU=1 selects walk the SAME chains -- digest of states, llikes, lpriors, counters and swap
