@@ -1495,8 +1495,9 @@ static bool ladder_applies(ptm_engine* e, long long* grid_out = nullptr, size_t*
       e->map.rungs || e->shard)
     return false;
   const SweepSel sel = sweep_sel(e);
-  // the plain workload; populations with whole waves per rung keep the throughput kernels
-  if (!sel.plain || sel.uni) return false;
+  // the plain workload, with open / `limit` boundaries if any; populations with whole waves per rung keep the throughput kernels
+  const bool plain_but_bounds = e->has_bounds && e->bounds_box && e->all_uniform && !e->has_mean && !e->any_oned && !e->cb && e->mix_K == 0 && !e->betaC && !e->pcb;
+  if (!(sel.plain || plain_but_bounds) || sel.uni) return false;
   const int R = 256 / e->DP, NB = (e->Nt + R - 1) / R;
   const long long grid = (long long)e->W * NB;
   const bool diag = e->prop_kind == PTM_PROP_DIAG;

@@ -29,7 +29,7 @@
 //
 // Arithmetic: the operation sequences of lanes_body / decide_body, number for number -- the chains are bit-identical to the
 // two-launch path and to the CPU checker (the parity suite runs through this kernel wherever it applies).
-// Scope: the plain workload (open bounds, all-uniform prior, zero mean, no one-dimensional moves, no mixture, fixed ladder,
+// Scope: the plain workload (open or `limit` bounds, all-uniform prior, zero mean, no one-dimensional moves, no mixture, fixed ladder,
 // device target), no history / MAP tracking, DP = 16 or 32.
 #pragma once
 #include "ptm_decide.hpp"
@@ -111,6 +111,9 @@ __global__ __launch_bounds__(256) void ladder_persistent_kernel(const Dev p, con
   unsigned int nhist = p.nhist[c];
   const double beta = p.beta[rg];
   const double plo = p.plo[d], phi = p.phi[d];
+  // open / `limit` boundaries (boundary::enforce, states.cc:53-55) as a second box: without bounds it holds everything
+  const double elo = (p.has_bounds && p.blo[d] == B_LIMIT) ? p.bmin[d] : -__builtin_inf();
+  const double ehi = (p.has_bounds && p.bhi[d] == B_LIMIT) ? p.bmax[d] : __builtin_inf();
   const uint32_t stream = (uint32_t)(w + p.w_off) * (uint32_t)Nt + (uint32_t)rg;
   // row d of the rung's factor (column-major [col][row]); the sigma of a diagonal proposal
   double tcol[KIND == KIND_DIAG ? 1 : DP];
@@ -292,8 +295,11 @@ __global__ __launch_bounds__(256) void ladder_persistent_kernel(const Dev p, con
       const double oldlprior = cur_lpost - bl;                    // chain.cc:973
       const bool ind = !(xn < plo) && !(xn > phi);
       const bool in = all_of_chain(ind);
-      const double newlprior = in ? p.lprior_const : -__builtin_inf();
-      const bool want_like = newlprior > -1e200 || newlprior - oldlprior > p.min_prior;   // chain.cc:980 (Q1)
+      // Q9: state::add builds on an enforced zero state -- an origin outside a `limit` bound invalidates every proposal
+      const bool valid = p.origin_valid != 0 && all_of_chain(!(xn < elo) && !(xn > ehi));   // stateSpace::enforce, states.cc:86-102
+      double newlprior = in ? p.lprior_const : -__builtin_inf();
+      if (!valid) newlprior = -__builtin_inf();
+      const bool want_like = valid && (newlprior > -1e200 || newlprior - oldlprior > p.min_prior);   // chain.cc:980 (Q1)
       vbuf[g * DP + d] = xn;
       sync_wave();
       {
@@ -321,8 +327,8 @@ __global__ __launch_bounds__(256) void ladder_persistent_kernel(const Dev p, con
       double newlpost = newlike * beta + newlprior;
       if (!want_like) newlike = newlpost = -__builtin_inf();
       const double logH = newlpost - cur_lpost;
-      bool accept = true;
-      if (logH < 0) accept = dlog_u01(o0.v0) < logH;              // chain.cc:998-1001 (NaN stays accepted)
+      bool accept = valid;
+      if (accept && logH < 0) accept = dlog_u01(o0.v0) < logH;    // chain.cc:998-1001 (NaN stays accepted)
       if (!tc) {
         ntries += 1;
         nhist += 1u;

@@ -1420,6 +1420,29 @@ LADDER_CASES = [
 ]
 
 
+@pytest.mark.parametrize("D,Nt,W,kind", [(32, 200, 1, E.PROP_LOWER), (12, 90, 3, E.PROP_DIAG), (24, 40, 2, E.PROP_DENSE)])
+def test_persistent_ladder_kernel_with_limit_bounds(D, Nt, W, kind):
+    """The persistent ladder kernel with open / `limit` boundaries (a second box test per lane: boundary::enforce for those sides,
+    states.cc:53-55): narrow limits, so that a good share of the proposals is invalid -- which is not the same as outside the prior
+    (chain.cc:976-986) --, many steps per launch, bit for bit the oracle's chains."""
+    rng = np.random.default_rng(5)
+    blo = [1 if d % 3 else 0 for d in range(D)]
+    bhi = [1 if d % 2 else 0 for d in range(D)]
+    bnd = (blo, bhi, list(rng.uniform(-2.5, -1.5, D)), list(rng.uniform(1.5, 2.5, D)))
+    prior = ([1] * D, [0.0] * D, list(rng.uniform(3.0, 6.0, D)))
+    x0 = rng.uniform(-1.2, 1.2, size=(Nt * W, D))
+    pr, eng, lad = PU.make_pair(D, Nt, W, 1e4, kind=kind, bounds=bnd, prior=prior, swap_rate=0.2, x0=x0)
+    assert eng.step_kernel_name.startswith("ladder_persistent_kernel<%d" % (16 if D <= 16 else 32)), eng.step_kernel_name
+    for n in (1, 2, 40, 100):
+        eng.step(n); eng.sync(); lad.pt_step(n)
+        PU.assert_same_state(eng, lad, "after %d more PT steps in one launch" % n)
+    t, a = eng.swap_counts()
+    assert np.array_equal(t, lad.swap_count) and np.array_equal(a, lad.swap_accept_count)
+    tries, acc = eng.ntries.sum() - eng.Nc, eng.naccept.sum() - eng.Nc
+    assert 0 < acc < 0.9 * tries
+    eng.close()
+
+
 @pytest.mark.parametrize("D,Nt,W,kind,sr", LADDER_CASES)
 def test_persistent_ladder_kernel_matches_the_oracle(D, Nt, W, kind, sr):
     """Long ladders of few walkers step through ONE launch per ptm_step(n) call: resident workgroups of 8 (16) rungs keep their
