@@ -5,6 +5,7 @@
 namespace ptm {
 
 constexpr int LADDER_H = 8;   // halo depth in rungs (parallel.DEFAULT_HALO has the run-length statistics)
+constexpr int LADDER_THREADS = 512;   // four waves of chains (256 lanes: a lane per dimension) + four bookkeeper waves
 
 struct LadderArgs {
   int nsteps;           // steps asked for
@@ -31,5 +32,10 @@ inline size_t ladder_window_lds_bytes(int DP) {
   const int R = 256 / DP, WN = 1 + R + LADDER_H;
   return (size_t)WN * 8 * 5 + (size_t)WN * DP * 8 + (size_t)((WN + 3) & ~3) * 4 + (size_t)R * 8 + 64;
 }
+
+// ... and, at 32 dimensions with a full factor, the precision matrix as padded rows (stride DP + 1: conflict-free for a lane per row):
+// with the bookkeeper wave two waves share a SIMD and a lane has 256 registers, not 512 -- its row of the matrix no longer fits beside
+// its row of the factor
+inline size_t ladder_psq_lds_bytes(int DP) { return DP == 32 ? (size_t)DP * (DP + 1) * 8 : 0; }
 
 }  // namespace ptm

@@ -39,7 +39,7 @@
 namespace ptm {
 
 template <int DP, int KIND>
-__global__ __launch_bounds__(256) void ladder_persistent_kernel(const Dev p, const LadderArgs a) {
+__global__ __launch_bounds__(LADDER_THREADS) void ladder_persistent_kernel(const Dev p, const LadderArgs a) {
   static_assert(DP == 16 || DP == 32, "persistent ladder kernel: DP 16 or 32");
   constexpr int R = 256 / DP;            // rungs per workgroup
   constexpr int CPW = 64 / DP;           // chains per wave
@@ -48,6 +48,9 @@ __global__ __launch_bounds__(256) void ladder_persistent_kernel(const Dev p, con
   static_assert(R >= H, "a halo must fit the neighbouring workgroup");
   extern __shared__ __attribute__((aligned(16))) double lds_all[];
   const int tid = threadIdx.x;
+  // Waves 0..3 hold the workgroup's chains (a lane per dimension); waves 4..7 are the BOOKKEEPERS of the exchange phase (step 2 below).
+  const bool helper = tid >= 256;
+  const int ht = tid - 256;   // a bookkeeper's thread number
   const int Nt = p.Nt, ms = a.ms, NB = a.NB;
   const int NONE = 0x7fffffff;
 
@@ -64,7 +67,7 @@ __global__ __launch_bounds__(256) void ladder_persistent_kernel(const Dev p, con
 
   // -- LDS carve
   double* p2s = lds_all + BM_TABLE_DOUBLES;
-  double* wsc = p2s + lanes_p2_doubles<DP>() + (tid >> 6) * (3 * 64 + 4 * CPW);
+  double* wsc = p2s + lanes_p2_doubles<DP>() + ((tid >> 6) & 3) * (3 * 64 + 4 * CPW);   // (the bookkeeper never touches it)
   double* vbuf = wsc;
   double* sbuf = wsc + 64;
   double* pbuf = wsc + 3 * 64;
@@ -85,9 +88,11 @@ __global__ __launch_bounds__(256) void ladder_persistent_kernel(const Dev p, con
   int* pacc = ptry + R;                                                   // [R] ... accepted
   double* llall = reinterpret_cast<double*>(pacc + R + ((2 * R) & 1));    // [Nt] whole-ladder llike view (steps with a run longer than the halo)
   int* permall = reinterpret_cast<int*>(llall + Nt);                      // [Nt] ... and row map
+  constexpr bool PROW_LDS = DP == 32 && KIND != KIND_DIAG;                // the precision matrix's rows from LDS (ptm_ladder_args.hpp)
+  double* psq = reinterpret_cast<double*>(permall + ((Nt + 1) & ~1));     // [DP][DP + 1], zeros above the diagonal
 
   lanes_stage<DP>(p, lds_all);
-  for (int i = tid; i < Nt; i += 256) first[i] = NONE;
+  for (int i = tid; i < Nt; i += LADDER_THREADS) first[i] = NONE;
   if (tid < R) { ptry[tid] = 0; pacc[tid] = 0; }
   if (tid < 4) sflag[tid] = 0;
   if (tid < WN - 1) wdb[tid] = -(p.beta[wlo + tid + 1] - p.beta[wlo + tid]);   // chain.cc:1463
@@ -96,7 +101,7 @@ __global__ __launch_bounds__(256) void ladder_persistent_kernel(const Dev p, con
   const int lane = tid & 63;
   const int d = lane % DP, g = lane / DP;
   const int slot = (tid >> 6) * CPW + g;        // rung of the workgroup
-  const bool live = r0 + slot < r1;
+  const bool live = !helper && r0 + slot < r1;
   const int rg = live ? r0 + slot : r1 - 1;     // dead lanes shadow the last rung and write nothing
   const int c = rg * p.W + w;
   const bool lead = d == 0;
@@ -123,9 +128,17 @@ __global__ __launch_bounds__(256) void ladder_persistent_kernel(const Dev p, con
     for (int j = 0; j < DP; ++j) tcol[KIND == KIND_DIAG ? 0 : j] = p.prop[(size_t)rg * p.prop_stride + (size_t)j * DP + d];
   }
   // row d of the packed precision matrix {2P_d0 .. 2P_d,d-1, P_dd}, zeros behind it (fma(0, y, s) == s: the chain below runs over all DP)
-  double prow[DP];
+  double prow[PROW_LDS ? 1 : DP];
+  if (PROW_LDS) {
+    for (int i = tid; i < DP * DP; i += LADDER_THREADS) {
+      const int r = i / DP, j = i - r * DP;
+      psq[r * (DP + 1) + j] = j <= r ? p2s[(size_t)r * (r + 1) / 2 + j] : 0.0;
+    }
+  } else {
 #pragma unroll
-  for (int j = 0; j < DP; ++j) prow[j] = j <= d ? p2s[(size_t)d * (d + 1) / 2 + j] : 0.0;
+    for (int j = 0; j < DP; ++j) prow[PROW_LDS ? 0 : j] = j <= d ? p2s[(size_t)d * (d + 1) / 2 + j] : 0.0;
+  }
+  const double* const prl = psq + d * (DP + 1);
   const size_t NcDP = (size_t)p.Nc * DP;
   const int blk = w * NB + b;
   __syncthreads();
@@ -186,53 +199,12 @@ __global__ __launch_bounds__(256) void ladder_persistent_kernel(const Dev p, con
     if (tid == 0) __hip_atomic_store(&a.flags[blk], s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     PTM_LADDER_TICK(1);
 
-    // ---- 2. what does not depend on anybody's state
-    // candidate draws (chain.cc:1410-1416) and survivor filter (:1417-1418) of the whole ladder: decide_body's, verbatim
-    for (int k = tid; k < ms; k += 256) {
-      const u32x4 o = draw_block(p.seed, TAG_PT, (uint32_t)(w + p.w_off), step, (uint32_t)k);
-      int n = -2;
-      if (Nt > 1 && u01(o.v0) < a.thresh) n = (int)(u01(o.v1) * (Nt - 1));
-      cand[k] = n;
-      ua[k] = o.v2;
-      alive[k] = 0;
-      if (n >= 0) atomicMin(&first[n], k);
-    }
-    __syncthreads();
-    for (int k = tid; k < ms; k += 256) {
-      const int n = cand[k];
-      if (n < 0 || first[n] != k) continue;                      // repeated rung value: dropped
-      if (n > 0 && first[n - 1] != NONE) continue;               // not a run head
-      bool al = true;
-      for (int m = n;; ++m) {
-        alive[first[m]] = al ? 1 : 0;
-        if (m + 1 > Nt - 2 || first[m + 1] == NONE) break;
-        al = !(al && first[m] < first[m + 1]);
-      }
-    }
-    __syncthreads();
-    // a run of more than H surviving picks on consecutive rungs anywhere in the ladder: the halos do not cover this step (every
-    // workgroup of the ladder sees the same draws): it takes the whole-ladder form below
-    for (int k = tid; k < ms; k += 256) {
-      const int n = cand[k];
-      if (n < 0 || !alive[k] || PTM_LADDER_ALIVE(n - 1)) continue;   // bottoms of runs of surviving picks
-      int len = 1;
-      while (PTM_LADDER_ALIVE(n + len)) ++len;
-      if (len > a.max_run) sflag[0] = 1;
-    }
-    // rungs an exchange attempt touches make no Metropolis move this step, one add_state per attempt (chain.cc:1487-1490,
-    // 1531-1534,1553-1557): known from the draws alone
-    const int tc = (PTM_LADDER_ALIVE(rg) ? 1 : 0) + (PTM_LADDER_ALIVE(rg - 1) ? 1 : 0);
-    // log of the accept uniform of every surviving pick in the window (the uniform's slot is the pick's whether needed or not: Q5),
-    // taken off the chain of dependent trials: the last wave's first lanes, which hold the workgroup's last rungs or nothing
-    if (tid >= 256 - 32 && tid - (256 - 32) < WN - 1) {
-      const int n = wlo + tid - (256 - 32);
-      if (PTM_LADDER_ALIVE(n)) wlu[n - wlo] = dlog_u01(ua[first[n]]);
-    }
-
-    // ---- 3. MH_chain::step (chain.cc:966-1022) for the rungs no exchange touches -- they need nothing of the neighbours.  The
-    //      hand-over rides behind it: every wave asks for the neighbours' flags now, looks at the answer after the proposal's
-    //      offset is computed (a microsecond later) and, if both neighbours have published, asks for its share of the window --
-    //      which is there when the Metropolis tests are done.  Touched chains' lanes run along and change nothing.
+    // ---- 2. the step in four segments, each ended by a workgroup barrier.  The bookkeepers (waves 4..7) replay the candidate draws
+    //      (chain.cc:1410-1416) and the survivor filter (:1417-1418) of the whole ladder -- decide_body's, verbatim --, wait for the
+    //      neighbours' flags, fetch the window and take the trials; the chains' waves (0..3) meanwhile do MH_chain::step
+    //      (chain.cc:966-1022) for every rung -- which needs nothing of the neighbours, and of the draws only WHICH rungs an exchange
+    //      touches (they make no Metropolis move: their lanes run along and the result is dropped when the moves are committed).
+    //      Two waves share each SIMD; a lone wave leaves more than half of a SIMD's issue slots idle (tools/probes/valu_cost_probe.hip).
     int fl_lo = s + 1, fl_hi = s + 1;
     auto ask_flags = [&] {
       if (lane == 0) {
@@ -241,7 +213,7 @@ __global__ __launch_bounds__(256) void ladder_persistent_kernel(const Dev p, con
       }
     };
     auto flags_up = [&] { return __builtin_amdgcn_readfirstlane(fl_lo) >= s + 1 && __builtin_amdgcn_readfirstlane(fl_hi) >= s + 1; };
-    // the window: rows, llikes and lpriors of rungs wlo .. whi as published for this step, NWR words per thread
+    // the window: rows, llikes and lpriors of rungs wlo .. whi as published for this step, NWR words per bookkeeper thread
     constexpr int NWR = (WNMAX * DP + 2 * WNMAX + 255) / 256;
     double wr[NWR];
     auto ask_window = [&] {
@@ -250,7 +222,7 @@ __global__ __launch_bounds__(256) void ladder_persistent_kernel(const Dev p, con
       const double* pp = a.pub_lp + (size_t)par * p.Nc;
 #pragma unroll
       for (int q = 0; q < NWR; ++q) {
-        const int i = tid + 256 * q;
+        const int i = ht + 256 * q;
         const double* src = nullptr;
         if (i < WN * DP) src = px + (size_t)((wlo + i / DP) * p.W + w) * DP + i % DP;
         else if (i < WN * DP + WN) src = pl + (size_t)(wlo + i - WN * DP) * p.W + w;
@@ -258,38 +230,104 @@ __global__ __launch_bounds__(256) void ladder_persistent_kernel(const Dev p, con
         wr[q] = src ? __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
       }
     };
-    ask_flags();
-    bool have_window = false;
-    {
-      const u32x4 o0 = draw_block(p.seed, TAG_MH, stream, step, 0);
-      double off;   // offset = factor . z of this lane's rung (gaussian_prop::draw, proposal_distribution.hh:194-218)
-      {
-        const u32x4 o = draw_block(p.seed, TAG_MH, stream, step, (uint32_t)((d >> 2) + 1));
-        const bool hi = (d & 2) != 0;
-        double z0, z1;
-        boxmuller(hi ? o.v2 : o.v0, hi ? o.v3 : o.v1, lds_all, z0, z1);
-        const double zd = (d & 1) ? z1 : z0;
-        if (KIND == KIND_DIAG) off = tcol[0] * zd;
-        else {
-          vbuf[g * DP + d] = zd;
-          sync_wave();
-          double acc = 0.0;
-#pragma unroll
-          for (int h = 0; h < DP / 16; ++h)
-#pragma unroll
-            for (int sl = 0; sl < 4; ++sl)
-#pragma unroll
-              for (int k = 0; k < 4; ++k) {
-                const int j = 16 * h + 4 * k + sl;
-                acc = __builtin_fma(tcol[KIND == KIND_DIAG ? 0 : j], vbuf[g * DP + j], acc);
-              }
-          off = acc;
-          sync_wave();
+    double xn = 0.0, newlike = 0.0, newlprior = 0.0, off = 0.0;
+    bool accept = false;
+    u32x4 o0 = u32x4{0u, 0u, 0u, 0u}, o = u32x4{0u, 0u, 0u, 0u};
+
+    // -- segment A: candidate draws | the chains' random blocks
+    if (helper) {
+      for (int k = ht; k < ms; k += 256) {
+        const u32x4 oc = draw_block(p.seed, TAG_PT, (uint32_t)(w + p.w_off), step, (uint32_t)k);
+        int n = -2;
+        if (Nt > 1 && u01(oc.v0) < a.thresh) n = (int)(u01(oc.v1) * (Nt - 1));
+        cand[k] = n;
+        ua[k] = oc.v2;
+        alive[k] = 0;
+        if (n >= 0) atomicMin(&first[n], k);
+      }
+      ask_flags();
+    } else {
+      o0 = draw_block(p.seed, TAG_MH, stream, step, 0);
+      o = draw_block(p.seed, TAG_MH, stream, step, (uint32_t)((d >> 2) + 1));
+    }
+    __syncthreads();
+
+    // -- segment B: survivor filter | the proposal's offset = factor . z of this lane's rung (gaussian_prop::draw, proposal_distribution.hh:194-218)
+    if (helper) {
+      for (int k = ht; k < ms; k += 256) {
+        const int n = cand[k];
+        if (n < 0 || first[n] != k) continue;                      // repeated rung value: dropped
+        if (n > 0 && first[n - 1] != NONE) continue;               // not a run head
+        bool al = true;
+        for (int m = n;; ++m) {
+          alive[first[m]] = al ? 1 : 0;
+          if (m + 1 > Nt - 2 || first[m + 1] == NONE) break;
+          al = !(al && first[m] < first[m + 1]);
         }
       }
-      if (flags_up()) { ask_window(); have_window = true; }
-      else ask_flags();
-      const double xn = xd + off;                                 // state::add (states.cc:205-214)
+    } else {
+      const bool hi = (d & 2) != 0;
+      double z0, z1;
+      boxmuller(hi ? o.v2 : o.v0, hi ? o.v3 : o.v1, lds_all, z0, z1);
+      const double zd = (d & 1) ? z1 : z0;
+      if (KIND == KIND_DIAG) off = tcol[0] * zd;
+      else {
+        vbuf[g * DP + d] = zd;
+        sync_wave();
+        double acc = 0.0;
+#pragma unroll
+        for (int h = 0; h < DP / 16; ++h)
+#pragma unroll
+          for (int sl = 0; sl < 4; ++sl)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const int j = 16 * h + 4 * k + sl;
+              acc = __builtin_fma(tcol[KIND == KIND_DIAG ? 0 : j], vbuf[g * DP + j], acc);
+            }
+        off = acc;
+        sync_wave();
+      }
+    }
+    __syncthreads();
+
+    // -- segment C: long runs, the picks' log-uniforms, flags, the window | prior box, likelihood, the Metropolis test
+    if (helper) {
+      // a run of more than H surviving picks on consecutive rungs anywhere in the ladder: the halos do not cover this step (every
+      // workgroup of the ladder sees the same draws): it takes the whole-ladder form below
+      for (int k = ht; k < ms; k += 256) {
+        const int n = cand[k];
+        if (n < 0 || !alive[k] || PTM_LADDER_ALIVE(n - 1)) continue;   // bottoms of runs of surviving picks
+        int len = 1;
+        while (PTM_LADDER_ALIVE(n + len)) ++len;
+        if (len > a.max_run) sflag[0] = 1;
+      }
+      // log of the accept uniform of every surviving pick in the window (the uniform's slot is the pick's whether needed or not: Q5),
+      // taken off the chain of dependent trials
+      if (ht < WN - 1) {
+        const int n = wlo + ht;
+        if (PTM_LADDER_ALIVE(n)) wlu[n - wlo] = dlog_u01(ua[first[n]]);
+      }
+      // the window into LDS (a wave whose neighbours had not published when it looked waits for them now)
+      if (!flags_up()) {
+        if (lane == 0) {
+          const long long t0 = wall_clock64();
+          bool ok = true;
+          if (b > 0) ok = wait_for(b - 1, s, t0);
+          if (ok && b + 1 < NB) ok = wait_for(b + 1, s, t0);
+          if (!ok) { __hip_atomic_store(&a.ctl[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); sflag[1] = 1; }
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+      ask_window();
+#pragma unroll
+      for (int q = 0; q < NWR; ++q) {
+        const int i = ht + 256 * q;
+        if (i < WN * DP) wx[i] = wr[q];
+        else if (i < WN * DP + WN) { wll[i - WN * DP] = wr[q]; wll0[i - WN * DP] = wr[q]; wperm[i - WN * DP] = wlo + i - WN * DP; }
+        else if (i < WN * DP + 2 * WN) wlp0[i - WN * DP - WN] = wr[q];
+      }
+    } else {
+      xn = xd + off;                                              // state::add (states.cc:205-214)
       const double bl = beta * ll;
       const double cur_lpost = lp + bl;
       const double oldlprior = cur_lpost - bl;                    // chain.cc:973
@@ -297,7 +335,7 @@ __global__ __launch_bounds__(256) void ladder_persistent_kernel(const Dev p, con
       const bool in = all_of_chain(ind);
       // Q9: state::add builds on an enforced zero state -- an origin outside a `limit` bound invalidates every proposal
       const bool valid = p.origin_valid != 0 && all_of_chain(!(xn < elo) && !(xn > ehi));   // stateSpace::enforce, states.cc:86-102
-      double newlprior = in ? p.lprior_const : -__builtin_inf();
+      newlprior = in ? p.lprior_const : -__builtin_inf();
       if (!valid) newlprior = -__builtin_inf();
       const bool want_like = valid && (newlprior > -1e200 || newlprior - oldlprior > p.min_prior);   // chain.cc:980 (Q1)
       vbuf[g * DP + d] = xn;
@@ -310,7 +348,7 @@ __global__ __launch_bounds__(256) void ladder_persistent_kernel(const Dev p, con
         const double* y = vbuf + g * DP;
         double sacc = 0.0;
 #pragma unroll
-        for (int j = 0; j < DP; ++j) sacc = __builtin_fma(prow[j], y[j], sacc);
+        for (int j = 0; j < DP; ++j) sacc = __builtin_fma(PROW_LDS ? prl[j] : prow[PROW_LDS ? 0 : j], y[j], sacc);
         sbuf[g * DP + d] = sacc;
       }
       sync_wave();
@@ -323,50 +361,34 @@ __global__ __launch_bounds__(256) void ladder_persistent_kernel(const Dev p, con
       sync_wave();
       const double quad = ((pbuf[g * 4 + 0] + pbuf[g * 4 + 1]) + pbuf[g * 4 + 2]) + pbuf[g * 4 + 3];
       sync_wave();   // (vbuf / pbuf are rewritten by the next step's draw)
-      double newlike = p.like0 - 0.5 * quad;
+      newlike = p.like0 - 0.5 * quad;
       double newlpost = newlike * beta + newlprior;
       if (!want_like) newlike = newlpost = -__builtin_inf();
       const double logH = newlpost - cur_lpost;
-      bool accept = valid;
+      accept = valid;
       if (accept && logH < 0) accept = dlog_u01(o0.v0) < logH;    // chain.cc:998-1001 (NaN stays accepted)
+    }
+    __syncthreads();
+    if (sflag[1]) { aborted = true; break; }
+    PTM_LADDER_TICK(2);
+    // rungs an exchange attempt touches make no Metropolis move this step, one add_state per attempt (chain.cc:1487-1490,
+    // 1531-1534,1553-1557): known from the draws alone
+    const int tc = helper ? 0 : (PTM_LADDER_ALIVE(rg) ? 1 : 0) + (PTM_LADDER_ALIVE(rg - 1) ? 1 : 0);
+    if (!helper) {
       if (!tc) {
         ntries += 1;
         nhist += 1u;
         if (accept) { xd = xn; ll = newlike; lp = newlprior; naccept += 1; last_type = 0; }
       } else nhist += (unsigned int)tc;
     }
-    PTM_LADDER_TICK(2);
-    // the window into LDS (a wave whose neighbours had not published when it looked waits for them now)
-    if (!have_window) {
-      if (!flags_up()) {
-        if (lane == 0) {
-          const long long t0 = wall_clock64();
-          bool ok = true;
-          if (b > 0) ok = wait_for(b - 1, s, t0);
-          if (ok && b + 1 < NB) ok = wait_for(b + 1, s, t0);
-          if (!ok) { __hip_atomic_store(&a.ctl[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); sflag[1] = 1; }
-        }
-        __builtin_amdgcn_wave_barrier();
-      }
-      ask_window();
-    }
     PTM_LADDER_TICK(3);
-#pragma unroll
-    for (int q = 0; q < NWR; ++q) {
-      const int i = tid + 256 * q;
-      if (i < WN * DP) wx[i] = wr[q];
-      else if (i < WN * DP + WN) { wll[i - WN * DP] = wr[q]; wll0[i - WN * DP] = wr[q]; wperm[i - WN * DP] = wlo + i - WN * DP; }
-      else if (i < WN * DP + 2 * WN) wlp0[i - WN * DP - WN] = wr[q];
-    }
-    __syncthreads();
-    if (sflag[1]) { aborted = true; break; }
     PTM_LADDER_TICK(4);
 
     if (!sflag[0]) {
       // ---- 4. the exchange phase from the neighbours' publications
       // trials (chain.cc:1436-1537): the top pick of each run of surviving picks inside the window walks it downwards
-      if (tid < WN - 1) {
-        const int n = wlo + tid;                                   // pair (n, n + 1), both inside the window
+      if (helper && ht < WN - 1) {
+        const int n = wlo + ht;                                    // pair (n, n + 1), both inside the window
         // A pick above that is inside the window walks this pick too.  One that lies outside (n + 1 == whi) may replace rung
         // whi, so the run below it is unknown here -- and it has at most H picks (checked above): it ends above this
         // workgroup's rungs.  Somebody else's.
@@ -393,19 +415,19 @@ __global__ __launch_bounds__(256) void ladder_persistent_kernel(const Dev p, con
       {
         const long long t0 = wall_clock64();
         bool ok = true;
-        for (int nb = tid; nb < NB && ok; nb += 256)
+        for (int nb = tid; nb < NB && ok; nb += LADDER_THREADS)
           if (nb != b) ok = wait_for(nb, s, t0);
         if (!ok) sflag[2] = 1;
       }
       __syncthreads();
       if (sflag[2]) { if (tid == 0) __hip_atomic_store(&a.ctl[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); aborted = true; break; }
       const double* pl = a.pub_ll + (size_t)par * p.Nc;
-      for (int r = tid; r < Nt; r += 256) {
+      for (int r = tid; r < Nt; r += LADDER_THREADS) {
         llall[r] = __hip_atomic_load(pl + (size_t)r * p.W + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         permall[r] = r;
       }
       __syncthreads();
-      for (int k = tid; k < ms; k += 256) {
+      for (int k = tid; k < ms; k += LADDER_THREADS) {
         const int n = cand[k];
         if (n < 0 || !alive[k] || PTM_LADDER_ALIVE(n + 1)) continue;   // tops of runs of surviving picks
         for (int i = n; i >= 0; --i) {
@@ -438,10 +460,10 @@ __global__ __launch_bounds__(256) void ladder_persistent_kernel(const Dev p, con
       if (sflag[2]) { if (tid == 0) __hip_atomic_store(&a.ctl[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); aborted = true; break; }
     }
     if (last_step && b == 0)                                      // the log lines of the picks that did not survive
-      for (int k = tid; k < ms; k += 256)
+      for (int k = tid; k < ms; k += LADDER_THREADS)
         if (!alive[k]) a.swap_log[(size_t)w * ms + k] = -2;
     __syncthreads();   // (first / alive / window are rewritten by the next step)
-    for (int k = tid; k < ms; k += 256) { const int n = cand[k]; if (n >= 0) first[n] = NONE; }
+    for (int k = tid; k < ms; k += LADDER_THREADS) { const int n = cand[k]; if (n >= 0) first[n] = NONE; }
     PTM_LADDER_TICK(6);
     done = s + 1;
   }
