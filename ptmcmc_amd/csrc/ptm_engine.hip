@@ -1550,6 +1550,7 @@ static int ladder_steps(ptm_engine* e, int n) {
     a.swap_cnt = e->swap_cnt; a.swap_log = e->swap_log + (size_t)e->log_head * e->W * e->ms;
     a.max_run = max_run;
     a.prof = e->lad_prof;
+    { static const int pt = [] { const char* v = getenv("PTM_LADDER_PROF"); return (v && *v == '2') ? 256 : ((v && *v == '3') ? 384 : 0); }(); a.prof_tid = pt; }
     if ((rc = fold_swap_log(e))) return rc;   // (the kernel adds to the swap counters itself: nothing logged may be pending behind it)
     a.spin_limit = 300000000ll;   // 3 s of the 100 MHz wall clock: a neighbour that is not there by then never will be
     HIPCHK(hipMemsetAsync(e->lad_flags, 0, ((size_t)grid + 16 + (size_t)e->W) * sizeof(int), e->stream));
@@ -1561,7 +1562,7 @@ static int ladder_steps(ptm_engine* e, int n) {
     if (e->lad_prof && ctl[1] > 0) {   // diagnostics: mean microseconds per step and phase over the workgroups, and the slowest workgroup's
       std::vector<long long> pr((size_t)grid * 8);
       HIPCHK(hipMemcpy(pr.data(), e->lad_prof, pr.size() * 8, hipMemcpyDeviceToHost));
-      static const char* const phase[7] = {"", "publish", "draws+moves", "wait", "window", "trials", "rows"};
+      static const char* const phase[7] = {"", "publish", "draws | random blocks", "filter | offsets", "window | Metropolis", "commit + trials", "rows"};
       fprintf(stderr, "[ladder kernel] %d steps, %lld workgroups; us per step (mean / max over workgroups):", ctl[1], grid);
       for (int k = 1; k < 7; ++k) {
         double sum = 0, mx = 0;

@@ -22,6 +22,7 @@ struct LadderArgs {
   int* swap_log;        // [W][ms] candidate log of the LAST step asked for (ptm_get_last_swaps)
   long long spin_limit; // wall-clock ticks a workgroup waits for a neighbour before it gives up
   long long* prof;      // null, or [W * NB][8] phase clocks (diagnostics)
+  int prof_tid;         // ... of this thread: 0 a chains' wave, 256 a replay wave, 384 a window wave (PTM_LADDER_PROF=1 / 2 / 3)
   int max_run;          // longest run of surviving picks on consecutive rungs a step may hold (<= LADDER_H; tests lower it)
 };
 

@@ -50,7 +50,9 @@ __global__ __launch_bounds__(LADDER_THREADS) void ladder_persistent_kernel(const
   const int tid = threadIdx.x;
   // Waves 0..3 hold the workgroup's chains (a lane per dimension); waves 4..7 are the BOOKKEEPERS of the exchange phase (step 2 below).
   const bool helper = tid >= 256;
-  const int ht = tid - 256;   // a bookkeeper's thread number
+  const int ht = tid - 256;   // a bookkeeper's thread number: 0..127 replay the draws (waves 4, 5), 128..255 fetch the window (waves 6, 7)
+  const bool drole = helper && ht < 128, wrole = helper && ht >= 128;
+  const int wt = ht - 128;
   const int Nt = p.Nt, ms = a.ms, NB = a.NB;
   const int NONE = 0x7fffffff;
 
@@ -94,7 +96,7 @@ __global__ __launch_bounds__(LADDER_THREADS) void ladder_persistent_kernel(const
   lanes_stage<DP>(p, lds_all);
   for (int i = tid; i < Nt; i += LADDER_THREADS) first[i] = NONE;
   if (tid < R) { ptry[tid] = 0; pacc[tid] = 0; }
-  if (tid < 4) sflag[tid] = 0;
+  if (tid < 8) sflag[tid] = 0;   // ([5], [6]: arrivals of the bookkeeper waves at their own barriers, counted over the steps)
   if (tid < WN - 1) wdb[tid] = -(p.beta[wlo + tid + 1] - p.beta[wlo + tid]);   // chain.cc:1463
 
   // -- this lane's chain
@@ -145,7 +147,7 @@ __global__ __launch_bounds__(LADDER_THREADS) void ladder_persistent_kernel(const
 
   // optional phase clock (a.prof != null: PTM_LADDER_PROF=1, tools/w1_probe.py): 100 MHz ticks per phase, summed over the steps
   long long tick_sum[7] = {0, 0, 0, 0, 0, 0, 0}, tick_last = 0;
-#define PTM_LADDER_TICK(k) do { if (a.prof && tid == 0) { const long long t_ = wall_clock64(); if ((k) > 0) tick_sum[(k)] += t_ - tick_last; tick_last = t_; } } while (0)
+#define PTM_LADDER_TICK(k) do { if (a.prof && tid == a.prof_tid) { const long long t_ = wall_clock64(); if ((k) > 0) tick_sum[(k)] += t_ - tick_last; tick_last = t_; } } while (0)
 #define PTM_LADDER_ALIVE(r) ((r) >= 0 && (r) <= Nt - 2 && first[(r)] != NONE && alive[first[(r)]])
   // one trial (chain.cc:1459-1467) on a llike view `lv` / row map `pm` indexed from rung `base`; own pairs are counted and logged
   auto trial = [&](double* lv, int* pm, int base, int i, bool last_step, double dbeta, double lu) {
@@ -175,6 +177,20 @@ __global__ __launch_bounds__(LADDER_THREADS) void ladder_persistent_kernel(const
       __builtin_amdgcn_s_sleep(1);
     }
     return true;
+  };
+  // The bookkeeper waves meet between the phases of the replay on counters in LDS (the workgroup's barrier would stop the chains'
+  // waves, which need nothing of the replay before the moves are committed): the waves of `arrives` count themselves in sflag[slot],
+  // those of `waits` go on when the count -- kept over the steps -- has reached `target`.
+  auto replay_sync = [&](int slot, int target, bool arrives, bool waits) {
+    if (!arrives) return;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+      __hip_atomic_fetch_add(&sflag[slot], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (waits)
+        while (__hip_atomic_load(&sflag[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(0);
+    }
+    __builtin_amdgcn_wave_barrier();
   };
   int done = 0, nslow = 0;
   bool aborted = false;
@@ -214,7 +230,7 @@ __global__ __launch_bounds__(LADDER_THREADS) void ladder_persistent_kernel(const
     };
     auto flags_up = [&] { return __builtin_amdgcn_readfirstlane(fl_lo) >= s + 1 && __builtin_amdgcn_readfirstlane(fl_hi) >= s + 1; };
     // the window: rows, llikes and lpriors of rungs wlo .. whi as published for this step, NWR words per bookkeeper thread
-    constexpr int NWR = (WNMAX * DP + 2 * WNMAX + 255) / 256;
+    constexpr int NWR = (WNMAX * DP + 2 * WNMAX + 127) / 128;
     double wr[NWR];
     auto ask_window = [&] {
       const double* px = a.pub_x + par * NcDP;
@@ -222,7 +238,7 @@ __global__ __launch_bounds__(LADDER_THREADS) void ladder_persistent_kernel(const
       const double* pp = a.pub_lp + (size_t)par * p.Nc;
 #pragma unroll
       for (int q = 0; q < NWR; ++q) {
-        const int i = ht + 256 * q;
+        const int i = wt + 128 * q;
         const double* src = nullptr;
         if (i < WN * DP) src = px + (size_t)((wlo + i / DP) * p.W + w) * DP + i % DP;
         else if (i < WN * DP + WN) src = pl + (size_t)(wlo + i - WN * DP) * p.W + w;
@@ -235,7 +251,8 @@ __global__ __launch_bounds__(LADDER_THREADS) void ladder_persistent_kernel(const
     u32x4 o0 = u32x4{0u, 0u, 0u, 0u}, o = u32x4{0u, 0u, 0u, 0u};
 
     // -- segment A: candidate draws | the chains' random blocks
-    if (helper) {
+    if (helper) {   // (all four bookkeeper waves draw; the window's two have asked for the neighbours' flags and look at them afterwards)
+      if (wrole) ask_flags();
       for (int k = ht; k < ms; k += 256) {
         const u32x4 oc = draw_block(p.seed, TAG_PT, (uint32_t)(w + p.w_off), step, (uint32_t)k);
         int n = -2;
@@ -245,16 +262,31 @@ __global__ __launch_bounds__(LADDER_THREADS) void ladder_persistent_kernel(const
         alive[k] = 0;
         if (n >= 0) atomicMin(&first[n], k);
       }
-      ask_flags();
     } else {
       o0 = draw_block(p.seed, TAG_MH, stream, step, 0);
       o = draw_block(p.seed, TAG_MH, stream, step, (uint32_t)((d >> 2) + 1));
     }
-    __syncthreads();
+    replay_sync(5, 4 * (s + 1), helper, drole);   // every bookkeeper wave has drawn: the two replay waves go on when all four have
+    PTM_LADDER_TICK(2);
 
     // -- segment B: survivor filter | the proposal's offset = factor . z of this lane's rung (gaussian_prop::draw, proposal_distribution.hh:194-218)
-    if (helper) {
-      for (int k = ht; k < ms; k += 256) {
+    if (wrole) {
+      // the window, as soon as both neighbours have published (their flags were asked for a segment ago; a wave that finds them
+      // down waits for them here)
+      if (!flags_up()) {
+        if (lane == 0) {
+          const long long t0 = wall_clock64();
+          bool ok = true;
+          if (b > 0) ok = wait_for(b - 1, s, t0);
+          if (ok && b + 1 < NB) ok = wait_for(b + 1, s, t0);
+          if (!ok) { __hip_atomic_store(&a.ctl[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); sflag[1] = 1; }
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+      ask_window();
+    }
+    if (drole) {
+      for (int k = ht; k < ms; k += 128) {
         const int n = cand[k];
         if (n < 0 || first[n] != k) continue;                      // repeated rung value: dropped
         if (n > 0 && first[n - 1] != NONE) continue;               // not a run head
@@ -265,7 +297,7 @@ __global__ __launch_bounds__(LADDER_THREADS) void ladder_persistent_kernel(const
           al = !(al && first[m] < first[m + 1]);
         }
       }
-    } else {
+    } else if (!helper) {
       const bool hi = (d & 2) != 0;
       double z0, z1;
       boxmuller(hi ? o.v2 : o.v0, hi ? o.v3 : o.v1, lds_all, z0, z1);
@@ -288,13 +320,14 @@ __global__ __launch_bounds__(LADDER_THREADS) void ladder_persistent_kernel(const
         sync_wave();
       }
     }
-    __syncthreads();
+    replay_sync(6, 2 * (s + 1), drole, drole);    // the filter is done
+    PTM_LADDER_TICK(3);
 
     // -- segment C: long runs, the picks' log-uniforms, flags, the window | prior box, likelihood, the Metropolis test
-    if (helper) {
+    if (drole) {
       // a run of more than H surviving picks on consecutive rungs anywhere in the ladder: the halos do not cover this step (every
       // workgroup of the ladder sees the same draws): it takes the whole-ladder form below
-      for (int k = ht; k < ms; k += 256) {
+      for (int k = ht; k < ms; k += 128) {
         const int n = cand[k];
         if (n < 0 || !alive[k] || PTM_LADDER_ALIVE(n - 1)) continue;   // bottoms of runs of surviving picks
         int len = 1;
@@ -307,26 +340,17 @@ __global__ __launch_bounds__(LADDER_THREADS) void ladder_persistent_kernel(const
         const int n = wlo + ht;
         if (PTM_LADDER_ALIVE(n)) wlu[n - wlo] = dlog_u01(ua[first[n]]);
       }
-      // the window into LDS (a wave whose neighbours had not published when it looked waits for them now)
-      if (!flags_up()) {
-        if (lane == 0) {
-          const long long t0 = wall_clock64();
-          bool ok = true;
-          if (b > 0) ok = wait_for(b - 1, s, t0);
-          if (ok && b + 1 < NB) ok = wait_for(b + 1, s, t0);
-          if (!ok) { __hip_atomic_store(&a.ctl[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); sflag[1] = 1; }
-        }
-        __builtin_amdgcn_wave_barrier();
-      }
-      ask_window();
+    }
+    if (wrole) {   // the window into LDS
 #pragma unroll
       for (int q = 0; q < NWR; ++q) {
-        const int i = ht + 256 * q;
+        const int i = wt + 128 * q;
         if (i < WN * DP) wx[i] = wr[q];
         else if (i < WN * DP + WN) { wll[i - WN * DP] = wr[q]; wll0[i - WN * DP] = wr[q]; wperm[i - WN * DP] = wlo + i - WN * DP; }
         else if (i < WN * DP + 2 * WN) wlp0[i - WN * DP - WN] = wr[q];
       }
-    } else {
+    }
+    if (!helper) {
       xn = xd + off;                                              // state::add (states.cc:205-214)
       const double bl = beta * ll;
       const double cur_lpost = lp + bl;
@@ -370,7 +394,7 @@ __global__ __launch_bounds__(LADDER_THREADS) void ladder_persistent_kernel(const
     }
     __syncthreads();
     if (sflag[1]) { aborted = true; break; }
-    PTM_LADDER_TICK(2);
+    PTM_LADDER_TICK(4);
     // rungs an exchange attempt touches make no Metropolis move this step, one add_state per attempt (chain.cc:1487-1490,
     // 1531-1534,1553-1557): known from the draws alone
     const int tc = helper ? 0 : (PTM_LADDER_ALIVE(rg) ? 1 : 0) + (PTM_LADDER_ALIVE(rg - 1) ? 1 : 0);
@@ -381,8 +405,6 @@ __global__ __launch_bounds__(LADDER_THREADS) void ladder_persistent_kernel(const
         if (accept) { xd = xn; ll = newlike; lp = newlprior; naccept += 1; last_type = 0; }
       } else nhist += (unsigned int)tc;
     }
-    PTM_LADDER_TICK(3);
-    PTM_LADDER_TICK(4);
 
     if (!sflag[0]) {
       // ---- 4. the exchange phase from the neighbours' publications
@@ -483,7 +505,7 @@ __global__ __launch_bounds__(LADDER_THREADS) void ladder_persistent_kernel(const
     sc[0] += ptry[tid];
     sc[1] += pacc[tid];
   }
-  if (a.prof && tid == 0)
+  if (a.prof && tid == a.prof_tid)
     for (int k = 0; k < 7; ++k) a.prof[(size_t)blk * 8 + k] = tick_sum[k];
 #undef PTM_LADDER_TICK
   if (L == 0 && tid == 0) { a.ctl[1] = aborted ? -1 : done; a.ctl[2] = nslow; }
