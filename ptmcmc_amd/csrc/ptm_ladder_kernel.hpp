@@ -6,10 +6,11 @@
 // boundaries and the ~10 dependent trips to memory between them.  Here a grid of resident workgroups walks the steps of a
 // ptm_step(n) call without returning to the host (the caller's loop this replaces: ptmcmc.cc:563-599):
 //
-//   * a workgroup of 256 lanes owns R = 256 / DP consecutive rungs of one walker's ladder (8 at DP = 32), a lane per
-//     dimension as in the lanes kernel (ptm_lanes_kernel.hpp): the state row sits in ONE register per lane, llike / lprior /
-//     the MH_chain counters in registers too, the rung's row of the proposal factor (it never changes) in 32 registers,
-//     tables in LDS -- loaded once per launch;
+//   * a workgroup owns R = 256 / DP consecutive rungs of one walker's ladder (8 at DP = 32).  Its waves 0..3 (256 lanes) hold the
+//     chains, a lane per dimension as in the lanes kernel (ptm_lanes_kernel.hpp): the state row sits in ONE register per lane,
+//     llike / lprior / the MH_chain counters in registers too, the rung's row of the proposal factor (it never changes) in 32
+//     registers, tables in LDS -- loaded once per launch.  Waves 4..7 are BOOKKEEPERS: they take the exchange phase's replay and
+//     the hand-over off the chains' waves (a lone wave uses less than half of its SIMD's issue slots; two share each SIMD here);
 //   * every workgroup replays the step's candidate draws and the survivor filter of the WHOLE ladder (chain.cc:1410-1418: they
 //     depend on the ladder's random stream only), exactly as the shards of a multi-GPU run do (ptm_decide.hpp), and decides the
 //     exchanges that can change its own rungs from its own llikes, the top rung of the workgroup below and the bottom H = 8
