@@ -202,8 +202,9 @@ def run_single(args):
         w1 = {"chains": NT, "value": NT * n1 / best, "ms_per_step": us * 1e-3, "us_per_step": us, "steps_per_launch": n1,
               "kernel": e1.step_kernel_name,
               "roofline": {"bound": "latency", "note": "1024 chains are 512 wavefronts on a 256-CU part: neither HBM nor the f64 pipes are near "
-                           "a limit; what bounds a step is the chain of dependent instructions of one wave (~830 per step, one issued "
-                           "per 8-11 cycles from a lone wave) plus one neighbour hand-over through memory (DESIGN.md section 3.8)",
+                           "a limit; what bounds a step is the chain of dependent instructions of a chains' wave (one issued per 8-11 cycles "
+                           "per wave; the exchange phase's replay runs beside it on bookkeeper waves) and the neighbour hand-over through "
+                           "memory: flag and window round trips of ~0.8 us each (DESIGN.md section 3.8)",
                            "hbm_frac_if_it_were_streaming": NT * n1 / best * algorithmic_bytes(D) / (HBM_PEAK_GBS * 1e9)}}
         e1.close()
     out = {
