@@ -171,13 +171,29 @@ __global__ __launch_bounds__(LADDER_THREADS) void ladder_persistent_kernel(const
     }
   };
   // thread 0 waits until workgroup `nb` of this ladder has published step s (false: gave up)
+  // (a look at a flag is a round trip through the L2, ~0.8 us: the abort word travels beside it, not behind it)
   auto wait_for = [&](int nb, int s, long long t0) {
     int* f = &a.flags[w * NB + nb];
-    while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < s + 1) {
-      if (__hip_atomic_load(&a.ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 || wall_clock64() - t0 > a.spin_limit) return false;
+    for (;;) {
+      const int fv = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int ab = __hip_atomic_load(&a.ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (fv >= s + 1) return true;
+      if (ab != 0 || wall_clock64() - t0 > a.spin_limit) return false;
       __builtin_amdgcn_s_sleep(1);
     }
-    return true;
+  };
+  // ... and both neighbours' flags in one round trip
+  auto wait_for_neighbours = [&](int s, long long t0) {
+    int* flo = &a.flags[blk - (b > 0 ? 1 : 0)];
+    int* fhi = &a.flags[blk + (b + 1 < NB ? 1 : 0)];
+    for (;;) {
+      const int vlo = __hip_atomic_load(flo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int vhi = __hip_atomic_load(fhi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int ab = __hip_atomic_load(&a.ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((b == 0 || vlo >= s + 1) && (b + 1 >= NB || vhi >= s + 1)) return true;
+      if (ab != 0 || wall_clock64() - t0 > a.spin_limit) return false;
+      __builtin_amdgcn_s_sleep(1);
+    }
   };
   // The bookkeeper waves meet between the phases of the replay on counters in LDS (the workgroup's barrier would stop the chains'
   // waves, which need nothing of the replay before the moves are committed): the waves of `arrives` count themselves in sflag[slot],
@@ -277,9 +293,7 @@ __global__ __launch_bounds__(LADDER_THREADS) void ladder_persistent_kernel(const
       if (!flags_up()) {
         if (lane == 0) {
           const long long t0 = wall_clock64();
-          bool ok = true;
-          if (b > 0) ok = wait_for(b - 1, s, t0);
-          if (ok && b + 1 < NB) ok = wait_for(b + 1, s, t0);
+          const bool ok = wait_for_neighbours(s, t0);
           if (!ok) { __hip_atomic_store(&a.ctl[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); sflag[1] = 1; }
         }
         __builtin_amdgcn_wave_barrier();
