@@ -1197,6 +1197,7 @@ static int launch_decide(ptm_engine* e, const double* ll_below, const double* ll
   const bool cut = e->evolve_rate > 0 && e->evolve_cut >= 0;
   const size_t lds = decide_lds_bytes(e->Nt, e->ms, WN, e->evolve_rate > 0, evb, cut);
   if (lds > 160 * 1024) return fail(PTM_ERR_UNSUPPORTED, "ladder too long for the LDS-resident exchange kernel (%zu B)", lds);
+  if (e->ms >= 65535) return fail(PTM_ERR_UNSUPPORTED, "more than 65534 exchange candidates per step (the exchange kernel numbers them in 16 bits)");
   // expected candidates inside the window; evolving ladders with history / MAP tracking: the wide form alone carries the
   // saved rows' temperatures through its own row moves
   // ... and a few ladders only (latency regime) whose moves may overflow the 64-thread block: one launch instead of two
