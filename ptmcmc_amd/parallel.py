@@ -548,8 +548,11 @@ def bench_main(args):
             mine = {"rank": rank, "device": local, "name": props.name, "uuid": str(getattr(props, "uuid", "")),
                     "rungs": [int(r0), int(r0 + nloc)], "walkers": int(eng.W), "walker_begin": int(eng.walker_begin)}
             seen = [None] * world
-            dist.all_gather_object(seen, mine)
-            evidence["ranks"] = seen
+            try:      # (over the host-side group where there is one: a record of who ran must not be what stops the run)
+                dist.all_gather_object(seen, mine, group=ctl)
+                evidence["ranks"] = seen
+            except Exception as ex:   # noqa: BLE001
+                evidence["ranks"] = "unavailable (%s: %s)" % (type(ex).__name__, ex)
         meet()
         t0 = time.perf_counter()
         lad.step(args.steps)
