@@ -1543,7 +1543,8 @@ static int ladder_steps(ptm_engine* e, int n) {
   if (prof_on && !e->lad_prof && (rc = dalloc(&e->lad_prof, (size_t)grid * 8))) return rc;
   int done = 0;
   while (done < n) {
-    const int k = n - done;
+    // (one launch walks at most 2^24 steps: its step-counted flags and LDS counters are ints, and a launch should end some day)
+    const int k = n - done < (1 << 24) ? n - done : (1 << 24);
     Dev p = make_dev(e);
     LadderArgs a;
     a.nsteps = k; a.NB = NB; a.ms = e->ms; a.thresh = e->thresh;
