@@ -49,7 +49,9 @@ __device__ __forceinline__ u32x4 draw_block(uint64_t seed, int tag, uint32_t str
 }
 
 // (k + 0.5) / 2^32: the open-interval map of MotherOfAll::Next (newran1.cxx:432), so log(u) is finite
-__device__ __forceinline__ double u01(uint32_t k) { return ((double)k + 0.5) * (1.0 / 4294967296.0); }
+// (one fma: k + 0.5 is exact and the scale a power of two, so fma(k, 2^-32, 2^-33) rounds the same real number -- the same bits as
+//  the checker's add-then-multiply, one instruction less)
+__device__ __forceinline__ double u01(uint32_t k) { return __builtin_fma((double)k, 1.0 / 4294967296.0, 0.5 / 4294967296.0); }
 
 // ------------------------------------------------------------------------------------------------
 // log / exp: classic argument reduction + polynomial (coefficients of the FreeBSD/fdlibm e_log.c /
@@ -304,7 +306,8 @@ template <class Tab>   // Tab: pointer to the BM_TABLE image (LDS or global)
 __device__ __forceinline__ void boxmuller_finish(double r, uint32_t k2, Tab tab, double& z0, double& z1) {
   const uint32_t idx = (k2 >> 21) & 1023u;
   const bm_d2 sc = *reinterpret_cast<const bm_d2*>(tab + 512 + 2 * idx);
-  const double d = ((double)((int)(k2 & 0x1FFFFFu) - (1 << 20)) + 0.5) * 1.4629180792671596e-09;  // 2 pi / 2^32
+  // 2 pi / 2^32 x (i + 0.5): i + 0.5 is exact, so fma(i, c, c / 2) rounds the same real number as the checker's (i + 0.5) * c
+  const double d = __builtin_fma((double)((int)(k2 & 0x1FFFFFu) - (1 << 20)), 1.4629180792671596e-09, 0.5 * 1.4629180792671596e-09);
   const double d2 = d * d;
   const double sd = __builtin_fma(d * d2, __builtin_fma(d2, 1.0 / 120.0, -1.0 / 6.0), d);
   const double cm1 = d2 * __builtin_fma(d2, 1.0 / 24.0, -0.5);
