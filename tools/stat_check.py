@@ -11,7 +11,10 @@ from ptmcmc_amd.problems import GaussianProblem
 
 worst = 0.0
 for D, Nt, W, kind, ev, burn in ((8, 12, 8192, E.PROP_LOWER, 0.0, 1500), (32, 8, 4096, E.PROP_LOWER, 0.0, 2500), (32, 8, 4096, E.PROP_LOWER, 0.01, 2500),
-                               (12, 10, 60, E.PROP_DENSE, 0.0, 3000)):
+                               (12, 10, 60, E.PROP_DENSE, 0.0, 3000),
+                               (64, 6, 2048, E.PROP_LOWER, 0.0, 4000), (128, 5, 1024, E.PROP_LOWER, 0.01, 60000),  # the 64- / 128-dimension MFMA kernels (from 100 sigma out, 128 dimensions take their time)
+                               (32, 40, 3, E.PROP_LOWER, 0.0, 3000)):                                              # the persistent ladder kernel
+
     pr = GaussianProblem(D, Nt, 1e2)
     eng = E.Engine(D, Nt, W, swap_rate=0.2)
     pr.configure(eng, kind)
@@ -20,7 +23,7 @@ for D, Nt, W, kind, ev, burn in ((8, 12, 8192, E.PROP_LOWER, 0.0, 1500), (32, 8,
     eng.init_from_prior()
     eng.step(burn); eng.sync()
     acc = np.zeros((Nt, D, D)); n = 0
-    reps = 40 if W >= 1000 else 1500
+    reps = (40 if D <= 64 else 120) if W >= 1000 else 1500
     for k in range(reps):
         eng.step(25 if W >= 1000 else 10); eng.sync()
         X = eng.states().reshape(Nt, W, D)
@@ -34,6 +37,6 @@ for D, Nt, W, kind, ev, burn in ((8, 12, 8192, E.PROP_LOWER, 0.0, 1500), (32, 8,
         errs.append(np.abs((C - want) / np.outer(s, s)).max())
     worst = max(worst, max(errs[:max(1, Nt // 2)]))
     print("D=%d %dx%d %s ladder, kernel %s: max |C - cov/beta| / (sigma_i sigma_j): cold rung %.4f, all rungs %.4f  (samples per rung %d)"
-          % (D, Nt, W, "evolving" if ev else "fixed", eng.sweep_kernel_name, errs[0], max(errs), n), flush=True)
+          % (D, Nt, W, "evolving" if ev else "fixed", eng.step_kernel_name, errs[0], max(errs), n), flush=True)
     eng.close()
 print("worst (colder half):", worst)
