@@ -31,5 +31,5 @@ if __name__ == "__main__":
     eng.sweep(2); eng.sync()
     h.update(np.ascontiguousarray(eng.states()).tobytes())
     acc = int(eng.naccept.sum() - eng.Nc)
-    print("ok %s %s accepts %d swaps %d" % (h.hexdigest(), eng.sweep_kernel_name, acc, int(eng.swap_counts()[1].sum())))
+    print("ok %s %s | %s accepts %d swaps %d" % (h.hexdigest(), eng.sweep_kernel_name, eng.step_kernel_name, acc, int(eng.swap_counts()[1].sum())))
     eng.close()

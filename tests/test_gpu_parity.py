@@ -1373,6 +1373,25 @@ def test_matrix_core_kernels_equal_the_vector_kernels_at_sizes_the_checker_canno
     assert int(outs[0][outs[0].index("accepts") + 1]) > 0 and int(outs[0][outs[0].index("swaps") + 1]) > 0
 
 
+@pytest.mark.parametrize("D,Nt,W,kind,nsteps", [(32, 1024, 1, "lower", 20000), (16, 300, 3, "diag", 20000), (24, 90, 5, "dense", 20000)])
+def test_persistent_ladder_kernel_equals_the_two_launch_path_over_many_steps(D, Nt, W, kind, nsteps):
+    """The persistent ladder kernel's workgroups hand their rungs to each other through flags and counters, thousands of times per
+    launch: a race there would show up rarely.  20 000 steps in two launches against the two-launch path (PTM_LADDER=0, which the
+    CPU checker pins step by step) -- digest of states, llikes, counters and swap bookkeeping, each engine in a process of its own."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    outs = []
+    for env in ({}, {"PTM_LADDER": "0"}):
+        r = subprocess.run([sys.executable, os.path.join(here, "hash_worker.py"), str(D), str(Nt), str(W), kind, str(nsteps)],
+                           env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0 and r.stdout.startswith("ok "), r.stdout[-2000:] + r.stderr[-3000:]
+        outs.append(r.stdout.split())
+    assert outs[0][1] == outs[1][1], (outs[0], outs[1])
+    assert int(outs[0][outs[0].index("swaps") + 1]) > 0
+
+
 @pytest.mark.parametrize("W,cap", [(3, 6), (4096, 4)])
 def test_reads_in_one_batch_equal_the_same_reads_one_by_one(W, cap):
     """ptm_batch_begin / ptm_batch_end: the reads between them return what the same calls return outside a bracket (small
