@@ -207,6 +207,20 @@ def run_single(args):
                            "memory: flag and window round trips of ~0.8 us each (DESIGN.md section 3.8)",
                            "hbm_frac_if_it_were_streaming": NT * n1 / best * algorithmic_bytes(D) / (HBM_PEAK_GBS * 1e9)}}
         e1.close()
+    # ... and the headline workload with EVOLVING ladders (pry_temps after every accepted exchange: the reference sampler's
+    # default, ptmcmc.cc:389,512): the same population, per-ladder temperatures
+    evolving = None
+    if not args.no_w1 and W == DEFAULT_WALKERS:
+        e2 = E.Engine(D, NT, W, seed=SEED, swap_rate=SWAP_RATE, add_every_n=100)
+        pr.configure(e2, E.PROP_LOWER)
+        e2.set_evolve_temps(0.01)
+        e2.init_from_prior()
+        e2.step(120); e2.sync()
+        t2 = time.perf_counter()
+        e2.step(20); e2.sync()
+        d2 = time.perf_counter() - t2
+        evolving = {"evolve_rate": 0.01, "value": nchains * 20 / d2, "ms_per_step": d2 / 20 * 1e3, "kernel": e2.sweep_kernel_name}
+        e2.close()
     out = {
         "metric": "ladder-wide MH steps/sec (D=32 Gaussian, 1024 temps)",
         "value": value, "unit": "MH steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
@@ -220,6 +234,7 @@ def run_single(args):
         "device_ms_per_step": ms_dev / args.steps,
         "mh_accept_rate": acc, "swap_accept_rate": float(a.sum()) / max(1, float(t.sum())),
         "w1": w1,
+        "evolving_ladders": evolving,
     }
     if not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(pr)
