@@ -1514,6 +1514,10 @@ static bool ladder_applies(ptm_engine* e, long long* grid_out = nullptr, size_t*
 static int ladder_steps(ptm_engine* e, int n) {
   long long grid = 0;
   size_t lds = 0;
+  // A launch of the persistent kernel is synchronous (its outcome is read back) and stages its tables: ~36 us on top of the steps
+  // (tools/step1_probe.py: ptm_step(1) 42 us, (2) 24, (4) 15, (64) 6 per step against the two-launch path's 19.6 whatever n).  A host
+  // loop that steps one at a time keeps the asynchronous two-launch path.
+  if (n < 4) return 0;
   if (!ladder_applies(e, &grid, &lds)) return 0;
   const int R = 256 / e->DP, NB = (e->Nt + R - 1) / R;
   const bool diag = e->prop_kind == PTM_PROP_DIAG;
