@@ -1490,6 +1490,9 @@ static int fused_steps(ptm_engine* e, int n) {
 // Plain workload only; PTM_LADDER=0 keeps the two-launch path.  Returns the steps taken (0: not this engine's case), or a negative
 // status.
 // does a ptm_step call of this engine go through the persistent ladder kernel?  (grid: its workgroups; lds: their LDS)
+#ifndef PTM_LADDER_MIN_STEPS
+#define PTM_LADDER_MIN_STEPS 1
+#endif
 static bool ladder_applies(ptm_engine* e, long long* grid_out = nullptr, size_t* lds_out = nullptr) {
   static const bool ladder_ok = [] { const char* v = getenv("PTM_LADDER"); return !(v && *v == '0'); }();
   if (!ladder_ok || (e->DP != 16 && e->DP != 32) || e->Nt < 2 || e->nloc != e->Nt || e->cfg.time_kernels || e->evolve_rate > 0 || e->hist.rungs ||
@@ -1514,10 +1517,9 @@ static bool ladder_applies(ptm_engine* e, long long* grid_out = nullptr, size_t*
 static int ladder_steps(ptm_engine* e, int n) {
   long long grid = 0;
   size_t lds = 0;
-  // A launch of the persistent kernel is synchronous (its outcome is read back) and stages its tables: ~36 us on top of the steps
-  // (tools/step1_probe.py: ptm_step(1) 42 us, (2) 24, (4) 15, (64) 6 per step against the two-launch path's 19.6 whatever n).  A host
-  // loop that steps one at a time keeps the asynchronous two-launch path.
-  if (n < 4) return 0;
+  // A launch of the persistent kernel stages its tables and loads its chains: a few microseconds on top of its steps
+  // (tools/step1_probe.py).  A host loop that steps one at a time keeps the two-launch path.
+  if (n < PTM_LADDER_MIN_STEPS) return 0;
   if (!ladder_applies(e, &grid, &lds)) return 0;
   const int R = 256 / e->DP, NB = (e->Nt + R - 1) / R;
   const bool diag = e->prop_kind == PTM_PROP_DIAG;
@@ -1561,27 +1563,32 @@ static int ladder_steps(ptm_engine* e, int n) {
     a.spin_limit = 300000000ll;   // 3 s of the 100 MHz wall clock: a neighbour that is not there by then never will be
     HIPCHK(hipMemsetAsync(e->lad_flags, 0, ((size_t)grid + 16 + (size_t)e->W) * sizeof(int), e->stream));
     HIPCHK(e->DP == 16 ? launch_ladder_16(p, a, diag, (int)grid, lds, e->stream) : launch_ladder_32(p, a, diag, (int)grid, lds, e->stream));
-    int ctl[4] = {0, 0, 0, 0};
-    HIPCHK(hipMemcpyAsync(ctl, e->lad_ctl, sizeof ctl, hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipStreamSynchronize(e->stream));
     e->ladder_launches++;
-    if (e->lad_prof && ctl[1] > 0) {   // diagnostics: mean microseconds per step and phase over the workgroups, and the slowest workgroup's
-      std::vector<long long> pr((size_t)grid * 8);
-      HIPCHK(hipMemcpy(pr.data(), e->lad_prof, pr.size() * 8, hipMemcpyDeviceToHost));
-      static const char* const phase[7] = {"", "publish", "draws | random blocks", "filter | offsets", "window | Metropolis", "commit + trials", "rows"};
-      fprintf(stderr, "[ladder kernel] %d steps, %lld workgroups; us per step (mean / max over workgroups):", ctl[1], grid);
-      for (int k = 1; k < 7; ++k) {
-        double sum = 0, mx = 0;
-        for (long long g2 = 0; g2 < grid; ++g2) { const double v = pr[(size_t)g2 * 8 + k] * 0.01 / ctl[1]; sum += v; if (v > mx) mx = v; }
-        fprintf(stderr, " %s %.2f/%.2f", phase[k], sum / grid, mx);
+    int took = k;
+    if (e->lad_prof) {
+      // diagnostics (PTM_LADDER_PROF): wait for the launch, read its outcome and its phase clocks -- mean microseconds per step and
+      // phase over the workgroups, and the slowest workgroup's
+      int ctl[4] = {0, 0, 0, 0};
+      HIPCHK(hipMemcpyAsync(ctl, e->lad_ctl, sizeof ctl, hipMemcpyDeviceToHost, e->stream));
+      HIPCHK(hipStreamSynchronize(e->stream));
+      if (ctl[1] > 0) {
+        std::vector<long long> pr((size_t)grid * 8);
+        HIPCHK(hipMemcpy(pr.data(), e->lad_prof, pr.size() * 8, hipMemcpyDeviceToHost));
+        static const char* const phase[7] = {"", "publish", "draws | random blocks", "filter | offsets", "window | Metropolis", "commit + trials", "rows"};
+        fprintf(stderr, "[ladder kernel] %d steps, %lld workgroups; us per step (mean / max over workgroups):", ctl[1], grid);
+        for (int q = 1; q < 7; ++q) {
+          double sum = 0, mx = 0;
+          for (long long g2 = 0; g2 < grid; ++g2) { const double v = pr[(size_t)g2 * 8 + q] * 0.01 / ctl[1]; sum += v; if (v > mx) mx = v; }
+          fprintf(stderr, " %s %.2f/%.2f", phase[q], sum / grid, mx);
+        }
+        fprintf(stderr, "\n");
       }
-      fprintf(stderr, "\n");
+      if (ctl[0] != 0 || ctl[1] != k) return fail(PTM_ERR_HIP, "the persistent ladder kernel gave up waiting for a neighbouring workgroup (is the device shared?); "
+                                                              "PTM_LADDER=0 selects the two-launch path");
+      e->ladder_whole_steps += ctl[2];
     }
-    if (ctl[0] != 0 || ctl[1] < 0) return fail(PTM_ERR_HIP, "the persistent ladder kernel gave up waiting for a neighbouring workgroup (is the device shared?); "
-                                                             "PTM_LADDER=0 selects the two-launch path");
-    const int took = ctl[1];
-    e->ladder_whole_steps += ctl[2];
-    if (took != k) return fail(PTM_ERR_HIP, "the persistent ladder kernel returned after %d of %d steps", took, k);
+    // (otherwise the launch is ASYNCHRONOUS like every other step: a workgroup that gave up waiting for a neighbour -- a shared
+    //  device, a grid that is not resident -- raises bit 32 of the deferred error word, which ptm_sync reports)
     e->step += (uint64_t)took;
     done += took;
     e->log_head = (e->log_head + 1) % PTM_LOG_RING;   // (the last step's candidate log sits in the slot handed over)
@@ -1624,6 +1631,8 @@ extern "C" int ptm_sync(ptm_engine* e) {
                             "ptm_config.exchange_row_capacity slots (%d)", e->row_cap);
   if (flag & 8) return fail(PTM_ERR_FAR_MOVE, "a boundary message carried a row this shard did not expect (neighbour shards out of step?)");
   if (flag & 16) return fail(PTM_ERR_UNSUPPORTED, "a recorded rung's in-between history row belongs to the neighbour shard");
+  if (flag & 32) return fail(PTM_ERR_HIP, "the persistent ladder kernel gave up waiting for a neighbouring workgroup (is the device shared?); "
+                                          "PTM_LADDER=0 selects the two-launch path");
   return PTM_OK;
 }
 

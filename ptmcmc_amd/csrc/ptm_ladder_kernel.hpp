@@ -524,6 +524,8 @@ __global__ __launch_bounds__(LADDER_THREADS) void ladder_persistent_kernel(const
     for (int k = 0; k < 7; ++k) a.prof[(size_t)blk * 8 + k] = tick_sum[k];
 #undef PTM_LADDER_TICK
   if (L == 0 && tid == 0) { a.ctl[1] = aborted ? -1 : done; a.ctl[2] = nslow; }
+  // (a launch is asynchronous: a workgroup that gave up says so in the engine's deferred error word, read at the next ptm_sync)
+  if (aborted && tid == 0) atomicOr(p.err, 32);
 }
 
 }  // namespace ptm
