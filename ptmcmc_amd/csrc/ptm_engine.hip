@@ -85,6 +85,7 @@ struct ptm_engine {
   // evolving ladders (ptm_set_evolve_temps): per-ladder inverse temperatures [W][Nt] and their chain-indexed image [Nc]
   double evolve_rate = 0, evolve_cut = -1;
   double *beta_w = nullptr, *betaC = nullptr, *beta_add = nullptr;
+  bool betaC_stale = false;   // the chain-indexed image of evolving temperatures lags the ladder-major one (ensure_betaC)
   // host copies / flags
   int has_bounds = 0, origin_valid = 1, all_uniform = 1, has_mean = 0, have_target = 0, have_ladder = 0,
       have_prop = 0, have_state = 0, prop_kind = KIND_DIAG, prop_stride = 0, any_oned = 0, bounds_box = 1;
@@ -216,6 +217,8 @@ extern "C" int ptm_engine_destroy(ptm_engine* e);
 extern "C" int ptm_shard_finalize(ptm_engine* e);
 static int build_engine(ptm_engine* e, const ptm_config* cfg);
 static int launch_beta_transpose(ptm_engine* e);
+static int ensure_betaC(ptm_engine* e);
+static bool lean_ev_sweeps(const ptm_engine* e);
 static int fill_evolving_ladders(ptm_engine* e);
 
 extern "C" int ptm_engine_create(const ptm_config* cfg, ptm_engine** out) {
@@ -943,7 +946,7 @@ static Dev make_dev(ptm_engine* e) {
   p.P2 = e->P2; p.mean = e->mean; p.has_mean = e->has_mean; p.like0 = e->like0;
   p.beta = e->beta; p.prop = e->prop; p.prop_tiles = e->prop_tiles; p.P2_tiles = e->P2_tiles; p.box_row = e->box_row; p.onedfrac = e->onedfrac; p.prop_stride = e->prop_stride; p.any_oned = e->any_oned;
   p.mix_K = e->mix_K; p.mix = e->mix;
-  p.betaC = e->betaC; p.beta_add = e->beta_add;
+  p.betaC = e->betaC; p.beta_add = e->beta_add; p.beta_w = e->beta_w;
   p.x = e->x; p.ll = e->ll; p.lp = e->lp;
   p.ntries = e->ntries; p.naccept = e->naccept; p.last_type = e->last_type; p.nhist = e->nhist;
   p.touch = e->touch; p.err = e->err;
@@ -966,6 +969,11 @@ static SweepSel sweep_sel(const ptm_engine* e) {
               !e->hist.rungs && !e->map.rungs;
   s.callback = e->cb != nullptr;
   return s;
+}
+
+static bool lean_ev_sweeps(const ptm_engine* e) {
+  static const bool forced = [] { const char* v = getenv("PTM_FORCE_VALU"); return v && *v && *v != '0'; }();
+  return e->DP == 32 && !forced && sweep_sel(e).lean_ev;
 }
 
 // the compacted sweep counts a step's add_state calls for all chains at once: bring nhist up to date before anything reads it
@@ -998,6 +1006,7 @@ static int launch_sweep(ptm_engine* e, int rung0 = 0, int nr = -1, bool last = t
     e->kev_used += 2;
   }
   const SweepSel sel = sweep_sel(e);
+  if (e->betaC_stale && !lean_ev_sweeps(e)) { int rc = ensure_betaC(e); if (rc) return rc; }   // (a build that reads the chain-indexed temperatures)
   // Compacted sweep: after an exchange phase ~1/6 of a long ladder's chains make no move; the lean MFMA build on a big
   // population then visits the moving chains only (partition_kernel packs them per rung).  PTM_COMPACT=0 switches it off.
   static const bool compact_ok = [] { const char* v = getenv("PTM_COMPACT"); return !(v && *v == '0'); }();
@@ -1085,6 +1094,7 @@ static int launch_sweep(ptm_engine* e, int rung0 = 0, int nr = -1, bool last = t
       std::vector<double> hll(Nc), hlp(Nc), hbeta(Nc), out;
       HIPCHK(hipMemcpy(hll.data(), e->ll, Nc * 8, hipMemcpyDeviceToHost));
       HIPCHK(hipMemcpy(hlp.data(), e->lp, Nc * 8, hipMemcpyDeviceToHost));
+      { int rc2 = ensure_betaC(e); if (rc2) return rc2; }
       if (e->betaC) HIPCHK(hipMemcpy(hbeta.data(), e->betaC, Nc * 8, hipMemcpyDeviceToHost));
       std::vector<size_t> vp;
       for (size_t c = 0; c < Nc; ++c)
@@ -1144,6 +1154,7 @@ static int fold_swap_log(ptm_engine* e) {
 
 // chain-indexed image of the evolving ladders' temperatures, for the sweep kernels
 static int launch_beta_transpose(ptm_engine* e) {
+  e->betaC_stale = false;
   if (e->nloc != e->Nt) {   // a rung shard: its own rungs' temperatures out of the whole ladders'
     hipLaunchKernelGGL(beta_local_kernel, dim3((unsigned)(((size_t)e->Nc + 255) / 256)), dim3(256), 0, e->stream, e->beta_w, e->betaC, e->W, e->Nt, e->r0, e->nloc);
     HIPCHK(hipGetLastError());
@@ -1152,6 +1163,12 @@ static int launch_beta_transpose(ptm_engine* e) {
   hipLaunchKernelGGL(beta_transpose_kernel, dim3((e->Nt + 31) / 32, (e->W + 31) / 32), dim3(256), 0, e->stream, e->beta_w, e->betaC, e->W, e->Nt);
   HIPCHK(hipGetLastError());
   return PTM_OK;
+}
+// the chain-indexed image, for everybody but the lean MFMA build of evolving ladders (which reads the ladder-major one)
+static int ensure_betaC(ptm_engine* e) {
+  if (!e->betaC_stale) return PTM_OK;
+  e->betaC_stale = false;
+  return launch_beta_transpose(e);
 }
 
 static Decide make_decide(ptm_engine* e, const double* ll_below, const double* ll_above, int H, double* send_up, double* send_down,
@@ -1220,7 +1237,10 @@ static int launch_decide(ptm_engine* e, const double* ll_below, const double* ll
     e->log_head = (e->log_head + 1) % PTM_LOG_RING;
     ++e->log_pending;
   }
-  if (e->evolve_rate > 0 && !beta_direct) { int rc = launch_beta_transpose(e); if (rc) return rc; }
+  if (e->evolve_rate > 0 && !beta_direct) {
+    if (lean_ev_sweeps(e)) e->betaC_stale = true;   // (nobody reads the chain-indexed image in such a step)
+    else { e->betaC_stale = false; int rc = launch_beta_transpose(e); if (rc) return rc; }
+  }
   if (wide) return PTM_OK;   // the 256-thread decide kernel has applied the moves itself
   // a pick lists at most four row moves (two rungs, each a local move and / or a departure) and one in-between row each for
   // the history and the MAP: short ladders
@@ -2004,6 +2024,7 @@ extern "C" int ptm_get_array(ptm_engine* e, int which, void* out) {
       const unsigned char *sl, *sp, *sb = nullptr;
       FETCH(sl, e->ll, Nc * 8);
       FETCH(sp, e->lp, Nc * 8);
+      { int rc2 = ensure_betaC(e); if (rc2) return rc2; }
       if (e->betaC) FETCH(sb, e->betaC, Nc * 8);
       e->fetch_after.push_back([=] {
         const double *ll = (const double*)sl, *lp = (const double*)sp, *bc = (const double*)sb;

@@ -105,6 +105,8 @@ struct Dev {
   const double* beta;      // [Nt] global
   const double* betaC;     // [Nc] per-chain inverse temperatures once the ladders evolve (evolve_temps), else null; the
                            // SIMPLE / GEN 0 / GEN 1 builds never see it
+  const double* beta_w;    // [W][Nt] the same, ladder-major: what the exchange kernel keeps.  The lean MFMA build for evolving
+                           // ladders reads it directly (strided: free in an issue-bound kernel) and spares the step the transposition
   const double* beta_add;  // [Nc] evolving ladders with history / MAP tracking: the inverse temperature a rung touched by the
                            // exchange phase had at its LAST add_state of that phase (between two pries of the step)
   const double* prop;      // [nloc][prop_stride]  factor, dense column-major [col][row] (DP*DP), or sigmas (DP)

@@ -221,7 +221,9 @@ __global__ __launch_bounds__(256, (GEN == 0 ? PTM_MFMA_WAVES : ((PTM_MFMA_GG == 
   const unsigned int nhist0 = CPT ? 0u : p.nhist[c];
   // (a per-chain beta in the plain GEN 1 build would cost its fixed-ladder users 4 %: evolving ladders have their own)
   constexpr bool PERCHAIN = GEN == 2 || EV;
-  const double beta = (PERCHAIN && p.betaC) ? p.betaC[c] : as_c(p.beta)[rg];
+  // (the lean build of evolving ladders takes its temperature from the ladder-major image the exchange kernel keeps: the chain-indexed
+  //  one is then brought up to date only when somebody else asks for it)
+  const double beta = (GEN == 0 && EV) ? p.beta_w[(size_t)wl * p.Nt + rg] : ((PERCHAIN && p.betaC) ? p.betaC[c] : as_c(p.beta)[rg]);
   // log of the chain's accept uniform (block 0 of its stream): drawn here once for all 64 chains -- the Metropolis test
   // itself runs per pass on half the lanes, and this is its expensive part.  (The reference draws the uniform only when
   // logH < 0, chain.cc:998; a counter-based stream makes the draw free of side effects, so drawing it always is the same.)
