@@ -158,16 +158,10 @@ struct Move {
   const double* beta;
   int r0;
 };
-template <int MV, int WPB, bool HIST>   // HIST: history destinations exist (compiled apart: the hot build carries none of it)
-__global__ __launch_bounds__(64 * WPB, MV > 64 ? 1 : 4) void move_kernel(const Move p) {
-  __shared__ int s_all[WPB][2][MV];
-  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int w = blockIdx.x * WPB + wv;
-  if (w >= p.W) return;
-  const int nmv = p.mv_n[w];
-  if (nmv <= 0 || nmv > MV) return;
-  int* s_src = s_all[wv][0];
-  int* s_dst = s_all[wv][1];   // >= 0 row slot, -3 nothing, <= -4: slot (-d-4)>>1 of the up (bit 0 clear) / down message
+// One ladder's listed moves, by one wave (s_src / s_dst: the wave's [MV] ints of LDS each).
+template <int MV, bool HIST>   // HIST: history destinations exist (compiled apart: the hot build carries none of it)
+__device__ __forceinline__ void move_ladder(const Move& p, const int w, const int nmv, int* s_src, int* s_dst, const int lane) {
+  // s_dst: >= 0 row slot, -3 nothing, <= -4: slot (-d-4)>>1 of the up (bit 0 clear) / down message
   const int DP = p.DP, RD = DP + ROW_EXTRA;
   // the list goes through LDS (this wave's private part: no block barrier) so that the row gathers below are not
   // chained behind index loads from memory
@@ -236,6 +230,25 @@ __global__ __launch_bounds__(64 * WPB, MV > 64 ? 1 : 4) void move_kernel(const M
     }
   }
   if (lane == 0) p.mv_n[w] = 0;
+  __builtin_amdgcn_wave_barrier();   // (the wave's LDS lists are reused for its next ladder)
+}
+// A wave looks at the list lengths of 64 consecutive ladders in ONE load and works through the few that have a list: the ladders
+// whose moves fitted their exchange block's registers (nearly all) cost nothing here -- a block per ladder spent 63 us at the
+// 8-GPU size's 131072 ladders finding that out.
+template <int MV, int WPB, bool HIST>
+__global__ __launch_bounds__(64 * WPB, MV > 64 ? 1 : 4) void move_kernel(const Move p) {
+  __shared__ int s_all[WPB][2][MV];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int base = (blockIdx.x * WPB + wv) * 64;
+  if (base >= p.W) return;
+  const int n = base + lane < p.W ? p.mv_n[base + lane] : 0;
+  unsigned long long todo = __builtin_amdgcn_ballot_w64(n > 0 && n <= MV);
+  while (todo) {
+    const int k = __builtin_ctzll(todo);
+    todo &= todo - 1;
+    const int nmv = __builtin_amdgcn_readlane(n, k);
+    move_ladder<MV, HIST>(p, base + k, nmv, s_all[wv][0], s_all[wv][1], lane);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -1254,8 +1254,9 @@ static int launch_decide(ptm_engine* e, const double* ll_below, const double* ll
   m.map = e->map; m.beta = e->beta; m.r0 = e->r0;
   // (64-thread form only) ladders whose list did not fit the decide block's registers: rare, the kernel exits at once
   // for everybody else
-  if (e->hist.rungs || e->map.rungs) hipLaunchKernelGGL((move_kernel<MVCAP, 1, true>), dim3(e->W), dim3(64), 0, e->stream, m);
-  else hipLaunchKernelGGL((move_kernel<MVCAP, 1, false>), dim3(e->W), dim3(64), 0, e->stream, m);
+  const dim3 mgrid((unsigned)((e->W + 63) / 64));   // (a wave scans the list lengths of 64 ladders)
+  if (e->hist.rungs || e->map.rungs) hipLaunchKernelGGL((move_kernel<MVCAP, 1, true>), mgrid, dim3(64), 0, e->stream, m);
+  else hipLaunchKernelGGL((move_kernel<MVCAP, 1, false>), mgrid, dim3(64), 0, e->stream, m);
   HIPCHK(hipGetLastError());
   return PTM_OK;
 }
