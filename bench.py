@@ -36,13 +36,14 @@ LAYOUT_NOTE = ("states are contiguous rows per chain (AoS, in MFMA accumulator o
                "and the precision matrix are read as MFMA operand tiles from L2 / LDS (north_star names SoA planes and an LDS-staged "
                "factor: both were measured and lost, DESIGN.md section 2 / 3.1)")
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+NOMINAL_F64_FMA_TFS = 70.0   # what ptm_calibrate's f64 fma loop reaches on the usual device of this pool (profiles/r04_calibration.json)
 
 
 def algorithmic_bytes(dim):
     return 16 * dim + 44   # r+w state, beta, r+w lpost & llike, accept/type flag
 
 
-def roofline_record(kernel, kernel_avg_ms, launches, moved_per_launch, chains_per_gpu, value, n_gpus, traffic):
+def roofline_record(kernel, kernel_avg_ms, launches, moved_per_launch, chains_per_gpu, value, n_gpus, traffic, kt=None, calibration=None):
     """The roofline object of the JSON line, for the dominant kernel (the fused MH sweep).
 
     achieved   = B(D) x (chains the kernel actually worked on per launch) / (its mean launch duration, HIP events on the engine's
@@ -55,7 +56,18 @@ def roofline_record(kernel, kernel_avg_ms, launches, moved_per_launch, chains_pe
                  traffic_frac = traffic / kernel time / peak: the real HBM rate."""
     B = algorithmic_bytes(D)
     achieved = B * moved_per_launch / (kernel_avg_ms * 1e-3) / 1e9
-    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+    spread = {}
+    if kt is not None and len(kt):
+        # the launches one by one: a box that throttles shows as a max far from the median, a slow box as all three moved together
+        spread = {"kernel_min_ms": float(np.min(kt)), "kernel_median_ms": float(np.median(kt)), "kernel_max_ms": float(np.max(kt)),
+                  "kernel_ms_series": [round(float(v), 4) for v in kt[:200]]}
+    if calibration:
+        # the same bytes against what a plain copy kernel reached on THIS device minutes before (calibration.copy_GBs), and the
+        # kernel's time scaled to a nominal device: it is bound by f64 issue (DESIGN.md 3.1), so its time goes with the f64 fma
+        # rate the device holds (calibration.f64_fma_TFs; NOMINAL_F64_FMA_TFS is the pool's usual figure)
+        spread["frac_of_measured_copy"] = achieved / calibration["copy_GBs"]
+        spread["kernel_avg_ms_at_nominal_f64_rate"] = kernel_avg_ms * calibration["f64_fma_TFs"] / NOMINAL_F64_FMA_TFS
+    return {**spread, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": (traffic["bytes"] if traffic else None),
             "traffic_frac": (traffic["bytes"] / (kernel_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if traffic else None),
             "traffic_detail": traffic,
@@ -167,10 +179,20 @@ def run_single(args):
     pr.configure(eng, E.PROP_LOWER)
     eng.init_from_prior()
     settle(eng)
+    # what THIS device gives a streaming copy and an f64 fma loop right now (a few hundred ms, before anything is timed): boxes of
+    # the pool differ by several per cent in the clock they hold under an f64 load, and the sweep kernel is bound by f64 issue
+    calibration = None if args.no_calibration else eng.calibrate()
+    # The GPU must not idle between the warm-up and the timed steps: after ~20 ms without work the device drops its clocks and the
+    # next ~100 ms of kernels run up to 40 % slower (profiles/r04_sweep_duration_series.txt: 1.67, 2.14, 1.91, 1.75 ... 1.42 ms
+    # after every gap).  Round 3's line read 67 MB of counters back right here and so timed exactly that ramp.  So: everything the
+    # host wants to know first (two sums reduced on the device: 16 bytes), then clocks up again, warm-up, and straight into the
+    # timed steps with nothing but the contract's synchronisation in between.
+    settle(eng, 0.25)
+    eng.kernel_times()   # drop the records so far
     eng.step(args.warmup)
-    eng.sync()
+    tries0 = eng.counter_sums()[0]   # MH_chain::Ntries counts the Metropolis moves made (chain.cc:1005); exchanged rungs make none
     eng.kernel_times()   # drop warm-up records
-    tries0 = int(eng.ntries.astype(np.int64).sum())   # MH_chain::Ntries counts the Metropolis moves made (chain.cc:1005); exchanged rungs make none
+    eng.sync()
     eng.timer_start()
     t0 = time.perf_counter()
     eng.step(args.steps)
@@ -178,11 +200,11 @@ def run_single(args):
     eng.sync()
     wall = time.perf_counter() - t0
     kt = eng.kernel_times()
-    moved = (int(eng.ntries.astype(np.int64).sum()) - tries0) / float(args.steps)   # chains the sweep kernel worked on, per launch
+    moved = (eng.counter_sums()[0] - tries0) / float(args.steps)   # chains the sweep kernel worked on, per launch
     nchains = NT * W
     value = nchains * args.steps / wall
     roof = roofline_record(eng.sweep_kernel_name, float(kt.mean()), int(kt.size), moved, nchains, value, 1,
-                           measured_traffic(eng.sweep_kernel_name) if W == DEFAULT_WALKERS else None)
+                           measured_traffic(eng.sweep_kernel_name) if W == DEFAULT_WALKERS else None, kt=kt, calibration=calibration)
     acc = float((eng.naccept.sum() - eng.Nc)) / max(1, float((eng.ntries.sum() - eng.Nc)))
     t, a = eng.swap_counts()
     # latency-bound companion: the bare 1024-chain ladder (W = 1, the reference's own shape and BASELINE's literal one)
@@ -231,6 +253,7 @@ def run_single(args):
                    "layout": LAYOUT_NOTE,
                    "dim": D, "rungs": NT, "walkers": W, "chains": nchains, "sharding": "1 GPU holds the whole ladder"},
         "roofline": roof,
+        "calibration": calibration,
         "device_ms_per_step": ms_dev / args.steps,
         "mh_accept_rate": acc, "swap_accept_rate": float(a.sum()) / max(1, float(t.sum())),
         "w1": w1,
@@ -253,6 +276,7 @@ def main():
     ap.add_argument("--halo", type=int, default=None, help="llike halo depth (rungs) between shards (default: ptmcmc_amd.parallel.DEFAULT_HALO)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-w1", action="store_true", help="skip the 1024-chain latency companion")
+    ap.add_argument("--no-calibration", action="store_true", help="skip the copy / f64-fma calibration of the device (ptm_calibrate)")
     ap.add_argument("--shard", choices=("rungs", "walkers"), default="rungs",
                     help="N > 1: how the population is spread -- contiguous rung blocks with neighbour exchanges over RCCL (BASELINE's "
                          "configuration, the default), or whole ladders per GPU (no message at all; the form evolving ladders need)")

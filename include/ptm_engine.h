@@ -337,6 +337,23 @@ const char* ptm_sweep_kernel_name(ptm_engine* e);
  * "decide_kernel + <sweep kernel>" per step */
 const char* ptm_step_kernel_name(ptm_engine* e);
 
+/* Sums of MH_chain::Ntries and ::Naccept (chain.hh:151-152) over this engine's chains, reduced on the device: a measurement
+ * that wants "Metropolis moves made so far" reads 16 bytes instead of two arrays (and leaves the GPU no idle gap to drop
+ * its clocks in).  Waits for the engine's stream. */
+int ptm_get_counter_sums(ptm_engine* e, int64_t* ntries_sum, int64_t* naccept_sum);
+/* What this device gives a plain streaming copy and an f64 fma issue loop right now, on the engine's stream (bench.py prints it
+ * beside its roofline: devices of one pool differ by several per cent in the clock they hold under load, and a line without it
+ * cannot tell a slow box from a slow kernel).  copy_GBs: bytes read + written by a 16-byte-per-lane copy of copy_bytes / 2 bytes,
+ * best of 5; f64_fma_TFs: 2 flops x v_fma_f64 issued by four waves per SIMD on every CU; sclk_MHz: the shader clock held during
+ * that loop (s_memtime ticks per s_memrealtime tick x 100 MHz, median over workgroups).  A measurement aid like ptm_timer_*: it
+ * reads and writes scratch buffers of its own and touches nothing of the engine's state.  No reference counterpart. */
+typedef struct ptm_calibration {
+  double copy_GBs, copy_bytes, copy_ms;
+  double f64_fma_TFs, fma_ms, sclk_MHz;
+  int32_t compute_units, reserved;
+} ptm_calibration;
+int ptm_calibrate(ptm_engine* e, ptm_calibration* out);
+
 /* ---- verification hooks (used by tests/ only; evaluate device functions on arrays) ---------------------- */
 enum { PTM_FN_LOG = 0, PTM_FN_EXP = 1, PTM_FN_SIN_0_PI = 2, PTM_FN_COS_HPI = 3, PTM_FN_SQRT = 4, PTM_FN_DIV = 5,
        PTM_FN_SQRT_RAW = 6 };

@@ -347,4 +347,49 @@ __global__ void debug_sqrt_scan_kernel(unsigned long long* mismatches) {
   if (out) atomicAdd(mismatches + 1, out);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Calibration of the box a measurement runs on (ptm_calibrate; bench.py puts the figures beside its roofline): MI355X devices of
+// one pool differ by several per cent in the clock they hold under an f64 load, and a bench line cannot otherwise tell a slow
+// box from a slow kernel.  (1) a plain streaming copy, 16 bytes per lane, grid-stride: what HBM gives this device;
+// (2) an f64 fma issue loop, four waves per SIMD on every CU, eight independent chains per lane: what the f64 vector pipe
+// gives it, with the shader clock it held meanwhile (s_memtime ticks per 100 MHz s_memrealtime tick).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void calib_copy_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) dst[i] = src[i];
+}
+// sums of the MH_chain counters over the engine's chains (ptm_get_counter_sums): a measurement reads two numbers instead of two arrays
+__global__ __launch_bounds__(256) void counter_sums_kernel(const int* __restrict__ ntries, const int* __restrict__ naccept, size_t n, unsigned long long* __restrict__ out) {
+  __shared__ unsigned long long sh[2][4];
+  unsigned long long t = 0, a = 0;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) { t += (unsigned long long)(long long)ntries[i]; a += (unsigned long long)(long long)naccept[i]; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { t += __shfl_down(t, o); a += __shfl_down(a, o); }
+  if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = t; sh[1][threadIdx.x >> 6] = a; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(out, sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3]);
+    atomicAdd(out + 1, sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3]);
+  }
+}
+__global__ __launch_bounds__(256) void calib_fma_kernel(double* __restrict__ out, long long* __restrict__ clk, int iters) {
+  double d[8];
+  const double e0 = 1.0 - 1e-9 * (threadIdx.x & 7), e1 = 1e-12 * (1 + (threadIdx.x & 3));
+#pragma unroll
+  for (int i = 0; i < 8; ++i) d[i] = 1.0 + 1e-3 * (threadIdx.x + i);
+  __syncthreads();
+  const long long c0 = (long long)__builtin_amdgcn_s_memtime(), r0 = (long long)__builtin_amdgcn_s_memrealtime();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(d[i]) : "v"(e0), "v"(e1));
+  }
+  const long long c1 = (long long)__builtin_amdgcn_s_memtime(), r1 = (long long)__builtin_amdgcn_s_memrealtime();
+  double r = 0.0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r += d[i];
+  if (r == 12345.678) out[0] = r;   // (keeps the chains alive; never true)
+  if (threadIdx.x == 0) { clk[2 * blockIdx.x] = c1 - c0; clk[2 * blockIdx.x + 1] = r1 - r0; }
+}
+
 }  // namespace ptm

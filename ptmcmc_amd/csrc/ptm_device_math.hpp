@@ -17,6 +17,11 @@ namespace ptm {
 // (seed, chain identity, step), never on launch geometry.
 // ------------------------------------------------------------------------------------------------
 struct u32x4 { uint32_t v0, v1, v2, v3; };
+// rounds of the generator: ONE constant shared with the checker (oracle/ptm_oracle.c: PTM_PHILOX_ROUNDS); Random123 publishes
+// known answers for 7 and for 10 rounds (tests/test_oracle_golden.py holds both sets)
+#ifndef PTM_PHILOX_ROUNDS
+#define PTM_PHILOX_ROUNDS 10
+#endif
 
 // one round and its key bump (a kernel that spreads a block's ten rounds over its schedule calls this itself)
 struct philox_state { uint32_t c0, c1, c2, c3, k0, k1; };
@@ -34,7 +39,7 @@ __device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_
                                                 uint32_t k1) {
   philox_state s = {c0, c1, c2, c3, k0, k1};
 #pragma unroll
-  for (int r = 0; r < 10; ++r) philox_round(s);
+  for (int r = 0; r < PTM_PHILOX_ROUNDS; ++r) philox_round(s);
   return {s.c0, s.c1, s.c2, s.c3};
 }
 

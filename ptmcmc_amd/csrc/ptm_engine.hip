@@ -144,6 +144,7 @@ struct ptm_engine {
   pinned_vector<double> h_xprop, h_llnew;
   std::vector<double> h_batch, h_llbatch;
   unsigned char* h_gate = nullptr;   // view into h_xprop's tail
+  unsigned long long *sums = nullptr, *h_sums = nullptr;   // ptm_get_counter_sums
   // timing
   hipEvent_t t0 = nullptr, t1 = nullptr;
   std::vector<hipEvent_t> kev;  // pairs
@@ -219,6 +220,7 @@ static int build_engine(ptm_engine* e, const ptm_config* cfg);
 static int launch_beta_transpose(ptm_engine* e);
 static int ensure_betaC(ptm_engine* e);
 static bool lean_ev_sweeps(const ptm_engine* e);
+static int ladder_settle(ptm_engine* e);
 static int fill_evolving_ladders(ptm_engine* e);
 
 extern "C" int ptm_engine_create(const ptm_config* cfg, ptm_engine** out) {
@@ -425,9 +427,10 @@ extern "C" int ptm_engine_destroy(ptm_engine* e) {
   void* ptrs[] = {e->x, e->ll, e->lp, e->ntries, e->naccept, e->last_type, e->arr_below, e->arr_above, e->mv_src, e->mv_dst, e->mv_n,
                   e->err, e->nhist, e->swap_cnt, e->touch, e->swap_log, e->hist.x, e->hist.ll, e->hist.lp, e->hist.meta, e->map.lpost, e->map.ll, e->map.lp, e->map.x, e->blo,
                   e->bhi, e->ptype, e->bmin, e->bmax, e->plo, e->phi, e->pcoef, e->P2, e->mean, e->beta, e->prop, e->prop_tiles, e->P2_tiles, e->box_row, e->onedfrac, e->mix, e->beta_w, e->betaC, e->beta_add, e->hist.beta, e->xprop, e->lprior_new, e->llike_new, e->hastings, e->htype, e->hvalid, e->acc_out, e->cidx, e->ccnt,
-                  e->pub_x, e->lad_flags, e->lad_prof, e->shard_ends, e->redo_flag};
+                  e->pub_x, e->lad_flags, e->lad_prof, e->shard_ends, e->redo_flag, e->sums};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
+  if (e->h_sums) (void)hipHostFree(e->h_sums);
   for (hipEvent_t ev : e->kev) (void)hipEventDestroy(ev);
   if (e->t0) (void)hipEventDestroy(e->t0);
   if (e->t1) (void)hipEventDestroy(e->t1);
@@ -1535,6 +1538,7 @@ static bool ladder_applies(ptm_engine* e, long long* grid_out = nullptr, size_t*
   if (lds_out) *lds_out = lds;
   return true;
 }
+static int ladder_settle(ptm_engine* e) { (void)e; return PTM_OK; }
 static int ladder_steps(ptm_engine* e, int n) {
   long long grid = 0;
   size_t lds = 0;
@@ -2207,6 +2211,89 @@ extern "C" int ptm_get_kernel_times(ptm_engine* e, float* ms, int capacity, int*
   }
   *count = n;
   e->kev_used = 0;
+  return PTM_OK;
+}
+
+extern "C" int ptm_get_counter_sums(ptm_engine* e, int64_t* ntries_sum, int64_t* naccept_sum) {
+  if (!e) return fail(PTM_ERR_INVALID, "null engine");
+  NO_BATCH(e, "ptm_get_counter_sums");
+  int rc = ladder_settle(e);
+  if (rc) return rc;
+  if (!e->sums) {
+    HIPCHK(hipMalloc((void**)&e->sums, 16));
+    HIPCHK(hipHostMalloc((void**)&e->h_sums, 16, hipHostMallocDefault));
+  }
+  HIPCHK(hipMemsetAsync(e->sums, 0, 16, e->stream));
+  hipLaunchKernelGGL(counter_sums_kernel, dim3(1024), dim3(256), 0, e->stream, e->ntries, e->naccept, (size_t)e->Nc, e->sums);
+  HIPCHK(hipMemcpyAsync(e->h_sums, e->sums, 16, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  if (ntries_sum) *ntries_sum = (int64_t)e->h_sums[0];
+  if (naccept_sum) *naccept_sum = (int64_t)e->h_sums[1];
+  return PTM_OK;
+}
+
+extern "C" int ptm_calibrate(ptm_engine* e, ptm_calibration* out) {
+  if (!e || !out) return fail(PTM_ERR_INVALID, "null argument");
+  NO_BATCH(e, "ptm_calibrate");
+  memset(out, 0, sizeof *out);
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, e->device));
+  const int cus = prop.multiProcessorCount;
+  out->compute_units = cus;
+  hipEvent_t a = nullptr, b = nullptr;
+  HIPCHK(hipEventCreate(&a));
+  HIPCHK(hipEventCreate(&b));
+  // (1) the copy: 2.4 GB read + 2.4 GB written (the bench's state is 4.8 GB), far beyond the 256 MiB Infinity Cache
+  const size_t half = (size_t)2400 << 20;
+  void *src = nullptr, *dst = nullptr;
+  HIPCHK(hipMalloc(&src, half));
+  if (hipMalloc(&dst, half) != hipSuccess) { (void)hipFree(src); return fail(PTM_ERR_HIP, "ptm_calibrate: no room for its 4.8 GB of scratch"); }
+  HIPCHK(hipMemsetAsync(src, 0x3c, half, e->stream));
+  HIPCHK(hipMemsetAsync(dst, 0, half, e->stream));
+  float best = 1e30f;
+  for (int rep = 0; rep < 6; ++rep) {
+    HIPCHK(hipEventRecord(a, e->stream));
+    // (a block per 4 KB: tools/probes/copy_probe.hip -- 6.2 TB/s; a persistent grid-stride copy reaches 4.7-5.5, hipMemcpyAsync 4.7)
+    hipLaunchKernelGGL(calib_copy_kernel, dim3((unsigned)(half / 16 / 256)), dim3(256), 0, e->stream, (const uint4*)src, (uint4*)dst, half / 16);
+    HIPCHK(hipEventRecord(b, e->stream));
+    HIPCHK(hipEventSynchronize(b));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, a, b));
+    if (rep > 0 && ms < best) best = ms;   // (the first pass warms the clocks and the page tables)
+  }
+  HIPCHK(hipFree(src));
+  HIPCHK(hipFree(dst));
+  out->copy_bytes = 2.0 * (double)half;
+  out->copy_ms = best;
+  out->copy_GBs = 2.0 * (double)half / (best * 1e-3) / 1e9;
+  // (2) the f64 issue loop: 4 blocks of 256 threads per CU (four waves per SIMD), 8 chains x iters fma per lane
+  const int blocks = cus * 4, iters = 1 << 15;
+  double* sink = nullptr;
+  long long* clk = nullptr;
+  HIPCHK(hipMalloc((void**)&sink, 64));
+  HIPCHK(hipMalloc((void**)&clk, (size_t)blocks * 16));
+  best = 1e30f;
+  std::vector<long long> hc((size_t)blocks * 2);
+  for (int rep = 0; rep < 4; ++rep) {
+    HIPCHK(hipEventRecord(a, e->stream));
+    hipLaunchKernelGGL(calib_fma_kernel, dim3(blocks), dim3(256), 0, e->stream, sink, clk, iters);
+    HIPCHK(hipEventRecord(b, e->stream));
+    HIPCHK(hipEventSynchronize(b));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, a, b));
+    if (rep > 0 && ms < best) { best = ms; HIPCHK(hipMemcpy(hc.data(), clk, hc.size() * 8, hipMemcpyDeviceToHost)); }
+  }
+  HIPCHK(hipFree(sink));
+  HIPCHK(hipFree(clk));
+  HIPCHK(hipEventDestroy(a));
+  HIPCHK(hipEventDestroy(b));
+  std::vector<double> mhz;
+  for (int i = 0; i < blocks; ++i)
+    if (hc[2 * i + 1] > 0) mhz.push_back(100.0 * (double)hc[2 * i] / (double)hc[2 * i + 1]);
+  std::sort(mhz.begin(), mhz.end());
+  out->sclk_MHz = mhz.empty() ? 0.0 : mhz[mhz.size() / 2];
+  out->fma_ms = best;
+  out->f64_fma_TFs = 2.0 * 8.0 * (double)iters * 256.0 * (double)blocks / (best * 1e-3) / 1e12;
   return PTM_OK;
 }
 

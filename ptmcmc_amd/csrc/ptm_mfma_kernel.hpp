@@ -50,7 +50,7 @@ typedef double mf_d2 __attribute__((ext_vector_type(2)));
 #define PTM_MFMA_G1C_GG 2      // groups per pass of the compacted box-bounds build
 #endif
 #ifndef PTM_MFMA_G1C_WAVES
-#define PTM_MFMA_G1C_WAVES 3
+#define PTM_MFMA_G1C_WAVES 2   // (2: 193-198 registers, no spills -- at 3 the compacted build spilled 13-22 and its sweep-in-step of the default Gaussian recipe took 2.40 instead of 2.01 ms)
 #endif
 #ifndef PTM_MFMA_PRIO
 #define PTM_MFMA_PRIO 2        // 1: a wave raises its issue priority over its matrix blocks (measured: nothing); 2: over its vector (draw)
@@ -70,13 +70,14 @@ typedef double mf_d2 __attribute__((ext_vector_type(2)));
 // listed walker of its group instead of walker w0 + l.
 template <int KIND, bool HIST, int GEN, bool EV = false, bool CPT = false>   // GEN: 0 lean, 1 box boundaries + uniform prior (+ mean, 1-D moves, mixtures), 2 everything,
                                                                             //      3 box boundaries + uniform prior and nothing else (GEN 1 without what it only carries)
-__global__ __launch_bounds__(256, (GEN == 0 ? PTM_MFMA_WAVES : ((PTM_MFMA_GG == 0 && GEN == 2 && KIND == KIND_LOWER) ? 4 : (((GEN == 1 || GEN == 3) && CPT) ? PTM_MFMA_G1C_WAVES : PTM_MFMA_GEN_WAVES)))) void sweep_mfma32_kernel(const Dev p) {
+__global__ __launch_bounds__(256, (GEN == 0 ? PTM_MFMA_WAVES : ((PTM_MFMA_GG == 0 && GEN == 2 && KIND == KIND_LOWER) ? 4 : ((GEN == 1 && CPT) ? PTM_MFMA_G1C_WAVES : PTM_MFMA_GEN_WAVES)))) void sweep_mfma32_kernel(const Dev p) {
   constexpr bool PERSIST = GEN == 0 || PTM_MFMA_GEN_PERSIST != 0 || CPT;   // (a compacted sweep walks its tiles: an idle tile must cost nothing)
   static_assert(!CPT || ((GEN <= 1 || GEN == 3) && !HIST), "the compacted sweep exists for the lean and the box-bounds builds, without history");
   constexpr bool GENX = GEN == 1 || GEN == 2;   // the builds that carry a mean, one-dimensional moves and scale mixtures
   constexpr int DP = 32;
   constexpr int GG = PTM_MFMA_GG ? PTM_MFMA_GG : (GEN == 2 ? 1 : (((GEN == 1 || GEN == 3) && CPT) ? PTM_MFMA_G1C_GG : 2)), NP = 4 / GG, PL = 16 * GG;   // groups per pass, passes per tile, chains (= stage-5 lanes) per pass
   constexpr bool LOW = KIND == KIND_LOWER;
+  static_assert(GEN != 2 || GG == 1, "the mixture scales share the GEN 2 build's red2 slots: its prior products must stay below index 64");
   // LDS: [2560] Box-Muller tables | [12][64] precision tiles | [64] prior box (all shared by the block's waves) |
   //      128 doubles per wave
   extern __shared__ __attribute__((aligned(16))) double lds_all[];
@@ -88,6 +89,9 @@ __global__ __launch_bounds__(256, (GEN == 0 ? PTM_MFMA_WAVES : ((PTM_MFMA_GG == 
   double* gtab = lbox + 64 + 4 * 128;                   // bmin | bmax | plo | phi | pcoef | mean, 32 each
   int* gint = reinterpret_cast<int*>(gtab + 6 * 32);    // blo | bhi | ptype, 32 each
   double* red2 = reinterpret_cast<double*>(gint + 3 * 32) + wave * 128;   // the prior's partial products
+  // the scales of the rung's mixture members (at most 64), this wave's copy: in the half of red2 the prior's products never reach (they are
+  // GEN 2's, which works one group per pass: indices below 64), or all of it in the builds without them
+  double* mixs = red2 + (GEN == 2 ? 64 : 0);
   // all boundaries open or `limit` (the usual case): enforcing is a box test -- lower | upper limits in row layout
   double* ebox = reinterpret_cast<double*>(gint + 3 * 32) + 4 * 128;
   const int q = l >> 4, j = l & 15;
@@ -230,20 +234,24 @@ __global__ __launch_bounds__(256, (GEN == 0 ? PTM_MFMA_WAVES : ((PTM_MFMA_GG == 
   const u32x4 o0 = draw_block(p.seed, TAG_MH, (uint32_t)(wl + p.w_off) * (uint32_t)p.Nt + (uint32_t)rg, p.step, 0);
   const double log_u = dlog_u01(o0.v0);
   // one-dimensional move of "my" chain (proposal_distribution.hh:196-206): its axis, or -1
-  int my_axis = -1, my_kmix = 0;
-  double my_scale = 1.0;   // scale mixture: "my" chain's member (proposal_distribution_set::draw, proposal_distribution.cc:99-129)
+  // ... and its member of a scale mixture (proposal_distribution_set::draw, proposal_distribution.cc:99-129), packed into ONE register:
+  // (axis + 1) | member << 8.  The member's scale is looked up where it is used, in this wave's copy of the rung's scales in LDS
+  // (as axis / member / scale of "my" chain and of the pass's chains these were ten registers of a kernel at its register cap)
+  int my_meta = 0;
   if (GENX) {
     double f = as_c(p.onedfrac)[rl];
+    int kmix = 0, axis1 = 0;
     if (p.mix_K > 0) {
       cdp mx = as_c(p.mix) + (size_t)rl * p.mix_K * 3;
       const double xs = p.mix_K > 1 ? u01(o0.v3) : 0.0;
-      my_kmix = p.mix_K - 1;
+      kmix = p.mix_K - 1;
       for (int k = p.mix_K - 2; k >= 0; --k)
-        if (xs < mx[3 * k]) my_kmix = k;
-      my_scale = mx[3 * my_kmix + 1];
-      f = mx[3 * my_kmix + 2];
+        if (xs < mx[3 * k]) kmix = k;
+      f = mx[3 * kmix + 2];
+      if (l < p.mix_K) mixs[l] = mx[3 * l + 1];
     }
-    if (p.any_oned && f > 0 && u01(o0.v1) < f) my_axis = (int)(p.D * u01(o0.v2));
+    if (p.any_oned && f > 0 && u01(o0.v1) < f) axis1 = 1 + (int)(p.D * u01(o0.v2));
+    my_meta = axis1 | (kmix << 8);
   }
 
   if (!PERSIST) {   // the tables go to LDS behind the tile's first loads; the block meets once
@@ -267,28 +275,16 @@ __global__ __launch_bounds__(256, (GEN == 0 ? PTM_MFMA_WAVES : ((PTM_MFMA_GG == 
     // ---- stage 2: T x Z, one 16-column half at a time (the half's normals: one Philox block per chain)
     mf_d4 acc[GG][2];
     double tb[4][2];
-    int axis[GG];        // GEN: the one-dimensional move's axis of chain (GG gp + gg, j), from its own lane
-    double mscale[GG];   // GEN: the chain's mixture scale
+    int meta[GG];        // GEN: axis + 1 | member << 8 of chain (GG gp + gg, j), from its own lane
 #pragma unroll
     for (int gg = 0; gg < GG; ++gg) {
       acc[gg][0] = mf_d4{0.0, 0.0, 0.0, 0.0};
       acc[gg][1] = mf_d4{0.0, 0.0, 0.0, 0.0};
-      axis[gg] = -1;
-      mscale[gg] = 1.0;
+      meta[gg] = 0;
     }
-    if (GENX && p.any_oned) {
+    if (GENX && (p.any_oned || p.mix_K > 0)) {
 #pragma unroll
-      for (int gg = 0; gg < GG; ++gg) axis[gg] = __builtin_amdgcn_ds_bpermute(4 * (PL * gp + 16 * gg + j), my_axis);
-    }
-    if (GENX && p.mix_K > 0) {
-#pragma unroll
-      for (int gg = 0; gg < GG; ++gg) {
-        const long long b = __double_as_longlong(my_scale);
-        const int src = 4 * (PL * gp + 16 * gg + j);
-        const unsigned int lo = (unsigned int)__builtin_amdgcn_ds_bpermute(src, (int)(unsigned int)b);
-        const unsigned int hi = (unsigned int)__builtin_amdgcn_ds_bpermute(src, (int)(unsigned int)(b >> 32));
-        mscale[gg] = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
-      }
+      for (int gg = 0; gg < GG; ++gg) meta[gg] = __builtin_amdgcn_ds_bpermute(4 * (PL * gp + 16 * gg + j), my_meta);
     }
 #pragma unroll
     for (int hb = 0; hb < 2; ++hb) {
@@ -299,10 +295,10 @@ __global__ __launch_bounds__(256, (GEN == 0 ? PTM_MFMA_WAVES : ((PTM_MFMA_GG == 
         const u32x4 o = draw_block(p.seed, TAG_MH, stream, p.step, (uint32_t)(1 + 4 * hb + qd));
         boxmuller(o.v0, o.v1, (const double*)lds_all, z[gg][0], z[gg][1]);
         boxmuller(o.v2, o.v3, (const double*)lds_all, z[gg][2], z[gg][3]);
-        if (GENX && axis[gg] >= 0) {
+        if (GENX && (meta[gg] & 0xFF) != 0) {   // one-dimensional move: every other normal is dropped (proposal_distribution.hh:197-205)
 #pragma unroll
           for (int sl = 0; sl < 4; ++sl)
-            if (16 * hb + 4 * q + sl != axis[gg]) z[gg][sl] = 0.0;
+            if (16 * hb + 4 * q + sl + 1 != (meta[gg] & 0xFF)) z[gg][sl] = 0.0;
         }
         PTM_STAGE();   // one chain's draw at a time: the temporaries of two interleaved draws cost 40 registers
       }
@@ -340,13 +336,15 @@ __global__ __launch_bounds__(256, (GEN == 0 ? PTM_MFMA_WAVES : ((PTM_MFMA_GG == 
     for (int gg = 0; gg < GG; ++gg) {
       bool ok = true, vok = true;
       double pp = 1.0;      // GEN: this lane's partial product of the prior's factors (its dimensions, ascending)
+      double msc = 1.0;     // GEN: the scale of the chain's mixture member
+      if (GENX && p.mix_K > 0) msc = mixs[meta[gg] >> 8];
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const mf_d2 v = rowv[gg][t], lo = box[4 * t], hi = box[16 + 4 * t];
         const int m = 2 * t;   // registers m, m+1 <-> dimensions q + 4m, q + 4m + 4
         if (GENX && p.mix_K > 0) {   // the member is scale_k times the rung's factor
-          xp[gg][m] = v.x + mscale[gg] * acc[gg][m >> 2][m & 3];
-          xp[gg][m + 1] = v.y + mscale[gg] * acc[gg][(m + 1) >> 2][(m + 1) & 3];
+          xp[gg][m] = v.x + msc * acc[gg][m >> 2][m & 3];
+          xp[gg][m + 1] = v.y + msc * acc[gg][(m + 1) >> 2][(m + 1) & 3];
         } else {
           xp[gg][m] = v.x + acc[gg][m >> 2][m & 3];
           xp[gg][m + 1] = v.y + acc[gg][(m + 1) >> 2][(m + 1) & 3];
@@ -463,8 +461,8 @@ __global__ __launch_bounds__(256, (GEN == 0 ? PTM_MFMA_WAVES : ((PTM_MFMA_GG == 
         const double logH = newlpost - cur_lpost;
         accept = valid;
         if (accept && logH < 0) accept = log_u < logH;  // chain.cc:998-1001 (NaN stays accepted)
-        int type = (GENX && my_axis >= 0) ? 1 : 0;
-        if (GENX && p.mix_K > 0) type = my_kmix + 10 * type;   // proposal_distribution.cc:117
+        int type = (GENX && (my_meta & 0xFF) != 0) ? 1 : 0;
+        if (GENX && p.mix_K > 0) type = (my_meta >> 8) + 10 * type;   // proposal_distribution.cc:117
         p.ntries[c] = ntries0 + 1;
         if (!CPT) p.nhist[c] = nhist0 + 1u;   // (compacted: the engine counts the step for everybody, ptm_aux_kernels.hpp)
         if (hist_on && nhist0 % (unsigned int)p.add_every_n == 0u) {

@@ -533,11 +533,10 @@ def bench_main(args):
                 dist.barrier()
                 torch.cuda.synchronize()
         lad.step(300)             # set-up (untimed, uncounted): clocks ramped, chains off their prior draws, RCCL channels open
-        lad.step(args.warmup)
         lad.drain()
         eng.sync()
-        eng.kernel_times()
-        tries0 = int(eng.ntries.astype(np.int64).sum())
+        # what each rank's device gives a streaming copy and an f64 fma loop right now (ptm_calibrate: devices differ by several per cent)
+        cal = None if getattr(args, "no_calibration", False) else eng.calibrate()
         # evidence of the transport, outside the timed region: what RCCL itself makes of "one from every rank"
         evidence = {"backend": dist.get_backend(), "world_size": dist.get_world_size()}
         if not fallback:
@@ -546,13 +545,20 @@ def bench_main(args):
             evidence["all_reduce_of_ones"] = float(ones.item())
             props = torch.cuda.get_device_properties(local)
             mine = {"rank": rank, "device": local, "name": props.name, "uuid": str(getattr(props, "uuid", "")),
-                    "rungs": [int(r0), int(r0 + nloc)], "walkers": int(eng.W), "walker_begin": int(eng.walker_begin)}
+                    "rungs": [int(r0), int(r0 + nloc)], "walkers": int(eng.W), "walker_begin": int(eng.walker_begin), "calibration": cal}
             seen = [None] * world
             try:      # (over the host-side group where there is one: a record of who ran must not be what stops the run)
                 dist.all_gather_object(seen, mine, group=ctl)
                 evidence["ranks"] = seen
             except Exception as ex:   # noqa: BLE001
                 evidence["ranks"] = "unavailable (%s: %s)" % (type(ex).__name__, ex)
+        # warm again and go straight into the timed steps: a device that idles for ~20 ms drops its clocks (bench.py has the story)
+        lad.step(150)
+        lad.step(args.warmup)
+        lad.drain()
+        eng.sync()
+        eng.kernel_times()
+        tries0 = eng.counter_sums()[0]   # (two sums reduced on the device: no idle gap for the clocks to drop in -- bench.py has the story)
         meet()
         t0 = time.perf_counter()
         lad.step(args.steps)
@@ -570,14 +576,14 @@ def bench_main(args):
     dist.all_reduce(dt, op=dist.ReduceOp.MAX, group=grp)
     wall = float(dt.item())
     kt = eng.kernel_times()              # one entry per sweep launch; a step's sweep is up to four launches
-    moved = (int(eng.ntries.astype(np.int64).sum()) - tries0) / float(args.steps)   # chains this rank's sweeps worked on, per step
+    moved = (eng.counter_sums()[0] - tries0) / float(args.steps)   # chains this rank's sweeps worked on, per step
     kavg = torch.tensor([float(kt.sum()) / args.steps], dtype=torch.float64, device=None if fallback else dev)
     dist.all_reduce(kavg, op=dist.ReduceOp.MAX, group=grp)
     nchains = NT * W
     if rank == 0:
         kavg_ms = float(kavg.item())
         value = nchains * args.steps / wall
-        roof = B.roofline_record(eng.sweep_kernel_name, kavg_ms, int(kt.size), moved, eng.Nc, value, world, None)
+        roof = B.roofline_record(eng.sweep_kernel_name, kavg_ms, int(kt.size), moved, eng.Nc, value, world, None, calibration=cal)
         roof["per_gpu"] = True
         roof["kernel_avg_ms_is"] = "sum of the rank's sweep launches of a step (up to four partial sweeps), max over ranks; chains_processed of rank 0"
         how = "walkers" if by_walkers else "rungs"
@@ -599,6 +605,7 @@ def bench_main(args):
                                    ("%d contiguous rung blocks of %d rungs; llike halo %d rungs; neighbour p2p over RCCL (%s)"
                                     % (world, nloc, args.halo, "ptm_shard_*: native ncclSend/ncclRecv" if getattr(args, "native_rccl", False) else "torch.distributed"))},
             "roofline": roof,
+            "calibration": cal,
         }
         if not getattr(args, "no_cpu", False) and not stalled:
             # the CPU baseline of the same workload on this box's host cores, rank 0 only, after the timed region (the other ranks

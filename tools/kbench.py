@@ -21,6 +21,8 @@ ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--tag", default="")
 ap.add_argument("--bounds", action="store_true", help="limit bounds on every dimension, uniform prior: the general build's cheap case")
 ap.add_argument("--general", action="store_true", help="limit bounds on every dimension + one gaussian prior factor: the general build")
+ap.add_argument("--recipe", action="store_true", help="the reference sampler's default Gaussian recipe (ptmcmc.cc:117-139) on limit bounds: a 4-member scale mixture of the rung's factor with gauss_1d_frac = 0.5")
+ap.add_argument("--recipe-null", action="store_true", help="the recipe's CODE without its physics: four members of scale 1, one-dimensional moves switched on but never drawn (gauss_1d_frac 1e-300) -- the chains move as in --bounds")
 ap.add_argument("--evolve", type=float, default=0.0, help="evolve_temps rate (per-ladder temperatures, sequential exchange decisions)")
 ap.add_argument("--history", type=int, default=0, help="rungs with a saved history (and MAP tracking on every rung): the sampler's engine")
 a = ap.parse_args()
@@ -35,6 +37,15 @@ if a.general:
     D = a.dim
     eng.set_bounds([1] * D, [1] * D, [-1e3] * D, [1e3] * D)
     eng.set_prior([2] + [1] * (D - 1), list(pr.centers), [30.0] + list(pr.halfwidths[1:]))
+if a.recipe_null:
+    D, K = a.dim, 4
+    eng.set_bounds([1] * D, [1] * D, [-1e3] * D, [1e3] * D)
+    eng.set_proposal_mixture(np.tile([0.25, 0.5, 0.75, 1.0], (a.rungs, 1)), np.ones((a.rungs, K)), np.full((a.rungs, K), 1e-300))
+if a.recipe:
+    D, K = a.dim, 4
+    eng.set_bounds([1] * D, [1] * D, [-1e3] * D, [1e3] * D)
+    sh = np.cumsum([2.0 ** (k + 1) for k in range(K)]); sh /= sh[-1]
+    eng.set_proposal_mixture(np.tile(sh, (a.rungs, 1)), np.tile([2.0 ** -k for k in range(K)], (a.rungs, 1)), np.full((a.rungs, K), 0.5))
 if a.evolve > 0:
     eng.set_evolve_temps(a.evolve)
 eng.init_from_prior()
