@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PTM_ABI_VERSION 2   /* 2: ptm_config.walker_begin (a v1 caller's shorter struct is still accepted: walker_begin = 0) */
+#define PTM_ABI_VERSION 3   /* 2: ptm_config.walker_begin (a v1 caller's shorter struct is still accepted: walker_begin = 0); 3: ptm_calibrate, ptm_get_counter_sums, ptm_get_ladder_stats (additions only) */
 
 typedef struct ptm_engine ptm_engine;
 
@@ -337,6 +337,13 @@ const char* ptm_sweep_kernel_name(ptm_engine* e);
  * "decide_kernel + <sweep kernel>" per step */
 const char* ptm_step_kernel_name(ptm_engine* e);
 
+/* Long ladders of few walkers step through ONE persistent kernel per ptm_step(n) call ("ladder_persistent_kernel<..>" in
+ * ptm_step_kernel_name).  A launch of it commits all of its steps or none: if its workgroups cannot all be resident (a shared device)
+ * one of them gives up waiting, nothing of the launch is kept, and the engine repeats the steps on the two-launch path at its
+ * next look at the device (any getter, setter, ptm_sync) and keeps that path from then on.  out[0] launches of that kernel,
+ * out[1] launches that gave up and were repeated, out[2] steps that took its whole-ladder exchange form (counted in diagnostics
+ * runs only), out[3] 1 if the kernel is switched off for this engine.  No reference counterpart. */
+int ptm_get_ladder_stats(ptm_engine* e, int64_t out[4]);
 /* Sums of MH_chain::Ntries and ::Naccept (chain.hh:151-152) over this engine's chains, reduced on the device: a measurement
  * that wants "Metropolis moves made so far" reads 16 bytes instead of two arrays (and leaves the GPU no idle gap to drop
  * its clocks in).  Waits for the engine's stream. */

@@ -117,8 +117,17 @@ struct ptm_engine {
   double *pub_x = nullptr, *pub_ll = nullptr, *pub_lp = nullptr;   // (one allocation: pub_x)
   int *lad_flags = nullptr, *lad_ctl = nullptr;                     // (one allocation: lad_flags)
   long long* lad_prof = nullptr;
-  int lad_capacity = -1;        // workgroups of that kernel the device holds at once (-1: not asked yet)
+  int lad_capacity[2][4] = {{-1, -1, -1, -1}, {-1, -1, -1, -1}};   // workgroups of each build of that kernel [diagonal][FL] the device holds at once (-1: not asked yet)
   long long ladder_launches = 0, ladder_whole_steps = 0;   // launches of that kernel; steps (of walker 0) whose exchange phase needed the whole ladder
+  // A launch of that kernel commits all of its steps or none (ptm_ladder_kernel.hpp) and is ASYNCHRONOUS: the host learns at its
+  // next look (ladder_settle) whether the launches since the last look were committed -- the device keeps the number of the last one
+  // that was (err[2]) -- and, if one gave up, repeats its steps and its successors' on the two-launch path.
+  struct LadLaunch { int seq; uint64_t step_before; int nsteps; int log_head_before; };
+  std::vector<LadLaunch> lad_log;   // launches not yet looked at
+  int lad_seq = 0;                  // number of the last launch issued
+  bool lad_disabled = false;        // a launch gave up once: this engine keeps the two-launch path from then on
+  long long ladder_fallbacks = 0;   // launches that gave up (their steps were repeated on the two-launch path)
+  hipEvent_t lad_event = nullptr;   // end of this engine's last launch of that kernel (two engines' grids must not share the device)
   unsigned int nhist_pending = 0;   // steps whose one-add-per-chain the compacted sweep left uncounted (flush_nhist)
   double* hastings = nullptr;
   int* htype = nullptr;
@@ -151,6 +160,13 @@ struct ptm_engine {
   size_t kev_used = 0;
   std::string kname;
 };
+
+// Persistent ladder kernels of different engines (streams) must not run at the same time: each sizes its grid for a device of its
+// own, two at once may not be resident together and would wait for each other's workgroups until they give up.  A launch
+// therefore waits for the event of the last such launch of any OTHER engine of the process.
+#include <mutex>
+static std::mutex g_lad_mutex;
+static ptm_engine* g_lad_last = nullptr;
 
 static int round_dp(int D) {
   if (D <= 4) return 4;
@@ -402,10 +418,13 @@ static int fetch(ptm_engine* e, const void* dev, size_t bytes, const unsigned ch
 static int fetch_done(ptm_engine* e) { return e->fetch_depth > 0 ? PTM_OK : fetch_flush(e); }
 // Between ptm_batch_begin and ptm_batch_end only reads are allowed: a queued read of mapped host memory (a small population's
 // history ring) is served in place at the flush, so nothing may change the engine's arrays in between.
+// the launches of the persistent ladder kernel since the last look: committed, or repeated on the two-launch path (ladder_settle)
+#define SETTLE(e) do { if (e) { const int _rc = ladder_settle(e); if (_rc) return _rc; } } while (0)
 #define NO_BATCH(e, name) do { if ((e) && (e)->fetch_depth > 0) return fail(PTM_ERR_INVALID, name " between ptm_batch_begin and ptm_batch_end (only reads go there)"); } while (0)
 #define FETCH(ptr, dev, bytes) do { int _rc = fetch(e, (dev), (bytes), &(ptr)); if (_rc) return _rc; } while (0)
 
 extern "C" int ptm_batch_begin(ptm_engine* e) {
+  SETTLE(e);
   if (!e) return fail(PTM_ERR_INVALID, "null engine");
   e->fetch_depth++;
   return PTM_OK;
@@ -421,6 +440,11 @@ extern "C" int ptm_engine_destroy(ptm_engine* e) {
   if (!e) return PTM_OK;
   (void)ptm_shard_finalize(e);
   (void)hipStreamSynchronize(e->stream);
+  {
+    std::lock_guard<std::mutex> lock(g_lad_mutex);
+    if (g_lad_last == e) g_lad_last = nullptr;
+  }
+  if (e->lad_event) (void)hipEventDestroy(e->lad_event);
   if (e->shared_handover) e->xprop = e->llike_new = nullptr, e->hastings = nullptr, e->htype = nullptr, e->hvalid = e->acc_out = nullptr;   // (these are the pinned vectors)
   if (e->hist_on_host) e->hist.x = e->hist.ll = e->hist.lp = e->hist.beta = nullptr, e->hist.meta = nullptr;
   for (auto& b : e->host_blocks) (void)hipHostFree(b.first);
@@ -441,6 +465,7 @@ extern "C" int ptm_engine_destroy(ptm_engine* e) {
 
 // ---- problem description ----------------------------------------------------------------------------------
 extern "C" int ptm_set_bounds(ptm_engine* e, const int32_t* lo, const int32_t* hi, const double* xmin, const double* xmax) {
+  SETTLE(e);
   if (!e || !lo || !hi || !xmin || !xmax) return fail(PTM_ERR_INVALID, "null argument");
   int rc;
   const int D = e->D;
@@ -473,6 +498,7 @@ extern "C" int ptm_set_bounds(ptm_engine* e, const int32_t* lo, const int32_t* h
 
 static inline size_t host_row_pos(size_t DP, size_t d);
 extern "C" int ptm_set_prior(ptm_engine* e, const int32_t* types, const double* c, const double* h) {
+  SETTLE(e);
   if (!e || !types || !c || !h) return fail(PTM_ERR_INVALID, "null argument");
   const int D = e->D;
   std::vector<double> lo(D), hi(D), coef(D);
@@ -531,6 +557,7 @@ extern "C" int ptm_set_prior(ptm_engine* e, const int32_t* types, const double* 
 }
 
 extern "C" int ptm_set_target_gaussian(ptm_engine* e, const double* mean, const double* P, double like0) {
+  SETTLE(e);
   if (!e || !P) return fail(PTM_ERR_INVALID, "null argument");
   const int D = e->D, DP = e->DP;
   std::vector<double> packed((size_t)DP * (DP + 1) / 2, 0.0);
@@ -600,6 +627,7 @@ static int alloc_proposal_buffers(ptm_engine* e) {
 }
 
 extern "C" int ptm_set_target_callback(ptm_engine* e, ptm_loglike_batch_fn fn, void* user) {
+  SETTLE(e);
   if (!e || !fn) return fail(PTM_ERR_INVALID, "null argument");
   int rc = alloc_proposal_buffers(e);
   if (rc) return rc;
@@ -609,6 +637,7 @@ extern "C" int ptm_set_target_callback(ptm_engine* e, ptm_loglike_batch_fn fn, v
 }
 
 extern "C" int ptm_set_prior_callback(ptm_engine* e, ptm_logprior_batch_fn fn, void* user) {
+  SETTLE(e);
   if (!e) return fail(PTM_ERR_INVALID, "null engine");
   e->prior_cb = fn; e->prior_user = fn ? user : nullptr;
   e->lp_is_const = false;
@@ -616,6 +645,7 @@ extern "C" int ptm_set_prior_callback(ptm_engine* e, ptm_logprior_batch_fn fn, v
 }
 
 extern "C" int ptm_set_proposal_callback(ptm_engine* e, ptm_propose_batch_fn propose, ptm_proposal_result_fn result, void* user) {
+  SETTLE(e);
   if (!e) return fail(PTM_ERR_INVALID, "null engine");
   if (!propose) {   // back to the device proposals, if any were set
     e->pcb = nullptr; e->pres = nullptr; e->pcb_user = nullptr;
@@ -679,6 +709,7 @@ static int host_prior_of_states(ptm_engine* e) {
 }
 
 extern "C" int ptm_set_ladder(ptm_engine* e, const double* beta) {
+  SETTLE(e);
   NO_BATCH(e, "ptm_set_ladder");
   if (!e || !beta) return fail(PTM_ERR_INVALID, "null argument");
   e->h_beta.assign(beta, beta + e->Nt);
@@ -700,6 +731,7 @@ static int fill_evolving_ladders(ptm_engine* e) {
 }
 
 extern "C" int ptm_set_evolve_temps(ptm_engine* e, double rate, double lpost_cut) {
+  SETTLE(e);
   if (!e) return fail(PTM_ERR_INVALID, "null engine");
   if (!(rate > 0)) {
     if (e->evolve_rate > 0) return fail(PTM_ERR_UNSUPPORTED, "an evolving ladder cannot be frozen again (the reference has no such call either)");
@@ -735,6 +767,7 @@ extern "C" int ptm_set_evolve_temps(ptm_engine* e, double rate, double lpost_cut
 }
 
 extern "C" int ptm_get_invtemps(ptm_engine* e, double* beta) {
+  SETTLE(e);
   if (!e || !beta) return fail(PTM_ERR_INVALID, "null argument");
   if (!e->have_ladder) return fail(PTM_ERR_INVALID, "no ladder set");
   if (e->beta_w) {
@@ -749,6 +782,7 @@ extern "C" int ptm_get_invtemps(ptm_engine* e, double* beta) {
 }
 
 extern "C" int ptm_get_history_invtemps(ptm_engine* e, double* beta) {
+  SETTLE(e);
   if (!e || !beta) return fail(PTM_ERR_INVALID, "null argument");
   if (!e->hist.rungs) return fail(PTM_ERR_INVALID, "this engine keeps no history (ptm_config.history_rungs)");
   if (!e->have_ladder) return fail(PTM_ERR_INVALID, "no ladder set");
@@ -764,6 +798,7 @@ extern "C" int ptm_get_history_invtemps(ptm_engine* e, double* beta) {
 }
 
 extern "C" int ptm_set_invtemps(ptm_engine* e, const double* beta) {
+  SETTLE(e);
   NO_BATCH(e, "ptm_set_invtemps");
   if (!e || !beta) return fail(PTM_ERR_INVALID, "null argument");
   if (!e->beta_w) return fail(PTM_ERR_INVALID, "per-ladder temperatures exist only once the ladders evolve (ptm_set_evolve_temps)");
@@ -773,6 +808,7 @@ extern "C" int ptm_set_invtemps(ptm_engine* e, const double* beta) {
 }
 
 extern "C" int ptm_set_proposals(ptm_engine* e, int kind, const double* factors, const double* one_d_frac) {
+  SETTLE(e);
   if (!e || !factors) return fail(PTM_ERR_INVALID, "null argument");
   const int D = e->D, DP = e->DP, nloc = e->nloc;
   int stride;
@@ -855,6 +891,7 @@ extern "C" int ptm_set_proposals(ptm_engine* e, int kind, const double* factors,
 // doubling shares, ptmcmc.cc:117-139).  Per local rung K members: cumulative shares (proposal_distribution_set's
 // bin_max), scales, oneDfracs.  K = 0 removes the mixture.  last_type becomes member + 10 * (member's type).
 extern "C" int ptm_set_proposal_mixture(ptm_engine* e, int K, const double* cum_shares, const double* scales, const double* one_d_fracs) {
+  SETTLE(e);
   if (!e) return fail(PTM_ERR_INVALID, "null engine");
   if (!e->have_prop) return fail(PTM_ERR_INVALID, "set the base proposals first (ptm_set_proposals)");
   if (K < 0 || K > 64) return fail(PTM_ERR_INVALID, "mixture size must be in 0..64");
@@ -884,6 +921,7 @@ extern "C" int ptm_set_proposal_mixture(ptm_engine* e, int K, const double* cum_
 // callback returns a new covariance for a chain (proposal_distribution.cc:406-441, reset_dist :340-403).  Same kind and
 // storage as the factors set by ptm_set_proposals; one_d_frac < 0 keeps the rung's current value.
 extern "C" int ptm_set_proposal_rung(ptm_engine* e, int local_rung, const double* factor, double one_d_frac) {
+  SETTLE(e);
   if (!e || !factor) return fail(PTM_ERR_INVALID, "null argument");
   if (!e->have_prop) return fail(PTM_ERR_INVALID, "set all proposals first (ptm_set_proposals)");
   if (local_rung < 0 || local_rung >= e->nloc) return fail(PTM_ERR_INVALID, "rung out of the shard");
@@ -1361,6 +1399,7 @@ static void unpad_rows(const double* r, size_t n, size_t D, size_t DP, double* X
 static void unpad_rows(const std::vector<double>& r, size_t n, size_t D, size_t DP, double* X) { unpad_rows(r.data(), n, D, DP, X); }
 
 extern "C" int ptm_set_states(ptm_engine* e, const double* X, const double* llike) {
+  SETTLE(e);
   NO_BATCH(e, "ptm_set_states");
   if (!e || !X) return fail(PTM_ERR_INVALID, "null argument");
   if (!e->have_target && !llike) return fail(PTM_ERR_INVALID, "set the target first (or pass llike)");
@@ -1411,6 +1450,7 @@ static int launch_init(ptm_engine* e, const Dev& p, long long attempt, unsigned 
 extern "C" int ptm_init_from_prior(ptm_engine* e) { return ptm_init_from_prior_k(e, 0); }
 
 extern "C" int ptm_init_from_prior_k(ptm_engine* e, int kdraw) {
+  SETTLE(e);
   NO_BATCH(e, "ptm_init_from_prior");
   if (!e) return fail(PTM_ERR_INVALID, "null engine");
   if (kdraw < 0 || kdraw > 8191) return fail(PTM_ERR_INVALID, "initial draw index out of range (0..8191)");
@@ -1465,6 +1505,7 @@ extern "C" int ptm_init_from_prior_k(ptm_engine* e, int kdraw) {
 
 // ---- hot path ----------------------------------------------------------------------------------------------------
 extern "C" int ptm_sweep(ptm_engine* e, int n) {
+  SETTLE(e);
   NO_BATCH(e, "ptm_sweep");
   int rc = ready(e);
   if (rc) return rc;
@@ -1517,28 +1558,64 @@ static int fused_steps(ptm_engine* e, int n) {
 #ifndef PTM_LADDER_MIN_STEPS
 #define PTM_LADDER_MIN_STEPS 1
 #endif
+static int ladder_flavour(const ptm_engine* e) { return ((e->any_oned || e->mix_K > 0) ? 1 : 0) | ((e->hist.rungs || e->map.rungs) ? 2 : 0); }
 static bool ladder_applies(ptm_engine* e, long long* grid_out = nullptr, size_t* lds_out = nullptr) {
   static const bool ladder_ok = [] { const char* v = getenv("PTM_LADDER"); return !(v && *v == '0'); }();
-  if (!ladder_ok || (e->DP != 16 && e->DP != 32) || e->Nt < 2 || e->nloc != e->Nt || e->cfg.time_kernels || e->evolve_rate > 0 || e->hist.rungs ||
-      e->map.rungs || e->shard)
+  if (!ladder_ok || e->lad_disabled || (e->DP != 16 && e->DP != 32) || e->Nt < 2 || e->nloc != e->Nt || e->cfg.time_kernels || e->evolve_rate > 0 || e->shard)
     return false;
   const SweepSel sel = sweep_sel(e);
-  // the plain workload, with open / `limit` boundaries if any; populations with whole waves per rung keep the throughput kernels
-  const bool plain_but_bounds = e->has_bounds && e->bounds_box && e->all_uniform && !e->has_mean && !e->any_oned && !e->cb && e->mix_K == 0 && !e->betaC && !e->pcb;
-  if (!(sel.plain || plain_but_bounds) || sel.uni) return false;
+  // open / `limit` boundaries, all-uniform prior, zero mean, fixed ladder, device target and proposals (one-dimensional moves, scale
+  // mixtures, history and MAP tracking have their builds: ladder_flavour); populations with whole waves per rung keep the throughput kernels
+  if (sel.uni || (e->has_bounds && !e->bounds_box) || !e->all_uniform || e->has_mean || e->cb || e->prior_cb || e->pcb || e->betaC) return false;
   const int R = 256 / e->DP, NB = (e->Nt + R - 1) / R;
   const long long grid = (long long)e->W * NB;
   const bool diag = e->prop_kind == PTM_PROP_DIAG;
+  const int fl = ladder_flavour(e);
   const size_t lds = e->DP == 16 ? ladder_lds_16(e->Nt, e->ms) : ladder_lds_32(e->Nt, e->ms);
   if (lds > 160 * 1024) return false;
-  if (e->lad_capacity < 0) e->lad_capacity = e->DP == 16 ? ladder_blocks_16(diag, lds) : ladder_blocks_32(diag, lds);
+  int& cap = e->lad_capacity[diag ? 1 : 0][fl];   // (asked per build: the builds differ in registers, and the LDS attribute is per kernel)
+  if (cap < 0) cap = e->DP == 16 ? ladder_blocks_16(diag, fl, lds) : ladder_blocks_32(diag, fl, lds);
   // every workgroup must be resident at once (they wait for each other)
-  if (grid > e->lad_capacity || grid > 1024) return false;
+  if (grid > cap || grid > 1024) return false;
   if (grid_out) *grid_out = grid;
   if (lds_out) *lds_out = lds;
   return true;
 }
-static int ladder_settle(ptm_engine* e) { (void)e; return PTM_OK; }
+static int two_launch_steps(ptm_engine* e, int n);
+// Have the launches of the persistent ladder kernel since the last look been committed?  If one gave up, the engine's arrays are as
+// they were before it (the kernel commits all of a launch or nothing, and the launches behind it found its number missing and did
+// nothing): its steps and theirs are repeated on the two-launch path, and this engine keeps that path from now on.
+static int ladder_settle(ptm_engine* e) {
+  if (e->lad_log.empty()) return PTM_OK;
+  HIPCHK(hipStreamSynchronize(e->stream));
+  int w[3] = {0, 0, 0};
+  HIPCHK(hipMemcpy(w, e->err, sizeof w, hipMemcpyDeviceToHost));
+  if (w[2] == e->lad_seq) { e->lad_log.clear(); return PTM_OK; }
+  size_t k = 0;
+  while (k < e->lad_log.size() && e->lad_log[k].seq != w[2] + 1) ++k;
+  if (k == e->lad_log.size()) return fail(PTM_ERR_HIP, "persistent ladder kernel: the device reports launch %d as the last one committed, the host has no record of its successor", w[2]);
+  long long todo = 0;
+  for (size_t j = k; j < e->lad_log.size(); ++j) todo += e->lad_log[j].nsteps;
+  e->step = e->lad_log[k].step_before;
+  e->log_head = e->lad_log[k].log_head_before;
+  e->lad_log.clear();
+  e->lad_disabled = true;
+  e->ladder_fallbacks += 1;
+  const int clr = w[0] & ~32;
+  HIPCHK(hipMemcpy(e->err, &clr, 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(e->err + 2, &e->lad_seq, 4, hipMemcpyHostToDevice));
+  static const bool quiet = [] { const char* v = getenv("PTM_QUIET"); return v && *v && *v != '0'; }();
+  if (!quiet)
+    fprintf(stderr, "[ptm] the persistent ladder kernel gave up waiting for a neighbouring workgroup (is the device shared?): nothing of that launch was "
+                    "kept, its %lld steps are repeated on the two-launch path, which this engine keeps from now on\n", todo);
+  while (todo > 0) {
+    const int n = todo > (1 << 30) ? (1 << 30) : (int)todo;
+    const int rc = two_launch_steps(e, n);
+    if (rc) return rc;
+    todo -= n;
+  }
+  return PTM_OK;
+}
 static int ladder_steps(ptm_engine* e, int n) {
   long long grid = 0;
   size_t lds = 0;
@@ -1548,9 +1625,15 @@ static int ladder_steps(ptm_engine* e, int n) {
   if (!ladder_applies(e, &grid, &lds)) return 0;
   const int R = 256 / e->DP, NB = (e->Nt + R - 1) / R;
   const bool diag = e->prop_kind == PTM_PROP_DIAG;
+  const int fl = ladder_flavour(e);
   static const int max_run = [] { const char* v = getenv("PTM_LADDER_MAXRUN"); const int m = v && *v ? atoi(v) : LADDER_H; return m < 1 ? 1 : (m > LADDER_H ? LADDER_H : m); }();
+  // how long a workgroup waits for a neighbour before it gives up: 3 s of the 100 MHz wall clock (a neighbour that is not there by
+  // then never will be); PTM_LADDER_SPIN_US shortens it (tests: 0 makes every flag that is not up at the first look a reason to give up)
+  static const long long spin_limit = [] { const char* v = getenv("PTM_LADDER_SPIN_US"); return v && *v ? atoll(v) * 100ll : 300000000ll; }();
   int rc = flush_nhist(e);
   if (rc) return rc;
+  if (e->lad_log.size() >= 256 && (rc = ladder_settle(e))) return rc;   // (a host that never looks: look for it now and then)
+  if (e->lad_disabled) return 0;
   const size_t Nc = e->Nc;
   if (!e->pub_x) {
     // what the workgroups publish for each other: fine-grained device memory where the runtime has it (a little faster across
@@ -1562,13 +1645,14 @@ static int ladder_steps(ptm_engine* e, int n) {
       HIPCHK(hipMalloc(&buf, doubles * sizeof(double)));
     }
     e->pub_x = (double*)buf; e->pub_ll = e->pub_x + 2 * Nc * e->DP; e->pub_lp = e->pub_ll + 2 * Nc;
-    void* fl = nullptr;
+    void* fl_ = nullptr;
     const size_t flbytes = ((size_t)grid + 16 + (size_t)e->W) * sizeof(int);
-    if (hipExtMallocWithFlags(&fl, flbytes, hipDeviceMallocFinegrained) != hipSuccess) {
+    if (hipExtMallocWithFlags(&fl_, flbytes, hipDeviceMallocFinegrained) != hipSuccess) {
       (void)hipGetLastError();
-      HIPCHK(hipMalloc(&fl, flbytes));
+      HIPCHK(hipMalloc(&fl_, flbytes));
     }
-    e->lad_flags = (int*)fl; e->lad_ctl = e->lad_flags + grid;   // [grid] flags | [16] control words | [W] whole-ladder barrier counters
+    e->lad_flags = (int*)fl_; e->lad_ctl = e->lad_flags + grid;   // [grid] flags | [16] control words | [W] whole-ladder barrier counters
+    HIPCHK(hipEventCreateWithFlags(&e->lad_event, hipEventDisableTiming));
   }
   static const bool prof_on = [] { const char* v = getenv("PTM_LADDER_PROF"); return v && *v && *v != '0'; }();
   if (prof_on && !e->lad_prof && (rc = dalloc(&e->lad_prof, (size_t)grid * 8))) return rc;
@@ -1585,11 +1669,25 @@ static int ladder_steps(ptm_engine* e, int n) {
     a.prof = e->lad_prof;
     { static const int pt = [] { const char* v = getenv("PTM_LADDER_PROF"); return (v && *v == '2') ? 256 : ((v && *v == '3') ? 384 : 0); }(); a.prof_tid = pt; }
     if ((rc = fold_swap_log(e))) return rc;   // (the kernel adds to the swap counters itself: nothing logged may be pending behind it)
-    a.spin_limit = 300000000ll;   // 3 s of the 100 MHz wall clock: a neighbour that is not there by then never will be
+    a.spin_limit = spin_limit;
+    a.done_seq = e->err + 2;
+    a.seq = e->lad_seq + 1;
     HIPCHK(hipMemsetAsync(e->lad_flags, 0, ((size_t)grid + 16 + (size_t)e->W) * sizeof(int), e->stream));
-    HIPCHK(e->DP == 16 ? launch_ladder_16(p, a, diag, (int)grid, lds, e->stream) : launch_ladder_32(p, a, diag, (int)grid, lds, e->stream));
+    {
+      std::lock_guard<std::mutex> lock(g_lad_mutex);
+      if (g_lad_last && g_lad_last != e && g_lad_last->lad_event) HIPCHK(hipStreamWaitEvent(e->stream, g_lad_last->lad_event, 0));
+      HIPCHK(e->DP == 16 ? launch_ladder_16(p, a, diag, fl, (int)grid, lds, e->stream) : launch_ladder_32(p, a, diag, fl, (int)grid, lds, e->stream));
+      // (the event costs a host call per launch: only a process with several engines on this path records it)
+      static int engines_seen = 0;
+      static ptm_engine* first_seen = nullptr;
+      if (!first_seen) first_seen = e;
+      if (first_seen != e) engines_seen = 2;
+      if (engines_seen >= 2 || (g_lad_last && g_lad_last != e)) HIPCHK(hipEventRecord(e->lad_event, e->stream));
+      g_lad_last = e;
+    }
     e->ladder_launches++;
-    int took = k;
+    e->lad_seq += 1;
+    e->lad_log.push_back({e->lad_seq, e->step, k, e->log_head});
     if (e->lad_prof) {
       // diagnostics (PTM_LADDER_PROF): wait for the launch, read its outcome and its phase clocks -- mean microseconds per step and
       // phase over the workgroups, and the slowest workgroup's
@@ -1607,19 +1705,24 @@ static int ladder_steps(ptm_engine* e, int n) {
           fprintf(stderr, " %s %.2f/%.2f", phase[q], sum / grid, mx);
         }
         fprintf(stderr, "\n");
+        e->ladder_whole_steps += ctl[2];
       }
-      if (ctl[0] != 0 || ctl[1] != k) return fail(PTM_ERR_HIP, "the persistent ladder kernel gave up waiting for a neighbouring workgroup (is the device shared?); "
-                                                              "PTM_LADDER=0 selects the two-launch path");
-      e->ladder_whole_steps += ctl[2];
     }
-    // (otherwise the launch is ASYNCHRONOUS like every other step: a workgroup that gave up waiting for a neighbour -- a shared
-    //  device, a grid that is not resident -- raises bit 32 of the deferred error word, which ptm_sync reports)
-    e->step += (uint64_t)took;
-    done += took;
+    e->step += (uint64_t)k;
+    done += k;
     e->log_head = (e->log_head + 1) % PTM_LOG_RING;   // (the last step's candidate log sits in the slot handed over)
   }
   e->touched = false;
   return done;
+}
+
+static int two_launch_steps(ptm_engine* e, int n) {
+  int rc;
+  for (int k = 0; k < n; ++k) {
+    if (e->Nt > 1 && (rc = launch_decide(e, nullptr, nullptr, 0, nullptr, nullptr))) return rc;
+    if ((rc = launch_sweep(e))) return rc;
+  }
+  return PTM_OK;
 }
 
 extern "C" int ptm_step(ptm_engine* e, int n) {
@@ -1632,20 +1735,18 @@ extern "C" int ptm_step(ptm_engine* e, int n) {
     if (f < 0) return f;
     n -= f;
     if (n > 0) {
-      f = ladder_steps(e, n);
+      f = ladder_steps(e, n);   // (launches of that kernel follow each other without a look at the outcome of the one before: ladder_settle)
       if (f < 0) return f;
       n -= f;
     }
   }
-  for (int k = 0; k < n; ++k) {
-    if (e->Nt > 1 && (rc = launch_decide(e, nullptr, nullptr, 0, nullptr, nullptr))) return rc;
-    if ((rc = launch_sweep(e))) return rc;
-  }
-  return PTM_OK;
+  if (n > 0 && (rc = ladder_settle(e))) return rc;
+  return two_launch_steps(e, n);
 }
 
 extern "C" int ptm_sync(ptm_engine* e) {
   if (!e) return fail(PTM_ERR_INVALID, "null engine");
+  { const int rc = ladder_settle(e); if (rc) return rc; }
   HIPCHK(hipStreamSynchronize(e->stream));
   if (e->shard && e->shard->cstream) HIPCHK(hipStreamSynchronize(e->shard->cstream));   // (halos left in flight for the next step)
   int flag = 0;
@@ -1656,8 +1757,7 @@ extern "C" int ptm_sync(ptm_engine* e) {
                             "ptm_config.exchange_row_capacity slots (%d)", e->row_cap);
   if (flag & 8) return fail(PTM_ERR_FAR_MOVE, "a boundary message carried a row this shard did not expect (neighbour shards out of step?)");
   if (flag & 16) return fail(PTM_ERR_UNSUPPORTED, "a recorded rung's in-between history row belongs to the neighbour shard");
-  if (flag & 32) return fail(PTM_ERR_HIP, "the persistent ladder kernel gave up waiting for a neighbouring workgroup (is the device shared?); "
-                                          "PTM_LADDER=0 selects the two-launch path");
+  // (bit 32 -- a launch of the persistent ladder kernel gave up -- is not an error any more: ladder_settle has repeated its steps)
   return PTM_OK;
 }
 
@@ -2009,6 +2109,7 @@ extern "C" int ptm_shard_step(ptm_engine* e, int n) {
 
 // ---- read-back ------------------------------------------------------------------------------------------------------
 extern "C" int ptm_get_states(ptm_engine* e, double* X) {
+  SETTLE(e);
   if (!e || !X) return fail(PTM_ERR_INVALID, "null argument");
   const size_t Nc = e->Nc, D = e->D, DP = e->DP;
   const unsigned char* s;
@@ -2018,6 +2119,7 @@ extern "C" int ptm_get_states(ptm_engine* e, double* X) {
 }
 
 extern "C" int ptm_get_array(ptm_engine* e, int which, void* out) {
+  SETTLE(e);
   if (!e || !out) return fail(PTM_ERR_INVALID, "null argument");
   const size_t Nc = e->Nc;
   const unsigned char* s;
@@ -2063,6 +2165,7 @@ extern "C" int ptm_get_array(ptm_engine* e, int which, void* out) {
 }
 
 extern "C" int ptm_get_swap_counts(ptm_engine* e, int64_t* tries, int64_t* accepts) {
+  SETTLE(e);
   if (!e) return fail(PTM_ERR_INVALID, "null engine");
   const size_t np = (size_t)e->W * (e->Nt > 1 ? e->Nt - 1 : 1);
   { int rc = fold_swap_log(e); if (rc) return rc; }
@@ -2079,6 +2182,7 @@ extern "C" int ptm_get_swap_counts(ptm_engine* e, int64_t* tries, int64_t* accep
 }
 
 extern "C" int ptm_get_last_swaps(ptm_engine* e, int32_t* pairs, int32_t* accepted) {
+  SETTLE(e);
   if (!e) return fail(PTM_ERR_INVALID, "null engine");
   const size_t n = (size_t)e->W * e->ms;
   const int newest = (e->log_head + PTM_LOG_RING - 1) % PTM_LOG_RING;
@@ -2096,6 +2200,7 @@ extern "C" int ptm_get_last_swaps(ptm_engine* e, int32_t* pairs, int32_t* accept
 }
 
 extern "C" int ptm_get_map(ptm_engine* e, double* X, double* lpost, double* llike, double* lprior) {
+  SETTLE(e);
   if (!e) return fail(PTM_ERR_INVALID, "null engine");
   if (!e->map.rungs) return fail(PTM_ERR_INVALID, "MAP tracking is off (ptm_config.map_rungs)");
   const size_t n = (size_t)e->map.MC, D = e->D, DP = e->DP;
@@ -2110,6 +2215,7 @@ extern "C" int ptm_get_map(ptm_engine* e, double* X, double* lpost, double* llik
 extern "C" int ptm_restore(ptm_engine* e, const double* X, const double* llike, const int32_t* ntries, const int32_t* naccept,
                            const int32_t* last_type, const int64_t* nhist, uint64_t step_count, const int64_t* swap_tries,
                            const int64_t* swap_accepts) {
+  SETTLE(e);
   NO_BATCH(e, "ptm_restore");
   if (!e || !X || !llike || !ntries || !naccept || !last_type || !nhist) return fail(PTM_ERR_INVALID, "null argument");
   // (a history ring / MAP restart from the restored state here; ptm_set_history / ptm_set_map put saved ones back)
@@ -2141,6 +2247,7 @@ extern "C" int ptm_restore(ptm_engine* e, const double* X, const double* llike, 
 }
 
 extern "C" int ptm_set_map(ptm_engine* e, const double* X, const double* lpost, const double* llike, const double* lprior) {
+  SETTLE(e);
   NO_BATCH(e, "ptm_set_map");
   if (!e || !X || !lpost || !llike || !lprior) return fail(PTM_ERR_INVALID, "null argument");
   if (!e->map.rungs) return fail(PTM_ERR_INVALID, "MAP tracking is off (ptm_config.map_rungs)");
@@ -2156,6 +2263,7 @@ extern "C" int ptm_set_map(ptm_engine* e, const double* X, const double* lpost, 
 
 extern "C" int ptm_set_history(ptm_engine* e, const double* X, const double* llike, const double* lprior, const int32_t* meta,
                                const double* invtemps) {
+  SETTLE(e);
   NO_BATCH(e, "ptm_set_history");
   if (!e || !X || !llike || !lprior || !meta) return fail(PTM_ERR_INVALID, "null argument");
   if (!e->hist.rungs) return fail(PTM_ERR_INVALID, "history is off (ptm_config.history_rungs)");
@@ -2174,6 +2282,7 @@ extern "C" int ptm_set_history(ptm_engine* e, const double* X, const double* lli
 extern "C" int ptm_max_swaps_per_step(ptm_engine* e) { return e ? e->ms : 0; }
 
 extern "C" int ptm_get_history(ptm_engine* e, double* X, double* llike, double* lprior, int32_t* meta) {
+  SETTLE(e);
   if (!e) return fail(PTM_ERR_INVALID, "null engine");
   if (!e->hist.rungs) return fail(PTM_ERR_INVALID, "history is off (ptm_config.history_rungs)");
   const size_t n = (size_t)e->hist.cap * e->hist.HC, D = e->D, DP = e->DP;
@@ -2184,7 +2293,10 @@ extern "C" int ptm_get_history(ptm_engine* e, double* X, double* llike, double* 
   if (meta) { FETCH(s, e->hist.meta, n * 16); e->fetch_after.push_back([=] { memcpy(meta, s, n * 16); }); }
   return fetch_done(e);
 }
-extern "C" uint64_t ptm_step_count(ptm_engine* e) { return e ? e->step : 0; }
+extern "C" uint64_t ptm_step_count(ptm_engine* e) {
+  if (e) (void)ladder_settle(e);
+  return e ? e->step : 0;
+}
 
 // ---- measurement ------------------------------------------------------------------------------------------------------
 extern "C" int ptm_timer_start(ptm_engine* e) {
@@ -2211,6 +2323,13 @@ extern "C" int ptm_get_kernel_times(ptm_engine* e, float* ms, int capacity, int*
   }
   *count = n;
   e->kev_used = 0;
+  return PTM_OK;
+}
+
+extern "C" int ptm_get_ladder_stats(ptm_engine* e, int64_t out[4]) {
+  if (!e || !out) return fail(PTM_ERR_INVALID, "null argument");
+  SETTLE(e);
+  out[0] = e->ladder_launches; out[1] = e->ladder_fallbacks; out[2] = e->ladder_whole_steps; out[3] = e->lad_disabled ? 1 : 0;
   return PTM_OK;
 }
 
@@ -2328,7 +2447,7 @@ extern "C" const char* ptm_step_kernel_name(ptm_engine* e) {
                      !(e->evolve_rate > 0 && (e->W > 64 || e->evolve_cut >= 0));
   if (e->nloc != e->Nt) snprintf(b, sizeof b, "(sharded: ptm_exchange_* / ptm_shard_step) decide_kernel + %s", ptm_sweep_kernel_name(e));
   else if (fused) snprintf(b, sizeof b, "ladder_steps_kernel<%d, %d, %d>", e->DP, e->prop_kind == PTM_PROP_DIAG ? KIND_DIAG : KIND_DENSE, (long long)e->Nt * e->DP <= 64 ? 64 : 256);
-  else if (ladder_applies(e)) snprintf(b, sizeof b, "ladder_persistent_kernel<%d, %d>", e->DP, e->prop_kind == PTM_PROP_DIAG ? KIND_DIAG : KIND_DENSE);
+  else if (ladder_applies(e)) snprintf(b, sizeof b, "ladder_persistent_kernel<%d, %d, %d>", e->DP, e->prop_kind == PTM_PROP_DIAG ? KIND_DIAG : KIND_DENSE, ladder_flavour(e));
   else snprintf(b, sizeof b, "decide_kernel + %s", ptm_sweep_kernel_name(e));
   name = b;
   return name.c_str();

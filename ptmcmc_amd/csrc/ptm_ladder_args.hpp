@@ -5,6 +5,7 @@
 namespace ptm {
 
 constexpr int LADDER_H = 8;   // halo depth in rungs (parallel.DEFAULT_HALO has the run-length statistics)
+constexpr int LADDER_ABORT_BIT = 1 << 30;   // in the arrivals word ctl[3]: some workgroup of the launch has given up
 constexpr int LADDER_THREADS = 512;   // four waves of chains (256 lanes: a lane per dimension) + four bookkeeper waves
 
 struct LadderArgs {
@@ -16,7 +17,10 @@ struct LadderArgs {
   double* pub_ll;       // [2][Nc]
   double* pub_lp;       // [2][Nc]
   int* flags;           // [W * NB]  steps published by each workgroup since the launch began
-  int* ctl;             // [0] abort (a neighbour never showed up), [1] steps done (set by workgroup 0), [2] whole-ladder steps taken
+  int* ctl;             // [0] abort (a neighbour never showed up), [1] steps done (set by workgroup 0), [2] whole-ladder steps taken,
+                        // [3] workgroups that have finished all their steps | LADDER_ABORT_BIT (the all-or-nothing word)
+  int* done_seq;        // sequence number of the engine's last launch of this kernel that was committed (persistent; not cleared per launch)
+  int seq;              // this launch's number: it runs only if *done_seq == seq - 1
   int* slow_done;       // [W] workgroups that finished a whole-ladder exchange (a barrier of the ladder's workgroups)
   long long* swap_cnt;  // [W][Nt-1][2] {tries, accepts} (chain.hh:244-245)
   int* swap_log;        // [W][ms] candidate log of the LAST step asked for (ptm_get_last_swaps)
@@ -27,11 +31,11 @@ struct LadderArgs {
 };
 
 // LDS of the decide replay (bytes): first[Nt] | cand[ms] | ua[ms] | alive[ms] (+pad) | flag words
-inline size_t ladder_decide_lds_bytes(int Nt, int ms) { return (size_t)((Nt + 1) & ~1) * 4 + (size_t)((ms + 1) & ~1) * 8 + (size_t)((ms + 7) & ~7) + 32 + (size_t)Nt * 12 + 16; }
+inline size_t ladder_decide_lds_bytes(int Nt, int ms) { return (size_t)((Nt + 1) & ~1) * 4 + (size_t)((ms + 1) & ~1) * 8 + (size_t)((ms + 7) & ~7) + 32 + (size_t)Nt * 8 + (size_t)((Nt + 1) & ~1) * 8 + 16; }
 // ... and of the window: llike (working + original), lprior, rows, perm | tries / accepts of the own pairs
 inline size_t ladder_window_lds_bytes(int DP) {
   const int R = 256 / DP, WN = 1 + R + LADDER_H;
-  return (size_t)WN * 8 * 5 + (size_t)WN * DP * 8 + (size_t)((WN + 3) & ~3) * 4 + (size_t)R * 8 + 64;
+  return (size_t)WN * 8 * 5 + (size_t)WN * DP * 8 + (size_t)((WN + 3) & ~3) * 8 + (size_t)R * 8 + 64;
 }
 
 // ... and, at 32 dimensions with a full factor, the precision matrix as padded rows (stride DP + 1: conflict-free for a lane per row):

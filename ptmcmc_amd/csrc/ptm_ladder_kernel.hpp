@@ -30,8 +30,30 @@
 //
 // Arithmetic: the operation sequences of lanes_body / decide_body, number for number -- the chains are bit-identical to the
 // two-launch path and to the CPU checker (the parity suite runs through this kernel wherever it applies).
-// Scope: the plain workload (open or `limit` bounds, all-uniform prior, zero mean, no one-dimensional moves, no mixture, fixed ladder,
-// device target), no history / MAP tracking, DP = 16 or 32.
+// Scope: open or `limit` bounds, all-uniform prior, zero mean, fixed ladder, device target, DP = 16 or 32; template flags FL: bit 0 =
+// one-dimensional moves and scale mixtures (the reference sampler's default Gaussian recipe, ptmcmc.cc:117-139), bit 1 = the history
+// ring and MAP tracking of MH_chain::add_state (chain.cc:931-946), rows of a rung exchanged twice in a step included (quirk Q6).
+//
+// ALL OR NOTHING.  A workgroup that waits in vain for a neighbour (a grid that is not resident: a shared device, a second engine's
+// kernel in the way) gives up, and then nothing of the launch may stay: the chains live in registers until every workgroup of the grid
+// has finished every step -- each adds itself to ONE counter word and waits for it to reach the grid size; giving up sets a bit in the
+// same word, so no workgroup can ever read "all there" once anybody has given up, and a workgroup that gives up waiting for the
+// counter itself learns from the value its atomic-or returns whether everybody had arrived after all.  Only then are rows, scalars,
+// counters and swap counters written back and the launch's sequence number stored (LadderArgs::done_seq): the host finds a launch
+// that gave up at its next look (ladder_settle, ptm_engine.hip), the engine's arrays untouched, and repeats its steps on the
+// two-launch path.  A launch that finds its predecessor's number missing does nothing.  History rows and MAP entries are written as
+// the steps produce them: the repeated steps produce the same rows into the same slots and the same maxima.
+//
+// MEMORY ORDER of the hand-over (the form MI355X_MICROARCH.md lists under "Hand-offs measured with sc1 loads in place of the
+// acquire", first row): every published word is stored with an agent-scope relaxed atomic (an sc1 store: written through to memory,
+// dropped from the XCD's L2); every storing wave waits for its stores (s_waitcnt vmcnt(0)) BEFORE the workgroup's barrier; ONE lane
+// raises the workgroup's flag (an sc1 store) AFTER that barrier; the consumer polls the flag with sc1 loads (they bypass its L1, no
+// stale line can answer), and the wave that polled issues the loads of the published words -- sc1 loads to registers, every one of
+// them -- only after its poll has matched: vector-memory loads of a wave return in issue order, and a compiler barrier after every
+// look at a flag keeps the compiler from hoisting a payload load above it; the other waves read what that wave put into LDS behind
+// a workgroup barrier.  This is measured hardware behaviour of gfx950 / ROCm 7.2, not a guarantee of the HIP memory model (which
+// would ask for a release / acquire pair: +0.4 us per hand-over, tools/probes/flag_pingpong_probe.hip); the parity suite, the soak
+// runs and the forced-give-up test run through it.
 #pragma once
 #include "ptm_decide.hpp"
 #include "ptm_ladder_args.hpp"
@@ -39,9 +61,13 @@
 
 namespace ptm {
 
-template <int DP, int KIND>
+template <int DP, int KIND, int FL>
 __global__ __launch_bounds__(LADDER_THREADS) void ladder_persistent_kernel(const Dev p, const LadderArgs a) {
   static_assert(DP == 16 || DP == 32, "persistent ladder kernel: DP 16 or 32");
+  constexpr bool GENX = (FL & 1) != 0;   // one-dimensional moves, scale mixtures
+  constexpr bool HIST = (FL & 2) != 0;   // history ring, MAP tracking
+  // a launch whose predecessor gave up does nothing: the host repeats that launch's steps, and this one's, on the two-launch path
+  if (__hip_atomic_load(a.done_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.seq - 1) return;
   constexpr int R = 256 / DP;            // rungs per workgroup
   constexpr int CPW = 64 / DP;           // chains per wave
   constexpr int H = LADDER_H;
@@ -87,12 +113,14 @@ __global__ __launch_bounds__(LADDER_THREADS) void ladder_persistent_kernel(const
   double* wlu = wdb + WNMAX;                                              // [WN] log of the accept uniform of the pair's surviving pick
   double* wx = wlu + WNMAX;                                               // [WN][DP] rows as published
   int* wperm = reinterpret_cast<int*>(wx + WNMAX * DP);                   // [WN] source rung of the row now at a rung
-  int* ptry = wperm + ((WNMAX + 3) & ~3);                                 // [R] exchange attempts of the own pairs (lower rung here)
+  int* wmid = wperm + ((WNMAX + 3) & ~3);                                 // [WN] source rung of the row a rung held BETWEEN its two exchanges of this step
+  int* ptry = wmid + ((WNMAX + 3) & ~3);                                  // [R] exchange attempts of the own pairs (lower rung here)
   int* pacc = ptry + R;                                                   // [R] ... accepted
   double* llall = reinterpret_cast<double*>(pacc + R + ((2 * R) & 1));    // [Nt] whole-ladder llike view (steps with a run longer than the halo)
   int* permall = reinterpret_cast<int*>(llall + Nt);                      // [Nt] ... and row map
+  int* midall = permall + ((Nt + 1) & ~1);                                // [Nt] ... and in-between rows
   constexpr bool PROW_LDS = DP == 32 && KIND != KIND_DIAG;                // the precision matrix's rows from LDS (ptm_ladder_args.hpp)
-  double* psq = reinterpret_cast<double*>(permall + ((Nt + 1) & ~1));     // [DP][DP + 1], zeros above the diagonal
+  double* psq = reinterpret_cast<double*>(midall + ((Nt + 1) & ~1));      // [DP][DP + 1], zeros above the diagonal
 
   lanes_stage<DP>(p, lds_all);
   for (int i = tid; i < Nt; i += LADDER_THREADS) first[i] = NONE;
@@ -109,6 +137,10 @@ __global__ __launch_bounds__(LADDER_THREADS) void ladder_persistent_kernel(const
   const int c = rg * p.W + w;
   const bool lead = d == 0;
   const int pos = row_pos<DP>(d);
+  const bool hist_on = HIST && rg < p.hist.rungs, map_on = HIST && rg < p.map.rungs;
+  const unsigned int every = (unsigned int)p.add_every_n;
+  // a flag of the chain's lead lane, for all its lanes
+  auto from_lead = [&](int v) { return __builtin_amdgcn_ds_bpermute(4 * (g * DP), v); };
   auto sync_wave = [] { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); };
   constexpr unsigned long long GM = DP == 64 ? ~0ull : ((1ull << (DP & 63)) - 1ull);
   auto all_of_chain = [&](bool v) { return ((__builtin_amdgcn_ballot_w64(v) >> (g * DP)) & GM) == GM; };
@@ -151,7 +183,7 @@ __global__ __launch_bounds__(LADDER_THREADS) void ladder_persistent_kernel(const
 #define PTM_LADDER_TICK(k) do { if (a.prof && tid == a.prof_tid) { const long long t_ = wall_clock64(); if ((k) > 0) tick_sum[(k)] += t_ - tick_last; tick_last = t_; } } while (0)
 #define PTM_LADDER_ALIVE(r) ((r) >= 0 && (r) <= Nt - 2 && first[(r)] != NONE && alive[first[(r)]])
   // one trial (chain.cc:1459-1467) on a llike view `lv` / row map `pm` indexed from rung `base`; own pairs are counted and logged
-  auto trial = [&](double* lv, int* pm, int base, int i, bool last_step, double dbeta, double lu) {
+  auto trial = [&](double* lv, int* pm, int* md, int base, int i, bool last_step, double dbeta, double lu) {
     const int kk = first[i];
     double lla = lv[i - base];
     if (!(lla > -1e200)) lla = -1e200;
@@ -164,6 +196,9 @@ __global__ __launch_bounds__(LADDER_THREADS) void ladder_persistent_kernel(const
       const double t = lv[i - base]; lv[i - base] = lv[i + 1 - base]; lv[i + 1 - base] = t;
       const int q = pm[i - base]; pm[i - base] = pm[i + 1 - base]; pm[i + 1 - base] = q;
     }
+    // rung i is exchanged once more if the pair below survived too: what it holds now is the row its FIRST add_state of the
+    // step sees (chain.cc:1487-1490; quirk Q6)
+    if (HIST && PTM_LADDER_ALIVE(i - 1)) md[i - base] = pm[i - base];
     if (i >= r0 && i < r1) {                              // an own pair: its counters, its line of the log
       ptry[i - r0] += 1;
       if (acc) pacc[i - r0] += 1;
@@ -177,7 +212,7 @@ __global__ __launch_bounds__(LADDER_THREADS) void ladder_persistent_kernel(const
     for (;;) {
       const int fv = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const int ab = __hip_atomic_load(&a.ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (fv >= s + 1) return true;
+      if (fv >= s + 1) { asm volatile("" ::: "memory"); return true; }   // (no load of the published words may be hoisted above this look)
       if (ab != 0 || wall_clock64() - t0 > a.spin_limit) return false;
       __builtin_amdgcn_s_sleep(1);
     }
@@ -190,7 +225,7 @@ __global__ __launch_bounds__(LADDER_THREADS) void ladder_persistent_kernel(const
       const int vlo = __hip_atomic_load(flo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const int vhi = __hip_atomic_load(fhi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const int ab = __hip_atomic_load(&a.ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if ((b == 0 || vlo >= s + 1) && (b + 1 >= NB || vhi >= s + 1)) return true;
+      if ((b == 0 || vlo >= s + 1) && (b + 1 >= NB || vhi >= s + 1)) { asm volatile("" ::: "memory"); return true; }
       if (ab != 0 || wall_clock64() - t0 > a.spin_limit) return false;
       __builtin_amdgcn_s_sleep(1);
     }
@@ -245,7 +280,11 @@ __global__ __launch_bounds__(LADDER_THREADS) void ladder_persistent_kernel(const
         if (b + 1 < NB) fl_hi = __hip_atomic_load(&a.flags[blk + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     };
-    auto flags_up = [&] { return __builtin_amdgcn_readfirstlane(fl_lo) >= s + 1 && __builtin_amdgcn_readfirstlane(fl_hi) >= s + 1; };
+    auto flags_up = [&] {
+      const bool up = __builtin_amdgcn_readfirstlane(fl_lo) >= s + 1 && __builtin_amdgcn_readfirstlane(fl_hi) >= s + 1;
+      asm volatile("" ::: "memory");   // (the window's loads stay behind this look at the flags)
+      return up;
+    };
     // the window: rows, llikes and lpriors of rungs wlo .. whi as published for this step, NWR words per bookkeeper thread
     constexpr int NWR = (WNMAX * DP + 2 * WNMAX + 127) / 128;
     double wr[NWR];
@@ -263,8 +302,10 @@ __global__ __launch_bounds__(LADDER_THREADS) void ladder_persistent_kernel(const
         wr[q] = src ? __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
       }
     };
-    double xn = 0.0, newlike = 0.0, newlprior = 0.0, off = 0.0;
+    double xn = 0.0, newlike = 0.0, newlprior = 0.0, newlpost = 0.0, off = 0.0;
     bool accept = false;
+    int type = 0, axis = -1, kmix = 0;   // GENX: the step's proposal type code, its one-dimensional move's axis, its mixture member
+    double mix_scale = 1.0;
     u32x4 o0 = u32x4{0u, 0u, 0u, 0u}, o = u32x4{0u, 0u, 0u, 0u};
 
     // -- segment A: candidate draws | the chains' random blocks
@@ -282,6 +323,19 @@ __global__ __launch_bounds__(LADDER_THREADS) void ladder_persistent_kernel(const
     } else {
       o0 = draw_block(p.seed, TAG_MH, stream, step, 0);
       o = draw_block(p.seed, TAG_MH, stream, step, (uint32_t)((d >> 2) + 1));
+      if (GENX) {   // lanes_body's, verbatim (proposal_distribution_set::draw, proposal_distribution.cc:99-129; gaussian_prop::draw, .hh:196-206)
+        double f = p.onedfrac[rg];
+        if (p.mix_K > 0) {
+          const double* mx = p.mix + (size_t)rg * p.mix_K * 3;
+          const double xs = p.mix_K > 1 ? u01(o0.v3) : 0.0;
+          kmix = p.mix_K - 1;
+          for (int k = p.mix_K - 2; k >= 0; --k)
+            if (xs < mx[3 * k]) kmix = k;
+          mix_scale = mx[3 * kmix + 1];
+          f = mx[3 * kmix + 2];
+        }
+        if (p.any_oned && f > 0 && u01(o0.v1) < f) { axis = (int)(p.D * u01(o0.v2)); type = 1; }
+      }
     }
     replay_sync(5, 4 * (s + 1), helper, drole);   // every bookkeeper wave has drawn: the two replay waves go on when all four have
     PTM_LADDER_TICK(2);
@@ -316,7 +370,8 @@ __global__ __launch_bounds__(LADDER_THREADS) void ladder_persistent_kernel(const
       const bool hi = (d & 2) != 0;
       double z0, z1;
       boxmuller(hi ? o.v2 : o.v0, hi ? o.v3 : o.v1, lds_all, z0, z1);
-      const double zd = (d & 1) ? z1 : z0;
+      double zd = (d & 1) ? z1 : z0;
+      if (GENX && axis >= 0 && d != axis) zd = 0.0;   // one-dimensional move (proposal_distribution.hh:197-205)
       if (KIND == KIND_DIAG) off = tcol[0] * zd;
       else {
         vbuf[g * DP + d] = zd;
@@ -333,6 +388,10 @@ __global__ __launch_bounds__(LADDER_THREADS) void ladder_persistent_kernel(const
             }
         off = acc;
         sync_wave();
+      }
+      if (GENX && p.mix_K > 0) {
+        type = kmix + 10 * type;        // proposal_distribution.cc:117
+        off = mix_scale * off;          // the member is scale_k times the rung's factor
       }
     }
     replay_sync(6, 2 * (s + 1), drole, drole);    // the filter is done
@@ -401,7 +460,7 @@ __global__ __launch_bounds__(LADDER_THREADS) void ladder_persistent_kernel(const
       const double quad = ((pbuf[g * 4 + 0] + pbuf[g * 4 + 1]) + pbuf[g * 4 + 2]) + pbuf[g * 4 + 3];
       sync_wave();   // (vbuf / pbuf are rewritten by the next step's draw)
       newlike = p.like0 - 0.5 * quad;
-      double newlpost = newlike * beta + newlprior;
+      newlpost = newlike * beta + newlprior;
       if (!want_like) newlike = newlpost = -__builtin_inf();
       const double logH = newlpost - cur_lpost;
       accept = valid;
@@ -413,13 +472,64 @@ __global__ __launch_bounds__(LADDER_THREADS) void ladder_persistent_kernel(const
     // rungs an exchange attempt touches make no Metropolis move this step, one add_state per attempt (chain.cc:1487-1490,
     // 1531-1534,1553-1557): known from the draws alone
     const int tc = helper ? 0 : (PTM_LADDER_ALIVE(rg) ? 1 : 0) + (PTM_LADDER_ALIVE(rg - 1) ? 1 : 0);
+    const unsigned int nh0 = nhist;   // add_state calls before this step's
     if (!helper) {
       if (!tc) {
         ntries += 1;
         nhist += 1u;
-        if (accept) { xd = xn; ll = newlike; lp = newlprior; naccept += 1; last_type = 0; }
+        if (HIST) {
+          // this add_state saves a row (chain.cc:935-946): the proposal if it was accepted, else the state as it stands
+          if (hist_on && nh0 % every == 0u) {
+            const long long hrow = 1 + (long long)(nh0 / every);
+            const size_t o = hist_slot(p.hist, hrow, c);
+            if (live) p.hist.x[o * DP + pos] = accept ? xn : xd;
+            if (live && lead) {
+              if (accept) hist_scalars(p.hist, o, hrow, newlike, newlprior, naccept + 1, ntries, GENX ? type : 0, beta);
+              else hist_scalars(p.hist, o, hrow, ll, lp, naccept, ntries, last_type, beta);
+            }
+          }
+          int mapw = 0;
+          if (map_on && lead && live && accept) mapw = map_try(p.map, c, newlpost, newlike, newlprior) ? 1 : 0;   // chain.cc:931-934
+          if (map_on) {
+            mapw = from_lead(mapw);
+            if (mapw && live) p.map.x[(size_t)c * DP + pos] = xn;
+          }
+        }
+        if (accept) { xd = xn; ll = newlike; lp = newlprior; naccept += 1; last_type = GENX ? type : 0; }
       } else nhist += (unsigned int)tc;
     }
+    // the add_state calls of a rung the exchange phase touched (one per attempt; the rung makes no Metropolis move): history and MAP
+    // see the row the rung holds at each call -- the in-between row `mid` at the first of two (its scalars, the rung's own counters)
+    auto exchanged_adds = [&](double xmid, double llmid, double lpmid) {
+      if (!HIST || !tc) return;
+      if (tc == 2) {
+        if (hist_on && nh0 % every == 0u) {
+          const long long hrow = 1 + (long long)(nh0 / every);
+          const size_t o = hist_slot(p.hist, hrow, c);
+          if (live) p.hist.x[o * DP + pos] = xmid;
+          if (live && lead) hist_scalars(p.hist, o, hrow, llmid, lpmid, naccept, ntries, last_type, beta);
+        }
+        int mw = 0;
+        if (map_on && lead && live) { const double tb = beta * llmid; mw = map_try(p.map, c, lpmid + tb, llmid, lpmid) ? 1 : 0; }
+        if (map_on) {
+          mw = from_lead(mw);
+          if (mw && live) p.map.x[(size_t)c * DP + pos] = xmid;
+        }
+      }
+      const unsigned int al = nh0 + (unsigned int)tc - 1u;   // the LAST of the adds saw the row as it is now
+      if (hist_on && al % every == 0u) {
+        const long long hrow = 1 + (long long)(al / every);
+        const size_t o = hist_slot(p.hist, hrow, c);
+        if (live) p.hist.x[o * DP + pos] = xd;
+        if (live && lead) hist_scalars(p.hist, o, hrow, ll, lp, naccept, ntries, last_type, beta);
+      }
+      int mw = 0;
+      if (map_on && lead && live) { const double tb = beta * ll; mw = map_try(p.map, c, lp + tb, ll, lp) ? 1 : 0; }
+      if (map_on) {
+        mw = from_lead(mw);
+        if (mw && live) p.map.x[(size_t)c * DP + pos] = xd;
+      }
+    };
 
     if (!sflag[0]) {
       // ---- 4. the exchange phase from the neighbours' publications
@@ -431,7 +541,7 @@ __global__ __launch_bounds__(LADDER_THREADS) void ladder_persistent_kernel(const
         // workgroup's rungs.  Somebody else's.
         if (PTM_LADDER_ALIVE(n) && !PTM_LADDER_ALIVE(n + 1))
           for (int i = n; i >= wlo; --i) {
-            trial(wll, wperm, wlo, i, last_step, wdb[i - wlo], wlu[i - wlo]);
+            trial(wll, wperm, wmid, wlo, i, last_step, wdb[i - wlo], wlu[i - wlo]);
             if (!PTM_LADDER_ALIVE(i - 1)) break;
           }
       }
@@ -441,6 +551,10 @@ __global__ __launch_bounds__(LADDER_THREADS) void ladder_persistent_kernel(const
       if (tc) {
         const int src = wperm[rg - wlo];
         if (src != rg) { xd = wx[(src - wlo) * DP + d]; ll = wll0[src - wlo]; lp = wlp0[src - wlo]; }
+        if (HIST) {
+          const int sm = tc == 2 ? wmid[rg - wlo] : rg;
+          exchanged_adds(wx[(sm - wlo) * DP + d], wll0[sm - wlo], wlp0[sm - wlo]);
+        }
       }
     } else {
       // ---- 4'. the same from the WHOLE ladder's publications (a run of surviving picks longer than the halo: rare).  Every
@@ -468,7 +582,7 @@ __global__ __launch_bounds__(LADDER_THREADS) void ladder_persistent_kernel(const
         const int n = cand[k];
         if (n < 0 || !alive[k] || PTM_LADDER_ALIVE(n + 1)) continue;   // tops of runs of surviving picks
         for (int i = n; i >= 0; --i) {
-          trial(llall, permall, 0, i, last_step, -(p.beta[i + 1] - p.beta[i]), dlog_u01(ua[first[i]]));
+          trial(llall, permall, midall, 0, i, last_step, -(p.beta[i + 1] - p.beta[i]), dlog_u01(ua[first[i]]));
           if (!PTM_LADDER_ALIVE(i - 1)) break;
         }
       }
@@ -480,6 +594,16 @@ __global__ __launch_bounds__(LADDER_THREADS) void ladder_persistent_kernel(const
           xd = __hip_atomic_load(a.pub_x + par * NcDP + cs * DP + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           ll = __hip_atomic_load(pl + cs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           lp = __hip_atomic_load(a.pub_lp + (size_t)par * p.Nc + cs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (HIST) {
+          double xm = xd, lm = ll, pm_ = lp;
+          if (tc == 2) {
+            const size_t cm = (size_t)midall[rg] * p.W + w;
+            xm = __hip_atomic_load(a.pub_x + par * NcDP + cm * DP + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            lm = __hip_atomic_load(pl + cm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            pm_ = __hip_atomic_load(a.pub_lp + (size_t)par * p.Nc + cm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          exchanged_adds(xm, lm, pm_);
         }
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -506,16 +630,39 @@ __global__ __launch_bounds__(LADDER_THREADS) void ladder_persistent_kernel(const
   }
 #undef PTM_LADDER_ALIVE
 
-  // -- back to the engine's arrays
-  if (!aborted && live) {
+  // -- all or nothing (header): every workgroup has finished every step, or nothing of this launch stays
+  if (tid == 0) {
+    int ok = 0;
+    if (aborted) __hip_atomic_fetch_or(&a.ctl[3], LADDER_ABORT_BIT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else {
+      const int old = __hip_atomic_fetch_add(&a.ctl[3], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (!(old & LADDER_ABORT_BIT)) {
+        const long long t0 = wall_clock64();
+        for (;;) {
+          const int v = __hip_atomic_load(&a.ctl[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (v == G) { ok = 1; break; }
+          if (v & LADDER_ABORT_BIT) break;
+          if (wall_clock64() - t0 > a.spin_limit) {
+            // (whoever sets the bit learns from the value it replaces whether everybody had arrived after all)
+            ok = __hip_atomic_fetch_or(&a.ctl[3], LADDER_ABORT_BIT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == G ? 1 : 0;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
+    }
+    sflag[3] = ok;
+  }
+  __syncthreads();
+  const bool commit = sflag[3] != 0;
+  if (commit && live) {
     p.x[(size_t)c * DP + pos] = xd;
     if (lead) {
       p.ll[c] = ll; p.lp[c] = lp;
       p.ntries[c] = ntries; p.naccept[c] = naccept; p.last_type[c] = last_type; p.nhist[c] = nhist;
     }
   }
-  __syncthreads();
-  if (!aborted && tid < R && r0 + tid < Nt - 1 && r0 + tid < r1) {
+  if (commit && tid < R && r0 + tid < Nt - 1 && r0 + tid < r1) {
     long long* sc = a.swap_cnt + ((size_t)w * (Nt - 1) + (r0 + tid)) * 2;
     sc[0] += ptry[tid];
     sc[1] += pacc[tid];
@@ -523,9 +670,12 @@ __global__ __launch_bounds__(LADDER_THREADS) void ladder_persistent_kernel(const
   if (a.prof && tid == a.prof_tid)
     for (int k = 0; k < 7; ++k) a.prof[(size_t)blk * 8 + k] = tick_sum[k];
 #undef PTM_LADDER_TICK
-  if (L == 0 && tid == 0) { a.ctl[1] = aborted ? -1 : done; a.ctl[2] = nslow; }
-  // (a launch is asynchronous: a workgroup that gave up says so in the engine's deferred error word, read at the next ptm_sync)
-  if (aborted && tid == 0) atomicOr(p.err, 32);
+  if (L == 0 && tid == 0) {
+    a.ctl[1] = commit ? done : -1; a.ctl[2] = nslow;
+    if (commit) *a.done_seq = a.seq;   // (visible to the next launch and to the host at the kernel's end)
+  }
+  // (a launch is asynchronous: a workgroup that gave up says so in the engine's deferred error word too; the host looks at done_seq)
+  if (!commit && tid == 0) atomicOr(p.err, 32);
 }
 
 }  // namespace ptm

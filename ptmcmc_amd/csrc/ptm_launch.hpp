@@ -38,8 +38,8 @@ PTM_DECL_FUSED(16)
 // ladder_blocks_N: how many of its workgroups the device holds at once (0: the kernel cannot run); launch_ladder_N: the launch
 #define PTM_DECL_LADDER(N)                                  \
   size_t ladder_lds_##N(int Nt, int ms);                    \
-  int ladder_blocks_##N(bool diag, size_t lds);             \
-  hipError_t launch_ladder_##N(const Dev& p, const LadderArgs& a, bool diag, int grid, size_t lds, hipStream_t st);
+  int ladder_blocks_##N(bool diag, int fl, size_t lds);     \
+  hipError_t launch_ladder_##N(const Dev& p, const LadderArgs& a, bool diag, int fl, int grid, size_t lds, hipStream_t st);
 PTM_DECL_LADDER(16)
 PTM_DECL_LADDER(32)
 #undef PTM_DECL_LADDER

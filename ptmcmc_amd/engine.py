@@ -27,7 +27,7 @@ EXPORTS = [
     "ptm_set_proposals", "ptm_set_proposal_rung", "ptm_set_proposal_mixture", "ptm_set_proposal_callback", "ptm_set_states", "ptm_init_from_prior", "ptm_init_from_prior_k", "ptm_sweep", "ptm_step", "ptm_sync",
     "ptm_copy_llike", "ptm_copy_lprior", "ptm_llike_device_ptr", "ptm_exchange_decide", "ptm_exchange_decide_gathered", "ptm_set_shard_map", "ptm_exchange_redo_count", "ptm_exchange_redo", "ptm_exchange_finish_and_sweep", "ptm_exchange_install", "ptm_sweep_rungs", "ptm_exchange_buffer_doubles", "ptm_exchange_row_capacity", "ptm_shard_unique_id", "ptm_shard_init", "ptm_shard_step", "ptm_shard_finalize", "ptm_get_states", "ptm_batch_begin", "ptm_batch_end",
     "ptm_get_array", "ptm_get_swap_counts", "ptm_get_last_swaps", "ptm_max_swaps_per_step", "ptm_get_history", "ptm_get_history_invtemps", "ptm_set_history", "ptm_set_map", "ptm_get_map", "ptm_restore", "ptm_step_count",
-    "ptm_timer_start", "ptm_timer_stop", "ptm_get_kernel_times", "ptm_calibrate", "ptm_get_counter_sums", "ptm_sweep_kernel_name", "ptm_step_kernel_name", "ptm_debug_eval",
+    "ptm_timer_start", "ptm_timer_stop", "ptm_get_kernel_times", "ptm_calibrate", "ptm_get_counter_sums", "ptm_get_ladder_stats", "ptm_sweep_kernel_name", "ptm_step_kernel_name", "ptm_debug_eval",
     "ptm_debug_philox", "ptm_debug_boxmuller", "ptm_debug_sqrt_scan", "ptm_debug_evaluate",
     "ptm_dev_alloc", "ptm_dev_free", "ptm_dev_copy",
 ]
@@ -131,6 +131,7 @@ def load():
     L.ptm_get_kernel_times.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_int)]
     L.ptm_calibrate.argtypes = [C.c_void_p, C.POINTER(PtmCalibration)]
     L.ptm_get_counter_sums.argtypes = [C.c_void_p, _i64p, _i64p]
+    L.ptm_get_ladder_stats.argtypes = [C.c_void_p, _i64p]
     L.ptm_debug_eval.argtypes = [C.c_int, C.c_int, _dp, _dp, _dp, C.c_int]
     L.ptm_debug_philox.argtypes = [C.c_int, C.c_uint64, C.c_int, C.c_uint32, C.c_uint64, C.c_uint32, _u32p]
     L.ptm_debug_boxmuller.argtypes = [C.c_int, _u32p, _u32p, _dp, _dp, C.c_int]
@@ -636,6 +637,12 @@ class Engine:
         n = C.c_int()
         _chk(self.L.ptm_get_kernel_times(self.h, buf, capacity, C.byref(n)))
         return np.array(buf[:min(n.value, capacity)], dtype=np.float64)
+
+    def ladder_stats(self):
+        """persistent ladder kernel: launches, launches that gave up (repeated on the two-launch path), whole-ladder steps, switched off"""
+        o = (C.c_int64 * 4)()
+        _chk(self.L.ptm_get_ladder_stats(self.h, o))
+        return dict(launches=o[0], fallbacks=o[1], whole_steps=o[2], disabled=bool(o[3]))
 
     def counter_sums(self):
         """(sum of MH_chain::Ntries, sum of ::Naccept) over the engine's chains, reduced on the device (ptm_get_counter_sums)"""

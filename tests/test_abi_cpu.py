@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     lib = C.CDLL(E.LIB_PATH)
     for name in declared_functions():
         assert hasattr(lib, name), name
-    assert lib.ptm_abi_version() == 2
+    assert lib.ptm_abi_version() == 3
 
 
 def test_header_is_plain_c():

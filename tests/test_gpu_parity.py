@@ -17,7 +17,7 @@ TOL = 1e-10
 
 def test_device_present_and_abi():
     assert E.device_count() >= 1
-    assert E.load().ptm_abi_version() == 2
+    assert E.load().ptm_abi_version() == 3
 
 
 def test_philox_on_device_matches_known_answers_and_oracle():
@@ -1488,4 +1488,132 @@ def test_persistent_ladder_kernel_matches_the_oracle(D, Nt, W, kind, sr):
     PU.assert_same_state(eng, lad, "after plain sweeps")
     eng.step(5); eng.sync(); lad.pt_step(5)
     PU.assert_same_state(eng, lad, "after PT steps again")
+    eng.close()
+
+
+LADDER_FLAVOURS = [
+    # D, Nt, W, kind, swap_rate, gauss_1d_frac, mixture members K, add_every_N (0: no history / MAP)
+    (32, 1024, 1, E.PROP_LOWER, 0.1, 0.3, 3, 3),     # the reference's own shape with the sampler's default Gaussian recipe, saved every 3rd add
+    (32, 100, 2, E.PROP_DENSE, 0.25, 0.5, 0, 2),     # one-dimensional moves + history, no mixture
+    (16, 70, 3, E.PROP_DIAG, 0.3, 0.0, 4, 0),        # mixture alone
+    (20, 37, 1, E.PROP_DENSE, 0.35, 0.0, 0, 1),      # history alone, every add saved: every in-between row of a rung exchanged twice is one
+    (32, 8, 5, E.PROP_LOWER, 0.35, 0.4, 2, 5),       # one workgroup per ladder
+    (9, 41, 2, E.PROP_LOWER, 0.45, 0.25, 1, 1),      # a set of one (draws nothing), many exchanges per step
+]
+
+
+def _ladder_flavour_pair(D, Nt, W, kind, sr, odf, K, N, cap=64):
+    pr = PU.problem_for(D, Nt, 1e4)
+    eng = E.Engine(D, Nt, W, swap_rate=sr, add_every_n=max(N, 1), history_rungs=Nt if N else 0, history_capacity=cap if N else 0, map_rungs=Nt if N else 0)
+    fac = pr.configure(eng, kind, np.full(Nt, odf) if odf > 0 else None)
+    eng.init_from_prior()
+    x0 = eng.states()
+    lad = O.Ladder(PU.oracle_problem(pr), pr.beta, W=W, swap_rate=sr, add_every_N=max(N, 1))
+    lad.set_proposals([(PU.KIND_TO_ORACLE[kind], fac[r], odf) for r in range(Nt)])
+    lad.use_philox(0x5EED0001)
+    if N:
+        lad.enable_history(cap)
+    lad.set_states(PU.to_oracle_order(x0, Nt, W))
+    if K:
+        rng = np.random.default_rng(K)
+        shares = 2.0 ** np.arange(1, K + 1)
+        cum = np.tile(np.cumsum(shares) / shares.sum(), (Nt, 1)); cum[:, -1] = 1.0
+        scales = np.tile(3.0 ** -np.arange(K)[::-1] * 1.2, (Nt, 1)) * rng.uniform(0.8, 1.2, (Nt, 1))
+        odfs = np.tile(np.where(np.arange(K) % 2 == 0, odf, 0.0), (Nt, 1))
+        eng.set_proposal_mixture(cum, scales, odfs); lad.set_mixture(cum, scales, odfs)
+    return pr, eng, lad
+
+
+def _assert_same_history_and_map(eng, lad, cap=64):
+    Nt, W = eng.Nt, eng.W
+    he, ho = eng.history(), lad.history()
+    nsize = eng.nsize
+    for name in ("x", "llike", "lprior", "naccept", "ntries", "last_type"):
+        a, b = he[name], ho[name]
+        for s_ in range(max(0, int(nsize.max()) - cap), int(nsize.max())):
+            have = (nsize > s_) & (nsize - s_ <= cap)
+            got, want = a[s_ % cap][have], PU.to_engine_order(b[:, s_ % cap] if b.shape[1] == cap and nsize.max() > cap else b[:, s_], Nt, W)[have]
+            assert np.array_equal(got, want), (name, s_, np.argwhere(got != want)[:3].tolist())
+    m = eng.map()
+    assert np.array_equal(m["lpost"], PU.to_engine_order(lad.map_lpost, Nt, W))
+    assert np.array_equal(m["x"], PU.to_engine_order(lad.map_x, Nt, W))
+
+
+@pytest.mark.parametrize("D,Nt,W,kind,sr,odf,K,N", LADDER_FLAVOURS)
+def test_persistent_ladder_kernel_runs_what_the_sampler_runs(D, Nt, W, kind, sr, odf, K, N):
+    """The persistent ladder kernel's builds for the reference sampler's defaults (ptmcmc.cc:117-139,601-616): one-dimensional moves and
+    scale mixtures (FL bit 0), the history ring and MAP tracking of MH_chain::add_state (chain.cc:931-946; FL bit 1) -- the rows a rung
+    holds BETWEEN its two exchanges of one step included (quirk Q6).  States, counters, type codes, every saved row and every rung's
+    MAP bit for bit the oracle's, step by step and over many steps per launch."""
+    pr, eng, lad = _ladder_flavour_pair(D, Nt, W, kind, sr, odf, K, N)
+    fl = (1 if (odf > 0 or K > 0) else 0) | (2 if N else 0)
+    want = "ladder_persistent_kernel<%d, %d, %d>" % (16 if D <= 16 else 32, 1 if kind == E.PROP_DIAG else 0, fl)
+    assert eng.step_kernel_name == want, (eng.step_kernel_name, want)
+    done = 0
+    for n in (1, 1, 2, 40):
+        eng.step(n); eng.sync(); lad.pt_step(n)
+        done += n
+        PU.assert_same_state(eng, lad, "after %d PT steps" % done)
+        if N:
+            _assert_same_history_and_map(eng, lad)
+    t, a = eng.swap_counts()
+    assert np.array_equal(t, lad.swap_count) and np.array_equal(a, lad.swap_accept_count)
+    if N:
+        assert int((eng.nhist > done).sum()) > 0          # some rungs made two add_state calls in one step
+    if odf > 0 or K > 1:
+        assert len(set(int(v) for v in np.unique(eng.last_type)) - {-1}) >= 2
+    st = eng.ladder_stats()
+    assert st["launches"] == 4 and st["fallbacks"] == 0 and not st["disabled"], st
+    eng.close()
+
+
+def test_persistent_ladder_kernel_that_gives_up_leaves_nothing_behind():
+    """A workgroup of the persistent ladder kernel that waits in vain for a neighbour gives up (a grid that is not resident: a shared
+    device).  PTM_LADDER_SPIN_US=0 makes every flag that is not up at the first look such a case.  The launch then commits NOTHING (the
+    chains live in registers until every workgroup has finished every step), the engine repeats its steps on the two-launch path at
+    its next look and keeps that path: the run equals the oracle's bit for bit, the event is counted, no error is raised."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, os.path.join(here, "variant_worker.py"), "32", "600", "1", "lower", "giveup"],
+                       env=dict(os.environ, PTM_LADDER_SPIN_US="0", PTM_QUIET="1"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "fallbacks=" in r.stdout and "fallbacks=0" not in r.stdout, r.stdout[-500:]
+
+
+def test_two_engines_with_persistent_ladder_kernels_take_turns():
+    """Two engines of one process, each with a grid of the persistent ladder kernel as large as the device holds alone: their launches
+    are put behind each other (an event of the last launch of the OTHER engine), so neither waits for workgroups that cannot become
+    resident; both equal their oracles and nobody gives up."""
+    pairs = [PU.make_pair(32, 1024, 1, 1e6, kind=E.PROP_LOWER, seed=0x5EED0001 + k) for k in range(2)]
+    for _, eng, _ in pairs:
+        assert eng.step_kernel_name.startswith("ladder_persistent_kernel<32")
+    for rep in range(3):
+        for _, eng, _ in pairs:
+            eng.step(200)                      # (asynchronous: the second engine's launch is queued while the first one's runs)
+    for _, eng, lad in pairs:
+        eng.sync(); lad.pt_step(600)
+        PU.assert_same_state(eng, lad, "after 600 PT steps beside another engine")
+        st = eng.ladder_stats()
+        assert st["fallbacks"] == 0 and st["launches"] == 3, st
+        eng.close()
+
+
+def test_persistent_ladder_kernel_after_the_proposal_kind_changes():
+    """The residency figure and the LDS attribute of the persistent ladder kernel are kept per build: a long ladder (more than 64 KB of
+    LDS per workgroup) that changes from diagonal to full factors between two ptm_step calls launches the other build with its own
+    figures, and stays bit-identical to the oracle."""
+    D, Nt, W = 32, 1500, 1
+    pr, eng, lad = PU.make_pair(D, Nt, W, 1e6, kind=E.PROP_DIAG, swap_rate=0.1)
+    name = eng.step_kernel_name
+    eng.step(30); eng.sync(); lad.pt_step(30)
+    PU.assert_same_state(eng, lad, "diagonal factors")
+    fac = pr.proposal_factors(range(Nt), lower=True)
+    eng.set_proposals(E.PROP_LOWER, fac)
+    lad.set_proposals([(O.PROP_DENSE, fac[r], 0.0) for r in range(Nt)])
+    assert eng.step_kernel_name != name or not name.startswith("ladder_persistent")
+    eng.step(30); eng.sync(); lad.pt_step(30)
+    PU.assert_same_state(eng, lad, "full factors")
+    assert eng.ladder_stats()["fallbacks"] == 0
     eng.close()
