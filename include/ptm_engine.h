@@ -174,6 +174,24 @@ int ptm_set_proposal_mixture(ptm_engine* e, int K, const double* cum_shares, con
  * proposals of ptm_set_proposals; propose == NULL goes back to them.  Whole-shard sweeps only (ptm_sweep, ptm_step,
  * ptm_exchange_finish_and_sweep; not ptm_sweep_rungs). */
 int ptm_set_proposal_callback(ptm_engine* e, ptm_propose_batch_fn propose, ptm_proposal_result_fn result, void* user);
+/* Differential evolution (ter Braak & Vrugt 2008) drawn ON THE DEVICE from each chain's own saved history -- the reference's
+ * differential_evolution (proposal_distribution.cc:476-801) as the reference sampler configures it by default (ptmcmc.cc:81-91: no
+ * temperature mixing, unlikely_alpha = 0).  It becomes the member of the rungs' proposal sets (ptm_set_proposal_mixture) whose SCALE
+ * IS NEGATIVE: the set's uniform picks the first ready member whose cumulative share it falls below
+ * (proposal_distribution_set::draw, proposal_distribution.cc:99-129; differential evolution is ready once the chain has saved
+ * 10 * dim rows, and is passed over until then -- give it a member behind it); type code = member + 10 * (0 parallel move, 1 snooker).
+ * The engine must have been created with history_rungs = rung_count and a history_capacity that holds EVERY row of the run (a row the
+ * ring has lost is reported by ptm_sync).  init_rows [n_init_extra][n_local_chains][dim], chain (local rung r, walker w) at
+ * r * n_walkers + w: the states MH_chain::initialize(n) saved in FRONT of the start state (chain.cc:846-876: n_init_extra = n - 1,
+ * oldest first), or NULL with n_init_extra = 0.  Needs dim <= 32.  q == NULL switches it off.  Host-side draws with temperature
+ * mixing or unlikely_alpha stay possible through ptm_set_proposal_callback. */
+typedef struct ptm_de_params {
+  double snooker;         /* probability of a snooker move (differential_evolution's first constructor argument; sampler: 0.1) */
+  double gamma_one_frac;  /* probability of gamma = 1 in a parallel move (de_g1_frac: 0.3) */
+  double reduce_gamma;    /* differential_evolution::reduce_gamma (de_reduce_gamma: 4) */
+  double ignore_frac;     /* early fraction of a long history that is not drawn from (sampler: 0) */
+} ptm_de_params;
+int ptm_set_proposal_de(ptm_engine* e, const ptm_de_params* q, int n_init_extra, const double* init_rows);
 
 /* ---- state ------------------------------------------------------------------------------------------ */
 /* X[n_local_chains][D]; llike may be NULL (the device target evaluates it).  Resets counters the way

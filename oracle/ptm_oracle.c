@@ -469,6 +469,7 @@ void ptmo_pt_free(ptmo_pt* s) {
   free(s->beta); free(s->x); free(s->llike); free(s->lprior); free(s->ntries); free(s->naccept); free(s->last_type);
   free(s->nhist); free(s->nsize); free(s->swap_count); free(s->swap_accept_count); free(s->last_pairs); free(s->last_accept);
   free(s->touched); free(s->last_accept_mh); free(s->map_lpost); free(s->map_x); free(s->betaw);
+  free(s->de_init);
   free(s->hist_x); free(s->hist_ll); free(s->hist_lp); free(s->hist_beta); free(s->hist_nacc); free(s->hist_ntry); free(s->hist_type);
   free(s);
 }
@@ -548,6 +549,92 @@ void ptmo_pt_set_states(ptmo_pt* s, const ptmo_problem* pb, const double* x, con
 }
 
 /* ============================================================================================
+ * differential_evolution::draw (proposal_distribution.cc:476-592; draw_i_from_chain :745-801 with unlikely_alpha = 0;
+ * ter Braak & Vrugt, Stat Comput 18 (2008) 435: eqs. 2-4).  state::scalar_mult followed by state::add: every product is
+ * rounded before its sum; innerprod sums in index order.
+ * ============================================================================================ */
+int ptmo_de_ready(int D, long rows) { return rows >= 10L * D; }
+static long de_pick_row(int D, long rows, double ignore_frac, double u) {
+  long spare = rows - 100L * D;                       /* size - get_min_cut_size() */
+  long first = (spare * (1 - ignore_frac) > 10L * D) ? (long)(spare * ignore_frac) : 0;
+  return (long)(first + (rows - first) * u);
+}
+int ptmo_de_draw(int D, const double* x, long rows, const ptmo_de_params* q, ptmo_de_uniform_fn u, void* uctx, ptmo_de_row_fn rowf,
+                 void* rctx, double* xn, double* log_hastings) {
+  const double u_snooker = u(uctx, 0);
+  if (!(q->snooker > u_snooker)) {                    /* draw_standard (:487-536) */
+    const double ug = u(uctx, 1);
+    double gamma = 1.68 / sqrt((double)D) / q->reduce_gamma;
+    if (ug < q->gamma_one_frac) gamma = 1;
+    const double* z1 = rowf(rctx, de_pick_row(D, rows, q->ignore_frac, u(uctx, 2)));
+    const double* z2 = rowf(rctx, de_pick_row(D, rows, q->ignore_frac, u(uctx, 3)));
+    for (int i = 0; i < D; i++) {
+      const double t1 = z1[i] * gamma;
+      const double a = x[i] + t1;
+      const double t2 = z2[i] * (-gamma);
+      xn[i] = a + t2;
+    }
+    *log_hastings = 0;
+    return 0;
+  }
+  /* draw_snooker (:539-592) */
+  const double gamma = (1.2 + u(uctx, 1)) / q->reduce_gamma;
+  const double* z = NULL;
+  double axis2 = 0;
+  for (int tries = 0; axis2 == 0; tries++) {          /* the history repeats states: z must differ from x */
+    if (tries > 1000) return -1;
+    z = rowf(rctx, de_pick_row(D, rows, q->ignore_frac, u(uctx, 4 + tries)));
+    axis2 = 0;
+    for (int i = 0; i < D; i++) { const double a = x[i] + z[i] * (-1.0); axis2 = axis2 + a * a; }
+  }
+  const double* z1 = rowf(rctx, de_pick_row(D, rows, q->ignore_frac, u(uctx, 2)));
+  const double* z2 = rowf(rctx, de_pick_row(D, rows, q->ignore_frac, u(uctx, 3)));
+  double proj = 0;
+  for (int i = 0; i < D; i++) {
+    const double a = z1[i] * gamma, b = z2[i] * (-gamma);
+    const double diff = a + b;
+    const double ax = x[i] + z[i] * (-1.0);
+    proj = proj + diff * ax;
+  }
+  proj = proj / axis2;
+  double fz2 = 0;
+  for (int i = 0; i < D; i++) {
+    const double ax = x[i] + z[i] * (-1.0);
+    const double t = ax * proj;
+    xn[i] = x[i] + t;
+    const double f = xn[i] + z[i] * (-1.0);
+    fz2 = fz2 + f * f;
+  }
+  *log_hastings = (ptmo_log(fz2) - ptmo_log(axis2)) * (D - 1) / 2.0;
+  return 1;
+}
+void ptmo_pt_set_de(ptmo_pt* s, const ptmo_de_params* q, int n_init_extra, const double* init_rows) {
+  s->de_on = q != NULL;
+  free(s->de_init);
+  s->de_init = NULL; s->de_init_extra = 0;
+  if (!q) return;
+  s->de = *q;
+  if (n_init_extra > 0 && init_rows) {
+    size_t n = (size_t)n_init_extra * s->Nt * s->W * s->D;
+    s->de_init = (double*)malloc(n * sizeof(double));
+    memcpy(s->de_init, init_rows, n * sizeof(double));
+    s->de_init_extra = n_init_extra;
+  }
+}
+typedef struct { const ptmo_pt* s; size_t c; } de_rows_ctx;
+static const double* de_row_of_chain(void* v, long row) {
+  de_rows_ctx* q = (de_rows_ctx*)v;
+  const ptmo_pt* s = q->s;
+  if (row < s->de_init_extra) return s->de_init + ((size_t)row * s->Nt * s->W + q->c) * s->D;
+  return s->hist_x + (q->c * s->hist_cap + (size_t)(row - s->de_init_extra)) * s->D;
+}
+typedef struct { const ptmo_rng* rng; int w, r; uint64_t step; } de_uni_ctx;
+static double de_uniform_of_chain(void* v, int slot) {
+  de_uni_ctx* q = (de_uni_ctx*)v;
+  return q->rng->de_uniform(q->rng->ctx, q->w, q->r, q->step, slot);
+}
+
+/* ============================================================================================
  * MH_chain::step  (chain.cc:966-1022) with gaussian_prop::draw (proposal_distribution.hh:194-218)
  * ============================================================================================ */
 int ptmo_mh_step(ptmo_pt* s, const ptmo_problem* pb, const ptmo_proposal* prop, const ptmo_rng* rng, int w, int r) {
@@ -567,10 +654,39 @@ int ptmo_mh_step(ptmo_pt* s, const ptmo_problem* pb, const ptmo_proposal* prop, 
     type = ty;
     valid = va != 0;                                                     /* the returned state's own validity (state::invalid()) */
   } else {
-    type = rng->draw_offset(rng->ctx, w, r, s->step, prop, D, off);     /* :975 prop.draw (gaussian_prop / scripted offsets) */
-    if (rng->log_hastings) hast = rng->log_hastings(rng->ctx, w, r, s->step);
-    for (int i = 0; i < D; i++) xn[i] = x[i] + off[i];                   /* state::add, states.cc:205-214 */
-    valid = pb->origin_valid;                                            /* Q9 */
+    /* a proposal set with differential evolution as a member (the member of negative scale): proposal_distribution_set::draw
+     * (proposal_distribution.cc:99-129) picks the first READY member whose bin the uniform falls below */
+    ptmo_proposal local = *prop;
+    double lmix[3 * 64];
+    int de_member = -1;
+    if (s->de_on && prop->K > 0 && prop->K <= 64 && rng->de_uniform) {
+      const double xs = prop->K > 1 ? rng->chain_uniform(rng->ctx, w, r, s->step, 3) : 0.0;
+      int kmix = prop->K - 1;
+      for (int k = 0; k < prop->K; k++)
+        if (xs < prop->mix[3 * k]) { kmix = k; break; }
+      if (prop->mix[3 * kmix + 1] < 0) {
+        const long rows = s->de_init_extra + s->nsize[c];
+        if (ptmo_de_ready(D, rows)) de_member = kmix;
+        else {                                                           /* not ready: passed over -- its bin closes, the next member's is met */
+          memcpy(lmix, prop->mix, (size_t)prop->K * 3 * sizeof(double));
+          lmix[3 * kmix] = kmix > 0 ? lmix[3 * (kmix - 1)] : -1.0;
+          local.mix = lmix;
+        }
+      }
+    }
+    if (de_member >= 0) {
+      de_rows_ctx rc = {s, c};
+      de_uni_ctx uc = {rng, w, r, s->step};
+      const long rows = s->de_init_extra + s->nsize[c];
+      const int t = ptmo_de_draw(D, x, rows, &s->de, de_uniform_of_chain, &uc, de_row_of_chain, &rc, xn, &hast);
+      type = de_member + 10 * (t < 0 ? 0 : t);                           /* proposal_distribution.cc:117 */
+      valid = t < 0 ? 0 : pb->origin_valid;                              /* state::add on an enforced origin: Q9 */
+    } else {
+      type = rng->draw_offset(rng->ctx, w, r, s->step, &local, D, off);   /* :975 prop.draw (gaussian_prop / scripted offsets) */
+      if (rng->log_hastings) hast = rng->log_hastings(rng->ctx, w, r, s->step);
+      for (int i = 0; i < D; i++) xn[i] = x[i] + off[i];                 /* state::add, states.cc:205-214 */
+      valid = pb->origin_valid;                                          /* Q9 */
+    }
   }
   if (valid) valid = ptmo_enforce(pb, xn);                               /* :976 newstate.enforce() */
   double newlprior = ptmo_lprior(pb, xn, valid);                         /* :977 */
@@ -892,11 +1008,19 @@ static double ph_pt_uniform(void* vctx, int w, uint64_t step, int k, int slot) {
   ptmo_draw_block(c->seed, PTMO_TAG_PT, (uint32_t)w, step, (uint32_t)k, o);
   return ptmo_u01(o[slot]);
 }
+/* uniform `slot` of the chain's differential-evolution draw of this step (ptm_oracle.h: ptmo_de_uniform_fn) */
+static double ph_de_uniform(void* vctx, int w, int r, uint64_t step, int slot) {
+  philox_ctx* c = (philox_ctx*)vctx;
+  uint32_t o[4];
+  ptmo_draw_block(c->seed, PTMO_TAG_MH, (uint32_t)((uint64_t)w * c->Nt + r), step, slot < 4 ? 0x0DE00000u : 0x0DE00001u + (uint32_t)(slot - 4), o);
+  return ptmo_u01(o[slot < 4 ? slot : 0]);
+}
 ptmo_rng* ptmo_rng_philox(uint64_t seed, int Nt) {
   ptmo_rng* r = (ptmo_rng*)calloc(1, sizeof *r);
   philox_ctx* c = (philox_ctx*)calloc(1, sizeof *c);
   c->seed = seed; c->Nt = Nt;
   r->ctx = c; r->chain_uniform = ph_chain_uniform; r->draw_offset = ph_draw_offset; r->pt_uniform = ph_pt_uniform;
+  r->de_uniform = ph_de_uniform;
   return r;
 }
 

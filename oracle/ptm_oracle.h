@@ -90,7 +90,29 @@ typedef struct ptmo_rng {
   /* proposal_distribution::log_hastings_ratio() of the offset just drawn (proposal_distribution.hh:68; MH_chain::step,
    * chain.cc:989-994); NULL = 0 (every gaussian_prop) */
   double (*log_hastings)(void* ctx, int w, int r, uint64_t step);
+  /* uniform `slot` of the chain's differential-evolution draw of this step (ptmo_de_uniform_fn); NULL: the provider has none */
+  double (*de_uniform)(void* ctx, int w, int r, uint64_t step, int slot);
 } ptmo_rng;
+
+/* differential_evolution (proposal_distribution.cc:476-801; ter Braak & Vrugt 2008): the parameters the draw depends on without
+ * temperature mixing and with unlikely_alpha = 0 (the sampler's defaults, ptmcmc.cc:81-91) */
+typedef struct {
+  double snooker;         /* probability of a snooker move (differential_evolution ctor arg 1) */
+  double gamma_one_frac;  /* probability of gamma = 1 in a parallel move (arg 2) */
+  double reduce_gamma;    /* reduce_gamma(factor): both gammas are divided by it */
+  double ignore_frac;     /* the early fraction of a long history that is not drawn from (arg 4) */
+} ptmo_de_params;
+/* uniform number `slot` of ONE draw: 0 the snooker test, 1 gamma, 2 the pick of z1, 3 the pick of z2, 4 + t the t-th attempt at the
+ * snooker move's z.  The function asks for them in the order the reference's generator delivers them (0, 1, [4, 5, ..], 2, 3), so
+ * a tape of the reference's uniforms can answer in sequence. */
+typedef double (*ptmo_de_uniform_fn)(void* ctx, int slot);
+typedef const double* (*ptmo_de_row_fn)(void* ctx, long row);   /* row `row` of the caller's saved history (raw indexing, chain.hh:155) */
+/* one differential_evolution::draw for the state x[D] of a chain whose history holds `rows` rows: the proposed state, its
+ * log-Hastings ratio; returns the move's type (0 parallel, 1 snooker; proposal_distribution::type()), -1 if a thousand history
+ * states in a row equalled x (the reference exits there) */
+int ptmo_de_draw(int D, const double* x, long rows, const ptmo_de_params* q, ptmo_de_uniform_fn u, void* uctx, ptmo_de_row_fn rowf,
+                 void* rctx, double* xn, double* log_hastings);
+int ptmo_de_ready(int D, long rows);   /* differential_evolution::is_ready(): the history holds 10 D rows */
 
 /* A proposal evaluated by the CALLER (the engine's ptm_propose_batch_fn, include/ptm_engine.h): any
  * proposal_distribution::draw(state&, chain*) (proposal_distribution.hh:65-87).  For n chains: current states X_cur[n][dim],
@@ -136,6 +158,11 @@ typedef struct {
   void* host_prop_user;
   uint8_t* last_accept_mh; /* [W*Nt] outcome of the last step's MH move: 1 accepted, 0 rejected, 2 no move (exchanged rung) */
   double evolve_cut;       /* evolve_temp_lpost_cut (chain.hh:254,302-307): < 0 off (the default) */
+  /* differential evolution as a member of the proposal set (ptmo_pt_set_de): the mixture member whose scale is negative */
+  int de_on;
+  ptmo_de_params de;
+  int de_init_extra;       /* rows of MH_chain::initialize(n) in front of the start state: n - 1 (chain.cc:846-876) */
+  double* de_init;         /* [de_init_extra][W*Nt][D] */
 } ptmo_pt;
 
 /* ---- RNG: Philox4x32-10 (Salmon et al., SC'11; Random123) -------------------------------- */
@@ -205,6 +232,12 @@ ptmo_rng* ptmo_rng_tape(int W, int Nt, int D, const double* chain_tapes, int len
 /* scripted log-Hastings ratios and type codes for the tape provider's offsets: [W*Nt][nsteps] each (types may be NULL) */
 void ptmo_rng_tape_hastings(ptmo_rng*, const double* log_hastings, const int32_t* types);
 void ptmo_pt_set_host_proposal(ptmo_pt*, ptmo_propose_fn fn, void* user);
+/* Differential evolution from each chain's OWN saved history as the member of the rungs' proposal sets whose scale is negative
+ * (ptmo_proposal::mix): needs the history (ptmo_pt_enable_history) with room for every row of the run.  init_rows: the
+ * n_init_extra states MH_chain::initialize(n) saved in front of the start state, [n_init_extra][W*Nt][D], or NULL.  A member that
+ * is not ready (fewer than 10 D rows) is passed over as proposal_distribution_set::draw passes over it (proposal_distribution.cc:111).
+ * The uniforms of a draw: Philox block 0x0DE00000 of the chain's MH stream (slots 0..3), blocks 0x0DE00001 + t (slot 4 + t). */
+void ptmo_pt_set_de(ptmo_pt*, const ptmo_de_params* q, int n_init_extra, const double* init_rows);
 void ptmo_rng_free(ptmo_rng*);
 
 /* prior draw used by init (uniform / gaussian dims only; others return NaN) */

@@ -82,6 +82,12 @@ struct ptm_engine {
   double *bmin = nullptr, *bmax = nullptr, *plo = nullptr, *phi = nullptr, *pcoef = nullptr;
   double *P2 = nullptr, *mean = nullptr, *beta = nullptr, *prop = nullptr, *prop_tiles = nullptr, *P2_tiles = nullptr, *box_row = nullptr, *onedfrac = nullptr, *mix = nullptr;
   int mix_K = 0;
+  // differential evolution on the device (ptm_set_proposal_de)
+  bool de_on = false;
+  ptm_de_params de = {0, 0, 0, 0};
+  int de_init_extra = 0;
+  double *de_init = nullptr, *de_hast = nullptr;
+  int* de_type = nullptr;
   // evolving ladders (ptm_set_evolve_temps): per-ladder inverse temperatures [W][Nt] and their chain-indexed image [Nc]
   double evolve_rate = 0, evolve_cut = -1;
   double *beta_w = nullptr, *betaC = nullptr, *beta_add = nullptr;
@@ -124,6 +130,10 @@ struct ptm_engine {
   // that was (err[2]) -- and, if one gave up, repeats its steps and its successors' on the two-launch path.
   struct LadLaunch { int seq; uint64_t step_before; int nsteps; int log_head_before; };
   std::vector<LadLaunch> lad_log;   // launches not yet looked at
+  // Steps asked for in small portions (a host loop that calls ptm_step(1): the reference sampler's, ptmcmc.cc:563-599) are only COUNTED
+  // here and launched together at the engine's next look at the device -- any getter, setter or ptm_sync -- or when enough have
+  // gathered: nothing can observe the difference, and a launch of the persistent kernel costs ~15 us on top of its 5 us steps.
+  int lad_deferred = 0;
   int lad_seq = 0;                  // number of the last launch issued
   bool lad_disabled = false;        // a launch gave up once: this engine keeps the two-launch path from then on
   long long ladder_fallbacks = 0;   // launches that gave up (their steps were repeated on the two-launch path)
@@ -451,7 +461,7 @@ extern "C" int ptm_engine_destroy(ptm_engine* e) {
   void* ptrs[] = {e->x, e->ll, e->lp, e->ntries, e->naccept, e->last_type, e->arr_below, e->arr_above, e->mv_src, e->mv_dst, e->mv_n,
                   e->err, e->nhist, e->swap_cnt, e->touch, e->swap_log, e->hist.x, e->hist.ll, e->hist.lp, e->hist.meta, e->map.lpost, e->map.ll, e->map.lp, e->map.x, e->blo,
                   e->bhi, e->ptype, e->bmin, e->bmax, e->plo, e->phi, e->pcoef, e->P2, e->mean, e->beta, e->prop, e->prop_tiles, e->P2_tiles, e->box_row, e->onedfrac, e->mix, e->beta_w, e->betaC, e->beta_add, e->hist.beta, e->xprop, e->lprior_new, e->llike_new, e->hastings, e->htype, e->hvalid, e->acc_out, e->cidx, e->ccnt,
-                  e->pub_x, e->lad_flags, e->lad_prof, e->shard_ends, e->redo_flag, e->sums};
+                  e->pub_x, e->lad_flags, e->lad_prof, e->shard_ends, e->redo_flag, e->sums, e->de_init, e->de_hast, e->de_type};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (e->h_sums) (void)hipHostFree(e->h_sums);
@@ -917,6 +927,41 @@ extern "C" int ptm_set_proposal_mixture(ptm_engine* e, int K, const double* cum_
   return PTM_OK;
 }
 
+// Differential evolution drawn on the device (include/ptm_engine.h)
+extern "C" int ptm_set_proposal_de(ptm_engine* e, const ptm_de_params* q, int n_init_extra, const double* init_rows) {
+  SETTLE(e);
+  if (!e) return fail(PTM_ERR_INVALID, "null engine");
+  NO_BATCH(e, "ptm_set_proposal_de");
+  HIPCHK(hipStreamSynchronize(e->stream));
+  if (e->de_init) { HIPCHK(hipFree(e->de_init)); e->de_init = nullptr; }
+  e->de_on = false; e->de_init_extra = 0;
+  if (!q) return PTM_OK;
+  if (e->DP > 32) return fail(PTM_ERR_UNSUPPORTED, "differential evolution on the device is built for up to 32 dimensions (the general sweep kernel's range); "
+                                                   "above, draw it on the host (ptm_set_proposal_callback)");
+  if (e->hist.rungs != e->nloc || e->hist.cap < 2)
+    return fail(PTM_ERR_INVALID, "differential evolution draws from every rung's saved history: create the engine with history_rungs = rung_count and a "
+                                 "history_capacity that holds every row of the run");
+  if (e->pcb) return fail(PTM_ERR_INVALID, "host-side proposals are set (ptm_set_proposal_callback): they replace every device proposal");
+  if (!(q->snooker >= 0 && q->snooker <= 1) || !(q->gamma_one_frac >= 0 && q->gamma_one_frac <= 1) || !(q->reduce_gamma > 0) ||
+      !(q->ignore_frac >= 0 && q->ignore_frac < 1) || n_init_extra < 0 || (n_init_extra > 0 && !init_rows))
+    return fail(PTM_ERR_INVALID, "differential evolution: snooker and gamma_one_frac in [0, 1], reduce_gamma > 0, ignore_frac in [0, 1), init rows given");
+  int rc;
+  if (n_init_extra > 0) {
+    const size_t Nc = e->Nc, D = e->D, DP = e->DP;
+    std::vector<double> img((size_t)n_init_extra * Nc * DP, 0.0);
+    for (size_t k = 0; k < (size_t)n_init_extra; ++k)
+      for (size_t c = 0; c < Nc; ++c)
+        for (size_t d = 0; d < D; ++d) img[(k * Nc + c) * DP + host_row_pos(DP, d)] = init_rows[(k * Nc + c) * D + d];
+    if ((rc = dalloc(&e->de_init, img.size()))) return rc;
+    HIPCHK(hipMemcpy(e->de_init, img.data(), img.size() * 8, hipMemcpyHostToDevice));
+  }
+  if (!e->de_hast && ((rc = dalloc(&e->de_hast, (size_t)e->Nc)) || (rc = dalloc(&e->de_type, (size_t)e->Nc)))) return rc;
+  e->de = *q;
+  e->de_init_extra = n_init_extra;
+  e->de_on = true;
+  return PTM_OK;
+}
+
 // One rung's factor replaced between steps -- what user_gaussian_prop::check_update achieves in the reference when its
 // callback returns a new covariance for a chain (proposal_distribution.cc:406-441, reset_dist :340-403).  Same kind and
 // storage as the factors set by ptm_set_proposals; one_d_frac < 0 keeps the rung's current value.
@@ -987,6 +1032,9 @@ static Dev make_dev(ptm_engine* e) {
   p.P2 = e->P2; p.mean = e->mean; p.has_mean = e->has_mean; p.like0 = e->like0;
   p.beta = e->beta; p.prop = e->prop; p.prop_tiles = e->prop_tiles; p.P2_tiles = e->P2_tiles; p.box_row = e->box_row; p.onedfrac = e->onedfrac; p.prop_stride = e->prop_stride; p.any_oned = e->any_oned;
   p.mix_K = e->mix_K; p.mix = e->mix;
+  p.de_on = e->de_on ? 1 : 0; p.de_init_extra = e->de_init_extra; p.de_init = e->de_init; p.de_hast = e->de_hast; p.de_type = e->de_type;
+  p.de_snooker = e->de.snooker; p.de_gamma_one = e->de.gamma_one_frac; p.de_gamma_div = e->de.reduce_gamma; p.de_ignore = e->de.ignore_frac;
+  p.de_gamma_std = e->de_on ? 1.68 / std::sqrt((double)e->D) / e->de.reduce_gamma : 0.0;   // (the reference's own expression, proposal_distribution.cc:492)
   p.betaC = e->betaC; p.beta_add = e->beta_add; p.beta_w = e->beta_w;
   p.x = e->x; p.ll = e->ll; p.lp = e->lp;
   p.ntries = e->ntries; p.naccept = e->naccept; p.last_type = e->last_type; p.nhist = e->nhist;
@@ -1009,6 +1057,7 @@ static SweepSel sweep_sel(const ptm_engine* e) {
   s.lean_ev = s.uni && e->betaC && !e->has_bounds && e->all_uniform && !e->has_mean && !e->any_oned && !e->cb && e->mix_K == 0 && !s.host_prop &&
               !e->hist.rungs && !e->map.rungs;
   s.callback = e->cb != nullptr;
+  s.de = e->de_on;
   return s;
 }
 
@@ -1052,7 +1101,7 @@ static int launch_sweep(ptm_engine* e, int rung0 = 0, int nr = -1, bool last = t
   // population then visits the moving chains only (partition_kernel packs them per rung).  PTM_COMPACT=0 switches it off.
   static const bool compact_ok = [] { const char* v = getenv("PTM_COMPACT"); return !(v && *v == '0'); }();
   // ... and the box-bounds build (uniform priors, open / limit bounds, a mean, one-dimensional moves, scale mixtures, evolving ladders)
-  const bool gen1 = sel.uni && !sel.callback && !sel.host_prop && e->all_uniform && (!e->has_bounds || e->bounds_box);
+  const bool gen1 = sel.uni && !sel.callback && !sel.host_prop && !sel.de && e->all_uniform && (!e->has_bounds || e->bounds_box);
   const bool compact = compact_ok && e->touched && e->DP == 32 && (sel.simple || gen1) && !e->hist.rungs && !e->map.rungs && !getenv("PTM_FORCE_VALU") &&
                        e->W >= 1024 && e->nloc <= 4096;   // (the same answer for every partial sweep of a step)
   if (!compact) { int rc = flush_nhist(e); if (rc) return rc; }
@@ -1519,7 +1568,7 @@ extern "C" int ptm_sweep(ptm_engine* e, int n) {
 // two-launch path.  Returns the steps taken (0: not this engine's case), or a negative status.
 static int fused_steps(ptm_engine* e, int n) {
   static const bool fused_ok = [] { const char* v = getenv("PTM_FUSED"); return !(v && *v == '0'); }();
-  if (!fused_ok || e->DP > 16 || (long long)e->Nt * e->DP > 256 || e->cb || e->pcb || e->cfg.time_kernels) return 0;
+  if (!fused_ok || e->DP > 16 || (long long)e->Nt * e->DP > 256 || e->cb || e->pcb || e->de_on || e->cfg.time_kernels) return 0;
   if (e->evolve_rate > 0 && (e->W > 64 || e->evolve_cut >= 0)) return 0;   // (the new temperatures' chain-indexed image is then a separate launch)
   const bool evb = e->evolve_rate > 0 && e->beta_add;
   const size_t dlds = decide_lds_bytes(e->Nt, e->ms, e->Nt, e->evolve_rate > 0, evb);
@@ -1566,7 +1615,7 @@ static bool ladder_applies(ptm_engine* e, long long* grid_out = nullptr, size_t*
   const SweepSel sel = sweep_sel(e);
   // open / `limit` boundaries, all-uniform prior, zero mean, fixed ladder, device target and proposals (one-dimensional moves, scale
   // mixtures, history and MAP tracking have their builds: ladder_flavour); populations with whole waves per rung keep the throughput kernels
-  if (sel.uni || (e->has_bounds && !e->bounds_box) || !e->all_uniform || e->has_mean || e->cb || e->prior_cb || e->pcb || e->betaC) return false;
+  if (sel.uni || (e->has_bounds && !e->bounds_box) || !e->all_uniform || e->has_mean || e->cb || e->prior_cb || e->pcb || e->betaC || e->de_on) return false;
   const int R = 256 / e->DP, NB = (e->Nt + R - 1) / R;
   const long long grid = (long long)e->W * NB;
   const bool diag = e->prop_kind == PTM_PROP_DIAG;
@@ -1585,7 +1634,22 @@ static int two_launch_steps(ptm_engine* e, int n);
 // Have the launches of the persistent ladder kernel since the last look been committed?  If one gave up, the engine's arrays are as
 // they were before it (the kernel commits all of a launch or nothing, and the launches behind it found its number missing and did
 // nothing): its steps and theirs are repeated on the two-launch path, and this engine keeps that path from now on.
+static int ladder_steps(ptm_engine* e, int n);
+static int ladder_flush(ptm_engine* e) {
+  if (!e->lad_deferred) return PTM_OK;
+  int n = e->lad_deferred;
+  e->lad_deferred = 0;
+  const int f = ladder_steps(e, n);
+  if (f < 0) return f;
+  n -= f;
+  if (n > 0) {   // (the kernel was switched off meanwhile: a launch gave up)
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return two_launch_steps(e, n);
+  }
+  return PTM_OK;
+}
 static int ladder_settle(ptm_engine* e) {
+  if (e->lad_deferred) { const int rc = ladder_flush(e); if (rc) return rc; }
   if (e->lad_log.empty()) return PTM_OK;
   HIPCHK(hipStreamSynchronize(e->stream));
   int w[3] = {0, 0, 0};
@@ -1734,7 +1798,14 @@ extern "C" int ptm_step(ptm_engine* e, int n) {
     int f = fused_steps(e, n);
     if (f < 0) return f;
     n -= f;
-    if (n > 0) {
+    if (n > 0 && ladder_applies(e)) {
+      // small portions are counted and launched together later (lad_deferred); PTM_LADDER_DEFER=0: every call launches
+      static const bool defer_ok = [] { const char* v = getenv("PTM_LADDER_DEFER"); return !(v && *v == '0'); }();
+      if (defer_ok && n < 64) {
+        e->lad_deferred += n;
+        return e->lad_deferred >= 1024 ? ladder_flush(e) : PTM_OK;
+      }
+      if ((rc = ladder_flush(e))) return rc;
       f = ladder_steps(e, n);   // (launches of that kernel follow each other without a look at the outcome of the one before: ladder_settle)
       if (f < 0) return f;
       n -= f;
@@ -1757,11 +1828,14 @@ extern "C" int ptm_sync(ptm_engine* e) {
                             "ptm_config.exchange_row_capacity slots (%d)", e->row_cap);
   if (flag & 8) return fail(PTM_ERR_FAR_MOVE, "a boundary message carried a row this shard did not expect (neighbour shards out of step?)");
   if (flag & 16) return fail(PTM_ERR_UNSUPPORTED, "a recorded rung's in-between history row belongs to the neighbour shard");
+  if (flag & 64) return fail(PTM_ERR_INVALID, "differential evolution asked for a saved row the history ring no longer holds: history_capacity (%d rows) must hold the whole run", e->hist.cap);
+  if (flag & 128) return fail(PTM_ERR_INVALID, "differential evolution: a thousand history states in a row equalled the current state (the reference exits here)");
   // (bit 32 -- a launch of the persistent ladder kernel gave up -- is not an error any more: ladder_settle has repeated its steps)
   return PTM_OK;
 }
 
 extern "C" int ptm_llike_device_ptr(ptm_engine* e, void** p) {
+  SETTLE(e);
   if (!e || !p) return fail(PTM_ERR_INVALID, "null argument");
   *p = e->ll;
   return PTM_OK;
@@ -1849,6 +1923,7 @@ extern "C" int ptm_exchange_redo(ptm_engine* e, const void* ll_all, const void* 
 }
 
 extern "C" int ptm_copy_lprior(ptm_engine* e, int first_local_rung, int n_rungs, void* dst_dev) {
+  SETTLE(e);
   if (!e || !dst_dev) return fail(PTM_ERR_INVALID, "null argument");
   if (first_local_rung < 0 || n_rungs < 1 || first_local_rung + n_rungs > e->nloc) return fail(PTM_ERR_INVALID, "rung range out of the shard");
   HIPCHK(hipMemcpyAsync(dst_dev, e->lp + (size_t)first_local_rung * e->W, (size_t)n_rungs * e->W * 8, hipMemcpyDeviceToDevice, e->stream));
@@ -1856,6 +1931,7 @@ extern "C" int ptm_copy_lprior(ptm_engine* e, int first_local_rung, int n_rungs,
 }
 
 extern "C" int ptm_copy_llike(ptm_engine* e, int first_local_rung, int n_rungs, void* dst_dev) {
+  SETTLE(e);
   if (!e || !dst_dev) return fail(PTM_ERR_INVALID, "null argument");
   if (first_local_rung < 0 || n_rungs < 1 || first_local_rung + n_rungs > e->nloc) return fail(PTM_ERR_INVALID, "rung range out of the shard");
   HIPCHK(hipMemcpyAsync(dst_dev, e->ll + (size_t)first_local_rung * e->W, (size_t)n_rungs * e->W * 8, hipMemcpyDeviceToDevice, e->stream));
@@ -2300,11 +2376,13 @@ extern "C" uint64_t ptm_step_count(ptm_engine* e) {
 
 // ---- measurement ------------------------------------------------------------------------------------------------------
 extern "C" int ptm_timer_start(ptm_engine* e) {
+  SETTLE(e);
   if (!e) return fail(PTM_ERR_INVALID, "null engine");
   HIPCHK(hipEventRecord(e->t0, e->stream));
   return PTM_OK;
 }
 extern "C" int ptm_timer_stop(ptm_engine* e, float* ms) {
+  SETTLE(e);
   if (!e || !ms) return fail(PTM_ERR_INVALID, "null argument");
   HIPCHK(hipEventRecord(e->t1, e->stream));
   HIPCHK(hipEventSynchronize(e->t1));
@@ -2312,6 +2390,7 @@ extern "C" int ptm_timer_stop(ptm_engine* e, float* ms) {
   return PTM_OK;
 }
 extern "C" int ptm_get_kernel_times(ptm_engine* e, float* ms, int capacity, int* count) {
+  SETTLE(e);
   if (!e || !count) return fail(PTM_ERR_INVALID, "null argument");
   HIPCHK(hipStreamSynchronize(e->stream));
   int n = 0;
@@ -2352,6 +2431,7 @@ extern "C" int ptm_get_counter_sums(ptm_engine* e, int64_t* ntries_sum, int64_t*
 }
 
 extern "C" int ptm_calibrate(ptm_engine* e, ptm_calibration* out) {
+  SETTLE(e);
   if (!e || !out) return fail(PTM_ERR_INVALID, "null argument");
   NO_BATCH(e, "ptm_calibrate");
   memset(out, 0, sizeof *out);
@@ -2421,7 +2501,7 @@ extern "C" const char* ptm_sweep_kernel_name(ptm_engine* e) {
   char b[96];
   const SweepSel s = sweep_sel(e);
   const char* fv = getenv("PTM_FORCE_VALU");
-  if (e->DP == 32 && s.uni && !s.callback && !s.host_prop && !(fv && *fv && *fv != '0')) {
+  if (e->DP == 32 && s.uni && !s.callback && !s.host_prop && !s.de && !(fv && *fv && *fv != '0')) {
     const char* cv = getenv("PTM_COMPACT");
     const bool g1 = !s.simple && e->all_uniform && (!e->has_bounds || e->bounds_box);
     const bool cpt = !(cv && *cv == '0') && (s.simple || g1) && !e->hist.rungs && !e->map.rungs && e->W >= 1024 && e->nloc <= 4096;   // (in PT steps; plain sweeps visit every chain)
@@ -2432,7 +2512,7 @@ extern "C" const char* ptm_sweep_kernel_name(ptm_engine* e) {
   else if ((e->DP == 64 || e->DP == 128) && s.uni && e->all_uniform && (!e->has_bounds || e->bounds_box) && !e->has_mean && !e->any_oned && e->mix_K == 0 && !s.callback &&
            !s.host_prop && !e->hist.rungs && !e->map.rungs && !(fv && *fv && *fv != '0'))
     snprintf(b, sizeof b, "sweep_mfma%d_kernel<%d, %s, %s>", e->DP, s.kind == KIND_DIAG ? KIND_LOWER : s.kind, e->has_bounds ? "true" : "false", e->betaC ? "true" : "false");
-  else if (e->DP >= 64 || s.host_prop || (!s.uni && !getenv("PTM_FORCE_VALU") && (long long)e->Nc * e->DP <= (e->DP >= 16 ? PTM_LANES_MAX : 4096ll * e->DP)))
+  else if (e->DP >= 64 || s.host_prop || (!s.uni && !s.de && !getenv("PTM_FORCE_VALU") && (long long)e->Nc * e->DP <= (e->DP >= 16 ? PTM_LANES_MAX : 4096ll * e->DP)))
     snprintf(b, sizeof b, "sweep_lanes_kernel<%d, %d, %s>", e->DP, s.kind, s.plain ? "false" : "true");
   else snprintf(b, sizeof b, "sweep_kernel<%d, %d, %s, %s>", e->DP, s.kind, s.uni ? "true" : "false", s.simple ? "true" : "false");
   e->kname = b;
@@ -2443,7 +2523,7 @@ extern "C" const char* ptm_step_kernel_name(ptm_engine* e) {
   if (!e) return "";
   static thread_local std::string name;
   char b[160];
-  const bool fused = e->DP <= 16 && (long long)e->Nt * e->DP <= 256 && !e->cb && !e->pcb && !e->cfg.time_kernels && !(getenv("PTM_FUSED") && *getenv("PTM_FUSED") == '0') &&
+  const bool fused = e->DP <= 16 && (long long)e->Nt * e->DP <= 256 && !e->cb && !e->pcb && !e->de_on && !e->cfg.time_kernels && !(getenv("PTM_FUSED") && *getenv("PTM_FUSED") == '0') &&
                      !(e->evolve_rate > 0 && (e->W > 64 || e->evolve_cut >= 0));
   if (e->nloc != e->Nt) snprintf(b, sizeof b, "(sharded: ptm_exchange_* / ptm_shard_step) decide_kernel + %s", ptm_sweep_kernel_name(e));
   else if (fused) snprintf(b, sizeof b, "ladder_steps_kernel<%d, %d, %d>", e->DP, e->prop_kind == PTM_PROP_DIAG ? KIND_DIAG : KIND_DENSE, (long long)e->Nt * e->DP <= 64 ? 64 : 256);

@@ -122,6 +122,14 @@ struct Dev {
   int mix_K;
   const double* mix;
   int prop_stride, any_oned;
+  // differential evolution (ptm_set_proposal_de) as the member of NEGATIVE scale of the mixture: a move drawn from the chain's own
+  // saved history (proposal_distribution.cc:476-592), rows 0 .. de_init_extra - 1 from de_init (what MH_chain::initialize(n) saved
+  // in front of the start state), the others from the history ring
+  int de_on, de_init_extra;
+  const double* de_init;      // [de_init_extra][Nc][DP] rows (row layout)
+  double de_snooker, de_gamma_one, de_gamma_std, de_gamma_div, de_ignore;   // gamma_std = 1.68 / sqrt(D) / reduce_gamma, made by the host
+  double* de_hast;            // [Nc] host-callback likelihood: the propose pass hands its log-Hastings ratio and type to the accept pass
+  int* de_type;               // [Nc]
   // state (in place)
   double* x;                              // [Nc][DP] rows
   double *ll, *lp;                        // [Nc]
@@ -411,6 +419,102 @@ __device__ __forceinline__ void dpp_half32(const DrawCtx& dc, const double* tab,
 }
 
 // ------------------------------------------------------------------------------------------------
+// differential_evolution::draw (proposal_distribution.cc:476-592; draw_i_from_chain :745-801 with unlikely_alpha = 0, no temperature
+// mixing: the reference sampler's defaults, ptmcmc.cc:81-91) for ONE chain on one lane, from the chain's own saved history on the
+// device: rows 0 .. de_init_extra - 1 of de_init, then the history ring.  The oracle states the same operations (ptmo_de_draw):
+// state::scalar_mult then state::add -- every product rounded before its sum --, innerprod in index order.  History rows are
+// read per dimension as they are used (no register image of a row).  The draw's uniforms: Philox block 0x0DE00000 of the chain's
+// MH stream = {snooker test, gamma, pick of z1, pick of z2}; blocks 0x0DE00001 + t: the t-th attempt at the snooker move's z.
+// Returns the move's type (0 parallel, 1 snooker), xn = the proposed state (natural order, pad dimensions 0).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool de_ready(const Dev& p, unsigned int nh0) {   // differential_evolution::is_ready(): 10 D rows
+  const long long rows = p.de_init_extra + 1 + (long long)((nh0 + (unsigned int)p.add_every_n - 1u) / (unsigned int)p.add_every_n);
+  return rows >= 10ll * p.D;
+}
+template <int DP>
+__device__ __forceinline__ int de_draw(const Dev& p, int c, uint32_t stream, uint64_t step, unsigned int nh0, const double* __restrict__ row, double (&xn)[DP],
+                                       double& log_hastings) {
+  // (every loop runs over the padded dimensions with a guard: xn stays in registers -- a run-time trip count would index it dynamically)
+  constexpr int DU = DP > 64 ? 1 : DP;
+  const int D = p.D;
+  const long long saved = 1 + (long long)((nh0 + (unsigned int)p.add_every_n - 1u) / (unsigned int)p.add_every_n);   // rows of the ring so far
+  const long long rows = p.de_init_extra + saved;
+  auto pick = [&](double u) -> const double* {
+    const long long spare = rows - 100ll * D;
+    const long long first = (spare * (1 - p.de_ignore) > 10ll * D) ? (long long)(spare * p.de_ignore) : 0;
+    const long long r = (long long)(first + (rows - first) * u);
+    if (r < p.de_init_extra) return p.de_init + ((size_t)r * p.Nc + c) * DP;
+    const long long hr = r - p.de_init_extra;
+    if (saved - hr > p.hist.cap) atomicOr(p.err, 64);   // the ring has lost that row: it must hold the whole run (ptm_set_proposal_de)
+    return p.hist.x + hist_slot(p.hist, hr, c) * DP;
+  };
+  const u32x4 b0 = draw_block(p.seed, TAG_MH, stream, step, 0x0DE00000u);
+  if (!(p.de_snooker > u01(b0.v0))) {                  // draw_standard
+    const double gamma = u01(b0.v1) < p.de_gamma_one ? 1.0 : p.de_gamma_std;
+    const double* z1 = pick(u01(b0.v2));
+    const double* z2 = pick(u01(b0.v3));
+#pragma unroll DU
+    for (int d = 0; d < DP; ++d) {
+      xn[d] = 0.0;
+      if (d < D) {
+        const int q = row_pos<DP>(d);
+        const double t1 = z1[q] * gamma;
+        const double a = row[q] + t1;
+        const double t2 = z2[q] * (-gamma);
+        xn[d] = a + t2;
+      }
+    }
+    log_hastings = 0.0;
+    return 0;
+  }
+  const double gamma = (1.2 + u01(b0.v1)) / p.de_gamma_div;   // draw_snooker
+  const double* z = row;
+  double axis2 = 0.0;
+  for (int tries = 0; axis2 == 0.0; ++tries) {         // the history repeats states: z must differ from the current state
+    if (tries > 1000) {                                // (the reference exits here; the engine raises an error bit and rejects the move)
+      atomicOr(p.err, 128);
+      log_hastings = __builtin_nan("");
+#pragma unroll DU
+      for (int d = 0; d < DP; ++d) xn[d] = d < D ? row[row_pos<DP>(d)] : 0.0;
+      return 1;
+    }
+    const u32x4 bt = draw_block(p.seed, TAG_MH, stream, step, 0x0DE00001u + (uint32_t)tries);
+    z = pick(u01(bt.v0));
+    axis2 = 0.0;
+#pragma unroll 1
+    for (int d = 0; d < D; ++d) { const int q = row_pos<DP>(d); const double a = row[q] + z[q] * (-1.0); axis2 = axis2 + a * a; }
+  }
+  const double* z1 = pick(u01(b0.v2));
+  const double* z2 = pick(u01(b0.v3));
+  double proj = 0.0;
+#pragma unroll 1
+  for (int d = 0; d < D; ++d) {
+    const int q = row_pos<DP>(d);
+    const double a = z1[q] * gamma, b = z2[q] * (-gamma);
+    const double diff = a + b;
+    const double ax = row[q] + z[q] * (-1.0);
+    proj = proj + diff * ax;
+  }
+  proj = proj / axis2;
+  double fz2 = 0.0;
+#pragma unroll DU
+  for (int d = 0; d < DP; ++d) {
+    xn[d] = 0.0;
+    if (d < D) {
+      const int q = row_pos<DP>(d);
+      const double ax = row[q] + z[q] * (-1.0);
+      const double t = ax * proj;
+      const double y = row[q] + t;
+      xn[d] = y;
+      const double f = y + z[q] * (-1.0);
+      fz2 = fz2 + f * f;
+    }
+  }
+  log_hastings = (dlog(fz2) - dlog(axis2)) * (double)(D - 1) / 2.0;
+  return 1;
+}
+
+// ------------------------------------------------------------------------------------------------
 // The general fused sweep kernel: one MH_chain::step (chain.cc:966-1022) per lane, all rungs x walkers per launch:
 //   gaussian_prop::draw (proposal_distribution.hh:194-218) -> state::add / enforce (states.cc:205-214,161-166)
 //   -> prior -> Gaussian likelihood -> Metropolis test -> add_state counters and history (chain.cc:916-949).
@@ -485,11 +589,16 @@ __global__ __launch_bounds__(256, PTM_SWEEP_WAVES) void sweep_kernel(const Dev p
       kmix = p.mix_K - 1;
       for (int k = p.mix_K - 2; k >= 0; --k)
         if (xs < mx[3 * k]) kmix = k;
+      // differential evolution: a member that is not ready yet (fewer than 10 D saved rows) is passed over, as
+      // proposal_distribution_set::draw passes over it (proposal_distribution.cc:111): the next member's bin is met
+      if (p.de_on && mx[3 * kmix + 1] < 0 && kmix + 1 < p.mix_K && !de_ready(p, p.nhist[c])) kmix += 1;
       mix_scale = mx[3 * kmix + 1];
       f = mx[3 * kmix + 2];
     }
     if (p.any_oned && !tc && f > 0 && u01(o0.v1) < f) { axis = (int)(p.D * u01(o0.v2)); type = 1; }
   }
+  const bool de_move = !SIMPLE && p.de_on && mix_scale < 0;
+  double de_hast = 0.0;
   double xn[DP];  // accumulates the offset, then becomes the proposed state
 #pragma unroll
   for (int i = 0; i < DP; ++i) xn[i] = 0.0;
@@ -529,14 +638,24 @@ __global__ __launch_bounds__(256, PTM_SWEEP_WAVES) void sweep_kernel(const Dev p
   //    proposal.  The row is written back only if the move is accepted.
   const double ll = p.ll[c], lp = p.lp[c];
   double* __restrict__ row = p.x + (size_t)c * DP;
-  if (!SIMPLE && p.mix_K > 0) {
+  if (de_move) {
+    // the member is differential evolution: the proposed state and its log-Hastings ratio from the chain's saved history (the accept
+    // pass of a host-callback likelihood takes ratio and type from the propose pass)
+    int dt;
+    if (mode == 2) { de_hast = p.de_hast[c]; dt = p.de_type[c]; }
+    else {
+      dt = de_draw<DP>(p, c, stream, p.step, p.nhist[c], row, xn, de_hast);
+      if (mode == 1) { p.de_hast[c] = de_hast; p.de_type[c] = dt; }
+    }
+    type = kmix + 10 * dt;     // proposal_distribution.cc:117
+  } else if (!SIMPLE && p.mix_K > 0) {
     type = kmix + 10 * type;   // proposal_distribution.cc:117
     if (mode != 2) {
 #pragma unroll
       for (int d = 0; d < DP; ++d) xn[d] = mix_scale * xn[d];   // the member is scale_k times the rung's factor
     }
   }
-  if (mode != 2) {
+  if (mode != 2 && !de_move) {
 #pragma unroll
     for (int d = 0; d < DP; ++d) xn[d] = row[row_pos<DP>(d)] + xn[d];  // state::add (states.cc:205-214)
   }
@@ -590,8 +709,12 @@ __global__ __launch_bounds__(256, PTM_SWEEP_WAVES) void sweep_kernel(const Dev p
   } else {
     newlike = newlpost = -__builtin_inf();
   }
-  const double logH = newlpost - cur_lpost;  // gaussian_prop: log_hastings_ratio() == 0
+  double logH = newlpost - cur_lpost;  // gaussian_prop: log_hastings_ratio() == 0
   bool accept = valid;
+  if (de_move) {                       // chain.cc:989-994: prop.log_hastings_ratio(), NaN => reject
+    if (de_hast != de_hast) accept = false;
+    logH = de_hast + logH;
+  }
   if (accept && logH < 0) accept = dlog_u01(o0.v0) < logH;  // chain.cc:998-1001 (NaN stays accepted)
 
   const int ntries1 = p.ntries[c] + 1;

@@ -24,7 +24,7 @@ PRIOR_NAMES = {"uni": 1, "uniform": 1, "gauss": 2, "gaussian": 2, "pol": 3, "pol
 EXPORTS = [
     "ptm_last_error", "ptm_abi_version", "ptm_device_count", "ptm_engine_create", "ptm_engine_destroy",
     "ptm_set_bounds", "ptm_set_prior", "ptm_set_target_gaussian", "ptm_set_target_callback", "ptm_set_prior_callback", "ptm_set_ladder", "ptm_set_evolve_temps", "ptm_get_invtemps", "ptm_set_invtemps",
-    "ptm_set_proposals", "ptm_set_proposal_rung", "ptm_set_proposal_mixture", "ptm_set_proposal_callback", "ptm_set_states", "ptm_init_from_prior", "ptm_init_from_prior_k", "ptm_sweep", "ptm_step", "ptm_sync",
+    "ptm_set_proposals", "ptm_set_proposal_rung", "ptm_set_proposal_mixture", "ptm_set_proposal_callback", "ptm_set_proposal_de", "ptm_set_states", "ptm_init_from_prior", "ptm_init_from_prior_k", "ptm_sweep", "ptm_step", "ptm_sync",
     "ptm_copy_llike", "ptm_copy_lprior", "ptm_llike_device_ptr", "ptm_exchange_decide", "ptm_exchange_decide_gathered", "ptm_set_shard_map", "ptm_exchange_redo_count", "ptm_exchange_redo", "ptm_exchange_finish_and_sweep", "ptm_exchange_install", "ptm_sweep_rungs", "ptm_exchange_buffer_doubles", "ptm_exchange_row_capacity", "ptm_shard_unique_id", "ptm_shard_init", "ptm_shard_step", "ptm_shard_finalize", "ptm_get_states", "ptm_batch_begin", "ptm_batch_end",
     "ptm_get_array", "ptm_get_swap_counts", "ptm_get_last_swaps", "ptm_max_swaps_per_step", "ptm_get_history", "ptm_get_history_invtemps", "ptm_set_history", "ptm_set_map", "ptm_get_map", "ptm_restore", "ptm_step_count",
     "ptm_timer_start", "ptm_timer_stop", "ptm_get_kernel_times", "ptm_calibrate", "ptm_get_counter_sums", "ptm_get_ladder_stats", "ptm_sweep_kernel_name", "ptm_step_kernel_name", "ptm_debug_eval",
@@ -44,6 +44,10 @@ class PtmConfig(C.Structure):
 class PtmCalibration(C.Structure):
     _fields_ = [("copy_GBs", C.c_double), ("copy_bytes", C.c_double), ("copy_ms", C.c_double), ("f64_fma_TFs", C.c_double),
                 ("fma_ms", C.c_double), ("sclk_MHz", C.c_double), ("compute_units", C.c_int32), ("reserved", C.c_int32)]
+
+
+class PtmDeParams(C.Structure):
+    _fields_ = [("snooker", C.c_double), ("gamma_one_frac", C.c_double), ("reduce_gamma", C.c_double), ("ignore_frac", C.c_double)]
 
 
 class PtmError(RuntimeError):
@@ -144,6 +148,7 @@ def load():
     L.ptm_get_map.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp]
     L.ptm_set_proposal_rung.argtypes = [C.c_void_p, C.c_int, _dp, C.c_double]
     L.ptm_set_proposal_mixture.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp]
+    L.ptm_set_proposal_de.argtypes = [C.c_void_p, C.POINTER(PtmDeParams), C.c_int, _dp]
     L.ptm_set_proposal_callback.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.ptm_shard_unique_id.argtypes = [C.c_void_p]
     L.ptm_shard_init.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, _i32p, C.c_int]
@@ -491,6 +496,16 @@ class Engine:
         cs, sc, od = (np.ascontiguousarray(a, dtype=np.float64) for a in (cum_shares, scales, one_d_fracs))
         K = 0 if cs.size == 0 else cs.shape[1]
         _chk(self.L.ptm_set_proposal_mixture(self.h, K, cs.ctypes.data_as(_dp), sc.ctypes.data_as(_dp), od.ctypes.data_as(_dp)))
+
+    def set_proposal_de(self, snooker=0.1, gamma_one_frac=0.3, reduce_gamma=4.0, ignore_frac=0.0, init_rows=None, off=False):
+        """differential evolution on the device as the member of negative scale of the proposal sets (ptm_set_proposal_de);
+        init_rows [n_extra][Nc][D] in the engine's chain order"""
+        if off:
+            _chk(self.L.ptm_set_proposal_de(self.h, None, 0, None))
+            return
+        q = PtmDeParams(snooker, gamma_one_frac, reduce_gamma, ignore_frac)
+        ir = None if init_rows is None else np.ascontiguousarray(init_rows, dtype=np.float64).reshape(-1, self.Nc, self.D)
+        _chk(self.L.ptm_set_proposal_de(self.h, C.byref(q), 0 if ir is None else ir.shape[0], None if ir is None else ir.ctypes.data_as(_dp)))
 
     def set_proposal_rung(self, local_rung, factor, one_d_frac=-1.0):
         f = np.ascontiguousarray(factor, dtype=np.float64)

@@ -58,7 +58,15 @@ class _PT(C.Structure):
                 ("hist_nacc", C.POINTER(C.c_int32)), ("hist_ntry", C.POINTER(C.c_int32)), ("hist_type", C.POINTER(C.c_int32)),
                 ("map_lpost", _dp), ("map_x", _dp), ("evolve_rate", C.c_double), ("betaw", _dp), ("hist_beta", _dp),
                 ("host_prop", C.c_void_p), ("host_prop_user", C.c_void_p), ("last_accept_mh", C.POINTER(C.c_uint8)),
-                ("evolve_cut", C.c_double)]
+                ("evolve_cut", C.c_double), ("de_on", C.c_int), ("de", C.c_double * 4), ("de_init_extra", C.c_int), ("de_init", _dp)]
+
+
+class _DeParams(C.Structure):
+    _fields_ = [("snooker", C.c_double), ("gamma_one_frac", C.c_double), ("reduce_gamma", C.c_double), ("ignore_frac", C.c_double)]
+
+
+DE_UNIFORM_FN = C.CFUNCTYPE(C.c_double, C.c_void_p, C.c_int)
+DE_ROW_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_long)
 
 
 _lib = None
@@ -116,6 +124,9 @@ def lib():
     L.ptmo_rng_free.argtypes = [C.c_void_p]
     L.ptmo_rng_tape_hastings.argtypes = [C.c_void_p, _dp, C.POINTER(C.c_int32)]
     L.ptmo_pt_set_host_proposal.argtypes = [C.POINTER(_PT), C.c_void_p, C.c_void_p]
+    L.ptmo_pt_set_de.argtypes = [C.POINTER(_PT), C.POINTER(_DeParams), C.c_int, _dp]
+    L.ptmo_de_draw.argtypes = [C.c_int, _dp, C.c_long, C.POINTER(_DeParams), DE_UNIFORM_FN, C.c_void_p, DE_ROW_FN, C.c_void_p, _dp, _dp]
+    L.ptmo_de_ready.argtypes = [C.c_int, C.c_long]
     L.ptmo_init_from_prior.argtypes = [C.POINTER(_PT), C.POINTER(_Problem), C.c_uint64]
     L.ptmo_selection_run_census.argtypes = [C.c_uint64, C.c_int, C.c_double, C.c_int, C.c_uint64, C.c_int, _ip, C.c_int, C.c_int,
                                             C.POINTER(C.c_int64), C.c_int]
@@ -135,6 +146,30 @@ LOGLIKE_FN = C.CFUNCTYPE(C.c_double, C.c_void_p, _dp, C.c_int)
 _i32p = C.POINTER(C.c_int32)
 # the engine's ptm_propose_batch_fn (include/ptm_engine.h) == the oracle's ptmo_propose_fn
 PROPOSE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int, _dp, _i32p, _i32p, C.c_uint64, _dp, _dp, _i32p, _i32p)
+
+
+def de_draw(x, history, uniforms, snooker, gamma_one_frac, reduce_gamma, ignore_frac):
+    """one differential_evolution::draw of the oracle (ptmo_de_draw) for the state x of a chain with the saved history `history`
+    [rows][D], fed the uniforms of a tape in sequence: (type, proposed state, log-Hastings ratio, uniforms used)"""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    H = np.ascontiguousarray(history, dtype=np.float64)
+    D = x.size
+    used = [0]
+
+    def uni(ctx, slot):
+        v = uniforms[used[0]]
+        used[0] += 1
+        return v
+
+    def row(ctx, r):
+        return H[r].ctypes.data
+
+    q = _DeParams(snooker, gamma_one_frac, reduce_gamma, ignore_frac)
+    xn = np.zeros(D)
+    lh = C.c_double(0.0)
+    cu, cr = DE_UNIFORM_FN(uni), DE_ROW_FN(row)
+    t = lib().ptmo_de_draw(D, _d(x), H.shape[0], C.byref(q), cu, None, cr, None, _d(xn), C.byref(lh))
+    return t, xn, lh.value, used[0]
 
 
 def make_propose_fn(pyfunc):
@@ -297,6 +332,13 @@ class Ladder:
             self._keep.append(m)
             self._props[r].K = K
             self._props[r].mix = _d(m)
+
+    def set_de(self, snooker=0.1, gamma_one_frac=0.3, reduce_gamma=4.0, ignore_frac=0.0, init_rows=None):
+        """differential evolution as the member of negative scale of the proposal sets (set_mixture); init_rows [n_extra][N][D] in the
+        oracle's chain order: what MH_chain::initialize(n) saved in front of the start state"""
+        q = _DeParams(snooker, gamma_one_frac, reduce_gamma, ignore_frac)
+        ir = None if init_rows is None else np.ascontiguousarray(init_rows, dtype=np.float64).reshape(-1, self.N, self.D)
+        lib().ptmo_pt_set_de(self.s, C.byref(q), 0 if ir is None else ir.shape[0], None if ir is None else _d(ir))
 
     def use_philox(self, seed):
         self.rng = lib().ptmo_rng_philox(seed, self.Nt)

@@ -278,3 +278,31 @@ def test_prior_given_as_a_function_equals_the_described_prior():
     assert len(asked) > Nt * W     # start states, then the valid proposals
     X = np.array(asked)
     assert (X[:, 0] >= lisa_toy.BMIN[0]).all() and (X[:, 0] <= lisa_toy.BMAX[0]).all()   # never asked about an invalid state
+
+
+def test_oracle_differential_evolution_matches_the_reference_draw_by_draw():
+    """The oracle's restatement of differential_evolution::draw (ptmo_de_draw; proposal_distribution.cc:476-592,745-801) against the
+    REAL reference: tests/golden/trace13.json.gz holds, per draw, the rung's saved history, the current state, the uniforms the
+    reference's generator delivered and what the reference proposed.  Fed those uniforms in sequence the oracle proposes the same
+    state (1e-12 relative), the same log-Hastings ratio and type, and asks for no more uniforms than the reference drew -- every draw
+    without temperature mixing and with unlikely_alpha = 0 (the sampler's defaults, ptmcmc.cc:81-91: what the engine draws on the
+    device), parallel and snooker moves, short histories and ones long enough for the ignored early fraction."""
+    g = golden_io.load("trace13.json.gz")
+    seen = set()
+    for c in g["cases"]:
+        D = c["D"]
+        for q in c["draws"]:
+            if q["mixing"] or q["unlikely_alpha"] > 0:
+                continue
+            r = c["rungs"][q["rung"]]
+            u = [(k + 0.5) / 4294967296.0 for k in q["uniform_k"]]     # MotherOfAll::Next (newran1.cxx:432)
+            t, xn, lh, used = O.de_draw(q["x"], r["x"], u, q["snooker"], q["gamma_one_frac"], q["reduce_gamma"], q["ignore_frac"])
+            what = (q["variant"], q["rung"])
+            assert t == q["type"] and q["valid"] == 1, what
+            want = np.array(q["proposed"])
+            assert np.allclose(xn, want, rtol=1e-12, atol=1e-12 * np.abs(np.array(q["x"])).max()), (what, xn, want)
+            assert abs(lh - q["log_hastings"]) <= 1e-12 * max(1.0, abs(q["log_hastings"])), (what, lh, q["log_hastings"])
+            # a snooker move uses every uniform the reference drew; a parallel move leaves the D normals of the small jump it discards
+            assert used == len(u) if t == 1 else used == 4 and len(u) - used >= D, (what, used, len(u))
+            seen.add((t, r["size"] > 110 * D, q["ignore_frac"] > 0))
+    assert {k[0] for k in seen} == {0, 1} and len({k[1] for k in seen}) == 2, seen
