@@ -124,7 +124,8 @@ int main(int argc, char* argv[]) {
     ptmcmc_sampler* ps = dynamic_cast<ptmcmc_sampler*>(s);
     std::cout << ps->chains()->status();
     std::cout << "MAP: lpost = " << ps->chains()->getMAPlpost() << " at " << ps->chains()->getMAPstate().get_string() << std::endl;
-    std::cout << "proposals drawn on the " << (ps->chains()->proposals_on_host() ? "host" : "device") << std::endl;
+    std::cout << "proposals drawn on the " << (ps->chains()->proposals_on_host() ? "host" : "device")
+              << (ps->chains()->draws_de_on_device() ? " (differential evolution from the device's own history)" : "") << std::endl;
     delete s;
   }
   // summary

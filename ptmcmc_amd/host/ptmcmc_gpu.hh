@@ -722,6 +722,9 @@ class proposal_distribution {
   virtual bool device_describe(int dim, int& kind, std::vector<double>& factor, double& oneDfrac) const { return false; }
   // a set of Gaussian members that are scalar multiples of one factor: cumulative shares, scales, oneDfracs (else false)
   virtual bool device_describe_mixture(int dim, std::vector<double>& cum, std::vector<double>& scales, std::vector<double>& odfs) const { return false; }
+  // differential evolution the device can draw itself (ptm_set_proposal_de): no temperature mixing, unlikely_alpha = 0; a set answers
+  // for its differential-evolution member
+  virtual bool device_describe_de(ptm_de_params& q) const { return false; }
 };
 
 namespace detail {
@@ -1152,27 +1155,53 @@ class proposal_distribution_set : public proposal_distribution {
     for (size_t i = 0; i < slots.size(); i++) v.push_back(slots[i].prop);
     return v;
   }
+  // the member that is a differential evolution the device can draw (at most one, and not the last: a member that is not ready is
+  // passed over for the NEXT one, proposal_distribution.cc:111), or -1
+  int device_de_member() const {
+    int at = -1;
+    for (size_t i = 0; i < slots.size(); i++) {
+      ptm_de_params q;
+      if (!slots[i].prop->device_describe_de(q)) continue;
+      if (at >= 0 || i + 1 == slots.size()) return -2;   // two of them, or nothing behind it: the host's business
+      at = (int)i;
+    }
+    return at;
+  }
+  int first_gaussian_member() const {
+    const int de = device_de_member();
+    for (size_t i = 0; i < slots.size(); i++) if ((int)i != de) return (int)i;
+    return -1;
+  }
+  bool device_describe_de(ptm_de_params& q) const override {
+    const int de = device_de_member();
+    return de >= 0 && adapt_rate == 0 && !(thermal_power > 0) && slots[de].prop->device_describe_de(q);
+  }
   bool device_describe(int dim, int& kind, std::vector<double>& f, double& odf) const override {
     if (adapt_rate != 0 || thermal_power > 0) return false;   // shares that move are the host's business
-    if (!slots[0].prop->device_describe(dim, kind, f, odf)) return false;
+    const int g0 = first_gaussian_member();
+    if (device_de_member() == -2 || g0 < 0 || !slots[g0].prop->device_describe(dim, kind, f, odf)) return false;
     std::vector<double> cum, sc, od;
     if (!device_describe_mixture(dim, cum, sc, od)) return false;
     odf = 0;   // the members' oneDfracs live in the mixture table
     return true;
   }
+  // Gaussian members that are scalar multiples of one factor, and at most one differential evolution (scale -1: ptm_set_proposal_de)
   bool device_describe_mixture(int dim, std::vector<double>& cum, std::vector<double>& scales, std::vector<double>& odfs) const override {
     if (adapt_rate != 0 || thermal_power > 0) return false;
+    const int de = device_de_member(), g0 = first_gaussian_member();
+    if (de == -2 || g0 < 0) return false;
     int kind0; double odf0; std::vector<double> f0;
-    if (!slots[0].prop->device_describe(dim, kind0, f0, odf0)) return false;
+    if (!slots[g0].prop->device_describe(dim, kind0, f0, odf0)) return false;
     cum.clear(); scales.clear(); odfs.clear();
     for (size_t i = 0; i < slots.size(); i++) {
+      cum.push_back(i + 1 == slots.size() ? 1.0 : upper[i]);
+      if ((int)i == de) { scales.push_back(-1.0); odfs.push_back(0.0); continue; }
       int kind; double odf; std::vector<double> f;
       if (!slots[i].prop->device_describe(dim, kind, f, odf) || kind != kind0 || f.size() != f0.size()) return false;
       double sc = 0;
       for (size_t k = 0; k < f.size(); k++) if (f0[k] != 0) { sc = f[k] / f0[k]; break; }
       for (size_t k = 0; k < f.size(); k++)
         if (std::fabs(f[k] - sc * f0[k]) > 1e-12 * (std::fabs(f[k]) + std::fabs(sc * f0[k])) + 1e-300) return false;   // not a multiple
-      cum.push_back(i + 1 == slots.size() ? 1.0 : upper[i]);
       scales.push_back(sc);
       odfs.push_back(odf);
     }
@@ -1334,6 +1363,14 @@ class differential_evolution : public proposal_distribution {
   }
   bool support_mixing(bool do_it) { mixing = do_it; return do_it; }
   bool support_mixing() override { return mixing; }
+  // what the engine draws on the device from its own history (ptm_set_proposal_de): everything but temperature mixing and
+  // unlikely_alpha, which stay with this class on the host
+  bool device_describe_de(ptm_de_params& q) const override {
+    static const bool off = [] { const char* v = getenv("PTM_HOST_DE"); return v && *v && *v != '0'; }();   // (A/B timing: keep the host path)
+    if (off || mixing || discount != 0) return false;
+    q.snooker = p_snooker; q.gamma_one_frac = p_unit_gamma; q.reduce_gamma = gamma_divisor; q.ignore_frac = skip_early;
+    return true;
+  }
 };
 
 // ---- effective sample size of a saved series ---------------------------------------------------------------------------------
@@ -1747,6 +1784,7 @@ class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:
   // MH_chain::add_state saves (chain.cc:935-946) is kept for the proposals that read the chain history (differential
   // evolution): all Ninit initial draws, then every saved row, pulled from the device's short history ring after each step.
   bool host_mode = false, want_host = false;
+  bool want_de = false, de_built = false;   // differential evolution drawn on the device from the device's history
   int ring_rows = 0, ring_rungs = 0;   // the device history ring as the engine was created with it
   uint64_t eng_seed = 0;
   struct mirror_t {   // one chain's saved history, raw indexing as MH_chain::states / lposts / llikes (chain.hh:155-163)
@@ -2135,6 +2173,10 @@ class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:
   bool have_start = false;
   // tell the ladder BEFORE initialize() that its proposal will be drawn on the host (saves building the engine twice)
   void use_host_proposals(bool on = true) { want_host = on; }
+  // ... or that its set holds a differential evolution the DEVICE draws (ptm_set_proposal_de): the engine then records every rung's
+  // history (keep_history must hold the whole run) and keeps the n - 1 extra draws of initialize(n) on the device
+  void use_device_de(bool on = true) { want_de = on; }
+  bool draws_de_on_device() const { return de_built; }
   void initialize(bayes_likelihood* log_likelihood, const sampleable_probability_function* log_prior, int n = 1, uint64_t seed = 0x5EED0001ull,
                   const std::vector<double>* start_states = nullptr) {
     init_like = log_likelihood; init_prior = log_prior; Ninit_asked = n < 1 ? 1 : n; eng_seed = seed;
@@ -2152,9 +2194,13 @@ class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:
     dim = log_prior->getDim();
     host_mode = host;
     Ninit_rows = host ? Ninit_asked : 1;
+    // differential evolution on the device: every rung's history stays there, in a ring as long as the run (keep_history), with the
+    // extra draws of initialize(n) beside it; the rows keep the ring's numbering (row 0 = the start state)
+    de_built = !host && want_de && hist_rows > 0;
+    const int draws = (host || de_built) ? Ninit_asked : 1;
     // host-side proposals: every rung's saved rows pass through a SHORT device ring into the host mirror after each step
     ring_rows = host ? 8 : hist_rows;
-    ring_rungs = host ? Ntemps : history_rungs();
+    ring_rungs = (host || de_built) ? Ntemps : history_rungs();
     ptm_config cfg = ptm_config();   // (zeroed: fields a newer ABI adds default to 0)
     cfg.struct_size = sizeof cfg;
     cfg.dim = dim; cfg.n_rungs = Ntemps; cfg.rung_begin = 0; cfg.rung_count = Ntemps; cfg.n_walkers = W; cfg.seed = eng_seed;
@@ -2196,7 +2242,7 @@ class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:
       // MH_chain::initialize (chain.cc:846-876) on the host: every start state is a draw of the prior's own drawSample with the
       // chain's generator, redrawn while the likelihood is below -1e100 (:856-869); draws 1 .. n-1 are kept for the mirror
       std::vector<double> x0(N * dim);
-      for (int k = host ? Ninit_rows - 1 : 0; k >= 0; k--) {
+      for (int k = draws - 1; k >= 0; k--) {
         std::vector<double> x(N * dim), ll(N), lp(N);
         for (size_t c = 0; c < N; c++) {
           philox_random rng;
@@ -2218,7 +2264,7 @@ class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:
       ptm_check(ptm_set_states(eng, x0.data(), nullptr), "set_states");
     } else {
       // draws 1 .. n-1 first (kept for the mirror), draw 0 last: it is the chain's start, whatever n is
-      for (int k = host ? Ninit_rows - 1 : 0; k >= 0; k--) {
+      for (int k = draws - 1; k >= 0; k--) {
         int rc = ptm_init_from_prior_k(eng, k);
         if (rc == PTM_ERR_UNSUPPORTED) {
           std::cout << "parallel_tempering_chains::initialize: " << ptm_last_error() << "; pass start states" << std::endl;
@@ -2274,6 +2320,15 @@ class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:
       all.insert(all.end(), f.begin(), f.end());
       odfs[i] = odf;
     }
+    {
+      ptm_de_params q;
+      if (on_device && proposal.device_describe_de(q)) {
+        // a set with a differential evolution for the device: possible if the ring holds the run and the dimensions fit the kernel
+        // that draws it (ptm_set_proposal_de); else the whole set is drawn on the host
+        if (hist_rows <= 0 || dim > 32) on_device = false;
+        else if (!de_built) { want_de = true; build_engine(false); }   // (initialize() did not know: set up again, with the same draws)
+      }
+    }
     if (on_device) {
       if (host_mode) build_engine(false);
       for (int i = 0; i < Ntemps; i++) props.push_back(proposal.clone());
@@ -2289,6 +2344,17 @@ class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:
         ptm_check(ptm_set_proposal_mixture(eng, 0, nullptr, nullptr, nullptr), "set_proposal_mixture");
       }
       ptm_check(ptm_set_proposal_callback(eng, nullptr, nullptr, nullptr), "set_proposal_callback");
+      ptm_de_params q;
+      if (proposal.device_describe_de(q)) {
+        // the set's differential evolution is drawn on the device from the device's own history: the extra draws of initialize(n),
+        // oldest first (init_x), then the ring
+        const size_t N = (size_t)Ntemps * W;
+        std::vector<double> rows(init_x.size() * N * dim);
+        for (size_t k = 0; k < init_x.size(); k++) std::copy(init_x[k].begin(), init_x[k].end(), rows.begin() + k * N * dim);
+        ptm_check(ptm_set_proposal_de(eng, &q, (int)init_x.size(), rows.empty() ? nullptr : rows.data()), "set_proposal_de");
+      } else {
+        ptm_check(ptm_set_proposal_de(eng, nullptr, 0, nullptr), "set_proposal_de");
+      }
       return;
     }
     if (!host_mode) build_engine(true);   // (initialize() did not know: the engine is set up again, with the same draws)
@@ -2395,14 +2461,26 @@ class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:
       hist_fresh = true;
     }
     const std::vector<int32_t>& meta = hmeta;
+    // (rows are numbered as the ring numbers them -- row 0 the start state --; with differential evolution on the device the header
+    //  names the initial draws the device keeps beside the ring, as the reference's file does)
     const int Ninit = 1, Nhist = (int)hnhist[at];
-    os << "#Ninit=" << Ninit << ", Nburn=" << Nburn << "\n";
+    os << "#Ninit=" << (de_built ? Ninit_asked : Ninit) << ", Nburn=" << Nburn << "\n";
     os << "#eval: log(posterior) log(likelihood) acceptance_ratio prop_type: ";
     for (int i = 0; i < dim; i++) os << (sp ? sp->get_name(i) : std::string("[unnamed]")) << " ";
     os << std::endl;
-    if (Nburn + Ninit < 0) Nburn = -Ninit;
+    const int Nfront = de_built ? Ninit_asked - 1 : 0;              // initial draws in front of the ring's row 0 (kept by the host too: init_x)
+    if (Nburn + Ninit + Nfront < 0) Nburn = -(Ninit + Nfront);
     const double invtemp = cur_beta(ichain, replica);   // the chain's CURRENT temperature on every row (chain.cc:1131)
     for (int i = Nburn; i < Nhist; i += ievery) {
+      if (i + Ninit < 0) {   // one of the initial draws in front of the start state (MH_chain::initialize adds every one, chain.cc:846-876)
+        const int k = Nfront + Ninit + i;
+        if (k < 0 || k >= (int)init_x.size()) continue;
+        const double t = (1 / temps[ichain]) * init_ll[k][at];
+        os << i << " " << init_lp[k][at] + t << " " << init_ll[k][at] << " " << 1.0 << " " << -1 << ": ";
+        for (int j = 0; j < dim - 1; j++) os << init_x[k][at * dim + j] << " ";
+        os << init_x[k][at * dim + dim - 1] << " " << invtemp << std::endl;
+        continue;
+      }
       int idx = Ninit + i;                                          // chain.cc:1124-1125
       if (i >= 0) idx = Ninit + i / add_every_N;                    // get_state_idx, chain.cc:1041-1050 (Nzero = 0)
       const size_t o = (size_t)(idx % (int)cap) * HC + at;
@@ -2885,14 +2963,27 @@ class ptmcmc_sampler : public bayes_sampler {
     int dn = dump_n;
     if (dn > Nptc || dn <= 0) dn = Nptc;   // ptmcmc.cc:458
     // ... and with an effective-sample-size stop (chain_ess_stop) the cold chain's whole saved history
-    cc->keep_history(2 + 2 * (ess_stop > 0 ? std::max(Nevery, Nstep) : Nevery) / std::max(1, save_every), dn);
-    cc->set_replica_range(replica_begin, nreplicas, device);
-    if (pt_evolve_rate > 0) cc->evolve_temps(pt_evolve_rate, pt_evolve_lpost_cut);   // ptmcmc.cc:512
     int kind; double odf; std::vector<double> f;
     const int dim = chain_prior->getDim();
-    const bool host = !cprop->device_describe(dim, kind, f, odf) && !dynamic_cast<user_gaussian_prop*>(cprop);
+    bool host = !cprop->device_describe(dim, kind, f, odf) && !dynamic_cast<user_gaussian_prop*>(cprop);
+    // A set with a differential evolution the device can draw (the default recipe): the device keeps EVERY rung's saved history of
+    // the whole run -- up to two add_state calls per step, every save_every-th saved -- if that fits (16 GB here); else the host draws
+    ptm_de_params deq;
+    const long long de_rows = 2 + 2ll * std::max(Nevery, Nstep) / std::max(1, save_every);
+    const double de_bytes = (double)de_rows * Nptc * std::max(1, nreplicas) * (8.0 * std::max(4, dim > 16 ? 32 : (dim > 8 ? 16 : (dim > 4 ? 8 : 4))) + 40.0);
+    const bool de_dev = !host && cprop->device_describe_de(deq) && dim <= 32 && de_bytes < 16e9 && de_rows < (1ll << 30);
+    if (!host && cprop->device_describe_de(deq) && !de_dev) host = true;
+    if (de_dev) {
+      if (restarting && Nstep > 0) Ninit = chain_Ninit;   // (the device's initial rows are drawn again, the same ones: they are not in the checkpoint)
+      cc->keep_history((int)de_rows, Nptc);
+      cc->use_device_de(true);
+    } else {
+      cc->keep_history(2 + 2 * (ess_stop > 0 ? std::max(Nevery, Nstep) : Nevery) / std::max(1, save_every), dn);
+    }
+    cc->set_replica_range(replica_begin, nreplicas, device);
+    if (pt_evolve_rate > 0) cc->evolve_temps(pt_evolve_rate, pt_evolve_lpost_cut);   // ptmcmc.cc:512
     cc->use_host_proposals(host);
-    cc->initialize(chain_llike, chain_prior, host ? Ninit : 1, ProbabilityDist::nextLadderSeed());
+    cc->initialize(chain_llike, chain_prior, (host || de_dev) ? Ninit : 1, ProbabilityDist::nextLadderSeed());
     cc->set_proposal(*cprop);
     return 0;
   }

@@ -16,4 +16,7 @@ for Z in 1 0; do
   per_step "lisa, device proposals"        2000 10000 ./lisa --outname=l1 --pt=20 --gauss_draw_frac=1
   per_step "lisa, default recipe"          2000 10000 ./lisa --outname=l2 --pt=20
   per_step "lisa, default recipe, 128 T"   2000 6000 ./lisa --outname=l3 --pt=128
+  # (the default recipe's differential evolution is drawn on the device since round 4; PTM_HOST_DE=1 keeps the host-proposal path)
+  PTM_HOST_DE=1 per_step "lisa, default recipe, DE on the host"          2000 10000 ./lisa --outname=l4 --pt=20
+  PTM_HOST_DE=1 per_step "lisa, default recipe, 128 T, DE on the host"   2000 6000 ./lisa --outname=l5 --pt=128
 done
