@@ -1,6 +1,10 @@
 #!/bin/bash
-# Issue / LDS / memory-instruction counters of the ptm:: kernels of ANY command, in small groups (separate --pmc passes, no trace
+# Issue / LDS / memory-instruction counters of the ptm:: kernels of a command, in small groups (separate --pmc passes, no trace
 # domain beside them).  usage (GPU box): bash tools/pmc_cmd.sh <tag> python3 tools/kbench_shard.py --walkers 16384 --gpus 8 --reps 3
+# The PROGRAM ITSELF must follow the tag -- an interpreter running the workload's script, or the workload's binary: under --pmc the
+# profiler's preloaded library has initialised the GPU before the program starts, and any hop through env / bash -c / sh -c /
+# taskset / numactl / torchrun / a re-exec'ing launcher is then an exec from a process that holds the GPU, which takes the machine
+# down on this pool.  Pin or set the environment BEFORE this script, never behind it; such launchers are refused below.
 # Writes gpurun_out/<tag>_pmc_cmd_summary.json (copy into profiles/).
 TAG=$1; shift
 cd /tmp && export TMPDIR=/tmp
@@ -8,6 +12,15 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/pmcc_$TAG
 rm -rf $OUT; mkdir -p $OUT
 PROG=$1; shift
+case "$(basename "$PROG")" in
+  env|bash|sh|dash|zsh|taskset|numactl|torchrun|nohup|timeout|time|xargs|sudo|stdbuf|nice)
+    echo "pmc_cmd.sh: refusing '$PROG' after 'rocprofv3 --pmc ... --': it would exec the real program from a process that already holds the GPU." >&2
+    echo "            Name the program itself (python3 <script> ..., or the binary); set environment and pinning before calling this script." >&2
+    exit 2;;
+esac
+if [ "$(basename "$PROG")" = "python3" ] || [ "$(basename "$PROG")" = "python" ]; then
+  case "$1" in -m) if [ "$2" = "torch.distributed.run" ] || [ "$2" = "torch.distributed.launch" ]; then echo "pmc_cmd.sh: refusing a launcher that starts the workload in child processes via exec" >&2; exit 2; fi;; esac
+fi
 ARGS=""
 for a in "$@"; do case "$a" in tools/*|bench.py) ARGS="$ARGS $R/$a";; *) ARGS="$ARGS $a";; esac; done
 i=0
