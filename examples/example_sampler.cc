@@ -4,6 +4,8 @@
 //   usage: example_sampler <outbase> [--nsteps=N] [--pt=Ntemps] [--save_every=S] [--nevery=E] [--nskip=K] [--pt_dump_n=M]
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
+#include <string>
 #include <vector>
 
 #include "ptmcmc_gpu.hh"
@@ -11,10 +13,25 @@ using namespace ptmgpu;
 
 int main(int argc, char** argv) {
   if (argc < 2) { printf("usage: %s <outbase> [--option=value ...]\n", argv[0]); return 2; }
-  const int D = 3;
+  // --dim=D (first option, if given): a D-dimensional tridiagonal-precision target instead of the 3-dimensional one -- e.g. --dim=12
+  // with --pt=64: a ladder long enough for the persistent ladder kernel (its build with everything the sampler switches on)
+  int D = 3;
+  if (argc > 2 && std::string(argv[2]).rfind("--dim=", 0) == 0) {
+    D = atoi(argv[2] + 6);
+    for (int k = 2; k + 1 < argc; k++) argv[k] = argv[k + 1];
+    argc--;
+  }
   std::vector<double> P = {2.0, 0.6, 0.0, 0.6, 1.0, -0.3, 0.0, -0.3, 1.5};   // precision of the target
+  if (D != 3) {
+    P.assign((size_t)D * D, 0.0);
+    for (int i = 0; i < D; i++) { P[(size_t)i * D + i] = 1.0 + 0.1 * i; if (i + 1 < D) P[(size_t)i * D + i + 1] = P[(size_t)(i + 1) * D + i] = 0.3; }
+  }
   stateSpace space(D);
-  space.set_names(std::vector<std::string>{"a", "b", "c"});
+  {
+    std::vector<std::string> names;
+    for (int i = 0; i < D; i++) names.push_back(D == 3 ? std::string(1, (char)('a' + i)) : "p" + std::to_string(i));
+    space.set_names(names);
+  }
   gaussian_likelihood like(P, 0.0);
   std::vector<std::string> types(D, "uni");
   std::vector<double> centers(D, 0.0), scales(D, 20.0);
@@ -42,5 +59,6 @@ int main(int argc, char** argv) {
   mcmc.initialize();
   mcmc.run(argv[1]);
   printf("%s", mcmc.chains()->status().c_str());
+  printf("step kernel: %s\n", ptm_step_kernel_name(mcmc.chains()->engine()));
   return 0;
 }

@@ -376,8 +376,9 @@ __device__ __forceinline__ void decide_body(const Decide& p, unsigned char* smem
               if (i + 1 < Nt - 1) bb = 1 - p0[i + 1] / nrm;
             }
             bklo[k] = ba;
-            p.beta_add[(size_t)(i + 1) * p.W + w] = bb;
-            if (!PTM_ALIVE_RUNG(i - 1)) p.beta_add[(size_t)i * p.W + w] = ba;
+            // (chain-indexed: the shard's own rungs -- a rung shard replays the whole ladder's picks, ptm_exchange_decide_gathered)
+            if (i + 1 >= p.r0 && i + 1 < r1) p.beta_add[(size_t)(i + 1 - p.r0) * p.W + w] = bb;
+            if (!PTM_ALIVE_RUNG(i - 1) && i >= p.r0 && i < r1) p.beta_add[(size_t)(i - p.r0) * p.W + w] = ba;
           }
           if (acc) {
             const double a = llv[i]; llv[i] = llv[i + 1]; llv[i + 1] = a;
@@ -596,8 +597,8 @@ __device__ __forceinline__ void decide_body(const Decide& p, unsigned char* smem
         bklo[k] = blo;
         // last add of the phase: always for the upper rung (a pick on the pair above came earlier), for the lower rung
         // unless a later pick exchanges it again
-        p.beta_add[(size_t)(i + 1) * p.W + w] = bhi;
-        if (!PTM_ALIVE_RUNG(i - 1)) p.beta_add[(size_t)i * p.W + w] = blo;
+        if (i + 1 >= p.r0 && i + 1 < r1) p.beta_add[(size_t)(i + 1 - p.r0) * p.W + w] = bhi;
+        if (!PTM_ALIVE_RUNG(i - 1) && i >= p.r0 && i < r1) p.beta_add[(size_t)(i - p.r0) * p.W + w] = blo;
       }
       __syncthreads();
     }

@@ -123,7 +123,7 @@ struct ptm_engine {
   double *pub_x = nullptr, *pub_ll = nullptr, *pub_lp = nullptr;   // (one allocation: pub_x)
   int *lad_flags = nullptr, *lad_ctl = nullptr;                     // (one allocation: lad_flags)
   long long* lad_prof = nullptr;
-  int lad_capacity[2][4] = {{-1, -1, -1, -1}, {-1, -1, -1, -1}};   // workgroups of each build of that kernel [diagonal][FL] the device holds at once (-1: not asked yet)
+  int lad_capacity[2][8] = {{-1, -1, -1, -1, -1, -1, -1, -1}, {-1, -1, -1, -1, -1, -1, -1, -1}};   // workgroups of each build of that kernel [diagonal][FL] the device holds at once (-1: not asked yet)
   long long ladder_launches = 0, ladder_whole_steps = 0;   // launches of that kernel; steps (of walker 0) whose exchange phase needed the whole ladder
   // A launch of that kernel commits all of its steps or none (ptm_ladder_kernel.hpp) and is ASYNCHRONOUS: the host learns at its
   // next look (ladder_settle) whether the launches since the last look were committed -- the device keeps the number of the last one
@@ -752,7 +752,9 @@ extern "C" int ptm_set_evolve_temps(ptm_engine* e, double rate, double lpost_cut
     // the whole ladder's trials -- from the whole ladder's llikes, which the caller gathers each step (ptm_exchange_decide_gathered;
     // the reference's MPI ranks do exactly that: gather_llikes, chain.cc:1433-1435,1950-1972).  Every shard keeps every ladder's
     // temperatures [W][Nt]; the gathered llikes (+ lpriors with a posterior-ordering cut) are [Nt][W] doubles per step.
-    if (e->hist.rungs || e->map.rungs) return fail(PTM_ERR_UNSUPPORTED, "evolving ladders on a rung shard: history / MAP tracking is not built (track them on whole-ladder engines)");
+    // (history / MAP tracking of the shard's own rungs: every shard replays every pick and so knows the temperature each of its
+    //  rungs had at each add_state of the exchange phase -- beta_add, chain-indexed; the shard's top rung cannot be recorded unless
+    //  it is the ladder's, as on a fixed ladder: ptm_engine_create)
     if ((double)e->W * e->Nt * 16.0 > 512.0 * 1024 * 1024)
       return fail(PTM_ERR_UNSUPPORTED, "evolving ladders on a rung shard gather %d x %d llikes (and lpriors) per step: more than 512 MB -- split such a population by walkers "
                                        "(ptm_config.walker_begin)", e->Nt, e->W);
@@ -1607,20 +1609,25 @@ static int fused_steps(ptm_engine* e, int n) {
 #ifndef PTM_LADDER_MIN_STEPS
 #define PTM_LADDER_MIN_STEPS 1
 #endif
-static int ladder_flavour(const ptm_engine* e) { return ((e->any_oned || e->mix_K > 0) ? 1 : 0) | ((e->hist.rungs || e->map.rungs) ? 2 : 0); }
+// the build of the persistent ladder kernel an engine takes: bit 0 one-dimensional moves / scale mixtures, bit 1 history / MAP tracking,
+// bit 2 evolving ladders (built plain, 4, and with everything, 7)
+static int ladder_flavour(const ptm_engine* e) {
+  const int fl = ((e->any_oned || e->mix_K > 0) ? 1 : 0) | ((e->hist.rungs || e->map.rungs) ? 2 : 0);
+  return e->evolve_rate > 0 ? (fl ? 7 : 4) : fl;
+}
 static bool ladder_applies(ptm_engine* e, long long* grid_out = nullptr, size_t* lds_out = nullptr) {
   static const bool ladder_ok = [] { const char* v = getenv("PTM_LADDER"); return !(v && *v == '0'); }();
-  if (!ladder_ok || e->lad_disabled || (e->DP != 16 && e->DP != 32) || e->Nt < 2 || e->nloc != e->Nt || e->cfg.time_kernels || e->evolve_rate > 0 || e->shard)
+  if (!ladder_ok || e->lad_disabled || (e->DP != 16 && e->DP != 32) || e->Nt < 2 || e->nloc != e->Nt || e->cfg.time_kernels || (e->evolve_rate > 0 && e->evolve_cut >= 0) || e->shard)
     return false;
   const SweepSel sel = sweep_sel(e);
   // open / `limit` boundaries, all-uniform prior, zero mean, fixed ladder, device target and proposals (one-dimensional moves, scale
   // mixtures, history and MAP tracking have their builds: ladder_flavour); populations with whole waves per rung keep the throughput kernels
-  if (sel.uni || (e->has_bounds && !e->bounds_box) || !e->all_uniform || e->has_mean || e->cb || e->prior_cb || e->pcb || e->betaC || e->de_on) return false;
+  if (sel.uni || (e->has_bounds && !e->bounds_box) || !e->all_uniform || e->has_mean || e->cb || e->prior_cb || e->pcb || e->de_on) return false;
   const int R = 256 / e->DP, NB = (e->Nt + R - 1) / R;
   const long long grid = (long long)e->W * NB;
   const bool diag = e->prop_kind == PTM_PROP_DIAG;
   const int fl = ladder_flavour(e);
-  const size_t lds = e->DP == 16 ? ladder_lds_16(e->Nt, e->ms) : ladder_lds_32(e->Nt, e->ms);
+  const size_t lds = e->DP == 16 ? ladder_lds_16(e->Nt, e->ms, e->evolve_rate > 0) : ladder_lds_32(e->Nt, e->ms, e->evolve_rate > 0);
   if (lds > 160 * 1024) return false;
   int& cap = e->lad_capacity[diag ? 1 : 0][fl];   // (asked per build: the builds differ in registers, and the LDS attribute is per kernel)
   if (cap < 0) cap = e->DP == 16 ? ladder_blocks_16(diag, fl, lds) : ladder_blocks_32(diag, fl, lds);
@@ -1734,6 +1741,7 @@ static int ladder_steps(ptm_engine* e, int n) {
     { static const int pt = [] { const char* v = getenv("PTM_LADDER_PROF"); return (v && *v == '2') ? 256 : ((v && *v == '3') ? 384 : 0); }(); a.prof_tid = pt; }
     if ((rc = fold_swap_log(e))) return rc;   // (the kernel adds to the swap counters itself: nothing logged may be pending behind it)
     a.spin_limit = spin_limit;
+    a.evolve_rate = e->evolve_rate;
     a.done_seq = e->err + 2;
     a.seq = e->lad_seq + 1;
     HIPCHK(hipMemsetAsync(e->lad_flags, 0, ((size_t)grid + 16 + (size_t)e->W) * sizeof(int), e->stream));
@@ -1761,7 +1769,7 @@ static int ladder_steps(ptm_engine* e, int n) {
       if (ctl[1] > 0) {
         std::vector<long long> pr((size_t)grid * 8);
         HIPCHK(hipMemcpy(pr.data(), e->lad_prof, pr.size() * 8, hipMemcpyDeviceToHost));
-        static const char* const phase[7] = {"", "publish", "draws | random blocks", "filter | offsets", "window | Metropolis", "commit + trials", "rows"};
+        static const char* const phase[7] = {"", "publish", "draws | random blocks", "filter | offsets", "window | Metropolis", "commit + trials (evolving: decisions + pries)", "rows (evolving: temperatures, Metropolis, rows)"};
         fprintf(stderr, "[ladder kernel] %d steps, %lld workgroups; us per step (mean / max over workgroups):", ctl[1], grid);
         for (int q = 1; q < 7; ++q) {
           double sum = 0, mx = 0;
@@ -1774,6 +1782,7 @@ static int ladder_steps(ptm_engine* e, int n) {
     }
     e->step += (uint64_t)k;
     done += k;
+    if (e->evolve_rate > 0) e->betaC_stale = true;    // (the kernel keeps the ladder-major temperatures; the chain-indexed image on demand: ensure_betaC)
     e->log_head = (e->log_head + 1) % PTM_LOG_RING;   // (the last step's candidate log sits in the slot handed over)
   }
   e->touched = false;

@@ -27,6 +27,7 @@ struct LadderArgs {
   long long spin_limit; // wall-clock ticks a workgroup waits for a neighbour before it gives up
   long long* prof;      // null, or [W * NB][8] phase clocks (diagnostics)
   int prof_tid;         // ... of this thread: 0 a chains' wave, 256 a replay wave, 384 a window wave (PTM_LADDER_PROF=1 / 2 / 3)
+  double evolve_rate;   // evolving ladders (FL bit 2): the rate of pry_temps (chain.cc:1829)
   int max_run;          // longest run of surviving picks on consecutive rungs a step may hold (<= LADDER_H; tests lower it)
 };
 
@@ -42,5 +43,9 @@ inline size_t ladder_window_lds_bytes(int DP) {
 // with the bookkeeper wave two waves share a SIMD and a lane has 256 registers, not 512 -- its row of the matrix no longer fits beside
 // its row of the factor
 inline size_t ladder_psq_lds_bytes(int DP) { return DP == 32 ? (size_t)DP * (DP + 1) * 8 : 0; }
+
+// ... and of an evolving ladder: temperatures, gaps, prefix sums [Nt] each | chunk totals and offsets | per candidate: log-uniform,
+// normaliser, increase (doubles), pries before, pried pair, pick list (ints) | two counters
+inline size_t ladder_ev_lds_bytes(int Nt, int ms) { return (size_t)Nt * 24 + (size_t)(2 * ((Nt + 31) / 32) + 4) * 8 + (size_t)ms * 24 + (size_t)ms * 12 + 64 + (size_t)((ms + 7) & ~7); }
 
 }  // namespace ptm

@@ -32,7 +32,13 @@
 // two-launch path and to the CPU checker (the parity suite runs through this kernel wherever it applies).
 // Scope: open or `limit` bounds, all-uniform prior, zero mean, fixed ladder, device target, DP = 16 or 32; template flags FL: bit 0 =
 // one-dimensional moves and scale mixtures (the reference sampler's default Gaussian recipe, ptmcmc.cc:117-139), bit 1 = the history
-// ring and MAP tracking of MH_chain::add_state (chain.cc:931-946), rows of a rung exchanged twice in a step included (quirk Q6).
+// ring and MAP tracking of MH_chain::add_state (chain.cc:931-946), rows of a rung exchanged twice in a step included (quirk Q6); bit 2 =
+// EVOLVING LADDERS (parallel_tempering_chains::evolve_temps: pry_temps after every accepted exchange, chain.cc:1501-1518,1809-1846,
+// without the posterior-ordering cut).  A pry renormalises ALL gaps and every later trial of the step sees it, so every workgroup
+// replays every trial of the ladder in pick order -- every step takes the whole ladder's published llikes (the form a run of picks
+// longer than the halo takes on a fixed ladder), keeps the ladder's temperatures in LDS, and the Metropolis tests wait for the
+// step's new temperatures.  With every step in that form the double buffer of the publications needs no second barrier: nobody
+// can publish step s + 2 before everybody has published step s + 1, i.e. has read step s.
 //
 // ALL OR NOTHING.  A workgroup that waits in vain for a neighbour (a grid that is not resident: a shared device, a second engine's
 // kernel in the way) gives up, and then nothing of the launch may stay: the chains live in registers until every workgroup of the grid
@@ -66,6 +72,7 @@ __global__ __launch_bounds__(LADDER_THREADS) void ladder_persistent_kernel(const
   static_assert(DP == 16 || DP == 32, "persistent ladder kernel: DP 16 or 32");
   constexpr bool GENX = (FL & 1) != 0;   // one-dimensional moves, scale mixtures
   constexpr bool HIST = (FL & 2) != 0;   // history ring, MAP tracking
+  constexpr bool EV = (FL & 4) != 0;     // evolving ladders
   // a launch whose predecessor gave up does nothing: the host repeats that launch's steps, and this one's, on the two-launch path
   if (__hip_atomic_load(a.done_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.seq - 1) return;
   constexpr int R = 256 / DP;            // rungs per workgroup
@@ -121,6 +128,21 @@ __global__ __launch_bounds__(LADDER_THREADS) void ladder_persistent_kernel(const
   int* midall = permall + ((Nt + 1) & ~1);                                // [Nt] ... and in-between rows
   constexpr bool PROW_LDS = DP == 32 && KIND != KIND_DIAG;                // the precision matrix's rows from LDS (ptm_ladder_args.hpp)
   double* psq = reinterpret_cast<double*>(midall + ((Nt + 1) & ~1));      // [DP][DP + 1], zeros above the diagonal
+  // evolving ladders: the ladder's inverse temperatures (kept over the steps), the step's gaps and their prefix sums, chunk totals,
+  // per candidate: the log of its accept uniform, the normaliser S and the number of pries BEFORE its trial; per pry: pair and increase
+  double* bwl = psq + (DP == 32 ? DP * (DP + 1) : 0);                     // [Nt]
+  double* spl = bwl + Nt;                                                 // [Nt]
+  double* P0l = spl + Nt;                                                 // [Nt] prefix sums of the step's first gaps (chunk order)
+  const int nchunk = (Nt + 31) / 32;                                      // chunks of 32 gaps (ptmo_chunk_prefix)
+  double* cts = P0l + Nt;                                                 // [nchunk] chunk totals, then the new prefix's offsets | [nchunk] the new normaliser |
+                                                                          // [nchunk + 1] S at the step's start | [nchunk + 2 ..) the first prefix's offsets
+  double* lul = cts + 2 * nchunk + 4;                                     // [ms]
+  double* kSl = lul + ms;                                                 // [ms]
+  double* incl = kSl + ms;                                                // [ms]
+  int* knp = reinterpret_cast<int*>(incl + ms);                           // [ms]
+  int* ipry = knp + ms;                                                   // [ms]
+  int* plist = ipry + ms;                                                 // [ms] surviving picks in pick order
+  int* evi = plist + ms;                                                  // [0] their number, [1] pries of this step
 
   lanes_stage<DP>(p, lds_all);
   for (int i = tid; i < Nt; i += LADDER_THREADS) first[i] = NONE;
@@ -149,7 +171,12 @@ __global__ __launch_bounds__(LADDER_THREADS) void ladder_persistent_kernel(const
   double ll = p.ll[c], lp = p.lp[c];
   int ntries = p.ntries[c], naccept = p.naccept[c], last_type = p.last_type[c];
   unsigned int nhist = p.nhist[c];
-  const double beta = p.beta[rg];
+  double beta = p.beta[rg];   // (evolving ladders: the ladder-major image, refreshed after every step's exchange phase)
+  if (EV) {
+    for (int k = tid; k < Nt; k += LADDER_THREADS) bwl[k] = p.beta_w[(size_t)w * Nt + k];
+    beta = p.beta_w[(size_t)w * Nt + rg];
+  }
+  const double grow = 1.0 + a.evolve_rate;
   const double plo = p.plo[d], phi = p.phi[d];
   // open / `limit` boundaries (boundary::enforce, states.cc:53-55) as a second box: without bounds it holds everything
   const double elo = (p.has_bounds && p.blo[d] == B_LIMIT) ? p.bmin[d] : -__builtin_inf();
@@ -244,6 +271,29 @@ __global__ __launch_bounds__(LADDER_THREADS) void ladder_persistent_kernel(const
     }
     __builtin_amdgcn_wave_barrier();
   };
+  // ptmo_chunk_prefix's two levels, with the operands fetched from LDS BEFORE the chain of dependent adds (a lone lane pays ~100
+  // cycles per dependent LDS read): chunk q of v[0 .. n): P[k] = the sum of the chunk's entries before k, returns the chunk's total ...
+  auto chunk_scan = [&](const double* v, double* P, int q, int n) -> double {
+    double r[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) { const int k = 32 * q + j; r[j] = k < n ? v[k] : 0.0; }
+    double loc = 0.0;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) { const int k = 32 * q + j; if (k < n) P[k] = loc; loc = loc + r[j]; }   // (+ 0.0 behind the end changes nothing)
+    return loc;
+  };
+  // ... and the chunk totals tot[0 .. nq) left to right: off[q] = the sum of the totals before q (may overwrite tot), returns the grand total
+  auto totals_scan = [&](const double* tot, double* off, int nq) -> double {
+    double run = 0.0;
+    for (int q0 = 0; q0 < nq; q0 += 16) {
+      double r[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) r[j] = q0 + j < nq ? tot[q0 + j] : 0.0;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) { if (q0 + j < nq) off[q0 + j] = run; run = run + r[j]; }
+    }
+    return run;
+  };
   int done = 0, nslow = 0;
   bool aborted = false;
   for (int s = 0; s < a.nsteps; ++s) {
@@ -307,10 +357,24 @@ __global__ __launch_bounds__(LADDER_THREADS) void ladder_persistent_kernel(const
     int type = 0, axis = -1, kmix = 0;   // GENX: the step's proposal type code, its one-dimensional move's axis, its mixture member
     double mix_scale = 1.0;
     u32x4 o0 = u32x4{0u, 0u, 0u, 0u}, o = u32x4{0u, 0u, 0u, 0u};
+    bool valid = false;
+    double cur_lpost = 0.0;
+    // the part of MH_chain::step that depends on the rung's temperature (chain.cc:973,980-1001)
+    auto metropolis = [&] {
+      const double bl = beta * ll;
+      cur_lpost = lp + bl;
+      const double oldlprior = cur_lpost - bl;                    // chain.cc:973
+      const bool want_like = valid && (newlprior > -1e200 || newlprior - oldlprior > p.min_prior);   // chain.cc:980 (Q1)
+      newlpost = newlike * beta + newlprior;
+      if (!want_like) newlike = newlpost = -__builtin_inf();
+      const double logH = newlpost - cur_lpost;
+      accept = valid;
+      if (accept && logH < 0) accept = dlog_u01(o0.v0) < logH;    // chain.cc:998-1001 (NaN stays accepted)
+    };
 
     // -- segment A: candidate draws | the chains' random blocks
     if (helper) {   // (all four bookkeeper waves draw; the window's two have asked for the neighbours' flags and look at them afterwards)
-      if (wrole) ask_flags();
+      if (wrole && !EV) ask_flags();
       for (int k = ht; k < ms; k += 256) {
         const u32x4 oc = draw_block(p.seed, TAG_PT, (uint32_t)(w + p.w_off), step, (uint32_t)k);
         int n = -2;
@@ -341,7 +405,24 @@ __global__ __launch_bounds__(LADDER_THREADS) void ladder_persistent_kernel(const
     PTM_LADDER_TICK(2);
 
     // -- segment B: survivor filter | the proposal's offset = factor . z of this lane's rung (gaussian_prop::draw, proposal_distribution.hh:194-218)
-    if (wrole) {
+    if (EV && wrole) {
+      // evolving ladders: every step takes the WHOLE ladder's llikes.  Each of the two window waves waits for every workgroup's flag
+      // itself (a wave's loads are ordered behind its own polls), then the two share the loads
+      {
+        const long long t0 = wall_clock64();
+        bool ok = true;
+        for (int nb = lane; nb < NB && ok; nb += 64)
+          if (nb != b) ok = wait_for(nb, s, t0);
+        if (!ok) { __hip_atomic_store(&a.ctl[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); sflag[1] = 1; }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("" ::: "memory");
+      }
+      const double* pl = a.pub_ll + (size_t)par * p.Nc;
+      for (int r = wt; r < Nt; r += 128) {
+        llall[r] = __hip_atomic_load(pl + (size_t)r * p.W + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        permall[r] = r;
+      }
+    } else if (wrole) {
       // the window, as soon as both neighbours have published (their flags were asked for a segment ago; a wave that finds them
       // down waits for them here)
       if (!flags_up()) {
@@ -398,7 +479,29 @@ __global__ __launch_bounds__(LADDER_THREADS) void ladder_persistent_kernel(const
     PTM_LADDER_TICK(3);
 
     // -- segment C: long runs, the picks' log-uniforms, flags, the window | prior box, likelihood, the Metropolis test
-    if (drole) {
+    if (EV && drole) {
+      // evolving ladders: the log of every surviving pick's accept uniform, the step's gaps (chain.cc:1816) with their prefix sums
+      // in the checker's order (ptmo_chunk_prefix: chunks of 32 left to right, then the chunk totals), the surviving picks in pick order
+      const int nch = (Nt - 1 + 31) / 32;
+      for (int k = ht; k < ms; k += 128)
+        if (alive[k]) lul[k] = dlog_u01(ua[k]);
+      for (int k = ht; k < Nt - 1; k += 128) spl[k] = bwl[k] - bwl[k + 1];
+      replay_sync(7, 2 * (s + 1), true, true);
+      for (int q = ht; q < nch; q += 128) cts[q] = chunk_scan(spl, P0l, q, Nt - 1);
+      replay_sync(4, 2 * (s + 1), true, true);
+      if (ht == 0) cts[nchunk + 1] = totals_scan(cts, cts + nchunk + 2, nch);   // S at the start of the step
+      if (ht < 64) {
+        int cnt = 0;
+        for (int base = 0; base < ms; base += 64) {
+          const int k = base + ht;
+          const bool al = k < ms && alive[k];
+          const unsigned long long m = __builtin_amdgcn_ballot_w64(al);
+          if (al) plist[cnt + __builtin_popcountll(m & ((1ull << ht) - 1ull))] = k;
+          cnt += __builtin_popcountll(m);
+        }
+        if (ht == 0) evi[0] = cnt;
+      }
+    } else if (drole) {
       // a run of more than H surviving picks on consecutive rungs anywhere in the ladder: the halos do not cover this step (every
       // workgroup of the ladder sees the same draws): it takes the whole-ladder form below
       for (int k = ht; k < ms; k += 128) {
@@ -415,7 +518,7 @@ __global__ __launch_bounds__(LADDER_THREADS) void ladder_persistent_kernel(const
         if (PTM_LADDER_ALIVE(n)) wlu[n - wlo] = dlog_u01(ua[first[n]]);
       }
     }
-    if (wrole) {   // the window into LDS
+    if (wrole && !EV) {   // the window into LDS
 #pragma unroll
       for (int q = 0; q < NWR; ++q) {
         const int i = wt + 128 * q;
@@ -426,16 +529,12 @@ __global__ __launch_bounds__(LADDER_THREADS) void ladder_persistent_kernel(const
     }
     if (!helper) {
       xn = xd + off;                                              // state::add (states.cc:205-214)
-      const double bl = beta * ll;
-      const double cur_lpost = lp + bl;
-      const double oldlprior = cur_lpost - bl;                    // chain.cc:973
       const bool ind = !(xn < plo) && !(xn > phi);
       const bool in = all_of_chain(ind);
       // Q9: state::add builds on an enforced zero state -- an origin outside a `limit` bound invalidates every proposal
-      const bool valid = p.origin_valid != 0 && all_of_chain(!(xn < elo) && !(xn > ehi));   // stateSpace::enforce, states.cc:86-102
+      valid = p.origin_valid != 0 && all_of_chain(!(xn < elo) && !(xn > ehi));   // stateSpace::enforce, states.cc:86-102
       newlprior = in ? p.lprior_const : -__builtin_inf();
       if (!valid) newlprior = -__builtin_inf();
-      const bool want_like = valid && (newlprior > -1e200 || newlprior - oldlprior > p.min_prior);   // chain.cc:980 (Q1)
       vbuf[g * DP + d] = xn;
       sync_wave();
       {
@@ -460,11 +559,7 @@ __global__ __launch_bounds__(LADDER_THREADS) void ladder_persistent_kernel(const
       const double quad = ((pbuf[g * 4 + 0] + pbuf[g * 4 + 1]) + pbuf[g * 4 + 2]) + pbuf[g * 4 + 3];
       sync_wave();   // (vbuf / pbuf are rewritten by the next step's draw)
       newlike = p.like0 - 0.5 * quad;
-      newlpost = newlike * beta + newlprior;
-      if (!want_like) newlike = newlpost = -__builtin_inf();
-      const double logH = newlpost - cur_lpost;
-      accept = valid;
-      if (accept && logH < 0) accept = dlog_u01(o0.v0) < logH;    // chain.cc:998-1001 (NaN stays accepted)
+      if (!EV) metropolis();   // (an evolving ladder's test waits for the temperature this step's exchange phase leaves the rung with)
     }
     __syncthreads();
     if (sflag[1]) { aborted = true; break; }
@@ -473,6 +568,148 @@ __global__ __launch_bounds__(LADDER_THREADS) void ladder_persistent_kernel(const
     // 1531-1534,1553-1557): known from the draws alone
     const int tc = helper ? 0 : (PTM_LADDER_ALIVE(rg) ? 1 : 0) + (PTM_LADDER_ALIVE(rg - 1) ? 1 : 0);
     const unsigned int nh0 = nhist;   // add_state calls before this step's
+    const double beta_old = beta;     // (evolving ladders: the rung's temperature before this step's pries)
+    if (EV) {
+      // ---- the exchange phase of an evolving ladder.  The trials are one chain only through the normaliser S, and S moves by
+      //      rate x (the pried gaps) -- a relative 1e-3 over a step.  lu * S is monotone in S: a trial that gives the same answer by
+      //      the first-trial form (nothing pried yet: no S) and by the pried form at BOTH ends of [S0, S0 + every increase a surviving
+      //      pick could add] gives that answer whatever came before it.  So every run of surviving picks is walked by its own lane,
+      //      top-down as on a fixed ladder; a step with a trial INSIDE that window (one in fifty at 1024 rungs) is walked in pick
+      //      order by one lane instead -- the checker's swap_phase operation for operation.  Then the pries, in pick order.
+      const double c1 = 1 - bwl[Nt - 1];                           // chain.cc:1833
+      const double S0 = cts[nchunk + 1];
+      const int np = evi[0];
+      // the largest S any order of acceptances could reach: S0 + the increases of ALL surviving picks (+ a margin for the roundings)
+      {
+        double v = 0.0;
+        for (int t = tid; t < np; t += LADDER_THREADS) { const double gq = spl[cand[plist[t]]]; v += gq * grow - gq; }
+#pragma unroll
+        for (int o_ = 32; o_ > 0; o_ >>= 1) v += __shfl_down(v, o_);
+        if (lane == 0) kSl[tid >> 6] = v;                          // (kSl is filled only after the decisions: its first 8 entries serve as scratch)
+      }
+      if (tid == 0) { evi[2] = 0; }
+      __syncthreads();
+      double Shi = S0;
+      for (int q = 0; q < LADDER_THREADS / 64; ++q) Shi += kSl[q];
+      Shi = Shi * (1.0 + 1e-9);
+      __syncthreads();
+      // decisions, a lane per run (no side effects yet): accb[k]
+      unsigned char* accb = reinterpret_cast<unsigned char*>(evi + 8);   // [ms]
+      auto decide3 = [&](int k, double lla, double llb, bool& acc) -> bool {   // false: the answer depends on what was pried before
+        const int i = cand[k];
+        const double gq = spl[i], dl = llb - lla, lu = lul[k];
+        const double logH = gq * dl;                                // chain.cc:1463 with the stored temperatures' difference
+        const bool a0 = logH < 0 ? lu < logH : true;
+        const double tt = (gq * c1) * dl;
+        const bool a1 = tt < 0 ? lu * S0 < tt : true;
+        const bool a2 = tt < 0 ? lu * Shi < tt : true;
+        acc = a0;
+        return a0 == a1 && a1 == a2;
+      };
+      for (int k = tid; k < ms; k += LADDER_THREADS) {
+        const int n = cand[k];
+        if (n < 0 || !alive[k] || PTM_LADDER_ALIVE(n + 1)) continue;   // tops of runs of surviving picks
+        double up = llall[n + 1];                                   // the upper rung's llike as the pick sees it
+        for (int i = n; i >= 0; --i) {
+          const int kk = first[i];
+          double lla = llall[i];
+          if (!(lla > -1e200)) lla = -1e200;
+          double llb = up;
+          if (!(llb > -1e200)) llb = -1e200;
+          bool acc;
+          if (!decide3(kk, lla, llb, acc)) evi[2] = 1;
+          accb[kk] = acc ? 1 : 0;
+          up = acc ? up : llall[i];                                 // what rung i holds after the trial: the next pick's upper rung
+          if (!PTM_LADDER_ALIVE(i - 1)) break;
+        }
+      }
+      __syncthreads();
+      if (evi[2]) {
+        // the rare step: in pick order, one lane (llall is exchanged as the picks are decided)
+        if (tid == 256) {
+          double S = S0;
+          int npry = 0;
+          for (int t = 0; t < np; ++t) {
+            const int k = plist[t], i = cand[k];
+            double lla = llall[i];
+            if (!(lla > -1e200)) lla = -1e200;
+            double llb = llall[i + 1];
+            if (!(llb > -1e200)) llb = -1e200;
+            bool acc = true;
+            if (npry) {
+              const double tt = (spl[i] * c1) * (llb - lla);
+              if (tt < 0) acc = lul[k] * S < tt;
+            } else {
+              const double logH = spl[i] * (llb - lla);
+              if (logH < 0) acc = lul[k] < logH;
+            }
+            accb[k] = acc ? 1 : 0;
+            if (acc) {
+              const double tl = llall[i]; llall[i] = llall[i + 1]; llall[i + 1] = tl;
+              S = S + (spl[i] * grow - spl[i]);                     // (spl itself is pried below, with everybody's)
+              npry++;
+            }
+          }
+        }
+        __syncthreads();
+      }
+      // the exchanges applied, a lane per run: the row map, the in-between rows, the own pairs' counters and log lines
+      for (int k = tid; k < ms; k += LADDER_THREADS) {
+        const int n = cand[k];
+        if (n < 0 || !alive[k] || PTM_LADDER_ALIVE(n + 1)) continue;
+        for (int i = n; i >= 0; --i) {
+          const int kk = first[i];
+          const bool acc = accb[kk] != 0;
+          if (acc) { const int q = permall[i]; permall[i] = permall[i + 1]; permall[i + 1] = q; }
+          if (HIST && PTM_LADDER_ALIVE(i - 1)) midall[i] = permall[i];
+          if (i >= r0 && i < r1) {
+            ptry[i - r0] += 1;
+            if (acc) pacc[i - r0] += 1;
+            if (last_step) a.swap_log[(size_t)w * ms + kk] = i | (acc ? 0x40000000 : 0);
+          }
+          if (!PTM_LADDER_ALIVE(i - 1)) break;
+        }
+      }
+      // the pries in pick order (chain.cc:1829): pair and increase of the q-th accepted pick; per pick the number of pries before it
+      if (tid < 64) {
+        int cnt = 0;
+        for (int base = 0; base < np; base += 64) {
+          const int t = base + tid;
+          const int k = t < np ? plist[t] : 0;
+          const bool ac = t < np && accb[k] != 0;
+          const unsigned long long m = __builtin_amdgcn_ballot_w64(ac);
+          const int q = cnt + __builtin_popcountll(m & ((1ull << tid) - 1ull));
+          if (t < np) knp[k] = q;
+          if (ac) {
+            const int i = cand[k];
+            const double gq = spl[i], sn = gq * grow;
+            ipry[q] = i; incl[q] = sn - gq; spl[i] = sn;
+          }
+          cnt += __builtin_popcountll(m);
+        }
+        if (tid == 0) evi[1] = cnt;
+      }
+      __syncthreads();
+      if (HIST && tid == 256) {   // the normaliser after each pry, summed in pick order (kSl[q]: after pry q): what the in-phase temperatures need
+        double S = S0;
+        const int nq = evi[1];
+        for (int q = 0; q < nq; ++q) { S = S + incl[q]; kSl[q] = S; }
+      }
+      PTM_LADDER_TICK(5);
+      if (evi[1] > 0) {   // the new temperatures (chain.cc:1834-1844): beta_k = 1 - P_k / (total / (1 - beta_last)), P in the checker's order
+        const int nch = (Nt - 1 + 31) / 32;
+        double* Pn = llall;   // (the llike view is done with)
+        for (int q = tid; q < nch; q += LADDER_THREADS) cts[q] = chunk_scan(spl, Pn, q, Nt - 1);
+        __syncthreads();
+        if (tid == 0) cts[nchunk] = totals_scan(cts, cts, nch) / (1 - bwl[Nt - 1]);
+        __syncthreads();
+        const double nn = cts[nchunk];
+        for (int k = 1 + tid; k < Nt - 1; k += LADDER_THREADS) bwl[k] = 1 - (cts[k >> 5] + Pn[k]) / nn;
+        __syncthreads();
+        beta = bwl[rg];
+      }
+      if (!helper) metropolis();
+    }
     if (!helper) {
       if (!tc) {
         ntries += 1;
@@ -490,9 +727,11 @@ __global__ __launch_bounds__(LADDER_THREADS) void ladder_persistent_kernel(const
           }
           int mapw = 0;
           if (map_on && lead && live && accept) mapw = map_try(p.map, c, newlpost, newlike, newlprior) ? 1 : 0;   // chain.cc:931-934
+          // an evolving ladder: the state that stays is added at a NEW temperature and may beat the MAP with it
+          else if (EV && map_on && lead && live) mapw = map_try(p.map, c, cur_lpost, ll, lp) ? 2 : 0;
           if (map_on) {
             mapw = from_lead(mapw);
-            if (mapw && live) p.map.x[(size_t)c * DP + pos] = xn;
+            if (mapw && live) p.map.x[(size_t)c * DP + pos] = mapw == 1 ? xn : xd;
           }
         }
         if (accept) { xd = xn; ll = newlike; lp = newlprior; naccept += 1; last_type = GENX ? type : 0; }
@@ -500,17 +739,33 @@ __global__ __launch_bounds__(LADDER_THREADS) void ladder_persistent_kernel(const
     }
     // the add_state calls of a rung the exchange phase touched (one per attempt; the rung makes no Metropolis move): history and MAP
     // see the row the rung holds at each call -- the in-between row `mid` at the first of two (its scalars, the rung's own counters)
+    // (evolving ladders: each add sees the temperature its rung had THEN -- before the pick's own pry, after the earlier ones:
+    //  1 - (P0 + D) / normaliser with P0 the prefix sum of the step's first gaps, D what the earlier pries added to the gaps below the
+    //  rung, in pick order; the ladder's ends never move.  The checker's swap_phase, chain.cc:1487-1490,1531-1534)
+    auto beta_at = [&](int k) -> double {
+      if (!EV) return beta;
+      const int np_ = knp[k];
+      if (np_ == 0 || rg == 0 || rg == Nt - 1) return beta_old;
+      double Dr = 0.0;
+      for (int q = 0; q < np_; ++q)
+        if (ipry[q] < rg) Dr = Dr + incl[q];
+      const double nrm = kSl[np_ - 1] / (1 - bwl[Nt - 1]);   // S after the pries before this pick
+      return 1 - ((cts[nchunk + 2 + (rg >> 5)] + P0l[rg]) + Dr) / nrm;
+    };
     auto exchanged_adds = [&](double xmid, double llmid, double lpmid) {
       if (!HIST || !tc) return;
+      // the pick on the pair above comes first in pick order whenever both survive (chain.cc:1417-1418)
+      const double bmid = tc == 2 ? beta_at(first[rg]) : 0.0;
+      const double beta = beta_at(PTM_LADDER_ALIVE(rg - 1) ? first[rg - 1] : first[rg]);   // (shadows the chain's: the LAST add's temperature)
       if (tc == 2) {
         if (hist_on && nh0 % every == 0u) {
           const long long hrow = 1 + (long long)(nh0 / every);
           const size_t o = hist_slot(p.hist, hrow, c);
           if (live) p.hist.x[o * DP + pos] = xmid;
-          if (live && lead) hist_scalars(p.hist, o, hrow, llmid, lpmid, naccept, ntries, last_type, beta);
+          if (live && lead) hist_scalars(p.hist, o, hrow, llmid, lpmid, naccept, ntries, last_type, EV ? bmid : beta);
         }
         int mw = 0;
-        if (map_on && lead && live) { const double tb = beta * llmid; mw = map_try(p.map, c, lpmid + tb, llmid, lpmid) ? 1 : 0; }
+        if (map_on && lead && live) { const double tb = (EV ? bmid : beta) * llmid; mw = map_try(p.map, c, lpmid + tb, llmid, lpmid) ? 1 : 0; }
         if (map_on) {
           mw = from_lead(mw);
           if (mw && live) p.map.x[(size_t)c * DP + pos] = xmid;
@@ -531,7 +786,32 @@ __global__ __launch_bounds__(LADDER_THREADS) void ladder_persistent_kernel(const
       }
     };
 
-    if (!sflag[0]) {
+    if (EV) {
+      // ---- 4''. evolving ladders: the walk above has decided every pick of the ladder; the rows of the own rungs come from wherever
+      //      the exchanges took them (the whole ladder's publications of this step; nobody can overwrite them before this workgroup
+      //      has published its next step)
+      if (tc) {
+        const double* pl = a.pub_ll + (size_t)par * p.Nc;
+        const int src = permall[rg];
+        if (src != rg) {
+          const size_t cs = (size_t)src * p.W + w;
+          xd = __hip_atomic_load(a.pub_x + par * NcDP + cs * DP + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ll = __hip_atomic_load(pl + cs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          lp = __hip_atomic_load(a.pub_lp + (size_t)par * p.Nc + cs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (HIST) {
+          double xm = xd, lm = ll, pm_ = lp;
+          if (tc == 2) {
+            const size_t cm = (size_t)midall[rg] * p.W + w;
+            xm = __hip_atomic_load(a.pub_x + par * NcDP + cm * DP + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            lm = __hip_atomic_load(pl + cm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            pm_ = __hip_atomic_load(a.pub_lp + (size_t)par * p.Nc + cm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          exchanged_adds(xm, lm, pm_);
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else if (!sflag[0]) {
       // ---- 4. the exchange phase from the neighbours' publications
       // trials (chain.cc:1436-1537): the top pick of each run of surviving picks inside the window walks it downwards
       if (helper && ht < WN - 1) {
@@ -662,6 +942,8 @@ __global__ __launch_bounds__(LADDER_THREADS) void ladder_persistent_kernel(const
       p.ntries[c] = ntries; p.naccept[c] = naccept; p.last_type[c] = last_type; p.nhist[c] = nhist;
     }
   }
+  if (EV && commit && b == 0)   // the ladder's temperatures (the chain-indexed image is brought up to date by the host when somebody asks for it)
+    for (int k = tid; k < Nt; k += LADDER_THREADS) const_cast<double*>(p.beta_w)[(size_t)w * Nt + k] = bwl[k];
   if (commit && tid < R && r0 + tid < Nt - 1 && r0 + tid < r1) {
     long long* sc = a.swap_cnt + ((size_t)w * (Nt - 1) + (r0 + tid)) * 2;
     sc[0] += ptry[tid];

@@ -38,7 +38,7 @@ PTM_DECL_FUSED(16)
 // long ladders of few walkers: many PT steps per launch on a grid of resident workgroups (ptm_ladder_kernel.hpp; DP 16 and 32).
 // ladder_blocks_N: how many of its workgroups the device holds at once (0: the kernel cannot run); launch_ladder_N: the launch
 #define PTM_DECL_LADDER(N)                                  \
-  size_t ladder_lds_##N(int Nt, int ms);                    \
+  size_t ladder_lds_##N(int Nt, int ms, bool ev);           \
   int ladder_blocks_##N(bool diag, int fl, size_t lds);     \
   hipError_t launch_ladder_##N(const Dev& p, const LadderArgs& a, bool diag, int fl, int grid, size_t lds, hipStream_t st);
 PTM_DECL_LADDER(16)

@@ -23,6 +23,7 @@ if __name__ == "__main__":
     D, Nt, W, nsteps, halo = (int(v) for v in sys.argv[1:6])
     sr, out = float(sys.argv[6]), sys.argv[7]
     evolve = float(sys.argv[8]) if len(sys.argv) > 8 else 0.0
+    hist_every = int(sys.argv[9]) if len(sys.argv) > 9 else 0      # > 0: record the history (every hist_every-th add) and the MAP of the shard's rungs
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     os.environ["PTM_BENCH_REHEARSAL"] = "1"
     dev = torch.device("cuda", 0)
@@ -36,7 +37,10 @@ if __name__ == "__main__":
     ref.close()
     r0, n = shard_bounds(Nt, world, rank)
     stream = torch.cuda.Stream(device=dev)
-    eng = E.Engine(D, Nt, W, swap_rate=sr, rung_begin=r0, rung_count=n, stream=stream.cuda_stream)
+    # (a shard below the ladder's top cannot record its top rung: its in-between row may be the neighbour's)
+    hr = 0 if not hist_every else (n if rank == world - 1 else n - 1)
+    eng = E.Engine(D, Nt, W, swap_rate=sr, rung_begin=r0, rung_count=n, stream=stream.cuda_stream, add_every_n=max(1, hist_every),
+                   history_rungs=hr, history_capacity=(2 * nsteps // max(1, hist_every) + 8) if hr else 0, map_rungs=hr)
     pr.configure(eng, E.PROP_LOWER)
     if evolve > 0:
         eng.set_evolve_temps(evolve)      # evolving ladders: ShardedLadder.step_gathered (an all-gather of the llikes per step)
@@ -48,7 +52,11 @@ if __name__ == "__main__":
     lad.drain()
     eng.sync()
     t, a = eng.swap_counts()
-    np.savez(out % rank, x=eng.states(), ll=eng.llike, nacc=eng.naccept, nhist=eng.nhist, st=t, sa=a, invtemps=eng.invtemps(), recovered=lad.recovered)
+    extra = {}
+    if hr:
+        h, m = eng.history(), eng.map()
+        extra = dict(hist_rungs=hr, **{"h_" + k: v for k, v in h.items()}, **{"m_" + k: v for k, v in m.items()})
+    np.savez(out % rank, x=eng.states(), ll=eng.llike, nacc=eng.naccept, nhist=eng.nhist, st=t, sa=a, invtemps=eng.invtemps(), recovered=lad.recovered, **extra)
     dist.barrier()
     eng.close()
     dist.destroy_process_group()

@@ -643,9 +643,8 @@ def test_evolving_ladders_checkpoint_resume_and_refusals():
     d.close()
     s = E.Engine(D, Nt, W, swap_rate=0.4, rung_begin=0, rung_count=4, history_rungs=2, history_capacity=8)
     s.set_ladder(pr.beta)
-    with pytest.raises(E.PtmError, match="history"):
-        s.set_evolve_temps(0.01)         # a shard of the ladder that records a history: not built (plain shards evolve:
-    s.close()                            #  test_evolving_ladders_on_rung_shards_match_the_single_engine)
+    s.set_evolve_temps(0.01)             # a shard of the ladder that records a history evolves too since round 4
+    s.close()                            #  (tests/test_gpu_sharding.py::test_evolving_sharded_ladder_records_history_and_map_like_one_engine)
 
 
 def test_bounds_and_mixed_prior_path_bit_exact():
@@ -1488,6 +1487,56 @@ def test_persistent_ladder_kernel_matches_the_oracle(D, Nt, W, kind, sr):
     PU.assert_same_state(eng, lad, "after plain sweeps")
     eng.step(5); eng.sync(); lad.pt_step(5)
     PU.assert_same_state(eng, lad, "after PT steps again")
+    eng.close()
+
+
+LADDER_EVOLVING = [
+    # D, Nt, W, kind, swap_rate, evolve rate, gauss_1d_frac, mixture members K, add_every_N (0: no history / MAP)
+    (32, 1024, 1, E.PROP_LOWER, 0.1, 0.01, 0.0, 0, 0),      # the reference's own shape with the sampler's default ladder (ptmcmc.cc:389,512)
+    (32, 1024, 1, E.PROP_LOWER, 0.1, 0.01, 0.5, 4, 2),      # ... and everything else the sampler switches on: recipe, history, MAP
+    (32, 100, 2, E.PROP_DENSE, 0.3, 0.03, 0.0, 0, 0),       # ragged last workgroup, many pries per step
+    (16, 70, 3, E.PROP_DIAG, 0.3, 0.02, 0.3, 2, 1),         # 16 rungs per workgroup, every add saved: every in-between row with its own temperature
+    (20, 37, 1, E.PROP_DENSE, 0.45, 0.05, 0.0, 0, 1),       # history alone
+    (32, 8, 5, E.PROP_LOWER, 0.35, 0.02, 0.4, 3, 3),        # one workgroup per ladder
+    (32, 1500, 1, E.PROP_DIAG, 0.1, 0.01, 0.0, 0, 0),       # more than 1024 rungs: 47 chunks of gaps
+]
+
+
+@pytest.mark.parametrize("D,Nt,W,kind,sr,rate,odf,K,N", LADDER_EVOLVING)
+def test_persistent_ladder_kernel_with_evolving_ladders(D, Nt, W, kind, sr, rate, odf, K, N):
+    """parallel_tempering_chains::evolve_temps (the reference sampler's default: pry_temps after every accepted exchange,
+    chain.cc:1501-1518,1809-1846) inside the persistent ladder kernel: every workgroup replays every trial of the ladder in pick order
+    from the whole ladder's published llikes and keeps the ladder's temperatures; the Metropolis tests take the step's new
+    temperatures.  States, counters, the temperatures themselves, and -- in the build with everything -- every saved row with the
+    temperature it was saved at and every rung's MAP: bit for bit the oracle's."""
+    pr, eng, lad = _ladder_flavour_pair(D, Nt, W, kind, sr, odf, K, N)
+    eng.set_evolve_temps(rate); lad.evolve_temps(rate)
+    fl = 7 if (odf > 0 or K > 0 or N) else 4
+    want = "ladder_persistent_kernel<%d, %d, %d>" % (16 if D <= 16 else 32, 1 if kind == E.PROP_DIAG else 0, fl)
+    assert eng.step_kernel_name == want, (eng.step_kernel_name, want)
+    done = 0
+    for n in (1, 1, 2, 30):
+        eng.step(n); eng.sync(); lad.pt_step(n)
+        done += n
+        PU.assert_same_state(eng, lad, "after %d PT steps" % done)
+        assert np.array_equal(eng.invtemps(), lad.betaw), "temperatures differ after %d steps" % done
+        if N:
+            _assert_same_history_and_map(eng, lad)
+            he, ho = eng.history(), lad.history()
+            nsize = eng.nsize
+            for s_ in range(int(nsize.max())):
+                have = nsize > s_
+                assert np.array_equal(he["invtemp"][s_ % 64][have], PU.to_engine_order(ho["invtemp"][:, s_], Nt, W)[have]), ("invtemp", s_)
+    assert not np.array_equal(eng.invtemps()[0], pr.beta)
+    t, a = eng.swap_counts()
+    assert np.array_equal(t, lad.swap_count) and np.array_equal(a, lad.swap_accept_count)
+    pairs, acc = eng.last_swaps()
+    assert np.array_equal(pairs, lad.last_pairs) and np.array_equal(acc, lad.last_accept)
+    # the two-launch path takes over the ladders the kernel left (temperatures, their chain-indexed image)
+    eng.sweep(2); eng.sync(); lad.sweep(2)
+    PU.assert_same_state(eng, lad, "after plain sweeps")
+    st = eng.ladder_stats()
+    assert st["launches"] == 4 and st["fallbacks"] == 0, st
     eng.close()
 
 

@@ -122,6 +122,62 @@ def test_sharded_ladder_between_processes_on_the_gpu(world, D, Nt, W, halo, sr, 
     ref.close()
 
 
+@pytest.mark.parametrize("world,D,Nt,W,sr,evolve,every,nsteps", [(2, 6, 20, 1, 0.1, 0.01, 40, 400),     # the reference's MPI regression: 20 rungs over 2 ranks, evolving, one ladder
+                                                                 (2, 6, 20, 3, 0.4, 0.02, 3, 60), (3, 32, 25, 64, 0.3, 0.01, 2, 30)])
+def test_evolving_sharded_ladder_records_history_and_map_like_one_engine(world, D, Nt, W, sr, evolve, every, nsteps):
+    """History and MAP tracking of an EVOLVING ladder on rung shards -- the reference's own multi-rank regression is that shape:
+    20 rungs over 2 ranks with --pt_evolve_rate=0.01, the cold chain's file compared with the 1-rank file
+    (test/exampleLISA/Makefile:7,29-31; the rows MH_chain::add_state saves, chain.cc:935-946, gathered :1905-1972).  Every shard
+    replays every pick of the ladder and so knows the temperature each of its rungs had at each add_state of the exchange phase:
+    the rows each rank recorded -- states, llikes, lpriors, counters, the temperatures they were saved at, in-between rows of rungs
+    exchanged twice included -- and its rungs' MAPs are, bit for bit, those of one engine holding the whole ladder."""
+    import socket
+    import tempfile
+    from ptmcmc_amd.parallel import shard_bounds
+    s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]; s_.close()
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "rank%d.npz")
+        procs = []
+        for r in range(world):
+            env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+            procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "gpu_dist_worker.py"), str(D), str(Nt), str(W), str(nsteps),
+                                           "4", str(sr), out, str(evolve), str(every)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+        res = [p.communicate(timeout=900) for p in procs]
+        assert all(p.returncode == 0 for p in procs), [r[1][-1500:] for r in res]
+        parts = [dict(np.load(out % r)) for r in range(world)]
+    pr = GaussianProblem(D, Nt, 1e6)
+    cap = 2 * nsteps // every + 8
+    ref = E.Engine(D, Nt, W, swap_rate=sr, add_every_n=every, history_rungs=Nt, history_capacity=cap, map_rungs=Nt)
+    pr.configure(ref, E.PROP_LOWER)
+    ref.set_evolve_temps(evolve)
+    ref.init_from_prior()
+    ref.step(nsteps); ref.sync()
+    assert np.array_equal(np.concatenate([p["x"] for p in parts]), ref.states())
+    assert np.array_equal(np.concatenate([p["nhist"] for p in parts]), ref.nhist)
+    assert not np.array_equal(ref.invtemps()[0], pr.beta)
+    hr_, mr = ref.history(), ref.map()
+    nsize = ref.nsize.reshape(Nt, W)
+    rows_checked = double_adds = 0
+    for g, p in enumerate(parts):
+        r0, n = shard_bounds(Nt, world, g)
+        hr = int(p["hist_rungs"])
+        assert hr == (n if g == world - 1 else n - 1)
+        sel = slice(r0 * W, (r0 + hr) * W)
+        for name in ("x", "llike", "lprior", "naccept", "ntries", "last_type", "invtemp", "row"):
+            a, b = p["h_" + name], hr_[name][:, sel]
+            for s_ in range(int(nsize[r0:r0 + hr].max())):
+                have = (nsize[r0:r0 + hr] > s_).ravel()
+                assert np.array_equal(a[s_ % cap][have], b[s_ % cap][have]), (g, name, s_)
+                rows_checked += int(have.sum()) if name == "x" else 0
+        for name in ("x", "lpost", "llike", "lprior"):
+            assert np.array_equal(p["m_" + name], mr[name][sel]), (g, name)
+        double_adds += int((ref.nhist.reshape(Nt, W)[r0:r0 + hr] > nsteps).sum())
+    assert rows_checked > world * W and (every > 3 or double_adds > 0)
+    # the temperatures saved with the rows are not the common ladder's: the rows of the exchange phases were saved between two pries
+    assert (np.abs(hr_["invtemp"][1:int(nsize.min())] - np.repeat(pr.beta, W)) > 0).any()
+    ref.close()
+
+
 def test_bench_distributed_path_with_one_rank():
     """bench.py --force-dist: init_process_group("nccl"), the engine on an explicit torch stream, EngineShard on torch
     tensors, the all_reduces of the record -- the N > 1 code path with world size 1"""

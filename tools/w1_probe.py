@@ -24,7 +24,7 @@ for D, Nt, W, tmax in ((32, 1024, 1, 1e9), (32, 256, 4, 1e6), (16, 64, 1, 1e4)):
 # the same ladder with what the reference sampler switches on by default (ptmcmc.cc:117-139,601-616): a 4-member scale mixture with
 # one-dimensional moves, the cold rungs' history (every 100th add saved) and MAP tracking on every rung
 import numpy as np
-for what in ("recipe", "history", "recipe + history"):
+for what in ("recipe", "history", "recipe + history", "evolving", "recipe + history + evolving"):
     D, Nt, W = 32, 1024, 1
     pr = GaussianProblem(D, Nt, 1e9)
     hist = "history" in what
@@ -34,6 +34,8 @@ for what in ("recipe", "history", "recipe + history"):
         K = 4
         sh = np.cumsum([2.0 ** (k + 1) for k in range(K)]); sh /= sh[-1]
         e.set_proposal_mixture(np.tile(sh, (Nt, 1)), np.tile([2.0 ** -k for k in range(K)], (Nt, 1)), np.full((Nt, K), 0.5))
+    if "evolving" in what:
+        e.set_evolve_temps(0.01)
     e.init_from_prior()
     e.step(200); e.sync()
     best = 1e9
