@@ -1709,13 +1709,14 @@ static int ladder_steps(ptm_engine* e, int n) {
   if (!e->pub_x) {
     // what the workgroups publish for each other: fine-grained device memory where the runtime has it (a little faster across
     // XCDs: tools/probes/flag_pingpong_probe.hip), else ordinary -- the accesses are agent-scope atomics either way
-    const size_t doubles = 2 * Nc * e->DP + 4 * Nc;
+    const size_t doubles = 2 * Nc * e->DP + 4 * Nc + 4 * Nc + 2;   // rows | llikes | lpriors | stamped llikes (16-byte aligned)
     void* buf = nullptr;
     if (hipExtMallocWithFlags(&buf, doubles * sizeof(double), hipDeviceMallocFinegrained) != hipSuccess) {
       (void)hipGetLastError();
       HIPCHK(hipMalloc(&buf, doubles * sizeof(double)));
     }
     e->pub_x = (double*)buf; e->pub_ll = e->pub_x + 2 * Nc * e->DP; e->pub_lp = e->pub_ll + 2 * Nc;
+    HIPCHK(hipMemsetAsync(e->pub_lp + 2 * Nc, 0, (4 * Nc + 2) * sizeof(double), e->stream));   // (no stale word may look like a stamp)
     void* fl_ = nullptr;
     const size_t flbytes = ((size_t)grid + 16 + (size_t)e->W) * sizeof(int);
     if (hipExtMallocWithFlags(&fl_, flbytes, hipDeviceMallocFinegrained) != hipSuccess) {
@@ -1734,7 +1735,7 @@ static int ladder_steps(ptm_engine* e, int n) {
     Dev p = make_dev(e);
     LadderArgs a;
     a.nsteps = k; a.NB = NB; a.ms = e->ms; a.thresh = e->thresh;
-    a.pub_x = e->pub_x; a.pub_ll = e->pub_ll; a.pub_lp = e->pub_lp; a.flags = e->lad_flags; a.ctl = e->lad_ctl; a.slow_done = e->lad_ctl + 16;
+    a.pub_x = e->pub_x; a.pub_ll = e->pub_ll; a.pub_lp = e->pub_lp; a.pub_s = e->pub_lp + 2 * (size_t)e->Nc + ((2 * (size_t)e->Nc * e->DP) & 1); a.flags = e->lad_flags; a.ctl = e->lad_ctl; a.slow_done = e->lad_ctl + 16;
     a.swap_cnt = e->swap_cnt; a.swap_log = e->swap_log + (size_t)e->log_head * e->W * e->ms;
     a.max_run = max_run;
     a.prof = e->lad_prof;

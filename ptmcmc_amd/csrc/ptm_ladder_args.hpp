@@ -16,6 +16,7 @@ struct LadderArgs {
   double* pub_x;        // [2][Nc][DP]  published rows (dimension d at d), by step parity
   double* pub_ll;       // [2][Nc]
   double* pub_lp;       // [2][Nc]
+  double* pub_s;        // [2][Nc][2]   evolving ladders: {llike, stamp} in one 16-byte word (stamp = launch number x 2^24 + step + 1)
   int* flags;           // [W * NB]  steps published by each workgroup since the launch began
   int* ctl;             // [0] abort (a neighbour never showed up), [1] steps done (set by workgroup 0), [2] whole-ladder steps taken,
                         // [3] workgroups that have finished all their steps | LADDER_ABORT_BIT (the all-or-nothing word)
