@@ -1853,6 +1853,7 @@ extern "C" int ptm_llike_device_ptr(ptm_engine* e, void** p) {
 
 extern "C" int ptm_exchange_decide(ptm_engine* e, const void* ll_below, const void* ll_above, int halo_rungs, void* send_up,
                                    void* send_down) {
+  SETTLE(e);
   NO_BATCH(e, "ptm_exchange_decide");
   int rc = ready(e);
   if (rc) return rc;
@@ -1869,6 +1870,7 @@ extern "C" int ptm_exchange_decide(ptm_engine* e, const void* ll_below, const vo
 }
 
 extern "C" int ptm_exchange_decide_gathered(ptm_engine* e, const void* ll_all, const void* lp_all, void* send_up, void* send_down) {
+  SETTLE(e);
   NO_BATCH(e, "ptm_exchange_decide_gathered");
   int rc = ready(e);
   if (rc) return rc;
@@ -1883,6 +1885,7 @@ extern "C" int ptm_exchange_decide_gathered(ptm_engine* e, const void* ll_all, c
 }
 
 extern "C" int ptm_set_shard_map(ptm_engine* e, int n_shards, const int32_t* rung_counts, int halo_rungs) {
+  SETTLE(e);
   NO_BATCH(e, "ptm_set_shard_map");
   if (!e || !rung_counts || n_shards < 1 || halo_rungs < 1) return fail(PTM_ERR_INVALID, "bad argument");
   std::vector<int> ends(n_shards);
@@ -1906,6 +1909,7 @@ extern "C" int ptm_set_shard_map(ptm_engine* e, int n_shards, const int32_t* run
 }
 
 extern "C" int ptm_exchange_redo_count(ptm_engine* e, int* n) {
+  SETTLE(e);
   if (!e || !n) return fail(PTM_ERR_INVALID, "null argument");
   *n = 0;
   if (!e->redo_flag) return PTM_OK;
@@ -1915,6 +1919,7 @@ extern "C" int ptm_exchange_redo_count(ptm_engine* e, int* n) {
 }
 
 extern "C" int ptm_exchange_redo(ptm_engine* e, const void* ll_all, const void* lp_all, void* send_up, void* send_down) {
+  SETTLE(e);
   NO_BATCH(e, "ptm_exchange_redo");
   int rc = ready(e);
   if (rc) return rc;
@@ -1966,6 +1971,7 @@ extern "C" int ptm_dev_copy(void* dst, const void* src, size_t bytes) {
 }
 
 extern "C" int ptm_exchange_install(ptm_engine* e, const void* recv_below, const void* recv_above) {
+  SETTLE(e);
   NO_BATCH(e, "ptm_exchange_install");
   int rc = ready(e);
   if (rc) return rc;
@@ -1974,6 +1980,7 @@ extern "C" int ptm_exchange_install(ptm_engine* e, const void* recv_below, const
   return launch_install(e, first ? nullptr : (const double*)recv_below, last ? nullptr : (const double*)recv_above);
 }
 extern "C" int ptm_sweep_rungs(ptm_engine* e, int first_local_rung, int n_rungs, int closes_step) {
+  SETTLE(e);
   NO_BATCH(e, "ptm_sweep_rungs");
   int rc = ready(e);
   if (rc) return rc;
@@ -1984,6 +1991,7 @@ extern "C" int ptm_exchange_buffer_doubles(ptm_engine* e) { return e ? MSG_HDR +
 extern "C" int ptm_exchange_row_capacity(ptm_engine* e) { return e ? e->row_cap : 0; }
 
 extern "C" int ptm_exchange_finish_and_sweep(ptm_engine* e, const void* recv_below, const void* recv_above) {
+  SETTLE(e);
   NO_BATCH(e, "ptm_exchange_finish_and_sweep");
   int rc = ready(e);
   if (rc) return rc;
@@ -2031,6 +2039,7 @@ extern "C" int ptm_shard_finalize(ptm_engine* e) {
 }
 
 extern "C" int ptm_shard_init(ptm_engine* e, const void* id, int rank, int world, const int32_t* rung_counts, int halo_rungs) {
+  SETTLE(e);
   if (!e || !id || !rung_counts) return fail(PTM_ERR_INVALID, "null argument");
   if (world < 1 || rank < 0 || rank >= world) return fail(PTM_ERR_INVALID, "bad rank / world size");
   if (e->shard) return fail(PTM_ERR_INVALID, "this engine is sharded already (ptm_shard_finalize first)");
@@ -2147,6 +2156,7 @@ static int shard_recover(ptm_engine* e) {
 }
 
 extern "C" int ptm_shard_step(ptm_engine* e, int n) {
+  SETTLE(e);
   NO_BATCH(e, "ptm_shard_step");
   int rc = ready(e);
   if (rc) return rc;

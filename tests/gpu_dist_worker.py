@@ -37,8 +37,10 @@ if __name__ == "__main__":
     ref.close()
     r0, n = shard_bounds(Nt, world, rank)
     stream = torch.cuda.Stream(device=dev)
-    # (a shard below the ladder's top cannot record its top rung: its in-between row may be the neighbour's)
-    hr = 0 if not hist_every else (n if rank == world - 1 else n - 1)
+    # (a shard below the ladder's top records its LOWER rungs: the row a rung holds between its two exchanges of a step comes from
+    #  the rung above -- through a run of accepted picks possibly from several rungs above --, and a row that still sits in the
+    #  neighbour shard at that moment is refused loudly, error bit 16; half a shard is a run no step ever sees)
+    hr = 0 if not hist_every else (n if rank == world - 1 else max(1, n // 2))
     eng = E.Engine(D, Nt, W, swap_rate=sr, rung_begin=r0, rung_count=n, stream=stream.cuda_stream, add_every_n=max(1, hist_every),
                    history_rungs=hr, history_capacity=(2 * nsteps // max(1, hist_every) + 8) if hr else 0, map_rungs=hr)
     pr.configure(eng, E.PROP_LOWER)

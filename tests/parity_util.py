@@ -45,10 +45,12 @@ def problem_for(D, Nt, tmax):
 
 
 def make_pair(D, Nt, W, tmax, kind=E.PROP_LOWER, seed=0x5EED0001, swap_rate=0.1, one_d_frac=None, add_every_n=1,
-              bounds=None, prior=None, mean=None, min_prior=-30.0, init="prior", x0=None):
-    """An engine and its oracle twin on the same synthetic Gaussian problem and the same start states."""
+              bounds=None, prior=None, mean=None, min_prior=-30.0, init="prior", x0=None, history_cap=0):
+    """An engine and its oracle twin on the same synthetic Gaussian problem and the same start states (history_cap > 0: both record
+    every rung's history -- every add_every_n-th add -- and MAP)."""
     pr = problem_for(D, Nt, tmax)
-    eng = E.Engine(D, Nt, W, seed=seed, swap_rate=swap_rate, add_every_n=add_every_n, min_prior=min_prior)
+    eng = E.Engine(D, Nt, W, seed=seed, swap_rate=swap_rate, add_every_n=add_every_n, min_prior=min_prior,
+                   history_rungs=Nt if history_cap else 0, history_capacity=history_cap, map_rungs=Nt if history_cap else 0)
     odf = None if one_d_frac is None else np.full(Nt, one_d_frac)
     fac = pr.configure(eng, kind, odf)
     if bounds is not None:
@@ -62,6 +64,8 @@ def make_pair(D, Nt, W, tmax, kind=E.PROP_LOWER, seed=0x5EED0001, swap_rate=0.1,
     f = 0.0 if one_d_frac is None else one_d_frac
     lad.set_proposals([(KIND_TO_ORACLE[kind], fac[r], f) for r in range(Nt)])
     lad.use_philox(seed)
+    if history_cap:
+        lad.enable_history(history_cap)
     if x0 is None:
         eng.init_from_prior()
         x0 = eng.states()
@@ -82,3 +86,19 @@ def assert_same_state(eng, lad, what=""):
         b = to_engine_order(getattr(lad, name), Nt, W)
         assert np.array_equal(a, b, equal_nan=True) if a.dtype.kind == "f" else np.array_equal(a, b), \
             "%s %s differ at %s" % (what, name, np.argwhere(a != b)[:4].tolist())
+
+
+def assert_same_history_and_map(eng, lad, cap):
+    """every saved row (states, scalars, counters, the temperature it was saved at) and every rung's MAP; the run must fit the ring"""
+    Nt, W = eng.Nt, eng.W
+    he, ho = eng.history(), lad.history()
+    nsize = eng.nsize
+    assert nsize.max() <= cap
+    for name in ("x", "llike", "lprior", "naccept", "ntries", "last_type", "invtemp"):
+        for s_ in range(int(nsize.max())):
+            have = nsize > s_
+            got, want = he[name][s_ % cap][have], to_engine_order(ho[name][:, s_], Nt, W)[have]
+            assert np.array_equal(got, want), (name, s_, np.argwhere(got != want)[:3].tolist())
+    m = eng.map()
+    assert np.array_equal(m["lpost"], to_engine_order(lad.map_lpost, Nt, W))
+    assert np.array_equal(m["x"], to_engine_order(lad.map_x, Nt, W))

@@ -1,6 +1,6 @@
 """Randomised bit-exact comparison of the engine with the CPU checker (test infrastructure: imports tests/): shapes, proposal
 kinds, boundaries, priors, a mean, one-dimensional moves, evolving ladders with and without the posterior-ordering cut, drawn
-from a seeded generator; a few PT steps and plain sweeps each.  Stops at the first difference with the case printed.
+scale mixtures, the history ring with MAP tracking -- drawn from a seeded generator; a few PT steps and plain sweeps each.  Stops at the first difference with the case printed.
 usage (GPU box): python tools/fuzz_parity.py [seconds] [seed]"""
 import math
 import os
@@ -51,9 +51,18 @@ while time.time() - t0 < budget:
     x0 = rng.uniform(-1.2, 1.2, size=(Nt * W, D)) if bounds is not None else None
     ev = 0.0 if (rng.random() < 0.5 or Nt < 3) else float(rng.choice([0.01, 0.05]))
     cut = -1.0 if rng.random() < 0.6 else float(rng.choice([0.0, 1.0, 3.0]))
-    case = dict(D=D, Nt=Nt, W=W, kind=kind, sr=sr, odf=odf, flav=flav, mean=mean is not None, ev=ev, cut=cut)
+    K = 0 if rng.random() < 0.65 else int(rng.choice([1, 2, 4]))                         # a scale mixture (the sampler's default Gaussian recipe)
+    hist = 0 if (rng.random() < 0.65 or Nt * W * D > 3e5 or D > 128) else int(rng.choice([1, 2, 3]))   # history + MAP, every hist-th add saved
+    case = dict(D=D, Nt=Nt, W=W, kind=kind, sr=sr, odf=odf, flav=flav, mean=mean is not None, ev=ev, cut=cut, K=K, hist=hist)
     try:
-        pr, eng, lad = PU.make_pair(D, Nt, W, 1e3, kind=kind, swap_rate=sr, one_d_frac=odf, bounds=bounds, prior=prior, mean=mean, x0=x0)
+        pr, eng, lad = PU.make_pair(D, Nt, W, 1e3, kind=kind, swap_rate=sr, one_d_frac=odf, bounds=bounds, prior=prior, mean=mean, x0=x0,
+                                    add_every_n=max(1, hist), history_cap=32 if hist else 0)
+        if K:
+            shares = 2.0 ** np.arange(1, K + 1)
+            cum = np.tile(np.cumsum(shares) / shares.sum(), (Nt, 1)); cum[:, -1] = 1.0
+            scales = np.tile(2.0 ** -np.arange(K)[::-1], (Nt, 1))
+            odfs = np.tile(np.where(np.arange(K) % 2 == 0, odf or 0.0, 0.0), (Nt, 1))
+            eng.set_proposal_mixture(cum, scales, odfs); lad.set_mixture(cum, scales, odfs)
         if ev:
             eng.set_evolve_temps(ev, lpost_cut=cut); lad.evolve_temps(ev, cut)
         for k in range(2):
@@ -66,6 +75,8 @@ while time.time() - t0 < budget:
                 PU.assert_same_state(eng, lad, "plain sweeps")
         t, a = eng.swap_counts()
         assert np.array_equal(t, lad.swap_count) and np.array_equal(a, lad.swap_accept_count)
+        if hist:
+            PU.assert_same_history_and_map(eng, lad, 32)
         for nm in {eng.sweep_kernel_name, eng.step_kernel_name}:      # (the step of a long ladder of few walkers is ONE kernel)
             kernels[nm] = kernels.get(nm, 0) + 1
         eng.close()

@@ -2,6 +2,8 @@ cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/prof_extra; rm -rf $O; mkdir -p $O
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/w1 -- python3 $R/tools/w1_probe.py > $O/w1.out 2> $O/w1.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/w1ev -- python3 $R/tools/w1_evolve_probe.py 2000 full > $O/w1ev.out 2> $O/w1ev.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/recipe -- python3 $R/tools/kbench.py --walkers 16384 --recipe > $O/recipe.out 2> $O/recipe.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ev -- python3 $R/tools/kbench.py --walkers 16384 --evolve 0.01 > $O/ev.out 2> $O/ev.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/d64 -- python3 $R/tools/kbench.py --dim 64 --rungs 1024 --walkers 4096 > $O/d64.out 2> $O/d64.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/d128 -- python3 $R/tools/kbench.py --dim 128 --rungs 256 --walkers 4096 > $O/d128.out 2> $O/d128.err
