@@ -188,10 +188,9 @@ def run_single(args):
     # host wants to know first (two sums reduced on the device: 16 bytes), then clocks up again, warm-up, and straight into the
     # timed steps with nothing but the contract's synchronisation in between.
     settle(eng, 0.25)
-    eng.kernel_times()   # drop the records so far
-    eng.step(args.warmup)
+    eng.step(args.warmup)            # (queued behind the settling steps: the device never idles from here to the end of the timed steps)
     tries0 = eng.counter_sums()[0]   # MH_chain::Ntries counts the Metropolis moves made (chain.cc:1005); exchanged rungs make none
-    eng.kernel_times()   # drop warm-up records
+    eng.kernel_times(drop=True)      # forget the records so far, unread (a few hundred event queries would be a gap of their own)
     eng.sync()
     eng.timer_start()
     t0 = time.perf_counter()

@@ -346,7 +346,8 @@ uint64_t ptm_step_count(ptm_engine* e);
 /* HIP events on the engine's stream */
 int ptm_timer_start(ptm_engine* e);
 int ptm_timer_stop(ptm_engine* e, float* elapsed_ms); /* synchronises on the stop event */
-/* per-launch durations of the fused sweep kernel recorded since the last call (cfg.time_kernels) */
+/* per-launch durations of the fused sweep kernel recorded since the last call (cfg.time_kernels); ms == NULL: the records are
+ * dropped unread (no event query: a measurement that discards its warm-up records must not leave the device idle meanwhile) */
 int ptm_get_kernel_times(ptm_engine* e, float* ms, int capacity, int* count);
 /* name of the sweep kernel variant in use (for matching rocprofv3 traces) */
 const char* ptm_sweep_kernel_name(ptm_engine* e);

@@ -284,23 +284,27 @@ __global__ __launch_bounds__(LADDER_THREADS) void ladder_persistent_kernel(const
   // ptmo_chunk_prefix's two levels, with the operands fetched from LDS BEFORE the chain of dependent adds (a lone lane pays ~100
   // cycles per dependent LDS read): chunk q of v[0 .. n): P[k] = the sum of the chunk's entries before k, returns the chunk's total ...
   auto chunk_scan = [&](const double* v, double* P, int q, int n) -> double {
-    double r[32];
-#pragma unroll
-    for (int j = 0; j < 32; ++j) { const int k = 32 * q + j; r[j] = k < n ? v[k] : 0.0; }
     double loc = 0.0;
+#pragma unroll 1
+    for (int j0 = 0; j0 < 32; j0 += 8) {   // (eight operands in flight: the kernel is short of registers, not of LDS bandwidth)
+      double r[8];
 #pragma unroll
-    for (int j = 0; j < 32; ++j) { const int k = 32 * q + j; if (k < n) P[k] = loc; loc = loc + r[j]; }   // (+ 0.0 behind the end changes nothing)
+      for (int j = 0; j < 8; ++j) { const int k = 32 * q + j0 + j; r[j] = k < n ? v[k] : 0.0; }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const int k = 32 * q + j0 + j; if (k < n) P[k] = loc; loc = loc + r[j]; }   // (+ 0.0 behind the end changes nothing)
+    }
     return loc;
   };
   // ... and the chunk totals tot[0 .. nq) left to right: off[q] = the sum of the totals before q (may overwrite tot), returns the grand total
   auto totals_scan = [&](const double* tot, double* off, int nq) -> double {
     double run = 0.0;
-    for (int q0 = 0; q0 < nq; q0 += 16) {
-      double r[16];
+#pragma unroll 1
+    for (int q0 = 0; q0 < nq; q0 += 8) {
+      double r[8];
 #pragma unroll
-      for (int j = 0; j < 16; ++j) r[j] = q0 + j < nq ? tot[q0 + j] : 0.0;
+      for (int j = 0; j < 8; ++j) r[j] = q0 + j < nq ? tot[q0 + j] : 0.0;
 #pragma unroll
-      for (int j = 0; j < 16; ++j) { if (q0 + j < nq) off[q0 + j] = run; run = run + r[j]; }
+      for (int j = 0; j < 8; ++j) { if (q0 + j < nq) off[q0 + j] = run; run = run + r[j]; }
     }
     return run;
   };
@@ -424,22 +428,22 @@ __global__ __launch_bounds__(LADDER_THREADS) void ladder_persistent_kernel(const
       // look again at those that were not there yet (one round trip where a flag and then the data would be two)
       {
         // (stamp first, value second: a wave's loads return in issue order and the word was stored whole, so a value read behind its
-        //  matching stamp is that step's; sixteen rungs per lane in flight at once)
+        //  matching stamp is that step's; eight rungs per lane in flight at once)
         const double* ps = a.pub_s + 2 * (size_t)par * p.Nc;
         const long long t0 = wall_clock64();
         bool ok = true;
-        for (int rb = 0; rb < Nt && ok; rb += 128 * 16) {
+        for (int rb = 0; rb < Nt && ok; rb += 128 * 8) {
           unsigned int pending = 0;
 #pragma unroll
-          for (int q = 0; q < 16; ++q) if (rb + wt + 128 * q < Nt) pending |= 1u << q;
+          for (int q = 0; q < 8; ++q) if (rb + wt + 128 * q < Nt) pending |= 1u << q;
           while (pending && ok) {
-            double st[16], vx[16];
+            double st[8], vx[8];
 #pragma unroll
-            for (int q = 0; q < 16; ++q) if ((pending >> q) & 1u) st[q] = __hip_atomic_load(ps + 2 * ((size_t)(rb + wt + 128 * q) * p.W + w) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int q = 0; q < 8; ++q) if ((pending >> q) & 1u) st[q] = __hip_atomic_load(ps + 2 * ((size_t)(rb + wt + 128 * q) * p.W + w) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-            for (int q = 0; q < 16; ++q) if ((pending >> q) & 1u) vx[q] = __hip_atomic_load(ps + 2 * ((size_t)(rb + wt + 128 * q) * p.W + w), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int q = 0; q < 8; ++q) if ((pending >> q) & 1u) vx[q] = __hip_atomic_load(ps + 2 * ((size_t)(rb + wt + 128 * q) * p.W + w), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-            for (int q = 0; q < 16; ++q)
+            for (int q = 0; q < 8; ++q)
               if (((pending >> q) & 1u) && st[q] == stamp) { const int r = rb + wt + 128 * q; llall[r] = vx[q]; permall[r] = r; pending &= ~(1u << q); }
             if (pending) {
               if (__hip_atomic_load(&a.ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 || wall_clock64() - t0 > a.spin_limit) ok = false;
@@ -831,7 +835,6 @@ __global__ __launch_bounds__(LADDER_THREADS) void ladder_persistent_kernel(const
       //      has published its next step)
       if (tc) {
         if (ex_src != rg) { xd = ex_x; ll = ex_ll; lp = ex_lp; }
-        if (HIST) exchanged_adds(tc == 2 ? exm_x : xd, tc == 2 ? exm_ll : ll, tc == 2 ? exm_lp : lp);
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else if (!sflag[0]) {
@@ -854,10 +857,7 @@ __global__ __launch_bounds__(LADDER_THREADS) void ladder_persistent_kernel(const
       if (tc) {
         const int src = wperm[rg - wlo];
         if (src != rg) { xd = wx[(src - wlo) * DP + d]; ll = wll0[src - wlo]; lp = wlp0[src - wlo]; }
-        if (HIST) {
-          const int sm = tc == 2 ? wmid[rg - wlo] : rg;
-          exchanged_adds(wx[(sm - wlo) * DP + d], wll0[sm - wlo], wlp0[sm - wlo]);
-        }
+        if (HIST && tc == 2) { const int sm = wmid[rg - wlo]; exm_x = wx[(sm - wlo) * DP + d]; exm_ll = wll0[sm - wlo]; exm_lp = wlp0[sm - wlo]; }
       }
     } else {
       // ---- 4'. the same from the WHOLE ladder's publications (a run of surviving picks longer than the halo: rare).  Every
@@ -898,15 +898,11 @@ __global__ __launch_bounds__(LADDER_THREADS) void ladder_persistent_kernel(const
           ll = __hip_atomic_load(pl + cs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           lp = __hip_atomic_load(a.pub_lp + (size_t)par * p.Nc + cs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if (HIST) {
-          double xm = xd, lm = ll, pm_ = lp;
-          if (tc == 2) {
-            const size_t cm = (size_t)midall[rg] * p.W + w;
-            xm = __hip_atomic_load(a.pub_x + par * NcDP + cm * DP + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            lm = __hip_atomic_load(pl + cm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            pm_ = __hip_atomic_load(a.pub_lp + (size_t)par * p.Nc + cm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          }
-          exchanged_adds(xm, lm, pm_);
+        if (HIST && tc == 2) {
+          const size_t cm = (size_t)midall[rg] * p.W + w;
+          exm_x = __hip_atomic_load(a.pub_x + par * NcDP + cm * DP + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          exm_ll = __hip_atomic_load(pl + cm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          exm_lp = __hip_atomic_load(a.pub_lp + (size_t)par * p.Nc + cm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -923,6 +919,8 @@ __global__ __launch_bounds__(LADDER_THREADS) void ladder_persistent_kernel(const
       __syncthreads();
       if (sflag[2]) { if (tid == 0) __hip_atomic_store(&a.ctl[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); aborted = true; break; }
     }
+    // the add_state calls of the exchanged rungs (history rows, MAP): one place for the three forms of the exchange phase above
+    if (HIST && tc) exchanged_adds(exm_x, exm_ll, exm_lp);
     if (last_step && b == 0)                                      // the log lines of the picks that did not survive
       for (int k = tid; k < ms; k += LADDER_THREADS)
         if (!alive[k]) a.swap_log[(size_t)w * ms + k] = -2;

@@ -647,9 +647,13 @@ class Engine:
         _chk(self.L.ptm_timer_stop(self.h, C.byref(ms)))
         return ms.value
 
-    def kernel_times(self, capacity=1 << 16):
-        buf = (C.c_float * capacity)()
+    def kernel_times(self, capacity=1 << 16, drop=False):
+        """per-launch durations (ms) of the sweep kernel since the last call; drop=True: forget them unread (no event queries)"""
         n = C.c_int()
+        if drop:
+            _chk(self.L.ptm_get_kernel_times(self.h, None, 0, C.byref(n)))
+            return np.zeros(0)
+        buf = (C.c_float * capacity)()
         _chk(self.L.ptm_get_kernel_times(self.h, buf, capacity, C.byref(n)))
         return np.array(buf[:min(n.value, capacity)], dtype=np.float64)
 
