@@ -18,9 +18,16 @@ cases = [(6, 12, 64, E.PROP_DENSE, 0.3, 0.02, "general kernel"), (5, 9, 5, E.PRO
          (32, 10, 64, E.PROP_LOWER, 0.3, 0.01, "MFMA kernel"), (40, 8, 2, E.PROP_DIAG, 0.4, 0.0, "lanes kernel, 64-dim rows"),
          (90, 6, 2, E.PROP_LOWER, 0.4, 0.01, "lanes kernel, 128-dim rows"),
          (32, 6, 1024, E.PROP_LOWER, 0.3, 0.0, "MFMA kernel, compacted"), (28, 6, 1024, E.PROP_DENSE, 0.3, 0.01, "MFMA kernel, box-bounds build, compacted")]
+# the persistent ladder kernel (round 4): its plain build, the evolving one, and the one with everything the sampler switches on
+cases += [(32, 96, 2, E.PROP_LOWER, 0.25, 0.0, "persistent ladder kernel"), (32, 96, 2, E.PROP_LOWER, 0.25, 0.02, "persistent ladder kernel, evolving"),
+          (20, 60, 3, E.PROP_DENSE, 0.3, 0.02, "persistent ladder kernel, everything")]
 for D, Nt, W, kind, sr, ev, what in cases:
-    lean = what == "MFMA kernel, compacted"
-    pr, eng, lad = PU.make_pair(D, Nt, W, 1e4, kind=kind, swap_rate=sr, one_d_frac=None if lean else 0.2)
+    lean = what == "MFMA kernel, compacted" or what.startswith("persistent ladder kernel") and "everything" not in what
+    hist = "everything" in what
+    pr, eng, lad = PU.make_pair(D, Nt, W, 1e4, kind=kind, swap_rate=sr, one_d_frac=None if lean else 0.2, add_every_n=50 if hist else 1,
+                                history_cap=(2 * steps // 50 + 8) if hist else 0)
+    if what.startswith("persistent ladder kernel"):
+        assert eng.step_kernel_name.startswith("ladder_persistent_kernel"), eng.step_kernel_name
     if W >= 1024:
         steps_case = min(steps, 600)   # (the checker walks 6144 chains per step on one core)
     else:
@@ -36,7 +43,9 @@ for D, Nt, W, kind, sr, ev, what in cases:
         PU.assert_same_state(eng, lad, "%s after %d steps" % (what, done))
         assert np.array_equal(eng.invtemps(), lad.betaw)
         print("  %-28s %6d steps ok (%.0fs)" % (what, done, time.time() - t0), flush=True)
+    if hist:
+        PU.assert_same_history_and_map(eng, lad, 2 * steps // 50 + 8)
     t, a = eng.swap_counts()
     print("%s: D=%d %dx%d, %d steps bit-identical; kernel %s; MH accept %.3f, swap accept %.3f" %
-          (what, D, Nt, W, steps_case, eng.sweep_kernel_name, (eng.naccept.sum() - eng.Nc) / max(1, eng.ntries.sum() - eng.Nc), a.sum() / max(1, t.sum())), flush=True)
+          (what, D, Nt, W, steps_case, eng.sweep_kernel_name, (eng.naccept.sum() - eng.Nc) / max(1, eng.ntries.sum() - eng.Nc), a.sum() / max(1, t.sum())) + ("  [step kernel %s]" % eng.step_kernel_name if what.startswith("persistent") else ""), flush=True)
     eng.close()
