@@ -1690,7 +1690,8 @@ class bayes_likelihood : public probability_function, public Optioned {  // baye
     if (nt > n / 8) nt = n / 8;      // at least 8 states per thread
     // starting and joining threads costs ~50 us: a batch that the measured cost per evaluation prices below ~4 such
     // units stays on this thread (eval_threads == 0 only; an explicit thread count is obeyed)
-    if (l->eval_threads <= 0 && l->eval_ns >= 0 && l->eval_ns * n < 200e3) nt = 1;
+    static const double pool_from_ns = [] { const char* v = getenv("PTM_EVAL_POOL_NS"); return v && *v ? atof(v) : 200e3; }();   // (A/B timing)
+    if (l->eval_threads <= 0 && l->eval_ns >= 0 && l->eval_ns * n < pool_from_ns) nt = 1;
     if (nt <= 1) {
       const auto t0 = std::chrono::steady_clock::now();
       work(0, n);
