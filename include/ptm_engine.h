@@ -209,7 +209,11 @@ int ptm_init_from_prior_k(ptm_engine* e, int k);
 /* ---- the hot path ------------------------------------------------------------------------------------- */
 /* n x { MH_chain::step for every chain } -- no exchange phase */
 int ptm_sweep(ptm_engine* e, int n);
-/* n x parallel_tempering_chains::step (single-shard engines: rung_count == n_rungs) */
+/* n x parallel_tempering_chains::step (chain.cc:1393-1571; single-shard engines: rung_count == n_rungs).  ASYNCHRONOUS: the call
+ * queues work on the engine's stream and returns; results are there when a getter, a setter or ptm_sync looks.  On the persistent
+ * ladder kernel's path (long ladders of few walkers, ptm_step_kernel_name) calls of fewer than 64 steps are only COUNTED and launched
+ * together at that next look (or when 1024 have gathered) -- nothing can observe the difference, and a loop of ptm_step(1) calls, the
+ * reference sampler's own (ptmcmc.cc:563-599), then costs what ptm_step(n) costs per step.  PTM_LADDER_DEFER=0 launches every call. */
 int ptm_step(ptm_engine* e, int n);
 /* wait for all queued work */
 int ptm_sync(ptm_engine* e);
