@@ -15,9 +15,17 @@ int main(int argc, char** argv) {
   if (argc < 2) { printf("usage: %s <outbase> [--option=value ...]\n", argv[0]); return 2; }
   // --dim=D (first option, if given): a D-dimensional tridiagonal-precision target instead of the 3-dimensional one -- e.g. --dim=12
   // with --pt=64: a ladder long enough for the persistent ladder kernel (its build with everything the sampler switches on)
+  // --default_recipe (next, if given): select_proposal() without an argument -- the reference's default set, 80 % differential evolution
+  // from the chains' saved history + six Gaussians (ptmcmc.cc:15-183), drawn on the device -- instead of the Gaussians below
   int D = 3;
+  bool default_recipe = false;
   if (argc > 2 && std::string(argv[2]).rfind("--dim=", 0) == 0) {
     D = atoi(argv[2] + 6);
+    for (int k = 2; k + 1 < argc; k++) argv[k] = argv[k + 1];
+    argc--;
+  }
+  if (argc > 2 && std::string(argv[2]) == "--default_recipe") {
+    default_recipe = true;
     for (int k = 2; k + 1 < argc; k++) argv[k] = argv[k + 1];
     argc--;
   }
@@ -55,10 +63,11 @@ int main(int argc, char** argv) {
   mcmc.set("nevery", "500"); mcmc.set("nskip", "4"); mcmc.set("pt_dump_n", "2"); mcmc.set("pt_swap_rate", "0.3");
   if (!mcmc.parse(argc - 1, argv + 1)) { printf("bad option\n"); return 2; }
   mcmc.setup(like);
-  mcmc.select_proposal(prop);
+  if (default_recipe) mcmc.select_proposal();
+  else mcmc.select_proposal(prop);
   mcmc.initialize();
   mcmc.run(argv[1]);
   printf("%s", mcmc.chains()->status().c_str());
-  printf("step kernel: %s\n", ptm_step_kernel_name(mcmc.chains()->engine()));
+  printf("step kernel: %s%s\n", ptm_step_kernel_name(mcmc.chains()->engine()), mcmc.chains()->draws_de_on_device() ? "  (differential evolution drawn on the device)" : "");
   return 0;
 }

@@ -123,7 +123,7 @@ struct ptm_engine {
   double *pub_x = nullptr, *pub_ll = nullptr, *pub_lp = nullptr;   // (one allocation: pub_x)
   int *lad_flags = nullptr, *lad_ctl = nullptr;                     // (one allocation: lad_flags)
   long long* lad_prof = nullptr;
-  int lad_capacity[2][8] = {{-1, -1, -1, -1, -1, -1, -1, -1}, {-1, -1, -1, -1, -1, -1, -1, -1}};   // workgroups of each build of that kernel [diagonal][FL] the device holds at once (-1: not asked yet)
+  int lad_capacity[2][16] = {{-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1}, {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1}};   // workgroups of each build of that kernel [diagonal][FL] the device holds at once (-1: not asked yet)
   long long ladder_launches = 0, ladder_whole_steps = 0;   // launches of that kernel; steps (of walker 0) whose exchange phase needed the whole ladder
   // A launch of that kernel commits all of its steps or none (ptm_ladder_kernel.hpp) and is ASYNCHRONOUS: the host learns at its
   // next look (ladder_settle) whether the launches since the last look were committed -- the device keeps the number of the last one
@@ -938,8 +938,7 @@ extern "C" int ptm_set_proposal_de(ptm_engine* e, const ptm_de_params* q, int n_
   if (e->de_init) { HIPCHK(hipFree(e->de_init)); e->de_init = nullptr; }
   e->de_on = false; e->de_init_extra = 0;
   if (!q) return PTM_OK;
-  if (e->DP > 32) return fail(PTM_ERR_UNSUPPORTED, "differential evolution on the device is built for up to 32 dimensions (the general sweep kernel's range); "
-                                                   "above, draw it on the host (ptm_set_proposal_callback)");
+  if (e->DP > 128) return fail(PTM_ERR_UNSUPPORTED, "differential evolution on the device is built for up to 128 dimensions; above, draw it on the host (ptm_set_proposal_callback)");
   if (e->hist.rungs != e->nloc || e->hist.cap < 2)
     return fail(PTM_ERR_INVALID, "differential evolution draws from every rung's saved history: create the engine with history_rungs = rung_count and a "
                                  "history_capacity that holds every row of the run");
@@ -1613,6 +1612,7 @@ static int fused_steps(ptm_engine* e, int n) {
 // bit 2 evolving ladders (built plain, 4, and with everything, 7)
 static int ladder_flavour(const ptm_engine* e) {
   const int fl = ((e->any_oned || e->mix_K > 0) ? 1 : 0) | ((e->hist.rungs || e->map.rungs) ? 2 : 0);
+  if (e->de_on) return e->evolve_rate > 0 ? 15 : 11;   // differential evolution: a member of a set, drawn from the history ring
   return e->evolve_rate > 0 ? (fl ? 7 : 4) : fl;
 }
 static bool ladder_applies(ptm_engine* e, long long* grid_out = nullptr, size_t* lds_out = nullptr) {
@@ -1622,7 +1622,7 @@ static bool ladder_applies(ptm_engine* e, long long* grid_out = nullptr, size_t*
   const SweepSel sel = sweep_sel(e);
   // open / `limit` boundaries, all-uniform prior, zero mean, fixed ladder, device target and proposals (one-dimensional moves, scale
   // mixtures, history and MAP tracking have their builds: ladder_flavour); populations with whole waves per rung keep the throughput kernels
-  if (sel.uni || (e->has_bounds && !e->bounds_box) || !e->all_uniform || e->has_mean || e->cb || e->prior_cb || e->pcb || e->de_on) return false;
+  if (sel.uni || (e->has_bounds && !e->bounds_box) || !e->all_uniform || e->has_mean || e->cb || e->prior_cb || e->pcb) return false;
   const int R = 256 / e->DP, NB = (e->Nt + R - 1) / R;
   const long long grid = (long long)e->W * NB;
   const bool diag = e->prop_kind == PTM_PROP_DIAG;
@@ -2534,7 +2534,7 @@ extern "C" const char* ptm_sweep_kernel_name(ptm_engine* e) {
   else if ((e->DP == 64 || e->DP == 128) && s.uni && e->all_uniform && (!e->has_bounds || e->bounds_box) && !e->has_mean && !e->any_oned && e->mix_K == 0 && !s.callback &&
            !s.host_prop && !e->hist.rungs && !e->map.rungs && !(fv && *fv && *fv != '0'))
     snprintf(b, sizeof b, "sweep_mfma%d_kernel<%d, %s, %s>", e->DP, s.kind == KIND_DIAG ? KIND_LOWER : s.kind, e->has_bounds ? "true" : "false", e->betaC ? "true" : "false");
-  else if (e->DP >= 64 || s.host_prop || (!s.uni && !s.de && !getenv("PTM_FORCE_VALU") && (long long)e->Nc * e->DP <= (e->DP >= 16 ? PTM_LANES_MAX : 4096ll * e->DP)))
+  else if (e->DP >= 64 || s.host_prop || (!s.uni && !getenv("PTM_FORCE_VALU") && (long long)e->Nc * e->DP <= (e->DP >= 16 ? PTM_LANES_MAX : 4096ll * e->DP)))
     snprintf(b, sizeof b, "sweep_lanes_kernel<%d, %d, %s>", e->DP, s.kind, s.plain ? "false" : "true");
   else snprintf(b, sizeof b, "sweep_kernel<%d, %d, %s, %s>", e->DP, s.kind, s.uni ? "true" : "false", s.simple ? "true" : "false");
   e->kname = b;

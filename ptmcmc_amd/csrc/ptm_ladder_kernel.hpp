@@ -83,6 +83,8 @@ __global__ __launch_bounds__(LADDER_THREADS) void ladder_persistent_kernel(const
   constexpr bool GENX = (FL & 1) != 0;   // one-dimensional moves, scale mixtures
   constexpr bool HIST = (FL & 2) != 0;   // history ring, MAP tracking
   constexpr bool EV = (FL & 4) != 0;     // evolving ladders
+  constexpr bool DEB = (FL & 8) != 0;    // differential evolution from the chain's saved history (with GENX and HIST: FL = 11, 15)
+  static_assert(!DEB || (GENX && HIST), "differential evolution is a member of a proposal set and draws from the history ring");
   // a launch whose predecessor gave up does nothing: the host repeats that launch's steps, and this one's, on the two-launch path
   if (__hip_atomic_load(a.done_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.seq - 1) return;
   constexpr int R = 256 / DP;            // rungs per workgroup
@@ -377,6 +379,9 @@ __global__ __launch_bounds__(LADDER_THREADS) void ladder_persistent_kernel(const
     u32x4 o0 = u32x4{0u, 0u, 0u, 0u}, o = u32x4{0u, 0u, 0u, 0u};
     bool valid = false;
     double cur_lpost = 0.0;
+    bool de_move = false;        // DEB: the step's member is differential evolution; its log-Hastings ratio, the error bits of its draw
+    double de_hast = 0.0;
+    int de_err = 0;
     // the part of MH_chain::step that depends on the rung's temperature (chain.cc:973,980-1001)
     auto metropolis = [&] {
       const double bl = beta * ll;
@@ -385,8 +390,12 @@ __global__ __launch_bounds__(LADDER_THREADS) void ladder_persistent_kernel(const
       const bool want_like = valid && (newlprior > -1e200 || newlprior - oldlprior > p.min_prior);   // chain.cc:980 (Q1)
       newlpost = newlike * beta + newlprior;
       if (!want_like) newlike = newlpost = -__builtin_inf();
-      const double logH = newlpost - cur_lpost;
+      double logH = newlpost - cur_lpost;
       accept = valid;
+      if (DEB && de_move) {                                       // chain.cc:989-994: prop.log_hastings_ratio(), NaN => reject
+        if (de_hast != de_hast) accept = false;
+        logH = de_hast + logH;
+      }
       if (accept && logH < 0) accept = dlog_u01(o0.v0) < logH;    // chain.cc:998-1001 (NaN stays accepted)
     };
 
@@ -413,10 +422,13 @@ __global__ __launch_bounds__(LADDER_THREADS) void ladder_persistent_kernel(const
           kmix = p.mix_K - 1;
           for (int k = p.mix_K - 2; k >= 0; --k)
             if (xs < mx[3 * k]) kmix = k;
+          // differential evolution that is not ready yet is passed over (proposal_distribution.cc:111)
+          if (DEB && mx[3 * kmix + 1] < 0 && kmix + 1 < p.mix_K && !de_ready(p, nhist)) kmix += 1;
           mix_scale = mx[3 * kmix + 1];
           f = mx[3 * kmix + 2];
         }
         if (p.any_oned && f > 0 && u01(o0.v1) < f) { axis = (int)(p.D * u01(o0.v2)); type = 1; }
+        de_move = DEB && mix_scale < 0;
       }
     }
     replay_sync(5, 4 * (s + 1), helper, drole);   // every bookkeeper wave has drawn: the two replay waves go on when all four have
@@ -564,6 +576,83 @@ __global__ __launch_bounds__(LADDER_THREADS) void ladder_persistent_kernel(const
     }
     if (!helper) {
       xn = xd + off;                                              // state::add (states.cc:205-214)
+      if (DEB && __builtin_amdgcn_ballot_w64(de_move) != 0ull) {
+        // differential_evolution::draw (proposal_distribution.cc:476-592) -- lanes_body's, with the state in its register and the
+        // history rows read past the L1 (this workgroup wrote the newest of them itself, some steps ago in this launch).  A chain that
+        // turns out to be touched by the exchange phase drops the result like any other move's, and its error bits with it.
+        auto hload = [](const double* q) { return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+        const int D = p.D;
+        const long long saved = 1 + (long long)((nhist + every - 1u) / every);   // rows of the ring so far
+        const long long rows = p.de_init_extra + saved;
+        auto pick = [&](double u) -> const double* {
+          const long long spare = rows - 100ll * D;
+          const long long first_ = (spare * (1 - p.de_ignore) > 10ll * D) ? (long long)(spare * p.de_ignore) : 0;
+          const long long r = (long long)(first_ + (rows - first_) * u);
+          if (r < p.de_init_extra) return p.de_init + ((size_t)r * p.Nc + c) * DP;
+          const long long hr = r - p.de_init_extra;
+          if (saved - hr > p.hist.cap) de_err |= 64;         // the ring has lost that row
+          return p.hist.x + hist_slot(p.hist, hr, c) * DP;
+        };
+        const u32x4 b0 = draw_block(p.seed, TAG_MH, stream, step, 0x0DE00000u);
+        const bool snk = de_move && p.de_snooker > u01(b0.v0);
+        double z1d = 0.0, z2d = 0.0, xde = 0.0;
+        if (de_move) { z1d = hload(pick(u01(b0.v2)) + pos); z2d = hload(pick(u01(b0.v3)) + pos); }
+        if (de_move && !snk) {                               // draw_standard
+          const double gamma = u01(b0.v1) < p.de_gamma_one ? 1.0 : p.de_gamma_std;
+          const double t1 = z1d * gamma;
+          const double a_ = xd + t1;
+          const double t2 = z2d * (-gamma);
+          xde = d < D ? a_ + t2 : 0.0;
+        }
+        int dt = 0;
+        if (__builtin_amdgcn_ballot_w64(snk) != 0ull) {      // draw_snooker (the whole wave walks along: the LDS hand-overs are the wave's)
+          const double gamma = (1.2 + u01(b0.v1)) / p.de_gamma_div;
+          auto chain_sum = [&](double term, bool mine, double& out) {   // the chain's sum of its lanes' terms, in index order
+            sbuf[g * DP + d] = term;
+            sync_wave();
+            if (mine) {
+              double sm = 0.0;
+              for (int j = 0; j < D; ++j) sm = sm + sbuf[g * DP + j];
+              out = sm;
+            }
+            sync_wave();
+          };
+          double zz = 0.0, ax = 0.0, axis2 = 0.0;
+          bool failed = false;
+          for (int tries = 0;; ++tries) {                    // the history repeats states: z must differ from the current state
+            bool need = snk && !failed && axis2 == 0.0;
+            if (need && tries > 1000) { failed = true; need = false; }
+            if (__builtin_amdgcn_ballot_w64(need) == 0ull) break;
+            if (need) {
+              const u32x4 bt = draw_block(p.seed, TAG_MH, stream, step, 0x0DE00001u + (uint32_t)tries);
+              zz = hload(pick(u01(bt.v0)) + pos);
+              ax = xd + zz * (-1.0);
+            }
+            chain_sum(ax * ax, need, axis2);
+          }
+          const bool go = snk && !failed;
+          double proj = 0.0, fz2 = 0.0;
+          {
+            const double a_ = z1d * gamma, b_ = z2d * (-gamma);
+            const double diff = a_ + b_;
+            chain_sum(diff * ax, go, proj);
+          }
+          if (go) proj = proj / axis2;
+          const double t = ax * proj;
+          const double y = xd + t;
+          if (go) xde = d < D ? y : 0.0;
+          const double f_ = y + zz * (-1.0);
+          chain_sum(f_ * f_, go, fz2);
+          if (go) de_hast = (dlog(fz2) - dlog(axis2)) * (double)(D - 1) / 2.0;
+          if (snk && failed) {                               // (the reference exits here; the engine raises an error bit and rejects the move)
+            de_err |= 128;
+            de_hast = __builtin_nan("");
+            xde = d < D ? xd : 0.0;
+          }
+          if (snk) dt = 1;
+        }
+        if (de_move) { xn = xde; type = kmix + 10 * dt; }    // proposal_distribution.cc:117
+      }
       const bool ind = !(xn < plo) && !(xn > phi);
       const bool in = all_of_chain(ind);
       // Q9: state::add builds on an enforced zero state -- an origin outside a `limit` bound invalidates every proposal
@@ -603,6 +692,7 @@ __global__ __launch_bounds__(LADDER_THREADS) void ladder_persistent_kernel(const
     // 1531-1534,1553-1557): known from the draws alone
     const int tc = helper ? 0 : (PTM_LADDER_ALIVE(rg) ? 1 : 0) + (PTM_LADDER_ALIVE(rg - 1) ? 1 : 0);
     const unsigned int nh0 = nhist;   // add_state calls before this step's
+    if (DEB && !helper && !tc && live && de_err) atomicOr(p.err, de_err);
     const double beta_old = beta;     // (evolving ladders: the rung's temperature before this step's pries)
     // evolving ladders: the row an exchanged rung receives (and the one it held in between) are asked for as soon as the row map is
     // known, and taken when the temperatures and the Metropolis tests are done

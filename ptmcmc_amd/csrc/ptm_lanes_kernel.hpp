@@ -119,6 +119,8 @@ __device__ __forceinline__ void lanes_body(const Dev& p, double* lds_all, const 
       kmix = p.mix_K - 1;
       for (int k = p.mix_K - 2; k >= 0; --k)
         if (xs < mx[3 * k]) kmix = k;
+      // differential evolution that is not ready yet is passed over (proposal_distribution.cc:111), as in the general kernel
+      if (p.de_on && mx[3 * kmix + 1] < 0 && kmix + 1 < p.mix_K && !de_ready(p, p.nhist[c])) kmix += 1;
       mix_scale = mx[3 * kmix + 1];
       f = mx[3 * kmix + 2];
     }
@@ -196,10 +198,120 @@ __device__ __forceinline__ void lanes_body(const Dev& p, double* lds_all, const 
     for (int e = 0; e < E; ++e) off[e] = mix_scale * off[e];     // the member is scale_k times the rung's factor
   }
   if (hp) type = p.htype[c];   // proposal_distribution::type()
+  // -- differential_evolution::draw (proposal_distribution.cc:476-592) for the chains whose member is the one with a negative scale:
+  //    de_draw of the general kernel with dimension d on lane d.  Every number is made by the same operations: products rounded
+  //    before their sums, the three inner products summed in index order (each lane of the chain walks the chain's terms in LDS).
+  const bool de_move = GEN && !hp && !tc && p.de_on && mix_scale < 0;
+  double de_hast = 0.0;
+  double xde[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) xde[e] = 0.0;
+  if constexpr (GEN) {
+    if (p.de_on && mode == 2 && de_move) { de_hast = p.de_hast[c]; type = kmix + 10 * p.de_type[c]; }
+    if (p.de_on && mode != 2 && __builtin_amdgcn_ballot_w64(de_move) != 0ull) {
+      const int D = p.D;
+      const unsigned int nh0 = p.nhist[c];
+      const long long saved = 1 + (long long)((nh0 + (unsigned int)p.add_every_n - 1u) / (unsigned int)p.add_every_n);   // rows of the ring so far
+      const long long rows = p.de_init_extra + saved;
+      auto pick = [&](double u) -> const double* {
+        const long long spare = rows - 100ll * D;
+        const long long first = (spare * (1 - p.de_ignore) > 10ll * D) ? (long long)(spare * p.de_ignore) : 0;
+        const long long r = (long long)(first + (rows - first) * u);
+        if (r < p.de_init_extra) return p.de_init + ((size_t)r * p.Nc + c) * DP;
+        const long long hr = r - p.de_init_extra;
+        if (saved - hr > p.hist.cap) atomicOr(p.err, 64);   // the ring has lost that row
+        return p.hist.x + hist_slot(p.hist, hr, c) * DP;
+      };
+      const u32x4 b0 = draw_block(p.seed, TAG_MH, stream, step, 0x0DE00000u);
+      const bool snk = de_move && p.de_snooker > u01(b0.v0);
+      const double* z1 = row;
+      const double* z2 = row;
+      if (de_move) { z1 = pick(u01(b0.v2)); z2 = pick(u01(b0.v3)); }
+      double xr[E], z1d[E], z2d[E];
+#pragma unroll
+      for (int e = 0; e < E; ++e) { xr[e] = row[pos + 64 * e]; z1d[e] = z1[pos + 64 * e]; z2d[e] = z2[pos + 64 * e]; }
+      if (de_move && !snk) {                               // draw_standard
+        const double gamma = u01(b0.v1) < p.de_gamma_one ? 1.0 : p.de_gamma_std;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          const double t1 = z1d[e] * gamma;
+          const double a = xr[e] + t1;
+          const double t2 = z2d[e] * (-gamma);
+          xde[e] = d + 64 * e < D ? a + t2 : 0.0;
+        }
+      }
+      int dt = 0;
+      if (__builtin_amdgcn_ballot_w64(snk) != 0ull) {      // draw_snooker (the whole wave walks along: the LDS hand-overs are the wave's)
+        const double gamma = (1.2 + u01(b0.v1)) / p.de_gamma_div;
+        // the chain's sum of its lanes' terms, in index order
+        auto chain_sum = [&](const double (&term)[E], bool mine, double& out) {
+#pragma unroll
+          for (int e = 0; e < E; ++e) sbuf[g * DP + d + 64 * e] = term[e];
+          sync_wave();
+          if (mine) {
+            double s = 0.0;
+            for (int j = 0; j < D; ++j) s = s + sbuf[g * DP + j];
+            out = s;
+          }
+          sync_wave();
+        };
+        double zz[E], ax[E], term[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) zz[e] = ax[e] = 0.0;
+        double axis2 = 0.0;
+        bool failed = false;
+        for (int tries = 0;; ++tries) {                    // the history repeats states: z must differ from the current state
+          bool need = snk && !failed && axis2 == 0.0;
+          if (need && tries > 1000) { failed = true; need = false; }   // (the reference exits here; the engine raises an error bit and rejects the move)
+          if (__builtin_amdgcn_ballot_w64(need) == 0ull) break;
+          if (need) {
+            const u32x4 bt = draw_block(p.seed, TAG_MH, stream, step, 0x0DE00001u + (uint32_t)tries);
+            const double* z = pick(u01(bt.v0));
+#pragma unroll
+            for (int e = 0; e < E; ++e) { zz[e] = z[pos + 64 * e]; ax[e] = xr[e] + zz[e] * (-1.0); }
+          }
+#pragma unroll
+          for (int e = 0; e < E; ++e) term[e] = ax[e] * ax[e];
+          chain_sum(term, need, axis2);
+        }
+        const bool go = snk && !failed;
+        double proj = 0.0, fz2 = 0.0;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          const double a = z1d[e] * gamma, b = z2d[e] * (-gamma);
+          const double diff = a + b;
+          term[e] = diff * ax[e];
+        }
+        chain_sum(term, go, proj);
+        if (go) proj = proj / axis2;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          const double t = ax[e] * proj;
+          const double y = xr[e] + t;
+          if (go) xde[e] = d + 64 * e < D ? y : 0.0;
+          const double f = y + zz[e] * (-1.0);
+          term[e] = f * f;
+        }
+        chain_sum(term, go, fz2);
+        if (go) de_hast = (dlog(fz2) - dlog(axis2)) * (double)(D - 1) / 2.0;
+        if (snk && failed) {
+          if (lead) atomicOr(p.err, 128);
+          de_hast = __builtin_nan("");
+#pragma unroll
+          for (int e = 0; e < E; ++e) xde[e] = d + 64 * e < D ? xr[e] : 0.0;
+        }
+        if (snk) dt = 1;
+      }
+      if (de_move) {
+        type = kmix + 10 * dt;     // proposal_distribution.cc:117
+        if (mode == 1 && live && lead) { p.de_hast[c] = de_hast; p.de_type[c] = dt; }
+      }
+    }
+  }
   double xn[E];
 #pragma unroll
   for (int e = 0; e < E; ++e)
-    xn[e] = (mode == 2 || hp) ? p.xprop[(size_t)c * DP + pos + 64 * e] : row[pos + 64 * e] + off[e];   // state::add (states.cc:205-214)
+    xn[e] = (mode == 2 || hp) ? p.xprop[(size_t)c * DP + pos + 64 * e] : de_move ? xde[e] : row[pos + 64 * e] + off[e];   // state::add (states.cc:205-214)
   // what the state is worth before enforcing: Q9 for a sum built by state::add (on an enforced zero state); a host-side
   // proposal brings its own validity (state::invalid())
   const bool valid0 = hp ? p.hvalid[c] != 0 : p.origin_valid != 0;
@@ -305,6 +417,10 @@ __device__ __forceinline__ void lanes_body(const Dev& p, double* lds_all, const 
     const double hast = p.hastings[c];
     if (hast != hast) accept = false;
     logH = hast + logH;
+  }
+  if (GEN && de_move) {                // the same for differential evolution's own ratio
+    if (de_hast != de_hast) accept = false;
+    logH = de_hast + logH;
   }
   if (accept && logH < 0) accept = dlog_u01(o0.v0) < logH;  // chain.cc:998-1001 (NaN stays accepted)
   (void)tbuf;

@@ -20,7 +20,7 @@ struct SweepSel {
   bool lean_ev; // uni, and plain but for evolving ladders (per-chain temperatures): the lean MFMA build that reads them
   bool callback;  // host-callback likelihood (propose / accept passes): general VALU kernel only
   bool host_prop; // host-side proposals (ptm_set_proposal_callback): the lanes kernel's general build, whatever the population
-  bool de;        // differential evolution drawn on the device (ptm_set_proposal_de): the general VALU kernel only
+  bool de;        // differential evolution drawn on the device (ptm_set_proposal_de): the general VALU kernel or the lanes kernel, not the MFMA kernels
 };
 #define PTM_DECL_DP(N)                                                                                              \
   hipError_t launch_sweep_##N(const Dev& p, SweepSel s, hipStream_t st);                                            \

@@ -2972,7 +2972,7 @@ class ptmcmc_sampler : public bayes_sampler {
     ptm_de_params deq;
     const long long de_rows = 2 + 2ll * std::max(Nevery, Nstep) / std::max(1, save_every);
     const double de_bytes = (double)de_rows * Nptc * std::max(1, nreplicas) * (8.0 * std::max(4, dim > 16 ? 32 : (dim > 8 ? 16 : (dim > 4 ? 8 : 4))) + 40.0);
-    const bool de_dev = !host && cprop->device_describe_de(deq) && dim <= 32 && de_bytes < 16e9 && de_rows < (1ll << 30);
+    const bool de_dev = !host && cprop->device_describe_de(deq) && dim <= 128 && de_bytes < 16e9 && de_rows < (1ll << 30);
     if (!host && cprop->device_describe_de(deq) && !de_dev) host = true;
     if (de_dev) {
       if (restarting && Nstep > 0) Ninit = chain_Ninit;   // (the device's initial rows are drawn again, the same ones: they are not in the checkpoint)

@@ -29,6 +29,11 @@ DE_CASES = [
     (32, 6, 2, E.PROP_DENSE, 1, 0.2, 10, 1, 30),     # 32 dimensions (rows in the matrix cores' layout)
     (3, 5, 7, E.PROP_DIAG, 3, 1.0, 40, 1, 60),       # snooker moves only
     (20, 4, 5, E.PROP_LOWER, 1, 0.0, 12, 2, 30),     # parallel moves only, padded dimensions
+    (32, 2, 64, E.PROP_DENSE, 1, 0.3, 10, 2, 30),    # 32 dimensions, a lane per chain
+    (3, 3, 128, E.PROP_DIAG, 1, 1.0, 40, 1, 40),     # snooker moves only, a lane per chain
+    (48, 4, 3, E.PROP_LOWER, 1, 0.3, 10, 2, 30),     # 33..64 dimensions: a wave per chain
+    (100, 3, 2, E.PROP_DENSE, 2, 0.4, 10, 1, 24),    # 65..128 dimensions: two dimensions per lane
+    (12, 16, 4, E.PROP_DIAG, 1, 0.2, 10, 6, 40),     # four chains per wave: snooker and parallel moves and Gaussians side by side in a wave
 ]
 
 
@@ -62,7 +67,13 @@ def test_differential_evolution_on_the_device_matches_the_oracle(D, Nt, W, kind,
     type codes -- states, counters, every saved row and every rung's MAP bit for bit the oracle's."""
     cap = 2 * steps + 8
     pr, eng, lad = _pair(D, Nt, W, kind, N, snooker, ninit, K, cap)
-    assert eng.sweep_kernel_name.startswith("sweep_kernel<"), eng.sweep_kernel_name
+    # whole waves per rung: the general kernel draws a chain's move on the chain's lane; small populations: a lane per dimension
+    assert eng.sweep_kernel_name.startswith("sweep_kernel<" if W % 64 == 0 else "sweep_lanes_kernel<"), eng.sweep_kernel_name
+    # ... and 9..32 dimensions of them step in the persistent ladder kernel's build with differential evolution (FL = 11)
+    on_ladder = W % 64 != 0 and 9 <= D <= 32
+    assert eng.step_kernel_name.startswith("ladder_persistent_kernel<") == on_ladder, eng.step_kernel_name
+    if on_ladder:
+        assert eng.step_kernel_name.endswith(", 11>"), eng.step_kernel_name
     done = 0
     for n in (1, 4, steps - 5):
         eng.step(n); eng.sync(); lad.pt_step(n)
@@ -85,6 +96,40 @@ def test_differential_evolution_on_the_device_matches_the_oracle(D, Nt, W, kind,
     if snooker > 0.0:
         assert 10 in seen, seen
     assert any(1 <= (v % 10) <= K for v in seen), seen
+    if on_ladder:
+        st = eng.ladder_stats()
+        assert st["launches"] > 0 and st["fallbacks"] == 0 and not st["disabled"], st
+    eng.close()
+
+
+@pytest.mark.parametrize("D,Nt,W,kind,snooker,K,steps", [
+    (12, 16, 4, E.PROP_DIAG, 0.2, 6, 60),
+    (32, 24, 2, E.PROP_DENSE, 0.3, 2, 40),
+    (20, 40, 3, E.PROP_LOWER, 0.1, 3, 40),
+    (6, 12, 3, E.PROP_DIAG, 0.3, 2, 60),       # (up to 8 dimensions: the two-launch path)
+])
+def test_differential_evolution_on_evolving_ladders(D, Nt, W, kind, snooker, K, steps):
+    """The reference sampler's defaults together: the default proposal set drawn on the device AND pry_temps after every accepted
+    exchange (chain.cc:1809-1846) -- 9..32 dimensions in one persistent launch per call (the ladder kernel's build FL = 15)."""
+    cap = 2 * steps + 8
+    pr, eng, lad = _pair(D, Nt, W, kind, 1, snooker, 12, K, cap)
+    eng.set_evolve_temps(0.01); lad.evolve_temps(0.01)
+    on_ladder = 9 <= D <= 32
+    assert eng.step_kernel_name.startswith("ladder_persistent_kernel<") == on_ladder, eng.step_kernel_name
+    if on_ladder:
+        assert eng.step_kernel_name.endswith(", 15>"), eng.step_kernel_name
+    done = 0
+    for n in (1, 7, steps - 8):
+        eng.step(n); eng.sync(); lad.pt_step(n)
+        done += n
+        PU.assert_same_state(eng, lad, "after %d PT steps" % done)
+        assert np.array_equal(eng.invtemps(), lad.betaw), done
+    PU.assert_same_history_and_map(eng, lad, cap)
+    lt = set(int(v) for v in np.unique(eng.last_type))
+    assert (0 in lt or 10 in lt) and any(1 <= v % 10 <= K for v in lt), lt
+    if on_ladder:
+        st = eng.ladder_stats()
+        assert st["launches"] > 0 and st["fallbacks"] == 0 and not st["disabled"], st
     eng.close()
 
 
