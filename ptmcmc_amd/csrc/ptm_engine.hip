@@ -1077,6 +1077,52 @@ static int flush_nhist(ptm_engine* e) {
 }
 
 // one fused MH sweep over local rungs [rung0, rung0 + nr); `last` closes the step (the step count is the RNG position)
+// host-callback likelihood, between the propose pass and the accept pass: the gated proposals to the host, the user's function on
+// them (the prior's first if it is a callback too), the new llikes back
+static int ensure_betaC(ptm_engine* e);
+static int callback_host_part(ptm_engine* e) {
+  const size_t Nc = e->Nc, DP = e->DP;
+  HIPCHK(copy_unless_shared(e->h_xprop.data(), e->xprop, Nc * DP * 8 + Nc, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  if (e->prior_cb) {
+    // host-evaluated prior: the valid proposals' log-priors, then the reference's prior gate on them -- want_like (chain.cc:980)
+    // with oldlprior = current_lpost - invtemp * current_llike (:973), rounded as the kernels round it
+    std::vector<double> hll(Nc), hlp(Nc), hbeta(Nc), out;
+    HIPCHK(hipMemcpy(hll.data(), e->ll, Nc * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(hlp.data(), e->lp, Nc * 8, hipMemcpyDeviceToHost));
+    { int rc2 = ensure_betaC(e); if (rc2) return rc2; }
+    if (e->betaC) HIPCHK(hipMemcpy(hbeta.data(), e->betaC, Nc * 8, hipMemcpyDeviceToHost));
+    std::vector<size_t> vp;
+    for (size_t c = 0; c < Nc; ++c)
+      if (e->h_gate[c] & 1) vp.push_back(c);
+    int rcp = call_user_prior(e, e->h_xprop, vp, out);
+    if (rcp) return rcp;
+    std::vector<double> lpn(Nc, -__builtin_inf());
+    for (size_t k = 0; k < vp.size(); ++k) {
+      const size_t c = vp[k];
+      const double beta = e->betaC ? hbeta[c] : e->h_beta[e->r0 + c / e->W];
+      const double bl = beta * hll[c];
+      const double cur_lpost = hlp[c] + bl;
+      const double oldlprior = cur_lpost - bl;
+      const double nl = out[k];
+      lpn[c] = nl;
+      const bool want = nl > -1e200 || nl - oldlprior > e->cfg.min_prior;
+      e->h_gate[c] = (unsigned char)(1 | (want ? 2 : 0));
+    }
+    HIPCHK(hipMemcpyAsync(e->lprior_new, lpn.data(), Nc * 8, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(copy_unless_shared(e->gate, e->h_gate, Nc, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));   // (lpn is a local)
+  }
+  std::vector<size_t> pick;
+  for (size_t c = 0; c < Nc; ++c)
+    if (e->h_gate[c] & 2) pick.push_back(c);
+  int rc = call_user(e, e->h_xprop, pick, e->h_llbatch);
+  if (rc) return rc;
+  for (size_t k = 0; k < pick.size(); ++k) e->h_llnew[pick[k]] = e->h_llbatch[k];
+  HIPCHK(copy_unless_shared(e->llike_new, e->h_llnew.data(), Nc * 8, hipMemcpyHostToDevice, e->stream));
+  return PTM_OK;
+}
+
 static int launch_sweep(ptm_engine* e, int rung0 = 0, int nr = -1, bool last = true) {
   Dev p = make_dev(e);
   if (nr < 0) nr = e->nloc - rung0;
@@ -1177,44 +1223,7 @@ static int launch_sweep(ptm_engine* e, int rung0 = 0, int nr = -1, bool last = t
     p.xprop = e->xprop; p.lprior_new = e->lprior_new; p.gate = e->gate; p.llike_new = e->llike_new;
     p.mode = 1;
     HIPCHK(launch(p));   // (the propose pass writes every chain's gate byte: 0 for the rungs that make no move)
-    HIPCHK(copy_unless_shared(e->h_xprop.data(), e->xprop, Nc * DP * 8 + Nc, hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipStreamSynchronize(e->stream));
-    if (e->prior_cb) {
-      // host-evaluated prior: the valid proposals' log-priors, then the reference's prior gate on them -- want_like (chain.cc:980)
-      // with oldlprior = current_lpost - invtemp * current_llike (:973), rounded as the kernels round it
-      std::vector<double> hll(Nc), hlp(Nc), hbeta(Nc), out;
-      HIPCHK(hipMemcpy(hll.data(), e->ll, Nc * 8, hipMemcpyDeviceToHost));
-      HIPCHK(hipMemcpy(hlp.data(), e->lp, Nc * 8, hipMemcpyDeviceToHost));
-      { int rc2 = ensure_betaC(e); if (rc2) return rc2; }
-      if (e->betaC) HIPCHK(hipMemcpy(hbeta.data(), e->betaC, Nc * 8, hipMemcpyDeviceToHost));
-      std::vector<size_t> vp;
-      for (size_t c = 0; c < Nc; ++c)
-        if (e->h_gate[c] & 1) vp.push_back(c);
-      int rcp = call_user_prior(e, e->h_xprop, vp, out);
-      if (rcp) return rcp;
-      std::vector<double> lpn(Nc, -__builtin_inf());
-      for (size_t k = 0; k < vp.size(); ++k) {
-        const size_t c = vp[k];
-        const double beta = e->betaC ? hbeta[c] : e->h_beta[e->r0 + c / e->W];
-        const double bl = beta * hll[c];
-        const double cur_lpost = hlp[c] + bl;
-        const double oldlprior = cur_lpost - bl;
-        const double nl = out[k];
-        lpn[c] = nl;
-        const bool want = nl > -1e200 || nl - oldlprior > e->cfg.min_prior;
-        e->h_gate[c] = (unsigned char)(1 | (want ? 2 : 0));
-      }
-      HIPCHK(hipMemcpyAsync(e->lprior_new, lpn.data(), Nc * 8, hipMemcpyHostToDevice, e->stream));
-      HIPCHK(copy_unless_shared(e->gate, e->h_gate, Nc, hipMemcpyHostToDevice, e->stream));
-      HIPCHK(hipStreamSynchronize(e->stream));   // (lpn is a local)
-    }
-    std::vector<size_t> pick;
-    for (size_t c = 0; c < Nc; ++c)
-      if (e->h_gate[c] & 2) pick.push_back(c);
-    int rc = call_user(e, e->h_xprop, pick, e->h_llbatch);
-    if (rc) return rc;
-    for (size_t k = 0; k < pick.size(); ++k) e->h_llnew[pick[k]] = e->h_llbatch[k];
-    HIPCHK(copy_unless_shared(e->llike_new, e->h_llnew.data(), Nc * 8, hipMemcpyHostToDevice, e->stream));
+    { const int rc = callback_host_part(e); if (rc) return rc; }
     p.mode = 2;
     HIPCHK(launch(p));
   }
@@ -1569,7 +1578,7 @@ extern "C" int ptm_sweep(ptm_engine* e, int n) {
 // two-launch path.  Returns the steps taken (0: not this engine's case), or a negative status.
 static int fused_steps(ptm_engine* e, int n) {
   static const bool fused_ok = [] { const char* v = getenv("PTM_FUSED"); return !(v && *v == '0'); }();
-  if (!fused_ok || e->DP > 16 || (long long)e->Nt * e->DP > 256 || e->cb || e->pcb || e->de_on || e->cfg.time_kernels) return 0;
+  if (!fused_ok || e->DP > 16 || (long long)e->Nt * e->DP > 256 || e->cb || e->pcb || e->cfg.time_kernels) return 0;
   if (e->evolve_rate > 0 && (e->W > 64 || e->evolve_cut >= 0)) return 0;   // (the new temperatures' chain-indexed image is then a separate launch)
   const bool evb = e->evolve_rate > 0 && e->beta_add;
   const size_t dlds = decide_lds_bytes(e->Nt, e->ms, e->Nt, e->evolve_rate > 0, evb);
@@ -2545,7 +2554,7 @@ extern "C" const char* ptm_step_kernel_name(ptm_engine* e) {
   if (!e) return "";
   static thread_local std::string name;
   char b[160];
-  const bool fused = e->DP <= 16 && (long long)e->Nt * e->DP <= 256 && !e->cb && !e->pcb && !e->de_on && !e->cfg.time_kernels && !(getenv("PTM_FUSED") && *getenv("PTM_FUSED") == '0') &&
+  const bool fused = e->DP <= 16 && (long long)e->Nt * e->DP <= 256 && !e->cb && !e->pcb && !e->cfg.time_kernels && !(getenv("PTM_FUSED") && *getenv("PTM_FUSED") == '0') &&
                      !(e->evolve_rate > 0 && (e->W > 64 || e->evolve_cut >= 0));
   if (e->nloc != e->Nt) snprintf(b, sizeof b, "(sharded: ptm_exchange_* / ptm_shard_step) decide_kernel + %s", ptm_sweep_kernel_name(e));
   else if (fused) snprintf(b, sizeof b, "ladder_steps_kernel<%d, %d, %d>", e->DP, e->prop_kind == PTM_PROP_DIAG ? KIND_DIAG : KIND_DENSE, (long long)e->Nt * e->DP <= 64 ? 64 : 256);

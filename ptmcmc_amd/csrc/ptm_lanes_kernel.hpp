@@ -222,6 +222,9 @@ __device__ __forceinline__ void lanes_body(const Dev& p, double* lds_all, const 
         if (saved - hr > p.hist.cap) atomicOr(p.err, 64);   // the ring has lost that row
         return p.hist.x + hist_slot(p.hist, hr, c) * DP;
       };
+      // (history rows are read past the L1: in a kernel that walks several steps -- ptm_fused_kernel.hpp -- the block wrote the newest
+      //  of them itself, and a neighbour chain's row may share the line)
+      auto hload = [](const double* q) { return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
       const u32x4 b0 = draw_block(p.seed, TAG_MH, stream, step, 0x0DE00000u);
       const bool snk = de_move && p.de_snooker > u01(b0.v0);
       const double* z1 = row;
@@ -229,7 +232,7 @@ __device__ __forceinline__ void lanes_body(const Dev& p, double* lds_all, const 
       if (de_move) { z1 = pick(u01(b0.v2)); z2 = pick(u01(b0.v3)); }
       double xr[E], z1d[E], z2d[E];
 #pragma unroll
-      for (int e = 0; e < E; ++e) { xr[e] = row[pos + 64 * e]; z1d[e] = z1[pos + 64 * e]; z2d[e] = z2[pos + 64 * e]; }
+      for (int e = 0; e < E; ++e) { xr[e] = row[pos + 64 * e]; z1d[e] = hload(z1 + pos + 64 * e); z2d[e] = hload(z2 + pos + 64 * e); }
       if (de_move && !snk) {                               // draw_standard
         const double gamma = u01(b0.v1) < p.de_gamma_one ? 1.0 : p.de_gamma_std;
 #pragma unroll
@@ -268,7 +271,7 @@ __device__ __forceinline__ void lanes_body(const Dev& p, double* lds_all, const 
             const u32x4 bt = draw_block(p.seed, TAG_MH, stream, step, 0x0DE00001u + (uint32_t)tries);
             const double* z = pick(u01(bt.v0));
 #pragma unroll
-            for (int e = 0; e < E; ++e) { zz[e] = z[pos + 64 * e]; ax[e] = xr[e] + zz[e] * (-1.0); }
+            for (int e = 0; e < E; ++e) { zz[e] = hload(z + pos + 64 * e); ax[e] = xr[e] + zz[e] * (-1.0); }
           }
 #pragma unroll
           for (int e = 0; e < E; ++e) term[e] = ax[e] * ax[e];

@@ -33,7 +33,7 @@ DE_CASES = [
     (3, 3, 128, E.PROP_DIAG, 1, 1.0, 40, 1, 40),     # snooker moves only, a lane per chain
     (48, 4, 3, E.PROP_LOWER, 1, 0.3, 10, 2, 30),     # 33..64 dimensions: a wave per chain
     (100, 3, 2, E.PROP_DENSE, 2, 0.4, 10, 1, 24),    # 65..128 dimensions: two dimensions per lane
-    (12, 16, 4, E.PROP_DIAG, 1, 0.2, 10, 6, 40),     # four chains per wave: snooker and parallel moves and Gaussians side by side in a wave
+    (12, 24, 4, E.PROP_DIAG, 1, 0.2, 10, 6, 40),     # four chains per wave: snooker and parallel moves and Gaussians side by side in a wave
 ]
 
 
@@ -70,8 +70,12 @@ def test_differential_evolution_on_the_device_matches_the_oracle(D, Nt, W, kind,
     # whole waves per rung: the general kernel draws a chain's move on the chain's lane; small populations: a lane per dimension
     assert eng.sweep_kernel_name.startswith("sweep_kernel<" if W % 64 == 0 else "sweep_lanes_kernel<"), eng.sweep_kernel_name
     # ... and 9..32 dimensions of them step in the persistent ladder kernel's build with differential evolution (FL = 11)
-    on_ladder = W % 64 != 0 and 9 <= D <= 32
+    # (a ladder whose rungs x padded dimensions fit 256 lanes: many steps per launch of the fused small-ladder kernel)
+    DPad = 4 if D <= 4 else 8 if D <= 8 else 16 if D <= 16 else 32
+    fused = D <= 16 and Nt * DPad <= 256
+    on_ladder = W % 64 != 0 and 9 <= D <= 32 and not fused
     assert eng.step_kernel_name.startswith("ladder_persistent_kernel<") == on_ladder, eng.step_kernel_name
+    assert eng.step_kernel_name.startswith("ladder_steps_kernel<") == fused, eng.step_kernel_name
     if on_ladder:
         assert eng.step_kernel_name.endswith(", 11>"), eng.step_kernel_name
     done = 0
@@ -103,7 +107,8 @@ def test_differential_evolution_on_the_device_matches_the_oracle(D, Nt, W, kind,
 
 
 @pytest.mark.parametrize("D,Nt,W,kind,snooker,K,steps", [
-    (12, 16, 4, E.PROP_DIAG, 0.2, 6, 60),
+    (12, 20, 4, E.PROP_DIAG, 0.2, 6, 60),
+    (12, 16, 2, E.PROP_LOWER, 0.2, 3, 40),     # (rungs x padded dimensions <= 256: the fused small-ladder kernel)
     (32, 24, 2, E.PROP_DENSE, 0.3, 2, 40),
     (20, 40, 3, E.PROP_LOWER, 0.1, 3, 40),
     (6, 12, 3, E.PROP_DIAG, 0.3, 2, 60),       # (up to 8 dimensions: the two-launch path)
@@ -114,8 +119,11 @@ def test_differential_evolution_on_evolving_ladders(D, Nt, W, kind, snooker, K, 
     cap = 2 * steps + 8
     pr, eng, lad = _pair(D, Nt, W, kind, 1, snooker, 12, K, cap)
     eng.set_evolve_temps(0.01); lad.evolve_temps(0.01)
-    on_ladder = 9 <= D <= 32
+    DPad = 4 if D <= 4 else 8 if D <= 8 else 16 if D <= 16 else 32
+    fused = D <= 16 and Nt * DPad <= 256
+    on_ladder = 9 <= D <= 32 and not fused
     assert eng.step_kernel_name.startswith("ladder_persistent_kernel<") == on_ladder, eng.step_kernel_name
+    assert eng.step_kernel_name.startswith("ladder_steps_kernel<") == fused, eng.step_kernel_name
     if on_ladder:
         assert eng.step_kernel_name.endswith(", 15>"), eng.step_kernel_name
     done = 0
