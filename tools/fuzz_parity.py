@@ -1,6 +1,6 @@
 """Randomised bit-exact comparison of the engine with the CPU checker (test infrastructure: imports tests/): shapes, proposal
 kinds, boundaries, priors, a mean, one-dimensional moves, evolving ladders with and without the posterior-ordering cut, drawn
-scale mixtures, the history ring with MAP tracking -- drawn from a seeded generator; a few PT steps and plain sweeps each.  Stops at the first difference with the case printed.
+scale mixtures, the history ring with MAP tracking, differential evolution from the device history -- drawn from a seeded generator; a few PT steps and plain sweeps each.  Stops at the first difference with the case printed.
 usage (GPU box): python tools/fuzz_parity.py [seconds] [seed]"""
 import math
 import os
@@ -53,16 +53,32 @@ while time.time() - t0 < budget:
     cut = -1.0 if rng.random() < 0.6 else float(rng.choice([0.0, 1.0, 3.0]))
     K = 0 if rng.random() < 0.65 else int(rng.choice([1, 2, 4]))                         # a scale mixture (the sampler's default Gaussian recipe)
     hist = 0 if (rng.random() < 0.65 or Nt * W * D > 3e5 or D > 128) else int(rng.choice([1, 2, 3]))   # history + MAP, every hist-th add saved
-    case = dict(D=D, Nt=Nt, W=W, kind=kind, sr=sr, odf=odf, flav=flav, mean=mean is not None, ev=ev, cut=cut, K=K, hist=hist)
+    # differential evolution as the first member of the set (needs every rung's history; 12 D initial rows make it ready, none: passed over)
+    de = bool(hist) and D <= 128 and rng.random() < 0.6
+    if de and not K:
+        K = int(rng.choice([1, 2, 6]))
+    de_init = int(rng.choice([0, 12])) * D if de else 0
+    de_snk = float(rng.choice([0.0, 0.1, 0.5, 1.0])) if de else 0.0
+    case = dict(D=D, Nt=Nt, W=W, kind=kind, sr=sr, odf=odf, flav=flav, mean=mean is not None, ev=ev, cut=cut, K=K, hist=hist, de=de, de_init=de_init, de_snk=de_snk)
     try:
         pr, eng, lad = PU.make_pair(D, Nt, W, 1e3, kind=kind, swap_rate=sr, one_d_frac=odf, bounds=bounds, prior=prior, mean=mean, x0=x0,
                                     add_every_n=max(1, hist), history_cap=32 if hist else 0)
         if K:
             shares = 2.0 ** np.arange(1, K + 1)
-            cum = np.tile(np.cumsum(shares) / shares.sum(), (Nt, 1)); cum[:, -1] = 1.0
-            scales = np.tile(2.0 ** -np.arange(K)[::-1], (Nt, 1))
-            odfs = np.tile(np.where(np.arange(K) % 2 == 0, odf or 0.0, 0.0), (Nt, 1))
+            cumk = np.cumsum(shares) / shares.sum()
+            sck = 2.0 ** -np.arange(K)[::-1]
+            odk = np.where(np.arange(K) % 2 == 0, odf or 0.0, 0.0)
+            if de:   # the sampler's default set: differential evolution first (negative scale), then the Gaussians
+                cumk, sck, odk = np.concatenate([[0.7], 0.7 + 0.3 * cumk]), np.concatenate([[-1.0], sck]), np.concatenate([[0.0], odk])
+            cum = np.tile(cumk, (Nt, 1)); cum[:, -1] = 1.0
+            scales, odfs = np.tile(sck, (Nt, 1)), np.tile(odk, (Nt, 1))
             eng.set_proposal_mixture(cum, scales, odfs); lad.set_mixture(cum, scales, odfs)
+        if de:
+            init = None
+            if de_init:
+                init = rng.uniform(-1.0, 1.0, size=(de_init, Nt * W, D)) * 0.3
+            eng.set_proposal_de(de_snk, 0.3, 4.0, 0.0, init_rows=init)
+            lad.set_de(de_snk, 0.3, 4.0, 0.0, init_rows=None if init is None else np.stack([PU.to_oracle_order(init[k], Nt, W) for k in range(de_init)]))
         if ev:
             eng.set_evolve_temps(ev, lpost_cut=cut); lad.evolve_temps(ev, cut)
         for k in range(2):
