@@ -49,3 +49,29 @@ for D, Nt, W, kind, sr, ev, what in cases:
     print("%s: D=%d %dx%d, %d steps bit-identical; kernel %s; MH accept %.3f, swap accept %.3f" %
           (what, D, Nt, W, steps_case, eng.sweep_kernel_name, (eng.naccept.sum() - eng.Nc) / max(1, eng.ntries.sum() - eng.Nc), a.sum() / max(1, t.sum())) + ("  [step kernel %s]" % eng.step_kernel_name if what.startswith("persistent") else ""), flush=True)
     eng.close()
+
+# differential evolution from the device history (round 4): the sampler's default set on an evolving ladder with history and MAP, in the
+# persistent ladder kernel (FL 15), the lanes kernel (64-dimensional rows) and the general kernel; long runs fill the ring, reach the
+# snooker move's retries and the early rows' picks
+import test_gpu_de as TD
+de_steps = min(steps, 1500)
+for D, Nt, W, kind, snk, ign, what in [(20, 48, 2, E.PROP_DENSE, 0.1, 0.0, "differential evolution, persistent ladder kernel"),
+                                       (40, 8, 2, E.PROP_DIAG, 0.3, 0.2, "differential evolution, lanes kernel, 64-dim rows"),
+                                       (6, 40, 64, E.PROP_LOWER, 0.1, 0.0, "differential evolution, general kernel")]:
+    cap = 2 * de_steps + 8
+    pr, eng, lad = TD._pair(D, Nt, W, kind, 1, snk, 12, 6, cap, de_share=0.8, ignore=ign)
+    eng.set_evolve_temps(0.01); lad.evolve_temps(0.01)
+    t0 = time.time()
+    done = 0
+    while done < de_steps:
+        n = min(250, de_steps - done)
+        eng.step(n); eng.sync(); lad.pt_step(n)
+        done += n
+        PU.assert_same_state(eng, lad, "%s after %d steps" % (what, done))
+        assert np.array_equal(eng.invtemps(), lad.betaw)
+        print("  %-28s %6d steps ok (%.0fs)" % (what, done, time.time() - t0), flush=True)
+    PU.assert_same_history_and_map(eng, lad, cap)
+    lt = np.unique(eng.last_type)
+    print("%s: D=%d %dx%d, %d steps bit-identical (states, every saved row, MAPs, temperatures); step kernel %s; accepted types %s" %
+          (what, D, Nt, W, de_steps, eng.step_kernel_name, lt.tolist()), flush=True)
+    eng.close()
