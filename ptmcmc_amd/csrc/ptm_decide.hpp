@@ -424,9 +424,10 @@ __device__ __forceinline__ void decide_body(const Decide& p, unsigned char* smem
     // monotone in S, so a trial that passes at S0 passes for every S of the interval and one that fails at the upper end fails
     // everywhere -- and as long as it also gives the same answer by the first-trial form (nothing pried yet: no S at all) the
     // decision is the sequential walk's, whatever came before it.  Only a ladder with a trial inside that window (about one
-    // in fifty at 1024 rungs) takes the sequential walk below.  (Not with history / MAP tracking: their rows want S itself.)
+    // in fifty at 1024 rungs) takes the sequential walk below.  (History / MAP tracking want the normaliser every pick SAW: with the
+    // decisions known it is a sum of the accepted picks' increases in pick order -- one lane's chain of additions, no trial on it.)
     bool walked = false;
-    if (!cutmode && !evb) {
+    if (!cutmode) {
       const double c1 = 1 - p.beta_w[(size_t)w * Nt + Nt - 1];   // chain.cc:1833
       const double grow = 1.0 + p.evolve_rate;
       if (lane == 0) {
@@ -474,6 +475,25 @@ __device__ __forceinline__ void decide_body(const Decide& p, unsigned char* smem
           if (tacc[t]) { gap[ti[t]] = tgap[t] * grow; atomicAdd(&cnt[3], 1); }   // chain.cc:1829
         __syncthreads();
         if (lane == 0) ev[1] = (double)cnt[3];
+        if (evb && lane == 0) {
+          // what the sequential walk would have noted per pick: the normaliser it saw (0: nothing pried yet), what it added
+          double S = ev[0];
+          int npry = 0;
+          for (int t0 = 0; t0 < nl; t0 += 8) {   // (operands first: a lone lane pays ~100 cycles per dependent LDS read)
+            double g8[8];
+            bool a8[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { g8[j] = t0 + j < nl ? tgap[t0 + j] : 0.0; a8[j] = t0 + j < nl && tacc[t0 + j] != 0; }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              if (t0 + j >= nl) break;
+              tS[t0 + j] = npry ? S : 0.0;
+              double inc = 0.0;
+              if (a8[j]) { const double sn = g8[j] * grow; inc = sn - g8[j]; S = S + inc; ++npry; }   // chain.cc:1829
+              tdl[t0 + j] = inc;
+            }
+          }
+        }
         walked = true;
       } else {
         for (int t = lane; t < nl; t += DECIDE_THREADS) tacc[t] = 0;
