@@ -41,6 +41,7 @@
 #include <thread>
 #include <valarray>
 #include <vector>
+#include <sched.h>
 #include <sys/stat.h>
 #include <sys/types.h>
 
@@ -1592,6 +1593,7 @@ class bayes_likelihood : public probability_function, public Optioned {  // baye
   void* user_object;
   bool evaluate_log_registered;
   double best_post;
+  std::atomic<double> best_seen;   // best_post as the evaluating threads may read it without the mutex (it only ever grows)
   state best;
   std::mutex best_mutex;
   std::vector<double> likelyScales;
@@ -1602,13 +1604,14 @@ class bayes_likelihood : public probability_function, public Optioned {  // baye
  public:
   bool check_posterior;
   bayes_likelihood() : probability_function(nullptr), user_evaluate_log(nullptr), user_object(nullptr),
-                       evaluate_log_registered(false), best_post(-INFINITY), have_scales(false), check_posterior(true) {}
+                       evaluate_log_registered(false), best_post(-INFINITY), best_seen(-INFINITY), have_scales(false), check_posterior(true) {}
   ~bayes_likelihood() { for (auto p : proposals) delete p; }
   bayes_likelihood(const bayes_likelihood&) = delete;
   void addOptions(Options& opt, const std::string& prefix = "") override { Optioned::addOptions(opt, prefix); }
   virtual void setup() {}   // the minimal interface has nothing to set up after basic_setup (bayesian.hh:394-405 is for data + signal)
   virtual void reset() {    // bayesian.hh:407-412
     best_post = -INFINITY;
+    best_seen.store(-INFINITY);
     if (space) best = state(space, space->size()).scalar_mult(0);
   }
   virtual state bestState() { return best; }
@@ -1663,8 +1666,11 @@ class bayes_likelihood : public probability_function, public Optioned {  // baye
     if (check_posterior) {
       const double lprior = nativePrior ? nativePrior->evaluate_log(s) : 0.0;
       const double post = result + lprior;
-      std::lock_guard<std::mutex> lk(best_mutex);
-      if (!(post <= best_post)) { best_post = post; best = s; }
+      // (the mutex only for a state that may be a new best: sixteen threads taking it for every evaluation evaluate one after the other)
+      if (!(post <= best_seen.load(std::memory_order_relaxed))) {
+        std::lock_guard<std::mutex> lk(best_mutex);
+        if (!(post <= best_post)) { best_post = post; best = s; best_seen.store(post, std::memory_order_relaxed); }   // (a NaN sticks, as in the unguarded form)
+      }
       if (!std::isfinite(post)) {
         if (!(post < 0)) std::cout << "Logpost is NAN!\n  params=" << s.get_string() << "\n  like=" << result << "  post=" << post << std::endl;
         result = -INFINITY;
@@ -1686,12 +1692,12 @@ class bayes_likelihood : public probability_function, public Optioned {  // baye
         out[k] = l->evaluate_log(s);
       }
     };
-    int nt = l->eval_threads > 0 ? l->eval_threads : (int)std::thread::hardware_concurrency();
+    int nt = l->eval_threads > 0 ? l->eval_threads : usable_cpus();
     if (nt > n / 8) nt = n / 8;      // at least 8 states per thread
     // starting and joining threads costs ~50 us: a batch that the measured cost per evaluation prices below ~4 such
     // units stays on this thread (eval_threads == 0 only; an explicit thread count is obeyed)
     static const double pool_from_ns = [] { const char* v = getenv("PTM_EVAL_POOL_NS"); return v && *v ? atof(v) : 200e3; }();   // (A/B timing)
-    if (l->eval_threads <= 0 && l->eval_ns >= 0 && l->eval_ns * n < pool_from_ns) nt = 1;
+    if (l->eval_threads <= 0 && l->eval_ns >= 0 && (l->eval_ns * n < pool_from_ns || l->pool_off)) nt = 1;
     if (nt <= 1) {
       const auto t0 = std::chrono::steady_clock::now();
       work(0, n);
@@ -1701,12 +1707,46 @@ class bayes_likelihood : public probability_function, public Optioned {  // baye
     }
     if (!l->pool) l->pool.reset(new eval_pool);
     l->pool->resize(nt - 1);   // the calling thread works too
+    const auto t0 = std::chrono::steady_clock::now();
     l->pool->run(n, (n + 4 * nt - 1) / (4 * nt), work);
+    // does the pool pay on this machine?  (a container may show more hardware threads than it lets the process use; a likelihood may
+    // serialise itself.)  Three batches in a row that cost more per evaluation than 0.7 of this thread alone: no pool from then on.
+    if (l->eval_threads <= 0 && l->eval_ns > 0 && n > 0) {
+      const double per = std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - t0).count() / n;
+      if (per > 0.7 * l->eval_ns) { if (++l->pool_bad >= 3) l->pool_off = true; }
+      else l->pool_bad = 0;
+    }
+  }
+  // the processors this process may really use: hardware threads, cut by its affinity mask and by a cgroup CPU quota
+  // (PTM_EVAL_THREADS overrides)
+  static int usable_cpus() {
+    static const int n = [] {
+      int c = (int)std::thread::hardware_concurrency();
+      if (c < 1) c = 1;
+#ifdef __linux__
+      cpu_set_t set;
+      if (sched_getaffinity(0, sizeof set, &set) == 0) { const int k = CPU_COUNT(&set); if (k > 0 && k < c) c = k; }
+      {
+        std::ifstream f2("/sys/fs/cgroup/cpu.max");   // cgroup v2: "<quota|max> <period>"
+        std::string q;
+        long long per = 0;
+        if (f2 >> q >> per && q != "max" && per > 0) { const long long k = (atoll(q.c_str()) + per - 1) / per; if (k >= 1 && k < c) c = (int)k; }
+        std::ifstream fq("/sys/fs/cgroup/cpu/cpu.cfs_quota_us"), fp("/sys/fs/cgroup/cpu/cpu.cfs_period_us");   // cgroup v1
+        long long q1 = 0, p1 = 0;
+        if (fq >> q1 && fp >> p1 && q1 > 0 && p1 > 0) { const long long k = (q1 + p1 - 1) / p1; if (k >= 1 && k < c) c = (int)k; }
+      }
+#endif
+      if (const char* v = getenv("PTM_EVAL_THREADS")) { const int k = atoi(v); if (k >= 1) c = k; }
+      return c;
+    }();
+    return n;
   }
 
  private:
   int eval_threads = 0;   // 0: all hardware threads
   double eval_ns = 0;     // running estimate of one evaluation's cost (the first batch runs serially and measures it)
+  int pool_bad = 0;       // batches in a row that the pool made no faster
+  bool pool_off = false;  // ... three of them: this likelihood stays on the calling thread
   std::unique_ptr<eval_pool> pool;
 
  public:
