@@ -125,13 +125,31 @@ def cpu_baseline(problem, budget_s=15.0):
     return cpu_port(problem, budget_s)   # fallback: the C restatement, all host cores
 
 
+def usable_cpus():
+    """the processors this process may really use: its affinity mask cut by a cgroup CPU quota (a GPU box shows 256 hardware
+    threads to a container that may use 16 of them: more OpenMP threads than that only take turns)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]          # cgroup v2
+        if q != "max" and int(per) > 0:
+            n = min(n, max(1, -(-int(q) // int(per))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())    # cgroup v1
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and per > 0:
+                n = min(n, max(1, -(-q // per)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def cpu_port(problem, budget_s=8.0):
     """the oracle's C restatement of the same step (oracle/ptm_oracle.c), OpenMP over chains on ALL host cores: what a
     straightforward multi-core CPU implementation with a counter-based RNG reaches on this box"""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
-    ncore = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
-    ncore = max(1, min(ncore, 64))
+    ncore = max(1, min(usable_cpus(), 64))
     W = 4
     pb = O.Problem(D)
     pb.set_bounds([0] * D, [0] * D, [0.0] * D, [0.0] * D)
