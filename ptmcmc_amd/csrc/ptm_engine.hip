@@ -2543,7 +2543,8 @@ extern "C" const char* ptm_sweep_kernel_name(ptm_engine* e) {
   else if ((e->DP == 64 || e->DP == 128) && s.uni && e->all_uniform && (!e->has_bounds || e->bounds_box) && !e->has_mean && !e->any_oned && e->mix_K == 0 && !s.callback &&
            !s.host_prop && !e->hist.rungs && !e->map.rungs && !(fv && *fv && *fv != '0'))
     snprintf(b, sizeof b, "sweep_mfma%d_kernel<%d, %s, %s>", e->DP, s.kind == KIND_DIAG ? KIND_LOWER : s.kind, e->has_bounds ? "true" : "false", e->betaC ? "true" : "false");
-  else if (e->DP >= 64 || s.host_prop || (!s.uni && !getenv("PTM_FORCE_VALU") && (long long)e->Nc * e->DP <= (e->DP >= 16 ? PTM_LANES_MAX : 4096ll * e->DP)))
+  else if (e->DP >= 64 || s.host_prop || (!getenv("PTM_FORCE_VALU") && ((!s.uni && (long long)e->Nc * e->DP <= (e->DP >= 16 ? PTM_LANES_MAX : 4096ll * e->DP)) ||
+                                                                           (s.uni && s.de && e->DP >= 16 && (long long)e->Nc * e->DP <= (e->DP >= 32 ? (1ll << 21) : (1ll << 19))))))   // (launch_kind's rule)
     snprintf(b, sizeof b, "sweep_lanes_kernel<%d, %d, %s>", e->DP, s.kind, s.plain ? "false" : "true");
   else snprintf(b, sizeof b, "sweep_kernel<%d, %d, %s, %s>", e->DP, s.kind, s.uni ? "true" : "false", s.simple ? "true" : "false");
   e->kname = b;

@@ -29,7 +29,8 @@ DE_CASES = [
     (32, 6, 2, E.PROP_DENSE, 1, 0.2, 10, 1, 30),     # 32 dimensions (rows in the matrix cores' layout)
     (3, 5, 7, E.PROP_DIAG, 3, 1.0, 40, 1, 60),       # snooker moves only
     (20, 4, 5, E.PROP_LOWER, 1, 0.0, 12, 2, 30),     # parallel moves only, padded dimensions
-    (32, 2, 64, E.PROP_DENSE, 1, 0.3, 10, 2, 30),    # 32 dimensions, a lane per chain
+    (32, 2, 64, E.PROP_DENSE, 1, 0.3, 10, 2, 30),    # 32 dimensions, whole waves per rung (a lane per dimension all the same: no matrix cores with differential evolution)
+    (7, 3, 64, E.PROP_LOWER, 2, 0.3, 12, 2, 40),     # a lane per chain
     (3, 3, 128, E.PROP_DIAG, 1, 1.0, 40, 1, 40),     # snooker moves only, a lane per chain
     (48, 4, 3, E.PROP_LOWER, 1, 0.3, 10, 2, 30),     # 33..64 dimensions: a wave per chain
     (100, 3, 2, E.PROP_DENSE, 2, 0.4, 10, 1, 24),    # 65..128 dimensions: two dimensions per lane
@@ -67,8 +68,9 @@ def test_differential_evolution_on_the_device_matches_the_oracle(D, Nt, W, kind,
     type codes -- states, counters, every saved row and every rung's MAP bit for bit the oracle's."""
     cap = 2 * steps + 8
     pr, eng, lad = _pair(D, Nt, W, kind, N, snooker, ninit, K, cap)
-    # whole waves per rung: the general kernel draws a chain's move on the chain's lane; small populations: a lane per dimension
-    assert eng.sweep_kernel_name.startswith("sweep_kernel<" if W % 64 == 0 else "sweep_lanes_kernel<"), eng.sweep_kernel_name
+    # whole waves per rung of up to 8 dimensions (and big populations): the general kernel draws a chain's move on the chain's lane;
+    # everything else: a lane per dimension
+    assert eng.sweep_kernel_name.startswith("sweep_kernel<" if (W % 64 == 0 and D <= 8) else "sweep_lanes_kernel<"), eng.sweep_kernel_name
     # ... and 9..32 dimensions of them step in the persistent ladder kernel's build with differential evolution (FL = 11)
     # (a ladder whose rungs x padded dimensions fit 256 lanes: many steps per launch of the fused small-ladder kernel)
     DPad = 4 if D <= 4 else 8 if D <= 8 else 16 if D <= 16 else 32
