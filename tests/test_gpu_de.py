@@ -31,6 +31,7 @@ DE_CASES = [
     (20, 4, 5, E.PROP_LOWER, 1, 0.0, 12, 2, 30),     # parallel moves only, padded dimensions
     (32, 2, 64, E.PROP_DENSE, 1, 0.3, 10, 2, 30),    # 32 dimensions, whole waves per rung (a lane per dimension all the same: no matrix cores with differential evolution)
     (7, 3, 64, E.PROP_LOWER, 2, 0.3, 12, 2, 40),     # a lane per chain
+    (20, 40, 64, E.PROP_LOWER, 1, 0.2, 10, 2, 24),   # whole waves per rung, too many workgroups for the persistent kernel: exchange kernel + lanes kernel
     (3, 3, 128, E.PROP_DIAG, 1, 1.0, 40, 1, 40),     # snooker moves only, a lane per chain
     (48, 4, 3, E.PROP_LOWER, 1, 0.3, 10, 2, 30),     # 33..64 dimensions: a wave per chain
     (100, 3, 2, E.PROP_DENSE, 2, 0.4, 10, 1, 24),    # 65..128 dimensions: two dimensions per lane
@@ -75,7 +76,8 @@ def test_differential_evolution_on_the_device_matches_the_oracle(D, Nt, W, kind,
     # (a ladder whose rungs x padded dimensions fit 256 lanes: many steps per launch of the fused small-ladder kernel)
     DPad = 4 if D <= 4 else 8 if D <= 8 else 16 if D <= 16 else 32
     fused = D <= 16 and Nt * DPad <= 256
-    on_ladder = W % 64 != 0 and 9 <= D <= 32 and not fused
+    # (the persistent kernel: any population whose grid -- walkers x workgroups per ladder -- is resident at once: a workgroup per CU)
+    on_ladder = 9 <= D <= 32 and not fused and W * -(-Nt // (256 // DPad)) <= 256
     assert eng.step_kernel_name.startswith("ladder_persistent_kernel<") == on_ladder, eng.step_kernel_name
     assert eng.step_kernel_name.startswith("ladder_steps_kernel<") == fused, eng.step_kernel_name
     if on_ladder:

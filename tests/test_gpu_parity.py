@@ -168,6 +168,11 @@ SWEEP_CASES = [
     (32, 7, 64, 1e3, E.PROP_DIAG, None),     # diagonal sigmas through the MFMA kernel (as the diagonal matrix they are)
     (19, 5, 128, 1e2, E.PROP_DIAG, 0.5),     # ... with one-dimensional moves: the sampler's default Gaussian flavour
     (27, 5, 192, 1e2, E.PROP_DENSE, None),
+    # (populations small enough for one workgroup per CU step in the persistent ladder kernel; these keep the MFMA kernel in PT steps)
+    (32, 16, 320, 1e6, E.PROP_LOWER, None),
+    (21, 6, 384, 1e3, E.PROP_LOWER, None),
+    (32, 8, 320, 1e3, E.PROP_DENSE, None),
+    (19, 5, 320, 1e2, E.PROP_DIAG, 0.5),
     (16, 12, 64, 1e3, E.PROP_DIAG, 0.5),     # the sampler's default Gaussian flavour: diagonal + 1-D moves
     (32, 9, 3, 1e3, E.PROP_DENSE, None),     # lanes kernel (a lane per dimension: fewer than 64 walkers per rung), dense
     (13, 11, 5, 1e2, E.PROP_DIAG, None),     # lanes kernel, 13 -> 16 dimensions, diagonal; 55 chains: a ragged last wave
@@ -248,7 +253,7 @@ def test_pt_steps_bit_exact(D, Nt, W, tmax, kind, odf):
 def test_mfma_kernel_with_a_tight_prior_box(D):
     """The MFMA kernels' box test (ballots over the four lanes of a chain): a uniform prior so narrow that a large share
     of the proposals leaves it on some dimension; accept stream, states and counters must still match the oracle."""
-    Nt, W = (6, 128) if D == 32 else (4, 64)
+    Nt, W = (6, 320) if D == 32 else (4, 64)   # (320 walkers: too many workgroups for the persistent ladder kernel, the MFMA kernel sweeps)
     rng = np.random.default_rng(12)
     prior = ([1] * D, list(rng.uniform(-0.2, 0.2, D)), list(rng.uniform(0.8, 1.6, D)))   # uniform: centers, halfwidths
     pr, eng, lad = PU.make_pair(D, Nt, W, 1e4, kind=E.PROP_LOWER, prior=prior, swap_rate=0.3)
@@ -724,7 +729,7 @@ def test_mfma_kernel_general_state_space_and_priors(kind, odf, with_mean, all_un
 def test_mfma_kernel_limit_bounds_with_uniform_prior(kind, odf, with_mean):
     """The usual real-world state space -- uniform priors, `limit` / open boundaries -- has its own build of the MFMA
     kernel (enforcing is a box test); narrow limits so that a good share of the proposals is invalid."""
-    D, Nt, W = 30, 6, 128
+    D, Nt, W = 30, 6, 320   # (more workgroups than the persistent ladder kernel holds: the MFMA kernel's box-bounds build sweeps)
     rng = np.random.default_rng(33)
     blo = [1 if d % 3 else 0 for d in range(D)]
     bhi = [1 if d % 2 else 0 for d in range(D)]

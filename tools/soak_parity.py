@@ -13,9 +13,9 @@ import parity_util as PU
 from ptmcmc_amd import engine as E
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 4000
-cases = [(6, 12, 64, E.PROP_DENSE, 0.3, 0.02, "general kernel"), (5, 9, 5, E.PROP_DENSE, 0.3, 0.02, "lanes kernel (8)"),
+cases = [(6, 40, 64, E.PROP_DENSE, 0.3, 0.02, "general kernel"), (5, 9, 5, E.PROP_DENSE, 0.3, 0.02, "lanes kernel (8)"),
          (14, 24, 3, E.PROP_LOWER, 0.2, 0.01, "lanes kernel"),
-         (32, 10, 64, E.PROP_LOWER, 0.3, 0.01, "MFMA kernel"), (40, 8, 2, E.PROP_DIAG, 0.4, 0.0, "lanes kernel, 64-dim rows"),
+         (32, 10, 320, E.PROP_LOWER, 0.3, 0.01, "MFMA kernel"), (40, 8, 2, E.PROP_DIAG, 0.4, 0.0, "lanes kernel, 64-dim rows"),
          (90, 6, 2, E.PROP_LOWER, 0.4, 0.01, "lanes kernel, 128-dim rows"),
          (32, 6, 1024, E.PROP_LOWER, 0.3, 0.0, "MFMA kernel, compacted"), (28, 6, 1024, E.PROP_DENSE, 0.3, 0.01, "MFMA kernel, box-bounds build, compacted")]
 # the persistent ladder kernel (round 4): its plain build, the evolving one, and the one with everything the sampler switches on
@@ -47,7 +47,7 @@ for D, Nt, W, kind, sr, ev, what in cases:
         PU.assert_same_history_and_map(eng, lad, 2 * steps // 50 + 8)
     t, a = eng.swap_counts()
     print("%s: D=%d %dx%d, %d steps bit-identical; kernel %s; MH accept %.3f, swap accept %.3f" %
-          (what, D, Nt, W, steps_case, eng.sweep_kernel_name, (eng.naccept.sum() - eng.Nc) / max(1, eng.ntries.sum() - eng.Nc), a.sum() / max(1, t.sum())) + ("  [step kernel %s]" % eng.step_kernel_name if what.startswith("persistent") else ""), flush=True)
+          (what, D, Nt, W, steps_case, eng.sweep_kernel_name, (eng.naccept.sum() - eng.Nc) / max(1, eng.ntries.sum() - eng.Nc), a.sum() / max(1, t.sum())) + "  [step kernel %s]" % eng.step_kernel_name, flush=True)
     eng.close()
 
 # differential evolution from the device history (round 4): the sampler's default set on an evolving ladder with history and MAP, in the
