@@ -183,7 +183,8 @@ int ptm_set_proposal_callback(ptm_engine* e, ptm_propose_batch_fn propose, ptm_p
  * The engine must have been created with history_rungs = rung_count and a history_capacity that holds EVERY row of the run (a row the
  * ring has lost is reported by ptm_sync).  init_rows [n_init_extra][n_local_chains][dim], chain (local rung r, walker w) at
  * r * n_walkers + w: the states MH_chain::initialize(n) saved in FRONT of the start state (chain.cc:846-876: n_init_extra = n - 1,
- * oldest first), or NULL with n_init_extra = 0.  Needs dim <= 128.  q == NULL switches it off.  Host-side draws with temperature
+ * oldest first), or NULL with n_init_extra = 0.  Needs dim <= 128 and the whole ladder on this engine (rung_count == n_rungs; populations
+ * split by walkers are fine: PTM_ERR_UNSUPPORTED on a rung shard, whose top rung's history cannot be complete).  q == NULL switches it off.  Host-side draws with temperature
  * mixing or unlikely_alpha stay possible through ptm_set_proposal_callback. */
 typedef struct ptm_de_params {
   double snooker;         /* probability of a snooker move (differential_evolution's first constructor argument; sampler: 0.1) */

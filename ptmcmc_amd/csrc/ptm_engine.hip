@@ -939,6 +939,10 @@ extern "C" int ptm_set_proposal_de(ptm_engine* e, const ptm_de_params* q, int n_
   e->de_on = false; e->de_init_extra = 0;
   if (!q) return PTM_OK;
   if (e->DP > 128) return fail(PTM_ERR_UNSUPPORTED, "differential evolution on the device is built for up to 128 dimensions; above, draw it on the host (ptm_set_proposal_callback)");
+  if (e->nloc != e->Nt)
+    return fail(PTM_ERR_UNSUPPORTED, "differential evolution draws from EVERY rung's saved history, and a rung shard cannot record its top rung's: the row that "
+                                     "rung holds between two exchanges of one step sits in the shard above (error bit 16).  Split the population by walkers "
+                                     "(whole ladders per GPU: walker_begin) or draw on the host (ptm_set_proposal_callback)");
   if (e->hist.rungs != e->nloc || e->hist.cap < 2)
     return fail(PTM_ERR_INVALID, "differential evolution draws from every rung's saved history: create the engine with history_rungs = rung_count and a "
                                  "history_capacity that holds every row of the run");

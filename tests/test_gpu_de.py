@@ -198,3 +198,20 @@ def test_a_history_ring_too_short_for_differential_evolution_is_reported():
     with pytest.raises(E.PtmError, match="history"):
         eng.sync()
     eng.close()
+
+
+def test_differential_evolution_is_refused_on_a_rung_shard():
+    """Every rung's history is what the draw reads; a rung shard cannot record its top rung's completely (the row held between two
+    exchanges of one step sits in the shard above): refused when it is set, not when the first such row is missed."""
+    D, Nt, W = 6, 12, 2
+    pr = PU.problem_for(D, Nt, 1e3)
+    # (a shard below the ladder's top is not even created with history on all its rungs; the top shard is, and is refused here)
+    with pytest.raises(E.PtmError, match="top rung of a shard"):
+        E.Engine(D, Nt, W, rung_begin=0, rung_count=6, history_rungs=6, history_capacity=64)
+    eng = E.Engine(D, Nt, W, rung_begin=6, rung_count=6, history_rungs=6, history_capacity=64)
+    pr.configure(eng, E.PROP_DIAG)
+    cum, scales, odfs = _recipe(Nt, 2, 0.7, 0.5)
+    eng.set_proposal_mixture(cum[:6], scales[:6], odfs[:6])
+    with pytest.raises(E.PtmError, match="rung shard"):
+        eng.set_proposal_de(0.1, 0.3, 4.0, 0.0)
+    eng.close()
