@@ -185,10 +185,12 @@ __device__ __forceinline__ void decide_body(const Decide& p, unsigned char* smem
   double* tS = p0 + (Nt > MVCAP ? Nt : MVCAP);                                // [ms]  sum of the gaps the pick saw (0: nothing pried yet)
   double* tdl = tS + msp;                                                     // [ms]  what the pick added to its gap
   double* bklo = tdl + msp;                                                   // [ms]  (by pick) temperature of the pick's lower rung then
+  double* tbl = bklo + msp;                                                   // [ms]  stored temperature of the pick's lower rung (asked for with the other operands:
+  double* tbh = tbl + msp;                                                    // [ms]  ... and of its upper rung     a trip to memory off the phase's critical path)
   double* gb = p0;                                                            // [MVCAP] temperature for a HIST / MAP move (p0 is done by then)
   // ... with a posterior-ordering cut (evolve_cut >= 0; the carve above is then taken as with history): the current llike and
   // lprior of EVERY rung, exchanged as the picks are decided
-  double* llv = bklo + msp;                                                   // [Nt]
+  double* llv = tbh + msp;                                                    // [Nt]
   double* lpv = llv + Nt;                                                     // [Nt]
   if (al) {
     inv_ = reinterpret_cast<unsigned short*>(tlu);
@@ -218,8 +220,10 @@ __device__ __forceinline__ void decide_body(const Decide& p, unsigned char* smem
   const bool evolve = p.evolve_rate > 0 && Nt > 1;
   const bool evb = evolve && p.beta_add != nullptr;   // history / MAP tracking of evolving ladders
   const bool cutmode = CUT && evolve && p.evolve_cut >= 0;   // ... with a posterior-ordering cut
+  double blast = 0.0;   // the ladder's last inverse temperature (chain.cc:1833 needs 1 - it): asked for here, used phases later
   if (evolve) {
     const double* bw = p.beta_w + (size_t)w * Nt;
+    blast = bw[Nt - 1];
     for (int k = lane; k < Nt - 1; k += DECIDE_THREADS) gap[k] = bw[k] - bw[k + 1];   // chain.cc:1816
   }
   __syncthreads();
@@ -307,10 +311,18 @@ __device__ __forceinline__ void decide_body(const Decide& p, unsigned char* smem
       }
     }
     for (int q = lane; q < nch; q += DECIDE_THREADS) {   // S: chunks of 32 left to right, then the chunk totals
+      // (eight operands asked for before the chain of dependent additions: a lone lane pays ~100 cycles per dependent LDS read)
       double loc = 0.0;
-      for (int k = 32 * q; k < Nt - 1 && k < 32 * q + 32; ++k) {
-        if (evb || cutmode) p0[k] = loc;
-        loc = loc + gap[k];
+#pragma unroll 1
+      for (int j0 = 0; j0 < 32; j0 += 8) {
+        double r8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const int k = 32 * q + j0 + j; r8[j] = k < Nt - 1 ? gap[k] : 0.0; }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int k = 32 * q + j0 + j;
+          if (k < Nt - 1) { if (evb || cutmode) p0[k] = loc; loc = loc + r8[j]; }
+        }
       }
       ct[q] = loc;
     }
@@ -325,6 +337,7 @@ __device__ __forceinline__ void decide_body(const Decide& p, unsigned char* smem
       tllb[t] = llc[i + 1];
       tdep[t] = PTM_ALIVE_RUNG(i - 1) ? (short)opos[first[i - 1]] : (short)-1;
       tacc[t] = 0;
+      if (evb && !cutmode) { const double* bw = p.beta_w + (size_t)w * Nt; tbl[t] = bw[i]; tbh[t] = bw[i + 1]; }
     }
     __syncthreads();
     if (cutmode) {
@@ -347,7 +360,7 @@ __device__ __forceinline__ void decide_body(const Decide& p, unsigned char* smem
       __syncthreads();
       for (int k = lane; k < Nt - 1; k += DECIDE_THREADS) p0[k] = ct[nch + (k >> 5)] + p0[k];
       __syncthreads();
-      const double c1 = 1 - bw[Nt - 1];   // chain.cc:1833
+      const double c1 = 1 - blast;   // chain.cc:1833
       const double grow = 1.0 + p.evolve_rate;
       for (int t = 0; t < nl; ++t) {
         const int k = olist[t], i = ti[t];
@@ -428,7 +441,7 @@ __device__ __forceinline__ void decide_body(const Decide& p, unsigned char* smem
     // decisions known it is a sum of the accepted picks' increases in pick order -- one lane's chain of additions, no trial on it.)
     bool walked = false;
     if (!cutmode) {
-      const double c1 = 1 - p.beta_w[(size_t)w * Nt + Nt - 1];   // chain.cc:1833
+      const double c1 = 1 - blast;   // chain.cc:1833
       const double grow = 1.0 + p.evolve_rate;
       if (lane == 0) {
         double S = 0.0;
@@ -503,7 +516,7 @@ __device__ __forceinline__ void decide_body(const Decide& p, unsigned char* smem
     if (!cutmode && !walked && lane == 0) {
       double S = 0.0;
       for (int q = 0; q < nch; ++q) { ct[nch + q] = S; S = S + ct[q]; }
-      const double c1 = 1 - p.beta_w[(size_t)w * Nt + Nt - 1];   // chain.cc:1833
+      const double c1 = 1 - blast;   // chain.cc:1833
       const double grow = 1.0 + p.evolve_rate;
       int npry = 0;
       // one lane streams the picks; the next pick's operands are asked for before this one is decided
@@ -602,7 +615,6 @@ __device__ __forceinline__ void decide_body(const Decide& p, unsigned char* smem
       // has been pried yet (a pair is tried once), so D is the same for both.
       for (int k = lane; k < Nt - 1; k += DECIDE_THREADS) p0[k] = ct[nch + (k >> 5)] + p0[k];
       __syncthreads();
-      const double* bw = p.beta_w + (size_t)w * Nt;
       for (int j = lane; j < nl; j += DECIDE_THREADS) {
         const int k = list[j];
         const int i = cand[k];
@@ -611,9 +623,9 @@ __device__ __forceinline__ void decide_body(const Decide& p, unsigned char* smem
         for (int t2 = 0; t2 < t; ++t2)
           if (tacc[t2] && ti[t2] < i) D = D + tdl[t2];
         const double Sk = tS[t];
-        const double nk = Sk / (1 - bw[Nt - 1]);   // the normaliser then (chain.cc:1833)
-        const double blo = (Sk == 0.0 || i == 0) ? bw[i] : 1 - (p0[i] + D) / nk;
-        const double bhi = (Sk == 0.0 || i + 1 == Nt - 1) ? bw[i + 1] : 1 - (p0[i + 1] + D) / nk;
+        const double nk = Sk / (1 - blast);   // the normaliser then (chain.cc:1833)
+        const double blo = (Sk == 0.0 || i == 0) ? tbl[t] : 1 - (p0[i] + D) / nk;
+        const double bhi = (Sk == 0.0 || i + 1 == Nt - 1) ? tbh[t] : 1 - (p0[i + 1] + D) / nk;
         bklo[k] = blo;
         // last add of the phase: always for the upper rung (a pick on the pair above came earlier), for the lower rung
         // unless a later pick exchanges it again
@@ -625,14 +637,24 @@ __device__ __forceinline__ void decide_body(const Decide& p, unsigned char* smem
     if (ev[1] > 0) {   // the new temperatures (chain.cc:1834-1844): beta_k = 1 - P_k / (total / (1 - beta_last))
       for (int q = lane; q < nch; q += DECIDE_THREADS) {
         double loc = 0.0;
-        for (int k = 32 * q; k < Nt - 1 && k < 32 * q + 32; ++k) { const double g = gap[k]; gap[k] = loc; loc = loc + g; }
+#pragma unroll 1
+        for (int j0 = 0; j0 < 32; j0 += 8) {
+          double r8[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { const int k = 32 * q + j0 + j; r8[j] = k < Nt - 1 ? gap[k] : 0.0; }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int k = 32 * q + j0 + j;
+            if (k < Nt - 1) { gap[k] = loc; loc = loc + r8[j]; }
+          }
+        }
         ct[q] = loc;
       }
       __syncthreads();
       if (lane == 0) {
         double off = 0.0;
         for (int q = 0; q < nch; ++q) { ct[nch + q] = off; off = off + ct[q]; }
-        ev[0] = off / (1 - p.beta_w[(size_t)w * Nt + Nt - 1]);
+        ev[0] = off / (1 - blast);
       }
       __syncthreads();
       const double nn = ev[0];
@@ -918,7 +940,7 @@ inline size_t decide_lds_bytes(int Nt, int ms, int WN, bool evolve, bool evb, bo
   return (size_t)WN * 8 + (size_t)((Nt + 3) & ~3) * 2 + (size_t)((ms + 1) & ~1) * 4 * 2 + 16 + (al ? 0 : 2 * WNp * 2) + 2 * msp * 2 +
          (size_t)((ms + 7) & ~7) * 2 + (al ? 0 : (size_t)2 * MVCAP * 4) + 32 +
          (evolve ? ((size_t)Nt + 2 * ((Nt + 31) / 32) + 2 + 4 * msp) * 8 + 4 * msp * 2 + ((ms + 7) & ~7) : 0) +
-         (evb ? ((size_t)(Nt > MVCAP ? Nt : MVCAP) + 3 * msp) * 8 : 0);
+         (evb ? ((size_t)(Nt > MVCAP ? Nt : MVCAP) + 5 * msp) * 8 : 0);
 }
 
 
