@@ -206,6 +206,11 @@ int ptm_init_from_prior(ptm_engine* e);
  * chain's initialisation stream, so a caller that wants n initial samples (the history seed of differential evolution,
  * ptmcmc.cc:86) calls it for k = n-1 .. 0, reading the states back in between.  Resets the counters like ptm_set_states. */
 int ptm_init_from_prior_k(ptm_engine* e, int k);
+/* Draws k_begin .. k_begin + n - 1 of every chain into host arrays -- x_out [n][n_local_chains][dim], ll_out / lp_out
+ * [n][n_local_chains], chain (local rung r, walker w) at r * n_walkers + w: exactly the states, log-likelihoods and log-priors that
+ * ptm_init_from_prior_k(e, k) would leave in the engine, whose own state stays untouched.  MH_chain::initialize(n)'s n - 1 rows in
+ * front of the start state (chain.cc:846-876) in one call (then ptm_init_from_prior_k(e, 0) for the start state itself). */
+int ptm_draw_prior_rows(ptm_engine* e, int k_begin, int n, double* x_out, double* ll_out, double* lp_out);
 
 /* ---- the hot path ------------------------------------------------------------------------------------- */
 /* n x { MH_chain::step for every chain } -- no exchange phase */

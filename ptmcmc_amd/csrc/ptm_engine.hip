@@ -1494,7 +1494,22 @@ extern "C" int ptm_set_states(ptm_engine* e, const double* X, const double* llik
   return PTM_OK;
 }
 
-static int launch_init(ptm_engine* e, const Dev& p, long long attempt, unsigned char* pending) {
+static int launch_init(ptm_engine* e, const Dev& p, long long attempt, unsigned char* pending, double* x = nullptr, double* ll = nullptr, double* lp = nullptr) {
+  if (x) {   // (into a caller's staging arrays: ptm_draw_prior_rows)
+    switch (e->DP) {
+      case 4: HIPCHK(launch_init_4(p, x, ll, lp, e->err + 1, attempt, pending, e->stream)); break;
+      case 8: HIPCHK(launch_init_8(p, x, ll, lp, e->err + 1, attempt, pending, e->stream)); break;
+      case 16: HIPCHK(launch_init_16(p, x, ll, lp, e->err + 1, attempt, pending, e->stream)); break;
+      case 32: HIPCHK(launch_init_32(p, x, ll, lp, e->err + 1, attempt, pending, e->stream)); break;
+      case 64: HIPCHK(launch_init_64(p, x, ll, lp, e->err + 1, attempt, pending, e->stream)); break;
+      case 128: HIPCHK(launch_init_128(p, x, ll, lp, e->err + 1, attempt, pending, e->stream)); break;
+      case 256: HIPCHK(launch_init_256(p, x, ll, lp, e->err + 1, attempt, pending, e->stream)); break;
+      case 512: HIPCHK(launch_init_512(p, x, ll, lp, e->err + 1, attempt, pending, e->stream)); break;
+      case 1024: HIPCHK(launch_init_1024(p, x, ll, lp, e->err + 1, attempt, pending, e->stream)); break;
+      default: return fail(PTM_ERR_UNSUPPORTED, "dim > 1024 is not built");
+    }
+    return PTM_OK;
+  }
   switch (e->DP) {
     case 4: HIPCHK(launch_init_4(p, e->x, e->ll, e->lp, e->err + 1, attempt, pending, e->stream)); break;
     case 8: HIPCHK(launch_init_8(p, e->x, e->ll, e->lp, e->err + 1, attempt, pending, e->stream)); break;
@@ -1564,6 +1579,90 @@ extern "C" int ptm_init_from_prior_k(ptm_engine* e, int kdraw) {
   if ((rc = check_lp_const(e))) return rc;
   e->have_state = 1;
   return PTM_OK;
+}
+
+// Draws k_begin .. k_begin + n - 1 of every chain's initial draws (the rows ptm_init_from_prior_k(e, k) would leave in the engine) into
+// host arrays, the engine's own state untouched: what MH_chain::initialize(n) saves in FRONT of the start state (chain.cc:846-876) in
+// one call -- the sampler's default asks for 50 x dim of them, and one engine initialisation per row was most of a short run's time.
+extern "C" int ptm_draw_prior_rows(ptm_engine* e, int k_begin, int n, double* x_out, double* ll_out, double* lp_out) {
+  SETTLE(e);
+  NO_BATCH(e, "ptm_draw_prior_rows");
+  if (!e || (n > 0 && (!x_out || !ll_out || !lp_out))) return fail(PTM_ERR_INVALID, "null argument");
+  if (n <= 0) return PTM_OK;
+  if (k_begin < 0 || k_begin + n - 1 > 8191) return fail(PTM_ERR_INVALID, "initial draw index out of range (0..8191)");
+  if (!e->have_target) return fail(PTM_ERR_INVALID, "set the target first");
+  if (e->prior_cb) return fail(PTM_ERR_UNSUPPORTED, "a host-evaluated prior cannot be drawn from here: draw with its drawSample");
+  for (int d = 0; d < e->D; ++d)
+    if (e->h_ptype[d] == PTM_PRIOR_FLAT)
+      return fail(PTM_ERR_UNSUPPORTED, "a flat (improper) prior cannot be drawn from (dimension %d)", d);
+  const size_t Nc = e->Nc, D = e->D, DP = e->DP;
+  // staging on the device: G draws at a time (at most ~256 MB of rows)
+  const size_t per = Nc * DP * 8;
+  size_t G = per ? (size_t)(256u << 20) / per : 1;
+  if (G < 1) G = 1;
+  if (G > (size_t)n) G = (size_t)n;
+  if (e->cb) G = 1;
+  double *xs = nullptr, *ls = nullptr, *ps = nullptr;
+  int rc = PTM_OK;
+  if ((rc = dalloc(&xs, G * Nc * DP)) || (rc = dalloc(&ls, G * Nc)) || (rc = dalloc(&ps, G * Nc))) { hipFree(xs); hipFree(ls); hipFree(ps); return rc; }
+  std::vector<double> hx(G * Nc * DP), hl(G * Nc), hp(G * Nc);
+  auto done = [&](int r) { hipFree(xs); hipFree(ls); hipFree(ps); return r; };
+#define PTM_DRAW_CHK(call) do { const hipError_t e_ = (call); if (e_ != hipSuccess) return done(fail(PTM_ERR_HIP, "%s: %s", #call, hipGetErrorString(e_))); } while (0)
+  PTM_DRAW_CHK(hipMemsetAsync(e->err + 1, 0, 4, e->stream));
+  for (int k0 = 0; k0 < n; k0 += (int)G) {
+    const int g = std::min((int)G, n - k0);
+    for (int j = 0; j < g; ++j) {
+      Dev p = make_dev(e);
+      p.init_base = (uint64_t)(k_begin + k0 + j) << 17;
+      double *xj = xs + (size_t)j * Nc * DP, *lj = ls + (size_t)j * Nc, *pj = ps + (size_t)j * Nc;
+      if (!e->cb) {
+        if ((rc = launch_init(e, p, -1, nullptr, xj, lj, pj))) return done(rc);
+      } else {
+        // the redraw loop of ptm_init_from_prior_k (chain.cc:856-869) on the staging row
+        PTM_DRAW_CHK(hipMemsetAsync(e->gate, 0, Nc, e->stream));
+        std::vector<double> llh(Nc, 0.0);
+        size_t left = Nc;
+        for (long long a = 0; left && a < 100000; ++a) {
+          if ((rc = launch_init(e, p, a, e->gate, xj, lj, pj))) return done(rc);
+          PTM_DRAW_CHK(copy_unless_shared(e->h_gate, e->gate, Nc, hipMemcpyDeviceToHost, e->stream));
+          PTM_DRAW_CHK(hipMemcpyAsync(e->h_xprop.data(), xj, Nc * DP * 8, hipMemcpyDeviceToHost, e->stream));
+          PTM_DRAW_CHK(hipStreamSynchronize(e->stream));
+          std::vector<size_t> pick;
+          for (size_t c = 0; c < Nc; ++c)
+            if (e->h_gate[c] == 1) pick.push_back(c);
+          if ((rc = call_user(e, e->h_xprop, pick, e->h_llbatch))) return done(rc);
+          for (size_t q = 0; q < pick.size(); ++q) {
+            const double v = e->h_llbatch[q];
+            if (v < -1e100) { e->h_gate[pick[q]] = 0; continue; }
+            llh[pick[q]] = v;
+            e->h_gate[pick[q]] = 2;
+            left--;
+          }
+          PTM_DRAW_CHK(copy_unless_shared(e->gate, e->h_gate, Nc, hipMemcpyHostToDevice, e->stream));
+        }
+        if (left) return done(fail(PTM_ERR_INVALID, "could not draw a valid state from the prior for some chain"));
+        PTM_DRAW_CHK(hipMemcpyAsync(lj, llh.data(), Nc * 8, hipMemcpyHostToDevice, e->stream));
+        PTM_DRAW_CHK(hipStreamSynchronize(e->stream));   // (llh is a local)
+      }
+    }
+    PTM_DRAW_CHK(hipMemcpyAsync(hx.data(), xs, (size_t)g * Nc * DP * 8, hipMemcpyDeviceToHost, e->stream));
+    PTM_DRAW_CHK(hipMemcpyAsync(hl.data(), ls, (size_t)g * Nc * 8, hipMemcpyDeviceToHost, e->stream));
+    PTM_DRAW_CHK(hipMemcpyAsync(hp.data(), ps, (size_t)g * Nc * 8, hipMemcpyDeviceToHost, e->stream));
+    PTM_DRAW_CHK(hipStreamSynchronize(e->stream));
+    for (int j = 0; j < g; ++j) {
+      const size_t o = (size_t)(k0 + j);
+      for (size_t c = 0; c < Nc; ++c) {
+        for (size_t d = 0; d < D; ++d) x_out[(o * Nc + c) * D + d] = hx[((size_t)j * Nc + c) * DP + host_row_pos(DP, d)];
+        ll_out[o * Nc + c] = hl[(size_t)j * Nc + c];
+        lp_out[o * Nc + c] = hp[(size_t)j * Nc + c];
+      }
+    }
+  }
+  int flag = 0;
+  PTM_DRAW_CHK(hipMemcpy(&flag, e->err + 1, 4, hipMemcpyDeviceToHost));
+#undef PTM_DRAW_CHK
+  if (flag) return done(fail(PTM_ERR_INVALID, "could not draw a valid state from the prior for some chain"));
+  return done(PTM_OK);
 }
 
 // ---- hot path ----------------------------------------------------------------------------------------------------

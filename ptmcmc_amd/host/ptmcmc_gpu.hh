@@ -2304,22 +2304,30 @@ class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:
       }
       ptm_check(ptm_set_states(eng, x0.data(), nullptr), "set_states");
     } else {
-      // draws 1 .. n-1 first (kept for the mirror), draw 0 last: it is the chain's start, whatever n is
-      for (int k = draws - 1; k >= 0; k--) {
-        int rc = ptm_init_from_prior_k(eng, k);
+      // draws 1 .. n-1 first (kept for the mirror; all of them in ONE call, the order of the rows as before: n-1 first), draw 0 last:
+      // it is the chain's start, whatever n is
+      if (draws > 1) {
+        const size_t nd = (size_t)draws - 1;
+        std::vector<double> ax(nd * N * dim), al(nd * N), ap(nd * N);
+        int rc = ptm_draw_prior_rows(eng, 1, (int)nd, ax.data(), al.data(), ap.data());
         if (rc == PTM_ERR_UNSUPPORTED) {
           std::cout << "parallel_tempering_chains::initialize: " << ptm_last_error() << "; pass start states" << std::endl;
           exit(1);
         }
-        ptm_check(rc, "init_from_prior");
-        if (k > 0) {
-          std::vector<double> x(N * dim), ll(N), lp(N);
-          ptm_check(ptm_get_states(eng, x.data()), "initialize");
-          ptm_check(ptm_get_array(eng, PTM_ARR_LLIKE, ll.data()), "initialize");
-          ptm_check(ptm_get_array(eng, PTM_ARR_LPRIOR, lp.data()), "initialize");
-          init_x.push_back(x); init_ll.push_back(ll); init_lp.push_back(lp);
+        ptm_check(rc, "draw_prior_rows");
+        for (size_t k = nd; k >= 1; k--) {
+          const size_t o = k - 1;   // (row of draw k)
+          init_x.push_back(std::vector<double>(ax.begin() + o * N * dim, ax.begin() + (o + 1) * N * dim));
+          init_ll.push_back(std::vector<double>(al.begin() + o * N, al.begin() + (o + 1) * N));
+          init_lp.push_back(std::vector<double>(ap.begin() + o * N, ap.begin() + (o + 1) * N));
         }
       }
+      int rc = ptm_init_from_prior_k(eng, 0);
+      if (rc == PTM_ERR_UNSUPPORTED) {
+        std::cout << "parallel_tempering_chains::initialize: " << ptm_last_error() << "; pass start states" << std::endl;
+        exit(1);
+      }
+      ptm_check(rc, "init_from_prior");
     }
     views.clear(); ladders.clear();
     for (int w = 0; w < W; w++) {

@@ -215,3 +215,33 @@ def test_differential_evolution_is_refused_on_a_rung_shard():
     with pytest.raises(E.PtmError, match="rung shard"):
         eng.set_proposal_de(0.1, 0.3, 4.0, 0.0)
     eng.close()
+
+
+@pytest.mark.parametrize("plugin", [False, True])
+def test_initial_rows_drawn_in_one_call_are_the_rows_of_one_initialisation_each(plugin):
+    """ptm_draw_prior_rows: MH_chain::initialize(n)'s rows in front of the start state (chain.cc:846-876) in one call, bit for bit what
+    ptm_init_from_prior_k leaves in the engine draw by draw -- device target and plug-in likelihood (with its redraw loop) -- and the
+    engine's own state untouched."""
+    if plugin:
+        import lisa_toy
+        D, Nt, W = 6, 10, 3
+        eng = E.Engine(D, Nt, W, swap_rate=0.1)
+        eng.set_bounds(lisa_toy.BLO, lisa_toy.BHI, lisa_toy.BMIN, lisa_toy.BMAX)
+        eng.set_prior(lisa_toy.TYPES, lisa_toy.CENTERS, lisa_toy.SCALES)
+        eng.set_target_callback(lisa_toy.loglike)
+        eng.set_ladder(E.geometric_ladder(Nt, 1e4))
+        eng.set_proposals(E.PROP_DIAG, np.tile(np.array(lisa_toy.SCALES) / 100.0, (Nt, 1)))
+    else:
+        D, Nt, W = 20, 7, 5
+        pr = PU.problem_for(D, Nt, 1e3)
+        eng = E.Engine(D, Nt, W)
+        pr.configure(eng, E.PROP_LOWER)
+    eng.init_from_prior()
+    x0, ll0 = eng.states(), eng.llike.copy()
+    x, ll, lp = eng.draw_prior_rows(2, 5)
+    assert np.array_equal(eng.states(), x0) and np.array_equal(eng.llike, ll0)
+    for j, k in enumerate(range(2, 7)):
+        eng.init_from_prior(k)
+        assert np.array_equal(eng.states(), x[j]) and np.array_equal(eng.llike, ll[j]) and np.array_equal(eng.lprior, lp[j]), k
+    assert len({tuple(r) for r in x[:, 0, :]}) == 5
+    eng.close()
