@@ -1530,13 +1530,26 @@ class ess_estimator {
 // A small persistent worker pool for the likelihood batches: starting and joining threads for every batch costs more than
 // a cheap plug-in's whole batch.  run(n, chunk, f) calls f(k0, k1) over [0, n) in chunks, on the workers and the caller.
 class eval_pool {
+  // Workers sleep on a condition variable between batches.  PTM_EVAL_SPIN_US=<us> lets them SPIN that long for the next batch first (a
+  // running sampler hands one over every ~50-100 us; a sleeping thread takes ~50 us to wake, the whole batch of a 128-chain ladder) --
+  // an OpenMP runtime's active wait policy.  Not the default: on a shared host it is a gamble (the LISA example at 128 temperatures,
+  // spinning / one thread, on two boxes of the pool: 76 / 102 and 117 / 84 us per step), and spinning workers eat a container's CPU quota.
   std::vector<std::thread> workers;
   std::mutex m;
   std::condition_variable cv_go, cv_done;
   std::function<void(int, int)> job;
-  std::atomic<int> next{0};
-  int n = 0, chunk = 1, generation = 0, busy = 0;
-  bool stop = false;
+  std::atomic<int> next{0}, gen{0}, busy{0}, sleepers{0};
+  std::atomic<bool> stop{false};
+  int n = 0, chunk = 1;
+  long long spin_ns = 0;
+  static long long now_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+  static void relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#else
+    std::this_thread::yield();
+#endif
+  }
   void drain() {
     for (;;) {
       const int k0 = next.fetch_add(chunk);
@@ -1546,21 +1559,29 @@ class eval_pool {
   }
   void loop(int seen) {   // `seen`: the generation current when this worker was created (resize() holds the mutex)
     for (;;) {
-      {
-        std::unique_lock<std::mutex> lk(m);
-        cv_go.wait(lk, [&] { return stop || generation != seen; });
-        if (stop) return;
-        seen = generation;
+      bool got = false;
+      for (const long long t0 = now_ns(); spin_ns > 0 && now_ns() - t0 < spin_ns;) {
+        if (stop.load(std::memory_order_acquire)) return;
+        if (gen.load(std::memory_order_acquire) != seen) { got = true; break; }
+        for (int k = 0; k < 32; k++) relax();
       }
+      if (!got) {
+        std::unique_lock<std::mutex> lk(m);
+        sleepers.fetch_add(1);
+        cv_go.wait(lk, [&] { return stop.load() || gen.load() != seen; });
+        sleepers.fetch_sub(1);
+        if (stop.load()) return;
+      }
+      seen = gen.load(std::memory_order_acquire);
       drain();
-      std::lock_guard<std::mutex> lk(m);
-      if (--busy == 0) cv_done.notify_one();
+      if (busy.fetch_sub(1, std::memory_order_acq_rel) == 1) { std::lock_guard<std::mutex> lk(m); cv_done.notify_one(); }
     }
   }
 
  public:
+  eval_pool() { if (const char* v = getenv("PTM_EVAL_SPIN_US")) spin_ns = (long long)(atof(v) * 1e3); }
   ~eval_pool() {
-    { std::lock_guard<std::mutex> lk(m); stop = true; }
+    { std::lock_guard<std::mutex> lk(m); stop.store(true); }
     cv_go.notify_all();
     for (auto& t : workers) t.join();
   }
@@ -1568,19 +1589,25 @@ class eval_pool {
   void resize(int nworkers) {
     std::lock_guard<std::mutex> lk(m);   // a new worker starts from the current generation: it waits for the NEXT run
     while ((int)workers.size() < nworkers) {
-      const int g = generation;
+      const int g = gen.load();
       workers.emplace_back([this, g] { loop(g); });
     }
   }
   void run(int n_, int chunk_, const std::function<void(int, int)>& f) {
-    {
-      std::lock_guard<std::mutex> lk(m);
-      job = f; n = n_; chunk = chunk_ < 1 ? 1 : chunk_; next = 0; busy = (int)workers.size(); ++generation;
-    }
-    cv_go.notify_all();
+    // (every worker has left the batch before: run() returns only when `busy` is back to zero)
+    job = f; n = n_; chunk = chunk_ < 1 ? 1 : chunk_;
+    next.store(0); busy.store((int)workers.size());
+    gen.fetch_add(1, std::memory_order_release);
+    if (sleepers.load() > 0) { std::lock_guard<std::mutex> lk(m); cv_go.notify_all(); }   // (a worker on its way to sleep checks `gen` under the mutex)
     drain();
-    std::unique_lock<std::mutex> lk(m);
-    cv_done.wait(lk, [&] { return busy == 0; });
+    for (const long long t0 = now_ns(); busy.load(std::memory_order_acquire) != 0;) {
+      if (now_ns() - t0 > 2000000) {   // a worker that sleeps or was descheduled: wait for it without burning this thread
+        std::unique_lock<std::mutex> lk(m);
+        cv_done.wait(lk, [&] { return busy.load() == 0; });
+        break;
+      }
+      relax();
+    }
   }
 };
 
@@ -1692,11 +1719,18 @@ class bayes_likelihood : public probability_function, public Optioned {  // baye
         out[k] = l->evaluate_log(s);
       }
     };
-    int nt = l->eval_threads > 0 ? l->eval_threads : usable_cpus();
-    if (nt > n / 8) nt = n / 8;      // at least 8 states per thread
-    // starting and joining threads costs ~50 us: a batch that the measured cost per evaluation prices below ~4 such
-    // units stays on this thread (eval_threads == 0 only; an explicit thread count is obeyed)
-    static const double pool_from_ns = [] { const char* v = getenv("PTM_EVAL_POOL_NS"); return v && *v ? atof(v) : 200e3; }();   // (A/B timing)
+    // (half of the usable processors: this thread and the HIP runtime's own need some, and a container's CPU quota throttles EVERY
+    //  thread of the process once it is used up)
+    int nt = l->eval_threads > 0 ? l->eval_threads : (usable_cpus() + 1) / 2;
+    if (nt > n / 16) nt = n / 16;    // at least 16 states per thread
+    // waking sleeping workers costs ~50 us: a batch that the measured cost per evaluation prices below ~4 such units stays on this
+    // thread -- 30 us if the workers spin for their batches (PTM_EVAL_SPIN_US) (eval_threads == 0 only; an explicit thread count is obeyed)
+    static const double pool_from_ns = [] {
+      const char* v = getenv("PTM_EVAL_POOL_NS");
+      if (v && *v) return atof(v);
+      const char* sp = getenv("PTM_EVAL_SPIN_US");
+      return (sp && atof(sp) > 0) ? 30e3 : 200e3;
+    }();
     if (l->eval_threads <= 0 && l->eval_ns >= 0 && (l->eval_ns * n < pool_from_ns || l->pool_off)) nt = 1;
     if (nt <= 1) {
       const auto t0 = std::chrono::steady_clock::now();

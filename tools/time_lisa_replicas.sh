@@ -10,8 +10,11 @@ per_step() {  # name, steps1, steps2, command... (--nsteps appended)
   local t1=$(t "$@" --nsteps=$n1 --nevery=$n2) t2=$(t "$@" --nsteps=$n2 --nevery=$n2)
   echo "$name: $(python3 -c "print('%.1f' % (($t2 - $t1) * 1e6 / ($n2 - $n1)))") us per step  ($n1 steps $t1 s, $n2 steps $t2 s)"
 }
-per_step "lisa, default recipe, 20 T x 64 replicas, pool as the facade sizes it"  500 1500 ./lisa --outname=l4 --pt=20 --replicas=64
-PTM_EVAL_THREADS=1 per_step "lisa, default recipe, 20 T x 64 replicas, one thread"  500 1500 ./lisa --outname=l5 --pt=20 --replicas=64
-PTM_EVAL_THREADS=8 per_step "lisa, default recipe, 20 T x 64 replicas, 8 threads"  500 1500 ./lisa --outname=l6 --pt=20 --replicas=64
-PTM_EVAL_THREADS=16 per_step "lisa, default recipe, 20 T x 64 replicas, 16 threads"  500 1500 ./lisa --outname=l6 --pt=20 --replicas=64
+per_step "lisa, default recipe, 20 T x 64 replicas, pool as the facade sizes it"  1000 4000 ./lisa --outname=l4 --pt=20 --replicas=64
+PTM_EVAL_THREADS=1 per_step "lisa, default recipe, 20 T x 64 replicas, one thread"  1000 4000 ./lisa --outname=l5 --pt=20 --replicas=64
+PTM_EVAL_THREADS=8 per_step "lisa, default recipe, 20 T x 64 replicas, 8 threads"  1000 4000 ./lisa --outname=l6 --pt=20 --replicas=64
+PTM_EVAL_THREADS=16 per_step "lisa, default recipe, 20 T x 64 replicas, 16 threads"  1000 4000 ./lisa --outname=l6 --pt=20 --replicas=64
 per_step "lisa, default recipe, 128 T"   2000 6000 ./lisa --outname=l3 --pt=128
+PTM_EVAL_THREADS=1 per_step "lisa, default recipe, 128 T, one thread"   2000 6000 ./lisa --outname=l3 --pt=128
+PTM_EVAL_SPIN_US=200 per_step "lisa, default recipe, 128 T, workers that spin 200 us for their next batch"   2000 6000 ./lisa --outname=l3 --pt=128
+per_step "lisa, default recipe, 20 T"   2000 10000 ./lisa --outname=l3 --pt=20
