@@ -1731,7 +1731,6 @@ static bool ladder_applies(ptm_engine* e, long long* grid_out = nullptr, size_t*
   static const bool ladder_ok = [] { const char* v = getenv("PTM_LADDER"); return !(v && *v == '0'); }();
   if (!ladder_ok || e->lad_disabled || (e->DP != 16 && e->DP != 32) || e->Nt < 2 || e->nloc != e->Nt || e->cfg.time_kernels || (e->evolve_rate > 0 && e->evolve_cut >= 0) || e->shard)
     return false;
-  const SweepSel sel = sweep_sel(e);
   // open / `limit` boundaries, all-uniform prior, zero mean, fixed ladder, device target and proposals (one-dimensional moves, scale
   // mixtures, history and MAP tracking have their builds: ladder_flavour); ANY population whose grid is resident at once (below): where
   // it fits, a step costs this kernel its ~6 us of latency whatever the walkers' number (64 walkers x 64 rungs of 12 dimensions with the
