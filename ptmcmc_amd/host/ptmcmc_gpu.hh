@@ -1597,7 +1597,7 @@ class eval_pool {
     // (every worker has left the batch before: run() returns only when `busy` is back to zero)
     job = f; n = n_; chunk = chunk_ < 1 ? 1 : chunk_;
     next.store(0); busy.store((int)workers.size());
-    gen.fetch_add(1, std::memory_order_release);
+    gen.fetch_add(1);   // (sequentially consistent, like the workers' `sleepers` count: one of the two sides always sees the other's write)
     if (sleepers.load() > 0) { std::lock_guard<std::mutex> lk(m); cv_go.notify_all(); }   // (a worker on its way to sleep checks `gen` under the mutex)
     drain();
     for (const long long t0 = now_ns(); busy.load(std::memory_order_acquire) != 0;) {
