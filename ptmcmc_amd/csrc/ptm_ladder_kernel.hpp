@@ -173,8 +173,6 @@ __global__ __launch_bounds__(LADDER_THREADS) void ladder_persistent_kernel(const
   const int pos = row_pos<DP>(d);
   const bool hist_on = HIST && rg < p.hist.rungs, map_on = HIST && rg < p.map.rungs;
   const unsigned int every = (unsigned int)p.add_every_n;
-  // a flag of the chain's lead lane, for all its lanes
-  auto from_lead = [&](int v) { return __builtin_amdgcn_ds_bpermute(4 * (g * DP), v); };
   auto sync_wave = [] { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); };
   constexpr unsigned long long GM = DP == 64 ? ~0ull : ((1ull << (DP & 63)) - 1ull);
   auto all_of_chain = [&](bool v) { return ((__builtin_amdgcn_ballot_w64(v) >> (g * DP)) & GM) == GM; };
@@ -183,6 +181,16 @@ __global__ __launch_bounds__(LADDER_THREADS) void ladder_persistent_kernel(const
   double ll = p.ll[c], lp = p.lp[c];
   int ntries = p.ntries[c], naccept = p.naccept[c], last_type = p.last_type[c];
   unsigned int nhist = p.nhist[c];
+  // the rung's MAP log-posterior in a register of every lane of the chain (the rung's MAP is this workgroup's alone for the launch;
+  // a look at memory per add_state would be a round trip on the chains' critical path, and every lane of a chain holds the same
+  // candidate scalars: all of them take the same decision, no lane exchange)
+  double map_lp = map_on ? p.map.lpost[c] : 0.0;
+  auto map_take = [&](double lpost, double l_, double p_) -> bool {   // chain.cc:931-934
+    if (!(lpost > map_lp)) return false;
+    map_lp = lpost;
+    if (lead && live) { p.map.lpost[c] = lpost; p.map.ll[c] = l_; p.map.lp[c] = p_; }
+    return true;
+  };
   double beta = p.beta[rg];   // (evolving ladders: the ladder-major image, refreshed after every step's exchange phase)
   if (EV) {
     for (int k = tid; k < Nt; k += LADDER_THREADS) bwl[k] = p.beta_w[(size_t)w * Nt + k];
@@ -826,7 +834,15 @@ __global__ __launch_bounds__(LADDER_THREADS) void ladder_persistent_kernel(const
       if (HIST && tid == 256) {   // the normaliser after each pry, summed in pick order (kSl[q]: after pry q): what the in-phase temperatures need
         double S = S0;
         const int nq = evi[1];
-        for (int q = 0; q < nq; ++q) { S = S + incl[q]; kSl[q] = S; }
+#pragma unroll 1
+        for (int q0 = 0; q0 < nq; q0 += 8) {   // (eight operands ahead of the additions, as in the scans)
+          double ic[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) ic[j] = q0 + j < nq ? incl[q0 + j] : 0.0;
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            if (q0 + j < nq) { S = S + ic[j]; kSl[q0 + j] = S; }
+        }
       }
       PTM_LADDER_TICK(5);
       if (evi[1] > 0) {   // the new temperatures (chain.cc:1834-1844): beta_k = 1 - P_k / (total / (1 - beta_last)), P in the checker's order
@@ -858,12 +874,11 @@ __global__ __launch_bounds__(LADDER_THREADS) void ladder_persistent_kernel(const
               else hist_scalars(p.hist, o, hrow, ll, lp, naccept, ntries, last_type, beta);
             }
           }
-          int mapw = 0;
-          if (map_on && lead && live && accept) mapw = map_try(p.map, c, newlpost, newlike, newlprior) ? 1 : 0;   // chain.cc:931-934
-          // an evolving ladder: the state that stays is added at a NEW temperature and may beat the MAP with it
-          else if (EV && map_on && lead && live) mapw = map_try(p.map, c, cur_lpost, ll, lp) ? 2 : 0;
           if (map_on) {
-            mapw = from_lead(mapw);
+            int mapw = 0;
+            if (accept) mapw = map_take(newlpost, newlike, newlprior) ? 1 : 0;
+            // an evolving ladder: the state that stays is added at a NEW temperature and may beat the MAP with it
+            else if (EV) mapw = map_take(cur_lpost, ll, lp) ? 2 : 0;
             if (mapw && live) p.map.x[(size_t)c * DP + pos] = mapw == 1 ? xn : xd;
           }
         }
@@ -879,9 +894,20 @@ __global__ __launch_bounds__(LADDER_THREADS) void ladder_persistent_kernel(const
       if (!EV) return beta;
       const int np_ = knp[k];
       if (np_ == 0 || rg == 0 || rg == Nt - 1) return beta_old;
+      // (the operands four pries ahead of the chain of additions: a lone dependent LDS read costs ~100 cycles, and a 1024-rung ladder
+      //  pries ~80 times a step; a pry at or above the rung adds +0.0, which changes nothing.  One walk for both temperatures of a rung
+      //  exchanged twice -- the earlier sum is a prefix of the later -- was tried: its two snapshot tests per pry cost more than the
+      //  second walk, 20.1 -> 21.4 us per step)
       double Dr = 0.0;
-      for (int q = 0; q < np_; ++q)
-        if (ipry[q] < rg) Dr = Dr + incl[q];
+#pragma unroll 1
+      for (int q0 = 0; q0 < np_; q0 += 4) {
+        int ip[4];
+        double ic[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const bool in = q0 + j < np_; ip[j] = in ? ipry[q0 + j] : Nt; ic[j] = in ? incl[q0 + j] : 0.0; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) Dr = Dr + (ip[j] < rg ? ic[j] : 0.0);
+      }
       const double nrm = kSl[np_ - 1] / (1 - bwl[Nt - 1]);   // S after the pries before this pick
       return 1 - ((cts[nchunk + 2 + (rg >> 5)] + P0l[rg]) + Dr) / nrm;
     };
@@ -897,11 +923,9 @@ __global__ __launch_bounds__(LADDER_THREADS) void ladder_persistent_kernel(const
           if (live) p.hist.x[o * DP + pos] = xmid;
           if (live && lead) hist_scalars(p.hist, o, hrow, llmid, lpmid, naccept, ntries, last_type, EV ? bmid : beta);
         }
-        int mw = 0;
-        if (map_on && lead && live) { const double tb = (EV ? bmid : beta) * llmid; mw = map_try(p.map, c, lpmid + tb, llmid, lpmid) ? 1 : 0; }
         if (map_on) {
-          mw = from_lead(mw);
-          if (mw && live) p.map.x[(size_t)c * DP + pos] = xmid;
+          const double tb = (EV ? bmid : beta) * llmid;
+          if (map_take(lpmid + tb, llmid, lpmid) && live) p.map.x[(size_t)c * DP + pos] = xmid;
         }
       }
       const unsigned int al = nh0 + (unsigned int)tc - 1u;   // the LAST of the adds saw the row as it is now
@@ -911,11 +935,9 @@ __global__ __launch_bounds__(LADDER_THREADS) void ladder_persistent_kernel(const
         if (live) p.hist.x[o * DP + pos] = xd;
         if (live && lead) hist_scalars(p.hist, o, hrow, ll, lp, naccept, ntries, last_type, beta);
       }
-      int mw = 0;
-      if (map_on && lead && live) { const double tb = beta * ll; mw = map_try(p.map, c, lp + tb, ll, lp) ? 1 : 0; }
       if (map_on) {
-        mw = from_lead(mw);
-        if (mw && live) p.map.x[(size_t)c * DP + pos] = xd;
+        const double tb = beta * ll;
+        if (map_take(lp + tb, ll, lp) && live) p.map.x[(size_t)c * DP + pos] = xd;
       }
     };
 
