@@ -834,15 +834,20 @@ __global__ __launch_bounds__(LADDER_THREADS) void ladder_persistent_kernel(const
       if (HIST && tid == 256) {   // the normaliser after each pry, summed in pick order (kSl[q]: after pry q): what the in-phase temperatures need
         double S = S0;
         const int nq = evi[1];
+        // (a lone lane issues an instruction every ~10 cycles whatever it is: whole groups of eight without a test per element -- paired
+        //  LDS reads, eight additions, paired writes --, the last few one by one)
+        int q0 = 0;
 #pragma unroll 1
-        for (int q0 = 0; q0 < nq; q0 += 8) {   // (eight operands ahead of the additions, as in the scans)
+        for (; q0 + 8 <= nq; q0 += 8) {
           double ic[8];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) ic[j] = q0 + j < nq ? incl[q0 + j] : 0.0;
+          for (int j = 0; j < 8; ++j) ic[j] = incl[q0 + j];
 #pragma unroll
-          for (int j = 0; j < 8; ++j)
-            if (q0 + j < nq) { S = S + ic[j]; kSl[q0 + j] = S; }
+          for (int j = 0; j < 8; ++j) { S = S + ic[j]; ic[j] = S; }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) kSl[q0 + j] = ic[j];
         }
+        for (; q0 < nq; ++q0) { S = S + incl[q0]; kSl[q0] = S; }
       }
       PTM_LADDER_TICK(5);
       if (evi[1] > 0) {   // the new temperatures (chain.cc:1834-1844): beta_k = 1 - P_k / (total / (1 - beta_last)), P in the checker's order
@@ -894,20 +899,22 @@ __global__ __launch_bounds__(LADDER_THREADS) void ladder_persistent_kernel(const
       if (!EV) return beta;
       const int np_ = knp[k];
       if (np_ == 0 || rg == 0 || rg == Nt - 1) return beta_old;
-      // (the operands four pries ahead of the chain of additions: a lone dependent LDS read costs ~100 cycles, and a 1024-rung ladder
+      // (the operands eight pries ahead of the chain of additions: a lone dependent LDS read costs ~100 cycles, and a 1024-rung ladder
       //  pries ~80 times a step; a pry at or above the rung adds +0.0, which changes nothing.  One walk for both temperatures of a rung
       //  exchanged twice -- the earlier sum is a prefix of the later -- was tried: its two snapshot tests per pry cost more than the
       //  second walk, 20.1 -> 21.4 us per step)
       double Dr = 0.0;
+      int q0 = 0;
 #pragma unroll 1
-      for (int q0 = 0; q0 < np_; q0 += 4) {
-        int ip[4];
-        double ic[4];
+      for (; q0 + 8 <= np_; q0 += 8) {   // (whole groups of eight without a test for the end, the last few one by one)
+        int ip[8];
+        double ic[8];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { const bool in = q0 + j < np_; ip[j] = in ? ipry[q0 + j] : Nt; ic[j] = in ? incl[q0 + j] : 0.0; }
+        for (int j = 0; j < 8; ++j) { ip[j] = ipry[q0 + j]; ic[j] = incl[q0 + j]; }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) Dr = Dr + (ip[j] < rg ? ic[j] : 0.0);
+        for (int j = 0; j < 8; ++j) Dr = Dr + (ip[j] < rg ? ic[j] : 0.0);
       }
+      for (; q0 < np_; ++q0) Dr = Dr + (ipry[q0] < rg ? incl[q0] : 0.0);
       const double nrm = kSl[np_ - 1] / (1 - bwl[Nt - 1]);   // S after the pries before this pick
       return 1 - ((cts[nchunk + 2 + (rg >> 5)] + P0l[rg]) + Dr) / nrm;
     };
