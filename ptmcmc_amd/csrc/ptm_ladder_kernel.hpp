@@ -308,14 +308,18 @@ __global__ __launch_bounds__(LADDER_THREADS) void ladder_persistent_kernel(const
   // ... and the chunk totals tot[0 .. nq) left to right: off[q] = the sum of the totals before q (may overwrite tot), returns the grand total
   auto totals_scan = [&](const double* tot, double* off, int nq) -> double {
     double run = 0.0;
+    int q0 = 0;
 #pragma unroll 1
-    for (int q0 = 0; q0 < nq; q0 += 8) {
+    for (; q0 + 8 <= nq; q0 += 8) {   // (whole groups of eight without a test per element; the last few one by one)
       double r[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) r[j] = q0 + j < nq ? tot[q0 + j] : 0.0;
+      for (int j = 0; j < 8; ++j) r[j] = tot[q0 + j];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { if (q0 + j < nq) off[q0 + j] = run; run = run + r[j]; }
+      for (int j = 0; j < 8; ++j) { const double t = run; run = run + r[j]; r[j] = t; }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) off[q0 + j] = r[j];
     }
+    for (; q0 < nq; ++q0) { const double t = tot[q0]; off[q0] = run; run = run + t; }
     return run;
   };
   int done = 0, nslow = 0;
