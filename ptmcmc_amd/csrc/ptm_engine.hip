@@ -1729,7 +1729,7 @@ static int ladder_flavour(const ptm_engine* e) {
 }
 static bool ladder_applies(ptm_engine* e, long long* grid_out = nullptr, size_t* lds_out = nullptr) {
   static const bool ladder_ok = [] { const char* v = getenv("PTM_LADDER"); return !(v && *v == '0'); }();
-  if (!ladder_ok || e->lad_disabled || (e->DP != 16 && e->DP != 32) || e->Nt < 2 || e->nloc != e->Nt || e->cfg.time_kernels || (e->evolve_rate > 0 && e->evolve_cut >= 0) || e->shard)
+  if (!ladder_ok || e->lad_disabled || e->DP > 32 || e->Nt < 2 || e->nloc != e->Nt || e->cfg.time_kernels || (e->evolve_rate > 0 && e->evolve_cut >= 0) || e->shard)
     return false;
   // open / `limit` boundaries, all-uniform prior, zero mean, fixed ladder, device target and proposals (one-dimensional moves, scale
   // mixtures, history and MAP tracking have their builds: ladder_flavour); ANY population whose grid is resident at once (below): where
@@ -1740,10 +1740,11 @@ static bool ladder_applies(ptm_engine* e, long long* grid_out = nullptr, size_t*
   const long long grid = (long long)e->W * NB;
   const bool diag = e->prop_kind == PTM_PROP_DIAG;
   const int fl = ladder_flavour(e);
-  const size_t lds = e->DP == 16 ? ladder_lds_16(e->Nt, e->ms, e->evolve_rate > 0) : ladder_lds_32(e->Nt, e->ms, e->evolve_rate > 0);
+  const bool ev_ = e->evolve_rate > 0;
+  const size_t lds = e->DP == 4 ? ladder_lds_4(e->Nt, e->ms, ev_) : e->DP == 8 ? ladder_lds_8(e->Nt, e->ms, ev_) : e->DP == 16 ? ladder_lds_16(e->Nt, e->ms, ev_) : ladder_lds_32(e->Nt, e->ms, ev_);
   if (lds > 160 * 1024) return false;
   int& cap = e->lad_capacity[diag ? 1 : 0][fl];   // (asked per build: the builds differ in registers, and the LDS attribute is per kernel)
-  if (cap < 0) cap = e->DP == 16 ? ladder_blocks_16(diag, fl, lds) : ladder_blocks_32(diag, fl, lds);
+  if (cap < 0) cap = e->DP == 4 ? ladder_blocks_4(diag, fl, lds) : e->DP == 8 ? ladder_blocks_8(diag, fl, lds) : e->DP == 16 ? ladder_blocks_16(diag, fl, lds) : ladder_blocks_32(diag, fl, lds);
   // every workgroup must be resident at once (they wait for each other)
   if (grid > cap || grid > 1024) return false;
   if (grid_out) *grid_out = grid;
@@ -1862,7 +1863,8 @@ static int ladder_steps(ptm_engine* e, int n) {
     {
       std::lock_guard<std::mutex> lock(g_lad_mutex);
       if (g_lad_last && g_lad_last != e && g_lad_last->lad_event) HIPCHK(hipStreamWaitEvent(e->stream, g_lad_last->lad_event, 0));
-      HIPCHK(e->DP == 16 ? launch_ladder_16(p, a, diag, fl, (int)grid, lds, e->stream) : launch_ladder_32(p, a, diag, fl, (int)grid, lds, e->stream));
+      HIPCHK(e->DP == 4 ? launch_ladder_4(p, a, diag, fl, (int)grid, lds, e->stream) : e->DP == 8 ? launch_ladder_8(p, a, diag, fl, (int)grid, lds, e->stream) :
+             e->DP == 16 ? launch_ladder_16(p, a, diag, fl, (int)grid, lds, e->stream) : launch_ladder_32(p, a, diag, fl, (int)grid, lds, e->stream));
       // (the event costs a host call per launch: only a process with several engines on this path records it)
       static int engines_seen = 0;
       static ptm_engine* first_seen = nullptr;
@@ -1918,10 +1920,10 @@ extern "C" int ptm_step(ptm_engine* e, int n) {
   if (e->nloc != e->Nt) return fail(PTM_ERR_INVALID, "ptm_step needs the whole ladder on this engine; sharded engines use ptm_exchange_*");
   NO_BATCH(e, "ptm_step");
   if (n > 0) {
-    int f = fused_steps(e, n);
-    if (f < 0) return f;
-    n -= f;
-    if (n > 0 && ladder_applies(e)) {
+    int f = 0;
+    // (the persistent ladder kernel first: where both apply it steps a small ladder in half the fused kernel's time -- 20 rungs of 6
+    //  dimensions with the sampler's defaults: 11 against 22 us)
+    if (ladder_applies(e)) {
       // small portions are counted and launched together later (lad_deferred); PTM_LADDER_DEFER=0: every call launches
       static const bool defer_ok = [] { const char* v = getenv("PTM_LADDER_DEFER"); return !(v && *v == '0'); }();
       if (defer_ok && n < 64) {
@@ -1930,6 +1932,12 @@ extern "C" int ptm_step(ptm_engine* e, int n) {
       }
       if ((rc = ladder_flush(e))) return rc;
       f = ladder_steps(e, n);   // (launches of that kernel follow each other without a look at the outcome of the one before: ladder_settle)
+      if (f < 0) return f;
+      n -= f;
+    }
+    if (n > 0) {
+      if ((rc = ladder_settle(e))) return rc;
+      f = fused_steps(e, n);
       if (f < 0) return f;
       n -= f;
     }
@@ -2662,8 +2670,8 @@ extern "C" const char* ptm_step_kernel_name(ptm_engine* e) {
   const bool fused = e->DP <= 16 && (long long)e->Nt * e->DP <= 256 && !e->cb && !e->pcb && !e->cfg.time_kernels && !(getenv("PTM_FUSED") && *getenv("PTM_FUSED") == '0') &&
                      !(e->evolve_rate > 0 && (e->W > 64 || e->evolve_cut >= 0));
   if (e->nloc != e->Nt) snprintf(b, sizeof b, "(sharded: ptm_exchange_* / ptm_shard_step) decide_kernel + %s", ptm_sweep_kernel_name(e));
-  else if (fused) snprintf(b, sizeof b, "ladder_steps_kernel<%d, %d, %d>", e->DP, e->prop_kind == PTM_PROP_DIAG ? KIND_DIAG : KIND_DENSE, (long long)e->Nt * e->DP <= 64 ? 64 : 256);
   else if (ladder_applies(e)) snprintf(b, sizeof b, "ladder_persistent_kernel<%d, %d, %d>", e->DP, e->prop_kind == PTM_PROP_DIAG ? KIND_DIAG : KIND_DENSE, ladder_flavour(e));
+  else if (fused) snprintf(b, sizeof b, "ladder_steps_kernel<%d, %d, %d>", e->DP, e->prop_kind == PTM_PROP_DIAG ? KIND_DIAG : KIND_DENSE, (long long)e->Nt * e->DP <= 64 ? 64 : 256);
   else snprintf(b, sizeof b, "decide_kernel + %s", ptm_sweep_kernel_name(e));
   name = b;
   return name.c_str();

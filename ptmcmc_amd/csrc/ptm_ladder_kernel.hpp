@@ -79,7 +79,7 @@ __device__ __forceinline__ void lad_store16(lad_d2* q, lad_d2 v) { asm volatile(
 
 template <int DP, int KIND, int FL>
 __global__ __launch_bounds__(LADDER_THREADS) void ladder_persistent_kernel(const Dev p, const LadderArgs a) {
-  static_assert(DP == 16 || DP == 32, "persistent ladder kernel: DP 16 or 32");
+  static_assert(DP == 4 || DP == 8 || DP == 16 || DP == 32, "persistent ladder kernel: DP 4 .. 32");
   constexpr bool GENX = (FL & 1) != 0;   // one-dimensional moves, scale mixtures
   constexpr bool HIST = (FL & 2) != 0;   // history ring, MAP tracking
   constexpr bool EV = (FL & 4) != 0;     // evolving ladders
@@ -514,15 +514,20 @@ __global__ __launch_bounds__(LADDER_THREADS) void ladder_persistent_kernel(const
         vbuf[g * DP + d] = zd;
         sync_wave();
         double acc = 0.0;
+        if constexpr (DP <= 8) {   // the shared column order (ptmo_column_order): natural up to 8 dimensions ...
 #pragma unroll
-        for (int h = 0; h < DP / 16; ++h)
+          for (int j = 0; j < DP; ++j) acc = __builtin_fma(tcol[KIND == KIND_DIAG ? 0 : j], vbuf[g * DP + j], acc);
+        } else {                   // ... else halves of 16 columns, inside a half s + 4k with s outer, k inner
 #pragma unroll
-          for (int sl = 0; sl < 4; ++sl)
+          for (int h = 0; h < DP / 16; ++h)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-              const int j = 16 * h + 4 * k + sl;
-              acc = __builtin_fma(tcol[KIND == KIND_DIAG ? 0 : j], vbuf[g * DP + j], acc);
-            }
+            for (int sl = 0; sl < 4; ++sl)
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                const int j = 16 * h + 4 * k + sl;
+                acc = __builtin_fma(tcol[KIND == KIND_DIAG ? 0 : j], vbuf[g * DP + j], acc);
+              }
+        }
         off = acc;
         sync_wave();
       }

@@ -41,6 +41,8 @@ PTM_DECL_FUSED(16)
   size_t ladder_lds_##N(int Nt, int ms, bool ev);           \
   int ladder_blocks_##N(bool diag, int fl, size_t lds);     \
   hipError_t launch_ladder_##N(const Dev& p, const LadderArgs& a, bool diag, int fl, int grid, size_t lds, hipStream_t st);
+PTM_DECL_LADDER(4)
+PTM_DECL_LADDER(8)
 PTM_DECL_LADDER(16)
 PTM_DECL_LADDER(32)
 #undef PTM_DECL_LADDER

@@ -73,11 +73,11 @@ def test_differential_evolution_on_the_device_matches_the_oracle(D, Nt, W, kind,
     # everything else: a lane per dimension
     assert eng.sweep_kernel_name.startswith("sweep_kernel<" if (W % 64 == 0 and D <= 8) else "sweep_lanes_kernel<"), eng.sweep_kernel_name
     # ... and 9..32 dimensions of them step in the persistent ladder kernel's build with differential evolution (FL = 11)
-    # (a ladder whose rungs x padded dimensions fit 256 lanes: many steps per launch of the fused small-ladder kernel)
+    # (the persistent kernel: up to 32 dimensions, any population whose grid -- walkers x workgroups per ladder -- is resident at once:
+    #  a workgroup per CU; else, a ladder whose rungs x padded dimensions fit 256 lanes: the fused small-ladder kernel)
     DPad = 4 if D <= 4 else 8 if D <= 8 else 16 if D <= 16 else 32
-    fused = D <= 16 and Nt * DPad <= 256
-    # (the persistent kernel: any population whose grid -- walkers x workgroups per ladder -- is resident at once: a workgroup per CU)
-    on_ladder = 9 <= D <= 32 and not fused and W * -(-Nt // (256 // DPad)) <= 256
+    on_ladder = D <= 32 and W * -(-Nt // (256 // DPad)) <= 256
+    fused = not on_ladder and D <= 16 and Nt * DPad <= 256
     assert eng.step_kernel_name.startswith("ladder_persistent_kernel<") == on_ladder, eng.step_kernel_name
     assert eng.step_kernel_name.startswith("ladder_steps_kernel<") == fused, eng.step_kernel_name
     if on_ladder:
@@ -112,10 +112,11 @@ def test_differential_evolution_on_the_device_matches_the_oracle(D, Nt, W, kind,
 
 @pytest.mark.parametrize("D,Nt,W,kind,snooker,K,steps", [
     (12, 20, 4, E.PROP_DIAG, 0.2, 6, 60),
-    (12, 16, 2, E.PROP_LOWER, 0.2, 3, 40),     # (rungs x padded dimensions <= 256: the fused small-ladder kernel)
+    (12, 16, 2, E.PROP_LOWER, 0.2, 3, 40),
     (32, 24, 2, E.PROP_DENSE, 0.3, 2, 40),
     (20, 40, 3, E.PROP_LOWER, 0.1, 3, 40),
-    (6, 12, 3, E.PROP_DIAG, 0.3, 2, 60),       # (up to 8 dimensions: the two-launch path)
+    (6, 12, 3, E.PROP_DIAG, 0.3, 2, 60),       # (8 padded dimensions: 32 rungs per workgroup)
+    (3, 10, 300, E.PROP_DIAG, 0.3, 2, 40),     # (more ladders than workgroups fit, evolving: exchange kernel + lanes kernel)
 ])
 def test_differential_evolution_on_evolving_ladders(D, Nt, W, kind, snooker, K, steps):
     """The reference sampler's defaults together: the default proposal set drawn on the device AND pry_temps after every accepted
@@ -124,8 +125,8 @@ def test_differential_evolution_on_evolving_ladders(D, Nt, W, kind, snooker, K, 
     pr, eng, lad = _pair(D, Nt, W, kind, 1, snooker, 12, K, cap)
     eng.set_evolve_temps(0.01); lad.evolve_temps(0.01)
     DPad = 4 if D <= 4 else 8 if D <= 8 else 16 if D <= 16 else 32
-    fused = D <= 16 and Nt * DPad <= 256
-    on_ladder = 9 <= D <= 32 and not fused
+    on_ladder = D <= 32 and W * -(-Nt // (256 // DPad)) <= 256
+    fused = not on_ladder and D <= 16 and Nt * DPad <= 256 and W <= 64   # (an evolving population beyond 64 ladders: two launches)
     assert eng.step_kernel_name.startswith("ladder_persistent_kernel<") == on_ladder, eng.step_kernel_name
     assert eng.step_kernel_name.startswith("ladder_steps_kernel<") == fused, eng.step_kernel_name
     if on_ladder:

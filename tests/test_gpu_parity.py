@@ -173,6 +173,10 @@ SWEEP_CASES = [
     (21, 6, 384, 1e3, E.PROP_LOWER, None),
     (32, 8, 320, 1e3, E.PROP_DENSE, None),
     (19, 5, 320, 1e2, E.PROP_DIAG, 0.5),
+    # (... and these the general kernel -- whole waves per rung, a lane per chain -- and the fused small-ladder kernel)
+    (6, 40, 320, 1e3, E.PROP_LOWER, None),
+    (3, 12, 320, 1e2, E.PROP_DENSE, None),
+    (5, 9, 300, 1e2, E.PROP_DENSE, 0.3),
     (16, 12, 64, 1e3, E.PROP_DIAG, 0.5),     # the sampler's default Gaussian flavour: diagonal + 1-D moves
     (32, 9, 3, 1e3, E.PROP_DENSE, None),     # lanes kernel (a lane per dimension: fewer than 64 walkers per rung), dense
     (13, 11, 5, 1e2, E.PROP_DIAG, None),     # lanes kernel, 13 -> 16 dimensions, diagonal; 55 chains: a ragged last wave

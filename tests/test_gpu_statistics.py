@@ -41,8 +41,10 @@ STAT_CASES = [
     ("general / fused kernel", 8, 12, 8192, E.PROP_LOWER, 0.0, 10, 100, "ladder_steps_kernel<8"),
     ("f64 matrix cores, 32 dimensions", 32, 8, 4096, E.PROP_LOWER, 0.0, 10, 150, "sweep_mfma32_kernel"),
     ("... with evolving ladders", 32, 8, 4096, E.PROP_LOWER, 0.01, 10, 150, "sweep_mfma32_kernel"),
-    ("small ladder in one workgroup", 12, 10, 60, E.PROP_DENSE, 0.0, 600, 60, "ladder_steps_kernel<16"),
-    ("lanes kernel", 8, 40, 60, E.PROP_DENSE, 0.0, 600, 60, "sweep_lanes_kernel<8"),
+    # (300 walkers: more ladders than the persistent ladder kernel's grid holds -- the fused small-ladder kernel / exchange + lanes kernel)
+    ("small ladder in one workgroup", 12, 10, 300, E.PROP_DENSE, 0.0, 120, 60, "ladder_steps_kernel<16"),
+    ("lanes kernel", 12, 40, 100, E.PROP_DENSE, 0.0, 360, 60, "decide_kernel + sweep_lanes_kernel<16"),
+    ("persistent ladder kernel, 8 padded dimensions", 8, 40, 60, E.PROP_DENSE, 0.0, 600, 60, "ladder_persistent_kernel<8"),
     ("f64 matrix cores, 64 dimensions", 64, 6, 2048, E.PROP_LOWER, 0.0, 8, 300, "sweep_mfma64_kernel"),
     ("f64 matrix cores, 128 dimensions, evolving", 128, 5, 1024, E.PROP_LOWER, 0.01, 8, 600, "sweep_mfma128_kernel"),
     ("persistent ladder kernel", 32, 40, 48, E.PROP_LOWER, 0.0, 1500, 60, "ladder_persistent_kernel<32"),
