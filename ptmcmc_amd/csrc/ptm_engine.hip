@@ -1735,7 +1735,7 @@ static bool ladder_applies(ptm_engine* e, long long* grid_out = nullptr, size_t*
   // mixtures, history and MAP tracking have their builds: ladder_flavour); ANY population whose grid is resident at once (below): where
   // it fits, a step costs this kernel its ~6 us of latency whatever the walkers' number (64 walkers x 64 rungs of 12 dimensions with the
   // sampler's defaults: 14 us against 40 on two launches)
-  if ((e->has_bounds && !e->bounds_box) || !e->all_uniform || e->has_mean || e->cb || e->prior_cb || e->pcb) return false;
+  if ((e->has_bounds && !e->bounds_box) || !e->all_uniform || e->cb || e->prior_cb || e->pcb) return false;
   const int R = 256 / e->DP, NB = (e->Nt + R - 1) / R;
   const long long grid = (long long)e->W * NB;
   const bool diag = e->prop_kind == PTM_PROP_DIAG;

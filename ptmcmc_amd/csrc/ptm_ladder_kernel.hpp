@@ -30,7 +30,7 @@
 //
 // Arithmetic: the operation sequences of lanes_body / decide_body, number for number -- the chains are bit-identical to the
 // two-launch path and to the CPU checker (the parity suite runs through this kernel wherever it applies).
-// Scope: open or `limit` bounds, all-uniform prior, zero mean, fixed ladder, device target, DP = 16 or 32; template flags FL: bit 0 =
+// Scope: open or `limit` bounds, all-uniform prior, device target (a mean included), DP = 4 .. 32; template flags FL: bit 0 =
 // one-dimensional moves and scale mixtures (the reference sampler's default Gaussian recipe, ptmcmc.cc:117-139), bit 1 = the history
 // ring and MAP tracking of MH_chain::add_state (chain.cc:931-946), rows of a rung exchanged twice in a step included (quirk Q6); bit 2 =
 // EVOLVING LADDERS (parallel_tempering_chains::evolve_temps: pry_temps after every accepted exchange, chain.cc:1501-1518,1809-1846,
@@ -198,6 +198,7 @@ __global__ __launch_bounds__(LADDER_THREADS) void ladder_persistent_kernel(const
   }
   const double grow = 1.0 + a.evolve_rate;
   const double plo = p.plo[d], phi = p.phi[d];
+  const double mean_d = p.has_mean ? p.mean[d] : 0.0;   // the target's mean (x - 0.0 is x, bit for bit: no second code path)
   // open / `limit` boundaries (boundary::enforce, states.cc:53-55) as a second box: without bounds it holds everything
   const double elo = (p.has_bounds && p.blo[d] == B_LIMIT) ? p.bmin[d] : -__builtin_inf();
   const double ehi = (p.has_bounds && p.bhi[d] == B_LIMIT) ? p.bmax[d] : __builtin_inf();
@@ -676,7 +677,7 @@ __global__ __launch_bounds__(LADDER_THREADS) void ladder_persistent_kernel(const
       valid = p.origin_valid != 0 && all_of_chain(!(xn < elo) && !(xn > ehi));   // stateSpace::enforce, states.cc:86-102
       newlprior = in ? p.lprior_const : -__builtin_inf();
       if (!valid) newlprior = -__builtin_inf();
-      vbuf[g * DP + d] = xn;
+      vbuf[g * DP + d] = xn - mean_d;
       sync_wave();
       {
         // s_d = sum_{j<=d} P2_dj y_j, one fma chain with j ascending (gauss_llike's order); the terms behind the diagonal add

@@ -1675,3 +1675,27 @@ def test_persistent_ladder_kernel_after_the_proposal_kind_changes():
     PU.assert_same_state(eng, lad, "full factors")
     assert eng.ladder_stats()["fallbacks"] == 0
     eng.close()
+
+
+@pytest.mark.parametrize("D,Nt,W,kind,ev,hist", [(32, 40, 3, E.PROP_LOWER, 0.0, 0), (12, 24, 5, E.PROP_DENSE, 0.02, 2), (5, 40, 2, E.PROP_DIAG, 0.0, 1), (20, 16, 64, E.PROP_LOWER, 0.01, 0)])
+def test_persistent_ladder_kernel_with_a_target_mean(D, Nt, W, kind, ev, hist):
+    """A Gaussian target that is not centred on the origin (gaussian_likelihood's mean: cython/exampleGaussian.py:46-109) in the
+    persistent ladder kernel -- one subtraction on the dimension's lane in front of the precision product, as in every other kernel
+    -- plain, evolving, with history and MAP, 4..32 padded dimensions, whole waves per rung."""
+    rng = np.random.default_rng(D + Nt)
+    mean = rng.normal(size=D) * 0.3
+    pr, eng, lad = PU.make_pair(D, Nt, W, 1e3, kind=kind, swap_rate=0.3, one_d_frac=0.3 if hist else None, mean=mean, add_every_n=max(1, hist),
+                                history_cap=64 if hist else 0)
+    if ev:
+        eng.set_evolve_temps(ev); lad.evolve_temps(ev)
+    assert eng.step_kernel_name.startswith("ladder_persistent_kernel<"), eng.step_kernel_name
+    for n in (1, 5, 24):
+        eng.step(n); eng.sync(); lad.pt_step(n)
+        PU.assert_same_state(eng, lad, "after %d more steps" % n)
+        if ev:
+            assert np.array_equal(eng.invtemps(), lad.betaw)
+    if hist:
+        PU.assert_same_history_and_map(eng, lad, 64)
+    st = eng.ladder_stats()
+    assert st["launches"] > 0 and st["fallbacks"] == 0
+    eng.close()
