@@ -341,6 +341,11 @@ int ptm_get_history(ptm_engine* e, double* X, double* llike, double* lprior, int
 /* the inverse temperature each saved row was saved at (MH_chain::invtemps, chain.cc:943), beta[k*HC + index]: the
  * ladder's value while the ladder is fixed, the chain's own once the ladders evolve */
 int ptm_get_history_invtemps(ptm_engine* e, double* beta);
+/* The ring entries of history chains [chain_begin, chain_begin + chain_count) only (chain = local rung * n_walkers + walker), written into
+ * host arrays of ptm_get_history's FULL layout -- [capacity][history chains][..] -- whose other entries stay untouched; any of the five
+ * pointers may be NULL.  What a chain-file writer needs (chain::dumpChain, chain.cc:1110-1140, for the rungs it dumps) without reading
+ * every rung's ring: with differential evolution on the device the ring holds all rungs for the whole run. */
+int ptm_get_history_chains(ptm_engine* e, int chain_begin, int chain_count, double* X, double* llike, double* lprior, int32_t* meta, double* invtemps);
 /* put a saved ring / MAP back (after ptm_restore): the arrays exactly as ptm_get_history (+ ptm_get_history_invtemps;
  * invtemps may be NULL while the ladder is fixed) and ptm_get_map returned them */
 int ptm_set_history(ptm_engine* e, const double* X, const double* llike, const double* lprior, const int32_t* meta,

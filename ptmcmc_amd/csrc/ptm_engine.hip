@@ -2510,6 +2510,39 @@ extern "C" int ptm_get_history(ptm_engine* e, double* X, double* llike, double* 
   if (meta) { FETCH(s, e->hist.meta, n * 16); e->fetch_after.push_back([=] { memcpy(meta, s, n * 16); }); }
   return fetch_done(e);
 }
+// The history ring of chains [chain_begin, chain_begin + chain_count) only, into host arrays of the FULL layout of ptm_get_history
+// ([capacity][history chains][..]: the other chains' entries stay as they are): a chain-file writer reads the two or three rungs it
+// dumps, not every rung's ring -- with differential evolution on the device the ring holds every rung for the whole run.
+extern "C" int ptm_get_history_chains(ptm_engine* e, int chain_begin, int chain_count, double* X, double* llike, double* lprior, int32_t* meta, double* beta) {
+  SETTLE(e);
+  NO_BATCH(e, "ptm_get_history_chains");
+  if (!e) return fail(PTM_ERR_INVALID, "null engine");
+  if (!e->hist.rungs) return fail(PTM_ERR_INVALID, "history is off (ptm_config.history_rungs)");
+  const size_t cap = (size_t)e->hist.cap, HC = (size_t)e->hist.HC, D = e->D, DP = e->DP;
+  if (chain_begin < 0 || chain_count < 0 || (size_t)chain_begin + (size_t)chain_count > HC) return fail(PTM_ERR_INVALID, "chain range outside the history's chains");
+  if (!chain_count) return PTM_OK;
+  const size_t n = (size_t)chain_count, b0 = (size_t)chain_begin;
+  HIPCHK(hipStreamSynchronize(e->stream));
+  std::vector<double> tmp;
+  if (X) {
+    tmp.resize(cap * n * DP);
+    HIPCHK(hipMemcpy2D(tmp.data(), n * DP * 8, e->hist.x + b0 * DP, HC * DP * 8, n * DP * 8, cap, hipMemcpyDeviceToHost));
+    for (size_t r = 0; r < cap; ++r) unpad_rows(tmp.data() + r * n * DP, n, D, DP, X + (r * HC + b0) * D);
+  }
+  auto scalars = [&](const double* dev, double* out) -> hipError_t { return hipMemcpy2D(out + b0, HC * 8, dev + b0, HC * 8, n * 8, cap, hipMemcpyDeviceToHost); };
+  if (llike) HIPCHK(scalars(e->hist.ll, llike));
+  if (lprior) HIPCHK(scalars(e->hist.lp, lprior));
+  if (meta) HIPCHK(hipMemcpy2D(meta + 4 * b0, HC * 16, reinterpret_cast<const char*>(e->hist.meta) + b0 * 16, HC * 16, n * 16, cap, hipMemcpyDeviceToHost));
+  if (beta) {
+    if (e->hist.beta) HIPCHK(scalars(e->hist.beta, beta));
+    else {
+      if (!e->have_ladder) return fail(PTM_ERR_INVALID, "no ladder set");
+      for (size_t r = 0; r < cap; ++r)
+        for (size_t c = b0; c < b0 + n; ++c) beta[r * HC + c] = e->h_beta[e->r0 + (int)c / e->W];
+    }
+  }
+  return PTM_OK;
+}
 extern "C" uint64_t ptm_step_count(ptm_engine* e) {
   if (e) (void)ladder_settle(e);
   return e ? e->step : 0;

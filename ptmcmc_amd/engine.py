@@ -24,7 +24,7 @@ PRIOR_NAMES = {"uni": 1, "uniform": 1, "gauss": 2, "gaussian": 2, "pol": 3, "pol
 EXPORTS = [
     "ptm_last_error", "ptm_abi_version", "ptm_device_count", "ptm_engine_create", "ptm_engine_destroy",
     "ptm_set_bounds", "ptm_set_prior", "ptm_set_target_gaussian", "ptm_set_target_callback", "ptm_set_prior_callback", "ptm_set_ladder", "ptm_set_evolve_temps", "ptm_get_invtemps", "ptm_set_invtemps",
-    "ptm_set_proposals", "ptm_set_proposal_rung", "ptm_set_proposal_mixture", "ptm_set_proposal_callback", "ptm_set_proposal_de", "ptm_set_states", "ptm_init_from_prior", "ptm_init_from_prior_k", "ptm_draw_prior_rows", "ptm_sweep", "ptm_step", "ptm_sync",
+    "ptm_set_proposals", "ptm_set_proposal_rung", "ptm_set_proposal_mixture", "ptm_set_proposal_callback", "ptm_set_proposal_de", "ptm_set_states", "ptm_init_from_prior", "ptm_init_from_prior_k", "ptm_draw_prior_rows", "ptm_get_history_chains", "ptm_sweep", "ptm_step", "ptm_sync",
     "ptm_copy_llike", "ptm_copy_lprior", "ptm_llike_device_ptr", "ptm_exchange_decide", "ptm_exchange_decide_gathered", "ptm_set_shard_map", "ptm_exchange_redo_count", "ptm_exchange_redo", "ptm_exchange_finish_and_sweep", "ptm_exchange_install", "ptm_sweep_rungs", "ptm_exchange_buffer_doubles", "ptm_exchange_row_capacity", "ptm_shard_unique_id", "ptm_shard_init", "ptm_shard_step", "ptm_shard_finalize", "ptm_get_states", "ptm_batch_begin", "ptm_batch_end",
     "ptm_get_array", "ptm_get_swap_counts", "ptm_get_last_swaps", "ptm_max_swaps_per_step", "ptm_get_history", "ptm_get_history_invtemps", "ptm_set_history", "ptm_set_map", "ptm_get_map", "ptm_restore", "ptm_step_count",
     "ptm_timer_start", "ptm_timer_stop", "ptm_get_kernel_times", "ptm_calibrate", "ptm_get_counter_sums", "ptm_get_ladder_stats", "ptm_sweep_kernel_name", "ptm_step_kernel_name", "ptm_debug_eval",
@@ -441,6 +441,16 @@ class Engine:
     def init_from_prior(self, k=0):
         """the k-th initial draw of every chain (k = 0: MH_chain::initialize(1)'s; ptm_init_from_prior_k)"""
         _chk(self.L.ptm_init_from_prior_k(self.h, int(k)))
+
+    def history_chains(self, chain_begin, chain_count):
+        """the ring entries of a range of history chains, in arrays of history()'s full layout whose other entries are NaN / -1 (ptm_get_history_chains)"""
+        cap, HC, D = self.hist_cap, self.hist_rungs * self.W, self.D
+        x = np.full((cap, HC, D), np.nan); ll = np.full((cap, HC), np.nan); lp = np.full((cap, HC), np.nan); beta = np.full((cap, HC), np.nan)
+        meta = np.full((cap, HC, 4), -1, dtype=np.int32)
+        self.L.ptm_get_history_chains.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp, _dp, _dp, C.c_void_p, _dp]
+        _chk(self.L.ptm_get_history_chains(self.h, int(chain_begin), int(chain_count), x.ctypes.data_as(_dp), ll.ctypes.data_as(_dp), lp.ctypes.data_as(_dp),
+                                           meta.ctypes.data, beta.ctypes.data_as(_dp)))
+        return dict(x=x, llike=ll, lprior=lp, meta=meta, invtemp=beta)
 
     def draw_prior_rows(self, k_begin, n):
         """draws k_begin .. k_begin + n - 1 of every chain, the engine's state untouched (ptm_draw_prior_rows): x [n][Nc][D], llike, lprior [n][Nc]"""

@@ -1819,6 +1819,8 @@ class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:
            // other, ptmcmc.cc main loop): chain (rung i, replica w) sits at index i*W + w of every engine array
   std::vector<double> temps, X, llike, lpost;
   bool fresh, hist_fresh = false;
+  size_t hist_have = 0;       // history chains [0, hist_have) are in hx / hl / hp / hmeta / hb (when hist_fresh)
+  int hist_read_rungs = 0;    // > 0: a read-back fetches this many rungs (limit_history_reads), 0: all that keep history
   // replica-exchange diagnostics of chain.cc:1346-1356,1448-1451,1495-1498 (directions / instances / ups / downs), kept
   // on the host by replaying each step's candidate log (replica 0); on after track_exchanges(true)
   bool tracking = false;
@@ -2047,7 +2049,7 @@ class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:
     hist_rows = rows_per_chain;
     hist_rungs = coldest_rungs > 0 && coldest_rungs < Ntemps ? coldest_rungs : 0;
   }
-  int history_rungs() const { return hist_rows > 0 ? (hist_rungs > 0 ? hist_rungs : Ntemps) : 0; }
+  int history_rungs() const { return hist_rows > 0 ? ((hist_rungs > 0 && !de_built) ? hist_rungs : Ntemps) : 0; }   // (differential evolution on the device: every rung's ring)
   // Run `n` independent replicas of the ladder in one engine (call before initialize()).  Replica w uses the random
   // streams of walker w; every accessor below takes the replica as an optional last argument (default 0).  Multiples
   // of 64 fill whole wavefronts and take the fast kernels.
@@ -2509,6 +2511,23 @@ class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:
   // MH_chain::dumpChain (chain.cc:1112-1135) for rung `ichain`: one line per saved step i = Nburn, Nburn+ievery, ... :
   //   i lpost llike acceptance_ratio prop_type: p0 ... pD-1 invtemp
   // Rows that have already left the ring are skipped (the ring holds the newest rows_per_chain saved states).
+  // The device's history ring -> hx / hl / hp / hmeta / hb (the ring's own layout [row][history chain]), the chains a dump or an
+  // effective-sample estimate reads: rungs [0, hist_read_rungs) if the driver has said which it writes out (limit_history_reads:
+  // ptmcmc_sampler::run dumps pt_dump_n rungs and estimates on the cold one), every history rung as soon as anybody asks beyond.  With
+  // differential evolution on the device the ring holds EVERY rung for the whole run: all of it was 0.1 s per output event at 128
+  // temperatures x 4000 rows of 32 parameters, most of a run that reports every 500 steps.
+  void read_history(size_t at, const char* who) {
+    const size_t HC = (size_t)history_rungs() * W, cap = hist_rows;
+    size_t want = hist_read_rungs > 0 ? (size_t)std::min(hist_read_rungs, history_rungs()) * W : HC;
+    if (at >= want) want = HC;
+    if (hist_fresh && hist_have >= want) return;
+    hx.resize(cap * HC * dim); hl.resize(cap * HC); hp.resize(cap * HC); hmeta.resize(cap * HC * 4); hnhist.resize((size_t)Ntemps * W); hb.resize(cap * HC);
+    ptm_check(ptm_get_history_chains(eng, 0, (int)want, hx.data(), hl.data(), hp.data(), hmeta.data(), hb.data()), who);   // (hb: the temperature each row was saved at)
+    ptm_check(ptm_get_array(eng, PTM_ARR_NHIST, hnhist.data()), who);
+    hist_fresh = true;
+    hist_have = want;
+  }
+  void limit_history_reads(int rungs) { hist_read_rungs = rungs; }
   void dumpChain(int ichain, std::ostream& os, int Nburn = 0, int ievery = 1, int replica = 0) {
     if (host_mode) {   // host-side proposals: the whole saved history is in the host mirror
       const size_t at = (size_t)ichain * W + replica;
@@ -2536,13 +2555,7 @@ class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:
     if (hist_rows <= 0) { std::cout << "parallel_tempering_chains::dumpChain: call keep_history(rows) before initialize()" << std::endl; exit(1); }
     if (ichain >= history_rungs()) { std::cout << "parallel_tempering_chains::dumpChain: rung " << ichain << " keeps no history (keep_history(rows, " << history_rungs() << "))" << std::endl; exit(1); }
     const size_t HC = (size_t)history_rungs() * W, cap = hist_rows, at = (size_t)ichain * W + replica;
-    if (!hist_fresh) {   // one read-back serves every rung / replica dumped at this step
-      hx.resize(cap * HC * dim); hl.resize(cap * HC); hp.resize(cap * HC); hmeta.resize(cap * HC * 4); hnhist.resize((size_t)Ntemps * W); hb.resize(cap * HC);
-      ptm_check(ptm_get_history(eng, hx.data(), hl.data(), hp.data(), hmeta.data()), "dumpChain");
-      ptm_check(ptm_get_history_invtemps(eng, hb.data()), "dumpChain");   // the temperature each row was saved at
-      ptm_check(ptm_get_array(eng, PTM_ARR_NHIST, hnhist.data()), "dumpChain");
-      hist_fresh = true;
-    }
+    read_history(at, "dumpChain");   // one read-back serves every rung / replica dumped at this step
     const std::vector<int32_t>& meta = hmeta;
     // (rows are numbered as the ring numbers them -- row 0 the start state --; with differential evolution on the device the header
     //  names the initial draws the device keeps beside the ring, as the reference's file does)
@@ -2592,13 +2605,7 @@ class parallel_tempering_chains : public chain {  // chain.hh:214-330, chain.cc:
     }
     if (hist_rows <= 0) return false;
     const size_t HC = (size_t)history_rungs() * W, cap = hist_rows;
-    if (!hist_fresh) {
-      hx.resize(cap * HC * dim); hl.resize(cap * HC); hp.resize(cap * HC); hmeta.resize(cap * HC * 4); hnhist.resize((size_t)Ntemps * W); hb.resize(cap * HC);
-      ptm_check(ptm_get_history(eng, hx.data(), hl.data(), hp.data(), hmeta.data()), "report_effective_samples");
-      ptm_check(ptm_get_history_invtemps(eng, hb.data()), "report_effective_samples");
-      ptm_check(ptm_get_array(eng, PTM_ARR_NHIST, hnhist.data()), "report_effective_samples");
-      hist_fresh = true;
-    }
+    read_history(at, "report_effective_samples");
     const int idx = 1 + step / add_every_N;
     const size_t o = (size_t)(idx % (int)cap) * HC + at;
     if (hmeta[4 * o + 3] != idx) return false;
@@ -3078,6 +3085,7 @@ class ptmcmc_sampler : public bayes_sampler {
     if (ic > 0 && restarting) { std::cout << "ptmcmc_sampler::run: Can't restart except for single chain ic=0." << std::endl; exit(1); }
     int dn = dump_n;
     if (dn > cc->multiplicity() || dn <= 0) dn = cc->multiplicity();   // ptmcmc.cc:458
+    cc->limit_history_reads(dn);   // (this loop dumps rungs 0 .. dn - 1 and estimates on the cold one: no other rung's ring is read back)
     const int nrep = cc->replicas(), every = std::max(1, Nevery), skip = std::max(1, Nskip);
     std::ios_base::openmode mode = std::ios::out;
     if (ic > 0 || restarting) mode = mode | std::ios::app;   // ptmcmc.cc:538

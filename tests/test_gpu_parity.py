@@ -1699,3 +1699,24 @@ def test_persistent_ladder_kernel_with_a_target_mean(D, Nt, W, kind, ev, hist):
     st = eng.ladder_stats()
     assert st["launches"] > 0 and st["fallbacks"] == 0
     eng.close()
+
+
+def test_history_of_a_range_of_chains_is_the_whole_history_s_slice():
+    """ptm_get_history_chains: the ring entries of some chains only -- what a chain-file writer reads for the rungs it dumps -- are,
+    entry for entry, those of ptm_get_history; the rest of the (full-layout) arrays is left alone."""
+    D, Nt, W = 7, 9, 5
+    pr, eng, lad = PU.make_pair(D, Nt, W, 1e3, kind=E.PROP_DENSE, swap_rate=0.4, add_every_n=2, history_cap=16)
+    eng.set_evolve_temps(0.02)
+    eng.step(40); eng.sync()
+    full = eng.history()
+    for b, n in ((0, W), (2 * W + 1, 3 * W), (Nt * W - 4, 4), (0, Nt * W)):
+        part = eng.history_chains(b, n)
+        sl = slice(b, b + n)
+        assert np.array_equal(part["x"][:, sl], full["x"][:, sl]) and np.array_equal(part["llike"][:, sl], full["llike"][:, sl])
+        assert np.array_equal(part["lprior"][:, sl], full["lprior"][:, sl]) and np.array_equal(part["invtemp"][:, sl], full["invtemp"][:, sl])
+        assert np.array_equal(part["meta"][:, sl, 3], full["row"][:, sl]) and np.array_equal(part["meta"][:, sl, 0], full["naccept"][:, sl])
+        rest = np.ones(Nt * W, bool); rest[sl] = False
+        assert np.isnan(part["x"][:, rest]).all() and (part["meta"][:, rest] == -1).all()
+    with pytest.raises(E.PtmError):
+        eng.history_chains(Nt * W - 2, 3)
+    eng.close()
