@@ -123,7 +123,8 @@ struct ptm_engine {
   double *pub_x = nullptr, *pub_ll = nullptr, *pub_lp = nullptr;   // (one allocation: pub_x)
   int *lad_flags = nullptr, *lad_ctl = nullptr;                     // (one allocation: lad_flags)
   long long* lad_prof = nullptr;
-  int lad_capacity[2][16] = {{-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1}, {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1}};   // workgroups of each build of that kernel [diagonal][FL] the device holds at once (-1: not asked yet)
+  int lad_capacity[2][32] = {{-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1},
+                             {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1}};   // workgroups of each build of that kernel [diagonal][FL] the device holds at once (-1: not asked yet)
   long long ladder_launches = 0, ladder_whole_steps = 0;   // launches of that kernel; steps (of walker 0) whose exchange phase needed the whole ladder
   // A launch of that kernel commits all of its steps or none (ptm_ladder_kernel.hpp) and is ASYNCHRONOUS: the host learns at its
   // next look (ladder_settle) whether the launches since the last look were committed -- the device keeps the number of the last one
@@ -1724,6 +1725,9 @@ static int fused_steps(ptm_engine* e, int n) {
 // bit 2 evolving ladders (built plain, 4, and with everything, 7)
 static int ladder_flavour(const ptm_engine* e) {
   const int fl = ((e->any_oned || e->mix_K > 0) ? 1 : 0) | ((e->hist.rungs || e->map.rungs) ? 2 : 0);
+  // any boundary (wrap, reflect) or a prior that is not all uniform: the builds with the general state space, which carry the recipe's and
+  // the history's code whether or not this engine uses them (19, 23, 27, 31)
+  if ((e->has_bounds && !e->bounds_box) || !e->all_uniform) return 16 | 3 | (e->evolve_rate > 0 ? 4 : 0) | (e->de_on ? 8 : 0);
   if (e->de_on) return e->evolve_rate > 0 ? 15 : 11;   // differential evolution: a member of a set, drawn from the history ring
   return e->evolve_rate > 0 ? (fl ? 7 : 4) : fl;
 }
@@ -1735,7 +1739,7 @@ static bool ladder_applies(ptm_engine* e, long long* grid_out = nullptr, size_t*
   // mixtures, history and MAP tracking have their builds: ladder_flavour); ANY population whose grid is resident at once (below): where
   // it fits, a step costs this kernel its ~6 us of latency whatever the walkers' number (64 walkers x 64 rungs of 12 dimensions with the
   // sampler's defaults: 14 us against 40 on two launches)
-  if ((e->has_bounds && !e->bounds_box) || !e->all_uniform || e->cb || e->prior_cb || e->pcb) return false;
+  if (e->cb || e->prior_cb || e->pcb) return false;
   const int R = 256 / e->DP, NB = (e->Nt + R - 1) / R;
   const long long grid = (long long)e->W * NB;
   const bool diag = e->prop_kind == PTM_PROP_DIAG;

@@ -30,7 +30,8 @@
 //
 // Arithmetic: the operation sequences of lanes_body / decide_body, number for number -- the chains are bit-identical to the
 // two-launch path and to the CPU checker (the parity suite runs through this kernel wherever it applies).
-// Scope: open or `limit` bounds, all-uniform prior, device target (a mean included), DP = 4 .. 32; template flags FL: bit 0 =
+// Scope: device target (a mean included), DP = 4 .. 32, open or `limit` bounds and an all-uniform prior -- or, bit 4 of FL, any boundary and
+// any per-dimension prior; template flags FL: bit 0 =
 // one-dimensional moves and scale mixtures (the reference sampler's default Gaussian recipe, ptmcmc.cc:117-139), bit 1 = the history
 // ring and MAP tracking of MH_chain::add_state (chain.cc:931-946), rows of a rung exchanged twice in a step included (quirk Q6); bit 2 =
 // EVOLVING LADDERS (parallel_tempering_chains::evolve_temps: pry_temps after every accepted exchange, chain.cc:1501-1518,1809-1846,
@@ -84,6 +85,7 @@ __global__ __launch_bounds__(LADDER_THREADS) void ladder_persistent_kernel(const
   constexpr bool HIST = (FL & 2) != 0;   // history ring, MAP tracking
   constexpr bool EV = (FL & 4) != 0;     // evolving ladders
   constexpr bool DEB = (FL & 8) != 0;    // differential evolution from the chain's saved history (with GENX and HIST: FL = 11, 15)
+  constexpr bool GENS = (FL & 16) != 0;  // general state space: any boundary (wrap, reflect) and any per-dimension prior (built with GENX and HIST: 19, 23, 27, 31)
   static_assert(!DEB || (GENX && HIST), "differential evolution is a member of a proposal set and draws from the history ring");
   // a launch whose predecessor gave up does nothing: the host repeats that launch's steps, and this one's, on the two-launch path
   if (__hip_atomic_load(a.done_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.seq - 1) return;
@@ -671,12 +673,38 @@ __global__ __launch_bounds__(LADDER_THREADS) void ladder_persistent_kernel(const
         }
         if (de_move) { xn = xde; type = kmix + 10 * dt; }    // proposal_distribution.cc:117
       }
-      const bool ind = !(xn < plo) && !(xn > phi);
-      const bool in = all_of_chain(ind);
-      // Q9: state::add builds on an enforced zero state -- an origin outside a `limit` bound invalidates every proposal
-      valid = p.origin_valid != 0 && all_of_chain(!(xn < elo) && !(xn > ehi));   // stateSpace::enforce, states.cc:86-102
-      newlprior = in ? p.lprior_const : -__builtin_inf();
-      if (!valid) newlprior = -__builtin_inf();
+      if constexpr (GENS) {
+        // lanes_body's general form, each dimension on its lane: stateSpace::enforce (states.cc:86-102; Q9: the sum is built on an enforced
+        // zero state), then the box of an all-uniform prior or mixed_dist_product::evaluate -- the factors in four interleaved partial
+        // products, combined ((p0 p1) p2) p3
+        bool vd = true;
+        if (p.has_bounds && d < p.D) vd = boundary_enforce(p.blo[d], p.bhi[d], p.bmin[d], p.bmax[d], xn);
+        valid = p.origin_valid != 0 && all_of_chain(vd);
+        if (p.all_uniform) {
+          const bool in = all_of_chain(!(xn < plo) && !(xn > phi));
+          newlprior = (valid && in) ? p.lprior_const : -__builtin_inf();
+        } else {
+          sbuf[g * DP + d] = d < p.D ? prior_pdf(p.ptype[d], plo, phi, p.pcoef[d], xn) : 1.0;
+          sync_wave();
+          if (d < 4) {
+            double pq = 1.0;
+#pragma unroll
+            for (int t = 0; t < DP / 4; ++t) pq *= sbuf[g * DP + d + 4 * t];
+            pbuf[g * 4 + d] = pq;
+          }
+          sync_wave();
+          const double result = ((pbuf[g * 4 + 0] * pbuf[g * 4 + 1]) * pbuf[g * 4 + 2]) * pbuf[g * 4 + 3];
+          sync_wave();   // (sbuf / pbuf are reused by the likelihood)
+          newlprior = valid ? dlog(result) : -__builtin_inf();
+        }
+      } else {
+        const bool ind = !(xn < plo) && !(xn > phi);
+        const bool in = all_of_chain(ind);
+        // Q9: state::add builds on an enforced zero state -- an origin outside a `limit` bound invalidates every proposal
+        valid = p.origin_valid != 0 && all_of_chain(!(xn < elo) && !(xn > ehi));   // stateSpace::enforce, states.cc:86-102
+        newlprior = in ? p.lprior_const : -__builtin_inf();
+        if (!valid) newlprior = -__builtin_inf();
+      }
       vbuf[g * DP + d] = xn - mean_d;
       sync_wave();
       {

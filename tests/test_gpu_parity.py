@@ -1720,3 +1720,43 @@ def test_history_of_a_range_of_chains_is_the_whole_history_s_slice():
     with pytest.raises(E.PtmError):
         eng.history_chains(Nt * W - 2, 3)
     eng.close()
+
+
+@pytest.mark.parametrize("D,Nt,W,kind,ev,hist,K,want", [(12, 40, 3, E.PROP_DENSE, 0.0, 0, 0, 19), (32, 24, 2, E.PROP_LOWER, 0.02, 2, 3, 23), (6, 30, 5, E.PROP_DIAG, 0.02, 1, 2, 23),
+                                                      (3, 12, 64, E.PROP_DENSE, 0.0, 1, 0, 19)])
+def test_persistent_ladder_kernel_with_any_boundary_and_any_per_dimension_prior(D, Nt, W, kind, ev, hist, K, want):
+    """The general state space in the persistent ladder kernel (its builds FL = 19 / 23 / 27 / 31): wrap, reflect, limit and open
+    boundaries (boundary::enforce, states.cc:11-58), a mixed prior -- uniform and Gaussian factors, four interleaved partial products
+    (mixed_dist_product::evaluate, probability_function.cc:219-262) --, a target mean; plain, evolving, with history, MAP and a scale
+    mixture: bit for bit the checker's chains, temperatures, saved rows."""
+    rng = np.random.default_rng(D * 7 + Nt)
+    blo = [int(rng.choice([0, 1, 2, 3])) for _ in range(D)]
+    bhi = [b if b in (2, 3) else int(rng.choice([0, 1])) for b in blo]
+    bounds = (blo, bhi, list(rng.uniform(-3.0, -1.5, D)), list(rng.uniform(1.5, 3.0, D)))
+    types, cen, hw = [1] * D, [0.0] * D, list(rng.uniform(3.5, 6.0, D))
+    for d in range(0, D, 2):
+        types[d] = 2; cen[d] = float(rng.normal() * 0.2); hw[d] = float(rng.uniform(0.8, 2.0))
+    mean = rng.normal(size=D) * 0.1
+    x0 = rng.uniform(-1.2, 1.2, size=(Nt * W, D))
+    pr, eng, lad = PU.make_pair(D, Nt, W, 1e3, kind=kind, swap_rate=0.3, one_d_frac=0.3 if K else None, bounds=bounds, prior=(types, cen, hw), mean=mean, x0=x0,
+                                add_every_n=max(1, hist), history_cap=64 if hist else 0)
+    if K:
+        shares = 2.0 ** np.arange(1, K + 1)
+        cum = np.tile(np.cumsum(shares) / shares.sum(), (Nt, 1)); cum[:, -1] = 1.0
+        scales = np.tile(2.0 ** -np.arange(K)[::-1], (Nt, 1)); odfs = np.full((Nt, K), 0.3)
+        eng.set_proposal_mixture(cum, scales, odfs); lad.set_mixture(cum, scales, odfs)
+    if ev:
+        eng.set_evolve_temps(ev); lad.evolve_temps(ev)
+    assert eng.step_kernel_name.startswith("ladder_persistent_kernel<") and eng.step_kernel_name.endswith(", %d>" % want), eng.step_kernel_name
+    for n in (1, 6, 23):
+        eng.step(n); eng.sync(); lad.pt_step(n)
+        PU.assert_same_state(eng, lad, "after %d more steps" % n)
+        if ev:
+            assert np.array_equal(eng.invtemps(), lad.betaw)
+    if hist:
+        PU.assert_same_history_and_map(eng, lad, 64)
+    tries, acc = eng.ntries.sum() - eng.Nc, eng.naccept.sum() - eng.Nc
+    assert 0 < acc < tries
+    st = eng.ladder_stats()
+    assert st["launches"] > 0 and st["fallbacks"] == 0
+    eng.close()

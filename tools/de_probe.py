@@ -1,7 +1,8 @@
 """The reference sampler's default configuration on a device target -- 80 % differential evolution from the chain's saved history + six
 Gaussians with gauss_1d_frac 0.5 (ptmcmc.cc:60-143), evolving ladder, history every second add, MAP tracking -- bare engine, us per PT
 step.  PTM_LADDER=0: two launches per step (lanes kernel); PTM_LADDER=0 PTM_FORCE_VALU=1: the general kernel.
-usage: python tools/de_probe.py [D] [Nt] [W] [steps]"""
+A fifth argument `general`: wrap / reflect boundaries and Gaussian priors on half of the dimensions (the general state space).
+usage: python tools/de_probe.py [D] [Nt] [W] [steps] [general]"""
 import os
 import sys
 import time
@@ -19,6 +20,13 @@ cap = (warm + reps * n) * 2 // every + 64
 pr = GaussianProblem(D, Nt, 1e6)
 e = E.Engine(D, Nt, W, add_every_n=every, history_rungs=Nt, history_capacity=cap, map_rungs=Nt)
 pr.configure(e, E.PROP_DIAG)
+general = len(sys.argv) > 5
+if general:
+    hw = np.asarray(pr.halfwidths)
+    blo = [3 if d % 3 == 0 else (2 if d % 3 == 1 else 0) for d in range(D)]   # wrap, reflect, open
+    e.set_bounds(blo, blo, list(-hw), list(hw))
+    types = [2 if d % 2 else 1 for d in range(D)]                              # gaussian / uniform
+    e.set_prior(types, [0.0] * D, list(hw))
 K = 6
 g = 2.0 ** np.arange(1, K + 1)
 shares = np.concatenate([[0.8], 0.2 * g / g.sum()])
@@ -38,6 +46,6 @@ for rep in range(reps):
     e.step(n); e.sync()
     best = min(best, (time.perf_counter() - t0) / n)
 t, a = e.counter_sums()
-print("D=%d, %d rungs x %d, default recipe + evolving ladder + history + MAP: %.2f us per PT step   [%s]  MH acceptance %.3f" %
-      (D, Nt, W, best * 1e6, e.step_kernel_name, a / max(1, t)), flush=True)
+print("D=%d, %d rungs x %d, default recipe + evolving ladder + history + MAP%s: %.2f us per PT step   [%s]  MH acceptance %.3f" %
+      (D, Nt, W, ", wrap / reflect bounds + Gaussian priors" if general else "", best * 1e6, e.step_kernel_name, a / max(1, t)), flush=True)
 e.close()
