@@ -676,7 +676,7 @@ def test_bounds_and_mixed_prior_path_bit_exact():
     eng.close()
 
 
-@pytest.mark.parametrize("W", [64, 3])
+@pytest.mark.parametrize("W", [320, 64, 3])   # (320 walkers: exchange kernel + the MFMA kernel's general build; 64 and 3: the persistent ladder kernel's)
 @pytest.mark.parametrize("kind,odf,with_mean,all_uniform", [(E.PROP_DENSE, 0.0, True, False), (E.PROP_LOWER, 0.3, False, False),
                                                             (E.PROP_LOWER, 0.0, False, True), (E.PROP_DENSE, 1.0, True, True)])
 def test_mfma_kernel_general_state_space_and_priors(kind, odf, with_mean, all_uniform, W):
@@ -714,16 +714,17 @@ def test_mfma_kernel_general_state_space_and_priors(kind, odf, with_mean, all_un
     mean = rng.normal(size=D) * 0.2 if with_mean else None
     pr, eng, lad = PU.make_pair(D, Nt, W, 50.0, kind=kind, bounds=(blo, bhi, bmin, bmax), prior=(types, cen, hw), swap_rate=0.3,
                                 x0=x0, mean=mean, one_d_frac=(odf if odf > 0 else None))
-    if W == 64:
+    if W % 64 == 0:
         assert "mfma32_kernel" in eng.sweep_kernel_name and ", 2, " in eng.sweep_kernel_name
     else:
         assert eng.sweep_kernel_name.startswith("sweep_lanes_kernel<32") and eng.sweep_kernel_name.endswith("true>")
+    assert eng.step_kernel_name.startswith("decide_kernel + sweep_mfma32" if W == 320 else "ladder_persistent_kernel<32"), eng.step_kernel_name
     PU.assert_same_state(eng, lad, "start")
     for k in range(6):
         eng.step(5); eng.sync(); lad.pt_step(5)
         PU.assert_same_state(eng, lad, "after %d steps" % (5 * (k + 1)))
     acc = eng.naccept.sum() - eng.Nc
-    assert acc > (100 if W == 64 else 10) and np.isfinite(eng.lprior).all()
+    assert acc > (100 if W >= 64 else 10) and np.isfinite(eng.lprior).all()
     if odf > 0:
         assert (eng.last_type == 1).any()
     eng.close()
