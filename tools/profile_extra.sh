@@ -12,3 +12,7 @@ find $O -name "*kernel_stats.csv"   # (gpurun_out/ keeps earlier rounds' runs to
 # one rank of the 8-GPU weak-scaling shape (128 of 1024 rungs x 131072 ladders), its launch sequence without the messages
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/shard -- python3 $R/tools/kbench_shard.py --walkers 16384 --gpus 8 > $O/shard.out 2> $O/shard.err
 find $O/shard -name "*kernel_stats.csv"
+# the sampler's whole default configuration (differential evolution, evolving ladder, history, MAP) in the persistent ladder kernel: 128 and 1024 rungs
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/de128 -- python3 $R/tools/de_probe.py 32 128 1 2000 > $O/de128.out 2> $O/de128.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/de1024 -- python3 $R/tools/de_probe.py 32 1024 1 1000 > $O/de1024.out 2> $O/de1024.err
+find $O/de128 $O/de1024 -name "*kernel_stats.csv"
