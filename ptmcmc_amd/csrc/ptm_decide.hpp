@@ -227,10 +227,11 @@ __device__ __forceinline__ void decide_body(const Decide& p, unsigned char* smem
   if (lane == 0) { cnt[0] = 0; cnt[1] = 0; p.arr_below[w] = -1; p.arr_above[w] = -1; }
   __syncthreads();
   // -- candidate draws (chain.cc:1410-1416): block k of the ladder stream gives {u_try, u_pick, u_accept}
+  const uint64_t try_below = u01_below_bound(p.thresh);
   for (int k = lane; k < ms; k += DECIDE_THREADS) {
     const u32x4 o = draw_block(p.seed, TAG_PT, (uint32_t)(w + p.w_off), step, (uint32_t)k);
     int n = -2;
-    if (Nt > 1 && u01(o.v0) < p.thresh) n = (int)(u01(o.v1) * (Nt - 1));
+    if (Nt > 1 && (uint64_t)o.v0 < try_below) n = u01_times(o.v1, Nt - 1);   // u01(v0) < thresh, (int)(u01(v1) (Nt - 1)): ptm_device_math.hpp
     cand[k] = n;
     ua[k] = o.v2;  // the accept uniform's slot is reserved whether or not it is needed (cf. Q5)
     alive[k] = 0;

@@ -102,6 +102,7 @@ __global__ __launch_bounds__(LADDER_THREADS) void ladder_persistent_kernel(const
   const bool drole = helper && ht < 128, wrole = helper && ht >= 128;
   const int wt = ht - 128;
   const int Nt = p.Nt, ms = a.ms, NB = a.NB;
+  const uint64_t try_below = u01_below_bound(a.thresh);
   const int NONE = 0x7fffffff;
 
   // -- which ladder, which rungs.  Consecutive workgroup ids go round the 8 XCDs; neighbours in the ladder should share an L2.
@@ -420,7 +421,7 @@ __global__ __launch_bounds__(LADDER_THREADS) void ladder_persistent_kernel(const
       for (int k = ht; k < ms; k += 256) {
         const u32x4 oc = draw_block(p.seed, TAG_PT, (uint32_t)(w + p.w_off), step, (uint32_t)k);
         int n = -2;
-        if (Nt > 1 && u01(oc.v0) < a.thresh) n = (int)(u01(oc.v1) * (Nt - 1));
+        if (Nt > 1 && (uint64_t)oc.v0 < try_below) n = u01_times(oc.v1, Nt - 1);   // u01(v0) < thresh, (int)(u01(v1) (Nt - 1)): ptm_device_math.hpp
         cand[k] = n;
         ua[k] = oc.v2;
         alive[k] = 0;
