@@ -217,7 +217,7 @@ int ptm_draw_prior_rows(ptm_engine* e, int k_begin, int n, double* x_out, double
 int ptm_sweep(ptm_engine* e, int n);
 /* n x parallel_tempering_chains::step (chain.cc:1393-1571; single-shard engines: rung_count == n_rungs).  ASYNCHRONOUS: the call
  * queues work on the engine's stream and returns; results are there when a getter, a setter or ptm_sync looks.  On the persistent
- * ladder kernel's path (long ladders of few walkers, ptm_step_kernel_name) calls of fewer than 64 steps are only COUNTED and launched
+ * ladder kernel's path (populations of up to 256 workgroups, ptm_step_kernel_name) calls of fewer than 64 steps are only COUNTED and launched
  * together at that next look (or when 1024 have gathered) -- nothing can observe the difference, and a loop of ptm_step(1) calls, the
  * reference sampler's own (ptmcmc.cc:563-599), then costs what ptm_step(n) costs per step.  PTM_LADDER_DEFER=0 launches every call. */
 int ptm_step(ptm_engine* e, int n);
@@ -367,7 +367,7 @@ int ptm_get_kernel_times(ptm_engine* e, float* ms, int capacity, int* count);
 /* name of the sweep kernel variant in use (for matching rocprofv3 traces) */
 const char* ptm_sweep_kernel_name(ptm_engine* e);
 /* what a ptm_step call of this engine launches: one kernel for many steps -- "ladder_steps_kernel<..>" (small ladders, a block per
- * ladder) or "ladder_persistent_kernel<..>" (long ladders of few walkers: resident workgroups, chains in registers) -- or
+ * ladder) or "ladder_persistent_kernel<..>" (populations whose ladders fit 256 resident workgroups, chains in registers) -- or
  * "decide_kernel + <sweep kernel>" per step */
 const char* ptm_step_kernel_name(ptm_engine* e);
 
